@@ -1,0 +1,414 @@
+// cm_stages.h - per-scanline streaming stages of the colour demodulators/modulators.
+//
+// Execution model: ONE LANE OWNS ONE SCANLINE.  A 64-lane wavefront
+// walks 64 consecutive "calls" (rows of one field, in the order the reference's ImageModem
+// presents them) in lock-step, one pixel per step.  Every filter of the reference is applied
+// as a streaming recurrence whose state lives in the lane's VGPRs:
+//
+//   * resample_poly 2x up / 2x down (41-tap Kaiser half-band FIR, scipy.signal.resample_poly
+//     as called at ref qam.py:35-57, pal.py:72-77, secam.py:136-149) -> transposed-form FIR
+//     chain, 19 accumulators, one 3-address FMA per tap and NO register moves;
+//   * lfilter (ref utils.py:28-36) -> cascade of second-order sections in transposed direct
+//     form II, float32 (direct form fails 1e-5, sections reach 2-6e-7);
+//   * FilterFunction's delay compensation (append `shift` copies of the last sample, drop the
+//     first `shift` outputs) -> index bookkeeping on the stream, no buffers.
+//
+// All coefficients are wave-uniform and sit in SGPRs; the only cross-lane traffic is the
+// comb filter's "previous line" term, exchanged at 1x rate after the base demodulation
+// (linearity: demod(curr +- last) = demod(curr) +- demod(last)).
+//
+// The header compiles for the device (T = float, hipcc) and for the host (T = float or
+// double, g++) - the host instantiation is used ONLY by tests/sim to check the streaming
+// schedule against the oracle without a GPU; the product never runs it.
+#ifndef CM_STAGES_H
+#define CM_STAGES_H
+
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define CM_HD __host__ __device__ __forceinline__
+#else
+#include <cmath>
+#define CM_HD inline
+#endif
+
+namespace cm {
+
+constexpr int kMaxSecE = 4;  // extract band-pass: up to order 8
+constexpr int kMaxSecR = 4;  // remove band-stop
+constexpr int kMaxSecL = 3;  // detector low-pass: order 6 (ref qam.py:18, pal.py:67, secam.py:131)
+constexpr int kMaxSecP = 2;  // pre-correction low-pass at 1x rate
+
+// ---- arithmetic helpers -------------------------------------------------------------------
+// fma3: d = c * x + acc with d allowed to differ from acc.  On the device this must be the
+// VOP3 form: hipcc otherwise picks the 2-address v_fmac and pays one v_mov per tap to rotate
+// the accumulators (profiles/r01_ubench_valu.txt, "chain" rows).
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ float fma3(float c, float x, float acc) {
+    float d;
+    asm("v_fma_f32 %0, %1, %2, %3" : "=v"(d) : "s"(c), "v"(x), "v"(acc));
+    return d;
+}
+__device__ __forceinline__ float fmaf_(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+#else
+inline float fma3(float c, float x, float acc) { return std::fma(c, x, acc); }
+inline double fma3(double c, double x, double acc) { return c * x + acc; }
+inline float fmaf_(float a, float b, float c) { return std::fma(a, b, c); }
+inline double fmaf_(double a, double b, double c) { return a * b + c; }
+#endif
+
+// ---- uniform coefficient blocks -----------------------------------------------------------
+template <typename T>
+struct Taps {  // 2*h[2i+1], i = 0..9 (h symmetric: tap 19-i equals tap i) and 2*h[20]
+    T c[10];
+    T c0;
+};
+
+template <typename T, int MAXSEC>
+struct SosK {  // sections normalised to b0 = 1; gains are folded elsewhere by the host
+    int32_t n;
+    T na1[MAXSEC], na2[MAXSEC];  // NEGATED denominator coefficients
+    T b1[MAXSEC], b2[MAXSEC];    // used by the SYM (b1) and GEN (b1, b2) forms
+};
+
+// ---- transposed-form half-band FIR --------------------------------------------------------
+// s[j] carries the partial sum of the output that completes j+1 pushes from now.
+template <typename T>
+struct HalfbandChain {
+    T s[19];
+    CM_HD void reset() {
+#pragma unroll
+        for (int j = 0; j < 19; ++j) s[j] = T(0);
+    }
+    // 2x interpolation, odd phase: returns out[n] = sum_i c_i * x[n + 10 - i] once x[n + 10] = x
+    // has been pushed (ref: resample_poly(x, 2, 1)[2n + 1]).
+    CM_HD T push(const Taps<T> &k, T x) {
+        T out = fma3(k.c[0], x, s[0]);
+#pragma unroll
+        for (int j = 0; j < 18; ++j) s[j] = fma3(k.c[(j + 1) < 10 ? (j + 1) : 18 - j], x, s[j + 1]);
+        s[18] = k.c[0] * x;
+        return out;
+    }
+    // 2x decimation: push the pair (z[2m], z[2m+1]); returns 2 * resample_poly(z, 1, 2)[m - 9].
+    CM_HD T push_pair(const Taps<T> &k, T even, T odd) {
+        T out = push(k, odd);
+        s[8] = fmaf_(k.c0, even, s[8]);  // centre tap lands on output m
+        return out;
+    }
+};
+
+// ---- second-order-section cascades (transposed direct form II) ------------------------------
+template <typename T, int MAXSEC>
+struct IirState {
+    T s1[MAXSEC], s2[MAXSEC];
+    CM_HD void reset() {
+#pragma unroll
+        for (int j = 0; j < MAXSEC; ++j) s1[j] = s2[j] = T(0);
+    }
+};
+
+// numerator 1 - z^-2 (Butterworth / Chebyshev-I band-pass sections)
+template <typename T, int MAXSEC>
+CM_HD T iir_bp(IirState<T, MAXSEC> &st, const SosK<T, MAXSEC> &k, T x) {
+#pragma unroll
+    for (int j = 0; j < MAXSEC; ++j) {
+        if (j < k.n) {
+            T y = x + st.s1[j];
+            st.s1[j] = fma3(k.na1[j], y, st.s2[j]);
+            st.s2[j] = fmaf_(k.na2[j], y, -x);
+            x = y;
+        }
+    }
+    return x;
+}
+// numerator 1 + b1 z^-1 + z^-2 (low-pass / band-stop sections with zeros on the unit circle)
+template <typename T, int MAXSEC>
+CM_HD T iir_sym(IirState<T, MAXSEC> &st, const SosK<T, MAXSEC> &k, T x) {
+#pragma unroll
+    for (int j = 0; j < MAXSEC; ++j) {
+        if (j < k.n) {
+            T y = x + st.s1[j];
+            T t = fma3(k.b1[j], x, st.s2[j]);
+            st.s1[j] = fmaf_(k.na1[j], y, t);
+            st.s2[j] = fmaf_(k.na2[j], y, x);
+            x = y;
+        }
+    }
+    return x;
+}
+// general numerator 1 + b1 z^-1 + b2 z^-2 (also first-order sections: b2 = a2 = 0)
+template <typename T, int MAXSEC>
+CM_HD T iir_gen(IirState<T, MAXSEC> &st, const SosK<T, MAXSEC> &k, T x) {
+#pragma unroll
+    for (int j = 0; j < MAXSEC; ++j) {
+        if (j < k.n) {
+            T y = x + st.s1[j];
+            T t = fma3(k.b1[j], x, st.s2[j]);
+            st.s1[j] = fmaf_(k.na1[j], y, t);
+            st.s2[j] = fmaf_(k.na2[j], y, k.b2[j] * x);
+            x = y;
+        }
+    }
+    return x;
+}
+
+// ---- per-lane constants (host-computed, float64 -> T) ---------------------------------------
+template <typename T>
+struct LaneK {
+    T sth, cth;  // sin/cos of the detector phase at sample 0 of this line
+    T sph, cph;  // sin/cos of the re-modulation phase, pre-multiplied by the pre-filter gain and
+                 // the V-switch sign; both 0 when luma is passed through unstripped
+    T cu[3][2];  // u = sum_j cu[j][0] * Bs[k-j] + cu[j][1] * Bc[k-j]
+    T cv[3][2];  // v likewise
+};
+
+template <typename T>
+struct Pair {
+    T s, c;
+};
+
+// ---- uniform parameters of the QAM-family demodulators --------------------------------------
+template <typename T>
+struct DemodK {
+    int32_t width;       // W
+    int32_t q_e, q_l, q_r, s_p;  // pair delays of the 2x-rate filters (ceil(shift / 2)), pre shift
+    int32_t pad_e, pad_l, pad_r; // FilterFunction shifts (tail padding length in 2x samples)
+    Taps<T> taps;
+    SosK<T, kMaxSecE> ext;   // ref qam.py:17 band-pass
+    SosK<T, kMaxSecR> rem;   // ref qam.py:17 band-stop
+    SosK<T, kMaxSecL> lpf;   // ref qam.py:18 (QAM front) or pal.py:67-69 (PAL-D front)
+    SosK<T, kMaxSecP> pre;   // ref qam.py:16
+    T luma_gain;             // gain of the band-stop path (sections * 1/2 from the decimator)
+    T m[3][3];               // (r, g, b) = m * (y, u, v)
+};
+
+// =============================================================================================
+// PAL-D front end: x -> E = dn2(BPF(up2 x)) -> up2 -> * {sin, cos}(theta + k cps) -> LPF -> dn2
+// (ref pal.py:71-77 applied to ref qam.py:34-37), producing the line's own base pair
+// (Ps, Pc)[n].  Gains (band-pass, low-pass, the two 1/2 of the decimators) are NOT applied
+// here; the host folds them into LaneK::cu/cv.
+//
+// Stream indices at step t (one 1x sample per step):
+//   n1 = t - 10        pair A(n1) = up2(x)[2 n1, 2 n1 + 1]
+//   n2 = n1 - q_e      pair B(n2) = BPF output
+//   n3 = n2 - 9        e[n3]
+//   n4 = n3 - 10       pair U(n4) = up2(e)
+//   n5 = n4 - q_l      pair Q(n5) = LPF output (two paths)
+//   n6 = n5 - 9        (Ps, Pc)[n6]
+// =============================================================================================
+template <typename T>
+struct PalDFront {
+    HalfbandChain<T> up_x, dn_e, up_e, dn_s, dn_c;
+    IirState<T, kMaxSecE> bpf;
+    IirState<T, kMaxSecL> lpf_s, lpf_c;
+    T a_last, ps_last, pc_last;
+
+    CM_HD void reset() {
+        up_x.reset(); dn_e.reset(); up_e.reset(); dn_s.reset(); dn_c.reset();
+        bpf.reset(); lpf_s.reset(); lpf_c.reset();
+        a_last = ps_last = pc_last = T(0);
+    }
+    CM_HD static int latency(const DemodK<T> &k) { return 10 + k.q_e + 9 + 10 + k.q_l + 9; }
+
+    // x_now = x[t] (0 beyond the row), x_d10 = x[t - 10], e_d10 = e[n3 - 10] (from the caller's
+    // delay window), car = {C[2 n4], S[2 n4], C[2 n4 + 1], S[2 n4 + 1]} (cos/sin of m * cps).
+    // Returns e[n3] through e_out (caller stores it in its window) and the base pair.
+    template <bool EDGE>
+    CM_HD Pair<T> step(const DemodK<T> &k, const LaneK<T> &lk, int t, T x_now, T x_d10, T e_d10, const T car[4],
+                       T &e_out) {
+        const int W = k.width;
+        const int n1 = t - 10, n2 = n1 - k.q_e, n3 = n2 - 9, n4 = n3 - 10, n5 = n4 - k.q_l;
+        // --- up2(x)
+        T a_odd = up_x.push(k.taps, x_now);
+        T a_even = k.taps.c0 * x_d10;
+        // --- band-pass at 2x rate with FilterFunction edge handling
+        T b_even = T(0), b_odd = T(0);
+        if (!EDGE || (n1 >= 0 && n1 < W + k.q_e)) {
+            if (EDGE) {
+                if (n1 == W - 1) a_last = a_odd;
+                if (n1 >= W) a_even = a_odd = a_last;
+            }
+            b_even = iir_bp(bpf, k.ext, a_even);
+            b_odd = iir_bp(bpf, k.ext, a_odd);
+        }
+        if (EDGE && (n2 < 0 || n2 >= W)) b_even = b_odd = T(0);
+        // --- dn2 -> e[n3]
+        T e = dn_e.push_pair(k.taps, b_even, b_odd);
+        if (EDGE && (n3 < 0 || n3 >= W)) e = T(0);
+        e_out = e;
+        // --- up2(e)
+        T u_odd = up_e.push(k.taps, e);
+        T u_even = k.taps.c0 * e_d10;
+        // --- product detectors: sin and cos of (theta + m cps), m = 2 n4, 2 n4 + 1
+        T sin_e = fmaf_(lk.sth, car[0], lk.cth * car[1]);
+        T cos_e = fmaf_(lk.cth, car[0], -(lk.sth * car[1]));
+        T sin_o = fmaf_(lk.sth, car[2], lk.cth * car[3]);
+        T cos_o = fmaf_(lk.cth, car[2], -(lk.sth * car[3]));
+        T ps_e = u_even * sin_e, pc_e = u_even * cos_e;
+        T ps_o = u_odd * sin_o, pc_o = u_odd * cos_o;
+        T qs_e = T(0), qs_o = T(0), qc_e = T(0), qc_o = T(0);
+        if (!EDGE || (n4 >= 0 && n4 < W + k.q_l)) {
+            if (EDGE) {
+                if (n4 == W - 1) { ps_last = ps_o; pc_last = pc_o; }
+                if (n4 >= W) { ps_e = ps_o = ps_last; pc_e = pc_o = pc_last; }
+            }
+            qs_e = iir_sym(lpf_s, k.lpf, ps_e);
+            qs_o = iir_sym(lpf_s, k.lpf, ps_o);
+            qc_e = iir_sym(lpf_c, k.lpf, pc_e);
+            qc_o = iir_sym(lpf_c, k.lpf, pc_o);
+        }
+        if (EDGE && (n5 < 0 || n5 >= W)) qs_e = qs_o = qc_e = qc_o = T(0);
+        Pair<T> out;
+        out.s = dn_s.push_pair(k.taps, qs_e, qs_o);
+        out.c = dn_c.push_pair(k.taps, qc_e, qc_o);
+        return out;
+    }
+};
+
+// =============================================================================================
+// QAM front end (ref qam.py:43-58): x -> up2 -> BPF -> * {2 sin, 2 cos}(theta + k cps) -> LPF
+// -> dn2 = base pair (Bs, Bc)[n]; optionally the band-stop luma dn2(BSF(up2 x)).
+// The factor 2 of the detector and all filter gains are folded into LaneK by the host.
+//   n1 = t - 10 ; n2 = n1 - q_e ; n5 = n2 - q_l ; n6 = n5 - 9 ; luma: nr = n1 - q_r, nl = nr - 9
+// ODD_x: the corresponding FilterFunction shift is odd, i.e. output pairs straddle input pairs.
+// =============================================================================================
+template <typename T, bool ODD_E, bool ODD_L, bool ODD_R, bool WITH_BSF>
+struct QamFront {
+    HalfbandChain<T> up_x, dn_s, dn_c, dn_y;
+    IirState<T, kMaxSecE> bpf;
+    IirState<T, kMaxSecL> lpf_s, lpf_c;
+    IirState<T, kMaxSecR> bsf;
+    T a_last, ps_last, pc_last;
+    T hold_b, hold_s, hold_c, hold_y;  // previous odd outputs for odd shifts
+
+    CM_HD void reset() {
+        up_x.reset(); dn_s.reset(); dn_c.reset(); dn_y.reset();
+        bpf.reset(); lpf_s.reset(); lpf_c.reset(); bsf.reset();
+        a_last = ps_last = pc_last = hold_b = hold_s = hold_c = hold_y = T(0);
+    }
+    CM_HD static int latency(const DemodK<T> &k) { return 10 + k.q_e + k.q_l + 9; }
+    CM_HD static int luma_latency(const DemodK<T> &k) { return 10 + k.q_r + 9; }
+
+    // car = {C[2 n2], S[2 n2], C[2 n2 + 1], S[2 n2 + 1]}
+    template <bool EDGE>
+    CM_HD Pair<T> step(const DemodK<T> &k, const LaneK<T> &lk, int t, T x_now, T x_d10, const T car[4], T &luma_out) {
+        const int W = k.width;
+        const int n1 = t - 10, n2 = n1 - k.q_e, n5 = n2 - k.q_l;
+        T a_odd = up_x.push(k.taps, x_now);
+        T a_even = k.taps.c0 * x_d10;
+        if (EDGE) {
+            if (n1 == W - 1) a_last = a_odd;
+            if (n1 >= W) a_even = a_odd = a_last;
+        }
+        // --- chroma band-pass
+        T b_even = T(0), b_odd = T(0);
+        if (!EDGE || (n1 >= 0 && n1 < W + k.q_e)) {
+            T y0 = iir_bp(bpf, k.ext, a_even);
+            T y1 = iir_bp(bpf, k.ext, a_odd);
+            if (ODD_E) { b_even = hold_b; b_odd = y0; hold_b = y1; } else { b_even = y0; b_odd = y1; }
+        }
+        // (band-pass output outside [0, 2W) is never used: the detector below is gated on n2)
+        // --- luma band-stop (ref qam.py:57)
+        if (WITH_BSF) {
+            const int nr = n1 - k.q_r;
+            T r_even = T(0), r_odd = T(0);
+            if (!EDGE || (n1 >= 0 && n1 < W + k.q_r)) {
+                T y0 = iir_sym(bsf, k.rem, a_even);
+                T y1 = iir_sym(bsf, k.rem, a_odd);
+                if (ODD_R) { r_even = hold_y; r_odd = y0; hold_y = y1; } else { r_even = y0; r_odd = y1; }
+            }
+            if (EDGE && (nr < 0 || nr >= W)) r_even = r_odd = T(0);
+            luma_out = dn_y.push_pair(k.taps, r_even, r_odd) * k.luma_gain;
+        }
+        // --- product detectors at 2x rate, m = 2 n2, 2 n2 + 1
+        T sin_e = fmaf_(lk.sth, car[0], lk.cth * car[1]);
+        T cos_e = fmaf_(lk.cth, car[0], -(lk.sth * car[1]));
+        T sin_o = fmaf_(lk.sth, car[2], lk.cth * car[3]);
+        T cos_o = fmaf_(lk.cth, car[2], -(lk.sth * car[3]));
+        T ps_e = b_even * sin_e, pc_e = b_even * cos_e;
+        T ps_o = b_odd * sin_o, pc_o = b_odd * cos_o;
+        T qs_e = T(0), qs_o = T(0), qc_e = T(0), qc_o = T(0);
+        if (!EDGE || (n2 >= 0 && n2 < W + k.q_l)) {
+            if (EDGE) {
+                if (n2 == W - 1) { ps_last = ps_o; pc_last = pc_o; }
+                if (n2 >= W) { ps_e = ps_o = ps_last; pc_e = pc_o = pc_last; }
+            }
+            T s0 = iir_sym(lpf_s, k.lpf, ps_e);
+            T s1 = iir_sym(lpf_s, k.lpf, ps_o);
+            T c0 = iir_sym(lpf_c, k.lpf, pc_e);
+            T c1 = iir_sym(lpf_c, k.lpf, pc_o);
+            if (ODD_L) {
+                qs_e = hold_s; qs_o = s0; hold_s = s1;
+                qc_e = hold_c; qc_o = c0; hold_c = c1;
+            } else {
+                qs_e = s0; qs_o = s1; qc_e = c0; qc_o = c1;
+            }
+        }
+        if (EDGE && (n5 < 0 || n5 >= W)) qs_e = qs_o = qc_e = qc_o = T(0);
+        Pair<T> out;
+        out.s = dn_s.push_pair(k.taps, qs_e, qs_o);
+        out.c = dn_c.push_pair(k.taps, qc_e, qc_o);
+        return out;
+    }
+};
+
+// =============================================================================================
+// Back end shared by every QAM-family decoder: comb combination of base pairs, chroma
+// re-modulation for the luma (ref comb.py:51-53 -> qam.py:20-26), colour matrix.
+//   n7 = n6 - s_p ; inputs: own/neighbour base pairs at n6, luma source sample x_l[n7] (or the
+//   band-stop luma), carrier {C[2 n7], S[2 n7]}.
+// =============================================================================================
+template <typename T>
+struct Rgb {
+    T r, g, b;
+};
+
+template <typename T, int DEPTH>
+struct DemodBack {
+    IirState<T, kMaxSecP> pre_u, pre_v;
+    T u_last, v_last;
+    CM_HD void reset() {
+        pre_u.reset(); pre_v.reset();
+        u_last = v_last = T(0);
+    }
+    // Combination only (the caller keeps the u/v delay windows).
+    CM_HD void combine(const LaneK<T> &lk, const Pair<T> &b0, const Pair<T> &b1, const Pair<T> &b2, T &u, T &v) const {
+        u = fmaf_(lk.cu[0][0], b0.s, lk.cu[0][1] * b0.c);
+        v = fmaf_(lk.cv[0][0], b0.s, lk.cv[0][1] * b0.c);
+        if (DEPTH >= 1) {
+            u = fmaf_(lk.cu[1][0], b1.s, fmaf_(lk.cu[1][1], b1.c, u));
+            v = fmaf_(lk.cv[1][0], b1.s, fmaf_(lk.cv[1][1], b1.c, v));
+        }
+        if (DEPTH >= 2) {
+            u = fmaf_(lk.cu[2][0], b2.s, fmaf_(lk.cu[2][1], b2.c, u));
+            v = fmaf_(lk.cv[2][0], b2.s, fmaf_(lk.cv[2][1], b2.c, v));
+        }
+    }
+    // u, v are the combined chroma at n6; u_d, v_d the same signals at n7 = n6 - s_p;
+    // y_src is the luma source at n7; car = {C[2 n7], S[2 n7]}.
+    template <bool EDGE>
+    CM_HD Rgb<T> step(const DemodK<T> &k, const LaneK<T> &lk, int n6, T u, T v, T u_d, T v_d, T y_src, const T car[2]) {
+        const int W = k.width;
+        T wu = T(0), wv = T(0);
+        if (!EDGE || (n6 >= 0 && n6 < W + k.s_p)) {
+            if (EDGE) {
+                if (n6 == W - 1) { u_last = u; v_last = v; }
+                if (n6 >= W) { u = u_last; v = v_last; }
+            }
+            wu = iir_gen(pre_u, k.pre, u);
+            wv = iir_gen(pre_v, k.pre, v);
+        }
+        T sn = fmaf_(lk.sph, car[0], lk.cph * car[1]);
+        T cs = fmaf_(lk.cph, car[0], -(lk.sph * car[1]));
+        T y = y_src - fmaf_(sn, wu, cs * wv);
+        Rgb<T> o;
+        o.r = fmaf_(k.m[0][0], y, fmaf_(k.m[0][1], u_d, k.m[0][2] * v_d));
+        o.g = fmaf_(k.m[1][0], y, fmaf_(k.m[1][1], u_d, k.m[1][2] * v_d));
+        o.b = fmaf_(k.m[2][0], y, fmaf_(k.m[2][1], u_d, k.m[2][2] * v_d));
+        return o;
+    }
+};
+
+}  // namespace cm
+#endif

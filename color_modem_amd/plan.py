@@ -1,0 +1,409 @@
+# -*- coding: utf-8 -*-
+"""Turn a modem stack into the flat plan descriptor of include/color_modem_hip.h.
+
+The reference decoders are stateful row-at-a-time objects.  Every one of them is, per
+output row, a *linear* function of at most three consecutive input rows of one field
+(no inter-line recurrence).  With
+
+    B_k = (Bs, Bc)[k] = base demodulation of call k's own input row, detector phase theta_k
+
+(ref qam.py:47-54 for the QAM front end, pal.py:71-77 on qam.py:34-37 for PAL-D) and the
+identity  demod(theta + d) = rot(demod(theta), d),  each decoder becomes
+
+    u = sum_j cu[j] . B_{k-j},   v = sum_j cv[j] . B_{k-j},   y = x_{k-dy} - remod(phi; u, v)
+
+with coefficients that depend only on (frame mod cycle, line, k regime).  This module derives
+those coefficients from the same formulas the reference executes on signals, applied to small
+symbolic objects (`Lin`), in float64.
+"""
+
+import ctypes
+
+import numpy
+import scipy.signal
+
+CM_ABI_VERSION = 1
+CM_PIPE_QAM, CM_PIPE_PAL_D, CM_PIPE_SECAM = 1, 2, 3
+CM_MAX_SECTIONS = 4
+CM_LANE_DOUBLES = 16
+
+
+class IirDesc(ctypes.Structure):
+    _fields_ = [('n_sections', ctypes.c_int32), ('shift', ctypes.c_int32),
+                ('sos', (ctypes.c_double * 6) * CM_MAX_SECTIONS)]
+
+
+class LaneTable(ctypes.Structure):
+    _fields_ = [('frame_cycle', ctypes.c_int32), ('n_lines', ctypes.c_int32),
+                ('table', ctypes.POINTER(ctypes.c_double)),
+                ('luma_from_prev', ctypes.c_int32), ('reserved', ctypes.c_int32)]
+
+
+class PlanDesc(ctypes.Structure):
+    _fields_ = [('abi_version', ctypes.c_int32), ('pipeline', ctypes.c_int32),
+                ('width', ctypes.c_int32), ('height', ctypes.c_int32),
+                ('demodulation_delay', ctypes.c_int32), ('modulation_delay', ctypes.c_int32),
+                ('depth', ctypes.c_int32), ('first_is_plain', ctypes.c_int32),
+                ('carrier_phase_step', ctypes.c_double),
+                ('resample_fir', ctypes.c_double * 41),
+                ('extract2x', IirDesc), ('remove2x', IirDesc), ('demod_lp', IirDesc),
+                ('pald_lp', IirDesc), ('precorrect', IirDesc),
+                ('decode_matrix', ctypes.c_double * 9), ('encode_matrix', ctypes.c_double * 9),
+                ('demod_main', LaneTable), ('demod_first', LaneTable), ('mod_main', LaneTable)]
+
+
+# ---------------------------------------------------------------------------------------------
+# symbolic linear combinations of base pairs
+
+class Lin(object):
+    """sum_j c[j, 0] * Bs[k - j] + c[j, 1] * Bc[k - j], j = 0..2."""
+    __slots__ = ('c',)
+
+    def __init__(self, c=None):
+        self.c = numpy.zeros((3, 2)) if c is None else numpy.array(c, dtype=numpy.float64)
+
+    def __add__(self, other):
+        return Lin(self.c + other.c)
+
+    def __sub__(self, other):
+        return Lin(self.c - other.c)
+
+    def __mul__(self, scalar):
+        return Lin(self.c * float(scalar))
+
+    __rmul__ = __mul__
+
+    def __neg__(self):
+        return Lin(-self.c)
+
+    def shifted(self, rows):
+        """The same combination evaluated `rows` calls earlier, seen from the current call."""
+        out = numpy.zeros((3, 2))
+        if rows:
+            assert not self.c[3 - rows:].any(), 'combination reaches further back than 2 lines'
+            out[rows:] = self.c[:3 - rows]
+        else:
+            out[:] = self.c
+        return Lin(out)
+
+
+def base(j):
+    s, c = Lin(), Lin()
+    s.c[j, 0] = 1.0
+    c.c[j, 1] = 1.0
+    return s, c
+
+
+def rot(pair, delta):
+    """Detector output for a phase advanced by `delta`: sin(a+d) = sin a cos d + cos a sin d, ..."""
+    s, c = pair
+    cd, sd = numpy.cos(delta), numpy.sin(delta)
+    return cd * s + sd * c, cd * c - sd * s
+
+
+def pair_sub(a, b):
+    return a[0] - b[0], a[1] - b[1]
+
+
+def pair_add(a, b):
+    return a[0] + b[0], a[1] + b[1]
+
+
+# ---------------------------------------------------------------------------------------------
+# IIR descriptors
+
+def iir_desc(filt):
+    """FilterFunction -> IirDesc (sections from the design's zpk form when available)."""
+    d = IirDesc()
+    if filt is None:
+        d.n_sections = 0
+        d.shift = 0
+        return d
+    sos = filt.sos()
+    if len(sos) > CM_MAX_SECTIONS:
+        raise NotImplementedError('filter order %d exceeds the %d sections this build carries'
+                                  % (filt.order, CM_MAX_SECTIONS))
+    d.n_sections = len(sos)
+    d.shift = int(filt.shift)
+    for j, row in enumerate(sos):
+        for i in range(6):
+            d.sos[j][i] = float(row[i])
+    return d
+
+
+def resample_fir():
+    # the filter scipy.signal.resample_poly designs for up/down = 2 (ref qam.py:35 etc.)
+    return scipy.signal.firwin(41, 0.5, window=('kaiser', 5.0))
+
+
+# ---------------------------------------------------------------------------------------------
+
+class QamTables(object):
+    """Per-line coefficient derivation for the QAM-family stacks."""
+
+    def __init__(self, stack):
+        self.stack = stack
+        self.kind = stack['kind']
+        self.backend = stack['backend']          # PalSModem / NtscModem
+        self.comb = stack.get('comb')            # PalDModem / Pal3DModem / NtscCombModem or None
+        self.demod_wrapper = stack.get('demod_wrapper')
+        self.mod_wrapper = stack.get('mod_wrapper')
+        b = self.backend
+        self.lc = b.line_config
+        self.LS = b.line_shift
+        self.ps = b.qam.extract_chroma_phase_shift
+        self.cycle = b.frame_cycle
+        if b.v_switch and self.cycle % 2:
+            self.cycle *= 2  # the V switch alternates with frame parity (line.py:64-65)
+        self.width, self.height = self.lc.size
+
+    # -- helpers ---------------------------------------------------------------------------
+    def phi(self, frame, line):
+        return self.backend.start_phase(frame, line)
+
+    def vsign(self, frame, line):
+        if self.backend.v_switch and self.lc.is_alternate_line(frame, line):
+            return -1.0
+        return 1.0
+
+    def q_row(self, j, d):
+        """qam.demodulate(phi_k + d, x_{k-j}) in terms of the base pairs (lines of one run are LS apart)."""
+        return rot(base(j), d + j * self.LS)
+
+    # -- base decoders: (u, v) of backend.demodulate_components at call k --------------------
+    def uv_plain(self, frame, line):
+        s, c = base(0)
+        return s, self.vsign(frame, line) * c
+
+    def uv_ntsc_comb(self, frame, line, k):
+        if k == 0:  # comb.py:48-49 -> ntsc.py:47-49
+            return self.uv_plain(frame, line)
+        # ntsc.py:74-81: demodulate (curr - last) half a line shift back, swap, scale
+        q = pair_sub(self.q_row(0, -0.5 * self.LS), self.q_row(1, -0.5 * self.LS))
+        f = self.comb._factor
+        return f * q[1], -f * q[0]
+
+    def uv_pal_d(self, frame, line, k):
+        if k == 0:
+            raise AssertionError('first line of a PAL-D run is decoded by the plain pass')
+        # base pair here is the PAL-D front end at theta = phi + ps - LS/2 (pal.py:113-114)
+        p0, p1 = base(0), rot(base(1), self.LS)
+        total = p0[0] + p1[0]          # AM(sum, sin carrier), pal.py:116,119
+        diff = p0[1] - p1[1]           # AM(diff, cos carrier), pal.py:117,120
+        sf, cf = self.comb._sin_factor, self.comb._cos_factor
+        u = sf * diff + cf * total     # pal.py:122
+        v = cf * diff - sf * total     # pal.py:123
+        return u, self.vsign(frame, line) * v  # pal.py:124-125
+
+    def uv_pal_3d(self, frame, line, k):
+        c3 = self.comb
+        if k == 0:                     # pal.py:191-195 (plain decode, luma left unstripped)
+            return self.uv_plain(frame, line)
+        if k == 1:                     # pal.py:199-201: replay the first line's own decode
+            u, v = self.uv_plain(frame, line - 2)
+            return u.shifted(1), v.shifted(1)
+        # pal.py:203-207: demodulate at the phase of line - 2
+        d = -self.LS
+        x0, x1, x2 = self.q_row(0, d), self.q_row(1, d), self.q_row(2, d)
+        sumsig = pair_sub(x0, x2)                                  # curr_diff + last_diff
+        diffsig = pair_add(pair_sub(x0, (2.0 * x1[0], 2.0 * x1[1])), x2)  # curr_diff - last_diff
+        if c3._use_sin and c3._use_cos:                            # pal.py:209-211 (arithmetic mean)
+            u = 0.5 * (c3._sin_sum_factor * sumsig[1] + c3._cos_u_factor * diffsig[0])
+            v = 0.5 * (c3._sin_sum_factor * sumsig[0] + c3._cos_v_factor * diffsig[1])
+        elif c3._use_sin:
+            u, v = c3._sin_sum_factor * sumsig[1], c3._sin_sum_factor * sumsig[0]
+        else:
+            u, v = c3._cos_u_factor * diffsig[0], c3._cos_v_factor * diffsig[1]
+        return u, self.vsign(frame, line - 2) * v                  # pal.py:219-220
+
+    def backend_uv(self, frame, line, k):
+        if self.kind in ('pal_s', 'ntsc'):
+            return self.uv_plain(frame, line)
+        if self.kind == 'ntsc_comb':
+            return self.uv_ntsc_comb(frame, line, k)
+        if self.kind == 'pal_d':
+            return self.uv_pal_d(frame, line, k)
+        if self.kind == 'pal_3d':
+            return self.uv_pal_3d(frame, line, k)
+        raise NotImplementedError(self.kind)
+
+    # -- full decoder at call k: (u, v, remod line or None, luma from previous call?) ---------
+    def decode(self, frame, line, k):
+        """Returns u, v, remod_line (None: luma unstripped or band-stop), luma_prev (bool)."""
+        w = self.demod_wrapper
+        if w is None:
+            if self.kind in ('pal_s', 'ntsc'):
+                u, v = self.uv_plain(frame, line)
+                return u, v, None, False
+            if self.kind in ('ntsc_comb', 'pal_d'):
+                u, v = self.backend_uv(frame, line, k)
+                return u, v, line, False              # comb.py:52-53
+            if self.kind == 'pal_3d':
+                u, v = self.uv_pal_3d(frame, line, k)
+                if k == 0:
+                    return u, v, None, False          # pal.py:195: returned before the strip
+                return u, v, line - 2, True           # pal.py:223,226
+        else:
+            own_delay = 1 if w == 'simple_3d' else 0
+            if self.kind == 'pal_3d':
+                raise NotImplementedError('SimpleCombModem around Pal3DModem reaches back 3 lines; not built')
+            if self.kind == 'pal_d':
+                raise NotImplementedError('SimpleCombModem around PalDModem mixes two front ends; not built')
+            cu, cv = self.backend_uv(frame, line, k)
+            if k == 0:                                # comb.py:97-99: luma left unstripped
+                return cu, cv, None, False
+            lu, lv = self.backend_uv(frame, line - 2, k - 1)
+            u = 0.5 * (lu.shifted(1) + cu)            # comb.py:103-104
+            v = 0.5 * (lv.shifted(1) + cv)
+            return u, v, line - 2 * own_delay, bool(own_delay)  # comb.py:102,106 (modulation_delay = 0)
+        raise NotImplementedError((self.kind, w))
+
+    @property
+    def demodulation_delay(self):
+        d = 1 if self.kind == 'pal_3d' else 0
+        if self.demod_wrapper == 'simple_3d':
+            d += 1
+        return d
+
+    @property
+    def modulation_delay(self):
+        return 1 if self.mod_wrapper == 'color_averaging' else 0
+
+    @property
+    def depth(self):
+        d = {'pal_s': 0, 'ntsc': 0, 'pal_d': 1, 'ntsc_comb': 1, 'pal_3d': 2}[self.kind]
+        if self.demod_wrapper:
+            d += 1
+        return d
+
+    @property
+    def first_is_plain(self):
+        # k == 0 goes through backend.demodulate_components(strip_chroma=True): band-stop luma
+        return self.demod_wrapper is None and self.kind in ('pal_s', 'ntsc', 'pal_d', 'ntsc_comb')
+
+    def detector_phase(self, frame, line):
+        theta = self.phi(frame, line) + self.ps
+        if self.kind == 'pal_d':
+            theta -= 0.5 * self.LS
+        return theta
+
+    def n_lines(self):
+        return self.height + 2 * max(self.demodulation_delay, self.modulation_delay) + 4
+
+    def demod_main_table(self):
+        n_lines = self.n_lines()
+        tab = numpy.zeros((self.cycle, 3, n_lines, CM_LANE_DOUBLES))
+        luma_prev_bits = 0
+        plain_stack = self.kind in ('pal_s', 'ntsc') and self.demod_wrapper is None
+        for f in range(self.cycle):
+            for k in range(3):
+                for line in range(n_lines):
+                    if line - 2 * k < -1:
+                        continue  # a run never starts above the top of the frame
+                    if self.first_is_plain and k == 0 and not plain_stack:
+                        continue  # produced by the plain pass
+                    u, v, remod_line, luma_prev = self.decode(f, line, k)
+                    e = tab[f, k, line]
+                    theta = self.detector_phase(f, line)
+                    e[0], e[1] = numpy.sin(theta), numpy.cos(theta)
+                    if remod_line is not None:
+                        p = self.phi(f, remod_line)
+                        e[2] = numpy.sin(p)
+                        e[3] = numpy.cos(p) * self.vsign(f, remod_line)  # pal.py:50-51
+                    e[4:10] = u.c.reshape(-1)
+                    e[10:16] = v.c.reshape(-1)
+                    if luma_prev:
+                        luma_prev_bits |= 1 << k
+        return tab, luma_prev_bits
+
+    def demod_first_table(self):
+        n_lines = self.n_lines()
+        tab = numpy.zeros((self.cycle, 3, n_lines, CM_LANE_DOUBLES))
+        for f in range(self.cycle):
+            for line in range(n_lines):
+                u, v = self.uv_plain(f, line)
+                e = tab[f, 0, line]
+                theta = self.phi(f, line) + self.ps
+                e[0], e[1] = numpy.sin(theta), numpy.cos(theta)
+                e[4:10] = u.c.reshape(-1)
+                e[10:16] = v.c.reshape(-1)
+        return tab
+
+    def mod_table(self):
+        """[0] sin, [1] cos * V sign of the start phase of the modulated line; [2..5] row weights
+        (luma: current, previous; chroma: current, previous), ref comb.py:141-152."""
+        n_lines = self.n_lines()
+        tab = numpy.zeros((self.cycle, 3, n_lines, CM_LANE_DOUBLES))
+        avg = self.mod_wrapper == 'color_averaging'
+        for f in range(self.cycle):
+            for k in range(3):
+                for line in range(n_lines):
+                    target = line - 2 if avg else line
+                    p = self.phi(f, target)
+                    e = tab[f, k, line]
+                    e[0] = numpy.sin(p)
+                    e[1] = numpy.cos(p) * self.vsign(f, target)
+                    if avg and k >= 1:
+                        e[2:6] = (0.0, 1.0, 0.5, 0.5)
+                    else:
+                        e[2:6] = (1.0, 0.0, 1.0, 0.0)
+        return tab
+
+
+class BuiltPlan(object):
+    """PlanDesc plus the numpy arrays it points into (kept alive here)."""
+
+    def __init__(self, desc, keep, tables):
+        self.desc = desc
+        self._keep = keep
+        self.tables = tables
+
+
+def _lane_table(arr, luma_prev_bits=0):
+    t = LaneTable()
+    if arr is None:
+        t.frame_cycle, t.n_lines, t.table = 0, 0, None
+        return t
+    t.frame_cycle, t.n_lines = arr.shape[0], arr.shape[2]
+    t.table = arr.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
+    t.luma_from_prev = luma_prev_bits
+    return t
+
+
+def build_qam_plan(stack):
+    tb = QamTables(stack)
+    b = tb.backend
+    d = PlanDesc()
+    d.abi_version = CM_ABI_VERSION
+    d.pipeline = CM_PIPE_PAL_D if tb.kind == 'pal_d' else CM_PIPE_QAM
+    d.width, d.height = tb.width, tb.height
+    d.demodulation_delay = tb.demodulation_delay
+    d.modulation_delay = tb.modulation_delay
+    d.depth = tb.depth
+    d.first_is_plain = 1 if tb.first_is_plain else 0
+    d.carrier_phase_step = float(b.qam.carrier_phase_step)
+    d.resample_fir[:] = list(resample_fir())
+    d.extract2x = iir_desc(b.qam._extract_chroma2x)
+    d.remove2x = iir_desc(b.qam._remove_chroma2x)
+    d.demod_lp = iir_desc(b.qam._demod_lowpass)
+    d.pald_lp = iir_desc(tb.comb._filter if tb.kind == 'pal_d' else None)
+    d.precorrect = iir_desc(b.qam._chroma_precorrect_lowpass)
+    d.decode_matrix[:] = list(numpy.asarray(b.decode_matrix).reshape(-1))
+    d.encode_matrix[:] = list(numpy.asarray(b.encode_matrix).reshape(-1))
+    main, bits = tb.demod_main_table()
+    first = tb.demod_first_table() if (tb.first_is_plain and tb.kind in ('pal_d', 'ntsc_comb')) else None
+    mod = tb.mod_table()
+    main = numpy.ascontiguousarray(main)
+    mod = numpy.ascontiguousarray(mod)
+    d.demod_main = _lane_table(main, bits)
+    d.demod_first = _lane_table(first)
+    d.mod_main = _lane_table(mod)
+    return BuiltPlan(d, [main, first, mod], tb)
+
+
+def build_plan(modem):
+    stack = modem._stack()
+    if stack['kind'] == 'secam':
+        from color_modem_amd import plan_secam
+        return plan_secam.build_secam_plan(stack)
+    return build_qam_plan(stack)

@@ -1,0 +1,144 @@
+/*
+ * color_modem_hip.h - C ABI of libcolor_modem_hip.so, the MI355X (gfx950) implementation of
+ * kFYatek/color_modem's per-line colour modulate/demodulate hot path.
+ *
+ * The reference has no FFI: its hot path is Python calling numpy/scipy once per scan line from
+ * ImageModem's row loops.  The entry points below are what a binding for that path needs - one
+ * immutable *plan* per modem stack (the state the reference builds in its constructors) and
+ * batch calls that replace the per-row loops:
+ *
+ *   cm_plan_create        <- the constructors: qam.py:14-18 (QamColorModem), pal.py:28-31,
+ *                            63-69, 131-178 (PalS/PalD/Pal3D), ntsc.py:23-26, 52-59, comb.py:
+ *                            24-31, 72-88, 126-127, 131-139, secam.py:153-190
+ *   cm_demodulate_frames  <- ImageModem.demodulate's row loop, image.py:75-83, calling
+ *                            Modem.demodulate(frame, line, composite) (comb.py:67-68, 121-122;
+ *                            qam.py:71-72; secam.py:278-304) for every row of every frame
+ *   cm_modulate_frames    <- ImageModem.modulate's row loop, image.py:47-55, calling
+ *                            Modem.modulate(frame, line, r, g, b) (qam.py:68-69, comb.py:154-155,
+ *                            secam.py:258-259)
+ *   cm_demodulate_run /   <- the same Modem.demodulate / Modem.modulate protocol for an explicit
+ *   cm_modulate_run          run of consecutive same-field lines (what the stateful per-row
+ *                            objects of the reference see between two resets)
+ *
+ * Conventions: plain C, no exceptions; every function returns CM_OK (0) or a negative code and
+ * records a message for cm_last_error() (thread-local).  All image buffers are DEVICE pointers
+ * to float32, caller-owned, row-major:  composite [frames][height][width],
+ * rgb [frames][3][height][width] (planar R, G, B).  `stream` is a hipStream_t (NULL = default
+ * stream); calls are asynchronous with respect to the host.  Plans are immutable after
+ * creation and may be shared by threads; a plan belongs to the device that was current when
+ * it was created.
+ *
+ * There is no CPU implementation behind this ABI: without a usable HIP device every compute
+ * entry point fails with CM_ERR_NO_DEVICE.
+ */
+#ifndef COLOR_MODEM_HIP_H
+#define COLOR_MODEM_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CM_ABI_VERSION 1
+
+enum cm_status {
+    CM_OK = 0,
+    CM_ERR_INVALID = -1,     /* bad argument / descriptor (ValueError on the Python side) */
+    CM_ERR_UNSUPPORTED = -2, /* valid request this build has no kernel for */
+    CM_ERR_NO_DEVICE = -3,   /* no HIP device / HIP runtime failure */
+    CM_ERR_LAUNCH = -4       /* kernel launch or memory operation failed */
+};
+
+/* which streaming pipeline runs the main pass */
+enum cm_pipeline {
+    CM_PIPE_QAM = 1,   /* synchronous QAM detector (qam.py:43-58): PAL-S, NTSC, NTSC comb, Pal3D, Simple*Comb */
+    CM_PIPE_PAL_D = 2, /* PAL delay-line decoder (pal.py:71-127) */
+    CM_PIPE_SECAM = 3  /* SECAM FM (secam.py:127-149, 240-304) */
+};
+
+#define CM_MAX_SECTIONS 4
+#define CM_LANE_DOUBLES 16
+
+/* One IIR filter of the reference (utils.py:9-26) in cascade form.
+ * sos rows follow scipy: [b0 b1 b2 1 a1 a2]; shift is FilterFunction._shift. */
+typedef struct {
+    int32_t n_sections;
+    int32_t shift;
+    double sos[CM_MAX_SECTIONS][6];
+} cm_iir_desc;
+
+/* Per-(frame mod cycle, regime, line) constants of one pass; CM_LANE_DOUBLES doubles each:
+ *   [0] sin, [1] cos of the detector phase at the first 2x sample of the line
+ *   [2] sin, [3] cos of the re-modulation phase (times the V-switch sign); both 0 = luma passes unstripped
+ *   [4..9]   u = sum_j t[4+2j] * Bs[k-j] + t[5+2j] * Bc[k-j],  j = 0..2
+ *   [10..15] v likewise
+ * where (Bs, Bc)[k] is the base demodulation of call k's own input line with the phase above
+ * (qam.py:47-54 for CM_PIPE_QAM, pal.py:71-77 applied to qam.py:34-37 for CM_PIPE_PAL_D).
+ * regime = min(k, 2), k = index of the call within its run (0 = first line after a reset). */
+typedef struct {
+    int32_t frame_cycle;  /* table rows per regime: frames repeat with this period */
+    int32_t n_lines;      /* line numbers 0 .. n_lines-1 are tabulated */
+    const double *table;  /* [frame_cycle][3][n_lines][CM_LANE_DOUBLES]; NULL = pass absent */
+    int32_t luma_from_prev; /* per regime (bit r): luma source is the previous call's input line */
+    int32_t reserved;
+} cm_lane_table;
+
+typedef struct {
+    int32_t abi_version;   /* CM_ABI_VERSION */
+    int32_t pipeline;      /* enum cm_pipeline of the main pass */
+    int32_t width, height; /* W, H of a frame */
+    int32_t demodulation_delay; /* image.py:63 */
+    int32_t modulation_delay;   /* image.py:30 */
+    int32_t depth;         /* how many previous calls of a run a demodulated line depends on (0..2) */
+    int32_t first_is_plain;/* 1: calls with k == 0 come from the plain band-stop decoder (comb.py:48-49) */
+    double carrier_phase_step; /* qam.py:15 */
+    double resample_fir[41];   /* scipy.signal.firwin(41, 0.5, window=('kaiser', 5.0)) */
+    cm_iir_desc extract2x;  /* qam.py:17 band-pass */
+    cm_iir_desc remove2x;   /* qam.py:17 band-stop */
+    cm_iir_desc demod_lp;   /* qam.py:18 */
+    cm_iir_desc pald_lp;    /* pal.py:67-69 (CM_PIPE_PAL_D only) */
+    cm_iir_desc precorrect; /* qam.py:16 */
+    double decode_matrix[9]; /* (r, g, b) = M (y, u, v): pal.py:43-45, ntsc.py:38-40 */
+    double encode_matrix[9]; /* (y, u, v) = M (r, g, b): pal.py:35-37, ntsc.py:30-32 */
+    cm_lane_table demod_main;  /* main pass */
+    cm_lane_table demod_first; /* plain pass for k == 0 (only regime 0 is read) */
+    cm_lane_table mod_main;    /* modulator: [0] sin, [1] cos of start phase (times V sign), [2..5] row weights */
+} cm_plan_desc;
+
+typedef struct cm_plan cm_plan;
+
+const char *cm_last_error(void);
+int cm_abi_version(void);
+
+/* Number of usable HIP devices (0 when there is none); never fails. */
+int cm_device_count(void);
+
+int cm_plan_create(const cm_plan_desc *desc, cm_plan **out);
+void cm_plan_destroy(cm_plan *plan);
+
+/* Demodulate n_frames frames; frame numbers first_frame .. first_frame + n_frames - 1.
+ * Equals looping ImageModem.demodulate's schedule (image.py:75-83) with a fresh modem. */
+int cm_demodulate_frames(const cm_plan *plan, const float *composite, float *rgb, int64_t n_frames,
+                         int64_t first_frame, void *stream);
+int cm_modulate_frames(const cm_plan *plan, const float *rgb, float *composite, int64_t n_frames,
+                       int64_t first_frame, void *stream);
+
+/* One run: n_calls consecutive calls Modem.demodulate(frame, first_line + 2 i, composite[i]),
+ * i = 0 .. n_calls-1, where the first of them is the k0-th call since the modem's last reset
+ * (k0 = 0: the run starts with a reset).  composite is [n_calls][width]; rgb receives what each
+ * call returns, [n_calls][3][width].  Calls whose history (depth lines) lies before the run
+ * start return unspecified data; the caller supplies enough history. */
+int cm_demodulate_run(const cm_plan *plan, const float *composite, float *rgb, int32_t n_calls, int32_t frame,
+                      int32_t first_line, int32_t k0, void *stream);
+int cm_modulate_run(const cm_plan *plan, const float *rgb, float *composite, int32_t n_calls, int32_t frame,
+                    int32_t first_line, int32_t k0, void *stream);
+
+/* Name, main-loop instruction mix and launch geometry of the dominant kernel of the last
+ * cm_demodulate_frames call on this plan (for bench.py / profiling); returns bytes written. */
+int cm_plan_describe(const cm_plan *plan, char *buf, int32_t buf_len);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

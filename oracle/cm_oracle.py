@@ -1,0 +1,238 @@
+# -*- coding: utf-8 -*-
+"""ctypes binding of oracle/libcm_oracle.so - TEST INFRASTRUCTURE (see oracle/cm_oracle.h).
+
+Builds an ``orc_desc_t`` from a color_modem_amd modem object (whose scipy-designed filters are
+themselves pinned against tests/golden/plans.json) and exposes the oracle's per-row, per-frame
+and batch entry points.  May be imported only by tests/, __graft_entry__.smoke() and the
+cpu_baseline leg of bench.py.
+"""
+
+import ctypes
+import os
+import subprocess
+
+import numpy
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, 'libcm_oracle.so')
+
+ORC_MAX_COEF = 8
+ORC_MAX_FILTERS = 8
+KIND = {'pal_s': 1, 'pal_d': 2, 'pal_3d': 3, 'ntsc': 4, 'ntsc_comb': 5, 'secam': 6}
+WRAP = {None: 0, 'simple': 1, 'simple_3d': 2, 'color_averaging': 3}
+
+
+class Filter(ctypes.Structure):
+    _fields_ = [('nb', ctypes.c_int32), ('na', ctypes.c_int32), ('shift', ctypes.c_int32),
+                ('present', ctypes.c_int32), ('b', ctypes.c_double * ORC_MAX_COEF),
+                ('a', ctypes.c_double * ORC_MAX_COEF), ('phase_shift', ctypes.c_double)]
+
+
+class Desc(ctypes.Structure):
+    _fields_ = [('kind', ctypes.c_int32), ('wrapper', ctypes.c_int32), ('use_minavg', ctypes.c_int32),
+                ('alternate_phases', ctypes.c_int32),
+                ('frame_rate', ctypes.c_double), ('total_lines', ctypes.c_int32),
+                ('odd_first', ctypes.c_int32), ('odd_last', ctypes.c_int32),
+                ('even_first', ctypes.c_int32), ('even_last', ctypes.c_int32),
+                ('width', ctypes.c_int32), ('height', ctypes.c_int32),
+                ('total_width_factor', ctypes.c_double),
+                ('fsc', ctypes.c_double), ('frame_cycle', ctypes.c_int32), ('pad0', ctypes.c_int32),
+                ('carrier_phase_step', ctypes.c_double),
+                ('fsc_dr', ctypes.c_double), ('fsc_db', ctypes.c_double), ('fdev_dr', ctypes.c_double),
+                ('fdev_db', ctypes.c_double), ('flimit_min', ctypes.c_double), ('flimit_max', ctypes.c_double),
+                ('bell_f0', ctypes.c_double), ('m0', ctypes.c_double), ('bell_kn', ctypes.c_double),
+                ('bell_kd', ctypes.c_double), ('fm_fc', ctypes.c_double),
+                ('filters', Filter * ORC_MAX_FILTERS)]
+
+
+def build_library(force=False):
+    if force or not os.path.exists(LIB_PATH) or \
+            os.path.getmtime(LIB_PATH) < os.path.getmtime(os.path.join(HERE, 'cm_oracle.cpp')):
+        subprocess.check_call(['make', '-C', HERE, 'libcm_oracle.so'], stdout=subprocess.DEVNULL)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build_library()
+        L = ctypes.CDLL(LIB_PATH)
+        dp = ctypes.POINTER(ctypes.c_double)
+        fp = ctypes.POINTER(ctypes.c_float)
+        u8 = ctypes.POINTER(ctypes.c_uint8)
+        L.orc_create.restype = ctypes.c_void_p
+        L.orc_create.argtypes = [ctypes.POINTER(Desc)]
+        L.orc_destroy.argtypes = [ctypes.c_void_p]
+        L.orc_last_error.restype = ctypes.c_char_p
+        L.orc_modulation_delay.argtypes = [ctypes.c_void_p]
+        L.orc_demodulation_delay.argtypes = [ctypes.c_void_p]
+        L.orc_modulate.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, dp, dp, dp, ctypes.c_int, dp]
+        L.orc_demodulate.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, dp, ctypes.c_int, dp, dp, dp]
+        L.orc_modulate_frame.argtypes = [ctypes.c_void_p, ctypes.c_int, dp, dp]
+        L.orc_demodulate_frame.argtypes = [ctypes.c_void_p, ctypes.c_int, dp, dp]
+        L.orc_image_modulate.argtypes = [ctypes.c_void_p, ctypes.c_int, u8, u8]
+        L.orc_image_demodulate.argtypes = [ctypes.c_void_p, ctypes.c_int, u8, u8]
+        L.orc_demodulate_frames_f32.argtypes = [ctypes.POINTER(Desc), fp, fp, ctypes.c_int64, ctypes.c_int64,
+                                                ctypes.c_int]
+        L.orc_modulate_frames_f32.argtypes = [ctypes.POINTER(Desc), fp, fp, ctypes.c_int64, ctypes.c_int64,
+                                              ctypes.c_int]
+        L.orc_firwin41.argtypes = [dp]
+        L.orc_resample_up2.argtypes = [dp, ctypes.c_int, dp]
+        L.orc_resample_dn2.argtypes = [dp, ctypes.c_int, dp]
+        L.orc_resample_dn2.restype = ctypes.c_int
+        L.orc_filter_apply.argtypes = [ctypes.POINTER(Filter), dp, ctypes.c_int, dp]
+        L.orc_start_phase.restype = ctypes.c_double
+        L.orc_start_phase.argtypes = [ctypes.POINTER(Desc), ctypes.c_int, ctypes.c_int]
+        L.orc_analog_line.argtypes = [ctypes.POINTER(Desc), ctypes.c_int]
+        L.orc_is_alternate_line.argtypes = [ctypes.POINTER(Desc), ctypes.c_int, ctypes.c_int]
+        _lib = L
+    return _lib
+
+
+def _dp(a):
+    return a.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
+
+
+def make_filter(f):
+    out = Filter()
+    if f is None:
+        out.present = 0
+        return out
+    b, a = numpy.atleast_1d(f.b), numpy.atleast_1d(f.a)
+    out.nb, out.na, out.shift, out.present = len(b), len(a), int(f.shift), 1
+    out.b[:len(b)] = list(b)
+    out.a[:len(a)] = list(a)
+    out.phase_shift = float(f.phase_shift)
+    return out
+
+
+def make_desc(modem):
+    """orc_desc_t for a color_modem_amd modem object."""
+    stack = modem._stack()
+    d = Desc()
+    d.kind = KIND[stack['kind']]
+    wrapper = stack.get('demod_wrapper') or stack.get('mod_wrapper')
+    if stack.get('demod_wrapper') and stack.get('mod_wrapper'):
+        raise NotImplementedError('the oracle descriptor carries one wrapper')
+    d.wrapper = WRAP[wrapper]
+    backend = stack['backend']
+    lc = backend.line_config if hasattr(backend, 'line_config') else backend._line_config
+    std = lc.line_standard
+    d.frame_rate, d.total_lines = std.frame_rate, std.total_lines
+    d.odd_first, d.odd_last = std.odd_field_first_active_line, std.odd_field_last_active_line
+    d.even_first, d.even_last = std.even_field_first_active_line, std.even_field_last_active_line
+    d.width, d.height = lc.size
+    d.total_width_factor = std.total_width_factor
+    if stack['kind'] == 'secam':
+        m = backend
+        d.alternate_phases = 1 if m._alternate_phases else 0
+        d.fsc_dr, d.fsc_db, d.fdev_dr, d.fdev_db = m._fsc_dr, m._fsc_db, m._fdev_dr, m._fdev_db
+        d.flimit_min, d.flimit_max, d.bell_f0 = m._flimit_min, m._flimit_max, m._bell_f0
+        d.m0, d.bell_kn, d.bell_kd = m._variant.m0, m._variant.bell_kn, m._variant.bell_kd
+        d.fm_fc = m._chroma_demod._fc
+        fl = [m._chroma_precorrect_lowpass, m._chroma_precorrect, m._reverse_chroma_precorrect,
+              m._chroma_demod_bell, m._chroma_demod_chroma_filter, m._chroma_demod_luma_filter,
+              m._chroma_demod._lowpass]
+        d.frame_cycle = 1
+    else:
+        d.fsc = backend.config.fsc
+        d.frame_cycle = backend.frame_cycle
+        d.carrier_phase_step = backend.qam.carrier_phase_step
+        comb = stack.get('comb')
+        fl = [backend.qam._chroma_precorrect_lowpass, backend.qam._extract_chroma2x, backend.qam._remove_chroma2x,
+              backend.qam._demod_lowpass, comb._filter if stack['kind'] in ('pal_d', 'pal_3d') else None]
+    for i, f in enumerate(fl):
+        d.filters[i] = make_filter(f)
+    return d
+
+
+class OracleModem(object):
+    """Stateful oracle object with the reference's per-row protocol."""
+
+    def __init__(self, modem):
+        self.desc = make_desc(modem)
+        self._h = lib().orc_create(ctypes.byref(self.desc))
+        if not self._h:
+            raise RuntimeError(lib().orc_last_error().decode())
+        self.width, self.height = self.desc.width, self.desc.height
+        self.modulation_delay = lib().orc_modulation_delay(self._h)
+        self.demodulation_delay = lib().orc_demodulation_delay(self._h)
+
+    def __del__(self):
+        if getattr(self, '_h', None):
+            lib().orc_destroy(self._h)
+            self._h = None
+
+    def demodulate(self, frame, line, composite):
+        x = numpy.ascontiguousarray(composite, dtype=numpy.float64)
+        n = len(x)
+        r, g, b = numpy.empty(n), numpy.empty(n), numpy.empty(n)
+        lib().orc_demodulate(self._h, frame, line, _dp(x), n, _dp(r), _dp(g), _dp(b))
+        return r, g, b
+
+    def modulate(self, frame, line, r, g, b):
+        r, g, b = [numpy.ascontiguousarray(v, dtype=numpy.float64) for v in (r, g, b)]
+        out = numpy.empty(len(r))
+        lib().orc_modulate(self._h, frame, line, _dp(r), _dp(g), _dp(b), len(r), _dp(out))
+        return out
+
+    def demodulate_frame(self, frame, composite):
+        x = numpy.ascontiguousarray(composite, dtype=numpy.float64)
+        assert x.shape == (self.height, self.width)
+        out = numpy.empty((3, self.height, self.width))
+        lib().orc_demodulate_frame(self._h, frame, _dp(x), _dp(out))
+        return out
+
+    def modulate_frame(self, frame, rgb):
+        x = numpy.ascontiguousarray(rgb, dtype=numpy.float64)
+        assert x.shape == (3, self.height, self.width)
+        out = numpy.empty((self.height, self.width))
+        lib().orc_modulate_frame(self._h, frame, _dp(x), _dp(out))
+        return out
+
+    def image_modulate(self, frame, rgb8):
+        x = numpy.ascontiguousarray(rgb8, dtype=numpy.uint8)
+        assert x.shape == (self.height, self.width, 3)
+        out = numpy.empty((self.height, self.width), dtype=numpy.uint8)
+        u8 = ctypes.POINTER(ctypes.c_uint8)
+        lib().orc_image_modulate(self._h, frame, x.ctypes.data_as(u8), out.ctypes.data_as(u8))
+        return out
+
+    def image_demodulate(self, frame, comp8):
+        x = numpy.ascontiguousarray(comp8, dtype=numpy.uint8)
+        assert x.shape == (self.height, self.width)
+        out = numpy.empty((self.height, self.width, 3), dtype=numpy.uint8)
+        u8 = ctypes.POINTER(ctypes.c_uint8)
+        lib().orc_image_demodulate(self._h, frame, x.ctypes.data_as(u8), out.ctypes.data_as(u8))
+        return out
+
+
+def demodulate_frames_f32(modem, composite, first_frame=0, n_threads=1):
+    desc = make_desc(modem)
+    x = numpy.ascontiguousarray(composite, dtype=numpy.float32)
+    n, h, w = x.shape
+    assert (h, w) == (desc.height, desc.width)
+    out = numpy.empty((n, 3, h, w), dtype=numpy.float32)
+    fp = ctypes.POINTER(ctypes.c_float)
+    rc = lib().orc_demodulate_frames_f32(ctypes.byref(desc), x.ctypes.data_as(fp), out.ctypes.data_as(fp), n,
+                                         first_frame, n_threads)
+    if rc:
+        raise RuntimeError(lib().orc_last_error().decode())
+    return out
+
+
+def modulate_frames_f32(modem, rgb, first_frame=0, n_threads=1):
+    desc = make_desc(modem)
+    x = numpy.ascontiguousarray(rgb, dtype=numpy.float32)
+    n, _, h, w = x.shape
+    assert (h, w) == (desc.height, desc.width)
+    out = numpy.empty((n, h, w), dtype=numpy.float32)
+    fp = ctypes.POINTER(ctypes.c_float)
+    rc = lib().orc_modulate_frames_f32(ctypes.byref(desc), x.ctypes.data_as(fp), out.ctypes.data_as(fp), n,
+                                       first_frame, n_threads)
+    if rc:
+        raise RuntimeError(lib().orc_last_error().decode())
+    return out

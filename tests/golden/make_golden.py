@@ -1,0 +1,307 @@
+# -*- coding: utf-8 -*-
+"""Generate the golden vectors under tests/golden/ by running the REFERENCE implementation.
+
+Run in the build container only (the reference does not exist on the GPU box):
+
+    python tests/golden/make_golden.py            # writes tests/golden/*.npz, plans.json
+
+What is recorded
+----------------
+* plans.json   - every plan constant the reference derives for PAL-BG / NTSC-M / SECAM IIIb at
+                 720 px (filter (b, a, shift, phase_shift), carrier steps, start-phase and
+                 parity tables, the 41-tap resampling FIR), full float64 repr.
+* <case>.npz   - `inp` (float32, exactly what is fed to the reference after a cast to float64)
+                 and `out` (float64, what the reference returned), for whole small frames run
+                 through the row schedule of color_modem/image.py:47-55,75-83 and for explicit
+                 (frame, line) row sequences at the full 576/480-line geometry.
+* image_*.npz  - uint8 in/out of the reference's own ImageModem on a tiny PIL image.
+
+Harness behaviour that is NOT reference code
+--------------------------------------------
+* scipy.signal.iirdesign shim: scipy >= 1.? validates `wp, ws > 0`; the
+  reference (qam.py:17 via utils.py:55,62) asks for a band edge < 0 for NTSC-M.  The shim
+  restores the pre-validation behaviour (buttord + iirfilter).  PAL/SECAM coefficients are
+  bit-identical with and without it (asserted below).
+* The float frame driver `run_*_frame` below is our restatement of the image.py row schedule
+  without the uint8 conversion; the image_* cases pin the uint8 path with the real ImageModem.
+"""
+
+import json
+import os
+import sys
+import warnings
+
+import numpy
+import scipy
+import scipy.signal
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, '/root/reference')
+warnings.simplefilter('ignore')
+
+from color_modem_amd import testing  # noqa: E402
+
+_orig_iirdesign = scipy.signal.iirdesign
+
+
+def _legacy_iirdesign(wp, ws, gpass, gstop, analog=False, ftype='ellip', output='ba', fs=None):
+    assert ftype == 'butter' and not analog and output == 'ba' and fs is None
+    wp = numpy.atleast_1d(wp)
+    ws = numpy.atleast_1d(ws)
+    band_type = 2 * (len(wp) - 1) + 1
+    if wp[0] >= ws[0]:
+        band_type += 1
+    btype = {1: 'lowpass', 2: 'highpass', 3: 'bandstop', 4: 'bandpass'}[band_type]
+    n, wn = scipy.signal.buttord(wp, ws, gpass, gstop, analog=False)
+    return scipy.signal.iirfilter(n, wn, rp=gpass, rs=gstop, analog=False, btype=btype, ftype='butter',
+                                  output='ba')
+
+
+def use_shim(on):
+    scipy.signal.iirdesign = _legacy_iirdesign if on else _orig_iirdesign
+
+
+use_shim(True)
+
+from color_modem import comb, image, line  # noqa: E402
+from color_modem.color import ntsc, pal, secam  # noqa: E402
+
+LS = line.LineStandard
+
+
+def filt(f):
+    return {'b': [repr(float(v)) for v in f._b], 'a': [repr(float(v)) for v in f._a],
+            'shift': int(f._shift), 'phase_shift': repr(float(f.phase_shift))}
+
+
+def qam_plan(modem, lc, height, n_frames, extra_lines=4):
+    q = modem.qam
+    d = {
+        'fs': repr(float(lc.fs)),
+        'fsc': repr(float(modem.config.fsc)),
+        'carrier_phase_step': repr(float(q.carrier_phase_step)),
+        'line_shift': repr(float(modem.line_shift)),
+        'frame_shift': repr(float(modem.frame_shift)),
+        'frame_cycle': int(modem.frame_cycle),
+        'precorrect': filt(q._chroma_precorrect_lowpass),
+        'extract2x': filt(q._extract_chroma2x),
+        'remove2x': filt(q._remove_chroma2x),
+        'demod_lp': filt(q._demod_lowpass),
+        'start_phase': [[repr(float(modem.start_phase(f, y))) for y in range(height + extra_lines)]
+                        for f in range(n_frames)],
+        'alt': [[bool(lc.is_alternate_line(f, y)) for y in range(height + extra_lines)] for f in range(n_frames)],
+        'analog_line': [int(lc.analog_line(y)) for y in range(height + extra_lines)],
+    }
+    return d
+
+
+def make_plans():
+    plans = {'versions': {'numpy': numpy.__version__, 'scipy': scipy.__version__,
+                          'note': 'scipy.signal.iirdesign shimmed (buttord+iirfilter), see module docstring'}}
+    h = scipy.signal.firwin(41, 0.5, window=('kaiser', 5.0))
+    plans['resample_fir'] = [repr(float(v)) for v in h]
+
+    # the shim must not move PAL/SECAM coefficients
+    use_shim(False)
+    p0 = pal.PalDModem(line.LineConfig((720, 576)))
+    s0 = secam.SecamModem(line.LineConfig((720, 576)))
+    use_shim(True)
+    p1 = pal.PalDModem(line.LineConfig((720, 576)))
+    s1 = secam.SecamModem(line.LineConfig((720, 576)))
+    for n in ('_chroma_precorrect_lowpass', '_extract_chroma2x', '_remove_chroma2x', '_demod_lowpass'):
+        a, b = getattr(p0.backend.qam, n), getattr(p1.backend.qam, n)
+        assert numpy.array_equal(a._b, b._b) and numpy.array_equal(a._a, b._a), n
+    for n in ('_chroma_precorrect_lowpass', '_chroma_demod_bell'):
+        a, b = getattr(s0, n), getattr(s1, n)
+        assert numpy.array_equal(a._b, b._b) and numpy.array_equal(a._a, b._a), n
+
+    lc = line.LineConfig((720, 576))
+    m = pal.PalDModem(lc)
+    d = qam_plan(m.backend, lc, 576, 6)
+    d['pald_lp'] = filt(m._filter)
+    d['sin_factor'] = repr(float(m._sin_factor))
+    d['cos_factor'] = repr(float(m._cos_factor))
+    plans['pal_720x576'] = d
+
+    lc = line.LineConfig((720, 480))
+    m = ntsc.NtscCombModem(lc)
+    d = qam_plan(m.backend, lc, 480, 4)
+    d['comb_factor'] = repr(float(m._factor))
+    plans['ntsc_720x480'] = d
+
+    lc = line.LineConfig((720, 576))
+    m = secam.SecamModem(lc)
+    d = {
+        'fs': repr(float(lc.fs)),
+        'fsc_dr': repr(float(m._fsc_dr)), 'fsc_db': repr(float(m._fsc_db)),
+        'fdev_dr': repr(float(m._fdev_dr)), 'fdev_db': repr(float(m._fdev_db)),
+        'flimit_min': repr(float(m._flimit_min)), 'flimit_max': repr(float(m._flimit_max)),
+        'bell_f0': repr(float(m._bell_f0)),
+        'm0': repr(float(m._variant.m0)), 'bell_kn': repr(float(m._variant.bell_kn)),
+        'bell_kd': repr(float(m._variant.bell_kd)),
+        'precorrect_lp': filt(m._chroma_precorrect_lowpass),
+        'lf_precorrect': filt(m._chroma_precorrect),
+        'lf_reverse': filt(m._reverse_chroma_precorrect),
+        'bell': filt(m._chroma_demod_bell),
+        'chroma_bp': filt(m._chroma_demod_chroma_filter),
+        'luma_bs': filt(m._chroma_demod_luma_filter),
+        'fm_lp': filt(m._chroma_demod._lowpass),
+        'fm_fc': repr(float(m._chroma_demod._fc)),
+        'start_phase_inverted': [[bool(m._start_phase_inverted(f, y)) for y in range(580)] for f in range(12)],
+        'alt': [[bool(lc.is_alternate_line(f, y)) for y in range(580)] for f in range(4)],
+    }
+    plans['secam_720x576'] = d
+    with open(os.path.join(HERE, 'plans.json'), 'w') as fh:
+        json.dump(plans, fh, indent=1)
+
+
+# ---------------------------------------------------------------------------------------------
+# float frame drivers: the row schedule of image.py without the uint8 conversion
+
+def run_demod_frame(modem, comp, frame):
+    height, width = comp.shape
+    delay = getattr(modem, 'demodulation_delay', 0)
+    out = numpy.zeros((3, height, width))
+    for field in range(2):
+        for y in range(field, 2 * delay, 2):
+            modem.demodulate(frame, y, comp[y])
+        for y in range(field, height, 2):
+            iy = y + 2 * delay
+            while iy >= height:
+                iy -= 2
+            r, g, b = modem.demodulate(frame, y + 2 * delay, comp[iy])
+            out[0, y], out[1, y], out[2, y] = r, g, b
+    return out
+
+
+def run_mod_frame(modem, rgb, frame):
+    _, height, width = rgb.shape
+    delay = getattr(modem, 'modulation_delay', 0)
+    out = numpy.zeros((height, width))
+    for field in range(2):
+        for y in range(field, 2 * delay, 2):
+            modem.modulate(frame, y, rgb[0, y], rgb[1, y], rgb[2, y])
+        for y in range(field, height, 2):
+            iy = y + 2 * delay
+            while iy >= height:
+                iy -= 2
+            out[y] = modem.modulate(frame, y + 2 * delay, rgb[0, iy], rgb[1, iy], rgb[2, iy])
+    return out
+
+
+STACKS = {
+    'pal_s': lambda lc: pal.PalSModem(lc),
+    'pal_d': lambda lc: pal.PalDModem(lc),
+    'pal_3d': lambda lc: pal.Pal3DModem(lc),
+    'ntsc': lambda lc: ntsc.NtscModem(lc),
+    'ntsc_comb': lambda lc: ntsc.NtscCombModem(lc),
+    'ntsc_comb_simple': lambda lc: comb.SimpleCombModem(ntsc.NtscCombModem(lc)),
+    'ntsc_comb_3d': lambda lc: comb.Simple3DCombModem(ntsc.NtscCombModem(lc)),
+    'secam': lambda lc: secam.SecamModem(lc),
+    'secam_avg': lambda lc: comb.ColorAveragingModem(secam.SecamModem(lc)),
+}
+
+STANDARD = {'pal': 'GERBER_625', 'ntsc': 'NTSC_525', 'secam': 'GERBER_625'}
+
+
+def line_config(stack, size):
+    std = getattr(LS, STANDARD[stack.split('_')[0]])
+    return line.LineConfig(size, std)
+
+
+def save(name, **arrays):
+    path = os.path.join(HERE, name + '.npz')
+    numpy.savez_compressed(path, **arrays)
+    print('%-28s %8.1f KB' % (name, os.path.getsize(path) / 1024.0))
+
+
+def frame_cases():
+    W, H = 720, 8
+    # (case, modulating stack for a valid input signal, demodulating stack, frames)
+    demods = [
+        ('pal_d', 'pal_s', [0, 1, 2, 3, 5]),
+        ('pal_s', 'pal_s', [0, 3]),
+        ('pal_3d', 'pal_s', [0, 1, 2, 3]),
+        ('ntsc', 'ntsc', [0, 1]),
+        ('ntsc_comb', 'ntsc', [0, 1, 2]),
+        ('ntsc_comb_simple', 'ntsc', [0, 1]),
+        ('ntsc_comb_3d', 'ntsc', [0, 1, 3]),
+        ('secam', 'secam', [0, 1, 2, 7]),
+    ]
+    mods = [
+        ('pal_s', [0, 1, 2, 3]),
+        ('ntsc', [0, 1]),
+        ('secam', [0, 1, 2, 3, 4, 5, 6]),
+        ('secam_avg', [0, 1]),
+    ]
+    for stack, frames in mods:
+        lc = line_config(stack, (W, H))
+        modem = STACKS[stack](lc)
+        rgb = testing.synthetic_rgb(len(frames), H, W, seed=100)
+        out = numpy.stack([run_mod_frame(modem, rgb[i].astype(numpy.float64), f) for i, f in enumerate(frames)])
+        save('frames_mod_' + stack, inp=rgb, out=out, frames=numpy.array(frames), size=numpy.array([W, H]))
+    for stack, mod_stack, frames in demods:
+        lc = line_config(stack, (W, H))
+        enc = STACKS[mod_stack](lc)
+        rgb = testing.synthetic_rgb(len(frames), H, W, seed=200)
+        comp = numpy.stack([run_mod_frame(enc, rgb[i].astype(numpy.float64), f) for i, f in enumerate(frames)])
+        comp = comp.astype(numpy.float32)
+        modem = STACKS[stack](lc)
+        out = numpy.stack([run_demod_frame(modem, comp[i].astype(numpy.float64), f) for i, f in enumerate(frames)])
+        save('frames_demod_' + stack, inp=comp, out=out, frames=numpy.array(frames), size=numpy.array([W, H]))
+    # noise input (not a valid colour signal) through the headline decoder, odd height, other width
+    for stack, (w, h), frames in [('pal_d', (720, 8), [0, 1, 2, 3]), ('pal_d', (704, 7), [1, 2]),
+                                  ('ntsc_comb_3d', (720, 7), [0, 1])]:
+        lc = line_config(stack, (w, h))
+        comp = testing.synthetic_composite(len(frames), h, w, seed=300)
+        modem = STACKS[stack](lc)
+        out = numpy.stack([run_demod_frame(modem, comp[i].astype(numpy.float64), f) for i, f in enumerate(frames)])
+        save('frames_demod_%s_noise_%dx%d' % (stack, w, h), inp=comp, out=out, frames=numpy.array(frames),
+             size=numpy.array([w, h]))
+
+
+def row_cases():
+    """Explicit (frame, line) sequences at the full-height geometry, fed to one modem object in order."""
+    seqs = {
+        'pal_d': ((720, 576), [(1, 0), (1, 2), (1, 4), (1, 571), (1, 573), (1, 575), (2, 1), (2, 3)]),
+        'pal_3d': ((720, 576), [(1, 0), (1, 2), (1, 4), (1, 6), (3, 573), (3, 575), (3, 577)]),
+        'ntsc_comb_3d': ((720, 480), [(1, 1), (1, 3), (1, 5), (1, 7), (0, 476), (0, 478), (0, 480)]),
+        'ntsc_comb': ((720, 480), [(0, 0), (0, 2), (0, 4), (1, 477), (1, 479)]),
+        'secam': ((720, 576), [(0, 0), (0, 2), (0, 4), (3, 571), (3, 573), (3, 575)]),
+    }
+    enc_of = {'pal_d': 'pal_s', 'pal_3d': 'pal_s', 'ntsc_comb_3d': 'ntsc', 'ntsc_comb': 'ntsc', 'secam': 'secam'}
+    for stack, (size, seq) in seqs.items():
+        lc = line.LineConfig(size)
+        enc = STACKS[enc_of[stack]](lc)
+        modem = STACKS[stack](lc)
+        rgb = testing.synthetic_rgb(1, len(seq), size[0], seed=400)[0]
+        comp = numpy.stack([enc.modulate(f, y, *[rgb[c, i].astype(numpy.float64) for c in range(3)])
+                            for i, (f, y) in enumerate(seq)]).astype(numpy.float32)
+        out = numpy.stack([numpy.stack(modem.demodulate(f, y, comp[i].astype(numpy.float64)))
+                           for i, (f, y) in enumerate(seq)])
+        save('rows_demod_' + stack, inp=comp, out=out, seq=numpy.array(seq), size=numpy.array(size))
+
+
+def image_cases():
+    """uint8 through the reference's own ImageModem (image.py:27-84) on a 720x8 image."""
+    from PIL import Image
+    W, H = 720, 8
+    rgb = testing.synthetic_rgb(1, H, W, seed=500)[0]
+    rgb8 = numpy.uint8(numpy.rint(255.0 * rgb)).transpose(1, 2, 0).copy()
+    img = Image.frombytes('RGB', (W, H), rgb8.tobytes())
+    for stack in ('pal_d', 'ntsc_comb_3d', 'secam_avg'):
+        lc = line_config(stack, (W, H))
+        im = image.ImageModem(STACKS[stack](lc))
+        comp_img = im.modulate(img, 1)
+        back = im.demodulate(comp_img, 1)
+        save('image_' + stack, rgb8=rgb8, comp8=numpy.frombuffer(comp_img.tobytes(), dtype=numpy.uint8).reshape(H, W),
+             back8=numpy.frombuffer(back.tobytes(), dtype=numpy.uint8).reshape(H, W, 3), frame=numpy.array(1))
+
+
+if __name__ == '__main__':
+    make_plans()
+    frame_cases()
+    row_cases()
+    image_cases()

@@ -1,0 +1,167 @@
+// cm_sim.cpp - TEST INFRASTRUCTURE.  Runs the streaming stages of color_modem_amd/csrc/cm_stages.h
+// on the host (T = double: checks the schedule/index logic against the oracle at ~1e-12;
+// T = float: predicts the float32 rounding error of the device kernels).  Never used by the
+// product path.
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../color_modem_amd/csrc/cm_plan.h"
+
+using namespace cm;
+
+static thread_local std::string g_err;
+
+template <typename T>
+struct RowCtx {
+    LaneK<T> lk;
+    std::vector<T> x, xl;  // own input row, luma source row
+    bool plain;            // produced by the band-stop (first line) decoder
+};
+
+template <typename T>
+static const double *lane_entry(const cm_lane_table &tb, int frame, int regime, int line) {
+    int f = ((frame % tb.frame_cycle) + tb.frame_cycle) % tb.frame_cycle;
+    return tb.table + (((size_t)f * 3 + regime) * tb.n_lines + line) * CM_LANE_DOUBLES;
+}
+
+// PIPE: 0 = QAM front, 1 = PAL-D front.  bsf: luma from the band-stop path.
+template <typename T, bool ODD_E, bool ODD_L, bool ODD_R>
+static int run_generic(const cm_plan_desc &d, bool pald, bool bsf, const cm_lane_table &tb, const std::vector<int> &calls,
+                       const double *comp, double *rgb, int n_calls, int frame, int first_line, int k0, bool mid_fast) {
+    DemodK<T> k;
+    DemodScales sc;
+    if (!build_demod_k<T>(d, pald, k, sc, g_err)) return CM_ERR_UNSUPPORTED;
+    const int W = d.width;
+    std::vector<T> car = build_carrier<T>(d.carrier_phase_step, W);
+    auto carrier = [&](int m, T *out2) {
+        if (m < 0) m = 0;
+        if (m > 2 * W - 1) m = 2 * W - 1;
+        out2[0] = car[2 * m];
+        out2[1] = car[2 * m + 1];
+    };
+    const int n = n_calls;
+    std::vector<LaneK<T>> lk(n);
+    std::vector<int> dy(n);
+    for (int i = 0; i < n; ++i) {
+        int kk = k0 + i, regime = kk < 2 ? kk : 2, line = first_line + 2 * i;
+        if (line < 0 || line >= tb.n_lines) { g_err = "line outside the lane table"; return CM_ERR_INVALID; }
+        lk[i] = convert_lane<T>(lane_entry<T>(tb, frame, regime, line), sc);
+        dy[i] = (tb.luma_from_prev >> regime) & 1;
+    }
+    auto xin = [&](int i, int s) -> T {
+        if (i < 0 || s < 0 || s >= W) return T(0);
+        return T(comp[(size_t)i * W + s]);
+    };
+    std::vector<PalDFront<T>> fp(n);
+    std::vector<QamFront<T, ODD_E, ODD_L, ODD_R, true>> fq(n);
+    std::vector<DemodBack<T, 2>> back(n);
+    for (int i = 0; i < n; ++i) { fp[i].reset(); fq[i].reset(); back[i].reset(); }
+    const int lat_front = pald ? PalDFront<T>::latency(k) : QamFront<T, ODD_E, ODD_L, ODD_R, true>::latency(k);
+    const int lat_luma = QamFront<T, ODD_E, ODD_L, ODD_R, true>::luma_latency(k);
+    const int lat_total = lat_front + k.s_p;
+    const int steps = W + lat_total;
+    // histories (the device keeps these in small register windows / an LDS ring)
+    std::vector<std::vector<T>> e_hist(n, std::vector<T>(steps + 64, T(0)));
+    std::vector<std::vector<T>> u_hist(n, std::vector<T>(steps + 64, T(0))), v_hist(n, std::vector<T>(steps + 64, T(0)));
+    std::vector<std::vector<T>> y_hist(n, std::vector<T>(steps + 64, T(0)));
+    std::vector<Pair<T>> base(n);
+    for (int t = 0; t < steps; ++t) {
+        // the device runs the EDGE-free body where no stage touches a row boundary
+        bool edge = !(mid_fast && t >= lat_total + 1 && t < W + 8);
+        const int n1 = t - 10;
+        for (int i = 0; i < n; ++i) {
+            T x_now = xin(i, t), x_d10 = xin(i, t - 10);
+            if (pald) {
+                const int n3 = n1 - k.q_e - 9, n4 = n3 - 10;
+                T cr[4];
+                carrier(2 * n4, cr);
+                carrier(2 * n4 + 1, cr + 2);
+                T e_d10 = (n3 - 10 >= 0) ? e_hist[i][n3 - 10] : T(0);
+                T e_out;
+                base[i] = edge ? fp[i].template step<true>(k, lk[i], t, x_now, x_d10, e_d10, cr, e_out)
+                               : fp[i].template step<false>(k, lk[i], t, x_now, x_d10, e_d10, cr, e_out);
+                if (n3 >= 0) e_hist[i][n3] = e_out;
+            } else {
+                const int n2 = n1 - k.q_e;
+                T cr[4];
+                carrier(2 * n2, cr);
+                carrier(2 * n2 + 1, cr + 2);
+                T luma = T(0);
+                base[i] = edge ? fq[i].template step<true>(k, lk[i], t, x_now, x_d10, cr, luma)
+                               : fq[i].template step<false>(k, lk[i], t, x_now, x_d10, cr, luma);
+                const int nl = t - lat_luma;
+                if (nl >= 0) y_hist[i][nl] = luma;
+            }
+        }
+        const int n6 = t - lat_front, n7 = n6 - k.s_p;
+        for (int i = 0; i < n; ++i) {
+            Pair<T> z{T(0), T(0)};
+            T u, v;
+            back[i].combine(lk[i], base[i], i >= 1 ? base[i - 1] : z, i >= 2 ? base[i - 2] : z, u, v);
+            if (n6 >= 0) { u_hist[i][n6] = u; v_hist[i][n6] = v; }
+            T u_d = n7 >= 0 ? u_hist[i][n7] : T(0), v_d = n7 >= 0 ? v_hist[i][n7] : T(0);
+            T y_src = bsf ? (n7 >= 0 ? y_hist[i][n7] : T(0)) : xin(i - dy[i], n7);
+            T cr[2];
+            carrier(2 * n7, cr);
+            Rgb<T> o = edge ? back[i].template step<true>(k, lk[i], n6, u, v, u_d, v_d, y_src, cr)
+                            : back[i].template step<false>(k, lk[i], n6, u, v, u_d, v_d, y_src, cr);
+            bool wanted = false;
+            for (int c : calls) wanted |= (c == i);
+            if (wanted && n7 >= 0 && n7 < W) {
+                rgb[((size_t)i * 3 + 0) * W + n7] = (double)o.r;
+                rgb[((size_t)i * 3 + 1) * W + n7] = (double)o.g;
+                rgb[((size_t)i * 3 + 2) * W + n7] = (double)o.b;
+            }
+        }
+    }
+    return CM_OK;
+}
+
+template <typename T>
+static int run_dispatch(const cm_plan_desc &d, bool pald, bool bsf, const cm_lane_table &tb, const std::vector<int> &calls,
+                        const double *comp, double *rgb, int n_calls, int frame, int first_line, int k0, bool mid_fast) {
+    const cm_iir_desc &lp = pald ? d.pald_lp : d.demod_lp;
+    bool oe = d.extract2x.shift & 1, ol = lp.shift & 1, orr = d.remove2x.shift & 1;
+    if (pald && (oe || ol)) { g_err = "PAL-D front end needs even filter shifts"; return CM_ERR_UNSUPPORTED; }
+#define GO(E, L, R) return run_generic<T, E, L, R>(d, pald, bsf, tb, calls, comp, rgb, n_calls, frame, first_line, k0, mid_fast)
+    if (!oe && !ol && !orr) GO(false, false, false);
+    if (!oe && ol && !orr) GO(false, true, false);
+    if (oe && !ol && !orr) GO(true, false, false);
+    if (oe && ol && !orr) GO(true, true, false);
+    if (!oe && !ol && orr) GO(false, false, true);
+    if (!oe && ol && orr) GO(false, true, true);
+    if (oe && !ol && orr) GO(true, false, true);
+    GO(true, true, true);
+#undef GO
+}
+
+template <typename T>
+static int sim_run(const cm_plan_desc *d, const double *comp, double *rgb, int n_calls, int frame, int first_line, int k0,
+                   int mid_fast) {
+    std::vector<int> main_calls, first_calls;
+    for (int i = 0; i < n_calls; ++i) {
+        if (d->first_is_plain && k0 + i == 0) first_calls.push_back(i); else main_calls.push_back(i);
+    }
+    int rc = CM_OK;
+    if (!main_calls.empty()) {
+        bool pald = d->pipeline == CM_PIPE_PAL_D;
+        bool bsf = (d->pipeline == CM_PIPE_QAM) && d->depth == 0 && d->first_is_plain;  // plain decoders: every call uses the band-stop
+        rc = run_dispatch<T>(*d, pald, bsf, d->demod_main, main_calls, comp, rgb, n_calls, frame, first_line, k0, mid_fast != 0);
+        if (rc) return rc;
+    }
+    if (!first_calls.empty()) rc = run_dispatch<T>(*d, false, true, d->demod_first, first_calls, comp, rgb, n_calls, frame, first_line, k0, mid_fast != 0);
+    return rc;
+}
+
+extern "C" {
+const char *cm_sim_last_error(void) { return g_err.c_str(); }
+int cm_sim_demodulate_run_f64(const cm_plan_desc *d, const double *comp, double *rgb, int n_calls, int frame, int first_line,
+                              int k0, int mid_fast) {
+    return sim_run<double>(d, comp, rgb, n_calls, frame, first_line, k0, mid_fast);
+}
+int cm_sim_demodulate_run_f32(const cm_plan_desc *d, const double *comp, double *rgb, int n_calls, int frame, int first_line,
+                              int k0, int mid_fast) {
+    return sim_run<float>(d, comp, rgb, n_calls, frame, first_line, k0, mid_fast);
+}
+}

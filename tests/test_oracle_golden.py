@@ -1,0 +1,68 @@
+# -*- coding: utf-8 -*-
+"""Pin the CPU oracle (oracle/cm_oracle.cpp) against vectors produced by the reference itself."""
+import glob
+import os
+
+import numpy
+import pytest
+
+import stacks
+from oracle import cm_oracle
+
+TOL = 1e-11
+
+FRAME_DEMOD = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(stacks.GOLDEN, 'frames_demod_*.npz')))
+FRAME_MOD = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(stacks.GOLDEN, 'frames_mod_*.npz')))
+ROWS = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(stacks.GOLDEN, 'rows_demod_*.npz')))
+IMAGES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(stacks.GOLDEN, 'image_*.npz')))
+
+
+def stack_of(name, prefix):
+    s = name[len(prefix):]
+    return s.split('_noise_')[0]
+
+
+@pytest.mark.parametrize('name', FRAME_DEMOD)
+def test_frames_demod(name):
+    g = stacks.load(name)
+    modem = stacks.make(stack_of(name, 'frames_demod_'), g['size'])
+    orc = cm_oracle.OracleModem(modem)
+    for i, f in enumerate(g['frames']):
+        out = orc.demodulate_frame(int(f), g['inp'][i].astype(numpy.float64))
+        assert stacks.rel_err(out, g['out'][i]) < TOL, (name, f)
+
+
+@pytest.mark.parametrize('name', FRAME_MOD)
+def test_frames_mod(name):
+    g = stacks.load(name)
+    modem = stacks.make(stack_of(name, 'frames_mod_'), g['size'])
+    orc = cm_oracle.OracleModem(modem)
+    for i, f in enumerate(g['frames']):
+        out = orc.modulate_frame(int(f), g['inp'][i].astype(numpy.float64))
+        assert stacks.rel_err(out, g['out'][i]) < TOL, (name, f)
+
+
+@pytest.mark.parametrize('name', ROWS)
+def test_rows_demod(name):
+    g = stacks.load(name)
+    modem = stacks.make(stack_of(name, 'rows_demod_'), g['size'], explicit=False)
+    orc = cm_oracle.OracleModem(modem)
+    for i, (f, y) in enumerate(g['seq']):
+        out = numpy.stack(orc.demodulate(int(f), int(y), g['inp'][i].astype(numpy.float64)))
+        assert stacks.rel_err(out, g['out'][i]) < TOL, (name, f, y)
+
+
+@pytest.mark.parametrize('name', IMAGES)
+def test_image_uint8(name):
+    g = stacks.load(name)
+    h, w = g['comp8'].shape
+    modem = stacks.make(name[len('image_'):], (w, h))
+    orc = cm_oracle.OracleModem(modem)
+    comp8 = orc.image_modulate(int(g['frame']), g['rgb8'])
+    # the byte rounding sits on a knife edge for a handful of samples; allow no more than 1 LSB
+    # on < 0.1 % of the samples (float64 op-order differences between numpy and the restatement)
+    diff = numpy.abs(comp8.astype(int) - g['comp8'].astype(int))
+    assert diff.max() <= 1 and (diff > 0).mean() < 1e-3
+    back8 = orc.image_demodulate(int(g['frame']), g['comp8'])
+    diff = numpy.abs(back8.astype(int) - g['back8'].astype(int))
+    assert diff.max() <= 1 and (diff > 0).mean() < 1e-3
