@@ -113,6 +113,8 @@ LaneK<T> convert_lane(const double *e, const DemodScales &sc) {
     l.cth = T(e[1]);
     l.sph = T(e[2] * sc.pre);
     l.cph = T(e[3] * sc.pre);
+    l.vsph = T(e[2] * sc.pre * e[16]);
+    l.vcph = T(e[3] * sc.pre * e[16]);
     for (int j = 0; j < 3; ++j) {
         l.cu[j][0] = T(e[4 + 2 * j] * sc.base);
         l.cu[j][1] = T(e[5 + 2 * j] * sc.base);

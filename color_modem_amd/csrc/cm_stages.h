@@ -157,8 +157,9 @@ CM_HD T iir_gen(IirState<T, MAXSEC> &st, const SosK<T, MAXSEC> &k, T x) {
 template <typename T>
 struct LaneK {
     T sth, cth;  // sin/cos of the detector phase at sample 0 of this line
-    T sph, cph;  // sin/cos of the re-modulation phase, pre-multiplied by the pre-filter gain and
-                 // the V-switch sign; both 0 when luma is passed through unstripped
+    T sph, cph;  // sin/cos of the re-modulation phase times the pre-filter gain; both 0 when luma
+                 // is passed through unstripped
+    T vsph, vcph;  // the same two times the V-switch sign of the re-modulated line (ref pal.py:50-51)
     T cu[3][2];  // u = sum_j cu[j][0] * Bs[k-j] + cu[j][1] * Bc[k-j]
     T cv[3][2];  // v likewise
 };
@@ -400,7 +401,7 @@ struct DemodBack {
             wv = iir_gen(pre_v, k.pre, v);
         }
         T sn = fmaf_(lk.sph, car[0], lk.cph * car[1]);
-        T cs = fmaf_(lk.cph, car[0], -(lk.sph * car[1]));
+        T cs = fmaf_(lk.vcph, car[0], -(lk.vsph * car[1]));  // +-cos(phi + 2 n7 cps)
         T y = y_src - fmaf_(sn, wu, cs * wv);
         Rgb<T> o;
         o.r = fmaf_(k.m[0][0], y, fmaf_(k.m[0][1], u_d, k.m[0][2] * v_d));

@@ -25,7 +25,7 @@ import scipy.signal
 CM_ABI_VERSION = 1
 CM_PIPE_QAM, CM_PIPE_PAL_D, CM_PIPE_SECAM = 1, 2, 3
 CM_MAX_SECTIONS = 4
-CM_LANE_DOUBLES = 16
+CM_LANE_DOUBLES = 20
 
 
 class IirDesc(ctypes.Structure):
@@ -44,6 +44,7 @@ class PlanDesc(ctypes.Structure):
                 ('width', ctypes.c_int32), ('height', ctypes.c_int32),
                 ('demodulation_delay', ctypes.c_int32), ('modulation_delay', ctypes.c_int32),
                 ('depth', ctypes.c_int32), ('first_is_plain', ctypes.c_int32),
+                ('main_luma_bandstop', ctypes.c_int32), ('reserved0', ctypes.c_int32),
                 ('carrier_phase_step', ctypes.c_double),
                 ('resample_fir', ctypes.c_double * 41),
                 ('extract2x', IirDesc), ('remove2x', IirDesc), ('demod_lp', IirDesc),
@@ -112,7 +113,25 @@ def pair_add(a, b):
 # ---------------------------------------------------------------------------------------------
 # IIR descriptors
 
-def iir_desc(filt):
+def bandpass_sections(sos):
+    """Re-pair the zeros of a Butterworth/Chebyshev band-pass so every section has the numerator
+    g * (1 - z^-2) (one zero at z = +1, one at z = -1).  scipy pairs (+1, +1) and (-1, -1); the
+    cascade's transfer function is unchanged, each section just becomes a 3-operation update."""
+    sos = numpy.array(sos, dtype=numpy.float64)
+    zeros = numpy.concatenate([numpy.roots(row[:3]) for row in sos])
+    n = len(sos)
+    plus = int(numpy.sum(numpy.abs(zeros - 1.0) < 1e-6))
+    minus = int(numpy.sum(numpy.abs(zeros + 1.0) < 1e-6))
+    if plus != n or minus != n:
+        raise NotImplementedError('band-pass with zeros %r is not of the (1 - z^-2)^n family' % (zeros,))
+    gain = float(numpy.prod(sos[:, 0]))
+    out = sos.copy()
+    out[:, 0:3] = (1.0, 0.0, -1.0)
+    out[0, 0:3] *= gain
+    return out
+
+
+def iir_desc(filt, bandpass=False):
     """FilterFunction -> IirDesc (sections from the design's zpk form when available)."""
     d = IirDesc()
     if filt is None:
@@ -120,6 +139,8 @@ def iir_desc(filt):
         d.shift = 0
         return d
     sos = filt.sos()
+    if bandpass:
+        sos = bandpass_sections(sos)
     if len(sos) > CM_MAX_SECTIONS:
         raise NotImplementedError('filter order %d exceeds the %d sections this build carries'
                                   % (filt.order, CM_MAX_SECTIONS))
@@ -277,9 +298,13 @@ class QamTables(object):
         return d
 
     @property
+    def plain_stack(self):
+        return self.demod_wrapper is None and self.kind in ('pal_s', 'ntsc')
+
+    @property
     def first_is_plain(self):
         # k == 0 goes through backend.demodulate_components(strip_chroma=True): band-stop luma
-        return self.demod_wrapper is None and self.kind in ('pal_s', 'ntsc', 'pal_d', 'ntsc_comb')
+        return self.demod_wrapper is None and self.kind in ('pal_d', 'ntsc_comb')
 
     def detector_phase(self, frame, line):
         theta = self.phi(frame, line) + self.ps
@@ -294,22 +319,22 @@ class QamTables(object):
         n_lines = self.n_lines()
         tab = numpy.zeros((self.cycle, 3, n_lines, CM_LANE_DOUBLES))
         luma_prev_bits = 0
-        plain_stack = self.kind in ('pal_s', 'ntsc') and self.demod_wrapper is None
         for f in range(self.cycle):
             for k in range(3):
                 for line in range(n_lines):
                     if line - 2 * k < -1:
                         continue  # a run never starts above the top of the frame
-                    if self.first_is_plain and k == 0 and not plain_stack:
-                        continue  # produced by the plain pass
-                    u, v, remod_line, luma_prev = self.decode(f, line, k)
                     e = tab[f, k, line]
                     theta = self.detector_phase(f, line)
                     e[0], e[1] = numpy.sin(theta), numpy.cos(theta)
+                    e[16] = 1.0
+                    if self.first_is_plain and k == 0:
+                        continue  # output produced by the plain pass; the base pair still feeds call 1
+                    u, v, remod_line, luma_prev = self.decode(f, line, k)
                     if remod_line is not None:
                         p = self.phi(f, remod_line)
-                        e[2] = numpy.sin(p)
-                        e[3] = numpy.cos(p) * self.vsign(f, remod_line)  # pal.py:50-51
+                        e[2], e[3] = numpy.sin(p), numpy.cos(p)
+                        e[16] = self.vsign(f, remod_line)  # pal.py:50-51
                     e[4:10] = u.c.reshape(-1)
                     e[10:16] = v.c.reshape(-1)
                     if luma_prev:
@@ -327,6 +352,7 @@ class QamTables(object):
                 e[0], e[1] = numpy.sin(theta), numpy.cos(theta)
                 e[4:10] = u.c.reshape(-1)
                 e[10:16] = v.c.reshape(-1)
+                e[16] = 1.0
         return tab
 
     def mod_table(self):
@@ -381,9 +407,10 @@ def build_qam_plan(stack):
     d.modulation_delay = tb.modulation_delay
     d.depth = tb.depth
     d.first_is_plain = 1 if tb.first_is_plain else 0
+    d.main_luma_bandstop = 1 if tb.plain_stack else 0
     d.carrier_phase_step = float(b.qam.carrier_phase_step)
     d.resample_fir[:] = list(resample_fir())
-    d.extract2x = iir_desc(b.qam._extract_chroma2x)
+    d.extract2x = iir_desc(b.qam._extract_chroma2x, bandpass=True)
     d.remove2x = iir_desc(b.qam._remove_chroma2x)
     d.demod_lp = iir_desc(b.qam._demod_lowpass)
     d.pald_lp = iir_desc(tb.comb._filter if tb.kind == 'pal_d' else None)
@@ -391,7 +418,7 @@ def build_qam_plan(stack):
     d.decode_matrix[:] = list(numpy.asarray(b.decode_matrix).reshape(-1))
     d.encode_matrix[:] = list(numpy.asarray(b.encode_matrix).reshape(-1))
     main, bits = tb.demod_main_table()
-    first = tb.demod_first_table() if (tb.first_is_plain and tb.kind in ('pal_d', 'ntsc_comb')) else None
+    first = tb.demod_first_table() if tb.first_is_plain else None
     mod = tb.mod_table()
     main = numpy.ascontiguousarray(main)
     mod = numpy.ascontiguousarray(mod)

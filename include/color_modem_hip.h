@@ -58,7 +58,7 @@ enum cm_pipeline {
 };
 
 #define CM_MAX_SECTIONS 4
-#define CM_LANE_DOUBLES 16
+#define CM_LANE_DOUBLES 20
 
 /* One IIR filter of the reference (utils.py:9-26) in cascade form.
  * sos rows follow scipy: [b0 b1 b2 1 a1 a2]; shift is FilterFunction._shift. */
@@ -70,9 +70,11 @@ typedef struct {
 
 /* Per-(frame mod cycle, regime, line) constants of one pass; CM_LANE_DOUBLES doubles each:
  *   [0] sin, [1] cos of the detector phase at the first 2x sample of the line
- *   [2] sin, [3] cos of the re-modulation phase (times the V-switch sign); both 0 = luma passes unstripped
+ *   [2] sin, [3] cos of the re-modulation phase; both 0 = luma passes unstripped
  *   [4..9]   u = sum_j t[4+2j] * Bs[k-j] + t[5+2j] * Bc[k-j],  j = 0..2
  *   [10..15] v likewise
+ *   [16]     +1 / -1: sign applied to v on re-modulation (the PAL V switch, pal.py:50-51)
+ *   [17..19] reserved (0)
  * where (Bs, Bc)[k] is the base demodulation of call k's own input line with the phase above
  * (qam.py:47-54 for CM_PIPE_QAM, pal.py:71-77 applied to qam.py:34-37 for CM_PIPE_PAL_D).
  * regime = min(k, 2), k = index of the call within its run (0 = first line after a reset). */
@@ -91,7 +93,9 @@ typedef struct {
     int32_t demodulation_delay; /* image.py:63 */
     int32_t modulation_delay;   /* image.py:30 */
     int32_t depth;         /* how many previous calls of a run a demodulated line depends on (0..2) */
-    int32_t first_is_plain;/* 1: calls with k == 0 come from the plain band-stop decoder (comb.py:48-49) */
+    int32_t first_is_plain;/* 1: calls with k == 0 come from the plain band-stop decoder (comb.py:48-49), table demod_first */
+    int32_t main_luma_bandstop; /* 1: the main pass takes luma from the band-stop path (qam.py:57): plain PAL-S / NTSC */
+    int32_t reserved0;
     double carrier_phase_step; /* qam.py:15 */
     double resample_fir[41];   /* scipy.signal.firwin(41, 0.5, window=('kaiser', 5.0)) */
     cm_iir_desc extract2x;  /* qam.py:17 band-pass */

@@ -146,7 +146,7 @@ static int sim_run(const cm_plan_desc *d, const double *comp, double *rgb, int n
     int rc = CM_OK;
     if (!main_calls.empty()) {
         bool pald = d->pipeline == CM_PIPE_PAL_D;
-        bool bsf = (d->pipeline == CM_PIPE_QAM) && d->depth == 0 && d->first_is_plain;  // plain decoders: every call uses the band-stop
+        bool bsf = d->main_luma_bandstop != 0;  // plain decoders: every call uses the band-stop
         rc = run_dispatch<T>(*d, pald, bsf, d->demod_main, main_calls, comp, rgb, n_calls, frame, first_line, k0, mid_fast != 0);
         if (rc) return rc;
     }
