@@ -1,0 +1,66 @@
+# -*- coding: utf-8 -*-
+"""ctypes binding of libcolor_modem_hip.so (include/color_modem_hip.h).
+
+The library is the product: if it is missing or cannot be loaded this module raises - there is
+no Python or CPU substitute behind the Modem / ImageModem entry points.
+"""
+
+import ctypes
+import os
+
+from color_modem_amd import plan
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, 'libcolor_modem_hip.so')
+
+CM_OK, CM_ERR_INVALID, CM_ERR_UNSUPPORTED, CM_ERR_NO_DEVICE, CM_ERR_LAUNCH = 0, -1, -2, -3, -4
+
+# every symbol include/color_modem_hip.h declares
+SYMBOLS = ('cm_last_error', 'cm_abi_version', 'cm_device_count', 'cm_plan_create', 'cm_plan_destroy',
+           'cm_demodulate_frames', 'cm_modulate_frames', 'cm_demodulate_run', 'cm_modulate_run',
+           'cm_plan_describe')
+
+_lib = None
+
+
+class NativeError(RuntimeError):
+    pass
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise NativeError('%s not found: build it with `python -c "import __graft_entry__ as g; g.build()"` '
+                          '(hipcc --offload-arch=gfx950); color_modem_amd has no CPU path' % LIB_PATH)
+    L = ctypes.CDLL(LIB_PATH)
+    fp = ctypes.POINTER(ctypes.c_float)
+    vp = ctypes.c_void_p
+    L.cm_last_error.restype = ctypes.c_char_p
+    L.cm_abi_version.restype = ctypes.c_int
+    L.cm_device_count.restype = ctypes.c_int
+    L.cm_plan_create.argtypes = [ctypes.POINTER(plan.PlanDesc), ctypes.POINTER(vp)]
+    L.cm_plan_destroy.argtypes = [vp]
+    L.cm_plan_destroy.restype = None
+    L.cm_demodulate_frames.argtypes = [vp, vp, vp, ctypes.c_int64, ctypes.c_int64, vp]
+    L.cm_modulate_frames.argtypes = [vp, vp, vp, ctypes.c_int64, ctypes.c_int64, vp]
+    L.cm_demodulate_run.argtypes = [vp, vp, vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, vp]
+    L.cm_modulate_run.argtypes = [vp, vp, vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, vp]
+    L.cm_plan_describe.argtypes = [vp, ctypes.c_char_p, ctypes.c_int32]
+    if L.cm_abi_version() != plan.CM_ABI_VERSION:
+        raise NativeError('libcolor_modem_hip.so ABI %d, Python side expects %d - rebuild the library'
+                          % (L.cm_abi_version(), plan.CM_ABI_VERSION))
+    _lib = L
+    return L
+
+
+def check(rc):
+    if rc == CM_OK:
+        return
+    msg = lib().cm_last_error().decode('utf-8', 'replace')
+    if rc == CM_ERR_INVALID:
+        raise ValueError(msg)
+    if rc == CM_ERR_UNSUPPORTED:
+        raise NotImplementedError(msg)
+    raise NativeError('libcolor_modem_hip: %s (code %d)' % (msg, rc))

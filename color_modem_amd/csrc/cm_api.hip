@@ -1,0 +1,305 @@
+// cm_api.hip - C ABI of libcolor_modem_hip.so (include/color_modem_hip.h): plan management and
+// kernel launches.  There is deliberately no host fallback in this file.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/color_modem_hip.h"
+#include "cm_kernels.h"
+#include "cm_plan.h"
+
+using namespace cm;
+
+namespace {
+
+thread_local std::string g_error;
+
+int fail(int code, const std::string &msg) {
+    g_error = msg;
+    return code;
+}
+#define HIP_TRY(expr, code)                                                                      \
+    do {                                                                                         \
+        hipError_t e_ = (expr);                                                                  \
+        if (e_ != hipSuccess) return fail(code, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+typedef int (*LaunchFn)(const Geom &, const void *k, int blocks, hipStream_t);
+
+template <class S, int FRONT, bool BSF, int DEPTH>
+int launch_demod(const Geom &g, const void *kv, int blocks, hipStream_t stream) {
+    const DemodK<float, S> &k = *static_cast<const DemodK<float, S> *>(kv);
+    hipLaunchKernelGGL((demod_kernel<S, FRONT, BSF, DEPTH>), dim3(blocks), dim3(64), 0, stream, g, k);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(CM_ERR_LAUNCH, std::string("demod_kernel launch: ") + hipGetErrorString(e));
+    return CM_OK;
+}
+
+struct Pass {
+    LaunchFn fn = nullptr;
+    std::vector<unsigned char> k;  // DemodK<float, S> blob
+    LaneK<float> *lanes = nullptr; // device
+    int cycle = 0, n_lines = 0, luma_prev_bits = 0;
+    int depth = 0;                 // halo lanes of the kernel instance
+    std::string name;
+};
+
+}  // namespace
+
+struct cm_plan {
+    cm_plan_desc desc;
+    int device = 0;
+    float *carrier = nullptr;
+    Pass main, first;
+    std::string last_launch;
+};
+
+namespace {
+
+template <class S>
+bool make_pass(const cm_plan_desc &d, bool pald, bool bsf, const cm_lane_table &tb, Pass &pass, std::string &err) {
+    DemodK<float, S> k;
+    DemodScales sc;
+    if (!build_demod_k<float, S>(d, pald, bsf, k, sc, err)) return false;
+    pass.k.resize(sizeof(k));
+    std::memcpy(pass.k.data(), &k, sizeof(k));
+    const size_t n = (size_t)tb.frame_cycle * 3 * tb.n_lines;
+    std::vector<LaneK<float>> host(n);
+    for (size_t i = 0; i < n; ++i) host[i] = convert_lane<float>(tb.table + i * CM_LANE_DOUBLES, sc);
+    if (hipMalloc((void **)&pass.lanes, n * sizeof(LaneK<float>)) != hipSuccess ||
+        hipMemcpy(pass.lanes, host.data(), n * sizeof(LaneK<float>), hipMemcpyHostToDevice) != hipSuccess) {
+        err = "device allocation / upload of the lane table failed";
+        return false;
+    }
+    pass.cycle = tb.frame_cycle;
+    pass.n_lines = tb.n_lines;
+    pass.luma_prev_bits = tb.luma_from_prev;
+    return true;
+}
+
+// Pick the kernel instance of a pass.  Returns false when this build has none for the filter set.
+bool select_pass(const cm_plan_desc &d, bool pald, bool bsf, int depth, const cm_lane_table &tb, Pass &pass,
+                 std::string &err) {
+    SysSignature want = signature_wanted(d, pald);
+    auto match = [&](SysSignature have) {
+        if (!bsf) { have.nr = want.nr; have.odd_r = want.odd_r; }
+        return same_signature(want, have);
+    };
+    if (match(signature_of<SysPal>())) {
+        if (pald) {
+            if (depth > 1) { err = "PAL-D front end is built with one line of history"; return false; }
+            pass.fn = launch_demod<SysPal, FRONT_PALD, false, 1>; pass.depth = 1; pass.name = "demod_kernel<pal, pal-d front, depth 1>";
+        } else if (bsf) {
+            if (depth > 0) { err = "band-stop luma is built for plain decoders only"; return false; }
+            pass.fn = launch_demod<SysPal, FRONT_QAM, true, 0>; pass.depth = 0; pass.name = "demod_kernel<pal, qam front + band-stop, depth 0>";
+        } else {
+            pass.fn = launch_demod<SysPal, FRONT_QAM, false, 2>; pass.depth = 2; pass.name = "demod_kernel<pal, qam front, depth 2>";
+        }
+        return make_pass<SysPal>(d, pald, bsf, tb, pass, err);
+    }
+    if (!pald && match(signature_of<SysNtsc>())) {
+        if (bsf) {
+            if (depth > 0) { err = "band-stop luma is built for plain decoders only"; return false; }
+            pass.fn = launch_demod<SysNtsc, FRONT_QAM, true, 0>; pass.depth = 0; pass.name = "demod_kernel<ntsc, qam front + band-stop, depth 0>";
+        } else if (depth <= 1) {
+            pass.fn = launch_demod<SysNtsc, FRONT_QAM, false, 1>; pass.depth = 1; pass.name = "demod_kernel<ntsc, qam front, depth 1>";
+        } else {
+            pass.fn = launch_demod<SysNtsc, FRONT_QAM, false, 2>; pass.depth = 2; pass.name = "demod_kernel<ntsc, qam front, depth 2>";
+        }
+        return make_pass<SysNtsc>(d, pald, bsf, tb, pass, err);
+    }
+    char buf[256];
+    snprintf(buf, sizeof buf,
+             "no kernel instance for this filter set (sections extract/remove/detect/pre = %d/%d/%d/%d, shift parities %d/%d/%d, "
+             "pre shift %d); built: PAL-BG and NTSC-M at 13.5 MHz",
+             want.ne, want.nr, want.nl, want.np, want.odd_e, want.odd_l, want.odd_r, want.sp);
+    err = buf;
+    return false;
+}
+
+int run_pass(const cm_plan *p, const Pass &pass, Geom g, hipStream_t stream) {
+    g.lanes = pass.lanes;
+    g.carrier = p->carrier;
+    g.cycle = pass.cycle;
+    g.n_lines = pass.n_lines;
+    g.luma_prev_bits = pass.luma_prev_bits;
+    long long per_block = g.sparse ? 64 : 64 - pass.depth;
+    long long blocks = (g.total_calls + per_block - 1) / per_block;
+    if (blocks <= 0) return CM_OK;
+    if (blocks > 0x7fffffffLL) return fail(CM_ERR_INVALID, "batch too large for one launch");
+    return pass.fn(g, pass.k.data(), (int)blocks, stream);
+}
+
+int check_lines(const cm_plan *p, const Pass &pass, int max_line) {
+    if (max_line >= pass.n_lines) return fail(CM_ERR_INVALID, "line number beyond the plan's phase tables");
+    (void)p;
+    return CM_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *cm_last_error(void) { return g_error.c_str(); }
+int cm_abi_version(void) { return CM_ABI_VERSION; }
+
+int cm_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int cm_plan_create(const cm_plan_desc *desc, cm_plan **out) {
+    if (!desc || !out) return fail(CM_ERR_INVALID, "null argument");
+    *out = nullptr;
+    if (desc->abi_version != CM_ABI_VERSION) return fail(CM_ERR_INVALID, "descriptor ABI version mismatch");
+    if (desc->width < 4 || desc->width % 4 != 0)
+        return fail(CM_ERR_UNSUPPORTED, "width must be a positive multiple of 4 (rows are moved as 16-byte vectors)");
+    if (desc->height < 1) return fail(CM_ERR_INVALID, "height must be positive");
+    if (desc->pipeline != CM_PIPE_QAM && desc->pipeline != CM_PIPE_PAL_D)
+        return fail(CM_ERR_UNSUPPORTED, "pipeline not built");
+    if (desc->depth < 0 || desc->depth > 2) return fail(CM_ERR_INVALID, "depth must be 0..2");
+    if (!desc->demod_main.table || desc->demod_main.frame_cycle < 1 || desc->demod_main.n_lines < 1)
+        return fail(CM_ERR_INVALID, "demod_main table missing");
+    if (desc->first_is_plain && (!desc->demod_first.table || desc->demod_first.n_lines != desc->demod_main.n_lines))
+        return fail(CM_ERR_INVALID, "demod_first table missing or of different size");
+    if (cm_device_count() < 1) return fail(CM_ERR_NO_DEVICE, "no HIP device available (this library has no CPU path)");
+    cm_plan *p = new cm_plan;
+    p->desc = *desc;
+    p->desc.demod_main.table = p->desc.demod_first.table = p->desc.mod_main.table = nullptr;  // not retained
+    if (hipGetDevice(&p->device) != hipSuccess) {
+        delete p;
+        return fail(CM_ERR_NO_DEVICE, "hipGetDevice failed");
+    }
+    std::string err;
+    std::vector<float> car = build_carrier<float>(desc->carrier_phase_step, desc->width);
+    if (hipMalloc((void **)&p->carrier, car.size() * sizeof(float)) != hipSuccess ||
+        hipMemcpy(p->carrier, car.data(), car.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) {
+        cm_plan_destroy(p);
+        return fail(CM_ERR_NO_DEVICE, "device allocation / upload of the carrier table failed");
+    }
+    const bool pald = desc->pipeline == CM_PIPE_PAL_D;
+    if (!select_pass(*desc, pald, desc->main_luma_bandstop != 0, desc->depth, desc->demod_main, p->main, err)) {
+        cm_plan_destroy(p);
+        return fail(CM_ERR_UNSUPPORTED, err);
+    }
+    if (desc->first_is_plain && !select_pass(*desc, false, true, 0, desc->demod_first, p->first, err)) {
+        cm_plan_destroy(p);
+        return fail(CM_ERR_UNSUPPORTED, err);
+    }
+    *out = p;
+    return CM_OK;
+}
+
+void cm_plan_destroy(cm_plan *p) {
+    if (!p) return;
+    if (p->carrier) (void)hipFree(p->carrier);
+    if (p->main.lanes) (void)hipFree(p->main.lanes);
+    if (p->first.lanes) (void)hipFree(p->first.lanes);
+    delete p;
+}
+
+int cm_demodulate_frames(const cm_plan *p, const float *composite, float *rgb, int64_t n_frames, int64_t first_frame,
+                         void *stream) {
+    if (!p || !composite || !rgb) return fail(CM_ERR_INVALID, "null argument");
+    if (n_frames < 0 || first_frame < 0) return fail(CM_ERR_INVALID, "negative frame count / number");
+    if (n_frames == 0) return CM_OK;
+    const cm_plan_desc &d = p->desc;
+    const int W = d.width, H = d.height, D = d.demodulation_delay;
+    Geom g;
+    std::memset(&g, 0, sizeof g);
+    g.in = composite;
+    g.out = rgb;
+    g.W = W;
+    g.H = H;
+    g.in_frame_stride = (long long)W * H;
+    g.out_plane_stride = (long long)W * H;
+    g.out_frame_stride = 3LL * W * H;
+    g.out_row_stride = W;
+    g.first_frame = (int)(first_frame % (int64_t)p->main.cycle);
+    const int rows0 = (H + 1) / 2, rows1 = H / 2;
+    g.calls_run0 = rows0 + D;
+    const int calls_run1 = rows1 > 0 ? rows1 + D : 0;
+    g.calls_per_frame = g.calls_run0 + calls_run1;
+    g.runs_per_frame = rows1 > 0 ? 2 : 1;
+    g.first_line[0] = 0;
+    g.first_line[1] = 1;
+    g.delay = D;
+    g.total_calls = n_frames * g.calls_per_frame;
+    g.skip_first = d.first_is_plain;
+    int rc = check_lines(p, p->main, H - 1 + 2 * D);
+    if (rc) return rc;
+    rc = run_pass(p, p->main, g, (hipStream_t)stream);
+    if (rc) return rc;
+    if (d.first_is_plain) {
+        Geom s = g;
+        s.sparse = 1;
+        s.skip_first = 0;
+        s.total_calls = n_frames * g.runs_per_frame;
+        s.first_frame = (int)(first_frame % (int64_t)p->first.cycle);
+        rc = run_pass(p, p->first, s, (hipStream_t)stream);
+    }
+    return rc;
+}
+
+int cm_demodulate_run(const cm_plan *p, const float *composite, float *rgb, int32_t n_calls, int32_t frame,
+                      int32_t first_line, int32_t k0, void *stream) {
+    if (!p || !composite || !rgb) return fail(CM_ERR_INVALID, "null argument");
+    if (n_calls < 0 || frame < 0 || k0 < 0) return fail(CM_ERR_INVALID, "negative count / frame / k0");
+    if (n_calls == 0) return CM_OK;
+    if (first_line < 0) return fail(CM_ERR_INVALID, "negative line number");
+    const cm_plan_desc &d = p->desc;
+    Geom g;
+    std::memset(&g, 0, sizeof g);
+    g.in = composite;
+    g.out = rgb;
+    g.W = d.width;
+    g.H = n_calls;
+    g.in_frame_stride = 0;
+    g.out_plane_stride = d.width;
+    g.out_frame_stride = 0;
+    g.rows_mode = 1;
+    g.first_frame = frame % p->main.cycle;
+    g.calls_run0 = n_calls;
+    g.calls_per_frame = n_calls;
+    g.runs_per_frame = 1;
+    g.first_line[0] = g.first_line[1] = first_line;
+    g.k0 = k0;
+    g.total_calls = n_calls;
+    g.skip_first = d.first_is_plain;
+    int rc = check_lines(p, p->main, first_line + 2 * (n_calls - 1));
+    if (rc) return rc;
+    // rows mode writes [call][plane][W]
+    g.out_plane_stride = d.width;
+    g.out_row_stride = 3LL * d.width;
+    rc = run_pass(p, p->main, g, (hipStream_t)stream);
+    if (rc) return rc;
+    if (d.first_is_plain && k0 == 0) {
+        Geom s = g;
+        s.sparse = 1;
+        s.skip_first = 0;
+        s.total_calls = 1;
+        s.first_frame = frame % p->first.cycle;
+        rc = run_pass(p, p->first, s, (hipStream_t)stream);
+    }
+    return rc;
+}
+
+int cm_modulate_frames(const cm_plan *, const float *, float *, int64_t, int64_t, void *) {
+    return fail(CM_ERR_UNSUPPORTED, "modulators are not built yet");
+}
+int cm_modulate_run(const cm_plan *, const float *, float *, int32_t, int32_t, int32_t, int32_t, void *) {
+    return fail(CM_ERR_UNSUPPORTED, "modulators are not built yet");
+}
+
+int cm_plan_describe(const cm_plan *p, char *buf, int32_t buf_len) {
+    if (!p || !buf || buf_len < 1) return 0;
+    int n = snprintf(buf, buf_len, "main: %s; first-line pass: %s; lanes per workgroup 64, halo %d", p->main.name.c_str(),
+                     p->first.fn ? p->first.name.c_str() : "none", p->main.depth);
+    return n < buf_len ? n : buf_len - 1;
+}
+
+}  // extern "C"

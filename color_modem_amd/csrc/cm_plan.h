@@ -17,16 +17,15 @@ namespace cm {
 enum SectionForm { FORM_BP, FORM_SYM, FORM_GEN };
 
 // Normalise scipy sections to b0 = 1, check the numerator form, return the product of the b0's.
-template <typename T, int MAXSEC>
-bool convert_sos(const cm_iir_desc &d, SectionForm form, SosK<T, MAXSEC> &out, double &gain, std::string &err,
+template <typename T, int NSEC>
+bool convert_sos(const cm_iir_desc &d, SectionForm form, SosK<T, NSEC> &out, double &gain, std::string &err,
                  const char *name) {
-    if (d.n_sections < 0 || d.n_sections > MAXSEC || d.n_sections > CM_MAX_SECTIONS) {
-        err = std::string(name) + ": section count not supported by this build";
+    if (d.n_sections != NSEC) {
+        err = std::string(name) + ": section count does not match the kernel instance";
         return false;
     }
     gain = 1.0;
-    out.n = d.n_sections;
-    for (int j = 0; j < MAXSEC; ++j) out.na1[j] = out.na2[j] = out.b1[j] = out.b2[j] = T(0);
+    for (int j = 0; j < NSEC; ++j) out.na1[j] = out.na2[j] = out.b1[j] = out.b2[j] = T(0);
     for (int j = 0; j < d.n_sections; ++j) {
         const double *s = d.sos[j];
         if (s[0] == 0.0 || std::fabs(s[3] - 1.0) > 1e-12) {
@@ -60,17 +59,26 @@ struct DemodScales {
 };
 
 // Build the uniform block of the QAM-family demodulators.  `pald`: front LPF = pald_lp.
-template <typename T>
-bool build_demod_k(const cm_plan_desc &d, bool pald, DemodK<T> &k, DemodScales &sc, std::string &err) {
+template <typename T, class S>
+bool build_demod_k(const cm_plan_desc &d, bool pald, bool need_bsf, DemodK<T, S> &k, DemodScales &sc, std::string &err) {
     k.width = d.width;
     for (int i = 0; i < 10; ++i) k.taps.c[i] = T(2.0 * d.resample_fir[2 * i + 1]);
     k.taps.c0 = T(2.0 * d.resample_fir[20]);
-    double g_e, g_r, g_l, g_p;
-    if (!convert_sos<T, kMaxSecE>(d.extract2x, FORM_BP, k.ext, g_e, err, "extract2x")) return false;
-    if (!convert_sos<T, kMaxSecR>(d.remove2x, FORM_SYM, k.rem, g_r, err, "remove2x")) return false;
+    double g_e, g_r = 0.0, g_l, g_p;
+    if (!convert_sos<T, S::NE>(d.extract2x, FORM_BP, k.ext, g_e, err, "extract2x")) return false;
+    if (need_bsf) {
+        if (!convert_sos<T, S::NR>(d.remove2x, FORM_SYM, k.rem, g_r, err, "remove2x")) return false;
+    } else {
+        for (int j = 0; j < S::NR; ++j) k.rem.na1[j] = k.rem.na2[j] = k.rem.b1[j] = k.rem.b2[j] = T(0);
+    }
     const cm_iir_desc &lp = pald ? d.pald_lp : d.demod_lp;
-    if (!convert_sos<T, kMaxSecL>(lp, FORM_SYM, k.lpf, g_l, err, pald ? "pald_lp" : "demod_lp")) return false;
-    if (!convert_sos<T, kMaxSecP>(d.precorrect, FORM_GEN, k.pre, g_p, err, "precorrect")) return false;
+    if (!convert_sos<T, S::NL>(lp, FORM_SYM, k.lpf, g_l, err, pald ? "pald_lp" : "demod_lp")) return false;
+    if (!convert_sos<T, S::NP>(d.precorrect, FORM_GEN, k.pre, g_p, err, "precorrect")) return false;
+    if ((d.extract2x.shift & 1) != (S::ODD_E ? 1 : 0) || (lp.shift & 1) != (S::ODD_L ? 1 : 0) ||
+        (need_bsf && (d.remove2x.shift & 1) != (S::ODD_R ? 1 : 0)) || d.precorrect.shift != S::SP) {
+        err = "filter shifts do not match the kernel instance";
+        return false;
+    }
     if (d.extract2x.shift < 0 || lp.shift < 0 || d.remove2x.shift < 0 || d.precorrect.shift < 0) {
         err = "negative FilterFunction shift is not used on this path";
         return false;
@@ -78,9 +86,6 @@ bool build_demod_k(const cm_plan_desc &d, bool pald, DemodK<T> &k, DemodScales &
     k.q_e = pair_delay(d.extract2x.shift);
     k.q_l = pair_delay(lp.shift);
     k.q_r = pair_delay(d.remove2x.shift);
-    k.pad_e = d.extract2x.shift;
-    k.pad_l = lp.shift;
-    k.pad_r = d.remove2x.shift;
     k.s_p = d.precorrect.shift;
     // every decimator output is doubled (taps are 2h)
     if (pald)
@@ -122,6 +127,29 @@ LaneK<T> convert_lane(const double *e, const DemodScales &sc) {
         l.cv[j][1] = T(e[11 + 2 * j] * sc.base);
     }
     return l;
+}
+
+// ---- the filter-set shapes this build carries ------------------------------------------------
+//                 NE NR NL NP  oddE   oddL   oddR  SP
+typedef Sys<2, 2, 3, 1, false, false, false, 2> SysPal;   // PAL-BG @ 13.5 MHz: shifts 4 / 4 (6 for PAL-D) / 2 / 2
+typedef Sys<3, 3, 3, 1, false, true, false, 2> SysNtsc;   // NTSC-M @ 13.5 MHz: shifts 6 / 5 / 4 / 2
+
+struct SysSignature {
+    int ne, nr, nl, np, odd_e, odd_l, odd_r, sp;
+};
+template <class S>
+inline SysSignature signature_of() {
+    return SysSignature{S::NE, S::NR, S::NL, S::NP, S::ODD_E, S::ODD_L, S::ODD_R, S::SP};
+}
+// signature a plan asks for; pald: front low-pass is pald_lp
+inline SysSignature signature_wanted(const cm_plan_desc &d, bool pald) {
+    const cm_iir_desc &lp = pald ? d.pald_lp : d.demod_lp;
+    return SysSignature{d.extract2x.n_sections, d.remove2x.n_sections, lp.n_sections, d.precorrect.n_sections,
+                        d.extract2x.shift & 1, lp.shift & 1, d.remove2x.shift & 1, d.precorrect.shift};
+}
+inline bool same_signature(const SysSignature &a, const SysSignature &b) {
+    return a.ne == b.ne && a.nr == b.nr && a.nl == b.nl && a.np == b.np && a.odd_e == b.odd_e && a.odd_l == b.odd_l &&
+           a.odd_r == b.odd_r && a.sp == b.sp;
 }
 
 }  // namespace cm

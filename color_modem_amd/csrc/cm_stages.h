@@ -35,10 +35,15 @@
 
 namespace cm {
 
-constexpr int kMaxSecE = 4;  // extract band-pass: up to order 8
-constexpr int kMaxSecR = 4;  // remove band-stop
-constexpr int kMaxSecL = 3;  // detector low-pass: order 6 (ref qam.py:18, pal.py:67, secam.py:131)
-constexpr int kMaxSecP = 2;  // pre-correction low-pass at 1x rate
+// Compile-time shape of one colour system's filter set: section counts of the extract band-pass,
+// remove band-stop, detector low-pass and pre-correction low-pass, the parity of the
+// FilterFunction shifts of the three 2x-rate filters (odd: output pairs straddle input pairs)
+// and the shift of the pre-correction filter (a register-window delay in the kernels).
+template <int NE_, int NR_, int NL_, int NP_, bool ODD_E_, bool ODD_L_, bool ODD_R_, int SP_>
+struct Sys {
+    static constexpr int NE = NE_, NR = NR_, NL = NL_, NP = NP_, SP = SP_;
+    static constexpr bool ODD_E = ODD_E_, ODD_L = ODD_L_, ODD_R = ODD_R_;
+};
 
 // ---- arithmetic helpers -------------------------------------------------------------------
 // fma3: d = c * x + acc with d allowed to differ from acc.  On the device this must be the
@@ -65,11 +70,10 @@ struct Taps {  // 2*h[2i+1], i = 0..9 (h symmetric: tap 19-i equals tap i) and 2
     T c0;
 };
 
-template <typename T, int MAXSEC>
-struct SosK {  // sections normalised to b0 = 1; gains are folded elsewhere by the host
-    int32_t n;
-    T na1[MAXSEC], na2[MAXSEC];  // NEGATED denominator coefficients
-    T b1[MAXSEC], b2[MAXSEC];    // used by the SYM (b1) and GEN (b1, b2) forms
+template <typename T, int NSEC>
+struct SosK {  // NSEC sections normalised to b0 = 1; gains are folded elsewhere by the host
+    T na1[NSEC], na2[NSEC];  // NEGATED denominator coefficients
+    T b1[NSEC], b2[NSEC];    // used by the SYM (b1) and GEN (b1, b2) forms
 };
 
 // ---- transposed-form half-band FIR --------------------------------------------------------
@@ -113,12 +117,10 @@ template <typename T, int MAXSEC>
 CM_HD T iir_bp(IirState<T, MAXSEC> &st, const SosK<T, MAXSEC> &k, T x) {
 #pragma unroll
     for (int j = 0; j < MAXSEC; ++j) {
-        if (j < k.n) {
-            T y = x + st.s1[j];
-            st.s1[j] = fma3(k.na1[j], y, st.s2[j]);
-            st.s2[j] = fmaf_(k.na2[j], y, -x);
-            x = y;
-        }
+        T y = x + st.s1[j];
+        st.s1[j] = fma3(k.na1[j], y, st.s2[j]);
+        st.s2[j] = fmaf_(k.na2[j], y, -x);
+        x = y;
     }
     return x;
 }
@@ -127,13 +129,11 @@ template <typename T, int MAXSEC>
 CM_HD T iir_sym(IirState<T, MAXSEC> &st, const SosK<T, MAXSEC> &k, T x) {
 #pragma unroll
     for (int j = 0; j < MAXSEC; ++j) {
-        if (j < k.n) {
-            T y = x + st.s1[j];
-            T t = fma3(k.b1[j], x, st.s2[j]);
-            st.s1[j] = fmaf_(k.na1[j], y, t);
-            st.s2[j] = fmaf_(k.na2[j], y, x);
-            x = y;
-        }
+        T y = x + st.s1[j];
+        T t = fma3(k.b1[j], x, st.s2[j]);
+        st.s1[j] = fmaf_(k.na1[j], y, t);
+        st.s2[j] = fmaf_(k.na2[j], y, x);
+        x = y;
     }
     return x;
 }
@@ -142,13 +142,11 @@ template <typename T, int MAXSEC>
 CM_HD T iir_gen(IirState<T, MAXSEC> &st, const SosK<T, MAXSEC> &k, T x) {
 #pragma unroll
     for (int j = 0; j < MAXSEC; ++j) {
-        if (j < k.n) {
-            T y = x + st.s1[j];
-            T t = fma3(k.b1[j], x, st.s2[j]);
-            st.s1[j] = fmaf_(k.na1[j], y, t);
-            st.s2[j] = fmaf_(k.na2[j], y, k.b2[j] * x);
-            x = y;
-        }
+        T y = x + st.s1[j];
+        T t = fma3(k.b1[j], x, st.s2[j]);
+        st.s1[j] = fmaf_(k.na1[j], y, t);
+        st.s2[j] = fmaf_(k.na2[j], y, k.b2[j] * x);
+        x = y;
     }
     return x;
 }
@@ -170,16 +168,15 @@ struct Pair {
 };
 
 // ---- uniform parameters of the QAM-family demodulators --------------------------------------
-template <typename T>
+template <typename T, class S>
 struct DemodK {
     int32_t width;       // W
     int32_t q_e, q_l, q_r, s_p;  // pair delays of the 2x-rate filters (ceil(shift / 2)), pre shift
-    int32_t pad_e, pad_l, pad_r; // FilterFunction shifts (tail padding length in 2x samples)
     Taps<T> taps;
-    SosK<T, kMaxSecE> ext;   // ref qam.py:17 band-pass
-    SosK<T, kMaxSecR> rem;   // ref qam.py:17 band-stop
-    SosK<T, kMaxSecL> lpf;   // ref qam.py:18 (QAM front) or pal.py:67-69 (PAL-D front)
-    SosK<T, kMaxSecP> pre;   // ref qam.py:16
+    SosK<T, S::NE> ext;   // ref qam.py:17 band-pass
+    SosK<T, S::NR> rem;   // ref qam.py:17 band-stop
+    SosK<T, S::NL> lpf;   // ref qam.py:18 (QAM front) or pal.py:67-69 (PAL-D front)
+    SosK<T, S::NP> pre;   // ref qam.py:16
     T luma_gain;             // gain of the band-stop path (sections * 1/2 from the decimator)
     T m[3][3];               // (r, g, b) = m * (y, u, v)
 };
@@ -198,11 +195,13 @@ struct DemodK {
 //   n5 = n4 - q_l      pair Q(n5) = LPF output (two paths)
 //   n6 = n5 - 9        (Ps, Pc)[n6]
 // =============================================================================================
-template <typename T>
+template <typename T, class S>
 struct PalDFront {
+    static_assert(!S::ODD_E && !S::ODD_L, "the PAL-D front end is built for even filter shifts");
+    typedef DemodK<T, S> K;
     HalfbandChain<T> up_x, dn_e, up_e, dn_s, dn_c;
-    IirState<T, kMaxSecE> bpf;
-    IirState<T, kMaxSecL> lpf_s, lpf_c;
+    IirState<T, S::NE> bpf;
+    IirState<T, S::NL> lpf_s, lpf_c;
     T a_last, ps_last, pc_last;
 
     CM_HD void reset() {
@@ -210,14 +209,13 @@ struct PalDFront {
         bpf.reset(); lpf_s.reset(); lpf_c.reset();
         a_last = ps_last = pc_last = T(0);
     }
-    CM_HD static int latency(const DemodK<T> &k) { return 10 + k.q_e + 9 + 10 + k.q_l + 9; }
+    CM_HD static int latency(const K &k) { return 10 + k.q_e + 9 + 10 + k.q_l + 9; }
 
     // x_now = x[t] (0 beyond the row), x_d10 = x[t - 10], e_d10 = e[n3 - 10] (from the caller's
     // delay window), car = {C[2 n4], S[2 n4], C[2 n4 + 1], S[2 n4 + 1]} (cos/sin of m * cps).
     // Returns e[n3] through e_out (caller stores it in its window) and the base pair.
     template <bool EDGE>
-    CM_HD Pair<T> step(const DemodK<T> &k, const LaneK<T> &lk, int t, T x_now, T x_d10, T e_d10, const T car[4],
-                       T &e_out) {
+    CM_HD Pair<T> step(const K &k, const LaneK<T> &lk, int t, T x_now, T x_d10, T e_d10, const T car[4], T &e_out) {
         const int W = k.width;
         const int n1 = t - 10, n2 = n1 - k.q_e, n3 = n2 - 9, n4 = n3 - 10, n5 = n4 - k.q_l;
         // --- up2(x)
@@ -274,12 +272,14 @@ struct PalDFront {
 //   n1 = t - 10 ; n2 = n1 - q_e ; n5 = n2 - q_l ; n6 = n5 - 9 ; luma: nr = n1 - q_r, nl = nr - 9
 // ODD_x: the corresponding FilterFunction shift is odd, i.e. output pairs straddle input pairs.
 // =============================================================================================
-template <typename T, bool ODD_E, bool ODD_L, bool ODD_R, bool WITH_BSF>
+template <typename T, class S, bool WITH_BSF>
 struct QamFront {
+    typedef DemodK<T, S> K;
+    static constexpr bool ODD_E = S::ODD_E, ODD_L = S::ODD_L, ODD_R = S::ODD_R;
     HalfbandChain<T> up_x, dn_s, dn_c, dn_y;
-    IirState<T, kMaxSecE> bpf;
-    IirState<T, kMaxSecL> lpf_s, lpf_c;
-    IirState<T, kMaxSecR> bsf;
+    IirState<T, S::NE> bpf;
+    IirState<T, S::NL> lpf_s, lpf_c;
+    IirState<T, S::NR> bsf;
     T a_last, ps_last, pc_last;
     T hold_b, hold_s, hold_c, hold_y;  // previous odd outputs for odd shifts
 
@@ -288,12 +288,12 @@ struct QamFront {
         bpf.reset(); lpf_s.reset(); lpf_c.reset(); bsf.reset();
         a_last = ps_last = pc_last = hold_b = hold_s = hold_c = hold_y = T(0);
     }
-    CM_HD static int latency(const DemodK<T> &k) { return 10 + k.q_e + k.q_l + 9; }
-    CM_HD static int luma_latency(const DemodK<T> &k) { return 10 + k.q_r + 9; }
+    CM_HD static int latency(const K &k) { return 10 + k.q_e + k.q_l + 9; }
+    CM_HD static int luma_latency(const K &k) { return 10 + k.q_r + 9; }
 
     // car = {C[2 n2], S[2 n2], C[2 n2 + 1], S[2 n2 + 1]}
     template <bool EDGE>
-    CM_HD Pair<T> step(const DemodK<T> &k, const LaneK<T> &lk, int t, T x_now, T x_d10, const T car[4], T &luma_out) {
+    CM_HD Pair<T> step(const K &k, const LaneK<T> &lk, int t, T x_now, T x_d10, const T car[4], T &luma_out) {
         const int W = k.width;
         const int n1 = t - 10, n2 = n1 - k.q_e, n5 = n2 - k.q_l;
         T a_odd = up_x.push(k.taps, x_now);
@@ -365,9 +365,10 @@ struct Rgb {
     T r, g, b;
 };
 
-template <typename T, int DEPTH>
+template <typename T, class S, int DEPTH>
 struct DemodBack {
-    IirState<T, kMaxSecP> pre_u, pre_v;
+    typedef DemodK<T, S> K;
+    IirState<T, S::NP> pre_u, pre_v;
     T u_last, v_last;
     CM_HD void reset() {
         pre_u.reset(); pre_v.reset();
@@ -389,7 +390,7 @@ struct DemodBack {
     // u, v are the combined chroma at n6; u_d, v_d the same signals at n7 = n6 - s_p;
     // y_src is the luma source at n7; car = {C[2 n7], S[2 n7]}.
     template <bool EDGE>
-    CM_HD Rgb<T> step(const DemodK<T> &k, const LaneK<T> &lk, int n6, T u, T v, T u_d, T v_d, T y_src, const T car[2]) {
+    CM_HD Rgb<T> step(const K &k, const LaneK<T> &lk, int n6, T u, T v, T u_d, T v_d, T y_src, const T car[2]) {
         const int W = k.width;
         T wu = T(0), wv = T(0);
         if (!EDGE || (n6 >= 0 && n6 < W + k.s_p)) {

@@ -1,0 +1,102 @@
+# -*- coding: utf-8 -*-
+"""Device engine: owns one plan (cm_plan) per modem stack and moves rows / frames through it.
+
+torch (ROCm build) is used only as the owner of device memory and of the HIP stream; all
+arithmetic happens in libcolor_modem_hip.so.
+"""
+
+import ctypes
+
+import numpy
+
+from color_modem_amd import _native, plan
+
+
+def _torch():
+    import torch
+    if not torch.cuda.is_available():
+        raise _native.NativeError('no HIP device visible to torch: color_modem_amd runs on the GPU only')
+    return torch
+
+
+class Engine(object):
+    def __init__(self, modem):
+        self.built = plan.build_plan(modem)
+        d = self.built.desc
+        self.width, self.height = d.width, d.height
+        self.demod_depth = d.depth
+        self.mod_depth = 1 if d.modulation_delay else 0
+        self.demodulation_delay = d.demodulation_delay
+        self.modulation_delay = d.modulation_delay
+        self._plan = ctypes.c_void_p()
+        _torch()
+        _native.check(_native.lib().cm_plan_create(ctypes.byref(d), ctypes.byref(self._plan)))
+
+    def __del__(self):
+        p = getattr(self, '_plan', None)
+        if p and _native is not None and getattr(_native, '_lib', None) is not None:
+            _native._lib.cm_plan_destroy(p)
+            self._plan = None
+
+    def describe(self):
+        buf = ctypes.create_string_buffer(512)
+        _native.lib().cm_plan_describe(self._plan, buf, 512)
+        return buf.value.decode()
+
+    # ---- frames -------------------------------------------------------------------------------
+    def _as_device(self, x, shape_tail):
+        torch = _torch()
+        was_numpy = isinstance(x, numpy.ndarray)
+        t = torch.from_numpy(numpy.ascontiguousarray(x, dtype=numpy.float32)) if was_numpy else x
+        if t.dtype != torch.float32:
+            raise ValueError('float32 expected')
+        if tuple(t.shape[1:]) != tuple(shape_tail):
+            raise ValueError('expected shape [frames, %s], got %s' % (', '.join(map(str, shape_tail)), tuple(t.shape)))
+        if not t.is_cuda:
+            t = t.cuda()
+        return t.contiguous(), was_numpy
+
+    def demodulate_frames(self, composite, first_frame=0, out=None):
+        """composite [F, H, W] float32 (numpy or cuda tensor) -> rgb [F, 3, H, W] of the same kind."""
+        torch = _torch()
+        comp, was_numpy = self._as_device(composite, (self.height, self.width))
+        n = comp.shape[0]
+        if out is None:
+            out = torch.empty((n, 3, self.height, self.width), dtype=torch.float32, device=comp.device)
+        stream = torch.cuda.current_stream(comp.device).cuda_stream
+        _native.check(_native.lib().cm_demodulate_frames(self._plan, comp.data_ptr(), out.data_ptr(), n,
+                                                         int(first_frame), stream))
+        return out.cpu().numpy() if was_numpy else out
+
+    def modulate_frames(self, rgb, first_frame=0, out=None):
+        torch = _torch()
+        x, was_numpy = self._as_device(rgb, (3, self.height, self.width))
+        n = x.shape[0]
+        if out is None:
+            out = torch.empty((n, self.height, self.width), dtype=torch.float32, device=x.device)
+        stream = torch.cuda.current_stream(x.device).cuda_stream
+        _native.check(_native.lib().cm_modulate_frames(self._plan, x.data_ptr(), out.data_ptr(), n,
+                                                       int(first_frame), stream))
+        return out.cpu().numpy() if was_numpy else out
+
+    # ---- runs (the per-row protocol) ----------------------------------------------------------
+    def demodulate_run(self, rows, frame, first_line, k0):
+        """rows [n, W] float32 numpy -> [n, 3, W] float32 numpy: what calls k0 .. k0+n-1 of a run return."""
+        torch = _torch()
+        x = torch.from_numpy(numpy.ascontiguousarray(rows, dtype=numpy.float32)).cuda()
+        n = x.shape[0]
+        out = torch.empty((n, 3, self.width), dtype=torch.float32, device=x.device)
+        stream = torch.cuda.current_stream(x.device).cuda_stream
+        _native.check(_native.lib().cm_demodulate_run(self._plan, x.data_ptr(), out.data_ptr(), n, int(frame),
+                                                      int(first_line), int(k0), stream))
+        return out.cpu().numpy()
+
+    def modulate_run(self, rows, frame, first_line, k0):
+        torch = _torch()
+        x = torch.from_numpy(numpy.ascontiguousarray(rows, dtype=numpy.float32)).cuda()
+        n = x.shape[0]
+        out = torch.empty((n, self.width), dtype=torch.float32, device=x.device)
+        stream = torch.cuda.current_stream(x.device).cuda_stream
+        _native.check(_native.lib().cm_modulate_run(self._plan, x.data_ptr(), out.data_ptr(), n, int(frame),
+                                                    int(first_line), int(k0), stream))
+        return out.cpu().numpy()

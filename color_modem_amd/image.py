@@ -1,0 +1,67 @@
+# -*- coding: utf-8 -*-
+"""Frame adapter (API mirror of /root/reference/color_modem/image.py:11-84) plus batch entry points.
+
+``ImageModem(modem).modulate(img, frame=0)`` / ``.demodulate(img, frame=0)`` take and return one
+PIL image exactly like the reference.  ``demodulate_frames`` / ``modulate_frames`` are the batch
+counterparts the GPU path sits behind: float32 planar frames in, float32 planar frames out,
+equal to looping the reference's row schedule (image.py:47-55, 75-83) over
+``frame = first_frame ..`` with a fresh modem per frame.
+"""
+
+import numpy
+
+from color_modem_amd import engine as _engine
+
+
+def _as_bytes(array):
+    # same clamp + round-half-even as ref image.py:7-8
+    return numpy.uint8(numpy.rint(255.0 * numpy.clip(array, 0.0, 1.0)))
+
+
+class ImageModem(object):
+    def __init__(self, modem):
+        self._modem = modem
+        self._engine_obj = None
+
+    def _engine(self):
+        if self._engine_obj is None:
+            self._engine_obj = _engine.Engine(self._modem)
+        return self._engine_obj
+
+    @staticmethod
+    def encode_composite_level(value):
+        return 0.6 * value + 0.2
+
+    @staticmethod
+    def decode_composite_level(value):
+        return (5.0 * value - 1.0) / 3.0
+
+    # ---- batch API ------------------------------------------------------------------------------
+    def demodulate_frames(self, composite, first_frame=0):
+        """composite [F, H, W] float32 -> rgb [F, 3, H, W] float32 (numpy in -> numpy out, cuda tensor in -> cuda tensor out)."""
+        return self._engine().demodulate_frames(composite, first_frame)
+
+    def modulate_frames(self, rgb, first_frame=0):
+        """rgb [F, 3, H, W] float32 -> composite [F, H, W] float32."""
+        return self._engine().modulate_frames(rgb, first_frame)
+
+    # ---- PIL API (one image = one frame) ---------------------------------------------------------
+    def modulate(self, img, frame=0):
+        from PIL import Image
+        if img.mode != 'RGB':
+            img = img.convert('RGB')
+        rgb8 = numpy.frombuffer(img.tobytes(), dtype=numpy.uint8).reshape(img.height, img.width, 3)
+        rgb = (rgb8.astype(numpy.float64) / 255.0).astype(numpy.float32).transpose(2, 0, 1)[None]
+        comp = self.modulate_frames(numpy.ascontiguousarray(rgb), frame)[0]
+        data = _as_bytes(self.encode_composite_level(comp.astype(numpy.float64)))
+        return Image.frombytes('L', (comp.shape[1], comp.shape[0]), data.tobytes())
+
+    def demodulate(self, img, frame=0):
+        from PIL import Image
+        if img.mode != 'L':
+            img = img.convert('L')
+        comp8 = numpy.frombuffer(img.tobytes(), dtype=numpy.uint8).reshape(img.height, img.width)
+        comp = self.decode_composite_level(comp8.astype(numpy.float64) / 255.0).astype(numpy.float32)[None]
+        rgb = self.demodulate_frames(numpy.ascontiguousarray(comp), frame)[0]
+        data = _as_bytes(rgb.astype(numpy.float64)).transpose(1, 2, 0)
+        return Image.frombytes('RGB', (rgb.shape[2], rgb.shape[1]), numpy.ascontiguousarray(data).tobytes())

@@ -3,6 +3,7 @@
 // T = float: predicts the float32 rounding error of the device kernels).  Never used by the
 // product path.
 #include <cstring>
+#include <type_traits>
 #include <string>
 #include <vector>
 
@@ -26,12 +27,12 @@ static const double *lane_entry(const cm_lane_table &tb, int frame, int regime, 
 }
 
 // PIPE: 0 = QAM front, 1 = PAL-D front.  bsf: luma from the band-stop path.
-template <typename T, bool ODD_E, bool ODD_L, bool ODD_R>
+template <typename T, class S>
 static int run_generic(const cm_plan_desc &d, bool pald, bool bsf, const cm_lane_table &tb, const std::vector<int> &calls,
                        const double *comp, double *rgb, int n_calls, int frame, int first_line, int k0, bool mid_fast) {
-    DemodK<T> k;
+    DemodK<T, S> k;
     DemodScales sc;
-    if (!build_demod_k<T>(d, pald, k, sc, g_err)) return CM_ERR_UNSUPPORTED;
+    if (!build_demod_k<T, S>(d, pald, bsf, k, sc, g_err)) return CM_ERR_UNSUPPORTED;
     const int W = d.width;
     std::vector<T> car = build_carrier<T>(d.carrier_phase_step, W);
     auto carrier = [&](int m, T *out2) {
@@ -53,12 +54,14 @@ static int run_generic(const cm_plan_desc &d, bool pald, bool bsf, const cm_lane
         if (i < 0 || s < 0 || s >= W) return T(0);
         return T(comp[(size_t)i * W + s]);
     };
-    std::vector<PalDFront<T>> fp(n);
-    std::vector<QamFront<T, ODD_E, ODD_L, ODD_R, true>> fq(n);
-    std::vector<DemodBack<T, 2>> back(n);
-    for (int i = 0; i < n; ++i) { fp[i].reset(); fq[i].reset(); back[i].reset(); }
-    const int lat_front = pald ? PalDFront<T>::latency(k) : QamFront<T, ODD_E, ODD_L, ODD_R, true>::latency(k);
-    const int lat_luma = QamFront<T, ODD_E, ODD_L, ODD_R, true>::luma_latency(k);
+    typedef SysPal SP_;  // the PAL-D front end only exists for even shifts
+    typedef typename std::conditional<S::ODD_E || S::ODD_L, SP_, S>::type SD;
+    std::vector<PalDFront<T, SD>> fp(pald ? n : 0);
+    std::vector<QamFront<T, S, true>> fq(n);
+    std::vector<DemodBack<T, S, 2>> back(n);
+    for (int i = 0; i < n; ++i) { if (pald) fp[i].reset(); fq[i].reset(); back[i].reset(); }
+    const int lat_front = pald ? (10 + k.q_e + 9 + 10 + k.q_l + 9) : QamFront<T, S, true>::latency(k);
+    const int lat_luma = QamFront<T, S, true>::luma_latency(k);
     const int lat_total = lat_front + k.s_p;
     const int steps = W + lat_total;
     // histories (the device keeps these in small register windows / an LDS ring)
@@ -79,8 +82,9 @@ static int run_generic(const cm_plan_desc &d, bool pald, bool bsf, const cm_lane
                 carrier(2 * n4 + 1, cr + 2);
                 T e_d10 = (n3 - 10 >= 0) ? e_hist[i][n3 - 10] : T(0);
                 T e_out;
-                base[i] = edge ? fp[i].template step<true>(k, lk[i], t, x_now, x_d10, e_d10, cr, e_out)
-                               : fp[i].template step<false>(k, lk[i], t, x_now, x_d10, e_d10, cr, e_out);
+                const DemodK<T, SD> &kd = reinterpret_cast<const DemodK<T, SD> &>(k);  // same type whenever pald
+                base[i] = edge ? fp[i].template step<true>(kd, lk[i], t, x_now, x_d10, e_d10, cr, e_out)
+                               : fp[i].template step<false>(kd, lk[i], t, x_now, x_d10, e_d10, cr, e_out);
                 if (n3 >= 0) e_hist[i][n3] = e_out;
             } else {
                 const int n2 = n1 - k.q_e;
@@ -121,19 +125,18 @@ static int run_generic(const cm_plan_desc &d, bool pald, bool bsf, const cm_lane
 template <typename T>
 static int run_dispatch(const cm_plan_desc &d, bool pald, bool bsf, const cm_lane_table &tb, const std::vector<int> &calls,
                         const double *comp, double *rgb, int n_calls, int frame, int first_line, int k0, bool mid_fast) {
-    const cm_iir_desc &lp = pald ? d.pald_lp : d.demod_lp;
-    bool oe = d.extract2x.shift & 1, ol = lp.shift & 1, orr = d.remove2x.shift & 1;
-    if (pald && (oe || ol)) { g_err = "PAL-D front end needs even filter shifts"; return CM_ERR_UNSUPPORTED; }
-#define GO(E, L, R) return run_generic<T, E, L, R>(d, pald, bsf, tb, calls, comp, rgb, n_calls, frame, first_line, k0, mid_fast)
-    if (!oe && !ol && !orr) GO(false, false, false);
-    if (!oe && ol && !orr) GO(false, true, false);
-    if (oe && !ol && !orr) GO(true, false, false);
-    if (oe && ol && !orr) GO(true, true, false);
-    if (!oe && !ol && orr) GO(false, false, true);
-    if (!oe && ol && orr) GO(false, true, true);
-    if (oe && !ol && orr) GO(true, false, true);
-    GO(true, true, true);
-#undef GO
+    SysSignature want = signature_wanted(d, pald);
+    if (!bsf) { want.nr = 0; want.odd_r = 0; }
+    auto match = [&](SysSignature have) {
+        if (!bsf) { have.nr = 0; have.odd_r = 0; }
+        return same_signature(want, have);
+    };
+    if (match(signature_of<SysPal>()))
+        return run_generic<T, SysPal>(d, pald, bsf, tb, calls, comp, rgb, n_calls, frame, first_line, k0, mid_fast);
+    if (!pald && match(signature_of<SysNtsc>()))
+        return run_generic<T, SysNtsc>(d, pald, bsf, tb, calls, comp, rgb, n_calls, frame, first_line, k0, mid_fast);
+    g_err = "no kernel instance for this filter set";
+    return CM_ERR_UNSUPPORTED;
 }
 
 template <typename T>

@@ -1,0 +1,68 @@
+# -*- coding: utf-8 -*-
+"""GPU parity: libcolor_modem_hip.so (through the Python API) against the reference-generated
+goldens and against the CPU oracle on seeded inputs.  Tolerance: max|out - ref| <= 1e-5 * max|ref|
+per frame (BASELINE.json north_star; convention of SURVEY.md Appendix C)."""
+import glob
+import os
+
+import numpy
+import pytest
+
+import stacks
+from color_modem_amd import image, testing
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+
+DEMOD_FRAMES = [n for n in sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(stacks.GOLDEN, 'frames_demod_*.npz')))
+                if 'secam' not in n]
+DEMOD_ROWS = [n for n in sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(stacks.GOLDEN, 'rows_demod_*.npz')))
+              if 'secam' not in n]
+
+
+def stack_of(name, prefix):
+    return name[len(prefix):].split('_noise_')[0]
+
+
+@pytest.mark.parametrize('name', DEMOD_FRAMES)
+def test_frames_demod_golden(name):
+    g = stacks.load(name)
+    if int(g['size'][0]) % 4:
+        pytest.skip('width not a multiple of 4')
+    modem = stacks.make(stack_of(name, 'frames_demod_'), g['size'])
+    im = image.ImageModem(modem)
+    for i, f in enumerate(g['frames']):
+        out = im.demodulate_frames(g['inp'][i:i + 1], first_frame=int(f))[0]
+        assert out.dtype == numpy.float32
+        assert stacks.rel_err(out, g['out'][i]) < TOL, (name, int(f))
+    # the same frames as one batch when they are consecutive
+    frames = [int(f) for f in g['frames']]
+    if frames == list(range(frames[0], frames[0] + len(frames))):
+        out = im.demodulate_frames(g['inp'], first_frame=frames[0])
+        for i in range(len(frames)):
+            assert stacks.rel_err(out[i], g['out'][i]) < TOL
+
+
+@pytest.mark.parametrize('name', DEMOD_ROWS)
+def test_rows_demod_golden(name):
+    """The stateful per-row protocol (Modem.demodulate) at full-height line numbers."""
+    g = stacks.load(name)
+    modem = stacks.make(stack_of(name, 'rows_demod_'), g['size'], explicit=False)
+    for i, (f, y) in enumerate(g['seq']):
+        out = numpy.stack(modem.demodulate(int(f), int(y), g['inp'][i]))
+        assert stacks.rel_err(out, g['out'][i]) < TOL, (name, int(f), int(y))
+
+
+@pytest.mark.parametrize('stack,size,n_frames,first', [
+    ('pal_d', (720, 576), 3, 2), ('pal_d', (720, 575), 2, 5), ('pal_d', (704, 6), 5, 0), ('pal_d', (724, 10), 2, 1), ('pal_s', (720, 32), 2, 1),
+    ('pal_3d', (720, 64), 3, 3), ('ntsc', (720, 480), 1, 1), ('ntsc_comb', (720, 33), 3, 0),
+    ('ntsc_comb_simple', (720, 24), 2, 1), ('ntsc_comb_3d', (720, 480), 2, 1),
+])
+def test_frames_demod_vs_oracle(stack, size, n_frames, first):
+    from oracle import cm_oracle
+    modem = stacks.make(stack, size)
+    comp = testing.synthetic_composite(n_frames, size[1], size[0], seed=900 + size[1])
+    got = image.ImageModem(modem).demodulate_frames(comp, first_frame=first)
+    want = cm_oracle.demodulate_frames_f32(modem, comp, first_frame=first, n_threads=8)
+    for i in range(n_frames):
+        assert stacks.rel_err(got[i], want[i]) < TOL, (stack, i)
