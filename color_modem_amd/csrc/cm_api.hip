@@ -27,19 +27,26 @@ int fail(int code, const std::string &msg) {
         if (e_ != hipSuccess) return fail(code, std::string(#expr) + ": " + hipGetErrorString(e_)); \
     } while (0)
 
-typedef int (*LaunchFn)(const Geom &, const void *k, int blocks, hipStream_t);
+// One launch = first-line workgroups [0, n_first) followed by the main pass's workgroups.
+typedef int (*LaunchFn)(const Geom &gm, const void *km, const Geom &gf, const void *kf, int n_first, int n_main,
+                        hipStream_t);
 
-template <class S, int FRONT, bool BSF, int DEPTH>
-int launch_demod(const Geom &g, const void *kv, int blocks, hipStream_t stream) {
-    const DemodK<float, S> &k = *static_cast<const DemodK<float, S> *>(kv);
-    hipLaunchKernelGGL((demod_kernel<S, FRONT, BSF, DEPTH>), dim3(blocks), dim3(64), 0, stream, g, k);
+template <class Main, class First>
+int launch_demod(const Geom &gm, const void *km, const Geom &gf, const void *kf, int n_first, int n_main,
+                 hipStream_t stream) {
+    typedef typename Main::S S;
+    PassArgs<S> am, af;
+    am.g = gm;
+    am.k = *static_cast<const DemodK<float, S> *>(km);
+    af.g = gf;
+    af.k = kf ? *static_cast<const DemodK<float, S> *>(kf) : am.k;
+    hipLaunchKernelGGL((demod_kernel<Main, First>), dim3(n_first + n_main), dim3(64), 0, stream, am, af, n_first);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(CM_ERR_LAUNCH, std::string("demod_kernel launch: ") + hipGetErrorString(e));
     return CM_OK;
 }
 
 struct Pass {
-    LaunchFn fn = nullptr;
     std::vector<unsigned char> k;  // DemodK<float, S> blob
     LaneK<float> *lanes = nullptr; // device
     int cycle = 0, n_lines = 0, luma_prev_bits = 0;
@@ -52,9 +59,10 @@ struct Pass {
 struct cm_plan {
     cm_plan_desc desc;
     int device = 0;
-    float *carrier = nullptr;
+    float *carrier4 = nullptr, *carrier2 = nullptr;
+    LaunchFn fn = nullptr;
+    bool has_first = false;
     Pass main, first;
-    std::string last_launch;
 };
 
 namespace {
@@ -80,36 +88,57 @@ bool make_pass(const cm_plan_desc &d, bool pald, bool bsf, const cm_lane_table &
     return true;
 }
 
-// Pick the kernel instance of a pass.  Returns false when this build has none for the filter set.
-bool select_pass(const cm_plan_desc &d, bool pald, bool bsf, int depth, const cm_lane_table &tb, Pass &pass,
-                 std::string &err) {
+template <class S>
+bool make_passes(cm_plan *p, const cm_plan_desc &d, bool pald, bool bsf, bool first, std::string &err) {
+    if (!make_pass<S>(d, pald, bsf, d.demod_main, p->main, err)) return false;
+    if (first && !make_pass<S>(d, false, true, d.demod_first, p->first, err)) return false;
+    p->has_first = first;
+    return true;
+}
+
+// Pick the kernel instance (main pass + optional plain first-line pass in one launch).
+bool select_kernels(cm_plan *p, const cm_plan_desc &d, std::string &err) {
+    const bool pald = d.pipeline == CM_PIPE_PAL_D;
+    const bool bsf = d.main_luma_bandstop != 0;
+    const bool first = d.first_is_plain != 0;
+    const int depth = d.depth;
     SysSignature want = signature_wanted(d, pald);
     auto match = [&](SysSignature have) {
-        if (!bsf) { have.nr = want.nr; have.odd_r = want.odd_r; }
+        if (!bsf && !first) { have.nr = want.nr; have.odd_r = want.odd_r; }
         return same_signature(want, have);
     };
+    typedef PassCfg<SysPal, FRONT_QAM, true, 0, 8> PalFirst;
+    typedef PassCfg<SysNtsc, FRONT_QAM, true, 0, 8> NtscFirst;
     if (match(signature_of<SysPal>())) {
         if (pald) {
-            if (depth > 1) { err = "PAL-D front end is built with one line of history"; return false; }
-            pass.fn = launch_demod<SysPal, FRONT_PALD, false, 1>; pass.depth = 1; pass.name = "demod_kernel<pal, pal-d front, depth 1>";
+            if (depth != 1 || !first) { err = "PAL-D front end is built with one line of history and a plain first line"; return false; }
+            p->fn = launch_demod<PassCfg<SysPal, FRONT_PALD, false, 1, 16>, PalFirst>;
+            p->main.depth = 1; p->main.name = "demod_kernel<pal: pal-d front, depth 1 | plain first line>";
         } else if (bsf) {
-            if (depth > 0) { err = "band-stop luma is built for plain decoders only"; return false; }
-            pass.fn = launch_demod<SysPal, FRONT_QAM, true, 0>; pass.depth = 0; pass.name = "demod_kernel<pal, qam front + band-stop, depth 0>";
+            if (depth != 0 || first) { err = "band-stop luma is built for plain decoders only"; return false; }
+            p->fn = launch_demod<PassCfg<SysPal, FRONT_QAM, true, 0, 16>, NoPass>;
+            p->main.depth = 0; p->main.name = "demod_kernel<pal: qam front + band-stop, depth 0>";
         } else {
-            pass.fn = launch_demod<SysPal, FRONT_QAM, false, 2>; pass.depth = 2; pass.name = "demod_kernel<pal, qam front, depth 2>";
+            if (first) { err = "no PAL kernel instance with a plain first line behind the QAM front end"; return false; }
+            p->fn = launch_demod<PassCfg<SysPal, FRONT_QAM, false, 2, 16>, NoPass>;
+            p->main.depth = 2; p->main.name = "demod_kernel<pal: qam front, depth 2>";
         }
-        return make_pass<SysPal>(d, pald, bsf, tb, pass, err);
+        return make_passes<SysPal>(p, d, pald, bsf, first, err);
     }
     if (!pald && match(signature_of<SysNtsc>())) {
         if (bsf) {
-            if (depth > 0) { err = "band-stop luma is built for plain decoders only"; return false; }
-            pass.fn = launch_demod<SysNtsc, FRONT_QAM, true, 0>; pass.depth = 0; pass.name = "demod_kernel<ntsc, qam front + band-stop, depth 0>";
-        } else if (depth <= 1) {
-            pass.fn = launch_demod<SysNtsc, FRONT_QAM, false, 1>; pass.depth = 1; pass.name = "demod_kernel<ntsc, qam front, depth 1>";
+            if (depth != 0 || first) { err = "band-stop luma is built for plain decoders only"; return false; }
+            p->fn = launch_demod<PassCfg<SysNtsc, FRONT_QAM, true, 0, 16>, NoPass>;
+            p->main.depth = 0; p->main.name = "demod_kernel<ntsc: qam front + band-stop, depth 0>";
+        } else if (first) {
+            if (depth != 1) { err = "NTSC comb with a plain first line is built with one line of history"; return false; }
+            p->fn = launch_demod<PassCfg<SysNtsc, FRONT_QAM, false, 1, 16>, NtscFirst>;
+            p->main.depth = 1; p->main.name = "demod_kernel<ntsc: qam front, depth 1 | plain first line>";
         } else {
-            pass.fn = launch_demod<SysNtsc, FRONT_QAM, false, 2>; pass.depth = 2; pass.name = "demod_kernel<ntsc, qam front, depth 2>";
+            p->fn = launch_demod<PassCfg<SysNtsc, FRONT_QAM, false, 2, 16>, NoPass>;
+            p->main.depth = 2; p->main.name = "demod_kernel<ntsc: qam front, depth 2>";
         }
-        return make_pass<SysNtsc>(d, pald, bsf, tb, pass, err);
+        return make_passes<SysNtsc>(p, d, pald, bsf, first, err);
     }
     char buf[256];
     snprintf(buf, sizeof buf,
@@ -120,17 +149,27 @@ bool select_pass(const cm_plan_desc &d, bool pald, bool bsf, int depth, const cm
     return false;
 }
 
-int run_pass(const cm_plan *p, const Pass &pass, Geom g, hipStream_t stream) {
+void finish_geom(const cm_plan *p, const Pass &pass, Geom &g) {
     g.lanes = pass.lanes;
-    g.carrier = p->carrier;
+    g.carrier4 = p->carrier4;
+    g.carrier2 = p->carrier2;
     g.cycle = pass.cycle;
     g.n_lines = pass.n_lines;
     g.luma_prev_bits = pass.luma_prev_bits;
-    long long per_block = g.sparse ? 64 : 64 - pass.depth;
-    long long blocks = (g.total_calls + per_block - 1) / per_block;
-    if (blocks <= 0) return CM_OK;
-    if (blocks > 0x7fffffffLL) return fail(CM_ERR_INVALID, "batch too large for one launch");
-    return pass.fn(g, pass.k.data(), (int)blocks, stream);
+}
+
+// gm: main-pass geometry (total_calls set); gf: first-line geometry (total_calls = number of runs) when the plan has one
+int run_plan(const cm_plan *p, Geom gm, Geom gf, bool with_first, hipStream_t stream) {
+    finish_geom(p, p->main, gm);
+    long long n_main = (gm.total_calls + (64 - p->main.depth) - 1) / (64 - p->main.depth);
+    long long n_first = 0;
+    if (with_first) {
+        finish_geom(p, p->first, gf);
+        n_first = (gf.total_calls + 63) / 64;
+    }
+    if (n_main + n_first <= 0) return CM_OK;
+    if (n_main + n_first > 0x7fffffffLL) return fail(CM_ERR_INVALID, "batch too large for one launch");
+    return p->fn(gm, p->main.k.data(), gf, with_first ? p->first.k.data() : nullptr, (int)n_first, (int)n_main, stream);
 }
 
 int check_lines(const cm_plan *p, const Pass &pass, int max_line) {
@@ -175,18 +214,20 @@ int cm_plan_create(const cm_plan_desc *desc, cm_plan **out) {
         return fail(CM_ERR_NO_DEVICE, "hipGetDevice failed");
     }
     std::string err;
-    std::vector<float> car = build_carrier<float>(desc->carrier_phase_step, desc->width);
-    if (hipMalloc((void **)&p->carrier, car.size() * sizeof(float)) != hipSuccess ||
-        hipMemcpy(p->carrier, car.data(), car.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) {
-        cm_plan_destroy(p);
-        return fail(CM_ERR_NO_DEVICE, "device allocation / upload of the carrier table failed");
+    std::vector<float> car = build_carrier<float>(desc->carrier_phase_step, desc->width);  // {C[m], S[m]}, m < 2W
+    std::vector<float> car2(2 * (size_t)desc->width);                                      // {C[2n], S[2n]}
+    for (int n = 0; n < desc->width; ++n) {
+        car2[2 * n] = car[4 * n];
+        car2[2 * n + 1] = car[4 * n + 1];
     }
-    const bool pald = desc->pipeline == CM_PIPE_PAL_D;
-    if (!select_pass(*desc, pald, desc->main_luma_bandstop != 0, desc->depth, desc->demod_main, p->main, err)) {
+    if (hipMalloc((void **)&p->carrier4, car.size() * sizeof(float)) != hipSuccess ||
+        hipMemcpy(p->carrier4, car.data(), car.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess ||
+        hipMalloc((void **)&p->carrier2, car2.size() * sizeof(float)) != hipSuccess ||
+        hipMemcpy(p->carrier2, car2.data(), car2.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) {
         cm_plan_destroy(p);
-        return fail(CM_ERR_UNSUPPORTED, err);
+        return fail(CM_ERR_NO_DEVICE, "device allocation / upload of the carrier tables failed");
     }
-    if (desc->first_is_plain && !select_pass(*desc, false, true, 0, desc->demod_first, p->first, err)) {
+    if (!select_kernels(p, *desc, err)) {
         cm_plan_destroy(p);
         return fail(CM_ERR_UNSUPPORTED, err);
     }
@@ -196,7 +237,8 @@ int cm_plan_create(const cm_plan_desc *desc, cm_plan **out) {
 
 void cm_plan_destroy(cm_plan *p) {
     if (!p) return;
-    if (p->carrier) (void)hipFree(p->carrier);
+    if (p->carrier4) (void)hipFree(p->carrier4);
+    if (p->carrier2) (void)hipFree(p->carrier2);
     if (p->main.lanes) (void)hipFree(p->main.lanes);
     if (p->first.lanes) (void)hipFree(p->first.lanes);
     delete p;
@@ -232,17 +274,14 @@ int cm_demodulate_frames(const cm_plan *p, const float *composite, float *rgb, i
     g.skip_first = d.first_is_plain;
     int rc = check_lines(p, p->main, H - 1 + 2 * D);
     if (rc) return rc;
-    rc = run_pass(p, p->main, g, (hipStream_t)stream);
-    if (rc) return rc;
-    if (d.first_is_plain) {
-        Geom s = g;
+    Geom s = g;
+    if (p->has_first) {
         s.sparse = 1;
         s.skip_first = 0;
         s.total_calls = n_frames * g.runs_per_frame;
         s.first_frame = (int)(first_frame % (int64_t)p->first.cycle);
-        rc = run_pass(p, p->first, s, (hipStream_t)stream);
     }
-    return rc;
+    return run_plan(p, g, s, p->has_first, (hipStream_t)stream);
 }
 
 int cm_demodulate_run(const cm_plan *p, const float *composite, float *rgb, int32_t n_calls, int32_t frame,
@@ -275,17 +314,15 @@ int cm_demodulate_run(const cm_plan *p, const float *composite, float *rgb, int3
     // rows mode writes [call][plane][W]
     g.out_plane_stride = d.width;
     g.out_row_stride = 3LL * d.width;
-    rc = run_pass(p, p->main, g, (hipStream_t)stream);
-    if (rc) return rc;
-    if (d.first_is_plain && k0 == 0) {
-        Geom s = g;
+    Geom s = g;
+    const bool with_first = p->has_first && k0 == 0;
+    if (with_first) {
         s.sparse = 1;
         s.skip_first = 0;
         s.total_calls = 1;
         s.first_frame = frame % p->first.cycle;
-        rc = run_pass(p, p->first, s, (hipStream_t)stream);
     }
-    return rc;
+    return run_plan(p, g, s, with_first, (hipStream_t)stream);
 }
 
 int cm_modulate_frames(const cm_plan *, const float *, float *, int64_t, int64_t, void *) {
@@ -297,8 +334,7 @@ int cm_modulate_run(const cm_plan *, const float *, float *, int32_t, int32_t, i
 
 int cm_plan_describe(const cm_plan *p, char *buf, int32_t buf_len) {
     if (!p || !buf || buf_len < 1) return 0;
-    int n = snprintf(buf, buf_len, "main: %s; first-line pass: %s; lanes per workgroup 64, halo %d", p->main.name.c_str(),
-                     p->first.fn ? p->first.name.c_str() : "none", p->main.depth);
+    int n = snprintf(buf, buf_len, "%s; lanes per workgroup 64, halo %d", p->main.name.c_str(), p->main.depth);
     return n < buf_len ? n : buf_len - 1;
 }
 

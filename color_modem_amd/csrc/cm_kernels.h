@@ -4,21 +4,18 @@
 // [frame][run][call]; lane j owns call  block * (64 - DEPTH) - DEPTH + j,  i.e. consecutive
 // workgroups overlap by DEPTH halo lanes that only feed their base pairs to their neighbours.
 //
-// Data movement per lane:
-//   input   x[t - dl .. +3]   one unaligned global_load_dwordx4 per 4 steps straight from the
-//                             lane's own row (64 rows per wave-instruction; the rows are re-used
-//                             from L2 for 32 steps; measured cost in profiles/r01_ubench_valu.txt)
-//   luma    x_l[n7 .. +3]     one aligned dwordx4 per 4 steps (second visit of the same row,
-//                             lat_r samples later; served by L2 / Infinity Cache)
-//   output  r, g, b           one ds_write_b32 per plane and step into a [3][64][16+4] LDS
-//                             tile; every 16 steps the tile is read back row-wise
-//                             (ds_read_b128) and stored as 64-byte row segments, 16 rows per
-//                             wave-instruction, so that HBM sees full-width writes.
-//   carrier cos/sin(m cps)    wave-uniform: scalar loads (constant address space) into SGPRs
-//   neighbours' base pairs    ds_bpermute_b32 (no VALU cycles)
-//
-// `dl` delays the input stream by 0..3 steps so that the output index n7 = t - lat_r is congruent
-// to t modulo 4: tile flushes and luma loads then fall on fixed sub-steps of the 4x unrolled body.
+// Data movement (per workgroup, 20 KiB of LDS -> 8 workgroups per CU = 2 waves per SIMD):
+//   input   64 rows x 32 samples per tile, filled with 8 global_load_lds_dwordx4 (8 rows x 128 B
+//           each, full cache lines, no VGPR staging); lane i then reads its own row with one
+//           ds_read_b128 per 4 steps.  Every input byte crosses the fabric once for this stream.
+//   luma    x_l[n7 .. +3]: second visit of the (own or previous) row lat samples later, one
+//           unaligned global_load_dwordx4 per lane and 4 steps (L2 / Infinity-Cache hits).
+//   output  r, g, b: one ds_write_b32 per plane and step into a [3][64][16] LDS tile (quad-
+//           swizzled columns); every 16 steps the tile is read back row-wise (ds_read_b128) and
+//           stored as 64-byte row segments, 16 rows per wave-instruction.
+//   carrier cos/sin(m cps): wave-uniform, one s_load_dwordx16 + one s_load_dwordx8 per 4 steps.
+//   neighbours' base pairs: ds_bpermute_b32, consumed one step later (the back end runs one
+//           sample behind the front end so that the permute latency is never waited for).
 #ifndef CM_KERNELS_H
 #define CM_KERNELS_H
 
@@ -34,7 +31,8 @@ struct Geom {
     const float *in;
     float *out;
     const LaneK<float> *lanes;  // [cycle][3][n_lines]
-    const float *carrier;       // {C[m], S[m]} interleaved, m < 2W
+    const float *carrier4;      // {C[2n], S[2n], C[2n+1], S[2n+1]}, n < W   (C/S = cos/sin(m cps))
+    const float *carrier2;      // {C[2n], S[2n]}, n < W
     long long in_frame_stride, out_frame_stride, out_plane_stride, out_row_stride;
     long long total_calls;      // main pass: n_frames * calls_per_frame; sparse pass: n_frames * runs_per_frame
     int first_frame, cycle, n_lines;
@@ -52,21 +50,56 @@ struct Geom {
 typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
 typedef float f4 __attribute__((ext_vector_type(4)));
 typedef float f2 __attribute__((ext_vector_type(2)));
+typedef float f8u __attribute__((ext_vector_type(8), aligned(4)));
+typedef float f16u __attribute__((ext_vector_type(16), aligned(4)));
 typedef const __attribute__((address_space(4))) f4 const_f4;
 typedef const __attribute__((address_space(4))) f2 const_f2;
+typedef const __attribute__((address_space(4))) f8u const_f8;
+typedef const __attribute__((address_space(4))) f16u const_f16;
 
-constexpr int kTile = 16;       // samples per output tile
-constexpr int kTileStride = 20; // floats per tile row (16 B aligned, spreads ds_read_b128 over banks)
+// Cache policy of the streaming accesses (measured, profiles/r01_notes.md): the input tile fill is
+// marked nt (each line is needed once by this stream) and the output stores are nt; both keep the
+// 4 MiB L2 of an XCD for the luma re-read, whose lines are touched 8 times.
+#ifndef CM_FILL_AUX
+#define CM_FILL_AUX 2
+#endif
+typedef __attribute__((address_space(3))) float lds_float;
+typedef __attribute__((address_space(3))) f4 lds_f4;
+constexpr int kInTile = 32;        // samples per input tile (one 128-byte line per row)
+constexpr int kLdsIn = 64 * kInTile;        // floats
+constexpr int kLdsRing = 16 * 64;           // floats (band-stop luma delay ring)
 
 __device__ __forceinline__ float lane_from(int byte_index, float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(byte_index, __builtin_bit_cast(int, v)));
 }
+__device__ __forceinline__ const float *ptr_from(int byte_index, const float *p) {
+    unsigned long long v = (unsigned long long)p;
+    unsigned lo = (unsigned)__builtin_amdgcn_ds_bpermute(byte_index, (int)(unsigned)v);
+    unsigned hi = (unsigned)__builtin_amdgcn_ds_bpermute(byte_index, (int)(unsigned)(v >> 32));
+    return (const float *)(((unsigned long long)hi << 32) | lo);
+}
 
-template <class S, int FRONT, bool BSF, int DEPTH>
+// TILE: samples per output tile (16: 64-byte row segments; 8: 32-byte segments, used where LDS is
+// short and the pass writes a negligible share of the rows)
+template <class S_, int FRONT_, bool BSF_, int DEPTH_, int TILE_>
+struct PassCfg {
+    typedef S_ S;
+    static constexpr int FRONT = FRONT_, DEPTH = DEPTH_, TILE = TILE_;
+    static constexpr bool BSF = BSF_;
+    static constexpr int kLdsOut = 3 * 64 * TILE_;
+    static constexpr int kLdsFloats = kLdsIn + kLdsOut + (BSF_ ? kLdsRing : 0);
+};
+struct NoPass {
+    static constexpr int kLdsFloats = 0;
+};
+
+template <class Cfg>
 struct DemodLane {
+    typedef typename Cfg::S S;
+    static constexpr int FRONT = Cfg::FRONT, DEPTH = Cfg::DEPTH, SP = S::SP, kTile = Cfg::TILE;
+    static constexpr bool BSF = Cfg::BSF;
     typedef DemodK<float, S> K;
     typedef typename std::conditional<FRONT == FRONT_PALD, PalDFront<float, S>, QamFront<float, S, BSF>>::type Front;
-    static constexpr int SP = S::SP;
 
     Front front;
     DemodBack<float, S, DEPTH> back;
@@ -75,53 +108,32 @@ struct DemodLane {
     float ew[FRONT == FRONT_PALD ? 14 : 1];
     float uw[SP + 4], vw[SP + 4];
     f4 lw;
-    const float *xp, *lp;
+    Pair<float> base_prev, b1_prev, b2_prev;
+    const float *lp;
     int idx1, idx2;
 
-    __device__ __forceinline__ f4 load_x(const Geom &g, int first, bool edge) const {
-        // x[first .. first + 3], zero outside [0, W)
-        if (!edge || (first >= 0 && first + 3 < g.W)) {
-            f4u v = *(const f4u *)(xp + first);
-            return f4{v.x, v.y, v.z, v.w};
-        }
-        f4 r = {0.f, 0.f, 0.f, 0.f};
-        if (first + 3 >= 0 && first < g.W) {
-            if (first >= 0 && first < g.W) r.x = xp[first];
-            if (first + 1 >= 0 && first + 1 < g.W) r.y = xp[first + 1];
-            if (first + 2 >= 0 && first + 2 < g.W) r.z = xp[first + 2];
-            if (first + 3 >= 0 && first + 3 < g.W) r.w = xp[first + 3];
-        }
-        return r;
-    }
-    __device__ __forceinline__ f4 load_luma(const Geom &g, int first, bool edge) const {
-        if (BSF) return f4{0.f, 0.f, 0.f, 0.f};
-        if (!edge || (first >= 0 && first < g.W)) return *(const f4 *)(lp + first);  // W % 4 == 0: all or nothing
-        return f4{0.f, 0.f, 0.f, 0.f};
-    }
-
+    // One step.  car: detector carriers of this step, carb: re-modulation carrier of the back-end
+    // sample n7 = tau - lat_front - 1 - SP.  Returns true when an output tile has just been completed.
     template <int SUB, bool EDGE>
-    __device__ __forceinline__ void substep(const Geom &g, const K &k, int tau, int lat_front, int lat_luma, float *tile,
-                                            float *yring, int lane) {
+    __device__ __forceinline__ void substep(const Geom &g, const K &k, int tau, int lat_front, int lat_luma, const float car[4],
+                                            const float carb[2], lds_float *otile, lds_float *yring, int lane, int wpos) {
         const int W = g.W;
-        const_f4 *car4 = (const_f4 *)g.carrier;
         float luma_bsf = 0.f;
         Pair<float> base;
         if constexpr (FRONT == FRONT_PALD) {
-            int n4 = tau - (10 + k.q_e + 9 + 10);
-            if (EDGE) n4 = n4 < 0 ? 0 : (n4 > W - 1 ? W - 1 : n4);
-            f4 c = car4[n4];
-            float car[4] = {c.x, c.y, c.z, c.w};
             float e_out;
             base = front.template step<EDGE>(k, lk, tau, xw[10 + SUB], xw[SUB], ew[FRONT == FRONT_PALD ? SUB : 0], car, e_out);
             ew[FRONT == FRONT_PALD ? 10 + SUB : 0] = e_out;
         } else {
-            int n2 = tau - (10 + k.q_e);
-            if (EDGE) n2 = n2 < 0 ? 0 : (n2 > W - 1 ? W - 1 : n2);
-            f4 c = car4[n2];
-            float car[4] = {c.x, c.y, c.z, c.w};
             base = front.template step<EDGE>(k, lk, tau, xw[10 + SUB], xw[SUB], car, luma_bsf);
         }
-        const int n6 = tau - lat_front, n7 = n6 - SP;
+        // the back end handles the PREVIOUS step's base pair: its neighbours were requested then
+        const int n6 = tau - lat_front - 1, n7 = n6 - SP;
+        float u, v;
+        back.combine(lk, base_prev, b1_prev, b2_prev, u, v);
+        base_prev = base;
+        if (DEPTH >= 1) { b1_prev.s = lane_from(idx1, base.s); b1_prev.c = lane_from(idx1, base.c); }
+        if (DEPTH >= 2) { b2_prev.s = lane_from(idx2, base.s); b2_prev.c = lane_from(idx2, base.c); }
         float y_src;
         if (BSF) {
             const int nl = tau - lat_luma;
@@ -130,54 +142,71 @@ struct DemodLane {
         } else {
             y_src = SUB == 0 ? lw.x : (SUB == 1 ? lw.y : (SUB == 2 ? lw.z : lw.w));
         }
-        Pair<float> b1 = {0.f, 0.f}, b2 = {0.f, 0.f};
-        if (DEPTH >= 1) { b1.s = lane_from(idx1, base.s); b1.c = lane_from(idx1, base.c); }
-        if (DEPTH >= 2) { b2.s = lane_from(idx2, base.s); b2.c = lane_from(idx2, base.c); }
-        float u, v;
-        back.combine(lk, base, b1, b2, u, v);
         uw[SP + SUB] = u;
         vw[SP + SUB] = v;
-        int n7c = n7;
-        if (EDGE) n7c = n7 < 0 ? 0 : (n7 > W - 1 ? W - 1 : n7);
-        const_f2 *car2 = (const_f2 *)g.carrier;
-        f2 cc = car2[2 * n7c];
-        float carb[2] = {cc.x, cc.y};
         Rgb<float> o = back.template step<EDGE>(k, lk, n6, u, v, uw[SUB], vw[SUB], y_src, carb);
         if (!EDGE || (n7 >= 0 && n7 < W)) {
-            float *tp = tile + lane * kTileStride + (n7 & (kTile - 1));
+            lds_float *tp = otile + (wpos ^ (n7 & (kTile - 1)));
             tp[0] = o.r;
-            tp[64 * kTileStride] = o.g;
-            tp[2 * 64 * kTileStride] = o.b;
+            tp[64 * kTile] = o.g;
+            tp[2 * 64 * kTile] = o.b;
         }
     }
 };
 
-// Row-wise read-back of the LDS tile and coalesced store: 16 rows x 64 B per wave-instruction.
-__device__ __forceinline__ void flush_tile(const Geom &g, const float *tile, float *const *optr, int first_col, int lane) {
+// Row-wise read-back of the output tile and coalesced store: (256 / kTile) rows x (4 kTile) bytes per
+// wave-instruction.
+template <int kTile>
+__device__ __forceinline__ void flush_tile(const Geom &g, const lds_float *otile, const float *op, int first_col, int lane) {
     __builtin_amdgcn_wave_barrier();
-    const int chunk = lane & 3;
+    constexpr int kChunks = kTile / 4;        // 16-byte chunks per row
+    constexpr int kRows = 64 / kChunks;       // rows per wave-instruction
+    const int chunk = lane & (kChunks - 1);
     const int col = first_col + 4 * chunk;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int row = (lane >> 2) + 16 * q;
-        float *dst = optr[row];
+    // rolled on purpose: this runs once per 16 steps, and unrolling it would add its temporaries to
+    // the register peak of the whole kernel
+#pragma nounroll
+    for (int q = 0; q < kChunks; ++q) {
+        const int row = lane / kChunks + kRows * q;
+        typedef __attribute__((address_space(1))) f4 global_f4;
+        global_f4 *dst = (global_f4 *)(unsigned long long)ptr_from(row * 4, op);
+        const int quad = chunk ^ ((row >> 1) & (kChunks - 1));
         if (dst != nullptr && col < g.W) {
-#pragma unroll
+            dst += col >> 2;
+#pragma nounroll
             for (int p = 0; p < 3; ++p) {
-                f4 v = *(const f4 *)(tile + (p * 64 + row) * kTileStride + 4 * chunk);
-                *(f4 *)(dst + p * g.out_plane_stride + col) = v;
+                f4 v = *(const lds_f4 *)(otile + p * 64 * kTile + row * kTile + 4 * quad);
+#ifdef CM_EXP_NO_STORE
+                if (v.x == 12345.678f)
+#endif
+                __builtin_nontemporal_store(v, &dst[(p * g.out_plane_stride) >> 2]);
             }
         }
     }
     __builtin_amdgcn_wave_barrier();
 }
 
-template <class S, int FRONT, bool BSF, int DEPTH>
-__global__ __launch_bounds__(64, 2) void demod_kernel(const Geom g, const DemodK<float, S> k) {
-    typedef DemodLane<S, FRONT, BSF, DEPTH> Lane;
-    __shared__ __attribute__((aligned(16))) float tile[3 * 64 * kTileStride];
-    __shared__ float *optr[64];
-    __shared__ float yring[BSF ? 16 * 64 : 1];
+// Fill input tile `c` (samples 32 c .. 32 c + 31 of all 64 rows) straight into LDS.
+__device__ __forceinline__ void fill_tile(const Geom &g, lds_float *itile, const float *xp, int c, int lane) {
+    int col = kInTile * c + 4 * (lane & 7);
+    if (col > g.W - 4) col = g.W - 4;  // never read past the row; such samples are masked by the consumer
+#pragma nounroll
+    for (int q = 0; q < 8; ++q) {
+        const float *src = ptr_from((8 * q + (lane >> 3)) * 4, xp) + col;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                         (__attribute__((address_space(3))) void *)(itile + q * 256), 16, 0, CM_FILL_AUX);
+    }
+}
+
+template <class Cfg>
+__device__ __forceinline__ void run_lane(const Geom &g, const DemodK<float, typename Cfg::S> &k, int block, lds_float *lds) {
+    typedef DemodLane<Cfg> Lane;
+    typedef typename Cfg::S S;
+    constexpr int FRONT = Cfg::FRONT, DEPTH = Cfg::DEPTH, kTile = Cfg::TILE;
+    constexpr bool BSF = Cfg::BSF;
+    lds_float *itile = lds;
+    lds_float *otile_base = lds + kLdsIn;
+    lds_float *yring = lds + kLdsIn + Cfg::kLdsOut;
 
     const int lane = threadIdx.x;
     // ---- which call does this lane own -------------------------------------------------------
@@ -186,14 +215,14 @@ __global__ __launch_bounds__(64, 2) void demod_kernel(const Geom g, const DemodK
     long long frame;
     int run, i;
     if (g.sparse) {
-        c = (long long)blockIdx.x * 64 + lane;
+        c = (long long)block * 64 + lane;
         active = c < g.total_calls;
         if (!active) c = g.total_calls - 1;
         frame = c / g.runs_per_frame;
         run = (int)(c - frame * g.runs_per_frame);
         i = 0;
     } else {
-        c = (long long)blockIdx.x * (64 - DEPTH) - DEPTH + lane;
+        c = (long long)block * (64 - DEPTH) - DEPTH + lane;
         active = lane >= DEPTH && c < g.total_calls;
         if (c < 0) c = 0;
         if (c >= g.total_calls) c = g.total_calls - 1;
@@ -222,10 +251,9 @@ __global__ __launch_bounds__(64, 2) void demod_kernel(const Geom g, const DemodK
         store_ok = store_ok && i >= g.delay && out_row >= 0 && out_row < g.H;
     }
     Lane L;
-    L.xp = g.in + frame * g.in_frame_stride + (long long)src_row * g.W;
+    const float *xp = g.in + frame * g.in_frame_stride + (long long)src_row * g.W;
     L.lp = g.in + frame * g.in_frame_stride + (long long)luma_row * g.W;
-    float *op = g.out + frame * g.out_frame_stride + (long long)out_row * g.out_row_stride;
-    optr[lane] = store_ok ? op : nullptr;
+    const float *op = store_ok ? g.out + frame * g.out_frame_stride + (long long)out_row * g.out_row_stride : nullptr;
     {
         int fmod = (int)((g.first_frame + frame) % g.cycle);
         L.lk = g.lanes[((long long)fmod * 3 + regime) * g.n_lines + line];
@@ -234,6 +262,7 @@ __global__ __launch_bounds__(64, 2) void demod_kernel(const Geom g, const DemodK
     L.idx2 = ((lane + 62) & 63) * 4;
     L.front.reset();
     L.back.reset();
+    L.base_prev = L.b1_prev = L.b2_prev = Pair<float>{0.f, 0.f};
 #pragma unroll
     for (int j = 0; j < 14; ++j) L.xw[j] = 0.f;
 #pragma unroll
@@ -243,51 +272,151 @@ __global__ __launch_bounds__(64, 2) void demod_kernel(const Geom g, const DemodK
     if (BSF) {
         for (int j = 0; j < 16; ++j) yring[j * 64 + lane] = 0.f;
     }
+    // output tile address of this lane's row: row * 16 + (column ^ quad swizzle)
+    lds_float *otile = otile_base + lane * kTile;
+    const int wpos = ((lane >> 1) & (kTile / 4 - 1)) << 2;
 
     // ---- stream geometry ----------------------------------------------------------------------
+    const int W = g.W;
     const int lat_front = Lane::Front::latency(k);
     int lat_luma = 0;
     if constexpr (FRONT == FRONT_QAM) lat_luma = Lane::Front::luma_latency(k);
-    const int lat_total = lat_front + S::SP;
-    const int lat_r = (lat_total + 3) & ~3;
-    const int dl = lat_r - lat_total;          // input delay, 0..3
-    const int W = g.W;
-    const int T = W + lat_r;                   // multiple of 4
-    int t_mid0 = lat_r;                        // first body whose every stage index is >= 0
-    int t_mid1 = (W + dl - 3) & ~3;            // bodies below this never touch the end of the row
+    const int lat_out = lat_front + 1 + S::SP;     // n7 = t - lat_out
+    const int T = (W + lat_out + 3) & ~3;
+    const int front_off = FRONT == FRONT_PALD ? 10 + k.q_e + 9 + 10 : 10 + k.q_e;  // detector sample pair = t - front_off
+    int t_mid0 = (lat_out + 3) & ~3;           // every stage index >= 0 from here on
+    int t_mid1 = (W - 4) & ~3;                 // bodies below this never touch the end of the row
     if (t_mid1 < t_mid0) t_mid1 = t_mid0;
 
-    f4 nx = L.load_x(g, -dl, true);
-    f4 nl = L.load_luma(g, -lat_r, true);
+    const lds_float *xrow = itile + lane * kInTile;
+    auto read_x = [&](int first) -> f4 {  // x[first .. first + 3] from the input tile, zero outside the row
+        f4 v = *(const lds_f4 *)(xrow + (first & (kInTile - 1)));
+        if (first + 3 >= W) {
+            if (first >= W) v.x = 0.f;
+            if (first + 1 >= W) v.y = 0.f;
+            if (first + 2 >= W) v.z = 0.f;
+            if (first + 3 >= W) v.w = 0.f;
+        }
+        return v;
+    };
+    auto read_luma = [&](int first, bool check) -> f4 {  // x_l[first .. first + 3], zero outside the row
+        if (BSF) return f4{0.f, 0.f, 0.f, 0.f};
+#ifdef CM_EXP_NO_LUMA
+        return f4{0.1f, 0.2f, 0.3f, 0.4f};
+#endif
+        if (!check || (first >= 0 && first + 3 < W)) {
+            f4u v = *(const f4u *)(L.lp + first);
+            return f4{v.x, v.y, v.z, v.w};
+        }
+        f4 r = {0.f, 0.f, 0.f, 0.f};
+        if (first + 3 >= 0 && first < W) {
+            if (first >= 0 && first < W) r.x = L.lp[first];
+            if (first + 1 >= 0 && first + 1 < W) r.y = L.lp[first + 1];
+            if (first + 2 >= 0 && first + 2 < W) r.z = L.lp[first + 2];
+            if (first + 3 >= 0 && first + 3 < W) r.w = L.lp[first + 3];
+        }
+        return r;
+    };
+
+    fill_tile(g, itile, xp, 0, lane);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    {
+        f4 x0 = read_x(0);
+        L.xw[10] = x0.x; L.xw[11] = x0.y; L.xw[12] = x0.z; L.xw[13] = x0.w;
+    }
+    f4 nl = read_luma(-lat_out, true);
+
+    auto carriers = [&](int t, bool edge, float car[4], float carb[2]) {
+        int nf = t - front_off, nb = t - lat_out;
+        if (edge) {
+            nf = nf < 0 ? 0 : (nf > W - 1 ? W - 1 : nf);
+            nb = nb < 0 ? 0 : (nb > W - 1 ? W - 1 : nb);
+        }
+        f4 c = ((const_f4 *)g.carrier4)[nf];
+        car[0] = c.x; car[1] = c.y; car[2] = c.z; car[3] = c.w;
+        f2 d = ((const_f2 *)g.carrier2)[nb];
+        carb[0] = d.x; carb[1] = d.y;
+    };
+
+    // An output tile (or the row) ends at samples n7 = 3 (mod 4) only (W and kTile are multiples of 4),
+    // i.e. always after the same sub-step of the 4x unrolled body.
+    const int s_flush = (lat_out + 3) & 3;
+    auto maybe_flush = [&](int t) {
+        const int n7 = t - lat_out;
+        if (n7 >= 0 && ((n7 & (kTile - 1)) == kTile - 1 || n7 == W - 1))
+            flush_tile<kTile>(g, otile_base, op, n7 & ~(kTile - 1), lane);
+    };
 
     auto body = [&](int tb, auto edge_tag) {
         constexpr bool EDGE = decltype(edge_tag)::value;
-        L.xw[10] = nx.x; L.xw[11] = nx.y; L.xw[12] = nx.z; L.xw[13] = nx.w;
         L.lw = nl;
-        // prefetch the next body's input (a whole body of arithmetic hides the latency)
-        nx = L.load_x(g, tb + 4 - dl, EDGE || tb + 4 >= t_mid1);
-        nl = L.load_luma(g, tb + 4 - lat_r, EDGE || tb + 4 >= t_mid1);
-        const int tau = tb - dl;
-        L.template substep<0, EDGE>(g, k, tau + 0, lat_front, lat_luma, tile, yring, lane);
-        L.template substep<1, EDGE>(g, k, tau + 1, lat_front, lat_luma, tile, yring, lane);
-        L.template substep<2, EDGE>(g, k, tau + 2, lat_front, lat_luma, tile, yring, lane);
-        L.template substep<3, EDGE>(g, k, tau + 3, lat_front, lat_luma, tile, yring, lane);
+        const int nxt = tb + 4;
+        nl = read_luma(nxt - lat_out, EDGE || nxt >= t_mid1);  // next body's luma: a whole body hides the latency
+        float carA[4], carbA[2], carB[4], carbB[2];
+        carriers(tb + 0, EDGE, carA, carbA);
+        carriers(tb + 1, EDGE, carB, carbB);
+        L.template substep<0, EDGE>(g, k, tb + 0, lat_front, lat_luma, carA, carbA, otile, yring, lane, wpos);
+        if (s_flush == 0) maybe_flush(tb + 0);
+        carriers(tb + 2, EDGE, carA, carbA);
+        L.template substep<1, EDGE>(g, k, tb + 1, lat_front, lat_luma, carB, carbB, otile, yring, lane, wpos);
+        if (s_flush == 1) maybe_flush(tb + 1);
+        carriers(tb + 3, EDGE, carB, carbB);
+        L.template substep<2, EDGE>(g, k, tb + 2, lat_front, lat_luma, carA, carbA, otile, yring, lane, wpos);
+        if (s_flush == 2) maybe_flush(tb + 2);
+        L.template substep<3, EDGE>(g, k, tb + 3, lat_front, lat_luma, carB, carbB, otile, yring, lane, wpos);
+        if (s_flush == 3) maybe_flush(tb + 3);
 #pragma unroll
         for (int j = 0; j < 10; ++j) L.xw[j] = L.xw[j + 4];
+        // ---- next body's input from the LDS tile ------------------------------------------------
+        if ((nxt & (kInTile - 1)) == 0 && nxt < W) {  // first read of a new tile: its fill was issued a body ago
+#ifndef CM_EXP_NO_FILL_WAIT
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+            __builtin_amdgcn_wave_barrier();
+        }
+        {
+            f4 xn = read_x(nxt);
+            L.xw[10] = xn.x; L.xw[11] = xn.y; L.xw[12] = xn.z; L.xw[13] = xn.w;
+        }
+        if ((nxt & (kInTile - 1)) == kInTile - 4 && nxt + 4 < W) {  // that was the last read of this tile: refill it
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+            fill_tile(g, itile, xp, (nxt >> 5) + 1, lane);
+        }
         if (FRONT == FRONT_PALD) {
 #pragma unroll
             for (int j = 0; j < 10; ++j) L.ew[FRONT == FRONT_PALD ? j : 0] = L.ew[FRONT == FRONT_PALD ? j + 4 : 0];
         }
 #pragma unroll
         for (int j = 0; j < S::SP; ++j) { L.uw[j] = L.uw[j + 4]; L.vw[j] = L.vw[j + 4]; }
-        const int n7_last = tb + 3 - lat_r;    // congruent to 3 modulo 4
-        if (n7_last >= 0 && ((n7_last & (kTile - 1)) == kTile - 1 || n7_last == W - 1))
-            flush_tile(g, tile, optr, n7_last & ~(kTile - 1), lane);
     };
     int tb = 0;
     for (; tb < t_mid0; tb += 4) body(tb, std::true_type());
     for (; tb < t_mid1; tb += 4) body(tb, std::false_type());
     for (; tb < T; tb += 4) body(tb, std::true_type());
+}
+
+template <class S>
+struct PassArgs {
+    Geom g;
+    DemodK<float, S> k;
+};
+
+// One launch runs the plain first-line pass (workgroups [0, n_first)) and the main pass.
+template <class Main, class First>
+__global__ __launch_bounds__(64, 2) void demod_kernel(const PassArgs<typename Main::S> main_args,
+                                                      const PassArgs<typename Main::S> first_args, const int n_first) {
+    constexpr int kFloats = Main::kLdsFloats > First::kLdsFloats ? Main::kLdsFloats : First::kLdsFloats;
+    __shared__ __attribute__((aligned(16))) float lds_store[kFloats];
+    lds_float *lds = (lds_float *)lds_store;
+    if constexpr (!std::is_same<First, NoPass>::value) {
+        if ((int)blockIdx.x < n_first) {
+            run_lane<First>(first_args.g, first_args.k, blockIdx.x, lds);
+            return;
+        }
+    }
+    run_lane<Main>(main_args.g, main_args.k, (int)blockIdx.x - n_first, lds);
 }
 
 }  // namespace cm

@@ -54,7 +54,7 @@ def test_rows_demod_golden(name):
 
 
 @pytest.mark.parametrize('stack,size,n_frames,first', [
-    ('pal_d', (720, 576), 3, 2), ('pal_d', (720, 575), 2, 5), ('pal_d', (704, 6), 5, 0), ('pal_d', (724, 10), 2, 1), ('pal_s', (720, 32), 2, 1),
+    ('pal_d', (720, 576), 3, 2), ('pal_d', (720, 575), 2, 5), ('pal_d', (704, 6), 5, 0), ('pal_d', (716, 10), 2, 1), ('pal_d', (688, 5), 3, 2), ('pal_s', (720, 32), 2, 1),
     ('pal_3d', (720, 64), 3, 3), ('ntsc', (720, 480), 1, 1), ('ntsc_comb', (720, 33), 3, 0),
     ('ntsc_comb_simple', (720, 24), 2, 1), ('ntsc_comb_3d', (720, 480), 2, 1),
 ])

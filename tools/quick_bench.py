@@ -1,7 +1,9 @@
 import sys, time, numpy, torch
 sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
 import stacks
-from color_modem_amd import image, testing
+import os
+from color_modem_amd import image, testing, _native
+if os.environ.get('CM_LIB'): _native.LIB_PATH = os.environ['CM_LIB']
 F = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 modem = stacks.make('pal_d', (720, 576))
 im = image.ImageModem(modem)
