@@ -1,0 +1,177 @@
+# -*- coding: utf-8 -*-
+"""Headline benchmark: Mpixels/s demodulated, 720x576 PAL-BG 2D comb (PalDModem), synthetic stream.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--frames F]
+
+One "step" = one pass of the hot path (cm_demodulate_frames, include/color_modem_hip.h) over one
+batch of F frames per GPU that is already resident in HBM.  For N > 1 the driver launches this
+file under torch.distributed.run, one rank per GPU (backend nccl = RCCL); frames are independent
+(SURVEY.md D2), so every rank demodulates its own F-frame stream with no data-path collective
+("weak" scaling, BASELINE.json configs[4]); the only collectives are the barriers and the
+max-over-ranks of the timing.
+
+Prints ONE JSON line (rank 0).  `roofline.achieved` = algorithmic bytes (16 B/pixel: 4 read +
+12 written) / mean duration of the demod kernel measured with HIP events on the
+launch stream.  `cpu_baseline` = the float64 C++ oracle (a port of the reference's per-line
+algorithm, oracle/cm_oracle.cpp) timed on this host on a bounded sample of the same workload.
+"""
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+WIDTH, HEIGHT = 720, 576
+HBM_PEAK_GBPS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+BYTES_PER_PIXEL = 16        # float32: one composite sample read, R, G, B written
+
+
+def synthetic_stream(torch, n_frames, seed, device):
+    """composite[F, 576, 720] float32 in [-0.05, 1.03): uniform noise, 4-tap box smoothed along the line.
+
+    Generated on the device, F distinct frames (a repeated frame would sit in the Infinity Cache and
+    hide HBM traffic).  The decoder has no data-dependent control flow; valid colour signals are
+    covered by the parity tests."""
+    gen = torch.Generator(device=device)
+    gen.manual_seed(seed)
+    out = torch.empty((n_frames, HEIGHT, WIDTH), dtype=torch.float32, device=device)
+    chunk = 50
+    for f0 in range(0, n_frames, chunk):
+        n = min(chunk, n_frames - f0)
+        wide = torch.rand((n, HEIGHT, WIDTH + 3), generator=gen, device=device, dtype=torch.float32)
+        acc = wide[..., 0:WIDTH] + wide[..., 1:WIDTH + 1] + wide[..., 2:WIDTH + 2] + wide[..., 3:WIDTH + 3]
+        out[f0:f0 + n] = 1.08 * (acc * 0.25) - 0.05
+    return out
+
+
+def cpu_baseline(sample_frames):
+    """Time the CPU oracle on `sample_frames` frames of the same workload, single thread and all cores."""
+    import numpy
+    from color_modem_amd import line, testing
+    from color_modem_amd.color import pal
+    from oracle import cm_oracle
+    modem = pal.PalDModem(line.LineConfig((WIDTH, HEIGHT)))
+    comp = testing.synthetic_composite(sample_frames, HEIGHT, WIDTH, seed=1234)
+    cores = os.cpu_count() or 1
+    t0 = time.perf_counter()
+    cm_oracle.demodulate_frames_f32(modem, comp[:max(1, sample_frames // 8)], 0, 1)
+    t1 = time.perf_counter()
+    single = max(1, sample_frames // 8) * WIDTH * HEIGHT / (t1 - t0) / 1e6
+    t0 = time.perf_counter()
+    cm_oracle.demodulate_frames_f32(modem, comp, 0, min(cores, sample_frames))
+    t1 = time.perf_counter()
+    multi = sample_frames * WIDTH * HEIGHT / (t1 - t0) / 1e6
+    model = ''
+    try:
+        with open('/proc/cpuinfo') as fh:
+            for ln in fh:
+                if ln.startswith('model name'):
+                    model = ln.split(':', 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    return {'value': round(multi, 3), 'unit': 'Mpixels/s', 'cores': min(cores, sample_frames), 'kind': 'port',
+            'single_thread_value': round(single, 3), 'cpu': model,
+            'sample': '%d frames 720x576 PAL-D demodulate, float64 C++ oracle (oracle/cm_oracle.cpp), frames sharded '
+                      'over threads; single-thread figure on %d frame(s). Reference itself (numpy/scipy, 1 core, '
+                      'survey container): 0.52 Mpixels/s' % (sample_frames, max(1, sample_frames // 8))}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--frames', type=int, default=1000, help='frames per GPU per step')
+    ap.add_argument('--cpu-sample', type=int, default=32, help='frames of the CPU baseline sample (0 = skip)')
+    args = ap.parse_args()
+
+    import torch
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit('--gpus %d needs torch.distributed.run with --nproc-per-node %d (WORLD_SIZE=%d)'
+                         % (args.gpus, args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs a GPU: the product path has no CPU implementation')
+    torch.cuda.set_device(local_rank)
+    device = torch.device('cuda', local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group('nccl', device_id=device)
+
+    from color_modem_amd import image, line
+    from color_modem_amd.color import pal
+    modem = pal.PalDModem(line.LineConfig((WIDTH, HEIGHT)))
+    eng = image.ImageModem(modem)._engine()
+    frames = args.frames
+    comp = synthetic_stream(torch, frames, 1234 + 7919 * rank, device)
+    out = torch.empty((frames, 3, HEIGHT, WIDTH), dtype=torch.float32, device=device)
+    first_frame = rank * frames  # every rank continues the frame numbering: all four PAL phases are exercised
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        eng.demodulate_frames(comp, first_frame, out=out)
+    barrier()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for a, b in ev:
+        a.record()                      # same stream the library launches on (torch's current stream)
+        eng.demodulate_frames(comp, first_frame, out=out)
+        b.record()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    kernel_ms = [a.elapsed_time(b) for a, b in ev]
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        px_step = frames * WIDTH * HEIGHT
+        value = world * px_step * args.steps / elapsed / 1e6
+        mean_kernel_ms = sum(kernel_ms) / len(kernel_ms)
+        achieved = BYTES_PER_PIXEL * px_step / (mean_kernel_ms * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, 'profiles', 'traffic.json')
+        if os.path.exists(tpath):
+            with open(tpath) as fh:
+                tj = json.load(fh)
+            if tj.get('frames') == frames:
+                traffic = tj.get('hbm_bytes_per_launch')
+        res = {
+            'metric': 'Mpixels/s demodulated (720x576 PAL, 2D comb)',
+            'value': round(value, 1), 'unit': 'Mpixels/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': round(elapsed / args.steps * 1e3, 4), 'higher_is_better': True, 'scaling': 'weak',
+            'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': 'PAL-BG 2D comb (PalDModem) demodulate, 720x576, %d-frame synthetic stream per GPU, '
+                                   'float32 planar in HBM' % frames,
+                       'frames_per_gpu': frames, 'parallelism': 'frames sharded, one stream per GPU, no data-path collective',
+                       'kernel': eng.describe()},
+            'roofline': {'bound': 'hbm', 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
+                         'frac': round(achieved / HBM_PEAK_GBPS, 4), 'traffic': traffic,
+                         'kernel_ms': round(mean_kernel_ms, 4), 'algorithmic_bytes_per_launch': BYTES_PER_PIXEL * px_step,
+                         'note': 'VALU-bound in practice: ~211 vector instructions per pixel (SURVEY.md D5); see DESIGN.md'},
+        }
+        if world == 1 and args.cpu_sample > 0:
+            res['cpu_baseline'] = cpu_baseline(args.cpu_sample)
+        print(json.dumps(res))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -44,7 +44,9 @@ class LineStandard(collections.namedtuple('LineStandard', _FIELDS)):
         fitting = [std for std in cls.presets() if std.active_lines >= active_lines]
         if not fitting:
             raise IndexError('No supported line standard supports %d lines' % (active_lines,))
-        return min(fitting, key=lambda std: std.active_lines)
+        smallest = min(std.active_lines for std in fitting)
+        # among equally sized standards the reference ends up with the one defined last
+        return [std for std in fitting if std.active_lines == smallest][-1]
 
 
 LineStandard.BAIRD_405 = LineStandard(25.0, 405, 16, 203, 218, 405, 1.2)

@@ -1,0 +1,142 @@
+# -*- coding: utf-8 -*-
+"""Host-side logic (no GPU): the scipy-based design code and the line/carrier bookkeeping of
+color_modem_amd against the constants the reference derives (tests/golden/plans.json)."""
+import numpy
+import pytest
+
+import stacks
+from color_modem_amd import line, plan
+from color_modem_amd.color import ntsc, pal, secam
+
+PLANS = stacks.plans()
+
+
+def check_filter(f, ref, name):
+    assert f.shift == ref['shift'], name
+    numpy.testing.assert_allclose(f.b, [float(v) for v in ref['b']], rtol=0, atol=1e-14, err_msg=name)
+    numpy.testing.assert_allclose(f.a, [float(v) for v in ref['a']], rtol=0, atol=1e-14, err_msg=name)
+    assert abs(f.phase_shift - float(ref['phase_shift'])) < 1e-12, name
+    # the cascade form handed to the device is the same transfer function
+    b, a = numpy.array([1.0]), numpy.array([1.0])
+    for row in f.sos():
+        b, a = numpy.convolve(b, row[:3]), numpy.convolve(a, row[3:])
+    n = max(len(f.b), len(f.a))
+    numpy.testing.assert_allclose(numpy.trim_zeros(b, 'b'), f.b, rtol=0, atol=1e-12, err_msg=name + ' sos')
+    numpy.testing.assert_allclose(numpy.trim_zeros(a, 'b'), f.a, rtol=0, atol=1e-12, err_msg=name + ' sos')
+    assert n <= 9
+
+
+def check_qam(backend, ref, height):
+    assert repr(float(backend.line_config.fs)) == ref['fs']
+    assert abs(backend.qam.carrier_phase_step - float(ref['carrier_phase_step'])) < 1e-15
+    assert abs(backend.line_shift - float(ref['line_shift'])) < 1e-13
+    assert abs(backend.frame_shift - float(ref['frame_shift'])) < 1e-13
+    assert backend.frame_cycle == ref['frame_cycle']
+    for key, attr in (('precorrect', '_chroma_precorrect_lowpass'), ('extract2x', '_extract_chroma2x'),
+                      ('remove2x', '_remove_chroma2x'), ('demod_lp', '_demod_lowpass')):
+        check_filter(getattr(backend.qam, attr), ref[key], key)
+    for f, row in enumerate(ref['start_phase']):
+        for y, v in enumerate(row):
+            assert abs(backend.start_phase(f, y) - float(v)) < 1e-12, (f, y)
+            assert backend.line_config.is_alternate_line(f, y) == ref['alt'][f][y]
+    assert [backend.line_config.analog_line(y) for y in range(len(ref['analog_line']))] == ref['analog_line']
+
+
+def test_pal_plan_constants():
+    m = pal.PalDModem(line.LineConfig((720, 576)))
+    ref = PLANS['pal_720x576']
+    check_qam(m.backend, ref, 576)
+    check_filter(m._filter, ref['pald_lp'], 'pald_lp')
+    assert abs(m._sin_factor - float(ref['sin_factor'])) < 1e-15
+    assert abs(m._cos_factor - float(ref['cos_factor'])) < 1e-15
+
+
+def test_ntsc_plan_constants():
+    """NTSC-M needs the pre-validation iirdesign behaviour; goldens were made with the same shim."""
+    m = ntsc.NtscCombModem(line.LineConfig((720, 480)))
+    ref = PLANS['ntsc_720x480']
+    check_qam(m.backend, ref, 480)
+    assert abs(m._factor - float(ref['comb_factor'])) < 1e-15
+
+
+def test_secam_plan_constants():
+    m = secam.SecamModem(line.LineConfig((720, 576)))
+    ref = PLANS['secam_720x576']
+    for key, attr in (('fsc_dr', '_fsc_dr'), ('fsc_db', '_fsc_db'), ('fdev_dr', '_fdev_dr'), ('fdev_db', '_fdev_db'),
+                      ('flimit_min', '_flimit_min'), ('flimit_max', '_flimit_max'), ('bell_f0', '_bell_f0')):
+        assert abs(getattr(m, attr) - float(ref[key])) < 1e-15, key
+    for key, f in (('precorrect_lp', m._chroma_precorrect_lowpass), ('lf_precorrect', m._chroma_precorrect),
+                   ('lf_reverse', m._reverse_chroma_precorrect), ('bell', m._chroma_demod_bell),
+                   ('chroma_bp', m._chroma_demod_chroma_filter), ('luma_bs', m._chroma_demod_luma_filter),
+                   ('fm_lp', m._chroma_demod._lowpass)):
+        check_filter(f, ref[key], key)
+    assert abs(m._chroma_demod._fc - float(ref['fm_fc'])) < 1e-15
+    for f, row in enumerate(ref['start_phase_inverted']):
+        for y, v in enumerate(row):
+            assert m._start_phase_inverted(f, y) == v
+
+
+def test_resample_fir_matches_scipy_and_oracle():
+    import ctypes
+    from oracle import cm_oracle
+    h_ref = numpy.array([float(v) for v in PLANS['resample_fir']])
+    numpy.testing.assert_allclose(plan.resample_fir(), h_ref, rtol=0, atol=1e-17)
+    h = numpy.empty(41)
+    cm_oracle.lib().orc_firwin41(h.ctypes.data_as(ctypes.POINTER(ctypes.c_double)))
+    numpy.testing.assert_allclose(h, h_ref, rtol=0, atol=1e-15)  # own Kaiser/I0 evaluation vs scipy: 1-2 ulp
+
+
+def test_oracle_primitives_match_scipy():
+    import ctypes
+    import scipy.signal
+    from oracle import cm_oracle
+    dp = ctypes.POINTER(ctypes.c_double)
+    rng = numpy.random.default_rng(5)
+    for n in (1, 2, 7, 40, 720, 737):
+        x = rng.standard_normal(n)
+        up = numpy.empty(2 * n)
+        cm_oracle.lib().orc_resample_up2(x.ctypes.data_as(dp), n, up.ctypes.data_as(dp))
+        numpy.testing.assert_allclose(up, scipy.signal.resample_poly(x, 2, 1), rtol=0, atol=1e-14)
+        dn = numpy.empty((n + 1) // 2)
+        k = cm_oracle.lib().orc_resample_dn2(x.ctypes.data_as(dp), n, dn.ctypes.data_as(dp))
+        assert k == len(dn)
+        numpy.testing.assert_allclose(dn, scipy.signal.resample_poly(x, 1, 2), rtol=0, atol=1e-14)
+
+
+def test_line_standard_detect_and_errors():
+    assert line.LineStandard.detect(480) is line.LineStandard.NTSC_525
+    assert line.LineStandard.detect(576) is line.LineStandard.GERBER_625
+    assert line.LineStandard.detect(376) is line.LineStandard.BAIRD_405
+    assert line.LineStandard.detect(405) is line.LineStandard.NTSC_525
+    assert line.LineStandard.detect(738) is line.LineStandard.FRENCH_819
+    assert line.LineStandard.detect(760) is line.LineStandard.BELGIAN_819
+    with pytest.raises(IndexError):
+        line.LineStandard.detect(2000)
+    lc = line.LineConfig((720, 576))
+    assert lc.fs == 13.5e6
+    assert [lc.analog_line(y) for y in range(4)] == [23, 336, 24, 337]
+
+
+def test_lane_tables_shapes_and_regimes():
+    for name, size in (('pal_d', (720, 576)), ('pal_3d', (720, 576)), ('ntsc_comb_3d', (720, 480)), ('pal_s', (720, 16))):
+        bp = plan.build_plan(stacks.make(name, size))
+        d = bp.desc
+        assert d.demod_main.n_lines >= size[1] + 2 * d.demodulation_delay
+        assert d.demod_main.frame_cycle in (2, 4)
+        tab = numpy.ctypeslib.as_array(d.demod_main.table, shape=(d.demod_main.frame_cycle, 3, d.demod_main.n_lines,
+                                                                   plan.CM_LANE_DOUBLES))
+        assert numpy.all(numpy.isfinite(tab))
+        # detector phase is a unit vector wherever it is defined
+        r = numpy.hypot(tab[..., 0], tab[..., 1])
+        assert numpy.all((numpy.abs(r - 1.0) < 1e-12) | (r == 0.0))
+    assert plan.build_plan(stacks.make('pal_d', (720, 576))).desc.first_is_plain == 1
+    assert plan.build_plan(stacks.make('pal_s', (720, 576))).desc.main_luma_bandstop == 1
+
+
+def test_unsupported_options_fail_loudly():
+    from color_modem_amd import comb
+    lc = line.LineConfig((720, 576))
+    with pytest.raises(NotImplementedError):
+        pal.PalDModem(lc, notch=2.0)
+    with pytest.raises(NotImplementedError):
+        comb.SimpleCombModem(ntsc.NtscCombModem(line.LineConfig((720, 480))), avg=comb.minavg)._stack()

@@ -1,0 +1,60 @@
+# -*- coding: utf-8 -*-
+"""The streaming stages of color_modem_amd/csrc/cm_stages.h, compiled for the host (tests/sim), against
+the oracle: float64 proves the stream schedule / edge handling / coefficient tables, float32 bounds the
+rounding error the device kernels can have.  No GPU needed."""
+import ctypes
+import os
+
+import numpy
+import pytest
+
+import stacks
+from color_modem_amd import plan, testing
+
+SIM = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'sim', 'libcm_sim.so')
+
+
+@pytest.fixture(scope='module')
+def sim():
+    import __graft_entry__
+    __graft_entry__.build()
+    L = ctypes.CDLL(SIM)
+    dp = ctypes.POINTER(ctypes.c_double)
+    for fn in (L.cm_sim_demodulate_run_f64, L.cm_sim_demodulate_run_f32):
+        fn.argtypes = [ctypes.POINTER(plan.PlanDesc), dp, dp] + [ctypes.c_int] * 5
+    L.cm_sim_last_error.restype = ctypes.c_char_p
+    return L
+
+
+def run(L, bp, comp, frame, first_line, k0, f32, mid=1):
+    n, w = comp.shape
+    comp = numpy.ascontiguousarray(comp, dtype=numpy.float64)
+    out = numpy.zeros((n, 3, w))
+    dp = ctypes.POINTER(ctypes.c_double)
+    fn = L.cm_sim_demodulate_run_f32 if f32 else L.cm_sim_demodulate_run_f64
+    rc = fn(ctypes.byref(bp.desc), comp.ctypes.data_as(dp), out.ctypes.data_as(dp), n, frame, first_line, k0, mid)
+    assert rc == 0, L.cm_sim_last_error()
+    return out
+
+
+@pytest.mark.parametrize('stack,size', [('pal_d', (720, 576)), ('pal_s', (720, 576)), ('pal_3d', (720, 576)),
+                                        ('ntsc', (720, 480)), ('ntsc_comb', (720, 480)),
+                                        ('ntsc_comb_simple', (720, 480)), ('ntsc_comb_3d', (720, 480)),
+                                        ('pal_d', (704, 8))])
+@pytest.mark.parametrize('frame,first_line', [(0, 0), (1, 1), (3, 2)])
+def test_streaming_matches_oracle(sim, stack, size, frame, first_line):
+    from oracle import cm_oracle
+    modem = stacks.make(stack, size, explicit=size[1] < 400)
+    bp = plan.build_plan(modem)
+    n = 5
+    comp = testing.synthetic_composite(1, n, size[0], seed=17 + frame)[0]
+    orc = cm_oracle.OracleModem(modem)
+    ref = numpy.stack([numpy.stack(orc.demodulate(frame, first_line + 2 * i, comp[i].astype(numpy.float64)))
+                       for i in range(n)])
+    o64 = run(sim, bp, comp, frame, first_line, 0, f32=False)
+    o64_edge = run(sim, bp, comp, frame, first_line, 0, f32=False, mid=0)
+    o32 = run(sim, bp, comp, frame, first_line, 0, f32=True)
+    assert numpy.array_equal(o64, o64_edge), 'edge-free body differs from the guarded body'
+    for i in range(n):
+        assert stacks.rel_err(o64[i], ref[i]) < 1e-11, (stack, i)
+        assert stacks.rel_err(o32[i], ref[i]) < 2e-6, (stack, i)
