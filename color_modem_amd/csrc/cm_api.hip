@@ -9,6 +9,7 @@
 
 #include "../../include/color_modem_hip.h"
 #include "cm_kernels.h"
+#include "cm_mod_kernels.h"
 #include "cm_plan.h"
 
 using namespace cm;
@@ -56,6 +57,8 @@ struct Pass {
 
 }  // namespace
 
+typedef int (*ModLaunchFn)(const Geom &g, const void *k, int blocks, hipStream_t);
+
 struct cm_plan {
     cm_plan_desc desc;
     int device = 0;
@@ -63,6 +66,12 @@ struct cm_plan {
     LaunchFn fn = nullptr;
     bool has_first = false;
     Pass main, first;
+    // modulator
+    ModLaunchFn mod_fn = nullptr;
+    std::vector<unsigned char> mod_k;
+    ModLaneK<float> *mod_lanes = nullptr;
+    int mod_cycle = 0, mod_n_lines = 0, mod_depth = 0;
+    std::string mod_name, demod_error;
 };
 
 namespace {
@@ -149,6 +158,58 @@ bool select_kernels(cm_plan *p, const cm_plan_desc &d, std::string &err) {
     return false;
 }
 
+template <int NP, int SP, int DEPTH>
+int launch_qam_mod(const Geom &g, const void *kv, int blocks, hipStream_t stream) {
+    ModArgs<NP> a;
+    a.g = g;
+    a.k = *static_cast<const ModK<float, NP> *>(kv);
+    hipLaunchKernelGGL((qam_mod_kernel<NP, SP, DEPTH>), dim3(blocks), dim3(64), 0, stream, a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(CM_ERR_LAUNCH, std::string("qam_mod_kernel launch: ") + hipGetErrorString(e));
+    return CM_OK;
+}
+
+// Modulator of the QAM systems (PAL / NTSC); absent tables leave the plan demodulate-only.
+bool select_modulator(cm_plan *p, const cm_plan_desc &d, std::string &err) {
+    const cm_lane_table &tb = d.mod_main;
+    if (!tb.table) return true;
+    if (d.precorrect.n_sections != 1 || d.precorrect.shift != 2) {
+        err = "no modulator instance for this pre-correction filter (built: one section, shift 2)";
+        return false;
+    }
+    ModK<float, 1> k;
+    double g_pre;
+    k.width = d.width;
+    k.s_p = d.precorrect.shift;
+    if (!convert_sos<float, 1>(d.precorrect, FORM_GEN, k.pre, g_pre, err, "precorrect")) return false;
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) k.e[i][j] = (float)d.encode_matrix[3 * i + j];
+    p->mod_k.resize(sizeof k);
+    std::memcpy(p->mod_k.data(), &k, sizeof k);
+    const size_t n = (size_t)tb.frame_cycle * 3 * tb.n_lines;
+    std::vector<ModLaneK<float>> host(n);
+    for (size_t i = 0; i < n; ++i) {
+        const double *e = tb.table + i * CM_LANE_DOUBLES;
+        ModLaneK<float> &l = host[i];
+        l.sph = (float)(e[0] * g_pre);
+        l.cph = (float)(e[1] * g_pre);
+        l.vsph = (float)(e[0] * g_pre * e[6]);
+        l.vcph = (float)(e[1] * g_pre * e[6]);
+        l.wy0 = (float)e[2]; l.wy1 = (float)e[3]; l.wc0 = (float)e[4]; l.wc1 = (float)e[5];
+    }
+    if (hipMalloc((void **)&p->mod_lanes, n * sizeof(ModLaneK<float>)) != hipSuccess ||
+        hipMemcpy(p->mod_lanes, host.data(), n * sizeof(ModLaneK<float>), hipMemcpyHostToDevice) != hipSuccess) {
+        err = "device allocation / upload of the modulator table failed";
+        return false;
+    }
+    p->mod_cycle = tb.frame_cycle;
+    p->mod_n_lines = tb.n_lines;
+    p->mod_depth = d.modulation_delay ? 1 : 0;
+    p->mod_fn = p->mod_depth ? launch_qam_mod<1, 2, 1> : launch_qam_mod<1, 2, 0>;
+    p->mod_name = p->mod_depth ? "qam_mod_kernel<line averaging>" : "qam_mod_kernel";
+    return true;
+}
+
 void finish_geom(const cm_plan *p, const Pass &pass, Geom &g) {
     g.lanes = pass.lanes;
     g.carrier4 = p->carrier4;
@@ -227,7 +288,15 @@ int cm_plan_create(const cm_plan_desc *desc, cm_plan **out) {
         cm_plan_destroy(p);
         return fail(CM_ERR_NO_DEVICE, "device allocation / upload of the carrier tables failed");
     }
-    if (!select_kernels(p, *desc, err)) {
+    // a plan is usable in one direction when only the other one lacks a kernel instance
+    std::string mod_err;
+    const bool have_demod = select_kernels(p, *desc, err);
+    const bool have_mod = select_modulator(p, *desc, mod_err) && p->mod_fn;
+    if (!have_demod) {
+        p->fn = nullptr;
+        p->demod_error = err;
+    }
+    if (!have_demod && !have_mod) {
         cm_plan_destroy(p);
         return fail(CM_ERR_UNSUPPORTED, err);
     }
@@ -241,6 +310,7 @@ void cm_plan_destroy(cm_plan *p) {
     if (p->carrier2) (void)hipFree(p->carrier2);
     if (p->main.lanes) (void)hipFree(p->main.lanes);
     if (p->first.lanes) (void)hipFree(p->first.lanes);
+    if (p->mod_lanes) (void)hipFree(p->mod_lanes);
     delete p;
 }
 
@@ -249,6 +319,7 @@ int cm_demodulate_frames(const cm_plan *p, const float *composite, float *rgb, i
     if (!p || !composite || !rgb) return fail(CM_ERR_INVALID, "null argument");
     if (n_frames < 0 || first_frame < 0) return fail(CM_ERR_INVALID, "negative frame count / number");
     if (n_frames == 0) return CM_OK;
+    if (!p->fn) return fail(CM_ERR_UNSUPPORTED, p->demod_error);
     const cm_plan_desc &d = p->desc;
     const int W = d.width, H = d.height, D = d.demodulation_delay;
     Geom g;
@@ -258,6 +329,7 @@ int cm_demodulate_frames(const cm_plan *p, const float *composite, float *rgb, i
     g.W = W;
     g.H = H;
     g.in_frame_stride = (long long)W * H;
+    g.in_row_stride = W;
     g.out_plane_stride = (long long)W * H;
     g.out_frame_stride = 3LL * W * H;
     g.out_row_stride = W;
@@ -290,6 +362,7 @@ int cm_demodulate_run(const cm_plan *p, const float *composite, float *rgb, int3
     if (n_calls < 0 || frame < 0 || k0 < 0) return fail(CM_ERR_INVALID, "negative count / frame / k0");
     if (n_calls == 0) return CM_OK;
     if (first_line < 0) return fail(CM_ERR_INVALID, "negative line number");
+    if (!p->fn) return fail(CM_ERR_UNSUPPORTED, p->demod_error);
     const cm_plan_desc &d = p->desc;
     Geom g;
     std::memset(&g, 0, sizeof g);
@@ -325,11 +398,78 @@ int cm_demodulate_run(const cm_plan *p, const float *composite, float *rgb, int3
     return run_plan(p, g, s, with_first, (hipStream_t)stream);
 }
 
-int cm_modulate_frames(const cm_plan *, const float *, float *, int64_t, int64_t, void *) {
-    return fail(CM_ERR_UNSUPPORTED, "modulators are not built yet");
+static int run_mod(const cm_plan *p, Geom g, hipStream_t stream) {
+    if (!p->mod_fn) return fail(CM_ERR_UNSUPPORTED, "this plan has no modulator");
+    g.lanes = reinterpret_cast<const LaneK<float> *>(p->mod_lanes);
+    g.carrier4 = p->carrier4;
+    g.carrier2 = p->carrier2;
+    g.cycle = p->mod_cycle;
+    g.n_lines = p->mod_n_lines;
+    long long blocks = (g.total_calls + (64 - p->mod_depth) - 1) / (64 - p->mod_depth);
+    if (blocks <= 0) return CM_OK;
+    if (blocks > 0x7fffffffLL) return fail(CM_ERR_INVALID, "batch too large for one launch");
+    return p->mod_fn(g, p->mod_k.data(), (int)blocks, stream);
 }
-int cm_modulate_run(const cm_plan *, const float *, float *, int32_t, int32_t, int32_t, int32_t, void *) {
-    return fail(CM_ERR_UNSUPPORTED, "modulators are not built yet");
+
+int cm_modulate_frames(const cm_plan *p, const float *rgb, float *composite, int64_t n_frames, int64_t first_frame,
+                       void *stream) {
+    if (!p || !rgb || !composite) return fail(CM_ERR_INVALID, "null argument");
+    if (n_frames < 0 || first_frame < 0) return fail(CM_ERR_INVALID, "negative frame count / number");
+    if (n_frames == 0) return CM_OK;
+    if (!p->mod_fn) return fail(CM_ERR_UNSUPPORTED, "this plan has no modulator");
+    const cm_plan_desc &d = p->desc;
+    const int W = d.width, H = d.height, D = d.modulation_delay;
+    Geom g;
+    std::memset(&g, 0, sizeof g);
+    g.in = rgb;
+    g.out = composite;
+    g.W = W;
+    g.H = H;
+    g.in_frame_stride = 3LL * W * H;
+    g.in_plane_stride = (long long)W * H;
+    g.in_row_stride = W;
+    g.out_frame_stride = (long long)W * H;
+    g.out_row_stride = W;
+    g.first_frame = (int)(first_frame % (int64_t)p->mod_cycle);
+    const int rows0 = (H + 1) / 2, rows1 = H / 2;
+    g.calls_run0 = rows0 + D;
+    const int calls_run1 = rows1 > 0 ? rows1 + D : 0;
+    g.calls_per_frame = g.calls_run0 + calls_run1;
+    g.runs_per_frame = rows1 > 0 ? 2 : 1;
+    g.first_line[0] = 0;
+    g.first_line[1] = 1;
+    g.delay = D;
+    g.total_calls = n_frames * g.calls_per_frame;
+    if (H - 1 + 2 * D >= p->mod_n_lines) return fail(CM_ERR_INVALID, "line number beyond the plan's phase tables");
+    return run_mod(p, g, (hipStream_t)stream);
+}
+
+int cm_modulate_run(const cm_plan *p, const float *rgb, float *composite, int32_t n_calls, int32_t frame, int32_t first_line,
+                    int32_t k0, void *stream) {
+    if (!p || !rgb || !composite) return fail(CM_ERR_INVALID, "null argument");
+    if (n_calls < 0 || frame < 0 || k0 < 0 || first_line < 0) return fail(CM_ERR_INVALID, "negative count / frame / line / k0");
+    if (n_calls == 0) return CM_OK;
+    if (!p->mod_fn) return fail(CM_ERR_UNSUPPORTED, "this plan has no modulator");
+    const cm_plan_desc &d = p->desc;
+    Geom g;
+    std::memset(&g, 0, sizeof g);
+    g.in = rgb;
+    g.out = composite;
+    g.W = d.width;
+    g.H = n_calls;
+    g.in_plane_stride = d.width;
+    g.in_row_stride = 3LL * d.width;
+    g.out_row_stride = d.width;
+    g.rows_mode = 1;
+    g.first_frame = frame % p->mod_cycle;
+    g.calls_run0 = n_calls;
+    g.calls_per_frame = n_calls;
+    g.runs_per_frame = 1;
+    g.first_line[0] = g.first_line[1] = first_line;
+    g.k0 = k0;
+    g.total_calls = n_calls;
+    if (first_line + 2 * (n_calls - 1) >= p->mod_n_lines) return fail(CM_ERR_INVALID, "line number beyond the plan's phase tables");
+    return run_mod(p, g, (hipStream_t)stream);
 }
 
 int cm_plan_describe(const cm_plan *p, char *buf, int32_t buf_len) {

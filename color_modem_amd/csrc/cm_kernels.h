@@ -33,7 +33,8 @@ struct Geom {
     const LaneK<float> *lanes;  // [cycle][3][n_lines]
     const float *carrier4;      // {C[2n], S[2n], C[2n+1], S[2n+1]}, n < W   (C/S = cos/sin(m cps))
     const float *carrier2;      // {C[2n], S[2n]}, n < W
-    long long in_frame_stride, out_frame_stride, out_plane_stride, out_row_stride;
+    long long in_frame_stride, in_plane_stride, in_row_stride;   // in_row_stride = 0 means W
+    long long out_frame_stride, out_plane_stride, out_row_stride;
     long long total_calls;      // main pass: n_frames * calls_per_frame; sparse pass: n_frames * runs_per_frame
     int first_frame, cycle, n_lines;
     int W, H;
@@ -198,18 +199,13 @@ __device__ __forceinline__ void fill_tile(const Geom &g, lds_float *itile, const
     }
 }
 
-template <class Cfg>
-__device__ __forceinline__ void run_lane(const Geom &g, const DemodK<float, typename Cfg::S> &k, int block, lds_float *lds) {
-    typedef DemodLane<Cfg> Lane;
-    typedef typename Cfg::S S;
-    constexpr int FRONT = Cfg::FRONT, DEPTH = Cfg::DEPTH, kTile = Cfg::TILE;
-    constexpr bool BSF = Cfg::BSF;
-    lds_float *itile = lds;
-    lds_float *otile_base = lds + kLdsIn;
-    lds_float *yring = lds + kLdsIn + Cfg::kLdsOut;
-
-    const int lane = threadIdx.x;
-    // ---- which call does this lane own -------------------------------------------------------
+// Which call of the flattened [frame][run][call] list a lane owns, and where its rows live.
+struct LaneCall {
+    long long frame;
+    int line, kk, regime, src_row, prev_row, out_row;
+    bool store_ok;
+};
+__device__ __forceinline__ LaneCall locate_call(const Geom &g, int block, int depth, int lane) {
     long long c;
     bool active;
     long long frame;
@@ -222,8 +218,8 @@ __device__ __forceinline__ void run_lane(const Geom &g, const DemodK<float, type
         run = (int)(c - frame * g.runs_per_frame);
         i = 0;
     } else {
-        c = (long long)block * (64 - DEPTH) - DEPTH + lane;
-        active = lane >= DEPTH && c < g.total_calls;
+        c = (long long)block * (64 - depth) - depth + lane;
+        active = lane >= depth && c < g.total_calls;
         if (c < 0) c = 0;
         if (c >= g.total_calls) c = g.total_calls - 1;
         frame = c / g.calls_per_frame;
@@ -231,25 +227,45 @@ __device__ __forceinline__ void run_lane(const Geom &g, const DemodK<float, type
         run = rem >= g.calls_run0 ? 1 : 0;
         i = rem - (run ? g.calls_run0 : 0);
     }
-    const int line = g.first_line[run] + 2 * i;
-    const int kk = g.k0 + i;
-    const int regime = kk < 2 ? kk : 2;
-    const int dy = (g.luma_prev_bits >> regime) & 1;
-    int src_row, luma_row, out_row;
-    bool store_ok = active && !(g.skip_first && kk == 0);
+    LaneCall r;
+    r.frame = frame;
+    r.line = g.first_line[run] + 2 * i;
+    r.kk = g.k0 + i;
+    r.regime = r.kk < 2 ? r.kk : 2;
+    r.store_ok = active && !(g.skip_first && r.kk == 0);
     if (g.rows_mode) {
-        src_row = i;
-        luma_row = i - dy < 0 ? i : i - dy;
-        out_row = i;
+        r.src_row = i;
+        r.prev_row = i - 1 < 0 ? i : i - 1;
+        r.out_row = i;
     } else {
-        src_row = line;
-        if (src_row >= g.H) src_row -= 2 * ((src_row - g.H) / 2 + 1);  // image.py:80-81: step back by 2 until inside
-        luma_row = line - 2 * dy;
-        if (luma_row < 0) luma_row = src_row;
-        if (luma_row >= g.H) luma_row -= 2 * ((luma_row - g.H) / 2 + 1);
-        out_row = line - 2 * g.delay;
-        store_ok = store_ok && i >= g.delay && out_row >= 0 && out_row < g.H;
+        r.src_row = r.line;
+        if (r.src_row >= g.H) r.src_row -= 2 * ((r.src_row - g.H) / 2 + 1);  // image.py:80-81: step back by 2 until inside
+        r.prev_row = r.line - 2;
+        if (r.prev_row < 0) r.prev_row = r.src_row;
+        if (r.prev_row >= g.H) r.prev_row -= 2 * ((r.prev_row - g.H) / 2 + 1);
+        r.out_row = r.line - 2 * g.delay;
+        r.store_ok = r.store_ok && i >= g.delay && r.out_row >= 0 && r.out_row < g.H;
     }
+    return r;
+}
+
+template <class Cfg>
+__device__ __forceinline__ void run_lane(const Geom &g, const DemodK<float, typename Cfg::S> &k, int block, lds_float *lds) {
+    typedef DemodLane<Cfg> Lane;
+    typedef typename Cfg::S S;
+    constexpr int FRONT = Cfg::FRONT, DEPTH = Cfg::DEPTH, kTile = Cfg::TILE;
+    constexpr bool BSF = Cfg::BSF;
+    lds_float *itile = lds;
+    lds_float *otile_base = lds + kLdsIn;
+    lds_float *yring = lds + kLdsIn + Cfg::kLdsOut;
+
+    const int lane = threadIdx.x;
+    const LaneCall lc = locate_call(g, block, DEPTH, lane);
+    const long long frame = lc.frame;
+    const int line = lc.line, regime = lc.regime;
+    const int dy = (g.luma_prev_bits >> regime) & 1;
+    const int src_row = lc.src_row, luma_row = dy ? lc.prev_row : lc.src_row, out_row = lc.out_row;
+    const bool store_ok = lc.store_ok;
     Lane L;
     const float *xp = g.in + frame * g.in_frame_stride + (long long)src_row * g.W;
     L.lp = g.in + frame * g.in_frame_stride + (long long)luma_row * g.W;

@@ -27,6 +27,7 @@
 
 #if defined(__HIPCC__)
 #include <hip/hip_runtime.h>
+#include <cmath>
 #define CM_HD __host__ __device__ __forceinline__
 #else
 #include <cmath>
@@ -49,19 +50,24 @@ struct Sys {
 // fma3: d = c * x + acc with d allowed to differ from acc.  On the device this must be the
 // VOP3 form: hipcc otherwise picks the 2-address v_fmac and pays one v_mov per tap to rotate
 // the accumulators (profiles/r01_ubench_valu.txt, "chain" rows).
+CM_HD float fma3(float c, float x, float acc) {
 #if defined(__HIP_DEVICE_COMPILE__)
-__device__ __forceinline__ float fma3(float c, float x, float acc) {
     float d;
     asm("v_fma_f32 %0, %1, %2, %3" : "=v"(d) : "s"(c), "v"(x), "v"(acc));
     return d;
-}
-__device__ __forceinline__ float fmaf_(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 #else
-inline float fma3(float c, float x, float acc) { return std::fma(c, x, acc); }
-inline double fma3(double c, double x, double acc) { return c * x + acc; }
-inline float fmaf_(float a, float b, float c) { return std::fma(a, b, c); }
-inline double fmaf_(double a, double b, double c) { return a * b + c; }
+    return std::fma(c, x, acc);
 #endif
+}
+CM_HD float fmaf_(float a, float b, float c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_fmaf(a, b, c);
+#else
+    return std::fma(a, b, c);
+#endif
+}
+CM_HD double fma3(double c, double x, double acc) { return c * x + acc; }
+CM_HD double fmaf_(double a, double b, double c) { return a * b + c; }
 
 // ---- uniform coefficient blocks -----------------------------------------------------------
 template <typename T>
@@ -409,6 +415,51 @@ struct DemodBack {
         o.g = fmaf_(k.m[1][0], y, fmaf_(k.m[1][1], u_d, k.m[1][2] * v_d));
         o.b = fmaf_(k.m[2][0], y, fmaf_(k.m[2][1], u_d, k.m[2][2] * v_d));
         return o;
+    }
+};
+
+// =============================================================================================
+// QAM modulator (ref qam.py:20-32 behind pal.py:48-52 / ntsc.py:43-45; encoder-side line averaging
+// of comb.py:141-152 folded into the row weights):
+//   composite[n] = y[n] + sin(phi + 2 n cps) * F_pre(u)[n] + (+-cos(phi + 2 n cps)) * F_pre(v)[n]
+// F_pre is FilterFunction(pre-correction low-pass): the stream index of its output is n7 = n - s_p.
+// =============================================================================================
+template <typename T, int NP>
+struct ModK {
+    int32_t width, s_p;
+    SosK<T, NP> pre;
+    T e[3][3];  // (y, u, v) = e . (r, g, b)
+};
+
+template <typename T>
+struct ModLaneK {
+    T sph, cph;      // sin/cos of the start phase of the modulated line, times the pre-filter gain
+    T vsph, vcph;    // the same two times the V-switch sign (pal.py:50-51)
+    T wy0, wy1;      // luma  = wy0 * own row + wy1 * previous call's row   (comb.py:147)
+    T wc0, wc1;      // chroma likewise                                     (comb.py:148-149)
+};
+
+template <typename T, int NP>
+struct QamModCore {
+    IirState<T, NP> pre_u, pre_v;
+    T u_last, v_last;
+    CM_HD void reset() {
+        pre_u.reset(); pre_v.reset();
+        u_last = v_last = T(0);
+    }
+    // n: index of (u, v); y_d = luma at n - s_p; car = {C[2 (n - s_p)], S[2 (n - s_p)]}
+    CM_HD T step(const ModK<T, NP> &k, const ModLaneK<T> &lk, int n, T y_d, T u, T v, const T car[2]) {
+        const int W = k.width;
+        T wu = T(0), wv = T(0);
+        if (n >= 0 && n < W + k.s_p) {
+            if (n == W - 1) { u_last = u; v_last = v; }
+            if (n >= W) { u = u_last; v = v_last; }
+            wu = iir_gen(pre_u, k.pre, u);
+            wv = iir_gen(pre_v, k.pre, v);
+        }
+        T sn = fmaf_(lk.sph, car[0], lk.cph * car[1]);
+        T cs = fmaf_(lk.vcph, car[0], -(lk.vsph * car[1]));
+        return y_d + fmaf_(sn, wu, cs * wv);
     }
 };
 

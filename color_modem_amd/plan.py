@@ -356,8 +356,8 @@ class QamTables(object):
         return tab
 
     def mod_table(self):
-        """[0] sin, [1] cos * V sign of the start phase of the modulated line; [2..5] row weights
-        (luma: current, previous; chroma: current, previous), ref comb.py:141-152."""
+        """[0] sin, [1] cos of the start phase of the modulated line; [2..5] row weights (luma: current,
+        previous; chroma: current, previous), ref comb.py:141-152; [6] V-switch sign (pal.py:50-51)."""
         n_lines = self.n_lines()
         tab = numpy.zeros((self.cycle, 3, n_lines, CM_LANE_DOUBLES))
         avg = self.mod_wrapper == 'color_averaging'
@@ -368,7 +368,8 @@ class QamTables(object):
                     p = self.phi(f, target)
                     e = tab[f, k, line]
                     e[0] = numpy.sin(p)
-                    e[1] = numpy.cos(p) * self.vsign(f, target)
+                    e[1] = numpy.cos(p)
+                    e[6] = self.vsign(f, target)
                     if avg and k >= 1:
                         e[2:6] = (0.0, 1.0, 0.5, 0.5)
                     else:

@@ -107,7 +107,9 @@ typedef struct {
     double encode_matrix[9]; /* (y, u, v) = M (r, g, b): pal.py:35-37, ntsc.py:30-32 */
     cm_lane_table demod_main;  /* main pass */
     cm_lane_table demod_first; /* plain pass for k == 0 (only regime 0 is read) */
-    cm_lane_table mod_main;    /* modulator: [0] sin, [1] cos of start phase (times V sign), [2..5] row weights */
+    cm_lane_table mod_main;    /* modulator: [0] sin, [1] cos of the start phase of the modulated line, [2] luma weight of the
+                                  call's own row, [3] of the previous call's row, [4], [5] chroma weights likewise
+                                  (comb.py:141-152), [6] V-switch sign */
 } cm_plan_desc;
 
 typedef struct cm_plan cm_plan;

@@ -18,6 +18,8 @@ STACKS = {
     'ntsc_comb': lambda lc: ntsc.NtscCombModem(lc),
     'ntsc_comb_simple': lambda lc: comb.SimpleCombModem(ntsc.NtscCombModem(lc)),
     'ntsc_comb_3d': lambda lc: comb.Simple3DCombModem(ntsc.NtscCombModem(lc)),
+    'pal_avg': lambda lc: comb.ColorAveragingModem(pal.PalSModem(lc)),
+    'ntsc_avg': lambda lc: comb.ColorAveragingModem(ntsc.NtscModem(lc)),
     'secam': lambda lc: secam.SecamModem(lc),
     'secam_avg': lambda lc: comb.ColorAveragingModem(secam.SecamModem(lc)),
 }

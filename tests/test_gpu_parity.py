@@ -66,3 +66,45 @@ def test_frames_demod_vs_oracle(stack, size, n_frames, first):
     want = cm_oracle.demodulate_frames_f32(modem, comp, first_frame=first, n_threads=8)
     for i in range(n_frames):
         assert stacks.rel_err(got[i], want[i]) < TOL, (stack, i)
+
+
+# ---- modulators ---------------------------------------------------------------------------------------
+MOD_FRAMES = [n for n in sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(stacks.GOLDEN, 'frames_mod_*.npz')))
+              if 'secam' not in n]
+
+
+@pytest.mark.parametrize('name', MOD_FRAMES)
+def test_frames_mod_golden(name):
+    g = stacks.load(name)
+    modem = stacks.make(name[len('frames_mod_'):], g['size'])
+    im = image.ImageModem(modem)
+    for i, f in enumerate(g['frames']):
+        out = im.modulate_frames(g['inp'][i:i + 1], first_frame=int(f))[0]
+        assert stacks.rel_err(out, g['out'][i]) < TOL, (name, int(f))
+
+
+@pytest.mark.parametrize('stack,size,n_frames,first', [
+    ('pal_s', (720, 576), 2, 1), ('ntsc', (720, 480), 2, 0), ('pal_avg', (720, 31), 3, 2), ('ntsc_avg', (704, 16), 2, 1),
+])
+def test_frames_mod_vs_oracle(stack, size, n_frames, first):
+    from oracle import cm_oracle
+    modem = stacks.make(stack, size)
+    rgb = testing.synthetic_rgb(n_frames, size[1], size[0], seed=40 + size[1])
+    got = image.ImageModem(modem).modulate_frames(rgb, first_frame=first)
+    want = cm_oracle.modulate_frames_f32(modem, rgb, first_frame=first, n_threads=8)
+    for i in range(n_frames):
+        assert stacks.rel_err(got[i], want[i]) < TOL, (stack, i)
+
+
+def test_rows_mod_protocol():
+    """Modem.modulate row by row, including the reset when a run is broken, against the oracle object."""
+    from oracle import cm_oracle
+    for stack in ('pal_s', 'pal_avg'):
+        modem = stacks.make(stack, (720, 576), explicit=False)
+        orc = cm_oracle.OracleModem(modem)
+        rgb = testing.synthetic_rgb(1, 8, 720, seed=61)[0]
+        seq = [(2, 0), (2, 2), (2, 4), (2, 9), (2, 11), (3, 13), (3, 15), (3, 17)]
+        for i, (f, y) in enumerate(seq):
+            got = modem.modulate(f, y, rgb[0, i], rgb[1, i], rgb[2, i])
+            want = orc.modulate(f, y, rgb[0, i], rgb[1, i], rgb[2, i])
+            assert stacks.rel_err(got, want) < TOL, (stack, f, y)
