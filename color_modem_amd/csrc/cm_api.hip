@@ -10,6 +10,7 @@
 #include "../../include/color_modem_hip.h"
 #include "cm_kernels.h"
 #include "cm_mod_kernels.h"
+#include "cm_secam_kernels.h"
 #include "cm_plan.h"
 
 using namespace cm;
@@ -72,6 +73,14 @@ struct cm_plan {
     ModLaneK<float> *mod_lanes = nullptr;
     int mod_cycle = 0, mod_n_lines = 0, mod_depth = 0;
     std::string mod_name, demod_error;
+    // SECAM
+    bool secam = false;
+    SecamDemodK<float> sd_k;
+    SecamDemodLaneK<float> *sd_lanes = nullptr;
+    float *fm_ref = nullptr;
+    int sd_cycle = 0, sd_n_lines = 0;
+    SecamModK<float, double> sm_k;
+    SecamModLaneK<float, double> *sm_lanes = nullptr;
 };
 
 namespace {
@@ -210,6 +219,85 @@ bool select_modulator(cm_plan *p, const cm_plan_desc &d, std::string &err) {
     return true;
 }
 
+template <class LaneT, class Conv>
+bool upload_lanes(const cm_lane_table &tb, LaneT **dev, Conv conv, std::string &err) {
+    const size_t n = (size_t)tb.frame_cycle * 3 * tb.n_lines;
+    std::vector<LaneT> host(n);
+    for (size_t i = 0; i < n; ++i) host[i] = conv(tb.table + i * CM_LANE_DOUBLES);
+    if (hipMalloc((void **)dev, n * sizeof(LaneT)) != hipSuccess ||
+        hipMemcpy(*dev, host.data(), n * sizeof(LaneT), hipMemcpyHostToDevice) != hipSuccess) {
+        err = "device allocation / upload of a lane table failed";
+        return false;
+    }
+    return true;
+}
+
+bool create_secam(cm_plan *p, const cm_plan_desc &d, std::string &err) {
+    p->secam = true;
+    if (d.secam.preroll >= kInTile) { err = "SECAM pre-roll longer than one input tile (width > 1319) is not built"; return false; }
+    if (!build_secam_demod_k<float>(d, p->sd_k, err)) return false;
+    if (!d.demod_main.table) { err = "demod_main table missing"; return false; }
+    if (!upload_lanes(d.demod_main, &p->sd_lanes, convert_secam_demod_lane<float>, err)) return false;
+    p->sd_cycle = d.demod_main.frame_cycle;
+    p->sd_n_lines = d.demod_main.n_lines;
+    std::vector<float> fm = build_fm_reference<float>(d.secam.fm_fc, d.width + d.secam.preroll);
+    if (hipMalloc((void **)&p->fm_ref, fm.size() * sizeof(float)) != hipSuccess ||
+        hipMemcpy(p->fm_ref, fm.data(), fm.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) {
+        err = "device allocation / upload of the FM reference failed";
+        return false;
+    }
+    if (d.mod_main.table) {
+        if (!build_secam_mod_k<float, double>(d, p->sm_k, err)) return false;
+        if (p->sm_k.s_p != 3) { err = "SECAM encoder is built for a pre-correction shift of 3"; return false; }
+        if (!upload_lanes(d.mod_main, &p->sm_lanes, convert_secam_mod_lane<float, double>, err)) return false;
+        p->mod_cycle = d.mod_main.frame_cycle;
+        p->mod_n_lines = d.mod_main.n_lines;
+        p->mod_depth = d.modulation_delay ? 1 : 0;
+    }
+    p->main.depth = 1;
+    p->main.name = "secam_demod_kernel";
+    return true;
+}
+
+int run_secam_demod(const cm_plan *p, Geom g, hipStream_t stream) {
+    g.lanes = reinterpret_cast<const LaneK<float> *>(p->sd_lanes);
+    g.carrier4 = p->fm_ref;
+    g.carrier2 = p->fm_ref;
+    g.cycle = p->sd_cycle;
+    g.n_lines = p->sd_n_lines;
+    g.skip_first = 0;
+    long long blocks = (g.total_calls + 62) / 63;
+    if (blocks <= 0) return CM_OK;
+    if (blocks > 0x7fffffffLL) return fail(CM_ERR_INVALID, "batch too large for one launch");
+    SecamDemodArgs a;
+    a.g = g;
+    a.k = p->sd_k;
+    hipLaunchKernelGGL(secam_demod_kernel, dim3((int)blocks), dim3(64), 0, stream, a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(CM_ERR_LAUNCH, std::string("secam_demod_kernel launch: ") + hipGetErrorString(e));
+    return CM_OK;
+}
+
+int run_secam_mod(const cm_plan *p, Geom g, hipStream_t stream) {
+    if (!p->sm_lanes) return fail(CM_ERR_UNSUPPORTED, "this plan has no modulator");
+    g.lanes = reinterpret_cast<const LaneK<float> *>(p->sm_lanes);
+    g.cycle = p->mod_cycle;
+    g.n_lines = p->mod_n_lines;
+    long long blocks = (g.total_calls + (64 - p->mod_depth) - 1) / (64 - p->mod_depth);
+    if (blocks <= 0) return CM_OK;
+    if (blocks > 0x7fffffffLL) return fail(CM_ERR_INVALID, "batch too large for one launch");
+    SecamModArgs a;
+    a.g = g;
+    a.k = p->sm_k;
+    if (p->mod_depth)
+        hipLaunchKernelGGL((secam_mod_kernel<3, 1>), dim3((int)blocks), dim3(64), 0, stream, a);
+    else
+        hipLaunchKernelGGL((secam_mod_kernel<3, 0>), dim3((int)blocks), dim3(64), 0, stream, a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(CM_ERR_LAUNCH, std::string("secam_mod_kernel launch: ") + hipGetErrorString(e));
+    return CM_OK;
+}
+
 void finish_geom(const cm_plan *p, const Pass &pass, Geom &g) {
     g.lanes = pass.lanes;
     g.carrier4 = p->carrier4;
@@ -259,8 +347,8 @@ int cm_plan_create(const cm_plan_desc *desc, cm_plan **out) {
     if (desc->width < 4 || desc->width % 4 != 0)
         return fail(CM_ERR_UNSUPPORTED, "width must be a positive multiple of 4 (rows are moved as 16-byte vectors)");
     if (desc->height < 1) return fail(CM_ERR_INVALID, "height must be positive");
-    if (desc->pipeline != CM_PIPE_QAM && desc->pipeline != CM_PIPE_PAL_D)
-        return fail(CM_ERR_UNSUPPORTED, "pipeline not built");
+    if (desc->pipeline != CM_PIPE_QAM && desc->pipeline != CM_PIPE_PAL_D && desc->pipeline != CM_PIPE_SECAM)
+        return fail(CM_ERR_INVALID, "unknown pipeline");
     if (desc->depth < 0 || desc->depth > 2) return fail(CM_ERR_INVALID, "depth must be 0..2");
     if (!desc->demod_main.table || desc->demod_main.frame_cycle < 1 || desc->demod_main.n_lines < 1)
         return fail(CM_ERR_INVALID, "demod_main table missing");
@@ -275,6 +363,14 @@ int cm_plan_create(const cm_plan_desc *desc, cm_plan **out) {
         return fail(CM_ERR_NO_DEVICE, "hipGetDevice failed");
     }
     std::string err;
+    if (desc->pipeline == CM_PIPE_SECAM) {
+        if (!create_secam(p, *desc, err)) {
+            cm_plan_destroy(p);
+            return fail(CM_ERR_UNSUPPORTED, err);
+        }
+        *out = p;
+        return CM_OK;
+    }
     std::vector<float> car = build_carrier<float>(desc->carrier_phase_step, desc->width);  // {C[m], S[m]}, m < 2W
     std::vector<float> car2(2 * (size_t)desc->width);                                      // {C[2n], S[2n]}
     for (int n = 0; n < desc->width; ++n) {
@@ -311,6 +407,9 @@ void cm_plan_destroy(cm_plan *p) {
     if (p->main.lanes) (void)hipFree(p->main.lanes);
     if (p->first.lanes) (void)hipFree(p->first.lanes);
     if (p->mod_lanes) (void)hipFree(p->mod_lanes);
+    if (p->sd_lanes) (void)hipFree(p->sd_lanes);
+    if (p->sm_lanes) (void)hipFree(p->sm_lanes);
+    if (p->fm_ref) (void)hipFree(p->fm_ref);
     delete p;
 }
 
@@ -319,7 +418,7 @@ int cm_demodulate_frames(const cm_plan *p, const float *composite, float *rgb, i
     if (!p || !composite || !rgb) return fail(CM_ERR_INVALID, "null argument");
     if (n_frames < 0 || first_frame < 0) return fail(CM_ERR_INVALID, "negative frame count / number");
     if (n_frames == 0) return CM_OK;
-    if (!p->fn) return fail(CM_ERR_UNSUPPORTED, p->demod_error);
+    if (!p->fn && !p->secam) return fail(CM_ERR_UNSUPPORTED, p->demod_error);
     const cm_plan_desc &d = p->desc;
     const int W = d.width, H = d.height, D = d.demodulation_delay;
     Geom g;
@@ -333,7 +432,7 @@ int cm_demodulate_frames(const cm_plan *p, const float *composite, float *rgb, i
     g.out_plane_stride = (long long)W * H;
     g.out_frame_stride = 3LL * W * H;
     g.out_row_stride = W;
-    g.first_frame = (int)(first_frame % (int64_t)p->main.cycle);
+    g.first_frame = (int)(first_frame % (int64_t)(p->secam ? p->sd_cycle : p->main.cycle));
     const int rows0 = (H + 1) / 2, rows1 = H / 2;
     g.calls_run0 = rows0 + D;
     const int calls_run1 = rows1 > 0 ? rows1 + D : 0;
@@ -344,6 +443,10 @@ int cm_demodulate_frames(const cm_plan *p, const float *composite, float *rgb, i
     g.delay = D;
     g.total_calls = n_frames * g.calls_per_frame;
     g.skip_first = d.first_is_plain;
+    if (p->secam) {
+        if (H - 1 >= p->sd_n_lines) return fail(CM_ERR_INVALID, "line number beyond the plan's tables");
+        return run_secam_demod(p, g, (hipStream_t)stream);
+    }
     int rc = check_lines(p, p->main, H - 1 + 2 * D);
     if (rc) return rc;
     Geom s = g;
@@ -362,7 +465,7 @@ int cm_demodulate_run(const cm_plan *p, const float *composite, float *rgb, int3
     if (n_calls < 0 || frame < 0 || k0 < 0) return fail(CM_ERR_INVALID, "negative count / frame / k0");
     if (n_calls == 0) return CM_OK;
     if (first_line < 0) return fail(CM_ERR_INVALID, "negative line number");
-    if (!p->fn) return fail(CM_ERR_UNSUPPORTED, p->demod_error);
+    if (!p->fn && !p->secam) return fail(CM_ERR_UNSUPPORTED, p->demod_error);
     const cm_plan_desc &d = p->desc;
     Geom g;
     std::memset(&g, 0, sizeof g);
@@ -374,7 +477,7 @@ int cm_demodulate_run(const cm_plan *p, const float *composite, float *rgb, int3
     g.out_plane_stride = d.width;
     g.out_frame_stride = 0;
     g.rows_mode = 1;
-    g.first_frame = frame % p->main.cycle;
+    g.first_frame = frame % (p->secam ? p->sd_cycle : p->main.cycle);
     g.calls_run0 = n_calls;
     g.calls_per_frame = n_calls;
     g.runs_per_frame = 1;
@@ -382,6 +485,12 @@ int cm_demodulate_run(const cm_plan *p, const float *composite, float *rgb, int3
     g.k0 = k0;
     g.total_calls = n_calls;
     g.skip_first = d.first_is_plain;
+    g.out_plane_stride = d.width;
+    g.out_row_stride = 3LL * d.width;
+    if (p->secam) {
+        if (first_line + 2 * (n_calls - 1) >= p->sd_n_lines) return fail(CM_ERR_INVALID, "line number beyond the plan's tables");
+        return run_secam_demod(p, g, (hipStream_t)stream);
+    }
     int rc = check_lines(p, p->main, first_line + 2 * (n_calls - 1));
     if (rc) return rc;
     // rows mode writes [call][plane][W]
@@ -399,6 +508,7 @@ int cm_demodulate_run(const cm_plan *p, const float *composite, float *rgb, int3
 }
 
 static int run_mod(const cm_plan *p, Geom g, hipStream_t stream) {
+    if (p->secam) return run_secam_mod(p, g, stream);
     if (!p->mod_fn) return fail(CM_ERR_UNSUPPORTED, "this plan has no modulator");
     g.lanes = reinterpret_cast<const LaneK<float> *>(p->mod_lanes);
     g.carrier4 = p->carrier4;
@@ -416,7 +526,7 @@ int cm_modulate_frames(const cm_plan *p, const float *rgb, float *composite, int
     if (!p || !rgb || !composite) return fail(CM_ERR_INVALID, "null argument");
     if (n_frames < 0 || first_frame < 0) return fail(CM_ERR_INVALID, "negative frame count / number");
     if (n_frames == 0) return CM_OK;
-    if (!p->mod_fn) return fail(CM_ERR_UNSUPPORTED, "this plan has no modulator");
+    if (!p->mod_fn && !p->sm_lanes) return fail(CM_ERR_UNSUPPORTED, "this plan has no modulator");
     const cm_plan_desc &d = p->desc;
     const int W = d.width, H = d.height, D = d.modulation_delay;
     Geom g;
@@ -449,7 +559,7 @@ int cm_modulate_run(const cm_plan *p, const float *rgb, float *composite, int32_
     if (!p || !rgb || !composite) return fail(CM_ERR_INVALID, "null argument");
     if (n_calls < 0 || frame < 0 || k0 < 0 || first_line < 0) return fail(CM_ERR_INVALID, "negative count / frame / line / k0");
     if (n_calls == 0) return CM_OK;
-    if (!p->mod_fn) return fail(CM_ERR_UNSUPPORTED, "this plan has no modulator");
+    if (!p->mod_fn && !p->sm_lanes) return fail(CM_ERR_UNSUPPORTED, "this plan has no modulator");
     const cm_plan_desc &d = p->desc;
     Geom g;
     std::memset(&g, 0, sizeof g);

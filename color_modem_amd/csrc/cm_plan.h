@@ -129,6 +129,102 @@ LaneK<T> convert_lane(const double *e, const DemodScales &sc) {
     return l;
 }
 
+// ---- SECAM ------------------------------------------------------------------------------------
+template <typename T>
+bool build_secam_demod_k(const cm_plan_desc &d, SecamDemodK<T> &k, std::string &err) {
+    const cm_secam_desc &s = d.secam;
+    if (!s.present) { err = "SECAM constants missing"; return false; }
+    k.width = d.width;
+    k.preroll = s.preroll;
+    for (int i = 0; i < 10; ++i) k.taps.c[i] = T(2.0 * d.resample_fir[2 * i + 1]);
+    k.taps.c0 = T(2.0 * d.resample_fir[20]);
+    double g_b, g_bell, g_l, g_y, g_d;
+    if (!convert_sos<T, 3>(s.chroma_bp, FORM_BP, k.bpf, g_b, err, "chroma_bp")) return false;
+    if (!convert_sos<T, 1>(s.bell, FORM_BP, k.bell, g_bell, err, "bell")) return false;
+    if (!convert_sos<T, 3>(s.fm_lp, FORM_SYM, k.lpf, g_l, err, "fm_lp")) return false;
+    if (!convert_sos<T, 3>(s.luma_bs, FORM_SYM, k.ybs, g_y, err, "luma_bs")) return false;
+    if (!convert_sos<T, 1>(s.lf_rev, FORM_GEN, k.deemph, g_d, err, "lf_rev")) return false;
+    if (s.bell.shift != 0 || s.lf_rev.shift != 0 || (s.fm_lp.shift & 1) || s.chroma_bp.shift < 0 || s.luma_bs.shift < 0) {
+        err = "SECAM filter shifts outside what the kernel is built for (bell 0, de-emphasis 0, FM low-pass even)";
+        return false;
+    }
+    if (g_b * g_bell * g_l <= 0.0) { err = "SECAM chroma path gain must be positive (the discriminator drops it)"; return false; }
+    k.s_b = s.chroma_bp.shift;
+    k.q_l = s.fm_lp.shift / 2;
+    k.s_y = s.luma_bs.shift;
+    k.fc = T(s.fm_fc);
+    k.two_over_pi = T(2.0 / 3.141592653589793238462643383279502884);
+    k.f2_min = T(2.0 * s.flimit_min);
+    k.f2_max = T(2.0 * s.flimit_max);
+    k.luma_gain = T(g_y);
+    for (int i = 0; i < 3; ++i) {
+        k.m[i][0] = T(d.decode_matrix[3 * i]);
+        k.m[i][1] = T(d.decode_matrix[3 * i + 1] * g_d);
+        k.m[i][2] = T(d.decode_matrix[3 * i + 2] * g_d);
+    }
+    return true;
+}
+
+template <typename T>
+SecamDemodLaneK<T> convert_secam_demod_lane(const double *e) {
+    SecamDemodLaneK<T> l;
+    l.scale = T(0.5 / e[1]);
+    l.offset = T(-e[0] / e[1]);
+    l.own_is_db = T(e[2]);
+    l.w_prev = T(e[3]);
+    return l;
+}
+
+template <typename T, typename TD>
+bool build_secam_mod_k(const cm_plan_desc &d, SecamModK<T, TD> &k, std::string &err) {
+    const cm_secam_desc &s = d.secam;
+    if (!s.present) { err = "SECAM constants missing"; return false; }
+    double g1, g2;
+    if (!convert_sos<TD, 2>(s.pre_lp, FORM_GEN, k.pre_lp, g1, err, "pre_lp")) return false;
+    if (!convert_sos<TD, 1>(s.lf_pre, FORM_GEN, k.lf_pre, g2, err, "lf_pre")) return false;
+    if (s.lf_pre.shift != 0 || s.pre_lp.shift < 0) { err = "SECAM encoder filter shifts outside what the kernel is built for"; return false; }
+    k.width = d.width;
+    k.s_p = s.pre_lp.shift;
+    k.gain = TD(g1 * g2);
+    k.f_min = TD(s.flimit_min);
+    k.f_max = TD(s.flimit_max);
+    k.f0 = TD(s.bell_f0);
+    k.pi = TD(3.141592653589793238462643383279502884);
+    k.two_pi = TD(2.0 * 3.141592653589793238462643383279502884);
+    k.m0 = T(s.m0);
+    k.kn = T(s.bell_kn);
+    k.kd = T(s.bell_kd);
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) k.e[i][j] = T(d.encode_matrix[3 * i + j]);
+    return true;
+}
+
+template <typename T, typename TD>
+SecamModLaneK<T, TD> convert_secam_mod_lane(const double *e) {
+    SecamModLaneK<T, TD> l;
+    l.fsc = TD(e[0]);
+    l.fdev = TD(e[1]);
+    l.own_is_db = T(e[2]);
+    l.start_phase = T(e[3]);
+    l.wy0 = T(e[4]); l.wy1 = T(e[5]); l.wc0 = T(e[6]); l.wc1 = T(e[7]);
+    return l;
+}
+
+// {cos, sin}(k * pi * fc / 2) for the 2x samples k = 0 .. 2 Lc - 1 (secam.py:137-140, phase not wrapped)
+template <typename T>
+std::vector<T> build_fm_reference(double fc, int lc) {
+    const int n = 2 * lc;
+    std::vector<T> t(2 * (size_t)n);
+    const double pi = 3.141592653589793238462643383279502884;
+    const double stop = (n * pi * fc) / 2.0;
+    const double delta = stop / n;
+    for (int i = 0; i < n; ++i) {
+        t[2 * i] = T(std::cos(i * delta));
+        t[2 * i + 1] = T(std::sin(i * delta));
+    }
+    return t;
+}
+
 // ---- the filter-set shapes this build carries ------------------------------------------------
 //                 NE NR NL NP  oddE   oddL   oddR  SP
 typedef Sys<2, 2, 3, 1, false, false, false, 2> SysPal;   // PAL-BG @ 13.5 MHz: shifts 4 / 4 (6 for PAL-D) / 2 / 2

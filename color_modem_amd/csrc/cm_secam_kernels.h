@@ -1,0 +1,230 @@
+// cm_secam_kernels.h - device-side lane drivers of the SECAM decoder and encoder (gfx950).
+//
+// Same execution model and data movement as cm_kernels.h (one lane = one scan line, input rows
+// staged through a 64 x 32-sample LDS tile filled by global_load_lds, outputs transposed through an
+// LDS tile into 64-byte row segments).  Differences:
+//   * the chroma stream starts with the mirrored pre-roll cc[m] = x[P - m], m < P (secam.py:283-284),
+//     read sample by sample out of the first input tile before the aligned main loop starts;
+//   * luma (band-stop at 1x rate) runs on a second, delayed visit of the row so that it meets the
+//     FM-decoded colour-difference sample of the same pixel without a delay line;
+//   * the previous line's colour-difference signal comes from the neighbouring lane.
+#ifndef CM_SECAM_KERNELS_H
+#define CM_SECAM_KERNELS_H
+
+#include "cm_kernels.h"
+#include "cm_mod_kernels.h"
+
+namespace cm {
+
+struct SecamDemodArgs {
+    Geom g;                    // g.lanes -> SecamDemodLaneK<float> table, g.carrier4 -> FM reference {cos, sin} pairs
+    SecamDemodK<float> k;
+};
+
+__global__ __launch_bounds__(64, 2) void secam_demod_kernel(const SecamDemodArgs args) {
+    constexpr int kTile = 16, DEPTH = 1;
+    __shared__ __attribute__((aligned(16))) float lds_store[kLdsIn + 3 * 64 * kTile];
+    lds_float *itile = (lds_float *)lds_store;
+    lds_float *otile_base = itile + kLdsIn;
+    const Geom &g = args.g;
+    const SecamDemodK<float> &k = args.k;
+    const int lane = threadIdx.x;
+    const LaneCall lc = locate_call(g, blockIdx.x, DEPTH, lane);
+    const float *xp = g.in + lc.frame * g.in_frame_stride + (long long)lc.src_row * g.W;
+    const float *op = lc.store_ok ? g.out + lc.frame * g.out_frame_stride + (long long)lc.out_row * g.out_row_stride : nullptr;
+    SecamDemodLaneK<float> lk;
+    {
+        int fmod = (int)((g.first_frame + lc.frame) % g.cycle);
+        lk = ((const SecamDemodLaneK<float> *)g.lanes)[((long long)fmod * 3 + lc.regime) * g.n_lines + lc.line];
+    }
+    const int idx1 = ((lane + 63) & 63) * 4;
+    SecamDemod<float> st;
+    st.reset();
+    float chw[14];
+#pragma unroll
+    for (int j = 0; j < 14; ++j) chw[j] = 0.f;
+    lds_float *otile = otile_base + lane * kTile;
+    const int wpos = ((lane >> 1) & (kTile / 4 - 1)) << 2;
+    const lds_float *xrow = itile + lane * kInTile;
+
+    const int W = g.W, P = k.preroll, Lc = W + P;
+    const int lat = SecamDemod<float>::latency(k);          // chroma sample n = m - lat
+    const int d_luma = lat + 1 - P - k.s_y;                 // luma filter input x[xi - d_luma] at main-loop sample xi
+    const int lat_out = d_luma + k.s_y;                     // output sample n' = xi - lat_out
+    const int s_flush = (lat_out + 3) & 3;
+    float own_prev = 0.f, nb_prev = 0.f;
+
+    // one step of the stream: cc = cc[m]; x_l = x[n' + s_y] for the luma filter
+    auto step = [&](int m, float cc, float x_l, int sub) {
+        int m2 = m - k.s_b - 10;
+        m2 = m2 < 0 ? 0 : (m2 > Lc - 1 ? Lc - 1 : m2);
+        f4 c = ((const_f4 *)g.carrier4)[m2];
+        float car[4] = {c.x, c.y, c.z, c.w};
+        float ch_out;
+        float own = st.chroma_step(k, lk, m, cc, chw[sub], car, ch_out);
+        chw[10 + sub] = ch_out;
+        const int n = m - 1 - lat;                          // the back end runs one sample behind the exchange
+        float luma = st.luma_step(k, n, x_l);
+        Rgb<float> o = st.finish(k, lk, luma, own_prev, nb_prev);
+        own_prev = own;
+        nb_prev = lane_from(idx1, own);
+        if (n >= 0 && n < W) {
+            lds_float *tp = otile + (wpos ^ (n & (kTile - 1)));
+            tp[0] = o.r;
+            tp[64 * kTile] = o.g;
+            tp[2 * 64 * kTile] = o.b;
+        }
+    };
+    auto shift_window = [&]() {
+#pragma unroll
+        for (int j = 0; j < 10; ++j) chw[j] = chw[j + 4];
+    };
+
+    fill_tile(g, itile, xp, 0, lane);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    // ---- pre-roll: cc[m] = x[P - m] for m < P, in bodies of 4 steps so that the windows keep their phase
+    const int m_start = -((4 - (P & 3)) & 3);
+    for (int mb = m_start; mb < P; mb += 4) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int m = mb + s;
+            float cc = 0.f;
+            if (m >= 0) {
+                int xi = P - m;
+                if (xi > W - 1) xi = W - 1;
+                cc = xrow[xi];
+            }
+            step(m, cc, 0.f, s);
+        }
+        shift_window();
+    }
+    // ---- main loop over the row samples xi = m - P
+    auto read_x = [&](int first) -> f4 {
+        f4 v = *(const lds_f4 *)(xrow + (first & (kInTile - 1)));
+        if (first + 3 >= W) {
+            if (first >= W) v.x = 0.f;
+            if (first + 1 >= W) v.y = 0.f;
+            if (first + 2 >= W) v.z = 0.f;
+            if (first + 3 >= W) v.w = 0.f;
+        }
+        return v;
+    };
+    auto read_luma = [&](int first) -> f4 {
+        if (first >= 0 && first + 3 < W) {
+            f4u v = *(const f4u *)(xp + first);
+            return f4{v.x, v.y, v.z, v.w};
+        }
+        f4 r = {0.f, 0.f, 0.f, 0.f};
+        if (first + 3 >= 0 && first < W) {
+            if (first >= 0 && first < W) r.x = xp[first];
+            if (first + 1 >= 0 && first + 1 < W) r.y = xp[first + 1];
+            if (first + 2 >= 0 && first + 2 < W) r.z = xp[first + 2];
+            if (first + 3 >= 0 && first + 3 < W) r.w = xp[first + 3];
+        }
+        return r;
+    };
+    const int T = (W + lat_out + 3) & ~3;
+    f4 xv = read_x(0);
+    f4 nl = read_luma(-d_luma);
+    for (int xb = 0; xb < T; xb += 4) {
+        const f4 lw = nl;
+        nl = read_luma(xb + 4 - d_luma);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            step(P + xb + s, xv[s], lw[s], s);
+            if (s == s_flush) {
+                const int n = xb + s - lat_out;
+                if (n >= 0 && ((n & (kTile - 1)) == kTile - 1 || n == W - 1))
+                    flush_tile<kTile>(g, otile_base, op, n & ~(kTile - 1), lane);
+            }
+        }
+        shift_window();
+        const int nxt = xb + 4;
+        if ((nxt & (kInTile - 1)) == 0 && nxt < W) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+        }
+        xv = read_x(nxt);
+        if ((nxt & (kInTile - 1)) == kInTile - 4 && nxt + 4 < W) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+            fill_tile(g, itile, xp, (nxt >> 5) + 1, lane);
+        }
+    }
+}
+
+struct SecamModArgs {
+    Geom g;                    // g.lanes -> SecamModLaneK<float, double> table
+    SecamModK<float, double> k;
+};
+
+// SP = shift of the pre-correction low-pass (register window of the luma delay); DEPTH = 1: line averaging
+template <int SP, int DEPTH>
+__global__ __launch_bounds__(64, 4) void secam_mod_kernel(const SecamModArgs args) {
+    constexpr int kTile = 16;
+    __shared__ __attribute__((aligned(16))) float lds_store[64 * kTile];
+    lds_float *otile_base = (lds_float *)lds_store;
+    const Geom &g = args.g;
+    const SecamModK<float, double> &k = args.k;
+    const int lane = threadIdx.x;
+    const LaneCall lc = locate_call(g, blockIdx.x, DEPTH, lane);
+    const long long row_stride = g.in_row_stride ? g.in_row_stride : g.W;
+    const float *rp = g.in + lc.frame * g.in_frame_stride + (long long)lc.src_row * row_stride;
+    const float *op = lc.store_ok ? g.out + lc.frame * g.out_frame_stride + (long long)lc.out_row * g.out_row_stride : nullptr;
+    SecamModLaneK<float, double> lk;
+    {
+        int fmod = (int)((g.first_frame + lc.frame) % g.cycle);
+        lk = ((const SecamModLaneK<float, double> *)g.lanes)[((long long)fmod * 3 + lc.regime) * g.n_lines + lc.line];
+    }
+    const int idx1 = ((lane + 63) & 63) * 4;
+    SecamMod<float, double> st;
+    st.reset();
+    float yw[SP + 4];
+#pragma unroll
+    for (int j = 0; j < SP + 4; ++j) yw[j] = 0.f;
+    lds_float *otile = otile_base + lane * kTile;
+    const int wpos = ((lane >> 1) & (kTile / 4 - 1)) << 2;
+    const int W = g.W;
+    const int T = (W + SP + 3) & ~3;
+    auto load3 = [&](int first, f4 out[3]) {
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+            if (first >= 0 && first + 3 < W) out[p] = *(const f4 *)(rp + p * g.in_plane_stride + first);
+            else out[p] = f4{0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    f4 cur[3], nxt[3];
+    load3(0, nxt);
+    for (int tb = 0; tb < T; tb += 4) {
+        cur[0] = nxt[0]; cur[1] = nxt[1]; cur[2] = nxt[2];
+        load3(tb + 4, nxt);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int t = tb + s;
+            float r = cur[0][s], gg = cur[1][s], b = cur[2][s];
+            float y = fmaf_(k.e[0][0], r, fmaf_(k.e[0][1], gg, k.e[0][2] * b));
+            float dr = fmaf_(k.e[1][0], r, fmaf_(k.e[1][1], gg, k.e[1][2] * b));
+            float db = fmaf_(k.e[2][0], r, fmaf_(k.e[2][1], gg, k.e[2][2] * b));
+            float d = lk.own_is_db != 0.f ? db : dr;     // secam.py:262-271 (the line being modulated decides)
+            if (DEPTH >= 1) {
+                // the previous call's components: its lane computed them with its own parity, so exchange both
+                float yp = lane_from(idx1, y), drp = lane_from(idx1, dr), dbp = lane_from(idx1, db);
+                float dp = lk.own_is_db != 0.f ? dbp : drp;
+                y = fmaf_(lk.wy0, y, lk.wy1 * yp);
+                d = fmaf_(lk.wc0, d, lk.wc1 * dp);
+            }
+            yw[SP + s] = y;
+            const int n7 = t - SP;
+            float comp = st.step(k, lk, t, yw[s], d);
+            if (n7 >= 0 && n7 < W) otile[wpos ^ (n7 & (kTile - 1))] = comp;
+            if (n7 >= 0 && ((n7 & (kTile - 1)) == kTile - 1 || n7 == W - 1))
+                flush_tile1<kTile>(g, otile_base, op, n7 & ~(kTile - 1), lane);
+        }
+#pragma unroll
+        for (int j = 0; j < SP; ++j) yw[j] = yw[j + 4];
+    }
+}
+
+}  // namespace cm
+#endif

@@ -463,5 +463,221 @@ struct QamModCore {
     }
 };
 
+// =============================================================================================
+// SECAM decoder (ref secam.py:278-304 with the FmDecoder of secam.py:127-149).
+//
+// Chroma stream index m runs over the pre-rolled row cc[m] (m < P: x[P - m], mirrored start;
+// m >= P: x[m - P]; secam.py:283-284), Lc = W + P samples:
+//   m1 = m - s_b          band-pass + bell output ch[m1]       (shift s_b, tail padded)
+//   m2 = m1 - 10          pair A(m2) = up2(ch)
+//   m3 = m2 - q_l         pair of low-passed I/Q products -> two phase steps -> frequencies_up
+//   m4 = m3 - 9           decimated frequency; row sample n = m4 - P
+// The discriminator is scale invariant, so no filter gain of this path is applied.  The phase
+// step is taken as atan2(cross, dot) of consecutive I/Q samples, which is the wrapped
+// difference numpy.unwrap + numpy.diff produce without the cancellation
+// of subtracting two angles.
+// =============================================================================================
+template <typename T>
+struct SecamDemodK {
+    int32_t width, preroll;      // W, P
+    int32_t s_b, q_l, s_y;       // chroma band-pass shift, low-pass pair delay, luma band-stop shift
+    Taps<T> taps;
+    SosK<T, 3> bpf;              // secam.py:183-184 (numerator 1 - z^-2 sections)
+    SosK<T, 1> bell;             // secam.py:168-170
+    SosK<T, 3> lpf;              // secam.py:131-132
+    SosK<T, 3> ybs;              // secam.py:185-186
+    SosK<T, 1> deemph;           // secam.py:175-177 (backward), first order
+    T fc, two_over_pi;           // frequencies_up = fc + 2 d / pi (secam.py:148)
+    T f2_min, f2_max;            // 2 * flimit (the decimator output is doubled)
+    T luma_gain;
+    T m[3][3];                   // (r, g, b) = m . (luma, dr, db), de-emphasis gain folded into columns 1, 2
+};
+
+template <typename T>
+struct SecamDemodLaneK {
+    T scale, offset;  // c = f2 * scale + offset  with scale = 0.5 / fdev_x, offset = -fsc_x / fdev_x
+    T own_is_db;      // 1: this line carries Db (alternate line), 0: Dr
+    T w_prev;         // 0 on the first call of a run (last_chroma = zeros), else 1
+};
+
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ float atan2_(float y, float x) { return atan2f(y, x); }
+#else
+inline float atan2_(float y, float x) { return std::atan2(y, x); }
+#endif
+CM_HD double atan2_(double y, double x) { return std::atan2(y, x); }
+
+template <typename T>
+struct SecamDemod {
+    IirState<T, 3> bpf, ybs;
+    IirState<T, 1> bell;
+    IirState<T, 3> lp_i, lp_q;
+    IirState<T, 1> deemph;
+    HalfbandChain<T> up, dn;
+    T cc_last, pi_last, pq_last, x_last;
+    T i_prev, q_prev;
+    int have_prev;
+
+    CM_HD void reset() {
+        bpf.reset(); ybs.reset(); bell.reset(); lp_i.reset(); lp_q.reset(); deemph.reset();
+        up.reset(); dn.reset();
+        cc_last = pi_last = pq_last = x_last = i_prev = q_prev = T(0);
+        have_prev = 0;
+    }
+    // row sample n = m - latency(k)
+    CM_HD static int latency(const SecamDemodK<T> &k) { return k.s_b + 10 + k.q_l + 9 + k.preroll; }
+
+    CM_HD static T phase_step(T i0, T q0, T i1, T q1) {
+        // angle of (i1 + j q1) * conj(i0 + j q0); the cross product with an error-free correction
+        T t = q0 * i1;
+        T e = fmaf_(-q0, i1, t);
+        T cross = fmaf_(i0, q1, -t) + e;
+        T dot = fmaf_(i0, i1, q0 * q1);
+        return atan2_(cross, dot);
+    }
+
+    // cc_now = cc[m]; ch_d10 = ch[m1 - 10] (caller's delay window); car = {cos, sin} of the FM
+    // reference at 2x samples 2 m2 and 2 m2 + 1.  Returns the de-emphasised colour-difference sample
+    // c[n], n = m - latency (meaningful for 0 <= n < W), and ch[m1] through ch_out.
+    CM_HD T chroma_step(const SecamDemodK<T> &k, const SecamDemodLaneK<T> &lk, int m, T cc_now, T ch_d10, const T car[4], T &ch_out) {
+        const int W = k.width, Lc = k.width + k.preroll;
+        const int m1 = m - k.s_b, m2 = m1 - 10, m3 = m2 - k.q_l, m4 = m3 - 9, n = m4 - k.preroll;
+        T ch = T(0);
+        if (m >= 0 && m < Lc + k.s_b) {
+            if (m == Lc - 1) cc_last = cc_now;
+            if (m >= Lc) cc_now = cc_last;
+            T b = iir_bp(bpf, k.bpf, cc_now);
+            if (m1 >= 0) ch = iir_bp(bell, k.bell, b);   // the bell sees the band-pass output from its sample 0 on
+        }
+        if (m1 < 0 || m1 >= Lc) ch = T(0);
+        ch_out = ch;
+        T a_odd = up.push(k.taps, ch);
+        T a_even = k.taps.c0 * ch_d10;
+        T pi_e = a_even * car[0], pq_e = -(a_even * car[1]);   // data_up = cos part - j sin part (secam.py:143)
+        T pi_o = a_odd * car[2], pq_o = -(a_odd * car[3]);
+        T f_e = T(0), f_o = T(0);
+        if (m2 >= 0 && m2 < Lc + k.q_l) {
+            if (m2 == Lc - 1) { pi_last = pi_o; pq_last = pq_o; }
+            if (m2 >= Lc) { pi_e = pi_o = pi_last; pq_e = pq_o = pq_last; }
+            T i0 = iir_sym(lp_i, k.lpf, pi_e), q0 = iir_sym(lp_q, k.lpf, pq_e);
+            T i1 = iir_sym(lp_i, k.lpf, pi_o), q1 = iir_sym(lp_q, k.lpf, pq_o);
+            if (m3 >= 0 && m3 < Lc) {
+                T d_e = have_prev ? phase_step(i_prev, q_prev, i0, q0) : T(0);  // secam.py:147: first step is 0
+                T d_o = phase_step(i0, q0, i1, q1);
+                have_prev = 1;
+                i_prev = i1;
+                q_prev = q1;
+                f_e = fmaf_(d_e, k.two_over_pi, k.fc);
+                f_o = fmaf_(d_o, k.two_over_pi, k.fc);
+            }
+        }
+        T f2 = dn.push_pair(k.taps, f_e, f_o);   // 2 * resample_poly(frequencies_up, 1, 2)[m4]
+        T c = T(0);
+        if (n >= 0 && n < W) {
+            f2 = f2 < k.f2_min ? k.f2_min : (f2 > k.f2_max ? k.f2_max : f2);   // secam.py:290
+            c = iir_gen(deemph, k.deemph, fmaf_(f2, lk.scale, lk.offset));   // secam.py:291-296
+        }
+        return c;
+    }
+    // luma[n] (secam.py:282): x_in = x[n + s_y] (anything beyond the row end: the filter is fed the last sample)
+    CM_HD T luma_step(const SecamDemodK<T> &k, int n, T x_in) {
+        const int W = k.width, j = n + k.s_y;
+        T y = T(0);
+        if (j >= 0 && j < W + k.s_y) {
+            if (j == W - 1) x_last = x_in;
+            if (j >= W) x_in = x_last;
+            y = iir_sym(ybs, k.ybs, x_in);
+        }
+        return y * k.luma_gain;
+    }
+    // own = this call's c[n], prev = the previous call's c[n]
+    CM_HD Rgb<T> finish(const SecamDemodK<T> &k, const SecamDemodLaneK<T> &lk, T luma, T own, T prev) const {
+        prev = prev * lk.w_prev;
+        T dr = lk.own_is_db != T(0) ? prev : own;   // secam.py:297-300
+        T db = lk.own_is_db != T(0) ? own : prev;
+        Rgb<T> o;
+        o.r = fmaf_(k.m[0][0], luma, fmaf_(k.m[0][1], dr, k.m[0][2] * db));
+        o.g = fmaf_(k.m[1][0], luma, fmaf_(k.m[1][1], dr, k.m[1][2] * db));
+        o.b = fmaf_(k.m[2][0], luma, fmaf_(k.m[2][1], dr, k.m[2][2] * db));
+        return o;
+    }
+};
+
+// =============================================================================================
+// SECAM modulator (ref secam.py:240-276; encoder-side line averaging of comb.py:141-152 is applied
+// by the caller on the components).  The colour-difference path - pre-correction low-pass, LF
+// pre-emphasis, frequency and the running phase sum (numpy.cumsum, secam.py:245) - is carried in
+// TD = double on the device: the phase is an integral over the whole line and float32 rounding of
+// it shows at 1e-4.
+//   n  : index of the component samples fed in;  n7 = n - s_p : index of the composite sample out
+// =============================================================================================
+template <typename T, typename TD>
+struct SecamModK {
+    int32_t width, s_p;
+    SosK<TD, 2> pre_lp;     // secam.py:171-172 (order 3: a first- and a second-order section)
+    SosK<TD, 1> lf_pre;     // secam.py:175-177 forward
+    TD gain;                // product of the section gains of both filters
+    TD f_min, f_max, f0, pi, two_pi;
+    T m0, kn, kd;
+    T e[3][3];              // (luma, dr, db) = e . (r, g, b)
+};
+
+template <typename T, typename TD>
+struct SecamModLaneK {
+    TD fsc, fdev;           // of the colour-difference signal this line carries
+    T own_is_db;
+    T start_phase;          // 0 or pi (secam.py:273)
+    T wy0, wy1, wc0, wc1;   // row weights (comb.py:147-149)
+};
+
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ void sincos_(float x, float &s, float &c) { sincosf(x, &s, &c); }
+#else
+inline void sincos_(float x, float &s, float &c) { s = std::sin(x); c = std::cos(x); }
+#endif
+CM_HD void sincos_(double x, double &s, double &c) { s = std::sin(x); c = std::cos(x); }
+
+template <typename T, typename TD>
+struct SecamMod {
+    IirState<TD, 2> pre_lp;
+    IirState<TD, 1> lf_pre;
+    TD d_last, acc;
+    CM_HD void reset() {
+        pre_lp.reset(); lf_pre.reset();
+        d_last = acc = TD(0);
+    }
+    // d = colour-difference sample n of this line; luma_d = luma sample n7 = n - s_p
+    CM_HD T step(const SecamModK<T, TD> &k, const SecamModLaneK<T, TD> &lk, int n, T luma_d, T d) {
+        const int W = k.width, n7 = n - k.s_p;
+        TD dd = TD(d);
+        TD w = TD(0);
+        if (n >= 0 && n < W + k.s_p) {
+            if (n == W - 1) d_last = dd;
+            if (n >= W) dd = d_last;
+            w = iir_gen(pre_lp, k.pre_lp, dd);
+        }
+        if (n7 < 0 || n7 >= W) return T(0);
+        TD x = iir_gen(lf_pre, k.lf_pre, w);
+        TD f = fmaf_(lk.fdev * k.gain, x, lk.fsc);                    // secam.py:266 / 271
+        f = f < k.f_min ? k.f_min : (f > k.f_max ? k.f_max : f);      // secam.py:272
+        // bell pre-emphasis G = m0 (1 + j kn F) / (1 + j kd F), F = f / f0 - f0 / f (secam.py:241-243)
+        T ff = T(f), f0 = T(k.f0);
+        T F = T(f - k.f0) * (ff + f0) / (ff * f0);
+        T den = T(1) + k.kd * k.kd * F * F;
+        T re = k.m0 * (T(1) + k.kn * k.kd * F * F) / den;
+        T im = k.m0 * F * (k.kn - k.kd) / den;
+        if (n7 == 0) {
+            acc = TD(lk.start_phase) - TD(atan2_(im, re));             // secam.py:244: start - pi f[0] - arg G[0] + pi f[0]
+        } else {
+            acc += k.pi * f;                                          // cumsum(pi f)
+        }
+        if (acc >= k.two_pi) acc -= k.two_pi;
+        if (acc < TD(0)) acc += k.two_pi;
+        T sn, cs;
+        sincos_(T(acc), sn, cs);
+        return luma_d + (re * cs - im * sn);                           // secam.py:246, 276
+    }
+};
+
 }  // namespace cm
 #endif

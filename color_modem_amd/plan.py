@@ -22,7 +22,7 @@ import ctypes
 import numpy
 import scipy.signal
 
-CM_ABI_VERSION = 1
+CM_ABI_VERSION = 2
 CM_PIPE_QAM, CM_PIPE_PAL_D, CM_PIPE_SECAM = 1, 2, 3
 CM_MAX_SECTIONS = 4
 CM_LANE_DOUBLES = 20
@@ -39,6 +39,15 @@ class LaneTable(ctypes.Structure):
                 ('luma_from_prev', ctypes.c_int32), ('reserved', ctypes.c_int32)]
 
 
+class SecamDesc(ctypes.Structure):
+    _fields_ = [('present', ctypes.c_int32), ('preroll', ctypes.c_int32),
+                ('flimit_min', ctypes.c_double), ('flimit_max', ctypes.c_double), ('bell_f0', ctypes.c_double),
+                ('m0', ctypes.c_double), ('bell_kn', ctypes.c_double), ('bell_kd', ctypes.c_double),
+                ('fm_fc', ctypes.c_double),
+                ('pre_lp', IirDesc), ('lf_pre', IirDesc), ('lf_rev', IirDesc), ('bell', IirDesc),
+                ('chroma_bp', IirDesc), ('luma_bs', IirDesc), ('fm_lp', IirDesc)]
+
+
 class PlanDesc(ctypes.Structure):
     _fields_ = [('abi_version', ctypes.c_int32), ('pipeline', ctypes.c_int32),
                 ('width', ctypes.c_int32), ('height', ctypes.c_int32),
@@ -50,7 +59,8 @@ class PlanDesc(ctypes.Structure):
                 ('extract2x', IirDesc), ('remove2x', IirDesc), ('demod_lp', IirDesc),
                 ('pald_lp', IirDesc), ('precorrect', IirDesc),
                 ('decode_matrix', ctypes.c_double * 9), ('encode_matrix', ctypes.c_double * 9),
-                ('demod_main', LaneTable), ('demod_first', LaneTable), ('mod_main', LaneTable)]
+                ('demod_main', LaneTable), ('demod_first', LaneTable), ('secam', SecamDesc),
+                ('mod_main', LaneTable)]
 
 
 # ---------------------------------------------------------------------------------------------

@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define CM_ABI_VERSION 1
+#define CM_ABI_VERSION 2
 
 enum cm_status {
     CM_OK = 0,
@@ -86,6 +86,27 @@ typedef struct {
     int32_t reserved;
 } cm_lane_table;
 
+/* SECAM constants (secam.py:153-190), frequencies normalised to the Nyquist rate like the reference.
+ * Lane tables of a CM_PIPE_SECAM plan (CM_LANE_DOUBLES doubles per (frame mod cycle, regime, line)):
+ *   demod_main: [0] fsc, [1] fdev of the colour-difference signal this line carries, [2] 1 = Db line
+ *               (LineConfig.is_alternate_line), [3] 0 on the first call of a run (last_chroma = 0) else 1
+ *   mod_main:   [0] fsc, [1] fdev, [2] 1 = Db line, [3] start phase (0 or pi, secam.py:248-256, 273),
+ *               [4] luma weight of the call's own row, [5] of the previous call's row, [6], [7] chroma
+ *               weights likewise (comb.py:141-152); all for the line that is actually modulated */
+typedef struct {
+    int32_t present;
+    int32_t preroll;       /* len(composite) // 40 - 1 mirrored samples in front of the chroma band-pass (secam.py:283) */
+    double flimit_min, flimit_max, bell_f0, m0, bell_kn, bell_kd;
+    double fm_fc;          /* FmDecoder centre (secam.py:179, 187) */
+    cm_iir_desc pre_lp;    /* secam.py:171-172 */
+    cm_iir_desc lf_pre;    /* secam.py:175-177 forward (absent: n_sections = 0) */
+    cm_iir_desc lf_rev;    /* secam.py:175-177 backward */
+    cm_iir_desc bell;      /* secam.py:168-170 */
+    cm_iir_desc chroma_bp; /* secam.py:183-184 */
+    cm_iir_desc luma_bs;   /* secam.py:185-186 */
+    cm_iir_desc fm_lp;     /* secam.py:131-132 */
+} cm_secam_desc;
+
 typedef struct {
     int32_t abi_version;   /* CM_ABI_VERSION */
     int32_t pipeline;      /* enum cm_pipeline of the main pass */
@@ -107,6 +128,7 @@ typedef struct {
     double encode_matrix[9]; /* (y, u, v) = M (r, g, b): pal.py:35-37, ntsc.py:30-32 */
     cm_lane_table demod_main;  /* main pass */
     cm_lane_table demod_first; /* plain pass for k == 0 (only regime 0 is read) */
+    cm_secam_desc secam;       /* CM_PIPE_SECAM only */
     cm_lane_table mod_main;    /* modulator: [0] sin, [1] cos of the start phase of the modulated line, [2] luma weight of the
                                   call's own row, [3] of the previous call's row, [4], [5] chroma weights likewise
                                   (comb.py:141-152), [6] V-switch sign */

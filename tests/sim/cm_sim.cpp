@@ -157,6 +157,109 @@ static int sim_run(const cm_plan_desc *d, const double *comp, double *rgb, int n
     return rc;
 }
 
+// ---- SECAM decoder -------------------------------------------------------------------------------
+template <typename T>
+static int sim_secam_run(const cm_plan_desc *d, const double *comp, double *rgb, int n_calls, int frame, int first_line, int k0) {
+    SecamDemodK<T> k;
+    if (!build_secam_demod_k<T>(*d, k, g_err)) return CM_ERR_UNSUPPORTED;
+    const int W = d->width, P = k.preroll, Lc = W + P;
+    std::vector<T> fm = build_fm_reference<T>(d->secam.fm_fc, Lc);
+    const cm_lane_table &tb = d->demod_main;
+    std::vector<SecamDemodLaneK<T>> lk(n_calls);
+    for (int i = 0; i < n_calls; ++i) {
+        int kk = k0 + i, regime = kk < 2 ? kk : 2, line = first_line + 2 * i;
+        if (line < 0 || line >= tb.n_lines) { g_err = "line outside the lane table"; return CM_ERR_INVALID; }
+        lk[i] = convert_secam_demod_lane<T>(lane_entry<T>(tb, frame, regime, line));
+    }
+    std::vector<SecamDemod<T>> st(n_calls);
+    for (auto &x : st) x.reset();
+    const int lat = SecamDemod<T>::latency(k);
+    const int steps = Lc + lat + 2;
+    std::vector<std::vector<T>> ch_hist(n_calls, std::vector<T>(steps + 64, T(0)));
+    std::vector<T> own(n_calls), prev_own(n_calls, T(0));
+    auto xin = [&](int i, int s) -> T { return (s < 0 || s >= W) ? T(0) : T(comp[(size_t)i * W + s]); };
+    for (int m = 0; m < steps; ++m) {
+        const int m1 = m - k.s_b, m2 = m1 - 10;
+        for (int i = 0; i < n_calls; ++i) {
+            T cc = m < P ? xin(i, P - m) : xin(i, m - P);
+            int mc = m2 < 0 ? 0 : (m2 > Lc - 1 ? Lc - 1 : m2);
+            T car[4] = {fm[4 * mc], fm[4 * mc + 1], fm[4 * mc + 2], fm[4 * mc + 3]};
+            T ch_d10 = (m1 - 10 >= 0) ? ch_hist[i][m1 - 10] : T(0);
+            T ch_out;
+            own[i] = st[i].chroma_step(k, lk[i], m, cc, ch_d10, car, ch_out);
+            if (m1 >= 0) ch_hist[i][m1] = ch_out;
+        }
+        // the back end runs one step behind (neighbour exchange), as on the device
+        const int n = m - 1 - lat;
+        for (int i = 0; i < n_calls; ++i) {
+            T luma = st[i].luma_step(k, n, xin(i, n + k.s_y));
+            Rgb<T> o = st[i].finish(k, lk[i], luma, prev_own[i], i >= 1 ? prev_own[i - 1] : T(0));
+            if (n >= 0 && n < W) {
+                rgb[((size_t)i * 3 + 0) * W + n] = (double)o.r;
+                rgb[((size_t)i * 3 + 1) * W + n] = (double)o.g;
+                rgb[((size_t)i * 3 + 2) * W + n] = (double)o.b;
+            }
+        }
+        prev_own = own;
+    }
+    return CM_OK;
+}
+
+// ---- SECAM modulator (rows mode: rgb [n][3][W] -> composite [n][W]) -------------------------------------
+template <typename T, typename TD>
+static int sim_secam_mod(const cm_plan_desc *d, const double *rgb, double *comp, int n_calls, int frame, int first_line, int k0) {
+    SecamModK<T, TD> k;
+    if (!build_secam_mod_k<T, TD>(*d, k, g_err)) return CM_ERR_UNSUPPORTED;
+    const int W = d->width;
+    const cm_lane_table &tb = d->mod_main;
+    for (int i = 0; i < n_calls; ++i) {
+        int kk = k0 + i, regime = kk < 2 ? kk : 2, line = first_line + 2 * i;
+        if (line < 0 || line >= tb.n_lines) { g_err = "line outside the lane table"; return CM_ERR_INVALID; }
+        SecamModLaneK<T, TD> lk = convert_secam_mod_lane<T, TD>(lane_entry<T>(tb, frame, regime, line));
+        SecamMod<T, TD> st;
+        st.reset();
+        std::vector<T> luma(W + 16, T(0));
+        for (int n = 0; n < W + k.s_p; ++n) {
+            T comp3[2][3] = {{0, 0, 0}, {0, 0, 0}};  // own row, previous call's row
+            for (int which = 0; which < 2; ++which) {
+                int row = i - which < 0 ? i : i - which;
+                if (n < W)
+                    for (int c = 0; c < 3; ++c) {
+                        T acc = T(0);
+                        for (int p = 0; p < 3; ++p) acc += k.e[c][p] * T(rgb[((size_t)row * 3 + p) * W + n]);
+                        comp3[which][c] = acc;
+                    }
+            }
+            T y = lk.wy0 * comp3[0][0] + lk.wy1 * comp3[1][0];
+            int sel = lk.own_is_db != T(0) ? 2 : 1;
+            T dsel = lk.wc0 * comp3[0][sel] + lk.wc1 * comp3[1][sel];
+            if (n < W) luma[n] = y;
+            int n7 = n - k.s_p;
+            T out = st.step(k, lk, n, n7 >= 0 ? luma[n7] : T(0), dsel);
+            if (n7 >= 0 && n7 < W) comp[(size_t)i * W + n7] = (double)out;
+        }
+    }
+    return CM_OK;
+}
+
+extern "C" {
+int cm_sim_secam_modulate_run_f64(const cm_plan_desc *d, const double *rgb, double *comp, int n_calls, int frame, int first_line, int k0) {
+    return sim_secam_mod<double, double>(d, rgb, comp, n_calls, frame, first_line, k0);
+}
+int cm_sim_secam_modulate_run_f32(const cm_plan_desc *d, const double *rgb, double *comp, int n_calls, int frame, int first_line, int k0) {
+    return sim_secam_mod<float, double>(d, rgb, comp, n_calls, frame, first_line, k0);
+}
+}
+
+extern "C" {
+int cm_sim_secam_demodulate_run_f64(const cm_plan_desc *d, const double *comp, double *rgb, int n_calls, int frame, int first_line, int k0) {
+    return sim_secam_run<double>(d, comp, rgb, n_calls, frame, first_line, k0);
+}
+int cm_sim_secam_demodulate_run_f32(const cm_plan_desc *d, const double *comp, double *rgb, int n_calls, int frame, int first_line, int k0) {
+    return sim_secam_run<float>(d, comp, rgb, n_calls, frame, first_line, k0);
+}
+}
+
 extern "C" {
 const char *cm_sim_last_error(void) { return g_err.c_str(); }
 int cm_sim_demodulate_run_f64(const cm_plan_desc *d, const double *comp, double *rgb, int n_calls, int frame, int first_line,

@@ -14,10 +14,8 @@ from color_modem_amd import image, testing
 pytestmark = pytest.mark.gpu
 TOL = 1e-5
 
-DEMOD_FRAMES = [n for n in sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(stacks.GOLDEN, 'frames_demod_*.npz')))
-                if 'secam' not in n]
-DEMOD_ROWS = [n for n in sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(stacks.GOLDEN, 'rows_demod_*.npz')))
-              if 'secam' not in n]
+DEMOD_FRAMES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(stacks.GOLDEN, 'frames_demod_*.npz')))
+DEMOD_ROWS = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(stacks.GOLDEN, 'rows_demod_*.npz')))
 
 
 def stack_of(name, prefix):
@@ -69,8 +67,7 @@ def test_frames_demod_vs_oracle(stack, size, n_frames, first):
 
 
 # ---- modulators ---------------------------------------------------------------------------------------
-MOD_FRAMES = [n for n in sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(stacks.GOLDEN, 'frames_mod_*.npz')))
-              if 'secam' not in n]
+MOD_FRAMES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(stacks.GOLDEN, 'frames_mod_*.npz')))
 
 
 @pytest.mark.parametrize('name', MOD_FRAMES)
@@ -85,6 +82,7 @@ def test_frames_mod_golden(name):
 
 @pytest.mark.parametrize('stack,size,n_frames,first', [
     ('pal_s', (720, 576), 2, 1), ('ntsc', (720, 480), 2, 0), ('pal_avg', (720, 31), 3, 2), ('ntsc_avg', (704, 16), 2, 1),
+    ('secam', (720, 576), 2, 5), ('secam_avg', (720, 33), 7, 0),
 ])
 def test_frames_mod_vs_oracle(stack, size, n_frames, first):
     from oracle import cm_oracle
@@ -108,3 +106,32 @@ def test_rows_mod_protocol():
             got = modem.modulate(f, y, rgb[0, i], rgb[1, i], rgb[2, i])
             want = orc.modulate(f, y, rgb[0, i], rgb[1, i], rgb[2, i])
             assert stacks.rel_err(got, want) < TOL, (stack, f, y)
+
+
+# ---- SECAM decoder on valid signals (the FM discriminator is ill-conditioned on noise) -----------------
+@pytest.mark.parametrize('size,n_frames,first', [((720, 576), 2, 3), ((720, 17), 4, 0), ((704, 8), 2, 1)])
+def test_secam_demod_vs_oracle(size, n_frames, first):
+    from oracle import cm_oracle
+    modem = stacks.make('secam', size)
+    rgb = testing.synthetic_rgb(n_frames, size[1], size[0], seed=70 + size[1])
+    comp = cm_oracle.modulate_frames_f32(modem, rgb, first_frame=first, n_threads=8)
+    got = image.ImageModem(modem).demodulate_frames(comp, first_frame=first)
+    want = cm_oracle.demodulate_frames_f32(modem, comp, first_frame=first, n_threads=8)
+    for i in range(n_frames):
+        assert stacks.rel_err(got[i], want[i]) < TOL, i
+
+
+def test_secam_round_trip_on_device():
+    """BASELINE.json configs[3]: encode + decode on the GPU; the round trip must equal the oracle's round trip."""
+    from oracle import cm_oracle
+    modem = stacks.make('secam', (720, 576))
+    im = image.ImageModem(modem)
+    rgb = testing.synthetic_rgb(2, 576, 720, seed=99)
+    comp = im.modulate_frames(rgb, first_frame=4)
+    back = im.demodulate_frames(comp, first_frame=4)
+    comp_ref = cm_oracle.modulate_frames_f32(modem, rgb, first_frame=4, n_threads=8)
+    back_ref = cm_oracle.demodulate_frames_f32(modem, comp_ref, first_frame=4, n_threads=8)
+    assert stacks.rel_err(comp, comp_ref) < TOL
+    # the decoder amplifies input differences (frequency / fdev): compare both decoders on the SAME input too
+    assert stacks.rel_err(im.demodulate_frames(comp_ref, first_frame=4), back_ref) < TOL
+    assert stacks.rel_err(back, back_ref) < 1e-4
