@@ -415,9 +415,9 @@ void cm_plan_destroy(cm_plan *p) {
 
 int cm_demodulate_frames(const cm_plan *p, const float *composite, float *rgb, int64_t n_frames, int64_t first_frame,
                          void *stream) {
+    if (p && n_frames == 0) return CM_OK;   // an empty batch may come with null buffers
     if (!p || !composite || !rgb) return fail(CM_ERR_INVALID, "null argument");
     if (n_frames < 0 || first_frame < 0) return fail(CM_ERR_INVALID, "negative frame count / number");
-    if (n_frames == 0) return CM_OK;
     if (!p->fn && !p->secam) return fail(CM_ERR_UNSUPPORTED, p->demod_error);
     const cm_plan_desc &d = p->desc;
     const int W = d.width, H = d.height, D = d.demodulation_delay;
@@ -523,9 +523,9 @@ static int run_mod(const cm_plan *p, Geom g, hipStream_t stream) {
 
 int cm_modulate_frames(const cm_plan *p, const float *rgb, float *composite, int64_t n_frames, int64_t first_frame,
                        void *stream) {
+    if (p && n_frames == 0) return CM_OK;
     if (!p || !rgb || !composite) return fail(CM_ERR_INVALID, "null argument");
     if (n_frames < 0 || first_frame < 0) return fail(CM_ERR_INVALID, "negative frame count / number");
-    if (n_frames == 0) return CM_OK;
     if (!p->mod_fn && !p->sm_lanes) return fail(CM_ERR_UNSUPPORTED, "this plan has no modulator");
     const cm_plan_desc &d = p->desc;
     const int W = d.width, H = d.height, D = d.modulation_delay;

@@ -135,3 +135,61 @@ def test_secam_round_trip_on_device():
     # the decoder amplifies input differences (frequency / fdev): compare both decoders on the SAME input too
     assert stacks.rel_err(im.demodulate_frames(comp_ref, first_frame=4), back_ref) < TOL
     assert stacks.rel_err(back, back_ref) < 1e-4
+
+
+# ---- the PIL / uint8 boundary (ImageModem.modulate / demodulate, image.py:27-84) -------------------------
+@pytest.mark.parametrize('name', sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(stacks.GOLDEN, 'image_*.npz'))))
+def test_image_uint8_golden(name):
+    from PIL import Image
+    g = stacks.load(name)
+    h, w = g['comp8'].shape
+    im = image.ImageModem(stacks.make(name[len('image_'):], (w, h)))
+    img = Image.frombytes('RGB', (w, h), numpy.ascontiguousarray(g['rgb8']).tobytes())
+    comp = im.modulate(img, int(g['frame']))
+    assert comp.mode == 'L' and comp.size == (w, h)
+    comp8 = numpy.frombuffer(comp.tobytes(), dtype=numpy.uint8).reshape(h, w)
+    diff = numpy.abs(comp8.astype(int) - g['comp8'].astype(int))
+    assert diff.max() <= 1 and (diff > 0).mean() < 2e-3     # float32 vs float64 at the rounding knife edge
+    back = im.demodulate(Image.frombytes('L', (w, h), numpy.ascontiguousarray(g['comp8']).tobytes()), int(g['frame']))
+    back8 = numpy.frombuffer(back.tobytes(), dtype=numpy.uint8).reshape(h, w, 3)
+    diff = numpy.abs(back8.astype(int) - g['back8'].astype(int))
+    assert diff.max() <= 1 and (diff > 0).mean() < 2e-3
+
+
+# ---- size-independent properties at the benchmark's frame size ------------------------------------------
+def test_full_size_properties_pal_d():
+    import torch
+    modem = stacks.make('pal_d', (720, 576))
+    eng = image.ImageModem(modem)._engine()
+    n = 24
+    comp = torch.from_numpy(testing.synthetic_composite(n, 576, 720, seed=4321)).cuda()
+    out = eng.demodulate_frames(comp, first_frame=0)
+    # (1) frames are independent: any sub-batch gives bit-identical results
+    part = eng.demodulate_frames(comp[5:9].contiguous(), first_frame=5)
+    assert torch.equal(out[5:9], part)
+    # (2) the carrier phase repeats every 4 frames (PAL 8-field sequence)
+    again = eng.demodulate_frames(comp, first_frame=4)
+    assert torch.equal(out, again)
+    other = eng.demodulate_frames(comp, first_frame=1)
+    assert not torch.equal(out, other)
+    # (3) the decoder is linear in the composite signal
+    a, b = comp[:n // 2], comp[n // 2:]
+    lin = eng.demodulate_frames((0.5 * a - 0.25 * b).contiguous(), first_frame=0)
+    ref = 0.5 * out[:n // 2] - 0.25 * eng.demodulate_frames(b.contiguous(), first_frame=0)
+    err = float((lin - ref).abs().max() / ref.abs().max())
+    assert err < 5e-6, err
+    # (4) a constant composite carries no chroma: the decoder returns grey at that level away from the row edges
+    flat = torch.full((1, 576, 720), 0.4, dtype=torch.float32, device='cuda')
+    g = eng.demodulate_frames(flat, 0)[0, :, 8:, 100:620]
+    assert float((g - 0.4).abs().max()) < 1e-4
+
+
+def test_empty_batch_and_bad_shapes():
+    import torch
+    eng = image.ImageModem(stacks.make('pal_d', (720, 576)))._engine()
+    out = eng.demodulate_frames(torch.empty((0, 576, 720), dtype=torch.float32, device='cuda'))
+    assert tuple(out.shape) == (0, 3, 576, 720)
+    with pytest.raises(ValueError):
+        eng.demodulate_frames(numpy.zeros((1, 575, 720), dtype=numpy.float32))
+    with pytest.raises(ValueError):
+        stacks.make('pal_d', (720, 576)).demodulate(0, 0, numpy.zeros(719))

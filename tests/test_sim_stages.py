@@ -58,3 +58,42 @@ def test_streaming_matches_oracle(sim, stack, size, frame, first_line):
     for i in range(n):
         assert stacks.rel_err(o64[i], ref[i]) < 1e-11, (stack, i)
         assert stacks.rel_err(o32[i], ref[i]) < 2e-6, (stack, i)
+
+
+@pytest.fixture(scope='module')
+def sim_secam(sim):
+    dp = ctypes.POINTER(ctypes.c_double)
+    for fn in (sim.cm_sim_secam_demodulate_run_f64, sim.cm_sim_secam_demodulate_run_f32,
+               sim.cm_sim_secam_modulate_run_f64, sim.cm_sim_secam_modulate_run_f32):
+        fn.argtypes = [ctypes.POINTER(plan.PlanDesc), dp, dp] + [ctypes.c_int] * 4
+    return sim
+
+
+@pytest.mark.parametrize('frame,first_line', [(0, 0), (1, 1), (5, 4)])
+def test_secam_streaming_matches_oracle(sim_secam, frame, first_line):
+    """SECAM encoder and decoder stages (float64: schedule; float32 (+ float64 phase path): device rounding)."""
+    from oracle import cm_oracle
+    dp = ctypes.POINTER(ctypes.c_double)
+    n = 4
+    for stack in ('secam', 'secam_avg'):
+        modem = stacks.make(stack, (720, 576), explicit=False)
+        bp = plan.build_plan(modem)
+        rgb = testing.synthetic_rgb(1, n, 720, seed=5 + frame)[0].astype(numpy.float64)
+        orc = cm_oracle.OracleModem(modem)
+        ref = numpy.stack([orc.modulate(frame, first_line + 2 * i, rgb[0, i], rgb[1, i], rgb[2, i]) for i in range(n)])
+        rows = numpy.ascontiguousarray(rgb.transpose(1, 0, 2))
+        for fn, tol in ((sim_secam.cm_sim_secam_modulate_run_f64, 1e-11), (sim_secam.cm_sim_secam_modulate_run_f32, 2e-6)):
+            out = numpy.zeros((n, 720))
+            assert fn(ctypes.byref(bp.desc), rows.ctypes.data_as(dp), out.ctypes.data_as(dp), n, frame, first_line, 0) == 0
+            for i in range(n):
+                assert stacks.rel_err(out[i], ref[i]) < tol, (stack, i)
+    modem = stacks.make('secam', (720, 576), explicit=False)
+    bp = plan.build_plan(modem)
+    comp = numpy.ascontiguousarray(ref.astype(numpy.float32).astype(numpy.float64))  # a valid SECAM signal (averaged variant)
+    orc = cm_oracle.OracleModem(modem)
+    want = numpy.stack([numpy.stack(orc.demodulate(frame, first_line + 2 * i, comp[i])) for i in range(n)])
+    for fn, tol in ((sim_secam.cm_sim_secam_demodulate_run_f64, 1e-11), (sim_secam.cm_sim_secam_demodulate_run_f32, 8e-6)):
+        out = numpy.zeros((n, 3, 720))
+        assert fn(ctypes.byref(bp.desc), comp.ctypes.data_as(dp), out.ctypes.data_as(dp), n, frame, first_line, 0) == 0
+        for i in range(n):
+            assert stacks.rel_err(out[i], want[i]) < tol, i
