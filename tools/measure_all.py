@@ -1,0 +1,53 @@
+"""Throughput of every built pipeline at its BASELINE.json frame size + parity error vs the oracle on 2 frames.
+Run on the GPU box: python tools/measure_all.py [frames]"""
+import sys, time, json, numpy, torch
+sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
+import stacks
+from color_modem_amd import image, testing
+from oracle import cm_oracle
+F = int(sys.argv[1]) if len(sys.argv) > 1 else 400
+rows = []
+def timeit(fn, reps=5):
+    fn(); torch.cuda.synchronize()
+    ts = []
+    for _ in range(reps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); fn(); e1.record(); torch.cuda.synchronize(); ts.append(e0.elapsed_time(e1))
+    return sorted(ts)[len(ts) // 2]
+for stack, size, direction in [('pal_d', (720, 576), 'demod'), ('pal_s', (720, 576), 'demod'), ('pal_3d', (720, 576), 'demod'),
+                               ('ntsc', (720, 480), 'demod'), ('ntsc_comb', (720, 480), 'demod'), ('ntsc_comb_3d', (720, 480), 'demod'),
+                               ('secam', (720, 576), 'demod'), ('secam', (720, 576), 'mod'), ('secam_avg', (720, 576), 'mod'),
+                               ('pal_s', (720, 576), 'mod'), ('ntsc', (720, 480), 'mod')]:
+    w, h = size
+    modem = stacks.make(stack, size)
+    im = image.ImageModem(modem); eng = im._engine()
+    rgb2 = testing.synthetic_rgb(2, h, w, seed=3)
+    base = stack.replace('_avg', '')
+    enc = stacks.make({'pal_d': 'pal_s', 'pal_3d': 'pal_s', 'ntsc_comb': 'ntsc', 'ntsc_comb_3d': 'ntsc'}.get(base, base), size)
+    if direction == 'demod':
+        comp2 = cm_oracle.modulate_frames_f32(enc, rgb2, 1, 8)
+        got = eng.demodulate_frames(comp2, 1); want = cm_oracle.demodulate_frames_f32(modem, comp2, 1, 8)
+        x = torch.from_numpy(comp2).cuda().repeat(F // 2, 1, 1).contiguous()
+        x += 0.001 * torch.rand_like(x)
+        out = torch.empty((F, 3, h, w), dtype=torch.float32, device='cuda')
+        ms = timeit(lambda: eng.demodulate_frames(x, 0, out=out))
+    else:
+        got = eng.modulate_frames(rgb2, 1); want = cm_oracle.modulate_frames_f32(modem, rgb2, 1, 8)
+        x = torch.rand((F, 3, h, w), dtype=torch.float32, device='cuda')
+        out = torch.empty((F, h, w), dtype=torch.float32, device='cuda')
+        ms = timeit(lambda: eng.modulate_frames(x, 0, out=out))
+    err = max(stacks.rel_err(got[i], want[i]) for i in range(2))
+    px = F * w * h
+    rows.append((stack, direction, '%dx%d' % size, F, round(ms, 3), round(px / ms / 1e3), round(16 * px / ms / 1e6), '%.1e' % err))
+    print(rows[-1], flush=True)
+# PCIe-inclusive: numpy in, numpy out through the Python API (pageable host memory)
+modem = stacks.make('pal_d', (720, 576)); eng = image.ImageModem(modem)._engine()
+comp = testing.synthetic_composite(4, 576, 720).repeat(25, axis=0)
+eng.demodulate_frames(comp[:4], 0)
+t = time.perf_counter(); eng.demodulate_frames(comp, 0); dt = time.perf_counter() - t
+print('PCIe-inclusive numpy->numpy PAL-D demod, 100 frames: %.1f ms -> %.0f Mpx/s' % (dt * 1e3, 100 * 576 * 720 / dt / 1e6))
+x = torch.from_numpy(comp).pin_memory(); o = torch.empty((100, 3, 576, 720), dtype=torch.float32).pin_memory()
+torch.cuda.synchronize(); t = time.perf_counter()
+d = x.cuda(non_blocking=True); r = eng.demodulate_frames(d, 0); o.copy_(r, non_blocking=True); torch.cuda.synchronize()
+dt = time.perf_counter() - t
+print('PCIe-inclusive pinned h2d + demod + d2h, 100 frames: %.1f ms -> %.0f Mpx/s' % (dt * 1e3, 100 * 576 * 720 / dt / 1e6))
