@@ -114,8 +114,6 @@ std::vector<T> build_carrier(double cps, int width) {
 template <typename T>
 LaneK<T> convert_lane(const double *e, const DemodScales &sc) {
     LaneK<T> l;
-    l.sth = T(e[0]);
-    l.cth = T(e[1]);
     l.sph = T(e[2] * sc.pre);
     l.cph = T(e[3] * sc.pre);
     l.vsph = T(e[2] * sc.pre * e[16]);

@@ -160,11 +160,13 @@ CM_HD T iir_gen(IirState<T, MAXSEC> &st, const SosK<T, MAXSEC> &k, T x) {
 // ---- per-lane constants (host-computed, float64 -> T) ---------------------------------------
 template <typename T>
 struct LaneK {
-    T sth, cth;  // sin/cos of the detector phase at sample 0 of this line
     T sph, cph;  // sin/cos of the re-modulation phase times the pre-filter gain; both 0 when luma
                  // is passed through unstripped
     T vsph, vcph;  // the same two times the V-switch sign of the re-modulated line (ref pal.py:50-51)
-    T cu[3][2];  // u = sum_j cu[j][0] * Bs[k-j] + cu[j][1] * Bc[k-j]
+    // R[k] = (Rs, Rc) = the line's phase-free base pair: detector products against sin / cos(m cps),
+    // low-passed and decimated.  The detector phase of every contributing line and all filter gains
+    // are folded into these coefficients by the host.
+    T cu[3][2];  // u = sum_j cu[j][0] * Rs[k-j] + cu[j][1] * Rc[k-j]
     T cv[3][2];  // v likewise
 };
 
@@ -245,13 +247,10 @@ struct PalDFront {
         // --- up2(e)
         T u_odd = up_e.push(k.taps, e);
         T u_even = k.taps.c0 * e_d10;
-        // --- product detectors: sin and cos of (theta + m cps), m = 2 n4, 2 n4 + 1
-        T sin_e = fmaf_(lk.sth, car[0], lk.cth * car[1]);
-        T cos_e = fmaf_(lk.cth, car[0], -(lk.sth * car[1]));
-        T sin_o = fmaf_(lk.sth, car[2], lk.cth * car[3]);
-        T cos_o = fmaf_(lk.cth, car[2], -(lk.sth * car[3]));
-        T ps_e = u_even * sin_e, pc_e = u_even * cos_e;
-        T ps_o = u_odd * sin_o, pc_o = u_odd * cos_o;
+        // --- product detectors against the phase-free carriers sin / cos(m cps), m = 2 n4, 2 n4 + 1; the
+        //     line's detector phase is a rotation of the resulting pair and lives in LaneK::cu / cv
+        T ps_e = u_even * car[1], pc_e = u_even * car[0];
+        T ps_o = u_odd * car[3], pc_o = u_odd * car[2];
         T qs_e = T(0), qs_o = T(0), qc_e = T(0), qc_o = T(0);
         if (!EDGE || (n4 >= 0 && n4 < W + k.q_l)) {
             if (EDGE) {
@@ -328,13 +327,9 @@ struct QamFront {
             if (EDGE && (nr < 0 || nr >= W)) r_even = r_odd = T(0);
             luma_out = dn_y.push_pair(k.taps, r_even, r_odd) * k.luma_gain;
         }
-        // --- product detectors at 2x rate, m = 2 n2, 2 n2 + 1
-        T sin_e = fmaf_(lk.sth, car[0], lk.cth * car[1]);
-        T cos_e = fmaf_(lk.cth, car[0], -(lk.sth * car[1]));
-        T sin_o = fmaf_(lk.sth, car[2], lk.cth * car[3]);
-        T cos_o = fmaf_(lk.cth, car[2], -(lk.sth * car[3]));
-        T ps_e = b_even * sin_e, pc_e = b_even * cos_e;
-        T ps_o = b_odd * sin_o, pc_o = b_odd * cos_o;
+        // --- product detectors at 2x rate against the phase-free carriers, m = 2 n2, 2 n2 + 1
+        T ps_e = b_even * car[1], pc_e = b_even * car[0];
+        T ps_o = b_odd * car[3], pc_o = b_odd * car[2];
         T qs_e = T(0), qs_o = T(0), qc_e = T(0), qc_o = T(0);
         if (!EDGE || (n2 >= 0 && n2 < W + k.q_l)) {
             if (EDGE) {

@@ -325,6 +325,19 @@ class QamTables(object):
     def n_lines(self):
         return self.height + 2 * max(self.demodulation_delay, self.modulation_delay) + 4
 
+    def phase_free(self, lin, frame, line):
+        """Re-express a combination over the base pairs B_{k-j} (detected at each line's own phase theta_j)
+        over the phase-free pairs R_{k-j}:  Bs = cos(theta) Rs + sin(theta) Rc,  Bc = -sin(theta) Rs + cos(theta) Rc."""
+        out = numpy.zeros((3, 2))
+        for j in range(3):
+            if not lin.c[j].any():
+                continue
+            th = self.detector_phase(frame, line - 2 * j)
+            c0, c1 = lin.c[j]
+            out[j, 0] = c0 * numpy.cos(th) - c1 * numpy.sin(th)
+            out[j, 1] = c0 * numpy.sin(th) + c1 * numpy.cos(th)
+        return out
+
     def demod_main_table(self):
         n_lines = self.n_lines()
         tab = numpy.zeros((self.cycle, 3, n_lines, CM_LANE_DOUBLES))
@@ -345,8 +358,8 @@ class QamTables(object):
                         p = self.phi(f, remod_line)
                         e[2], e[3] = numpy.sin(p), numpy.cos(p)
                         e[16] = self.vsign(f, remod_line)  # pal.py:50-51
-                    e[4:10] = u.c.reshape(-1)
-                    e[10:16] = v.c.reshape(-1)
+                    e[4:10] = self.phase_free(u, f, line).reshape(-1)
+                    e[10:16] = self.phase_free(v, f, line).reshape(-1)
                     if luma_prev:
                         luma_prev_bits |= 1 << k
         return tab, luma_prev_bits
@@ -360,8 +373,10 @@ class QamTables(object):
                 e = tab[f, 0, line]
                 theta = self.phi(f, line) + self.ps
                 e[0], e[1] = numpy.sin(theta), numpy.cos(theta)
-                e[4:10] = u.c.reshape(-1)
-                e[10:16] = v.c.reshape(-1)
+                for lin, lo in ((u, 4), (v, 10)):   # plain decoder: the QAM front end's phase, not the PAL-D one
+                    c0, c1 = lin.c[0]
+                    e[lo] = c0 * numpy.cos(theta) - c1 * numpy.sin(theta)
+                    e[lo + 1] = c0 * numpy.sin(theta) + c1 * numpy.cos(theta)
                 e[16] = 1.0
         return tab
 

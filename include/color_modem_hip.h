@@ -69,14 +69,16 @@ typedef struct {
 } cm_iir_desc;
 
 /* Per-(frame mod cycle, regime, line) constants of one pass; CM_LANE_DOUBLES doubles each:
- *   [0] sin, [1] cos of the detector phase at the first 2x sample of the line
+ *   [0] sin, [1] cos of the detector phase at the first 2x sample of the line (informative; already folded
+ *            into [4..15])
  *   [2] sin, [3] cos of the re-modulation phase; both 0 = luma passes unstripped
- *   [4..9]   u = sum_j t[4+2j] * Bs[k-j] + t[5+2j] * Bc[k-j],  j = 0..2
+ *   [4..9]   u = sum_j t[4+2j] * Rs[k-j] + t[5+2j] * Rc[k-j],  j = 0..2
  *   [10..15] v likewise
  *   [16]     +1 / -1: sign applied to v on re-modulation (the PAL V switch, pal.py:50-51)
  *   [17..19] reserved (0)
- * where (Bs, Bc)[k] is the base demodulation of call k's own input line with the phase above
- * (qam.py:47-54 for CM_PIPE_QAM, pal.py:71-77 applied to qam.py:34-37 for CM_PIPE_PAL_D).
+ * where (Rs, Rc)[k] is the phase-free base demodulation of call k's own input line: the detector chain of
+ * qam.py:45-54 (CM_PIPE_QAM) or of pal.py:71-77 applied to qam.py:34-37 (CM_PIPE_PAL_D) run with the carriers
+ * sin(m cps) / cos(m cps) and without its gains; the line's carrier phase is a rotation of that pair.
  * regime = min(k, 2), k = index of the call within its run (0 = first line after a reset). */
 typedef struct {
     int32_t frame_cycle;  /* table rows per regime: frames repeat with this period */
