@@ -343,15 +343,22 @@ __device__ __forceinline__ void run_lane(const Geom &g, const DemodK<float, type
     }
     f4 nl = read_luma(-lat_out, true);
 
-    auto carriers = [&](int t, bool edge, float car[4], float carb[2]) {
-        int nf = t - front_off, nb = t - lat_out;
+    // carriers of step base + sub; in the edge-free body the two table pointers are formed once per body
+    // and the sub-steps differ by immediate offsets only
+    auto carriers = [&](const_f4 *c4, const_f2 *c2, int t, int sub, bool edge, float car[4], float carb[2]) {
+        f4 c;
+        f2 d;
         if (edge) {
+            int nf = t - front_off, nb = t - lat_out;
             nf = nf < 0 ? 0 : (nf > W - 1 ? W - 1 : nf);
             nb = nb < 0 ? 0 : (nb > W - 1 ? W - 1 : nb);
+            c = ((const_f4 *)g.carrier4)[nf];
+            d = ((const_f2 *)g.carrier2)[nb];
+        } else {
+            c = c4[sub];
+            d = c2[sub];
         }
-        f4 c = ((const_f4 *)g.carrier4)[nf];
         car[0] = c.x; car[1] = c.y; car[2] = c.z; car[3] = c.w;
-        f2 d = ((const_f2 *)g.carrier2)[nb];
         carb[0] = d.x; carb[1] = d.y;
     };
 
@@ -370,14 +377,16 @@ __device__ __forceinline__ void run_lane(const Geom &g, const DemodK<float, type
         const int nxt = tb + 4;
         nl = read_luma(nxt - lat_out, EDGE || nxt >= t_mid1);  // next body's luma: a whole body hides the latency
         float carA[4], carbA[2], carB[4], carbB[2];
-        carriers(tb + 0, EDGE, carA, carbA);
-        carriers(tb + 1, EDGE, carB, carbB);
+        const_f4 *c4 = (const_f4 *)g.carrier4 + (tb - front_off);
+        const_f2 *c2 = (const_f2 *)g.carrier2 + (tb - lat_out);
+        carriers(c4, c2, tb + 0, 0, EDGE, carA, carbA);
+        carriers(c4, c2, tb + 1, 1, EDGE, carB, carbB);
         L.template substep<0, EDGE>(g, k, tb + 0, lat_front, lat_luma, carA, carbA, otile, yring, lane, wpos);
         if (s_flush == 0) maybe_flush(tb + 0);
-        carriers(tb + 2, EDGE, carA, carbA);
+        carriers(c4, c2, tb + 2, 2, EDGE, carA, carbA);
         L.template substep<1, EDGE>(g, k, tb + 1, lat_front, lat_luma, carB, carbB, otile, yring, lane, wpos);
         if (s_flush == 1) maybe_flush(tb + 1);
-        carriers(tb + 3, EDGE, carB, carbB);
+        carriers(c4, c2, tb + 3, 3, EDGE, carB, carbB);
         L.template substep<2, EDGE>(g, k, tb + 2, lat_front, lat_luma, carA, carbA, otile, yring, lane, wpos);
         if (s_flush == 2) maybe_flush(tb + 2);
         L.template substep<3, EDGE>(g, k, tb + 3, lat_front, lat_luma, carB, carbB, otile, yring, lane, wpos);
