@@ -107,7 +107,7 @@ struct DemodLane {
     LaneK<float> lk;
     float xw[14];
     float ew[FRONT == FRONT_PALD ? 14 : 1];
-    float uw[SP + 4], vw[SP + 4];
+    float ud[SP > 0 ? SP : 1], vd[SP > 0 ? SP : 1];   // u, v of the last SP steps (newest first)
     f4 lw;
     Pair<float> base_prev, b1_prev, b2_prev;
     const float *lp;
@@ -116,17 +116,18 @@ struct DemodLane {
     // One step.  car: detector carriers of this step, carb: re-modulation carrier of the back-end
     // sample n7 = tau - lat_front - 1 - SP.  Returns true when an output tile has just been completed.
     template <int SUB, bool EDGE>
-    __device__ __forceinline__ void substep(const Geom &g, const K &k, int tau, int lat_front, int lat_luma, const float car[4],
-                                            const float carb[2], lds_float *otile, lds_float *yring, int lane, int wpos) {
+    __device__ __forceinline__ void substep(const Geom &g, const K &k, FrontLatch<float> &fla, BackLatch<float> &bla, int tau,
+                                            int lat_front, int lat_luma, const float car[4], const float carb[2],
+                                            lds_float *otile, lds_float *yring, int lane, int wpos) {
         const int W = g.W;
         float luma_bsf = 0.f;
         Pair<float> base;
         if constexpr (FRONT == FRONT_PALD) {
             float e_out;
-            base = front.template step<EDGE>(k, lk, tau, xw[10 + SUB], xw[SUB], ew[FRONT == FRONT_PALD ? SUB : 0], car, e_out);
+            base = front.template step<EDGE>(k, fla, tau, xw[10 + SUB], xw[SUB], ew[FRONT == FRONT_PALD ? SUB : 0], car, e_out);
             ew[FRONT == FRONT_PALD ? 10 + SUB : 0] = e_out;
         } else {
-            base = front.template step<EDGE>(k, lk, tau, xw[10 + SUB], xw[SUB], car, luma_bsf);
+            base = front.template step<EDGE>(k, fla, tau, xw[10 + SUB], xw[SUB], car, luma_bsf);
         }
         // the back end handles the PREVIOUS step's base pair: its neighbours were requested then
         const int n6 = tau - lat_front - 1, n7 = n6 - SP;
@@ -143,9 +144,11 @@ struct DemodLane {
         } else {
             y_src = SUB == 0 ? lw.x : (SUB == 1 ? lw.y : (SUB == 2 ? lw.z : lw.w));
         }
-        uw[SP + SUB] = u;
-        vw[SP + SUB] = v;
-        Rgb<float> o = back.template step<EDGE>(k, lk, n6, u, v, uw[SUB], vw[SUB], y_src, carb);
+        const float u_d = SP > 0 ? ud[SP > 0 ? SP - 1 : 0] : u, v_d = SP > 0 ? vd[SP > 0 ? SP - 1 : 0] : v;
+        Rgb<float> o = back.template step<EDGE>(k, lk, bla, n6, u, v, u_d, v_d, y_src, carb);
+#pragma unroll
+        for (int j = SP - 1; j > 0; --j) { ud[j] = ud[j - 1]; vd[j] = vd[j - 1]; }
+        if (SP > 0) { ud[0] = u; vd[0] = v; }
         if (!EDGE || (n7 >= 0 && n7 < W)) {
             lds_float *tp = otile + (wpos ^ (n7 & (kTile - 1)));
             tp[0] = o.r;
@@ -250,8 +253,14 @@ __device__ __forceinline__ LaneCall locate_call(const Geom &g, int block, int de
 }
 
 template <class Cfg>
-__device__ __forceinline__ void run_lane(const Geom &g, const DemodK<float, typename Cfg::S> &k, int block, lds_float *lds) {
+__device__ __forceinline__ void run_lane(const Geom &g, const DemodK<float, typename Cfg::S> &k_in, int block, lds_float *lds) {
     typedef DemodLane<Cfg> Lane;
+    // hot coefficient blocks live in VGPRs (see cm_stages.h: CM_V_*)
+    DemodK<float, typename Cfg::S> k = k_in;
+    typedef typename Lane::Front::VP VP;
+    if (VP::VT) pin_block(k.taps);
+    if (VP::VL) pin_block(k.lpf, true);
+    if (VP::VB) pin_block(k.ext, false);
     typedef typename Cfg::S S;
     constexpr int FRONT = Cfg::FRONT, DEPTH = Cfg::DEPTH, kTile = Cfg::TILE;
     constexpr bool BSF = Cfg::BSF;
@@ -284,7 +293,7 @@ __device__ __forceinline__ void run_lane(const Geom &g, const DemodK<float, type
 #pragma unroll
     for (int j = 0; j < (FRONT == FRONT_PALD ? 14 : 1); ++j) L.ew[j] = 0.f;
 #pragma unroll
-    for (int j = 0; j < S::SP + 4; ++j) L.uw[j] = L.vw[j] = 0.f;
+    for (int j = 0; j < (S::SP > 0 ? S::SP : 1); ++j) L.ud[j] = L.vd[j] = 0.f;
     if (BSF) {
         for (int j = 0; j < 16; ++j) yring[j * 64 + lane] = 0.f;
     }
@@ -302,7 +311,6 @@ __device__ __forceinline__ void run_lane(const Geom &g, const DemodK<float, type
     const int front_off = FRONT == FRONT_PALD ? 10 + k.q_e + 9 + 10 : 10 + k.q_e;  // detector sample pair = t - front_off
     int t_mid0 = (lat_out + 3) & ~3;           // every stage index >= 0 from here on
     int t_mid1 = (W - 4) & ~3;                 // bodies below this never touch the end of the row
-    if (t_mid1 < t_mid0) t_mid1 = t_mid0;
 
     const lds_float *xrow = itile + lane * kInTile;
     auto read_x = [&](int first) -> f4 {  // x[first .. first + 3] from the input tile, zero outside the row
@@ -371,7 +379,7 @@ __device__ __forceinline__ void run_lane(const Geom &g, const DemodK<float, type
             flush_tile<kTile>(g, otile_base, op, n7 & ~(kTile - 1), lane);
     };
 
-    auto body = [&](int tb, auto edge_tag) {
+    auto body = [&](int tb, auto edge_tag, FrontLatch<float> &fla, BackLatch<float> &bla) {
         constexpr bool EDGE = decltype(edge_tag)::value;
         L.lw = nl;
         const int nxt = tb + 4;
@@ -381,15 +389,15 @@ __device__ __forceinline__ void run_lane(const Geom &g, const DemodK<float, type
         const_f2 *c2 = (const_f2 *)g.carrier2 + (tb - lat_out);
         carriers(c4, c2, tb + 0, 0, EDGE, carA, carbA);
         carriers(c4, c2, tb + 1, 1, EDGE, carB, carbB);
-        L.template substep<0, EDGE>(g, k, tb + 0, lat_front, lat_luma, carA, carbA, otile, yring, lane, wpos);
+        L.template substep<0, EDGE>(g, k, fla, bla, tb + 0, lat_front, lat_luma, carA, carbA, otile, yring, lane, wpos);
         if (s_flush == 0) maybe_flush(tb + 0);
         carriers(c4, c2, tb + 2, 2, EDGE, carA, carbA);
-        L.template substep<1, EDGE>(g, k, tb + 1, lat_front, lat_luma, carB, carbB, otile, yring, lane, wpos);
+        L.template substep<1, EDGE>(g, k, fla, bla, tb + 1, lat_front, lat_luma, carB, carbB, otile, yring, lane, wpos);
         if (s_flush == 1) maybe_flush(tb + 1);
         carriers(c4, c2, tb + 3, 3, EDGE, carB, carbB);
-        L.template substep<2, EDGE>(g, k, tb + 2, lat_front, lat_luma, carA, carbA, otile, yring, lane, wpos);
+        L.template substep<2, EDGE>(g, k, fla, bla, tb + 2, lat_front, lat_luma, carA, carbA, otile, yring, lane, wpos);
         if (s_flush == 2) maybe_flush(tb + 2);
-        L.template substep<3, EDGE>(g, k, tb + 3, lat_front, lat_luma, carB, carbB, otile, yring, lane, wpos);
+        L.template substep<3, EDGE>(g, k, fla, bla, tb + 3, lat_front, lat_luma, carB, carbB, otile, yring, lane, wpos);
         if (s_flush == 3) maybe_flush(tb + 3);
 #pragma unroll
         for (int j = 0; j < 10; ++j) L.xw[j] = L.xw[j + 4];
@@ -413,13 +421,24 @@ __device__ __forceinline__ void run_lane(const Geom &g, const DemodK<float, type
 #pragma unroll
             for (int j = 0; j < 10; ++j) L.ew[FRONT == FRONT_PALD ? j : 0] = L.ew[FRONT == FRONT_PALD ? j + 4 : 0];
         }
-#pragma unroll
-        for (int j = 0; j < S::SP; ++j) { L.uw[j] = L.uw[j + 4]; L.vw[j] = L.vw[j + 4]; }
     };
+    // The end-of-row latches are only ever set at t >= W - 1.  When an edge-free region exists they
+    // are therefore dead until the tail loop; without one (tiny rows) the tail loop runs everything.
+    if (t_mid1 <= t_mid0) t_mid0 = t_mid1 = 0;
     int tb = 0;
-    for (; tb < t_mid0; tb += 4) body(tb, std::true_type());
-    for (; tb < t_mid1; tb += 4) body(tb, std::false_type());
-    for (; tb < T; tb += 4) body(tb, std::true_type());
+    {
+        FrontLatch<float> fla;
+        BackLatch<float> bla;
+        fla.reset();
+        bla.reset();
+        for (; tb < t_mid0; tb += 4) body(tb, std::true_type(), fla, bla);
+        for (; tb < t_mid1; tb += 4) body(tb, std::false_type(), fla, bla);
+    }
+    FrontLatch<float> fla;
+    BackLatch<float> bla;
+    fla.reset();
+    bla.reset();
+    for (; tb < T; tb += 4) body(tb, std::true_type(), fla, bla);
 }
 
 template <class S>

@@ -27,7 +27,11 @@ __global__ __launch_bounds__(64, 2) void secam_demod_kernel(const SecamDemodArgs
     lds_float *itile = (lds_float *)lds_store;
     lds_float *otile_base = itile + kLdsIn;
     const Geom &g = args.g;
-    const SecamDemodK<float> &k = args.k;
+    SecamDemodK<float> k = args.k;
+    typedef SecamDemod<float>::VP VP;
+    if (VP::VT) pin_block(k.taps);
+    if (VP::VL) pin_block(k.lpf, true);
+    if (VP::VB) pin_block(k.bpf, false);
     const int lane = threadIdx.x;
     const LaneCall lc = locate_call(g, blockIdx.x, DEPTH, lane);
     const float *xp = g.in + lc.frame * g.in_frame_stride + (long long)lc.src_row * g.W;

@@ -50,15 +50,48 @@ struct Sys {
 // fma3: d = c * x + acc with d allowed to differ from acc.  On the device this must be the
 // VOP3 form: hipcc otherwise picks the 2-address v_fmac and pays one v_mov per tap to rotate
 // the accumulators (profiles/r01_ubench_valu.txt, "chain" rows).
+// Where a wave-uniform coefficient block lives on the device.  Measured (profiles/r01_notes.md): vector
+// instructions that read many different SGPRs issue at ~0.6e12 /s chip-wide at 2 waves per SIMD, the same
+// instructions with the coefficient in a VGPR at ~0.9e12 /s.  The hot blocks (FIR taps, the 2x-rate
+// low-pass and band-pass sections) are therefore pinned into VGPRs by the kernels; V selects the asm form.
+// per front end: {FIR taps, detector low-pass, band-pass} -> 1 = VGPR
+#ifndef CM_V_PALD
+#define CM_V_PALD 1, 0, 0     /* 245 VGPRs without pinning: only the taps (100 of 202 instructions) fit */
+#endif
+#ifndef CM_V_QAM
+#define CM_V_QAM 1, 1, 1
+#endif
+#ifndef CM_V_SECAM
+#define CM_V_SECAM 1, 1, 1
+#endif
+template <int VT_, int VL_, int VB_>
+struct VPolicy {
+    static constexpr bool VT = VT_ != 0, VL = VL_ != 0, VB = VB_ != 0;
+};
+template <bool V>
 CM_HD float fma3(float c, float x, float acc) {
 #if defined(__HIP_DEVICE_COMPILE__)
     float d;
-    asm("v_fma_f32 %0, %1, %2, %3" : "=v"(d) : "s"(c), "v"(x), "v"(acc));
+    if (V)
+        asm("v_fma_f32 %0, %1, %2, %3" : "=v"(d) : "v"(c), "v"(x), "v"(acc));
+    else
+        asm("v_fma_f32 %0, %1, %2, %3" : "=v"(d) : "s"(c), "v"(x), "v"(acc));
     return d;
 #else
     return std::fma(c, x, acc);
 #endif
 }
+template <bool V>
+CM_HD double fma3(double c, double x, double acc) { return c * x + acc; }
+// keep a value in a vector register (no-op on the host)
+CM_HD void pin_vgpr(float &v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" : "+v"(v));
+#else
+    (void)v;
+#endif
+}
+CM_HD void pin_vgpr(double &) {}
 CM_HD float fmaf_(float a, float b, float c) {
 #if defined(__HIP_DEVICE_COMPILE__)
     return __builtin_fmaf(a, b, c);
@@ -66,7 +99,6 @@ CM_HD float fmaf_(float a, float b, float c) {
     return std::fma(a, b, c);
 #endif
 }
-CM_HD double fma3(double c, double x, double acc) { return c * x + acc; }
 CM_HD double fmaf_(double a, double b, double c) { return a * b + c; }
 
 // ---- uniform coefficient blocks -----------------------------------------------------------
@@ -82,6 +114,22 @@ struct SosK {  // NSEC sections normalised to b0 = 1; gains are folded elsewhere
     T b1[NSEC], b2[NSEC];    // used by the SYM (b1) and GEN (b1, b2) forms
 };
 
+template <typename T>
+CM_HD void pin_block(Taps<T> &t) {
+#pragma unroll
+    for (int i = 0; i < 10; ++i) pin_vgpr(t.c[i]);
+    pin_vgpr(t.c0);
+}
+template <typename T, int N>
+CM_HD void pin_block(SosK<T, N> &k, bool with_b1) {
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+        pin_vgpr(k.na1[j]);
+        pin_vgpr(k.na2[j]);
+        if (with_b1) pin_vgpr(k.b1[j]);
+    }
+}
+
 // ---- transposed-form half-band FIR --------------------------------------------------------
 // s[j] carries the partial sum of the output that completes j+1 pushes from now.
 template <typename T>
@@ -93,16 +141,18 @@ struct HalfbandChain {
     }
     // 2x interpolation, odd phase: returns out[n] = sum_i c_i * x[n + 10 - i] once x[n + 10] = x
     // has been pushed (ref: resample_poly(x, 2, 1)[2n + 1]).
+    template <bool V>
     CM_HD T push(const Taps<T> &k, T x) {
-        T out = fma3(k.c[0], x, s[0]);
+        T out = fma3<V>(k.c[0], x, s[0]);
 #pragma unroll
-        for (int j = 0; j < 18; ++j) s[j] = fma3(k.c[(j + 1) < 10 ? (j + 1) : 18 - j], x, s[j + 1]);
+        for (int j = 0; j < 18; ++j) s[j] = fma3<V>(k.c[(j + 1) < 10 ? (j + 1) : 18 - j], x, s[j + 1]);
         s[18] = k.c[0] * x;
         return out;
     }
     // 2x decimation: push the pair (z[2m], z[2m+1]); returns 2 * resample_poly(z, 1, 2)[m - 9].
+    template <bool V>
     CM_HD T push_pair(const Taps<T> &k, T even, T odd) {
-        T out = push(k, odd);
+        T out = push<V>(k, odd);
         s[8] = fmaf_(k.c0, even, s[8]);  // centre tap lands on output m
         return out;
     }
@@ -119,24 +169,24 @@ struct IirState {
 };
 
 // numerator 1 - z^-2 (Butterworth / Chebyshev-I band-pass sections)
-template <typename T, int MAXSEC>
+template <bool V, typename T, int MAXSEC>
 CM_HD T iir_bp(IirState<T, MAXSEC> &st, const SosK<T, MAXSEC> &k, T x) {
 #pragma unroll
     for (int j = 0; j < MAXSEC; ++j) {
         T y = x + st.s1[j];
-        st.s1[j] = fma3(k.na1[j], y, st.s2[j]);
+        st.s1[j] = fma3<V>(k.na1[j], y, st.s2[j]);
         st.s2[j] = fmaf_(k.na2[j], y, -x);
         x = y;
     }
     return x;
 }
 // numerator 1 + b1 z^-1 + z^-2 (low-pass / band-stop sections with zeros on the unit circle)
-template <typename T, int MAXSEC>
+template <bool V, typename T, int MAXSEC>
 CM_HD T iir_sym(IirState<T, MAXSEC> &st, const SosK<T, MAXSEC> &k, T x) {
 #pragma unroll
     for (int j = 0; j < MAXSEC; ++j) {
         T y = x + st.s1[j];
-        T t = fma3(k.b1[j], x, st.s2[j]);
+        T t = fma3<V>(k.b1[j], x, st.s2[j]);
         st.s1[j] = fmaf_(k.na1[j], y, t);
         st.s2[j] = fmaf_(k.na2[j], y, x);
         x = y;
@@ -144,12 +194,12 @@ CM_HD T iir_sym(IirState<T, MAXSEC> &st, const SosK<T, MAXSEC> &k, T x) {
     return x;
 }
 // general numerator 1 + b1 z^-1 + b2 z^-2 (also first-order sections: b2 = a2 = 0)
-template <typename T, int MAXSEC>
+template <bool V, typename T, int MAXSEC>
 CM_HD T iir_gen(IirState<T, MAXSEC> &st, const SosK<T, MAXSEC> &k, T x) {
 #pragma unroll
     for (int j = 0; j < MAXSEC; ++j) {
         T y = x + st.s1[j];
-        T t = fma3(k.b1[j], x, st.s2[j]);
+        T t = fma3<V>(k.b1[j], x, st.s2[j]);
         st.s1[j] = fmaf_(k.na1[j], y, t);
         st.s2[j] = fmaf_(k.na2[j], y, k.b2[j] * x);
         x = y;
@@ -173,6 +223,20 @@ struct LaneK {
 template <typename T>
 struct Pair {
     T s, c;
+};
+
+// Values a FilterFunction stage latches when its input ends (utils.py:31-33 pads with them).  They are
+// parameters, not members of the stage state, so that the kernels can keep them out of the registers
+// that are live across the edge-free main loop.
+template <typename T>
+struct FrontLatch {
+    T a_last, ps_last, pc_last;
+    CM_HD void reset() { a_last = ps_last = pc_last = T(0); }
+};
+template <typename T>
+struct BackLatch {
+    T u_last, v_last;
+    CM_HD void reset() { u_last = v_last = T(0); }
 };
 
 // ---- uniform parameters of the QAM-family demodulators --------------------------------------
@@ -207,15 +271,14 @@ template <typename T, class S>
 struct PalDFront {
     static_assert(!S::ODD_E && !S::ODD_L, "the PAL-D front end is built for even filter shifts");
     typedef DemodK<T, S> K;
+    typedef VPolicy<CM_V_PALD> VP;
     HalfbandChain<T> up_x, dn_e, up_e, dn_s, dn_c;
     IirState<T, S::NE> bpf;
     IirState<T, S::NL> lpf_s, lpf_c;
-    T a_last, ps_last, pc_last;
 
     CM_HD void reset() {
         up_x.reset(); dn_e.reset(); up_e.reset(); dn_s.reset(); dn_c.reset();
         bpf.reset(); lpf_s.reset(); lpf_c.reset();
-        a_last = ps_last = pc_last = T(0);
     }
     CM_HD static int latency(const K &k) { return 10 + k.q_e + 9 + 10 + k.q_l + 9; }
 
@@ -223,29 +286,29 @@ struct PalDFront {
     // delay window), car = {C[2 n4], S[2 n4], C[2 n4 + 1], S[2 n4 + 1]} (cos/sin of m * cps).
     // Returns e[n3] through e_out (caller stores it in its window) and the base pair.
     template <bool EDGE>
-    CM_HD Pair<T> step(const K &k, const LaneK<T> &lk, int t, T x_now, T x_d10, T e_d10, const T car[4], T &e_out) {
+    CM_HD Pair<T> step(const K &k, FrontLatch<T> &la, int t, T x_now, T x_d10, T e_d10, const T car[4], T &e_out) {
         const int W = k.width;
         const int n1 = t - 10, n2 = n1 - k.q_e, n3 = n2 - 9, n4 = n3 - 10, n5 = n4 - k.q_l;
         // --- up2(x)
-        T a_odd = up_x.push(k.taps, x_now);
+        T a_odd = up_x.template push<VP::VT>(k.taps, x_now);
         T a_even = k.taps.c0 * x_d10;
         // --- band-pass at 2x rate with FilterFunction edge handling
         T b_even = T(0), b_odd = T(0);
         if (!EDGE || (n1 >= 0 && n1 < W + k.q_e)) {
             if (EDGE) {
-                if (n1 == W - 1) a_last = a_odd;
-                if (n1 >= W) a_even = a_odd = a_last;
+                if (n1 == W - 1) la.a_last = a_odd;
+                if (n1 >= W) a_even = a_odd = la.a_last;
             }
-            b_even = iir_bp(bpf, k.ext, a_even);
-            b_odd = iir_bp(bpf, k.ext, a_odd);
+            b_even = iir_bp<VP::VB>(bpf, k.ext, a_even);
+            b_odd = iir_bp<VP::VB>(bpf, k.ext, a_odd);
         }
         if (EDGE && (n2 < 0 || n2 >= W)) b_even = b_odd = T(0);
         // --- dn2 -> e[n3]
-        T e = dn_e.push_pair(k.taps, b_even, b_odd);
+        T e = dn_e.template push_pair<VP::VT>(k.taps, b_even, b_odd);
         if (EDGE && (n3 < 0 || n3 >= W)) e = T(0);
         e_out = e;
         // --- up2(e)
-        T u_odd = up_e.push(k.taps, e);
+        T u_odd = up_e.template push<VP::VT>(k.taps, e);
         T u_even = k.taps.c0 * e_d10;
         // --- product detectors against the phase-free carriers sin / cos(m cps), m = 2 n4, 2 n4 + 1; the
         //     line's detector phase is a rotation of the resulting pair and lives in LaneK::cu / cv
@@ -254,18 +317,18 @@ struct PalDFront {
         T qs_e = T(0), qs_o = T(0), qc_e = T(0), qc_o = T(0);
         if (!EDGE || (n4 >= 0 && n4 < W + k.q_l)) {
             if (EDGE) {
-                if (n4 == W - 1) { ps_last = ps_o; pc_last = pc_o; }
-                if (n4 >= W) { ps_e = ps_o = ps_last; pc_e = pc_o = pc_last; }
+                if (n4 == W - 1) { la.ps_last = ps_o; la.pc_last = pc_o; }
+                if (n4 >= W) { ps_e = ps_o = la.ps_last; pc_e = pc_o = la.pc_last; }
             }
-            qs_e = iir_sym(lpf_s, k.lpf, ps_e);
-            qs_o = iir_sym(lpf_s, k.lpf, ps_o);
-            qc_e = iir_sym(lpf_c, k.lpf, pc_e);
-            qc_o = iir_sym(lpf_c, k.lpf, pc_o);
+            qs_e = iir_sym<VP::VL>(lpf_s, k.lpf, ps_e);
+            qs_o = iir_sym<VP::VL>(lpf_s, k.lpf, ps_o);
+            qc_e = iir_sym<VP::VL>(lpf_c, k.lpf, pc_e);
+            qc_o = iir_sym<VP::VL>(lpf_c, k.lpf, pc_o);
         }
         if (EDGE && (n5 < 0 || n5 >= W)) qs_e = qs_o = qc_e = qc_o = T(0);
         Pair<T> out;
-        out.s = dn_s.push_pair(k.taps, qs_e, qs_o);
-        out.c = dn_c.push_pair(k.taps, qc_e, qc_o);
+        out.s = dn_s.template push_pair<VP::VT>(k.taps, qs_e, qs_o);
+        out.c = dn_c.template push_pair<VP::VT>(k.taps, qc_e, qc_o);
         return out;
     }
 };
@@ -280,38 +343,38 @@ struct PalDFront {
 template <typename T, class S, bool WITH_BSF>
 struct QamFront {
     typedef DemodK<T, S> K;
+    typedef VPolicy<CM_V_QAM> VP;
     static constexpr bool ODD_E = S::ODD_E, ODD_L = S::ODD_L, ODD_R = S::ODD_R;
     HalfbandChain<T> up_x, dn_s, dn_c, dn_y;
     IirState<T, S::NE> bpf;
     IirState<T, S::NL> lpf_s, lpf_c;
     IirState<T, S::NR> bsf;
-    T a_last, ps_last, pc_last;
     T hold_b, hold_s, hold_c, hold_y;  // previous odd outputs for odd shifts
 
     CM_HD void reset() {
         up_x.reset(); dn_s.reset(); dn_c.reset(); dn_y.reset();
         bpf.reset(); lpf_s.reset(); lpf_c.reset(); bsf.reset();
-        a_last = ps_last = pc_last = hold_b = hold_s = hold_c = hold_y = T(0);
+        hold_b = hold_s = hold_c = hold_y = T(0);
     }
     CM_HD static int latency(const K &k) { return 10 + k.q_e + k.q_l + 9; }
     CM_HD static int luma_latency(const K &k) { return 10 + k.q_r + 9; }
 
     // car = {C[2 n2], S[2 n2], C[2 n2 + 1], S[2 n2 + 1]}
     template <bool EDGE>
-    CM_HD Pair<T> step(const K &k, const LaneK<T> &lk, int t, T x_now, T x_d10, const T car[4], T &luma_out) {
+    CM_HD Pair<T> step(const K &k, FrontLatch<T> &la, int t, T x_now, T x_d10, const T car[4], T &luma_out) {
         const int W = k.width;
         const int n1 = t - 10, n2 = n1 - k.q_e, n5 = n2 - k.q_l;
-        T a_odd = up_x.push(k.taps, x_now);
+        T a_odd = up_x.template push<VP::VT>(k.taps, x_now);
         T a_even = k.taps.c0 * x_d10;
         if (EDGE) {
-            if (n1 == W - 1) a_last = a_odd;
-            if (n1 >= W) a_even = a_odd = a_last;
+            if (n1 == W - 1) la.a_last = a_odd;
+            if (n1 >= W) a_even = a_odd = la.a_last;
         }
         // --- chroma band-pass
         T b_even = T(0), b_odd = T(0);
         if (!EDGE || (n1 >= 0 && n1 < W + k.q_e)) {
-            T y0 = iir_bp(bpf, k.ext, a_even);
-            T y1 = iir_bp(bpf, k.ext, a_odd);
+            T y0 = iir_bp<VP::VB>(bpf, k.ext, a_even);
+            T y1 = iir_bp<VP::VB>(bpf, k.ext, a_odd);
             if (ODD_E) { b_even = hold_b; b_odd = y0; hold_b = y1; } else { b_even = y0; b_odd = y1; }
         }
         // (band-pass output outside [0, 2W) is never used: the detector below is gated on n2)
@@ -320,12 +383,12 @@ struct QamFront {
             const int nr = n1 - k.q_r;
             T r_even = T(0), r_odd = T(0);
             if (!EDGE || (n1 >= 0 && n1 < W + k.q_r)) {
-                T y0 = iir_sym(bsf, k.rem, a_even);
-                T y1 = iir_sym(bsf, k.rem, a_odd);
+                T y0 = iir_sym<false>(bsf, k.rem, a_even);
+                T y1 = iir_sym<false>(bsf, k.rem, a_odd);
                 if (ODD_R) { r_even = hold_y; r_odd = y0; hold_y = y1; } else { r_even = y0; r_odd = y1; }
             }
             if (EDGE && (nr < 0 || nr >= W)) r_even = r_odd = T(0);
-            luma_out = dn_y.push_pair(k.taps, r_even, r_odd) * k.luma_gain;
+            luma_out = dn_y.template push_pair<VP::VT>(k.taps, r_even, r_odd) * k.luma_gain;
         }
         // --- product detectors at 2x rate against the phase-free carriers, m = 2 n2, 2 n2 + 1
         T ps_e = b_even * car[1], pc_e = b_even * car[0];
@@ -333,13 +396,13 @@ struct QamFront {
         T qs_e = T(0), qs_o = T(0), qc_e = T(0), qc_o = T(0);
         if (!EDGE || (n2 >= 0 && n2 < W + k.q_l)) {
             if (EDGE) {
-                if (n2 == W - 1) { ps_last = ps_o; pc_last = pc_o; }
-                if (n2 >= W) { ps_e = ps_o = ps_last; pc_e = pc_o = pc_last; }
+                if (n2 == W - 1) { la.ps_last = ps_o; la.pc_last = pc_o; }
+                if (n2 >= W) { ps_e = ps_o = la.ps_last; pc_e = pc_o = la.pc_last; }
             }
-            T s0 = iir_sym(lpf_s, k.lpf, ps_e);
-            T s1 = iir_sym(lpf_s, k.lpf, ps_o);
-            T c0 = iir_sym(lpf_c, k.lpf, pc_e);
-            T c1 = iir_sym(lpf_c, k.lpf, pc_o);
+            T s0 = iir_sym<VP::VL>(lpf_s, k.lpf, ps_e);
+            T s1 = iir_sym<VP::VL>(lpf_s, k.lpf, ps_o);
+            T c0 = iir_sym<VP::VL>(lpf_c, k.lpf, pc_e);
+            T c1 = iir_sym<VP::VL>(lpf_c, k.lpf, pc_o);
             if (ODD_L) {
                 qs_e = hold_s; qs_o = s0; hold_s = s1;
                 qc_e = hold_c; qc_o = c0; hold_c = c1;
@@ -349,8 +412,8 @@ struct QamFront {
         }
         if (EDGE && (n5 < 0 || n5 >= W)) qs_e = qs_o = qc_e = qc_o = T(0);
         Pair<T> out;
-        out.s = dn_s.push_pair(k.taps, qs_e, qs_o);
-        out.c = dn_c.push_pair(k.taps, qc_e, qc_o);
+        out.s = dn_s.template push_pair<VP::VT>(k.taps, qs_e, qs_o);
+        out.c = dn_c.template push_pair<VP::VT>(k.taps, qc_e, qc_o);
         return out;
     }
 };
@@ -370,10 +433,8 @@ template <typename T, class S, int DEPTH>
 struct DemodBack {
     typedef DemodK<T, S> K;
     IirState<T, S::NP> pre_u, pre_v;
-    T u_last, v_last;
     CM_HD void reset() {
         pre_u.reset(); pre_v.reset();
-        u_last = v_last = T(0);
     }
     // Combination only (the caller keeps the u/v delay windows).
     CM_HD void combine(const LaneK<T> &lk, const Pair<T> &b0, const Pair<T> &b1, const Pair<T> &b2, T &u, T &v) const {
@@ -391,16 +452,16 @@ struct DemodBack {
     // u, v are the combined chroma at n6; u_d, v_d the same signals at n7 = n6 - s_p;
     // y_src is the luma source at n7; car = {C[2 n7], S[2 n7]}.
     template <bool EDGE>
-    CM_HD Rgb<T> step(const K &k, const LaneK<T> &lk, int n6, T u, T v, T u_d, T v_d, T y_src, const T car[2]) {
+    CM_HD Rgb<T> step(const K &k, const LaneK<T> &lk, BackLatch<T> &la, int n6, T u, T v, T u_d, T v_d, T y_src, const T car[2]) {
         const int W = k.width;
         T wu = T(0), wv = T(0);
         if (!EDGE || (n6 >= 0 && n6 < W + k.s_p)) {
             if (EDGE) {
-                if (n6 == W - 1) { u_last = u; v_last = v; }
-                if (n6 >= W) { u = u_last; v = v_last; }
+                if (n6 == W - 1) { la.u_last = u; la.v_last = v; }
+                if (n6 >= W) { u = la.u_last; v = la.v_last; }
             }
-            wu = iir_gen(pre_u, k.pre, u);
-            wv = iir_gen(pre_v, k.pre, v);
+            wu = iir_gen<false>(pre_u, k.pre, u);
+            wv = iir_gen<false>(pre_v, k.pre, v);
         }
         T sn = fmaf_(lk.sph, car[0], lk.cph * car[1]);
         T cs = fmaf_(lk.vcph, car[0], -(lk.vsph * car[1]));  // +-cos(phi + 2 n7 cps)
@@ -449,8 +510,8 @@ struct QamModCore {
         if (n >= 0 && n < W + k.s_p) {
             if (n == W - 1) { u_last = u; v_last = v; }
             if (n >= W) { u = u_last; v = v_last; }
-            wu = iir_gen(pre_u, k.pre, u);
-            wv = iir_gen(pre_v, k.pre, v);
+            wu = iir_gen<false>(pre_u, k.pre, u);
+            wv = iir_gen<false>(pre_v, k.pre, v);
         }
         T sn = fmaf_(lk.sph, car[0], lk.cph * car[1]);
         T cs = fmaf_(lk.vcph, car[0], -(lk.vsph * car[1]));
@@ -504,6 +565,7 @@ CM_HD double atan2_(double y, double x) { return std::atan2(y, x); }
 
 template <typename T>
 struct SecamDemod {
+    typedef VPolicy<CM_V_SECAM> VP;
     IirState<T, 3> bpf, ybs;
     IirState<T, 1> bell;
     IirState<T, 3> lp_i, lp_q;
@@ -541,12 +603,12 @@ struct SecamDemod {
         if (m >= 0 && m < Lc + k.s_b) {
             if (m == Lc - 1) cc_last = cc_now;
             if (m >= Lc) cc_now = cc_last;
-            T b = iir_bp(bpf, k.bpf, cc_now);
-            if (m1 >= 0) ch = iir_bp(bell, k.bell, b);   // the bell sees the band-pass output from its sample 0 on
+            T b = iir_bp<VP::VB>(bpf, k.bpf, cc_now);
+            if (m1 >= 0) ch = iir_bp<false>(bell, k.bell, b);   // the bell sees the band-pass output from its sample 0 on
         }
         if (m1 < 0 || m1 >= Lc) ch = T(0);
         ch_out = ch;
-        T a_odd = up.push(k.taps, ch);
+        T a_odd = up.template push<VP::VT>(k.taps, ch);
         T a_even = k.taps.c0 * ch_d10;
         T pi_e = a_even * car[0], pq_e = -(a_even * car[1]);   // data_up = cos part - j sin part (secam.py:143)
         T pi_o = a_odd * car[2], pq_o = -(a_odd * car[3]);
@@ -554,8 +616,8 @@ struct SecamDemod {
         if (m2 >= 0 && m2 < Lc + k.q_l) {
             if (m2 == Lc - 1) { pi_last = pi_o; pq_last = pq_o; }
             if (m2 >= Lc) { pi_e = pi_o = pi_last; pq_e = pq_o = pq_last; }
-            T i0 = iir_sym(lp_i, k.lpf, pi_e), q0 = iir_sym(lp_q, k.lpf, pq_e);
-            T i1 = iir_sym(lp_i, k.lpf, pi_o), q1 = iir_sym(lp_q, k.lpf, pq_o);
+            T i0 = iir_sym<VP::VL>(lp_i, k.lpf, pi_e), q0 = iir_sym<VP::VL>(lp_q, k.lpf, pq_e);
+            T i1 = iir_sym<VP::VL>(lp_i, k.lpf, pi_o), q1 = iir_sym<VP::VL>(lp_q, k.lpf, pq_o);
             if (m3 >= 0 && m3 < Lc) {
                 T d_e = have_prev ? phase_step(i_prev, q_prev, i0, q0) : T(0);  // secam.py:147: first step is 0
                 T d_o = phase_step(i0, q0, i1, q1);
@@ -566,11 +628,11 @@ struct SecamDemod {
                 f_o = fmaf_(d_o, k.two_over_pi, k.fc);
             }
         }
-        T f2 = dn.push_pair(k.taps, f_e, f_o);   // 2 * resample_poly(frequencies_up, 1, 2)[m4]
+        T f2 = dn.template push_pair<VP::VT>(k.taps, f_e, f_o);   // 2 * resample_poly(frequencies_up, 1, 2)[m4]
         T c = T(0);
         if (n >= 0 && n < W) {
             f2 = f2 < k.f2_min ? k.f2_min : (f2 > k.f2_max ? k.f2_max : f2);   // secam.py:290
-            c = iir_gen(deemph, k.deemph, fmaf_(f2, lk.scale, lk.offset));   // secam.py:291-296
+            c = iir_gen<false>(deemph, k.deemph, fmaf_(f2, lk.scale, lk.offset));   // secam.py:291-296
         }
         return c;
     }
@@ -581,7 +643,7 @@ struct SecamDemod {
         if (j >= 0 && j < W + k.s_y) {
             if (j == W - 1) x_last = x_in;
             if (j >= W) x_in = x_last;
-            y = iir_sym(ybs, k.ybs, x_in);
+            y = iir_sym<false>(ybs, k.ybs, x_in);
         }
         return y * k.luma_gain;
     }
@@ -649,10 +711,10 @@ struct SecamMod {
         if (n >= 0 && n < W + k.s_p) {
             if (n == W - 1) d_last = dd;
             if (n >= W) dd = d_last;
-            w = iir_gen(pre_lp, k.pre_lp, dd);
+            w = iir_gen<false>(pre_lp, k.pre_lp, dd);
         }
         if (n7 < 0 || n7 >= W) return T(0);
-        TD x = iir_gen(lf_pre, k.lf_pre, w);
+        TD x = iir_gen<false>(lf_pre, k.lf_pre, w);
         TD f = fmaf_(lk.fdev * k.gain, x, lk.fsc);                    // secam.py:266 / 271
         f = f < k.f_min ? k.f_min : (f > k.f_max ? k.f_max : f);      // secam.py:272
         // bell pre-emphasis G = m0 (1 + j kn F) / (1 + j kd F), F = f / f0 - f0 / f (secam.py:241-243)

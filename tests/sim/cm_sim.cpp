@@ -59,6 +59,9 @@ static int run_generic(const cm_plan_desc &d, bool pald, bool bsf, const cm_lane
     std::vector<PalDFront<T, SD>> fp(pald ? n : 0);
     std::vector<QamFront<T, S, true>> fq(n);
     std::vector<DemodBack<T, S, 2>> back(n);
+    std::vector<FrontLatch<T>> fla(n);
+    std::vector<BackLatch<T>> bla(n);
+    for (int i = 0; i < n; ++i) { fla[i].reset(); bla[i].reset(); }
     for (int i = 0; i < n; ++i) { if (pald) fp[i].reset(); fq[i].reset(); back[i].reset(); }
     const int lat_front = pald ? (10 + k.q_e + 9 + 10 + k.q_l + 9) : QamFront<T, S, true>::latency(k);
     const int lat_luma = QamFront<T, S, true>::luma_latency(k);
@@ -83,8 +86,8 @@ static int run_generic(const cm_plan_desc &d, bool pald, bool bsf, const cm_lane
                 T e_d10 = (n3 - 10 >= 0) ? e_hist[i][n3 - 10] : T(0);
                 T e_out;
                 const DemodK<T, SD> &kd = reinterpret_cast<const DemodK<T, SD> &>(k);  // same type whenever pald
-                base[i] = edge ? fp[i].template step<true>(kd, lk[i], t, x_now, x_d10, e_d10, cr, e_out)
-                               : fp[i].template step<false>(kd, lk[i], t, x_now, x_d10, e_d10, cr, e_out);
+                base[i] = edge ? fp[i].template step<true>(kd, fla[i], t, x_now, x_d10, e_d10, cr, e_out)
+                               : fp[i].template step<false>(kd, fla[i], t, x_now, x_d10, e_d10, cr, e_out);
                 if (n3 >= 0) e_hist[i][n3] = e_out;
             } else {
                 const int n2 = n1 - k.q_e;
@@ -92,8 +95,8 @@ static int run_generic(const cm_plan_desc &d, bool pald, bool bsf, const cm_lane
                 carrier(2 * n2, cr);
                 carrier(2 * n2 + 1, cr + 2);
                 T luma = T(0);
-                base[i] = edge ? fq[i].template step<true>(k, lk[i], t, x_now, x_d10, cr, luma)
-                               : fq[i].template step<false>(k, lk[i], t, x_now, x_d10, cr, luma);
+                base[i] = edge ? fq[i].template step<true>(k, fla[i], t, x_now, x_d10, cr, luma)
+                               : fq[i].template step<false>(k, fla[i], t, x_now, x_d10, cr, luma);
                 const int nl = t - lat_luma;
                 if (nl >= 0) y_hist[i][nl] = luma;
             }
@@ -108,8 +111,8 @@ static int run_generic(const cm_plan_desc &d, bool pald, bool bsf, const cm_lane
             T y_src = bsf ? (n7 >= 0 ? y_hist[i][n7] : T(0)) : xin(i - dy[i], n7);
             T cr[2];
             carrier(2 * n7, cr);
-            Rgb<T> o = edge ? back[i].template step<true>(k, lk[i], n6, u, v, u_d, v_d, y_src, cr)
-                            : back[i].template step<false>(k, lk[i], n6, u, v, u_d, v_d, y_src, cr);
+            Rgb<T> o = edge ? back[i].template step<true>(k, lk[i], bla[i], n6, u, v, u_d, v_d, y_src, cr)
+                            : back[i].template step<false>(k, lk[i], bla[i], n6, u, v, u_d, v_d, y_src, cr);
             bool wanted = false;
             for (int c : calls) wanted |= (c == i);
             if (wanted && n7 >= 0 && n7 < W) {
