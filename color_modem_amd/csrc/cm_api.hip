@@ -308,8 +308,14 @@ void finish_geom(const cm_plan *p, const Pass &pass, Geom &g) {
 }
 
 // gm: main-pass geometry (total_calls set); gf: first-line geometry (total_calls = number of runs) when the plan has one
+#ifdef CM_DIAG
+static unsigned long long *g_diag;
+#endif
 int run_plan(const cm_plan *p, Geom gm, Geom gf, bool with_first, hipStream_t stream) {
     finish_geom(p, p->main, gm);
+#ifdef CM_DIAG
+    gm.diag = g_diag;
+#endif
     long long n_main = (gm.total_calls + (64 - p->main.depth) - 1) / (64 - p->main.depth);
     long long n_first = 0;
     if (with_first) {
@@ -581,6 +587,10 @@ int cm_modulate_run(const cm_plan *p, const float *rgb, float *composite, int32_
     if (first_line + 2 * (n_calls - 1) >= p->mod_n_lines) return fail(CM_ERR_INVALID, "line number beyond the plan's phase tables");
     return run_mod(p, g, (hipStream_t)stream);
 }
+
+#ifdef CM_DIAG
+extern "C" void cm_diag_set_buffer(unsigned long long *dev) { g_diag = dev; }
+#endif
 
 int cm_plan_describe(const cm_plan *p, char *buf, int32_t buf_len) {
     if (!p || !buf || buf_len < 1) return 0;

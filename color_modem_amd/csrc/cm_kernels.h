@@ -46,7 +46,21 @@ struct Geom {
     int luma_prev_bits;  // bit r: regime r takes its luma from the previous call's input row
     int sparse;          // 1: one lane per run, call 0 of each run only (plain first-line pass)
     int skip_first;      // 1: calls with k == 0 are written by the sparse pass, not by this one
+    unsigned long long *diag;  // diagnostic builds only (-DCM_DIAG): per-workgroup cycle sums; null otherwise
 };
+
+#ifdef CM_DIAG
+__device__ __forceinline__ unsigned long long cm_stamp() {
+    unsigned long long t;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    return t;
+}
+#define CM_STAMP(var) unsigned long long var = cm_stamp()
+#define CM_ACC(acc, t0) acc += cm_stamp() - (t0)
+#else
+#define CM_STAMP(var)
+#define CM_ACC(acc, t0)
+#endif
 
 typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
 typedef float f4 __attribute__((ext_vector_type(4)));
@@ -177,6 +191,14 @@ __device__ __forceinline__ void flush_tile(const Geom &g, const lds_float *otile
         const int quad = chunk ^ ((row >> 1) & (kChunks - 1));
         if (dst != nullptr && col < g.W) {
             dst += col >> 2;
+#ifndef CM_FLUSH_SERIAL   /* the three planes of a row group in one LDS round trip (-1 % kernel time) */
+            f4 v0 = *(const lds_f4 *)(otile + 0 * 64 * kTile + row * kTile + 4 * quad);
+            f4 v1 = *(const lds_f4 *)(otile + 1 * 64 * kTile + row * kTile + 4 * quad);
+            f4 v2 = *(const lds_f4 *)(otile + 2 * 64 * kTile + row * kTile + 4 * quad);
+            __builtin_nontemporal_store(v0, &dst[0]);
+            __builtin_nontemporal_store(v1, &dst[g.out_plane_stride >> 2]);
+            __builtin_nontemporal_store(v2, &dst[(2 * g.out_plane_stride) >> 2]);
+#else
 #pragma nounroll
             for (int p = 0; p < 3; ++p) {
                 f4 v = *(const lds_f4 *)(otile + p * 64 * kTile + row * kTile + 4 * quad);
@@ -185,6 +207,7 @@ __device__ __forceinline__ void flush_tile(const Geom &g, const lds_float *otile
 #endif
                 __builtin_nontemporal_store(v, &dst[(p * g.out_plane_stride) >> 2]);
             }
+#endif
         }
     }
     __builtin_amdgcn_wave_barrier();
@@ -373,17 +396,35 @@ __device__ __forceinline__ void run_lane(const Geom &g, const DemodK<float, type
     // An output tile (or the row) ends at samples n7 = 3 (mod 4) only (W and kTile are multiples of 4),
     // i.e. always after the same sub-step of the 4x unrolled body.
     const int s_flush = (lat_out + 3) & 3;
+#ifdef CM_DIAG
+    unsigned long long d_flush = 0, d_fill = 0, d_xread = 0, d_luma = 0, d_sub = 0;
+    const unsigned long long d_begin = cm_stamp();
+#endif
     auto maybe_flush = [&](int t) {
         const int n7 = t - lat_out;
-        if (n7 >= 0 && ((n7 & (kTile - 1)) == kTile - 1 || n7 == W - 1))
+        if (n7 >= 0 && ((n7 & (kTile - 1)) == kTile - 1 || n7 == W - 1)) {
+            CM_STAMP(t0);
             flush_tile<kTile>(g, otile_base, op, n7 & ~(kTile - 1), lane);
+#ifdef CM_DIAG
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#endif
+            CM_ACC(d_flush, t0);
+        }
     };
 
     auto body = [&](int tb, auto edge_tag, FrontLatch<float> &fla, BackLatch<float> &bla) {
         constexpr bool EDGE = decltype(edge_tag)::value;
+#ifdef CM_DIAG
+        {
+            CM_STAMP(t0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // how long the luma prefetch still needs
+            CM_ACC(d_luma, t0);
+        }
+#endif
         L.lw = nl;
         const int nxt = tb + 4;
         nl = read_luma(nxt - lat_out, EDGE || nxt >= t_mid1);  // next body's luma: a whole body hides the latency
+        CM_STAMP(t_sub);
         float carA[4], carbA[2], carB[4], carbB[2];
         const_f4 *c4 = (const_f4 *)g.carrier4 + (tb - front_off);
         const_f2 *c2 = (const_f2 *)g.carrier2 + (tb - lat_out);
@@ -399,23 +440,33 @@ __device__ __forceinline__ void run_lane(const Geom &g, const DemodK<float, type
         if (s_flush == 2) maybe_flush(tb + 2);
         L.template substep<3, EDGE>(g, k, fla, bla, tb + 3, lat_front, lat_luma, carB, carbB, otile, yring, lane, wpos);
         if (s_flush == 3) maybe_flush(tb + 3);
+        CM_ACC(d_sub, t_sub);
 #pragma unroll
         for (int j = 0; j < 10; ++j) L.xw[j] = L.xw[j + 4];
         // ---- next body's input from the LDS tile ------------------------------------------------
         if ((nxt & (kInTile - 1)) == 0 && nxt < W) {  // first read of a new tile: its fill was issued a body ago
+            CM_STAMP(t0);
 #ifndef CM_EXP_NO_FILL_WAIT
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
             __builtin_amdgcn_wave_barrier();
+            CM_ACC(d_fill, t0);
         }
         {
+            CM_STAMP(t0);
             f4 xn = read_x(nxt);
             L.xw[10] = xn.x; L.xw[11] = xn.y; L.xw[12] = xn.z; L.xw[13] = xn.w;
+#ifdef CM_DIAG
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+            CM_ACC(d_xread, t0);
         }
         if ((nxt & (kInTile - 1)) == kInTile - 4 && nxt + 4 < W) {  // that was the last read of this tile: refill it
+            CM_STAMP(t0);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_wave_barrier();
             fill_tile(g, itile, xp, (nxt >> 5) + 1, lane);
+            CM_ACC(d_fill, t0);
         }
         if (FRONT == FRONT_PALD) {
 #pragma unroll
@@ -439,6 +490,12 @@ __device__ __forceinline__ void run_lane(const Geom &g, const DemodK<float, type
     fla.reset();
     bla.reset();
     for (; tb < T; tb += 4) body(tb, std::true_type(), fla, bla);
+#ifdef CM_DIAG
+    if (g.diag && lane == 0 && !g.sparse) {
+        unsigned long long *d = g.diag + 8ull * block;
+        d[0] = cm_stamp() - d_begin; d[1] = d_flush; d[2] = d_fill; d[3] = d_xread; d[4] = d_luma; d[5] = d_sub;
+    }
+#endif
 }
 
 template <class S>
