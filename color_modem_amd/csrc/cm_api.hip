@@ -127,6 +127,7 @@ bool select_kernels(cm_plan *p, const cm_plan_desc &d, std::string &err) {
     };
     typedef PassCfg<SysPal, FRONT_QAM, true, 0, 8> PalFirst;
     typedef PassCfg<SysNtsc, FRONT_QAM, true, 0, 8> NtscFirst;
+    typedef PassCfg<SysNtscI, FRONT_QAM, true, 0, 8> NtscIFirst;
     if (match(signature_of<SysPal>())) {
         if (pald) {
             if (depth != 1 || !first) { err = "PAL-D front end is built with one line of history and a plain first line"; return false; }
@@ -158,10 +159,25 @@ bool select_kernels(cm_plan *p, const cm_plan_desc &d, std::string &err) {
         }
         return make_passes<SysNtsc>(p, d, pald, bsf, first, err);
     }
+    if (!pald && match(signature_of<SysNtscI>())) {
+        if (bsf) {
+            if (depth != 0 || first) { err = "band-stop luma is built for plain decoders only"; return false; }
+            p->fn = launch_demod<PassCfg<SysNtscI, FRONT_QAM, true, 0, 16>, NoPass>;
+            p->main.depth = 0; p->main.name = "demod_kernel<ntsc-i: qam front + band-stop, depth 0>";
+        } else if (first) {
+            if (depth != 1) { err = "NTSC comb with a plain first line is built with one line of history"; return false; }
+            p->fn = launch_demod<PassCfg<SysNtscI, FRONT_QAM, false, 1, 16>, NtscIFirst>;
+            p->main.depth = 1; p->main.name = "demod_kernel<ntsc-i: qam front, depth 1 | plain first line>";
+        } else {
+            p->fn = launch_demod<PassCfg<SysNtscI, FRONT_QAM, false, 2, 16>, NoPass>;
+            p->main.depth = 2; p->main.name = "demod_kernel<ntsc-i: qam front, depth 2>";
+        }
+        return make_passes<SysNtscI>(p, d, pald, bsf, first, err);
+    }
     char buf[256];
     snprintf(buf, sizeof buf,
              "no kernel instance for this filter set (sections extract/remove/detect/pre = %d/%d/%d/%d, shift parities %d/%d/%d, "
-             "pre shift %d); built: PAL-BG and NTSC-M at 13.5 MHz",
+             "pre shift %d); built: the filter shapes of PAL-BG, NTSC-M (= PAL-M/N, NTSC-N/3.61) and NTSC-I/4.43 at 13.5 MHz",
              want.ne, want.nr, want.nl, want.np, want.odd_e, want.odd_l, want.odd_r, want.sp);
     err = buf;
     return false;

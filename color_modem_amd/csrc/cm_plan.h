@@ -226,7 +226,8 @@ std::vector<T> build_fm_reference(double fc, int lc) {
 // ---- the filter-set shapes this build carries ------------------------------------------------
 //                 NE NR NL NP  oddE   oddL   oddR  SP
 typedef Sys<2, 2, 3, 1, false, false, false, 2> SysPal;   // PAL-BG @ 13.5 MHz: shifts 4 / 4 (6 for PAL-D) / 2 / 2
-typedef Sys<3, 3, 3, 1, false, true, false, 2> SysNtsc;   // NTSC-M @ 13.5 MHz: shifts 6 / 5 / 4 / 2
+typedef Sys<3, 3, 3, 1, false, true, false, 2> SysNtsc;   // NTSC-M @ 13.5 MHz: shifts 6 / 5 / 4 / 2 (also NTSC-N, NTSC 3.61, PAL-M, PAL-N)
+typedef Sys<3, 2, 3, 1, false, true, false, 2> SysNtscI;  // NTSC-I, NTSC 4.43 on 625 lines: narrower band-stop
 
 struct SysSignature {
     int ne, nr, nl, np, odd_e, odd_l, odd_r, sp;

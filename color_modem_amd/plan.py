@@ -186,6 +186,10 @@ class QamTables(object):
         self.cycle = b.frame_cycle
         if b.v_switch and self.cycle % 2:
             self.cycle *= 2  # the V switch alternates with frame parity (line.py:64-65)
+        if self.cycle > 64:
+            raise NotImplementedError(
+                'the sub-carrier phase of this variant / line standard pair repeats only every %d frames; the per-line '
+                'tables of this build are laid out per frame of the cycle (limit 64)' % self.cycle)
         self.width, self.height = self.lc.size
 
     # -- helpers ---------------------------------------------------------------------------

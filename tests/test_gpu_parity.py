@@ -193,3 +193,51 @@ def test_empty_batch_and_bad_shapes():
         eng.demodulate_frames(numpy.zeros((1, 575, 720), dtype=numpy.float32))
     with pytest.raises(ValueError):
         stacks.make('pal_d', (720, 576)).demodulate(0, 0, numpy.zeros(719))
+
+
+# ---- other colour-system variants that share a built filter-set shape -----------------------------------
+def _variant_modem(kind, variant, size):
+    from color_modem_amd import comb, line
+    from color_modem_amd.color import ntsc, pal, secam
+    lc = line.LineConfig(size)
+    if kind == 'pal_s':
+        return pal.PalSModem(lc, getattr(pal.PalVariant, variant))
+    if kind == 'ntsc_comb':
+        return ntsc.NtscCombModem(lc, getattr(ntsc.NtscVariant, variant))
+    if kind == 'ntsc_comb_3d':
+        return comb.Simple3DCombModem(ntsc.NtscCombModem(lc, getattr(ntsc.NtscVariant, variant)))
+    if kind == 'secam':
+        return secam.SecamModem(lc, getattr(secam.SecamVariant, variant))
+    raise KeyError(kind)
+
+
+@pytest.mark.parametrize('kind,variant,size', [
+    ('pal_s', 'PAL_N', (720, 576)), ('pal_s', 'PAL_M', (720, 480)), ('ntsc_comb', 'NTSC_I', (720, 480)),
+    ('ntsc_comb_3d', 'NTSC443', (720, 576)), ('ntsc_comb', 'NTSC_N', (720, 576)), ('ntsc_comb', 'NTSC361', (720, 480)),
+    ('secam', 'SECAM_III', (720, 576)), ('secam', 'SECAM_M', (720, 480)), ('secam', 'SECAM_N', (720, 576)),
+])
+def test_variants_round_trip_vs_oracle(kind, variant, size):
+    from oracle import cm_oracle
+    modem = _variant_modem(kind, variant, size)
+    im = image.ImageModem(modem)
+    rgb = testing.synthetic_rgb(2, size[1], size[0], seed=123)
+    comp_ref = cm_oracle.modulate_frames_f32(modem, rgb, first_frame=1, n_threads=8)
+    comp = im.modulate_frames(rgb, first_frame=1)
+    assert stacks.rel_err(comp, comp_ref) < TOL
+    got = im.demodulate_frames(comp_ref, first_frame=1)
+    want = cm_oracle.demodulate_frames_f32(modem, comp_ref, first_frame=1, n_threads=8)
+    for i in range(2):
+        assert stacks.rel_err(got[i], want[i]) < TOL, i
+
+
+def test_unsupported_variants_fail_loudly():
+    from color_modem_amd import line
+    from color_modem_amd.color import ntsc, pal, secam
+    with pytest.raises(NotImplementedError):
+        image.ImageModem(pal.PalSModem(line.LineConfig((720, 480)))).demodulate_frames(numpy.zeros((1, 480, 720), 'f4'))
+    with pytest.raises(NotImplementedError):
+        image.ImageModem(ntsc.NtscModem(line.LineConfig((720, 480)), ntsc.NtscVariant.NTSC_A)).demodulate_frames(
+            numpy.zeros((1, 480, 720), 'f4'))
+    with pytest.raises(NotImplementedError):
+        image.ImageModem(secam.SecamModem(line.LineConfig((720, 576)), secam.SecamVariant.SECAM_I)).demodulate_frames(
+            numpy.zeros((1, 576, 720), 'f4'))
