@@ -64,7 +64,7 @@ struct cm_plan {
     cm_plan_desc desc;
     int device = 0;
     float *carrier4 = nullptr, *carrier2 = nullptr;
-    LaunchFn fn = nullptr;
+    LaunchFn fn = nullptr, fn_u8 = nullptr;
     bool has_first = false;
     Pass main, first;
     // modulator
@@ -126,20 +126,26 @@ bool select_kernels(cm_plan *p, const cm_plan_desc &d, std::string &err) {
         return same_signature(want, have);
     };
     typedef PassCfg<SysPal, FRONT_QAM, true, 0, 8> PalFirst;
+    typedef PassCfg<SysPal, FRONT_QAM, true, 0, 16, true> PalFirstU8;      // byte tiles are small: no need for 8-sample tiles
+    typedef PassCfg<SysNtsc, FRONT_QAM, true, 0, 16, true> NtscFirstU8;
+    typedef PassCfg<SysNtscI, FRONT_QAM, true, 0, 16, true> NtscIFirstU8;
     typedef PassCfg<SysNtsc, FRONT_QAM, true, 0, 8> NtscFirst;
     typedef PassCfg<SysNtscI, FRONT_QAM, true, 0, 8> NtscIFirst;
     if (match(signature_of<SysPal>())) {
         if (pald) {
             if (depth != 1 || !first) { err = "PAL-D front end is built with one line of history and a plain first line"; return false; }
             p->fn = launch_demod<PassCfg<SysPal, FRONT_PALD, false, 1, 16>, PalFirst>;
+            p->fn_u8 = launch_demod<PassCfg<SysPal, FRONT_PALD, false, 1, 16, true>, PalFirstU8>;
             p->main.depth = 1; p->main.name = "demod_kernel<pal: pal-d front, depth 1 | plain first line>";
         } else if (bsf) {
             if (depth != 0 || first) { err = "band-stop luma is built for plain decoders only"; return false; }
             p->fn = launch_demod<PassCfg<SysPal, FRONT_QAM, true, 0, 16>, NoPass>;
+            p->fn_u8 = launch_demod<PassCfg<SysPal, FRONT_QAM, true, 0, 16, true>, NoPass>;
             p->main.depth = 0; p->main.name = "demod_kernel<pal: qam front + band-stop, depth 0>";
         } else {
             if (first) { err = "no PAL kernel instance with a plain first line behind the QAM front end"; return false; }
             p->fn = launch_demod<PassCfg<SysPal, FRONT_QAM, false, 2, 16>, NoPass>;
+            p->fn_u8 = launch_demod<PassCfg<SysPal, FRONT_QAM, false, 2, 16, true>, NoPass>;
             p->main.depth = 2; p->main.name = "demod_kernel<pal: qam front, depth 2>";
         }
         return make_passes<SysPal>(p, d, pald, bsf, first, err);
@@ -148,13 +154,16 @@ bool select_kernels(cm_plan *p, const cm_plan_desc &d, std::string &err) {
         if (bsf) {
             if (depth != 0 || first) { err = "band-stop luma is built for plain decoders only"; return false; }
             p->fn = launch_demod<PassCfg<SysNtsc, FRONT_QAM, true, 0, 16>, NoPass>;
+            p->fn_u8 = launch_demod<PassCfg<SysNtsc, FRONT_QAM, true, 0, 16, true>, NoPass>;
             p->main.depth = 0; p->main.name = "demod_kernel<ntsc: qam front + band-stop, depth 0>";
         } else if (first) {
             if (depth != 1) { err = "NTSC comb with a plain first line is built with one line of history"; return false; }
             p->fn = launch_demod<PassCfg<SysNtsc, FRONT_QAM, false, 1, 16>, NtscFirst>;
+            p->fn_u8 = launch_demod<PassCfg<SysNtsc, FRONT_QAM, false, 1, 16, true>, NtscFirstU8>;
             p->main.depth = 1; p->main.name = "demod_kernel<ntsc: qam front, depth 1 | plain first line>";
         } else {
             p->fn = launch_demod<PassCfg<SysNtsc, FRONT_QAM, false, 2, 16>, NoPass>;
+            p->fn_u8 = launch_demod<PassCfg<SysNtsc, FRONT_QAM, false, 2, 16, true>, NoPass>;
             p->main.depth = 2; p->main.name = "demod_kernel<ntsc: qam front, depth 2>";
         }
         return make_passes<SysNtsc>(p, d, pald, bsf, first, err);
@@ -163,13 +172,16 @@ bool select_kernels(cm_plan *p, const cm_plan_desc &d, std::string &err) {
         if (bsf) {
             if (depth != 0 || first) { err = "band-stop luma is built for plain decoders only"; return false; }
             p->fn = launch_demod<PassCfg<SysNtscI, FRONT_QAM, true, 0, 16>, NoPass>;
+            p->fn_u8 = launch_demod<PassCfg<SysNtscI, FRONT_QAM, true, 0, 16, true>, NoPass>;
             p->main.depth = 0; p->main.name = "demod_kernel<ntsc-i: qam front + band-stop, depth 0>";
         } else if (first) {
             if (depth != 1) { err = "NTSC comb with a plain first line is built with one line of history"; return false; }
             p->fn = launch_demod<PassCfg<SysNtscI, FRONT_QAM, false, 1, 16>, NtscIFirst>;
+            p->fn_u8 = launch_demod<PassCfg<SysNtscI, FRONT_QAM, false, 1, 16, true>, NtscIFirstU8>;
             p->main.depth = 1; p->main.name = "demod_kernel<ntsc-i: qam front, depth 1 | plain first line>";
         } else {
             p->fn = launch_demod<PassCfg<SysNtscI, FRONT_QAM, false, 2, 16>, NoPass>;
+            p->fn_u8 = launch_demod<PassCfg<SysNtscI, FRONT_QAM, false, 2, 16, true>, NoPass>;
             p->main.depth = 2; p->main.name = "demod_kernel<ntsc-i: qam front, depth 2>";
         }
         return make_passes<SysNtscI>(p, d, pald, bsf, first, err);
@@ -327,7 +339,7 @@ void finish_geom(const cm_plan *p, const Pass &pass, Geom &g) {
 #ifdef CM_DIAG
 static unsigned long long *g_diag;
 #endif
-int run_plan(const cm_plan *p, Geom gm, Geom gf, bool with_first, hipStream_t stream) {
+int run_plan(const cm_plan *p, Geom gm, Geom gf, bool with_first, hipStream_t stream, bool u8 = false) {
     finish_geom(p, p->main, gm);
 #ifdef CM_DIAG
     gm.diag = g_diag;
@@ -340,7 +352,9 @@ int run_plan(const cm_plan *p, Geom gm, Geom gf, bool with_first, hipStream_t st
     }
     if (n_main + n_first <= 0) return CM_OK;
     if (n_main + n_first > 0x7fffffffLL) return fail(CM_ERR_INVALID, "batch too large for one launch");
-    return p->fn(gm, p->main.k.data(), gf, with_first ? p->first.k.data() : nullptr, (int)n_first, (int)n_main, stream);
+    LaunchFn fn = u8 ? p->fn_u8 : p->fn;
+    if (!fn) return fail(CM_ERR_UNSUPPORTED, "no kernel instance for this request");
+    return fn(gm, p->main.k.data(), gf, with_first ? p->first.k.data() : nullptr, (int)n_first, (int)n_main, stream);
 }
 
 int check_lines(const cm_plan *p, const Pass &pass, int max_line) {
@@ -479,6 +493,48 @@ int cm_demodulate_frames(const cm_plan *p, const float *composite, float *rgb, i
         s.first_frame = (int)(first_frame % (int64_t)p->first.cycle);
     }
     return run_plan(p, g, s, p->has_first, (hipStream_t)stream);
+}
+
+int cm_demodulate_frames_u8(const cm_plan *p, const uint8_t *composite8, uint8_t *rgb8, int64_t n_frames, int64_t first_frame,
+                            void *stream) {
+    if (p && n_frames == 0) return CM_OK;
+    if (!p || !composite8 || !rgb8) return fail(CM_ERR_INVALID, "null argument");
+    if (n_frames < 0 || first_frame < 0) return fail(CM_ERR_INVALID, "negative frame count / number");
+    if (p->secam || !p->fn_u8) return fail(CM_ERR_UNSUPPORTED, "the fused uint8 boundary is built for the PAL / NTSC decoders");
+    const cm_plan_desc &d = p->desc;
+    const int W = d.width, H = d.height, D = d.demodulation_delay;
+    Geom g;
+    std::memset(&g, 0, sizeof g);
+    g.in = reinterpret_cast<const float *>(composite8);   // strides below count bytes (PassCfg::U8)
+    g.out = reinterpret_cast<float *>(rgb8);
+    g.W = W;
+    g.H = H;
+    g.in_frame_stride = (long long)W * H;
+    g.in_row_stride = W;
+    g.out_plane_stride = 0;
+    g.out_frame_stride = 3LL * W * H;
+    g.out_row_stride = 3LL * W;
+    g.first_frame = (int)(first_frame % (int64_t)p->main.cycle);
+    const int rows0 = (H + 1) / 2, rows1 = H / 2;
+    g.calls_run0 = rows0 + D;
+    const int calls_run1 = rows1 > 0 ? rows1 + D : 0;
+    g.calls_per_frame = g.calls_run0 + calls_run1;
+    g.runs_per_frame = rows1 > 0 ? 2 : 1;
+    g.first_line[0] = 0;
+    g.first_line[1] = 1;
+    g.delay = D;
+    g.total_calls = n_frames * g.calls_per_frame;
+    g.skip_first = d.first_is_plain;
+    int rc = check_lines(p, p->main, H - 1 + 2 * D);
+    if (rc) return rc;
+    Geom s = g;
+    if (p->has_first) {
+        s.sparse = 1;
+        s.skip_first = 0;
+        s.total_calls = n_frames * g.runs_per_frame;
+        s.first_frame = (int)(first_frame % (int64_t)p->first.cycle);
+    }
+    return run_plan(p, g, s, p->has_first, (hipStream_t)stream, true);
 }
 
 int cm_demodulate_run(const cm_plan *p, const float *composite, float *rgb, int32_t n_calls, int32_t frame,

@@ -96,13 +96,17 @@ __device__ __forceinline__ const float *ptr_from(int byte_index, const float *p)
 
 // TILE: samples per output tile (16: 64-byte row segments; 8: 32-byte segments, used where LDS is
 // short and the pass writes a negligible share of the rows)
-template <class S_, int FRONT_, bool BSF_, int DEPTH_, int TILE_>
+// U8: the ImageModem byte boundary fused into the kernel (ref image.py:7-8, 24-25, 62, 65-71): composite is
+// uint8 [F][H][W] and enters through (5 * (byte / 255) - 1) / 3; the output is interleaved uint8 RGB
+// [F][H][W][3] = rint(255 * clip(x, 0, 1)).  The LDS tiles hold bytes in that mode (same float-sized budget).
+template <class S_, int FRONT_, bool BSF_, int DEPTH_, int TILE_, bool U8_ = false>
 struct PassCfg {
     typedef S_ S;
     static constexpr int FRONT = FRONT_, DEPTH = DEPTH_, TILE = TILE_;
-    static constexpr bool BSF = BSF_;
-    static constexpr int kLdsOut = 3 * 64 * TILE_;
-    static constexpr int kLdsFloats = kLdsIn + kLdsOut + (BSF_ ? kLdsRing : 0);
+    static constexpr bool BSF = BSF_, U8 = U8_;
+    static constexpr int kLdsInF = U8_ ? 64 * kInTile / 4 : kLdsIn;            // floats: byte tiles are a quarter
+    static constexpr int kLdsOut = U8_ ? 64 * 3 * TILE_ / 4 : 3 * 64 * TILE_;  // floats
+    static constexpr int kLdsFloats = kLdsInF + kLdsOut + (BSF_ ? kLdsRing : 0);
 };
 struct NoPass {
     static constexpr int kLdsFloats = 0;
@@ -164,13 +168,56 @@ struct DemodLane {
         for (int j = SP - 1; j > 0; --j) { ud[j] = ud[j - 1]; vd[j] = vd[j - 1]; }
         if (SP > 0) { ud[0] = u; vd[0] = v; }
         if (!EDGE || (n7 >= 0 && n7 < W)) {
-            lds_float *tp = otile + (wpos ^ (n7 & (kTile - 1)));
-            tp[0] = o.r;
-            tp[64 * kTile] = o.g;
-            tp[2 * 64 * kTile] = o.b;
+            if constexpr (Cfg::U8) {
+                // image.py:7-8: uint8(rint(255 * clip(x, 0, 1))); bytes interleaved R, G, B, 48 per tile row
+                typedef __attribute__((address_space(3))) unsigned char lds_u8;
+                lds_u8 *tb = (lds_u8 *)otile + 3 * (n7 & (kTile - 1));   // otile: this lane's 48-byte row
+                tb[0] = (unsigned char)__builtin_rintf(255.f * __builtin_fminf(__builtin_fmaxf(o.r, 0.f), 1.f));
+                tb[1] = (unsigned char)__builtin_rintf(255.f * __builtin_fminf(__builtin_fmaxf(o.g, 0.f), 1.f));
+                tb[2] = (unsigned char)__builtin_rintf(255.f * __builtin_fminf(__builtin_fmaxf(o.b, 0.f), 1.f));
+            } else {
+                lds_float *tp = otile + (wpos ^ (n7 & (kTile - 1)));
+                tp[0] = o.r;
+                tp[64 * kTile] = o.g;
+                tp[2 * 64 * kTile] = o.b;
+            }
         }
     }
 };
+
+// uint8 composite sample -> level-decoded float (image.py:24-25, 62)
+__device__ __forceinline__ f4 decode_bytes(unsigned w) {
+    const float a = 5.0f / (255.0f * 3.0f), b = -1.0f / 3.0f;
+    f4 v;
+    v.x = __builtin_fmaf((float)(w & 0xffu), a, b);
+    v.y = __builtin_fmaf((float)((w >> 8) & 0xffu), a, b);
+    v.z = __builtin_fmaf((float)((w >> 16) & 0xffu), a, b);
+    v.w = __builtin_fmaf((float)(w >> 24), a, b);
+    return v;
+}
+
+// Byte variant of flush_tile: the tile row of a lane is 16 pixels x 3 bytes; 16 rows x 48 bytes per wave-instruction.
+__device__ __forceinline__ void flush_tile_u8(const Geom &g, const lds_float *otile, const float *op, int first_col, int lane) {
+    __builtin_amdgcn_wave_barrier();
+    typedef __attribute__((address_space(3))) unsigned lds_u32;
+    typedef __attribute__((address_space(1))) unsigned global_u32;
+    const int chunk = lane & 3;               // 4 pixels = 12 bytes
+    const int col = first_col + 4 * chunk;
+#pragma nounroll
+    for (int q = 0; q < 4; ++q) {
+        const int row = (lane >> 2) + 16 * q;
+        global_u32 *dst = (global_u32 *)(unsigned long long)ptr_from(row * 4, op);
+        if (dst != nullptr && col < g.W) {
+            const lds_u32 *src = (const lds_u32 *)otile + row * 12 + 3 * chunk;
+            unsigned w0 = src[0], w1 = src[1], w2 = src[2];
+            dst += (3 * col) >> 2;
+            __builtin_nontemporal_store(w0, &dst[0]);
+            __builtin_nontemporal_store(w1, &dst[1]);
+            __builtin_nontemporal_store(w2, &dst[2]);
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+}
 
 // Row-wise read-back of the output tile and coalesced store: (256 / kTile) rows x (4 kTile) bytes per
 // wave-instruction.
@@ -275,6 +322,18 @@ __device__ __forceinline__ LaneCall locate_call(const Geom &g, int block, int de
     return r;
 }
 
+// Byte variant: rows of W bytes; a tile row is 32 bytes, 8 lanes x 4 bytes per row, 8 rows per instruction.
+__device__ __forceinline__ void fill_tile_u8(const Geom &g, lds_float *itile, const float *xp, int c, int lane) {
+    int col = kInTile * c + 4 * (lane & 7);
+    if (col > g.W - 4) col = g.W - 4;
+#pragma nounroll
+    for (int q = 0; q < 8; ++q) {
+        const unsigned char *src = (const unsigned char *)ptr_from((8 * q + (lane >> 3)) * 4, xp) + col;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                         (__attribute__((address_space(3))) void *)(itile + q * 64), 4, 0, CM_FILL_AUX);
+    }
+}
+
 template <class Cfg>
 __device__ __forceinline__ void run_lane(const Geom &g, const DemodK<float, typename Cfg::S> &k_in, int block, lds_float *lds) {
     typedef DemodLane<Cfg> Lane;
@@ -288,8 +347,8 @@ __device__ __forceinline__ void run_lane(const Geom &g, const DemodK<float, type
     constexpr int FRONT = Cfg::FRONT, DEPTH = Cfg::DEPTH, kTile = Cfg::TILE;
     constexpr bool BSF = Cfg::BSF;
     lds_float *itile = lds;
-    lds_float *otile_base = lds + kLdsIn;
-    lds_float *yring = lds + kLdsIn + Cfg::kLdsOut;
+    lds_float *otile_base = lds + Cfg::kLdsInF;
+    lds_float *yring = lds + Cfg::kLdsInF + Cfg::kLdsOut;
 
     const int lane = threadIdx.x;
     const LaneCall lc = locate_call(g, block, DEPTH, lane);
@@ -299,9 +358,21 @@ __device__ __forceinline__ void run_lane(const Geom &g, const DemodK<float, type
     const int src_row = lc.src_row, luma_row = dy ? lc.prev_row : lc.src_row, out_row = lc.out_row;
     const bool store_ok = lc.store_ok;
     Lane L;
-    const float *xp = g.in + frame * g.in_frame_stride + (long long)src_row * g.W;
-    L.lp = g.in + frame * g.in_frame_stride + (long long)luma_row * g.W;
-    const float *op = store_ok ? g.out + frame * g.out_frame_stride + (long long)out_row * g.out_row_stride : nullptr;
+    constexpr bool U8 = Cfg::U8;
+    typedef __attribute__((address_space(3))) unsigned char lds_u8;
+    typedef __attribute__((address_space(3))) unsigned lds_u32;
+    const float *xp, *op;
+    if (U8) {   // strides count bytes in this mode; the pointers are carried as opaque 64-bit values
+        const unsigned char *ib = (const unsigned char *)g.in + frame * g.in_frame_stride;
+        xp = (const float *)(ib + (long long)src_row * g.W);
+        L.lp = (const float *)(ib + (long long)luma_row * g.W);
+        op = store_ok ? (const float *)((unsigned char *)g.out + frame * g.out_frame_stride + (long long)out_row * g.out_row_stride)
+                      : nullptr;
+    } else {
+        xp = g.in + frame * g.in_frame_stride + (long long)src_row * g.W;
+        L.lp = g.in + frame * g.in_frame_stride + (long long)luma_row * g.W;
+        op = store_ok ? g.out + frame * g.out_frame_stride + (long long)out_row * g.out_row_stride : nullptr;
+    }
     {
         int fmod = (int)((g.first_frame + frame) % g.cycle);
         L.lk = g.lanes[((long long)fmod * 3 + regime) * g.n_lines + line];
@@ -321,7 +392,7 @@ __device__ __forceinline__ void run_lane(const Geom &g, const DemodK<float, type
         for (int j = 0; j < 16; ++j) yring[j * 64 + lane] = 0.f;
     }
     // output tile address of this lane's row: row * 16 + (column ^ quad swizzle)
-    lds_float *otile = otile_base + lane * kTile;
+    lds_float *otile = U8 ? (lds_float *)((lds_u8 *)otile_base + lane * 3 * kTile) : otile_base + lane * kTile;
     const int wpos = ((lane >> 1) & (kTile / 4 - 1)) << 2;
 
     // ---- stream geometry ----------------------------------------------------------------------
@@ -337,7 +408,11 @@ __device__ __forceinline__ void run_lane(const Geom &g, const DemodK<float, type
 
     const lds_float *xrow = itile + lane * kInTile;
     auto read_x = [&](int first) -> f4 {  // x[first .. first + 3] from the input tile, zero outside the row
-        f4 v = *(const lds_f4 *)(xrow + (first & (kInTile - 1)));
+        f4 v;
+        if (U8)
+            v = decode_bytes(*(const lds_u32 *)((const lds_u8 *)itile + lane * kInTile + (first & (kInTile - 1))));
+        else
+            v = *(const lds_f4 *)(xrow + (first & (kInTile - 1)));
         if (first + 3 >= W) {
             if (first >= W) v.x = 0.f;
             if (first + 1 >= W) v.y = 0.f;
@@ -351,6 +426,27 @@ __device__ __forceinline__ void run_lane(const Geom &g, const DemodK<float, type
 #ifdef CM_EXP_NO_LUMA
         return f4{0.1f, 0.2f, 0.3f, 0.4f};
 #endif
+        if (U8) {
+            const unsigned char *lb = (const unsigned char *)L.lp;
+            if (!check || (first >= 0 && first + 3 < W)) {
+                typedef unsigned u32u __attribute__((aligned(1)));
+                return decode_bytes(*(const u32u *)(lb + first));
+            }
+            f4 r = {0.f, 0.f, 0.f, 0.f};
+            if (first + 3 >= 0 && first < W) {
+                unsigned w = 0;
+                if (first >= 0 && first < W) w |= lb[first];
+                if (first + 1 >= 0 && first + 1 < W) w |= (unsigned)lb[first + 1] << 8;
+                if (first + 2 >= 0 && first + 2 < W) w |= (unsigned)lb[first + 2] << 16;
+                if (first + 3 >= 0 && first + 3 < W) w |= (unsigned)lb[first + 3] << 24;
+                f4 d = decode_bytes(w);
+                if (first >= 0 && first < W) r.x = d.x;
+                if (first + 1 >= 0 && first + 1 < W) r.y = d.y;
+                if (first + 2 >= 0 && first + 2 < W) r.z = d.z;
+                if (first + 3 >= 0 && first + 3 < W) r.w = d.w;
+            }
+            return r;
+        }
         if (!check || (first >= 0 && first + 3 < W)) {
             f4u v = *(const f4u *)(L.lp + first);
             return f4{v.x, v.y, v.z, v.w};
@@ -365,7 +461,7 @@ __device__ __forceinline__ void run_lane(const Geom &g, const DemodK<float, type
         return r;
     };
 
-    fill_tile(g, itile, xp, 0, lane);
+    if (U8) fill_tile_u8(g, itile, xp, 0, lane); else fill_tile(g, itile, xp, 0, lane);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_wave_barrier();
     {
@@ -404,7 +500,8 @@ __device__ __forceinline__ void run_lane(const Geom &g, const DemodK<float, type
         const int n7 = t - lat_out;
         if (n7 >= 0 && ((n7 & (kTile - 1)) == kTile - 1 || n7 == W - 1)) {
             CM_STAMP(t0);
-            flush_tile<kTile>(g, otile_base, op, n7 & ~(kTile - 1), lane);
+            if (U8) flush_tile_u8(g, otile_base, op, n7 & ~(kTile - 1), lane);
+            else flush_tile<kTile>(g, otile_base, op, n7 & ~(kTile - 1), lane);
 #ifdef CM_DIAG
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
 #endif
@@ -465,7 +562,7 @@ __device__ __forceinline__ void run_lane(const Geom &g, const DemodK<float, type
             CM_STAMP(t0);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_wave_barrier();
-            fill_tile(g, itile, xp, (nxt >> 5) + 1, lane);
+            if (U8) fill_tile_u8(g, itile, xp, (nxt >> 5) + 1, lane); else fill_tile(g, itile, xp, (nxt >> 5) + 1, lane);
             CM_ACC(d_fill, t0);
         }
         if (FRONT == FRONT_PALD) {

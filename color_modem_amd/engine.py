@@ -68,6 +68,23 @@ class Engine(object):
                                                          int(first_frame), stream))
         return out.cpu().numpy() if was_numpy else out
 
+    def demodulate_frames_u8(self, composite8, first_frame=0, out=None):
+        """uint8 composite [F, H, W] -> interleaved uint8 rgb [F, H, W, 3] with ImageModem's level mapping and
+        rounding fused into the kernel (PAL / NTSC decoders; raises NotImplementedError otherwise)."""
+        torch = _torch()
+        was_numpy = isinstance(composite8, numpy.ndarray)
+        t = torch.from_numpy(numpy.ascontiguousarray(composite8, dtype=numpy.uint8)) if was_numpy else composite8
+        if t.dtype != torch.uint8 or tuple(t.shape[1:]) != (self.height, self.width):
+            raise ValueError('expected uint8 [frames, %d, %d]' % (self.height, self.width))
+        t = t.cuda().contiguous() if not t.is_cuda else t.contiguous()
+        n = t.shape[0]
+        if out is None:
+            out = torch.empty((n, self.height, self.width, 3), dtype=torch.uint8, device=t.device)
+        stream = torch.cuda.current_stream(t.device).cuda_stream
+        _native.check(_native.lib().cm_demodulate_frames_u8(self._plan, t.data_ptr(), out.data_ptr(), n,
+                                                            int(first_frame), stream))
+        return out.cpu().numpy() if was_numpy else out
+
     def modulate_frames(self, rgb, first_frame=0, out=None):
         torch = _torch()
         x, was_numpy = self._as_device(rgb, (3, self.height, self.width))

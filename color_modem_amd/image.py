@@ -41,6 +41,10 @@ class ImageModem(object):
         """composite [F, H, W] float32 -> rgb [F, 3, H, W] float32 (numpy in -> numpy out, cuda tensor in -> cuda tensor out)."""
         return self._engine().demodulate_frames(composite, first_frame)
 
+    def demodulate_frames_u8(self, composite8, first_frame=0):
+        """composite uint8 [F, H, W] -> rgb uint8 [F, H, W, 3], the byte conversions of ImageModem fused into the kernel."""
+        return self._engine().demodulate_frames_u8(composite8, first_frame)
+
     def modulate_frames(self, rgb, first_frame=0):
         """rgb [F, 3, H, W] float32 -> composite [F, H, W] float32."""
         return self._engine().modulate_frames(rgb, first_frame)
@@ -60,7 +64,12 @@ class ImageModem(object):
         from PIL import Image
         if img.mode != 'L':
             img = img.convert('L')
-        comp8 = numpy.frombuffer(img.tobytes(), dtype=numpy.uint8).reshape(img.height, img.width)
+        comp8 = numpy.frombuffer(img.tobytes(), dtype=numpy.uint8).reshape(img.height, img.width).copy()
+        try:  # byte boundary fused into the kernel where this stack has it (PAL / NTSC)
+            rgb8 = self._engine().demodulate_frames_u8(comp8[None], frame)[0]
+            return Image.frombytes('RGB', (img.width, img.height), numpy.ascontiguousarray(rgb8).tobytes())
+        except NotImplementedError:
+            pass
         comp = self.decode_composite_level(comp8.astype(numpy.float64) / 255.0).astype(numpy.float32)[None]
         rgb = self.demodulate_frames(numpy.ascontiguousarray(comp), frame)[0]
         data = _as_bytes(rgb.astype(numpy.float64)).transpose(1, 2, 0)

@@ -154,6 +154,13 @@ int cm_demodulate_frames(const cm_plan *plan, const float *composite, float *rgb
 int cm_modulate_frames(const cm_plan *plan, const float *rgb, float *composite, int64_t n_frames,
                        int64_t first_frame, void *stream);
 
+/* The same with ImageModem's byte boundary fused in (image.py:58-84): composite8 is uint8 [frames][height][width]
+ * (PIL mode 'L'), decoded as (5 * (byte / 255) - 1) / 3 (image.py:24-25, 62); rgb8 is interleaved uint8
+ * [frames][height][width][3] (PIL mode 'RGB') = rint(255 * clip(x, 0, 1)) (image.py:7-8).  4 bytes per pixel
+ * cross HBM instead of 16.  PAL / NTSC decoders. */
+int cm_demodulate_frames_u8(const cm_plan *plan, const uint8_t *composite8, uint8_t *rgb8, int64_t n_frames,
+                            int64_t first_frame, void *stream);
+
 /* One run: n_calls consecutive calls Modem.demodulate(frame, first_line + 2 i, composite[i]),
  * i = 0 .. n_calls-1, where the first of them is the k0-th call since the modem's last reset
  * (k0 = 0: the run starts with a reset).  composite is [n_calls][width]; rgb receives what each

@@ -241,3 +241,25 @@ def test_unsupported_variants_fail_loudly():
     with pytest.raises(NotImplementedError):
         image.ImageModem(secam.SecamModem(line.LineConfig((720, 576)), secam.SecamVariant.SECAM_I)).demodulate_frames(
             numpy.zeros((1, 576, 720), 'f4'))
+
+
+# ---- fused uint8 boundary (cm_demodulate_frames_u8) --------------------------------------------------------
+@pytest.mark.parametrize('stack,size,n_frames,first', [('pal_d', (720, 576), 2, 1), ('pal_s', (720, 40), 3, 0),
+                                                       ('pal_3d', (720, 33), 2, 2), ('ntsc_comb_3d', (720, 480), 2, 1),
+                                                       ('ntsc', (720, 18), 2, 0), ('pal_d', (704, 9), 2, 3)])
+def test_fused_uint8_matches_float_path(stack, size, n_frames, first):
+    """uint8 in / uint8 out through the kernel == host-side level decode -> float kernel -> host-side _as_bytes,
+    up to float32 rounding of the level mapping at the knife edge of rint (<= 1 LSB on < 0.2 % of the samples)."""
+    from color_modem_amd.image import _as_bytes
+    modem = stacks.make(stack, size)
+    im = image.ImageModem(modem)
+    rgb = testing.synthetic_rgb(n_frames, size[1], size[0], seed=31)
+    enc = stacks.make('pal_s' if stack.startswith('pal') else 'ntsc', size)
+    comp = image.ImageModem(enc).modulate_frames(rgb, first_frame=first)
+    comp8 = _as_bytes(image.ImageModem.encode_composite_level(comp.astype(numpy.float64)))
+    got = im.demodulate_frames_u8(comp8, first_frame=first)
+    assert got.dtype == numpy.uint8 and got.shape == (n_frames, size[1], size[0], 3)
+    ref_in = image.ImageModem.decode_composite_level(comp8.astype(numpy.float64) / 255.0).astype(numpy.float32)
+    want = _as_bytes(im.demodulate_frames(ref_in, first_frame=first).astype(numpy.float64)).transpose(0, 2, 3, 1)
+    diff = numpy.abs(got.astype(int) - want.astype(int))
+    assert diff.max() <= 1 and (diff > 0).mean() < 2e-3, (diff.max(), (diff > 0).mean())
