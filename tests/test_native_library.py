@@ -22,7 +22,7 @@ def test_library_builds_and_loads():
 
 def test_exports_every_declared_symbol():
     header = open(os.path.join(ROOT, 'include', 'color_modem_hip.h')).read()
-    declared = set(re.findall(r'\b(cm_[a-z_]+)\s*\(', header))
+    declared = set(re.findall(r'\b(cm_[a-z0-9_]+)\s*\(', header))
     declared -= {'cm_status', 'cm_pipeline'}
     assert declared == set(_native.SYMBOLS), declared ^ set(_native.SYMBOLS)
     L = _native.lib()
