@@ -45,12 +45,53 @@ __device__ __forceinline__ void flush_tile1(const Geom &g, const lds_float *otil
     __builtin_amdgcn_wave_barrier();
 }
 
+// Three-plane input tile of the modulators: [3][64 rows][32 samples], filled like the demodulators' tile
+// (8 rows x 128 B per global_load_lds_dwordx4), single-buffered: refilled right after its last sample has
+// been read, waited for before the first sample of the next tile is read.
+constexpr int kLdsIn3 = 3 * kLdsIn;
+__device__ __forceinline__ void fill_tile3(const Geom &g, lds_float *itile, const float *rp, int c, int lane) {
+    int col = kInTile * c + 4 * (lane & 7);
+    if (col > g.W - 4) col = g.W - 4;
+#pragma nounroll
+    for (int q = 0; q < 8; ++q) {
+        const float *src = ptr_from((8 * q + (lane >> 3)) * 4, rp) + col;
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + p * g.in_plane_stride),
+                                             (__attribute__((address_space(3))) void *)(itile + p * kLdsIn + q * 256), 16, 0,
+                                             CM_FILL_AUX);
+    }
+}
+// r, g, b of samples first .. first + 3 of this lane's row out of the tile; zero beyond the row
+__device__ __forceinline__ void read_tile3(const lds_float *itile, int lane, int first, int W, f4 out[3]) {
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+        f4 v = *(const lds_f4 *)(itile + p * kLdsIn + lane * kInTile + (first & (kInTile - 1)));
+        if (first >= W) v = f4{0.f, 0.f, 0.f, 0.f};   // W % 4 == 0: a quad is inside or outside as a whole
+        out[p] = v;
+    }
+}
+// Advance the input stream by one body: returns samples nxt .. nxt + 3 and keeps the tile protocol.
+__device__ __forceinline__ void next_tile3(const Geom &g, lds_float *itile, const float *rp, int lane, int nxt, f4 out[3]) {
+    if ((nxt & (kInTile - 1)) == 0 && nxt < g.W) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+    }
+    read_tile3(itile, lane, nxt, g.W, out);
+    if ((nxt & (kInTile - 1)) == kInTile - 4 && nxt + 4 < g.W) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        fill_tile3(g, itile, rp, (nxt >> 5) + 1, lane);
+    }
+}
+
 // DEPTH = 1: encoder-side line averaging (ColorAveragingModem) needs the previous call's components.
 template <int NP, int SP, int DEPTH>
-__global__ __launch_bounds__(64, 4) void qam_mod_kernel(const ModArgs<NP> args) {
+__global__ __launch_bounds__(64, 2) void qam_mod_kernel(const ModArgs<NP> args) {
     constexpr int kTile = 16;
-    __shared__ __attribute__((aligned(16))) float lds_store[64 * kTile];
-    lds_float *otile_base = (lds_float *)lds_store;
+    __shared__ __attribute__((aligned(16))) float lds_store[kLdsIn3 + 64 * kTile];
+    lds_float *itile = (lds_float *)lds_store;
+    lds_float *otile_base = itile + kLdsIn3;
     const Geom &g = args.g;
     const ModK<float, NP> &k = args.k;
     const int lane = threadIdx.x;
@@ -73,21 +114,14 @@ __global__ __launch_bounds__(64, 4) void qam_mod_kernel(const ModArgs<NP> args) 
     const int wpos = ((lane >> 1) & (kTile / 4 - 1)) << 2;
     const int W = g.W;
     const int T = (W + SP + 3) & ~3;
-    auto load3 = [&](int first, f4 out[3]) {
-#pragma unroll
-        for (int p = 0; p < 3; ++p) {
-            if (first >= 0 && first + 3 < W) {
-                out[p] = *(const f4 *)(rp + p * g.in_plane_stride + first);
-            } else {
-                out[p] = f4{0.f, 0.f, 0.f, 0.f};
-            }
-        }
-    };
+    fill_tile3(g, itile, rp, 0, lane);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
     f4 cur[3], nxt[3];
-    load3(0, nxt);
+    read_tile3(itile, lane, 0, W, nxt);
     for (int tb = 0; tb < T; tb += 4) {
         cur[0] = nxt[0]; cur[1] = nxt[1]; cur[2] = nxt[2];
-        load3(tb + 4, nxt);
+        next_tile3(g, itile, rp, lane, tb + 4, nxt);
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             const int t = tb + s;

@@ -165,10 +165,11 @@ struct SecamModArgs {
 
 // SP = shift of the pre-correction low-pass (register window of the luma delay); DEPTH = 1: line averaging
 template <int SP, int DEPTH>
-__global__ __launch_bounds__(64, 4) void secam_mod_kernel(const SecamModArgs args) {
+__global__ __launch_bounds__(64, 2) void secam_mod_kernel(const SecamModArgs args) {
     constexpr int kTile = 16;
-    __shared__ __attribute__((aligned(16))) float lds_store[64 * kTile];
-    lds_float *otile_base = (lds_float *)lds_store;
+    __shared__ __attribute__((aligned(16))) float lds_store[kLdsIn3 + 64 * kTile];
+    lds_float *itile = (lds_float *)lds_store;
+    lds_float *otile_base = itile + kLdsIn3;
     const Geom &g = args.g;
     const SecamModK<float, double> &k = args.k;
     const int lane = threadIdx.x;
@@ -191,18 +192,14 @@ __global__ __launch_bounds__(64, 4) void secam_mod_kernel(const SecamModArgs arg
     const int wpos = ((lane >> 1) & (kTile / 4 - 1)) << 2;
     const int W = g.W;
     const int T = (W + SP + 3) & ~3;
-    auto load3 = [&](int first, f4 out[3]) {
-#pragma unroll
-        for (int p = 0; p < 3; ++p) {
-            if (first >= 0 && first + 3 < W) out[p] = *(const f4 *)(rp + p * g.in_plane_stride + first);
-            else out[p] = f4{0.f, 0.f, 0.f, 0.f};
-        }
-    };
+    fill_tile3(g, itile, rp, 0, lane);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
     f4 cur[3], nxt[3];
-    load3(0, nxt);
+    read_tile3(itile, lane, 0, W, nxt);
     for (int tb = 0; tb < T; tb += 4) {
         cur[0] = nxt[0]; cur[1] = nxt[1]; cur[2] = nxt[2];
-        load3(tb + 4, nxt);
+        next_tile3(g, itile, rp, lane, tb + 4, nxt);
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             const int t = tb + s;

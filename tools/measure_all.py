@@ -51,3 +51,12 @@ torch.cuda.synchronize(); t = time.perf_counter()
 d = x.cuda(non_blocking=True); r = eng.demodulate_frames(d, 0); o.copy_(r, non_blocking=True); torch.cuda.synchronize()
 dt = time.perf_counter() - t
 print('PCIe-inclusive pinned h2d + demod + d2h, 100 frames: %.1f ms -> %.0f Mpx/s' % (dt * 1e3, 100 * 576 * 720 / dt / 1e6))
+# fused uint8 boundary
+for stack, size in [('pal_d', (720, 576)), ('ntsc_comb_3d', (720, 480))]:
+    w, h = size
+    eng = image.ImageModem(stacks.make(stack, size))._engine()
+    x8 = torch.randint(0, 256, (F, h, w), dtype=torch.uint8, device='cuda')
+    o8 = torch.empty((F, h, w, 3), dtype=torch.uint8, device='cuda')
+    ms = timeit(lambda: eng.demodulate_frames_u8(x8, 0, out=o8))
+    px = F * w * h
+    print((stack, 'demod uint8 fused', '%dx%d' % size, F, round(ms, 3), round(px / ms / 1e3), 'GB/s at 4 B/px:', round(4 * px / ms / 1e6)), flush=True)
