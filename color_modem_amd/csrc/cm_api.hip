@@ -150,8 +150,13 @@ bool select_kernels(cm_plan *p, const cm_plan_desc &d, std::string &err) {
         }
         return make_passes<SysPal>(p, d, pald, bsf, first, err);
     }
-    if (!pald && match(signature_of<SysNtsc>())) {
-        if (bsf) {
+    if (match(signature_of<SysNtsc>())) {      // also the filter shapes of PAL-M / PAL-N
+        if (pald) {
+            if (depth != 1 || !first) { err = "PAL-D front end is built with one line of history and a plain first line"; return false; }
+            p->fn = launch_demod<PassCfg<SysNtsc, FRONT_PALD, false, 1, 16>, NtscFirst>;
+            p->fn_u8 = launch_demod<PassCfg<SysNtsc, FRONT_PALD, false, 1, 16, true>, NtscFirstU8>;
+            p->main.depth = 1; p->main.name = "demod_kernel<pal-m/n: pal-d front, depth 1 | plain first line>";
+        } else if (bsf) {
             if (depth != 0 || first) { err = "band-stop luma is built for plain decoders only"; return false; }
             p->fn = launch_demod<PassCfg<SysNtsc, FRONT_QAM, true, 0, 16>, NoPass>;
             p->fn_u8 = launch_demod<PassCfg<SysNtsc, FRONT_QAM, true, 0, 16, true>, NoPass>;

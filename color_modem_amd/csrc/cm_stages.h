@@ -269,16 +269,18 @@ struct DemodK {
 // =============================================================================================
 template <typename T, class S>
 struct PalDFront {
-    static_assert(!S::ODD_E && !S::ODD_L, "the PAL-D front end is built for even filter shifts");
     typedef DemodK<T, S> K;
     typedef VPolicy<CM_V_PALD> VP;
+    static constexpr bool ODD_E = S::ODD_E, ODD_L = S::ODD_L;
     HalfbandChain<T> up_x, dn_e, up_e, dn_s, dn_c;
     IirState<T, S::NE> bpf;
     IirState<T, S::NL> lpf_s, lpf_c;
+    T hold_b, hold_s, hold_c;   // previous odd outputs for odd shifts (as in QamFront)
 
     CM_HD void reset() {
         up_x.reset(); dn_e.reset(); up_e.reset(); dn_s.reset(); dn_c.reset();
         bpf.reset(); lpf_s.reset(); lpf_c.reset();
+        hold_b = hold_s = hold_c = T(0);
     }
     CM_HD static int latency(const K &k) { return 10 + k.q_e + 9 + 10 + k.q_l + 9; }
 
@@ -299,8 +301,9 @@ struct PalDFront {
                 if (n1 == W - 1) la.a_last = a_odd;
                 if (n1 >= W) a_even = a_odd = la.a_last;
             }
-            b_even = iir_bp<VP::VB>(bpf, k.ext, a_even);
-            b_odd = iir_bp<VP::VB>(bpf, k.ext, a_odd);
+            T y0 = iir_bp<VP::VB>(bpf, k.ext, a_even);
+            T y1 = iir_bp<VP::VB>(bpf, k.ext, a_odd);
+            if (ODD_E) { b_even = hold_b; b_odd = y0; hold_b = y1; } else { b_even = y0; b_odd = y1; }
         }
         if (EDGE && (n2 < 0 || n2 >= W)) b_even = b_odd = T(0);
         // --- dn2 -> e[n3]
@@ -320,10 +323,16 @@ struct PalDFront {
                 if (n4 == W - 1) { la.ps_last = ps_o; la.pc_last = pc_o; }
                 if (n4 >= W) { ps_e = ps_o = la.ps_last; pc_e = pc_o = la.pc_last; }
             }
-            qs_e = iir_sym<VP::VL>(lpf_s, k.lpf, ps_e);
-            qs_o = iir_sym<VP::VL>(lpf_s, k.lpf, ps_o);
-            qc_e = iir_sym<VP::VL>(lpf_c, k.lpf, pc_e);
-            qc_o = iir_sym<VP::VL>(lpf_c, k.lpf, pc_o);
+            T s0 = iir_sym<VP::VL>(lpf_s, k.lpf, ps_e);
+            T s1 = iir_sym<VP::VL>(lpf_s, k.lpf, ps_o);
+            T c0 = iir_sym<VP::VL>(lpf_c, k.lpf, pc_e);
+            T c1 = iir_sym<VP::VL>(lpf_c, k.lpf, pc_o);
+            if (ODD_L) {
+                qs_e = hold_s; qs_o = s0; hold_s = s1;
+                qc_e = hold_c; qc_o = c0; hold_c = c1;
+            } else {
+                qs_e = s0; qs_o = s1; qc_e = c0; qc_o = c1;
+            }
         }
         if (EDGE && (n5 < 0 || n5 >= W)) qs_e = qs_o = qc_e = qc_o = T(0);
         Pair<T> out;
@@ -537,6 +546,7 @@ template <typename T>
 struct SecamDemodK {
     int32_t width, preroll;      // W, P
     int32_t s_b, q_l, s_y;       // chroma band-pass shift, low-pass pair delay, luma band-stop shift
+    int32_t has_bell;            // 0: the variant has no bell filter (secam.py:167-170)
     Taps<T> taps;
     SosK<T, 3> bpf;              // secam.py:183-184 (numerator 1 - z^-2 sections)
     SosK<T, 1> bell;             // secam.py:168-170
@@ -604,7 +614,7 @@ struct SecamDemod {
             if (m == Lc - 1) cc_last = cc_now;
             if (m >= Lc) cc_now = cc_last;
             T b = iir_bp<VP::VB>(bpf, k.bpf, cc_now);
-            if (m1 >= 0) ch = iir_bp<false>(bell, k.bell, b);   // the bell sees the band-pass output from its sample 0 on
+            if (m1 >= 0) ch = k.has_bell ? iir_bp<false>(bell, k.bell, b) : b;   // the bell sees the band-pass output from its sample 0 on
         }
         if (m1 < 0 || m1 >= Lc) ch = T(0);
         ch_out = ch;

@@ -202,6 +202,12 @@ def _variant_modem(kind, variant, size):
     lc = line.LineConfig(size)
     if kind == 'pal_s':
         return pal.PalSModem(lc, getattr(pal.PalVariant, variant))
+    if kind == 'pal_d':
+        return pal.PalDModem(lc, getattr(pal.PalVariant, variant))
+    if kind == 'pal_3d':
+        return pal.Pal3DModem(lc, getattr(pal.PalVariant, variant))
+    if kind == 'secam_avg':
+        return comb.ColorAveragingModem(secam.SecamModem(lc, getattr(secam.SecamVariant, variant)))
     if kind == 'ntsc_comb':
         return ntsc.NtscCombModem(lc, getattr(ntsc.NtscVariant, variant))
     if kind == 'ntsc_comb_3d':
@@ -215,6 +221,8 @@ def _variant_modem(kind, variant, size):
     ('pal_s', 'PAL_N', (720, 576)), ('pal_s', 'PAL_M', (720, 480)), ('ntsc_comb', 'NTSC_I', (720, 480)),
     ('ntsc_comb_3d', 'NTSC443', (720, 576)), ('ntsc_comb', 'NTSC_N', (720, 576)), ('ntsc_comb', 'NTSC361', (720, 480)),
     ('secam', 'SECAM_III', (720, 576)), ('secam', 'SECAM_M', (720, 480)), ('secam', 'SECAM_N', (720, 576)),
+    ('pal_d', 'PAL_M', (720, 480)), ('pal_d', 'PAL_N', (720, 576)), ('pal_3d', 'PAL_N', (720, 576)),
+    ('secam', 'SECAM_I', (720, 576)), ('secam', 'SECAM_II', (720, 576)), ('secam_avg', 'SECAM_A', (720, 576)),
 ])
 def test_variants_round_trip_vs_oracle(kind, variant, size):
     from oracle import cm_oracle
@@ -238,9 +246,8 @@ def test_unsupported_variants_fail_loudly():
     with pytest.raises(NotImplementedError):
         image.ImageModem(ntsc.NtscModem(line.LineConfig((720, 480)), ntsc.NtscVariant.NTSC_A)).demodulate_frames(
             numpy.zeros((1, 480, 720), 'f4'))
-    with pytest.raises(NotImplementedError):
-        image.ImageModem(secam.SecamModem(line.LineConfig((720, 576)), secam.SecamVariant.SECAM_I)).demodulate_frames(
-            numpy.zeros((1, 576, 720), 'f4'))
+    with pytest.raises(ValueError):     # same failure as the reference: the band edge is beyond Nyquist at 13.5 MHz
+        secam.SecamModem(line.LineConfig((720, 576)), secam.SecamVariant.SECAM_E)
 
 
 # ---- fused uint8 boundary (cm_demodulate_frames_u8) --------------------------------------------------------
