@@ -64,6 +64,8 @@ struct cm_plan {
     cm_plan_desc desc;
     int device = 0;
     float *carrier4 = nullptr, *carrier2 = nullptr;
+    float *frame_rot = nullptr;   // {cos, sin} per frame of the rotation cycle (long sub-carrier cycles), else null
+    int rot_cycle = 0;
     LaunchFn fn = nullptr, fn_u8 = nullptr;
     bool has_first = false;
     Pass main, first;
@@ -331,6 +333,14 @@ int run_secam_mod(const cm_plan *p, Geom g, hipStream_t stream) {
     return CM_OK;
 }
 
+// frame numbering of a launch: table row of the first frame and, for rotating plans, its place in the rotation cycle
+void set_first_frame(const cm_plan *p, Geom &g, int64_t first_frame, int table_cycle) {
+    g.first_frame = (int)(first_frame % (int64_t)table_cycle);
+    g.frame_rot = p->frame_rot;
+    g.rot_cycle = p->rot_cycle;
+    g.rot_first = p->frame_rot ? (int)(first_frame % (int64_t)p->rot_cycle) : 0;
+}
+
 void finish_geom(const cm_plan *p, const Pass &pass, Geom &g) {
     g.lanes = pass.lanes;
     g.carrier4 = p->carrier4;
@@ -399,6 +409,7 @@ int cm_plan_create(const cm_plan_desc *desc, cm_plan **out) {
     cm_plan *p = new cm_plan;
     p->desc = *desc;
     p->desc.demod_main.table = p->desc.demod_first.table = p->desc.mod_main.table = nullptr;  // not retained
+    p->desc.frame_rotation = nullptr;
     if (hipGetDevice(&p->device) != hipSuccess) {
         delete p;
         return fail(CM_ERR_NO_DEVICE, "hipGetDevice failed");
@@ -425,6 +436,24 @@ int cm_plan_create(const cm_plan_desc *desc, cm_plan **out) {
         cm_plan_destroy(p);
         return fail(CM_ERR_NO_DEVICE, "device allocation / upload of the carrier tables failed");
     }
+    if (desc->frame_rotation) {
+        const int n = desc->frame_rotation_cycle;
+        const cm_lane_table *tabs[3] = {&desc->demod_main, &desc->demod_first, &desc->mod_main};
+        bool ok = n >= 2 && n % 2 == 0;
+        for (const cm_lane_table *t : tabs) ok = ok && (!t->table || t->frame_cycle == 2);
+        if (!ok) {
+            cm_plan_destroy(p);
+            return fail(CM_ERR_INVALID, "frame_rotation needs an even cycle and lane tables of exactly two frames");
+        }
+        std::vector<float> rot(2 * (size_t)n);
+        for (size_t i = 0; i < rot.size(); ++i) rot[i] = (float)desc->frame_rotation[i];
+        if (hipMalloc((void **)&p->frame_rot, rot.size() * sizeof(float)) != hipSuccess ||
+            hipMemcpy(p->frame_rot, rot.data(), rot.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) {
+            cm_plan_destroy(p);
+            return fail(CM_ERR_NO_DEVICE, "device allocation / upload of the frame rotation table failed");
+        }
+        p->rot_cycle = n;
+    }
     // a plan is usable in one direction when only the other one lacks a kernel instance
     std::string mod_err;
     const bool have_demod = select_kernels(p, *desc, err);
@@ -445,6 +474,7 @@ void cm_plan_destroy(cm_plan *p) {
     if (!p) return;
     if (p->carrier4) (void)hipFree(p->carrier4);
     if (p->carrier2) (void)hipFree(p->carrier2);
+    if (p->frame_rot) (void)hipFree(p->frame_rot);
     if (p->main.lanes) (void)hipFree(p->main.lanes);
     if (p->first.lanes) (void)hipFree(p->first.lanes);
     if (p->mod_lanes) (void)hipFree(p->mod_lanes);
@@ -473,7 +503,7 @@ int cm_demodulate_frames(const cm_plan *p, const float *composite, float *rgb, i
     g.out_plane_stride = (long long)W * H;
     g.out_frame_stride = 3LL * W * H;
     g.out_row_stride = W;
-    g.first_frame = (int)(first_frame % (int64_t)(p->secam ? p->sd_cycle : p->main.cycle));
+    set_first_frame(p, g, first_frame, p->secam ? p->sd_cycle : p->main.cycle);
     const int rows0 = (H + 1) / 2, rows1 = H / 2;
     g.calls_run0 = rows0 + D;
     const int calls_run1 = rows1 > 0 ? rows1 + D : 0;
@@ -495,7 +525,7 @@ int cm_demodulate_frames(const cm_plan *p, const float *composite, float *rgb, i
         s.sparse = 1;
         s.skip_first = 0;
         s.total_calls = n_frames * g.runs_per_frame;
-        s.first_frame = (int)(first_frame % (int64_t)p->first.cycle);
+        set_first_frame(p, s, first_frame, p->first.cycle);
     }
     return run_plan(p, g, s, p->has_first, (hipStream_t)stream);
 }
@@ -519,7 +549,7 @@ int cm_demodulate_frames_u8(const cm_plan *p, const uint8_t *composite8, uint8_t
     g.out_plane_stride = 0;
     g.out_frame_stride = 3LL * W * H;
     g.out_row_stride = 3LL * W;
-    g.first_frame = (int)(first_frame % (int64_t)p->main.cycle);
+    set_first_frame(p, g, first_frame, p->main.cycle);
     const int rows0 = (H + 1) / 2, rows1 = H / 2;
     g.calls_run0 = rows0 + D;
     const int calls_run1 = rows1 > 0 ? rows1 + D : 0;
@@ -537,7 +567,7 @@ int cm_demodulate_frames_u8(const cm_plan *p, const uint8_t *composite8, uint8_t
         s.sparse = 1;
         s.skip_first = 0;
         s.total_calls = n_frames * g.runs_per_frame;
-        s.first_frame = (int)(first_frame % (int64_t)p->first.cycle);
+        set_first_frame(p, s, first_frame, p->first.cycle);
     }
     return run_plan(p, g, s, p->has_first, (hipStream_t)stream, true);
 }
@@ -560,7 +590,7 @@ int cm_demodulate_run(const cm_plan *p, const float *composite, float *rgb, int3
     g.out_plane_stride = d.width;
     g.out_frame_stride = 0;
     g.rows_mode = 1;
-    g.first_frame = frame % (p->secam ? p->sd_cycle : p->main.cycle);
+    set_first_frame(p, g, frame, p->secam ? p->sd_cycle : p->main.cycle);
     g.calls_run0 = n_calls;
     g.calls_per_frame = n_calls;
     g.runs_per_frame = 1;
@@ -585,7 +615,7 @@ int cm_demodulate_run(const cm_plan *p, const float *composite, float *rgb, int3
         s.sparse = 1;
         s.skip_first = 0;
         s.total_calls = 1;
-        s.first_frame = frame % p->first.cycle;
+        set_first_frame(p, s, frame, p->first.cycle);
     }
     return run_plan(p, g, s, with_first, (hipStream_t)stream);
 }
@@ -623,7 +653,7 @@ int cm_modulate_frames(const cm_plan *p, const float *rgb, float *composite, int
     g.in_row_stride = W;
     g.out_frame_stride = (long long)W * H;
     g.out_row_stride = W;
-    g.first_frame = (int)(first_frame % (int64_t)p->mod_cycle);
+    set_first_frame(p, g, first_frame, p->mod_cycle);
     const int rows0 = (H + 1) / 2, rows1 = H / 2;
     g.calls_run0 = rows0 + D;
     const int calls_run1 = rows1 > 0 ? rows1 + D : 0;
@@ -654,7 +684,7 @@ int cm_modulate_run(const cm_plan *p, const float *rgb, float *composite, int32_
     g.in_row_stride = 3LL * d.width;
     g.out_row_stride = d.width;
     g.rows_mode = 1;
-    g.first_frame = frame % p->mod_cycle;
+    set_first_frame(p, g, frame, p->mod_cycle);
     g.calls_run0 = n_calls;
     g.calls_per_frame = n_calls;
     g.runs_per_frame = 1;

@@ -37,6 +37,8 @@ struct Geom {
     long long out_frame_stride, out_plane_stride, out_row_stride;
     long long total_calls;      // main pass: n_frames * calls_per_frame; sparse pass: n_frames * runs_per_frame
     int first_frame, cycle, n_lines;
+    const float *frame_rot;     // {cos, sin} per frame of the rotation cycle, or null (cm_plan_desc::frame_rotation)
+    int rot_first, rot_cycle;
     int W, H;
     int calls_per_frame, calls_run0, runs_per_frame;
     int first_line[2];
@@ -48,6 +50,32 @@ struct Geom {
     int skip_first;      // 1: calls with k == 0 are written by the sparse pass, not by this one
     unsigned long long *diag;  // diagnostic builds only (-DCM_DIAG): per-workgroup cycle sums; null otherwise
 };
+
+// Long sub-carrier cycles: advance every phase a lane constant carries by the frame's angle (c, s) = {cos, sin}.
+// A coefficient pair (a, b) standing for a cos(theta) - b sin(theta) / a sin(theta) + b cos(theta) turns with it.
+__device__ __forceinline__ void turn(float &a, float &b, float c, float s) {
+    const float a2 = a * c - b * s, b2 = a * s + b * c;
+    a = a2;
+    b = b2;
+}
+__device__ __forceinline__ bool frame_turn(const Geom &g, long long frame, float &c, float &s) {
+    if (!g.frame_rot) return false;
+    const int i = (int)((g.rot_first + frame) % g.rot_cycle);
+    c = g.frame_rot[2 * i];
+    s = g.frame_rot[2 * i + 1];
+    return true;
+}
+__device__ __forceinline__ void apply_frame_rotation(const Geom &g, long long frame, LaneK<float> &lk) {
+    float c, s;
+    if (!frame_turn(g, frame, c, s)) return;
+    turn(lk.cph, lk.sph, c, s);
+    turn(lk.vcph, lk.vsph, c, s);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        turn(lk.cu[j][0], lk.cu[j][1], c, s);
+        turn(lk.cv[j][0], lk.cv[j][1], c, s);
+    }
+}
 
 #ifdef CM_DIAG
 __device__ __forceinline__ unsigned long long cm_stamp() {
@@ -376,6 +404,7 @@ __device__ __forceinline__ void run_lane(const Geom &g, const DemodK<float, type
     {
         int fmod = (int)((g.first_frame + frame) % g.cycle);
         L.lk = g.lanes[((long long)fmod * 3 + regime) * g.n_lines + line];
+        apply_frame_rotation(g, frame, L.lk);
     }
     L.idx1 = ((lane + 63) & 63) * 4;
     L.idx2 = ((lane + 62) & 63) * 4;

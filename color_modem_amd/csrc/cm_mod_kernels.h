@@ -103,6 +103,11 @@ __global__ __launch_bounds__(64, 2) void qam_mod_kernel(const ModArgs<NP> args) 
     {
         int fmod = (int)((g.first_frame + lc.frame) % g.cycle);
         lk = ((const ModLaneK<float> *)g.lanes)[((long long)fmod * 3 + lc.regime) * g.n_lines + lc.line];
+        float rc, rs;
+        if (frame_turn(g, lc.frame, rc, rs)) {
+            turn(lk.cph, lk.sph, rc, rs);
+            turn(lk.vcph, lk.vsph, rc, rs);
+        }
     }
     const int idx1 = ((lane + 63) & 63) * 4;
     QamModCore<float, NP> core;

@@ -22,10 +22,13 @@ import ctypes
 import numpy
 import scipy.signal
 
-CM_ABI_VERSION = 2
+CM_ABI_VERSION = 3
 CM_PIPE_QAM, CM_PIPE_PAL_D, CM_PIPE_SECAM = 1, 2, 3
 CM_MAX_SECTIONS = 4
-CM_LANE_DOUBLES = 20
+CM_LANE_DOUBLES = 32
+CM_AVG_FOLDED, CM_AVG_MIN = 0, 1
+MAX_TABLE_CYCLE = 64          # longer sub-carrier cycles: two parity frames + a per-frame rotation
+MAX_ROTATION_CYCLE = 1 << 21
 
 
 class IirDesc(ctypes.Structure):
@@ -60,7 +63,9 @@ class PlanDesc(ctypes.Structure):
                 ('pald_lp', IirDesc), ('precorrect', IirDesc),
                 ('decode_matrix', ctypes.c_double * 9), ('encode_matrix', ctypes.c_double * 9),
                 ('demod_main', LaneTable), ('demod_first', LaneTable), ('secam', SecamDesc),
-                ('mod_main', LaneTable)]
+                ('mod_main', LaneTable),
+                ('frame_rotation', ctypes.POINTER(ctypes.c_double)), ('frame_rotation_cycle', ctypes.c_int32),
+                ('chroma_average', ctypes.c_int32), ('notch', IirDesc)]
 
 
 # ---------------------------------------------------------------------------------------------
@@ -183,18 +188,38 @@ class QamTables(object):
         self.lc = b.line_config
         self.LS = b.line_shift
         self.ps = b.qam.extract_chroma_phase_shift
-        self.cycle = b.frame_cycle
+        self.carrier_cycle = b.frame_cycle       # utils.py:78-80
+        self.cycle = self.carrier_cycle
         if b.v_switch and self.cycle % 2:
             self.cycle *= 2  # the V switch alternates with frame parity (line.py:64-65)
-        if self.cycle > 64:
-            raise NotImplementedError(
-                'the sub-carrier phase of this variant / line standard pair repeats only every %d frames; the per-line '
-                'tables of this build are laid out per frame of the cycle (limit 64)' % self.cycle)
+        # Long cycles (4.43 MHz colour on 525 lines: 4800 frames) are not tabulated frame by frame: the tables hold
+        # frames 0 and 1 (both parities of is_alternate_line) and frame F is frame F % 2 with every phase advanced
+        # by frame_rotation()[F % rotation_cycle], applied by the kernels (cm_plan_desc::frame_rotation).
+        self.rotating = self.cycle > MAX_TABLE_CYCLE
+        self.rotation_cycle = 0
+        self.table_frames = self.cycle
+        if self.rotating:
+            self.rotation_cycle = self.carrier_cycle * (2 if self.carrier_cycle % 2 else 1)
+            if self.rotation_cycle > MAX_ROTATION_CYCLE:
+                raise NotImplementedError('sub-carrier phase cycle of %d frames exceeds the rotation table limit'
+                                          % self.carrier_cycle)
+            self.table_frames = 2
         self.width, self.height = self.lc.size
 
     # -- helpers ---------------------------------------------------------------------------
     def phi(self, frame, line):
         return self.backend.start_phase(frame, line)
+
+    def frame_rotation(self):
+        """{cos, sin} of phi(F, line) - phi(F % 2, line) for F < rotation_cycle (utils.py:82-88: the frame's
+        share of the start phase is ((F % cycle) * frame_shift) % 2 pi for every line)."""
+        two_pi = 2.0 * numpy.pi
+        fs = self.backend.frame_shift
+        rot = numpy.zeros((self.rotation_cycle, 2))
+        for i in range(self.rotation_cycle):
+            delta = ((i % self.carrier_cycle) * fs) % two_pi - (((i % 2) % self.carrier_cycle) * fs) % two_pi
+            rot[i] = numpy.cos(delta), numpy.sin(delta)
+        return rot
 
     def vsign(self, frame, line):
         if self.backend.v_switch and self.lc.is_alternate_line(frame, line):
@@ -344,9 +369,9 @@ class QamTables(object):
 
     def demod_main_table(self):
         n_lines = self.n_lines()
-        tab = numpy.zeros((self.cycle, 3, n_lines, CM_LANE_DOUBLES))
+        tab = numpy.zeros((self.table_frames, 3, n_lines, CM_LANE_DOUBLES))
         luma_prev_bits = 0
-        for f in range(self.cycle):
+        for f in range(self.table_frames):
             for k in range(3):
                 for line in range(n_lines):
                     if line - 2 * k < -1:
@@ -370,8 +395,8 @@ class QamTables(object):
 
     def demod_first_table(self):
         n_lines = self.n_lines()
-        tab = numpy.zeros((self.cycle, 3, n_lines, CM_LANE_DOUBLES))
-        for f in range(self.cycle):
+        tab = numpy.zeros((self.table_frames, 3, n_lines, CM_LANE_DOUBLES))
+        for f in range(self.table_frames):
             for line in range(n_lines):
                 u, v = self.uv_plain(f, line)
                 e = tab[f, 0, line]
@@ -388,9 +413,9 @@ class QamTables(object):
         """[0] sin, [1] cos of the start phase of the modulated line; [2..5] row weights (luma: current,
         previous; chroma: current, previous), ref comb.py:141-152; [6] V-switch sign (pal.py:50-51)."""
         n_lines = self.n_lines()
-        tab = numpy.zeros((self.cycle, 3, n_lines, CM_LANE_DOUBLES))
+        tab = numpy.zeros((self.table_frames, 3, n_lines, CM_LANE_DOUBLES))
         avg = self.mod_wrapper == 'color_averaging'
-        for f in range(self.cycle):
+        for f in range(self.table_frames):
             for k in range(3):
                 for line in range(n_lines):
                     target = line - 2 if avg else line
@@ -455,7 +480,14 @@ def build_qam_plan(stack):
     d.demod_main = _lane_table(main, bits)
     d.demod_first = _lane_table(first)
     d.mod_main = _lane_table(mod)
-    return BuiltPlan(d, [main, first, mod], tb)
+    rot = None
+    if tb.rotating:
+        rot = numpy.ascontiguousarray(tb.frame_rotation())
+        d.frame_rotation = rot.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
+        d.frame_rotation_cycle = tb.rotation_cycle
+    d.chroma_average = CM_AVG_FOLDED
+    d.notch = iir_desc(None)
+    return BuiltPlan(d, [main, first, mod, rot], tb)
 
 
 def build_plan(modem):

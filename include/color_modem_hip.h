@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define CM_ABI_VERSION 2
+#define CM_ABI_VERSION 3
 
 enum cm_status {
     CM_OK = 0,
@@ -57,8 +57,13 @@ enum cm_pipeline {
     CM_PIPE_SECAM = 3  /* SECAM FM (secam.py:127-149, 240-304) */
 };
 
+enum cm_chroma_average {
+    CM_AVG_FOLDED = 0, /* none, or the arithmetic mean (comb.py:9-10): folded into the lane tables by linearity */
+    CM_AVG_MIN = 1     /* comb.py:13-15 minavg: sign-aware minimum of two linear combinations */
+};
+
 #define CM_MAX_SECTIONS 4
-#define CM_LANE_DOUBLES 20
+#define CM_LANE_DOUBLES 32
 
 /* One IIR filter of the reference (utils.py:9-26) in cascade form.
  * sos rows follow scipy: [b0 b1 b2 1 a1 a2]; shift is FilterFunction._shift. */
@@ -76,6 +81,8 @@ typedef struct {
  *   [10..15] v likewise
  *   [16]     +1 / -1: sign applied to v on re-modulation (the PAL V switch, pal.py:50-51)
  *   [17..19] reserved (0)
+ *   [20..31] chroma_average == CM_AVG_MIN only: a second (u, v) coefficient set laid out like [4..15]; the decoder
+ *            outputs minavg(set A, set B) (comb.py:13-15, 103-104).  0 otherwise.
  * where (Rs, Rc)[k] is the phase-free base demodulation of call k's own input line: the detector chain of
  * qam.py:45-54 (CM_PIPE_QAM) or of pal.py:71-77 applied to qam.py:34-37 (CM_PIPE_PAL_D) run with the carriers
  * sin(m cps) / cos(m cps) and without its gains; the line's carrier phase is a rotation of that pair.
@@ -134,6 +141,15 @@ typedef struct {
     cm_lane_table mod_main;    /* modulator: [0] sin, [1] cos of the start phase of the modulated line, [2] luma weight of the
                                   call's own row, [3] of the previous call's row, [4], [5] chroma weights likewise
                                   (comb.py:141-152), [6] V-switch sign */
+    /* Sub-carrier phase cycles too long to tabulate per frame (utils.py:78-80 yields e.g. 4800 frames for 4.43 MHz
+     * colour on 525 lines): when frame_rotation is not NULL every lane table above holds exactly two frames -
+     * frame numbers 0 and 1, i.e. both parities of LineConfig.is_alternate_line - and frame F uses table row F % 2
+     * with all its phases advanced by the angle whose {cos, sin} is frame_rotation[2 * (F % frame_rotation_cycle)],
+     * which the kernels apply to the lane constants when a lane starts.  NULL: tables are indexed by F % frame_cycle. */
+    const double *frame_rotation;
+    int32_t frame_rotation_cycle; /* even */
+    int32_t chroma_average;       /* enum cm_chroma_average */
+    cm_iir_desc notch;            /* comb.py:18-20 luma notch after the chroma strip (n_sections 0 = none); shift must be 0 */
 } cm_plan_desc;
 
 typedef struct cm_plan cm_plan;

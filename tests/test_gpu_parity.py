@@ -238,11 +238,54 @@ def test_variants_round_trip_vs_oracle(kind, variant, size):
         assert stacks.rel_err(got[i], want[i]) < TOL, i
 
 
+# ---- sub-carrier cycles too long to tabulate per frame: two parity frames + per-frame rotation ---------------------
+@pytest.mark.parametrize('kind,variant,size,first', [
+    ('ntsc_comb_3d', 'NTSC443', (720, 480), 4798),     # NTSC 4.43 on 525 lines: cycle 4800, batch wraps around it
+    ('pal_d', 'PAL', (720, 480), 1201),                # PAL-60
+    ('pal_3d', 'PAL_M', (720, 576), 284),              # cycle 286
+    ('ntsc_comb', 'NTSC361', (720, 576), 141),         # cycle 143 (odd)
+    ('pal_s', 'PAL_N', (720, 480), 1599),              # cycle 1600
+])
+def test_long_subcarrier_cycles_vs_oracle(kind, variant, size, first):
+    from oracle import cm_oracle
+    modem = _variant_modem(kind, variant, size)
+    im = image.ImageModem(modem)
+    assert im._engine().built.desc.frame_rotation_cycle > 64
+    rgb = testing.synthetic_rgb(4, size[1], size[0], seed=77)
+    comp_ref = cm_oracle.modulate_frames_f32(modem, rgb, first_frame=first, n_threads=8)
+    comp = im.modulate_frames(rgb, first_frame=first)
+    assert stacks.rel_err(comp, comp_ref) < TOL
+    got = im.demodulate_frames(comp_ref, first_frame=first)
+    want = cm_oracle.demodulate_frames_f32(modem, comp_ref, first_frame=first, n_threads=8)
+    for i in range(4):
+        assert stacks.rel_err(got[i], want[i]) < TOL, i
+
+
+@pytest.mark.parametrize('stack,size', [('pal_d', (720, 576)), ('ntsc_comb_3d', (720, 480)), ('pal_3d', (720, 34))])
+def test_rotating_tables_equal_per_frame_tables(stack, size, monkeypatch):
+    """The same stack through both table layouts: forcing the rotation path on a short-cycle system must not move
+    the output by more than float32 rounding of the lane constants."""
+    from color_modem_amd import plan
+    rgb = testing.synthetic_rgb(6, size[1], size[0], seed=78)
+    enc = stacks.make('pal_s' if stack.startswith('pal') else 'ntsc', size)
+    comp = image.ImageModem(enc).modulate_frames(rgb, first_frame=3)
+    want = image.ImageModem(stacks.make(stack, size)).demodulate_frames(comp, first_frame=3)
+    monkeypatch.setattr(plan, 'MAX_TABLE_CYCLE', 1)
+    im = image.ImageModem(stacks.make(stack, size))
+    assert im._engine().built.desc.frame_rotation_cycle in (2, 4)
+    got = im.demodulate_frames(comp, first_frame=3)
+    assert stacks.rel_err(got, want) < 2e-6
+    comp2 = image.ImageModem(stacks.make('pal_s' if stack.startswith('pal') else 'ntsc', size)).modulate_frames(
+        rgb, first_frame=3)
+    assert stacks.rel_err(comp2, comp) < 2e-6
+
+
 def test_unsupported_variants_fail_loudly():
     from color_modem_amd import line
     from color_modem_amd.color import ntsc, pal, secam
-    with pytest.raises(NotImplementedError):
-        image.ImageModem(pal.PalSModem(line.LineConfig((720, 480)))).demodulate_frames(numpy.zeros((1, 480, 720), 'f4'))
+    with pytest.raises(NotImplementedError):   # PAL-A at 13.5 MHz: buttord asks for order 154; the reference returns NaN
+        image.ImageModem(pal.PalSModem(line.LineConfig((720, 576)), pal.PalVariant.PAL_A)).demodulate_frames(
+            numpy.zeros((1, 576, 720), 'f4'))
     with pytest.raises(NotImplementedError):
         image.ImageModem(ntsc.NtscModem(line.LineConfig((720, 480)), ntsc.NtscVariant.NTSC_A)).demodulate_frames(
             numpy.zeros((1, 480, 720), 'f4'))

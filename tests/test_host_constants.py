@@ -140,3 +140,58 @@ def test_unsupported_options_fail_loudly():
         pal.PalDModem(lc, notch=2.0)
     with pytest.raises(NotImplementedError):
         comb.SimpleCombModem(ntsc.NtscCombModem(line.LineConfig((720, 480))), avg=comb.minavg)._stack()
+
+
+def _turned(entry, c, s, pairs):
+    out = entry.copy()
+    for ia, ib in pairs:      # (a, b) -> (a c - b s, a s + b c)
+        a, b = entry[ia], entry[ib]
+        out[ia], out[ib] = a * c - b * s, a * s + b * c
+    return out
+
+
+@pytest.mark.parametrize('stack,size', [('pal_d', (720, 576)), ('pal_3d', (720, 576)), ('ntsc_comb_3d', (720, 480)),
+                                        ('pal_s', (720, 576))])
+def test_frame_rotation_reproduces_per_frame_tables(stack, size, monkeypatch):
+    """Long sub-carrier cycles: table(F) == table(F % 2) with every phase advanced by frame_rotation[F] - checked
+    on the short-cycle systems, where both layouts can be built (cm_plan_desc::frame_rotation)."""
+    exact = plan.QamTables(stacks.make(stack, size)._stack())
+    monkeypatch.setattr(plan, 'MAX_TABLE_CYCLE', 1)
+    turning = plan.QamTables(stacks.make(stack, size)._stack())
+    assert turning.rotating and turning.table_frames == 2 and not exact.rotating
+    assert turning.rotation_cycle == exact.cycle or exact.cycle == 1
+    rot = turning.frame_rotation()
+    # demodulator: [0],[1] = sin, cos(theta): the pair (cos, sin) turns; likewise [2],[3]; coefficient pairs [4..15]
+    demod_pairs = [(1, 0), (3, 2)] + [(4 + 2 * j, 5 + 2 * j) for j in range(6)]
+    want, bits_w = exact.demod_main_table()
+    have, bits_h = turning.demod_main_table()
+    assert bits_w == bits_h and have.shape[0] == 2
+    for F in range(exact.cycle):
+        c, s = rot[F % turning.rotation_cycle]
+        for k in range(3):
+            for ln in range(0, want.shape[2], 7):
+                got = _turned(have[F % 2, k, ln], c, s, demod_pairs)
+                numpy.testing.assert_allclose(got, want[F, k, ln], rtol=0, atol=1e-12, err_msg=str((F, k, ln)))
+    if exact.first_is_plain:
+        want, have = exact.demod_first_table(), turning.demod_first_table()
+        for F in range(exact.cycle):
+            c, s = rot[F]
+            for ln in range(0, want.shape[2], 5):
+                got = _turned(have[F % 2, 0, ln], c, s, [(1, 0), (4, 5), (10, 11)])
+                numpy.testing.assert_allclose(got, want[F, 0, ln], rtol=0, atol=1e-12)
+    want, have = exact.mod_table(), turning.mod_table()
+    for F in range(exact.cycle):
+        c, s = rot[F]
+        for ln in range(0, want.shape[2], 5):
+            got = _turned(have[F % 2, 1, ln], c, s, [(1, 0)])
+            numpy.testing.assert_allclose(got, want[F, 1, ln], rtol=0, atol=1e-12)
+
+
+def test_long_cycle_plans_build():
+    """4.43 MHz colour on 525 lines repeats every 4800 frames (utils.py:78-80); PAL-M on 625 lines every 286."""
+    for modem, cyc in ((ntsc.NtscCombModem(line.LineConfig((720, 480)), ntsc.NtscVariant.NTSC443), 4800),
+                       (pal.PalDModem(line.LineConfig((720, 480))), 4800),
+                       (pal.PalSModem(line.LineConfig((720, 576)), pal.PalVariant.PAL_M), 286)):
+        bp = plan.build_plan(modem)
+        assert bp.desc.frame_rotation_cycle == cyc
+        assert bp.desc.demod_main.frame_cycle == 2 and bp.desc.mod_main.frame_cycle == 2
