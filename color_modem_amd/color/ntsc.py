@@ -61,6 +61,4 @@ class NtscCombModem(comb.AbstractCombModem):
         self._factor = 0.5 / sine if abs(sine) > 0.05 else numpy.inf
 
     def _stack(self):
-        if not numpy.isfinite(self._factor):
-            return {'kind': 'ntsc', 'backend': self.backend}
-        return {'kind': 'ntsc_comb', 'backend': self.backend, 'comb': self}
+        return {'kind': 'ntsc_comb', 'backend': self.backend, 'comb': self, 'comb_notch': self.notch}

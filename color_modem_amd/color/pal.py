@@ -68,7 +68,7 @@ class PalDModem(comb.AbstractCombModem):
             rs=48.0, btype='lowpass', ftype='cheby2')
 
     def _stack(self):
-        return {'kind': 'pal_d', 'backend': self.backend, 'comb': self}
+        return {'kind': 'pal_d', 'backend': self.backend, 'comb': self, 'comb_notch': self.notch}
 
 
 class Pal3DModem(PalDModem):
@@ -95,5 +95,5 @@ class Pal3DModem(PalDModem):
 
     def _stack(self):
         if not (self._use_sin or self._use_cos):
-            return {'kind': 'pal_d', 'backend': self.backend, 'comb': self}
-        return {'kind': 'pal_3d', 'backend': self.backend, 'comb': self}
+            return {'kind': 'pal_d', 'backend': self.backend, 'comb': self, 'comb_notch': self.notch}
+        return {'kind': 'pal_3d', 'backend': self.backend, 'comb': self, 'comb_notch': self.notch}

@@ -8,6 +8,7 @@ a linear combination of the base demodulations of at most three consecutive line
 
 import numpy
 
+from color_modem_amd import utils
 from color_modem_amd.rowapi import RowApi
 
 
@@ -20,9 +21,14 @@ def minavg(val1, val2):
     return sign * numpy.minimum(numpy.abs(val1), numpy.abs(val2))
 
 
-def _reject_notch(notch):
-    if notch:
-        raise NotImplementedError('notch= is not built yet (SURVEY.md 8f rank 3); use notch=0.0')
+def _notch(qam_modem, q):
+    return utils.notch(qam_modem, q)
+
+
+def _qam_backend(modem):
+    while not hasattr(modem, 'qam'):
+        modem = modem.backend
+    return modem
 
 
 class AbstractCombModem(RowApi):
@@ -30,9 +36,8 @@ class AbstractCombModem(RowApi):
 
     def __init__(self, backend, notch=0.0):
         RowApi.__init__(self)
-        _reject_notch(notch)
         self.backend = backend
-        self.notch = None
+        self.notch = _notch(backend, notch) if notch else None     # ref comb.py:29-31
 
     @property
     def config(self):
@@ -54,8 +59,8 @@ class SimpleCombModem(RowApi):
 
     def __init__(self, backend, notch=0.0, avg=None, delay=False):
         RowApi.__init__(self)
-        _reject_notch(notch)
         self.backend = backend
+        self._notch = _notch(_qam_backend(backend), notch) if notch else None   # ref comb.py:86-88
         self._own_delay = 1 if delay else 0
         self.modulation_delay = getattr(backend, 'modulation_delay', 0)
         self.demodulation_delay = getattr(backend, 'demodulation_delay', 0) + self._own_delay
@@ -71,10 +76,12 @@ class SimpleCombModem(RowApi):
         inner = dict(self.backend._stack())
         if 'demod_wrapper' in inner:
             raise NotImplementedError('nested SimpleCombModem wrappers are not supported')
-        if self._avg is not globals()['avg']:
-            raise NotImplementedError('avg=%r: only the default arithmetic mean is built (SURVEY.md 8f rank 3)'
-                                      % (self._avg,))
+        if self._avg is not globals()['avg'] and self._avg is not globals()['minavg']:
+            raise NotImplementedError('avg=%r: the device path implements comb.avg and comb.minavg, not arbitrary '
+                                      'callables' % (self._avg,))
         inner['demod_wrapper'] = 'simple_3d' if self._own_delay else 'simple'
+        inner['wrapper_notch'] = self._notch
+        inner['wrapper_avg'] = self._avg
         return inner
 
 

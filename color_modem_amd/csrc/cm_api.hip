@@ -116,83 +116,85 @@ bool make_passes(cm_plan *p, const cm_plan_desc &d, bool pald, bool bsf, bool fi
     return true;
 }
 
+// Kernel instances of one filter-set shape S.  HAS_PALD / HAS_D1: whether the PAL-D front end and the one-line
+// comb behind the QAM front end (NTSC comb) exist for this shape.  The notch variants are float-only.
+template <class S, bool HAS_PALD, bool HAS_D1>
+bool select_for_shape(cm_plan *p, const cm_plan_desc &d, const char *sys, std::string &err) {
+    const bool pald = d.pipeline == CM_PIPE_PAL_D;
+    const bool bsf = d.main_luma_bandstop != 0;
+    const bool first = d.first_is_plain != 0;
+    const bool notch = d.notch.n_sections != 0;
+    const bool minavg = d.chroma_average == CM_AVG_MIN;
+    const int depth = d.depth;
+    typedef PassCfg<S, FRONT_QAM, true, 0, 8> First;
+    typedef PassCfg<S, FRONT_QAM, true, 0, 16, true> FirstU8;      // byte tiles are small: no need for 8-sample tiles
+    std::string what;
+    p->fn = nullptr;
+    p->fn_u8 = nullptr;
+    if (minavg) {
+        // comb.py:13-15 behind SimpleCombModem / Pal3DModem: one instance per shape (depth 2, notch switchable)
+        if (pald || bsf || first) { err = "minavg is built behind the QAM front end (SimpleCombModem, Pal3DModem)"; return false; }
+        p->fn = launch_demod<PassCfg<S, FRONT_QAM, false, 2, 16, false, true, true>, NoPass>;
+        p->main.depth = 2; what = "qam front, depth 2, minavg";
+    } else if (pald) {
+        if constexpr (HAS_PALD) {
+            if (depth != 1 || !first) { err = "PAL-D front end is built with one line of history and a plain first line"; return false; }
+            if (notch) {
+                p->fn = launch_demod<PassCfg<S, FRONT_PALD, false, 1, 16, false, true>, First>;
+            } else {
+                p->fn = launch_demod<PassCfg<S, FRONT_PALD, false, 1, 16>, First>;
+                p->fn_u8 = launch_demod<PassCfg<S, FRONT_PALD, false, 1, 16, true>, FirstU8>;
+            }
+            p->main.depth = 1; what = "pal-d front, depth 1 | plain first line";
+        } else {
+            err = std::string("no PAL-D front end for the ") + sys + " filter shapes";
+            return false;
+        }
+    } else if (bsf) {
+        if (depth != 0 || first || notch) { err = "band-stop luma is built for plain decoders only"; return false; }
+        p->fn = launch_demod<PassCfg<S, FRONT_QAM, true, 0, 16>, NoPass>;
+        p->fn_u8 = launch_demod<PassCfg<S, FRONT_QAM, true, 0, 16, true>, NoPass>;
+        p->main.depth = 0; what = "qam front + band-stop, depth 0";
+    } else if (first) {
+        if constexpr (HAS_D1) {
+            if (depth != 1) { err = "a comb with a plain first line is built with one line of history"; return false; }
+            if (notch) {
+                p->fn = launch_demod<PassCfg<S, FRONT_QAM, false, 1, 16, false, true>, First>;
+            } else {
+                p->fn = launch_demod<PassCfg<S, FRONT_QAM, false, 1, 16>, First>;
+                p->fn_u8 = launch_demod<PassCfg<S, FRONT_QAM, false, 1, 16, true>, FirstU8>;
+            }
+            p->main.depth = 1; what = "qam front, depth 1 | plain first line";
+        } else {
+            err = std::string("no kernel instance with a plain first line behind the QAM front end for the ") + sys + " filter shapes";
+            return false;
+        }
+    } else {
+        if (notch) {
+            p->fn = launch_demod<PassCfg<S, FRONT_QAM, false, 2, 16, false, true>, NoPass>;
+        } else {
+            p->fn = launch_demod<PassCfg<S, FRONT_QAM, false, 2, 16>, NoPass>;
+            p->fn_u8 = launch_demod<PassCfg<S, FRONT_QAM, false, 2, 16, true>, NoPass>;
+        }
+        p->main.depth = 2; what = "qam front, depth 2";
+    }
+    p->main.name = std::string("demod_kernel<") + sys + ": " + what + (notch ? " + notch>" : ">");
+    return make_passes<S>(p, d, pald, bsf, first, err);
+}
+
 // Pick the kernel instance (main pass + optional plain first-line pass in one launch).
 bool select_kernels(cm_plan *p, const cm_plan_desc &d, std::string &err) {
     const bool pald = d.pipeline == CM_PIPE_PAL_D;
     const bool bsf = d.main_luma_bandstop != 0;
     const bool first = d.first_is_plain != 0;
-    const int depth = d.depth;
     SysSignature want = signature_wanted(d, pald);
     auto match = [&](SysSignature have) {
         if (!bsf && !first) { have.nr = want.nr; have.odd_r = want.odd_r; }
         return same_signature(want, have);
     };
-    typedef PassCfg<SysPal, FRONT_QAM, true, 0, 8> PalFirst;
-    typedef PassCfg<SysPal, FRONT_QAM, true, 0, 16, true> PalFirstU8;      // byte tiles are small: no need for 8-sample tiles
-    typedef PassCfg<SysNtsc, FRONT_QAM, true, 0, 16, true> NtscFirstU8;
-    typedef PassCfg<SysNtscI, FRONT_QAM, true, 0, 16, true> NtscIFirstU8;
-    typedef PassCfg<SysNtsc, FRONT_QAM, true, 0, 8> NtscFirst;
-    typedef PassCfg<SysNtscI, FRONT_QAM, true, 0, 8> NtscIFirst;
-    if (match(signature_of<SysPal>())) {
-        if (pald) {
-            if (depth != 1 || !first) { err = "PAL-D front end is built with one line of history and a plain first line"; return false; }
-            p->fn = launch_demod<PassCfg<SysPal, FRONT_PALD, false, 1, 16>, PalFirst>;
-            p->fn_u8 = launch_demod<PassCfg<SysPal, FRONT_PALD, false, 1, 16, true>, PalFirstU8>;
-            p->main.depth = 1; p->main.name = "demod_kernel<pal: pal-d front, depth 1 | plain first line>";
-        } else if (bsf) {
-            if (depth != 0 || first) { err = "band-stop luma is built for plain decoders only"; return false; }
-            p->fn = launch_demod<PassCfg<SysPal, FRONT_QAM, true, 0, 16>, NoPass>;
-            p->fn_u8 = launch_demod<PassCfg<SysPal, FRONT_QAM, true, 0, 16, true>, NoPass>;
-            p->main.depth = 0; p->main.name = "demod_kernel<pal: qam front + band-stop, depth 0>";
-        } else {
-            if (first) { err = "no PAL kernel instance with a plain first line behind the QAM front end"; return false; }
-            p->fn = launch_demod<PassCfg<SysPal, FRONT_QAM, false, 2, 16>, NoPass>;
-            p->fn_u8 = launch_demod<PassCfg<SysPal, FRONT_QAM, false, 2, 16, true>, NoPass>;
-            p->main.depth = 2; p->main.name = "demod_kernel<pal: qam front, depth 2>";
-        }
-        return make_passes<SysPal>(p, d, pald, bsf, first, err);
-    }
-    if (match(signature_of<SysNtsc>())) {      // also the filter shapes of PAL-M / PAL-N
-        if (pald) {
-            if (depth != 1 || !first) { err = "PAL-D front end is built with one line of history and a plain first line"; return false; }
-            p->fn = launch_demod<PassCfg<SysNtsc, FRONT_PALD, false, 1, 16>, NtscFirst>;
-            p->fn_u8 = launch_demod<PassCfg<SysNtsc, FRONT_PALD, false, 1, 16, true>, NtscFirstU8>;
-            p->main.depth = 1; p->main.name = "demod_kernel<pal-m/n: pal-d front, depth 1 | plain first line>";
-        } else if (bsf) {
-            if (depth != 0 || first) { err = "band-stop luma is built for plain decoders only"; return false; }
-            p->fn = launch_demod<PassCfg<SysNtsc, FRONT_QAM, true, 0, 16>, NoPass>;
-            p->fn_u8 = launch_demod<PassCfg<SysNtsc, FRONT_QAM, true, 0, 16, true>, NoPass>;
-            p->main.depth = 0; p->main.name = "demod_kernel<ntsc: qam front + band-stop, depth 0>";
-        } else if (first) {
-            if (depth != 1) { err = "NTSC comb with a plain first line is built with one line of history"; return false; }
-            p->fn = launch_demod<PassCfg<SysNtsc, FRONT_QAM, false, 1, 16>, NtscFirst>;
-            p->fn_u8 = launch_demod<PassCfg<SysNtsc, FRONT_QAM, false, 1, 16, true>, NtscFirstU8>;
-            p->main.depth = 1; p->main.name = "demod_kernel<ntsc: qam front, depth 1 | plain first line>";
-        } else {
-            p->fn = launch_demod<PassCfg<SysNtsc, FRONT_QAM, false, 2, 16>, NoPass>;
-            p->fn_u8 = launch_demod<PassCfg<SysNtsc, FRONT_QAM, false, 2, 16, true>, NoPass>;
-            p->main.depth = 2; p->main.name = "demod_kernel<ntsc: qam front, depth 2>";
-        }
-        return make_passes<SysNtsc>(p, d, pald, bsf, first, err);
-    }
-    if (!pald && match(signature_of<SysNtscI>())) {
-        if (bsf) {
-            if (depth != 0 || first) { err = "band-stop luma is built for plain decoders only"; return false; }
-            p->fn = launch_demod<PassCfg<SysNtscI, FRONT_QAM, true, 0, 16>, NoPass>;
-            p->fn_u8 = launch_demod<PassCfg<SysNtscI, FRONT_QAM, true, 0, 16, true>, NoPass>;
-            p->main.depth = 0; p->main.name = "demod_kernel<ntsc-i: qam front + band-stop, depth 0>";
-        } else if (first) {
-            if (depth != 1) { err = "NTSC comb with a plain first line is built with one line of history"; return false; }
-            p->fn = launch_demod<PassCfg<SysNtscI, FRONT_QAM, false, 1, 16>, NtscIFirst>;
-            p->fn_u8 = launch_demod<PassCfg<SysNtscI, FRONT_QAM, false, 1, 16, true>, NtscIFirstU8>;
-            p->main.depth = 1; p->main.name = "demod_kernel<ntsc-i: qam front, depth 1 | plain first line>";
-        } else {
-            p->fn = launch_demod<PassCfg<SysNtscI, FRONT_QAM, false, 2, 16>, NoPass>;
-            p->fn_u8 = launch_demod<PassCfg<SysNtscI, FRONT_QAM, false, 2, 16, true>, NoPass>;
-            p->main.depth = 2; p->main.name = "demod_kernel<ntsc-i: qam front, depth 2>";
-        }
-        return make_passes<SysNtscI>(p, d, pald, bsf, first, err);
-    }
+    if (match(signature_of<SysPal>())) return select_for_shape<SysPal, true, false>(p, d, "pal", err);
+    if (match(signature_of<SysNtsc>())) return select_for_shape<SysNtsc, true, true>(p, d, "ntsc (pal-m/n)", err);
+    if (!pald && match(signature_of<SysNtscI>())) return select_for_shape<SysNtscI, false, true>(p, d, "ntsc-i", err);
     char buf[256];
     snprintf(buf, sizeof buf,
              "no kernel instance for this filter set (sections extract/remove/detect/pre = %d/%d/%d/%d, shift parities %d/%d/%d, "

@@ -74,6 +74,8 @@ __device__ __forceinline__ void apply_frame_rotation(const Geom &g, long long fr
     for (int j = 0; j < 3; ++j) {
         turn(lk.cu[j][0], lk.cu[j][1], c, s);
         turn(lk.cv[j][0], lk.cv[j][1], c, s);
+        turn(lk.cu2[j][0], lk.cu2[j][1], c, s);
+        turn(lk.cv2[j][0], lk.cv2[j][1], c, s);
     }
 }
 
@@ -127,11 +129,11 @@ __device__ __forceinline__ const float *ptr_from(int byte_index, const float *p)
 // U8: the ImageModem byte boundary fused into the kernel (ref image.py:7-8, 24-25, 62, 65-71): composite is
 // uint8 [F][H][W] and enters through (5 * (byte / 255) - 1) / 3; the output is interleaved uint8 RGB
 // [F][H][W][3] = rint(255 * clip(x, 0, 1)).  The LDS tiles hold bytes in that mode (same float-sized budget).
-template <class S_, int FRONT_, bool BSF_, int DEPTH_, int TILE_, bool U8_ = false>
+template <class S_, int FRONT_, bool BSF_, int DEPTH_, int TILE_, bool U8_ = false, bool NOTCH_ = false, bool MINAVG_ = false>
 struct PassCfg {
     typedef S_ S;
     static constexpr int FRONT = FRONT_, DEPTH = DEPTH_, TILE = TILE_;
-    static constexpr bool BSF = BSF_, U8 = U8_;
+    static constexpr bool BSF = BSF_, U8 = U8_, NOTCH = NOTCH_, MINAVG = MINAVG_;
     static constexpr int kLdsInF = U8_ ? 64 * kInTile / 4 : kLdsIn;            // floats: byte tiles are a quarter
     static constexpr int kLdsOut = U8_ ? 64 * 3 * TILE_ / 4 : 3 * 64 * TILE_;  // floats
     static constexpr int kLdsFloats = kLdsInF + kLdsOut + (BSF_ ? kLdsRing : 0);
@@ -149,7 +151,7 @@ struct DemodLane {
     typedef typename std::conditional<FRONT == FRONT_PALD, PalDFront<float, S>, QamFront<float, S, BSF>>::type Front;
 
     Front front;
-    DemodBack<float, S, DEPTH> back;
+    DemodBack<float, S, DEPTH, Cfg::NOTCH, Cfg::MINAVG> back;
     LaneK<float> lk;
     float xw[14];
     float ew[FRONT == FRONT_PALD ? 14 : 1];

@@ -106,6 +106,10 @@ bool build_demod_k(const cm_plan_desc &d, bool pald, bool need_bsf, DemodK<T, S>
     k.luma_gain = T(g_r * 0.5);
     for (int i = 0; i < 3; ++i)
         for (int j = 0; j < 3; ++j) k.m[i][j] = T(d.decode_matrix[3 * i + j]);
+    double g_n;
+    if (!convert_sos_optional<T, 1>(d.notch, FORM_SYM, k.notch, g_n, err, "notch")) return false;
+    if (d.notch.n_sections && d.notch.shift != 0) { err = "notch: only shift 0 is built"; return false; }
+    k.notch_gain = d.notch.n_sections ? T(g_n) : T(0);   // 0 switches the notch off in instances that carry it
     return true;
 }
 
@@ -133,6 +137,10 @@ LaneK<T> convert_lane(const double *e, const DemodScales &sc) {
         l.cu[j][1] = T(e[5 + 2 * j] * sc.base);
         l.cv[j][0] = T(e[10 + 2 * j] * sc.base);
         l.cv[j][1] = T(e[11 + 2 * j] * sc.base);
+        l.cu2[j][0] = T(e[20 + 2 * j] * sc.base);
+        l.cu2[j][1] = T(e[21 + 2 * j] * sc.base);
+        l.cv2[j][0] = T(e[26 + 2 * j] * sc.base);
+        l.cv2[j][1] = T(e[27 + 2 * j] * sc.base);
     }
     return l;
 }

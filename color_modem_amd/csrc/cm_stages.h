@@ -218,7 +218,26 @@ struct LaneK {
     // are folded into these coefficients by the host.
     T cu[3][2];  // u = sum_j cu[j][0] * Rs[k-j] + cu[j][1] * Rc[k-j]
     T cv[3][2];  // v likewise
+    // second combination, read by MINAVG instances only: (u, v) = minavg(first, second), ref comb.py:13-15
+    T cu2[3][2];
+    T cv2[3][2];
 };
+
+// comb.py:13-15: sign * min(|a|, |b|) with sign = (1 - signbit(a)) - signbit(b): 0 when the signs differ
+CM_HD float minavg_(float a, float b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const float m = __builtin_fminf(__builtin_fabsf(a), __builtin_fabsf(b));
+    const unsigned differ = (__builtin_bit_cast(unsigned, a) ^ __builtin_bit_cast(unsigned, b)) & 0x80000000u;
+    return differ ? 0.f : __builtin_copysignf(m, a);
+#else
+    const float m = std::fmin(std::fabs(a), std::fabs(b));
+    return std::signbit(a) != std::signbit(b) ? 0.f : std::copysign(m, a);
+#endif
+}
+CM_HD double minavg_(double a, double b) {
+    const double m = std::fmin(std::fabs(a), std::fabs(b));
+    return std::signbit(a) != std::signbit(b) ? 0.0 : std::copysign(m, a);
+}
 
 template <typename T>
 struct Pair {
@@ -251,6 +270,8 @@ struct DemodK {
     SosK<T, S::NP> pre;   // ref qam.py:16
     T luma_gain;             // gain of the band-stop path (sections * 1/2 from the decimator)
     T m[3][3];               // (r, g, b) = m * (y, u, v)
+    SosK<T, 1> notch;        // ref comb.py:18-20 (numerator b0 (1 + b1 z^-1 + z^-2), shift 0); NOTCH instances only
+    T notch_gain;
 };
 
 // =============================================================================================
@@ -438,12 +459,13 @@ struct Rgb {
     T r, g, b;
 };
 
-template <typename T, class S, int DEPTH>
+template <typename T, class S, int DEPTH, bool NOTCH = false, bool MINAVG = false>
 struct DemodBack {
     typedef DemodK<T, S> K;
     IirState<T, S::NP> pre_u, pre_v;
+    IirState<T, 1> notch;   // touched by NOTCH instances only
     CM_HD void reset() {
-        pre_u.reset(); pre_v.reset();
+        pre_u.reset(); pre_v.reset(); notch.reset();
     }
     // Combination only (the caller keeps the u/v delay windows).
     CM_HD void combine(const LaneK<T> &lk, const Pair<T> &b0, const Pair<T> &b1, const Pair<T> &b2, T &u, T &v) const {
@@ -456,6 +478,20 @@ struct DemodBack {
         if (DEPTH >= 2) {
             u = fmaf_(lk.cu[2][0], b2.s, fmaf_(lk.cu[2][1], b2.c, u));
             v = fmaf_(lk.cv[2][0], b2.s, fmaf_(lk.cv[2][1], b2.c, v));
+        }
+        if (MINAVG) {
+            T u2 = fmaf_(lk.cu2[0][0], b0.s, lk.cu2[0][1] * b0.c);
+            T v2 = fmaf_(lk.cv2[0][0], b0.s, lk.cv2[0][1] * b0.c);
+            if (DEPTH >= 1) {
+                u2 = fmaf_(lk.cu2[1][0], b1.s, fmaf_(lk.cu2[1][1], b1.c, u2));
+                v2 = fmaf_(lk.cv2[1][0], b1.s, fmaf_(lk.cv2[1][1], b1.c, v2));
+            }
+            if (DEPTH >= 2) {
+                u2 = fmaf_(lk.cu2[2][0], b2.s, fmaf_(lk.cu2[2][1], b2.c, u2));
+                v2 = fmaf_(lk.cv2[2][0], b2.s, fmaf_(lk.cv2[2][1], b2.c, v2));
+            }
+            u = minavg_(u, u2);
+            v = minavg_(v, v2);
         }
     }
     // u, v are the combined chroma at n6; u_d, v_d the same signals at n7 = n6 - s_p;
@@ -475,6 +511,15 @@ struct DemodBack {
         T sn = fmaf_(lk.sph, car[0], lk.cph * car[1]);
         T cs = fmaf_(lk.vcph, car[0], -(lk.vsph * car[1]));  // +-cos(phi + 2 n7 cps)
         T y = y_src - fmaf_(sn, wu, cs * wv);
+        if (NOTCH) {
+            // comb.py:54-55, 109-110, pal.py:227-228: the notch follows the chroma strip, i.e. it acts on exactly the
+            // lanes that re-modulate (sph, cph != 0); it sees luma[0 .. W) from a zero state (FilterFunction, shift 0)
+            const int n7 = n6 - k.s_p;
+            if (k.notch_gain != T(0) && (!EDGE || (n7 >= 0 && n7 < W))) {   // gain 0: the plan has no notch
+                T yn = iir_sym<false>(notch, k.notch, y) * k.notch_gain;
+                if (lk.sph != T(0) || lk.cph != T(0)) y = yn;
+            }
+        }
         Rgb<T> o;
         o.r = fmaf_(k.m[0][0], y, fmaf_(k.m[0][1], u_d, k.m[0][2] * v_d));
         o.g = fmaf_(k.m[1][0], y, fmaf_(k.m[1][1], u_d, k.m[1][2] * v_d));

@@ -205,6 +205,20 @@ class QamTables(object):
                                           % self.carrier_cycle)
             self.table_frames = 2
         self.width, self.height = self.lc.size
+        # comb.py:9-15: which averaging function combines the two chroma estimates (wrapper, or Pal3DModem's two paths)
+        from color_modem_amd import comb as comb_module
+        fn = None
+        if self.demod_wrapper:
+            fn = stack.get('wrapper_avg')
+        elif self.kind == 'pal_3d' and self.comb._use_sin and self.comb._use_cos:
+            fn = self.comb._avg
+        if fn is None or fn is comb_module.avg:
+            self.minavg = False
+        elif fn is comb_module.minavg:
+            self.minavg = True
+        else:
+            raise NotImplementedError('avg=%r: the device path implements comb.avg and comb.minavg, not arbitrary '
+                                      'callables' % (fn,))
 
     # -- helpers ---------------------------------------------------------------------------
     def phi(self, frame, line):
@@ -239,8 +253,10 @@ class QamTables(object):
         if k == 0:  # comb.py:48-49 -> ntsc.py:47-49
             return self.uv_plain(frame, line)
         # ntsc.py:74-81: demodulate (curr - last) half a line shift back, swap, scale
-        q = pair_sub(self.q_row(0, -0.5 * self.LS), self.q_row(1, -0.5 * self.LS))
         f = self.comb._factor
+        if not numpy.isfinite(f):   # ntsc.py:62-63: lines nearly in phase, the comb falls back to the plain decode
+            return self.uv_plain(frame, line)
+        q = pair_sub(self.q_row(0, -0.5 * self.LS), self.q_row(1, -0.5 * self.LS))
         return f * q[1], -f * q[0]
 
     def uv_pal_d(self, frame, line, k):
@@ -267,6 +283,10 @@ class QamTables(object):
         x0, x1, x2 = self.q_row(0, d), self.q_row(1, d), self.q_row(2, d)
         sumsig = pair_sub(x0, x2)                                  # curr_diff + last_diff
         diffsig = pair_add(pair_sub(x0, (2.0 * x1[0], 2.0 * x1[1])), x2)  # curr_diff - last_diff
+        if c3._use_sin and c3._use_cos and self.minavg:            # pal.py:209-211 with comb.minavg: two estimates
+            s = self.vsign(frame, line - 2)                        # pal.py:219-220 (minavg is odd: the sign commutes)
+            return ((c3._sin_sum_factor * sumsig[1], s * (c3._sin_sum_factor * sumsig[0])),
+                    (c3._cos_u_factor * diffsig[0], s * (c3._cos_v_factor * diffsig[1])))
         if c3._use_sin and c3._use_cos:                            # pal.py:209-211 (arithmetic mean)
             u = 0.5 * (c3._sin_sum_factor * sumsig[1] + c3._cos_u_factor * diffsig[0])
             v = 0.5 * (c3._sin_sum_factor * sumsig[0] + c3._cos_v_factor * diffsig[1])
@@ -287,22 +307,29 @@ class QamTables(object):
             return self.uv_pal_3d(frame, line, k)
         raise NotImplementedError(self.kind)
 
-    # -- full decoder at call k: (u, v, remod line or None, luma from previous call?) ---------
+    # -- full decoder at call k ---------------------------------------------------------------
     def decode(self, frame, line, k):
-        """Returns u, v, remod_line (None: luma unstripped or band-stop), luma_prev (bool)."""
+        """Returns u, v, remod_line (None: luma unstripped or band-stop), luma_prev (bool), u2, v2.
+        u2, v2 are None unless the decoder combines two estimates with comb.minavg: then the output is
+        minavg(u, u2), minavg(v, v2)."""
         w = self.demod_wrapper
         if w is None:
             if self.kind in ('pal_s', 'ntsc'):
                 u, v = self.uv_plain(frame, line)
-                return u, v, None, False
+                return u, v, None, False, None, None
             if self.kind in ('ntsc_comb', 'pal_d'):
                 u, v = self.backend_uv(frame, line, k)
-                return u, v, line, False              # comb.py:52-53
+                return u, v, line, False, None, None  # comb.py:52-53
             if self.kind == 'pal_3d':
-                u, v = self.uv_pal_3d(frame, line, k)
+                r = self.uv_pal_3d(frame, line, k)
+                u2 = v2 = None
+                if self.minavg and k >= 2:
+                    (u, v), (u2, v2) = r
+                else:
+                    u, v = r
                 if k == 0:
-                    return u, v, None, False          # pal.py:195: returned before the strip
-                return u, v, line - 2, True           # pal.py:223,226
+                    return u, v, None, False, None, None   # pal.py:195: returned before the strip
+                return u, v, line - 2, True, u2, v2         # pal.py:223,226
         else:
             own_delay = 1 if w == 'simple_3d' else 0
             if self.kind == 'pal_3d':
@@ -311,11 +338,14 @@ class QamTables(object):
                 raise NotImplementedError('SimpleCombModem around PalDModem mixes two front ends; not built')
             cu, cv = self.backend_uv(frame, line, k)
             if k == 0:                                # comb.py:97-99: luma left unstripped
-                return cu, cv, None, False
+                return cu, cv, None, False, None, None
             lu, lv = self.backend_uv(frame, line - 2, k - 1)
+            remod, luma_prev = line - 2 * own_delay, bool(own_delay)   # comb.py:102,106 (modulation_delay = 0)
+            if self.minavg:                           # comb.py:103-104 with comb.minavg
+                return lu.shifted(1), lv.shifted(1), remod, luma_prev, cu, cv
             u = 0.5 * (lu.shifted(1) + cu)            # comb.py:103-104
             v = 0.5 * (lv.shifted(1) + cv)
-            return u, v, line - 2 * own_delay, bool(own_delay)  # comb.py:102,106 (modulation_delay = 0)
+            return u, v, remod, luma_prev, None, None
         raise NotImplementedError((self.kind, w))
 
     @property
@@ -382,13 +412,16 @@ class QamTables(object):
                     e[16] = 1.0
                     if self.first_is_plain and k == 0:
                         continue  # output produced by the plain pass; the base pair still feeds call 1
-                    u, v, remod_line, luma_prev = self.decode(f, line, k)
+                    u, v, remod_line, luma_prev, u2, v2 = self.decode(f, line, k)
                     if remod_line is not None:
                         p = self.phi(f, remod_line)
                         e[2], e[3] = numpy.sin(p), numpy.cos(p)
                         e[16] = self.vsign(f, remod_line)  # pal.py:50-51
                     e[4:10] = self.phase_free(u, f, line).reshape(-1)
                     e[10:16] = self.phase_free(v, f, line).reshape(-1)
+                    if self.minavg:   # no second estimate at this call: minavg(a, a) = a
+                        e[20:26] = self.phase_free(u2 if u2 is not None else u, f, line).reshape(-1)
+                        e[26:32] = self.phase_free(v2 if v2 is not None else v, f, line).reshape(-1)
                     if luma_prev:
                         luma_prev_bits |= 1 << k
         return tab, luma_prev_bits
@@ -485,8 +518,14 @@ def build_qam_plan(stack):
         rot = numpy.ascontiguousarray(tb.frame_rotation())
         d.frame_rotation = rot.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
         d.frame_rotation_cycle = tb.rotation_cycle
-    d.chroma_average = CM_AVG_FOLDED
-    d.notch = iir_desc(None)
+    d.chroma_average = CM_AVG_MIN if tb.minavg else CM_AVG_FOLDED
+    # comb.py:52-55 / 107-110 / pal.py:225-228: the notch follows the chroma strip of whichever layer strips; a
+    # wrapped comb is called with strip_chroma=False, so only the wrapper's notch acts then
+    notch = stack.get('wrapper_notch') if tb.demod_wrapper else stack.get('comb_notch')
+    if notch is not None and notch.shift != 0:
+        raise NotImplementedError('notch filters with a group delay at DC that rounds to %d samples (very low Q) '
+                                  'are not built; shift 0 is' % notch.shift)
+    d.notch = iir_desc(notch)
     return BuiltPlan(d, [main, first, mod, rot], tb)
 
 

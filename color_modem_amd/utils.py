@@ -75,6 +75,12 @@ class FilterFunction(object):
                            '(use the Modem / ImageModem entry points)')
 
 
+def notch(qam_modem, q):
+    """Luma notch at the sub-carrier (ref comb.py:18-20)."""
+    b, a = scipy.signal.iirnotch(2.0 * qam_modem.config.fsc / qam_modem.line_config.fs, q)
+    return FilterFunction(b, a, wp=0.0, btype='bandstop', shift=True)
+
+
 def iirfilter(N, Wn, rp=None, rs=None, btype='band', ftype='butter', shift=True):
     b, a = scipy.signal.iirfilter(N, Wn, rp, rs, btype, ftype=ftype)
     sos = scipy.signal.iirfilter(N, Wn, rp, rs, btype, ftype=ftype, output='sos')

@@ -356,6 +356,7 @@ struct AbstractComb : Modem {
     int last_frame = -1, last_line = -1;
     bool have_last = false;
     vec last_composite;
+    Filter notch{}; /* comb.py:29-31 */
     explicit AbstractComb(QamBackend *b) : backend(b) {}
     bool has_components() const override { return true; }
     virtual YUV demodulate_components_combed(int frame, int line, const vec &last, const vec &curr) = 0;
@@ -375,7 +376,7 @@ struct AbstractComb : Modem {
                 vec zeros(composite.size(), 0.0);
                 vec m = backend->modulate_components(frame, line, zeros, c.u, c.v);
                 for (size_t k = 0; k < m.size(); ++k) c.y[k] = c.y[k] - m[k];
-                /* comb.py:54-55 notch: not built (notch=0.0 default) */
+                if (notch.present()) c.y = notch(c.y); /* comb.py:54-55 */
             }
         }
         last_frame = frame;
@@ -397,6 +398,7 @@ struct PalD : AbstractComb {
     double sin_factor, cos_factor;
     Filter filter;
     explicit PalD(const orc_desc_t &d) : AbstractComb(new PalS(d)) {
+        notch.f = d.filters[ORC_F_COMB_NOTCH];
         sin_factor = std::sin(0.5 * backend->line_shift()); /* pal.py:65 */
         cos_factor = std::cos(0.5 * backend->line_shift()); /* pal.py:66 */
         filter.f = d.filters[ORC_F_PALD_LP];                /* pal.py:67-69 */
@@ -448,7 +450,7 @@ struct Pal3D : PalD {
     bool have_last_diff = false, have_last_demodulated = false;
     vec last_diff;
     YUV last_demodulated;
-    Pal3D(const orc_desc_t &d) : PalD(d), use_minavg(d.use_minavg != 0) {
+    Pal3D(const orc_desc_t &d) : PalD(d), use_minavg((d.use_minavg & 1) != 0) {
         double lssin = std::sin(backend->line_shift()); /* pal.py:154-156 */
         if (std::fabs(lssin) < 0.1) use_sin = false;
         double lscos = std::cos(backend->line_shift()); /* pal.py:158-160 */
@@ -507,6 +509,7 @@ struct Pal3D : PalD {
             vec zeros(n, 0.0);
             vec m = backend->modulate_components(frame, line - 2, zeros, c.u, c.v);
             for (size_t k = 0; k < n; ++k) c.y[k] = c.y[k] - m[k];
+            if (notch.present()) c.y = notch(c.y); /* pal.py:227-228 */
         }
         last_frame = frame;
         last_line = line;
@@ -522,6 +525,7 @@ struct NtscComb : AbstractComb {
     double factor;
     bool finite;
     explicit NtscComb(const orc_desc_t &d) : AbstractComb(new Ntsc(d)) {
+        notch.f = d.filters[ORC_F_COMB_NOTCH];
         double sine = std::sin(backend->line_shift() * 0.5); /* ntsc.py:55-59 */
         finite = std::fabs(sine) > 0.05;
         factor = finite ? 0.5 / sine : INFINITY;
@@ -548,7 +552,9 @@ struct SimpleComb : Modem {
     bool use_minavg;
     int last_frame = -1, last_line = -1;
     YUV last_demodulated;
-    SimpleComb(Modem *b, bool delay, bool minavg) : backend(b), own_delay(delay ? 1 : 0), use_minavg(minavg) {
+    Filter notch{}; /* comb.py:86-88 */
+    SimpleComb(Modem *b, bool delay, bool minavg, const orc_filter_t &nf) : backend(b), own_delay(delay ? 1 : 0), use_minavg(minavg) {
+        notch.f = nf;
         modulation_delay = backend->modulation_delay;                 /* comb.py:75 */
         demodulation_delay = backend->demodulation_delay + own_delay; /* comb.py:76 */
     }
@@ -578,6 +584,7 @@ struct SimpleComb : Modem {
                 vec zeros(n, 0.0);
                 vec m = backend->modulate_components(frame, line - 2 * (own_delay - modulation_delay), zeros, c.u, c.v);
                 for (size_t k = 0; k < n; ++k) c.y[k] = c.y[k] - m[k];
+                if (notch.present()) c.y = notch(c.y); /* comb.py:109-110 */
             }
         }
         last_frame = frame;
@@ -826,7 +833,7 @@ Modem *build(const orc_desc_t &d) {
                 g_error = "SimpleCombModem needs a backend with demodulate_components";
                 return nullptr;
             }
-            m = new SimpleComb(m, d.wrapper == ORC_WRAP_SIMPLE_3D_COMB, d.use_minavg != 0);
+            m = new SimpleComb(m, d.wrapper == ORC_WRAP_SIMPLE_3D_COMB, (d.use_minavg & 2) != 0, d.filters[ORC_F_WRAP_NOTCH]);
             break;
         case ORC_WRAP_COLOR_AVERAGING: m = new ColorAveraging(m); break;
         default:

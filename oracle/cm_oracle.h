@@ -63,6 +63,8 @@ enum {
     ORC_F_QAM_REMOVE2X = 2, /* qam.py:17 */
     ORC_F_QAM_DEMOD_LP = 3, /* qam.py:18 */
     ORC_F_PALD_LP = 4,      /* pal.py:67-69 */
+    ORC_F_COMB_NOTCH = 5,   /* comb.py:29-31: notch of PalD / Pal3D / NtscComb (absent: notch=0.0) */
+    ORC_F_WRAP_NOTCH = 6,   /* comb.py:86-88: notch of SimpleCombModem / Simple3DCombModem */
     ORC_F_SECAM_PRE_LP = 0,   /* secam.py:171-172 */
     ORC_F_SECAM_LF_PRE = 1,   /* secam.py:175-177 forward */
     ORC_F_SECAM_LF_REV = 2,   /* secam.py:175-177 backward */
@@ -75,7 +77,7 @@ enum {
 typedef struct {
     int32_t kind;    /* enum orc_kind */
     int32_t wrapper; /* enum orc_wrapper */
-    int32_t use_minavg; /* comb.py:13-15 instead of comb.py:9-10 */
+    int32_t use_minavg; /* comb.py:13-15 instead of comb.py:9-10: bit 0 Pal3DModem(avg=), bit 1 SimpleCombModem(avg=) */
     int32_t alternate_phases; /* secam.py:164-167 */
     /* line.py:6-13 LineStandard fields + line.py:50-55 LineConfig */
     double frame_rate;

@@ -143,7 +143,13 @@ def make_desc(modem):
         d.carrier_phase_step = backend.qam.carrier_phase_step
         comb = stack.get('comb')
         fl = [backend.qam._chroma_precorrect_lowpass, backend.qam._extract_chroma2x, backend.qam._remove_chroma2x,
-              backend.qam._demod_lowpass, comb._filter if stack['kind'] in ('pal_d', 'pal_3d') else None]
+              backend.qam._demod_lowpass, comb._filter if stack['kind'] in ('pal_d', 'pal_3d') else None,
+              stack.get('comb_notch'), stack.get('wrapper_notch')]
+        from color_modem_amd import comb as comb_module
+        if stack['kind'] == 'pal_3d' and comb._avg is comb_module.minavg:
+            d.use_minavg |= 1
+        if stack.get('wrapper_avg') is comb_module.minavg:
+            d.use_minavg |= 2
     for i, f in enumerate(fl):
         d.filters[i] = make_filter(f)
     return d

@@ -203,11 +203,31 @@ STACKS = {
     'secam_avg': lambda lc: comb.ColorAveragingModem(secam.SecamModem(lc)),
 }
 
+# options and variants: luma notch, sign-aware minimum averaging, SECAM without bell /
+# LF pre-emphasis, PAL-D on the PAL-M filter shapes, sub-carrier cycles of 4800 frames (4.43 MHz on 525 lines)
+STACKS.update({
+    'pal_d_notch': lambda lc: pal.PalDModem(lc, notch=5.0),
+    'pal_3d_notch': lambda lc: pal.Pal3DModem(lc, notch=3.0),
+    'ntsc_comb_3d_notch': lambda lc: comb.Simple3DCombModem(ntsc.NtscCombModem(lc, notch=2.5), notch=8.0),
+    'pal_3d_minavg': lambda lc: pal.Pal3DModem(lc, avg=comb.minavg),
+    'ntsc_simple_minavg': lambda lc: comb.SimpleCombModem(ntsc.NtscModem(lc), avg=comb.minavg),
+    'ntsc_comb_3d_minavg': lambda lc: comb.Simple3DCombModem(ntsc.NtscCombModem(lc), avg=comb.minavg),
+    'secam_i': lambda lc: secam.SecamModem(lc, secam.SecamVariant.SECAM_I),
+    'secam_ii': lambda lc: secam.SecamModem(lc, secam.SecamVariant.SECAM_II),
+    'pal_d_palm': lambda lc: pal.PalDModem(lc, pal.PalVariant.PAL_M),
+    'pal_s_palm': lambda lc: pal.PalSModem(lc, pal.PalVariant.PAL_M),
+    'ntsc_comb_443': lambda lc: ntsc.NtscCombModem(lc, ntsc.NtscVariant.NTSC443),
+    'ntsc_443': lambda lc: ntsc.NtscModem(lc, ntsc.NtscVariant.NTSC443),
+    'pal_d_60': lambda lc: pal.PalDModem(lc),
+    'pal_s_60': lambda lc: pal.PalSModem(lc),
+})
+
 STANDARD = {'pal': 'GERBER_625', 'ntsc': 'NTSC_525', 'secam': 'GERBER_625'}
+STANDARD_OF = {'pal_d_palm': 'NTSC_525', 'pal_s_palm': 'NTSC_525', 'pal_d_60': 'NTSC_525', 'pal_s_60': 'NTSC_525'}
 
 
 def line_config(stack, size):
-    std = getattr(LS, STANDARD[stack.split('_')[0]])
+    std = getattr(LS, STANDARD_OF.get(stack, STANDARD[stack.split('_')[0]]))
     return line.LineConfig(size, std)
 
 
@@ -262,6 +282,40 @@ def frame_cases():
              size=numpy.array([w, h]))
 
 
+def option_cases():
+    """Options and variants beyond the three headline systems, 720x8 frames."""
+    W, H = 720, 8
+    demods = [
+        ('pal_d_notch', 'pal_s', [0, 3]),
+        ('pal_3d_notch', 'pal_s', [1, 2]),
+        ('ntsc_comb_3d_notch', 'ntsc', [0, 1]),
+        ('pal_3d_minavg', 'pal_s', [0, 1, 2]),
+        ('ntsc_simple_minavg', 'ntsc', [0, 1]),
+        ('ntsc_comb_3d_minavg', 'ntsc', [0, 1]),
+        ('secam_i', 'secam_i', [0, 1]),
+        ('secam_ii', 'secam_ii', [0, 3]),
+        ('pal_d_palm', 'pal_s_palm', [0, 1, 2, 3]),
+        ('ntsc_comb_443', 'ntsc_443', [0, 1, 4799, 4802]),
+        ('pal_d_60', 'pal_s_60', [1, 2402, 4799, 4800]),
+    ]
+    mods = [('secam_i', [0, 2]), ('secam_ii', [1, 5]), ('pal_s_60', [3, 4798]), ('ntsc_443', [0, 4797])]
+    for stack, frames in mods:
+        lc = line_config(stack, (W, H))
+        modem = STACKS[stack](lc)
+        rgb = testing.synthetic_rgb(len(frames), H, W, seed=600)
+        out = numpy.stack([run_mod_frame(modem, rgb[i].astype(numpy.float64), f) for i, f in enumerate(frames)])
+        save('frames_mod_' + stack, inp=rgb, out=out, frames=numpy.array(frames), size=numpy.array([W, H]))
+    for stack, mod_stack, frames in demods:
+        lc = line_config(stack, (W, H))
+        enc = STACKS[mod_stack](lc)
+        rgb = testing.synthetic_rgb(len(frames), H, W, seed=700)
+        comp = numpy.stack([run_mod_frame(enc, rgb[i].astype(numpy.float64), f) for i, f in enumerate(frames)])
+        comp = comp.astype(numpy.float32)
+        modem = STACKS[stack](lc)
+        out = numpy.stack([run_demod_frame(modem, comp[i].astype(numpy.float64), f) for i, f in enumerate(frames)])
+        save('frames_demod_' + stack, inp=comp, out=out, frames=numpy.array(frames), size=numpy.array([W, H]))
+
+
 def row_cases():
     """Explicit (frame, line) sequences at the full-height geometry, fed to one modem object in order."""
     seqs = {
@@ -301,7 +355,11 @@ def image_cases():
 
 
 if __name__ == '__main__':
+    if sys.argv[1:] == ['options']:      # only the option / variant cases (the rest is unchanged)
+        option_cases()
+        sys.exit(0)
     make_plans()
     frame_cases()
+    option_cases()
     row_cases()
     image_cases()

@@ -23,13 +23,31 @@ STACKS = {
     'secam': lambda lc: secam.SecamModem(lc),
     'secam_avg': lambda lc: comb.ColorAveragingModem(secam.SecamModem(lc)),
 }
+# options and variants (tests/golden/make_golden.py: option_cases)
+STACKS.update({
+    'pal_d_notch': lambda lc: pal.PalDModem(lc, notch=5.0),
+    'pal_3d_notch': lambda lc: pal.Pal3DModem(lc, notch=3.0),
+    'ntsc_comb_3d_notch': lambda lc: comb.Simple3DCombModem(ntsc.NtscCombModem(lc, notch=2.5), notch=8.0),
+    'pal_3d_minavg': lambda lc: pal.Pal3DModem(lc, avg=comb.minavg),
+    'ntsc_simple_minavg': lambda lc: comb.SimpleCombModem(ntsc.NtscModem(lc), avg=comb.minavg),
+    'ntsc_comb_3d_minavg': lambda lc: comb.Simple3DCombModem(ntsc.NtscCombModem(lc), avg=comb.minavg),
+    'secam_i': lambda lc: secam.SecamModem(lc, secam.SecamVariant.SECAM_I),
+    'secam_ii': lambda lc: secam.SecamModem(lc, secam.SecamVariant.SECAM_II),
+    'pal_d_palm': lambda lc: pal.PalDModem(lc, pal.PalVariant.PAL_M),
+    'pal_s_palm': lambda lc: pal.PalSModem(lc, pal.PalVariant.PAL_M),
+    'ntsc_comb_443': lambda lc: ntsc.NtscCombModem(lc, ntsc.NtscVariant.NTSC443),
+    'ntsc_443': lambda lc: ntsc.NtscModem(lc, ntsc.NtscVariant.NTSC443),
+    'pal_d_60': lambda lc: pal.PalDModem(lc),
+    'pal_s_60': lambda lc: pal.PalSModem(lc),
+})
 STANDARD = {'pal': 'GERBER_625', 'ntsc': 'NTSC_525', 'secam': 'GERBER_625'}
+STANDARD_OF = {'pal_d_palm': 'NTSC_525', 'pal_s_palm': 'NTSC_525', 'pal_d_60': 'NTSC_525', 'pal_s_60': 'NTSC_525'}
 
 
 def line_config(stack, size, explicit=True):
     if not explicit:
         return line.LineConfig(tuple(int(v) for v in size))
-    std = getattr(line.LineStandard, STANDARD[stack.split('_')[0]])
+    std = getattr(line.LineStandard, STANDARD_OF.get(stack, STANDARD[stack.split('_')[0]]))
     return line.LineConfig(tuple(int(v) for v in size), std)
 
 

@@ -136,10 +136,18 @@ def test_lane_tables_shapes_and_regimes():
 def test_unsupported_options_fail_loudly():
     from color_modem_amd import comb
     lc = line.LineConfig((720, 576))
+    with pytest.raises(NotImplementedError):       # Q = 1: the notch's group delay at DC rounds to 1 sample
+        plan.build_plan(pal.PalDModem(lc, notch=1.0))
+    with pytest.raises(NotImplementedError):       # arbitrary averaging callables cannot be compiled into the plan
+        plan.build_plan(comb.SimpleCombModem(ntsc.NtscCombModem(line.LineConfig((720, 480))), avg=max))
     with pytest.raises(NotImplementedError):
-        pal.PalDModem(lc, notch=2.0)
+        plan.build_plan(pal.Pal3DModem(lc, avg=lambda a, b: a))
     with pytest.raises(NotImplementedError):
-        comb.SimpleCombModem(ntsc.NtscCombModem(line.LineConfig((720, 480))), avg=comb.minavg)._stack()
+        plan.build_plan(comb.SimpleCombModem(pal.PalDModem(lc)))
+    # built options
+    assert plan.build_plan(pal.PalDModem(lc, notch=2.0)).desc.notch.n_sections == 1
+    d = plan.build_plan(comb.Simple3DCombModem(ntsc.NtscCombModem(line.LineConfig((720, 480))), avg=comb.minavg)).desc
+    assert d.chroma_average == plan.CM_AVG_MIN
 
 
 def _turned(entry, c, s, pairs):
@@ -151,7 +159,7 @@ def _turned(entry, c, s, pairs):
 
 
 @pytest.mark.parametrize('stack,size', [('pal_d', (720, 576)), ('pal_3d', (720, 576)), ('ntsc_comb_3d', (720, 480)),
-                                        ('pal_s', (720, 576))])
+                                        ('pal_s', (720, 576)), ('pal_3d_minavg', (720, 576))])
 def test_frame_rotation_reproduces_per_frame_tables(stack, size, monkeypatch):
     """Long sub-carrier cycles: table(F) == table(F % 2) with every phase advanced by frame_rotation[F] - checked
     on the short-cycle systems, where both layouts can be built (cm_plan_desc::frame_rotation)."""
@@ -162,7 +170,7 @@ def test_frame_rotation_reproduces_per_frame_tables(stack, size, monkeypatch):
     assert turning.rotation_cycle == exact.cycle or exact.cycle == 1
     rot = turning.frame_rotation()
     # demodulator: [0],[1] = sin, cos(theta): the pair (cos, sin) turns; likewise [2],[3]; coefficient pairs [4..15]
-    demod_pairs = [(1, 0), (3, 2)] + [(4 + 2 * j, 5 + 2 * j) for j in range(6)]
+    demod_pairs = [(1, 0), (3, 2)] + [(4 + 2 * j, 5 + 2 * j) for j in range(6)] + [(20 + 2 * j, 21 + 2 * j) for j in range(6)]
     want, bits_w = exact.demod_main_table()
     have, bits_h = turning.demod_main_table()
     assert bits_w == bits_h and have.shape[0] == 2
