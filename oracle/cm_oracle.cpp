@@ -451,6 +451,8 @@ struct Pal3D : PalD {
     vec last_diff;
     YUV last_demodulated;
     Pal3D(const orc_desc_t &d) : PalD(d), use_minavg((d.use_minavg & 1) != 0) {
+        if (d.pal3d_disable & 1) use_sin = false;
+        if (d.pal3d_disable & 2) use_cos = false;
         double lssin = std::sin(backend->line_shift()); /* pal.py:154-156 */
         if (std::fabs(lssin) < 0.1) use_sin = false;
         double lscos = std::cos(backend->line_shift()); /* pal.py:158-160 */

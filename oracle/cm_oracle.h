@@ -89,7 +89,7 @@ typedef struct {
        fractions.Fraction, exactly as the reference does) */
     double fsc;
     int32_t frame_cycle;
-    int32_t pad0;
+    int32_t pal3d_disable; /* Pal3DModem(use_sin=False): bit 0, (use_cos=False): bit 1 (pal.py:132-142) */
     double carrier_phase_step; /* qam.py:15 */
     /* SECAM: secam.py:156-162 normalised values + variant m0/kn/kd */
     double fsc_dr, fsc_db, fdev_dr, fdev_db, flimit_min, flimit_max, bell_f0, m0, bell_kn, bell_kd;

@@ -36,7 +36,7 @@ class Desc(ctypes.Structure):
                 ('even_first', ctypes.c_int32), ('even_last', ctypes.c_int32),
                 ('width', ctypes.c_int32), ('height', ctypes.c_int32),
                 ('total_width_factor', ctypes.c_double),
-                ('fsc', ctypes.c_double), ('frame_cycle', ctypes.c_int32), ('pad0', ctypes.c_int32),
+                ('fsc', ctypes.c_double), ('frame_cycle', ctypes.c_int32), ('pal3d_disable', ctypes.c_int32),
                 ('carrier_phase_step', ctypes.c_double),
                 ('fsc_dr', ctypes.c_double), ('fsc_db', ctypes.c_double), ('fdev_dr', ctypes.c_double),
                 ('fdev_db', ctypes.c_double), ('flimit_min', ctypes.c_double), ('flimit_max', ctypes.c_double),
@@ -148,6 +148,8 @@ def make_desc(modem):
         from color_modem_amd import comb as comb_module
         if stack['kind'] == 'pal_3d' and comb._avg is comb_module.minavg:
             d.use_minavg |= 1
+        if stack['kind'] == 'pal_3d':
+            d.pal3d_disable = (0 if comb._use_sin else 1) | (0 if comb._use_cos else 2)
         if stack.get('wrapper_avg') is comb_module.minavg:
             d.use_minavg |= 2
     for i, f in enumerate(fl):

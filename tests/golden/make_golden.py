@@ -210,6 +210,8 @@ STACKS.update({
     'pal_3d_notch': lambda lc: pal.Pal3DModem(lc, notch=3.0),
     'ntsc_comb_3d_notch': lambda lc: comb.Simple3DCombModem(ntsc.NtscCombModem(lc, notch=2.5), notch=8.0),
     'pal_3d_minavg': lambda lc: pal.Pal3DModem(lc, avg=comb.minavg),
+    'pal_3d_sin': lambda lc: pal.Pal3DModem(lc, use_cos=False),
+    'pal_3d_cos': lambda lc: pal.Pal3DModem(lc, use_sin=False, notch=4.0),
     'ntsc_simple_minavg': lambda lc: comb.SimpleCombModem(ntsc.NtscModem(lc), avg=comb.minavg),
     'ntsc_comb_3d_minavg': lambda lc: comb.Simple3DCombModem(ntsc.NtscCombModem(lc), avg=comb.minavg),
     'secam_i': lambda lc: secam.SecamModem(lc, secam.SecamVariant.SECAM_I),
@@ -282,7 +284,7 @@ def frame_cases():
              size=numpy.array([w, h]))
 
 
-def option_cases():
+def option_cases(only=()):
     """Options and variants beyond the three headline systems, 720x8 frames."""
     W, H = 720, 8
     demods = [
@@ -290,6 +292,8 @@ def option_cases():
         ('pal_3d_notch', 'pal_s', [1, 2]),
         ('ntsc_comb_3d_notch', 'ntsc', [0, 1]),
         ('pal_3d_minavg', 'pal_s', [0, 1, 2]),
+        ('pal_3d_sin', 'pal_s', [1, 2]),
+        ('pal_3d_cos', 'pal_s', [0, 3]),
         ('ntsc_simple_minavg', 'ntsc', [0, 1]),
         ('ntsc_comb_3d_minavg', 'ntsc', [0, 1]),
         ('secam_i', 'secam_i', [0, 1]),
@@ -299,6 +303,9 @@ def option_cases():
         ('pal_d_60', 'pal_s_60', [1, 2402, 4799, 4800]),
     ]
     mods = [('secam_i', [0, 2]), ('secam_ii', [1, 5]), ('pal_s_60', [3, 4798]), ('ntsc_443', [0, 4797])]
+    if only:
+        mods = [m for m in mods if m[0] in only]
+        demods = [d for d in demods if d[0] in only]
     for stack, frames in mods:
         lc = line_config(stack, (W, H))
         modem = STACKS[stack](lc)
@@ -355,8 +362,8 @@ def image_cases():
 
 
 if __name__ == '__main__':
-    if sys.argv[1:] == ['options']:      # only the option / variant cases (the rest is unchanged)
-        option_cases()
+    if sys.argv[1:2] == ['options']:     # only the option / variant cases (the rest is unchanged), optionally some
+        option_cases(sys.argv[2:])
         sys.exit(0)
     make_plans()
     frame_cases()

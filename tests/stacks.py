@@ -29,6 +29,8 @@ STACKS.update({
     'pal_3d_notch': lambda lc: pal.Pal3DModem(lc, notch=3.0),
     'ntsc_comb_3d_notch': lambda lc: comb.Simple3DCombModem(ntsc.NtscCombModem(lc, notch=2.5), notch=8.0),
     'pal_3d_minavg': lambda lc: pal.Pal3DModem(lc, avg=comb.minavg),
+    'pal_3d_sin': lambda lc: pal.Pal3DModem(lc, use_cos=False),
+    'pal_3d_cos': lambda lc: pal.Pal3DModem(lc, use_sin=False, notch=4.0),
     'ntsc_simple_minavg': lambda lc: comb.SimpleCombModem(ntsc.NtscModem(lc), avg=comb.minavg),
     'ntsc_comb_3d_minavg': lambda lc: comb.Simple3DCombModem(ntsc.NtscCombModem(lc), avg=comb.minavg),
     'secam_i': lambda lc: secam.SecamModem(lc, secam.SecamVariant.SECAM_I),

@@ -280,6 +280,45 @@ def test_rotating_tables_equal_per_frame_tables(stack, size, monkeypatch):
     assert stacks.rel_err(comp2, comp) < 2e-6
 
 
+# ---- options at full geometry -----------------------------------------------------------------------------------
+def _option_modem(name):
+    from color_modem_amd import comb, line
+    from color_modem_amd.color import ntsc, pal
+    pal_lc, ntsc_lc = line.LineConfig((720, 576)), line.LineConfig((720, 480))
+    if name == 'pal_d_notch':
+        return pal.PalDModem(pal_lc, notch=4.0), pal.PalSModem(pal_lc)
+    if name == 'pal_3d_notch_minavg':
+        return pal.Pal3DModem(pal_lc, notch=10.0, avg=comb.minavg), pal.PalSModem(pal_lc)
+    if name == 'pal_3d_sin_only':
+        return pal.Pal3DModem(pal_lc, use_cos=False, avg=comb.minavg), pal.PalSModem(pal_lc)
+    if name == 'simple_pal_s_minavg':
+        return comb.SimpleCombModem(pal.PalSModem(pal_lc), avg=comb.minavg, notch=6.0), pal.PalSModem(pal_lc)
+    if name == 'ntsc_comb_notch':
+        return ntsc.NtscCombModem(ntsc_lc, notch=3.0), ntsc.NtscModem(ntsc_lc)
+    if name == 'ntsc_comb_3d_minavg':
+        return comb.Simple3DCombModem(ntsc.NtscCombModem(ntsc_lc), avg=comb.minavg), ntsc.NtscModem(ntsc_lc)
+    if name == 'ntsc_comb_in_phase':
+        # a sub-carrier at a multiple of the line rate: consecutive lines in phase, the comb switches itself off
+        # (ntsc.py:55-59, 70-71) and every line after the first is the plain decode with re-modulated luma
+        v = ntsc.NtscVariant(fsc=228.0 * 15750.0 * 1000.0 / 1001.0, bandwidth3db=1300000.0, bandwidth20db=3600000.0)
+        return ntsc.NtscCombModem(ntsc_lc, v), ntsc.NtscModem(ntsc_lc, v)
+    raise KeyError(name)
+
+
+@pytest.mark.parametrize('name', ['pal_d_notch', 'pal_3d_notch_minavg', 'pal_3d_sin_only', 'simple_pal_s_minavg',
+                                  'ntsc_comb_notch', 'ntsc_comb_3d_minavg', 'ntsc_comb_in_phase'])
+def test_options_vs_oracle(name):
+    from oracle import cm_oracle
+    modem, enc = _option_modem(name)
+    size = modem.line_config.size if hasattr(modem, 'line_config') else modem.backend.line_config.size
+    rgb = testing.synthetic_rgb(3, size[1], size[0], seed=91)
+    comp = cm_oracle.modulate_frames_f32(enc, rgb, first_frame=2, n_threads=8)
+    got = image.ImageModem(modem).demodulate_frames(comp, first_frame=2)
+    want = cm_oracle.demodulate_frames_f32(modem, comp, first_frame=2, n_threads=8)
+    for i in range(3):
+        assert stacks.rel_err(got[i], want[i]) < TOL, i
+
+
 def test_unsupported_variants_fail_loudly():
     from color_modem_amd import line
     from color_modem_amd.color import ntsc, pal, secam
