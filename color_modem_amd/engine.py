@@ -20,8 +20,8 @@ def _torch():
 
 
 class Engine(object):
-    def __init__(self, modem):
-        self.built = plan.build_plan(modem)
+    def __init__(self, modem, components=False, strip_chroma=True):
+        self.built = plan.build_plan(modem, components, strip_chroma)
         d = self.built.desc
         self.width, self.height = d.width, d.height
         self.demod_depth = d.depth

@@ -177,8 +177,9 @@ def resample_fir():
 class QamTables(object):
     """Per-line coefficient derivation for the QAM-family stacks."""
 
-    def __init__(self, stack):
+    def __init__(self, stack, strip_chroma=True):
         self.stack = stack
+        self.strip_chroma = strip_chroma         # False: demodulate_components(..., strip_chroma=False)
         self.kind = stack['kind']
         self.backend = stack['backend']          # PalSModem / NtscModem
         self.comb = stack.get('comb')            # PalDModem / Pal3DModem / NtscCombModem or None
@@ -312,6 +313,12 @@ class QamTables(object):
         """Returns u, v, remod_line (None: luma unstripped or band-stop), luma_prev (bool), u2, v2.
         u2, v2 are None unless the decoder combines two estimates with comb.minavg: then the output is
         minavg(u, u2), minavg(v, v2)."""
+        u, v, remod_line, luma_prev, u2, v2 = self._decode(frame, line, k)
+        if not self.strip_chroma:
+            remod_line = None   # qam.py:55-57, comb.py:52, 105, pal.py:225: luma stays the (previous) composite row
+        return u, v, remod_line, luma_prev, u2, v2
+
+    def _decode(self, frame, line, k):
         w = self.demod_wrapper
         if w is None:
             if self.kind in ('pal_s', 'ntsc'):
@@ -368,7 +375,8 @@ class QamTables(object):
 
     @property
     def plain_stack(self):
-        return self.demod_wrapper is None and self.kind in ('pal_s', 'ntsc')
+        # luma from the band-stop path (qam.py:57); with strip_chroma=False luma is the composite row itself
+        return self.demod_wrapper is None and self.kind in ('pal_s', 'ntsc') and self.strip_chroma
 
     @property
     def first_is_plain(self):
@@ -484,8 +492,8 @@ def _lane_table(arr, luma_prev_bits=0):
     return t
 
 
-def build_qam_plan(stack):
-    tb = QamTables(stack)
+def build_qam_plan(stack, components=False, strip_chroma=True):
+    tb = QamTables(stack, strip_chroma)
     b = tb.backend
     d = PlanDesc()
     d.abi_version = CM_ABI_VERSION
@@ -503,8 +511,10 @@ def build_qam_plan(stack):
     d.demod_lp = iir_desc(b.qam._demod_lowpass)
     d.pald_lp = iir_desc(tb.comb._filter if tb.kind == 'pal_d' else None)
     d.precorrect = iir_desc(b.qam._chroma_precorrect_lowpass)
-    d.decode_matrix[:] = list(numpy.asarray(b.decode_matrix).reshape(-1))
-    d.encode_matrix[:] = list(numpy.asarray(b.encode_matrix).reshape(-1))
+    # components=True: the *_components protocol - (y, u, v) cross the boundary instead of (r, g, b)
+    eye = numpy.eye(3)
+    d.decode_matrix[:] = list(numpy.asarray(eye if components else b.decode_matrix).reshape(-1))
+    d.encode_matrix[:] = list(numpy.asarray(eye if components else b.encode_matrix).reshape(-1))
     main, bits = tb.demod_main_table()
     first = tb.demod_first_table() if tb.first_is_plain else None
     mod = tb.mod_table()
@@ -522,6 +532,8 @@ def build_qam_plan(stack):
     # comb.py:52-55 / 107-110 / pal.py:225-228: the notch follows the chroma strip of whichever layer strips; a
     # wrapped comb is called with strip_chroma=False, so only the wrapper's notch acts then
     notch = stack.get('wrapper_notch') if tb.demod_wrapper else stack.get('comb_notch')
+    if not strip_chroma:
+        notch = None
     if notch is not None and notch.shift != 0:
         raise NotImplementedError('notch filters with a group delay at DC that rounds to %d samples (very low Q) '
                                   'are not built; shift 0 is' % notch.shift)
@@ -529,9 +541,11 @@ def build_qam_plan(stack):
     return BuiltPlan(d, [main, first, mod, rot], tb)
 
 
-def build_plan(modem):
+def build_plan(modem, components=False, strip_chroma=True):
+    """components: (y, u, v) instead of (r, g, b) at the boundary (modulate_components / demodulate_components);
+    strip_chroma: the flag of demodulate_components (False: luma is returned unstripped)."""
     stack = modem._stack()
     if stack['kind'] == 'secam':
         from color_modem_amd import plan_secam
-        return plan_secam.build_secam_plan(stack)
-    return build_qam_plan(stack)
+        return plan_secam.build_secam_plan(stack, components)
+    return build_qam_plan(stack, components, strip_chroma)

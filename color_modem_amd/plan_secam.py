@@ -6,7 +6,7 @@ import numpy
 from color_modem_amd import plan
 
 
-def build_secam_plan(stack):
+def build_secam_plan(stack, components=False):
     m = stack['backend']
     if stack.get('demod_wrapper'):
         # the reference would fail at the first row: SecamModem has no demodulate_components
@@ -24,8 +24,9 @@ def build_secam_plan(stack):
     d.first_is_plain = 0
     d.main_luma_bandstop = 0
     d.resample_fir[:] = list(plan.resample_fir())
-    d.decode_matrix[:] = list(numpy.asarray(m.decode_matrix).reshape(-1))
-    d.encode_matrix[:] = list(numpy.asarray(m.encode_matrix).reshape(-1))
+    eye = numpy.eye(3)   # components: (luma, dr, db) cross the boundary (secam.py:258 modulate_components)
+    d.decode_matrix[:] = list(numpy.asarray(eye if components else m.decode_matrix).reshape(-1))
+    d.encode_matrix[:] = list(numpy.asarray(eye if components else m.encode_matrix).reshape(-1))
     s = d.secam
     s.present = 1
     s.preroll = width // 40 - 1

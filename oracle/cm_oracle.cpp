@@ -897,6 +897,25 @@ int orc_demodulate(orc_modem *m, int frame, int line, const double *composite, i
     return 0;
 }
 
+/* the component-level protocol (qam.py / comb.py / secam.py *_components); returns -1 when the stack has none */
+int orc_modulate_components(orc_modem *m, int frame, int line, const double *y, const double *u, const double *v, int n,
+                            double *composite) {
+    vec out = m->m->modulate_components(frame, line, vec(y, y + n), vec(u, u + n), vec(v, v + n));
+    if (out.size() != (size_t)n) return -1;   /* the base class returns an empty row: no such member */
+    std::copy(out.begin(), out.end(), composite);
+    return 0;
+}
+int orc_demodulate_components(orc_modem *m, int frame, int line, const double *composite, int n, int strip_chroma,
+                              double *y, double *u, double *v) {
+    if (!m->m->has_components()) return -1;
+    YUV out = m->m->demodulate_components(frame, line, vec(composite, composite + n), strip_chroma != 0);
+    if (out.y.size() != (size_t)n) return -1;
+    std::copy(out.y.begin(), out.y.end(), y);
+    std::copy(out.u.begin(), out.u.end(), u);
+    std::copy(out.v.begin(), out.v.end(), v);
+    return 0;
+}
+
 /* image.py:47-55 */
 int orc_modulate_frame(orc_modem *m, int frame, const double *rgb, double *composite) {
     const int W = m->desc.width, H = m->desc.height;

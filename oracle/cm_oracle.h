@@ -113,6 +113,12 @@ int orc_modulate(orc_modem *m, int frame, int line, const double *r, const doubl
 int orc_demodulate(orc_modem *m, int frame, int line, const double *composite, int n, double *r, double *g,
                    double *b);
 
+/* component-level rows: (y, u, v) / (luma, dr, db) instead of (r, g, b); -1 if the stack has no such member */
+int orc_modulate_components(orc_modem *m, int frame, int line, const double *y, const double *u, const double *v, int n,
+                            double *composite);
+int orc_demodulate_components(orc_modem *m, int frame, int line, const double *composite, int n, int strip_chroma,
+                              double *y, double *u, double *v);
+
 /* image.py:47-55 / 75-83 row schedule without the uint8 conversion.
    rgb is planar [3][H][W], composite [H][W]. */
 int orc_modulate_frame(orc_modem *m, int frame, const double *rgb, double *composite);

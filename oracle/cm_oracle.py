@@ -71,6 +71,9 @@ def lib():
         L.orc_demodulation_delay.argtypes = [ctypes.c_void_p]
         L.orc_modulate.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, dp, dp, dp, ctypes.c_int, dp]
         L.orc_demodulate.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, dp, ctypes.c_int, dp, dp, dp]
+        L.orc_modulate_components.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, dp, dp, dp, ctypes.c_int, dp]
+        L.orc_demodulate_components.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, dp, ctypes.c_int,
+                                                ctypes.c_int, dp, dp, dp]
         L.orc_modulate_frame.argtypes = [ctypes.c_void_p, ctypes.c_int, dp, dp]
         L.orc_demodulate_frame.argtypes = [ctypes.c_void_p, ctypes.c_int, dp, dp]
         L.orc_image_modulate.argtypes = [ctypes.c_void_p, ctypes.c_int, u8, u8]
@@ -186,6 +189,22 @@ class OracleModem(object):
         out = numpy.empty(len(r))
         lib().orc_modulate(self._h, frame, line, _dp(r), _dp(g), _dp(b), len(r), _dp(out))
         return out
+
+    def modulate_components(self, frame, line, y, u, v):
+        y, u, v = [numpy.ascontiguousarray(c, dtype=numpy.float64) for c in (y, u, v)]
+        out = numpy.empty(len(y))
+        if lib().orc_modulate_components(self._h, frame, line, _dp(y), _dp(u), _dp(v), len(y), _dp(out)):
+            raise AttributeError('this stack has no modulate_components')
+        return out
+
+    def demodulate_components(self, frame, line, composite, strip_chroma=True):
+        x = numpy.ascontiguousarray(composite, dtype=numpy.float64)
+        n = len(x)
+        y, u, v = numpy.empty(n), numpy.empty(n), numpy.empty(n)
+        if lib().orc_demodulate_components(self._h, frame, line, _dp(x), n, 1 if strip_chroma else 0, _dp(y), _dp(u),
+                                           _dp(v)):
+            raise AttributeError('this stack has no demodulate_components')
+        return y, u, v
 
     def demodulate_frame(self, frame, composite):
         x = numpy.ascontiguousarray(composite, dtype=numpy.float64)

@@ -352,3 +352,53 @@ def test_fused_uint8_matches_float_path(stack, size, n_frames, first):
     want = _as_bytes(im.demodulate_frames(ref_in, first_frame=first).astype(numpy.float64)).transpose(0, 2, 3, 1)
     diff = numpy.abs(got.astype(int) - want.astype(int))
     assert diff.max() <= 1 and (diff > 0).mean() < 2e-3, (diff.max(), (diff > 0).mean())
+
+
+# ---- component-level protocol: modulate_components / demodulate_components ---------------------------------------------
+def _rows_through(fn_dev, fn_orc, seq, rows):
+    worst = 0.0
+    for (f, y), row in zip(seq, rows):
+        got = numpy.stack(fn_dev(f, y, row))
+        want = numpy.stack(fn_orc(f, y, row))
+        worst = max(worst, stacks.rel_err(got, want))
+    return worst
+
+
+@pytest.mark.parametrize('stack,size,strip', [
+    ('pal_s', (720, 576), True), ('pal_s', (720, 576), False), ('pal_d', (720, 576), True), ('pal_d', (720, 576), False),
+    ('pal_3d', (720, 576), True), ('pal_3d', (720, 576), False), ('ntsc_comb', (720, 480), False),
+    ('ntsc_comb_3d', (720, 480), True), ('ntsc_comb_3d', (720, 480), False), ('pal_d_notch', (720, 576), True),
+    ('ntsc_simple_minavg', (720, 480), True)])
+def test_demodulate_components_rows(stack, size, strip):
+    """(y, u, v) of the per-row protocol against the oracle's restatement of the same members (qam.py:43-58,
+    comb.py:47-59, 96-113, pal.py:180-234), including a run restart in the middle of the sequence."""
+    from oracle import cm_oracle
+    modem = stacks.make(stack, size, explicit=False)
+    enc = stacks.make('pal_s' if stack.startswith('pal') else 'ntsc', size, explicit=False)
+    orc = cm_oracle.OracleModem(stacks.make(stack, size, explicit=False))
+    seq = [(1, 3), (1, 5), (1, 7), (1, 9), (2, 0), (2, 2), (2, 4), (2, 8), (2, 10)]
+    rgb = testing.synthetic_rgb(1, len(seq), size[0], seed=17)[0]
+    rows = [cm_oracle.OracleModem(enc).modulate(f, y, rgb[0, i], rgb[1, i], rgb[2, i]).astype(numpy.float32)
+            for i, (f, y) in enumerate(seq)]
+    err = _rows_through(lambda f, y, r: modem.demodulate_components(f, y, r, strip_chroma=strip),
+                        lambda f, y, r: orc.demodulate_components(f, y, r.astype(numpy.float64), strip_chroma=strip),
+                        seq, rows)
+    assert err < TOL
+
+
+@pytest.mark.parametrize('stack,size', [('pal_s', (720, 576)), ('ntsc', (720, 480)), ('pal_avg', (720, 576)),
+                                        ('secam', (720, 576)), ('secam_avg', (720, 576)), ('pal_d', (720, 576))])
+def test_modulate_components_rows(stack, size):
+    from oracle import cm_oracle
+    modem = stacks.make(stack, size, explicit=False)
+    orc = cm_oracle.OracleModem(stacks.make(stack, size, explicit=False))
+    seq = [(0, 1), (0, 3), (0, 5), (4, 2), (4, 4), (4, 8)]
+    comps = testing.synthetic_rgb(1, len(seq), size[0], seed=19)[0]
+    comps[1:] -= 0.5     # colour-difference signals are signed
+    worst = 0.0
+    for i, (f, y) in enumerate(seq):
+        got = modem.modulate_components(f, y, comps[0, i], comps[1, i], comps[2, i])
+        want = orc.modulate_components(f, y, comps[0, i].astype(numpy.float64), comps[1, i].astype(numpy.float64),
+                                       comps[2, i].astype(numpy.float64))
+        worst = max(worst, stacks.rel_err(got, want))
+    assert worst < TOL
