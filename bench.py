@@ -163,7 +163,8 @@ def main():
             'roofline': {'bound': 'hbm', 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
                          'frac': round(achieved / HBM_PEAK_GBPS, 4), 'traffic': traffic,
                          'kernel_ms': round(mean_kernel_ms, 4), 'algorithmic_bytes_per_launch': BYTES_PER_PIXEL * px_step,
-                         'note': 'VALU-bound in practice: ~211 vector instructions per pixel (SURVEY.md D5); see DESIGN.md'},
+                         'note': 'not bandwidth-bound: ~200 float32 FMAs per pixel; the chip holds 1.45 GHz of 2.4 under this kernel '
+                                 '(profiles/r01_pair_notes.md, DESIGN.md section 5)'},
         }
         if world == 1 and args.cpu_sample > 0:
             res['cpu_baseline'] = cpu_baseline(args.cpu_sample)

@@ -11,7 +11,7 @@ import os
 from color_modem_amd import plan
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, 'libcolor_modem_hip.so')
+LIB_PATH = os.environ.get('CM_LIB') or os.path.join(HERE, 'libcolor_modem_hip.so')   # CM_LIB: A/B builds of the same ABI
 
 CM_OK, CM_ERR_INVALID, CM_ERR_UNSUPPORTED, CM_ERR_NO_DEVICE, CM_ERR_LAUNCH = 0, -1, -2, -3, -4
 

@@ -13,6 +13,10 @@
 #include "cm_secam_kernels.h"
 #include "cm_plan.h"
 
+#ifndef CM_PAIR
+#define CM_PAIR 1   /* 1: wave-pair kernels (demod_pair_kernel) where they fit; 0: one wave per 64 calls (demod_kernel) everywhere */
+#endif
+
 using namespace cm;
 
 namespace {
@@ -42,7 +46,12 @@ int launch_demod(const Geom &gm, const void *km, const Geom &gf, const void *kf,
     am.k = *static_cast<const DemodK<float, S> *>(km);
     af.g = gf;
     af.k = kf ? *static_cast<const DemodK<float, S> *>(kf) : am.k;
-    hipLaunchKernelGGL((demod_kernel<Main, First>), dim3(n_first + n_main), dim3(64), 0, stream, am, af, n_first);
+    // wave-pair kernel where stage B fits the 168 VGPRs of 3 waves per SIMD, one wave per 64 calls otherwise
+    // (measured on those instances: the pair at 2 waves per SIMD is 2-5 % slower than the single wave)
+    if constexpr (CM_PAIR != 0 && Main::kPairWaves == 3)
+        hipLaunchKernelGGL((demod_pair_kernel<Main, First>), dim3(n_first + n_main), dim3(128), 0, stream, am, af, n_first);
+    else
+        hipLaunchKernelGGL((demod_kernel<Main, First>), dim3(n_first + n_main), dim3(64), 0, stream, am, af, n_first);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(CM_ERR_LAUNCH, std::string("demod_kernel launch: ") + hipGetErrorString(e));
     return CM_OK;
@@ -63,11 +72,13 @@ typedef int (*ModLaunchFn)(const Geom &g, const void *k, int blocks, hipStream_t
 struct cm_plan {
     cm_plan_desc desc;
     int device = 0;
-    float *carrier4 = nullptr, *carrier2 = nullptr;
+    float *carrier4 = nullptr, *carrier2 = nullptr;             // entry 0 of the padded tables
+    float *carrier4_base = nullptr, *carrier2_base = nullptr;   // the allocations
     float *frame_rot = nullptr;   // {cos, sin} per frame of the rotation cycle (long sub-carrier cycles), else null
     int rot_cycle = 0;
     LaunchFn fn = nullptr, fn_u8 = nullptr;
     bool has_first = false;
+    bool pair = false;             // wave-pair kernel (two wavefronts per 64 calls)
     Pass main, first;
     // modulator
     ModLaunchFn mod_fn = nullptr;
@@ -131,6 +142,22 @@ bool select_for_shape(cm_plan *p, const cm_plan_desc &d, const char *sys, std::s
     std::string what;
     p->fn = nullptr;
     p->fn_u8 = nullptr;
+#ifdef CM_DEV_PALD_ONLY   /* development builds: the headline instance only (compiles in seconds) */
+    if constexpr (HAS_PALD) {
+        if (pald && !notch && !minavg && depth == 1 && first) {
+#ifndef CM_DEV_TILE
+#define CM_DEV_TILE 16
+#endif
+            p->fn = launch_demod<PassCfg<S, FRONT_PALD, false, 1, CM_DEV_TILE>, First>;
+            p->main.depth = 1;
+            p->pair = CM_PAIR != 0;
+            p->main.name = std::string(CM_PAIR ? "demod_pair_kernel<" : "demod_kernel<") + sys + ": pal-d front, depth 1 | plain first line>";
+            return make_passes<S>(p, d, pald, bsf, first, err);
+        }
+    }
+    err = "development build: PAL-D only";
+    return false;
+#else
     if (minavg) {
         // comb.py:13-15 behind SimpleCombModem / Pal3DModem: one instance per shape (depth 2, notch switchable)
         if (pald || bsf || first) { err = "minavg is built behind the QAM front end (SimpleCombModem, Pal3DModem)"; return false; }
@@ -178,8 +205,11 @@ bool select_for_shape(cm_plan *p, const cm_plan_desc &d, const char *sys, std::s
         }
         p->main.depth = 2; what = "qam front, depth 2";
     }
-    p->main.name = std::string("demod_kernel<") + sys + ": " + what + (notch ? " + notch>" : ">");
+    const bool pair = CM_PAIR != 0 && p->main.depth < 2 && !notch && !minavg;   // PassCfg::kPairWaves == 3
+    p->pair = pair;
+    p->main.name = std::string(pair ? "demod_pair_kernel<" : "demod_kernel<") + sys + ": " + what + (notch ? " + notch>" : ">");
     return make_passes<S>(p, d, pald, bsf, first, err);
+#endif
 }
 
 // Pick the kernel instance (main pass + optional plain first-line pass in one launch).
@@ -193,8 +223,10 @@ bool select_kernels(cm_plan *p, const cm_plan_desc &d, std::string &err) {
         return same_signature(want, have);
     };
     if (match(signature_of<SysPal>())) return select_for_shape<SysPal, true, false>(p, d, "pal", err);
+#ifndef CM_DEV_PALD_ONLY
     if (match(signature_of<SysNtsc>())) return select_for_shape<SysNtsc, true, true>(p, d, "ntsc (pal-m/n)", err);
     if (!pald && match(signature_of<SysNtscI>())) return select_for_shape<SysNtscI, false, true>(p, d, "ntsc-i", err);
+#endif
     char buf[256];
     snprintf(buf, sizeof buf,
              "no kernel instance for this filter set (sections extract/remove/detect/pre = %d/%d/%d/%d, shift parities %d/%d/%d, "
@@ -425,19 +457,27 @@ int cm_plan_create(const cm_plan_desc *desc, cm_plan **out) {
         *out = p;
         return CM_OK;
     }
-    std::vector<float> car = build_carrier<float>(desc->carrier_phase_step, desc->width);  // {C[m], S[m]}, m < 2W
-    std::vector<float> car2(2 * (size_t)desc->width);                                      // {C[2n], S[2n]}
-    for (int n = 0; n < desc->width; ++n) {
-        car2[2 * n] = car[4 * n];
-        car2[2 * n + 1] = car[4 * n + 1];
+    // Carrier tables, padded by kCarrierPad entries on both sides with copies of the first / last entry: the kernels
+    // index them with stream positions that run from -latency to W + latency and the padding stands for the clamp.
+    std::vector<float> car0 = build_carrier<float>(desc->carrier_phase_step, desc->width);  // {C[m], S[m]}, m < 2W
+    const int W_ = desc->width, P_ = kCarrierPad;
+    std::vector<float> car(4 * (size_t)(W_ + 2 * P_)), car2(2 * (size_t)(W_ + 2 * P_));   // {C, S}[2n, 2n+1]; {C, S}[2n]
+    for (int i = 0; i < W_ + 2 * P_; ++i) {
+        int n = i - P_;
+        n = n < 0 ? 0 : (n > W_ - 1 ? W_ - 1 : n);
+        for (int j = 0; j < 4; ++j) car[4 * (size_t)i + j] = car0[4 * (size_t)n + j];
+        car2[2 * (size_t)i] = car0[4 * (size_t)n];
+        car2[2 * (size_t)i + 1] = car0[4 * (size_t)n + 1];
     }
-    if (hipMalloc((void **)&p->carrier4, car.size() * sizeof(float)) != hipSuccess ||
-        hipMemcpy(p->carrier4, car.data(), car.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess ||
-        hipMalloc((void **)&p->carrier2, car2.size() * sizeof(float)) != hipSuccess ||
-        hipMemcpy(p->carrier2, car2.data(), car2.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) {
+    if (hipMalloc((void **)&p->carrier4_base, car.size() * sizeof(float)) != hipSuccess ||
+        hipMemcpy(p->carrier4_base, car.data(), car.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess ||
+        hipMalloc((void **)&p->carrier2_base, car2.size() * sizeof(float)) != hipSuccess ||
+        hipMemcpy(p->carrier2_base, car2.data(), car2.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) {
         cm_plan_destroy(p);
         return fail(CM_ERR_NO_DEVICE, "device allocation / upload of the carrier tables failed");
     }
+    p->carrier4 = p->carrier4_base + 4 * (size_t)P_;   // entry 0
+    p->carrier2 = p->carrier2_base + 2 * (size_t)P_;
     if (desc->frame_rotation) {
         const int n = desc->frame_rotation_cycle;
         const cm_lane_table *tabs[3] = {&desc->demod_main, &desc->demod_first, &desc->mod_main};
@@ -474,8 +514,8 @@ int cm_plan_create(const cm_plan_desc *desc, cm_plan **out) {
 
 void cm_plan_destroy(cm_plan *p) {
     if (!p) return;
-    if (p->carrier4) (void)hipFree(p->carrier4);
-    if (p->carrier2) (void)hipFree(p->carrier2);
+    if (p->carrier4_base) (void)hipFree(p->carrier4_base);
+    if (p->carrier2_base) (void)hipFree(p->carrier2_base);
     if (p->frame_rot) (void)hipFree(p->frame_rot);
     if (p->main.lanes) (void)hipFree(p->main.lanes);
     if (p->first.lanes) (void)hipFree(p->first.lanes);
@@ -703,7 +743,8 @@ extern "C" void cm_diag_set_buffer(unsigned long long *dev) { g_diag = dev; }
 
 int cm_plan_describe(const cm_plan *p, char *buf, int32_t buf_len) {
     if (!p || !buf || buf_len < 1) return 0;
-    int n = snprintf(buf, buf_len, "%s; lanes per workgroup 64, halo %d", p->main.name.c_str(), p->main.depth);
+    int n = snprintf(buf, buf_len, "%s; calls per workgroup 64 (%s), halo %d", p->main.name.c_str(),
+                     p->pair ? "two wavefronts: front end | detectors + back end" : "one wavefront", p->main.depth);
     return n < buf_len ? n : buf_len - 1;
 }
 

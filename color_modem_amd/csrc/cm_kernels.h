@@ -22,6 +22,7 @@
 #include <type_traits>
 
 #include "cm_stages.h"
+#include "cm_stages_pk.h"
 
 namespace cm {
 
@@ -85,6 +86,11 @@ __device__ __forceinline__ unsigned long long cm_stamp() {
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
     return t;
 }
+__device__ __forceinline__ unsigned long long cm_realtime() {   // 100 MHz reference
+    unsigned long long t;
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    return t;
+}
 #define CM_STAMP(var) unsigned long long var = cm_stamp()
 #define CM_ACC(acc, t0) acc += cm_stamp() - (t0)
 #else
@@ -111,6 +117,7 @@ typedef const __attribute__((address_space(4))) f16u const_f16;
 typedef __attribute__((address_space(3))) float lds_float;
 typedef __attribute__((address_space(3))) f4 lds_f4;
 constexpr int kInTile = 32;        // samples per input tile (one 128-byte line per row)
+constexpr int kCarrierPad = 128;   // entries before and after the carrier tables (copies of the first / last entry)
 constexpr int kLdsIn = 64 * kInTile;        // floats
 constexpr int kLdsRing = 16 * 64;           // floats (band-stop luma delay ring)
 
@@ -137,6 +144,9 @@ struct PassCfg {
     static constexpr int kLdsInF = U8_ ? 64 * kInTile / 4 : kLdsIn;            // floats: byte tiles are a quarter
     static constexpr int kLdsOut = U8_ ? 64 * 3 * TILE_ / 4 : 3 * 64 * TILE_;  // floats
     static constexpr int kLdsFloats = kLdsInF + kLdsOut + (BSF_ ? kLdsRing : 0);
+    // wave-pair kernels: 3 waves per SIMD need <= 168 VGPRs; the instances with more per-lane state in stage B (a second
+    // line of history, the notch, the second combination of minavg) would spill there and get 2 waves per SIMD instead
+    static constexpr int kPairWaves = (DEPTH_ >= 2 || NOTCH_ || MINAVG_) ? 2 : 3;
 };
 struct NoPass {
     static constexpr int kLdsFloats = 0;
@@ -272,9 +282,14 @@ __device__ __forceinline__ void flush_tile(const Geom &g, const lds_float *otile
             f4 v0 = *(const lds_f4 *)(otile + 0 * 64 * kTile + row * kTile + 4 * quad);
             f4 v1 = *(const lds_f4 *)(otile + 1 * 64 * kTile + row * kTile + 4 * quad);
             f4 v2 = *(const lds_f4 *)(otile + 2 * 64 * kTile + row * kTile + 4 * quad);
-            __builtin_nontemporal_store(v0, &dst[0]);
-            __builtin_nontemporal_store(v1, &dst[g.out_plane_stride >> 2]);
-            __builtin_nontemporal_store(v2, &dst[(2 * g.out_plane_stride) >> 2]);
+#ifdef CM_EXP_NO_STORE   /* timing experiment: results are not written */
+            if (v0.x == 12345.678f)
+#endif
+            {
+                __builtin_nontemporal_store(v0, &dst[0]);
+                __builtin_nontemporal_store(v1, &dst[g.out_plane_stride >> 2]);
+                __builtin_nontemporal_store(v2, &dst[(2 * g.out_plane_stride) >> 2]);
+            }
 #else
 #pragma nounroll
             for (int p = 0; p < 3; ++p) {
@@ -626,6 +641,378 @@ __device__ __forceinline__ void run_lane(const Geom &g, const DemodK<float, type
 #endif
 }
 
+// =============================================================================================
+// Wave-pair driver: one 128-thread workgroup = two wavefronts that walk the same 64 calls.
+//   wave 0 (stage A)  owns every global LOAD: the input tile and the luma source samples (second visit of the own or
+//                     the previous row), which it leaves in LDS for B; runs the front end up to the 2x-rate pair the
+//                     product detectors multiply (cm_stages.h: StageA); every 4 steps it leaves the 4 pairs of each
+//                     lane in an LDS ring
+//   wave 1 (stage B)  picks them up one block later: detectors, low-passes, decimators, comb combination, back end,
+//                     output tile and every global STORE.  vmcnt counts loads and stores of a wave in one queue, so a
+//                     wave that does both drains its stores each time it waits for a load (0.5 ms of 3.0 per 1000
+//                     frames, profiles/r01_pair_notes.md); B never waits on vmcnt
+// The halves keep 110-130 VGPRs each instead of 250 for the whole line, so 3-4 waves share a SIMD instead of 2 and
+// a wave that waits (LDS round trips, tile refills, flushes, scalar loads) no longer idles the vector pipe.
+// Synchronisation: the ring is double-buffered and both waves execute one s_barrier per block - A after writing
+// block i, B before reading it - so A runs at most one block ahead and B never reads a block that is not complete.
+// =============================================================================================
+constexpr int kMidRing = 2 * 2 * 64 * 4;    // floats: [buffer][even | odd][lane][4 steps]
+constexpr int kLumaRing2 = 32 * 64;         // floats: band-stop luma, written by A and read by B up to ~14 steps later
+
+constexpr int kLumaSlots = 2 * 64 * 4;      // floats: [buffer][lane][4 steps] luma source samples fetched by A for B
+
+template <class Cfg>
+struct PairLds {
+    static constexpr int kIn = Cfg::kLdsInF, kOut = Cfg::kLdsOut, kY = Cfg::BSF ? kLumaRing2 : kLumaSlots;
+    static constexpr int kFloats = kIn + kMidRing + kOut + kY;
+};
+template <>
+struct PairLds<NoPass> {
+    static constexpr int kFloats = 0;
+};
+
+#ifdef CM_DIAG
+// diagnostic builds: cycles spent waiting in the barrier are summed into acc
+#define PAIR_BARRIER(acc)                                                        \
+    do {                                                                         \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                       \
+        unsigned long long t0_ = cm_stamp();                                     \
+        asm volatile("s_barrier" ::: "memory");                                  \
+        acc += cm_stamp() - t0_;                                                 \
+    } while (0)
+#else
+#define PAIR_BARRIER(acc) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+#endif
+
+template <class Cfg>
+__device__ __forceinline__ void run_pair(const Geom &g, const DemodK<float, typename Cfg::S> &k_in, int block, lds_float *lds,
+                                         int role) {
+    typedef typename Cfg::S S;
+    typedef DemodK<float, S> K;
+    constexpr int FRONT = Cfg::FRONT, DEPTH = Cfg::DEPTH, kTile = Cfg::TILE, SP = S::SP;
+    constexpr bool BSF = Cfg::BSF, U8 = Cfg::U8, PALD = FRONT == FRONT_PALD;
+    typedef typename std::conditional<PALD, PalDFront<float, S>, QamFront<float, S, BSF>>::type Front;
+    typedef typename Front::StageA StageA;
+    typedef typename Front::StageB StageB;
+    typedef typename Front::VP VP;
+    typedef __attribute__((address_space(3))) unsigned char lds_u8;
+    typedef __attribute__((address_space(3))) unsigned lds_u32;
+
+    lds_float *itile = lds;
+    lds_float *ring = lds + PairLds<Cfg>::kIn;
+    lds_float *otile_base = ring + kMidRing;
+    lds_float *yring = otile_base + PairLds<Cfg>::kOut;
+
+    const int lane = threadIdx.x & 63;
+    const LaneCall lc = locate_call(g, block, DEPTH, lane);
+    const long long frame = lc.frame;
+    const int regime = lc.regime;
+
+    // ---- stream geometry (identical in both waves) ---------------------------------------------
+    K k = k_in;
+    const int W = g.W;
+    const int lat_front = Front::latency(k);
+    int lat_luma = 0;
+    if constexpr (!PALD) lat_luma = Front::luma_latency(k);
+    const int lat_out = lat_front + 1 + SP;     // n7 = t - lat_out
+    const int T = (W + lat_out + 3) & ~3;
+    const int front_off = StageA::pair_offset(k);   // detector pair index nd = t - front_off
+    int t_mid0 = (lat_out + 3) & ~3;           // every stage index >= 0 from here on
+    int t_mid1 = (W - 4) & ~3;                 // bodies below this never touch the end of the row
+    if (t_mid1 <= t_mid0) t_mid0 = t_mid1 = 0; // tiny rows: the guarded body runs everything
+
+#ifdef CM_DIAG
+    unsigned long long d_bar = 0, d_flush = 0, d_other = 0;
+    const unsigned long long d_begin = cm_stamp(), d_rbegin = cm_realtime();
+#endif
+    lds_float *lring = yring;   // luma hand-off slots share the place of the band-stop ring (the two exclude each other)
+
+    if (role == 0) {
+        // =================================== stage A ===========================================
+        const int luma_row = ((g.luma_prev_bits >> regime) & 1) ? lc.prev_row : lc.src_row;
+        const float *lp;
+        if (U8) lp = (const float *)((const unsigned char *)g.in + frame * g.in_frame_stride + (long long)luma_row * g.W);
+        else lp = g.in + frame * g.in_frame_stride + (long long)luma_row * g.W;
+        if (VP::VT) pin_block(k.taps);
+        if (VP::VB) pin_block(k.ext, false);
+        const float *xp;
+        if (U8) xp = (const float *)((const unsigned char *)g.in + frame * g.in_frame_stride + (long long)lc.src_row * g.W);
+        else xp = g.in + frame * g.in_frame_stride + (long long)lc.src_row * g.W;
+        StageA fa;
+        fa.reset();
+        float xw[14], ew[PALD ? 14 : 1];
+#pragma unroll
+        for (int j = 0; j < 14; ++j) xw[j] = 0.f;
+#pragma unroll
+        for (int j = 0; j < (PALD ? 14 : 1); ++j) ew[j] = 0.f;
+        if (BSF) {
+            for (int j = 0; j < 32; ++j) yring[j * 64 + lane] = 0.f;
+        }
+        const lds_float *xrow = itile + lane * kInTile;
+        auto read_x = [&](int first) -> f4 {  // x[first .. first + 3] from the input tile, zero outside the row
+            f4 v;
+            if (U8)
+                v = decode_bytes(*(const lds_u32 *)((const lds_u8 *)itile + lane * kInTile + (first & (kInTile - 1))));
+            else
+                v = *(const lds_f4 *)(xrow + (first & (kInTile - 1)));
+            if (first + 3 >= W) {
+                if (first >= W) v.x = 0.f;
+                if (first + 1 >= W) v.y = 0.f;
+                if (first + 2 >= W) v.z = 0.f;
+                if (first + 3 >= W) v.w = 0.f;
+            }
+            return v;
+        };
+        auto read_luma = [&](int first, bool check) -> f4 {  // x_l[first .. first + 3], zero outside the row
+            if (BSF) return f4{0.f, 0.f, 0.f, 0.f};
+    #ifdef CM_EXP_NO_LUMA   /* timing experiment */
+            return f4{0.1f, 0.2f, 0.3f, 0.4f};
+    #endif
+            if (U8) {
+                const unsigned char *lb = (const unsigned char *)lp;
+                if (!check || (first >= 0 && first + 3 < W)) {
+                    typedef unsigned u32u __attribute__((aligned(1)));
+                    return decode_bytes(*(const u32u *)(lb + first));
+                }
+                f4 r = {0.f, 0.f, 0.f, 0.f};
+                if (first + 3 >= 0 && first < W) {
+                    unsigned w = 0;
+                    if (first >= 0 && first < W) w |= lb[first];
+                    if (first + 1 >= 0 && first + 1 < W) w |= (unsigned)lb[first + 1] << 8;
+                    if (first + 2 >= 0 && first + 2 < W) w |= (unsigned)lb[first + 2] << 16;
+                    if (first + 3 >= 0 && first + 3 < W) w |= (unsigned)lb[first + 3] << 24;
+                    f4 d = decode_bytes(w);
+                    if (first >= 0 && first < W) r.x = d.x;
+                    if (first + 1 >= 0 && first + 1 < W) r.y = d.y;
+                    if (first + 2 >= 0 && first + 2 < W) r.z = d.z;
+                    if (first + 3 >= 0 && first + 3 < W) r.w = d.w;
+                }
+                return r;
+            }
+            if (!check || (first >= 0 && first + 3 < W)) {
+                f4u v = *(const f4u *)(lp + first);
+                return f4{v.x, v.y, v.z, v.w};
+            }
+            f4 r = {0.f, 0.f, 0.f, 0.f};
+            if (first + 3 >= 0 && first < W) {
+                if (first >= 0 && first < W) r.x = lp[first];
+                if (first + 1 >= 0 && first + 1 < W) r.y = lp[first + 1];
+                if (first + 2 >= 0 && first + 2 < W) r.z = lp[first + 2];
+                if (first + 3 >= 0 && first + 3 < W) r.w = lp[first + 3];
+            }
+            return r;
+        };
+        if (U8) fill_tile_u8(g, itile, xp, 0, lane); else fill_tile(g, itile, xp, 0, lane);
+        f4 lum_cur = read_luma(-lat_out, true);   // luma source of B's block 0
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        {
+            f4 x0 = read_x(0);
+            xw[10] = x0.x; xw[11] = x0.y; xw[12] = x0.z; xw[13] = x0.w;
+        }
+        auto sub_a = [&](auto sub_tag, auto edge_tag, FrontLatch<float> &fla, int tau, float &m_even, float &m_odd) {
+            constexpr int SUB = decltype(sub_tag)::value;
+            constexpr bool EDGE = decltype(edge_tag)::value;
+            Mid<float> m;
+            if constexpr (PALD) {
+                float e_out;
+                m = fa.template step<EDGE>(k, fla, tau, xw[10 + SUB], xw[SUB], ew[PALD ? SUB : 0], e_out);
+                ew[PALD ? 10 + SUB : 0] = e_out;
+            } else {
+                float luma_bsf = 0.f;
+                m = fa.template step<EDGE>(k, fla, tau, xw[10 + SUB], xw[SUB], luma_bsf);
+                if (BSF) yring[((tau - lat_luma) & 31) * 64 + lane] = luma_bsf;
+            }
+            m_even = m.even;
+            m_odd = m.odd;
+        };
+        auto body_a = [&](int tb, auto edge_tag, FrontLatch<float> &fla) {
+            constexpr bool EDGE_A = decltype(edge_tag)::value;
+            // luma source of B's next block: a whole body hides the latency
+            const f4 lum_next = read_luma(tb + 4 - lat_out, EDGE_A || tb + 4 >= t_mid1);
+            float me[4], mo[4];
+            sub_a(std::integral_constant<int, 0>(), edge_tag, fla, tb + 0, me[0], mo[0]);
+            sub_a(std::integral_constant<int, 1>(), edge_tag, fla, tb + 1, me[1], mo[1]);
+            sub_a(std::integral_constant<int, 2>(), edge_tag, fla, tb + 2, me[2], mo[2]);
+            sub_a(std::integral_constant<int, 3>(), edge_tag, fla, tb + 3, me[3], mo[3]);
+            const int nxt = tb + 4;
+#pragma unroll
+            for (int j = 0; j < 10; ++j) xw[j] = xw[j + 4];
+            if ((nxt & (kInTile - 1)) == 0 && nxt < W) {  // first read of a new tile: its fill was issued a body ago
+                CM_STAMP(t0);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_wave_barrier();
+                CM_ACC(d_other, t0);
+            }
+            {
+                f4 xn = read_x(nxt);
+                xw[10] = xn.x; xw[11] = xn.y; xw[12] = xn.z; xw[13] = xn.w;
+            }
+            if ((nxt & (kInTile - 1)) == kInTile - 4 && nxt + 4 < W) {  // that was the last read of this tile: refill it
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_wave_barrier();
+                if (U8) fill_tile_u8(g, itile, xp, (nxt >> 5) + 1, lane); else fill_tile(g, itile, xp, (nxt >> 5) + 1, lane);
+            }
+            if (PALD) {
+#pragma unroll
+                for (int j = 0; j < 10; ++j) ew[PALD ? j : 0] = ew[PALD ? j + 4 : 0];
+            }
+            lds_float *slot = ring + ((tb >> 2) & 1) * (kMidRing / 2) + lane * 4;
+            *(lds_f4 *)slot = f4{me[0], me[1], me[2], me[3]};
+            *(lds_f4 *)(slot + 256) = f4{mo[0], mo[1], mo[2], mo[3]};
+            if (!BSF) *(lds_f4 *)(lring + ((tb >> 2) & 1) * (kLumaSlots / 2) + lane * 4) = lum_cur;
+            lum_cur = lum_next;
+            PAIR_BARRIER(d_bar);
+        };
+        int tb = 0;
+        {
+            FrontLatch<float> fla;
+            fla.reset();
+            for (; tb < t_mid0; tb += 4) body_a(tb, std::true_type(), fla);
+            for (; tb < t_mid1; tb += 4) body_a(tb, std::false_type(), fla);
+        }
+        FrontLatch<float> fla;
+        fla.reset();
+        for (; tb < T; tb += 4) body_a(tb, std::true_type(), fla);
+#ifdef CM_DIAG
+        if (g.diag && lane == 0 && !g.sparse) {
+            unsigned long long *d = g.diag + 16ull * block;
+            d[0] = cm_stamp() - d_begin; d[1] = d_bar; d[2] = d_other;
+        }
+#endif
+        return;
+    }
+
+    // ======================================= stage B ===========================================
+    // packed float32 throughout (cm_stages_pk.h): pairs (cos, sin) up to the base pair, (u, v) behind it
+    StageBK<S> kb;
+    kb.load(k);
+    const float *op;   // U8: strides count bytes; the pointer is carried as an opaque 64-bit value
+    if (U8) op = lc.store_ok ? (const float *)((unsigned char *)g.out + frame * g.out_frame_stride + (long long)lc.out_row * g.out_row_stride)
+                             : nullptr;
+    else op = lc.store_ok ? g.out + frame * g.out_frame_stride + (long long)lc.out_row * g.out_row_stride : nullptr;
+    LaneKPk lk;
+    {
+        int fmod = (int)((g.first_frame + frame) % g.cycle);
+        LaneK<float> l1 = g.lanes[((long long)fmod * 3 + regime) * g.n_lines + lc.line];
+        apply_frame_rotation(g, frame, l1);
+        lk.load(l1, DEPTH, Cfg::MINAVG);
+    }
+    const int idx1 = ((lane + 63) & 63) * 4, idx2 = ((lane + 62) & 63) * 4;
+    DetectorPk<S> det;
+    DemodBackPk<S, DEPTH, Cfg::NOTCH, Cfg::MINAVG> back;
+    det.reset();
+    back.reset();
+    pf2 base_prev = {0.f, 0.f}, b1_prev = {0.f, 0.f}, b2_prev = {0.f, 0.f};
+    pf2 uvd[SP > 0 ? SP : 1];   // (u, v) of the last SP steps (newest first)
+#pragma unroll
+    for (int j = 0; j < (SP > 0 ? SP : 1); ++j) uvd[j] = pf2{0.f, 0.f};
+    // output tile address of this lane's row: row * 16 + (column ^ quad swizzle)
+    lds_float *otile = U8 ? (lds_float *)((lds_u8 *)otile_base + lane * 3 * kTile) : otile_base + lane * kTile;
+    const int wpos = ((lane >> 1) & (kTile / 4 - 1)) << 2;
+
+
+    // Carriers of one body, fetched a body ahead (the tables are padded, so no index needs a clamp):
+    //   c4[0 .. 15] = {C, S}(2 nd), {C, S}(2 nd + 1) for the four detector pairs nd = tb - front_off + sub
+    //   c2[0 .. 7]  = {C, S}(2 n7) for the four back-end samples n7 = tb - lat_out + sub
+    auto load_c4 = [&](int tb) -> f16u { return *(const_f16 *)(g.carrier4 + 4 * (long long)(tb - front_off)); };
+    auto load_c2 = [&](int tb) -> f8u { return *(const_f8 *)(g.carrier2 + 2 * (long long)(tb - lat_out)); };
+    const int s_flush = (lat_out + 3) & 3;
+    auto maybe_flush = [&](int t) {
+        const int n7 = t - lat_out;
+        if (n7 >= 0 && ((n7 & (kTile - 1)) == kTile - 1 || n7 == W - 1)) {
+            CM_STAMP(t0);
+            if (U8) flush_tile_u8(g, otile_base, op, n7 & ~(kTile - 1), lane);
+            else flush_tile<kTile>(g, otile_base, op, n7 & ~(kTile - 1), lane);
+            CM_ACC(d_flush, t0);
+        }
+    };
+    f4 lw;
+    // p_e, p_o: detector products of this step's pair; sc: (sn, cs) of the back-end sample
+    auto sub_b = [&](auto sub_tag, auto edge_tag, pf2 &p_last, pf2 &uv_last, int tau, pf2 p_e, pf2 p_o, pf2 sc) {
+        constexpr int SUB = decltype(sub_tag)::value;
+        constexpr bool EDGE = decltype(edge_tag)::value;
+        pf2 base = det.template step<EDGE>(k, kb, p_last, tau - front_off, p_e, p_o);
+        // the back end handles the PREVIOUS step's base pair: its neighbours were requested then
+        const int n6 = tau - lat_front - 1, n7 = n6 - SP;
+        pf2 uv = back.combine(lk, base_prev, b1_prev, b2_prev);
+        base_prev = base;
+        if (DEPTH >= 1) b1_prev = pf2{lane_from(idx1, base.x), lane_from(idx1, base.y)};
+        if (DEPTH >= 2) b2_prev = pf2{lane_from(idx2, base.x), lane_from(idx2, base.y)};
+        float y_src;
+        if (BSF) y_src = yring[(n7 & 31) * 64 + lane];
+        else y_src = SUB == 0 ? lw.x : (SUB == 1 ? lw.y : (SUB == 2 ? lw.z : lw.w));
+        const pf2 uv_d = SP > 0 ? uvd[SP > 0 ? SP - 1 : 0] : uv;
+        Rgb<float> o = back.template step<EDGE>(k, kb, lk, uv_last, n6, uv, uv_d, y_src, sc);
+#pragma unroll
+        for (int j = SP - 1; j > 0; --j) uvd[j] = uvd[j - 1];
+        if (SP > 0) uvd[0] = uv;
+        if (!EDGE || (n7 >= 0 && n7 < W)) {
+            if constexpr (U8) {
+                // image.py:7-8: uint8(rint(255 * clip(x, 0, 1))); bytes interleaved R, G, B, 48 per tile row
+                lds_u8 *tbp = (lds_u8 *)otile + 3 * (n7 & (kTile - 1));   // otile: this lane's 48-byte row
+                tbp[0] = (unsigned char)__builtin_rintf(255.f * __builtin_fminf(__builtin_fmaxf(o.r, 0.f), 1.f));
+                tbp[1] = (unsigned char)__builtin_rintf(255.f * __builtin_fminf(__builtin_fmaxf(o.g, 0.f), 1.f));
+                tbp[2] = (unsigned char)__builtin_rintf(255.f * __builtin_fminf(__builtin_fmaxf(o.b, 0.f), 1.f));
+            } else {
+                lds_float *tp = otile + (wpos ^ (n7 & (kTile - 1)));
+                tp[0] = o.r;
+                tp[64 * kTile] = o.g;
+                tp[2 * 64 * kTile] = o.b;
+            }
+        }
+    };
+    // the first block of the ring and the first body's carriers
+    PAIR_BARRIER(d_bar);
+    f4 me = *(const lds_f4 *)(ring + lane * 4);
+    f4 mo = *(const lds_f4 *)(ring + lane * 4 + 256);
+    f16u c4 = load_c4(0);
+    f8u c2 = load_c2(0);
+    auto body_b = [&](int tb, auto edge_tag, pf2 &p_last, pf2 &uv_last) {
+        constexpr bool EDGE = decltype(edge_tag)::value;
+        const int nxt = tb + 4;
+        if (!BSF) lw = *(const lds_f4 *)(lring + ((tb >> 2) & 1) * (kLumaSlots / 2) + lane * 4);   // left there by A
+        // first half: detector products and re-modulation carriers of sub-steps 0, 1
+        pf2 pe0 = pk_mul_bs<0>(pf2{me.x, me.y}, pf2{c4[0], c4[1]}), po0 = pk_mul_bs<0>(pf2{mo.x, mo.y}, pf2{c4[2], c4[3]});
+        pf2 pe1 = pk_mul_bs<1>(pf2{me.x, me.y}, pf2{c4[4], c4[5]}), po1 = pk_mul_bs<1>(pf2{mo.x, mo.y}, pf2{c4[6], c4[7]});
+        pf2 sc0 = back.remod(lk, pf2{c2[0], c2[1]}), sc1 = back.remod(lk, pf2{c2[2], c2[3]});
+        sub_b(std::integral_constant<int, 0>(), edge_tag, p_last, uv_last, tb + 0, pe0, po0, sc0);
+        if (s_flush == 0) maybe_flush(tb + 0);
+        sub_b(std::integral_constant<int, 1>(), edge_tag, p_last, uv_last, tb + 1, pe1, po1, sc1);
+        if (s_flush == 1) maybe_flush(tb + 1);
+        // second half; once its products are formed this block and its carriers are dead: fetch the next ones
+        pf2 pe2 = pk_mul_bs<0>(pf2{me.z, me.w}, pf2{c4[8], c4[9]}), po2 = pk_mul_bs<0>(pf2{mo.z, mo.w}, pf2{c4[10], c4[11]});
+        pf2 pe3 = pk_mul_bs<1>(pf2{me.z, me.w}, pf2{c4[12], c4[13]}), po3 = pk_mul_bs<1>(pf2{mo.z, mo.w}, pf2{c4[14], c4[15]});
+        pf2 sc2 = back.remod(lk, pf2{c2[4], c2[5]}), sc3 = back.remod(lk, pf2{c2[6], c2[7]});
+        if (nxt < T) {
+            PAIR_BARRIER(d_bar);   // block nxt / 4 of the ring is complete
+            const lds_float *slot = ring + ((nxt >> 2) & 1) * (kMidRing / 2) + lane * 4;
+            me = *(const lds_f4 *)slot;
+            mo = *(const lds_f4 *)(slot + 256);
+            c4 = load_c4(nxt);
+            c2 = load_c2(nxt);
+        }
+        sub_b(std::integral_constant<int, 2>(), edge_tag, p_last, uv_last, tb + 2, pe2, po2, sc2);
+        if (s_flush == 2) maybe_flush(tb + 2);
+        sub_b(std::integral_constant<int, 3>(), edge_tag, p_last, uv_last, tb + 3, pe3, po3, sc3);
+        if (s_flush == 3) maybe_flush(tb + 3);
+    };
+    int tb = 0;
+    {
+        pf2 p_last = {0.f, 0.f}, uv_last = {0.f, 0.f};
+        for (; tb < t_mid0; tb += 4) body_b(tb, std::true_type(), p_last, uv_last);
+        for (; tb < t_mid1; tb += 4) body_b(tb, std::false_type(), p_last, uv_last);
+    }
+    pf2 p_last = {0.f, 0.f}, uv_last = {0.f, 0.f};
+    for (; tb < T; tb += 4) body_b(tb, std::true_type(), p_last, uv_last);
+#ifdef CM_DIAG
+    if (g.diag && lane == 0 && !g.sparse) {
+        unsigned long long *d = g.diag + 16ull * block + 8;
+        d[0] = cm_stamp() - d_begin; d[1] = d_bar; d[2] = d_flush; d[3] = cm_realtime() - d_rbegin;
+    }
+#endif
+}
+
 template <class S>
 struct PassArgs {
     Geom g;
@@ -646,6 +1033,37 @@ __global__ __launch_bounds__(64, 2) void demod_kernel(const PassArgs<typename Ma
         }
     }
     run_lane<Main>(main_args.g, main_args.k, (int)blockIdx.x - n_first, lds);
+}
+
+#ifndef CM_PAIR_WAVES_PER_SIMD
+#define CM_PAIR_WAVES_PER_SIMD Main::kPairWaves
+#endif
+// Wave-pair variant: 128 threads, wave 0 = stage A, wave 1 = stage B of the same 64 calls.
+template <class Main, class First>
+__global__ __launch_bounds__(128, CM_PAIR_WAVES_PER_SIMD) void demod_pair_kernel(const PassArgs<typename Main::S> main_args,
+                                                                                 const PassArgs<typename Main::S> first_args,
+                                                                                 const int n_first) {
+    constexpr int kFloats = PairLds<Main>::kFloats > PairLds<First>::kFloats ? PairLds<Main>::kFloats : PairLds<First>::kFloats;
+    __shared__ __attribute__((aligned(16))) float lds_store[kFloats];
+    lds_float *lds = (lds_float *)lds_store;
+#ifdef CM_DEV_ROLE   /* register-pressure experiments: compile one stage only (the result does not run) */
+    const int role = CM_DEV_ROLE;
+#else
+    const int role = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+#endif
+#ifdef CM_EXP_STAGGER   /* experiment: de-phase the workgroups' flushes */
+    {
+        const int ph = (int)(blockIdx.x >> 3) & 3;
+        for (int i = 0; i < ph; ++i) __builtin_amdgcn_s_sleep(CM_EXP_STAGGER);
+    }
+#endif
+    if constexpr (!std::is_same<First, NoPass>::value) {
+        if ((int)blockIdx.x < n_first) {
+            run_pair<First>(first_args.g, first_args.k, blockIdx.x, lds, role);
+            return;
+        }
+    }
+    run_pair<Main>(main_args.g, main_args.k, (int)blockIdx.x - n_first, lds, role);
 }
 
 }  // namespace cm

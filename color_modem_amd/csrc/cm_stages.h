@@ -275,74 +275,44 @@ struct DemodK {
 };
 
 // =============================================================================================
-// PAL-D front end: x -> E = dn2(BPF(up2 x)) -> up2 -> * {sin, cos}(theta + k cps) -> LPF -> dn2
-// (ref pal.py:71-77 applied to ref qam.py:34-37), producing the line's own base pair
-// (Ps, Pc)[n].  Gains (band-pass, low-pass, the two 1/2 of the decimators) are NOT applied
-// here; the host folds them into LaneK::cu/cv.
-//
-// Stream indices at step t (one 1x sample per step):
-//   n1 = t - 10        pair A(n1) = up2(x)[2 n1, 2 n1 + 1]
-//   n2 = n1 - q_e      pair B(n2) = BPF output
-//   n3 = n2 - 9        e[n3]
-//   n4 = n3 - 10       pair U(n4) = up2(e)
-//   n5 = n4 - q_l      pair Q(n5) = LPF output (two paths)
-//   n6 = n5 - 9        (Ps, Pc)[n6]
+// The front ends are cut in two stages at a 2x-rate sample pair (Mid), so that a kernel can give each
+// stage to a wavefront of its own (cm_kernels.h, "wave pair") and hand the pair over through LDS:
+//   stage A (per front end)  x -> ... -> the pair the product detectors multiply
+//   stage B (Detector)       pair * {sin, cos}(m cps) -> LPF -> dn2 = the line's base pair
+// The one-wave composition (PalDFront / QamFront::step) is what tests/sim runs on the host.
 // =============================================================================================
-template <typename T, class S>
-struct PalDFront {
+template <typename T>
+struct Mid {
+    T even, odd;
+};
+
+// Stage B of both front ends (ref qam.py:47-54 / pal.py:73-77): product detectors against the phase-free
+// carriers sin / cos(m cps), m = 2 nd, 2 nd + 1, the detector low-pass with FilterFunction edge handling, dn2.
+// nd = index of the incoming pair; the line's detector phase is a rotation of the resulting pair and lives in
+// LaneK::cu / cv.  car = {C[2 nd], S[2 nd], C[2 nd + 1], S[2 nd + 1]}.
+template <typename T, class S, class VP>
+struct Detector {
     typedef DemodK<T, S> K;
-    typedef VPolicy<CM_V_PALD> VP;
-    static constexpr bool ODD_E = S::ODD_E, ODD_L = S::ODD_L;
-    HalfbandChain<T> up_x, dn_e, up_e, dn_s, dn_c;
-    IirState<T, S::NE> bpf;
+    static constexpr bool ODD_L = S::ODD_L;
+    HalfbandChain<T> dn_s, dn_c;
     IirState<T, S::NL> lpf_s, lpf_c;
-    T hold_b, hold_s, hold_c;   // previous odd outputs for odd shifts (as in QamFront)
+    T hold_s, hold_c;   // previous odd outputs for an odd shift
 
     CM_HD void reset() {
-        up_x.reset(); dn_e.reset(); up_e.reset(); dn_s.reset(); dn_c.reset();
-        bpf.reset(); lpf_s.reset(); lpf_c.reset();
-        hold_b = hold_s = hold_c = T(0);
+        dn_s.reset(); dn_c.reset(); lpf_s.reset(); lpf_c.reset();
+        hold_s = hold_c = T(0);
     }
-    CM_HD static int latency(const K &k) { return 10 + k.q_e + 9 + 10 + k.q_l + 9; }
-
-    // x_now = x[t] (0 beyond the row), x_d10 = x[t - 10], e_d10 = e[n3 - 10] (from the caller's
-    // delay window), car = {C[2 n4], S[2 n4], C[2 n4 + 1], S[2 n4 + 1]} (cos/sin of m * cps).
-    // Returns e[n3] through e_out (caller stores it in its window) and the base pair.
     template <bool EDGE>
-    CM_HD Pair<T> step(const K &k, FrontLatch<T> &la, int t, T x_now, T x_d10, T e_d10, const T car[4], T &e_out) {
+    CM_HD Pair<T> step(const K &k, FrontLatch<T> &la, int nd, const Mid<T> &m, const T car[4]) {
         const int W = k.width;
-        const int n1 = t - 10, n2 = n1 - k.q_e, n3 = n2 - 9, n4 = n3 - 10, n5 = n4 - k.q_l;
-        // --- up2(x)
-        T a_odd = up_x.template push<VP::VT>(k.taps, x_now);
-        T a_even = k.taps.c0 * x_d10;
-        // --- band-pass at 2x rate with FilterFunction edge handling
-        T b_even = T(0), b_odd = T(0);
-        if (!EDGE || (n1 >= 0 && n1 < W + k.q_e)) {
-            if (EDGE) {
-                if (n1 == W - 1) la.a_last = a_odd;
-                if (n1 >= W) a_even = a_odd = la.a_last;
-            }
-            T y0 = iir_bp<VP::VB>(bpf, k.ext, a_even);
-            T y1 = iir_bp<VP::VB>(bpf, k.ext, a_odd);
-            if (ODD_E) { b_even = hold_b; b_odd = y0; hold_b = y1; } else { b_even = y0; b_odd = y1; }
-        }
-        if (EDGE && (n2 < 0 || n2 >= W)) b_even = b_odd = T(0);
-        // --- dn2 -> e[n3]
-        T e = dn_e.template push_pair<VP::VT>(k.taps, b_even, b_odd);
-        if (EDGE && (n3 < 0 || n3 >= W)) e = T(0);
-        e_out = e;
-        // --- up2(e)
-        T u_odd = up_e.template push<VP::VT>(k.taps, e);
-        T u_even = k.taps.c0 * e_d10;
-        // --- product detectors against the phase-free carriers sin / cos(m cps), m = 2 n4, 2 n4 + 1; the
-        //     line's detector phase is a rotation of the resulting pair and lives in LaneK::cu / cv
-        T ps_e = u_even * car[1], pc_e = u_even * car[0];
-        T ps_o = u_odd * car[3], pc_o = u_odd * car[2];
+        const int n5 = nd - k.q_l;
+        T ps_e = m.even * car[1], pc_e = m.even * car[0];
+        T ps_o = m.odd * car[3], pc_o = m.odd * car[2];
         T qs_e = T(0), qs_o = T(0), qc_e = T(0), qc_o = T(0);
-        if (!EDGE || (n4 >= 0 && n4 < W + k.q_l)) {
+        if (!EDGE || (nd >= 0 && nd < W + k.q_l)) {
             if (EDGE) {
-                if (n4 == W - 1) { la.ps_last = ps_o; la.pc_last = pc_o; }
-                if (n4 >= W) { ps_e = ps_o = la.ps_last; pc_e = pc_o = la.pc_last; }
+                if (nd == W - 1) { la.ps_last = ps_o; la.pc_last = pc_o; }
+                if (nd >= W) { ps_e = ps_o = la.ps_last; pc_e = pc_o = la.pc_last; }
             }
             T s0 = iir_sym<VP::VL>(lpf_s, k.lpf, ps_e);
             T s1 = iir_sym<VP::VL>(lpf_s, k.lpf, ps_o);
@@ -364,36 +334,115 @@ struct PalDFront {
 };
 
 // =============================================================================================
+// PAL-D front end: x -> E = dn2(BPF(up2 x)) -> up2 -> * {sin, cos}(theta + k cps) -> LPF -> dn2
+// (ref pal.py:71-77 applied to ref qam.py:34-37), producing the line's own base pair
+// (Ps, Pc)[n].  Gains (band-pass, low-pass, the two 1/2 of the decimators) are NOT applied
+// here; the host folds them into LaneK::cu/cv.
+//
+// Stream indices at step t (one 1x sample per step):
+//   n1 = t - 10        pair A(n1) = up2(x)[2 n1, 2 n1 + 1]
+//   n2 = n1 - q_e      pair B(n2) = BPF output
+//   n3 = n2 - 9        e[n3]
+//   n4 = n3 - 10       pair U(n4) = up2(e)                      <- stage A ends here
+//   n5 = n4 - q_l      pair Q(n5) = LPF output (two paths)
+//   n6 = n5 - 9        (Ps, Pc)[n6]
+// =============================================================================================
+template <typename T, class S>
+struct PalDFrontA {
+    typedef DemodK<T, S> K;
+    typedef VPolicy<CM_V_PALD> VP;
+    static constexpr bool ODD_E = S::ODD_E;
+    HalfbandChain<T> up_x, dn_e, up_e;
+    IirState<T, S::NE> bpf;
+    T hold_b;
+
+    CM_HD void reset() {
+        up_x.reset(); dn_e.reset(); up_e.reset(); bpf.reset();
+        hold_b = T(0);
+    }
+    CM_HD static int pair_offset(const K &k) { return 10 + k.q_e + 9 + 10; }   // nd = t - pair_offset
+
+    // x_now = x[t] (0 beyond the row), x_d10 = x[t - 10], e_d10 = e[n3 - 10] (from the caller's
+    // delay window).  Returns e[n3] through e_out (caller stores it in its window) and the pair U(n4).
+    template <bool EDGE>
+    CM_HD Mid<T> step(const K &k, FrontLatch<T> &la, int t, T x_now, T x_d10, T e_d10, T &e_out) {
+        const int W = k.width;
+        const int n1 = t - 10, n2 = n1 - k.q_e, n3 = n2 - 9;
+        // --- up2(x)
+        T a_odd = up_x.template push<VP::VT>(k.taps, x_now);
+        T a_even = k.taps.c0 * x_d10;
+        // --- band-pass at 2x rate with FilterFunction edge handling
+        T b_even = T(0), b_odd = T(0);
+        if (!EDGE || (n1 >= 0 && n1 < W + k.q_e)) {
+            if (EDGE) {
+                if (n1 == W - 1) la.a_last = a_odd;
+                if (n1 >= W) a_even = a_odd = la.a_last;
+            }
+            T y0 = iir_bp<VP::VB>(bpf, k.ext, a_even);
+            T y1 = iir_bp<VP::VB>(bpf, k.ext, a_odd);
+            if (ODD_E) { b_even = hold_b; b_odd = y0; hold_b = y1; } else { b_even = y0; b_odd = y1; }
+        }
+        if (EDGE && (n2 < 0 || n2 >= W)) b_even = b_odd = T(0);
+        // --- dn2 -> e[n3]
+        T e = dn_e.template push_pair<VP::VT>(k.taps, b_even, b_odd);
+        if (EDGE && (n3 < 0 || n3 >= W)) e = T(0);
+        e_out = e;
+        // --- up2(e)
+        Mid<T> m;
+        m.odd = up_e.template push<VP::VT>(k.taps, e);
+        m.even = k.taps.c0 * e_d10;
+        return m;
+    }
+};
+
+template <typename T, class S>
+struct PalDFront {
+    typedef DemodK<T, S> K;
+    typedef VPolicy<CM_V_PALD> VP;
+    typedef PalDFrontA<T, S> StageA;
+    typedef Detector<T, S, VP> StageB;
+    StageA a;
+    StageB b;
+
+    CM_HD void reset() { a.reset(); b.reset(); }
+    CM_HD static int latency(const K &k) { return 10 + k.q_e + 9 + 10 + k.q_l + 9; }
+
+    // car = {C[2 n4], S[2 n4], C[2 n4 + 1], S[2 n4 + 1]} (cos/sin of m * cps)
+    template <bool EDGE>
+    CM_HD Pair<T> step(const K &k, FrontLatch<T> &la, int t, T x_now, T x_d10, T e_d10, const T car[4], T &e_out) {
+        Mid<T> m = a.template step<EDGE>(k, la, t, x_now, x_d10, e_d10, e_out);
+        return b.template step<EDGE>(k, la, t - StageA::pair_offset(k), m, car);
+    }
+};
+
+// =============================================================================================
 // QAM front end (ref qam.py:43-58): x -> up2 -> BPF -> * {2 sin, 2 cos}(theta + k cps) -> LPF
 // -> dn2 = base pair (Bs, Bc)[n]; optionally the band-stop luma dn2(BSF(up2 x)).
 // The factor 2 of the detector and all filter gains are folded into LaneK by the host.
-//   n1 = t - 10 ; n2 = n1 - q_e ; n5 = n2 - q_l ; n6 = n5 - 9 ; luma: nr = n1 - q_r, nl = nr - 9
+//   n1 = t - 10 ; n2 = n1 - q_e (stage A ends) ; n5 = n2 - q_l ; n6 = n5 - 9 ; luma: nr = n1 - q_r, nl = nr - 9
 // ODD_x: the corresponding FilterFunction shift is odd, i.e. output pairs straddle input pairs.
 // =============================================================================================
 template <typename T, class S, bool WITH_BSF>
-struct QamFront {
+struct QamFrontA {
     typedef DemodK<T, S> K;
     typedef VPolicy<CM_V_QAM> VP;
-    static constexpr bool ODD_E = S::ODD_E, ODD_L = S::ODD_L, ODD_R = S::ODD_R;
-    HalfbandChain<T> up_x, dn_s, dn_c, dn_y;
+    static constexpr bool ODD_E = S::ODD_E, ODD_R = S::ODD_R;
+    HalfbandChain<T> up_x, dn_y;
     IirState<T, S::NE> bpf;
-    IirState<T, S::NL> lpf_s, lpf_c;
     IirState<T, S::NR> bsf;
-    T hold_b, hold_s, hold_c, hold_y;  // previous odd outputs for odd shifts
+    T hold_b, hold_y;  // previous odd outputs for odd shifts
 
     CM_HD void reset() {
-        up_x.reset(); dn_s.reset(); dn_c.reset(); dn_y.reset();
-        bpf.reset(); lpf_s.reset(); lpf_c.reset(); bsf.reset();
-        hold_b = hold_s = hold_c = hold_y = T(0);
+        up_x.reset(); dn_y.reset(); bpf.reset(); bsf.reset();
+        hold_b = hold_y = T(0);
     }
-    CM_HD static int latency(const K &k) { return 10 + k.q_e + k.q_l + 9; }
+    CM_HD static int pair_offset(const K &k) { return 10 + k.q_e; }
     CM_HD static int luma_latency(const K &k) { return 10 + k.q_r + 9; }
 
-    // car = {C[2 n2], S[2 n2], C[2 n2 + 1], S[2 n2 + 1]}
     template <bool EDGE>
-    CM_HD Pair<T> step(const K &k, FrontLatch<T> &la, int t, T x_now, T x_d10, const T car[4], T &luma_out) {
+    CM_HD Mid<T> step(const K &k, FrontLatch<T> &la, int t, T x_now, T x_d10, T &luma_out) {
         const int W = k.width;
-        const int n1 = t - 10, n2 = n1 - k.q_e, n5 = n2 - k.q_l;
+        const int n1 = t - 10;
         T a_odd = up_x.template push<VP::VT>(k.taps, x_now);
         T a_even = k.taps.c0 * x_d10;
         if (EDGE) {
@@ -401,13 +450,14 @@ struct QamFront {
             if (n1 >= W) a_even = a_odd = la.a_last;
         }
         // --- chroma band-pass
-        T b_even = T(0), b_odd = T(0);
+        Mid<T> m;
+        m.even = m.odd = T(0);
         if (!EDGE || (n1 >= 0 && n1 < W + k.q_e)) {
             T y0 = iir_bp<VP::VB>(bpf, k.ext, a_even);
             T y1 = iir_bp<VP::VB>(bpf, k.ext, a_odd);
-            if (ODD_E) { b_even = hold_b; b_odd = y0; hold_b = y1; } else { b_even = y0; b_odd = y1; }
+            if (ODD_E) { m.even = hold_b; m.odd = y0; hold_b = y1; } else { m.even = y0; m.odd = y1; }
         }
-        // (band-pass output outside [0, 2W) is never used: the detector below is gated on n2)
+        // (band-pass output outside [0, 2W) is never used: the detector is gated on n2)
         // --- luma band-stop (ref qam.py:57)
         if (WITH_BSF) {
             const int nr = n1 - k.q_r;
@@ -420,31 +470,28 @@ struct QamFront {
             if (EDGE && (nr < 0 || nr >= W)) r_even = r_odd = T(0);
             luma_out = dn_y.template push_pair<VP::VT>(k.taps, r_even, r_odd) * k.luma_gain;
         }
-        // --- product detectors at 2x rate against the phase-free carriers, m = 2 n2, 2 n2 + 1
-        T ps_e = b_even * car[1], pc_e = b_even * car[0];
-        T ps_o = b_odd * car[3], pc_o = b_odd * car[2];
-        T qs_e = T(0), qs_o = T(0), qc_e = T(0), qc_o = T(0);
-        if (!EDGE || (n2 >= 0 && n2 < W + k.q_l)) {
-            if (EDGE) {
-                if (n2 == W - 1) { la.ps_last = ps_o; la.pc_last = pc_o; }
-                if (n2 >= W) { ps_e = ps_o = la.ps_last; pc_e = pc_o = la.pc_last; }
-            }
-            T s0 = iir_sym<VP::VL>(lpf_s, k.lpf, ps_e);
-            T s1 = iir_sym<VP::VL>(lpf_s, k.lpf, ps_o);
-            T c0 = iir_sym<VP::VL>(lpf_c, k.lpf, pc_e);
-            T c1 = iir_sym<VP::VL>(lpf_c, k.lpf, pc_o);
-            if (ODD_L) {
-                qs_e = hold_s; qs_o = s0; hold_s = s1;
-                qc_e = hold_c; qc_o = c0; hold_c = c1;
-            } else {
-                qs_e = s0; qs_o = s1; qc_e = c0; qc_o = c1;
-            }
-        }
-        if (EDGE && (n5 < 0 || n5 >= W)) qs_e = qs_o = qc_e = qc_o = T(0);
-        Pair<T> out;
-        out.s = dn_s.template push_pair<VP::VT>(k.taps, qs_e, qs_o);
-        out.c = dn_c.template push_pair<VP::VT>(k.taps, qc_e, qc_o);
-        return out;
+        return m;
+    }
+};
+
+template <typename T, class S, bool WITH_BSF>
+struct QamFront {
+    typedef DemodK<T, S> K;
+    typedef VPolicy<CM_V_QAM> VP;
+    typedef QamFrontA<T, S, WITH_BSF> StageA;
+    typedef Detector<T, S, VP> StageB;
+    StageA a;
+    StageB b;
+
+    CM_HD void reset() { a.reset(); b.reset(); }
+    CM_HD static int latency(const K &k) { return 10 + k.q_e + k.q_l + 9; }
+    CM_HD static int luma_latency(const K &k) { return StageA::luma_latency(k); }
+
+    // car = {C[2 n2], S[2 n2], C[2 n2 + 1], S[2 n2 + 1]}
+    template <bool EDGE>
+    CM_HD Pair<T> step(const K &k, FrontLatch<T> &la, int t, T x_now, T x_d10, const T car[4], T &luma_out) {
+        Mid<T> m = a.template step<EDGE>(k, la, t, x_now, x_d10, luma_out);
+        return b.template step<EDGE>(k, la, t - StageA::pair_offset(k), m, car);
     }
 };
 

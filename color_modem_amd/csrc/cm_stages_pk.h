@@ -1,0 +1,422 @@
+// cm_stages_pk.h - stage B of the QAM-family demodulators in packed float32 (device only, gfx950).
+//
+// Everything behind the product detectors runs on PAIRS of signals that share their coefficients: the two detector
+// channels (cos, sin) through the low-pass and the decimator, (u, v) through the comb combination, the
+// pre-correction low-pass and the colour matrix.  v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 process such a pair in
+// one instruction: the arithmetic per pixel is unchanged, but a wavefront issues ~60 instructions per pixel less,
+// and at the 3 waves per SIMD of the wave-pair kernels (cm_kernels.h) instruction issue, not the vector pipe, is what
+// a wave runs out of (profiles/r01_pair_notes.md).
+//
+// Pair layout: lane .x = cos channel / u, lane .y = sin channel / v.  Coefficients are wave-uniform; two of them
+// share a VGPR pair and the instruction's op_sel bits pick the half (no register is spent on duplicates).
+// The scalar templates of cm_stages.h stay the definition of the arithmetic (tests/sim runs them on the host); the
+// forms here perform the same operations in the same order, two at a time.
+#ifndef CM_STAGES_PK_H
+#define CM_STAGES_PK_H
+
+#include "cm_stages.h"
+
+#if defined(__HIP_DEVICE_COMPILE__) || defined(__HIPCC__)
+namespace cm {
+
+typedef float pf2 __attribute__((ext_vector_type(2)));
+
+// d = c[H] * x + acc
+template <int H>
+__device__ __forceinline__ pf2 pk_fma_c(pf2 c, pf2 x, pf2 acc) {
+    pf2 d;
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (H == 0) asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[0,1,1]" : "=v"(d) : "v"(c), "v"(x), "v"(acc));
+    else asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "=v"(d) : "v"(c), "v"(x), "v"(acc));
+#else
+    d = c[H] * x + acc;
+#endif
+    return d;
+}
+// d = c[H] * x
+template <int H>
+__device__ __forceinline__ pf2 pk_mul_c(pf2 c, pf2 x) {
+    pf2 d;
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (H == 0) asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(d) : "v"(c), "v"(x));
+    else asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,1]" : "=v"(d) : "v"(c), "v"(x));
+#else
+    d = c[H] * x;
+#endif
+    return d;
+}
+// the same two with the broadcast operand in an SGPR pair (carriers, matrix columns)
+template <int H>
+__device__ __forceinline__ pf2 pk_fma_cs(pf2 c, pf2 x, pf2 acc) {
+    pf2 d;
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (H == 0) asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[0,1,1]" : "=v"(d) : "s"(c), "v"(x), "v"(acc));
+    else asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "=v"(d) : "s"(c), "v"(x), "v"(acc));
+#else
+    d = c[H] * x + acc;
+#endif
+    return d;
+}
+template <int H>
+__device__ __forceinline__ pf2 pk_mul_cs(pf2 c, pf2 x) {
+    pf2 d;
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (H == 0) asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(d) : "s"(c), "v"(x));
+    else asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,1]" : "=v"(d) : "s"(c), "v"(x));
+#else
+    d = c[H] * x;
+#endif
+    return d;
+}
+// d = x[H] * k (k: full pair in SGPRs)
+template <int H>
+__device__ __forceinline__ pf2 pk_mul_bs(pf2 x, pf2 k) {
+    pf2 d;
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (H == 0) asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(d) : "v"(x), "s"(k));
+    else asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,1]" : "=v"(d) : "v"(x), "s"(k));
+#else
+    d = x[H] * k;
+#endif
+    return d;
+}
+template <int H>
+__device__ __forceinline__ pf2 pk_fma_bs(pf2 x, pf2 k, pf2 acc) {
+    pf2 d;
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (H == 0) asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[0,1,1]" : "=v"(d) : "v"(x), "s"(k), "v"(acc));
+    else asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "=v"(d) : "v"(x), "s"(k), "v"(acc));
+#else
+    d = x[H] * k + acc;
+#endif
+    return d;
+}
+__device__ __forceinline__ pf2 pk_add(pf2 a, pf2 b) {
+    pf2 d;
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm("v_pk_add_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+#else
+    d = a + b;
+#endif
+    return d;
+}
+__device__ __forceinline__ pf2 pk_mul(pf2 a, pf2 b) {
+    pf2 d;
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm("v_pk_mul_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+#else
+    d = a * b;
+#endif
+    return d;
+}
+__device__ __forceinline__ void pin_pair(pf2 &v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" : "+v"(v));
+#endif
+}
+
+// One scalar of a uniform block, moved to a VGPR on its own.  Without the barrier the optimiser merges neighbouring
+// elements into overlapping vector loads of the by-value kernel argument copy, which then stays in scratch memory.
+__device__ __forceinline__ float take(const float &x) {
+    float v = x;
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" : "+v"(v));
+#endif
+    return v;
+}
+
+__device__ __forceinline__ float take_s(const float &x) {   // the same, staying in an SGPR
+    float v = x;
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" : "+s"(v));
+#endif
+    return v;
+}
+
+// ---- coefficient blocks, two per VGPR pair ------------------------------------------------------
+struct TapsPk {
+    pf2 c2[5];   // (c[0], c[1]) ... (c[8], c[9])
+    pf2 c0;      // (c0, c0)
+    template <int I>
+    __device__ __forceinline__ void load_one(const Taps<float> &t) {
+        c2[I] = pf2{take(t.c[2 * I]), take(t.c[2 * I + 1])};
+        pin_pair(c2[I]);
+        if constexpr (I + 1 < 5) load_one<I + 1>(t);
+    }
+    __device__ __forceinline__ void load(const Taps<float> &t) {
+        load_one<0>(t);
+        c0 = pf2{take(t.c0), take(t.c0)};
+        pin_pair(c0);
+    }
+};
+// d = tap(I) * x + acc with tap(I) = c[I < 10 ? I : 19 - I]
+template <int I>
+__device__ __forceinline__ pf2 tap_fma(const TapsPk &k, pf2 x, pf2 acc) {
+    constexpr int idx = I < 10 ? I : 19 - I;
+    return pk_fma_c<idx & 1>(k.c2[idx >> 1], x, acc);
+}
+
+template <int NSEC>
+struct SosPk {
+    static constexpr int NB = (NSEC + 1) / 2;
+    pf2 a[NSEC];      // (na1, na2) of section j
+    pf2 b[NB];        // b1 of sections 2i, 2i + 1
+    pf2 b2[NB];       // b2 likewise (general numerators only)
+    template <int J>
+    __device__ __forceinline__ void load_a(const SosK<float, NSEC> &k) {
+        a[J] = pf2{take(k.na1[J]), take(k.na2[J])};
+        pin_pair(a[J]);
+        if constexpr (J + 1 < NSEC) load_a<J + 1>(k);
+    }
+    template <int I>
+    __device__ __forceinline__ void load_b(const SosK<float, NSEC> &k, bool with_b2) {
+        constexpr int lo = 2 * I, hi = 2 * I + 1 < NSEC ? 2 * I + 1 : lo;
+        constexpr float keep = 2 * I + 1 < NSEC ? 1.f : 0.f;
+        b[I] = pf2{take(k.b1[lo]), take(k.b1[hi]) * keep};
+        pin_pair(b[I]);
+        if (with_b2) {
+            b2[I] = pf2{take(k.b2[lo]), take(k.b2[hi]) * keep};
+            pin_pair(b2[I]);
+        }
+        if constexpr (I + 1 < NB) load_b<I + 1>(k, with_b2);
+    }
+    __device__ __forceinline__ void load(const SosK<float, NSEC> &k, bool with_b2) {
+        load_a<0>(k);
+        load_b<0>(k, with_b2);
+    }
+};
+
+// ---- transposed-form half-band decimator on a pair (cm_stages.h: HalfbandChain) ---------------------
+struct HalfbandChainPk {
+    pf2 s[19];
+    __device__ __forceinline__ void reset() {
+#pragma unroll
+        for (int j = 0; j < 19; ++j) s[j] = pf2{0.f, 0.f};
+    }
+    template <int J>
+    __device__ __forceinline__ void update(const TapsPk &k, pf2 x) {
+        s[J] = tap_fma<J + 1>(k, x, s[J + 1]);
+        if constexpr (J < 17) update<J + 1>(k, x);
+    }
+    __device__ __forceinline__ pf2 push_pair(const TapsPk &k, pf2 even, pf2 odd) {
+        pf2 out = tap_fma<0>(k, odd, s[0]);
+        update<0>(k, odd);
+        s[18] = pk_mul_c<0>(k.c2[0], odd);
+        s[8] = pk_fma_c<0>(k.c0, even, s[8]);   // centre tap lands on output m
+        return out;
+    }
+};
+
+template <int NSEC>
+struct IirStatePk {
+    pf2 s1[NSEC], s2[NSEC];
+    __device__ __forceinline__ void reset() {
+#pragma unroll
+        for (int j = 0; j < NSEC; ++j) s1[j] = s2[j] = pf2{0.f, 0.f};
+    }
+};
+// numerator 1 + b1 z^-1 + z^-2 (cm_stages.h: iir_sym)
+template <int J, int NSEC>
+__device__ __forceinline__ pf2 iir_sym_pk(IirStatePk<NSEC> &st, const SosPk<NSEC> &k, pf2 x) {
+    // order: no instruction reads the result of the one right before it (hipcc pads such pairs of packed
+    // instructions with an s_nop)
+    pf2 y = pk_add(x, st.s1[J]);
+    pf2 t = pk_fma_c<J & 1>(k.b[J >> 1], x, st.s2[J]);
+    st.s2[J] = pk_fma_c<1>(k.a[J], y, x);
+    st.s1[J] = pk_fma_c<0>(k.a[J], y, t);
+    if constexpr (J + 1 < NSEC) return iir_sym_pk<J + 1, NSEC>(st, k, y);
+    else return y;
+}
+// general numerator 1 + b1 z^-1 + b2 z^-2 (cm_stages.h: iir_gen)
+template <int J, int NSEC>
+__device__ __forceinline__ pf2 iir_gen_pk(IirStatePk<NSEC> &st, const SosPk<NSEC> &k, pf2 x) {
+    pf2 y = pk_add(x, st.s1[J]);
+    pf2 t = pk_fma_c<J & 1>(k.b[J >> 1], x, st.s2[J]);
+    pf2 z = pk_mul_c<J & 1>(k.b2[J >> 1], x);
+    st.s1[J] = pk_fma_c<0>(k.a[J], y, t);
+    st.s2[J] = pk_fma_c<1>(k.a[J], y, z);
+    if constexpr (J + 1 < NSEC) return iir_gen_pk<J + 1, NSEC>(st, k, y);
+    else return y;
+}
+
+// the same with the coefficients in SGPR pairs (light filters: saves the VGPR copies)
+template <int NSEC>
+struct SosPkS {
+    pf2 a[NSEC], b[NSEC];     // (na1, na2), (b1, b2) of section j
+    template <int J>
+    __device__ __forceinline__ void load_j(const SosK<float, NSEC> &k) {
+        a[J] = pf2{take_s(k.na1[J]), take_s(k.na2[J])};
+        b[J] = pf2{take_s(k.b1[J]), take_s(k.b2[J])};
+        if constexpr (J + 1 < NSEC) load_j<J + 1>(k);
+    }
+    __device__ __forceinline__ void load(const SosK<float, NSEC> &k) { load_j<0>(k); }
+};
+template <int J, int NSEC>
+__device__ __forceinline__ pf2 iir_gen_pks(IirStatePk<NSEC> &st, const SosPkS<NSEC> &k, pf2 x) {
+    pf2 y = pk_add(x, st.s1[J]);
+    pf2 t = pk_fma_cs<0>(k.b[J], x, st.s2[J]);
+    pf2 z = pk_mul_cs<1>(k.b[J], x);
+    st.s1[J] = pk_fma_cs<0>(k.a[J], y, t);
+    st.s2[J] = pk_fma_cs<1>(k.a[J], y, z);
+    if constexpr (J + 1 < NSEC) return iir_gen_pks<J + 1, NSEC>(st, k, y);
+    else return y;
+}
+
+// ---- uniform blocks of stage B in registers ----------------------------------------------------------
+template <class S>
+struct StageBK {
+    TapsPk taps;
+    SosPk<S::NL> lpf;
+    SosPkS<S::NP> pre;
+    pf2 m_u, m_v;                  // colour matrix columns of u and v, rows (r, g): SGPR pairs
+    float m_yr, m_yg, m_b[3];      // luma column of r and g; row of b
+    __device__ __forceinline__ void load(const DemodK<float, S> &k) {
+        taps.load(k.taps);
+        lpf.load(k.lpf, false);
+        pre.load(k.pre);
+        m_u = pf2{take_s(k.m[0][1]), take_s(k.m[1][1])};
+        m_v = pf2{take_s(k.m[0][2]), take_s(k.m[1][2])};
+        m_yr = take_s(k.m[0][0]);
+        m_yg = take_s(k.m[1][0]);
+        m_b[0] = take_s(k.m[2][0]); m_b[1] = take_s(k.m[2][1]); m_b[2] = take_s(k.m[2][2]);
+    }
+};
+
+// =============================================================================================
+// Detector (cm_stages.h) on the pair (cos channel, sin channel).
+// =============================================================================================
+template <class S>
+struct DetectorPk {
+    typedef DemodK<float, S> K;
+    static constexpr bool ODD_L = S::ODD_L;
+    HalfbandChainPk dn;
+    IirStatePk<S::NL> lpf;
+    pf2 hold;
+
+    __device__ __forceinline__ void reset() {
+        dn.reset();
+        lpf.reset();
+        hold = pf2{0.f, 0.f};
+    }
+    // p_e, p_o: the incoming pair times {C, S}(2 nd) and {C, S}(2 nd + 1) (the caller forms them: pk_mul_bs)
+    template <bool EDGE>
+    __device__ __forceinline__ pf2 step(const K &k, const StageBK<S> &kb, pf2 &p_last, int nd, pf2 p_e, pf2 p_o) {
+        const int W = k.width;
+        const int n5 = nd - k.q_l;
+        pf2 q_e = {0.f, 0.f}, q_o = {0.f, 0.f};
+        if (!EDGE || (nd >= 0 && nd < W + k.q_l)) {
+            if (EDGE) {
+                if (nd == W - 1) p_last = p_o;
+                if (nd >= W) p_e = p_o = p_last;
+            }
+            pf2 y0 = iir_sym_pk<0, S::NL>(lpf, kb.lpf, p_e);
+            pf2 y1 = iir_sym_pk<0, S::NL>(lpf, kb.lpf, p_o);
+            if (ODD_L) { q_e = hold; q_o = y0; hold = y1; } else { q_e = y0; q_o = y1; }
+        }
+        if (EDGE && (n5 < 0 || n5 >= W)) q_e = q_o = pf2{0.f, 0.f};
+        return dn.push_pair(kb.taps, q_e, q_o);
+    }
+};
+
+// per-lane constants of the back end as pairs over (u, v)
+struct LaneKPk {
+    pf2 ks[3], kc[3];      // (u, v) = sum_j ks[j] * Rs[k-j] + kc[j] * Rc[k-j]
+    pf2 ks2[3], kc2[3];    // second combination (MINAVG)
+    pf2 ra, rb;            // (sn, cs) = ra * C + rb * S, ra = (sph, vcph), rb = (cph, -vsph)
+    bool remod;            // sph or cph non-zero
+    __device__ __forceinline__ void load(const LaneK<float> &lk, int depth, bool minavg) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            ks[j] = pf2{take(lk.cu[j][0]), take(lk.cv[j][0])};
+            kc[j] = pf2{take(lk.cu[j][1]), take(lk.cv[j][1])};
+            if (minavg) {
+                ks2[j] = pf2{take(lk.cu2[j][0]), take(lk.cv2[j][0])};
+                kc2[j] = pf2{take(lk.cu2[j][1]), take(lk.cv2[j][1])};
+            }
+        }
+        (void)depth;
+        ra = pf2{take(lk.sph), take(lk.vcph)};
+        rb = pf2{take(lk.cph), -take(lk.vsph)};
+        remod = lk.sph != 0.f || lk.cph != 0.f;
+    }
+};
+
+// =============================================================================================
+// DemodBack (cm_stages.h) on the pair (u, v).  Base pairs are (Rc, Rs).
+// =============================================================================================
+template <class S, int DEPTH, bool NOTCH, bool MINAVG>
+struct DemodBackPk {
+    typedef DemodK<float, S> K;
+    IirStatePk<S::NP> pre;
+    IirState<float, 1> notch;
+    __device__ __forceinline__ void reset() {
+        pre.reset();
+        notch.reset();
+    }
+    __device__ __forceinline__ pf2 combine(const LaneKPk &lk, pf2 b0, pf2 b1, pf2 b2) const {
+        pf2 uv = pk_mul_c<1>(b0, lk.ks[0]);
+        uv = pk_fma_c<0>(b0, lk.kc[0], uv);
+        if (DEPTH >= 1) {
+            uv = pk_fma_c<0>(b1, lk.kc[1], uv);
+            uv = pk_fma_c<1>(b1, lk.ks[1], uv);
+        }
+        if (DEPTH >= 2) {
+            uv = pk_fma_c<0>(b2, lk.kc[2], uv);
+            uv = pk_fma_c<1>(b2, lk.ks[2], uv);
+        }
+        if (MINAVG) {
+            pf2 w = pk_mul_c<1>(b0, lk.ks2[0]);
+            w = pk_fma_c<0>(b0, lk.kc2[0], w);
+            if (DEPTH >= 1) {
+                w = pk_fma_c<0>(b1, lk.kc2[1], w);
+                w = pk_fma_c<1>(b1, lk.ks2[1], w);
+            }
+            if (DEPTH >= 2) {
+                w = pk_fma_c<0>(b2, lk.kc2[2], w);
+                w = pk_fma_c<1>(b2, lk.ks2[2], w);
+            }
+            uv = pf2{minavg_(uv.x, w.x), minavg_(uv.y, w.y)};
+        }
+        return uv;
+    }
+    // (sn, cs) = (sin, +-cos)(phi + 2 n7 cps) times the pre-filter gain; carb = {C[2 n7], S[2 n7]} (SGPRs)
+    __device__ __forceinline__ pf2 remod(const LaneKPk &lk, pf2 carb) const {
+        pf2 sc = pk_mul_cs<0>(carb, lk.ra);
+        return pk_fma_cs<1>(carb, lk.rb, sc);
+    }
+    // uv: combined chroma at n6; uv_d: the same at n7 = n6 - s_p; y_src: luma source at n7; sc: remod() of sample n7
+    template <bool EDGE>
+    __device__ __forceinline__ Rgb<float> step(const K &k, const StageBK<S> &kb, const LaneKPk &lk, pf2 &uv_last, int n6, pf2 uv,
+                                               pf2 uv_d, float y_src, pf2 sc) {
+        const int W = k.width;
+        pf2 w = {0.f, 0.f};
+        if (!EDGE || (n6 >= 0 && n6 < W + k.s_p)) {
+            if (EDGE) {
+                if (n6 == W - 1) uv_last = uv;
+                if (n6 >= W) uv = uv_last;
+            }
+            w = iir_gen_pks<0, S::NP>(pre, kb.pre, uv);
+        }
+        pf2 pr = pk_mul(sc, w);
+        float y = (y_src - pr.x) - pr.y;
+        if (NOTCH) {
+            const int n7 = n6 - k.s_p;
+            if (k.notch_gain != 0.f && (!EDGE || (n7 >= 0 && n7 < W))) {
+                float yn = iir_sym<false>(notch, k.notch, y) * k.notch_gain;
+                if (lk.remod) y = yn;
+            }
+        }
+        // (r, g) as a pair, b alone; matrix columns from SGPRs
+        pf2 rg = pk_mul_bs<0>(uv_d, kb.m_u);
+        rg = pk_fma_bs<1>(uv_d, kb.m_v, rg);
+        Rgb<float> o;
+        o.r = fmaf_(kb.m_yr, y, rg.x);
+        o.g = fmaf_(kb.m_yg, y, rg.y);
+        o.b = fmaf_(kb.m_b[0], y, fmaf_(kb.m_b[1], uv_d.x, kb.m_b[2] * uv_d.y));
+        return o;
+    }
+};
+
+}  // namespace cm
+#endif
+#endif

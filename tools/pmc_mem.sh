@@ -10,7 +10,7 @@ import csv, glob, collections, sys
 tot = collections.defaultdict(list)
 for p in glob.glob(sys.argv[1] + '/p*/**/*counter_collection.csv', recursive=True):
     for r in csv.DictReader(open(p)):
-        if 'demod_kernel' in r['Kernel_Name']: tot[r['Counter_Name']].append(float(r['Counter_Value']))
+        if 'demod_' in r['Kernel_Name']: tot[r['Counter_Name']].append(float(r['Counter_Value']))
 m = {c: sum(v) / len(v) for c, v in tot.items()}
 print(sys.argv[1], 'FETCH raw GB %.3f  WRITE GB %.3f  L2 hit %.3f' % (m['FETCH_SIZE'] * 1024 / 1e9, m['WRITE_SIZE'] * 1024 / 1e9, m['TCC_HIT_sum'] / (m['TCC_HIT_sum'] + m['TCC_MISS_sum'])))
 PY

@@ -18,7 +18,7 @@ for p in sorted(glob.glob('gpurun_out/pmc/p*/**/*counter_collection.csv', recurs
         agg[r['Kernel_Name'][:60]][r['Counter_Name']].append(float(r['Counter_Value']))
     print(p)
     for k, d in agg.items():
-        if 'demod_kernel' not in k: continue
+        if 'demod_' not in k: continue
         print('  ', k)
         for c, v in d.items():
             print('      %-22s n=%d  mean=%.4g' % (c, len(v), sum(v) / len(v)))

@@ -2,7 +2,7 @@ import csv, glob, collections, sys
 tot = collections.defaultdict(list)
 for p in sorted(glob.glob('gpurun_out/pmc/p*/**/*counter_collection.csv', recursive=True)):
     for r in csv.DictReader(open(p)):
-        if 'demod_kernel' not in r['Kernel_Name']: continue
+        if 'demod_' not in r['Kernel_Name']: continue
         tot[r['Counter_Name']].append(float(r['Counter_Value']))
 m = {c: sum(v) / len(v) for c, v in tot.items()}
 for c in sorted(m): print('   %-22s %.4g  (n=%d)' % (c, m[c], len(tot[c])))

@@ -8,6 +8,7 @@ F = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 modem = stacks.make('pal_d', (720, 576))
 im = image.ImageModem(modem)
 comp = torch.from_numpy(testing.synthetic_composite(4, 576, 720)).cuda().repeat(F // 4, 1, 1).contiguous()
+if os.environ.get('CM_ZERO'): comp.zero_()   # power check: all-zero operands switch fewer bits
 out = torch.empty((F, 3, 576, 720), dtype=torch.float32, device='cuda')
 eng = im._engine()
 print(eng.describe())
