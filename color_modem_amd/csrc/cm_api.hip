@@ -226,11 +226,12 @@ bool select_kernels(cm_plan *p, const cm_plan_desc &d, std::string &err) {
 #ifndef CM_DEV_PALD_ONLY
     if (match(signature_of<SysNtsc>())) return select_for_shape<SysNtsc, true, true>(p, d, "ntsc (pal-m/n)", err);
     if (!pald && match(signature_of<SysNtscI>())) return select_for_shape<SysNtscI, false, true>(p, d, "ntsc-i", err);
+    if (!pald && match(signature_of<SysNtscA>())) return select_for_shape<SysNtscA, false, true>(p, d, "ntsc-a", err);
 #endif
     char buf[256];
     snprintf(buf, sizeof buf,
              "no kernel instance for this filter set (sections extract/remove/detect/pre = %d/%d/%d/%d, shift parities %d/%d/%d, "
-             "pre shift %d); built: the filter shapes of PAL-BG, NTSC-M (= PAL-M/N, NTSC-N/3.61) and NTSC-I/4.43 at 13.5 MHz",
+             "pre shift %d); built: the filter shapes of PAL-BG, NTSC-M (= PAL-M/N, NTSC-N/3.61), NTSC-I/4.43 and NTSC-A at 13.5 MHz",
              want.ne, want.nr, want.nl, want.np, want.odd_e, want.odd_l, want.odd_r, want.sp);
     err = buf;
     return false;
@@ -251,19 +252,32 @@ int launch_qam_mod(const Geom &g, const void *kv, int blocks, hipStream_t stream
 bool select_modulator(cm_plan *p, const cm_plan_desc &d, std::string &err) {
     const cm_lane_table &tb = d.mod_main;
     if (!tb.table) return true;
-    if (d.precorrect.n_sections != 1 || d.precorrect.shift != 2) {
-        err = "no modulator instance for this pre-correction filter (built: one section, shift 2)";
+    const bool shape1 = d.precorrect.n_sections == 1 && d.precorrect.shift == 2;   // every system but NTSC-A
+    const bool shape2 = d.precorrect.n_sections == 2 && d.precorrect.shift == 4;   // NTSC-A
+    if (!shape1 && !shape2) {
+        err = "no modulator instance for this pre-correction filter (built: one section with shift 2, two sections with shift 4)";
         return false;
     }
-    ModK<float, 1> k;
     double g_pre;
-    k.width = d.width;
-    k.s_p = d.precorrect.shift;
-    if (!convert_sos<float, 1>(d.precorrect, FORM_GEN, k.pre, g_pre, err, "precorrect")) return false;
-    for (int i = 0; i < 3; ++i)
-        for (int j = 0; j < 3; ++j) k.e[i][j] = (float)d.encode_matrix[3 * i + j];
-    p->mod_k.resize(sizeof k);
-    std::memcpy(p->mod_k.data(), &k, sizeof k);
+    if (shape1) {
+        ModK<float, 1> k;
+        k.width = d.width;
+        k.s_p = d.precorrect.shift;
+        if (!convert_sos<float, 1>(d.precorrect, FORM_GEN, k.pre, g_pre, err, "precorrect")) return false;
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j) k.e[i][j] = (float)d.encode_matrix[3 * i + j];
+        p->mod_k.resize(sizeof k);
+        std::memcpy(p->mod_k.data(), &k, sizeof k);
+    } else {
+        ModK<float, 2> k;
+        k.width = d.width;
+        k.s_p = d.precorrect.shift;
+        if (!convert_sos<float, 2>(d.precorrect, FORM_GEN, k.pre, g_pre, err, "precorrect")) return false;
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j) k.e[i][j] = (float)d.encode_matrix[3 * i + j];
+        p->mod_k.resize(sizeof k);
+        std::memcpy(p->mod_k.data(), &k, sizeof k);
+    }
     const size_t n = (size_t)tb.frame_cycle * 3 * tb.n_lines;
     std::vector<ModLaneK<float>> host(n);
     for (size_t i = 0; i < n; ++i) {
@@ -283,7 +297,8 @@ bool select_modulator(cm_plan *p, const cm_plan_desc &d, std::string &err) {
     p->mod_cycle = tb.frame_cycle;
     p->mod_n_lines = tb.n_lines;
     p->mod_depth = d.modulation_delay ? 1 : 0;
-    p->mod_fn = p->mod_depth ? launch_qam_mod<1, 2, 1> : launch_qam_mod<1, 2, 0>;
+    if (shape1) p->mod_fn = p->mod_depth ? launch_qam_mod<1, 2, 1> : launch_qam_mod<1, 2, 0>;
+    else p->mod_fn = p->mod_depth ? launch_qam_mod<2, 4, 1> : launch_qam_mod<2, 4, 0>;
     p->mod_name = p->mod_depth ? "qam_mod_kernel<line averaging>" : "qam_mod_kernel";
     return true;
 }

@@ -247,6 +247,7 @@ std::vector<T> build_fm_reference(double fc, int lc) {
 typedef Sys<2, 2, 3, 1, false, false, false, 2> SysPal;   // PAL-BG @ 13.5 MHz: shifts 4 / 4 (6 for PAL-D) / 2 / 2
 typedef Sys<3, 3, 3, 1, false, true, false, 2> SysNtsc;   // NTSC-M @ 13.5 MHz: shifts 6 / 5 / 4 / 2 (also NTSC-N, NTSC 3.61, PAL-M, PAL-N)
 typedef Sys<3, 2, 3, 1, false, true, false, 2> SysNtscI;  // NTSC-I, NTSC 4.43 on 625 lines: narrower band-stop
+typedef Sys<4, 3, 3, 2, true, true, true, 4> SysNtscA;    // NTSC-A (405 lines, 2.66 MHz sub-carrier): shifts 9 / 7 / 5 / 4
 
 struct SysSignature {
     int ne, nr, nl, np, odd_e, odd_l, odd_r, sp;

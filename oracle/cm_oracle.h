@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define ORC_MAX_COEF 8
+#define ORC_MAX_COEF 12
 #define ORC_MAX_FILTERS 8
 
 /* utils.py:9-36 FilterFunction state after construction */

@@ -16,7 +16,7 @@ import numpy
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, 'libcm_oracle.so')
 
-ORC_MAX_COEF = 8
+ORC_MAX_COEF = 12
 ORC_MAX_FILTERS = 8
 KIND = {'pal_s': 1, 'pal_d': 2, 'pal_3d': 3, 'ntsc': 4, 'ntsc_comb': 5, 'secam': 6}
 WRAP = {None: 0, 'simple': 1, 'simple_3d': 2, 'color_averaging': 3}

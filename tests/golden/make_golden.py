@@ -220,6 +220,8 @@ STACKS.update({
     'pal_s_palm': lambda lc: pal.PalSModem(lc, pal.PalVariant.PAL_M),
     'ntsc_comb_443': lambda lc: ntsc.NtscCombModem(lc, ntsc.NtscVariant.NTSC443),
     'ntsc_443': lambda lc: ntsc.NtscModem(lc, ntsc.NtscVariant.NTSC443),
+    'ntsc_a': lambda lc: ntsc.NtscModem(lc, ntsc.NtscVariant.NTSC_A),
+    'ntsc_comb_a': lambda lc: ntsc.NtscCombModem(lc, ntsc.NtscVariant.NTSC_A),
     'pal_d_60': lambda lc: pal.PalDModem(lc),
     'pal_s_60': lambda lc: pal.PalSModem(lc),
 })
@@ -301,8 +303,10 @@ def option_cases(only=()):
         ('pal_d_palm', 'pal_s_palm', [0, 1, 2, 3]),
         ('ntsc_comb_443', 'ntsc_443', [0, 1, 4799, 4802]),
         ('pal_d_60', 'pal_s_60', [1, 2402, 4799, 4800]),
+        ('ntsc_comb_a', 'ntsc_a', [0, 1, 2]),      # NTSC-A: order-8 band-pass, odd shifts, two-section pre-correction
+        ('ntsc_a', 'ntsc_a', [1, 4]),
     ]
-    mods = [('secam_i', [0, 2]), ('secam_ii', [1, 5]), ('pal_s_60', [3, 4798]), ('ntsc_443', [0, 4797])]
+    mods = [('secam_i', [0, 2]), ('secam_ii', [1, 5]), ('pal_s_60', [3, 4798]), ('ntsc_443', [0, 4797]), ('ntsc_a', [0, 3])]
     if only:
         mods = [m for m in mods if m[0] in only]
         demods = [d for d in demods if d[0] in only]

@@ -140,6 +140,8 @@ static int run_dispatch(const cm_plan_desc &d, bool pald, bool bsf, const cm_lan
         return run_generic<T, SysNtsc>(d, pald, bsf, tb, calls, comp, rgb, n_calls, frame, first_line, k0, mid_fast);
     if (!pald && match(signature_of<SysNtscI>()))
         return run_generic<T, SysNtscI>(d, pald, bsf, tb, calls, comp, rgb, n_calls, frame, first_line, k0, mid_fast);
+    if (!pald && match(signature_of<SysNtscA>()))
+        return run_generic<T, SysNtscA>(d, pald, bsf, tb, calls, comp, rgb, n_calls, frame, first_line, k0, mid_fast);
     g_err = "no kernel instance for this filter set";
     return CM_ERR_UNSUPPORTED;
 }

@@ -39,6 +39,9 @@ STACKS.update({
     'pal_s_palm': lambda lc: pal.PalSModem(lc, pal.PalVariant.PAL_M),
     'ntsc_comb_443': lambda lc: ntsc.NtscCombModem(lc, ntsc.NtscVariant.NTSC443),
     'ntsc_443': lambda lc: ntsc.NtscModem(lc, ntsc.NtscVariant.NTSC443),
+    'ntsc_a': lambda lc: ntsc.NtscModem(lc, ntsc.NtscVariant.NTSC_A),
+    'ntsc_comb_a': lambda lc: ntsc.NtscCombModem(lc, ntsc.NtscVariant.NTSC_A),
+    'ntsc_comb_3d_a': lambda lc: comb.Simple3DCombModem(ntsc.NtscCombModem(lc, ntsc.NtscVariant.NTSC_A)),
     'pal_d_60': lambda lc: pal.PalDModem(lc),
     'pal_s_60': lambda lc: pal.PalSModem(lc),
 })

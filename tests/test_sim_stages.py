@@ -40,7 +40,7 @@ def run(L, bp, comp, frame, first_line, k0, f32, mid=1):
 @pytest.mark.parametrize('stack,size', [('pal_d', (720, 576)), ('pal_s', (720, 576)), ('pal_3d', (720, 576)),
                                         ('ntsc', (720, 480)), ('ntsc_comb', (720, 480)),
                                         ('ntsc_comb_simple', (720, 480)), ('ntsc_comb_3d', (720, 480)),
-                                        ('pal_d', (704, 8))])
+                                        ('pal_d', (704, 8)), ('ntsc_a', (720, 480)), ('ntsc_comb_3d_a', (720, 480))])
 @pytest.mark.parametrize('frame,first_line', [(0, 0), (1, 1), (3, 2)])
 def test_streaming_matches_oracle(sim, stack, size, frame, first_line):
     from oracle import cm_oracle
