@@ -17,7 +17,8 @@ CM_OK, CM_ERR_INVALID, CM_ERR_UNSUPPORTED, CM_ERR_NO_DEVICE, CM_ERR_LAUNCH = 0, 
 
 # every symbol include/color_modem_hip.h declares
 SYMBOLS = ('cm_last_error', 'cm_abi_version', 'cm_device_count', 'cm_plan_create', 'cm_plan_destroy',
-           'cm_demodulate_frames', 'cm_modulate_frames', 'cm_demodulate_frames_u8', 'cm_demodulate_run', 'cm_modulate_run',
+           'cm_demodulate_frames', 'cm_modulate_frames', 'cm_demodulate_frames_u8', 'cm_modulate_frames_u8', 'cm_demodulate_run',
+           'cm_modulate_run',
            'cm_plan_describe')
 
 _lib = None
@@ -46,6 +47,7 @@ def lib():
     L.cm_demodulate_frames.argtypes = [vp, vp, vp, ctypes.c_int64, ctypes.c_int64, vp]
     L.cm_modulate_frames.argtypes = [vp, vp, vp, ctypes.c_int64, ctypes.c_int64, vp]
     L.cm_demodulate_frames_u8.argtypes = [vp, vp, vp, ctypes.c_int64, ctypes.c_int64, vp]
+    L.cm_modulate_frames_u8.argtypes = [vp, vp, vp, ctypes.c_int64, ctypes.c_int64, vp]
     L.cm_demodulate_run.argtypes = [vp, vp, vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, vp]
     L.cm_modulate_run.argtypes = [vp, vp, vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, vp]
     L.cm_plan_describe.argtypes = [vp, ctypes.c_char_p, ctypes.c_int32]

@@ -48,7 +48,7 @@ int launch_demod(const Geom &gm, const void *km, const Geom &gf, const void *kf,
     af.k = kf ? *static_cast<const DemodK<float, S> *>(kf) : am.k;
     // wave-pair kernel where stage B fits the 168 VGPRs of 3 waves per SIMD, one wave per 64 calls otherwise
     // (measured on those instances: the pair at 2 waves per SIMD is 2-5 % slower than the single wave)
-    if constexpr (CM_PAIR != 0 && Main::kPairWaves == 3)
+    if constexpr (CM_PAIR != 0 && Main::kUsePair)
         hipLaunchKernelGGL((demod_pair_kernel<Main, First>), dim3(n_first + n_main), dim3(128), 0, stream, am, af, n_first);
     else
         hipLaunchKernelGGL((demod_kernel<Main, First>), dim3(n_first + n_main), dim3(64), 0, stream, am, af, n_first);
@@ -81,7 +81,7 @@ struct cm_plan {
     bool pair = false;             // wave-pair kernel (two wavefronts per 64 calls)
     Pass main, first;
     // modulator
-    ModLaunchFn mod_fn = nullptr;
+    ModLaunchFn mod_fn = nullptr, mod_fn_u8 = nullptr;
     std::vector<unsigned char> mod_k;
     ModLaneK<float> *mod_lanes = nullptr;
     int mod_cycle = 0, mod_n_lines = 0, mod_depth = 0;
@@ -205,7 +205,7 @@ bool select_for_shape(cm_plan *p, const cm_plan_desc &d, const char *sys, std::s
         }
         p->main.depth = 2; what = "qam front, depth 2";
     }
-    const bool pair = CM_PAIR != 0 && p->main.depth < 2 && !notch && !minavg;   // PassCfg::kPairWaves == 3
+    const bool pair = CM_PAIR != 0 && ((p->main.depth < 2 && !notch && !minavg && S::NE < 4 && S::NP < 2) || (pald && notch));   // PassCfg::kUsePair
     p->pair = pair;
     p->main.name = std::string(pair ? "demod_pair_kernel<" : "demod_kernel<") + sys + ": " + what + (notch ? " + notch>" : ">");
     return make_passes<S>(p, d, pald, bsf, first, err);
@@ -237,12 +237,12 @@ bool select_kernels(cm_plan *p, const cm_plan_desc &d, std::string &err) {
     return false;
 }
 
-template <int NP, int SP, int DEPTH>
+template <int NP, int SP, int DEPTH, bool U8 = false>
 int launch_qam_mod(const Geom &g, const void *kv, int blocks, hipStream_t stream) {
     ModArgs<NP> a;
     a.g = g;
     a.k = *static_cast<const ModK<float, NP> *>(kv);
-    hipLaunchKernelGGL((qam_mod_kernel<NP, SP, DEPTH>), dim3(blocks), dim3(64), 0, stream, a);
+    hipLaunchKernelGGL((qam_mod_kernel<NP, SP, DEPTH, U8>), dim3(blocks), dim3(64), 0, stream, a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(CM_ERR_LAUNCH, std::string("qam_mod_kernel launch: ") + hipGetErrorString(e));
     return CM_OK;
@@ -297,8 +297,13 @@ bool select_modulator(cm_plan *p, const cm_plan_desc &d, std::string &err) {
     p->mod_cycle = tb.frame_cycle;
     p->mod_n_lines = tb.n_lines;
     p->mod_depth = d.modulation_delay ? 1 : 0;
-    if (shape1) p->mod_fn = p->mod_depth ? launch_qam_mod<1, 2, 1> : launch_qam_mod<1, 2, 0>;
-    else p->mod_fn = p->mod_depth ? launch_qam_mod<2, 4, 1> : launch_qam_mod<2, 4, 0>;
+    if (shape1) {
+        p->mod_fn = p->mod_depth ? launch_qam_mod<1, 2, 1> : launch_qam_mod<1, 2, 0>;
+        p->mod_fn_u8 = p->mod_depth ? launch_qam_mod<1, 2, 1, true> : launch_qam_mod<1, 2, 0, true>;
+    } else {
+        p->mod_fn = p->mod_depth ? launch_qam_mod<2, 4, 1> : launch_qam_mod<2, 4, 0>;
+        p->mod_fn_u8 = p->mod_depth ? launch_qam_mod<2, 4, 1, true> : launch_qam_mod<2, 4, 0, true>;
+    }
     p->mod_name = p->mod_depth ? "qam_mod_kernel<line averaging>" : "qam_mod_kernel";
     return true;
 }
@@ -343,7 +348,7 @@ bool create_secam(cm_plan *p, const cm_plan_desc &d, std::string &err) {
     return true;
 }
 
-int run_secam_demod(const cm_plan *p, Geom g, hipStream_t stream) {
+int run_secam_demod(const cm_plan *p, Geom g, hipStream_t stream, bool u8 = false) {
     g.lanes = reinterpret_cast<const LaneK<float> *>(p->sd_lanes);
     g.carrier4 = p->fm_ref;
     g.carrier2 = p->fm_ref;
@@ -356,13 +361,14 @@ int run_secam_demod(const cm_plan *p, Geom g, hipStream_t stream) {
     SecamDemodArgs a;
     a.g = g;
     a.k = p->sd_k;
-    hipLaunchKernelGGL(secam_demod_kernel, dim3((int)blocks), dim3(64), 0, stream, a);
+    if (u8) hipLaunchKernelGGL(secam_demod_kernel<true>, dim3((int)blocks), dim3(64), 0, stream, a);
+    else hipLaunchKernelGGL(secam_demod_kernel<false>, dim3((int)blocks), dim3(64), 0, stream, a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(CM_ERR_LAUNCH, std::string("secam_demod_kernel launch: ") + hipGetErrorString(e));
     return CM_OK;
 }
 
-int run_secam_mod(const cm_plan *p, Geom g, hipStream_t stream) {
+int run_secam_mod(const cm_plan *p, Geom g, hipStream_t stream, bool u8 = false) {
     if (!p->sm_lanes) return fail(CM_ERR_UNSUPPORTED, "this plan has no modulator");
     g.lanes = reinterpret_cast<const LaneK<float> *>(p->sm_lanes);
     g.cycle = p->mod_cycle;
@@ -373,10 +379,13 @@ int run_secam_mod(const cm_plan *p, Geom g, hipStream_t stream) {
     SecamModArgs a;
     a.g = g;
     a.k = p->sm_k;
-    if (p->mod_depth)
-        hipLaunchKernelGGL((secam_mod_kernel<3, 1>), dim3((int)blocks), dim3(64), 0, stream, a);
-    else
-        hipLaunchKernelGGL((secam_mod_kernel<3, 0>), dim3((int)blocks), dim3(64), 0, stream, a);
+    if (p->mod_depth) {
+        if (u8) hipLaunchKernelGGL((secam_mod_kernel<3, 1, true>), dim3((int)blocks), dim3(64), 0, stream, a);
+        else hipLaunchKernelGGL((secam_mod_kernel<3, 1>), dim3((int)blocks), dim3(64), 0, stream, a);
+    } else {
+        if (u8) hipLaunchKernelGGL((secam_mod_kernel<3, 0, true>), dim3((int)blocks), dim3(64), 0, stream, a);
+        else hipLaunchKernelGGL((secam_mod_kernel<3, 0>), dim3((int)blocks), dim3(64), 0, stream, a);
+    }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(CM_ERR_LAUNCH, std::string("secam_mod_kernel launch: ") + hipGetErrorString(e));
     return CM_OK;
@@ -592,7 +601,9 @@ int cm_demodulate_frames_u8(const cm_plan *p, const uint8_t *composite8, uint8_t
     if (p && n_frames == 0) return CM_OK;
     if (!p || !composite8 || !rgb8) return fail(CM_ERR_INVALID, "null argument");
     if (n_frames < 0 || first_frame < 0) return fail(CM_ERR_INVALID, "negative frame count / number");
-    if (p->secam || !p->fn_u8) return fail(CM_ERR_UNSUPPORTED, "the fused uint8 boundary is built for the PAL / NTSC decoders");
+    if (!p->secam && !p->fn_u8)
+        return fail(CM_ERR_UNSUPPORTED, p->fn ? "no kernel instance with the fused uint8 boundary for this decoder (notch / minavg)"
+                                              : p->demod_error);
     const cm_plan_desc &d = p->desc;
     const int W = d.width, H = d.height, D = d.demodulation_delay;
     Geom g;
@@ -606,7 +617,7 @@ int cm_demodulate_frames_u8(const cm_plan *p, const uint8_t *composite8, uint8_t
     g.out_plane_stride = 0;
     g.out_frame_stride = 3LL * W * H;
     g.out_row_stride = 3LL * W;
-    set_first_frame(p, g, first_frame, p->main.cycle);
+    set_first_frame(p, g, first_frame, p->secam ? p->sd_cycle : p->main.cycle);
     const int rows0 = (H + 1) / 2, rows1 = H / 2;
     g.calls_run0 = rows0 + D;
     const int calls_run1 = rows1 > 0 ? rows1 + D : 0;
@@ -617,6 +628,10 @@ int cm_demodulate_frames_u8(const cm_plan *p, const uint8_t *composite8, uint8_t
     g.delay = D;
     g.total_calls = n_frames * g.calls_per_frame;
     g.skip_first = d.first_is_plain;
+    if (p->secam) {
+        if (H - 1 >= p->sd_n_lines) return fail(CM_ERR_INVALID, "line number beyond the plan's tables");
+        return run_secam_demod(p, g, (hipStream_t)stream, true);
+    }
     int rc = check_lines(p, p->main, H - 1 + 2 * D);
     if (rc) return rc;
     Geom s = g;
@@ -677,8 +692,8 @@ int cm_demodulate_run(const cm_plan *p, const float *composite, float *rgb, int3
     return run_plan(p, g, s, with_first, (hipStream_t)stream);
 }
 
-static int run_mod(const cm_plan *p, Geom g, hipStream_t stream) {
-    if (p->secam) return run_secam_mod(p, g, stream);
+static int run_mod(const cm_plan *p, Geom g, hipStream_t stream, bool u8 = false) {
+    if (p->secam) return run_secam_mod(p, g, stream, u8);
     if (!p->mod_fn) return fail(CM_ERR_UNSUPPORTED, "this plan has no modulator");
     g.lanes = reinterpret_cast<const LaneK<float> *>(p->mod_lanes);
     g.carrier4 = p->carrier4;
@@ -688,7 +703,7 @@ static int run_mod(const cm_plan *p, Geom g, hipStream_t stream) {
     long long blocks = (g.total_calls + (64 - p->mod_depth) - 1) / (64 - p->mod_depth);
     if (blocks <= 0) return CM_OK;
     if (blocks > 0x7fffffffLL) return fail(CM_ERR_INVALID, "batch too large for one launch");
-    return p->mod_fn(g, p->mod_k.data(), (int)blocks, stream);
+    return (u8 ? p->mod_fn_u8 : p->mod_fn)(g, p->mod_k.data(), (int)blocks, stream);
 }
 
 int cm_modulate_frames(const cm_plan *p, const float *rgb, float *composite, int64_t n_frames, int64_t first_frame,
@@ -722,6 +737,40 @@ int cm_modulate_frames(const cm_plan *p, const float *rgb, float *composite, int
     g.total_calls = n_frames * g.calls_per_frame;
     if (H - 1 + 2 * D >= p->mod_n_lines) return fail(CM_ERR_INVALID, "line number beyond the plan's phase tables");
     return run_mod(p, g, (hipStream_t)stream);
+}
+
+int cm_modulate_frames_u8(const cm_plan *p, const uint8_t *rgb8, uint8_t *composite8, int64_t n_frames, int64_t first_frame,
+                          void *stream) {
+    if (p && n_frames == 0) return CM_OK;
+    if (!p || !rgb8 || !composite8) return fail(CM_ERR_INVALID, "null argument");
+    if (n_frames < 0 || first_frame < 0) return fail(CM_ERR_INVALID, "negative frame count / number");
+    if (!p->mod_fn && !p->sm_lanes) return fail(CM_ERR_UNSUPPORTED, "this plan has no modulator");
+    const cm_plan_desc &d = p->desc;
+    const int W = d.width, H = d.height, D = d.modulation_delay;
+    if (W % 16 != 0) return fail(CM_ERR_UNSUPPORTED, "the fused uint8 boundary of the encoders needs a width that is a multiple of 16");
+    Geom g;
+    std::memset(&g, 0, sizeof g);
+    g.in = reinterpret_cast<const float *>(rgb8);         // strides below count bytes (U8 kernels)
+    g.out = reinterpret_cast<float *>(composite8);
+    g.W = W;
+    g.H = H;
+    g.in_frame_stride = 3LL * W * H;
+    g.in_plane_stride = 0;
+    g.in_row_stride = 3LL * W;
+    g.out_frame_stride = (long long)W * H;
+    g.out_row_stride = W;
+    set_first_frame(p, g, first_frame, p->mod_cycle);
+    const int rows0 = (H + 1) / 2, rows1 = H / 2;
+    g.calls_run0 = rows0 + D;
+    const int calls_run1 = rows1 > 0 ? rows1 + D : 0;
+    g.calls_per_frame = g.calls_run0 + calls_run1;
+    g.runs_per_frame = rows1 > 0 ? 2 : 1;
+    g.first_line[0] = 0;
+    g.first_line[1] = 1;
+    g.delay = D;
+    g.total_calls = n_frames * g.calls_per_frame;
+    if (H - 1 + 2 * D >= p->mod_n_lines) return fail(CM_ERR_INVALID, "line number beyond the plan's phase tables");
+    return run_mod(p, g, (hipStream_t)stream, true);
 }
 
 int cm_modulate_run(const cm_plan *p, const float *rgb, float *composite, int32_t n_calls, int32_t frame, int32_t first_line,

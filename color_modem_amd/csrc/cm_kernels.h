@@ -146,7 +146,10 @@ struct PassCfg {
     static constexpr int kLdsFloats = kLdsInF + kLdsOut + (BSF_ ? kLdsRing : 0);
     // wave-pair kernels: 3 waves per SIMD need <= 168 VGPRs; the instances with more per-lane state in stage B (a second
     // line of history, the notch, the second combination of minavg) would spill there and get 2 waves per SIMD instead
-    static constexpr int kPairWaves = (DEPTH_ >= 2 || NOTCH_ || MINAVG_) ? 2 : 3;
+    static constexpr int kPairWaves = (DEPTH_ >= 2 || NOTCH_ || MINAVG_ || S_::NE >= 4 || S_::NP >= 2) ? 2 : 3;
+    // which kernel structure runs this instance: the pair where it gets 3 waves per SIMD (measured 1-3 % faster there,
+    // 2-5 % slower at 2), and for the PAL-D front end with the notch, which does not fit one wave's 256 VGPRs
+    static constexpr bool kUsePair = kPairWaves == 3 || (FRONT_ == 1 && NOTCH_);
 };
 struct NoPass {
     static constexpr int kLdsFloats = 0;

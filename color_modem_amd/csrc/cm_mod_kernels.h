@@ -85,20 +85,128 @@ __device__ __forceinline__ void next_tile3(const Geom &g, lds_float *itile, cons
     }
 }
 
+// ---- the ImageModem byte boundary of the encoders (ref image.py:27-56): mode-'RGB' images in, mode-'L' images out.
+// Input rows are W x 3 interleaved bytes; a tile holds 32 pixels = 96 bytes of each of the 64 rows, filled with 16 bytes
+// per lane (6 lanes per row, 10 rows per global_load_lds_dwordx4); rows are 16-byte aligned because W % 16 == 0 is
+// required for this path.  The composite leaves as bytes through a [64 rows][64 pixels] tile, 64-byte row segments.
+constexpr int kInTile3Bytes = 64 * 96;     // bytes
+constexpr int kOutTileU8 = 64;             // pixels per row of the byte output tile
+typedef __attribute__((address_space(3))) unsigned char lds_byte;
+typedef __attribute__((address_space(3))) unsigned lds_word;
+
+__device__ __forceinline__ void fill_tile3_u8(const Geom &g, lds_float *itile, const float *rp, int c, int lane) {
+    const int r10 = lane / 6, j = lane - 6 * r10;        // lanes 60..63 idle
+    long long off = 96LL * c + 16 * j;                   // byte offset in the row
+    const long long last = 3LL * g.W - 16;
+    if (off > last) off = last;                          // never read past the row; such bytes are masked by the consumer
+#pragma nounroll
+    for (int q = 0; q < 7; ++q) {
+        const int row = 10 * q + r10;
+        const unsigned char *src = (const unsigned char *)ptr_from((row < 64 ? row : 63) * 4, rp) + off;
+        if (lane < 60 && row < 64)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                             (__attribute__((address_space(3))) void *)((lds_byte *)itile + q * 960), 16, 0,
+                                             CM_FILL_AUX);
+    }
+}
+// r, g, b of pixels first .. first + 3 of this lane's row (bytes / 255, ref image.py:43-45); zero beyond the row
+__device__ __forceinline__ void read_tile3_u8(const lds_float *itile, int lane, int first, int W, f4 out[3]) {
+    const lds_word *p = (const lds_word *)((const lds_byte *)itile + lane * 96 + 3 * (first & (kInTile - 1)));
+    const unsigned w0 = p[0], w1 = p[1], w2 = p[2];      // R0 G0 B0 R1 | G1 B1 R2 G2 | B2 R3 G3 B3
+    const float s = 1.0f / 255.0f;
+    out[0] = f4{(float)(w0 & 0xffu) * s, (float)(w0 >> 24) * s, (float)((w1 >> 16) & 0xffu) * s, (float)((w2 >> 8) & 0xffu) * s};
+    out[1] = f4{(float)((w0 >> 8) & 0xffu) * s, (float)(w1 & 0xffu) * s, (float)(w1 >> 24) * s, (float)((w2 >> 16) & 0xffu) * s};
+    out[2] = f4{(float)((w0 >> 16) & 0xffu) * s, (float)((w1 >> 8) & 0xffu) * s, (float)(w2 & 0xffu) * s, (float)(w2 >> 24) * s};
+    if (first >= W) out[0] = out[1] = out[2] = f4{0.f, 0.f, 0.f, 0.f};
+}
+template <bool U8>
+__device__ __forceinline__ void first_tile3(const Geom &g, lds_float *itile, const float *rp, int lane, f4 out[3]) {
+    if (U8) fill_tile3_u8(g, itile, rp, 0, lane); else fill_tile3(g, itile, rp, 0, lane);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    if (U8) read_tile3_u8(itile, lane, 0, g.W, out); else read_tile3(itile, lane, 0, g.W, out);
+}
+template <bool U8>
+__device__ __forceinline__ void next_tile3x(const Geom &g, lds_float *itile, const float *rp, int lane, int nxt, f4 out[3]) {
+    if (!U8) { next_tile3(g, itile, rp, lane, nxt, out); return; }
+    if ((nxt & (kInTile - 1)) == 0 && nxt < g.W) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+    }
+    read_tile3_u8(itile, lane, nxt, g.W, out);
+    if ((nxt & (kInTile - 1)) == kInTile - 4 && nxt + 4 < g.W) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        fill_tile3_u8(g, itile, rp, (nxt >> 5) + 1, lane);
+    }
+}
+// composite sample -> mode-'L' byte: encode_composite_level (image.py:20-21) then _as_bytes (image.py:7-8)
+__device__ __forceinline__ unsigned char composite_byte(float comp) {
+    const float v = __builtin_fmaf(0.6f, comp, 0.2f);
+    return (unsigned char)__builtin_rintf(255.f * __builtin_fminf(__builtin_fmaxf(v, 0.f), 1.f));
+}
+// byte output tile [64 rows][64 pixels] -> 64-byte row segments, 16 rows per wave-instruction
+__device__ __forceinline__ void flush_tile1_u8(const Geom &g, const lds_float *otile, const float *op, int first_col, int lane) {
+    __builtin_amdgcn_wave_barrier();
+    const int chunk = lane & 3;
+    const int col = first_col + 16 * chunk;
+#pragma nounroll
+    for (int q = 0; q < 4; ++q) {
+        const int row = (lane >> 2) + 16 * q;
+        typedef __attribute__((address_space(1))) f4 global_f4;
+        unsigned char *dst = (unsigned char *)(unsigned long long)ptr_from(row * 4, op);
+        if (dst != nullptr && col < g.W) {   // W % 16 == 0: a 16-byte chunk is inside or outside the row as a whole
+            f4 v = *(const lds_f4 *)((const lds_byte *)otile + row * kOutTileU8 + 16 * chunk);
+            __builtin_nontemporal_store(v, (global_f4 *)(dst + col));
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+// one composite sample into the output tile + the flush when a tile (or the row) is complete
+template <bool U8, int kTile>
+__device__ __forceinline__ void put_composite(const Geom &g, lds_float *otile_base, const float *op, int lane, int wpos, int n7,
+                                              float comp) {
+    const int W = g.W;
+    if (U8) {
+        if (n7 >= 0 && n7 < W) ((lds_byte *)otile_base)[lane * kOutTileU8 + (n7 & (kOutTileU8 - 1))] = composite_byte(comp);
+        if (n7 >= 0 && ((n7 & (kOutTileU8 - 1)) == kOutTileU8 - 1 || n7 == W - 1))
+            flush_tile1_u8(g, otile_base, op, n7 & ~(kOutTileU8 - 1), lane);
+    } else {
+        if (n7 >= 0 && n7 < W) otile_base[lane * kTile + (wpos ^ (n7 & (kTile - 1)))] = comp;
+        if (n7 >= 0 && ((n7 & (kTile - 1)) == kTile - 1 || n7 == W - 1))
+            flush_tile1<kTile>(g, otile_base, op, n7 & ~(kTile - 1), lane);
+    }
+}
+// row pointers of a modulator lane; in the byte mode the strides of Geom count bytes
+template <bool U8>
+__device__ __forceinline__ void mod_rows(const Geom &g, const LaneCall &lc, const float *&rp, const float *&op) {
+    const long long row_stride = g.in_row_stride ? g.in_row_stride : g.W;
+    if (U8) {
+        rp = (const float *)((const unsigned char *)g.in + lc.frame * g.in_frame_stride + (long long)lc.src_row * row_stride);
+        op = lc.store_ok ? (const float *)((unsigned char *)g.out + lc.frame * g.out_frame_stride + (long long)lc.out_row * g.out_row_stride)
+                         : nullptr;
+    } else {
+        rp = g.in + lc.frame * g.in_frame_stride + (long long)lc.src_row * row_stride;
+        op = lc.store_ok ? g.out + lc.frame * g.out_frame_stride + (long long)lc.out_row * g.out_row_stride : nullptr;
+    }
+}
+constexpr int kModLdsFloats = kLdsIn3 + 64 * 16;                          // float mode: 3-plane input tile + output tile
+constexpr int kModLdsFloatsU8 = (kInTile3Bytes + 64 * kOutTileU8) / 4;    // byte mode
+
 // DEPTH = 1: encoder-side line averaging (ColorAveragingModem) needs the previous call's components.
-template <int NP, int SP, int DEPTH>
+// U8: the ImageModem byte boundary fused in (interleaved RGB bytes in, composite bytes out)
+template <int NP, int SP, int DEPTH, bool U8 = false>
 __global__ __launch_bounds__(64, 2) void qam_mod_kernel(const ModArgs<NP> args) {
     constexpr int kTile = 16;
-    __shared__ __attribute__((aligned(16))) float lds_store[kLdsIn3 + 64 * kTile];
+    __shared__ __attribute__((aligned(16))) float lds_store[U8 ? kModLdsFloatsU8 : kModLdsFloats];
     lds_float *itile = (lds_float *)lds_store;
-    lds_float *otile_base = itile + kLdsIn3;
+    lds_float *otile_base = itile + (U8 ? kInTile3Bytes / 4 : kLdsIn3);
     const Geom &g = args.g;
     const ModK<float, NP> &k = args.k;
     const int lane = threadIdx.x;
     const LaneCall lc = locate_call(g, blockIdx.x, DEPTH, lane);
-    const long long row_stride = g.in_row_stride ? g.in_row_stride : g.W;
-    const float *rp = g.in + lc.frame * g.in_frame_stride + (long long)lc.src_row * row_stride;
-    const float *op = lc.store_ok ? g.out + lc.frame * g.out_frame_stride + (long long)lc.out_row * g.out_row_stride : nullptr;
+    const float *rp, *op;
+    mod_rows<U8>(g, lc, rp, op);
     ModLaneK<float> lk;
     {
         int fmod = (int)((g.first_frame + lc.frame) % g.cycle);
@@ -115,18 +223,14 @@ __global__ __launch_bounds__(64, 2) void qam_mod_kernel(const ModArgs<NP> args) 
     float yw[SP + 4];
 #pragma unroll
     for (int j = 0; j < SP + 4; ++j) yw[j] = 0.f;
-    lds_float *otile = otile_base + lane * kTile;
     const int wpos = ((lane >> 1) & (kTile / 4 - 1)) << 2;
     const int W = g.W;
     const int T = (W + SP + 3) & ~3;
-    fill_tile3(g, itile, rp, 0, lane);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_wave_barrier();
     f4 cur[3], nxt[3];
-    read_tile3(itile, lane, 0, W, nxt);
+    first_tile3<U8>(g, itile, rp, lane, nxt);
     for (int tb = 0; tb < T; tb += 4) {
         cur[0] = nxt[0]; cur[1] = nxt[1]; cur[2] = nxt[2];
-        next_tile3(g, itile, rp, lane, tb + 4, nxt);
+        next_tile3x<U8>(g, itile, rp, lane, tb + 4, nxt);
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             const int t = tb + s;
@@ -146,9 +250,7 @@ __global__ __launch_bounds__(64, 2) void qam_mod_kernel(const ModArgs<NP> args) 
             f2 cc = ((const_f2 *)g.carrier2)[nc];
             float car[2] = {cc.x, cc.y};
             float comp = core.step(k, lk, t, yw[s], u, v, car);
-            if (n7 >= 0 && n7 < W) otile[wpos ^ (n7 & (kTile - 1))] = comp;
-            if (n7 >= 0 && ((n7 & (kTile - 1)) == kTile - 1 || n7 == W - 1))
-                flush_tile1<kTile>(g, otile_base, op, n7 & ~(kTile - 1), lane);
+            put_composite<U8, kTile>(g, otile_base, op, lane, wpos, n7, comp);
         }
 #pragma unroll
         for (int j = 0; j < SP; ++j) yw[j] = yw[j + 4];

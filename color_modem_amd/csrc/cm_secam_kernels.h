@@ -21,11 +21,16 @@ struct SecamDemodArgs {
     SecamDemodK<float> k;
 };
 
+// U8: the ImageModem byte boundary fused in, as in the PAL / NTSC decoders (cm_kernels.h: PassCfg::U8): composite bytes
+// enter through (5 (byte / 255) - 1) / 3, interleaved RGB bytes leave; the tiles hold bytes and the strides count bytes.
+template <bool U8>
 __global__ __launch_bounds__(64, 2) void secam_demod_kernel(const SecamDemodArgs args) {
     constexpr int kTile = 16, DEPTH = 1;
-    __shared__ __attribute__((aligned(16))) float lds_store[kLdsIn + 3 * 64 * kTile];
+    __shared__ __attribute__((aligned(16))) float lds_store[U8 ? (kLdsIn + 3 * 64 * kTile) / 4 : kLdsIn + 3 * 64 * kTile];
     lds_float *itile = (lds_float *)lds_store;
-    lds_float *otile_base = itile + kLdsIn;
+    lds_float *otile_base = itile + (U8 ? kLdsIn / 4 : kLdsIn);
+    typedef __attribute__((address_space(3))) unsigned char lds_u8;
+    typedef __attribute__((address_space(3))) unsigned lds_u32;
     const Geom &g = args.g;
     SecamDemodK<float> k = args.k;
     typedef SecamDemod<float>::VP VP;
@@ -34,8 +39,15 @@ __global__ __launch_bounds__(64, 2) void secam_demod_kernel(const SecamDemodArgs
     if (VP::VB) pin_block(k.bpf, false);
     const int lane = threadIdx.x;
     const LaneCall lc = locate_call(g, blockIdx.x, DEPTH, lane);
-    const float *xp = g.in + lc.frame * g.in_frame_stride + (long long)lc.src_row * g.W;
-    const float *op = lc.store_ok ? g.out + lc.frame * g.out_frame_stride + (long long)lc.out_row * g.out_row_stride : nullptr;
+    const float *xp, *op;
+    if (U8) {
+        xp = (const float *)((const unsigned char *)g.in + lc.frame * g.in_frame_stride + (long long)lc.src_row * g.W);
+        op = lc.store_ok ? (const float *)((unsigned char *)g.out + lc.frame * g.out_frame_stride + (long long)lc.out_row * g.out_row_stride)
+                         : nullptr;
+    } else {
+        xp = g.in + lc.frame * g.in_frame_stride + (long long)lc.src_row * g.W;
+        op = lc.store_ok ? g.out + lc.frame * g.out_frame_stride + (long long)lc.out_row * g.out_row_stride : nullptr;
+    }
     SecamDemodLaneK<float> lk;
     {
         int fmod = (int)((g.first_frame + lc.frame) % g.cycle);
@@ -47,9 +59,10 @@ __global__ __launch_bounds__(64, 2) void secam_demod_kernel(const SecamDemodArgs
     float chw[14];
 #pragma unroll
     for (int j = 0; j < 14; ++j) chw[j] = 0.f;
-    lds_float *otile = otile_base + lane * kTile;
+    lds_float *otile = U8 ? (lds_float *)((lds_u8 *)otile_base + lane * 3 * kTile) : otile_base + lane * kTile;
     const int wpos = ((lane >> 1) & (kTile / 4 - 1)) << 2;
     const lds_float *xrow = itile + lane * kInTile;
+    const lds_u8 *xrow8 = (const lds_u8 *)itile + lane * kInTile;
 
     const int W = g.W, P = k.preroll, Lc = W + P;
     const int lat = SecamDemod<float>::latency(k);          // chroma sample n = m - lat
@@ -73,10 +86,17 @@ __global__ __launch_bounds__(64, 2) void secam_demod_kernel(const SecamDemodArgs
         own_prev = own;
         nb_prev = lane_from(idx1, own);
         if (n >= 0 && n < W) {
-            lds_float *tp = otile + (wpos ^ (n & (kTile - 1)));
-            tp[0] = o.r;
-            tp[64 * kTile] = o.g;
-            tp[2 * 64 * kTile] = o.b;
+            if (U8) {   // image.py:7-8: uint8(rint(255 * clip(x, 0, 1))); bytes interleaved R, G, B
+                lds_u8 *tbp = (lds_u8 *)otile + 3 * (n & (kTile - 1));
+                tbp[0] = (unsigned char)__builtin_rintf(255.f * __builtin_fminf(__builtin_fmaxf(o.r, 0.f), 1.f));
+                tbp[1] = (unsigned char)__builtin_rintf(255.f * __builtin_fminf(__builtin_fmaxf(o.g, 0.f), 1.f));
+                tbp[2] = (unsigned char)__builtin_rintf(255.f * __builtin_fminf(__builtin_fmaxf(o.b, 0.f), 1.f));
+            } else {
+                lds_float *tp = otile + (wpos ^ (n & (kTile - 1)));
+                tp[0] = o.r;
+                tp[64 * kTile] = o.g;
+                tp[2 * 64 * kTile] = o.b;
+            }
         }
     };
     auto shift_window = [&]() {
@@ -84,7 +104,7 @@ __global__ __launch_bounds__(64, 2) void secam_demod_kernel(const SecamDemodArgs
         for (int j = 0; j < 10; ++j) chw[j] = chw[j + 4];
     };
 
-    fill_tile(g, itile, xp, 0, lane);
+    if (U8) fill_tile_u8(g, itile, xp, 0, lane); else fill_tile(g, itile, xp, 0, lane);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_wave_barrier();
     // ---- pre-roll: cc[m] = x[P - m] for m < P, in bodies of 4 steps so that the windows keep their phase
@@ -97,7 +117,7 @@ __global__ __launch_bounds__(64, 2) void secam_demod_kernel(const SecamDemodArgs
             if (m >= 0) {
                 int xi = P - m;
                 if (xi > W - 1) xi = W - 1;
-                cc = xrow[xi];
+                cc = U8 ? __builtin_fmaf((float)xrow8[xi], 5.0f / (255.0f * 3.0f), -1.0f / 3.0f) : xrow[xi];
             }
             step(m, cc, 0.f, s);
         }
@@ -105,7 +125,9 @@ __global__ __launch_bounds__(64, 2) void secam_demod_kernel(const SecamDemodArgs
     }
     // ---- main loop over the row samples xi = m - P
     auto read_x = [&](int first) -> f4 {
-        f4 v = *(const lds_f4 *)(xrow + (first & (kInTile - 1)));
+        f4 v;
+        if (U8) v = decode_bytes(*(const lds_u32 *)(xrow8 + (first & (kInTile - 1))));
+        else v = *(const lds_f4 *)(xrow + (first & (kInTile - 1)));
         if (first + 3 >= W) {
             if (first >= W) v.x = 0.f;
             if (first + 1 >= W) v.y = 0.f;
@@ -115,6 +137,20 @@ __global__ __launch_bounds__(64, 2) void secam_demod_kernel(const SecamDemodArgs
         return v;
     };
     auto read_luma = [&](int first) -> f4 {
+        if (U8) {
+            const unsigned char *lb = (const unsigned char *)xp;
+            if (first >= 0 && first + 3 < W) {
+                typedef unsigned u32u __attribute__((aligned(1)));
+                return decode_bytes(*(const u32u *)(lb + first));
+            }
+            f4 r = {0.f, 0.f, 0.f, 0.f};
+            const float a = 5.0f / (255.0f * 3.0f), b = -1.0f / 3.0f;
+            if (first >= 0 && first < W) r.x = __builtin_fmaf((float)lb[first], a, b);
+            if (first + 1 >= 0 && first + 1 < W) r.y = __builtin_fmaf((float)lb[first + 1], a, b);
+            if (first + 2 >= 0 && first + 2 < W) r.z = __builtin_fmaf((float)lb[first + 2], a, b);
+            if (first + 3 >= 0 && first + 3 < W) r.w = __builtin_fmaf((float)lb[first + 3], a, b);
+            return r;
+        }
         if (first >= 0 && first + 3 < W) {
             f4u v = *(const f4u *)(xp + first);
             return f4{v.x, v.y, v.z, v.w};
@@ -139,8 +175,10 @@ __global__ __launch_bounds__(64, 2) void secam_demod_kernel(const SecamDemodArgs
             step(P + xb + s, xv[s], lw[s], s);
             if (s == s_flush) {
                 const int n = xb + s - lat_out;
-                if (n >= 0 && ((n & (kTile - 1)) == kTile - 1 || n == W - 1))
-                    flush_tile<kTile>(g, otile_base, op, n & ~(kTile - 1), lane);
+                if (n >= 0 && ((n & (kTile - 1)) == kTile - 1 || n == W - 1)) {
+                    if (U8) flush_tile_u8(g, otile_base, op, n & ~(kTile - 1), lane);
+                    else flush_tile<kTile>(g, otile_base, op, n & ~(kTile - 1), lane);
+                }
             }
         }
         shift_window();
@@ -153,7 +191,7 @@ __global__ __launch_bounds__(64, 2) void secam_demod_kernel(const SecamDemodArgs
         if ((nxt & (kInTile - 1)) == kInTile - 4 && nxt + 4 < W) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_wave_barrier();
-            fill_tile(g, itile, xp, (nxt >> 5) + 1, lane);
+            if (U8) fill_tile_u8(g, itile, xp, (nxt >> 5) + 1, lane); else fill_tile(g, itile, xp, (nxt >> 5) + 1, lane);
         }
     }
 }
@@ -164,19 +202,18 @@ struct SecamModArgs {
 };
 
 // SP = shift of the pre-correction low-pass (register window of the luma delay); DEPTH = 1: line averaging
-template <int SP, int DEPTH>
+template <int SP, int DEPTH, bool U8 = false>
 __global__ __launch_bounds__(64, 2) void secam_mod_kernel(const SecamModArgs args) {
     constexpr int kTile = 16;
-    __shared__ __attribute__((aligned(16))) float lds_store[kLdsIn3 + 64 * kTile];
+    __shared__ __attribute__((aligned(16))) float lds_store[U8 ? kModLdsFloatsU8 : kModLdsFloats];
     lds_float *itile = (lds_float *)lds_store;
-    lds_float *otile_base = itile + kLdsIn3;
+    lds_float *otile_base = itile + (U8 ? kInTile3Bytes / 4 : kLdsIn3);
     const Geom &g = args.g;
     const SecamModK<float, double> &k = args.k;
     const int lane = threadIdx.x;
     const LaneCall lc = locate_call(g, blockIdx.x, DEPTH, lane);
-    const long long row_stride = g.in_row_stride ? g.in_row_stride : g.W;
-    const float *rp = g.in + lc.frame * g.in_frame_stride + (long long)lc.src_row * row_stride;
-    const float *op = lc.store_ok ? g.out + lc.frame * g.out_frame_stride + (long long)lc.out_row * g.out_row_stride : nullptr;
+    const float *rp, *op;
+    mod_rows<U8>(g, lc, rp, op);
     SecamModLaneK<float, double> lk;
     {
         int fmod = (int)((g.first_frame + lc.frame) % g.cycle);
@@ -188,18 +225,14 @@ __global__ __launch_bounds__(64, 2) void secam_mod_kernel(const SecamModArgs arg
     float yw[SP + 4];
 #pragma unroll
     for (int j = 0; j < SP + 4; ++j) yw[j] = 0.f;
-    lds_float *otile = otile_base + lane * kTile;
     const int wpos = ((lane >> 1) & (kTile / 4 - 1)) << 2;
     const int W = g.W;
     const int T = (W + SP + 3) & ~3;
-    fill_tile3(g, itile, rp, 0, lane);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_wave_barrier();
     f4 cur[3], nxt[3];
-    read_tile3(itile, lane, 0, W, nxt);
+    first_tile3<U8>(g, itile, rp, lane, nxt);
     for (int tb = 0; tb < T; tb += 4) {
         cur[0] = nxt[0]; cur[1] = nxt[1]; cur[2] = nxt[2];
-        next_tile3(g, itile, rp, lane, tb + 4, nxt);
+        next_tile3x<U8>(g, itile, rp, lane, tb + 4, nxt);
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             const int t = tb + s;
@@ -218,9 +251,7 @@ __global__ __launch_bounds__(64, 2) void secam_mod_kernel(const SecamModArgs arg
             yw[SP + s] = y;
             const int n7 = t - SP;
             float comp = st.step(k, lk, t, yw[s], d);
-            if (n7 >= 0 && n7 < W) otile[wpos ^ (n7 & (kTile - 1))] = comp;
-            if (n7 >= 0 && ((n7 & (kTile - 1)) == kTile - 1 || n7 == W - 1))
-                flush_tile1<kTile>(g, otile_base, op, n7 & ~(kTile - 1), lane);
+            put_composite<U8, kTile>(g, otile_base, op, lane, wpos, n7, comp);
         }
 #pragma unroll
         for (int j = 0; j < SP; ++j) yw[j] = yw[j + 4];

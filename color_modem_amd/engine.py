@@ -70,7 +70,7 @@ class Engine(object):
 
     def demodulate_frames_u8(self, composite8, first_frame=0, out=None):
         """uint8 composite [F, H, W] -> interleaved uint8 rgb [F, H, W, 3] with ImageModem's level mapping and
-        rounding fused into the kernel (PAL / NTSC decoders; raises NotImplementedError otherwise)."""
+        rounding fused into the kernel (every decoder except the notch / minavg instances: NotImplementedError there)."""
         torch = _torch()
         was_numpy = isinstance(composite8, numpy.ndarray)
         t = torch.from_numpy(numpy.ascontiguousarray(composite8, dtype=numpy.uint8)) if was_numpy else composite8
@@ -94,6 +94,23 @@ class Engine(object):
         stream = torch.cuda.current_stream(x.device).cuda_stream
         _native.check(_native.lib().cm_modulate_frames(self._plan, x.data_ptr(), out.data_ptr(), n,
                                                        int(first_frame), stream))
+        return out.cpu().numpy() if was_numpy else out
+
+    def modulate_frames_u8(self, rgb8, first_frame=0, out=None):
+        """interleaved uint8 rgb [F, H, W, 3] -> uint8 composite [F, H, W]: ImageModem.modulate's byte / 255 on the way in
+        and encode_composite_level + clamp + rint on the way out fused into the kernel (widths that are multiples of 16)."""
+        torch = _torch()
+        was_numpy = isinstance(rgb8, numpy.ndarray)
+        t = torch.from_numpy(numpy.ascontiguousarray(rgb8, dtype=numpy.uint8)) if was_numpy else rgb8
+        if t.dtype != torch.uint8 or tuple(t.shape[1:]) != (self.height, self.width, 3):
+            raise ValueError('expected uint8 [frames, %d, %d, 3]' % (self.height, self.width))
+        t = t.cuda().contiguous() if not t.is_cuda else t.contiguous()
+        n = t.shape[0]
+        if out is None:
+            out = torch.empty((n, self.height, self.width), dtype=torch.uint8, device=t.device)
+        stream = torch.cuda.current_stream(t.device).cuda_stream
+        _native.check(_native.lib().cm_modulate_frames_u8(self._plan, t.data_ptr(), out.data_ptr(), n,
+                                                          int(first_frame), stream))
         return out.cpu().numpy() if was_numpy else out
 
     # ---- runs (the per-row protocol) ----------------------------------------------------------

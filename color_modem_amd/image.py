@@ -49,12 +49,21 @@ class ImageModem(object):
         """rgb [F, 3, H, W] float32 -> composite [F, H, W] float32."""
         return self._engine().modulate_frames(rgb, first_frame)
 
+    def modulate_frames_u8(self, rgb8, first_frame=0):
+        """rgb uint8 [F, H, W, 3] -> composite uint8 [F, H, W], the byte conversions of ImageModem fused into the kernel."""
+        return self._engine().modulate_frames_u8(rgb8, first_frame)
+
     # ---- PIL API (one image = one frame) ---------------------------------------------------------
     def modulate(self, img, frame=0):
         from PIL import Image
         if img.mode != 'RGB':
             img = img.convert('RGB')
         rgb8 = numpy.frombuffer(img.tobytes(), dtype=numpy.uint8).reshape(img.height, img.width, 3)
+        try:  # byte boundary fused into the kernel (widths that are multiples of 16)
+            comp8 = self._engine().modulate_frames_u8(rgb8[None].copy(), frame)[0]
+            return Image.frombytes('L', (img.width, img.height), numpy.ascontiguousarray(comp8).tobytes())
+        except NotImplementedError:
+            pass
         rgb = (rgb8.astype(numpy.float64) / 255.0).astype(numpy.float32).transpose(2, 0, 1)[None]
         comp = self.modulate_frames(numpy.ascontiguousarray(rgb), frame)[0]
         data = _as_bytes(self.encode_composite_level(comp.astype(numpy.float64)))
@@ -65,7 +74,7 @@ class ImageModem(object):
         if img.mode != 'L':
             img = img.convert('L')
         comp8 = numpy.frombuffer(img.tobytes(), dtype=numpy.uint8).reshape(img.height, img.width).copy()
-        try:  # byte boundary fused into the kernel where this stack has it (PAL / NTSC)
+        try:  # byte boundary fused into the kernel where this stack has an instance (all but notch / minavg)
             rgb8 = self._engine().demodulate_frames_u8(comp8[None], frame)[0]
             return Image.frombytes('RGB', (img.width, img.height), numpy.ascontiguousarray(rgb8).tobytes())
         except NotImplementedError:

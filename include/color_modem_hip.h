@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define CM_ABI_VERSION 3
+#define CM_ABI_VERSION 4
 
 enum cm_status {
     CM_OK = 0,
@@ -173,9 +173,16 @@ int cm_modulate_frames(const cm_plan *plan, const float *rgb, float *composite, 
 /* The same with ImageModem's byte boundary fused in (image.py:58-84): composite8 is uint8 [frames][height][width]
  * (PIL mode 'L'), decoded as (5 * (byte / 255) - 1) / 3 (image.py:24-25, 62); rgb8 is interleaved uint8
  * [frames][height][width][3] (PIL mode 'RGB') = rint(255 * clip(x, 0, 1)) (image.py:7-8).  4 bytes per pixel
- * cross HBM instead of 16.  PAL / NTSC decoders. */
+ * cross HBM instead of 16.  Every decoder (PAL / NTSC / SECAM). */
 int cm_demodulate_frames_u8(const cm_plan *plan, const uint8_t *composite8, uint8_t *rgb8, int64_t n_frames,
                             int64_t first_frame, void *stream);
+
+/* The encoder side of the same boundary (image.py:27-56): rgb8 is interleaved uint8 [frames][height][width][3] (PIL mode
+ * 'RGB'), entering as byte / 255 (image.py:43-45); composite8 is uint8 [frames][height][width] (PIL mode 'L') =
+ * rint(255 * clip(0.6 x + 0.2, 0, 1)) (encode_composite_level image.py:20-21, _as_bytes image.py:7-8).  Every encoder;
+ * width must be a multiple of 16 (rows are moved as 16-byte vectors), else CM_ERR_UNSUPPORTED. */
+int cm_modulate_frames_u8(const cm_plan *plan, const uint8_t *rgb8, uint8_t *composite8, int64_t n_frames,
+                          int64_t first_frame, void *stream);
 
 /* One run: n_calls consecutive calls Modem.demodulate(frame, first_line + 2 i, composite[i]),
  * i = 0 .. n_calls-1, where the first of them is the k0-th call since the modem's last reset

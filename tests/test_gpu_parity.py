@@ -354,6 +354,48 @@ def test_fused_uint8_matches_float_path(stack, size, n_frames, first):
     assert diff.max() <= 1 and (diff > 0).mean() < 2e-3, (diff.max(), (diff > 0).mean())
 
 
+@pytest.mark.parametrize('stack,size,n_frames,first', [('pal_s', (720, 576), 2, 1), ('ntsc', (720, 480), 2, 0), ('ntsc_avg', (720, 18), 3, 1),
+                                                       ('secam', (720, 576), 2, 3), ('secam_avg', (720, 17), 2, 2), ('pal_s', (704, 9), 2, 3),
+                                                       ('ntsc_a', (720, 24), 2, 1)])
+def test_fused_uint8_modulate_matches_float_path(stack, size, n_frames, first):
+    """cm_modulate_frames_u8 == host-side byte / 255 -> float kernel -> host-side encode_composite_level + _as_bytes (<= 1 LSB
+    at the knife edge of rint on < 0.2 % of the samples)."""
+    from color_modem_amd.image import _as_bytes
+    im = image.ImageModem(stacks.make(stack, size))
+    rgb8 = numpy.random.default_rng(5).integers(0, 256, size=(n_frames, size[1], size[0], 3), dtype=numpy.uint8)
+    rgb8[:, :, 1:] = (rgb8[:, :, 1:].astype(int) + rgb8[:, :, :-1]) // 2     # some horizontal correlation
+    got = im.modulate_frames_u8(rgb8, first_frame=first)
+    assert got.dtype == numpy.uint8 and got.shape == (n_frames, size[1], size[0])
+    rgb = (rgb8.astype(numpy.float64) / 255.0).astype(numpy.float32).transpose(0, 3, 1, 2)
+    comp = im.modulate_frames(numpy.ascontiguousarray(rgb), first_frame=first)
+    want = _as_bytes(image.ImageModem.encode_composite_level(comp.astype(numpy.float64)))
+    diff = numpy.abs(got.astype(int) - want.astype(int))
+    assert diff.max() <= 1 and (diff > 0).mean() < 2e-3, (diff.max(), (diff > 0).mean())
+
+
+def test_fused_uint8_modulate_needs_width_multiple_of_16():
+    im = image.ImageModem(stacks.make('pal_s', (712, 8)))
+    with pytest.raises(NotImplementedError):
+        im.modulate_frames_u8(numpy.zeros((1, 8, 712, 3), numpy.uint8))
+    from PIL import Image      # the PIL entry point falls back to the float kernel
+    out = im.modulate(Image.frombytes('RGB', (712, 8), bytes(712 * 8 * 3)), 0)
+    assert out.size == (712, 8)
+
+
+@pytest.mark.parametrize('size,n_frames,first', [((720, 576), 2, 1), ((720, 21), 3, 4)])
+def test_fused_uint8_secam_demodulate_matches_float_path(size, n_frames, first):
+    from color_modem_amd.image import _as_bytes
+    im = image.ImageModem(stacks.make('secam', size))
+    rgb = testing.synthetic_rgb(n_frames, size[1], size[0], seed=41)
+    comp = im.modulate_frames(rgb, first_frame=first)
+    comp8 = _as_bytes(image.ImageModem.encode_composite_level(comp.astype(numpy.float64)))
+    got = im.demodulate_frames_u8(comp8, first_frame=first)
+    ref_in = image.ImageModem.decode_composite_level(comp8.astype(numpy.float64) / 255.0).astype(numpy.float32)
+    want = _as_bytes(im.demodulate_frames(ref_in, first_frame=first).astype(numpy.float64)).transpose(0, 2, 3, 1)
+    diff = numpy.abs(got.astype(int) - want.astype(int))
+    assert diff.max() <= 1 and (diff > 0).mean() < 2e-3, (diff.max(), (diff > 0).mean())
+
+
 # ---- component-level protocol: modulate_components / demodulate_components ---------------------------------------------
 def _rows_through(fn_dev, fn_orc, seq, rows):
     worst = 0.0
