@@ -33,10 +33,11 @@ __global__ __launch_bounds__(64, 2) void secam_demod_kernel(const SecamDemodArgs
     typedef __attribute__((address_space(3))) unsigned lds_u32;
     const Geom &g = args.g;
     SecamDemodK<float> k = args.k;
-    typedef SecamDemod<float>::VP VP;
+    typedef SecamDemodPk::VP VP;
     if (VP::VT) pin_block(k.taps);
-    if (VP::VL) pin_block(k.lpf, true);
     if (VP::VB) pin_block(k.bpf, false);
+    SecamDemodKPk kp;      // the quadrature low-pass runs on the pair (I, Q) (cm_stages_pk.h)
+    kp.load(k);
     const int lane = threadIdx.x;
     const LaneCall lc = locate_call(g, blockIdx.x, DEPTH, lane);
     const float *xp, *op;
@@ -54,7 +55,7 @@ __global__ __launch_bounds__(64, 2) void secam_demod_kernel(const SecamDemodArgs
         lk = ((const SecamDemodLaneK<float> *)g.lanes)[((long long)fmod * 3 + lc.regime) * g.n_lines + lc.line];
     }
     const int idx1 = ((lane + 63) & 63) * 4;
-    SecamDemod<float> st;
+    SecamDemodPk st;
     st.reset();
     float chw[14];
 #pragma unroll
@@ -65,7 +66,7 @@ __global__ __launch_bounds__(64, 2) void secam_demod_kernel(const SecamDemodArgs
     const lds_u8 *xrow8 = (const lds_u8 *)itile + lane * kInTile;
 
     const int W = g.W, P = k.preroll, Lc = W + P;
-    const int lat = SecamDemod<float>::latency(k);          // chroma sample n = m - lat
+    const int lat = SecamDemod<float>::latency(k);          // chroma sample n = m - lat (the packed form keeps the schedule)
     const int d_luma = lat + 1 - P - k.s_y;                 // luma filter input x[xi - d_luma] at main-loop sample xi
     const int lat_out = d_luma + k.s_y;                     // output sample n' = xi - lat_out
     const int s_flush = (lat_out + 3) & 3;
@@ -76,9 +77,8 @@ __global__ __launch_bounds__(64, 2) void secam_demod_kernel(const SecamDemodArgs
         int m2 = m - k.s_b - 10;
         m2 = m2 < 0 ? 0 : (m2 > Lc - 1 ? Lc - 1 : m2);
         f4 c = ((const_f4 *)g.carrier4)[m2];
-        float car[4] = {c.x, c.y, c.z, c.w};
         float ch_out;
-        float own = st.chroma_step(k, lk, m, cc, chw[sub], car, ch_out);
+        float own = st.chroma_step(k, kp, lk, m, cc, chw[sub], pf2{c.x, c.y}, pf2{c.z, c.w}, ch_out);
         chw[10 + sub] = ch_out;
         const int n = m - 1 - lat;                          // the back end runs one sample behind the exchange
         float luma = st.luma_step(k, n, x_l);

@@ -417,6 +417,122 @@ struct DemodBackPk {
     }
 };
 
+// =============================================================================================
+// SECAM decoder with the two quadrature channels as one pair (cm_stages.h: SecamDemod::chroma_step is the
+// definition; this is the same stream with (I, Q) = data_up * (cos, -sin) carried through the low-pass two at a time).
+// The phase step between consecutive I/Q samples is small for an FM signal inside the channel (|d| < 0.15 rad at
+// +-500 kHz): atan(r), r = cross / dot, from five odd terms when dot > 0 and |r| <= 1/4 (truncation 2e-8 rad,
+// v_rcp_f32 1 ulp), the library atan2f otherwise (noise, unlocked input).
+// =============================================================================================
+__device__ __forceinline__ float phase_step_fast(float i0, float q0, float i1, float q1) {
+    // angle of (i1 + j q1) * conj(i0 + j q0); the cross product with an error-free correction (SecamDemod::phase_step)
+    const float t = q0 * i1;
+    const float e = __builtin_fmaf(-q0, i1, t);
+    const float cross = __builtin_fmaf(i0, q1, -t) + e;
+    const float dot = __builtin_fmaf(i0, i1, q0 * q1);
+    if (dot > 0.f && __builtin_fabsf(cross) <= 0.25f * dot) {
+        const float r = cross * __builtin_amdgcn_rcpf(dot);
+        const float z = r * r;
+        float p = __builtin_fmaf(z, 1.0f / 9.0f, -1.0f / 7.0f);
+        p = __builtin_fmaf(z, p, 1.0f / 5.0f);
+        p = __builtin_fmaf(z, p, -1.0f / 3.0f);
+        return __builtin_fmaf(r * z, p, r);
+    }
+    return atan2f(cross, dot);
+}
+
+struct SecamDemodKPk {   // uniform blocks of the chroma path in VGPR pairs
+    TapsPk taps;
+    SosPk<3> lpf;
+    __device__ __forceinline__ void load(const SecamDemodK<float> &k) {
+        taps.load(k.taps);
+        lpf.load(k.lpf, false);
+    }
+};
+
+struct SecamDemodPk {
+    typedef VPolicy<CM_V_SECAM> VP;
+    IirState<float, 3> bpf, ybs;
+    IirState<float, 1> bell;
+    IirStatePk<3> lp;               // (I, Q)
+    IirState<float, 1> deemph;
+    HalfbandChain<float> up, dn;
+    float cc_last, x_last;
+    pf2 p_last, iq_prev;
+    int have_prev;
+
+    __device__ __forceinline__ void reset() {
+        bpf.reset(); ybs.reset(); bell.reset(); lp.reset(); deemph.reset();
+        up.reset(); dn.reset();
+        cc_last = x_last = 0.f;
+        p_last = iq_prev = pf2{0.f, 0.f};
+        have_prev = 0;
+    }
+    // car_e / car_o: {cos, sin} of the FM reference at 2x samples 2 m2 and 2 m2 + 1 (SGPR pairs)
+    __device__ __forceinline__ float chroma_step(const SecamDemodK<float> &k, const SecamDemodKPk &kp, const SecamDemodLaneK<float> &lk, int m,
+                                                 float cc_now, float ch_d10, pf2 car_e, pf2 car_o, float &ch_out) {
+        const int W = k.width, Lc = k.width + k.preroll;
+        const int m1 = m - k.s_b, m2 = m1 - 10, m3 = m2 - k.q_l, m4 = m3 - 9, n = m4 - k.preroll;
+        float ch = 0.f;
+        if (m >= 0 && m < Lc + k.s_b) {
+            if (m == Lc - 1) cc_last = cc_now;
+            if (m >= Lc) cc_now = cc_last;
+            float b = iir_bp<VP::VB>(bpf, k.bpf, cc_now);
+            if (m1 >= 0) ch = k.has_bell ? iir_bp<false>(bell, k.bell, b) : b;
+        }
+        if (m1 < 0 || m1 >= Lc) ch = 0.f;
+        ch_out = ch;
+        const float a_odd = up.template push<VP::VT>(k.taps, ch);
+        const float a_even = k.taps.c0 * ch_d10;
+        // data_up = cos part - j sin part (secam.py:143): the sign of Q rides on the pair (1, -1)
+        const pf2 sgn = {1.f, -1.f};
+        pf2 p_e = pk_mul(pk_mul_bs<0>(pf2{a_even, a_even}, car_e), sgn);
+        pf2 p_o = pk_mul(pk_mul_bs<0>(pf2{a_odd, a_odd}, car_o), sgn);
+        float f_e = 0.f, f_o = 0.f;
+        if (m2 >= 0 && m2 < Lc + k.q_l) {
+            if (m2 == Lc - 1) p_last = p_o;
+            if (m2 >= Lc) p_e = p_o = p_last;
+            const pf2 y0 = iir_sym_pk<0, 3>(lp, kp.lpf, p_e);
+            const pf2 y1 = iir_sym_pk<0, 3>(lp, kp.lpf, p_o);
+            if (m3 >= 0 && m3 < Lc) {
+                const float d_e = have_prev ? phase_step_fast(iq_prev.x, iq_prev.y, y0.x, y0.y) : 0.f;  // secam.py:147: first step is 0
+                const float d_o = phase_step_fast(y0.x, y0.y, y1.x, y1.y);
+                have_prev = 1;
+                iq_prev = y1;
+                f_e = __builtin_fmaf(d_e, k.two_over_pi, k.fc);
+                f_o = __builtin_fmaf(d_o, k.two_over_pi, k.fc);
+            }
+        }
+        float f2 = dn.template push_pair<VP::VT>(k.taps, f_e, f_o);   // 2 * resample_poly(frequencies_up, 1, 2)[m4]
+        float c = 0.f;
+        if (n >= 0 && n < W) {
+            f2 = f2 < k.f2_min ? k.f2_min : (f2 > k.f2_max ? k.f2_max : f2);   // secam.py:290
+            c = iir_gen<false>(deemph, k.deemph, __builtin_fmaf(f2, lk.scale, lk.offset));   // secam.py:291-296
+        }
+        return c;
+    }
+    __device__ __forceinline__ float luma_step(const SecamDemodK<float> &k, int n, float x_in) {
+        const int W = k.width, j = n + k.s_y;
+        float y = 0.f;
+        if (j >= 0 && j < W + k.s_y) {
+            if (j == W - 1) x_last = x_in;
+            if (j >= W) x_in = x_last;
+            y = iir_sym<false>(ybs, k.ybs, x_in);
+        }
+        return y * k.luma_gain;
+    }
+    __device__ __forceinline__ Rgb<float> finish(const SecamDemodK<float> &k, const SecamDemodLaneK<float> &lk, float luma, float own, float prev) const {
+        prev = prev * lk.w_prev;
+        const float dr = lk.own_is_db != 0.f ? prev : own;   // secam.py:297-300
+        const float db = lk.own_is_db != 0.f ? own : prev;
+        Rgb<float> o;
+        o.r = fmaf_(k.m[0][0], luma, fmaf_(k.m[0][1], dr, k.m[0][2] * db));
+        o.g = fmaf_(k.m[1][0], luma, fmaf_(k.m[1][1], dr, k.m[1][2] * db));
+        o.b = fmaf_(k.m[2][0], luma, fmaf_(k.m[2][1], dr, k.m[2][2] * db));
+        return o;
+    }
+};
+
 }  // namespace cm
 #endif
 #endif
