@@ -543,7 +543,7 @@ __device__ __forceinline__ void run_lane(const Geom &g, const DemodK<float, type
     const int s_flush = (lat_out + 3) & 3;
 #ifdef CM_DIAG
     unsigned long long d_flush = 0, d_fill = 0, d_xread = 0, d_luma = 0, d_sub = 0;
-    const unsigned long long d_begin = cm_stamp();
+    const unsigned long long d_begin = cm_stamp(), d_rbegin = cm_realtime();
 #endif
     auto maybe_flush = [&](int t) {
         const int n7 = t - lat_out;
@@ -640,6 +640,7 @@ __device__ __forceinline__ void run_lane(const Geom &g, const DemodK<float, type
     if (g.diag && lane == 0 && !g.sparse) {
         unsigned long long *d = g.diag + 8ull * block;
         d[0] = cm_stamp() - d_begin; d[1] = d_flush; d[2] = d_fill; d[3] = d_xread; d[4] = d_luma; d[5] = d_sub;
+        d[6] = cm_realtime() - d_rbegin;
     }
 #endif
 }
@@ -1053,12 +1054,6 @@ __global__ __launch_bounds__(128, CM_PAIR_WAVES_PER_SIMD) void demod_pair_kernel
     const int role = CM_DEV_ROLE;
 #else
     const int role = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
-#endif
-#ifdef CM_EXP_STAGGER   /* experiment: de-phase the workgroups' flushes */
-    {
-        const int ph = (int)(blockIdx.x >> 3) & 3;
-        for (int i = 0; i < ph; ++i) __builtin_amdgcn_s_sleep(CM_EXP_STAGGER);
-    }
 #endif
     if constexpr (!std::is_same<First, NoPass>::value) {
         if ((int)blockIdx.x < n_first) {

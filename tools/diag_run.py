@@ -17,3 +17,5 @@ tot = d[:, 0]
 print('workgroups', len(d), 'mean total cycles %.0f (min %.0f max %.0f)' % (tot.mean(), tot.min(), tot.max()))
 for i, n in enumerate(['total', 'flush(+drain)', 'fill issue + tile wait', 'x read (LDS latency)', 'luma vmcnt wait', 'substeps']):
     print('  %-26s %10.0f  %.1f %%' % (n, d[:, i].mean(), 100 * d[:, i].mean() / tot.mean()))
+if d[:, 6].max() > 0:
+    print('in-kernel clock: %.3f GHz (d s_memtime / d s_memrealtime x 100 MHz, median); lifetime %.1f us' % (numpy.median(d[:, 0] / d[:, 6]) * 0.1, numpy.median(d[:, 6]) / 100))
