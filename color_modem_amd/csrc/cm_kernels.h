@@ -155,6 +155,77 @@ struct NoPass {
     static constexpr int kLdsFloats = 0;
 };
 
+// uint8 composite sample -> level-decoded float (image.py:24-25, 62)
+__device__ __forceinline__ f4 decode_bytes(unsigned w) {
+    const float a = 5.0f / (255.0f * 3.0f), b = -1.0f / 3.0f;
+    f4 v;
+    v.x = __builtin_fmaf((float)(w & 0xffu), a, b);
+    v.y = __builtin_fmaf((float)((w >> 8) & 0xffu), a, b);
+    v.z = __builtin_fmaf((float)((w >> 16) & 0xffu), a, b);
+    v.w = __builtin_fmaf((float)(w >> 24), a, b);
+    return v;
+}
+
+// x_l[first .. first + 3] of the luma source row lp (the second visit of the own or the previous row), zero outside
+// the row.  check = false: the caller knows the four samples lie inside.  U8: the row holds bytes (level-decoded here).
+template <bool U8>
+__device__ __forceinline__ f4 load_luma(const float *lp, int first, bool check, int W) {
+#ifdef CM_EXP_NO_LUMA   /* timing experiment (profiles/r01_pair_notes.md) */
+    return f4{0.1f, 0.2f, 0.3f, 0.4f};
+#endif
+    if (U8) {
+        const unsigned char *lb = (const unsigned char *)lp;
+        if (!check || (first >= 0 && first + 3 < W)) {
+            typedef unsigned u32u __attribute__((aligned(1)));
+            return decode_bytes(*(const u32u *)(lb + first));
+        }
+        f4 r = {0.f, 0.f, 0.f, 0.f};
+        if (first + 3 >= 0 && first < W) {
+            unsigned w = 0;
+            if (first >= 0 && first < W) w |= lb[first];
+            if (first + 1 >= 0 && first + 1 < W) w |= (unsigned)lb[first + 1] << 8;
+            if (first + 2 >= 0 && first + 2 < W) w |= (unsigned)lb[first + 2] << 16;
+            if (first + 3 >= 0 && first + 3 < W) w |= (unsigned)lb[first + 3] << 24;
+            f4 d = decode_bytes(w);
+            if (first >= 0 && first < W) r.x = d.x;
+            if (first + 1 >= 0 && first + 1 < W) r.y = d.y;
+            if (first + 2 >= 0 && first + 2 < W) r.z = d.z;
+            if (first + 3 >= 0 && first + 3 < W) r.w = d.w;
+        }
+        return r;
+    }
+    if (!check || (first >= 0 && first + 3 < W)) {
+        f4u v = *(const f4u *)(lp + first);
+        return f4{v.x, v.y, v.z, v.w};
+    }
+    f4 r = {0.f, 0.f, 0.f, 0.f};
+    if (first + 3 >= 0 && first < W) {
+        if (first >= 0 && first < W) r.x = lp[first];
+        if (first + 1 >= 0 && first + 1 < W) r.y = lp[first + 1];
+        if (first + 2 >= 0 && first + 2 < W) r.z = lp[first + 2];
+        if (first + 3 >= 0 && first + 3 < W) r.w = lp[first + 3];
+    }
+    return r;
+}
+
+// One output sample into this lane's row of the output tile (float: three quad-swizzled planes; U8: interleaved R, G, B
+// bytes = uint8(rint(255 * clip(x, 0, 1))), image.py:7-8).
+template <bool U8, int kTile>
+__device__ __forceinline__ void put_rgb(lds_float *otile, int wpos, int n7, const Rgb<float> &o) {
+    if constexpr (U8) {
+        typedef __attribute__((address_space(3))) unsigned char lds_u8;
+        lds_u8 *tb = (lds_u8 *)otile + 3 * (n7 & (kTile - 1));   // otile: this lane's 48-byte row
+        tb[0] = (unsigned char)__builtin_rintf(255.f * __builtin_fminf(__builtin_fmaxf(o.r, 0.f), 1.f));
+        tb[1] = (unsigned char)__builtin_rintf(255.f * __builtin_fminf(__builtin_fmaxf(o.g, 0.f), 1.f));
+        tb[2] = (unsigned char)__builtin_rintf(255.f * __builtin_fminf(__builtin_fmaxf(o.b, 0.f), 1.f));
+    } else {
+        lds_float *tp = otile + (wpos ^ (n7 & (kTile - 1)));
+        tp[0] = o.r;
+        tp[64 * kTile] = o.g;
+        tp[2 * 64 * kTile] = o.b;
+    }
+}
+
 template <class Cfg>
 struct DemodLane {
     typedef typename Cfg::S S;
@@ -210,34 +281,10 @@ struct DemodLane {
 #pragma unroll
         for (int j = SP - 1; j > 0; --j) { ud[j] = ud[j - 1]; vd[j] = vd[j - 1]; }
         if (SP > 0) { ud[0] = u; vd[0] = v; }
-        if (!EDGE || (n7 >= 0 && n7 < W)) {
-            if constexpr (Cfg::U8) {
-                // image.py:7-8: uint8(rint(255 * clip(x, 0, 1))); bytes interleaved R, G, B, 48 per tile row
-                typedef __attribute__((address_space(3))) unsigned char lds_u8;
-                lds_u8 *tb = (lds_u8 *)otile + 3 * (n7 & (kTile - 1));   // otile: this lane's 48-byte row
-                tb[0] = (unsigned char)__builtin_rintf(255.f * __builtin_fminf(__builtin_fmaxf(o.r, 0.f), 1.f));
-                tb[1] = (unsigned char)__builtin_rintf(255.f * __builtin_fminf(__builtin_fmaxf(o.g, 0.f), 1.f));
-                tb[2] = (unsigned char)__builtin_rintf(255.f * __builtin_fminf(__builtin_fmaxf(o.b, 0.f), 1.f));
-            } else {
-                lds_float *tp = otile + (wpos ^ (n7 & (kTile - 1)));
-                tp[0] = o.r;
-                tp[64 * kTile] = o.g;
-                tp[2 * 64 * kTile] = o.b;
-            }
-        }
+        if (!EDGE || (n7 >= 0 && n7 < W)) put_rgb<Cfg::U8, kTile>(otile, wpos, n7, o);
     }
 };
 
-// uint8 composite sample -> level-decoded float (image.py:24-25, 62)
-__device__ __forceinline__ f4 decode_bytes(unsigned w) {
-    const float a = 5.0f / (255.0f * 3.0f), b = -1.0f / 3.0f;
-    f4 v;
-    v.x = __builtin_fmaf((float)(w & 0xffu), a, b);
-    v.y = __builtin_fmaf((float)((w >> 8) & 0xffu), a, b);
-    v.z = __builtin_fmaf((float)((w >> 16) & 0xffu), a, b);
-    v.w = __builtin_fmaf((float)(w >> 24), a, b);
-    return v;
-}
 
 // Byte variant of flush_tile: the tile row of a lane is 16 pixels x 3 bytes; 16 rows x 48 bytes per wave-instruction.
 __device__ __forceinline__ void flush_tile_u8(const Geom &g, const lds_float *otile, const float *op, int first_col, int lane) {
@@ -472,42 +519,7 @@ __device__ __forceinline__ void run_lane(const Geom &g, const DemodK<float, type
     };
     auto read_luma = [&](int first, bool check) -> f4 {  // x_l[first .. first + 3], zero outside the row
         if (BSF) return f4{0.f, 0.f, 0.f, 0.f};
-#ifdef CM_EXP_NO_LUMA
-        return f4{0.1f, 0.2f, 0.3f, 0.4f};
-#endif
-        if (U8) {
-            const unsigned char *lb = (const unsigned char *)L.lp;
-            if (!check || (first >= 0 && first + 3 < W)) {
-                typedef unsigned u32u __attribute__((aligned(1)));
-                return decode_bytes(*(const u32u *)(lb + first));
-            }
-            f4 r = {0.f, 0.f, 0.f, 0.f};
-            if (first + 3 >= 0 && first < W) {
-                unsigned w = 0;
-                if (first >= 0 && first < W) w |= lb[first];
-                if (first + 1 >= 0 && first + 1 < W) w |= (unsigned)lb[first + 1] << 8;
-                if (first + 2 >= 0 && first + 2 < W) w |= (unsigned)lb[first + 2] << 16;
-                if (first + 3 >= 0 && first + 3 < W) w |= (unsigned)lb[first + 3] << 24;
-                f4 d = decode_bytes(w);
-                if (first >= 0 && first < W) r.x = d.x;
-                if (first + 1 >= 0 && first + 1 < W) r.y = d.y;
-                if (first + 2 >= 0 && first + 2 < W) r.z = d.z;
-                if (first + 3 >= 0 && first + 3 < W) r.w = d.w;
-            }
-            return r;
-        }
-        if (!check || (first >= 0 && first + 3 < W)) {
-            f4u v = *(const f4u *)(L.lp + first);
-            return f4{v.x, v.y, v.z, v.w};
-        }
-        f4 r = {0.f, 0.f, 0.f, 0.f};
-        if (first + 3 >= 0 && first < W) {
-            if (first >= 0 && first < W) r.x = L.lp[first];
-            if (first + 1 >= 0 && first + 1 < W) r.y = L.lp[first + 1];
-            if (first + 2 >= 0 && first + 2 < W) r.z = L.lp[first + 2];
-            if (first + 3 >= 0 && first + 3 < W) r.w = L.lp[first + 3];
-        }
-        return r;
+        return load_luma<U8>(L.lp, first, check, W);
     };
 
     if (U8) fill_tile_u8(g, itile, xp, 0, lane); else fill_tile(g, itile, xp, 0, lane);
@@ -769,42 +781,7 @@ __device__ __forceinline__ void run_pair(const Geom &g, const DemodK<float, type
         };
         auto read_luma = [&](int first, bool check) -> f4 {  // x_l[first .. first + 3], zero outside the row
             if (BSF) return f4{0.f, 0.f, 0.f, 0.f};
-    #ifdef CM_EXP_NO_LUMA   /* timing experiment */
-            return f4{0.1f, 0.2f, 0.3f, 0.4f};
-    #endif
-            if (U8) {
-                const unsigned char *lb = (const unsigned char *)lp;
-                if (!check || (first >= 0 && first + 3 < W)) {
-                    typedef unsigned u32u __attribute__((aligned(1)));
-                    return decode_bytes(*(const u32u *)(lb + first));
-                }
-                f4 r = {0.f, 0.f, 0.f, 0.f};
-                if (first + 3 >= 0 && first < W) {
-                    unsigned w = 0;
-                    if (first >= 0 && first < W) w |= lb[first];
-                    if (first + 1 >= 0 && first + 1 < W) w |= (unsigned)lb[first + 1] << 8;
-                    if (first + 2 >= 0 && first + 2 < W) w |= (unsigned)lb[first + 2] << 16;
-                    if (first + 3 >= 0 && first + 3 < W) w |= (unsigned)lb[first + 3] << 24;
-                    f4 d = decode_bytes(w);
-                    if (first >= 0 && first < W) r.x = d.x;
-                    if (first + 1 >= 0 && first + 1 < W) r.y = d.y;
-                    if (first + 2 >= 0 && first + 2 < W) r.z = d.z;
-                    if (first + 3 >= 0 && first + 3 < W) r.w = d.w;
-                }
-                return r;
-            }
-            if (!check || (first >= 0 && first + 3 < W)) {
-                f4u v = *(const f4u *)(lp + first);
-                return f4{v.x, v.y, v.z, v.w};
-            }
-            f4 r = {0.f, 0.f, 0.f, 0.f};
-            if (first + 3 >= 0 && first < W) {
-                if (first >= 0 && first < W) r.x = lp[first];
-                if (first + 1 >= 0 && first + 1 < W) r.y = lp[first + 1];
-                if (first + 2 >= 0 && first + 2 < W) r.z = lp[first + 2];
-                if (first + 3 >= 0 && first + 3 < W) r.w = lp[first + 3];
-            }
-            return r;
+            return load_luma<U8>(lp, first, check, W);
         };
         if (U8) fill_tile_u8(g, itile, xp, 0, lane); else fill_tile(g, itile, xp, 0, lane);
         f4 lum_cur = read_luma(-lat_out, true);   // luma source of B's block 0
@@ -951,20 +928,7 @@ __device__ __forceinline__ void run_pair(const Geom &g, const DemodK<float, type
 #pragma unroll
         for (int j = SP - 1; j > 0; --j) uvd[j] = uvd[j - 1];
         if (SP > 0) uvd[0] = uv;
-        if (!EDGE || (n7 >= 0 && n7 < W)) {
-            if constexpr (U8) {
-                // image.py:7-8: uint8(rint(255 * clip(x, 0, 1))); bytes interleaved R, G, B, 48 per tile row
-                lds_u8 *tbp = (lds_u8 *)otile + 3 * (n7 & (kTile - 1));   // otile: this lane's 48-byte row
-                tbp[0] = (unsigned char)__builtin_rintf(255.f * __builtin_fminf(__builtin_fmaxf(o.r, 0.f), 1.f));
-                tbp[1] = (unsigned char)__builtin_rintf(255.f * __builtin_fminf(__builtin_fmaxf(o.g, 0.f), 1.f));
-                tbp[2] = (unsigned char)__builtin_rintf(255.f * __builtin_fminf(__builtin_fmaxf(o.b, 0.f), 1.f));
-            } else {
-                lds_float *tp = otile + (wpos ^ (n7 & (kTile - 1)));
-                tp[0] = o.r;
-                tp[64 * kTile] = o.g;
-                tp[2 * 64 * kTile] = o.b;
-            }
-        }
+        if (!EDGE || (n7 >= 0 && n7 < W)) put_rgb<U8, kTile>(otile, wpos, n7, o);
     };
     // the first block of the ring and the first body's carriers
     PAIR_BARRIER(d_bar);

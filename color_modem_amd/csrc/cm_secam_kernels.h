@@ -85,19 +85,7 @@ __global__ __launch_bounds__(64, 2) void secam_demod_kernel(const SecamDemodArgs
         Rgb<float> o = st.finish(k, lk, luma, own_prev, nb_prev);
         own_prev = own;
         nb_prev = lane_from(idx1, own);
-        if (n >= 0 && n < W) {
-            if (U8) {   // image.py:7-8: uint8(rint(255 * clip(x, 0, 1))); bytes interleaved R, G, B
-                lds_u8 *tbp = (lds_u8 *)otile + 3 * (n & (kTile - 1));
-                tbp[0] = (unsigned char)__builtin_rintf(255.f * __builtin_fminf(__builtin_fmaxf(o.r, 0.f), 1.f));
-                tbp[1] = (unsigned char)__builtin_rintf(255.f * __builtin_fminf(__builtin_fmaxf(o.g, 0.f), 1.f));
-                tbp[2] = (unsigned char)__builtin_rintf(255.f * __builtin_fminf(__builtin_fmaxf(o.b, 0.f), 1.f));
-            } else {
-                lds_float *tp = otile + (wpos ^ (n & (kTile - 1)));
-                tp[0] = o.r;
-                tp[64 * kTile] = o.g;
-                tp[2 * 64 * kTile] = o.b;
-            }
-        }
+        if (n >= 0 && n < W) put_rgb<U8, kTile>(otile, wpos, n, o);
     };
     auto shift_window = [&]() {
 #pragma unroll
@@ -136,34 +124,7 @@ __global__ __launch_bounds__(64, 2) void secam_demod_kernel(const SecamDemodArgs
         }
         return v;
     };
-    auto read_luma = [&](int first) -> f4 {
-        if (U8) {
-            const unsigned char *lb = (const unsigned char *)xp;
-            if (first >= 0 && first + 3 < W) {
-                typedef unsigned u32u __attribute__((aligned(1)));
-                return decode_bytes(*(const u32u *)(lb + first));
-            }
-            f4 r = {0.f, 0.f, 0.f, 0.f};
-            const float a = 5.0f / (255.0f * 3.0f), b = -1.0f / 3.0f;
-            if (first >= 0 && first < W) r.x = __builtin_fmaf((float)lb[first], a, b);
-            if (first + 1 >= 0 && first + 1 < W) r.y = __builtin_fmaf((float)lb[first + 1], a, b);
-            if (first + 2 >= 0 && first + 2 < W) r.z = __builtin_fmaf((float)lb[first + 2], a, b);
-            if (first + 3 >= 0 && first + 3 < W) r.w = __builtin_fmaf((float)lb[first + 3], a, b);
-            return r;
-        }
-        if (first >= 0 && first + 3 < W) {
-            f4u v = *(const f4u *)(xp + first);
-            return f4{v.x, v.y, v.z, v.w};
-        }
-        f4 r = {0.f, 0.f, 0.f, 0.f};
-        if (first + 3 >= 0 && first < W) {
-            if (first >= 0 && first < W) r.x = xp[first];
-            if (first + 1 >= 0 && first + 1 < W) r.y = xp[first + 1];
-            if (first + 2 >= 0 && first + 2 < W) r.z = xp[first + 2];
-            if (first + 3 >= 0 && first + 3 < W) r.w = xp[first + 3];
-        }
-        return r;
-    };
+    auto read_luma = [&](int first) -> f4 { return load_luma<U8>(xp, first, true, W); };
     const int T = (W + lat_out + 3) & ~3;
     f4 xv = read_x(0);
     f4 nl = read_luma(-d_luma);
