@@ -35,6 +35,9 @@ def lib():
     if not os.path.exists(LIB_PATH):
         raise NativeError('%s not found: build it with `python -c "import __graft_entry__ as g; g.build()"` '
                           '(hipcc --offload-arch=gfx950); color_modem_amd has no CPU path' % LIB_PATH)
+    # torch first: it ships its own libamdhip64 and the library must bind to that copy - two HIP runtimes in one process
+    # do not see each other's devices (cm_plan_create then reports CM_ERR_NO_DEVICE on a machine that has one)
+    import torch  # noqa: F401
     L = ctypes.CDLL(LIB_PATH)
     fp = ctypes.POINTER(ctypes.c_float)
     vp = ctypes.c_void_p
