@@ -212,13 +212,53 @@ bool select_for_shape(cm_plan *p, const cm_plan_desc &d, const char *sys, std::s
 #endif
 }
 
+// Run-time shape (SysAny): any sampling rate whose filters fit 4 / 3 / 3 / 2 sections and a pre-correction shift <= 12.
+// One wave per 64 calls, float32 planes only (no notch, no minavg, no fused byte boundary: those raise and the Python
+// layer converts on the host).
+bool select_any(cm_plan *p, const cm_plan_desc &d, std::string &err) {
+    typedef SysAny S;
+    const bool pald = d.pipeline == CM_PIPE_PAL_D;
+    const bool bsf = d.main_luma_bandstop != 0;
+    const bool first = d.first_is_plain != 0;
+    const int depth = d.depth;
+    typedef PassCfg<S, FRONT_QAM, true, 0, 8> First;
+    p->fn = nullptr;
+    p->fn_u8 = nullptr;
+    std::string what;
+    if (d.notch.n_sections != 0 || d.chroma_average == CM_AVG_MIN) {
+        err = "notch / minavg are built for the tuned filter shapes (13.5 MHz) only";
+        return false;
+    }
+    if (pald) {
+        if (depth != 1 || !first) { err = "PAL-D front end is built with one line of history and a plain first line"; return false; }
+        p->fn = launch_demod<PassCfg<S, FRONT_PALD, false, 1, 16>, First>;
+        p->main.depth = 1; what = "pal-d front, depth 1 | plain first line";
+    } else if (bsf) {
+        if (depth != 0 || first) { err = "band-stop luma is built for plain decoders only"; return false; }
+        p->fn = launch_demod<PassCfg<S, FRONT_QAM, true, 0, 16>, NoPass>;
+        p->main.depth = 0; what = "qam front + band-stop, depth 0";
+    } else if (first) {
+        if (depth != 1) { err = "a comb with a plain first line is built with one line of history"; return false; }
+        p->fn = launch_demod<PassCfg<S, FRONT_QAM, false, 1, 16>, First>;
+        p->main.depth = 1; what = "qam front, depth 1 | plain first line";
+    } else {
+        p->fn = launch_demod<PassCfg<S, FRONT_QAM, false, 2, 16>, NoPass>;
+        p->main.depth = 2; what = "qam front, depth 2";
+    }
+    p->pair = CM_PAIR != 0 && (pald || bsf);   // PassCfg::kUsePair: these do not fit one wave's registers
+    p->main.name = std::string(p->pair ? "demod_pair_kernel" : "demod_kernel") + "<run-time shape: " + what + ">";
+    return make_passes<S>(p, d, pald, bsf, first, err);
+}
+
 // Pick the kernel instance (main pass + optional plain first-line pass in one launch).
 bool select_kernels(cm_plan *p, const cm_plan_desc &d, std::string &err) {
     const bool pald = d.pipeline == CM_PIPE_PAL_D;
     const bool bsf = d.main_luma_bandstop != 0;
     const bool first = d.first_is_plain != 0;
     SysSignature want = signature_wanted(d, pald);
+    const SysSignature want_first = signature_wanted(d, false);   // the plain first-line pass runs the QAM front + band-stop
     auto match = [&](SysSignature have) {
+        if (first && !same_signature(want_first, have)) return false;   // one launch, one shape for both passes
         if (!bsf && !first) { have.nr = want.nr; have.odd_r = want.odd_r; }
         return same_signature(want, have);
     };
@@ -228,6 +268,7 @@ bool select_kernels(cm_plan *p, const cm_plan_desc &d, std::string &err) {
     if (!pald && match(signature_of<SysNtscI>())) return select_for_shape<SysNtscI, false, true>(p, d, "ntsc-i", err);
     if (!pald && match(signature_of<SysNtscA>())) return select_for_shape<SysNtscA, false, true>(p, d, "ntsc-a", err);
 #endif
+    if (fits_any(want) && (!first || fits_any(want_first))) return select_any(p, d, err);
     char buf[256];
     snprintf(buf, sizeof buf,
              "no kernel instance for this filter set (sections extract/remove/detect/pre = %d/%d/%d/%d, shift parities %d/%d/%d, "
@@ -237,12 +278,14 @@ bool select_kernels(cm_plan *p, const cm_plan_desc &d, std::string &err) {
     return false;
 }
 
-template <int NP, int SP, int DEPTH, bool U8 = false>
+constexpr int kModAnyShift = 12;   // luma delay window of the run-time-shape modulators
+
+template <int NP, int SP, int DEPTH, bool U8 = false, bool RT = false>
 int launch_qam_mod(const Geom &g, const void *kv, int blocks, hipStream_t stream) {
     ModArgs<NP> a;
     a.g = g;
     a.k = *static_cast<const ModK<float, NP> *>(kv);
-    hipLaunchKernelGGL((qam_mod_kernel<NP, SP, DEPTH, U8>), dim3(blocks), dim3(64), 0, stream, a);
+    hipLaunchKernelGGL((qam_mod_kernel<NP, SP, DEPTH, U8, RT>), dim3(blocks), dim3(64), 0, stream, a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(CM_ERR_LAUNCH, std::string("qam_mod_kernel launch: ") + hipGetErrorString(e));
     return CM_OK;
@@ -252,14 +295,25 @@ int launch_qam_mod(const Geom &g, const void *kv, int blocks, hipStream_t stream
 bool select_modulator(cm_plan *p, const cm_plan_desc &d, std::string &err) {
     const cm_lane_table &tb = d.mod_main;
     if (!tb.table) return true;
-    const bool shape1 = d.precorrect.n_sections == 1 && d.precorrect.shift == 2;   // every system but NTSC-A
+    const bool shape1 = d.precorrect.n_sections == 1 && d.precorrect.shift == 2;   // every system but NTSC-A at 13.5 MHz
     const bool shape2 = d.precorrect.n_sections == 2 && d.precorrect.shift == 4;   // NTSC-A
-    if (!shape1 && !shape2) {
-        err = "no modulator instance for this pre-correction filter (built: one section with shift 2, two sections with shift 4)";
+    const bool shape_any = !shape1 && !shape2 && d.precorrect.n_sections <= 2 && d.precorrect.shift >= 0 &&
+                           d.precorrect.shift <= kModAnyShift;                     // run-time shape: other sampling rates
+    if (!shape1 && !shape2 && !shape_any) {
+        err = "no modulator instance for this pre-correction filter (built: up to two sections, shift <= 12)";
         return false;
     }
     double g_pre;
-    if (shape1) {
+    if (shape_any) {
+        ModK<float, 2> k;
+        k.width = d.width;
+        k.s_p = d.precorrect.shift;
+        if (!convert_sos<float, 2>(d.precorrect, FORM_GEN, k.pre, g_pre, err, "precorrect", true)) return false;
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j) k.e[i][j] = (float)d.encode_matrix[3 * i + j];
+        p->mod_k.resize(sizeof k);
+        std::memcpy(p->mod_k.data(), &k, sizeof k);
+    } else if (shape1) {
         ModK<float, 1> k;
         k.width = d.width;
         k.s_p = d.precorrect.shift;
@@ -297,14 +351,17 @@ bool select_modulator(cm_plan *p, const cm_plan_desc &d, std::string &err) {
     p->mod_cycle = tb.frame_cycle;
     p->mod_n_lines = tb.n_lines;
     p->mod_depth = d.modulation_delay ? 1 : 0;
-    if (shape1) {
+    if (shape_any) {
+        p->mod_fn = p->mod_depth ? launch_qam_mod<2, kModAnyShift, 1, false, true> : launch_qam_mod<2, kModAnyShift, 0, false, true>;
+        p->mod_fn_u8 = p->mod_depth ? launch_qam_mod<2, kModAnyShift, 1, true, true> : launch_qam_mod<2, kModAnyShift, 0, true, true>;
+    } else if (shape1) {
         p->mod_fn = p->mod_depth ? launch_qam_mod<1, 2, 1> : launch_qam_mod<1, 2, 0>;
         p->mod_fn_u8 = p->mod_depth ? launch_qam_mod<1, 2, 1, true> : launch_qam_mod<1, 2, 0, true>;
     } else {
         p->mod_fn = p->mod_depth ? launch_qam_mod<2, 4, 1> : launch_qam_mod<2, 4, 0>;
         p->mod_fn_u8 = p->mod_depth ? launch_qam_mod<2, 4, 1, true> : launch_qam_mod<2, 4, 0, true>;
     }
-    p->mod_name = p->mod_depth ? "qam_mod_kernel<line averaging>" : "qam_mod_kernel";
+    p->mod_name = std::string(p->mod_depth ? "qam_mod_kernel<line averaging" : "qam_mod_kernel<") + (shape_any ? ", run-time shape>" : ">");
     return true;
 }
 

@@ -146,10 +146,11 @@ struct PassCfg {
     static constexpr int kLdsFloats = kLdsInF + kLdsOut + (BSF_ ? kLdsRing : 0);
     // wave-pair kernels: 3 waves per SIMD need <= 168 VGPRs; the instances with more per-lane state in stage B (a second
     // line of history, the notch, the second combination of minavg) would spill there and get 2 waves per SIMD instead
-    static constexpr int kPairWaves = (DEPTH_ >= 2 || NOTCH_ || MINAVG_ || S_::NE >= 4 || S_::NP >= 2) ? 2 : 3;
+    static constexpr int kPairWaves = (DEPTH_ >= 2 || NOTCH_ || MINAVG_ || S_::NE >= 4 || S_::NP >= 2 || S_::RT) ? 2 : 3;
     // which kernel structure runs this instance: the pair where it gets 3 waves per SIMD (measured 1-3 % faster there,
-    // 2-5 % slower at 2), and for the PAL-D front end with the notch, which does not fit one wave's 256 VGPRs
-    static constexpr bool kUsePair = kPairWaves == 3 || (FRONT_ == 1 && NOTCH_);
+    // 2-5 % slower at 2), and where one wave's 256 VGPRs do not hold the line: the PAL-D front end with the notch, the
+    // PAL-D and band-stop instances of the run-time shape
+    static constexpr bool kUsePair = kPairWaves == 3 || (FRONT_ == 1 && NOTCH_) || (S_::RT && (FRONT_ == 1 || BSF_));
 };
 struct NoPass {
     static constexpr int kLdsFloats = 0;
@@ -262,7 +263,8 @@ struct DemodLane {
             base = front.template step<EDGE>(k, fla, tau, xw[10 + SUB], xw[SUB], car, luma_bsf);
         }
         // the back end handles the PREVIOUS step's base pair: its neighbours were requested then
-        const int n6 = tau - lat_front - 1, n7 = n6 - SP;
+        const int sp = S::RT ? k.s_p : SP;     // run-time shapes: SP is the window size, k.s_p the delay
+        const int n6 = tau - lat_front - 1, n7 = n6 - sp;
         float u, v;
         back.combine(lk, base_prev, b1_prev, b2_prev, u, v);
         base_prev = base;
@@ -276,7 +278,13 @@ struct DemodLane {
         } else {
             y_src = SUB == 0 ? lw.x : (SUB == 1 ? lw.y : (SUB == 2 ? lw.z : lw.w));
         }
-        const float u_d = SP > 0 ? ud[SP > 0 ? SP - 1 : 0] : u, v_d = SP > 0 ? vd[SP > 0 ? SP - 1 : 0] : v;
+        float u_d = SP > 0 ? ud[SP > 0 ? SP - 1 : 0] : u, v_d = SP > 0 ? vd[SP > 0 ? SP - 1 : 0] : v;
+        if (S::RT) {   // (u, v)[n6 - s_p] out of the window: a chain of uniform selects instead of a dynamic register index
+            if (sp == 0) { u_d = u; v_d = v; }
+#pragma unroll
+            for (int j = 0; j + 1 < SP; ++j)
+                if (sp == j + 1) { u_d = ud[j]; v_d = vd[j]; }
+        }
         Rgb<float> o = back.template step<EDGE>(k, lk, bla, n6, u, v, u_d, v_d, y_src, carb);
 #pragma unroll
         for (int j = SP - 1; j > 0; --j) { ud[j] = ud[j - 1]; vd[j] = vd[j - 1]; }
@@ -496,7 +504,7 @@ __device__ __forceinline__ void run_lane(const Geom &g, const DemodK<float, type
     const int lat_front = Lane::Front::latency(k);
     int lat_luma = 0;
     if constexpr (FRONT == FRONT_QAM) lat_luma = Lane::Front::luma_latency(k);
-    const int lat_out = lat_front + 1 + S::SP;     // n7 = t - lat_out
+    const int lat_out = lat_front + 1 + (S::RT ? k.s_p : S::SP);     // n7 = t - lat_out
     const int T = (W + lat_out + 3) & ~3;
     const int front_off = FRONT == FRONT_PALD ? 10 + k.q_e + 9 + 10 : 10 + k.q_e;  // detector sample pair = t - front_off
     int t_mid0 = (lat_out + 3) & ~3;           // every stage index >= 0 from here on
@@ -730,7 +738,8 @@ __device__ __forceinline__ void run_pair(const Geom &g, const DemodK<float, type
     const int lat_front = Front::latency(k);
     int lat_luma = 0;
     if constexpr (!PALD) lat_luma = Front::luma_latency(k);
-    const int lat_out = lat_front + 1 + SP;     // n7 = t - lat_out
+    const int sp = S::RT ? k.s_p : SP;          // run-time shapes: SP is the window size, k.s_p the delay
+    const int lat_out = lat_front + 1 + sp;     // n7 = t - lat_out
     const int T = (W + lat_out + 3) & ~3;
     const int front_off = StageA::pair_offset(k);   // detector pair index nd = t - front_off
     int t_mid0 = (lat_out + 3) & ~3;           // every stage index >= 0 from here on
@@ -915,7 +924,7 @@ __device__ __forceinline__ void run_pair(const Geom &g, const DemodK<float, type
         constexpr bool EDGE = decltype(edge_tag)::value;
         pf2 base = det.template step<EDGE>(k, kb, p_last, tau - front_off, p_e, p_o);
         // the back end handles the PREVIOUS step's base pair: its neighbours were requested then
-        const int n6 = tau - lat_front - 1, n7 = n6 - SP;
+        const int n6 = tau - lat_front - 1, n7 = n6 - sp;
         pf2 uv = back.combine(lk, base_prev, b1_prev, b2_prev);
         base_prev = base;
         if (DEPTH >= 1) b1_prev = pf2{lane_from(idx1, base.x), lane_from(idx1, base.y)};
@@ -923,7 +932,13 @@ __device__ __forceinline__ void run_pair(const Geom &g, const DemodK<float, type
         float y_src;
         if (BSF) y_src = yring[(n7 & 31) * 64 + lane];
         else y_src = SUB == 0 ? lw.x : (SUB == 1 ? lw.y : (SUB == 2 ? lw.z : lw.w));
-        const pf2 uv_d = SP > 0 ? uvd[SP > 0 ? SP - 1 : 0] : uv;
+        pf2 uv_d = SP > 0 ? uvd[SP > 0 ? SP - 1 : 0] : uv;
+        if (S::RT) {   // (u, v)[n6 - s_p] out of the window: a chain of uniform selects instead of a dynamic register index
+            if (sp == 0) uv_d = uv;
+#pragma unroll
+            for (int j = 0; j + 1 < SP; ++j)
+                if (sp == j + 1) uv_d = uvd[j];
+        }
         Rgb<float> o = back.template step<EDGE>(k, kb, lk, uv_last, n6, uv, uv_d, y_src, sc);
 #pragma unroll
         for (int j = SP - 1; j > 0; --j) uvd[j] = uvd[j - 1];

@@ -195,7 +195,8 @@ constexpr int kModLdsFloatsU8 = (kInTile3Bytes + 64 * kOutTileU8) / 4;    // byt
 
 // DEPTH = 1: encoder-side line averaging (ColorAveragingModem) needs the previous call's components.
 // U8: the ImageModem byte boundary fused in (interleaved RGB bytes in, composite bytes out)
-template <int NP, int SP, int DEPTH, bool U8 = false>
+// RT: run-time shape - SP is the size of the luma delay window, the delay itself is k.s_p <= SP (any sampling rate)
+template <int NP, int SP, int DEPTH, bool U8 = false, bool RT = false>
 __global__ __launch_bounds__(64, 2) void qam_mod_kernel(const ModArgs<NP> args) {
     constexpr int kTile = 16;
     __shared__ __attribute__((aligned(16))) float lds_store[U8 ? kModLdsFloatsU8 : kModLdsFloats];
@@ -225,7 +226,8 @@ __global__ __launch_bounds__(64, 2) void qam_mod_kernel(const ModArgs<NP> args) 
     for (int j = 0; j < SP + 4; ++j) yw[j] = 0.f;
     const int wpos = ((lane >> 1) & (kTile / 4 - 1)) << 2;
     const int W = g.W;
-    const int T = (W + SP + 3) & ~3;
+    const int sp = RT ? k.s_p : SP;
+    const int T = (W + sp + 3) & ~3;
     f4 cur[3], nxt[3];
     first_tile3<U8>(g, itile, rp, lane, nxt);
     for (int tb = 0; tb < T; tb += 4) {
@@ -245,11 +247,17 @@ __global__ __launch_bounds__(64, 2) void qam_mod_kernel(const ModArgs<NP> args) 
                 v = fmaf_(lk.wc0, v, lk.wc1 * vp);
             }
             yw[SP + s] = y;
-            const int n7 = t - SP;
+            const int n7 = t - sp;
             int nc = n7 < 0 ? 0 : (n7 > W - 1 ? W - 1 : n7);
             f2 cc = ((const_f2 *)g.carrier2)[nc];
             float car[2] = {cc.x, cc.y};
-            float comp = core.step(k, lk, t, yw[s], u, v, car);
+            float y_d = yw[s];                 // luma of sample n7 = t - SP
+            if (RT) {                          // ... = t - s_p: a chain of uniform selects instead of a dynamic register index
+#pragma unroll
+                for (int j = 0; j < SP; ++j)
+                    if (sp == j) y_d = yw[SP - j + s];
+            }
+            float comp = core.step(k, lk, t, y_d, u, v, car);
             put_composite<U8, kTile>(g, otile_base, op, lane, wpos, n7, comp);
         }
 #pragma unroll

@@ -17,15 +17,21 @@ namespace cm {
 enum SectionForm { FORM_BP, FORM_SYM, FORM_GEN };
 
 // Normalise scipy sections to b0 = 1, check the numerator form, return the product of the b0's.
+// pad = true (run-time shapes): a shorter cascade is completed with identity sections - numerator equal to the denominator
+// and a zero state that stays exactly zero: 1 - z^-2 over 1 - z^-2 (BP), 1 + z^-2 over 1 + z^-2 (SYM), 1 over 1 (GEN).
 template <typename T, int NSEC>
 bool convert_sos(const cm_iir_desc &d, SectionForm form, SosK<T, NSEC> &out, double &gain, std::string &err,
-                 const char *name) {
-    if (d.n_sections != NSEC) {
+                 const char *name, bool pad = false) {
+    if (pad ? d.n_sections > NSEC : d.n_sections != NSEC) {
         err = std::string(name) + ": section count does not match the kernel instance";
         return false;
     }
     gain = 1.0;
-    for (int j = 0; j < NSEC; ++j) out.na1[j] = out.na2[j] = out.b1[j] = out.b2[j] = T(0);
+    for (int j = 0; j < NSEC; ++j) {
+        out.na1[j] = out.b1[j] = T(0);
+        out.na2[j] = form == FORM_BP ? T(1) : (form == FORM_SYM ? T(-1) : T(0));   // -a2
+        out.b2[j] = form == FORM_BP ? T(-1) : (form == FORM_SYM ? T(1) : T(0));
+    }
     for (int j = 0; j < d.n_sections; ++j) {
         const double *s = d.sos[j];
         if (s[0] == 0.0 || std::fabs(s[3] - 1.0) > 1e-12) {
@@ -75,20 +81,25 @@ bool build_demod_k(const cm_plan_desc &d, bool pald, bool need_bsf, DemodK<T, S>
     for (int i = 0; i < 10; ++i) k.taps.c[i] = T(2.0 * d.resample_fir[2 * i + 1]);
     k.taps.c0 = T(2.0 * d.resample_fir[20]);
     double g_e, g_r = 0.0, g_l, g_p;
-    if (!convert_sos<T, S::NE>(d.extract2x, FORM_BP, k.ext, g_e, err, "extract2x")) return false;
+    if (!convert_sos<T, S::NE>(d.extract2x, FORM_BP, k.ext, g_e, err, "extract2x", S::RT)) return false;
     if (need_bsf) {
-        if (!convert_sos<T, S::NR>(d.remove2x, FORM_SYM, k.rem, g_r, err, "remove2x")) return false;
+        if (!convert_sos<T, S::NR>(d.remove2x, FORM_SYM, k.rem, g_r, err, "remove2x", S::RT)) return false;
     } else {
         for (int j = 0; j < S::NR; ++j) k.rem.na1[j] = k.rem.na2[j] = k.rem.b1[j] = k.rem.b2[j] = T(0);
     }
     const cm_iir_desc &lp = pald ? d.pald_lp : d.demod_lp;
-    if (!convert_sos<T, S::NL>(lp, FORM_SYM, k.lpf, g_l, err, pald ? "pald_lp" : "demod_lp")) return false;
-    if (!convert_sos<T, S::NP>(d.precorrect, FORM_GEN, k.pre, g_p, err, "precorrect")) return false;
-    if ((d.extract2x.shift & 1) != (S::ODD_E ? 1 : 0) || (lp.shift & 1) != (S::ODD_L ? 1 : 0) ||
-        (need_bsf && (d.remove2x.shift & 1) != (S::ODD_R ? 1 : 0)) || d.precorrect.shift != S::SP) {
+    if (!convert_sos<T, S::NL>(lp, FORM_SYM, k.lpf, g_l, err, pald ? "pald_lp" : "demod_lp", S::RT)) return false;
+    if (!convert_sos<T, S::NP>(d.precorrect, FORM_GEN, k.pre, g_p, err, "precorrect", S::RT)) return false;
+    if (S::RT) {
+        if (d.precorrect.shift > S::SP) { err = "pre-correction shift beyond the window of the run-time shape"; return false; }
+    } else if ((d.extract2x.shift & 1) != (S::ODD_E ? 1 : 0) || (lp.shift & 1) != (S::ODD_L ? 1 : 0) ||
+               (need_bsf && (d.remove2x.shift & 1) != (S::ODD_R ? 1 : 0)) || d.precorrect.shift != S::SP) {
         err = "filter shifts do not match the kernel instance";
         return false;
     }
+    k.odd_e = d.extract2x.shift & 1;
+    k.odd_l = lp.shift & 1;
+    k.odd_r = d.remove2x.shift & 1;
     if (d.extract2x.shift < 0 || lp.shift < 0 || d.remove2x.shift < 0 || d.precorrect.shift < 0) {
         err = "negative FilterFunction shift is not used on this path";
         return false;
@@ -248,6 +259,7 @@ typedef Sys<2, 2, 3, 1, false, false, false, 2> SysPal;   // PAL-BG @ 13.5 MHz: 
 typedef Sys<3, 3, 3, 1, false, true, false, 2> SysNtsc;   // NTSC-M @ 13.5 MHz: shifts 6 / 5 / 4 / 2 (also NTSC-N, NTSC 3.61, PAL-M, PAL-N)
 typedef Sys<3, 2, 3, 1, false, true, false, 2> SysNtscI;  // NTSC-I, NTSC 4.43 on 625 lines: narrower band-stop
 typedef Sys<4, 3, 3, 2, true, true, true, 4> SysNtscA;    // NTSC-A (405 lines, 2.66 MHz sub-carrier): shifts 9 / 7 / 5 / 4
+typedef Sys<4, 3, 3, 2, false, false, false, 12, true> SysAny;   // run-time shape: up to 4 / 3 / 3 / 2 sections, pre shift <= 12
 
 struct SysSignature {
     int ne, nr, nl, np, odd_e, odd_l, odd_r, sp;
@@ -261,6 +273,10 @@ inline SysSignature signature_wanted(const cm_plan_desc &d, bool pald) {
     const cm_iir_desc &lp = pald ? d.pald_lp : d.demod_lp;
     return SysSignature{d.extract2x.n_sections, d.remove2x.n_sections, lp.n_sections, d.precorrect.n_sections,
                         d.extract2x.shift & 1, lp.shift & 1, d.remove2x.shift & 1, d.precorrect.shift};
+}
+// can the run-time shape carry this filter set?
+inline bool fits_any(const SysSignature &w) {
+    return w.ne <= SysAny::NE && w.nr <= SysAny::NR && w.nl <= SysAny::NL && w.np <= SysAny::NP && w.sp <= SysAny::SP;
 }
 inline bool same_signature(const SysSignature &a, const SysSignature &b) {
     return a.ne == b.ne && a.nr == b.nr && a.nl == b.nl && a.np == b.np && a.odd_e == b.odd_e && a.odd_l == b.odd_l &&

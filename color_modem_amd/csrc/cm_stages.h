@@ -40,10 +40,13 @@ namespace cm {
 // remove band-stop, detector low-pass and pre-correction low-pass, the parity of the
 // FilterFunction shifts of the three 2x-rate filters (odd: output pairs straddle input pairs)
 // and the shift of the pre-correction filter (a register-window delay in the kernels).
-template <int NE_, int NR_, int NL_, int NP_, bool ODD_E_, bool ODD_L_, bool ODD_R_, int SP_>
+// RT_ = true: a run-time shape.  The section counts and SP_ are then MAXIMA (the host pads a shorter cascade with
+// identity sections, which cost arithmetic but no branch), the shift parities and the pre-correction shift are read from
+// DemodK at run time.  One such instance serves every sampling rate (= image width) without a tuned instance.
+template <int NE_, int NR_, int NL_, int NP_, bool ODD_E_, bool ODD_L_, bool ODD_R_, int SP_, bool RT_ = false>
 struct Sys {
     static constexpr int NE = NE_, NR = NR_, NL = NL_, NP = NP_, SP = SP_;
-    static constexpr bool ODD_E = ODD_E_, ODD_L = ODD_L_, ODD_R = ODD_R_;
+    static constexpr bool ODD_E = ODD_E_, ODD_L = ODD_L_, ODD_R = ODD_R_, RT = RT_;
 };
 
 // ---- arithmetic helpers -------------------------------------------------------------------
@@ -263,6 +266,7 @@ template <typename T, class S>
 struct DemodK {
     int32_t width;       // W
     int32_t q_e, q_l, q_r, s_p;  // pair delays of the 2x-rate filters (ceil(shift / 2)), pre shift
+    int32_t odd_e, odd_l, odd_r; // shift parities of the 2x-rate filters (read by run-time shapes, S::RT)
     Taps<T> taps;
     SosK<T, S::NE> ext;   // ref qam.py:17 band-pass
     SosK<T, S::NR> rem;   // ref qam.py:17 band-stop
@@ -293,7 +297,6 @@ struct Mid {
 template <typename T, class S, class VP>
 struct Detector {
     typedef DemodK<T, S> K;
-    static constexpr bool ODD_L = S::ODD_L;
     HalfbandChain<T> dn_s, dn_c;
     IirState<T, S::NL> lpf_s, lpf_c;
     T hold_s, hold_c;   // previous odd outputs for an odd shift
@@ -306,6 +309,7 @@ struct Detector {
     CM_HD Pair<T> step(const K &k, FrontLatch<T> &la, int nd, const Mid<T> &m, const T car[4]) {
         const int W = k.width;
         const int n5 = nd - k.q_l;
+        const bool ODD_L = S::RT ? k.odd_l != 0 : S::ODD_L;
         T ps_e = m.even * car[1], pc_e = m.even * car[0];
         T ps_o = m.odd * car[3], pc_o = m.odd * car[2];
         T qs_e = T(0), qs_o = T(0), qc_e = T(0), qc_o = T(0);
@@ -351,7 +355,6 @@ template <typename T, class S>
 struct PalDFrontA {
     typedef DemodK<T, S> K;
     typedef VPolicy<CM_V_PALD> VP;
-    static constexpr bool ODD_E = S::ODD_E;
     HalfbandChain<T> up_x, dn_e, up_e;
     IirState<T, S::NE> bpf;
     T hold_b;
@@ -368,6 +371,7 @@ struct PalDFrontA {
     CM_HD Mid<T> step(const K &k, FrontLatch<T> &la, int t, T x_now, T x_d10, T e_d10, T &e_out) {
         const int W = k.width;
         const int n1 = t - 10, n2 = n1 - k.q_e, n3 = n2 - 9;
+        const bool ODD_E = S::RT ? k.odd_e != 0 : S::ODD_E;
         // --- up2(x)
         T a_odd = up_x.template push<VP::VT>(k.taps, x_now);
         T a_even = k.taps.c0 * x_d10;
@@ -426,7 +430,6 @@ template <typename T, class S, bool WITH_BSF>
 struct QamFrontA {
     typedef DemodK<T, S> K;
     typedef VPolicy<CM_V_QAM> VP;
-    static constexpr bool ODD_E = S::ODD_E, ODD_R = S::ODD_R;
     HalfbandChain<T> up_x, dn_y;
     IirState<T, S::NE> bpf;
     IirState<T, S::NR> bsf;
@@ -443,6 +446,7 @@ struct QamFrontA {
     CM_HD Mid<T> step(const K &k, FrontLatch<T> &la, int t, T x_now, T x_d10, T &luma_out) {
         const int W = k.width;
         const int n1 = t - 10;
+        const bool ODD_E = S::RT ? k.odd_e != 0 : S::ODD_E, ODD_R = S::RT ? k.odd_r != 0 : S::ODD_R;
         T a_odd = up_x.template push<VP::VT>(k.taps, x_now);
         T a_even = k.taps.c0 * x_d10;
         if (EDGE) {

@@ -288,7 +288,6 @@ struct StageBK {
 template <class S>
 struct DetectorPk {
     typedef DemodK<float, S> K;
-    static constexpr bool ODD_L = S::ODD_L;
     HalfbandChainPk dn;
     IirStatePk<S::NL> lpf;
     pf2 hold;
@@ -303,6 +302,7 @@ struct DetectorPk {
     __device__ __forceinline__ pf2 step(const K &k, const StageBK<S> &kb, pf2 &p_last, int nd, pf2 p_e, pf2 p_o) {
         const int W = k.width;
         const int n5 = nd - k.q_l;
+        const bool ODD_L = S::RT ? k.odd_l != 0 : S::ODD_L;
         pf2 q_e = {0.f, 0.f}, q_o = {0.f, 0.f};
         if (!EDGE || (nd >= 0 && nd < W + k.q_l)) {
             if (EDGE) {

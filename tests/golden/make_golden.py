@@ -327,6 +327,21 @@ def option_cases(only=()):
         save('frames_demod_' + stack, inp=comp, out=out, frames=numpy.array(frames), size=numpy.array([W, H]))
 
 
+def width_cases():
+    """Other sampling rates (image widths): different filter orders / shift parities than at 13.5 MHz, W x 6 frames."""
+    H = 6
+    for stack, mod_stack, W, frames in [('pal_d', 'pal_s', 768, [0, 3]), ('ntsc_comb', 'ntsc', 640, [0, 1]), ('pal_3d', 'pal_s', 1024, [1, 2])]:
+        lc = line_config(stack, (W, H))
+        enc = STACKS[mod_stack](lc)
+        rgb = testing.synthetic_rgb(len(frames), H, W, seed=800 + W)
+        comp = numpy.stack([run_mod_frame(enc, rgb[i].astype(numpy.float64), f) for i, f in enumerate(frames)])
+        save('frames_mod_%s_w%d' % (mod_stack, W), inp=rgb, out=comp, frames=numpy.array(frames), size=numpy.array([W, H]))
+        comp = comp.astype(numpy.float32)
+        modem = STACKS[stack](lc)
+        out = numpy.stack([run_demod_frame(modem, comp[i].astype(numpy.float64), f) for i, f in enumerate(frames)])
+        save('frames_demod_%s_w%d' % (stack, W), inp=comp, out=out, frames=numpy.array(frames), size=numpy.array([W, H]))
+
+
 def row_cases():
     """Explicit (frame, line) sequences at the full-height geometry, fed to one modem object in order."""
     seqs = {
@@ -369,8 +384,12 @@ if __name__ == '__main__':
     if sys.argv[1:2] == ['options']:     # only the option / variant cases (the rest is unchanged), optionally some
         option_cases(sys.argv[2:])
         sys.exit(0)
+    if sys.argv[1:2] == ['widths']:
+        width_cases()
+        sys.exit(0)
     make_plans()
     frame_cases()
     option_cases()
+    width_cases()
     row_cases()
     image_cases()

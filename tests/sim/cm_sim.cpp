@@ -142,6 +142,8 @@ static int run_dispatch(const cm_plan_desc &d, bool pald, bool bsf, const cm_lan
         return run_generic<T, SysNtscI>(d, pald, bsf, tb, calls, comp, rgb, n_calls, frame, first_line, k0, mid_fast);
     if (!pald && match(signature_of<SysNtscA>()))
         return run_generic<T, SysNtscA>(d, pald, bsf, tb, calls, comp, rgb, n_calls, frame, first_line, k0, mid_fast);
+    if (fits_any(want))   // the run-time shape: identity-padded cascades, shift parities read at run time
+        return run_generic<T, SysAny>(d, pald, bsf, tb, calls, comp, rgb, n_calls, frame, first_line, k0, mid_fast);
     g_err = "no kernel instance for this filter set";
     return CM_ERR_UNSUPPORTED;
 }

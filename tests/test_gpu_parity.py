@@ -19,7 +19,8 @@ DEMOD_ROWS = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(sta
 
 
 def stack_of(name, prefix):
-    return name[len(prefix):].split('_noise_')[0]
+    import re
+    return re.sub(r'_w\d+$', '', name[len(prefix):].split('_noise_')[0])     # ..._w768: the same stack at another image width
 
 
 @pytest.mark.parametrize('name', DEMOD_FRAMES)
@@ -73,7 +74,7 @@ MOD_FRAMES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(sta
 @pytest.mark.parametrize('name', MOD_FRAMES)
 def test_frames_mod_golden(name):
     g = stacks.load(name)
-    modem = stacks.make(name[len('frames_mod_'):], g['size'])
+    modem = stacks.make(stack_of(name, 'frames_mod_'), g['size'])
     im = image.ImageModem(modem)
     for i, f in enumerate(g['frames']):
         out = im.modulate_frames(g['inp'][i:i + 1], first_frame=int(f))[0]
@@ -239,6 +240,30 @@ def test_variants_round_trip_vs_oracle(kind, variant, size):
     want = cm_oracle.demodulate_frames_f32(modem, comp_ref, first_frame=1, n_threads=8)
     for i in range(2):
         assert stacks.rel_err(got[i], want[i]) < TOL, i
+
+
+# ---- other sampling rates (= image widths): the run-time-shape kernel instances ----------------------------------------------
+@pytest.mark.parametrize('stack,size', [
+    ('pal_d', (768, 576)), ('pal_d', (640, 575)), ('pal_d', (1024, 40)), ('pal_s', (1920, 24)), ('pal_3d', (960, 33)), ('pal_d', (480, 576)),
+    ('ntsc', (640, 480)), ('ntsc_comb', (704, 480)), ('ntsc_comb_3d', (1280, 30)), ('ntsc_comb', (1440, 21)), ('ntsc_comb_simple', (768, 16)),
+])
+def test_other_widths_vs_oracle(stack, size):
+    """Filter sets whose section counts / shift parities / pre-correction shift differ from the tuned 13.5 MHz shapes run on
+    the run-time-shape instances (identity-padded cascades, parities and shift read at run time): both directions."""
+    from oracle import cm_oracle
+    modem = stacks.make(stack, size, explicit=False)
+    im = image.ImageModem(modem)
+    n = 2
+    enc = stacks.make({'pal_d': 'pal_s', 'pal_3d': 'pal_s', 'ntsc_comb': 'ntsc', 'ntsc_comb_3d': 'ntsc', 'ntsc_comb_simple': 'ntsc'}.get(stack, stack),
+                      size, explicit=False)
+    rgb = testing.synthetic_rgb(n, size[1], size[0], seed=77)
+    comp_ref = cm_oracle.modulate_frames_f32(enc, rgb, first_frame=1, n_threads=8)
+    comp = image.ImageModem(enc).modulate_frames(rgb, first_frame=1)
+    assert stacks.rel_err(comp, comp_ref) < TOL
+    got = im.demodulate_frames(comp_ref, first_frame=1)
+    want = cm_oracle.demodulate_frames_f32(modem, comp_ref, first_frame=1, n_threads=8)
+    for i in range(n):
+        assert stacks.rel_err(got[i], want[i]) < TOL, (stack, size, i)
 
 
 # ---- sub-carrier cycles too long to tabulate per frame: two parity frames + per-frame rotation ---------------------

@@ -2,6 +2,7 @@
 """Pin the CPU oracle (oracle/cm_oracle.cpp) against vectors produced by the reference itself."""
 import glob
 import os
+import re
 
 import numpy
 import pytest
@@ -19,7 +20,7 @@ IMAGES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(stacks.
 
 def stack_of(name, prefix):
     s = name[len(prefix):]
-    return s.split('_noise_')[0]
+    return re.sub(r'_w\d+$', '', s.split('_noise_')[0])     # ..._w768: the same stack at another image width
 
 
 @pytest.mark.parametrize('name', FRAME_DEMOD)

@@ -60,6 +60,26 @@ def test_streaming_matches_oracle(sim, stack, size, frame, first_line):
         assert stacks.rel_err(o32[i], ref[i]) < 2e-6, (stack, i)
 
 
+@pytest.mark.parametrize('stack,size', [('pal_d', (768, 576)), ('pal_d', (640, 576)), ('pal_3d', (1920, 576)), ('pal_s', (1024, 576)),
+                                        ('ntsc', (768, 480)), ('ntsc_comb', (704, 480)), ('ntsc_comb_3d', (1440, 480))])
+def test_run_time_shape_matches_oracle(sim, stack, size):
+    """Other sampling rates: cascades padded with identity sections, shift parities and pre-correction shift read at run time
+    (cm_stages.h: Sys<..., RT>); the PAL-D front end with odd shifts is exercised here."""
+    from oracle import cm_oracle
+    modem = stacks.make(stack, size, explicit=False)
+    bp = plan.build_plan(modem)
+    n, frame, first_line = 4, 1, 1
+    comp = testing.synthetic_composite(1, n, size[0], seed=23)[0]
+    orc = cm_oracle.OracleModem(modem)
+    ref = numpy.stack([numpy.stack(orc.demodulate(frame, first_line + 2 * i, comp[i].astype(numpy.float64)))
+                       for i in range(n)])
+    o64 = run(sim, bp, comp, frame, first_line, 0, f32=False)
+    o32 = run(sim, bp, comp, frame, first_line, 0, f32=True)
+    for i in range(n):
+        assert stacks.rel_err(o64[i], ref[i]) < 1e-11, (stack, i)
+        assert stacks.rel_err(o32[i], ref[i]) < 3e-6, (stack, i)
+
+
 @pytest.fixture(scope='module')
 def sim_secam(sim):
     dp = ctypes.POINTER(ctypes.c_double)
