@@ -13,6 +13,8 @@
 #include "cm_secam_kernels.h"
 #include "cm_plan.h"
 
+constexpr int kModAnyShift = 12;   // luma delay window of the run-time-shape modulators (pre-correction shift <= 12)
+
 #ifndef CM_PAIR
 #define CM_PAIR 1   /* 1: wave-pair kernels (demod_pair_kernel) where they fit; 0: one wave per 64 calls (demod_kernel) everywhere */
 #endif
@@ -278,8 +280,6 @@ bool select_kernels(cm_plan *p, const cm_plan_desc &d, std::string &err) {
     return false;
 }
 
-constexpr int kModAnyShift = 12;   // luma delay window of the run-time-shape modulators
-
 template <int NP, int SP, int DEPTH, bool U8 = false, bool RT = false>
 int launch_qam_mod(const Geom &g, const void *kv, int blocks, hipStream_t stream) {
     ModArgs<NP> a;
@@ -380,7 +380,6 @@ bool upload_lanes(const cm_lane_table &tb, LaneT **dev, Conv conv, std::string &
 
 bool create_secam(cm_plan *p, const cm_plan_desc &d, std::string &err) {
     p->secam = true;
-    if (d.secam.preroll >= kInTile) { err = "SECAM pre-roll longer than one input tile (width > 1319) is not built"; return false; }
     if (!build_secam_demod_k<float>(d, p->sd_k, err)) return false;
     if (!d.demod_main.table) { err = "demod_main table missing"; return false; }
     if (!upload_lanes(d.demod_main, &p->sd_lanes, convert_secam_demod_lane<float>, err)) return false;
@@ -394,7 +393,7 @@ bool create_secam(cm_plan *p, const cm_plan_desc &d, std::string &err) {
     }
     if (d.mod_main.table) {
         if (!build_secam_mod_k<float, double>(d, p->sm_k, err)) return false;
-        if (p->sm_k.s_p != 3) { err = "SECAM encoder is built for a pre-correction shift of 3"; return false; }
+        if (p->sm_k.s_p < 0 || p->sm_k.s_p > kModAnyShift) { err = "SECAM encoder: pre-correction shift beyond the luma delay window (12)"; return false; }
         if (!upload_lanes(d.mod_main, &p->sm_lanes, convert_secam_mod_lane<float, double>, err)) return false;
         p->mod_cycle = d.mod_main.frame_cycle;
         p->mod_n_lines = d.mod_main.n_lines;
@@ -436,7 +435,16 @@ int run_secam_mod(const cm_plan *p, Geom g, hipStream_t stream, bool u8 = false)
     SecamModArgs a;
     a.g = g;
     a.k = p->sm_k;
-    if (p->mod_depth) {
+    const bool any = p->sm_k.s_p != 3;   // 13.5 MHz: shift 3 (tuned instance); other sampling rates: run-time window
+    if (any) {
+        if (p->mod_depth) {
+            if (u8) hipLaunchKernelGGL((secam_mod_kernel<kModAnyShift, 1, true, true>), dim3((int)blocks), dim3(64), 0, stream, a);
+            else hipLaunchKernelGGL((secam_mod_kernel<kModAnyShift, 1, false, true>), dim3((int)blocks), dim3(64), 0, stream, a);
+        } else {
+            if (u8) hipLaunchKernelGGL((secam_mod_kernel<kModAnyShift, 0, true, true>), dim3((int)blocks), dim3(64), 0, stream, a);
+            else hipLaunchKernelGGL((secam_mod_kernel<kModAnyShift, 0, false, true>), dim3((int)blocks), dim3(64), 0, stream, a);
+        }
+    } else if (p->mod_depth) {
         if (u8) hipLaunchKernelGGL((secam_mod_kernel<3, 1, true>), dim3((int)blocks), dim3(64), 0, stream, a);
         else hipLaunchKernelGGL((secam_mod_kernel<3, 1>), dim3((int)blocks), dim3(64), 0, stream, a);
     } else {

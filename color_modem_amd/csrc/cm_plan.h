@@ -172,13 +172,14 @@ bool build_secam_demod_k(const cm_plan_desc &d, SecamDemodK<T> &k, std::string &
     if (!convert_sos<T, 3>(s.fm_lp, FORM_SYM, k.lpf, g_l, err, "fm_lp")) return false;
     if (!convert_sos<T, 3>(s.luma_bs, FORM_SYM, k.ybs, g_y, err, "luma_bs")) return false;
     if (!convert_sos_optional<T, 1>(s.lf_rev, FORM_GEN, k.deemph, g_d, err, "lf_rev")) return false;   // secam.py:173-177
-    if (s.bell.shift != 0 || s.lf_rev.shift != 0 || (s.fm_lp.shift & 1) || s.chroma_bp.shift < 0 || s.luma_bs.shift < 0) {
-        err = "SECAM filter shifts outside what the kernel is built for (bell 0, de-emphasis 0, FM low-pass even)";
+    if (s.bell.shift != 0 || s.lf_rev.shift != 0 || s.fm_lp.shift < 0 || s.chroma_bp.shift < 0 || s.luma_bs.shift < 0) {
+        err = "SECAM filter shifts outside what the kernel is built for (bell 0, de-emphasis 0)";
         return false;
     }
     if (g_b * g_bell * g_l <= 0.0) { err = "SECAM chroma path gain must be positive (the discriminator drops it)"; return false; }
     k.s_b = s.chroma_bp.shift;
-    k.q_l = s.fm_lp.shift / 2;
+    k.q_l = pair_delay(s.fm_lp.shift);
+    k.odd_l = s.fm_lp.shift & 1;
     k.s_y = s.luma_bs.shift;
     k.fc = T(s.fm_fc);
     k.two_over_pi = T(2.0 / 3.141592653589793238462643383279502884);

@@ -105,7 +105,10 @@ __global__ __launch_bounds__(64, 2) void secam_demod_kernel(const SecamDemodArgs
             if (m >= 0) {
                 int xi = P - m;
                 if (xi > W - 1) xi = W - 1;
-                cc = U8 ? __builtin_fmaf((float)xrow8[xi], 5.0f / (255.0f * 3.0f), -1.0f / 3.0f) : xrow[xi];
+                if (P < kInTile)   // the mirrored samples lie in the first input tile
+                    cc = U8 ? __builtin_fmaf((float)xrow8[xi], 5.0f / (255.0f * 3.0f), -1.0f / 3.0f) : xrow[xi];
+                else               // long pre-rolls (sampling rates above ~27 MHz): straight from the row, once per line
+                    cc = U8 ? __builtin_fmaf((float)((const unsigned char *)xp)[xi], 5.0f / (255.0f * 3.0f), -1.0f / 3.0f) : xp[xi];
             }
             step(m, cc, 0.f, s);
         }
@@ -163,7 +166,8 @@ struct SecamModArgs {
 };
 
 // SP = shift of the pre-correction low-pass (register window of the luma delay); DEPTH = 1: line averaging
-template <int SP, int DEPTH, bool U8 = false>
+// RT: SP is the size of the luma delay window, the delay itself is k.s_p <= SP (other sampling rates)
+template <int SP, int DEPTH, bool U8 = false, bool RT = false>
 __global__ __launch_bounds__(64, 2) void secam_mod_kernel(const SecamModArgs args) {
     constexpr int kTile = 16;
     __shared__ __attribute__((aligned(16))) float lds_store[U8 ? kModLdsFloatsU8 : kModLdsFloats];
@@ -188,7 +192,8 @@ __global__ __launch_bounds__(64, 2) void secam_mod_kernel(const SecamModArgs arg
     for (int j = 0; j < SP + 4; ++j) yw[j] = 0.f;
     const int wpos = ((lane >> 1) & (kTile / 4 - 1)) << 2;
     const int W = g.W;
-    const int T = (W + SP + 3) & ~3;
+    const int sp = RT ? k.s_p : SP;
+    const int T = (W + sp + 3) & ~3;
     f4 cur[3], nxt[3];
     first_tile3<U8>(g, itile, rp, lane, nxt);
     for (int tb = 0; tb < T; tb += 4) {
@@ -210,8 +215,14 @@ __global__ __launch_bounds__(64, 2) void secam_mod_kernel(const SecamModArgs arg
                 d = fmaf_(lk.wc0, d, lk.wc1 * dp);
             }
             yw[SP + s] = y;
-            const int n7 = t - SP;
-            float comp = st.step(k, lk, t, yw[s], d);
+            const int n7 = t - sp;
+            float y_d = yw[s];                 // luma of sample t - SP
+            if (RT) {                          // ... t - s_p: uniform selects instead of a dynamic register index
+#pragma unroll
+                for (int j = 0; j < SP; ++j)
+                    if (sp == j) y_d = yw[SP - j + s];
+            }
+            float comp = st.step(k, lk, t, y_d, d);
             put_composite<U8, kTile>(g, otile_base, op, lane, wpos, n7, comp);
         }
 #pragma unroll

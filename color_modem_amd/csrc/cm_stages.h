@@ -641,7 +641,8 @@ struct QamModCore {
 template <typename T>
 struct SecamDemodK {
     int32_t width, preroll;      // W, P
-    int32_t s_b, q_l, s_y;       // chroma band-pass shift, low-pass pair delay, luma band-stop shift
+    int32_t s_b, q_l, s_y;       // chroma band-pass shift, low-pass pair delay ceil(shift / 2), luma band-stop shift
+    int32_t odd_l;               // 1: the low-pass shift is odd (output pairs straddle the filter's pairs)
     int32_t has_bell;            // 0: the variant has no bell filter (secam.py:167-170)
     Taps<T> taps;
     SosK<T, 3> bpf;              // secam.py:183-184 (numerator 1 - z^-2 sections)
@@ -679,12 +680,13 @@ struct SecamDemod {
     HalfbandChain<T> up, dn;
     T cc_last, pi_last, pq_last, x_last;
     T i_prev, q_prev;
+    T i_hold, q_hold;   // previous odd low-pass output (odd shifts)
     int have_prev;
 
     CM_HD void reset() {
         bpf.reset(); ybs.reset(); bell.reset(); lp_i.reset(); lp_q.reset(); deemph.reset();
         up.reset(); dn.reset();
-        cc_last = pi_last = pq_last = x_last = i_prev = q_prev = T(0);
+        cc_last = pi_last = pq_last = x_last = i_prev = q_prev = i_hold = q_hold = T(0);
         have_prev = 0;
     }
     // row sample n = m - latency(k)
@@ -724,6 +726,12 @@ struct SecamDemod {
             if (m2 >= Lc) { pi_e = pi_o = pi_last; pq_e = pq_o = pq_last; }
             T i0 = iir_sym<VP::VL>(lp_i, k.lpf, pi_e), q0 = iir_sym<VP::VL>(lp_q, k.lpf, pq_e);
             T i1 = iir_sym<VP::VL>(lp_i, k.lpf, pi_o), q1 = iir_sym<VP::VL>(lp_q, k.lpf, pq_o);
+            if (k.odd_l) {   // pair m3 of the shifted stream = (odd output of the previous pair, even output of this one)
+                const T ih = i_hold, qh = q_hold;
+                i_hold = i1; q_hold = q1;
+                i1 = i0; q1 = q0;
+                i0 = ih; q0 = qh;
+            }
             if (m3 >= 0 && m3 < Lc) {
                 T d_e = have_prev ? phase_step(i_prev, q_prev, i0, q0) : T(0);  // secam.py:147: first step is 0
                 T d_o = phase_step(i0, q0, i1, q1);

@@ -458,14 +458,14 @@ struct SecamDemodPk {
     IirState<float, 1> deemph;
     HalfbandChain<float> up, dn;
     float cc_last, x_last;
-    pf2 p_last, iq_prev;
+    pf2 p_last, iq_prev, iq_hold;
     int have_prev;
 
     __device__ __forceinline__ void reset() {
         bpf.reset(); ybs.reset(); bell.reset(); lp.reset(); deemph.reset();
         up.reset(); dn.reset();
         cc_last = x_last = 0.f;
-        p_last = iq_prev = pf2{0.f, 0.f};
+        p_last = iq_prev = iq_hold = pf2{0.f, 0.f};
         have_prev = 0;
     }
     // car_e / car_o: {cos, sin} of the FM reference at 2x samples 2 m2 and 2 m2 + 1 (SGPR pairs)
@@ -492,8 +492,14 @@ struct SecamDemodPk {
         if (m2 >= 0 && m2 < Lc + k.q_l) {
             if (m2 == Lc - 1) p_last = p_o;
             if (m2 >= Lc) p_e = p_o = p_last;
-            const pf2 y0 = iir_sym_pk<0, 3>(lp, kp.lpf, p_e);
-            const pf2 y1 = iir_sym_pk<0, 3>(lp, kp.lpf, p_o);
+            pf2 y0 = iir_sym_pk<0, 3>(lp, kp.lpf, p_e);
+            pf2 y1 = iir_sym_pk<0, 3>(lp, kp.lpf, p_o);
+            if (k.odd_l) {   // odd shift: pair m3 = (odd output of the previous pair, even output of this one)
+                const pf2 h = iq_hold;
+                iq_hold = y1;
+                y1 = y0;
+                y0 = h;
+            }
             if (m3 >= 0 && m3 < Lc) {
                 const float d_e = have_prev ? phase_step_fast(iq_prev.x, iq_prev.y, y0.x, y0.y) : 0.f;  // secam.py:147: first step is 0
                 const float d_o = phase_step_fast(y0.x, y0.y, y1.x, y1.y);

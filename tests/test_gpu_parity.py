@@ -266,6 +266,21 @@ def test_other_widths_vs_oracle(stack, size):
         assert stacks.rel_err(got[i], want[i]) < TOL, (stack, size, i)
 
 
+@pytest.mark.parametrize('size', [(640, 576), (768, 576), (960, 40), (1024, 576), (1280, 31), (1440, 12), (1920, 9)])
+def test_secam_other_widths_vs_oracle(size):
+    """SECAM at other sampling rates: odd FM low-pass shifts (640, 960, 1024), other pre-correction / band-pass shifts."""
+    from oracle import cm_oracle
+    modem = stacks.make('secam', size, explicit=False)
+    im = image.ImageModem(modem)
+    rgb = testing.synthetic_rgb(2, size[1], size[0], seed=78)
+    comp_ref = cm_oracle.modulate_frames_f32(modem, rgb, first_frame=2, n_threads=8)
+    assert stacks.rel_err(im.modulate_frames(rgb, first_frame=2), comp_ref) < TOL
+    got = im.demodulate_frames(comp_ref, first_frame=2)
+    want = cm_oracle.demodulate_frames_f32(modem, comp_ref, first_frame=2, n_threads=8)
+    for i in range(2):
+        assert stacks.rel_err(got[i], want[i]) < TOL, (size, i)
+
+
 # ---- sub-carrier cycles too long to tabulate per frame: two parity frames + per-frame rotation ---------------------
 @pytest.mark.parametrize('kind,variant,size,first', [
     ('ntsc_comb_3d', 'NTSC443', (720, 480), 4798),     # NTSC 4.43 on 525 lines: cycle 4800, batch wraps around it
