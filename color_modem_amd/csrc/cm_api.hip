@@ -215,40 +215,45 @@ bool select_for_shape(cm_plan *p, const cm_plan_desc &d, const char *sys, std::s
 }
 
 // Run-time shape (SysAny): any sampling rate whose filters fit 4 / 3 / 3 / 2 sections and a pre-correction shift <= 12.
-// One wave per 64 calls, float32 planes only (no notch, no minavg, no fused byte boundary: those raise and the Python
-// layer converts on the host).
+// float32 planes only (no fused byte boundary: cm_demodulate_frames_u8 reports CM_ERR_UNSUPPORTED and the Python layer
+// converts on the host).
 bool select_any(cm_plan *p, const cm_plan_desc &d, std::string &err) {
     typedef SysAny S;
     const bool pald = d.pipeline == CM_PIPE_PAL_D;
     const bool bsf = d.main_luma_bandstop != 0;
     const bool first = d.first_is_plain != 0;
+    const bool notch = d.notch.n_sections != 0;
+    const bool minavg = d.chroma_average == CM_AVG_MIN;
     const int depth = d.depth;
     typedef PassCfg<S, FRONT_QAM, true, 0, 8> First;
     p->fn = nullptr;
     p->fn_u8 = nullptr;
     std::string what;
-    if (d.notch.n_sections != 0 || d.chroma_average == CM_AVG_MIN) {
-        err = "notch / minavg are built for the tuned filter shapes (13.5 MHz) only";
-        return false;
-    }
-    if (pald) {
+    if (minavg) {
+        if (pald || bsf || first) { err = "minavg is built behind the QAM front end (SimpleCombModem, Pal3DModem)"; return false; }
+        p->fn = launch_demod<PassCfg<S, FRONT_QAM, false, 2, 16, false, true, true>, NoPass>;
+        p->main.depth = 2; what = "qam front, depth 2, minavg";
+    } else if (pald) {
         if (depth != 1 || !first) { err = "PAL-D front end is built with one line of history and a plain first line"; return false; }
-        p->fn = launch_demod<PassCfg<S, FRONT_PALD, false, 1, 16>, First>;
+        if (notch) p->fn = launch_demod<PassCfg<S, FRONT_PALD, false, 1, 16, false, true>, First>;
+        else p->fn = launch_demod<PassCfg<S, FRONT_PALD, false, 1, 16>, First>;
         p->main.depth = 1; what = "pal-d front, depth 1 | plain first line";
     } else if (bsf) {
-        if (depth != 0 || first) { err = "band-stop luma is built for plain decoders only"; return false; }
+        if (depth != 0 || first || notch) { err = "band-stop luma is built for plain decoders only"; return false; }
         p->fn = launch_demod<PassCfg<S, FRONT_QAM, true, 0, 16>, NoPass>;
         p->main.depth = 0; what = "qam front + band-stop, depth 0";
     } else if (first) {
         if (depth != 1) { err = "a comb with a plain first line is built with one line of history"; return false; }
-        p->fn = launch_demod<PassCfg<S, FRONT_QAM, false, 1, 16>, First>;
+        if (notch) p->fn = launch_demod<PassCfg<S, FRONT_QAM, false, 1, 16, false, true>, First>;
+        else p->fn = launch_demod<PassCfg<S, FRONT_QAM, false, 1, 16>, First>;
         p->main.depth = 1; what = "qam front, depth 1 | plain first line";
     } else {
-        p->fn = launch_demod<PassCfg<S, FRONT_QAM, false, 2, 16>, NoPass>;
+        if (notch) p->fn = launch_demod<PassCfg<S, FRONT_QAM, false, 2, 16, false, true>, NoPass>;
+        else p->fn = launch_demod<PassCfg<S, FRONT_QAM, false, 2, 16>, NoPass>;
         p->main.depth = 2; what = "qam front, depth 2";
     }
-    p->pair = CM_PAIR != 0 && (pald || bsf);   // PassCfg::kUsePair: these do not fit one wave's registers
-    p->main.name = std::string(p->pair ? "demod_pair_kernel" : "demod_kernel") + "<run-time shape: " + what + ">";
+    p->pair = CM_PAIR != 0 && (pald || bsf || notch || minavg);   // PassCfg::kUsePair: these do not fit one wave's registers
+    p->main.name = std::string(p->pair ? "demod_pair_kernel" : "demod_kernel") + "<run-time shape: " + what + (notch ? " + notch>" : ">");
     return make_passes<S>(p, d, pald, bsf, first, err);
 }
 

@@ -266,6 +266,19 @@ def test_other_widths_vs_oracle(stack, size):
         assert stacks.rel_err(got[i], want[i]) < TOL, (stack, size, i)
 
 
+@pytest.mark.parametrize('stack,size', [('pal_d_notch', (768, 576)), ('pal_3d_notch', (1024, 576)), ('ntsc_comb_3d_notch', (640, 480)),
+                                        ('pal_3d_minavg', (960, 576)), ('ntsc_simple_minavg', (768, 480)), ('ntsc_comb_3d_minavg', (1280, 480))])
+def test_options_at_other_widths_vs_oracle(stack, size):
+    from oracle import cm_oracle
+    from color_modem_amd import line
+    comp = testing.synthetic_composite(2, 24, size[0], seed=91)
+    modem = stacks.STACKS[stack](line.LineConfig((size[0], 24), line.LineStandard.detect(size[1])))   # 24 rows of the full-height standard
+    got = image.ImageModem(modem).demodulate_frames(comp, first_frame=1)
+    want = cm_oracle.demodulate_frames_f32(modem, comp, first_frame=1, n_threads=8)
+    for i in range(2):
+        assert stacks.rel_err(got[i], want[i]) < TOL, (stack, size, i)
+
+
 @pytest.mark.parametrize('size', [(640, 576), (768, 576), (960, 40), (1024, 576), (1280, 31), (1440, 12), (1920, 9)])
 def test_secam_other_widths_vs_oracle(size):
     """SECAM at other sampling rates: odd FM low-pass shifts (640, 960, 1024), other pre-correction / band-pass shifts."""
