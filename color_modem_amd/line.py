@@ -14,6 +14,16 @@ _FIELDS = ('frame_rate', 'total_lines',
            'even_field_first_active_line', 'even_field_last_active_line',
            'total_width_factor')
 
+# name, frames per second, lines per frame, active lines of the odd field (first, last), of the even field, ratio of the
+# whole line to its active part (ref line.py:42-46)
+_PRESETS = (
+    ('BAIRD_405', 25.0, 405, (16, 203), (218, 405), 1.2),
+    ('NTSC_525', 30000.0 / 1001.0, 525, (21, 263), (283, 525), 858.0 / 720.0),
+    ('GERBER_625', 25.0, 625, (336, 623), (23, 310), 1.2),
+    ('FRENCH_819', 25.0, 819, (39, 407), (448, 816), 1.2),
+    ('BELGIAN_819', 25.0, 819, (437, 816), (27, 406), 1.2),
+)
+
 
 class LineStandard(collections.namedtuple('LineStandard', _FIELDS)):
     """Timing of one analog scanning standard (ref line.py:6-39)."""
@@ -21,9 +31,9 @@ class LineStandard(collections.namedtuple('LineStandard', _FIELDS)):
 
     def __new__(cls, *args, **kwargs):
         std = super(LineStandard, cls).__new__(cls, *args, **kwargs)
-        odd = std.odd_field_last_active_line - std.odd_field_first_active_line
-        even = std.even_field_last_active_line - std.even_field_first_active_line
-        if odd < 0 or even < 0 or odd != even:
+        per_field = (std.odd_field_last_active_line - std.odd_field_first_active_line,
+                     std.even_field_last_active_line - std.even_field_first_active_line)
+        if min(per_field) < 0 or per_field[0] != per_field[1]:
             raise AssertionError('fields must hold the same, non-negative number of lines')
         if std.active_lines > std.total_lines:
             raise AssertionError('more active lines than total lines')
@@ -31,12 +41,12 @@ class LineStandard(collections.namedtuple('LineStandard', _FIELDS)):
 
     @property
     def active_lines(self):
-        return (self.odd_field_last_active_line - self.odd_field_first_active_line
-                + self.even_field_last_active_line - self.even_field_first_active_line + 2)
+        # both fields hold the same number of lines (checked at construction)
+        return 2 * (self.odd_field_last_active_line - self.odd_field_first_active_line + 1)
 
     @classmethod
     def presets(cls):
-        return [v for v in vars(cls).values() if isinstance(v, cls)]
+        return [getattr(cls, name) for name, *_ in _PRESETS]
 
     @classmethod
     def detect(cls, active_lines):
@@ -49,29 +59,27 @@ class LineStandard(collections.namedtuple('LineStandard', _FIELDS)):
         return [std for std in fitting if std.active_lines == smallest][-1]
 
 
-LineStandard.BAIRD_405 = LineStandard(25.0, 405, 16, 203, 218, 405, 1.2)
-LineStandard.NTSC_525 = LineStandard(30000.0 / 1001.0, 525, 21, 263, 283, 525, 858.0 / 720.0)
-LineStandard.GERBER_625 = LineStandard(25.0, 625, 336, 623, 23, 310, 1.2)
-LineStandard.FRENCH_819 = LineStandard(25.0, 819, 39, 407, 448, 816, 1.2)
-LineStandard.BELGIAN_819 = LineStandard(25.0, 819, 437, 816, 27, 406, 1.2)
+for _name, _rate, _total, _odd, _even, _factor in _PRESETS:
+    setattr(LineStandard, _name, LineStandard(_rate, _total, _odd[0], _odd[1], _even[0], _even[1], _factor))
 
 
 class LineConfig(object):
     """Image size bound to a line standard (ref line.py:49-65)."""
 
     def __init__(self, size, line_standard=None):
-        if line_standard is None:
-            line_standard = LineStandard.detect(size[1])
-        self.size = (int(size[0]), int(size[1]))
-        self.line_standard = line_standard
-        self.fs = line_standard.frame_rate * line_standard.total_lines * size[0] * line_standard.total_width_factor
-        self._line_shift = (line_standard.active_lines - size[1]) // 2
+        width, height = int(size[0]), int(size[1])
+        std = LineStandard.detect(height) if line_standard is None else line_standard
+        self.size = (width, height)
+        self.line_standard = std
+        # sampling rate: `width` samples in the active part of every line
+        self.fs = std.frame_rate * std.total_lines * size[0] * std.total_width_factor
+        # image rows are centred in the active lines; rows alternate between the fields, even rows first
+        self._line_shift = (std.active_lines - height) // 2
+        self._field_start = (std.even_field_first_active_line, std.odd_field_first_active_line)
 
     def analog_line(self, digital_line):
-        adjusted = digital_line + self._line_shift
-        first = (self.line_standard.even_field_first_active_line if adjusted % 2 == 0
-                 else self.line_standard.odd_field_first_active_line)
-        return first + adjusted // 2
+        row = digital_line + self._line_shift
+        return self._field_start[row & 1] + (row >> 1)
 
     def is_alternate_line(self, frame, line):
-        return self.analog_line(line) % 2 == frame % 2
+        return (self.analog_line(line) ^ frame) & 1 == 0
