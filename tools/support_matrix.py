@@ -63,7 +63,19 @@ def try_pair(make, variant, size):
         return 'ERROR %s: %s' % (type(e).__name__, e)
 
 
+def widths():
+    """The default variant of each system at other image widths (= sampling rates): the run-time-shape instances."""
+    for system, v in (('pal', pal.PalVariant.PAL), ('ntsc', ntsc.NtscVariant.NTSC), ('secam', secam.SecamVariant.SECAM)):
+        for w in (480, 544, 640, 704, 768, 960, 1024, 1280, 1440, 1920):
+            size = (w, 480 if system == 'ntsc' else 576)
+            for sname, make in stacks_for(system):
+                print('%-8s %-10s %-9s %-20s %s' % (system, 'default', '%dx%d' % size, sname, try_pair(make, v, size)))
+                sys.stdout.flush()
+
+
 def main():
+    if sys.argv[1:2] == ['widths']:
+        return widths()
     for system, cls in (('pal', pal.PalVariant), ('ntsc', ntsc.NtscVariant), ('secam', secam.SecamVariant)):
         for vname in variants(cls):
             v = getattr(cls, vname)
