@@ -215,8 +215,7 @@ bool select_for_shape(cm_plan *p, const cm_plan_desc &d, const char *sys, std::s
 }
 
 // Run-time shape (SysAny): any sampling rate whose filters fit 4 / 3 / 3 / 2 sections and a pre-correction shift <= 12.
-// float32 planes only (no fused byte boundary: cm_demodulate_frames_u8 reports CM_ERR_UNSUPPORTED and the Python layer
-// converts on the host).
+// The fused byte boundary exists where the tuned shapes have it (not with notch / minavg).
 bool select_any(cm_plan *p, const cm_plan_desc &d, std::string &err) {
     typedef SysAny S;
     const bool pald = d.pipeline == CM_PIPE_PAL_D;
@@ -226,6 +225,7 @@ bool select_any(cm_plan *p, const cm_plan_desc &d, std::string &err) {
     const bool minavg = d.chroma_average == CM_AVG_MIN;
     const int depth = d.depth;
     typedef PassCfg<S, FRONT_QAM, true, 0, 8> First;
+    typedef PassCfg<S, FRONT_QAM, true, 0, 16, true> FirstU8;
     p->fn = nullptr;
     p->fn_u8 = nullptr;
     std::string what;
@@ -236,23 +236,33 @@ bool select_any(cm_plan *p, const cm_plan_desc &d, std::string &err) {
     } else if (pald) {
         if (depth != 1 || !first) { err = "PAL-D front end is built with one line of history and a plain first line"; return false; }
         if (notch) p->fn = launch_demod<PassCfg<S, FRONT_PALD, false, 1, 16, false, true>, First>;
-        else p->fn = launch_demod<PassCfg<S, FRONT_PALD, false, 1, 16>, First>;
+        else {
+            p->fn = launch_demod<PassCfg<S, FRONT_PALD, false, 1, 16>, First>;
+            p->fn_u8 = launch_demod<PassCfg<S, FRONT_PALD, false, 1, 16, true>, FirstU8>;
+        }
         p->main.depth = 1; what = "pal-d front, depth 1 | plain first line";
     } else if (bsf) {
         if (depth != 0 || first || notch) { err = "band-stop luma is built for plain decoders only"; return false; }
         p->fn = launch_demod<PassCfg<S, FRONT_QAM, true, 0, 16>, NoPass>;
+        p->fn_u8 = launch_demod<PassCfg<S, FRONT_QAM, true, 0, 16, true>, NoPass>;
         p->main.depth = 0; what = "qam front + band-stop, depth 0";
     } else if (first) {
         if (depth != 1) { err = "a comb with a plain first line is built with one line of history"; return false; }
         if (notch) p->fn = launch_demod<PassCfg<S, FRONT_QAM, false, 1, 16, false, true>, First>;
-        else p->fn = launch_demod<PassCfg<S, FRONT_QAM, false, 1, 16>, First>;
+        else {
+            p->fn = launch_demod<PassCfg<S, FRONT_QAM, false, 1, 16>, First>;
+            p->fn_u8 = launch_demod<PassCfg<S, FRONT_QAM, false, 1, 16, true>, FirstU8>;
+        }
         p->main.depth = 1; what = "qam front, depth 1 | plain first line";
     } else {
         if (notch) p->fn = launch_demod<PassCfg<S, FRONT_QAM, false, 2, 16, false, true>, NoPass>;
-        else p->fn = launch_demod<PassCfg<S, FRONT_QAM, false, 2, 16>, NoPass>;
+        else {
+            p->fn = launch_demod<PassCfg<S, FRONT_QAM, false, 2, 16>, NoPass>;
+            p->fn_u8 = launch_demod<PassCfg<S, FRONT_QAM, false, 2, 16, true>, NoPass>;
+        }
         p->main.depth = 2; what = "qam front, depth 2";
     }
-    p->pair = CM_PAIR != 0 && (pald || bsf || notch || minavg);   // PassCfg::kUsePair: these do not fit one wave's registers
+    p->pair = CM_PAIR != 0;   // PassCfg::kUsePair: the run-time shape does not fit one wave's registers
     p->main.name = std::string(p->pair ? "demod_pair_kernel" : "demod_kernel") + "<run-time shape: " + what + (notch ? " + notch>" : ">");
     return make_passes<S>(p, d, pald, bsf, first, err);
 }

@@ -148,9 +148,9 @@ struct PassCfg {
     // line of history, the notch, the second combination of minavg) would spill there and get 2 waves per SIMD instead
     static constexpr int kPairWaves = (DEPTH_ >= 2 || NOTCH_ || MINAVG_ || S_::NE >= 4 || S_::NP >= 2 || S_::RT) ? 2 : 3;
     // which kernel structure runs this instance: the pair where it gets 3 waves per SIMD (measured 1-3 % faster there,
-    // 2-5 % slower at 2), and where one wave's 256 VGPRs do not hold the line: the PAL-D front end with the notch, the
-    // PAL-D, band-stop, notch and minavg instances of the run-time shape
-    static constexpr bool kUsePair = kPairWaves == 3 || (FRONT_ == 1 && NOTCH_) || (S_::RT && (FRONT_ == 1 || BSF_ || NOTCH_ || MINAVG_));
+    // 2-5 % slower at 2), and where one wave's 256 VGPRs do not hold the line: the PAL-D front end with the notch and the
+    // run-time shape (maximum section counts, 12-sample delay windows)
+    static constexpr bool kUsePair = kPairWaves == 3 || (FRONT_ == 1 && NOTCH_) || S_::RT;
 };
 struct NoPass {
     static constexpr int kLdsFloats = 0;

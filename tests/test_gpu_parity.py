@@ -388,7 +388,10 @@ def test_unsupported_variants_fail_loudly():
 # ---- fused uint8 boundary (cm_demodulate_frames_u8) --------------------------------------------------------
 @pytest.mark.parametrize('stack,size,n_frames,first', [('pal_d', (720, 576), 2, 1), ('pal_s', (720, 40), 3, 0),
                                                        ('pal_3d', (720, 33), 2, 2), ('ntsc_comb_3d', (720, 480), 2, 1),
-                                                       ('ntsc', (720, 18), 2, 0), ('pal_d', (704, 9), 2, 3)])
+                                                       ('ntsc', (720, 18), 2, 0), ('pal_d', (704, 9), 2, 3),
+                                                       # the run-time filter shape (other image widths)
+                                                       ('pal_d', (768, 576), 2, 1), ('ntsc_comb', (640, 480), 2, 0), ('pal_3d', (1024, 576), 2, 2),
+                                                       ('pal_s', (1280, 576), 1, 3)])
 def test_fused_uint8_matches_float_path(stack, size, n_frames, first):
     """uint8 in / uint8 out through the kernel == host-side level decode -> float kernel -> host-side _as_bytes,
     up to float32 rounding of the level mapping at the knife edge of rint (<= 1 LSB on < 0.2 % of the samples)."""
