@@ -105,6 +105,12 @@ bool make_pass(const cm_plan_desc &d, bool pald, bool bsf, const cm_lane_table &
     DemodK<float, S> k;
     DemodScales sc;
     if (!build_demod_k<float, S>(d, pald, bsf, k, sc, err)) return false;
+    {   // capacities the kernels assume (cm_kernels.h): carrier padding, band-stop luma ring of the wave pair
+        const int lat_front = pald ? 10 + k.q_e + 9 + 10 + k.q_l + 9 : 10 + k.q_e + k.q_l + 9;
+        const int lat_out = lat_front + 1 + k.s_p;
+        if (lat_out + 8 > kCarrierPad) { err = "pipeline latency beyond the carrier table padding"; return false; }
+        if (bsf && lat_out - (10 + k.q_r + 9) + 12 > 32) { err = "band-stop luma delay beyond its LDS ring"; return false; }
+    }
     pass.k.resize(sizeof(k));
     std::memcpy(pass.k.data(), &k, sizeof(k));
     const size_t n = (size_t)tb.frame_cycle * 3 * tb.n_lines;
