@@ -344,9 +344,15 @@ __device__ __forceinline__ void flush_tile(const Geom &g, const lds_float *otile
             if (v0.x == 12345.678f)
 #endif
             {
+#ifdef CM_EXP_PLAIN_STORE   /* experiment: default cache policy for the output stores */
+                dst[0] = v0;
+                dst[g.out_plane_stride >> 2] = v1;
+                dst[(2 * g.out_plane_stride) >> 2] = v2;
+#else
                 __builtin_nontemporal_store(v0, &dst[0]);
                 __builtin_nontemporal_store(v1, &dst[g.out_plane_stride >> 2]);
                 __builtin_nontemporal_store(v2, &dst[(2 * g.out_plane_stride) >> 2]);
+#endif
             }
 #else
 #pragma nounroll
