@@ -92,7 +92,8 @@ struct cm_plan {
     bool secam = false;
     SecamDemodK<float> sd_k;
     SecamDemodLaneK<float> *sd_lanes = nullptr;
-    float *fm_ref = nullptr;
+    float *fm_ref = nullptr;      // SECAM discriminator reference {cos, sin} pairs
+    float *fm_dc = nullptr;       // SECAM: decimator response to the constant fc beyond 2 fc (cm_plan.h: build_fm_dc)
     int sd_cycle = 0, sd_n_lines = 0;
     SecamModK<float, double> sm_k;
     SecamModLaneK<float, double> *sm_lanes = nullptr;
@@ -403,12 +404,16 @@ bool create_secam(cm_plan *p, const cm_plan_desc &d, std::string &err) {
     p->secam = true;
     if (!build_secam_demod_k<float>(d, p->sd_k, err)) return false;
     if (!d.demod_main.table) { err = "demod_main table missing"; return false; }
-    if (!upload_lanes(d.demod_main, &p->sd_lanes, convert_secam_demod_lane<float>, err)) return false;
+    if (!upload_lanes(d.demod_main, &p->sd_lanes, [&](const double *e) { return convert_secam_demod_lane<float>(e, d.secam); }, err))
+        return false;
     p->sd_cycle = d.demod_main.frame_cycle;
     p->sd_n_lines = d.demod_main.n_lines;
     std::vector<float> fm = build_fm_reference<float>(d.secam.fm_fc, d.width + d.secam.preroll);
+    std::vector<float> dc = build_fm_dc<float>(d, d.width + d.secam.preroll);
     if (hipMalloc((void **)&p->fm_ref, fm.size() * sizeof(float)) != hipSuccess ||
-        hipMemcpy(p->fm_ref, fm.data(), fm.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) {
+        hipMemcpy(p->fm_ref, fm.data(), fm.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess ||
+        hipMalloc((void **)&p->fm_dc, dc.size() * sizeof(float)) != hipSuccess ||
+        hipMemcpy(p->fm_dc, dc.data(), dc.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) {
         err = "device allocation / upload of the FM reference failed";
         return false;
     }
@@ -428,7 +433,7 @@ bool create_secam(cm_plan *p, const cm_plan_desc &d, std::string &err) {
 int run_secam_demod(const cm_plan *p, Geom g, hipStream_t stream, bool u8 = false) {
     g.lanes = reinterpret_cast<const LaneK<float> *>(p->sd_lanes);
     g.carrier4 = p->fm_ref;
-    g.carrier2 = p->fm_ref;
+    g.carrier2 = p->fm_dc;
     g.cycle = p->sd_cycle;
     g.n_lines = p->sd_n_lines;
     g.skip_first = 0;
@@ -633,6 +638,7 @@ void cm_plan_destroy(cm_plan *p) {
     if (p->sd_lanes) (void)hipFree(p->sd_lanes);
     if (p->sm_lanes) (void)hipFree(p->sm_lanes);
     if (p->fm_ref) (void)hipFree(p->fm_ref);
+    if (p->fm_dc) (void)hipFree(p->fm_dc);
     delete p;
 }
 

@@ -181,10 +181,7 @@ bool build_secam_demod_k(const cm_plan_desc &d, SecamDemodK<T> &k, std::string &
     k.q_l = pair_delay(s.fm_lp.shift);
     k.odd_l = s.fm_lp.shift & 1;
     k.s_y = s.luma_bs.shift;
-    k.fc = T(s.fm_fc);
     k.two_over_pi = T(2.0 / 3.141592653589793238462643383279502884);
-    k.f2_min = T(2.0 * s.flimit_min);
-    k.f2_max = T(2.0 * s.flimit_max);
     k.luma_gain = T(g_y);
     for (int i = 0; i < 3; ++i) {
         k.m[i][0] = T(d.decode_matrix[3 * i]);
@@ -194,14 +191,33 @@ bool build_secam_demod_k(const cm_plan_desc &d, SecamDemodK<T> &k, std::string &
     return true;
 }
 
+// e = {fsc, fdev, own_is_db, w_prev} of the line (normalised frequencies)
 template <typename T>
-SecamDemodLaneK<T> convert_secam_demod_lane(const double *e) {
+SecamDemodLaneK<T> convert_secam_demod_lane(const double *e, const cm_secam_desc &s) {
     SecamDemodLaneK<T> l;
     l.scale = T(0.5 / e[1]);
-    l.offset = T(-e[0] / e[1]);
+    l.off2 = T(2.0 * (s.fm_fc - e[0]));
+    l.lo = T(2.0 * (s.flimit_min - e[0]));
+    l.hi = T(2.0 * (s.flimit_max - e[0]));
     l.own_is_db = T(e[2]);
     l.w_prev = T(e[3]);
     return l;
+}
+
+// dc[n] = fc (2 sum_k h[k] [0 <= 2 n + 20 - k < 2 lc] - 2): what the decimator makes of the constant fc of
+// frequencies_up (length 2 lc, zero-padded by resample_poly) beyond 2 fc, n = 0 .. lc - 1 (float64 arithmetic)
+template <typename T>
+std::vector<T> build_fm_dc(const cm_plan_desc &d, int lc) {
+    std::vector<T> t((size_t)lc);
+    for (int n = 0; n < lc; ++n) {
+        double acc = 0.0;
+        for (int k = 0; k < 41; ++k) {
+            const long long j = 2LL * n + 20 - k;
+            if (j >= 0 && j < 2LL * lc) acc += d.resample_fir[k];
+        }
+        t[n] = T(d.secam.fm_fc * (2.0 * acc - 2.0));
+    }
+    return t;
 }
 
 template <typename T, typename TD>

@@ -17,7 +17,8 @@
 namespace cm {
 
 struct SecamDemodArgs {
-    Geom g;                    // g.lanes -> SecamDemodLaneK<float> table, g.carrier4 -> FM reference {cos, sin} pairs
+    Geom g;                    // g.lanes -> SecamDemodLaneK<float> table, g.carrier4 -> FM reference {cos, sin} pairs,
+                               // g.carrier2 -> dc table (cm_plan.h: build_fm_dc)
     SecamDemodK<float> k;
 };
 
@@ -77,8 +78,11 @@ __global__ __launch_bounds__(64, 2) void secam_demod_kernel(const SecamDemodArgs
         int m2 = m - k.s_b - 10;
         m2 = m2 < 0 ? 0 : (m2 > Lc - 1 ? Lc - 1 : m2);
         f4 c = ((const_f4 *)g.carrier4)[m2];
+        int m4 = m - lat + P;                               // row-stream sample the decimator completes in this step
+        m4 = m4 < 0 ? 0 : (m4 > Lc - 1 ? Lc - 1 : m4);
+        const float dc = ((const __attribute__((address_space(4))) float *)g.carrier2)[m4];
         float ch_out;
-        float own = st.chroma_step(k, kp, lk, m, cc, chw[sub], pf2{c.x, c.y}, pf2{c.z, c.w}, ch_out);
+        float own = st.chroma_step(k, kp, lk, m, cc, chw[sub], pf2{c.x, c.y}, pf2{c.z, c.w}, dc, ch_out);
         chw[10 + sub] = ch_out;
         const int n = m - 1 - lat;                          // the back end runs one sample behind the exchange
         float luma = st.luma_step(k, n, x_l);

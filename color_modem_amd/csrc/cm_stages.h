@@ -650,15 +650,20 @@ struct SecamDemodK {
     SosK<T, 3> lpf;              // secam.py:131-132
     SosK<T, 3> ybs;              // secam.py:185-186
     SosK<T, 1> deemph;           // secam.py:175-177 (backward), first order
-    T fc, two_over_pi;           // frequencies_up = fc + 2 d / pi (secam.py:148)
-    T f2_min, f2_max;            // 2 * flimit (the decimator output is doubled)
+    T two_over_pi;               // frequencies_up - fc = 2 d / pi (secam.py:148)
     T luma_gain;
     T m[3][3];                   // (r, g, b) = m . (luma, dr, db), de-emphasis gain folded into columns 1, 2
 };
 
+// The decimated frequency is carried as its deviation from the discriminator centre: the float32 decimator runs on
+// g = frequencies_up - fc (|g| < 0.1, so its rounding is an order of magnitude below that of values around fc = 0.64), the
+// response to the constant fc - including the zero-padded row ends - comes from a float64 table of the plan:
+//   2 resample_poly(frequencies_up, 1, 2)[n] = dn(g)[n] + 2 fc + dc[n],   dc[n] = fc (2 sum_k h[k] [inside] - 2)
 template <typename T>
 struct SecamDemodLaneK {
-    T scale, offset;  // c = f2 * scale + offset  with scale = 0.5 / fdev_x, offset = -fsc_x / fdev_x
+    T scale;          // 0.5 / fdev_x:  c = clip(dn(g) + dc + off2, lo, hi) * scale   (secam.py:290-296)
+    T off2;           // 2 (fc - fsc_x)
+    T lo, hi;         // 2 (flimit - fsc_x)
     T own_is_db;      // 1: this line carries Db (alternate line), 0: Dr
     T w_prev;         // 0 on the first call of a run (last_chroma = zeros), else 1
 };
@@ -704,7 +709,8 @@ struct SecamDemod {
     // cc_now = cc[m]; ch_d10 = ch[m1 - 10] (caller's delay window); car = {cos, sin} of the FM
     // reference at 2x samples 2 m2 and 2 m2 + 1.  Returns the de-emphasised colour-difference sample
     // c[n], n = m - latency (meaningful for 0 <= n < W), and ch[m1] through ch_out.
-    CM_HD T chroma_step(const SecamDemodK<T> &k, const SecamDemodLaneK<T> &lk, int m, T cc_now, T ch_d10, const T car[4], T &ch_out) {
+    // dc = the plan's table entry of row-stream sample m4 (see SecamDemodLaneK)
+    CM_HD T chroma_step(const SecamDemodK<T> &k, const SecamDemodLaneK<T> &lk, int m, T cc_now, T ch_d10, const T car[4], T dc, T &ch_out) {
         const int W = k.width, Lc = k.width + k.preroll;
         const int m1 = m - k.s_b, m2 = m1 - 10, m3 = m2 - k.q_l, m4 = m3 - 9, n = m4 - k.preroll;
         T ch = T(0);
@@ -738,15 +744,16 @@ struct SecamDemod {
                 have_prev = 1;
                 i_prev = i1;
                 q_prev = q1;
-                f_e = fmaf_(d_e, k.two_over_pi, k.fc);
-                f_o = fmaf_(d_o, k.two_over_pi, k.fc);
+                f_e = d_e * k.two_over_pi;
+                f_o = d_o * k.two_over_pi;
             }
         }
-        T f2 = dn.template push_pair<VP::VT>(k.taps, f_e, f_o);   // 2 * resample_poly(frequencies_up, 1, 2)[m4]
+        T g2 = dn.template push_pair<VP::VT>(k.taps, f_e, f_o);   // 2 * resample_poly(frequencies_up - fc [inside], 1, 2)[m4]
         T c = T(0);
         if (n >= 0 && n < W) {
-            f2 = f2 < k.f2_min ? k.f2_min : (f2 > k.f2_max ? k.f2_max : f2);   // secam.py:290
-            c = iir_gen<false>(deemph, k.deemph, fmaf_(f2, lk.scale, lk.offset));   // secam.py:291-296
+            T f2 = (g2 + dc) + lk.off2;                              // 2 (f - fsc)
+            f2 = f2 < lk.lo ? lk.lo : (f2 > lk.hi ? lk.hi : f2);     // secam.py:290
+            c = iir_gen<false>(deemph, k.deemph, f2 * lk.scale);     // secam.py:291-296
         }
         return c;
     }

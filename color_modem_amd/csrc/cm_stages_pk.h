@@ -470,7 +470,7 @@ struct SecamDemodPk {
     }
     // car_e / car_o: {cos, sin} of the FM reference at 2x samples 2 m2 and 2 m2 + 1 (SGPR pairs)
     __device__ __forceinline__ float chroma_step(const SecamDemodK<float> &k, const SecamDemodKPk &kp, const SecamDemodLaneK<float> &lk, int m,
-                                                 float cc_now, float ch_d10, pf2 car_e, pf2 car_o, float &ch_out) {
+                                                 float cc_now, float ch_d10, pf2 car_e, pf2 car_o, float dc, float &ch_out) {
         const int W = k.width, Lc = k.width + k.preroll;
         const int m1 = m - k.s_b, m2 = m1 - 10, m3 = m2 - k.q_l, m4 = m3 - 9, n = m4 - k.preroll;
         float ch = 0.f;
@@ -505,15 +505,16 @@ struct SecamDemodPk {
                 const float d_o = phase_step_fast(y0.x, y0.y, y1.x, y1.y);
                 have_prev = 1;
                 iq_prev = y1;
-                f_e = __builtin_fmaf(d_e, k.two_over_pi, k.fc);
-                f_o = __builtin_fmaf(d_o, k.two_over_pi, k.fc);
+                f_e = d_e * k.two_over_pi;
+                f_o = d_o * k.two_over_pi;
             }
         }
-        float f2 = dn.template push_pair<VP::VT>(k.taps, f_e, f_o);   // 2 * resample_poly(frequencies_up, 1, 2)[m4]
+        const float g2 = dn.template push_pair<VP::VT>(k.taps, f_e, f_o);   // decimated deviation from fc (cm_stages.h: SecamDemodLaneK)
         float c = 0.f;
         if (n >= 0 && n < W) {
-            f2 = f2 < k.f2_min ? k.f2_min : (f2 > k.f2_max ? k.f2_max : f2);   // secam.py:290
-            c = iir_gen<false>(deemph, k.deemph, __builtin_fmaf(f2, lk.scale, lk.offset));   // secam.py:291-296
+            float f2 = (g2 + dc) + lk.off2;                              // 2 (f - fsc)
+            f2 = f2 < lk.lo ? lk.lo : (f2 > lk.hi ? lk.hi : f2);         // secam.py:290
+            c = iir_gen<false>(deemph, k.deemph, f2 * lk.scale);         // secam.py:291-296
         }
         return c;
     }

@@ -173,12 +173,13 @@ static int sim_secam_run(const cm_plan_desc *d, const double *comp, double *rgb,
     if (!build_secam_demod_k<T>(*d, k, g_err)) return CM_ERR_UNSUPPORTED;
     const int W = d->width, P = k.preroll, Lc = W + P;
     std::vector<T> fm = build_fm_reference<T>(d->secam.fm_fc, Lc);
+    std::vector<T> dc = build_fm_dc<T>(*d, Lc);
     const cm_lane_table &tb = d->demod_main;
     std::vector<SecamDemodLaneK<T>> lk(n_calls);
     for (int i = 0; i < n_calls; ++i) {
         int kk = k0 + i, regime = kk < 2 ? kk : 2, line = first_line + 2 * i;
         if (line < 0 || line >= tb.n_lines) { g_err = "line outside the lane table"; return CM_ERR_INVALID; }
-        lk[i] = convert_secam_demod_lane<T>(lane_entry<T>(tb, frame, regime, line));
+        lk[i] = convert_secam_demod_lane<T>(lane_entry<T>(tb, frame, regime, line), d->secam);
     }
     std::vector<SecamDemod<T>> st(n_calls);
     for (auto &x : st) x.reset();
@@ -195,7 +196,9 @@ static int sim_secam_run(const cm_plan_desc *d, const double *comp, double *rgb,
             T car[4] = {fm[4 * mc], fm[4 * mc + 1], fm[4 * mc + 2], fm[4 * mc + 3]};
             T ch_d10 = (m1 - 10 >= 0) ? ch_hist[i][m1 - 10] : T(0);
             T ch_out;
-            own[i] = st[i].chroma_step(k, lk[i], m, cc, ch_d10, car, ch_out);
+            int m4 = m - lat + P;
+            m4 = m4 < 0 ? 0 : (m4 > Lc - 1 ? Lc - 1 : m4);
+            own[i] = st[i].chroma_step(k, lk[i], m, cc, ch_d10, car, dc[m4], ch_out);
             if (m1 >= 0) ch_hist[i][m1] = ch_out;
         }
         // the back end runs one step behind (neighbour exchange), as on the device

@@ -1,0 +1,65 @@
+"""Randomised parity sweep: random (stack, variant, image size, frame count, first frame) against the float64 oracle,
+both directions.  TEST TOOL (uses oracle/): python tools/fuzz_parity.py [cases] [seed]"""
+import sys, time, warnings
+import numpy
+sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
+warnings.filterwarnings('ignore')
+from color_modem_amd import comb, image, line, testing
+from color_modem_amd.color import ntsc, pal, secam
+from oracle import cm_oracle
+import stacks
+
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 60
+rng = numpy.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+PAL_V = ['PAL', 'PAL_M', 'PAL_N']
+NTSC_V = ['NTSC', 'NTSC_I', 'NTSC_N', 'NTSC361', 'NTSC443', 'NTSC_A']
+SECAM_V = ['SECAM', 'SECAM_I', 'SECAM_II', 'SECAM_III', 'SECAM_A', 'SECAM_M', 'SECAM_N']
+MAKERS = [
+    ('PalS', 'pal', lambda lc, v: pal.PalSModem(lc, v)), ('PalD', 'pal', lambda lc, v: pal.PalDModem(lc, v)),
+    ('Pal3D', 'pal', lambda lc, v: pal.Pal3DModem(lc, v)), ('PalD+notch', 'pal', lambda lc, v: pal.PalDModem(lc, v, notch=4.0)),
+    ('Pal3D minavg', 'pal', lambda lc, v: pal.Pal3DModem(lc, v, avg=comb.minavg)),
+    ('Simple(PalS)', 'pal', lambda lc, v: comb.SimpleCombModem(pal.PalSModem(lc, v))),
+    ('Avg(PalS)', 'pal', lambda lc, v: comb.ColorAveragingModem(pal.PalSModem(lc, v))),
+    ('Ntsc', 'ntsc', lambda lc, v: ntsc.NtscModem(lc, v)), ('NtscComb', 'ntsc', lambda lc, v: ntsc.NtscCombModem(lc, v)),
+    ('Simple3D(NtscComb)', 'ntsc', lambda lc, v: comb.Simple3DCombModem(ntsc.NtscCombModem(lc, v))),
+    ('Simple(Ntsc) nodelay', 'ntsc', lambda lc, v: comb.SimpleCombModem(ntsc.NtscModem(lc, v), delay=False)),
+    ('Avg(Ntsc)', 'ntsc', lambda lc, v: comb.ColorAveragingModem(ntsc.NtscModem(lc, v))),
+    ('Secam', 'secam', lambda lc, v: secam.SecamModem(lc, v)), ('Avg(Secam)', 'secam', lambda lc, v: comb.ColorAveragingModem(secam.SecamModem(lc, v))),
+]
+WIDTHS = [640, 704, 720, 720, 720, 768, 960, 1024, 1280]
+worst = 0.0
+bad = []
+t0 = time.time()
+done = 0
+while done < N:
+    name, system, make = MAKERS[rng.integers(len(MAKERS))]
+    vname = {'pal': PAL_V, 'ntsc': NTSC_V, 'secam': SECAM_V}[system][rng.integers({'pal': 3, 'ntsc': 6, 'secam': 7}[system])]
+    v = getattr({'pal': pal.PalVariant, 'ntsc': ntsc.NtscVariant, 'secam': secam.SecamVariant}[system], vname)
+    w = int(WIDTHS[rng.integers(len(WIDTHS))])
+    full = int(rng.choice([480, 576]))
+    h = int(rng.integers(1, 140)) if rng.random() < 0.8 else full
+    nfr = int(rng.integers(1, 4))
+    first = int(rng.integers(0, 5000))
+    tag = '%-22s %-9s %4dx%-3d frames %d first %d' % (name, vname, w, h, nfr, first)
+    try:
+        lc = line.LineConfig((w, h), line.LineStandard.detect(full))
+        modem = make(lc, v)
+        im = image.ImageModem(modem)
+        rgb = testing.synthetic_rgb(nfr, h, w, seed=int(rng.integers(1 << 30)))
+        comp_ref = cm_oracle.modulate_frames_f32(modem, rgb, first_frame=first, n_threads=8)
+        e_mod = stacks.rel_err(im.modulate_frames(rgb, first_frame=first), comp_ref)
+        got = im.demodulate_frames(comp_ref, first_frame=first)
+        want = cm_oracle.demodulate_frames_f32(modem, comp_ref, first_frame=first, n_threads=8)
+        e_dem = max(stacks.rel_err(got[i], want[i]) for i in range(nfr))
+    except (NotImplementedError, ValueError, IndexError) as e:
+        print('skip  %s: %s' % (tag, str(e)[:70]))
+        continue
+    done += 1
+    worst = max(worst, e_mod, e_dem)
+    flag = '' if max(e_mod, e_dem) < 1e-5 else '   <-- FAIL'
+    if flag:
+        bad.append(tag)
+    print('%s  mod %.1e demod %.1e%s' % (tag, e_mod, e_dem, flag))
+    sys.stdout.flush()
+print('cases %d, worst error %.2e, failures %d, %.0f s' % (done, worst, len(bad), time.time() - t0))
+sys.exit(1 if bad else 0)
