@@ -102,7 +102,7 @@ struct cm_plan {
 namespace {
 
 template <class S>
-bool make_pass(const cm_plan_desc &d, bool pald, bool bsf, const cm_lane_table &tb, Pass &pass, std::string &err) {
+bool make_pass(const cm_plan_desc &d, bool pald, bool bsf, const cm_lane_table &tb, Pass &pass, std::string &err, bool pair) {
     DemodK<float, S> k;
     DemodScales sc;
     if (!build_demod_k<float, S>(d, pald, bsf, k, sc, err)) return false;
@@ -110,7 +110,8 @@ bool make_pass(const cm_plan_desc &d, bool pald, bool bsf, const cm_lane_table &
         const int lat_front = pald ? 10 + k.q_e + 9 + 10 + k.q_l + 9 : 10 + k.q_e + k.q_l + 9;
         const int lat_out = lat_front + 1 + k.s_p;
         if (lat_out + 8 > kCarrierPad) { err = "pipeline latency beyond the carrier table padding"; return false; }
-        if (bsf && lat_out - (10 + k.q_r + 9) + 12 > 32) { err = "band-stop luma delay beyond its LDS ring"; return false; }
+        const int luma_lag = lat_out - (10 + k.q_r + 9);   // steps between the band-stop luma sample and its use
+        if (bsf && (pair ? luma_lag + 12 > luma_ring_slots<S>() : luma_lag > 15)) { err = "band-stop luma delay beyond its LDS ring"; return false; }
     }
     pass.k.resize(sizeof(k));
     std::memcpy(pass.k.data(), &k, sizeof(k));
@@ -130,8 +131,8 @@ bool make_pass(const cm_plan_desc &d, bool pald, bool bsf, const cm_lane_table &
 
 template <class S>
 bool make_passes(cm_plan *p, const cm_plan_desc &d, bool pald, bool bsf, bool first, std::string &err) {
-    if (!make_pass<S>(d, pald, bsf, d.demod_main, p->main, err)) return false;
-    if (first && !make_pass<S>(d, false, true, d.demod_first, p->first, err)) return false;
+    if (!make_pass<S>(d, pald, bsf, d.demod_main, p->main, err, p->pair)) return false;
+    if (first && !make_pass<S>(d, false, true, d.demod_first, p->first, err, p->pair)) return false;
     p->has_first = first;
     return true;
 }

@@ -687,13 +687,15 @@ __device__ __forceinline__ void run_lane(const Geom &g, const DemodK<float, type
 // block i, B before reading it - so A runs at most one block ahead and B never reads a block that is not complete.
 // =============================================================================================
 constexpr int kMidRing = 2 * 2 * 64 * 4;    // floats: [buffer][even | odd][lane][4 steps]
-constexpr int kLumaRing2 = 32 * 64;         // floats: band-stop luma, written by A and read by B up to ~14 steps later
+// band-stop luma ring of the pair kernels, written by A and read by B (lat_out - lat_luma + up to 12) steps later: 32 slots
+// for the tuned shapes, 64 for the run-time shape (high sampling rates; it runs 4 workgroups per CU, so the LDS is there)
+template <class S> constexpr int luma_ring_slots() { return S::RT ? 64 : 32; }
 
 constexpr int kLumaSlots = 2 * 64 * 4;      // floats: [buffer][lane][4 steps] luma source samples fetched by A for B
 
 template <class Cfg>
 struct PairLds {
-    static constexpr int kIn = Cfg::kLdsInF, kOut = Cfg::kLdsOut, kY = Cfg::BSF ? kLumaRing2 : kLumaSlots;
+    static constexpr int kIn = Cfg::kLdsInF, kOut = Cfg::kLdsOut, kY = Cfg::BSF ? luma_ring_slots<typename Cfg::S>() * 64 : kLumaSlots;
     static constexpr int kFloats = kIn + kMidRing + kOut + kY;
 };
 template <>
@@ -721,6 +723,7 @@ __device__ __forceinline__ void run_pair(const Geom &g, const DemodK<float, type
     typedef DemodK<float, S> K;
     constexpr int FRONT = Cfg::FRONT, DEPTH = Cfg::DEPTH, kTile = Cfg::TILE, SP = S::SP;
     constexpr bool BSF = Cfg::BSF, U8 = Cfg::U8, PALD = FRONT == FRONT_PALD;
+    constexpr int kYSlots = luma_ring_slots<S>();
     typedef typename std::conditional<PALD, PalDFront<float, S>, QamFront<float, S, BSF>>::type Front;
     typedef typename Front::StageA StageA;
     typedef typename Front::StageB StageB;
@@ -777,7 +780,7 @@ __device__ __forceinline__ void run_pair(const Geom &g, const DemodK<float, type
 #pragma unroll
         for (int j = 0; j < (PALD ? 14 : 1); ++j) ew[j] = 0.f;
         if (BSF) {
-            for (int j = 0; j < 32; ++j) yring[j * 64 + lane] = 0.f;
+            for (int j = 0; j < kYSlots; ++j) yring[j * 64 + lane] = 0.f;
         }
         const lds_float *xrow = itile + lane * kInTile;
         auto read_x = [&](int first) -> f4 {  // x[first .. first + 3] from the input tile, zero outside the row
@@ -817,7 +820,7 @@ __device__ __forceinline__ void run_pair(const Geom &g, const DemodK<float, type
             } else {
                 float luma_bsf = 0.f;
                 m = fa.template step<EDGE>(k, fla, tau, xw[10 + SUB], xw[SUB], luma_bsf);
-                if (BSF) yring[((tau - lat_luma) & 31) * 64 + lane] = luma_bsf;
+                if (BSF) yring[((tau - lat_luma) & (kYSlots - 1)) * 64 + lane] = luma_bsf;
             }
             m_even = m.even;
             m_odd = m.odd;
@@ -936,7 +939,7 @@ __device__ __forceinline__ void run_pair(const Geom &g, const DemodK<float, type
         if (DEPTH >= 1) b1_prev = pf2{lane_from(idx1, base.x), lane_from(idx1, base.y)};
         if (DEPTH >= 2) b2_prev = pf2{lane_from(idx2, base.x), lane_from(idx2, base.y)};
         float y_src;
-        if (BSF) y_src = yring[(n7 & 31) * 64 + lane];
+        if (BSF) y_src = yring[(n7 & (kYSlots - 1)) * 64 + lane];
         else y_src = SUB == 0 ? lw.x : (SUB == 1 ? lw.y : (SUB == 2 ? lw.z : lw.w));
         pf2 uv_d = SP > 0 ? uvd[SP > 0 ? SP - 1 : 0] : uv;
         if (S::RT) {   // (u, v)[n6 - s_p] out of the window: a chain of uniform selects instead of a dynamic register index

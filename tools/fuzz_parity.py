@@ -26,7 +26,7 @@ MAKERS = [
     ('Avg(Ntsc)', 'ntsc', lambda lc, v: comb.ColorAveragingModem(ntsc.NtscModem(lc, v))),
     ('Secam', 'secam', lambda lc, v: secam.SecamModem(lc, v)), ('Avg(Secam)', 'secam', lambda lc, v: comb.ColorAveragingModem(secam.SecamModem(lc, v))),
 ]
-WIDTHS = [640, 704, 720, 720, 720, 768, 960, 1024, 1280]
+WIDTHS = [480, 544, 640, 704, 720, 720, 720, 768, 960, 1024, 1280, 1440, 1920]
 worst = 0.0
 bad = []
 t0 = time.time()
