@@ -51,6 +51,26 @@ while done < N:
         got = im.demodulate_frames(comp_ref, first_frame=first)
         want = cm_oracle.demodulate_frames_f32(modem, comp_ref, first_frame=first, n_threads=8)
         e_dem = max(stacks.rel_err(got[i], want[i]) for i in range(nfr))
+        e_u8 = 0.0
+        if rng.random() < 0.4:   # the fused byte boundaries against the host-side conversions around the float kernels
+            from color_modem_amd.image import _as_bytes
+            try:
+                comp8 = _as_bytes(image.ImageModem.encode_composite_level(comp_ref.astype(numpy.float64)))
+                got8 = im.demodulate_frames_u8(comp8, first_frame=first)
+                ref_in = image.ImageModem.decode_composite_level(comp8.astype(numpy.float64) / 255.0).astype(numpy.float32)
+                want8 = _as_bytes(im.demodulate_frames(ref_in, first_frame=first).astype(numpy.float64)).transpose(0, 2, 3, 1)
+                d8 = numpy.abs(got8.astype(int) - want8.astype(int))
+                rgb8 = _as_bytes(rgb.astype(numpy.float64)).transpose(0, 2, 3, 1)
+                m8 = im.modulate_frames_u8(numpy.ascontiguousarray(rgb8), first_frame=first)
+                rgbf = (rgb8.astype(numpy.float64) / 255.0).astype(numpy.float32).transpose(0, 3, 1, 2)
+                w8 = _as_bytes(image.ImageModem.encode_composite_level(im.modulate_frames(numpy.ascontiguousarray(rgbf), first_frame=first).astype(numpy.float64)))
+                dm = numpy.abs(m8.astype(int) - w8.astype(int))
+                e_u8 = max(d8.max(), dm.max()) + max((d8 > 0).mean(), (dm > 0).mean())   # LSBs + share of differing bytes
+                tag += '  u8 %d LSB %.1e' % (max(d8.max(), dm.max()), max((d8 > 0).mean(), (dm > 0).mean()))
+                if d8.max() > 1 or dm.max() > 1 or max((d8 > 0).mean(), (dm > 0).mean()) > 5e-3:
+                    e_dem = 1.0
+            except NotImplementedError as e:
+                tag += '  u8 n/a'
     except (NotImplementedError, ValueError, IndexError) as e:
         print('skip  %s: %s' % (tag, str(e)[:70]))
         continue
