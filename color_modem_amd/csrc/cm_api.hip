@@ -528,6 +528,38 @@ int check_lines(const cm_plan *p, const Pass &pass, int max_line) {
     return CM_OK;
 }
 
+
+// ---- widths that are not multiples of 4 ---------------------------------------------------------------------------------
+// The kernels move rows as 16-byte vectors and need every row 16-byte aligned.  Dense float images of such a width go
+// through device buffers whose rows are pitched to the next multiple of 4 samples: one strided copy in, one out, both on
+// the caller's stream (stream-ordered allocations).  The pad samples are never read as data and what lands in them on the
+// way out is dropped by the copy.
+struct PitchedIO {
+    hipStream_t stream = nullptr;
+    float *in = nullptr, *out = nullptr;     // null: the caller's dense buffer is used directly
+    ~PitchedIO() {
+        if (in) (void)hipFreeAsync(in, stream);
+        if (out) (void)hipFreeAsync(out, stream);
+    }
+};
+// run(in_ptr, out_ptr) launches on buffers with rows of `wp` samples
+template <class F>
+int with_pitched_rows(const float *in, long long in_rows, float *out, long long out_rows, int W, hipStream_t stream, F run) {
+    const int wp = (W + 3) & ~3;
+    if (wp == W) return run(in, out);
+    PitchedIO io;
+    io.stream = stream;
+    HIP_TRY(hipMallocAsync((void **)&io.in, (size_t)in_rows * wp * sizeof(float), stream), CM_ERR_LAUNCH);
+    HIP_TRY(hipMallocAsync((void **)&io.out, (size_t)out_rows * wp * sizeof(float), stream), CM_ERR_LAUNCH);
+    HIP_TRY(hipMemcpy2DAsync(io.in, (size_t)wp * sizeof(float), in, (size_t)W * sizeof(float), (size_t)W * sizeof(float), (size_t)in_rows,
+                             hipMemcpyDeviceToDevice, stream), CM_ERR_LAUNCH);
+    int rc = run(io.in, io.out);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpy2DAsync(out, (size_t)W * sizeof(float), io.out, (size_t)wp * sizeof(float), (size_t)W * sizeof(float), (size_t)out_rows,
+                             hipMemcpyDeviceToDevice, stream), CM_ERR_LAUNCH);
+    return CM_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -545,8 +577,7 @@ int cm_plan_create(const cm_plan_desc *desc, cm_plan **out) {
     if (!desc || !out) return fail(CM_ERR_INVALID, "null argument");
     *out = nullptr;
     if (desc->abi_version != CM_ABI_VERSION) return fail(CM_ERR_INVALID, "descriptor ABI version mismatch");
-    if (desc->width < 4 || desc->width % 4 != 0)
-        return fail(CM_ERR_UNSUPPORTED, "width must be a positive multiple of 4 (rows are moved as 16-byte vectors)");
+    if (desc->width < 4) return fail(CM_ERR_UNSUPPORTED, "width must be at least 4");
     if (desc->height < 1) return fail(CM_ERR_INVALID, "height must be positive");
     if (desc->pipeline != CM_PIPE_QAM && desc->pipeline != CM_PIPE_PAL_D && desc->pipeline != CM_PIPE_SECAM)
         return fail(CM_ERR_INVALID, "unknown pipeline");
@@ -651,42 +682,46 @@ int cm_demodulate_frames(const cm_plan *p, const float *composite, float *rgb, i
     if (!p->fn && !p->secam) return fail(CM_ERR_UNSUPPORTED, p->demod_error);
     const cm_plan_desc &d = p->desc;
     const int W = d.width, H = d.height, D = d.demodulation_delay;
-    Geom g;
-    std::memset(&g, 0, sizeof g);
-    g.in = composite;
-    g.out = rgb;
-    g.W = W;
-    g.H = H;
-    g.in_frame_stride = (long long)W * H;
-    g.in_row_stride = W;
-    g.out_plane_stride = (long long)W * H;
-    g.out_frame_stride = 3LL * W * H;
-    g.out_row_stride = W;
-    set_first_frame(p, g, first_frame, p->secam ? p->sd_cycle : p->main.cycle);
-    const int rows0 = (H + 1) / 2, rows1 = H / 2;
-    g.calls_run0 = rows0 + D;
-    const int calls_run1 = rows1 > 0 ? rows1 + D : 0;
-    g.calls_per_frame = g.calls_run0 + calls_run1;
-    g.runs_per_frame = rows1 > 0 ? 2 : 1;
-    g.first_line[0] = 0;
-    g.first_line[1] = 1;
-    g.delay = D;
-    g.total_calls = n_frames * g.calls_per_frame;
-    g.skip_first = d.first_is_plain;
-    if (p->secam) {
-        if (H - 1 >= p->sd_n_lines) return fail(CM_ERR_INVALID, "line number beyond the plan's tables");
-        return run_secam_demod(p, g, (hipStream_t)stream);
-    }
-    int rc = check_lines(p, p->main, H - 1 + 2 * D);
-    if (rc) return rc;
-    Geom s = g;
-    if (p->has_first) {
-        s.sparse = 1;
-        s.skip_first = 0;
-        s.total_calls = n_frames * g.runs_per_frame;
-        set_first_frame(p, s, first_frame, p->first.cycle);
-    }
-    return run_plan(p, g, s, p->has_first, (hipStream_t)stream);
+    const int wp = (W + 3) & ~3;
+    return with_pitched_rows(composite, n_frames * H, rgb, n_frames * 3 * H, W, (hipStream_t)stream, [&](const float *in, float *out) -> int {
+        Geom g;
+        std::memset(&g, 0, sizeof g);
+        g.in = in;
+        g.out = out;
+        g.W = W;
+        g.Wp = wp;
+        g.H = H;
+        g.in_frame_stride = (long long)wp * H;
+        g.in_row_stride = wp;
+        g.out_plane_stride = (long long)wp * H;
+        g.out_frame_stride = 3LL * wp * H;
+        g.out_row_stride = wp;
+        set_first_frame(p, g, first_frame, p->secam ? p->sd_cycle : p->main.cycle);
+        const int rows0 = (H + 1) / 2, rows1 = H / 2;
+        g.calls_run0 = rows0 + D;
+        const int calls_run1 = rows1 > 0 ? rows1 + D : 0;
+        g.calls_per_frame = g.calls_run0 + calls_run1;
+        g.runs_per_frame = rows1 > 0 ? 2 : 1;
+        g.first_line[0] = 0;
+        g.first_line[1] = 1;
+        g.delay = D;
+        g.total_calls = n_frames * g.calls_per_frame;
+        g.skip_first = d.first_is_plain;
+        if (p->secam) {
+            if (H - 1 >= p->sd_n_lines) return fail(CM_ERR_INVALID, "line number beyond the plan's tables");
+            return run_secam_demod(p, g, (hipStream_t)stream);
+        }
+        int rc = check_lines(p, p->main, H - 1 + 2 * D);
+        if (rc) return rc;
+        Geom s = g;
+        if (p->has_first) {
+            s.sparse = 1;
+            s.skip_first = 0;
+            s.total_calls = n_frames * g.runs_per_frame;
+            set_first_frame(p, s, first_frame, p->first.cycle);
+        }
+        return run_plan(p, g, s, p->has_first, (hipStream_t)stream);
+    });
 }
 
 int cm_demodulate_frames_u8(const cm_plan *p, const uint8_t *composite8, uint8_t *rgb8, int64_t n_frames, int64_t first_frame,
@@ -701,9 +736,11 @@ int cm_demodulate_frames_u8(const cm_plan *p, const uint8_t *composite8, uint8_t
     const int W = d.width, H = d.height, D = d.demodulation_delay;
     Geom g;
     std::memset(&g, 0, sizeof g);
+    if (W % 4 != 0) return fail(CM_ERR_UNSUPPORTED, "the fused uint8 boundary needs a width that is a multiple of 4");
     g.in = reinterpret_cast<const float *>(composite8);   // strides below count bytes (PassCfg::U8)
     g.out = reinterpret_cast<float *>(rgb8);
     g.W = W;
+    g.Wp = W;
     g.H = H;
     g.in_frame_stride = (long long)W * H;
     g.in_row_stride = W;
@@ -745,44 +782,44 @@ int cm_demodulate_run(const cm_plan *p, const float *composite, float *rgb, int3
     if (first_line < 0) return fail(CM_ERR_INVALID, "negative line number");
     if (!p->fn && !p->secam) return fail(CM_ERR_UNSUPPORTED, p->demod_error);
     const cm_plan_desc &d = p->desc;
-    Geom g;
-    std::memset(&g, 0, sizeof g);
-    g.in = composite;
-    g.out = rgb;
-    g.W = d.width;
-    g.H = n_calls;
-    g.in_frame_stride = 0;
-    g.out_plane_stride = d.width;
-    g.out_frame_stride = 0;
-    g.rows_mode = 1;
-    set_first_frame(p, g, frame, p->secam ? p->sd_cycle : p->main.cycle);
-    g.calls_run0 = n_calls;
-    g.calls_per_frame = n_calls;
-    g.runs_per_frame = 1;
-    g.first_line[0] = g.first_line[1] = first_line;
-    g.k0 = k0;
-    g.total_calls = n_calls;
-    g.skip_first = d.first_is_plain;
-    g.out_plane_stride = d.width;
-    g.out_row_stride = 3LL * d.width;
-    if (p->secam) {
-        if (first_line + 2 * (n_calls - 1) >= p->sd_n_lines) return fail(CM_ERR_INVALID, "line number beyond the plan's tables");
-        return run_secam_demod(p, g, (hipStream_t)stream);
-    }
-    int rc = check_lines(p, p->main, first_line + 2 * (n_calls - 1));
-    if (rc) return rc;
-    // rows mode writes [call][plane][W]
-    g.out_plane_stride = d.width;
-    g.out_row_stride = 3LL * d.width;
-    Geom s = g;
-    const bool with_first = p->has_first && k0 == 0;
-    if (with_first) {
-        s.sparse = 1;
-        s.skip_first = 0;
-        s.total_calls = 1;
-        set_first_frame(p, s, frame, p->first.cycle);
-    }
-    return run_plan(p, g, s, with_first, (hipStream_t)stream);
+    const int W = d.width, wp = (W + 3) & ~3;
+    return with_pitched_rows(composite, n_calls, rgb, 3LL * n_calls, W, (hipStream_t)stream, [&](const float *in, float *out) -> int {
+        Geom g;
+        std::memset(&g, 0, sizeof g);
+        g.in = in;
+        g.out = out;
+        g.W = W;
+        g.Wp = wp;
+        g.H = n_calls;
+        g.in_frame_stride = 0;
+        g.out_frame_stride = 0;
+        g.rows_mode = 1;
+        set_first_frame(p, g, frame, p->secam ? p->sd_cycle : p->main.cycle);
+        g.calls_run0 = n_calls;
+        g.calls_per_frame = n_calls;
+        g.runs_per_frame = 1;
+        g.first_line[0] = g.first_line[1] = first_line;
+        g.k0 = k0;
+        g.total_calls = n_calls;
+        g.skip_first = d.first_is_plain;
+        g.out_plane_stride = wp;            // rows mode writes [call][plane][W]
+        g.out_row_stride = 3LL * wp;
+        if (p->secam) {
+            if (first_line + 2 * (n_calls - 1) >= p->sd_n_lines) return fail(CM_ERR_INVALID, "line number beyond the plan's tables");
+            return run_secam_demod(p, g, (hipStream_t)stream);
+        }
+        int rc = check_lines(p, p->main, first_line + 2 * (n_calls - 1));
+        if (rc) return rc;
+        Geom s = g;
+        const bool with_first = p->has_first && k0 == 0;
+        if (with_first) {
+            s.sparse = 1;
+            s.skip_first = 0;
+            s.total_calls = 1;
+            set_first_frame(p, s, frame, p->first.cycle);
+        }
+        return run_plan(p, g, s, with_first, (hipStream_t)stream);
+    });
 }
 
 static int run_mod(const cm_plan *p, Geom g, hipStream_t stream, bool u8 = false) {
@@ -807,29 +844,33 @@ int cm_modulate_frames(const cm_plan *p, const float *rgb, float *composite, int
     if (!p->mod_fn && !p->sm_lanes) return fail(CM_ERR_UNSUPPORTED, "this plan has no modulator");
     const cm_plan_desc &d = p->desc;
     const int W = d.width, H = d.height, D = d.modulation_delay;
-    Geom g;
-    std::memset(&g, 0, sizeof g);
-    g.in = rgb;
-    g.out = composite;
-    g.W = W;
-    g.H = H;
-    g.in_frame_stride = 3LL * W * H;
-    g.in_plane_stride = (long long)W * H;
-    g.in_row_stride = W;
-    g.out_frame_stride = (long long)W * H;
-    g.out_row_stride = W;
-    set_first_frame(p, g, first_frame, p->mod_cycle);
-    const int rows0 = (H + 1) / 2, rows1 = H / 2;
-    g.calls_run0 = rows0 + D;
-    const int calls_run1 = rows1 > 0 ? rows1 + D : 0;
-    g.calls_per_frame = g.calls_run0 + calls_run1;
-    g.runs_per_frame = rows1 > 0 ? 2 : 1;
-    g.first_line[0] = 0;
-    g.first_line[1] = 1;
-    g.delay = D;
-    g.total_calls = n_frames * g.calls_per_frame;
+    const int wp = (W + 3) & ~3;
     if (H - 1 + 2 * D >= p->mod_n_lines) return fail(CM_ERR_INVALID, "line number beyond the plan's phase tables");
-    return run_mod(p, g, (hipStream_t)stream);
+    return with_pitched_rows(rgb, n_frames * 3 * H, composite, n_frames * H, W, (hipStream_t)stream, [&](const float *in, float *out) -> int {
+        Geom g;
+        std::memset(&g, 0, sizeof g);
+        g.in = in;
+        g.out = out;
+        g.W = W;
+        g.Wp = wp;
+        g.H = H;
+        g.in_frame_stride = 3LL * wp * H;
+        g.in_plane_stride = (long long)wp * H;
+        g.in_row_stride = wp;
+        g.out_frame_stride = (long long)wp * H;
+        g.out_row_stride = wp;
+        set_first_frame(p, g, first_frame, p->mod_cycle);
+        const int rows0 = (H + 1) / 2, rows1 = H / 2;
+        g.calls_run0 = rows0 + D;
+        const int calls_run1 = rows1 > 0 ? rows1 + D : 0;
+        g.calls_per_frame = g.calls_run0 + calls_run1;
+        g.runs_per_frame = rows1 > 0 ? 2 : 1;
+        g.first_line[0] = 0;
+        g.first_line[1] = 1;
+        g.delay = D;
+        g.total_calls = n_frames * g.calls_per_frame;
+        return run_mod(p, g, (hipStream_t)stream);
+    });
 }
 
 int cm_modulate_frames_u8(const cm_plan *p, const uint8_t *rgb8, uint8_t *composite8, int64_t n_frames, int64_t first_frame,
@@ -846,6 +887,7 @@ int cm_modulate_frames_u8(const cm_plan *p, const uint8_t *rgb8, uint8_t *compos
     g.in = reinterpret_cast<const float *>(rgb8);         // strides below count bytes (U8 kernels)
     g.out = reinterpret_cast<float *>(composite8);
     g.W = W;
+    g.Wp = W;
     g.H = H;
     g.in_frame_stride = 3LL * W * H;
     g.in_plane_stride = 0;
@@ -873,25 +915,29 @@ int cm_modulate_run(const cm_plan *p, const float *rgb, float *composite, int32_
     if (n_calls == 0) return CM_OK;
     if (!p->mod_fn && !p->sm_lanes) return fail(CM_ERR_UNSUPPORTED, "this plan has no modulator");
     const cm_plan_desc &d = p->desc;
-    Geom g;
-    std::memset(&g, 0, sizeof g);
-    g.in = rgb;
-    g.out = composite;
-    g.W = d.width;
-    g.H = n_calls;
-    g.in_plane_stride = d.width;
-    g.in_row_stride = 3LL * d.width;
-    g.out_row_stride = d.width;
-    g.rows_mode = 1;
-    set_first_frame(p, g, frame, p->mod_cycle);
-    g.calls_run0 = n_calls;
-    g.calls_per_frame = n_calls;
-    g.runs_per_frame = 1;
-    g.first_line[0] = g.first_line[1] = first_line;
-    g.k0 = k0;
-    g.total_calls = n_calls;
+    const int W = d.width, wp = (W + 3) & ~3;
     if (first_line + 2 * (n_calls - 1) >= p->mod_n_lines) return fail(CM_ERR_INVALID, "line number beyond the plan's phase tables");
-    return run_mod(p, g, (hipStream_t)stream);
+    return with_pitched_rows(rgb, 3LL * n_calls, composite, n_calls, W, (hipStream_t)stream, [&](const float *in, float *out) -> int {
+        Geom g;
+        std::memset(&g, 0, sizeof g);
+        g.in = in;
+        g.out = out;
+        g.W = W;
+        g.Wp = wp;
+        g.H = n_calls;
+        g.in_plane_stride = wp;             // rows mode reads [call][plane][W]
+        g.in_row_stride = 3LL * wp;
+        g.out_row_stride = wp;
+        g.rows_mode = 1;
+        set_first_frame(p, g, frame, p->mod_cycle);
+        g.calls_run0 = n_calls;
+        g.calls_per_frame = n_calls;
+        g.runs_per_frame = 1;
+        g.first_line[0] = g.first_line[1] = first_line;
+        g.k0 = k0;
+        g.total_calls = n_calls;
+        return run_mod(p, g, (hipStream_t)stream);
+    });
 }
 
 #ifdef CM_DIAG

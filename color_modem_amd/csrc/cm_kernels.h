@@ -41,6 +41,8 @@ struct Geom {
     const float *frame_rot;     // {cos, sin} per frame of the rotation cycle, or null (cm_plan_desc::frame_rotation)
     int rot_first, rot_cycle;
     int W, H;
+    int Wp;              // float rows: row pitch in samples = W rounded up to a multiple of 4 (rows move as 16-byte vectors; for
+                         // other widths the library stages the images through pitched buffers); byte modes: = W
     int calls_per_frame, calls_run0, runs_per_frame;
     int first_line[2];
     int k0;              // rows mode: index of the first submitted call within its run
@@ -334,7 +336,7 @@ __device__ __forceinline__ void flush_tile(const Geom &g, const lds_float *otile
         typedef __attribute__((address_space(1))) f4 global_f4;
         global_f4 *dst = (global_f4 *)(unsigned long long)ptr_from(row * 4, op);
         const int quad = chunk ^ ((row >> 1) & (kChunks - 1));
-        if (dst != nullptr && col < g.W) {
+        if (dst != nullptr && col < g.Wp) {
             dst += col >> 2;
 #ifndef CM_FLUSH_SERIAL   /* the three planes of a row group in one LDS round trip (-1 % kernel time) */
             f4 v0 = *(const lds_f4 *)(otile + 0 * 64 * kTile + row * kTile + 4 * quad);
@@ -372,7 +374,7 @@ __device__ __forceinline__ void flush_tile(const Geom &g, const lds_float *otile
 // Fill input tile `c` (samples 32 c .. 32 c + 31 of all 64 rows) straight into LDS.
 __device__ __forceinline__ void fill_tile(const Geom &g, lds_float *itile, const float *xp, int c, int lane) {
     int col = kInTile * c + 4 * (lane & 7);
-    if (col > g.W - 4) col = g.W - 4;  // never read past the row; such samples are masked by the consumer
+    if (col > g.Wp - 4) col = g.Wp - 4;  // never read past the (pitched) row; such samples are masked by the consumer
 #pragma nounroll
     for (int q = 0; q < 8; ++q) {
         const float *src = ptr_from((8 * q + (lane >> 3)) * 4, xp) + col;
@@ -478,8 +480,8 @@ __device__ __forceinline__ void run_lane(const Geom &g, const DemodK<float, type
         op = store_ok ? (const float *)((unsigned char *)g.out + frame * g.out_frame_stride + (long long)out_row * g.out_row_stride)
                       : nullptr;
     } else {
-        xp = g.in + frame * g.in_frame_stride + (long long)src_row * g.W;
-        L.lp = g.in + frame * g.in_frame_stride + (long long)luma_row * g.W;
+        xp = g.in + frame * g.in_frame_stride + (long long)src_row * g.Wp;
+        L.lp = g.in + frame * g.in_frame_stride + (long long)luma_row * g.Wp;
         op = store_ok ? g.out + frame * g.out_frame_stride + (long long)out_row * g.out_row_stride : nullptr;
     }
     {
@@ -511,7 +513,8 @@ __device__ __forceinline__ void run_lane(const Geom &g, const DemodK<float, type
     int lat_luma = 0;
     if constexpr (FRONT == FRONT_QAM) lat_luma = Lane::Front::luma_latency(k);
     const int lat_out = lat_front + 1 + (S::RT ? k.s_p : S::SP);     // n7 = t - lat_out
-    const int T = (W + lat_out + 3) & ~3;
+    const int Wp = g.Wp;                          // the output row ends with the quad that holds sample W - 1
+    const int T = (Wp + lat_out + 3) & ~3;
     const int front_off = FRONT == FRONT_PALD ? 10 + k.q_e + 9 + 10 : 10 + k.q_e;  // detector sample pair = t - front_off
     int t_mid0 = (lat_out + 3) & ~3;           // every stage index >= 0 from here on
     int t_mid1 = (W - 4) & ~3;                 // bodies below this never touch the end of the row
@@ -573,7 +576,7 @@ __device__ __forceinline__ void run_lane(const Geom &g, const DemodK<float, type
 #endif
     auto maybe_flush = [&](int t) {
         const int n7 = t - lat_out;
-        if (n7 >= 0 && ((n7 & (kTile - 1)) == kTile - 1 || n7 == W - 1)) {
+        if (n7 >= 0 && ((n7 & (kTile - 1)) == kTile - 1 || n7 == Wp - 1)) {
             CM_STAMP(t0);
             if (U8) flush_tile_u8(g, otile_base, op, n7 & ~(kTile - 1), lane);
             else flush_tile<kTile>(g, otile_base, op, n7 & ~(kTile - 1), lane);
@@ -749,7 +752,8 @@ __device__ __forceinline__ void run_pair(const Geom &g, const DemodK<float, type
     if constexpr (!PALD) lat_luma = Front::luma_latency(k);
     const int sp = S::RT ? k.s_p : SP;          // run-time shapes: SP is the window size, k.s_p the delay
     const int lat_out = lat_front + 1 + sp;     // n7 = t - lat_out
-    const int T = (W + lat_out + 3) & ~3;
+    const int Wp = g.Wp;                          // the output row ends with the quad that holds sample W - 1
+    const int T = (Wp + lat_out + 3) & ~3;
     const int front_off = StageA::pair_offset(k);   // detector pair index nd = t - front_off
     int t_mid0 = (lat_out + 3) & ~3;           // every stage index >= 0 from here on
     int t_mid1 = (W - 4) & ~3;                 // bodies below this never touch the end of the row
@@ -766,12 +770,12 @@ __device__ __forceinline__ void run_pair(const Geom &g, const DemodK<float, type
         const int luma_row = ((g.luma_prev_bits >> regime) & 1) ? lc.prev_row : lc.src_row;
         const float *lp;
         if (U8) lp = (const float *)((const unsigned char *)g.in + frame * g.in_frame_stride + (long long)luma_row * g.W);
-        else lp = g.in + frame * g.in_frame_stride + (long long)luma_row * g.W;
+        else lp = g.in + frame * g.in_frame_stride + (long long)luma_row * g.Wp;
         if (VP::VT) pin_block(k.taps);
         if (VP::VB) pin_block(k.ext, false);
         const float *xp;
         if (U8) xp = (const float *)((const unsigned char *)g.in + frame * g.in_frame_stride + (long long)lc.src_row * g.W);
-        else xp = g.in + frame * g.in_frame_stride + (long long)lc.src_row * g.W;
+        else xp = g.in + frame * g.in_frame_stride + (long long)lc.src_row * g.Wp;
         StageA fa;
         fa.reset();
         float xw[14], ew[PALD ? 14 : 1];
@@ -919,7 +923,7 @@ __device__ __forceinline__ void run_pair(const Geom &g, const DemodK<float, type
     const int s_flush = (lat_out + 3) & 3;
     auto maybe_flush = [&](int t) {
         const int n7 = t - lat_out;
-        if (n7 >= 0 && ((n7 & (kTile - 1)) == kTile - 1 || n7 == W - 1)) {
+        if (n7 >= 0 && ((n7 & (kTile - 1)) == kTile - 1 || n7 == Wp - 1)) {
             CM_STAMP(t0);
             if (U8) flush_tile_u8(g, otile_base, op, n7 & ~(kTile - 1), lane);
             else flush_tile<kTile>(g, otile_base, op, n7 & ~(kTile - 1), lane);

@@ -37,7 +37,7 @@ __device__ __forceinline__ void flush_tile1(const Geom &g, const lds_float *otil
         typedef __attribute__((address_space(1))) f4 global_f4;
         global_f4 *dst = (global_f4 *)(unsigned long long)ptr_from(row * 4, op);
         const int quad = chunk ^ ((row >> 1) & (kChunks - 1));
-        if (dst != nullptr && col < g.W) {
+        if (dst != nullptr && col < g.Wp) {
             f4 v = *(const lds_f4 *)(otile + row * kTile + 4 * quad);
             __builtin_nontemporal_store(v, &dst[col >> 2]);
         }
@@ -51,7 +51,7 @@ __device__ __forceinline__ void flush_tile1(const Geom &g, const lds_float *otil
 constexpr int kLdsIn3 = 3 * kLdsIn;
 __device__ __forceinline__ void fill_tile3(const Geom &g, lds_float *itile, const float *rp, int c, int lane) {
     int col = kInTile * c + 4 * (lane & 7);
-    if (col > g.W - 4) col = g.W - 4;
+    if (col > g.Wp - 4) col = g.Wp - 4;
 #pragma nounroll
     for (int q = 0; q < 8; ++q) {
         const float *src = ptr_from((8 * q + (lane >> 3)) * 4, rp) + col;
@@ -67,7 +67,12 @@ __device__ __forceinline__ void read_tile3(const lds_float *itile, int lane, int
 #pragma unroll
     for (int p = 0; p < 3; ++p) {
         f4 v = *(const lds_f4 *)(itile + p * kLdsIn + lane * kInTile + (first & (kInTile - 1)));
-        if (first >= W) v = f4{0.f, 0.f, 0.f, 0.f};   // W % 4 == 0: a quad is inside or outside as a whole
+        if (first + 3 >= W) {   // the last quad of a row may be partial (pitched rows)
+            if (first >= W) v.x = 0.f;
+            if (first + 1 >= W) v.y = 0.f;
+            if (first + 2 >= W) v.z = 0.f;
+            if (first + 3 >= W) v.w = 0.f;
+        }
         out[p] = v;
     }
 }
@@ -173,7 +178,7 @@ __device__ __forceinline__ void put_composite(const Geom &g, lds_float *otile_ba
             flush_tile1_u8(g, otile_base, op, n7 & ~(kOutTileU8 - 1), lane);
     } else {
         if (n7 >= 0 && n7 < W) otile_base[lane * kTile + (wpos ^ (n7 & (kTile - 1)))] = comp;
-        if (n7 >= 0 && ((n7 & (kTile - 1)) == kTile - 1 || n7 == W - 1))
+        if (n7 >= 0 && ((n7 & (kTile - 1)) == kTile - 1 || n7 == g.Wp - 1))   // the row ends with the quad that holds W - 1
             flush_tile1<kTile>(g, otile_base, op, n7 & ~(kTile - 1), lane);
     }
 }
@@ -227,7 +232,7 @@ __global__ __launch_bounds__(64, 2) void qam_mod_kernel(const ModArgs<NP> args) 
     const int wpos = ((lane >> 1) & (kTile / 4 - 1)) << 2;
     const int W = g.W;
     const int sp = RT ? k.s_p : SP;
-    const int T = (W + sp + 3) & ~3;
+    const int T = (g.Wp + sp + 3) & ~3;
     f4 cur[3], nxt[3];
     first_tile3<U8>(g, itile, rp, lane, nxt);
     for (int tb = 0; tb < T; tb += 4) {

@@ -47,7 +47,7 @@ __global__ __launch_bounds__(64, 2) void secam_demod_kernel(const SecamDemodArgs
         op = lc.store_ok ? (const float *)((unsigned char *)g.out + lc.frame * g.out_frame_stride + (long long)lc.out_row * g.out_row_stride)
                          : nullptr;
     } else {
-        xp = g.in + lc.frame * g.in_frame_stride + (long long)lc.src_row * g.W;
+        xp = g.in + lc.frame * g.in_frame_stride + (long long)lc.src_row * g.Wp;
         op = lc.store_ok ? g.out + lc.frame * g.out_frame_stride + (long long)lc.out_row * g.out_row_stride : nullptr;
     }
     SecamDemodLaneK<float> lk;
@@ -132,7 +132,7 @@ __global__ __launch_bounds__(64, 2) void secam_demod_kernel(const SecamDemodArgs
         return v;
     };
     auto read_luma = [&](int first) -> f4 { return load_luma<U8>(xp, first, true, W); };
-    const int T = (W + lat_out + 3) & ~3;
+    const int T = (g.Wp + lat_out + 3) & ~3;
     f4 xv = read_x(0);
     f4 nl = read_luma(-d_luma);
     for (int xb = 0; xb < T; xb += 4) {
@@ -143,7 +143,7 @@ __global__ __launch_bounds__(64, 2) void secam_demod_kernel(const SecamDemodArgs
             step(P + xb + s, xv[s], lw[s], s);
             if (s == s_flush) {
                 const int n = xb + s - lat_out;
-                if (n >= 0 && ((n & (kTile - 1)) == kTile - 1 || n == W - 1)) {
+                if (n >= 0 && ((n & (kTile - 1)) == kTile - 1 || n == g.Wp - 1)) {
                     if (U8) flush_tile_u8(g, otile_base, op, n & ~(kTile - 1), lane);
                     else flush_tile<kTile>(g, otile_base, op, n & ~(kTile - 1), lane);
                 }
@@ -197,7 +197,7 @@ __global__ __launch_bounds__(64, 2) void secam_mod_kernel(const SecamModArgs arg
     const int wpos = ((lane >> 1) & (kTile / 4 - 1)) << 2;
     const int W = g.W;
     const int sp = RT ? k.s_p : SP;
-    const int T = (W + sp + 3) & ~3;
+    const int T = (g.Wp + sp + 3) & ~3;
     f4 cur[3], nxt[3];
     first_tile3<U8>(g, itile, rp, lane, nxt);
     for (int tb = 0; tb < T; tb += 4) {

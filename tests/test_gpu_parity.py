@@ -294,6 +294,29 @@ def test_secam_other_widths_vs_oracle(size):
         assert stacks.rel_err(got[i], want[i]) < TOL, (size, i)
 
 
+@pytest.mark.parametrize('stack,size', [('pal_d', (702, 576)), ('pal_s', (718, 21)), ('pal_3d', (721, 24)), ('ntsc_comb', (711, 480)),
+                                        ('ntsc_comb_3d', (642, 19)), ('secam', (702, 576)), ('secam_avg', (715, 12)), ('ntsc_avg', (1023, 9))])
+def test_widths_that_are_not_multiples_of_4(stack, size):
+    """Dense images of such widths are staged through pitched device buffers inside the library (cm_api.hip:
+    with_pitched_rows); frames and the per-row protocol, both directions."""
+    from oracle import cm_oracle
+    modem = stacks.make(stack, size, explicit=True)
+    im = image.ImageModem(modem)
+    rgb = testing.synthetic_rgb(2, size[1], size[0], seed=79)
+    comp_ref = cm_oracle.modulate_frames_f32(modem, rgb, first_frame=1, n_threads=8)
+    assert stacks.rel_err(im.modulate_frames(rgb, first_frame=1), comp_ref) < TOL
+    got = im.demodulate_frames(comp_ref, first_frame=1)
+    want = cm_oracle.demodulate_frames_f32(modem, comp_ref, first_frame=1, n_threads=8)
+    for i in range(2):
+        assert stacks.rel_err(got[i], want[i]) < TOL, (stack, size, i)
+    # the stateful per-row protocol on a fresh modem: the first rows of field 0 of frame 1
+    dev, orc = stacks.make(stack, size, explicit=True), cm_oracle.OracleModem(stacks.make(stack, size, explicit=True))
+    for y in range(0, min(size[1], 8), 2):
+        a = numpy.stack(dev.demodulate(1, y, comp_ref[0, y]))
+        b = numpy.stack(orc.demodulate(1, y, comp_ref[0, y].astype(numpy.float64)))
+        assert stacks.rel_err(a, b) < TOL, (stack, size, y)
+
+
 # ---- sub-carrier cycles too long to tabulate per frame: two parity frames + per-frame rotation ---------------------
 @pytest.mark.parametrize('kind,variant,size,first', [
     ('ntsc_comb_3d', 'NTSC443', (720, 480), 4798),     # NTSC 4.43 on 525 lines: cycle 4800, batch wraps around it
