@@ -67,6 +67,6 @@ def test_descriptor_validation_messages():
     bp.desc.abi_version = 99
     assert L.cm_plan_create(ctypes.byref(bp.desc), ctypes.byref(handle)) == _native.CM_ERR_INVALID
     bp.desc.abi_version = plan.CM_ABI_VERSION
-    bp.desc.width = 722
+    bp.desc.width = 3
     assert L.cm_plan_create(ctypes.byref(bp.desc), ctypes.byref(handle)) == _native.CM_ERR_UNSUPPORTED
-    assert b'multiple of 4' in L.cm_last_error()
+    assert b'at least 4' in L.cm_last_error()
