@@ -1,5 +1,5 @@
 """Randomised parity sweep: random (stack, variant, image size, frame count, first frame) against the float64 oracle,
-both directions.  TEST TOOL (uses oracle/): python tools/fuzz_parity.py [cases] [seed]"""
+both directions.  TEST TOOL (uses oracle/): python tests/fuzz_parity.py [cases] [seed]"""
 import sys, time, warnings
 import numpy
 sys.path.insert(0, '.'); sys.path.insert(0, 'tests')

@@ -1,5 +1,5 @@
 """Throughput of every built pipeline at its BASELINE.json frame size + parity error vs the oracle on 2 frames.
-Run on the GPU box: python tools/measure_all.py [frames]"""
+Run on the GPU box: python tests/measure_all.py [frames]"""
 import sys, time, json, numpy, torch
 sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
 import stacks

@@ -1,4 +1,4 @@
-"""Where the SECAM decoder's float32 error sits: python tools/secam_err_probe.py (GPU; uses the oracle: test tool)"""
+"""Where the SECAM decoder's float32 error sits: python tests/secam_err_probe.py (GPU; uses the oracle: test tool)"""
 import sys, warnings
 import numpy
 sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
