@@ -1,21 +1,26 @@
-// cm_kernels.h - device-side lane driver of the QAM-family demodulators (gfx950).
+// cm_kernels.h - device-side lane drivers of the QAM-family demodulators (gfx950).
 //
-// One 64-lane workgroup (= one wavefront) walks 64 consecutive calls of the flattened call list
-// [frame][run][call]; lane j owns call  block * (64 - DEPTH) - DEPTH + j,  i.e. consecutive
-// workgroups overlap by DEPTH halo lanes that only feed their base pairs to their neighbours.
+// 64 consecutive calls of the flattened call list [frame][run][call] form one workgroup; lane j owns call
+// block * (64 - DEPTH) - DEPTH + j, i.e. consecutive workgroups overlap by DEPTH halo lanes that only feed their base
+// pairs to their neighbours.  Two drivers run the same stages (cm_stages.h, cm_stages_pk.h):
+//   run_pair  (demod_pair_kernel)  two wavefronts per workgroup: stage A = loads + front end, stage B = detectors in packed
+//             float32 + back end + stores, hand-over through an LDS ring; 3 waves per SIMD.  See the comment above run_pair.
+//   run_lane  (demod_kernel)       one wavefront per workgroup, 2 waves per SIMD: the instances whose stage B does not fit
+//             168 VGPRs (PassCfg::kUsePair).
 //
-// Data movement (per workgroup, 20 KiB of LDS -> 8 workgroups per CU = 2 waves per SIMD):
-//   input   64 rows x 32 samples per tile, filled with 8 global_load_lds_dwordx4 (8 rows x 128 B
-//           each, full cache lines, no VGPR staging); lane i then reads its own row with one
-//           ds_read_b128 per 4 steps.  Every input byte crosses the fabric once for this stream.
-//   luma    x_l[n7 .. +3]: second visit of the (own or previous) row lat samples later, one
-//           unaligned global_load_dwordx4 per lane and 4 steps (L2 / Infinity-Cache hits).
-//   output  r, g, b: one ds_write_b32 per plane and step into a [3][64][16] LDS tile (quad-
-//           swizzled columns); every 16 steps the tile is read back row-wise (ds_read_b128) and
-//           stored as 64-byte row segments, 16 rows per wave-instruction.
-//   carrier cos/sin(m cps): wave-uniform, one s_load_dwordx16 + one s_load_dwordx8 per 4 steps.
-//   neighbours' base pairs: ds_bpermute_b32, consumed one step later (the back end runs one
-//           sample behind the front end so that the permute latency is never waited for).
+// Data movement of a workgroup:
+//   input   64 rows x 32 samples per tile, filled with 8 global_load_lds_dwordx4 (8 rows x 128 B each, full cache
+//           lines, no VGPR staging); lane i then reads its own row with one ds_read_b128 per 4 steps.  Every input
+//           byte crosses the fabric once for this stream.
+//   luma    x_l[n7 .. +3]: second visit of the (own or previous) row lat samples later, one unaligned
+//           global_load_dwordx4 per lane and 4 steps (L2 / Infinity-Cache hits); in the pair kernel stage A fetches it
+//           and leaves it in LDS for stage B.
+//   output  r, g, b: one ds_write_b32 per plane and step into a [3][64][16] LDS tile (quad-swizzled columns); every
+//           16 steps the tile is read back row-wise (ds_read_b128) and stored as 64-byte row segments, 16 rows per
+//           wave-instruction.
+//   carrier cos/sin(m cps): wave-uniform scalar loads from tables padded by kCarrierPad entries at both ends.
+//   neighbours' base pairs: ds_bpermute_b32, consumed one step later (the back end runs one sample behind the
+//           detectors so that the permute latency is never waited for).
 #ifndef CM_KERNELS_H
 #define CM_KERNELS_H
 

@@ -13,8 +13,8 @@
 //   * FilterFunction's delay compensation (append `shift` copies of the last sample, drop the
 //     first `shift` outputs) -> index bookkeeping on the stream, no buffers.
 //
-// All coefficients are wave-uniform and sit in SGPRs; the only cross-lane traffic is the
-// comb filter's "previous line" term, exchanged at 1x rate after the base demodulation
+// All coefficients are wave-uniform (SGPRs, or VGPR copies for the hot blocks: see VPolicy); the only cross-lane
+// traffic is the comb filter's "previous line" term, exchanged at 1x rate after the base demodulation
 // (linearity: demod(curr +- last) = demod(curr) +- demod(last)).
 //
 // The header compiles for the device (T = float, hipcc) and for the host (T = float or
