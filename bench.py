@@ -163,7 +163,8 @@ def main():
             'roofline': {'bound': 'hbm', 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
                          'frac': round(achieved / HBM_PEAK_GBPS, 4), 'traffic': traffic,
                          'kernel_ms': round(mean_kernel_ms, 4), 'algorithmic_bytes_per_launch': BYTES_PER_PIXEL * px_step,
-                         'note': 'not bandwidth-bound: ~200 float32 FMAs per pixel; the chip holds 1.45 GHz of 2.4 under this kernel '
+                         'note': 'not bandwidth-bound: ~229 float32 FMA-equivalents per pixel = ~72 TFLOP/s, 60 % of the 119 TFLOP/s a pure '
+                                 'v_fma_f32 loop sustains; the board runs at its 1400 W power cap and holds 1.45 GHz of 2.4 '
                                  '(profiles/r01_pair_notes.md, DESIGN.md section 5)'},
         }
         if world == 1 and args.cpu_sample > 0:
