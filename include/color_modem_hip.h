@@ -24,9 +24,11 @@
  * records a message for cm_last_error() (thread-local).  All image buffers are DEVICE pointers
  * to float32, caller-owned, row-major:  composite [frames][height][width],
  * rgb [frames][3][height][width] (planar R, G, B).  `stream` is a hipStream_t (NULL = default
- * stream); calls are asynchronous with respect to the host.  Plans are immutable after
- * creation and may be shared by threads; a plan belongs to the device that was current when
- * it was created.
+ * stream); calls are asynchronous with respect to the host.  Images are dense (no row padding) whatever the width;
+ * when the width is not a multiple of 4 the float entry points stage them through pitched device buffers
+ * (stream-ordered allocation + two strided copies on `stream`), the byte entry points report CM_ERR_UNSUPPORTED.
+ * Plans are immutable after creation and may be shared by threads; a plan belongs to the device that was
+ * current when it was created.
  *
  * There is no CPU implementation behind this ABI: without a usable HIP device every compute
  * entry point fails with CM_ERR_NO_DEVICE.
