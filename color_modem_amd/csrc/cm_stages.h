@@ -146,6 +146,9 @@ struct HalfbandChain {
     // has been pushed (ref: resample_poly(x, 2, 1)[2n + 1]).
     template <bool V>
     CM_HD T push(const Taps<T> &k, T x) {
+#ifdef CM_EXP_NO_FIR   /* timing experiment: the scalar half-band chains cost nothing (results are wrong) */
+        return x + s[0];
+#endif
         T out = fma3<V>(k.c[0], x, s[0]);
 #pragma unroll
         for (int j = 0; j < 18; ++j) s[j] = fma3<V>(k.c[(j + 1) < 10 ? (j + 1) : 18 - j], x, s[j + 1]);

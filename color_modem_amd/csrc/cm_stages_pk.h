@@ -199,6 +199,9 @@ struct HalfbandChainPk {
         if constexpr (J < 17) update<J + 1>(k, x);
     }
     __device__ __forceinline__ pf2 push_pair(const TapsPk &k, pf2 even, pf2 odd) {
+#ifdef CM_EXP_NO_PKFIR   /* timing experiment: the packed decimator costs nothing (results are wrong) */
+        return pk_add(even, odd);
+#endif
         pf2 out = tap_fma<0>(k, odd, s[0]);
         update<0>(k, odd);
         s[18] = pk_mul_c<0>(k.c2[0], odd);
@@ -309,8 +312,12 @@ struct DetectorPk {
                 if (nd == W - 1) p_last = p_o;
                 if (nd >= W) p_e = p_o = p_last;
             }
+#ifdef CM_EXP_NO_LPF   /* timing experiment: the packed detector low-pass costs nothing (results are wrong) */
+            pf2 y0 = p_e, y1 = p_o;
+#else
             pf2 y0 = iir_sym_pk<0, S::NL>(lpf, kb.lpf, p_e);
             pf2 y1 = iir_sym_pk<0, S::NL>(lpf, kb.lpf, p_o);
+#endif
             if (ODD_L) { q_e = hold; q_o = y0; hold = y1; } else { q_e = y0; q_o = y1; }
         }
         if (EDGE && (n5 < 0 || n5 >= W)) q_e = q_o = pf2{0.f, 0.f};
