@@ -195,7 +195,11 @@ __device__ __forceinline__ void mod_rows(const Geom &g, const LaneCall &lc, cons
         op = lc.store_ok ? g.out + lc.frame * g.out_frame_stride + (long long)lc.out_row * g.out_row_stride : nullptr;
     }
 }
-constexpr int kModLdsFloats = kLdsIn3 + 64 * 16;                          // float mode: 3-plane input tile + output tile
+// samples per output tile row of the encoders: the QAM encoders write 128-byte row segments (measured 2.31 -> 2.04 ms per
+// 1000 frames against 64-byte segments: they are bandwidth-bound and the tile is a single plane, 8 KiB), the SECAM
+// encoder keeps 64-byte segments (it is arithmetic-bound: the wider tile cost it 19 %)
+constexpr int kQamModTile = 32, kSecamModTile = 16;
+template <int kTile> constexpr int mod_lds_floats() { return kLdsIn3 + 64 * kTile; }   // float mode: 3-plane input tile + output tile
 constexpr int kModLdsFloatsU8 = (kInTile3Bytes + 64 * kOutTileU8) / 4;    // byte mode
 
 // DEPTH = 1: encoder-side line averaging (ColorAveragingModem) needs the previous call's components.
@@ -203,8 +207,8 @@ constexpr int kModLdsFloatsU8 = (kInTile3Bytes + 64 * kOutTileU8) / 4;    // byt
 // RT: run-time shape - SP is the size of the luma delay window, the delay itself is k.s_p <= SP (any sampling rate)
 template <int NP, int SP, int DEPTH, bool U8 = false, bool RT = false>
 __global__ __launch_bounds__(64, 2) void qam_mod_kernel(const ModArgs<NP> args) {
-    constexpr int kTile = 16;
-    __shared__ __attribute__((aligned(16))) float lds_store[U8 ? kModLdsFloatsU8 : kModLdsFloats];
+    constexpr int kTile = kQamModTile;
+    __shared__ __attribute__((aligned(16))) float lds_store[U8 ? kModLdsFloatsU8 : mod_lds_floats<kTile>()];
     lds_float *itile = (lds_float *)lds_store;
     lds_float *otile_base = itile + (U8 ? kInTile3Bytes / 4 : kLdsIn3);
     const Geom &g = args.g;

@@ -173,8 +173,8 @@ struct SecamModArgs {
 // RT: SP is the size of the luma delay window, the delay itself is k.s_p <= SP (other sampling rates)
 template <int SP, int DEPTH, bool U8 = false, bool RT = false>
 __global__ __launch_bounds__(64, 2) void secam_mod_kernel(const SecamModArgs args) {
-    constexpr int kTile = 16;
-    __shared__ __attribute__((aligned(16))) float lds_store[U8 ? kModLdsFloatsU8 : kModLdsFloats];
+    constexpr int kTile = kSecamModTile;
+    __shared__ __attribute__((aligned(16))) float lds_store[U8 ? kModLdsFloatsU8 : mod_lds_floats<kTile>()];
     lds_float *itile = (lds_float *)lds_store;
     lds_float *otile_base = itile + (U8 ? kInTile3Bytes / 4 : kLdsIn3);
     const Geom &g = args.g;
