@@ -998,11 +998,29 @@ __device__ __forceinline__ void run_pair(const Geom &g, const DemodK<float, type
         sub_b(std::integral_constant<int, 3>(), edge_tag, p_last, uv_last, tb + 3, pe3, po3, sc3);
         if (s_flush == 3) maybe_flush(tb + 3);
     };
+    // Stage B's own schedule.  Bodies whose four detector samples all lie before the row (nd = t - front_off < 0) leave
+    // every state of this stage at its reset value: only the hand-over protocol runs there.  At the other end B meets its
+    // first end-of-row event at nd = W - 1 (the detector's latch), front_off steps after stage A met its first one.
+#ifdef CM_EXP_NO_BSKIP   /* timing experiment: stage B on stage A's schedule */
+    const int t_skip = 0, t_mid0b = t_mid0, t_mid1b = t_mid1;
+#else
+    const int t_skip = front_off & ~3;
+    int t_mid0b = (lat_out + 3) & ~3, t_mid1b = (W - 1 + front_off) & ~3;
+    if (t_mid1b <= t_mid0b) t_mid0b = t_mid1b = 0;   // tiny rows: the guarded body runs everything
+#endif
     int tb = 0;
+    for (; tb < t_skip; tb += 4) {
+        PAIR_BARRIER(d_bar);   // t_skip < T: block tb / 4 + 1 of the ring exists
+        const lds_float *slot = ring + (((tb + 4) >> 2) & 1) * (kMidRing / 2) + lane * 4;
+        me = *(const lds_f4 *)slot;
+        mo = *(const lds_f4 *)(slot + 256);
+        c4 = load_c4(tb + 4);
+        c2 = load_c2(tb + 4);
+    }
     {
         pf2 p_last = {0.f, 0.f}, uv_last = {0.f, 0.f};
-        for (; tb < t_mid0; tb += 4) body_b(tb, std::true_type(), p_last, uv_last);
-        for (; tb < t_mid1; tb += 4) body_b(tb, std::false_type(), p_last, uv_last);
+        for (; tb < t_mid0b; tb += 4) body_b(tb, std::true_type(), p_last, uv_last);
+        for (; tb < t_mid1b; tb += 4) body_b(tb, std::false_type(), p_last, uv_last);
     }
     pf2 p_last = {0.f, 0.f}, uv_last = {0.f, 0.f};
     for (; tb < T; tb += 4) body_b(tb, std::true_type(), p_last, uv_last);
