@@ -121,6 +121,12 @@ typedef const __attribute__((address_space(4))) f16u const_f16;
 #ifndef CM_FILL_AUX
 #define CM_FILL_AUX 2
 #endif
+// Wave-pair kernels without a band-stop luma: 1 = stage A leaves the luma source samples x_l[n7] in an LDS delay ring straight
+// out of its x window (every input byte is read from memory once); 0 = stage A fetches them a second time with one
+// global_load_dwordx4 per lane and body (the one-wave kernels always do).
+#ifndef CM_LUMA_RING
+#define CM_LUMA_RING 1
+#endif
 typedef __attribute__((address_space(3))) float lds_float;
 typedef __attribute__((address_space(3))) f4 lds_f4;
 constexpr int kInTile = 32;        // samples per input tile (one 128-byte line per row)
@@ -151,6 +157,10 @@ struct PassCfg {
     static constexpr int kLdsInF = U8_ ? 64 * kInTile / 4 : kLdsIn;            // floats: byte tiles are a quarter
     static constexpr int kLdsOut = U8_ ? 64 * 3 * TILE_ / 4 : 3 * 64 * TILE_;  // floats
     static constexpr int kLdsFloats = kLdsInF + kLdsOut + (BSF_ ? kLdsRing : 0);
+    // wave-pair kernels: float rows enter through 16-sample tiles (64-byte row segments) when the luma delay ring takes the
+    // LDS (CM_LUMA_RING); byte tiles stay 32 samples wide
+    static constexpr int kPairInTile = (U8_ || !CM_LUMA_RING) ? kInTile : 16;
+    static constexpr int kPairLdsIn = U8_ ? 64 * kInTile / 4 : 64 * kPairInTile;   // floats
     // wave-pair kernels: 3 waves per SIMD need <= 168 VGPRs; the instances with more per-lane state in stage B (a second
     // line of history, the notch, the second combination of minavg) would spill there and get 2 waves per SIMD instead
     static constexpr int kPairWaves = (DEPTH_ >= 2 || NOTCH_ || MINAVG_ || S_::NE >= 4 || S_::NP >= 2 || S_::RT) ? 2 : 3;
@@ -377,14 +387,19 @@ __device__ __forceinline__ void flush_tile(const Geom &g, const lds_float *otile
 }
 
 // Fill input tile `c` (samples 32 c .. 32 c + 31 of all 64 rows) straight into LDS.
+// IT samples per tile row: IT / 4 lanes x 16 bytes per row, 256 / IT rows per instruction, IT / 4 instructions.
+template <int IT = kInTile>
 __device__ __forceinline__ void fill_tile(const Geom &g, lds_float *itile, const float *xp, int c, int lane) {
-    int col = kInTile * c + 4 * (lane & 7);
+    constexpr int kLanesPerRow = IT / 4, kRowsPerInstr = 64 / kLanesPerRow;
+    // 64-byte segments: both halves of a 128-byte line are asked for 16 steps apart - no streaming hint there
+    constexpr int kAux = IT == kInTile ? CM_FILL_AUX : 0;
+    int col = IT * c + 4 * (lane & (kLanesPerRow - 1));
     if (col > g.Wp - 4) col = g.Wp - 4;  // never read past the (pitched) row; such samples are masked by the consumer
 #pragma nounroll
-    for (int q = 0; q < 8; ++q) {
-        const float *src = ptr_from((8 * q + (lane >> 3)) * 4, xp) + col;
+    for (int q = 0; q < kLanesPerRow; ++q) {
+        const float *src = ptr_from((kRowsPerInstr * q + lane / kLanesPerRow) * 4, xp) + col;
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
-                                         (__attribute__((address_space(3))) void *)(itile + q * 256), 16, 0, CM_FILL_AUX);
+                                         (__attribute__((address_space(3))) void *)(itile + q * 256), 16, 0, kAux);
     }
 }
 
@@ -700,10 +715,17 @@ constexpr int kMidRing = 2 * 2 * 64 * 4;    // floats: [buffer][even | odd][lane
 template <class S> constexpr int luma_ring_slots() { return S::RT ? 64 : 32; }
 
 constexpr int kLumaSlots = 2 * 64 * 4;      // floats: [buffer][lane][4 steps] luma source samples fetched by A for B
+// CM_LUMA_RING: blocks of [lane][4 steps] x samples; A writes x[tb - 10 + o .. + 3] at the end of body tb, B reads the block
+// m bodies later, lat_out = 4 m + 10 - o; A runs at most two blocks ahead of B's read, so m + 2 blocks are live
+// (the host checks lat_out against this: cm_api.hip).  11 KiB for PAL-BG (lat_out 46 = the limit), 12 KiB for the order-6 band-pass shapes, 20 KiB for the run-time shape.
+template <class S> constexpr int luma_delay_blocks() { return S::RT ? 20 : (S::NE >= 3 ? 12 : 11); }
+template <class S> constexpr int luma_delay_max_latency() { return 4 * (luma_delay_blocks<S>() - 2) + 10; }
 
 template <class Cfg>
 struct PairLds {
-    static constexpr int kIn = Cfg::kLdsInF, kOut = Cfg::kLdsOut, kY = Cfg::BSF ? luma_ring_slots<typename Cfg::S>() * 64 : kLumaSlots;
+    static constexpr int kIn = Cfg::kPairLdsIn, kOut = Cfg::kLdsOut;
+    static constexpr int kY = Cfg::BSF ? luma_ring_slots<typename Cfg::S>() * 64
+                                       : (CM_LUMA_RING ? luma_delay_blocks<typename Cfg::S>() * 256 : kLumaSlots);
     static constexpr int kFloats = kIn + kMidRing + kOut + kY;
 };
 template <>
@@ -732,6 +754,9 @@ __device__ __forceinline__ void run_pair(const Geom &g, const DemodK<float, type
     constexpr int FRONT = Cfg::FRONT, DEPTH = Cfg::DEPTH, kTile = Cfg::TILE, SP = S::SP;
     constexpr bool BSF = Cfg::BSF, U8 = Cfg::U8, PALD = FRONT == FRONT_PALD;
     constexpr int kYSlots = luma_ring_slots<S>();
+    constexpr bool LRING = CM_LUMA_RING && !BSF;         // luma source samples through the LDS delay ring
+    constexpr int kIT = Cfg::kPairInTile;                // samples per input tile row
+    constexpr int kLB = luma_delay_blocks<S>();
     typedef typename std::conditional<PALD, PalDFront<float, S>, QamFront<float, S, BSF>>::type Front;
     typedef typename Front::StageA StageA;
     typedef typename Front::StageB StageB;
@@ -769,6 +794,9 @@ __device__ __forceinline__ void run_pair(const Geom &g, const DemodK<float, type
     const unsigned long long d_begin = cm_stamp(), d_rbegin = cm_realtime();
 #endif
     lds_float *lring = yring;   // luma hand-off slots share the place of the band-stop ring (the two exclude each other)
+    // delay ring: A leaves x[tb - 10 + lr_o .. + 3] at the end of body tb, B needs x_l[tb - lat_out .. + 3] at the start of
+    // body tb, i.e. the block A wrote lr_m bodies before: lat_out = 4 lr_m + 10 - lr_o
+    const int lr_o = (10 - lat_out) & 3, lr_m = (lat_out - 10 + lr_o) >> 2;
 
     if (role == 0) {
         // =================================== stage A ===========================================
@@ -791,13 +819,13 @@ __device__ __forceinline__ void run_pair(const Geom &g, const DemodK<float, type
         if (BSF) {
             for (int j = 0; j < kYSlots; ++j) yring[j * 64 + lane] = 0.f;
         }
-        const lds_float *xrow = itile + lane * kInTile;
+        const lds_float *xrow = itile + lane * kIT;
         auto read_x = [&](int first) -> f4 {  // x[first .. first + 3] from the input tile, zero outside the row
             f4 v;
             if (U8)
-                v = decode_bytes(*(const lds_u32 *)((const lds_u8 *)itile + lane * kInTile + (first & (kInTile - 1))));
+                v = decode_bytes(*(const lds_u32 *)((const lds_u8 *)itile + lane * kIT + (first & (kIT - 1))));
             else
-                v = *(const lds_f4 *)(xrow + (first & (kInTile - 1)));
+                v = *(const lds_f4 *)(xrow + (first & (kIT - 1)));
             if (first + 3 >= W) {
                 if (first >= W) v.x = 0.f;
                 if (first + 1 >= W) v.y = 0.f;
@@ -807,11 +835,15 @@ __device__ __forceinline__ void run_pair(const Geom &g, const DemodK<float, type
             return v;
         };
         auto read_luma = [&](int first, bool check) -> f4 {  // x_l[first .. first + 3], zero outside the row
-            if (BSF) return f4{0.f, 0.f, 0.f, 0.f};
+            if (BSF || LRING) return f4{0.f, 0.f, 0.f, 0.f};
             return load_luma<U8>(lp, first, check, W);
         };
-        if (U8) fill_tile_u8(g, itile, xp, 0, lane); else fill_tile(g, itile, xp, 0, lane);
+        if (U8) fill_tile_u8(g, itile, xp, 0, lane); else fill_tile<kIT>(g, itile, xp, 0, lane);
         f4 lum_cur = read_luma(-lat_out, true);   // luma source of B's block 0
+        if (LRING) {   // blocks B reads before A has written them lie before the row: zeros
+            for (int j = 0; j < kLB; ++j) *(lds_f4 *)(lring + j * 256 + lane * 4) = f4{0.f, 0.f, 0.f, 0.f};
+        }
+        int lr_w = 0;   // ring block of this body
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_wave_barrier();
         {
@@ -838,6 +870,12 @@ __device__ __forceinline__ void run_pair(const Geom &g, const DemodK<float, type
             constexpr bool EDGE_A = decltype(edge_tag)::value;
             // luma source of B's next block: a whole body hides the latency
             const f4 lum_next = read_luma(tb + 4 - lat_out, EDGE_A || tb + 4 >= t_mid1);
+            f4 lum_blk = {0.f, 0.f, 0.f, 0.f};
+            if (LRING) {   // x[tb - 10 + lr_o .. + 3] out of the window (xw[j] = x[tb - 10 + j], zero outside the row)
+                lum_blk = lr_o == 0 ? f4{xw[0], xw[1], xw[2], xw[3]}
+                        : lr_o == 1 ? f4{xw[1], xw[2], xw[3], xw[4]}
+                        : lr_o == 2 ? f4{xw[2], xw[3], xw[4], xw[5]} : f4{xw[3], xw[4], xw[5], xw[6]};
+            }
             float me[4], mo[4];
             sub_a(std::integral_constant<int, 0>(), edge_tag, fla, tb + 0, me[0], mo[0]);
             sub_a(std::integral_constant<int, 1>(), edge_tag, fla, tb + 1, me[1], mo[1]);
@@ -846,7 +884,7 @@ __device__ __forceinline__ void run_pair(const Geom &g, const DemodK<float, type
             const int nxt = tb + 4;
 #pragma unroll
             for (int j = 0; j < 10; ++j) xw[j] = xw[j + 4];
-            if ((nxt & (kInTile - 1)) == 0 && nxt < W) {  // first read of a new tile: its fill was issued a body ago
+            if ((nxt & (kIT - 1)) == 0 && nxt < W) {  // first read of a new tile: its fill was issued a body ago
                 CM_STAMP(t0);
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __builtin_amdgcn_wave_barrier();
@@ -856,10 +894,10 @@ __device__ __forceinline__ void run_pair(const Geom &g, const DemodK<float, type
                 f4 xn = read_x(nxt);
                 xw[10] = xn.x; xw[11] = xn.y; xw[12] = xn.z; xw[13] = xn.w;
             }
-            if ((nxt & (kInTile - 1)) == kInTile - 4 && nxt + 4 < W) {  // that was the last read of this tile: refill it
+            if ((nxt & (kIT - 1)) == kIT - 4 && nxt + 4 < W) {  // that was the last read of this tile: refill it
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_wave_barrier();
-                if (U8) fill_tile_u8(g, itile, xp, (nxt >> 5) + 1, lane); else fill_tile(g, itile, xp, (nxt >> 5) + 1, lane);
+                if (U8) fill_tile_u8(g, itile, xp, nxt / kIT + 1, lane); else fill_tile<kIT>(g, itile, xp, nxt / kIT + 1, lane);
             }
             if (PALD) {
 #pragma unroll
@@ -868,7 +906,12 @@ __device__ __forceinline__ void run_pair(const Geom &g, const DemodK<float, type
             lds_float *slot = ring + ((tb >> 2) & 1) * (kMidRing / 2) + lane * 4;
             *(lds_f4 *)slot = f4{me[0], me[1], me[2], me[3]};
             *(lds_f4 *)(slot + 256) = f4{mo[0], mo[1], mo[2], mo[3]};
-            if (!BSF) *(lds_f4 *)(lring + ((tb >> 2) & 1) * (kLumaSlots / 2) + lane * 4) = lum_cur;
+            if (LRING) {
+                *(lds_f4 *)(lring + lr_w * 256 + lane * 4) = lum_blk;
+                lr_w = lr_w + 1 == kLB ? 0 : lr_w + 1;
+            } else if (!BSF) {
+                *(lds_f4 *)(lring + ((tb >> 2) & 1) * (kLumaSlots / 2) + lane * 4) = lum_cur;
+            }
             lum_cur = lum_next;
             PAIR_BARRIER(d_bar);
         };
@@ -936,6 +979,11 @@ __device__ __forceinline__ void run_pair(const Geom &g, const DemodK<float, type
         }
     };
     f4 lw;
+    // delay ring: the block of body tb is lr_m blocks behind A's; a luma source row other than the own one (decoders with a
+    // line of delay) is the row of the previous call, i.e. of the neighbouring lane
+    int lr_r = lr_m == 0 ? 0 : kLB - lr_m;
+    const bool luma_prev = DEPTH >= 1 && ((g.luma_prev_bits >> regime) & 1) && lc.prev_row != lc.src_row;
+    const lds_float *lr_lane = lring + (luma_prev ? ((lane + 63) & 63) : lane) * 4;
     // p_e, p_o: detector products of this step's pair; sc: (sn, cs) of the back-end sample
     auto sub_b = [&](auto sub_tag, auto edge_tag, pf2 &p_last, pf2 &uv_last, int tau, pf2 p_e, pf2 p_o, pf2 sc) {
         constexpr int SUB = decltype(sub_tag)::value;
@@ -972,7 +1020,12 @@ __device__ __forceinline__ void run_pair(const Geom &g, const DemodK<float, type
     auto body_b = [&](int tb, auto edge_tag, pf2 &p_last, pf2 &uv_last) {
         constexpr bool EDGE = decltype(edge_tag)::value;
         const int nxt = tb + 4;
-        if (!BSF) lw = *(const lds_f4 *)(lring + ((tb >> 2) & 1) * (kLumaSlots / 2) + lane * 4);   // left there by A
+        if (LRING) {
+            lw = *(const lds_f4 *)(lr_lane + lr_r * 256);
+            lr_r = lr_r + 1 == kLB ? 0 : lr_r + 1;
+        } else if (!BSF) {
+            lw = *(const lds_f4 *)(lring + ((tb >> 2) & 1) * (kLumaSlots / 2) + lane * 4);   // left there by A
+        }
         // first half: detector products and re-modulation carriers of sub-steps 0, 1
         pf2 pe0 = pk_mul_bs<0>(pf2{me.x, me.y}, pf2{c4[0], c4[1]}), po0 = pk_mul_bs<0>(pf2{mo.x, mo.y}, pf2{c4[2], c4[3]});
         pf2 pe1 = pk_mul_bs<1>(pf2{me.x, me.y}, pf2{c4[4], c4[5]}), po1 = pk_mul_bs<1>(pf2{mo.x, mo.y}, pf2{c4[6], c4[7]});
@@ -1016,6 +1069,7 @@ __device__ __forceinline__ void run_pair(const Geom &g, const DemodK<float, type
         mo = *(const lds_f4 *)(slot + 256);
         c4 = load_c4(tb + 4);
         c2 = load_c2(tb + 4);
+        if (LRING) lr_r = lr_r + 1 == kLB ? 0 : lr_r + 1;
     }
     {
         pf2 p_last = {0.f, 0.f}, uv_last = {0.f, 0.f};
