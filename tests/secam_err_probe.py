@@ -1,4 +1,4 @@
-"""Where the SECAM decoder's float32 error sits: python tests/secam_err_probe.py (GPU; uses the oracle: test tool)"""
+"""Where the SECAM decoder's float32 error sits: python tests/secam_err_probe.py [widths] [variants] [seed] (GPU; uses the oracle: test tool)"""
 import sys, warnings
 import numpy
 sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
@@ -6,12 +6,15 @@ warnings.filterwarnings('ignore')
 from color_modem_amd import image, line, testing
 from color_modem_amd.color import secam
 from oracle import cm_oracle
-for w in (720, 1280, 1920):
-    for vn in ('SECAM', 'SECAM_II', 'SECAM_M'):
+WIDTHS = [int(a) for a in sys.argv[1].split(',')] if len(sys.argv) > 1 else (720, 1280, 1920)
+VARIANTS = sys.argv[2].split(',') if len(sys.argv) > 2 else ('SECAM', 'SECAM_II', 'SECAM_M')
+SEED = int(sys.argv[3]) if len(sys.argv) > 3 else 5
+for w in WIDTHS:
+    for vn in VARIANTS:
         lc = line.LineConfig((w, 120), line.LineStandard.detect(576))
         modem = secam.SecamModem(lc, getattr(secam.SecamVariant, vn))
         im = image.ImageModem(modem)
-        rgb = testing.synthetic_rgb(2, 120, w, seed=5)
+        rgb = testing.synthetic_rgb(2, 120, w, seed=SEED)
         comp = cm_oracle.modulate_frames_f32(modem, rgb, first_frame=3, n_threads=8)
         got = im.demodulate_frames(comp, first_frame=3).astype(numpy.float64)
         want = cm_oracle.demodulate_frames_f32(modem, comp, first_frame=3, n_threads=8)
