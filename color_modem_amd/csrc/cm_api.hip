@@ -77,6 +77,7 @@ struct cm_plan {
     float *carrier4 = nullptr, *carrier2 = nullptr;             // entry 0 of the padded tables
     float *carrier4_base = nullptr, *carrier2_base = nullptr;   // the allocations
     float *frame_rot = nullptr;   // {cos, sin} per frame of the rotation cycle (long sub-carrier cycles), else null
+    unsigned *simd_load = nullptr; // wave-pair kernels: live load per (XCC, CU, SIMD), kSimdLoadEntries counters (cm_kernels.h)
     int rot_cycle = 0;
     LaunchFn fn = nullptr, fn_u8 = nullptr;
     bool has_first = false;
@@ -507,6 +508,7 @@ static unsigned long long *g_diag;
 #endif
 int run_plan(const cm_plan *p, Geom gm, Geom gf, bool with_first, hipStream_t stream, bool u8 = false) {
     finish_geom(p, p->main, gm);
+    gm.simd_load = p->simd_load;
 #ifdef CM_DIAG
     gm.diag = g_diag;
 #endif
@@ -605,6 +607,13 @@ int cm_plan_create(const cm_plan_desc *desc, cm_plan **out) {
         *out = p;
         return CM_OK;
     }
+    if (CM_SIMD_BALANCE) {   // counters return to zero with every kernel (each workgroup takes back what it added)
+        if (hipMalloc((void **)&p->simd_load, kSimdLoadEntries * sizeof(unsigned)) != hipSuccess ||
+            hipMemset(p->simd_load, 0, kSimdLoadEntries * sizeof(unsigned)) != hipSuccess) {
+            cm_plan_destroy(p);
+            return fail(CM_ERR_LAUNCH, "device allocation of the SIMD load counters failed");
+        }
+    }
     // Carrier tables, padded by kCarrierPad entries on both sides with copies of the first / last entry: the kernels
     // index them with stream positions that run from -latency to W + latency and the padding stands for the clamp.
     std::vector<float> car0 = build_carrier<float>(desc->carrier_phase_step, desc->width);  // {C[m], S[m]}, m < 2W
@@ -665,6 +674,7 @@ void cm_plan_destroy(cm_plan *p) {
     if (p->carrier4_base) (void)hipFree(p->carrier4_base);
     if (p->carrier2_base) (void)hipFree(p->carrier2_base);
     if (p->frame_rot) (void)hipFree(p->frame_rot);
+    if (p->simd_load) (void)hipFree(p->simd_load);
     if (p->main.lanes) (void)hipFree(p->main.lanes);
     if (p->first.lanes) (void)hipFree(p->first.lanes);
     if (p->mod_lanes) (void)hipFree(p->mod_lanes);

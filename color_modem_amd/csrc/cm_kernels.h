@@ -57,6 +57,7 @@ struct Geom {
     int sparse;          // 1: one lane per run, call 0 of each run only (plain first-line pass)
     int skip_first;      // 1: calls with k == 0 are written by the sparse pass, not by this one
     unsigned long long *diag;  // diagnostic builds only (-DCM_DIAG): per-workgroup cycle sums; null otherwise
+    unsigned *simd_load;       // wave-pair kernels (CM_SIMD_BALANCE): live load per (XCC, CU, SIMD); null: waves keep their order
 };
 
 // Long sub-carrier cycles: advance every phase a lane constant carries by the frame's angle (c, s) = {cos, sin}.
@@ -929,6 +930,9 @@ __device__ __forceinline__ void run_pair(const Geom &g, const DemodK<float, type
         if (g.diag && lane == 0 && !g.sparse) {
             unsigned long long *d = g.diag + 16ull * block;
             d[0] = cm_stamp() - d_begin; d[1] = d_bar; d[2] = d_other;
+            unsigned hw;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+            d[4] = hw;
         }
 #endif
         return;
@@ -1082,6 +1086,9 @@ __device__ __forceinline__ void run_pair(const Geom &g, const DemodK<float, type
     if (g.diag && lane == 0 && !g.sparse) {
         unsigned long long *d = g.diag + 16ull * block + 8;
         d[0] = cm_stamp() - d_begin; d[1] = d_bar; d[2] = d_flush; d[3] = cm_realtime() - d_rbegin;
+        unsigned hw;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        d[4] = hw;
     }
 #endif
 }
@@ -1108,6 +1115,19 @@ __global__ __launch_bounds__(64, 2) void demod_kernel(const PassArgs<typename Ma
     run_lane<Main>(main_args.g, main_args.k, (int)blockIdx.x - n_first, lds);
 }
 
+// Which wave of a pair plays which stage (experiment, off by default).  Stage B is the heavier one (about 290 against 168
+// vector-pipe cycles per step) and the two waves of a workgroup sit on two different SIMDs of the CU; with 10 or 12 waves on
+// 4 SIMDs a SIMD that happens to host two or three B waves paces every workgroup that has a wave on it.  With
+// -DCM_SIMD_BALANCE=1 the pair looks at the live load of its two SIMDs (counters per (XCC, CU, SIMD) in global memory,
+// weights 4 / 7) and gives stage B to the wave on the lighter one; each wave takes its weight back when it ends.
+// Measured (profiles/r01_pair_notes.md section 8): 2.7 % fewer cycles per workgroup, 2 % less clock, 0.5 % less time - the
+// board is power-bound, so the product keeps the waves in launch order.
+#ifndef CM_SIMD_BALANCE
+#define CM_SIMD_BALANCE 0
+#endif
+constexpr int kSimdLoadEntries = 16 * 256 * 4;   // [XCC_ID 4 bits][SE, SH, CU ids = HW_ID bits 15:8][SIMD]
+constexpr unsigned kLoadA = 4, kLoadB = 7;
+
 #ifndef CM_PAIR_WAVES_PER_SIMD
 #define CM_PAIR_WAVES_PER_SIMD Main::kPairWaves
 #endif
@@ -1122,7 +1142,14 @@ __global__ __launch_bounds__(128, CM_PAIR_WAVES_PER_SIMD) void demod_pair_kernel
 #ifdef CM_DEV_ROLE   /* register-pressure experiments: compile one stage only (the result does not run) */
     const int role = CM_DEV_ROLE;
 #else
-    const int role = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    int role = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+#if defined(CM_EXP_ROLE_SWAP) && CM_EXP_ROLE_SWAP == 1   /* experiment: which wave of the pair plays which stage */
+    role ^= (int)blockIdx.x & 1;
+#elif defined(CM_EXP_ROLE_SWAP) && CM_EXP_ROLE_SWAP == 2
+    role ^= (int)(((unsigned)blockIdx.x * 2654435761u) >> 31);
+#elif defined(CM_EXP_ROLE_SWAP) && CM_EXP_ROLE_SWAP == 3
+    role ^= 1;
+#endif
 #endif
     if constexpr (!std::is_same<First, NoPass>::value) {
         if ((int)blockIdx.x < n_first) {
@@ -1130,7 +1157,39 @@ __global__ __launch_bounds__(128, CM_PAIR_WAVES_PER_SIMD) void demod_pair_kernel
             return;
         }
     }
+#if CM_SIMD_BALANCE
+    __shared__ int bal[4];
+    unsigned *cnt = main_args.g.simd_load;
+    unsigned my_load = 0;
+    int simd = 0;
+    if (cnt) {
+        unsigned hw, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        simd = (int)(hw >> 4) & 3;
+        cnt += (((xcc & 15u) << 8) | ((hw >> 8) & 0xffu)) << 2;
+        if ((threadIdx.x & 63) == 0) bal[role] = simd;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const int s0 = bal[0], s1 = bal[1];
+            const unsigned l0 = __hip_atomic_load(cnt + s0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned l1 = __hip_atomic_load(cnt + s1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned keep = (l0 + kLoadA > l1 + kLoadB ? l0 + kLoadA : l1 + kLoadB);    // wave 0 = stage A
+            const unsigned swap = (l0 + kLoadB > l1 + kLoadA ? l0 + kLoadB : l1 + kLoadA);    // wave 0 = stage B
+            const int sw = swap < keep || (swap == keep && (blockIdx.x & 1)) ? 1 : 0;
+            bal[2] = sw;
+            atomicAdd(cnt + s0, sw ? kLoadB : kLoadA);
+            atomicAdd(cnt + s1, sw ? kLoadA : kLoadB);
+        }
+        __syncthreads();
+        role ^= __builtin_amdgcn_readfirstlane(bal[2]);
+        my_load = role ? kLoadB : kLoadA;
+    }
+#endif
     run_pair<Main>(main_args.g, main_args.k, (int)blockIdx.x - n_first, lds, role);
+#if CM_SIMD_BALANCE
+    if (cnt && (threadIdx.x & 63) == 0) atomicSub(cnt + simd, my_load);
+#endif
 }
 
 }  // namespace cm

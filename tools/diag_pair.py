@@ -21,3 +21,11 @@ for role, off, names in (('A', 0, ['total', 'barrier wait', 'tile fill wait']), 
         print('  %-18s %10.0f  %.1f %%' % (n, d[:, off + i].mean(), 100 * d[:, off + i].mean() / tot.mean()))
 rt = d[:, 11]
 print('in-kernel clock: %.3f GHz (median over workgroups of d s_memtime / d s_memrealtime x 100 MHz); lifetime %.1f us' % (numpy.median(d[:, 8] / rt) * 0.1, numpy.median(rt) / 100))
+# which SIMD hosts which stage (HW_ID: SIMD_ID = bits 5:4, CU_ID = bits 11:8)
+import collections
+for role, off in (('A', 4), ('B', 12)):
+    hw = d[:, off].astype(numpy.int64)
+    print('stage %s waves per SIMD id:' % role, dict(sorted(collections.Counter(((hw >> 4) & 3).tolist()).items())))
+a, b = d[:, 4].astype(numpy.int64), d[:, 12].astype(numpy.int64)
+print('pairs (SIMD of A, SIMD of B):', dict(sorted(collections.Counter(zip(((a >> 4) & 3).tolist(), ((b >> 4) & 3).tolist())).items())))
+print('same CU for both waves: %.3f' % numpy.mean(((a >> 8) & 15) == ((b >> 8) & 15)))
