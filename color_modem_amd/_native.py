@@ -19,9 +19,18 @@ CM_OK, CM_ERR_INVALID, CM_ERR_UNSUPPORTED, CM_ERR_NO_DEVICE, CM_ERR_LAUNCH = 0, 
 SYMBOLS = ('cm_last_error', 'cm_abi_version', 'cm_device_count', 'cm_plan_create', 'cm_plan_destroy',
            'cm_demodulate_frames', 'cm_modulate_frames', 'cm_demodulate_frames_u8', 'cm_modulate_frames_u8', 'cm_demodulate_run',
            'cm_modulate_run',
-           'cm_plan_describe')
+           'cm_plan_describe',
+           'cm_mac_modulate_frames', 'cm_mac_demodulate_frames', 'cm_mac_modulate_run', 'cm_mac_demodulate_run')
 
 _lib = None
+
+
+class MacDesc(ctypes.Structure):
+    """cm_mac_desc (include/color_modem_hip.h)"""
+    _fields_ = [('height', ctypes.c_int32), ('line_shift', ctypes.c_int32), ('even_first', ctypes.c_int32),
+                ('odd_first', ctypes.c_int32), ('averaging', ctypes.c_int32), ('reserved', ctypes.c_int32),
+                ('resample_fir', ctypes.c_double * 41), ('decode_matrix', ctypes.c_double * 9),
+                ('encode_matrix', ctypes.c_double * 9)]
 
 
 class NativeError(RuntimeError):
@@ -54,6 +63,11 @@ def lib():
     L.cm_demodulate_run.argtypes = [vp, vp, vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, vp]
     L.cm_modulate_run.argtypes = [vp, vp, vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, vp]
     L.cm_plan_describe.argtypes = [vp, ctypes.c_char_p, ctypes.c_int32]
+    md = ctypes.POINTER(MacDesc)
+    L.cm_mac_modulate_frames.argtypes = [md, vp, vp, ctypes.c_int64, ctypes.c_int64, vp]
+    L.cm_mac_demodulate_frames.argtypes = [md, vp, vp, ctypes.c_int64, ctypes.c_int64, vp]
+    L.cm_mac_modulate_run.argtypes = [md, vp, vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, vp]
+    L.cm_mac_demodulate_run.argtypes = [md, vp, vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, vp]
     if L.cm_abi_version() != plan.CM_ABI_VERSION:
         raise NativeError('libcolor_modem_hip.so ABI %d, Python side expects %d - rebuild the library'
                           % (L.cm_abi_version(), plan.CM_ABI_VERSION))

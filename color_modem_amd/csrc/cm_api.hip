@@ -11,6 +11,7 @@
 #include "cm_kernels.h"
 #include "cm_mod_kernels.h"
 #include "cm_secam_kernels.h"
+#include "cm_mac_kernels.h"
 #include "cm_plan.h"
 
 constexpr int kModAnyShift = 12;   // luma delay window of the run-time-shape modulators (pre-correction shift <= 12)
@@ -949,6 +950,85 @@ int cm_modulate_run(const cm_plan *p, const float *rgb, float *composite, int32_
         g.total_calls = n_calls;
         return run_mod(p, g, (hipStream_t)stream);
     });
+}
+
+// ---- D2-MAC style time-multiplex modem (cm_mac_kernels.h) -------------------------------------------------------------
+namespace {
+int mac_launch(const cm_mac_desc *d, bool demod, const float *in, float *out, int n_frames, int height, int rows_mode,
+               int first_line, int64_t first_frame, hipStream_t stream) {
+    if (cm_device_count() <= 0) return fail(CM_ERR_NO_DEVICE, "no HIP device: the MAC path runs on the GPU only");
+    cm::MacArgs a;
+    std::memset(&a, 0, sizeof a);
+    a.in = in;
+    a.out = out;
+    a.n_frames = n_frames;
+    a.H = height;
+    a.rows_mode = rows_mode;
+    a.first_line = first_line;
+    a.first_frame = first_frame;
+    a.averaging = d->averaging ? 1 : 0;
+    a.line_shift = d->line_shift;
+    a.even_first = d->even_first;
+    a.odd_first = d->odd_first;
+    const double scale = demod ? 2.0 : 1.0;     // resample_poly scales the filter by `up`
+    a.c0 = (float)(scale * d->resample_fir[20]);
+    for (int j = 0; j < 20; ++j) a.taps[j] = (float)(scale * d->resample_fir[2 * j + 1]);
+    for (int i = 0; i < 9; ++i) a.m[i] = (float)(demod ? d->decode_matrix[i] : d->encode_matrix[i]);
+    long long blocks;
+    if (rows_mode) blocks = (height + cm::kMacSegment - 1) / cm::kMacSegment;
+    else blocks = (long long)n_frames * 2 * ((((height + 1) >> 1) + cm::kMacSegment - 1) / cm::kMacSegment);
+    if (blocks <= 0) return CM_OK;
+    if (blocks > 0x7fffffffLL) return fail(CM_ERR_INVALID, "batch too large for one launch");
+    if (demod) hipLaunchKernelGGL(cm::mac_demod_kernel, dim3((unsigned)blocks), dim3(cm::kMacThreads), 0, stream, a);
+    else hipLaunchKernelGGL(cm::mac_mod_kernel, dim3((unsigned)blocks), dim3(cm::kMacThreads), 0, stream, a);
+    HIP_TRY(hipGetLastError(), CM_ERR_LAUNCH);
+    return CM_OK;
+}
+int mac_check(const cm_mac_desc *d, const void *in, const void *out, long long n) {
+    if (!d) return fail(CM_ERR_INVALID, "null argument");
+    if (n == 0) return CM_OK;     // an empty batch may come with null buffers
+    if (!in || !out) return fail(CM_ERR_INVALID, "null argument");
+    if (((unsigned long long)in | (unsigned long long)out) & 15) return fail(CM_ERR_INVALID, "buffers must be 16-byte aligned");
+    if (d->height <= 0) return fail(CM_ERR_INVALID, "height must be positive");
+    return CM_OK;
+}
+}  // namespace
+
+extern "C" {
+int cm_mac_modulate_frames(const cm_mac_desc *d, const float *rgb, float *composite, int64_t n_frames, int64_t first_frame,
+                           void *stream) {
+    int rc = mac_check(d, rgb, composite, n_frames);
+    if (rc) return rc;
+    if (n_frames < 0 || first_frame < 0) return fail(CM_ERR_INVALID, "negative frame count / number");
+    if (n_frames == 0) return CM_OK;
+    if (n_frames > 0x7fffffffLL) return fail(CM_ERR_INVALID, "batch too large for one launch");
+    return mac_launch(d, false, rgb, composite, (int)n_frames, d->height, 0, 0, first_frame, (hipStream_t)stream);
+}
+int cm_mac_demodulate_frames(const cm_mac_desc *d, const float *composite, float *rgb, int64_t n_frames, int64_t first_frame,
+                             void *stream) {
+    int rc = mac_check(d, composite, rgb, n_frames);
+    if (rc) return rc;
+    if (n_frames < 0 || first_frame < 0) return fail(CM_ERR_INVALID, "negative frame count / number");
+    if (n_frames == 0) return CM_OK;
+    if (n_frames > 0x7fffffffLL) return fail(CM_ERR_INVALID, "batch too large for one launch");
+    return mac_launch(d, true, composite, rgb, (int)n_frames, d->height, 0, 0, first_frame, (hipStream_t)stream);
+}
+int cm_mac_modulate_run(const cm_mac_desc *d, const float *rgb, float *composite, int32_t n_calls, int32_t frame,
+                        int32_t first_line, int32_t k0, void *stream) {
+    int rc = mac_check(d, rgb, composite, n_calls);
+    if (rc) return rc;
+    if (n_calls < 0 || frame < 0 || k0 < 0) return fail(CM_ERR_INVALID, "negative count / frame / k0");
+    if (n_calls == 0) return CM_OK;
+    return mac_launch(d, false, rgb, composite, 1, n_calls, 1, first_line, frame, (hipStream_t)stream);
+}
+int cm_mac_demodulate_run(const cm_mac_desc *d, const float *composite, float *rgb, int32_t n_calls, int32_t frame,
+                          int32_t first_line, int32_t k0, void *stream) {
+    int rc = mac_check(d, composite, rgb, n_calls);
+    if (rc) return rc;
+    if (n_calls < 0 || frame < 0 || k0 < 0) return fail(CM_ERR_INVALID, "negative count / frame / k0");
+    if (n_calls == 0) return CM_OK;
+    return mac_launch(d, true, composite, rgb, 1, n_calls, 1, first_line, frame, (hipStream_t)stream);
+}
 }
 
 #ifdef CM_DIAG

@@ -1,0 +1,272 @@
+// cm_mac_kernels.h - D2-MAC style time-multiplex modem (ref color_modem/color/mac.py) on gfx950.
+//
+// Unlike the QAM / SECAM paths this one has no recursive filter: a line is two half-band FIR passes (the 41-tap Kaiser
+// filter of scipy's resample_poly) and a fixed re-arrangement of samples, so nothing runs
+// sequentially along a row and the layout is the opposite of the IIR kernels': ONE WORKGROUP WALKS A SEGMENT OF
+// CONSECUTIVE ROWS OF ONE FIELD, its 256 threads spread along the row (every global access is a run of consecutive
+// floats), the half-rate chroma of the row staged in LDS between the two passes.  Bandwidth-bound: 4 * (3 * 720 + 1080)
+// = 12960 algorithmic bytes per row either way, about 25 FMAs per sample.
+//
+//   line (1080 samples, mac.py:56-69): [15..17] chroma ramp-in, [18..368] chroma[5..355], [369..371] cross-fade,
+//   [372..1070] luma[11..709], [1071..1073] luma ramp-out, 0.5 elsewhere;  chroma = dn2(dr or db) + 0.5 (360 samples)
+//
+// A "call" is one Modem.modulate() / demodulate() of the reference; calls of a field form a run (image.py:47-55, 75-83).
+//   decoder  (mac.py:84-125)  call k uses the line of call k and, for the other colour-difference signal, the
+//            interpolated chroma of call k - 1 (zeros on the first call of a run)
+//   encoder  plain: call k uses its own row;  inside ColorAveragingModem (comb.py:141-152, modulation_delay 1): luma of
+//            call k - 1, chroma = mean of calls k - 1 and k, colour-difference signal chosen for line - 2
+#ifndef CM_MAC_KERNELS_H
+#define CM_MAC_KERNELS_H
+
+#include <hip/hip_runtime.h>
+
+namespace cm {
+
+constexpr int kMacLuma = 720, kMacChroma = 360, kMacLine = 1080;
+constexpr int kMacThreads = 256;
+constexpr int kMacSegment = 8;        // rows of one field per workgroup
+
+struct MacArgs {
+    const float *in;
+    float *out;
+    int n_frames, H;            // frames mode: H rows per frame; rows mode: n_frames = 1, H = number of submitted rows
+    int rows_mode;              // 1: row i of the buffers is call k0 + i of one run (line first_line + 2 i)
+    int first_line;
+    long long first_frame;      // frame number of frame 0 (rows mode: the frame of the run)
+    int averaging;              // encoder inside ColorAveragingModem
+    int line_shift, even_first, odd_first;   // LineConfig (line.py:49-65)
+    float c0;                   // centre tap: 2 h[20] (decoder, up2) or h[20] (encoder, dn2)
+    float taps[20];             // odd taps 2 h[2 j + 1] resp. h[2 j + 1], j = 0 .. 19
+    float m[9];                 // decoder: (r, g, b) = m . (luma, dr, db);  encoder: (luma, dr, db) = m . (r, g, b)
+};
+
+// line.py:54-65: analog line parity against frame parity
+__device__ __forceinline__ bool mac_alternate(const MacArgs &a, long long frame, int line) {
+    const int adj = line + a.line_shift;
+    const int analog = ((adj & 1) ? a.odd_first : a.even_first) + (adj >> 1);
+    return (analog & 1) == (int)(frame & 1);
+}
+
+// Which rows of the buffers a workgroup walks: field `fld` of frame `f`, calls [k_begin, k_end) of that field's run.
+struct MacSegment {
+    int f, fld, k_begin, k_end, n_field;
+};
+__device__ __forceinline__ MacSegment mac_segment(const MacArgs &a) {
+    MacSegment s;
+    if (a.rows_mode) {
+        s.f = 0;
+        s.fld = 0;
+        s.n_field = a.H;
+        s.k_begin = (int)blockIdx.x * kMacSegment;
+    } else {
+        const int half = (a.H + 1) >> 1;
+        const int segs = (half + kMacSegment - 1) / kMacSegment;
+        const int b = (int)blockIdx.x;
+        const int seg = b % segs, ff = b / segs;
+        s.f = ff >> 1;
+        s.fld = ff & 1;
+        s.n_field = (a.H - s.fld + 1) >> 1;
+        s.k_begin = seg * kMacSegment;
+    }
+    s.k_end = s.k_begin + kMacSegment < s.n_field ? s.k_begin + kMacSegment : s.n_field;
+    return s;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// decoder: composite [F][H][1080] (rows mode [n][1080]) -> rgb [F][3][H][720] (rows mode [n][3][720])
+// ---------------------------------------------------------------------------------------------------------------------
+// chroma[i] of one line, mac.py:101-118 (sample 1 keeps 0.5: mac.py:113 assigns chroma[0:1]); p: the line, in LDS
+template <class P>
+__device__ __forceinline__ float mac_line_chroma(P p, int i) {
+    if (i >= 5 && i <= 355) return p[13 + i];
+    switch (i) {
+        case 0:
+        case 2: return 8.f * p[15] - 3.5f;
+        case 1: return 0.5f;
+        case 3: return 2.f * p[16] - 0.5f;
+        case 4: return (p[17] - 0.0625f) / 0.875f;
+        case 356: return (p[369] - 0.125f * p[372]) / 0.875f;
+        case 357: return 2.f * p[370] - p[372];
+        default: return 8.f * p[371] - 7.f * p[372];     // 358, 359
+    }
+}
+// luma[n] of one line, mac.py:96-111
+template <class P>
+__device__ __forceinline__ float mac_line_luma(P p, int n) {
+    if (n >= 11 && n <= 709) return p[361 + n];
+    if (n < 8) n = 8;
+    if (n > 712) n = 712;
+    switch (n) {
+        case 8: return 8.f * p[369] - 7.f * p[368];
+        case 9: return 2.f * p[370] - p[368];
+        case 10: return (p[371] - 0.125f * p[368]) / 0.875f;
+        case 710: return (p[1071] - 0.0625f) / 0.875f;
+        case 711: return 2.f * p[1072] - 0.5f;
+        default: return 8.f * p[1073] - 3.5f;            // 712
+    }
+}
+
+// Per row: the line arrives in LDS (16-byte loads, issued a row ahead and parked in registers), its chroma is laid out
+// with the zero extension of resample_poly, and every thread below 180 turns 21 chroma samples into four interpolated
+// ones (two of them 20-tap sums over the same window), adds the previous call's four from LDS and stores 3 x 16 bytes.
+__global__ __launch_bounds__(kMacThreads) void mac_demod_kernel(const MacArgs a) {
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    __shared__ __attribute__((aligned(16))) float lin[kMacLine];          // the line in work
+    __shared__ __attribute__((aligned(16))) float ch[kMacChroma + 24];    // its chroma, 10 zeros before, 14 behind
+    __shared__ __attribute__((aligned(16))) float up[2][kMacLuma];        // resample_poly(chroma, 2, 1) - 0.5 of this call and the one before
+    const MacSegment s = mac_segment(a);
+    if (s.k_begin >= s.k_end) return;
+    const int t = threadIdx.x;
+    const long long frame = a.first_frame + s.f;
+    auto row_of = [&](int k) -> int { return a.rows_mode ? k : s.fld + 2 * k; };
+    auto in_row = [&](int k) -> const f4 * { return (const f4 *)(a.in + ((long long)s.f * a.H + row_of(k)) * kMacLine); };
+    constexpr int kQuads = kMacLine / 4;   // 270 16-byte pieces per line: thread t takes t and t + 256
+    auto fetch = [&](int k, f4 &r0, f4 &r1) {
+        const f4 *p = in_row(k);
+        r0 = p[t];
+        if (t + kMacThreads < kQuads) r1 = p[t + kMacThreads];
+    };
+    auto park = [&](const f4 &r0, const f4 &r1) {
+        ((f4 *)lin)[t] = r0;
+        if (t + kMacThreads < kQuads) ((f4 *)lin)[t + kMacThreads] = r1;
+    };
+    // the first call of a run has no previous chroma (zeros); a segment that starts inside a run walks the row before it
+    // without writing anything
+    const int k_first = s.k_begin > 0 ? s.k_begin - 1 : s.k_begin;
+    f4 r0 = {0.f, 0.f, 0.f, 0.f}, r1 = r0;
+    fetch(k_first, r0, r1);
+    int cur = 0;
+    bool have_prev = false;
+    for (int k = k_first; k < s.k_end; ++k) {
+        park(r0, r1);
+        if (k + 1 < s.k_end) fetch(k + 1, r0, r1);      // the next line travels while this one is worked on
+        __syncthreads();
+        for (int i = t; i < kMacChroma + 24; i += kMacThreads)
+            ch[i] = (i < 10 || i >= kMacChroma + 10) ? 0.f : mac_line_chroma(lin, i - 10);
+        __syncthreads();
+        if (t < kMacLuma / 4) {
+            // outputs n = 4 t .. 4 t + 3 = samples 2 i, 2 i + 1, 2 i + 2, 2 i + 3 of up2(chroma), i = 2 t:
+            //   y[2 i] = 2 h[20] c[i];  y[2 i + 1] = sum_j 2 h[2 j + 1] c[i + 10 - j]   (c = ch[. + 10])
+            const int i = 2 * t;
+            float w[24];
+#pragma unroll
+            for (int q = 0; q < 12; ++q) {
+                typedef float f2 __attribute__((ext_vector_type(2)));
+                const f2 v = *(const f2 *)(ch + i + 2 * q);       // ch[i .. i + 23] = c[i - 10 .. i + 13]; i is even: 8-byte pieces
+                w[2 * q] = v.x; w[2 * q + 1] = v.y;
+            }
+            float o1 = 0.f, o3 = 0.f;
+#pragma unroll
+            for (int j = 0; j < 20; ++j) {
+                o1 = __builtin_fmaf(a.taps[j], w[20 - j], o1);     // c[i + 10 - j] = ch[i + 20 - j]
+                o3 = __builtin_fmaf(a.taps[j], w[21 - j], o3);     // c[i + 11 - j]
+            }
+            const f4 own = {a.c0 * w[10] - 0.5f, o1 - 0.5f, a.c0 * w[11] - 0.5f, o3 - 0.5f};
+            f4 other = {0.f, 0.f, 0.f, 0.f};
+            if (have_prev) other = *(const f4 *)(up[cur ^ 1] + 4 * t);
+            *(f4 *)(up[cur] + 4 * t) = own;
+            if (k >= s.k_begin) {
+                const int line = a.rows_mode ? a.first_line + 2 * k : row_of(k);
+                const bool alt = mac_alternate(a, frame, line);
+                const f4 dr = alt ? other : own, db = alt ? own : other;   // mac.py:115-120
+                f4 luma;
+                luma.x = mac_line_luma(lin, 4 * t);
+                luma.y = mac_line_luma(lin, 4 * t + 1);
+                luma.z = mac_line_luma(lin, 4 * t + 2);
+                luma.w = mac_line_luma(lin, 4 * t + 3);
+                float *o = a.rows_mode ? a.out + (long long)k * 3 * kMacLuma
+                                       : a.out + (((long long)s.f * 3) * a.H + row_of(k)) * kMacLuma;
+                const long long plane = a.rows_mode ? kMacLuma : (long long)a.H * kMacLuma;
+                *(f4 *)(o + 4 * t) = a.m[0] * luma + a.m[1] * dr + a.m[2] * db;
+                *(f4 *)(o + plane + 4 * t) = a.m[3] * luma + a.m[4] * dr + a.m[5] * db;
+                *(f4 *)(o + 2 * plane + 4 * t) = a.m[6] * luma + a.m[7] * dr + a.m[8] * db;
+            }
+        }
+        have_prev = true;
+        cur ^= 1;
+        __syncthreads();      // lin / ch are free for the next line
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// encoder: rgb [F][3][H][720] (rows mode [n][3][720]) -> composite [F][H][1080] (rows mode [n][1080])
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kMacThreads) void mac_mod_kernel(const MacArgs a) {
+    __shared__ float cf[kMacLuma + 40];        // full-rate colour-difference signal of the call, 20 zeros on either side
+    __shared__ float lum[kMacLuma];
+    const MacSegment s = mac_segment(a);
+    if (s.k_begin >= s.k_end) return;
+    const int t = threadIdx.x;
+    const long long frame = a.first_frame + s.f;
+    const long long plane = a.rows_mode ? kMacLuma : (long long)a.H * kMacLuma;
+    auto in_row = [&](int row) -> const float * {
+        return a.rows_mode ? a.in + (long long)row * 3 * kMacLuma : a.in + (((long long)s.f * 3) * a.H + row) * kMacLuma;
+    };
+    for (int k = s.k_begin; k < s.k_end; ++k) {
+        // rows of the two calls that meet in this output row, and the line the backend sees (comb.py:152: line - 2)
+        int row_a, row_b, line, out_row;
+        if (a.rows_mode) {
+            out_row = k;
+            row_b = k;
+            row_a = a.averaging && k > 0 ? k - 1 : k;
+            line = a.first_line + 2 * k - (a.averaging ? 2 : 0);
+        } else {
+            out_row = s.fld + 2 * k;
+            row_a = out_row;
+            row_b = out_row;
+            if (a.averaging) {     // image.py:50-53 with modulation_delay 1: this call's input is row y + 2, stepped back into the image
+                row_b = out_row + 2;
+                while (row_b >= a.H) row_b -= 2;
+            }
+            line = out_row;
+        }
+        const bool alt = mac_alternate(a, frame, line);
+        const float *pa = in_row(row_a), *pb = in_row(row_b);
+        const float e0 = a.m[0], e1 = a.m[1], e2 = a.m[2];
+        const float s0 = alt ? a.m[6] : a.m[3], s1 = alt ? a.m[7] : a.m[4], s2 = alt ? a.m[8] : a.m[5];   // mac.py:44-47
+        __syncthreads();      // the previous row's readers of cf / lum are done
+        for (int n = t; n < kMacLuma + 40; n += kMacThreads) {
+            const int i = n - 20;
+            float c = 0.f;
+            if (i >= 0 && i < kMacLuma) {
+                const float ra = pa[i], ga = pa[plane + i], ba = pa[2 * plane + i];
+                lum[i] = __builtin_fmaf(e0, ra, __builtin_fmaf(e1, ga, e2 * ba));           // luma of call k - 1
+                const float ca = __builtin_fmaf(s0, ra, __builtin_fmaf(s1, ga, s2 * ba));
+                if (row_b != row_a) {
+                    const float cb = __builtin_fmaf(s0, pb[i], __builtin_fmaf(s1, pb[plane + i], s2 * pb[2 * plane + i]));
+                    c = 0.5f * (cb + ca);                                                   // comb.py:147-148
+                } else {
+                    c = ca;
+                }
+            }
+            cf[n] = c;
+        }
+        __syncthreads();
+        // chroma[i] = resample_poly(c, 1, 2)[i] + 0.5 = h[20] c[2 i] + sum_j h[2 j + 1] c[2 i + 19 - 2 j] + 0.5
+        auto chroma = [&](int i) -> float {
+            float v = a.c0 * cf[20 + 2 * i];
+#pragma unroll
+            for (int j = 0; j < 20; ++j) v = __builtin_fmaf(a.taps[j], cf[39 + 2 * i - 2 * j], v);
+            return v + 0.5f;
+        };
+        float *o = a.out + ((long long)s.f * a.H + out_row) * kMacLine;
+        for (int n = t; n < kMacLine; n += kMacThreads) {
+            float v = 0.5f;
+            if (n >= 18 && n <= 368) v = chroma(n - 13);
+            else if (n >= 372 && n <= 1070) v = lum[n - 361];
+            else if (n == 15) v = 0.4375f + 0.125f * chroma(2);
+            else if (n == 16) v = 0.25f + 0.5f * chroma(3);
+            else if (n == 17) v = 0.0625f + 0.875f * chroma(4);
+            else if (n == 369) v = 0.875f * chroma(356) + 0.125f * lum[8];
+            else if (n == 370) v = 0.5f * chroma(357) + 0.5f * lum[9];
+            else if (n == 371) v = 0.125f * chroma(358) + 0.875f * lum[10];
+            else if (n == 1071) v = 0.0625f + 0.875f * lum[710];
+            else if (n == 1072) v = 0.25f + 0.5f * lum[711];
+            else if (n == 1073) v = 0.4375f + 0.125f * lum[712];
+            o[n] = v;
+        }
+    }
+}
+
+}  // namespace cm
+#endif

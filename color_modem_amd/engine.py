@@ -19,11 +19,19 @@ def _torch():
     return torch
 
 
+def make_engine(modem, components=False, strip_chroma=True):
+    """The engine of a modem stack: a cm_plan for the QAM / SECAM families, the plan-less MAC entry points for MacModem."""
+    if modem._stack()['kind'] == 'mac':
+        return MacEngine(modem, components)
+    return Engine(modem, components, strip_chroma)
+
+
 class Engine(object):
     def __init__(self, modem, components=False, strip_chroma=True):
         self.built = plan.build_plan(modem, components, strip_chroma)
         d = self.built.desc
         self.width, self.height = d.width, d.height
+        self.comp_width = d.width
         self.demod_depth = d.depth
         self.mod_depth = 1 if d.modulation_delay else 0
         self.demodulation_delay = d.demodulation_delay
@@ -133,4 +141,100 @@ class Engine(object):
         stream = torch.cuda.current_stream(x.device).cuda_stream
         _native.check(_native.lib().cm_modulate_run(self._plan, x.data_ptr(), out.data_ptr(), n, int(frame),
                                                     int(first_line), int(k0), stream))
+        return out.cpu().numpy()
+
+
+class MacEngine(object):
+    """MacModem / ColorAveragingModem(MacModem) on the cm_mac_* entry points (rows of 720 samples <-> lines of 1080)."""
+
+    def __init__(self, modem, components=False):
+        from color_modem_amd.color import mac
+        stack = modem._stack()
+        backend = stack['backend']
+        lc = backend.line_config
+        std = lc.line_standard
+        d = _native.MacDesc()
+        d.height = int(lc.size[1])
+        d.line_shift = int(lc._line_shift)
+        d.even_first = int(std.even_field_first_active_line)
+        d.odd_first = int(std.odd_field_first_active_line)
+        d.averaging = 1 if stack.get('mod_wrapper') == 'color_averaging' else 0
+        d.resample_fir[:] = list(plan.resample_fir())
+        eye = numpy.eye(3)
+        d.decode_matrix[:] = list(numpy.asarray(eye if components else mac.DECODE).reshape(-1))
+        d.encode_matrix[:] = list(numpy.asarray(eye if components else mac.ENCODE).reshape(-1))
+        self.desc = d
+        self.width, self.comp_width, self.height = mac.LUMA_WIDTH, mac.LINE_WIDTH, d.height
+        self.demod_depth = 1                     # the other colour-difference signal is the previous call's
+        self.mod_depth = d.averaging
+        self.demodulation_delay = 0
+        self.modulation_delay = d.averaging
+        _torch()
+        _native.lib()
+
+    def describe(self):
+        return 'mac_demod_kernel / mac_mod_kernel: one workgroup of 256 threads per 8 rows of a field, threads along the row'
+
+    def _as_device(self, x, shape_tail):
+        torch = _torch()
+        was_numpy = isinstance(x, numpy.ndarray)
+        t = torch.from_numpy(numpy.ascontiguousarray(x, dtype=numpy.float32)) if was_numpy else x
+        if t.dtype != torch.float32:
+            raise ValueError('float32 expected')
+        if tuple(t.shape[1:]) != tuple(shape_tail):
+            raise ValueError('expected shape [frames, %s], got %s' % (', '.join(map(str, shape_tail)), tuple(t.shape)))
+        if not t.is_cuda:
+            t = t.cuda()
+        return t.contiguous(), was_numpy
+
+    def demodulate_frames(self, composite, first_frame=0, out=None):
+        """composite [F, H, 1080] float32 -> rgb [F, 3, H, 720] (numpy in -> numpy out, cuda tensor in -> cuda tensor out)."""
+        torch = _torch()
+        comp, was_numpy = self._as_device(composite, (self.height, self.comp_width))
+        n = comp.shape[0]
+        if out is None:
+            out = torch.empty((n, 3, self.height, self.width), dtype=torch.float32, device=comp.device)
+        stream = torch.cuda.current_stream(comp.device).cuda_stream
+        _native.check(_native.lib().cm_mac_demodulate_frames(ctypes.byref(self.desc), comp.data_ptr(), out.data_ptr(), n,
+                                                             int(first_frame), stream))
+        return out.cpu().numpy() if was_numpy else out
+
+    def modulate_frames(self, rgb, first_frame=0, out=None):
+        """rgb [F, 3, H, 720] float32 -> composite [F, H, 1080]."""
+        torch = _torch()
+        x, was_numpy = self._as_device(rgb, (3, self.height, self.width))
+        n = x.shape[0]
+        if self.height < 2 * self.modulation_delay and n:
+            raise IndexError('image.py:49-50 feeds row 1 ahead of a field under modulation_delay 1: the image has %d row(s)' % self.height)
+        if out is None:
+            out = torch.empty((n, self.height, self.comp_width), dtype=torch.float32, device=x.device)
+        stream = torch.cuda.current_stream(x.device).cuda_stream
+        _native.check(_native.lib().cm_mac_modulate_frames(ctypes.byref(self.desc), x.data_ptr(), out.data_ptr(), n,
+                                                           int(first_frame), stream))
+        return out.cpu().numpy() if was_numpy else out
+
+    def demodulate_frames_u8(self, composite8, first_frame=0, out=None):
+        raise NotImplementedError('the MAC kernels have no fused byte boundary (ImageModem converts on the host)')
+
+    def modulate_frames_u8(self, rgb8, first_frame=0, out=None):
+        raise NotImplementedError('the MAC kernels have no fused byte boundary (ImageModem converts on the host)')
+
+    def demodulate_run(self, rows, frame, first_line, k0):
+        torch = _torch()
+        x = torch.from_numpy(numpy.ascontiguousarray(rows, dtype=numpy.float32)).cuda()
+        n = x.shape[0]
+        out = torch.empty((n, 3, self.width), dtype=torch.float32, device=x.device)
+        stream = torch.cuda.current_stream(x.device).cuda_stream
+        _native.check(_native.lib().cm_mac_demodulate_run(ctypes.byref(self.desc), x.data_ptr(), out.data_ptr(), n,
+                                                          int(frame), int(first_line), int(k0), stream))
+        return out.cpu().numpy()
+
+    def modulate_run(self, rows, frame, first_line, k0):
+        torch = _torch()
+        x = torch.from_numpy(numpy.ascontiguousarray(rows, dtype=numpy.float32)).cuda()
+        n = x.shape[0]
+        out = torch.empty((n, self.comp_width), dtype=torch.float32, device=x.device)
+        stream = torch.cuda.current_stream(x.device).cuda_stream
+        _native.check(_native.lib().cm_mac_modulate_run(ctypes.byref(self.desc), x.data_ptr(), out.data_ptr(), n,
+                                                        int(frame), int(first_line), int(k0), stream))
         return out.cpu().numpy()

@@ -25,7 +25,7 @@ class ImageModem(object):
 
     def _engine(self):
         if self._engine_obj is None:
-            self._engine_obj = _engine.Engine(self._modem)
+            self._engine_obj = _engine.make_engine(self._modem)
         return self._engine_obj
 
     @staticmethod

@@ -34,7 +34,7 @@ class RowApi(object):
         key = (bool(components), bool(strip_chroma))
         if key not in self._engines:
             from color_modem_amd import engine
-            self._engines[key] = engine.Engine(self, components=key[0], strip_chroma=key[1])
+            self._engines[key] = engine.make_engine(self, components=key[0], strip_chroma=key[1])
         return self._engines[key]
 
     @staticmethod
@@ -68,8 +68,8 @@ class RowApi(object):
 
     def _demodulate(self, eng, frame, line, composite):
         row = numpy.ascontiguousarray(composite, dtype=numpy.float32)
-        if row.ndim != 1 or row.shape[0] != eng.width:
-            raise ValueError('composite must be one row of %d samples' % eng.width)
+        if row.ndim != 1 or row.shape[0] != eng.comp_width:
+            raise ValueError('composite must be one row of %d samples' % eng.comp_width)
         run = self._demod_run
         self._advance(run, frame, line, row, eng.demod_depth)
         n = len(run.rows)

@@ -196,6 +196,40 @@ int cm_demodulate_run(const cm_plan *plan, const float *composite, float *rgb, i
 int cm_modulate_run(const cm_plan *plan, const float *rgb, float *composite, int32_t n_calls, int32_t frame,
                     int32_t first_line, int32_t k0, void *stream);
 
+/* ---- D2-MAC style time-multiplex modem (ref color_modem/color/mac.py:16-125) --------------------
+ * MacModem(line_config, MacVariant.D2MAC_12MHZ) for 720-sample rows: no resampling of luma (mac.py:49-52 with
+ * len(luma) == 720), chroma 720 -> 360 by resample_poly(., 1, 2) (mac.py:53-55), the 1080-sample line of mac.py:57-69
+ * left at its own rate (mac.py:71-74 with width 1080), and the inverse (mac.py:84-125).  `averaging` = the encoder sits
+ * inside ColorAveragingModem (comb.py:130-152: modulation_delay 1).  The path has no design step and no tables, so there
+ * is no plan object: the descriptor is plain data, passed by value on every call. */
+#define CM_MAC_LUMA_WIDTH 720
+#define CM_MAC_LINE_WIDTH 1080
+typedef struct cm_mac_desc {
+    int32_t height;               /* rows per frame */
+    int32_t line_shift;           /* LineConfig._line_shift (line.py:53) */
+    int32_t even_first, odd_first;/* LineStandard.even_field_first_active_line / odd_... (line.py:56-60) */
+    int32_t averaging;            /* 1: ColorAveragingModem(MacModem) on the encoder side */
+    int32_t reserved;
+    double resample_fir[41];      /* firwin(41, 0.5, ('kaiser', 5.0)), as in cm_plan_desc */
+    double decode_matrix[9];      /* (r, g, b) = M . (luma, dr, db), mac.py:38-41 (identity: the *_components protocol) */
+    double encode_matrix[9];      /* (luma, dr, db) = M . (r, g, b), mac.py:29-32 */
+} cm_mac_desc;
+
+/* rgb [n_frames][3][height][720] -> composite [n_frames][height][1080]; equals ImageModem.modulate's row schedule
+ * (image.py:47-55) over frames first_frame .. with a fresh modem per frame. */
+int cm_mac_modulate_frames(const cm_mac_desc *desc, const float *rgb, float *composite, int64_t n_frames,
+                           int64_t first_frame, void *stream);
+/* composite [n_frames][height][1080] -> rgb [n_frames][3][height][720] (image.py:75-83). */
+int cm_mac_demodulate_frames(const cm_mac_desc *desc, const float *composite, float *rgb, int64_t n_frames,
+                             int64_t first_frame, void *stream);
+/* One run of n_calls consecutive calls (lines first_line, first_line + 2, ...), the first being the k0-th call since
+ * the modem's reset; rows [n_calls][3][720] / [n_calls][1080].  Row 0 has no history inside the buffers: with k0 > 0 its
+ * output is unspecified (the caller submits one row of history, as for cm_demodulate_run). */
+int cm_mac_modulate_run(const cm_mac_desc *desc, const float *rgb, float *composite, int32_t n_calls, int32_t frame,
+                        int32_t first_line, int32_t k0, void *stream);
+int cm_mac_demodulate_run(const cm_mac_desc *desc, const float *composite, float *rgb, int32_t n_calls, int32_t frame,
+                          int32_t first_line, int32_t k0, void *stream);
+
 /* Name, main-loop instruction mix and launch geometry of the dominant kernel of the last
  * cm_demodulate_frames call on this plan (for bench.py / profiling); returns bytes written. */
 int cm_plan_describe(const cm_plan *plan, char *buf, int32_t buf_len);
