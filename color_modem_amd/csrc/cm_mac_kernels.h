@@ -191,9 +191,16 @@ __global__ __launch_bounds__(kMacThreads) void mac_demod_kernel(const MacArgs a)
 // ---------------------------------------------------------------------------------------------------------------------
 // encoder: rgb [F][3][H][720] (rows mode [n][3][720]) -> composite [F][H][1080] (rows mode [n][1080])
 // ---------------------------------------------------------------------------------------------------------------------
+// Per output row: the new input row of the call arrives as 3 x 16 bytes per thread (issued a row ahead, parked in
+// registers), is turned into (luma, dr, db) on its way into LDS, where the previous call's components still sit; the
+// colour-difference signal of the line (mean of the two calls inside ColorAveragingModem) is laid out with the zero
+// extension of resample_poly, and every thread below 270 forms four samples of the line and stores 16 bytes.
 __global__ __launch_bounds__(kMacThreads) void mac_mod_kernel(const MacArgs a) {
-    __shared__ float cf[kMacLuma + 40];        // full-rate colour-difference signal of the call, 20 zeros on either side
-    __shared__ float lum[kMacLuma];
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    __shared__ __attribute__((aligned(16))) float comp[2][3][kMacLuma];   // (luma, dr, db) of this call's row and the previous one's
+    // colour-difference signal c of the line by parity: ce[i] = c[2 i]; co[m + 10] = c[2 m + 1], 10 zeros on either side
+    // (the zero extension of resample_poly); c3 = the 360 chroma samples of the line
+    __shared__ float ce[kMacChroma], co[kMacChroma + 20], c3[kMacChroma];
     const MacSegment s = mac_segment(a);
     if (s.k_begin >= s.k_end) return;
     const int t = threadIdx.x;
@@ -202,69 +209,102 @@ __global__ __launch_bounds__(kMacThreads) void mac_mod_kernel(const MacArgs a) {
     auto in_row = [&](int row) -> const float * {
         return a.rows_mode ? a.in + (long long)row * 3 * kMacLuma : a.in + (((long long)s.f * 3) * a.H + row) * kMacLuma;
     };
-    for (int k = s.k_begin; k < s.k_end; ++k) {
-        // rows of the two calls that meet in this output row, and the line the backend sees (comb.py:152: line - 2)
-        int row_a, row_b, line, out_row;
+    // rows of the two calls that meet in output row k (comb.py:141-152, image.py:47-55): a = the previous call's input
+    // (luma, half of the chroma), b = this call's
+    auto rows_of = [&](int k, int &row_a, int &row_b) {
         if (a.rows_mode) {
-            out_row = k;
             row_b = k;
             row_a = a.averaging && k > 0 ? k - 1 : k;
-            line = a.first_line + 2 * k - (a.averaging ? 2 : 0);
         } else {
-            out_row = s.fld + 2 * k;
-            row_a = out_row;
-            row_b = out_row;
-            if (a.averaging) {     // image.py:50-53 with modulation_delay 1: this call's input is row y + 2, stepped back into the image
-                row_b = out_row + 2;
+            row_a = row_b = s.fld + 2 * k;
+            if (a.averaging) {     // modulation_delay 1: this call's input is row y + 2, stepped back into the image
+                row_b += 2;
                 while (row_b >= a.H) row_b -= 2;
             }
-            line = out_row;
         }
-        const bool alt = mac_alternate(a, frame, line);
-        const float *pa = in_row(row_a), *pb = in_row(row_b);
-        const float e0 = a.m[0], e1 = a.m[1], e2 = a.m[2];
-        const float s0 = alt ? a.m[6] : a.m[3], s1 = alt ? a.m[7] : a.m[4], s2 = alt ? a.m[8] : a.m[5];   // mac.py:44-47
-        __syncthreads();      // the previous row's readers of cf / lum are done
-        for (int n = t; n < kMacLuma + 40; n += kMacThreads) {
-            const int i = n - 20;
-            float c = 0.f;
-            if (i >= 0 && i < kMacLuma) {
-                const float ra = pa[i], ga = pa[plane + i], ba = pa[2 * plane + i];
-                lum[i] = __builtin_fmaf(e0, ra, __builtin_fmaf(e1, ga, e2 * ba));           // luma of call k - 1
-                const float ca = __builtin_fmaf(s0, ra, __builtin_fmaf(s1, ga, s2 * ba));
-                if (row_b != row_a) {
-                    const float cb = __builtin_fmaf(s0, pb[i], __builtin_fmaf(s1, pb[plane + i], s2 * pb[2 * plane + i]));
-                    c = 0.5f * (cb + ca);                                                   // comb.py:147-148
-                } else {
-                    c = ca;
-                }
-            }
-            cf[n] = c;
+    };
+    constexpr int kQuads = kMacLuma / 4;   // 180 16-byte pieces per plane
+    auto fetch = [&](int row, f4 &r, f4 &g, f4 &b) {
+        if (t < kQuads) {
+            const float *p = in_row(row) + 4 * t;
+            r = *(const f4 *)p;
+            g = *(const f4 *)(p + plane);
+            b = *(const f4 *)(p + 2 * plane);
+        }
+    };
+    auto park = [&](int slot, const f4 &r, const f4 &g, const f4 &b) {
+        if (t < kQuads) {
+            *(f4 *)(comp[slot][0] + 4 * t) = a.m[0] * r + a.m[1] * g + a.m[2] * b;
+            *(f4 *)(comp[slot][1] + 4 * t) = a.m[3] * r + a.m[4] * g + a.m[5] * b;
+            *(f4 *)(comp[slot][2] + 4 * t) = a.m[6] * r + a.m[7] * g + a.m[8] * b;
+        }
+    };
+    f4 r = {0.f, 0.f, 0.f, 0.f}, g = r, b = r;
+    int row_a, row_b;
+    rows_of(s.k_begin, row_a, row_b);
+    int cur = 0;
+    if (row_a != row_b) {      // a segment inside a run: the previous call's row comes first
+        fetch(row_a, r, g, b);
+        park(1, r, g, b);
+    }
+    fetch(row_b, r, g, b);
+    for (int k = s.k_begin; k < s.k_end; ++k) {
+        rows_of(k, row_a, row_b);
+        park(cur, r, g, b);
+        if (k + 1 < s.k_end) {
+            int na, nb;
+            rows_of(k + 1, na, nb);
+            fetch(nb, r, g, b);       // the next call's row travels while this line is formed
+        }
+        const int sa = row_a != row_b ? cur ^ 1 : cur;
+        const int line = a.rows_mode ? a.first_line + 2 * k - (a.averaging ? 2 : 0) : s.fld + 2 * k;   // comb.py:152: line - 2
+        const int sel = mac_alternate(a, frame, line) ? 2 : 1;     // mac.py:44-47
+        __syncthreads();
+        for (int i = t; i < kMacLuma; i += kMacThreads) {
+            const float c = sa != cur ? 0.5f * (comp[cur][sel][i] + comp[sa][sel][i]) : comp[cur][sel][i];   // comb.py:147-148
+            if (i & 1) co[(i >> 1) + 10] = c; else ce[i >> 1] = c;
+        }
+        if (t < 10) co[t] = co[kMacChroma + 10 + t] = 0.f;
+        __syncthreads();
+        // chroma[i] = resample_poly(c, 1, 2)[i] + 0.5 = h[20] c[2 i] + sum_j h[2 j + 1] c[2 (i + 9 - j) + 1] + 0.5
+        for (int i = t; i < kMacChroma; i += kMacThreads) {
+            float v = a.c0 * ce[i];
+#pragma unroll
+            for (int j = 0; j < 20; ++j) v = __builtin_fmaf(a.taps[j], co[i + 19 - j], v);
+            c3[i] = v + 0.5f;
         }
         __syncthreads();
-        // chroma[i] = resample_poly(c, 1, 2)[i] + 0.5 = h[20] c[2 i] + sum_j h[2 j + 1] c[2 i + 19 - 2 j] + 0.5
-        auto chroma = [&](int i) -> float {
-            float v = a.c0 * cf[20 + 2 * i];
-#pragma unroll
-            for (int j = 0; j < 20; ++j) v = __builtin_fmaf(a.taps[j], cf[39 + 2 * i - 2 * j], v);
-            return v + 0.5f;
+        const float *lum = comp[sa][0];
+        auto chroma = [&](int i) -> float { return c3[i]; };
+        auto sample = [&](int n) -> float {      // mac.py:56-69
+            if (n >= 18 && n <= 368) return chroma(n - 13);
+            if (n >= 372 && n <= 1070) return lum[n - 361];
+            switch (n) {
+                case 15: return 0.4375f + 0.125f * chroma(2);
+                case 16: return 0.25f + 0.5f * chroma(3);
+                case 17: return 0.0625f + 0.875f * chroma(4);
+                case 369: return 0.875f * chroma(356) + 0.125f * lum[8];
+                case 370: return 0.5f * chroma(357) + 0.5f * lum[9];
+                case 371: return 0.125f * chroma(358) + 0.875f * lum[10];
+                case 1071: return 0.0625f + 0.875f * lum[710];
+                case 1072: return 0.25f + 0.5f * lum[711];
+                case 1073: return 0.4375f + 0.125f * lum[712];
+                default: return 0.5f;
+            }
         };
+        const int out_row = a.rows_mode ? k : s.fld + 2 * k;
         float *o = a.out + ((long long)s.f * a.H + out_row) * kMacLine;
-        for (int n = t; n < kMacLine; n += kMacThreads) {
-            float v = 0.5f;
-            if (n >= 18 && n <= 368) v = chroma(n - 13);
-            else if (n >= 372 && n <= 1070) v = lum[n - 361];
-            else if (n == 15) v = 0.4375f + 0.125f * chroma(2);
-            else if (n == 16) v = 0.25f + 0.5f * chroma(3);
-            else if (n == 17) v = 0.0625f + 0.875f * chroma(4);
-            else if (n == 369) v = 0.875f * chroma(356) + 0.125f * lum[8];
-            else if (n == 370) v = 0.5f * chroma(357) + 0.5f * lum[9];
-            else if (n == 371) v = 0.125f * chroma(358) + 0.875f * lum[10];
-            else if (n == 1071) v = 0.0625f + 0.875f * lum[710];
-            else if (n == 1072) v = 0.25f + 0.5f * lum[711];
-            else if (n == 1073) v = 0.4375f + 0.125f * lum[712];
-            o[n] = v;
+        for (int q = t; q < kMacLine / 4; q += kMacThreads) {
+            f4 v;
+            v.x = sample(4 * q);
+            v.y = sample(4 * q + 1);
+            v.z = sample(4 * q + 2);
+            v.w = sample(4 * q + 3);
+            *(f4 *)(o + 4 * q) = v;
         }
+        cur ^= 1;
+        // the next park() overwrites the older slot; ce / co / c3 are rewritten behind the next barriers
+        __syncthreads();
     }
 }
 
