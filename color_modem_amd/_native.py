@@ -20,17 +20,26 @@ SYMBOLS = ('cm_last_error', 'cm_abi_version', 'cm_device_count', 'cm_plan_create
            'cm_demodulate_frames', 'cm_modulate_frames', 'cm_demodulate_frames_u8', 'cm_modulate_frames_u8', 'cm_demodulate_run',
            'cm_modulate_run',
            'cm_plan_describe',
+           'cm_mac_plan_create', 'cm_mac_plan_destroy',
            'cm_mac_modulate_frames', 'cm_mac_demodulate_frames', 'cm_mac_modulate_run', 'cm_mac_demodulate_run')
 
 _lib = None
 
 
+class MacFir(ctypes.Structure):
+    """cm_mac_fir (include/color_modem_hip.h)"""
+    _fields_ = [('up', ctypes.c_int32), ('down', ctypes.c_int32), ('n_taps', ctypes.c_int32), ('reserved', ctypes.c_int32),
+                ('taps', ctypes.POINTER(ctypes.c_double))]
+
+
 class MacDesc(ctypes.Structure):
     """cm_mac_desc (include/color_modem_hip.h)"""
-    _fields_ = [('height', ctypes.c_int32), ('line_shift', ctypes.c_int32), ('even_first', ctypes.c_int32),
-                ('odd_first', ctypes.c_int32), ('averaging', ctypes.c_int32), ('reserved', ctypes.c_int32),
+    _fields_ = [('width', ctypes.c_int32), ('height', ctypes.c_int32), ('line_width', ctypes.c_int32),
+                ('line_shift', ctypes.c_int32), ('even_first', ctypes.c_int32), ('odd_first', ctypes.c_int32),
+                ('averaging', ctypes.c_int32), ('reserved', ctypes.c_int32),
                 ('resample_fir', ctypes.c_double * 41), ('decode_matrix', ctypes.c_double * 9),
-                ('encode_matrix', ctypes.c_double * 9)]
+                ('encode_matrix', ctypes.c_double * 9),
+                ('luma_in', MacFir), ('chroma_in', MacFir), ('line_out', MacFir), ('line_in', MacFir)]
 
 
 class NativeError(RuntimeError):
@@ -63,7 +72,10 @@ def lib():
     L.cm_demodulate_run.argtypes = [vp, vp, vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, vp]
     L.cm_modulate_run.argtypes = [vp, vp, vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, vp]
     L.cm_plan_describe.argtypes = [vp, ctypes.c_char_p, ctypes.c_int32]
-    md = ctypes.POINTER(MacDesc)
+    L.cm_mac_plan_create.argtypes = [ctypes.POINTER(MacDesc), ctypes.POINTER(vp)]
+    L.cm_mac_plan_destroy.argtypes = [vp]
+    L.cm_mac_plan_destroy.restype = None
+    md = vp
     L.cm_mac_modulate_frames.argtypes = [md, vp, vp, ctypes.c_int64, ctypes.c_int64, vp]
     L.cm_mac_demodulate_frames.argtypes = [md, vp, vp, ctypes.c_int64, ctypes.c_int64, vp]
     L.cm_mac_modulate_run.argtypes = [md, vp, vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, vp]

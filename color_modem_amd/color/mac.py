@@ -5,9 +5,9 @@ Host side: the variant presets and the colour matrices.  The per-line work - chr
 scipy's resampling FIR and the sample re-arrangement of mac.py:56-69, 93-113 - runs in the HIP kernels ``mac_mod_kernel``
 / ``mac_demod_kernel`` (csrc/cm_mac_kernels.h) behind ``cm_mac_*`` (include/color_modem_hip.h).
 
-Built: 720-sample rows and the 1080-sample line (``MacVariant.D2MAC_12MHZ``, the default), i.e. the cases in which
-mac.py:49-52 and 71-74 do not resample; other image widths / ``D2MAC_7MHZ`` need rational resamplers that are not
-built and raise NotImplementedError.
+720-sample rows <-> the 1080-sample line (``MacVariant.D2MAC_12MHZ``, the default) run on the tuned kernels; every
+other row / line length (``D2MAC_7MHZ``, other image widths: the rational resamplers of mac.py:49-55, 71-74, 88-91) on
+the resampling kernels.  The decoder always returns rows of 720 samples, like the reference.
 """
 
 import collections
@@ -41,12 +41,8 @@ class MacModem(RowApi):
             self._width = int(variant_or_width.width)
         except AttributeError:
             self._width = int(variant_or_width)
-        if self._width != LINE_WIDTH:
-            raise NotImplementedError('MacModem: only the 1080-sample line (MacVariant.D2MAC_12MHZ) is built; resampling '
-                                      'it to %d samples (mac.py:71-74) is not' % self._width)
-        if line_config.size[0] != LUMA_WIDTH:
-            raise NotImplementedError('MacModem: rows of 720 samples only (mac.py:49-55 resamples other widths to 720 / '
-                                      '360; those resamplers are not built), got %d' % line_config.size[0])
+        if self._width < 1 or self._width > 4096 or line_config.size[0] > 1920:
+            raise NotImplementedError('MacModem: lines of 1 .. 4096 samples and rows of up to 1920 samples are built')
 
     @staticmethod
     def encode_components(r, g, b):

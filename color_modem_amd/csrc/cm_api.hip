@@ -953,10 +953,28 @@ int cm_modulate_run(const cm_plan *p, const float *rgb, float *composite, int32_
 }
 
 // ---- D2-MAC style time-multiplex modem (cm_mac_kernels.h) -------------------------------------------------------------
+struct cm_mac_plan {
+    cm_mac_desc desc;
+    float *fir[4] = {nullptr, nullptr, nullptr, nullptr};   // device copies of luma_in, chroma_in, line_out, line_in
+    bool tuned = false;                                      // 720-sample rows <-> 1080-sample lines
+};
+
 namespace {
-int mac_launch(const cm_mac_desc *d, bool demod, const float *in, float *out, int n_frames, int height, int rows_mode,
+const cm_mac_fir *mac_fir(const cm_mac_desc &d, int i) {
+    return i == 0 ? &d.luma_in : (i == 1 ? &d.chroma_in : (i == 2 ? &d.line_out : &d.line_in));
+}
+cm::MacFir mac_dev_fir(const cm_mac_plan *p, int i) {
+    const cm_mac_fir &f = *mac_fir(p->desc, i);
+    cm::MacFir r;
+    r.h = p->fir[i];
+    r.up = f.up;
+    r.down = f.down;
+    r.half_len = (f.n_taps - 1) / 2;
+    return r;
+}
+int mac_launch(const cm_mac_plan *p, bool demod, const float *in, float *out, int n_frames, int height, int rows_mode,
                int first_line, int64_t first_frame, hipStream_t stream) {
-    if (cm_device_count() <= 0) return fail(CM_ERR_NO_DEVICE, "no HIP device: the MAC path runs on the GPU only");
+    const cm_mac_desc *d = &p->desc;
     cm::MacArgs a;
     std::memset(&a, 0, sizeof a);
     a.in = in;
@@ -974,60 +992,111 @@ int mac_launch(const cm_mac_desc *d, bool demod, const float *in, float *out, in
     a.c0 = (float)(scale * d->resample_fir[20]);
     for (int j = 0; j < 20; ++j) a.taps[j] = (float)(scale * d->resample_fir[2 * j + 1]);
     for (int i = 0; i < 9; ++i) a.m[i] = (float)(demod ? d->decode_matrix[i] : d->encode_matrix[i]);
-    long long blocks;
-    if (rows_mode) blocks = (height + cm::kMacSegment - 1) / cm::kMacSegment;
-    else blocks = (long long)n_frames * 2 * ((((height + 1) >> 1) + cm::kMacSegment - 1) / cm::kMacSegment);
-    if (blocks <= 0) return CM_OK;
-    if (blocks > 0x7fffffffLL) return fail(CM_ERR_INVALID, "batch too large for one launch");
-    if (demod) hipLaunchKernelGGL(cm::mac_demod_kernel, dim3((unsigned)blocks), dim3(cm::kMacThreads), 0, stream, a);
-    else hipLaunchKernelGGL(cm::mac_mod_kernel, dim3((unsigned)blocks), dim3(cm::kMacThreads), 0, stream, a);
+    if (p->tuned) {
+        long long blocks;
+        if (rows_mode) blocks = (height + cm::kMacSegment - 1) / cm::kMacSegment;
+        else blocks = (long long)n_frames * 2 * ((((height + 1) >> 1) + cm::kMacSegment - 1) / cm::kMacSegment);
+        if (blocks <= 0) return CM_OK;
+        if (blocks > 0x7fffffffLL) return fail(CM_ERR_INVALID, "batch too large for one launch");
+        if (demod) hipLaunchKernelGGL(cm::mac_demod_kernel, dim3((unsigned)blocks), dim3(cm::kMacThreads), 0, stream, a);
+        else hipLaunchKernelGGL(cm::mac_mod_kernel, dim3((unsigned)blocks), dim3(cm::kMacThreads), 0, stream, a);
+    } else {
+        cm::MacGenArgs g;
+        g.a = a;
+        g.W = d->width;
+        g.CW = d->line_width;
+        g.luma_in = mac_dev_fir(p, 0);
+        g.chroma_in = mac_dev_fir(p, 1);
+        g.line_out = mac_dev_fir(p, 2);
+        g.line_in = mac_dev_fir(p, 3);
+        const long long blocks = (long long)n_frames * height;       // one workgroup per call
+        if (blocks <= 0) return CM_OK;
+        if (blocks > 0x7fffffffLL) return fail(CM_ERR_INVALID, "batch too large for one launch");
+        const size_t lds_demod = sizeof(float) * (cm::kMacLine + cm::kMacChroma + 24 + 2 * cm::kMacLuma + (size_t)d->line_width);
+        const size_t lds_mod = sizeof(float) * (cm::kMacLine + cm::kMacLuma + cm::kMacChroma + 7 * (size_t)d->width);
+        if (demod) hipLaunchKernelGGL(cm::mac_demod_generic_kernel, dim3((unsigned)blocks), dim3(cm::kMacThreads), lds_demod, stream, g);
+        else hipLaunchKernelGGL(cm::mac_mod_generic_kernel, dim3((unsigned)blocks), dim3(cm::kMacThreads), lds_mod, stream, g);
+    }
     HIP_TRY(hipGetLastError(), CM_ERR_LAUNCH);
     return CM_OK;
 }
-int mac_check(const cm_mac_desc *d, const void *in, const void *out, long long n) {
-    if (!d) return fail(CM_ERR_INVALID, "null argument");
+int mac_check(const cm_mac_plan *p, const void *in, const void *out, long long n) {
+    if (!p) return fail(CM_ERR_INVALID, "null argument");
     if (n == 0) return CM_OK;     // an empty batch may come with null buffers
     if (!in || !out) return fail(CM_ERR_INVALID, "null argument");
-    if (((unsigned long long)in | (unsigned long long)out) & 15) return fail(CM_ERR_INVALID, "buffers must be 16-byte aligned");
-    if (d->height <= 0) return fail(CM_ERR_INVALID, "height must be positive");
+    if (p->tuned && (((unsigned long long)in | (unsigned long long)out) & 15)) return fail(CM_ERR_INVALID, "buffers must be 16-byte aligned");
     return CM_OK;
 }
 }  // namespace
 
 extern "C" {
-int cm_mac_modulate_frames(const cm_mac_desc *d, const float *rgb, float *composite, int64_t n_frames, int64_t first_frame,
+int cm_mac_plan_create(const cm_mac_desc *desc, cm_mac_plan **out) {
+    if (!desc || !out) return fail(CM_ERR_INVALID, "null argument");
+    *out = nullptr;
+    if (desc->height <= 0 || desc->width <= 0 || desc->line_width <= 0) return fail(CM_ERR_INVALID, "width, height and line width must be positive");
+    if (desc->width > 1920) return fail(CM_ERR_UNSUPPORTED, "MAC: rows of more than 1920 samples do not fit the encoder's LDS layout");
+    if (desc->line_width > 4096) return fail(CM_ERR_UNSUPPORTED, "MAC: lines of more than 4096 samples are not supported");
+    if (cm_device_count() <= 0) return fail(CM_ERR_NO_DEVICE, "no HIP device: the MAC path runs on the GPU only");
+    cm_mac_plan *p = new cm_mac_plan();
+    p->desc = *desc;
+    p->tuned = desc->width == CM_MAC_LUMA_WIDTH && desc->line_width == CM_MAC_LINE_WIDTH;
+    for (int i = 0; i < 4; ++i) {
+        const cm_mac_fir &f = *mac_fir(*desc, i);
+        if (f.up <= 0 || f.down <= 0) { cm_mac_plan_destroy(p); return fail(CM_ERR_INVALID, "MAC: resampling ratio must be positive"); }
+        if (f.up == f.down) continue;
+        const int max_rate = f.up > f.down ? f.up : f.down;
+        if (!f.taps || f.n_taps != 2 * 10 * max_rate + 1) { cm_mac_plan_destroy(p); return fail(CM_ERR_INVALID, "MAC: resampling filter must have 2 * 10 * max(up, down) + 1 taps"); }
+        std::vector<float> h(f.n_taps);
+        for (int j = 0; j < f.n_taps; ++j) h[j] = (float)f.taps[j];
+        if (hipMalloc((void **)&p->fir[i], h.size() * sizeof(float)) != hipSuccess ||
+            hipMemcpy(p->fir[i], h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) {
+            cm_mac_plan_destroy(p);
+            return fail(CM_ERR_LAUNCH, "device allocation / upload of a resampling filter failed");
+        }
+    }
+    p->desc.luma_in.taps = p->desc.chroma_in.taps = p->desc.line_out.taps = p->desc.line_in.taps = nullptr;   // the caller's arrays are not kept
+    *out = p;
+    return CM_OK;
+}
+void cm_mac_plan_destroy(cm_mac_plan *p) {
+    if (!p) return;
+    for (int i = 0; i < 4; ++i)
+        if (p->fir[i]) (void)hipFree(p->fir[i]);
+    delete p;
+}
+int cm_mac_modulate_frames(const cm_mac_plan *p, const float *rgb, float *composite, int64_t n_frames, int64_t first_frame,
                            void *stream) {
-    int rc = mac_check(d, rgb, composite, n_frames);
+    int rc = mac_check(p, rgb, composite, n_frames);
     if (rc) return rc;
     if (n_frames < 0 || first_frame < 0) return fail(CM_ERR_INVALID, "negative frame count / number");
     if (n_frames == 0) return CM_OK;
     if (n_frames > 0x7fffffffLL) return fail(CM_ERR_INVALID, "batch too large for one launch");
-    return mac_launch(d, false, rgb, composite, (int)n_frames, d->height, 0, 0, first_frame, (hipStream_t)stream);
+    return mac_launch(p, false, rgb, composite, (int)n_frames, p->desc.height, 0, 0, first_frame, (hipStream_t)stream);
 }
-int cm_mac_demodulate_frames(const cm_mac_desc *d, const float *composite, float *rgb, int64_t n_frames, int64_t first_frame,
+int cm_mac_demodulate_frames(const cm_mac_plan *p, const float *composite, float *rgb, int64_t n_frames, int64_t first_frame,
                              void *stream) {
-    int rc = mac_check(d, composite, rgb, n_frames);
+    int rc = mac_check(p, composite, rgb, n_frames);
     if (rc) return rc;
     if (n_frames < 0 || first_frame < 0) return fail(CM_ERR_INVALID, "negative frame count / number");
     if (n_frames == 0) return CM_OK;
     if (n_frames > 0x7fffffffLL) return fail(CM_ERR_INVALID, "batch too large for one launch");
-    return mac_launch(d, true, composite, rgb, (int)n_frames, d->height, 0, 0, first_frame, (hipStream_t)stream);
+    return mac_launch(p, true, composite, rgb, (int)n_frames, p->desc.height, 0, 0, first_frame, (hipStream_t)stream);
 }
-int cm_mac_modulate_run(const cm_mac_desc *d, const float *rgb, float *composite, int32_t n_calls, int32_t frame,
+int cm_mac_modulate_run(const cm_mac_plan *p, const float *rgb, float *composite, int32_t n_calls, int32_t frame,
                         int32_t first_line, int32_t k0, void *stream) {
-    int rc = mac_check(d, rgb, composite, n_calls);
+    int rc = mac_check(p, rgb, composite, n_calls);
     if (rc) return rc;
     if (n_calls < 0 || frame < 0 || k0 < 0) return fail(CM_ERR_INVALID, "negative count / frame / k0");
     if (n_calls == 0) return CM_OK;
-    return mac_launch(d, false, rgb, composite, 1, n_calls, 1, first_line, frame, (hipStream_t)stream);
+    return mac_launch(p, false, rgb, composite, 1, n_calls, 1, first_line, frame, (hipStream_t)stream);
 }
-int cm_mac_demodulate_run(const cm_mac_desc *d, const float *composite, float *rgb, int32_t n_calls, int32_t frame,
+int cm_mac_demodulate_run(const cm_mac_plan *p, const float *composite, float *rgb, int32_t n_calls, int32_t frame,
                           int32_t first_line, int32_t k0, void *stream) {
-    int rc = mac_check(d, composite, rgb, n_calls);
+    int rc = mac_check(p, composite, rgb, n_calls);
     if (rc) return rc;
     if (n_calls < 0 || frame < 0 || k0 < 0) return fail(CM_ERR_INVALID, "negative count / frame / k0");
     if (n_calls == 0) return CM_OK;
-    return mac_launch(d, true, composite, rgb, 1, n_calls, 1, first_line, frame, (hipStream_t)stream);
+    return mac_launch(p, true, composite, rgb, 1, n_calls, 1, first_line, frame, (hipStream_t)stream);
 }
 }
 

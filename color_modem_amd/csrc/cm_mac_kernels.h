@@ -308,5 +308,149 @@ __global__ __launch_bounds__(kMacThreads) void mac_mod_kernel(const MacArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The cases that resample (mac.py:49-55, 71-74, 88-91): rows of a length other than 720 samples, lines of a length other
+// than 1080 (MacVariant.D2MAC_7MHZ: 720).  scipy's resample_poly(x, up, down) written out (zero extension):
+//     y[n] = sum_j up h[j] xu[n down + half_len - j],  xu = x with up - 1 zeros after every sample,
+//     h = firwin(2 half_len + 1, 1 / max(up, down), ('kaiser', 5.0)),  half_len = 10 max(up, down)
+// i.e. about 21 products per output whatever the ratio.  One workgroup per call, everything of the call in LDS; these are
+// plain kernels for the uncommon shapes, the tuned pair above serves 720 <-> 1080.
+// ---------------------------------------------------------------------------------------------------------------------
+struct MacFir {
+    const float *h;              // up * firwin(...), 2 half_len + 1 taps, device memory; null: up == down (a copy)
+    int up, down, half_len;
+};
+struct MacGenArgs {
+    MacArgs a;
+    int W, CW;                   // samples per rgb row / per transmitted line
+    MacFir luma_in, chroma_in, line_out, line_in;   // W -> 720, W -> 360, 1080 -> CW, CW -> 1080
+};
+__device__ __forceinline__ float mac_resample_at(const float *src, int n_in, const MacFir &f, int n) {
+    if (!f.h) return src[n];
+    const int t0 = n * f.down + f.half_len;
+    int j = t0 % f.up, i = t0 / f.up;
+    if (i > n_in - 1) {          // taps that would meet samples behind the row
+        const int skip = i - (n_in - 1);
+        j += skip * f.up;
+        i -= skip;
+    }
+    float acc = 0.f;
+    for (; j <= 2 * f.half_len && i >= 0; j += f.up, --i) acc = __builtin_fmaf(f.h[j], src[i], acc);
+    return acc;
+}
+
+__global__ __launch_bounds__(kMacThreads) void mac_demod_generic_kernel(const MacGenArgs ga) {
+    const MacArgs &a = ga.a;
+    extern __shared__ __attribute__((aligned(16))) float mac_lds[];
+    float *lin = mac_lds;                       // [1080] the line at its own rate
+    float *ch = lin + kMacLine;                 // [360 + 24]
+    float *up = ch + kMacChroma + 24;           // [2][720]
+    float *raw = up + 2 * kMacLuma;             // [CW] the transmitted line
+    const int t = threadIdx.x;
+    int f, row, prev_row, line;
+    if (a.rows_mode) {
+        f = 0; row = (int)blockIdx.x; prev_row = row - 1; line = a.first_line + 2 * row;
+    } else {
+        f = (int)(blockIdx.x / a.H); row = (int)(blockIdx.x % a.H); prev_row = row - 2; line = row;
+    }
+    const long long frame = a.first_frame + f;
+    const bool have_prev = prev_row >= 0;
+    for (int pass = have_prev ? 0 : 1; pass < 2; ++pass) {      // pass 0: the previous call's line, pass 1: this call's
+        const float *p = a.in + ((long long)f * a.H + (pass ? row : prev_row)) * ga.CW;
+        __syncthreads();
+        for (int i = t; i < ga.CW; i += kMacThreads) raw[i] = p[i];
+        __syncthreads();
+        for (int n = t; n < kMacLine; n += kMacThreads) lin[n] = mac_resample_at(raw, ga.CW, ga.line_in, n);    // mac.py:88-91
+        __syncthreads();
+        for (int i = t; i < kMacChroma + 24; i += kMacThreads)
+            ch[i] = (i < 10 || i >= kMacChroma + 10) ? 0.f : mac_line_chroma(lin, i - 10);
+        __syncthreads();
+        for (int n = t; n < kMacLuma; n += kMacThreads) {
+            const int i = n >> 1;
+            float v;
+            if (n & 1) {
+                v = 0.f;
+                for (int j = 0; j < 20; ++j) v = __builtin_fmaf(a.taps[j], ch[i + 20 - j], v);
+            } else {
+                v = a.c0 * ch[i + 10];
+            }
+            up[pass * kMacLuma + n] = v - 0.5f;
+        }
+    }
+    __syncthreads();
+    const bool alt = mac_alternate(a, frame, line);
+    float *o = a.rows_mode ? a.out + (long long)row * 3 * kMacLuma : a.out + (((long long)f * 3) * a.H + row) * kMacLuma;
+    const long long plane = a.rows_mode ? kMacLuma : (long long)a.H * kMacLuma;
+    for (int n = t; n < kMacLuma; n += kMacThreads) {
+        const float luma = mac_line_luma(lin, n);
+        const float own = up[kMacLuma + n], other = have_prev ? up[n] : 0.f;
+        const float dr = alt ? other : own, db = alt ? own : other;
+        o[n] = __builtin_fmaf(a.m[0], luma, __builtin_fmaf(a.m[1], dr, a.m[2] * db));
+        o[plane + n] = __builtin_fmaf(a.m[3], luma, __builtin_fmaf(a.m[4], dr, a.m[5] * db));
+        o[2 * plane + n] = __builtin_fmaf(a.m[6], luma, __builtin_fmaf(a.m[7], dr, a.m[8] * db));
+    }
+}
+
+__global__ __launch_bounds__(kMacThreads) void mac_mod_generic_kernel(const MacGenArgs ga) {
+    const MacArgs &a = ga.a;
+    extern __shared__ __attribute__((aligned(16))) float mac_lds[];
+    const int W = ga.W;
+    float *lin = mac_lds;                       // [1080]
+    float *lum = lin + kMacLine;                // [720]
+    float *c3 = lum + kMacLuma;                 // [360]
+    float *cavg = c3 + kMacChroma;              // [W] colour-difference signal of the line at the rows' rate
+    float *comp = cavg + W;                     // [2][3][W] (luma, dr, db) of the previous call's row and of this call's
+    const int t = threadIdx.x;
+    int f, out_row, row_a, row_b, line;
+    if (a.rows_mode) {
+        f = 0; out_row = (int)blockIdx.x; row_b = out_row; row_a = a.averaging && out_row > 0 ? out_row - 1 : out_row;
+        line = a.first_line + 2 * out_row - (a.averaging ? 2 : 0);
+    } else {
+        f = (int)(blockIdx.x / a.H); out_row = (int)(blockIdx.x % a.H); row_a = row_b = out_row; line = out_row;
+        if (a.averaging) {
+            row_b += 2;
+            while (row_b >= a.H) row_b -= 2;
+        }
+    }
+    const long long frame = a.first_frame + f;
+    const long long plane = a.rows_mode ? W : (long long)a.H * W;
+    for (int slot = 0; slot < 2; ++slot) {
+        const int row = slot ? row_b : row_a;
+        const float *p = a.rows_mode ? a.in + (long long)row * 3 * W : a.in + (((long long)f * 3) * a.H + row) * W;
+        for (int i = t; i < W; i += kMacThreads) {
+            const float r = p[i], g = p[plane + i], b = p[2 * plane + i];
+            comp[(slot * 3 + 0) * W + i] = __builtin_fmaf(a.m[0], r, __builtin_fmaf(a.m[1], g, a.m[2] * b));
+            comp[(slot * 3 + 1) * W + i] = __builtin_fmaf(a.m[3], r, __builtin_fmaf(a.m[4], g, a.m[5] * b));
+            comp[(slot * 3 + 2) * W + i] = __builtin_fmaf(a.m[6], r, __builtin_fmaf(a.m[7], g, a.m[8] * b));
+        }
+    }
+    __syncthreads();
+    const int sel = mac_alternate(a, frame, line) ? 2 : 1;
+    for (int i = t; i < W; i += kMacThreads)
+        cavg[i] = row_a != row_b ? 0.5f * (comp[(3 + sel) * W + i] + comp[sel * W + i]) : comp[sel * W + i];
+    __syncthreads();
+    for (int n = t; n < kMacLuma; n += kMacThreads) lum[n] = mac_resample_at(comp, W, ga.luma_in, n);                 // mac.py:49-52
+    for (int i = t; i < kMacChroma; i += kMacThreads) c3[i] = mac_resample_at(cavg, W, ga.chroma_in, i) + 0.5f;       // mac.py:53-55, 57
+    __syncthreads();
+    for (int n = t; n < kMacLine; n += kMacThreads) {        // mac.py:56-69
+        float v = 0.5f;
+        if (n >= 18 && n <= 368) v = c3[n - 13];
+        else if (n >= 372 && n <= 1070) v = lum[n - 361];
+        else if (n == 15) v = 0.4375f + 0.125f * c3[2];
+        else if (n == 16) v = 0.25f + 0.5f * c3[3];
+        else if (n == 17) v = 0.0625f + 0.875f * c3[4];
+        else if (n == 369) v = 0.875f * c3[356] + 0.125f * lum[8];
+        else if (n == 370) v = 0.5f * c3[357] + 0.5f * lum[9];
+        else if (n == 371) v = 0.125f * c3[358] + 0.875f * lum[10];
+        else if (n == 1071) v = 0.0625f + 0.875f * lum[710];
+        else if (n == 1072) v = 0.25f + 0.5f * lum[711];
+        else if (n == 1073) v = 0.4375f + 0.125f * lum[712];
+        lin[n] = v;
+    }
+    __syncthreads();
+    float *o = a.out + ((long long)f * a.H + out_row) * ga.CW;
+    for (int m = t; m < ga.CW; m += kMacThreads) o[m] = mac_resample_at(lin, kMacLine, ga.line_out, m);              // mac.py:71-74
+}
+
 }  // namespace cm
 #endif

@@ -32,6 +32,7 @@ class Engine(object):
         d = self.built.desc
         self.width, self.height = d.width, d.height
         self.comp_width = d.width
+        self.in_width = d.width
         self.demod_depth = d.depth
         self.mod_depth = 1 if d.modulation_delay else 0
         self.demodulation_delay = d.demodulation_delay
@@ -148,13 +149,16 @@ class MacEngine(object):
     """MacModem / ColorAveragingModem(MacModem) on the cm_mac_* entry points (rows of 720 samples <-> lines of 1080)."""
 
     def __init__(self, modem, components=False):
+        import fractions
+        import scipy.signal
         from color_modem_amd.color import mac
         stack = modem._stack()
         backend = stack['backend']
         lc = backend.line_config
         std = lc.line_standard
         d = _native.MacDesc()
-        d.height = int(lc.size[1])
+        d.width, d.height = int(lc.size[0]), int(lc.size[1])
+        d.line_width = int(backend._width)
         d.line_shift = int(lc._line_shift)
         d.even_first = int(std.even_field_first_active_line)
         d.odd_first = int(std.odd_field_first_active_line)
@@ -163,17 +167,47 @@ class MacEngine(object):
         eye = numpy.eye(3)
         d.decode_matrix[:] = list(numpy.asarray(eye if components else mac.DECODE).reshape(-1))
         d.encode_matrix[:] = list(numpy.asarray(eye if components else mac.ENCODE).reshape(-1))
+        self._keep = []
+
+        def fir(n_to, n_from):
+            """the filter scipy.signal.resample_poly(x, n_to, n_from) designs (its defaults), as mac.py:49-55, 71-74, 88-91 call it"""
+            fr = fractions.Fraction(n_to, n_from)
+            f = _native.MacFir()
+            f.up, f.down = fr.numerator, fr.denominator
+            if f.up != f.down:
+                max_rate = max(f.up, f.down)
+                h = f.up * scipy.signal.firwin(2 * 10 * max_rate + 1, 1.0 / max_rate, window=('kaiser', 5.0))
+                h = numpy.ascontiguousarray(h, dtype=numpy.float64)
+                self._keep.append(h)
+                f.n_taps = len(h)
+                f.taps = h.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
+            return f
+
+        d.luma_in = fir(mac.LUMA_WIDTH, d.width)
+        d.chroma_in = fir(mac.LUMA_WIDTH // 2, d.width)
+        d.line_out = fir(d.line_width, mac.LINE_WIDTH)
+        d.line_in = fir(mac.LINE_WIDTH, d.line_width)
         self.desc = d
-        self.width, self.comp_width, self.height = mac.LUMA_WIDTH, mac.LINE_WIDTH, d.height
+        self.in_width, self.width, self.comp_width, self.height = d.width, mac.LUMA_WIDTH, d.line_width, d.height
         self.demod_depth = 1                     # the other colour-difference signal is the previous call's
         self.mod_depth = d.averaging
         self.demodulation_delay = 0
         self.modulation_delay = d.averaging
+        self._plan = ctypes.c_void_p()
         _torch()
-        _native.lib()
+        _native.check(_native.lib().cm_mac_plan_create(ctypes.byref(d), ctypes.byref(self._plan)))
+        self._keep = []
+
+    def __del__(self):
+        p = getattr(self, '_plan', None)
+        if p and _native is not None and getattr(_native, '_lib', None) is not None:
+            _native._lib.cm_mac_plan_destroy(p)
+            self._plan = None
 
     def describe(self):
-        return 'mac_demod_kernel / mac_mod_kernel: one workgroup of 256 threads per 8 rows of a field, threads along the row'
+        if self.in_width == 720 and self.comp_width == 1080:
+            return 'mac_demod_kernel / mac_mod_kernel: one workgroup of 256 threads per 8 rows of a field, threads along the row'
+        return 'mac_demod_generic_kernel / mac_mod_generic_kernel (resampling rows / lines): one workgroup per call'
 
     def _as_device(self, x, shape_tail):
         torch = _torch()
@@ -195,21 +229,21 @@ class MacEngine(object):
         if out is None:
             out = torch.empty((n, 3, self.height, self.width), dtype=torch.float32, device=comp.device)
         stream = torch.cuda.current_stream(comp.device).cuda_stream
-        _native.check(_native.lib().cm_mac_demodulate_frames(ctypes.byref(self.desc), comp.data_ptr(), out.data_ptr(), n,
+        _native.check(_native.lib().cm_mac_demodulate_frames(self._plan, comp.data_ptr(), out.data_ptr(), n,
                                                              int(first_frame), stream))
         return out.cpu().numpy() if was_numpy else out
 
     def modulate_frames(self, rgb, first_frame=0, out=None):
-        """rgb [F, 3, H, 720] float32 -> composite [F, H, 1080]."""
+        """rgb [F, 3, H, W] float32 -> composite [F, H, line width]."""
         torch = _torch()
-        x, was_numpy = self._as_device(rgb, (3, self.height, self.width))
+        x, was_numpy = self._as_device(rgb, (3, self.height, self.in_width))
         n = x.shape[0]
         if self.height < 2 * self.modulation_delay and n:
             raise IndexError('image.py:49-50 feeds row 1 ahead of a field under modulation_delay 1: the image has %d row(s)' % self.height)
         if out is None:
             out = torch.empty((n, self.height, self.comp_width), dtype=torch.float32, device=x.device)
         stream = torch.cuda.current_stream(x.device).cuda_stream
-        _native.check(_native.lib().cm_mac_modulate_frames(ctypes.byref(self.desc), x.data_ptr(), out.data_ptr(), n,
+        _native.check(_native.lib().cm_mac_modulate_frames(self._plan, x.data_ptr(), out.data_ptr(), n,
                                                            int(first_frame), stream))
         return out.cpu().numpy() if was_numpy else out
 
@@ -225,7 +259,7 @@ class MacEngine(object):
         n = x.shape[0]
         out = torch.empty((n, 3, self.width), dtype=torch.float32, device=x.device)
         stream = torch.cuda.current_stream(x.device).cuda_stream
-        _native.check(_native.lib().cm_mac_demodulate_run(ctypes.byref(self.desc), x.data_ptr(), out.data_ptr(), n,
+        _native.check(_native.lib().cm_mac_demodulate_run(self._plan, x.data_ptr(), out.data_ptr(), n,
                                                           int(frame), int(first_line), int(k0), stream))
         return out.cpu().numpy()
 
@@ -235,6 +269,6 @@ class MacEngine(object):
         n = x.shape[0]
         out = torch.empty((n, self.comp_width), dtype=torch.float32, device=x.device)
         stream = torch.cuda.current_stream(x.device).cuda_stream
-        _native.check(_native.lib().cm_mac_modulate_run(ctypes.byref(self.desc), x.data_ptr(), out.data_ptr(), n,
+        _native.check(_native.lib().cm_mac_modulate_run(self._plan, x.data_ptr(), out.data_ptr(), n,
                                                         int(frame), int(first_line), int(k0), stream))
         return out.cpu().numpy()

@@ -88,8 +88,8 @@ class RowApi(object):
     def _modulate(self, eng, frame, line, r, g, b):
         assert len(r) == len(g) == len(b)
         row = numpy.ascontiguousarray(numpy.stack([r, g, b]), dtype=numpy.float32)
-        if row.shape[1] != eng.width:
-            raise ValueError('r, g, b must be rows of %d samples' % eng.width)
+        if row.shape[1] != eng.in_width:
+            raise ValueError('r, g, b must be rows of %d samples' % eng.in_width)
         run = self._mod_run
         self._advance(run, frame, line, row, eng.mod_depth)
         n = len(run.rows)

@@ -197,37 +197,54 @@ int cm_modulate_run(const cm_plan *plan, const float *rgb, float *composite, int
                     int32_t first_line, int32_t k0, void *stream);
 
 /* ---- D2-MAC style time-multiplex modem (ref color_modem/color/mac.py:16-125) --------------------
- * MacModem(line_config, MacVariant.D2MAC_12MHZ) for 720-sample rows: no resampling of luma (mac.py:49-52 with
- * len(luma) == 720), chroma 720 -> 360 by resample_poly(., 1, 2) (mac.py:53-55), the 1080-sample line of mac.py:57-69
- * left at its own rate (mac.py:71-74 with width 1080), and the inverse (mac.py:84-125).  `averaging` = the encoder sits
- * inside ColorAveragingModem (comb.py:130-152: modulation_delay 1).  The path has no design step and no tables, so there
- * is no plan object: the descriptor is plain data, passed by value on every call. */
+ * MacModem(line_config, variant_or_width): rows of `width` samples are brought to 720 (luma) and 360 (one colour-
+ * difference signal per line) samples (mac.py:49-55), time-multiplexed into the 1080-sample line of mac.py:57-69 and
+ * brought to `line_width` samples (mac.py:71-74: 1080 = D2MAC_12MHZ, 720 = D2MAC_7MHZ, or any number); the decoder
+ * inverts this and always returns rows of 720 samples (mac.py:84-125).  `averaging` = the encoder sits inside
+ * ColorAveragingModem (comb.py:130-152: modulation_delay 1).  720-sample rows <-> 1080-sample lines run on the tuned
+ * kernels, everything else on the resampling ones. */
 #define CM_MAC_LUMA_WIDTH 720
 #define CM_MAC_LINE_WIDTH 1080
+typedef struct cm_mac_fir {       /* one scipy.signal.resample_poly(x, up, down) of the path */
+    int32_t up, down;             /* reduced fraction; up == down == 1: no resampling, taps ignored */
+    int32_t n_taps;               /* 2 * 10 * max(up, down) + 1 */
+    int32_t reserved;
+    const double *taps;           /* up * firwin(n_taps, 1 / max(up, down), window=('kaiser', 5.0)) */
+} cm_mac_fir;
 typedef struct cm_mac_desc {
+    int32_t width;                /* samples per rgb row (1 .. 1920) */
     int32_t height;               /* rows per frame */
+    int32_t line_width;           /* samples per transmitted line (1 .. 4096) */
     int32_t line_shift;           /* LineConfig._line_shift (line.py:53) */
     int32_t even_first, odd_first;/* LineStandard.even_field_first_active_line / odd_... (line.py:56-60) */
     int32_t averaging;            /* 1: ColorAveragingModem(MacModem) on the encoder side */
     int32_t reserved;
-    double resample_fir[41];      /* firwin(41, 0.5, ('kaiser', 5.0)), as in cm_plan_desc */
+    double resample_fir[41];      /* firwin(41, 0.5, ('kaiser', 5.0)): the decoder's chroma 360 -> 720, as in cm_plan_desc */
     double decode_matrix[9];      /* (r, g, b) = M . (luma, dr, db), mac.py:38-41 (identity: the *_components protocol) */
     double encode_matrix[9];      /* (luma, dr, db) = M . (r, g, b), mac.py:29-32 */
+    cm_mac_fir luma_in;           /* width -> 720        mac.py:49-52 */
+    cm_mac_fir chroma_in;         /* width -> 360        mac.py:53-55 */
+    cm_mac_fir line_out;          /* 1080 -> line_width  mac.py:71-74 */
+    cm_mac_fir line_in;           /* line_width -> 1080  mac.py:88-91 */
 } cm_mac_desc;
+typedef struct cm_mac_plan cm_mac_plan;
 
-/* rgb [n_frames][3][height][720] -> composite [n_frames][height][1080]; equals ImageModem.modulate's row schedule
- * (image.py:47-55) over frames first_frame .. with a fresh modem per frame. */
-int cm_mac_modulate_frames(const cm_mac_desc *desc, const float *rgb, float *composite, int64_t n_frames,
+int cm_mac_plan_create(const cm_mac_desc *desc, cm_mac_plan **out);
+void cm_mac_plan_destroy(cm_mac_plan *plan);
+
+/* rgb [n_frames][3][height][width] -> composite [n_frames][height][line_width]; equals ImageModem.modulate's row
+ * schedule (image.py:47-55) over frames first_frame .. with a fresh modem per frame. */
+int cm_mac_modulate_frames(const cm_mac_plan *plan, const float *rgb, float *composite, int64_t n_frames,
                            int64_t first_frame, void *stream);
-/* composite [n_frames][height][1080] -> rgb [n_frames][3][height][720] (image.py:75-83). */
-int cm_mac_demodulate_frames(const cm_mac_desc *desc, const float *composite, float *rgb, int64_t n_frames,
+/* composite [n_frames][height][line_width] -> rgb [n_frames][3][height][720] (image.py:75-83). */
+int cm_mac_demodulate_frames(const cm_mac_plan *plan, const float *composite, float *rgb, int64_t n_frames,
                              int64_t first_frame, void *stream);
 /* One run of n_calls consecutive calls (lines first_line, first_line + 2, ...), the first being the k0-th call since
- * the modem's reset; rows [n_calls][3][720] / [n_calls][1080].  Row 0 has no history inside the buffers: with k0 > 0 its
- * output is unspecified (the caller submits one row of history, as for cm_demodulate_run). */
-int cm_mac_modulate_run(const cm_mac_desc *desc, const float *rgb, float *composite, int32_t n_calls, int32_t frame,
+ * the modem's reset; rows [n_calls][3][width] / [n_calls][line_width].  Row 0 has no history inside the buffers: with
+ * k0 > 0 its output is unspecified (the caller submits one row of history, as for cm_demodulate_run). */
+int cm_mac_modulate_run(const cm_mac_plan *plan, const float *rgb, float *composite, int32_t n_calls, int32_t frame,
                         int32_t first_line, int32_t k0, void *stream);
-int cm_mac_demodulate_run(const cm_mac_desc *desc, const float *composite, float *rgb, int32_t n_calls, int32_t frame,
+int cm_mac_demodulate_run(const cm_mac_plan *plan, const float *composite, float *rgb, int32_t n_calls, int32_t frame,
                           int32_t first_line, int32_t k0, void *stream);
 
 /* Name, main-loop instruction mix and launch geometry of the dominant kernel of the last

@@ -1,7 +1,7 @@
 # -*- coding: utf-8 -*-
 """float64 restatement of the reference's D2-MAC style time-multiplex modem - TEST INFRASTRUCTURE.
 
-Follows /root/reference/color_modem/color/mac.py (MacModem, 720-sample rows, the 1080-sample D2MAC_12MHZ line) and the
+Follows /root/reference/color_modem/color/mac.py (MacModem: rows and lines of any length) and the
 encoder-side wrapper of comb.py:130-167 (ColorAveragingModem) in plain numpy, with scipy's ``resample_poly`` written out
 (41-tap Kaiser(5) half-band FIR, zero-extended).  Pinned against vectors the reference itself
 produced (tests/golden/mac_*.npz, made by tests/golden/make_golden_mac.py) in tests/test_mac_oracle.py.  May be imported
@@ -43,11 +43,45 @@ def resample_up2(x):
     return numpy.convolve(xu, h)[20:20 + 2 * len(x)]
 
 
-def modulate_components(alternate, luma, dr, db):
-    """mac.py:43-82 for 720-sample components and the 1080-sample line (no resampling on either side but chroma / 2)."""
-    assert len(luma) == len(dr) == len(db) == LUMA_W
-    chroma = resample_dn2(numpy.asarray(db if alternate else dr, dtype=numpy.float64)) + 0.5
-    luma = numpy.asarray(luma, dtype=numpy.float64)
+def firwin_kaiser(half_len, cutoff):
+    """scipy.signal.firwin(2 half_len + 1, cutoff, window=('kaiser', 5.0)): windowed sinc, unit gain at DC."""
+    n = numpy.arange(2 * half_len + 1) - float(half_len)
+    h = cutoff * numpy.sinc(cutoff * n) * numpy.kaiser(2 * half_len + 1, 5.0)
+    return h / h.sum()
+
+
+def resample_poly(x, up, down):
+    """scipy.signal.resample_poly(x, up, down) with its defaults (window ('kaiser', 5.0), zero padding), written out:
+    y[n] = sum_j up h[j] xu[n down + half_len - j],  xu = x with up - 1 zeros after every sample, h = firwin(2 half_len + 1,
+    1 / max(up, down)), half_len = 10 max(up, down);  ceil(len(x) up / down) outputs."""
+    import math
+    g = math.gcd(int(up), int(down))
+    up, down = int(up) // g, int(down) // g
+    x = numpy.asarray(x, dtype=numpy.float64)
+    if up == down == 1:
+        return x.copy()
+    half_len = 10 * max(up, down)
+    h = up * firwin_kaiser(half_len, 1.0 / max(up, down))
+    n_out = -(-len(x) * up // down)
+    # only every up-th sample of xu is non-zero: with t0 = n down + half_len, j = t0 % up + up q meets x[t0 // up - q]
+    t0 = numpy.arange(n_out) * down + half_len
+    q = numpy.arange(-(-len(h) // up))
+    j = (t0 % up)[:, None] + up * q[None, :]
+    i = (t0 // up)[:, None] - q[None, :]
+    ok = (j < len(h)) & (i >= 0) & (i < len(x))
+    return numpy.sum(numpy.where(ok, h[numpy.minimum(j, len(h) - 1)] * x[numpy.clip(i, 0, len(x) - 1)], 0.0), axis=1)
+
+
+def modulate_components(alternate, luma, dr, db, line_width=LINE_W):
+    """mac.py:43-82: components of any length -> the 1080-sample line -> `line_width` samples."""
+    assert len(luma) == len(dr) == len(db)
+    chroma = resample_poly(db if alternate else dr, CHROMA_W, len(dr)) + 0.5
+    luma = resample_poly(luma, LUMA_W, len(luma))
+    out = _assemble(luma, chroma)
+    return resample_poly(out, line_width, LINE_W)
+
+
+def _assemble(luma, chroma):
     out = 0.5 * numpy.ones(LINE_W)
     out[15] = 0.4375 + 0.125 * chroma[2]
     out[16] = 0.25 + 0.5 * chroma[3]
@@ -64,8 +98,8 @@ def modulate_components(alternate, luma, dr, db):
 
 
 def split_line(comp):
-    """mac.py:93-118: (luma[720], chroma[360]) of one 1080-sample line, before the chroma interpolation."""
-    comp = numpy.asarray(comp, dtype=numpy.float64)
+    """mac.py:88-118: (luma[720], chroma[360]) of one line (brought to 1080 samples first), before the chroma interpolation."""
+    comp = resample_poly(numpy.asarray(comp, dtype=numpy.float64), LINE_W, len(comp))
     assert len(comp) == LINE_W
     luma = 0.5 * numpy.ones(LUMA_W)
     chroma = 0.5 * numpy.ones(CHROMA_W)
@@ -98,8 +132,9 @@ def is_alternate_line(lc, frame, line):
 class OracleMac(object):
     """The stateful per-row protocol of MacModem, optionally inside ColorAveragingModem (averaging=True)."""
 
-    def __init__(self, line_config, averaging=False):
+    def __init__(self, line_config, averaging=False, line_width=LINE_W):
         self.lc = line_config
+        self.line_width = line_width
         self.averaging = averaging
         self.modulation_delay = 1 if averaging else 0
         self.demodulation_delay = 0
@@ -131,15 +166,15 @@ class OracleMac(object):
             self._mod_last = (frame, line, (y, u, v))
             y, u, v = last[0], 0.5 * (u + last[1]), 0.5 * (v + last[2])
             line = line - 2
-        return modulate_components(is_alternate_line(self.lc, frame, line), y, u, v)
+        return modulate_components(is_alternate_line(self.lc, frame, line), y, u, v, self.line_width)
 
 
-def modulate_frames(line_config, rgb, first_frame=0, averaging=False):
-    """rgb [F, 3, H, 720] -> composite [F, H, 1080] float64 through the row schedule of image.py:47-55."""
+def modulate_frames(line_config, rgb, first_frame=0, averaging=False, line_width=LINE_W):
+    """rgb [F, 3, H, W] -> composite [F, H, line_width] float64 through the row schedule of image.py:47-55."""
     n, _, height, _ = rgb.shape
-    out = numpy.zeros((n, height, LINE_W))
+    out = numpy.zeros((n, height, line_width))
     for f in range(n):
-        m = OracleMac(line_config, averaging)
+        m = OracleMac(line_config, averaging, line_width)
         for field in range(2):
             for y in range(field, 2 * m.modulation_delay, 2):
                 m.modulate(first_frame + f, y, rgb[f, 0, y], rgb[f, 1, y], rgb[f, 2, y])
@@ -152,7 +187,7 @@ def modulate_frames(line_config, rgb, first_frame=0, averaging=False):
 
 
 def demodulate_frames(line_config, comp, first_frame=0):
-    """composite [F, H, 1080] -> rgb [F, 3, H, 720] float64 through the row schedule of image.py:75-83."""
+    """composite [F, H, line width] -> rgb [F, 3, H, 720] float64 through the row schedule of image.py:75-83."""
     n, height, _ = comp.shape
     out = numpy.zeros((n, 3, height, LUMA_W))
     for f in range(n):

@@ -73,6 +73,20 @@ def main():
             comp = out.astype(numpy.float32)
             back = numpy.stack([run_demod_frame(make(lc), comp[i], f) for i, f in enumerate(frames)])
             save('mac_demod_plain', inp=comp, out=back, frames=numpy.array(frames), height=numpy.array(H))
+    # the cases that resample (mac.py:49-55, 71-74, 88-91): other row lengths, the 720-sample D2MAC_7MHZ line, an odd width
+    for name, Wi, cw, H, frames, avg in (('w768_7mhz', 768, mac.MacVariant.D2MAC_7MHZ, 8, [0, 1], False),
+                                         ('w768_7mhz_avg', 768, mac.MacVariant.D2MAC_7MHZ, 7, [2], True),
+                                         ('w640_12mhz', 640, mac.MacVariant.D2MAC_12MHZ, 6, [1], False),
+                                         ('w720_7mhz', 720, mac.MacVariant.D2MAC_7MHZ, 6, [0], False),
+                                         ('w1000_900', 1000, 900, 5, [3], True)):
+        lc = line.LineConfig((Wi, H), std)
+        mk = (lambda: comb.ColorAveragingModem(mac.MacModem(lc, cw))) if avg else (lambda: mac.MacModem(lc, cw))
+        rgb = testing.synthetic_rgb(len(frames), H, Wi, seed=1200 + Wi)
+        out = numpy.stack([run_mod_frame(mk(), rgb[i], f) for i, f in enumerate(frames)])
+        comp = out.astype(numpy.float32)
+        back = numpy.stack([run_demod_frame(mac.MacModem(lc, cw), comp[i], f) for i, f in enumerate(frames)])
+        save('mac_resampled_' + name, rgb=rgb, comp=out, back=back, frames=numpy.array(frames), height=numpy.array(H),
+             width=numpy.array(Wi), line_width=numpy.array(out.shape[2]), averaging=numpy.array(1 if avg else 0))
     # not a valid MAC signal: noise rows (every sample of the row, incl. the guard areas the encoder leaves at 0.5)
     H = 9
     lc = line.LineConfig((W, H), std)

@@ -132,11 +132,54 @@ def test_full_size_properties():
     assert float((comp[:, :, 372:1071] - y[:, :, 11:710]).abs().max()) < 1e-6
 
 
-def test_unbuilt_cases_fail_loudly():
+RESAMPLED = ['w768_7mhz', 'w768_7mhz_avg', 'w640_12mhz', 'w720_7mhz', 'w1000_900']
+
+
+@pytest.mark.parametrize('name', RESAMPLED)
+def test_resampled_golden(name):
+    """Rows of other lengths / the 720-sample D2MAC_7MHZ line / an arbitrary line length (mac.py:49-55, 71-74, 88-91)."""
+    g = stacks.load('mac_resampled_' + name)
+    H, W, cw, avg = int(g['height']), int(g['width']), int(g['line_width']), bool(g['averaging'])
+    lc = line.LineConfig((W, H), STD)
+    variant = {1080: mac.MacVariant.D2MAC_12MHZ, 720: mac.MacVariant.D2MAC_7MHZ}.get(cw, cw)
+    enc = mac.MacModem(lc, variant)
+    im_enc = image.ImageModem(comb.ColorAveragingModem(enc) if avg else enc)
+    im_dec = image.ImageModem(mac.MacModem(lc, variant))
+    for i, f in enumerate(g['frames']):
+        comp = im_enc.modulate_frames(g['rgb'][i:i + 1], first_frame=int(f))[0]
+        assert comp.shape == (H, cw) and stacks.rel_err(comp, g['comp'][i]) < TOL, (name, int(f))
+        back = im_dec.demodulate_frames(g['comp'][i:i + 1].astype(numpy.float32), first_frame=int(f))[0]
+        assert back.shape == (3, H, 720) and stacks.rel_err(back, g['back'][i]) < TOL, (name, int(f))
+
+
+@pytest.mark.parametrize('width,line_width', [(720, 720), (1920, 1080), (479, 1081), (704, 720)])
+def test_resampled_against_oracle(width, line_width):
+    H = 21
+    lc = line.LineConfig((width, H), STD)
+    enc = comb.ColorAveragingModem(mac.MacModem(lc, line_width))
+    rgb = testing.synthetic_rgb(2, H, width, seed=width)
+    want = om.modulate_frames(lc, rgb.astype(numpy.float64), 1, True, line_width)
+    comp = image.ImageModem(enc).modulate_frames(rgb, first_frame=1)
+    comp32 = want.astype(numpy.float32)
+    back = image.ImageModem(mac.MacModem(lc, line_width)).demodulate_frames(comp32, first_frame=1)
+    want_back = om.demodulate_frames(lc, comp32.astype(numpy.float64), 1)
+    for i in range(2):
+        assert stacks.rel_err(comp[i], want[i]) < TOL and stacks.rel_err(back[i], want_back[i]) < TOL
+    # the per-row protocol on the resampling kernels
+    dev, ref = mac.MacModem(lc, line_width), om.OracleMac(lc, False, line_width)
+    for ln in (1, 3, 5):
+        r, g, b = (rgb[0, p, ln].astype(numpy.float64) for p in range(3))
+        got, exp = dev.modulate(4, ln, r, g, b), ref.modulate(4, ln, r, g, b)
+        assert got.shape == (line_width,) and stacks.rel_err(got, exp) < TOL
+        got3, exp3 = dev.demodulate(4, ln, exp.astype(numpy.float32)), ref.demodulate(4, ln, exp.astype(numpy.float32).astype(numpy.float64))
+        assert stacks.rel_err(numpy.stack(got3), numpy.stack(exp3)) < TOL
+
+
+def test_limits_fail_loudly():
     with pytest.raises(NotImplementedError):
-        mac.MacModem(line.LineConfig((720, 8), STD), mac.MacVariant.D2MAC_7MHZ)
+        mac.MacModem(line.LineConfig((2048, 8), STD))
     with pytest.raises(NotImplementedError):
-        mac.MacModem(line.LineConfig((768, 8), STD))
+        mac.MacModem(line.LineConfig((720, 8), STD), 5000)
     im = image.ImageModem(make(8))
     with pytest.raises(ValueError):
         im.demodulate_frames(numpy.zeros((1, 8, 720), dtype=numpy.float32))

@@ -44,6 +44,18 @@ def test_demodulate_frames_golden(name):
         assert numpy.abs(got - z['out'][i]).max() < 1e-12
 
 
+@pytest.mark.parametrize('name', ['w768_7mhz', 'w768_7mhz_avg', 'w640_12mhz', 'w720_7mhz', 'w1000_900'])
+def test_resampled_golden(name):
+    z = _load('mac_resampled_' + name)
+    H, W, cw, avg = int(z['height']), int(z['width']), int(z['line_width']), bool(z['averaging'])
+    lc = line.LineConfig((W, H), STD)
+    for i, f in enumerate(z['frames']):
+        got = om.modulate_frames(lc, z['rgb'][i:i + 1].astype(numpy.float64), int(f), avg, cw)[0]
+        assert numpy.abs(got - z['comp'][i]).max() < 1e-12
+        back = om.demodulate_frames(lc, z['comp'][i:i + 1].astype(numpy.float32).astype(numpy.float64), int(f))[0]
+        assert numpy.abs(back - z['back'][i]).max() < 1e-12
+
+
 def test_image_round_trip_golden():
     """uint8 through the oracle with ImageModem's level mapping against the reference's own ImageModem."""
     from color_modem_amd.image import ImageModem, _as_bytes
