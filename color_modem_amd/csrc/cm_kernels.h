@@ -128,6 +128,11 @@ typedef const __attribute__((address_space(4))) f16u const_f16;
 #ifndef CM_LUMA_RING
 #define CM_LUMA_RING 1
 #endif
+// Output tiles are [row = lane][kTile samples]; the 16-byte quad a lane writes is XORed with lane bits CM_TILE_SWZ, +1 so that
+// the one ds_write_b32 per plane and step of 64 lanes spreads over more banks (rows are 64 bytes apart).
+#ifndef CM_TILE_SWZ
+#define CM_TILE_SWZ 1
+#endif
 typedef __attribute__((address_space(3))) float lds_float;
 typedef __attribute__((address_space(3))) f4 lds_f4;
 constexpr int kInTile = 32;        // samples per input tile (one 128-byte line per row)
@@ -351,7 +356,7 @@ __device__ __forceinline__ void flush_tile(const Geom &g, const lds_float *otile
         const int row = lane / kChunks + kRows * q;
         typedef __attribute__((address_space(1))) f4 global_f4;
         global_f4 *dst = (global_f4 *)(unsigned long long)ptr_from(row * 4, op);
-        const int quad = chunk ^ ((row >> 1) & (kChunks - 1));
+        const int quad = chunk ^ ((row >> CM_TILE_SWZ) & (kChunks - 1));
         if (dst != nullptr && col < g.Wp) {
             dst += col >> 2;
 #ifndef CM_FLUSH_SERIAL   /* the three planes of a row group in one LDS round trip (-1 % kernel time) */
@@ -526,7 +531,7 @@ __device__ __forceinline__ void run_lane(const Geom &g, const DemodK<float, type
     }
     // output tile address of this lane's row: row * 16 + (column ^ quad swizzle)
     lds_float *otile = U8 ? (lds_float *)((lds_u8 *)otile_base + lane * 3 * kTile) : otile_base + lane * kTile;
-    const int wpos = ((lane >> 1) & (kTile / 4 - 1)) << 2;
+    const int wpos = ((lane >> CM_TILE_SWZ) & (kTile / 4 - 1)) << 2;
 
     // ---- stream geometry ----------------------------------------------------------------------
     const int W = g.W;
@@ -964,7 +969,7 @@ __device__ __forceinline__ void run_pair(const Geom &g, const DemodK<float, type
     for (int j = 0; j < (SP > 0 ? SP : 1); ++j) uvd[j] = pf2{0.f, 0.f};
     // output tile address of this lane's row: row * 16 + (column ^ quad swizzle)
     lds_float *otile = U8 ? (lds_float *)((lds_u8 *)otile_base + lane * 3 * kTile) : otile_base + lane * kTile;
-    const int wpos = ((lane >> 1) & (kTile / 4 - 1)) << 2;
+    const int wpos = ((lane >> CM_TILE_SWZ) & (kTile / 4 - 1)) << 2;
 
 
     // Carriers of one body, fetched a body ahead (the tables are padded, so no index needs a clamp):

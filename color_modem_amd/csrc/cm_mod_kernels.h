@@ -36,7 +36,7 @@ __device__ __forceinline__ void flush_tile1(const Geom &g, const lds_float *otil
         const int row = lane / kChunks + kRows * q;
         typedef __attribute__((address_space(1))) f4 global_f4;
         global_f4 *dst = (global_f4 *)(unsigned long long)ptr_from(row * 4, op);
-        const int quad = chunk ^ ((row >> 1) & (kChunks - 1));
+        const int quad = chunk ^ ((row >> CM_TILE_SWZ) & (kChunks - 1));
         if (dst != nullptr && col < g.Wp) {
             f4 v = *(const lds_f4 *)(otile + row * kTile + 4 * quad);
             __builtin_nontemporal_store(v, &dst[col >> 2]);
@@ -233,7 +233,7 @@ __global__ __launch_bounds__(64, 2) void qam_mod_kernel(const ModArgs<NP> args) 
     float yw[SP + 4];
 #pragma unroll
     for (int j = 0; j < SP + 4; ++j) yw[j] = 0.f;
-    const int wpos = ((lane >> 1) & (kTile / 4 - 1)) << 2;
+    const int wpos = ((lane >> CM_TILE_SWZ) & (kTile / 4 - 1)) << 2;
     const int W = g.W;
     const int sp = RT ? k.s_p : SP;
     const int T = (g.Wp + sp + 3) & ~3;

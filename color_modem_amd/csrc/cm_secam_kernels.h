@@ -62,7 +62,7 @@ __global__ __launch_bounds__(64, 2) void secam_demod_kernel(const SecamDemodArgs
 #pragma unroll
     for (int j = 0; j < 14; ++j) chw[j] = 0.f;
     lds_float *otile = U8 ? (lds_float *)((lds_u8 *)otile_base + lane * 3 * kTile) : otile_base + lane * kTile;
-    const int wpos = ((lane >> 1) & (kTile / 4 - 1)) << 2;
+    const int wpos = ((lane >> CM_TILE_SWZ) & (kTile / 4 - 1)) << 2;
     const lds_float *xrow = itile + lane * kInTile;
     const lds_u8 *xrow8 = (const lds_u8 *)itile + lane * kInTile;
 
@@ -194,7 +194,7 @@ __global__ __launch_bounds__(64, 2) void secam_mod_kernel(const SecamModArgs arg
     float yw[SP + 4];
 #pragma unroll
     for (int j = 0; j < SP + 4; ++j) yw[j] = 0.f;
-    const int wpos = ((lane >> 1) & (kTile / 4 - 1)) << 2;
+    const int wpos = ((lane >> CM_TILE_SWZ) & (kTile / 4 - 1)) << 2;
     const int W = g.W;
     const int sp = RT ? k.s_p : SP;
     const int T = (g.Wp + sp + 3) & ~3;
