@@ -79,6 +79,13 @@ while done < N:
     flag = '' if max(e_mod, e_dem) < 1e-5 else '   <-- FAIL'
     if flag:
         bad.append(tag)
+        import os
+        if os.path.isdir('gpurun_out'):     # keep the case for a look on the host (tests/secam_sim_probe.py and friends)
+            err = numpy.abs(got.astype(numpy.float64) - want) / numpy.abs(want).max(axis=(1, 2, 3), keepdims=True)
+            ix = numpy.unravel_index(err.argmax(), err.shape)
+            print('      worst demod sample at (frame, plane, row, col) = %s: got %.9g want %.9g' % (ix, got[ix], want[ix]))
+            numpy.savez_compressed('gpurun_out/fuzz_fail_%d.npz' % len(bad), tag=tag, comp=comp_ref[ix[0]:ix[0] + 1], got=got[ix[0]:ix[0] + 1],
+                                   first=first + ix[0], name=name, vname=vname, size=numpy.array([w, h, full]))
     print('%s  mod %.1e demod %.1e%s' % (tag, e_mod, e_dem, flag))
     sys.stdout.flush()
 print('cases %d, worst error %.2e, failures %d, %.0f s' % (done, worst, len(bad), time.time() - t0))
