@@ -49,8 +49,7 @@ int launch_demod(const Geom &gm, const void *km, const Geom &gf, const void *kf,
     am.k = *static_cast<const DemodK<float, S> *>(km);
     af.g = gf;
     af.k = kf ? *static_cast<const DemodK<float, S> *>(kf) : am.k;
-    // wave-pair kernel where stage B fits the 168 VGPRs of 3 waves per SIMD, one wave per 64 calls otherwise
-    // (measured on those instances: the pair at 2 waves per SIMD is 2-5 % slower than the single wave)
+    // PassCfg::kUsePair: the wave pair for every instance unless the build asks for the earlier selection
     if constexpr (CM_PAIR != 0 && Main::kUsePair)
         hipLaunchKernelGGL((demod_pair_kernel<Main, First>), dim3(n_first + n_main), dim3(128), 0, stream, am, af, n_first);
     else
@@ -218,7 +217,11 @@ bool select_for_shape(cm_plan *p, const cm_plan_desc &d, const char *sys, std::s
         }
         p->main.depth = 2; what = "qam front, depth 2";
     }
+#ifdef CM_ONE_WAVE_SELECT
     const bool pair = CM_PAIR != 0 && ((p->main.depth < 2 && !notch && !minavg && S::NE < 4 && S::NP < 2) || (pald && notch));   // PassCfg::kUsePair
+#else
+    const bool pair = CM_PAIR != 0;   // PassCfg::kUsePair
+#endif
     p->pair = pair;
     p->main.name = std::string(pair ? "demod_pair_kernel<" : "demod_kernel<") + sys + ": " + what + (notch ? " + notch>" : ">");
     return make_passes<S>(p, d, pald, bsf, first, err);

@@ -170,10 +170,16 @@ struct PassCfg {
     // wave-pair kernels: 3 waves per SIMD need <= 168 VGPRs; the instances with more per-lane state in stage B (a second
     // line of history, the notch, the second combination of minavg) would spill there and get 2 waves per SIMD instead
     static constexpr int kPairWaves = (DEPTH_ >= 2 || NOTCH_ || MINAVG_ || S_::NE >= 4 || S_::NP >= 2 || S_::RT) ? 2 : 3;
-    // which kernel structure runs this instance: the pair where it gets 3 waves per SIMD (measured 1-3 % faster there,
-    // 2-5 % slower at 2), and where one wave's 256 VGPRs do not hold the line: the PAL-D front end with the notch and the
-    // run-time shape (maximum section counts, 12-sample delay windows)
+    // which kernel structure runs this instance.  Since the luma delay ring (CM_LUMA_RING) every instance runs on the wave
+    // pair - those with more per-lane state in stage B at 2 waves per SIMD (measured: Pal3D 2.92 -> 2.72 ms, Simple3DComb(
+    // NtscComb) 2.43 -> 2.34 ms per 1000 frames against the one-wave kernel, profiles/r01_pair_notes.md section 9).
+    // -DCM_ONE_WAVE_SELECT restores the earlier choice: the pair only where it gets 3 waves per SIMD or one wave's 256 VGPRs
+    // do not hold the line (PAL-D front end with the notch, the run-time shape).
+#ifdef CM_ONE_WAVE_SELECT
     static constexpr bool kUsePair = kPairWaves == 3 || (FRONT_ == 1 && NOTCH_) || S_::RT;
+#else
+    static constexpr bool kUsePair = true;
+#endif
 };
 struct NoPass {
     static constexpr int kLdsFloats = 0;
