@@ -4,17 +4,18 @@
 // block * (64 - DEPTH) - DEPTH + j, i.e. consecutive workgroups overlap by DEPTH halo lanes that only feed their base
 // pairs to their neighbours.  Two drivers run the same stages (cm_stages.h, cm_stages_pk.h):
 //   run_pair  (demod_pair_kernel)  two wavefronts per workgroup: stage A = loads + front end, stage B = detectors in packed
-//             float32 + back end + stores, hand-over through an LDS ring; 3 waves per SIMD.  See the comment above run_pair.
-//   run_lane  (demod_kernel)       one wavefront per workgroup, 2 waves per SIMD: the instances whose stage B does not fit
-//             168 VGPRs (PassCfg::kUsePair).
+//             float32 + back end + stores, hand-over through an LDS ring; 2.5 - 3 waves per SIMD (2 where stage B carries a
+//             second line of history, the notch or minavg).  Every instance of the default build.  See the comment above run_pair.
+//   run_lane  (demod_kernel)       one wavefront per workgroup, 2 waves per SIMD: the earlier structure, kept for A/B builds
+//             (-DCM_PAIR=0, -DCM_ONE_WAVE_SELECT: PassCfg::kUsePair).
 //
 // Data movement of a workgroup:
-//   input   64 rows x 32 samples per tile, filled with 8 global_load_lds_dwordx4 (8 rows x 128 B each, full cache
-//           lines, no VGPR staging); lane i then reads its own row with one ds_read_b128 per 4 steps.  Every input
-//           byte crosses the fabric once for this stream.
-//   luma    x_l[n7 .. +3]: second visit of the (own or previous) row lat samples later, one unaligned
-//           global_load_dwordx4 per lane and 4 steps (L2 / Infinity-Cache hits); in the pair kernel stage A fetches it
-//           and leaves it in LDS for stage B.
+//   input   64 rows x 16 samples per tile in the pair kernels (4 global_load_lds_dwordx4, 16 rows x 64 B each; 32 samples
+//           for byte rows and in the one-wave kernel), no VGPR staging; lane i then reads its own row with one
+//           ds_read_b128 per 4 steps.  Every input byte crosses the fabric once for this stream.
+//   luma    x_l[n7 .. +3]: in the pair kernels stage A leaves the samples in an LDS delay ring straight out of its x window
+//           (CM_LUMA_RING: every input byte is read from memory once); the one-wave kernel visits the (own or previous) row
+//           a second time, one unaligned global_load_dwordx4 per lane and 4 steps.
 //   output  r, g, b: one ds_write_b32 per plane and step into a [3][64][16] LDS tile (quad-swizzled columns); every
 //           16 steps the tile is read back row-wise (ds_read_b128) and stored as 64-byte row segments, 16 rows per
 //           wave-instruction.
