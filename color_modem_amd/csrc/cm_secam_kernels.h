@@ -164,6 +164,203 @@ __global__ __launch_bounds__(64, 2) void secam_demod_kernel(const SecamDemodArgs
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Wave-pair form of the decoder (the structure of cm_kernels.h: run_pair): two wavefronts walk the same 64 calls.
+//   wave 0 (stage A)  every global load (the input tile, 16 samples per row), the mirrored pre-roll, band-pass + bell,
+//                     up2, quadrature mix and the packed (I, Q) low-pass; per body of 4 steps it leaves the low-passed pairs
+//                     (I0, Q0, I1, Q1) of each lane in a double-buffered LDS ring and the 4 row samples the luma filter will
+//                     want d_luma steps later in a delay ring (no second visit of the row)
+//   wave 1 (stage B)  phase steps, decimator, clip, de-emphasis, the luma band-stop on the delayed samples, the other
+//                     colour-difference signal from the neighbouring lane, matrix, output tile and every global store
+// One s_barrier per body: A after writing block b, B before reading it.
+// ---------------------------------------------------------------------------------------------------------------------
+// Off by default: parity-green (the 36 SECAM GPU tests) but 3.96 ms against 3.48 ms per 1000 frames for the one-wave kernel -
+// 38 KiB of LDS leave 4 workgroups = 2 waves per SIMD, and half a line per wave has too little independent work for that
+// (profiles/r01_pair_notes.md section 10).  -DCM_SECAM_PAIR=1 selects it.
+#ifndef CM_SECAM_PAIR
+#define CM_SECAM_PAIR 0
+#endif
+constexpr int kSecamMid = 2 * 4 * 256;        // floats: [buffer][I0 | Q0 | I1 | Q1][lane][4 steps]
+constexpr int kSecamLumaBlocks = 14;          // delay ring blocks of [lane][4 samples]: d_luma <= 4 * (blocks - 2) + 3
+constexpr int kSecamPairMaxLumaDelay = 4 * (kSecamLumaBlocks - 2) + 3;
+
+template <bool U8>
+__global__ __launch_bounds__(128, 2) void secam_demod_pair_kernel(const SecamDemodArgs args) {
+    constexpr int kTile = 16, DEPTH = 1;
+    constexpr int kIT = U8 ? kInTile : 16;                                   // samples per input tile row
+    constexpr int kIn = U8 ? 64 * kInTile / 4 : 64 * kIT, kOut = U8 ? 64 * 3 * kTile / 4 : 3 * 64 * kTile;   // floats
+    __shared__ __attribute__((aligned(16))) float lds_store[kIn + kSecamMid + kOut + kSecamLumaBlocks * 256];
+    lds_float *itile = (lds_float *)lds_store;
+    lds_float *ring = itile + kIn;
+    lds_float *otile_base = ring + kSecamMid;
+    lds_float *xring = otile_base + kOut;
+    typedef __attribute__((address_space(3))) unsigned char lds_u8;
+    typedef __attribute__((address_space(3))) unsigned lds_u32;
+    const Geom &g = args.g;
+    SecamDemodK<float> k = args.k;
+    const int role = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const LaneCall lc = locate_call(g, blockIdx.x, DEPTH, lane);
+
+    // ---- stream geometry (identical in both waves) ------------------------------------------------
+    const int W = g.W, P = k.preroll, Lc = W + P;
+    const int lat = SecamDemod<float>::latency(k);
+    const int d_luma = lat + 1 - P - k.s_y;                 // luma filter input x[xi - d_luma] at main-loop sample xi
+    const int lat_out = d_luma + k.s_y;                     // output sample n' = xi - lat_out
+    const int s_flush = (lat_out + 3) & 3;
+    const int m_start = -((4 - (P & 3)) & 3);               // the pre-roll in bodies of 4 steps
+    const int n_pre = (P - m_start) >> 2;
+    const int T = (g.Wp + lat_out + 3) & ~3;
+    const int n_bodies = n_pre + (T >> 2);
+    const int lr_o = d_luma & 3, lr_m = d_luma >> 2;        // A writes x[xb - lr_o .. + 3]; B reads it lr_m bodies later
+
+    if (role == 0) {
+        // =================================== stage A ===========================================
+        typedef SecamDemodPkA::VP VP;
+        if (VP::VT) pin_block(k.taps);
+        if (VP::VB) pin_block(k.bpf, false);
+        SecamDemodKPk kp;
+        kp.load(k);
+        const float *xp;
+        if (U8) xp = (const float *)((const unsigned char *)g.in + lc.frame * g.in_frame_stride + (long long)lc.src_row * g.W);
+        else xp = g.in + lc.frame * g.in_frame_stride + (long long)lc.src_row * g.Wp;
+        SecamDemodPkA st;
+        st.reset();
+        float chw[14];
+#pragma unroll
+        for (int j = 0; j < 14; ++j) chw[j] = 0.f;
+        const lds_float *xrow = itile + lane * kIT;
+        const lds_u8 *xrow8 = (const lds_u8 *)itile + lane * kInTile;
+        for (int j = 0; j < kSecamLumaBlocks; ++j) *(lds_f4 *)(xring + j * 256 + lane * 4) = f4{0.f, 0.f, 0.f, 0.f};
+        if (U8) fill_tile_u8(g, itile, xp, 0, lane); else fill_tile<kIT>(g, itile, xp, 0, lane);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        auto read_x = [&](int first) -> f4 {
+            f4 v;
+            if (U8) v = decode_bytes(*(const lds_u32 *)(xrow8 + (first & (kInTile - 1))));
+            else v = *(const lds_f4 *)(xrow + (first & (kIT - 1)));
+            if (first + 3 >= W) {
+                if (first >= W) v.x = 0.f;
+                if (first + 1 >= W) v.y = 0.f;
+                if (first + 2 >= W) v.z = 0.f;
+                if (first + 3 >= W) v.w = 0.f;
+            }
+            return v;
+        };
+        f4 xv = {0.f, 0.f, 0.f, 0.f}, xprev = xv;
+        int xw = 0;      // delay ring block of this body
+        for (int b = 0; b < n_bodies; ++b) {
+            const bool pre = b < n_pre;
+            const int xb = (b - n_pre) << 2;
+            if (b == n_pre) xv = read_x(0);
+            float yi0[4], yq0[4], yi1[4], yq1[4];
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const int m = m_start + 4 * b + s;
+                float cc = 0.f;
+                if (pre) {
+                    if (m >= 0) {      // cc[m] = x[P - m] (secam.py:283-284)
+                        int xi = P - m;
+                        if (xi > W - 1) xi = W - 1;
+                        if (P < kIT)
+                            cc = U8 ? __builtin_fmaf((float)xrow8[xi], 5.0f / (255.0f * 3.0f), -1.0f / 3.0f) : xrow[xi];
+                        else
+                            cc = U8 ? __builtin_fmaf((float)((const unsigned char *)xp)[xi], 5.0f / (255.0f * 3.0f), -1.0f / 3.0f) : xp[xi];
+                    }
+                } else {
+                    cc = xv[s];
+                }
+                int m2 = m - k.s_b - 10;
+                m2 = m2 < 0 ? 0 : (m2 > Lc - 1 ? Lc - 1 : m2);
+                const f4 c = ((const_f4 *)g.carrier4)[m2];
+                float ch_out;
+                pf2 y0, y1;
+                st.step(k, kp, m, cc, chw[s], pf2{c.x, c.y}, pf2{c.z, c.w}, ch_out, y0, y1);
+                chw[10 + s] = ch_out;
+                yi0[s] = y0.x; yq0[s] = y0.y; yi1[s] = y1.x; yq1[s] = y1.y;
+            }
+#pragma unroll
+            for (int j = 0; j < 10; ++j) chw[j] = chw[j + 4];
+            // the row samples the luma filter meets d_luma steps from now: x[xb - lr_o .. + 3] (zeros in the pre-roll)
+            f4 blk = {0.f, 0.f, 0.f, 0.f};
+            if (!pre) {
+                blk = lr_o == 0 ? xv
+                    : lr_o == 1 ? f4{xprev.w, xv.x, xv.y, xv.z}
+                    : lr_o == 2 ? f4{xprev.z, xprev.w, xv.x, xv.y} : f4{xprev.y, xprev.z, xprev.w, xv.x};
+                xprev = xv;
+                const int nxt = xb + 4;
+                if ((nxt & (kIT - 1)) == 0 && nxt < W) {   // first read of a new tile: its fill was issued a body ago
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_wave_barrier();
+                }
+                xv = read_x(nxt);
+                if ((nxt & (kIT - 1)) == kIT - 4 && nxt + 4 < W) {   // that was the last read of this tile: refill it
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_wave_barrier();
+                    if (U8) fill_tile_u8(g, itile, xp, nxt / kIT + 1, lane); else fill_tile<kIT>(g, itile, xp, nxt / kIT + 1, lane);
+                }
+            }
+            lds_float *slot = ring + (b & 1) * (kSecamMid / 2) + lane * 4;
+            *(lds_f4 *)slot = f4{yi0[0], yi0[1], yi0[2], yi0[3]};
+            *(lds_f4 *)(slot + 256) = f4{yq0[0], yq0[1], yq0[2], yq0[3]};
+            *(lds_f4 *)(slot + 512) = f4{yi1[0], yi1[1], yi1[2], yi1[3]};
+            *(lds_f4 *)(slot + 768) = f4{yq1[0], yq1[1], yq1[2], yq1[3]};
+            *(lds_f4 *)(xring + xw * 256 + lane * 4) = blk;
+            xw = xw + 1 == kSecamLumaBlocks ? 0 : xw + 1;
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        }
+        return;
+    }
+
+    // ======================================= stage B ===========================================
+    const float *op;
+    if (U8) op = lc.store_ok ? (const float *)((unsigned char *)g.out + lc.frame * g.out_frame_stride + (long long)lc.out_row * g.out_row_stride) : nullptr;
+    else op = lc.store_ok ? g.out + lc.frame * g.out_frame_stride + (long long)lc.out_row * g.out_row_stride : nullptr;
+    SecamDemodLaneK<float> lk;
+    {
+        int fmod = (int)((g.first_frame + lc.frame) % g.cycle);
+        lk = ((const SecamDemodLaneK<float> *)g.lanes)[((long long)fmod * 3 + lc.regime) * g.n_lines + lc.line];
+    }
+    if (SecamDemodPkB::VP::VT) pin_block(k.taps);
+    const int idx1 = ((lane + 63) & 63) * 4;
+    SecamDemodPkB st;
+    st.reset();
+    lds_float *otile = U8 ? (lds_float *)((lds_u8 *)otile_base + lane * 3 * kTile) : otile_base + lane * kTile;
+    const int wpos = ((lane >> CM_TILE_SWZ) & (kTile / 4 - 1)) << 2;
+    float own_prev = 0.f, nb_prev = 0.f;
+    int xr = lr_m == 0 ? 0 : kSecamLumaBlocks - lr_m;    // delay ring block of body b: lr_m bodies behind A's
+    for (int b = 0; b < n_bodies; ++b) {
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // block b of the ring is complete
+        const lds_float *slot = ring + (b & 1) * (kSecamMid / 2) + lane * 4;
+        const f4 i0 = *(const lds_f4 *)slot, q0 = *(const lds_f4 *)(slot + 256);
+        const f4 i1 = *(const lds_f4 *)(slot + 512), q1 = *(const lds_f4 *)(slot + 768);
+        const f4 lw = *(const lds_f4 *)(xring + xr * 256 + lane * 4);
+        xr = xr + 1 == kSecamLumaBlocks ? 0 : xr + 1;
+        const int xb = (b - n_pre) << 2;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int m = m_start + 4 * b + s;
+            int m4 = m - lat + P;                               // row-stream sample the decimator completes in this step
+            m4 = m4 < 0 ? 0 : (m4 > Lc - 1 ? Lc - 1 : m4);
+            const float dc = ((const __attribute__((address_space(4))) float *)g.carrier2)[m4];
+            const float own = st.chroma_step(k, lk, m, pf2{i0[s], q0[s]}, pf2{i1[s], q1[s]}, dc);
+            const int n = m - 1 - lat;                          // the back end runs one sample behind the exchange
+            const float luma = st.luma_step(k, n, lw[s]);
+            Rgb<float> o = st.finish(k, lk, luma, own_prev, nb_prev);
+            own_prev = own;
+            nb_prev = lane_from(idx1, own);
+            if (n >= 0 && n < W) put_rgb<U8, kTile>(otile, wpos, n, o);
+            if (s == s_flush && b >= n_pre) {
+                const int nn = xb + s - lat_out;
+                if (nn >= 0 && ((nn & (kTile - 1)) == kTile - 1 || nn == g.Wp - 1)) {
+                    if (U8) flush_tile_u8(g, otile_base, op, nn & ~(kTile - 1), lane);
+                    else flush_tile<kTile>(g, otile_base, op, nn & ~(kTile - 1), lane);
+                }
+            }
+        }
+    }
+}
+
 struct SecamModArgs {
     Geom g;                    // g.lanes -> SecamModLaneK<float, double> table
     SecamModK<float, double> k;

@@ -547,6 +547,118 @@ struct SecamDemodPk {
     }
 };
 
+// =============================================================================================
+// The same decoder cut in two for the wave pair (cm_secam_kernels.h: secam_demod_pair_kernel): stage A runs the chroma
+// path up to the low-passed (I, Q) pairs, stage B turns them into frequencies and finishes the line.  The two halves
+// execute exactly the operations of SecamDemodPk::chroma_step, in the same order.
+// =============================================================================================
+struct SecamDemodPkA {
+    typedef VPolicy<CM_V_SECAM> VP;
+    IirState<float, 3> bpf;
+    IirState<float, 1> bell;
+    IirStatePk<3> lp;               // (I, Q)
+    HalfbandChain<float> up;
+    float cc_last;
+    pf2 p_last, iq_hold;
+
+    __device__ __forceinline__ void reset() {
+        bpf.reset(); bell.reset(); lp.reset(); up.reset();
+        cc_last = 0.f;
+        p_last = iq_hold = pf2{0.f, 0.f};
+    }
+    // y0, y1: the low-passed (I, Q) of the pair m3 (meaningful where stage B's guards hold)
+    __device__ __forceinline__ void step(const SecamDemodK<float> &k, const SecamDemodKPk &kp, int m, float cc_now, float ch_d10, pf2 car_e,
+                                         pf2 car_o, float &ch_out, pf2 &y0, pf2 &y1) {
+        const int Lc = k.width + k.preroll;
+        const int m1 = m - k.s_b, m2 = m1 - 10;
+        float ch = 0.f;
+        if (m >= 0 && m < Lc + k.s_b) {
+            if (m == Lc - 1) cc_last = cc_now;
+            if (m >= Lc) cc_now = cc_last;
+            float b = iir_bp<VP::VB>(bpf, k.bpf, cc_now);
+            if (m1 >= 0) ch = k.has_bell ? iir_bp<false>(bell, k.bell, b) : b;
+        }
+        if (m1 < 0 || m1 >= Lc) ch = 0.f;
+        ch_out = ch;
+        const float a_odd = up.template push<VP::VT>(k.taps, ch);
+        const float a_even = k.taps.c0 * ch_d10;
+        const pf2 sgn = {1.f, -1.f};
+        pf2 p_e = pk_mul(pk_mul_bs<0>(pf2{a_even, a_even}, car_e), sgn);
+        pf2 p_o = pk_mul(pk_mul_bs<0>(pf2{a_odd, a_odd}, car_o), sgn);
+        y0 = y1 = pf2{0.f, 0.f};
+        if (m2 >= 0 && m2 < Lc + k.q_l) {
+            if (m2 == Lc - 1) p_last = p_o;
+            if (m2 >= Lc) p_e = p_o = p_last;
+            y0 = iir_sym_pk<0, 3>(lp, kp.lpf, p_e);
+            y1 = iir_sym_pk<0, 3>(lp, kp.lpf, p_o);
+            if (k.odd_l) {
+                const pf2 h = iq_hold;
+                iq_hold = y1;
+                y1 = y0;
+                y0 = h;
+            }
+        }
+    }
+};
+
+struct SecamDemodPkB {
+    typedef VPolicy<CM_V_SECAM> VP;
+    IirState<float, 3> ybs;
+    IirState<float, 1> deemph;
+    HalfbandChain<float> dn;
+    float x_last;
+    pf2 iq_prev;
+    int have_prev;
+
+    __device__ __forceinline__ void reset() {
+        ybs.reset(); deemph.reset(); dn.reset();
+        x_last = 0.f;
+        iq_prev = pf2{0.f, 0.f};
+        have_prev = 0;
+    }
+    __device__ __forceinline__ float chroma_step(const SecamDemodK<float> &k, const SecamDemodLaneK<float> &lk, int m, pf2 y0, pf2 y1, float dc) {
+        const int W = k.width, Lc = k.width + k.preroll;
+        const int m2 = m - k.s_b - 10, m3 = m2 - k.q_l, m4 = m3 - 9, n = m4 - k.preroll;
+        float f_e = 0.f, f_o = 0.f;
+        if (m2 >= 0 && m2 < Lc + k.q_l && m3 >= 0 && m3 < Lc) {
+            const float d_e = have_prev ? phase_step_fast(iq_prev.x, iq_prev.y, y0.x, y0.y) : 0.f;  // secam.py:147: first step is 0
+            const float d_o = phase_step_fast(y0.x, y0.y, y1.x, y1.y);
+            have_prev = 1;
+            iq_prev = y1;
+            f_e = d_e * k.two_over_pi;
+            f_o = d_o * k.two_over_pi;
+        }
+        const float g2 = dn.template push_pair<VP::VT>(k.taps, f_e, f_o);
+        float c = 0.f;
+        if (n >= 0 && n < W) {
+            float f2 = (g2 + dc) + lk.off2;
+            f2 = f2 < lk.lo ? lk.lo : (f2 > lk.hi ? lk.hi : f2);
+            c = iir_gen<false>(deemph, k.deemph, f2 * lk.scale);
+        }
+        return c;
+    }
+    __device__ __forceinline__ float luma_step(const SecamDemodK<float> &k, int n, float x_in) {
+        const int W = k.width, j = n + k.s_y;
+        float y = 0.f;
+        if (j >= 0 && j < W + k.s_y) {
+            if (j == W - 1) x_last = x_in;
+            if (j >= W) x_in = x_last;
+            y = iir_sym<false>(ybs, k.ybs, x_in);
+        }
+        return y * k.luma_gain;
+    }
+    __device__ __forceinline__ Rgb<float> finish(const SecamDemodK<float> &k, const SecamDemodLaneK<float> &lk, float luma, float own, float prev) const {
+        prev = prev * lk.w_prev;
+        const float dr = lk.own_is_db != 0.f ? prev : own;   // secam.py:297-300
+        const float db = lk.own_is_db != 0.f ? own : prev;
+        Rgb<float> o;
+        o.r = fmaf_(k.m[0][0], luma, fmaf_(k.m[0][1], dr, k.m[0][2] * db));
+        o.g = fmaf_(k.m[1][0], luma, fmaf_(k.m[1][1], dr, k.m[1][2] * db));
+        o.b = fmaf_(k.m[2][0], luma, fmaf_(k.m[2][1], dr, k.m[2][2] * db));
+        return o;
+    }
+};
+
 }  // namespace cm
 #endif
 #endif
