@@ -27,11 +27,42 @@ MAKERS = [
     ('Secam', 'secam', lambda lc, v: secam.SecamModem(lc, v)), ('Avg(Secam)', 'secam', lambda lc, v: comb.ColorAveragingModem(secam.SecamModem(lc, v))),
 ]
 WIDTHS = [480, 544, 640, 704, 720, 720, 720, 768, 960, 1024, 1280, 1440, 1920]
+
+
+def mac_case(rng):
+    """MacModem / ColorAveragingModem(MacModem): random row length, line length, height, against oracle/cm_oracle_mac.py"""
+    from color_modem_amd.color import mac
+    from oracle import cm_oracle_mac as om
+    w = int(rng.choice([720, 720, 720, 768, 640, 1024, int(rng.integers(300, 1921))]))
+    cw = rng.choice([1080, 1080, 720, int(rng.integers(400, 2000))])
+    full = int(rng.choice([480, 576]))
+    h = int(rng.integers(2, 60)) if rng.random() < 0.8 else full
+    nfr, first, avg = int(rng.integers(1, 3)), int(rng.integers(0, 5000)), bool(rng.random() < 0.5)
+    tag = '%-22s %-9s %4dx%-3d frames %d first %d' % ('Avg(Mac)' if avg else 'Mac', 'line %d' % cw, w, h, nfr, first)
+    lc = line.LineConfig((w, h), line.LineStandard.detect(full))
+    enc = mac.MacModem(lc, int(cw))
+    im_enc, im_dec = image.ImageModem(comb.ColorAveragingModem(enc) if avg else enc), image.ImageModem(mac.MacModem(lc, int(cw)))
+    rgb = testing.synthetic_rgb(nfr, h, w, seed=int(rng.integers(1 << 30)))
+    want = om.modulate_frames(lc, rgb.astype(numpy.float64), first, avg, int(cw))
+    e_mod = max(stacks.rel_err(a, b) for a, b in zip(im_enc.modulate_frames(rgb, first_frame=first), want))
+    comp = want.astype(numpy.float32)
+    back, want_back = im_dec.demodulate_frames(comp, first_frame=first), om.demodulate_frames(lc, comp.astype(numpy.float64), first)
+    e_dem = max(stacks.rel_err(a, b) for a, b in zip(back, want_back))
+    return tag, e_mod, e_dem
 worst = 0.0
 bad = []
 t0 = time.time()
 done = 0
 while done < N:
+    if rng.random() < 0.08:
+        tag, e_mod, e_dem = mac_case(rng)
+        done += 1
+        worst = max(worst, e_mod, e_dem)
+        flag = '' if max(e_mod, e_dem) < 1e-5 else '   <-- FAIL'
+        if flag:
+            bad.append(tag)
+        print('%s  mod %.1e demod %.1e%s' % (tag, e_mod, e_dem, flag))
+        continue
     name, system, make = MAKERS[rng.integers(len(MAKERS))]
     vname = {'pal': PAL_V, 'ntsc': NTSC_V, 'secam': SECAM_V}[system][rng.integers({'pal': 3, 'ntsc': 6, 'secam': 7}[system])]
     v = getattr({'pal': pal.PalVariant, 'ntsc': ntsc.NtscVariant, 'secam': secam.SecamVariant}[system], vname)
