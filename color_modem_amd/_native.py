@@ -21,7 +21,8 @@ SYMBOLS = ('cm_last_error', 'cm_abi_version', 'cm_device_count', 'cm_plan_create
            'cm_modulate_run',
            'cm_plan_describe',
            'cm_mac_plan_create', 'cm_mac_plan_destroy',
-           'cm_mac_modulate_frames', 'cm_mac_demodulate_frames', 'cm_mac_modulate_run', 'cm_mac_demodulate_run')
+           'cm_mac_modulate_frames', 'cm_mac_demodulate_frames', 'cm_mac_modulate_frames_u8', 'cm_mac_demodulate_frames_u8',
+           'cm_mac_modulate_run', 'cm_mac_demodulate_run')
 
 _lib = None
 
@@ -78,6 +79,8 @@ def lib():
     md = vp
     L.cm_mac_modulate_frames.argtypes = [md, vp, vp, ctypes.c_int64, ctypes.c_int64, vp]
     L.cm_mac_demodulate_frames.argtypes = [md, vp, vp, ctypes.c_int64, ctypes.c_int64, vp]
+    L.cm_mac_modulate_frames_u8.argtypes = [md, vp, vp, ctypes.c_int64, ctypes.c_int64, vp]
+    L.cm_mac_demodulate_frames_u8.argtypes = [md, vp, vp, ctypes.c_int64, ctypes.c_int64, vp]
     L.cm_mac_modulate_run.argtypes = [md, vp, vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, vp]
     L.cm_mac_demodulate_run.argtypes = [md, vp, vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, vp]
     if L.cm_abi_version() != plan.CM_ABI_VERSION:

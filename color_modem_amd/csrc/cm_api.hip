@@ -981,7 +981,7 @@ cm::MacFir mac_dev_fir(const cm_mac_plan *p, int i) {
     return r;
 }
 int mac_launch(const cm_mac_plan *p, bool demod, const float *in, float *out, int n_frames, int height, int rows_mode,
-               int first_line, int64_t first_frame, hipStream_t stream) {
+               int first_line, int64_t first_frame, hipStream_t stream, bool u8 = false) {
     const cm_mac_desc *d = &p->desc;
     cm::MacArgs a;
     std::memset(&a, 0, sizeof a);
@@ -1000,7 +1000,7 @@ int mac_launch(const cm_mac_plan *p, bool demod, const float *in, float *out, in
     a.c0 = (float)(scale * d->resample_fir[20]);
     for (int j = 0; j < 20; ++j) a.taps[j] = (float)(scale * d->resample_fir[2 * j + 1]);
     for (int i = 0; i < 9; ++i) a.m[i] = (float)(demod ? d->decode_matrix[i] : d->encode_matrix[i]);
-    if (p->tuned) {
+    if (p->tuned && !u8) {
         long long blocks;
         if (rows_mode) blocks = (height + cm::kMacSegment - 1) / cm::kMacSegment;
         else blocks = (long long)n_frames * 2 * ((((height + 1) >> 1) + cm::kMacSegment - 1) / cm::kMacSegment);
@@ -1022,8 +1022,10 @@ int mac_launch(const cm_mac_plan *p, bool demod, const float *in, float *out, in
         if (blocks > 0x7fffffffLL) return fail(CM_ERR_INVALID, "batch too large for one launch");
         const size_t lds_demod = sizeof(float) * (cm::kMacLine + cm::kMacChroma + 24 + 2 * cm::kMacLuma + (size_t)d->line_width);
         const size_t lds_mod = sizeof(float) * (cm::kMacLine + cm::kMacLuma + cm::kMacChroma + 7 * (size_t)d->width);
-        if (demod) hipLaunchKernelGGL(cm::mac_demod_generic_kernel, dim3((unsigned)blocks), dim3(cm::kMacThreads), lds_demod, stream, g);
-        else hipLaunchKernelGGL(cm::mac_mod_generic_kernel, dim3((unsigned)blocks), dim3(cm::kMacThreads), lds_mod, stream, g);
+        if (demod && u8) hipLaunchKernelGGL(cm::mac_demod_generic_kernel<true>, dim3((unsigned)blocks), dim3(cm::kMacThreads), lds_demod, stream, g);
+        else if (demod) hipLaunchKernelGGL(cm::mac_demod_generic_kernel<false>, dim3((unsigned)blocks), dim3(cm::kMacThreads), lds_demod, stream, g);
+        else if (u8) hipLaunchKernelGGL(cm::mac_mod_generic_kernel<true>, dim3((unsigned)blocks), dim3(cm::kMacThreads), lds_mod, stream, g);
+        else hipLaunchKernelGGL(cm::mac_mod_generic_kernel<false>, dim3((unsigned)blocks), dim3(cm::kMacThreads), lds_mod, stream, g);
     }
     HIP_TRY(hipGetLastError(), CM_ERR_LAUNCH);
     return CM_OK;
@@ -1089,6 +1091,24 @@ int cm_mac_demodulate_frames(const cm_mac_plan *p, const float *composite, float
     if (n_frames == 0) return CM_OK;
     if (n_frames > 0x7fffffffLL) return fail(CM_ERR_INVALID, "batch too large for one launch");
     return mac_launch(p, true, composite, rgb, (int)n_frames, p->desc.height, 0, 0, first_frame, (hipStream_t)stream);
+}
+int cm_mac_modulate_frames_u8(const cm_mac_plan *p, const uint8_t *rgb8, uint8_t *composite8, int64_t n_frames, int64_t first_frame,
+                              void *stream) {
+    if (!p) return fail(CM_ERR_INVALID, "null argument");
+    if (n_frames < 0 || first_frame < 0) return fail(CM_ERR_INVALID, "negative frame count / number");
+    if (n_frames == 0) return CM_OK;
+    if (!rgb8 || !composite8) return fail(CM_ERR_INVALID, "null argument");
+    if (n_frames > 0x7fffffffLL) return fail(CM_ERR_INVALID, "batch too large for one launch");
+    return mac_launch(p, false, (const float *)rgb8, (float *)composite8, (int)n_frames, p->desc.height, 0, 0, first_frame, (hipStream_t)stream, true);
+}
+int cm_mac_demodulate_frames_u8(const cm_mac_plan *p, const uint8_t *composite8, uint8_t *rgb8, int64_t n_frames, int64_t first_frame,
+                                void *stream) {
+    if (!p) return fail(CM_ERR_INVALID, "null argument");
+    if (n_frames < 0 || first_frame < 0) return fail(CM_ERR_INVALID, "negative frame count / number");
+    if (n_frames == 0) return CM_OK;
+    if (!rgb8 || !composite8) return fail(CM_ERR_INVALID, "null argument");
+    if (n_frames > 0x7fffffffLL) return fail(CM_ERR_INVALID, "batch too large for one launch");
+    return mac_launch(p, true, (const float *)composite8, (float *)rgb8, (int)n_frames, p->desc.height, 0, 0, first_frame, (hipStream_t)stream, true);
 }
 int cm_mac_modulate_run(const cm_mac_plan *p, const float *rgb, float *composite, int32_t n_calls, int32_t frame,
                         int32_t first_line, int32_t k0, void *stream) {

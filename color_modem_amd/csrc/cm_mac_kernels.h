@@ -339,6 +339,9 @@ __device__ __forceinline__ float mac_resample_at(const float *src, int n_in, con
     return acc;
 }
 
+// U8: the ImageModem byte boundary fused in (image.py:7-8, 24-25, 62): lines are uint8 [..][CW], entering as
+// (5 (byte / 255) - 1) / 3; the output is interleaved uint8 RGB [..][720][3] = rint(255 clip(x, 0, 1)).
+template <bool U8>
 __global__ __launch_bounds__(kMacThreads) void mac_demod_generic_kernel(const MacGenArgs ga) {
     const MacArgs &a = ga.a;
     extern __shared__ __attribute__((aligned(16))) float mac_lds[];
@@ -356,9 +359,12 @@ __global__ __launch_bounds__(kMacThreads) void mac_demod_generic_kernel(const Ma
     const long long frame = a.first_frame + f;
     const bool have_prev = prev_row >= 0;
     for (int pass = have_prev ? 0 : 1; pass < 2; ++pass) {      // pass 0: the previous call's line, pass 1: this call's
-        const float *p = a.in + ((long long)f * a.H + (pass ? row : prev_row)) * ga.CW;
+        const long long row_index = (long long)f * a.H + (pass ? row : prev_row);
+        const float *p = a.in + row_index * ga.CW;
+        const unsigned char *p8 = (const unsigned char *)a.in + row_index * ga.CW;
         __syncthreads();
-        for (int i = t; i < ga.CW; i += kMacThreads) raw[i] = p[i];
+        for (int i = t; i < ga.CW; i += kMacThreads)
+            raw[i] = U8 ? __builtin_fmaf((float)p8[i], 5.0f / (255.0f * 3.0f), -1.0f / 3.0f) : p[i];
         __syncthreads();
         for (int n = t; n < kMacLine; n += kMacThreads) lin[n] = mac_resample_at(raw, ga.CW, ga.line_in, n);    // mac.py:88-91
         __syncthreads();
@@ -380,17 +386,30 @@ __global__ __launch_bounds__(kMacThreads) void mac_demod_generic_kernel(const Ma
     __syncthreads();
     const bool alt = mac_alternate(a, frame, line);
     float *o = a.rows_mode ? a.out + (long long)row * 3 * kMacLuma : a.out + (((long long)f * 3) * a.H + row) * kMacLuma;
+    unsigned char *o8 = (unsigned char *)a.out + ((long long)f * a.H + row) * 3 * kMacLuma;
     const long long plane = a.rows_mode ? kMacLuma : (long long)a.H * kMacLuma;
     for (int n = t; n < kMacLuma; n += kMacThreads) {
         const float luma = mac_line_luma(lin, n);
         const float own = up[kMacLuma + n], other = have_prev ? up[n] : 0.f;
         const float dr = alt ? other : own, db = alt ? own : other;
-        o[n] = __builtin_fmaf(a.m[0], luma, __builtin_fmaf(a.m[1], dr, a.m[2] * db));
-        o[plane + n] = __builtin_fmaf(a.m[3], luma, __builtin_fmaf(a.m[4], dr, a.m[5] * db));
-        o[2 * plane + n] = __builtin_fmaf(a.m[6], luma, __builtin_fmaf(a.m[7], dr, a.m[8] * db));
+        const float r = __builtin_fmaf(a.m[0], luma, __builtin_fmaf(a.m[1], dr, a.m[2] * db));
+        const float g = __builtin_fmaf(a.m[3], luma, __builtin_fmaf(a.m[4], dr, a.m[5] * db));
+        const float b = __builtin_fmaf(a.m[6], luma, __builtin_fmaf(a.m[7], dr, a.m[8] * db));
+        if (U8) {
+            o8[3 * n] = (unsigned char)__builtin_rintf(255.f * __builtin_fminf(__builtin_fmaxf(r, 0.f), 1.f));
+            o8[3 * n + 1] = (unsigned char)__builtin_rintf(255.f * __builtin_fminf(__builtin_fmaxf(g, 0.f), 1.f));
+            o8[3 * n + 2] = (unsigned char)__builtin_rintf(255.f * __builtin_fminf(__builtin_fmaxf(b, 0.f), 1.f));
+        } else {
+            o[n] = r;
+            o[plane + n] = g;
+            o[2 * plane + n] = b;
+        }
     }
 }
 
+// U8: interleaved uint8 RGB rows [..][W][3] enter as byte / 255 (image.py:43-45); the line leaves as
+// uint8 = rint(255 clip(0.6 x + 0.2, 0, 1)) (image.py:20-21, 7-8).
+template <bool U8>
 __global__ __launch_bounds__(kMacThreads) void mac_mod_generic_kernel(const MacGenArgs ga) {
     const MacArgs &a = ga.a;
     extern __shared__ __attribute__((aligned(16))) float mac_lds[];
@@ -417,8 +436,11 @@ __global__ __launch_bounds__(kMacThreads) void mac_mod_generic_kernel(const MacG
     for (int slot = 0; slot < 2; ++slot) {
         const int row = slot ? row_b : row_a;
         const float *p = a.rows_mode ? a.in + (long long)row * 3 * W : a.in + (((long long)f * 3) * a.H + row) * W;
+        const unsigned char *p8 = (const unsigned char *)a.in + ((long long)f * a.H + row) * 3 * W;
         for (int i = t; i < W; i += kMacThreads) {
-            const float r = p[i], g = p[plane + i], b = p[2 * plane + i];
+            float r, g, b;
+            if (U8) { r = (float)p8[3 * i] / 255.0f; g = (float)p8[3 * i + 1] / 255.0f; b = (float)p8[3 * i + 2] / 255.0f; }
+            else { r = p[i]; g = p[plane + i]; b = p[2 * plane + i]; }
             comp[(slot * 3 + 0) * W + i] = __builtin_fmaf(a.m[0], r, __builtin_fmaf(a.m[1], g, a.m[2] * b));
             comp[(slot * 3 + 1) * W + i] = __builtin_fmaf(a.m[3], r, __builtin_fmaf(a.m[4], g, a.m[5] * b));
             comp[(slot * 3 + 2) * W + i] = __builtin_fmaf(a.m[6], r, __builtin_fmaf(a.m[7], g, a.m[8] * b));
@@ -449,7 +471,12 @@ __global__ __launch_bounds__(kMacThreads) void mac_mod_generic_kernel(const MacG
     }
     __syncthreads();
     float *o = a.out + ((long long)f * a.H + out_row) * ga.CW;
-    for (int m = t; m < ga.CW; m += kMacThreads) o[m] = mac_resample_at(lin, kMacLine, ga.line_out, m);              // mac.py:71-74
+    unsigned char *o8 = (unsigned char *)a.out + ((long long)f * a.H + out_row) * ga.CW;
+    for (int m = t; m < ga.CW; m += kMacThreads) {
+        const float v = mac_resample_at(lin, kMacLine, ga.line_out, m);              // mac.py:71-74
+        if (U8) o8[m] = (unsigned char)__builtin_rintf(255.f * __builtin_fminf(__builtin_fmaxf(__builtin_fmaf(0.6f, v, 0.2f), 0.f), 1.f));
+        else o[m] = v;
+    }
 }
 
 }  // namespace cm

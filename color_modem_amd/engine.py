@@ -247,11 +247,38 @@ class MacEngine(object):
                                                            int(first_frame), stream))
         return out.cpu().numpy() if was_numpy else out
 
+    def _as_device_u8(self, x, shape_tail):
+        torch = _torch()
+        was_numpy = isinstance(x, numpy.ndarray)
+        t = torch.from_numpy(numpy.ascontiguousarray(x, dtype=numpy.uint8)) if was_numpy else x
+        if t.dtype != torch.uint8 or tuple(t.shape[1:]) != tuple(shape_tail):
+            raise ValueError('expected uint8 [frames, %s]' % ', '.join(map(str, shape_tail)))
+        return (t.cuda() if not t.is_cuda else t).contiguous(), was_numpy
+
     def demodulate_frames_u8(self, composite8, first_frame=0, out=None):
-        raise NotImplementedError('the MAC kernels have no fused byte boundary (ImageModem converts on the host)')
+        """uint8 lines [F, H, line width] -> interleaved uint8 rgb [F, H, 720, 3], ImageModem's level mapping and rounding
+        fused into the kernel (the resampling kernels serve every shape here)."""
+        torch = _torch()
+        t, was_numpy = self._as_device_u8(composite8, (self.height, self.comp_width))
+        n = t.shape[0]
+        if out is None:
+            out = torch.empty((n, self.height, self.width, 3), dtype=torch.uint8, device=t.device)
+        stream = torch.cuda.current_stream(t.device).cuda_stream
+        _native.check(_native.lib().cm_mac_demodulate_frames_u8(self._plan, t.data_ptr(), out.data_ptr(), n, int(first_frame), stream))
+        return out.cpu().numpy() if was_numpy else out
 
     def modulate_frames_u8(self, rgb8, first_frame=0, out=None):
-        raise NotImplementedError('the MAC kernels have no fused byte boundary (ImageModem converts on the host)')
+        """interleaved uint8 rgb [F, H, W, 3] -> uint8 lines [F, H, line width]."""
+        torch = _torch()
+        t, was_numpy = self._as_device_u8(rgb8, (self.height, self.in_width, 3))
+        n = t.shape[0]
+        if self.height < 2 * self.modulation_delay and n:
+            raise IndexError('image.py:49-50 feeds row 1 ahead of a field under modulation_delay 1: the image has %d row(s)' % self.height)
+        if out is None:
+            out = torch.empty((n, self.height, self.comp_width), dtype=torch.uint8, device=t.device)
+        stream = torch.cuda.current_stream(t.device).cuda_stream
+        _native.check(_native.lib().cm_mac_modulate_frames_u8(self._plan, t.data_ptr(), out.data_ptr(), n, int(first_frame), stream))
+        return out.cpu().numpy() if was_numpy else out
 
     def demodulate_run(self, rows, frame, first_line, k0):
         torch = _torch()

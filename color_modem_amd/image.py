@@ -61,7 +61,7 @@ class ImageModem(object):
         rgb8 = numpy.frombuffer(img.tobytes(), dtype=numpy.uint8).reshape(img.height, img.width, 3)
         try:  # byte boundary fused into the kernel (widths that are multiples of 16)
             comp8 = self._engine().modulate_frames_u8(rgb8[None].copy(), frame)[0]
-            return Image.frombytes('L', (img.width, img.height), numpy.ascontiguousarray(comp8).tobytes())
+            return Image.frombytes('L', (comp8.shape[1], comp8.shape[0]), numpy.ascontiguousarray(comp8).tobytes())
         except NotImplementedError:
             pass
         rgb = (rgb8.astype(numpy.float64) / 255.0).astype(numpy.float32).transpose(2, 0, 1)[None]
@@ -76,7 +76,7 @@ class ImageModem(object):
         comp8 = numpy.frombuffer(img.tobytes(), dtype=numpy.uint8).reshape(img.height, img.width).copy()
         try:  # byte boundary fused into the kernel where this stack has an instance (all but notch / minavg)
             rgb8 = self._engine().demodulate_frames_u8(comp8[None], frame)[0]
-            return Image.frombytes('RGB', (img.width, img.height), numpy.ascontiguousarray(rgb8).tobytes())
+            return Image.frombytes('RGB', (rgb8.shape[1], rgb8.shape[0]), numpy.ascontiguousarray(rgb8).tobytes())
         except NotImplementedError:
             pass
         comp = self.decode_composite_level(comp8.astype(numpy.float64) / 255.0).astype(numpy.float32)[None]

@@ -239,6 +239,12 @@ int cm_mac_modulate_frames(const cm_mac_plan *plan, const float *rgb, float *com
 /* composite [n_frames][height][line_width] -> rgb [n_frames][3][height][720] (image.py:75-83). */
 int cm_mac_demodulate_frames(const cm_mac_plan *plan, const float *composite, float *rgb, int64_t n_frames,
                              int64_t first_frame, void *stream);
+/* The same with ImageModem's byte boundary fused in (image.py:7-8, 20-25, 43-45, 62): rgb8 interleaved uint8
+ * [n_frames][height][width][3] -> composite8 uint8 [n_frames][height][line_width] -> rgb8 [n_frames][height][720][3]. */
+int cm_mac_modulate_frames_u8(const cm_mac_plan *plan, const uint8_t *rgb8, uint8_t *composite8, int64_t n_frames,
+                              int64_t first_frame, void *stream);
+int cm_mac_demodulate_frames_u8(const cm_mac_plan *plan, const uint8_t *composite8, uint8_t *rgb8, int64_t n_frames,
+                                int64_t first_frame, void *stream);
 /* One run of n_calls consecutive calls (lines first_line, first_line + 2, ...), the first being the k0-th call since
  * the modem's reset; rows [n_calls][3][width] / [n_calls][line_width].  Row 0 has no history inside the buffers: with
  * k0 > 0 its output is unspecified (the caller submits one row of history, as for cm_demodulate_run). */

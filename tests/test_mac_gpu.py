@@ -175,6 +175,29 @@ def test_resampled_against_oracle(width, line_width):
         assert stacks.rel_err(numpy.stack(got3), numpy.stack(exp3)) < TOL
 
 
+@pytest.mark.parametrize('width,line_width,averaging', [(720, 1080, False), (720, 1080, True), (768, 720, True), (1000, 900, False)])
+def test_fused_byte_boundary(width, line_width, averaging):
+    """cm_mac_*_frames_u8 against the float kernels with ImageModem's conversions on the host (image.py:7-8, 20-25, 43-45)."""
+    from color_modem_amd.image import _as_bytes
+    H = 14
+    lc = line.LineConfig((width, H), STD)
+    enc = mac.MacModem(lc, line_width)
+    im = image.ImageModem(comb.ColorAveragingModem(enc) if averaging else enc)
+    rgb8 = _as_bytes(testing.synthetic_rgb(3, H, width, seed=width + 1).astype(numpy.float64)).transpose(0, 2, 3, 1).copy()
+    comp8 = im.modulate_frames_u8(rgb8, first_frame=5)
+    assert comp8.dtype == numpy.uint8 and comp8.shape == (3, H, line_width)
+    rgbf = (rgb8.astype(numpy.float64) / 255.0).astype(numpy.float32).transpose(0, 3, 1, 2)
+    want8 = _as_bytes(image.ImageModem.encode_composite_level(im.modulate_frames(numpy.ascontiguousarray(rgbf), first_frame=5).astype(numpy.float64)))
+    d = numpy.abs(comp8.astype(int) - want8.astype(int))
+    assert d.max() <= 1 and (d > 0).mean() < 2e-3
+    back8 = im.demodulate_frames_u8(want8, first_frame=5)
+    assert back8.shape == (3, H, 720, 3)
+    comp = image.ImageModem.decode_composite_level(want8.astype(numpy.float64) / 255.0).astype(numpy.float32)
+    wantb = _as_bytes(im.demodulate_frames(comp, first_frame=5).astype(numpy.float64)).transpose(0, 2, 3, 1)
+    d = numpy.abs(back8.astype(int) - wantb.astype(int))
+    assert d.max() <= 1 and (d > 0).mean() < 2e-3
+
+
 def test_limits_fail_loudly():
     with pytest.raises(NotImplementedError):
         mac.MacModem(line.LineConfig((2048, 8), STD))
@@ -183,6 +206,4 @@ def test_limits_fail_loudly():
     im = image.ImageModem(make(8))
     with pytest.raises(ValueError):
         im.demodulate_frames(numpy.zeros((1, 8, 720), dtype=numpy.float32))
-    with pytest.raises(NotImplementedError):
-        im.demodulate_frames_u8(numpy.zeros((1, 8, 1080), dtype=numpy.uint8))
     assert im.demodulate_frames(numpy.zeros((0, 8, 1080), dtype=numpy.float32)).shape == (0, 3, 8, 720)
