@@ -452,9 +452,9 @@ int run_secam_demod(const cm_plan *p, Geom g, hipStream_t stream, bool u8 = fals
     a.k = p->sd_k;
     // the wave pair with the luma delay ring where the delay fits the ring (cm_secam_kernels.h), else one wave per 64 calls
     const int d_luma = p->sd_k.s_b + 20 + p->sd_k.q_l - p->sd_k.s_y;
-    if (CM_SECAM_PAIR && d_luma >= 0 && d_luma <= kSecamPairMaxLumaDelay) {
-        if (u8) hipLaunchKernelGGL(secam_demod_pair_kernel<true>, dim3((int)blocks), dim3(128), 0, stream, a);
-        else hipLaunchKernelGGL(secam_demod_pair_kernel<false>, dim3((int)blocks), dim3(128), 0, stream, a);
+    if (CM_SECAM_PAIR && d_luma >= 4 && d_luma <= kSecamPairMaxLumaDelay) {
+        if (u8) hipLaunchKernelGGL(secam_demod_pair_kernel<true>, dim3((int)blocks), dim3(128), sizeof(float) * secam_pair_lds_floats<true>(d_luma), stream, a);
+        else hipLaunchKernelGGL(secam_demod_pair_kernel<false>, dim3((int)blocks), dim3(128), sizeof(float) * secam_pair_lds_floats<false>(d_luma), stream, a);
     } else if (u8) hipLaunchKernelGGL(secam_demod_kernel<true>, dim3((int)blocks), dim3(64), 0, stream, a);
     else hipLaunchKernelGGL(secam_demod_kernel<false>, dim3((int)blocks), dim3(64), 0, stream, a);
     hipError_t e = hipGetLastError();

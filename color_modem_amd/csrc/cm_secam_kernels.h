@@ -174,23 +174,24 @@ __global__ __launch_bounds__(64, 2) void secam_demod_kernel(const SecamDemodArgs
 //                     colour-difference signal from the neighbouring lane, matrix, output tile and every global store
 // One s_barrier per body: A after writing block b, B before reading it.
 // ---------------------------------------------------------------------------------------------------------------------
-// Off by default: parity-green (the 36 SECAM GPU tests) but 3.96 ms against 3.48 ms per 1000 frames for the one-wave kernel -
-// 38 KiB of LDS leave 4 workgroups = 2 waves per SIMD, and half a line per wave has too little independent work for that
-// (profiles/r01_pair_notes.md section 10).  -DCM_SECAM_PAIR=1 selects it.
+// Off by default: parity-green (the 36 SECAM GPU tests) but 4.0 - 4.1 ms against 3.5 ms per 1000 frames for the one-wave
+// kernel (profiles/r01_pair_notes.md section 10).  -DCM_SECAM_PAIR=1 selects it.
 #ifndef CM_SECAM_PAIR
 #define CM_SECAM_PAIR 0
 #endif
 constexpr int kSecamMid = 2 * 4 * 256;        // floats: [buffer][I0 | Q0 | I1 | Q1][lane][4 steps]
-constexpr int kSecamLumaBlocks = 14;          // delay ring blocks of [lane][4 samples]: d_luma <= 4 * (blocks - 2) + 3
-constexpr int kSecamPairMaxLumaDelay = 4 * (kSecamLumaBlocks - 2) + 3;
+constexpr int kSecamPairMaxLumaDelay = 4 + 4 * 14 + 3;   // delay ring of at most 16 blocks of [lane][4 samples]
+template <bool U8> constexpr int secam_pair_lds_floats(int d_luma) {
+    return (U8 ? 64 * kInTile / 4 : 64 * 16) + kSecamMid + (U8 ? 64 * 3 * 16 / 4 : 3 * 64 * 16) + (((d_luma - 4) >> 2) + 2) * 256;
+}
 
 template <bool U8>
 __global__ __launch_bounds__(128, 2) void secam_demod_pair_kernel(const SecamDemodArgs args) {
     constexpr int kTile = 16, DEPTH = 1;
     constexpr int kIT = U8 ? kInTile : 16;                                   // samples per input tile row
     constexpr int kIn = U8 ? 64 * kInTile / 4 : 64 * kIT, kOut = U8 ? 64 * 3 * kTile / 4 : 3 * 64 * kTile;   // floats
-    __shared__ __attribute__((aligned(16))) float lds_store[kIn + kSecamMid + kOut + kSecamLumaBlocks * 256];
-    lds_float *itile = (lds_float *)lds_store;
+    extern __shared__ __attribute__((aligned(16))) float secam_pair_lds[];   // kIn + kSecamMid + kOut + blocks * 256 floats
+    lds_float *itile = (lds_float *)secam_pair_lds;
     lds_float *ring = itile + kIn;
     lds_float *otile_base = ring + kSecamMid;
     lds_float *xring = otile_base + kOut;
@@ -212,7 +213,9 @@ __global__ __launch_bounds__(128, 2) void secam_demod_pair_kernel(const SecamDem
     const int n_pre = (P - m_start) >> 2;
     const int T = (g.Wp + lat_out + 3) & ~3;
     const int n_bodies = n_pre + (T >> 2);
-    const int lr_o = d_luma & 3, lr_m = d_luma >> 2;        // A writes x[xb - lr_o .. + 3]; B reads it lr_m bodies later
+    // A writes x[xb - 4 - lr_o .. + 3] (out of the samples of its last two bodies); B reads it lr_m bodies later
+    const int lr_o = (d_luma - 4) & 3, lr_m = (d_luma - 4) >> 2;
+    const int n_blocks = lr_m + 2;                          // delay ring blocks (the host sizes the LDS with the same number)
 
     if (role == 0) {
         // =================================== stage A ===========================================
@@ -231,8 +234,15 @@ __global__ __launch_bounds__(128, 2) void secam_demod_pair_kernel(const SecamDem
         for (int j = 0; j < 14; ++j) chw[j] = 0.f;
         const lds_float *xrow = itile + lane * kIT;
         const lds_u8 *xrow8 = (const lds_u8 *)itile + lane * kInTile;
-        for (int j = 0; j < kSecamLumaBlocks; ++j) *(lds_f4 *)(xring + j * 256 + lane * 4) = f4{0.f, 0.f, 0.f, 0.f};
-        if (U8) fill_tile_u8(g, itile, xp, 0, lane); else fill_tile<kIT>(g, itile, xp, 0, lane);
+        for (int j = 0; j < n_blocks; ++j) *(lds_f4 *)(xring + j * 256 + lane * 4) = f4{0.f, 0.f, 0.f, 0.f};
+        // the mirrored pre-roll wants x[1 .. P]: float rows get a 32-sample copy of the row start in the (still unused)
+        // output tile area, byte tiles are 32 samples wide anyway
+        const lds_float *pre_row = otile_base + lane * kInTile;
+        if (U8) fill_tile_u8(g, itile, xp, 0, lane);
+        else {
+            fill_tile<kIT>(g, itile, xp, 0, lane);
+            if (P < kInTile) fill_tile<kInTile>(g, otile_base, xp, 0, lane);
+        }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_wave_barrier();
         auto read_x = [&](int first) -> f4 {
@@ -247,7 +257,7 @@ __global__ __launch_bounds__(128, 2) void secam_demod_pair_kernel(const SecamDem
             }
             return v;
         };
-        f4 xv = {0.f, 0.f, 0.f, 0.f}, xprev = xv;
+        f4 xv = {0.f, 0.f, 0.f, 0.f}, xprev = xv, xprev2 = xv;
         int xw = 0;      // delay ring block of this body
         for (int b = 0; b < n_bodies; ++b) {
             const bool pre = b < n_pre;
@@ -262,8 +272,8 @@ __global__ __launch_bounds__(128, 2) void secam_demod_pair_kernel(const SecamDem
                     if (m >= 0) {      // cc[m] = x[P - m] (secam.py:283-284)
                         int xi = P - m;
                         if (xi > W - 1) xi = W - 1;
-                        if (P < kIT)
-                            cc = U8 ? __builtin_fmaf((float)xrow8[xi], 5.0f / (255.0f * 3.0f), -1.0f / 3.0f) : xrow[xi];
+                        if (P < kInTile)
+                            cc = U8 ? __builtin_fmaf((float)xrow8[xi], 5.0f / (255.0f * 3.0f), -1.0f / 3.0f) : pre_row[xi];
                         else
                             cc = U8 ? __builtin_fmaf((float)((const unsigned char *)xp)[xi], 5.0f / (255.0f * 3.0f), -1.0f / 3.0f) : xp[xi];
                     }
@@ -284,9 +294,10 @@ __global__ __launch_bounds__(128, 2) void secam_demod_pair_kernel(const SecamDem
             // the row samples the luma filter meets d_luma steps from now: x[xb - lr_o .. + 3] (zeros in the pre-roll)
             f4 blk = {0.f, 0.f, 0.f, 0.f};
             if (!pre) {
-                blk = lr_o == 0 ? xv
-                    : lr_o == 1 ? f4{xprev.w, xv.x, xv.y, xv.z}
-                    : lr_o == 2 ? f4{xprev.z, xprev.w, xv.x, xv.y} : f4{xprev.y, xprev.z, xprev.w, xv.x};
+                blk = lr_o == 0 ? xprev
+                    : lr_o == 1 ? f4{xprev2.w, xprev.x, xprev.y, xprev.z}
+                    : lr_o == 2 ? f4{xprev2.z, xprev2.w, xprev.x, xprev.y} : f4{xprev2.y, xprev2.z, xprev2.w, xprev.x};
+                xprev2 = xprev;
                 xprev = xv;
                 const int nxt = xb + 4;
                 if ((nxt & (kIT - 1)) == 0 && nxt < W) {   // first read of a new tile: its fill was issued a body ago
@@ -306,7 +317,7 @@ __global__ __launch_bounds__(128, 2) void secam_demod_pair_kernel(const SecamDem
             *(lds_f4 *)(slot + 512) = f4{yi1[0], yi1[1], yi1[2], yi1[3]};
             *(lds_f4 *)(slot + 768) = f4{yq1[0], yq1[1], yq1[2], yq1[3]};
             *(lds_f4 *)(xring + xw * 256 + lane * 4) = blk;
-            xw = xw + 1 == kSecamLumaBlocks ? 0 : xw + 1;
+            xw = xw + 1 == n_blocks ? 0 : xw + 1;
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         }
         return;
@@ -328,14 +339,14 @@ __global__ __launch_bounds__(128, 2) void secam_demod_pair_kernel(const SecamDem
     lds_float *otile = U8 ? (lds_float *)((lds_u8 *)otile_base + lane * 3 * kTile) : otile_base + lane * kTile;
     const int wpos = ((lane >> CM_TILE_SWZ) & (kTile / 4 - 1)) << 2;
     float own_prev = 0.f, nb_prev = 0.f;
-    int xr = lr_m == 0 ? 0 : kSecamLumaBlocks - lr_m;    // delay ring block of body b: lr_m bodies behind A's
+    int xr = lr_m == 0 ? 0 : n_blocks - lr_m;    // delay ring block of body b: lr_m bodies behind A's
     for (int b = 0; b < n_bodies; ++b) {
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // block b of the ring is complete
         const lds_float *slot = ring + (b & 1) * (kSecamMid / 2) + lane * 4;
         const f4 i0 = *(const lds_f4 *)slot, q0 = *(const lds_f4 *)(slot + 256);
         const f4 i1 = *(const lds_f4 *)(slot + 512), q1 = *(const lds_f4 *)(slot + 768);
         const f4 lw = *(const lds_f4 *)(xring + xr * 256 + lane * 4);
-        xr = xr + 1 == kSecamLumaBlocks ? 0 : xr + 1;
+        xr = xr + 1 == n_blocks ? 0 : xr + 1;
         const int xb = (b - n_pre) << 2;
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
