@@ -589,8 +589,12 @@ struct SecamDemodPkA {
         if (m2 >= 0 && m2 < Lc + k.q_l) {
             if (m2 == Lc - 1) p_last = p_o;
             if (m2 >= Lc) p_e = p_o = p_last;
+#ifdef CM_EXP_SECAM_NO_LPF   /* timing experiment (results wrong) */
+            y0 = p_e; y1 = p_o;
+#else
             y0 = iir_sym_pk<0, 3>(lp, kp.lpf, p_e);
             y1 = iir_sym_pk<0, 3>(lp, kp.lpf, p_o);
+#endif
             if (k.odd_l) {
                 const pf2 h = iq_hold;
                 iq_hold = y1;
@@ -621,8 +625,12 @@ struct SecamDemodPkB {
         const int m2 = m - k.s_b - 10, m3 = m2 - k.q_l, m4 = m3 - 9, n = m4 - k.preroll;
         float f_e = 0.f, f_o = 0.f;
         if (m2 >= 0 && m2 < Lc + k.q_l && m3 >= 0 && m3 < Lc) {
+#ifdef CM_EXP_SECAM_NO_PHASE   /* timing experiment (results wrong) */
+            const float d_e = y0.x, d_o = y1.y;
+#else
             const float d_e = have_prev ? phase_step_fast(iq_prev.x, iq_prev.y, y0.x, y0.y) : 0.f;  // secam.py:147: first step is 0
             const float d_o = phase_step_fast(y0.x, y0.y, y1.x, y1.y);
+#endif
             have_prev = 1;
             iq_prev = y1;
             f_e = d_e * k.two_over_pi;
