@@ -429,7 +429,7 @@ struct DemodBackPk {
 // definition; this is the same stream with (I, Q) = data_up * (cos, -sin) carried through the low-pass two at a time).
 // The phase step between consecutive I/Q samples is small for an FM signal inside the channel (|d| < 0.15 rad at
 // +-500 kHz): atan(r), r = cross / dot, from five odd terms when dot > 0 and |r| <= 1/4 (truncation 2e-8 rad,
-// v_rcp_f32 1 ulp), the library atan2f otherwise (noise, unlocked input).
+// v_rcp_f32 1 ulp), the library atan2f otherwise (noise, unlocked input, the first samples of a row).
 // =============================================================================================
 __device__ __forceinline__ float phase_step_fast(float i0, float q0, float i1, float q1) {
     // angle of (i1 + j q1) * conj(i0 + j q0); the cross product with an error-free correction (SecamDemod::phase_step)
@@ -437,7 +437,11 @@ __device__ __forceinline__ float phase_step_fast(float i0, float q0, float i1, f
     const float e = __builtin_fmaf(-q0, i1, t);
     const float cross = __builtin_fmaf(i0, q1, -t) + e;
     const float dot = __builtin_fmaf(i0, i1, q0 * q1);
+#ifdef CM_EXP_SECAM_ALWAYS_FAST   /* timing experiment: never the library atan2f (results wrong for large steps) */
+    if (true) {
+#else
     if (dot > 0.f && __builtin_fabsf(cross) <= 0.25f * dot) {
+#endif
         const float r = cross * __builtin_amdgcn_rcpf(dot);
         const float z = r * r;
         float p = __builtin_fmaf(z, 1.0f / 9.0f, -1.0f / 7.0f);
