@@ -163,8 +163,8 @@ def main():
             'roofline': {'bound': 'hbm', 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
                          'frac': round(achieved / HBM_PEAK_GBPS, 4), 'traffic': traffic,
                          'kernel_ms': round(mean_kernel_ms, 4), 'algorithmic_bytes_per_launch': BYTES_PER_PIXEL * px_step,
-                         'note': 'traffic = 1.03 x algorithmic (every byte moves once); not bandwidth-bound: ~229 float32 FMA-equivalents per pixel = '
-                                 '~78 TFLOP/s, 65 % of the 119 TFLOP/s a pure v_fma_f32 loop sustains at the 1400 W power cap '
+                         'note': 'traffic = 1.02 x algorithmic (every byte moves once); not bandwidth-bound: ~229 float32 FMA-equivalents per pixel = '
+                                 '~80 TFLOP/s, 67 % of the 119 TFLOP/s a pure v_fma_f32 loop sustains at the 1400 W power cap '
                                  '(profiles/r01_pair_notes.md, DESIGN.md section 5)'},
         }
         if world == 1 and args.cpu_sample > 0:

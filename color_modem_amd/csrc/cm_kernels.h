@@ -129,6 +129,17 @@ typedef const __attribute__((address_space(4))) f16u const_f16;
 #ifndef CM_LUMA_RING
 #define CM_LUMA_RING 1
 #endif
+// LDS budget knobs of the pair kernels (profiles/r01_pair_notes.md section 11): samples per float input tile row (8: 32-byte
+// row segments, 2 KiB) and extra x samples stage A of the PAL-D front end keeps in registers behind its 14-sample window (a
+// multiple of 4; every 4 shorten the delay ring by one 1 KiB block).  8 / 12 bring the PAL-BG decoder from 31 to 26 KiB =
+// 6 workgroups per CU (measured 2.86 -> 2.74 ms per 1000 frames against 16 / 0; either knob alone changes nothing).
+#ifndef CM_PAIR_TILE
+#define CM_PAIR_TILE 8
+#endif
+#ifndef CM_RING_WINDOW
+#define CM_RING_WINDOW 12
+#endif
+template <class S, int FRONT> constexpr int ring_window() { return (FRONT == 1 && !S::RT && S::NE < 3) ? CM_RING_WINDOW : 0; }
 // Output tiles are [row = lane][kTile samples]; the 16-byte quad a lane writes is XORed with lane bits CM_TILE_SWZ, +1 so that
 // the one ds_write_b32 per plane and step of 64 lanes spreads over more banks (rows are 64 bytes apart).
 #ifndef CM_TILE_SWZ
@@ -166,7 +177,7 @@ struct PassCfg {
     static constexpr int kLdsFloats = kLdsInF + kLdsOut + (BSF_ ? kLdsRing : 0);
     // wave-pair kernels: float rows enter through 16-sample tiles (64-byte row segments) when the luma delay ring takes the
     // LDS (CM_LUMA_RING); byte tiles stay 32 samples wide
-    static constexpr int kPairInTile = (U8_ || !CM_LUMA_RING) ? kInTile : 16;
+    static constexpr int kPairInTile = (U8_ || !CM_LUMA_RING) ? kInTile : CM_PAIR_TILE;
     static constexpr int kPairLdsIn = U8_ ? 64 * kInTile / 4 : 64 * kPairInTile;   // floats
     // wave-pair kernels: 3 waves per SIMD need <= 168 VGPRs; the instances with more per-lane state in stage B (a second
     // line of history, the notch, the second combination of minavg) would spill there and get 2 waves per SIMD instead
@@ -731,14 +742,14 @@ constexpr int kLumaSlots = 2 * 64 * 4;      // floats: [buffer][lane][4 steps] l
 // CM_LUMA_RING: blocks of [lane][4 steps] x samples; A writes x[tb - 10 + o .. + 3] at the end of body tb, B reads the block
 // m bodies later, lat_out = 4 m + 10 - o; A runs at most two blocks ahead of B's read, so m + 2 blocks are live
 // (the host checks lat_out against this: cm_api.hip).  11 KiB for PAL-BG (lat_out 46 = the limit), 12 KiB for the order-6 band-pass shapes, 20 KiB for the run-time shape.
-template <class S> constexpr int luma_delay_blocks() { return S::RT ? 20 : (S::NE >= 3 ? 12 : 11); }
-template <class S> constexpr int luma_delay_max_latency() { return 4 * (luma_delay_blocks<S>() - 2) + 10; }
+template <class S, int FRONT = 0> constexpr int luma_delay_blocks() { return S::RT ? 20 : (S::NE >= 3 ? 12 : 11 - ring_window<S, FRONT>() / 4); }
+template <class S, int FRONT = 0> constexpr int luma_delay_max_latency() { return 4 * (luma_delay_blocks<S, FRONT>() - 2) + 10 + ring_window<S, FRONT>(); }
 
 template <class Cfg>
 struct PairLds {
     static constexpr int kIn = Cfg::kPairLdsIn, kOut = Cfg::kLdsOut;
     static constexpr int kY = Cfg::BSF ? luma_ring_slots<typename Cfg::S>() * 64
-                                       : (CM_LUMA_RING ? luma_delay_blocks<typename Cfg::S>() * 256 : kLumaSlots);
+                                       : (CM_LUMA_RING ? luma_delay_blocks<typename Cfg::S, Cfg::FRONT>() * 256 : kLumaSlots);
     static constexpr int kFloats = kIn + kMidRing + kOut + kY;
 };
 template <>
@@ -769,7 +780,8 @@ __device__ __forceinline__ void run_pair(const Geom &g, const DemodK<float, type
     constexpr int kYSlots = luma_ring_slots<S>();
     constexpr bool LRING = CM_LUMA_RING && !BSF;         // luma source samples through the LDS delay ring
     constexpr int kIT = Cfg::kPairInTile;                // samples per input tile row
-    constexpr int kLB = luma_delay_blocks<S>();
+    constexpr int kLB = luma_delay_blocks<S, FRONT>();
+    constexpr int kWinX = ring_window<S, FRONT>();        // extra x samples stage A keeps behind its window
     typedef typename std::conditional<PALD, PalDFront<float, S>, QamFront<float, S, BSF>>::type Front;
     typedef typename Front::StageA StageA;
     typedef typename Front::StageB StageB;
@@ -809,7 +821,7 @@ __device__ __forceinline__ void run_pair(const Geom &g, const DemodK<float, type
     lds_float *lring = yring;   // luma hand-off slots share the place of the band-stop ring (the two exclude each other)
     // delay ring: A leaves x[tb - 10 + lr_o .. + 3] at the end of body tb, B needs x_l[tb - lat_out .. + 3] at the start of
     // body tb, i.e. the block A wrote lr_m bodies before: lat_out = 4 lr_m + 10 - lr_o
-    const int lr_o = (10 - lat_out) & 3, lr_m = (lat_out - 10 + lr_o) >> 2;
+    const int lr_o = (10 + kWinX - lat_out) & 3, lr_m = (lat_out - 10 - kWinX + lr_o) >> 2;
 
     if (role == 0) {
         // =================================== stage A ===========================================
@@ -825,6 +837,9 @@ __device__ __forceinline__ void run_pair(const Geom &g, const DemodK<float, type
         StageA fa;
         fa.reset();
         float xw[14], ew[PALD ? 14 : 1];
+        float xo[kWinX >= 8 ? kWinX : 1];        // x[tb - 10 - kWinX ..]: older than xw
+#pragma unroll
+        for (int j = 0; j < (kWinX >= 8 ? kWinX : 1); ++j) xo[j] = 0.f;
 #pragma unroll
         for (int j = 0; j < 14; ++j) xw[j] = 0.f;
 #pragma unroll
@@ -885,9 +900,10 @@ __device__ __forceinline__ void run_pair(const Geom &g, const DemodK<float, type
             const f4 lum_next = read_luma(tb + 4 - lat_out, EDGE_A || tb + 4 >= t_mid1);
             f4 lum_blk = {0.f, 0.f, 0.f, 0.f};
             if (LRING) {   // x[tb - 10 + lr_o .. + 3] out of the window (xw[j] = x[tb - 10 + j], zero outside the row)
-                lum_blk = lr_o == 0 ? f4{xw[0], xw[1], xw[2], xw[3]}
-                        : lr_o == 1 ? f4{xw[1], xw[2], xw[3], xw[4]}
-                        : lr_o == 2 ? f4{xw[2], xw[3], xw[4], xw[5]} : f4{xw[3], xw[4], xw[5], xw[6]};
+                const float *xs = kWinX >= 8 ? xo : xw;     // the oldest samples of the window
+                lum_blk = lr_o == 0 ? f4{xs[0], xs[1], xs[2], xs[3]}
+                        : lr_o == 1 ? f4{xs[1], xs[2], xs[3], xs[4]}
+                        : lr_o == 2 ? f4{xs[2], xs[3], xs[4], xs[5]} : f4{xs[3], xs[4], xs[5], xs[6]};
             }
             float me[4], mo[4];
             sub_a(std::integral_constant<int, 0>(), edge_tag, fla, tb + 0, me[0], mo[0]);
@@ -895,6 +911,12 @@ __device__ __forceinline__ void run_pair(const Geom &g, const DemodK<float, type
             sub_a(std::integral_constant<int, 2>(), edge_tag, fla, tb + 2, me[2], mo[2]);
             sub_a(std::integral_constant<int, 3>(), edge_tag, fla, tb + 3, me[3], mo[3]);
             const int nxt = tb + 4;
+            if (kWinX >= 8) {
+#pragma unroll
+                for (int j = 0; j + 4 < kWinX; ++j) xo[kWinX >= 8 ? j : 0] = xo[kWinX >= 8 ? j + 4 : 0];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) xo[kWinX >= 8 ? kWinX - 4 + j : 0] = xw[j];
+            }
 #pragma unroll
             for (int j = 0; j < 10; ++j) xw[j] = xw[j + 4];
             if ((nxt & (kIT - 1)) == 0 && nxt < W) {  // first read of a new tile: its fill was issued a body ago
