@@ -114,7 +114,7 @@ bool make_pass(const cm_plan_desc &d, bool pald, bool bsf, const cm_lane_table &
         const int luma_lag = lat_out - (10 + k.q_r + 9);   // steps between the band-stop luma sample and its use
         if (bsf && (pair ? luma_lag + 12 > luma_ring_slots<S>() : luma_lag > 15)) { err = "band-stop luma delay beyond its LDS ring"; return false; }
         if (CM_LUMA_RING && !bsf && pair && (pald ? lat_out > luma_delay_max_latency<S, 1>() : lat_out > luma_delay_max_latency<S, 0>())) { err = "pipeline latency beyond the luma delay ring"; return false; }
-        if (CM_LUMA_RING && !bsf && pair && pald && lat_out < 10 + ring_window<S, 1>()) { err = "pipeline latency below the luma window"; return false; }
+        if (CM_LUMA_RING && !bsf && pair && lat_out < 10 + (pald ? ring_window<S, 1>() : ring_window<S, 0>())) { err = "pipeline latency below the luma window"; return false; }
     }
     pass.k.resize(sizeof(k));
     std::memcpy(pass.k.data(), &k, sizeof(k));

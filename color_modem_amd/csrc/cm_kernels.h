@@ -139,7 +139,15 @@ typedef const __attribute__((address_space(4))) f16u const_f16;
 #ifndef CM_RING_WINDOW
 #define CM_RING_WINDOW 12
 #endif
-template <class S, int FRONT> constexpr int ring_window() { return (FRONT == 1 && !S::RT && S::NE < 3) ? CM_RING_WINDOW : 0; }
+#ifndef CM_RING_WINDOW_QAM
+#define CM_RING_WINDOW_QAM 0
+#endif
+// PAL-D front end on the PAL-BG filter shape: CM_RING_WINDOW; on the order-6 band-pass shapes its stage A has no registers
+// to spare.  QAM front end: CM_RING_WINDOW_QAM (16 brings the NTSC comb decoder to 26 KiB as well, measured without effect:
+// 2.165 ms either way - off).  Run-time shape: none (it runs 4 workgroups per CU).
+template <class S, int FRONT> constexpr int ring_window() {
+    return S::RT ? 0 : (FRONT == 1 ? (S::NE < 3 ? CM_RING_WINDOW : 0) : CM_RING_WINDOW_QAM);
+}
 // Output tiles are [row = lane][kTile samples]; the 16-byte quad a lane writes is XORed with lane bits CM_TILE_SWZ, +1 so that
 // the one ds_write_b32 per plane and step of 64 lanes spreads over more banks (rows are 64 bytes apart).
 #ifndef CM_TILE_SWZ
@@ -900,7 +908,7 @@ __device__ __forceinline__ void run_pair(const Geom &g, const DemodK<float, type
             const f4 lum_next = read_luma(tb + 4 - lat_out, EDGE_A || tb + 4 >= t_mid1);
             f4 lum_blk = {0.f, 0.f, 0.f, 0.f};
             if (LRING) {   // x[tb - 10 + lr_o .. + 3] out of the window (xw[j] = x[tb - 10 + j], zero outside the row)
-                const float *xs = kWinX >= 8 ? xo : xw;     // the oldest samples of the window
+                const float *xs = kWinX >= 8 ? xo : xw;     // the oldest samples of the window (kWinX = 0 or >= 8)
                 lum_blk = lr_o == 0 ? f4{xs[0], xs[1], xs[2], xs[3]}
                         : lr_o == 1 ? f4{xs[1], xs[2], xs[3], xs[4]}
                         : lr_o == 2 ? f4{xs[2], xs[3], xs[4], xs[5]} : f4{xs[3], xs[4], xs[5], xs[6]};
