@@ -94,6 +94,9 @@ struct cm_plan {
     SecamDemodK<float> sd_k;
     SecamDemodLaneK<float> *sd_lanes = nullptr;
     float *fm_ref = nullptr;      // SECAM discriminator reference {cos, sin} pairs
+    double *fm_ref64 = nullptr;   // the same in float64, for the float64 front end (sd_f64)
+    SecamDemodK<double> sd_k64;
+    bool sd_f64 = false;          // decoder shapes whose float32 margin is thin: stage A of the wave pair in float64
     float *fm_dc = nullptr;       // SECAM: decimator response to the constant fc beyond 2 fc (cm_plan.h: build_fm_dc)
     int sd_cycle = 0, sd_n_lines = 0;
     SecamModK<float, double> sm_k;
@@ -425,6 +428,27 @@ bool create_secam(cm_plan *p, const cm_plan_desc &d, std::string &err) {
         err = "device allocation / upload of the FM reference failed";
         return false;
     }
+    {   // Where float32 is too thin for 1e-5: the discriminator divides by the deviation, so its error grows
+        // with fs / fdev; variants without de-emphasis show every row-end transient undamped.  lane entry e[1] = fdev.
+        double fdev_min = 1e9;
+        const size_t n_lanes = (size_t)d.demod_main.frame_cycle * 3 * d.demod_main.n_lines;
+        for (size_t i = 0; i < n_lanes; ++i) {
+            const double fd = d.demod_main.table[i * CM_LANE_DOUBLES + 1];
+            if (fd > 0.0 && fd < fdev_min) fdev_min = fd;
+        }
+        const int d_luma = p->sd_k.s_b + 20 + p->sd_k.q_l - p->sd_k.s_y;
+        const bool thin = d.secam.lf_rev.n_sections == 0 || 2.0 / fdev_min > 100.0;     // fdev is normalised to fs / 2
+        p->sd_f64 = CM_SECAM_F64 && thin && d_luma >= 4 && d_luma <= kSecamPairMaxLumaDelay;
+        if (p->sd_f64) {
+            if (!build_secam_demod_k<double>(d, p->sd_k64, err)) return false;
+            std::vector<double> fm64 = build_fm_reference<double>(d.secam.fm_fc, d.width + d.secam.preroll);
+            if (hipMalloc((void **)&p->fm_ref64, fm64.size() * sizeof(double)) != hipSuccess ||
+                hipMemcpy(p->fm_ref64, fm64.data(), fm64.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) {
+                err = "device allocation / upload of the float64 FM reference failed";
+                return false;
+            }
+        }
+    }
     if (d.mod_main.table) {
         if (!build_secam_mod_k<float, double>(d, p->sm_k, err)) return false;
         if (p->sm_k.s_p < 0 || p->sm_k.s_p > kModAnyShift) { err = "SECAM encoder: pre-correction shift beyond the luma delay window (12)"; return false; }
@@ -453,7 +477,14 @@ int run_secam_demod(const cm_plan *p, Geom g, hipStream_t stream, bool u8 = fals
     a.k = p->sd_k;
     // the wave pair with the luma delay ring where the delay fits the ring (cm_secam_kernels.h), else one wave per 64 calls
     const int d_luma = p->sd_k.s_b + 20 + p->sd_k.q_l - p->sd_k.s_y;
-    if (CM_SECAM_PAIR && d_luma >= 4 && d_luma <= kSecamPairMaxLumaDelay) {
+    if (p->sd_f64) {
+        SecamDemodArgs64 a64;
+        a64.a = a;
+        a64.k64 = p->sd_k64;
+        a64.fm_ref64 = p->fm_ref64;
+        if (u8) hipLaunchKernelGGL(secam_demod_pair64_kernel<true>, dim3((int)blocks), dim3(128), sizeof(float) * secam_pair_lds_floats<true>(d_luma), stream, a64);
+        else hipLaunchKernelGGL(secam_demod_pair64_kernel<false>, dim3((int)blocks), dim3(128), sizeof(float) * secam_pair_lds_floats<false>(d_luma), stream, a64);
+    } else if (CM_SECAM_PAIR && d_luma >= 4 && d_luma <= kSecamPairMaxLumaDelay) {
         if (u8) hipLaunchKernelGGL(secam_demod_pair_kernel<true>, dim3((int)blocks), dim3(128), sizeof(float) * secam_pair_lds_floats<true>(d_luma), stream, a);
         else hipLaunchKernelGGL(secam_demod_pair_kernel<false>, dim3((int)blocks), dim3(128), sizeof(float) * secam_pair_lds_floats<false>(d_luma), stream, a);
     } else if (u8) hipLaunchKernelGGL(secam_demod_kernel<true>, dim3((int)blocks), dim3(64), 0, stream, a);
@@ -691,6 +722,7 @@ void cm_plan_destroy(cm_plan *p) {
     if (p->sd_lanes) (void)hipFree(p->sd_lanes);
     if (p->sm_lanes) (void)hipFree(p->sm_lanes);
     if (p->fm_ref) (void)hipFree(p->fm_ref);
+    if (p->fm_ref64) (void)hipFree(p->fm_ref64);
     if (p->fm_dc) (void)hipFree(p->fm_dc);
     delete p;
 }

@@ -179,14 +179,46 @@ __global__ __launch_bounds__(64, 2) void secam_demod_kernel(const SecamDemodArgs
 #ifndef CM_SECAM_PAIR
 #define CM_SECAM_PAIR 0
 #endif
+// 1: the shapes whose float32 margin is thin (cm_api.hip: create_secam) run on the wave pair with stage A in float64
+#ifndef CM_SECAM_F64
+#define CM_SECAM_F64 1
+#endif
 constexpr int kSecamMid = 2 * 4 * 256;        // floats: [buffer][I0 | Q0 | I1 | Q1][lane][4 steps]
 constexpr int kSecamPairMaxLumaDelay = 4 + 4 * 14 + 3;   // delay ring of at most 16 blocks of [lane][4 samples]
 template <bool U8> constexpr int secam_pair_lds_floats(int d_luma) {
     return (U8 ? 64 * kInTile / 4 : 64 * 16) + kSecamMid + (U8 ? 64 * 3 * 16 / 4 : 3 * 64 * 16) + (((d_luma - 4) >> 2) + 2) * 256;
 }
 
+struct SecamDemodArgs64 {
+    SecamDemodArgs a;
+    SecamDemodK<double> k64;       // the constants of stage A in float64
+    const double *fm_ref64;        // FM reference {cos, sin} pairs in float64 (same layout as g.carrier4)
+};
+
+// F64: stage A in float64 (SecamDemodA64); the launch passes SecamDemodArgs64
+template <bool U8, bool F64, class Args>
+__device__ __forceinline__ void secam_demod_pair_body(const Args &args_in);
+
 template <bool U8>
 __global__ __launch_bounds__(128, 2) void secam_demod_pair_kernel(const SecamDemodArgs args) {
+    secam_demod_pair_body<U8, false>(args);
+}
+template <bool U8>
+__global__ __launch_bounds__(128, 2) void secam_demod_pair64_kernel(const SecamDemodArgs64 args) {
+    secam_demod_pair_body<U8, true>(args);
+}
+
+template <bool F64> struct SecamPairArgs;
+template <> struct SecamPairArgs<false> {
+    static __device__ __forceinline__ const SecamDemodArgs &base(const SecamDemodArgs &a) { return a; }
+};
+template <> struct SecamPairArgs<true> {
+    static __device__ __forceinline__ const SecamDemodArgs &base(const SecamDemodArgs64 &a) { return a.a; }
+};
+
+template <bool U8, bool F64, class Args>
+__device__ __forceinline__ void secam_demod_pair_body(const Args &args_in) {
+    const SecamDemodArgs &args = SecamPairArgs<F64>::base(args_in);
     constexpr int kTile = 16, DEPTH = 1;
     constexpr int kIT = U8 ? kInTile : 16;                                   // samples per input tile row
     constexpr int kIn = U8 ? 64 * kInTile / 4 : 64 * kIT, kOut = U8 ? 64 * 3 * kTile / 4 : 3 * 64 * kTile;   // floats
@@ -227,11 +259,11 @@ __global__ __launch_bounds__(128, 2) void secam_demod_pair_kernel(const SecamDem
         const float *xp;
         if (U8) xp = (const float *)((const unsigned char *)g.in + lc.frame * g.in_frame_stride + (long long)lc.src_row * g.W);
         else xp = g.in + lc.frame * g.in_frame_stride + (long long)lc.src_row * g.Wp;
-        SecamDemodPkA st;
+        typename std::conditional<F64, SecamDemodA64, SecamDemodPkA>::type st;
         st.reset();
-        float chw[14];
+        typename std::conditional<F64, double, float>::type chw[14];
 #pragma unroll
-        for (int j = 0; j < 14; ++j) chw[j] = 0.f;
+        for (int j = 0; j < 14; ++j) chw[j] = 0;
         const lds_float *xrow = itile + lane * kIT;
         const lds_u8 *xrow8 = (const lds_u8 *)itile + lane * kInTile;
         for (int j = 0; j < n_blocks; ++j) *(lds_f4 *)(xring + j * 256 + lane * 4) = f4{0.f, 0.f, 0.f, 0.f};
@@ -282,11 +314,19 @@ __global__ __launch_bounds__(128, 2) void secam_demod_pair_kernel(const SecamDem
                 }
                 int m2 = m - k.s_b - 10;
                 m2 = m2 < 0 ? 0 : (m2 > Lc - 1 ? Lc - 1 : m2);
-                const f4 c = ((const_f4 *)g.carrier4)[m2];
-                float ch_out;
                 pf2 y0, y1;
-                st.step(k, kp, m, cc, chw[s], pf2{c.x, c.y}, pf2{c.z, c.w}, ch_out, y0, y1);
-                chw[10 + s] = ch_out;
+                if constexpr (F64) {
+                    const double *cp = args_in.fm_ref64 + 4 * (long long)m2;
+                    const double car[4] = {cp[0], cp[1], cp[2], cp[3]};
+                    double ch_out;
+                    st.step(args_in.k64, m, (double)cc, chw[s], car, ch_out, y0, y1);
+                    chw[10 + s] = ch_out;
+                } else {
+                    const f4 c = ((const_f4 *)g.carrier4)[m2];
+                    float ch_out;
+                    st.step(k, kp, m, cc, chw[s], pf2{c.x, c.y}, pf2{c.z, c.w}, ch_out, y0, y1);
+                    chw[10 + s] = ch_out;
+                }
                 yi0[s] = y0.x; yq0[s] = y0.y; yi1[s] = y1.x; yq1[s] = y1.y;
             }
 #pragma unroll

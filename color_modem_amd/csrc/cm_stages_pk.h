@@ -609,6 +609,57 @@ struct SecamDemodPkA {
     }
 };
 
+// Stage A with the whole chroma front end in float64 (scalar): for the SECAM shapes whose float32 margin is thin - the
+// variants without de-emphasis and sampling rates from about 24 MHz on, where isolated samples near a row end (small
+// band-passed sub-carrier, ill-conditioned angle) miss 1e-5 in float32.  (I, Q) leave as float32: rounding
+// them keeps their RELATIVE precision, which is what the angle needs.
+struct SecamDemodA64 {
+    IirState<double, 3> bpf;
+    IirState<double, 1> bell;
+    IirState<double, 3> lp_i, lp_q;
+    HalfbandChain<double> up;
+    double cc_last, pi_last, pq_last, i_hold, q_hold;
+
+    __device__ __forceinline__ void reset() {
+        bpf.reset(); bell.reset(); lp_i.reset(); lp_q.reset(); up.reset();
+        cc_last = pi_last = pq_last = i_hold = q_hold = 0.0;
+    }
+    // car = {cos, sin} of the FM reference at 2x samples 2 m2 and 2 m2 + 1 (float64 table)
+    __device__ __forceinline__ void step(const SecamDemodK<double> &k, int m, double cc_now, double ch_d10, const double car[4], double &ch_out,
+                                         pf2 &y0, pf2 &y1) {
+        const int Lc = k.width + k.preroll;
+        const int m1 = m - k.s_b, m2 = m1 - 10;
+        double ch = 0.0;
+        if (m >= 0 && m < Lc + k.s_b) {
+            if (m == Lc - 1) cc_last = cc_now;
+            if (m >= Lc) cc_now = cc_last;
+            double b = iir_bp<false>(bpf, k.bpf, cc_now);
+            if (m1 >= 0) ch = k.has_bell ? iir_bp<false>(bell, k.bell, b) : b;
+        }
+        if (m1 < 0 || m1 >= Lc) ch = 0.0;
+        ch_out = ch;
+        const double a_odd = up.template push<false>(k.taps, ch);
+        const double a_even = k.taps.c0 * ch_d10;
+        double pi_e = a_even * car[0], pq_e = -(a_even * car[1]);
+        double pi_o = a_odd * car[2], pq_o = -(a_odd * car[3]);
+        y0 = y1 = pf2{0.f, 0.f};
+        if (m2 >= 0 && m2 < Lc + k.q_l) {
+            if (m2 == Lc - 1) { pi_last = pi_o; pq_last = pq_o; }
+            if (m2 >= Lc) { pi_e = pi_o = pi_last; pq_e = pq_o = pq_last; }
+            double i0 = iir_sym<false>(lp_i, k.lpf, pi_e), q0 = iir_sym<false>(lp_q, k.lpf, pq_e);
+            double i1 = iir_sym<false>(lp_i, k.lpf, pi_o), q1 = iir_sym<false>(lp_q, k.lpf, pq_o);
+            if (k.odd_l) {
+                const double ih = i_hold, qh = q_hold;
+                i_hold = i1; q_hold = q1;
+                i1 = i0; q1 = q0;
+                i0 = ih; q0 = qh;
+            }
+            y0 = pf2{(float)i0, (float)q0};
+            y1 = pf2{(float)i1, (float)q1};
+        }
+    }
+};
+
 struct SecamDemodPkB {
     typedef VPolicy<CM_V_SECAM> VP;
     IirState<float, 3> ybs;
