@@ -16,7 +16,10 @@ from PIL import Image
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
+from color_modem_amd.color.mac import MacModem  # noqa: E402
 from color_modem_amd.color.pal import PalDModem, PalSModem  # noqa: E402
+from color_modem_amd.color.secam import SecamModem  # noqa: E402
+from color_modem_amd.comb import ColorAveragingModem  # noqa: E402
 from color_modem_amd.image import ImageModem  # noqa: E402
 from color_modem_amd.line import LineConfig  # noqa: E402
 
@@ -38,6 +41,14 @@ def main():
     print('%dx%d: composite %s, decoded %s, mean |decoded - original| = %.2f of 255' % (img.size + (composite.mode, decoded.mode, err)))
     if len(sys.argv) > 2:
         decoded.save(sys.argv[2])
+    # the reference's cli.py default (SECAM with encoder-side averaging) and the D2-MAC style time multiplex
+    for name, enc, dec in (('SECAM', ColorAveragingModem(SecamModem(line_config)), SecamModem(line_config)),
+                           ('MAC', ColorAveragingModem(MacModem(line_config)), MacModem(line_config))):
+        composite = ImageModem(enc).modulate(img, frame=0)
+        decoded = ImageModem(dec).demodulate(composite, frame=0)
+        ref = numpy.asarray(img.resize(decoded.size) if decoded.size != img.size else img, dtype=float)
+        err = numpy.abs(numpy.asarray(decoded, dtype=float) - ref).mean()
+        print('%-5s composite %dx%d, decoded %dx%d, mean |decoded - original| = %.2f of 255' % ((name,) + composite.size + decoded.size + (err,)))
 
 
 if __name__ == '__main__':
