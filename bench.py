@@ -100,12 +100,18 @@ def main():
                          % (args.gpus, args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a GPU: the product path has no CPU implementation')
-    torch.cuda.set_device(local_rank)
-    device = torch.device('cuda', local_rank)
+    backend = os.environ.get('CM_BENCH_BACKEND', 'nccl')     # 'gloo': rehearsal of the N > 1 path on a box with fewer GPUs than ranks
+    n_dev = torch.cuda.device_count()
+    dev_index = local_rank if backend == 'nccl' else local_rank % max(n_dev, 1)
+    torch.cuda.set_device(dev_index)
+    device = torch.device('cuda', dev_index)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group('nccl', device_id=device)
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=device)
+        else:
+            dist.init_process_group(backend)
 
     from color_modem_amd import image, line
     from color_modem_amd.color import pal
