@@ -1050,7 +1050,11 @@ int mac_launch(const cm_mac_plan *p, bool demod, const float *in, float *out, in
         g.chroma_in = mac_dev_fir(p, 1);
         g.line_out = mac_dev_fir(p, 2);
         g.line_in = mac_dev_fir(p, 3);
-        const long long blocks = (long long)n_frames * height;       // one workgroup per call
+        long long blocks = (long long)n_frames * height;             // encoder: one workgroup per call
+        if (demod) {                                                 // decoder: segments of a field, like the tuned kernel
+            if (rows_mode) blocks = (height + cm::kMacSegment - 1) / cm::kMacSegment;
+            else blocks = (long long)n_frames * 2 * ((((height + 1) >> 1) + cm::kMacSegment - 1) / cm::kMacSegment);
+        }
         if (blocks <= 0) return CM_OK;
         if (blocks > 0x7fffffffLL) return fail(CM_ERR_INVALID, "batch too large for one launch");
         const size_t lds_demod = sizeof(float) * (cm::kMacLine + cm::kMacChroma + 24 + 2 * cm::kMacLuma + (size_t)d->line_width);

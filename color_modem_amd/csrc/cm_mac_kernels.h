@@ -347,19 +347,19 @@ __global__ __launch_bounds__(kMacThreads) void mac_demod_generic_kernel(const Ma
     extern __shared__ __attribute__((aligned(16))) float mac_lds[];
     float *lin = mac_lds;                       // [1080] the line at its own rate
     float *ch = lin + kMacLine;                 // [360 + 24]
-    float *up = ch + kMacChroma + 24;           // [2][720]
+    float *up = ch + kMacChroma + 24;           // [2][720] interpolated chroma of this call and of the one before
     float *raw = up + 2 * kMacLuma;             // [CW] the transmitted line
+    const MacSegment s = mac_segment(a);        // a segment of consecutive calls of one field, like the tuned kernel
+    if (s.k_begin >= s.k_end) return;
     const int t = threadIdx.x;
-    int f, row, prev_row, line;
-    if (a.rows_mode) {
-        f = 0; row = (int)blockIdx.x; prev_row = row - 1; line = a.first_line + 2 * row;
-    } else {
-        f = (int)(blockIdx.x / a.H); row = (int)(blockIdx.x % a.H); prev_row = row - 2; line = row;
-    }
-    const long long frame = a.first_frame + f;
-    const bool have_prev = prev_row >= 0;
-    for (int pass = have_prev ? 0 : 1; pass < 2; ++pass) {      // pass 0: the previous call's line, pass 1: this call's
-        const long long row_index = (long long)f * a.H + (pass ? row : prev_row);
+    const long long frame = a.first_frame + s.f;
+    auto row_of = [&](int k) -> int { return a.rows_mode ? k : s.fld + 2 * k; };
+    const int k_first = s.k_begin > 0 ? s.k_begin - 1 : s.k_begin;   // a segment inside a run walks the row before it silently
+    int cur = 0;
+    bool have_prev = false;
+    for (int k = k_first; k < s.k_end; ++k) {
+        const int row = row_of(k);
+        const long long row_index = (long long)s.f * a.H + row;
         const float *p = a.in + row_index * ga.CW;
         const unsigned char *p8 = (const unsigned char *)a.in + row_index * ga.CW;
         __syncthreads();
@@ -380,30 +380,35 @@ __global__ __launch_bounds__(kMacThreads) void mac_demod_generic_kernel(const Ma
             } else {
                 v = a.c0 * ch[i + 10];
             }
-            up[pass * kMacLuma + n] = v - 0.5f;
+            up[cur * kMacLuma + n] = v - 0.5f;
         }
-    }
-    __syncthreads();
-    const bool alt = mac_alternate(a, frame, line);
-    float *o = a.rows_mode ? a.out + (long long)row * 3 * kMacLuma : a.out + (((long long)f * 3) * a.H + row) * kMacLuma;
-    unsigned char *o8 = (unsigned char *)a.out + ((long long)f * a.H + row) * 3 * kMacLuma;
-    const long long plane = a.rows_mode ? kMacLuma : (long long)a.H * kMacLuma;
-    for (int n = t; n < kMacLuma; n += kMacThreads) {
-        const float luma = mac_line_luma(lin, n);
-        const float own = up[kMacLuma + n], other = have_prev ? up[n] : 0.f;
-        const float dr = alt ? other : own, db = alt ? own : other;
-        const float r = __builtin_fmaf(a.m[0], luma, __builtin_fmaf(a.m[1], dr, a.m[2] * db));
-        const float g = __builtin_fmaf(a.m[3], luma, __builtin_fmaf(a.m[4], dr, a.m[5] * db));
-        const float b = __builtin_fmaf(a.m[6], luma, __builtin_fmaf(a.m[7], dr, a.m[8] * db));
-        if (U8) {
-            o8[3 * n] = (unsigned char)__builtin_rintf(255.f * __builtin_fminf(__builtin_fmaxf(r, 0.f), 1.f));
-            o8[3 * n + 1] = (unsigned char)__builtin_rintf(255.f * __builtin_fminf(__builtin_fmaxf(g, 0.f), 1.f));
-            o8[3 * n + 2] = (unsigned char)__builtin_rintf(255.f * __builtin_fminf(__builtin_fmaxf(b, 0.f), 1.f));
-        } else {
-            o[n] = r;
-            o[plane + n] = g;
-            o[2 * plane + n] = b;
+        __syncthreads();
+        if (k >= s.k_begin) {
+            const int line = a.rows_mode ? a.first_line + 2 * k : row;
+            const bool alt = mac_alternate(a, frame, line);
+            float *o = a.rows_mode ? a.out + (long long)row * 3 * kMacLuma : a.out + (((long long)s.f * 3) * a.H + row) * kMacLuma;
+            unsigned char *o8 = (unsigned char *)a.out + ((long long)s.f * a.H + row) * 3 * kMacLuma;
+            const long long plane = a.rows_mode ? kMacLuma : (long long)a.H * kMacLuma;
+            for (int n = t; n < kMacLuma; n += kMacThreads) {
+                const float luma = mac_line_luma(lin, n);
+                const float own = up[cur * kMacLuma + n], other = have_prev ? up[(cur ^ 1) * kMacLuma + n] : 0.f;
+                const float dr = alt ? other : own, db = alt ? own : other;
+                const float r = __builtin_fmaf(a.m[0], luma, __builtin_fmaf(a.m[1], dr, a.m[2] * db));
+                const float g = __builtin_fmaf(a.m[3], luma, __builtin_fmaf(a.m[4], dr, a.m[5] * db));
+                const float b = __builtin_fmaf(a.m[6], luma, __builtin_fmaf(a.m[7], dr, a.m[8] * db));
+                if (U8) {
+                    o8[3 * n] = (unsigned char)__builtin_rintf(255.f * __builtin_fminf(__builtin_fmaxf(r, 0.f), 1.f));
+                    o8[3 * n + 1] = (unsigned char)__builtin_rintf(255.f * __builtin_fminf(__builtin_fmaxf(g, 0.f), 1.f));
+                    o8[3 * n + 2] = (unsigned char)__builtin_rintf(255.f * __builtin_fminf(__builtin_fmaxf(b, 0.f), 1.f));
+                } else {
+                    o[n] = r;
+                    o[plane + n] = g;
+                    o[2 * plane + n] = b;
+                }
+            }
         }
+        have_prev = true;
+        cur ^= 1;
     }
 }
 
@@ -433,7 +438,7 @@ __global__ __launch_bounds__(kMacThreads) void mac_mod_generic_kernel(const MacG
     }
     const long long frame = a.first_frame + f;
     const long long plane = a.rows_mode ? W : (long long)a.H * W;
-    for (int slot = 0; slot < 2; ++slot) {
+    for (int slot = 0; slot < (row_a != row_b ? 2 : 1); ++slot) {
         const int row = slot ? row_b : row_a;
         const float *p = a.rows_mode ? a.in + (long long)row * 3 * W : a.in + (((long long)f * 3) * a.H + row) * W;
         const unsigned char *p8 = (const unsigned char *)a.in + ((long long)f * a.H + row) * 3 * W;
