@@ -1011,6 +1011,7 @@ cm::MacFir mac_dev_fir(const cm_mac_plan *p, int i) {
     r.up = f.up;
     r.down = f.down;
     r.half_len = (f.n_taps - 1) / 2;
+    r.stage = 0;
     return r;
 }
 int mac_launch(const cm_mac_plan *p, bool demod, const float *in, float *out, int n_frames, int height, int rows_mode,
@@ -1057,8 +1058,17 @@ int mac_launch(const cm_mac_plan *p, bool demod, const float *in, float *out, in
         }
         if (blocks <= 0) return CM_OK;
         if (blocks > 0x7fffffffLL) return fail(CM_ERR_INVALID, "batch too large for one launch");
-        const size_t lds_demod = sizeof(float) * (cm::kMacLine + cm::kMacChroma + 24 + 2 * cm::kMacLuma + (size_t)d->line_width);
-        const size_t lds_mod = sizeof(float) * (cm::kMacLine + cm::kMacLuma + cm::kMacChroma + 7 * (size_t)d->width);
+        size_t lds_demod = sizeof(float) * (cm::kMacLine + cm::kMacChroma + 24 + 2 * cm::kMacLuma + (size_t)d->line_width);
+        size_t lds_mod = sizeof(float) * (cm::kMacLine + cm::kMacLuma + cm::kMacChroma + 7 * (size_t)d->width);
+        // the taps go to LDS while the workgroup stays within 48 KiB (cm_mac_kernels.h: mac_stage_taps)
+        auto stage = [](cm::MacFir &f, size_t &lds) {
+            const size_t bytes = f.h ? sizeof(float) * (2 * (size_t)f.half_len + 1) : 0;
+            f.stage = bytes && lds + bytes <= 48 * 1024 ? 1 : 0;
+            if (f.stage) lds += bytes;
+        };
+        g.luma_in.stage = g.chroma_in.stage = g.line_out.stage = g.line_in.stage = 0;
+        if (demod) stage(g.line_in, lds_demod);
+        else { stage(g.luma_in, lds_mod); stage(g.chroma_in, lds_mod); stage(g.line_out, lds_mod); }
         if (demod && u8) hipLaunchKernelGGL(cm::mac_demod_generic_kernel<true>, dim3((unsigned)blocks), dim3(cm::kMacThreads), lds_demod, stream, g);
         else if (demod) hipLaunchKernelGGL(cm::mac_demod_generic_kernel<false>, dim3((unsigned)blocks), dim3(cm::kMacThreads), lds_demod, stream, g);
         else if (u8) hipLaunchKernelGGL(cm::mac_mod_generic_kernel<true>, dim3((unsigned)blocks), dim3(cm::kMacThreads), lds_mod, stream, g);

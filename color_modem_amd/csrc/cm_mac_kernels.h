@@ -319,12 +319,22 @@ __global__ __launch_bounds__(kMacThreads) void mac_mod_kernel(const MacArgs a) {
 struct MacFir {
     const float *h;              // up * firwin(...), 2 half_len + 1 taps, device memory; null: up == down (a copy)
     int up, down, half_len;
+    int stage;                   // 1: the kernel copies the taps into LDS first (the host sets it while they fit)
 };
 struct MacGenArgs {
     MacArgs a;
     int W, CW;                   // samples per rgb row / per transmitted line
     MacFir luma_in, chroma_in, line_out, line_in;   // W -> 720, W -> 360, 1080 -> CW, CW -> 1080
 };
+// Taps read in the product loop come from LDS where they fit (the loop's loads depend on each other through the
+// address arithmetic only, but hipcc does not batch them: from global memory their latency is the kernel's time).
+__device__ __forceinline__ float *mac_stage_taps(MacFir &f, float *lds, int t) {
+    if (!f.h || !f.stage) return lds;
+    const int n = 2 * f.half_len + 1;
+    for (int i = t; i < n; i += kMacThreads) lds[i] = f.h[i];
+    f.h = lds;
+    return lds + n;
+}
 __device__ __forceinline__ float mac_resample_at(const float *src, int n_in, const MacFir &f, int n) {
     if (!f.h) return src[n];
     const int t0 = n * f.down + f.half_len;
@@ -352,6 +362,8 @@ __global__ __launch_bounds__(kMacThreads) void mac_demod_generic_kernel(const Ma
     const MacSegment s = mac_segment(a);        // a segment of consecutive calls of one field, like the tuned kernel
     if (s.k_begin >= s.k_end) return;
     const int t = threadIdx.x;
+    MacFir line_in = ga.line_in;
+    mac_stage_taps(line_in, raw + ga.CW, t);
     const long long frame = a.first_frame + s.f;
     auto row_of = [&](int k) -> int { return a.rows_mode ? k : s.fld + 2 * k; };
     const int k_first = s.k_begin > 0 ? s.k_begin - 1 : s.k_begin;   // a segment inside a run walks the row before it silently
@@ -366,7 +378,7 @@ __global__ __launch_bounds__(kMacThreads) void mac_demod_generic_kernel(const Ma
         for (int i = t; i < ga.CW; i += kMacThreads)
             raw[i] = U8 ? __builtin_fmaf((float)p8[i], 5.0f / (255.0f * 3.0f), -1.0f / 3.0f) : p[i];
         __syncthreads();
-        for (int n = t; n < kMacLine; n += kMacThreads) lin[n] = mac_resample_at(raw, ga.CW, ga.line_in, n);    // mac.py:88-91
+        for (int n = t; n < kMacLine; n += kMacThreads) lin[n] = mac_resample_at(raw, ga.CW, line_in, n);    // mac.py:88-91
         __syncthreads();
         for (int i = t; i < kMacChroma + 24; i += kMacThreads)
             ch[i] = (i < 10 || i >= kMacChroma + 10) ? 0.f : mac_line_chroma(lin, i - 10);
@@ -425,6 +437,8 @@ __global__ __launch_bounds__(kMacThreads) void mac_mod_generic_kernel(const MacG
     float *cavg = c3 + kMacChroma;              // [W] colour-difference signal of the line at the rows' rate
     float *comp = cavg + W;                     // [2][3][W] (luma, dr, db) of the previous call's row and of this call's
     const int t = threadIdx.x;
+    MacFir luma_in = ga.luma_in, chroma_in = ga.chroma_in, line_out = ga.line_out;
+    mac_stage_taps(line_out, mac_stage_taps(chroma_in, mac_stage_taps(luma_in, comp + 6 * W, t), t), t);
     int f, out_row, row_a, row_b, line;
     if (a.rows_mode) {
         f = 0; out_row = (int)blockIdx.x; row_b = out_row; row_a = a.averaging && out_row > 0 ? out_row - 1 : out_row;
@@ -456,8 +470,8 @@ __global__ __launch_bounds__(kMacThreads) void mac_mod_generic_kernel(const MacG
     for (int i = t; i < W; i += kMacThreads)
         cavg[i] = row_a != row_b ? 0.5f * (comp[(3 + sel) * W + i] + comp[sel * W + i]) : comp[sel * W + i];
     __syncthreads();
-    for (int n = t; n < kMacLuma; n += kMacThreads) lum[n] = mac_resample_at(comp, W, ga.luma_in, n);                 // mac.py:49-52
-    for (int i = t; i < kMacChroma; i += kMacThreads) c3[i] = mac_resample_at(cavg, W, ga.chroma_in, i) + 0.5f;       // mac.py:53-55, 57
+    for (int n = t; n < kMacLuma; n += kMacThreads) lum[n] = mac_resample_at(comp, W, luma_in, n);                 // mac.py:49-52
+    for (int i = t; i < kMacChroma; i += kMacThreads) c3[i] = mac_resample_at(cavg, W, chroma_in, i) + 0.5f;       // mac.py:53-55, 57
     __syncthreads();
     for (int n = t; n < kMacLine; n += kMacThreads) {        // mac.py:56-69
         float v = 0.5f;
@@ -478,7 +492,7 @@ __global__ __launch_bounds__(kMacThreads) void mac_mod_generic_kernel(const MacG
     float *o = a.out + ((long long)f * a.H + out_row) * ga.CW;
     unsigned char *o8 = (unsigned char *)a.out + ((long long)f * a.H + out_row) * ga.CW;
     for (int m = t; m < ga.CW; m += kMacThreads) {
-        const float v = mac_resample_at(lin, kMacLine, ga.line_out, m);              // mac.py:71-74
+        const float v = mac_resample_at(lin, kMacLine, line_out, m);              // mac.py:71-74
         if (U8) o8[m] = (unsigned char)__builtin_rintf(255.f * __builtin_fminf(__builtin_fmaxf(__builtin_fmaf(0.6f, v, 0.2f), 0.f), 1.f));
         else o[m] = v;
     }
