@@ -1059,7 +1059,7 @@ int mac_launch(const cm_mac_plan *p, bool demod, const float *in, float *out, in
         if (blocks <= 0) return CM_OK;
         if (blocks > 0x7fffffffLL) return fail(CM_ERR_INVALID, "batch too large for one launch");
         size_t lds_demod = sizeof(float) * (cm::kMacLine + cm::kMacChroma + 24 + 2 * cm::kMacLuma + (size_t)d->line_width);
-        size_t lds_mod = sizeof(float) * (cm::kMacLine + cm::kMacLuma + cm::kMacChroma + 7 * (size_t)d->width);
+        size_t lds_mod = sizeof(float) * (cm::kMacLine + cm::kMacLuma + cm::kMacChroma + (d->averaging ? 7 : 4) * (size_t)d->width);
         // the taps go to LDS while the workgroup stays within 48 KiB (cm_mac_kernels.h: mac_stage_taps)
         auto stage = [](cm::MacFir &f, size_t &lds) {
             const size_t bytes = f.h ? sizeof(float) * (2 * (size_t)f.half_len + 1) : 0;

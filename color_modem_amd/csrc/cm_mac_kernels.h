@@ -438,7 +438,7 @@ __global__ __launch_bounds__(kMacThreads) void mac_mod_generic_kernel(const MacG
     float *comp = cavg + W;                     // [2][3][W] (luma, dr, db) of the previous call's row and of this call's
     const int t = threadIdx.x;
     MacFir luma_in = ga.luma_in, chroma_in = ga.chroma_in, line_out = ga.line_out;
-    mac_stage_taps(line_out, mac_stage_taps(chroma_in, mac_stage_taps(luma_in, comp + 6 * W, t), t), t);
+    mac_stage_taps(line_out, mac_stage_taps(chroma_in, mac_stage_taps(luma_in, comp + (a.averaging ? 6 : 3) * W, t), t), t);   // the second row slot exists with averaging only
     int f, out_row, row_a, row_b, line;
     if (a.rows_mode) {
         f = 0; out_row = (int)blockIdx.x; row_b = out_row; row_a = a.averaging && out_row > 0 ? out_row - 1 : out_row;
