@@ -4,21 +4,31 @@
     python bench.py [--gpus N] [--steps K] [--warmup W] [--frames F]
 
 One "step" = one pass of the hot path (cm_demodulate_frames, include/color_modem_hip.h) over one
-batch of F frames per GPU that is already resident in HBM.  For N > 1 the driver launches this
-file under torch.distributed.run, one rank per GPU (backend nccl = RCCL); frames are independent
-(SURVEY.md D2), so every rank demodulates its own F-frame stream with no data-path collective
-("weak" scaling, BASELINE.json configs[4]); the only collectives are the barriers and the
-max-over-ranks of the timing.
+batch of F frames per GPU that is already resident in HBM.  The input is a valid colour signal:
+smoothed random RGB frames encoded by this library's own PAL modulator on the device, outside the
+timed region.
+
+N > 1: one rank per GPU (torch.distributed, backend nccl = RCCL).  Either the caller launches this
+file under torch.distributed.run (the driver does), or - plain `python bench.py --gpus N` - this
+process starts that launcher as a CHILD before anything here touches the GPU and relays rank 0's
+line.  Frames are independent, so every rank demodulates its own F-frame stream with
+no data-path collective ("weak" scaling, BASELINE.json configs[4]); the only collectives inside the
+timed region are the two barriers.  After it, the output gather the survey asks to be timed on its
+own (8e) is measured separately on a bounded batch (`gather_ms`), and `rccl_ranks` is the world
+size RCCL itself reports after an all_reduce on device memory.
 
 Prints ONE JSON line (rank 0).  `roofline.achieved` = algorithmic bytes (16 B/pixel: 4 read +
 12 written) / mean duration of the demod kernel measured with HIP events on the
-launch stream.  `cpu_baseline` = the float64 C++ oracle (a port of the reference's per-line
-algorithm, oracle/cm_oracle.cpp) timed on this host on a bounded sample of the same workload.
+launch stream.  `check` = frames of the timed output compared with the float64 CPU oracle after
+the timed region.  `cpu_baseline` = the same oracle (a port of the reference's per-line algorithm,
+oracle/cm_oracle.cpp) timed on this host's cores on a bounded sample of the same workload.
 """
 
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -29,57 +39,111 @@ if ROOT not in sys.path:
 WIDTH, HEIGHT = 720, 576
 HBM_PEAK_GBPS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 BYTES_PER_PIXEL = 16        # float32: one composite sample read, R, G, B written
+# vector-pipe side of the same kernel: float32 FMA-equivalents the kernel executes per pixel
+# (instruction count of the main loop, cm_plan_describe) against the chip's vector float32 peak and against what a bare
+# v_fma_f32 loop sustains under the board's power cap (profiles/r01_ubench_valu.txt)
+FMA_EQ_PER_PIXEL = 229
+VALU_PEAK_TFLOPS = 157.3
+VALU_SUSTAINED_TFLOPS = 119.0
 
 
-def synthetic_stream(torch, n_frames, seed, device):
-    """composite[F, 576, 720] float32 in [-0.05, 1.03): uniform noise, 4-tap box smoothed along the line.
-
-    Generated on the device, F distinct frames (a repeated frame would sit in the Infinity Cache and
-    hide HBM traffic).  The decoder has no data-dependent control flow; valid colour signals are
-    covered by the parity tests."""
+def synthetic_stream(torch, eng, n_frames, seed, first_frame, device):
+    """composite[F, 576, 720] float32: F distinct frames of smoothed uniform RGB (4-tap box along the line), encoded by
+    the library's own PAL modulator (PalDModem.modulate = qam.py:28-32 with the V switch of pal.py:48-52) under the
+    frame numbers the decoder will be given.  Generated on the device (a repeated frame would sit in the Infinity
+    Cache and hide HBM traffic)."""
     gen = torch.Generator(device=device)
     gen.manual_seed(seed)
     out = torch.empty((n_frames, HEIGHT, WIDTH), dtype=torch.float32, device=device)
-    chunk = 50
+    chunk = 40
     for f0 in range(0, n_frames, chunk):
         n = min(chunk, n_frames - f0)
-        wide = torch.rand((n, HEIGHT, WIDTH + 3), generator=gen, device=device, dtype=torch.float32)
-        acc = wide[..., 0:WIDTH] + wide[..., 1:WIDTH + 1] + wide[..., 2:WIDTH + 2] + wide[..., 3:WIDTH + 3]
-        out[f0:f0 + n] = 1.08 * (acc * 0.25) - 0.05
+        wide = torch.rand((n, 3, HEIGHT, WIDTH + 3), generator=gen, device=device, dtype=torch.float32)
+        rgb = (wide[..., 0:WIDTH] + wide[..., 1:WIDTH + 1] + wide[..., 2:WIDTH + 2] + wide[..., 3:WIDTH + 3]) * 0.25
+        eng.modulate_frames(rgb.contiguous(), first_frame + f0, out=out[f0:f0 + n])
+    torch.cuda.synchronize()
     return out
 
 
-def cpu_baseline(sample_frames):
-    """Time the CPU oracle on `sample_frames` frames of the same workload, single thread and all cores."""
-    import numpy
-    from color_modem_amd import line, testing
-    from color_modem_amd.color import pal
-    from oracle import cm_oracle
-    modem = pal.PalDModem(line.LineConfig((WIDTH, HEIGHT)))
-    comp = testing.synthetic_composite(sample_frames, HEIGHT, WIDTH, seed=1234)
-    cores = os.cpu_count() or 1
-    t0 = time.perf_counter()
-    cm_oracle.demodulate_frames_f32(modem, comp[:max(1, sample_frames // 8)], 0, 1)
-    t1 = time.perf_counter()
-    single = max(1, sample_frames // 8) * WIDTH * HEIGHT / (t1 - t0) / 1e6
-    t0 = time.perf_counter()
-    cm_oracle.demodulate_frames_f32(modem, comp, 0, min(cores, sample_frames))
-    t1 = time.perf_counter()
-    multi = sample_frames * WIDTH * HEIGHT / (t1 - t0) / 1e6
-    model = ''
+def host_threads():
+    try:
+        return max(1, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        return max(1, os.cpu_count() or 1)
+
+
+def cpu_model():
     try:
         with open('/proc/cpuinfo') as fh:
             for ln in fh:
                 if ln.startswith('model name'):
-                    model = ln.split(':', 1)[1].strip()
-                    break
+                    return ln.split(':', 1)[1].strip()
     except OSError:
         pass
-    return {'value': round(multi, 3), 'unit': 'Mpixels/s', 'cores': min(cores, sample_frames), 'kind': 'port',
-            'single_thread_value': round(single, 3), 'cpu': model,
-            'sample': '%d frames 720x576 PAL-D demodulate, float64 C++ oracle (oracle/cm_oracle.cpp), frames sharded '
-                      'over threads; single-thread figure on %d frame(s). Reference itself (numpy/scipy, 1 core, '
-                      'survey container): 0.52 Mpixels/s' % (sample_frames, max(1, sample_frames // 8))}
+    return ''
+
+
+def cpu_baseline(modem, comp_host, first_frame):
+    """Time the CPU oracle on frames of the same workload: one thread, then every core this process may run on."""
+    from oracle import cm_oracle
+    threads = host_threads()
+    n = comp_host.shape[0]
+    n1 = max(1, min(4, n))
+    t0 = time.perf_counter()
+    cm_oracle.demodulate_frames_f32(modem, comp_host[:n1], first_frame, 1)
+    single = n1 * WIDTH * HEIGHT / (time.perf_counter() - t0) / 1e6
+    t0 = time.perf_counter()
+    cm_oracle.demodulate_frames_f32(modem, comp_host, first_frame, min(threads, n))
+    multi = n * WIDTH * HEIGHT / (time.perf_counter() - t0) / 1e6
+    return {'value': round(multi, 3), 'unit': 'Mpixels/s', 'cores': min(threads, n), 'kind': 'port',
+            'single_thread_value': round(single, 3), 'cpu': cpu_model(),
+            'sample': '%d frames 720x576 of the benchmark stream (PAL-encoded), PAL-D demodulate, float64 C++ oracle '
+                      '(oracle/cm_oracle.cpp), frames sharded over %d threads (every core this process may run on); '
+                      'single-thread figure on %d frames. Reference itself (numpy/scipy, 1 core, survey container): '
+                      '0.52 Mpixels/s' % (n, min(threads, n), n1)}
+
+
+def check_frames(torch, modem, comp, out, first_frame, picks):
+    """Frames `picks` of the timed output against the float64 oracle (CPU, after the timed region)."""
+    import numpy
+    from oracle import cm_oracle
+    worst, bad = 0.0, 0
+    for f in picks:
+        want = cm_oracle.demodulate_frames_f32(modem, comp[f:f + 1].cpu().numpy(), first_frame + f, 1).astype(numpy.float64)
+        got = out[f:f + 1].cpu().numpy().astype(numpy.float64)
+        for p in range(3):
+            worst = max(worst, float(numpy.max(numpy.abs(got[0, p] - want[0, p])) / numpy.max(numpy.abs(want[0, p]))))
+            bad += int(numpy.count_nonzero(numpy.abs(got[0, p] - want[0, p]) > 1e-6 + 1e-5 * numpy.abs(want[0, p])))
+    return worst, bad
+
+
+def launch_ranks(args):
+    """Plain `python bench.py --gpus N`: start torch.distributed.run as a child process (this process has not touched
+    the GPU and never replaces itself), relay rank 0's JSON line, fail if any rank failed."""
+    import torch
+    n_dev = torch.cuda.device_count()       # counting devices does not initialise the GPU
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    if n_dev < args.gpus and 'CM_BENCH_BACKEND' not in env:
+        # fewer GPUs than ranks (a 1-GPU test box): rehearse the same launch path with gloo, ranks sharing the devices;
+        # the line then says so ("rccl_ranks": null, "rehearsal": ...), it is not a scaling measurement
+        env['CM_BENCH_BACKEND'] = 'gloo'
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus),
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__),
+           '--gpus', str(args.gpus), '--steps', str(args.steps), '--warmup', str(args.warmup),
+           '--frames', str(args.frames), '--gather-frames', str(args.gather_frames), '--cpu-sample', str(args.cpu_sample)]
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, universal_newlines=True)
+    line = None
+    for ln in proc.stdout.splitlines():
+        if ln.startswith('{') and '"metric"' in ln:
+            line = ln
+    if proc.returncode != 0 or line is None:
+        sys.stderr.write(proc.stdout)
+        raise SystemExit('bench.py: the %d-rank launch failed (exit code %d)' % (args.gpus, proc.returncode or 1))
+    print(line)
 
 
 def main():
@@ -88,16 +152,20 @@ def main():
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--frames', type=int, default=1000, help='frames per GPU per step')
-    ap.add_argument('--cpu-sample', type=int, default=32, help='frames of the CPU baseline sample (0 = skip)')
+    ap.add_argument('--cpu-sample', type=int, default=-1,
+                    help='frames of the CPU baseline sample (0 = skip; default: 4 per host thread, 32 ... 256)')
+    ap.add_argument('--gather-frames', type=int, default=16, help='N > 1: frames per rank of the separately timed output gather')
     args = ap.parse_args()
 
-    import torch
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    if args.gpus > 1 and world != args.gpus:
-        raise SystemExit('--gpus %d needs torch.distributed.run with --nproc-per-node %d (WORLD_SIZE=%d)'
-                         % (args.gpus, args.gpus, world))
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        return launch_ranks(args)
+    if args.gpus != world:
+        raise SystemExit('--gpus %d but WORLD_SIZE=%d' % (args.gpus, world))
+
+    import torch
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a GPU: the product path has no CPU implementation')
     backend = os.environ.get('CM_BENCH_BACKEND', 'nccl')     # 'gloo': rehearsal of the N > 1 path on a box with fewer GPUs than ranks
@@ -113,14 +181,14 @@ def main():
         else:
             dist.init_process_group(backend)
 
-    from color_modem_amd import image, line
+    from color_modem_amd import image, line, parallel
     from color_modem_amd.color import pal
     modem = pal.PalDModem(line.LineConfig((WIDTH, HEIGHT)))
     eng = image.ImageModem(modem)._engine()
     frames = args.frames
-    comp = synthetic_stream(torch, frames, 1234 + 7919 * rank, device)
-    out = torch.empty((frames, 3, HEIGHT, WIDTH), dtype=torch.float32, device=device)
     first_frame = rank * frames  # every rank continues the frame numbering: all four PAL phases are exercised
+    comp = synthetic_stream(torch, eng, frames, 1234 + 7919 * rank, first_frame, device)
+    out = torch.empty((frames, 3, HEIGHT, WIDTH), dtype=torch.float32, device=device)
 
     def barrier():
         torch.cuda.synchronize()
@@ -140,16 +208,50 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     kernel_ms = [a.elapsed_time(b) for a, b in ev]
+
+    # ---- after the timed region -------------------------------------------------------------------------------------
+    picks = sorted(set([0, frames // 2 - 1 if frames > 1 else 0, frames - 1])) if rank == 0 else [frames - 1]
+    worst, bad = check_frames(torch, modem, comp, out, first_frame, picks)
+    rccl_ranks, gather = None, None
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        t = torch.tensor([elapsed, worst, float(bad)], dtype=torch.float64, device=device if backend == 'nccl' else 'cpu')
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        elapsed, worst, bad = float(t[0]), float(t[1]), int(t[2])
+        ones = torch.ones(1, dtype=torch.int32, device=device if backend == 'nccl' else 'cpu')
+        dist.all_reduce(ones, op=dist.ReduceOp.SUM)      # one element per rank through the collective library itself
+        if backend == 'nccl':
+            rccl_ranks = int(ones.item())
+        # the output gather, timed on its own: every rank holds the same G * N frame batch, demodulates its share
+        # (parallel.demodulate_frames_sharded) and the shares are exchanged with one all_gather
+        g = max(1, min(args.gather_frames, frames))
+        batch = synthetic_stream(torch, eng, g * world, 4321, 0, device)
+        gdev = (lambda x: x) if backend == 'nccl' else (lambda x: x.cpu())
+        for timed in (False, True):
+            barrier()
+            t1 = time.perf_counter()
+            local = parallel.demodulate_frames_sharded(eng.demodulate_frames, batch, 0, gather=False)
+            torch.cuda.synchronize()
+            t2 = time.perf_counter()
+            full = parallel.gather_frames(gdev(local), g * world)
+            barrier()
+            t3 = time.perf_counter()
+        lo, hi = parallel.frame_range(g * world, world, rank)
+        same = bool(torch.equal(full[lo:hi].to(local.device), local)) and full.shape[0] == g * world
+        tg = torch.tensor([t3 - t2, 0.0 if same else 1.0], dtype=torch.float64, device=device if backend == 'nccl' else 'cpu')
+        dist.all_reduce(tg, op=dist.ReduceOp.MAX)
+        gbytes = g * world * 3 * HEIGHT * WIDTH * 4
+        gather = {'gather_ms': round(float(tg[0]) * 1e3, 3), 'frames': g * world, 'bytes_per_rank_received': gbytes,
+                  'GBps_per_rank': round(gbytes / max(float(tg[0]), 1e-9) / 1e9, 2),
+                  'demodulate_ms': round((t2 - t1) * 1e3, 3), 'own_share_intact': float(tg[1]) == 0.0,
+                  'what': 'all_gather of rgb[%d, 3, 576, 720] float32 (every rank receives the whole batch), '
+                          'parallel.gather_frames; outside the timed steps' % (g * world)}
 
     if rank == 0:
         px_step = frames * WIDTH * HEIGHT
         value = world * px_step * args.steps / elapsed / 1e6
         mean_kernel_ms = sum(kernel_ms) / len(kernel_ms)
         achieved = BYTES_PER_PIXEL * px_step / (mean_kernel_ms * 1e-3) / 1e9
+        valu_tflops = 2.0 * FMA_EQ_PER_PIXEL * px_step / (mean_kernel_ms * 1e-3) / 1e12
         traffic = None
         tpath = os.path.join(ROOT, 'profiles', 'traffic.json')
         if os.path.exists(tpath):
@@ -162,20 +264,41 @@ def main():
             'value': round(value, 1), 'unit': 'Mpixels/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(elapsed / args.steps * 1e3, 4), 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': 'PAL-BG 2D comb (PalDModem) demodulate, 720x576, %d-frame synthetic stream per GPU, '
-                                   'float32 planar in HBM' % frames,
+            'config': {'workload': 'PAL-BG 2D comb (PalDModem) demodulate, 720x576, %d-frame synthetic stream per GPU: smoothed '
+                                   'random RGB, PAL-encoded on the device by the library\'s own modulator; float32 planar in HBM'
+                                   % frames,
                        'frames_per_gpu': frames, 'parallelism': 'frames sharded, one stream per GPU, no data-path collective',
                        'kernel': eng.describe()},
             'roofline': {'bound': 'hbm', 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
                          'frac': round(achieved / HBM_PEAK_GBPS, 4), 'traffic': traffic,
                          'kernel_ms': round(mean_kernel_ms, 4), 'algorithmic_bytes_per_launch': BYTES_PER_PIXEL * px_step,
-                         'note': 'traffic = 1.02 x algorithmic (every byte moves once); not bandwidth-bound: ~229 float32 FMA-equivalents per pixel = '
-                                 '~80 TFLOP/s, 67 % of the 119 TFLOP/s a pure v_fma_f32 loop sustains at the 1400 W power cap '
-                                 '(profiles/r01_pair_notes.md, DESIGN.md section 5)'},
+                         'note': 'the HBM roofline is the one the metric names; the kernel is limited by the vector pipe and the '
+                                 'power cap, see roofline_valu (DESIGN.md section 5)'},
+            'roofline_valu': {'bound': 'valu', 'achieved': round(valu_tflops, 1), 'peak': VALU_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                              'frac': round(valu_tflops / VALU_PEAK_TFLOPS, 4),
+                              'sustained_peak': VALU_SUSTAINED_TFLOPS, 'frac_of_sustained': round(valu_tflops / VALU_SUSTAINED_TFLOPS, 4),
+                              'fma_equivalents_per_pixel': FMA_EQ_PER_PIXEL,
+                              'note': 'float32 vector instructions of the main loop per pixel x 2 flop; sustained_peak = a bare '
+                                      'v_fma_f32 loop under the 1400 W cap (profiles/r01_ubench_valu.txt)'},
+            'check': {'max_rel_err': float('%.3g' % worst), 'allclose_violations': bad, 'tolerance': 1e-5,
+                      'frames': picks if world == 1 else 'rank 0: %s, other ranks: their last frame' % picks,
+                      'what': 'timed output vs float64 CPU oracle: max |out - ref| / max |ref| per plane, and the count of '
+                              'samples outside numpy.allclose(rtol=1e-5, atol=1e-6)'},
         }
-        if world == 1 and args.cpu_sample > 0:
-            res['cpu_baseline'] = cpu_baseline(args.cpu_sample)
+        if world > 1:
+            res['rccl_ranks'] = rccl_ranks
+            res['gather'] = gather
+            if backend != 'nccl':
+                res['rehearsal'] = 'backend %s, %d ranks on %d GPU(s): launch-path rehearsal, not a scaling measurement' \
+                                   % (backend, world, n_dev)
+        if world == 1 and args.cpu_sample != 0:
+            n_cpu = args.cpu_sample if args.cpu_sample > 0 else max(32, min(256, 4 * host_threads()))
+            n_cpu = min(n_cpu, frames)
+            res['cpu_baseline'] = cpu_baseline(modem, comp[:n_cpu].cpu().numpy(), first_frame)
         print(json.dumps(res))
+        if worst > 1e-5:
+            sys.stdout.flush()
+            raise SystemExit('bench.py: the timed output misses the oracle by %.3g (> 1e-5)' % worst)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

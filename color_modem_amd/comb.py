@@ -76,6 +76,11 @@ class SimpleCombModem(RowApi):
         inner = dict(self.backend._stack())
         if 'demod_wrapper' in inner:
             raise NotImplementedError('nested SimpleCombModem wrappers are not supported')
+        if 'mod_wrapper' in inner:
+            # ref comb.py:104-106: the luma strip would re-modulate through the stateful averaging encoder at line
+            # - 2 (own_delay - 1); the flattened plan has no such path.  ColorAveragingModem(SimpleCombModem(x)) is the
+            # supported order (the comb then re-modulates through x itself).
+            raise NotImplementedError('SimpleCombModem around ColorAveragingModem is not supported; wrap the other way round')
         if self._avg is not globals()['avg'] and self._avg is not globals()['minavg']:
             raise NotImplementedError('avg=%r: the device path implements comb.avg and comb.minavg, not arbitrary '
                                       'callables' % (self._avg,))

@@ -30,6 +30,34 @@ int fail(int code, const std::string &msg) {
     g_error = msg;
     return code;
 }
+// A plan's tables live on the device that was current in cm_*_plan_create.  Every compute entry point checks that this
+// device is still the current one and that both image buffers are device memory of it: a plan used under another current
+// device, or fed another GPU's pointers, would otherwise fault inside the kernel (or run over peer access) instead of
+// returning an error.  -DCM_NO_POINTER_CHECK drops the two hipPointerGetAttributes calls (a few microseconds per call).
+int check_device(int plan_device, const void *a, const void *b) {
+    int cur = -1;
+    if (hipGetDevice(&cur) != hipSuccess) return fail(CM_ERR_NO_DEVICE, "hipGetDevice failed");
+    if (cur != plan_device)
+        return fail(CM_ERR_INVALID, "the plan belongs to HIP device " + std::to_string(plan_device) + ", the current device is " +
+                                        std::to_string(cur));
+#ifndef CM_NO_POINTER_CHECK
+    const void *ptrs[2] = {a, b};
+    for (const void *ptr : ptrs) {
+        if (!ptr) continue;
+        hipPointerAttribute_t at;
+        if (hipPointerGetAttributes(&at, ptr) != hipSuccess) {
+            (void)hipGetLastError();
+            return fail(CM_ERR_INVALID, "an image buffer is not device memory (the ABI takes device pointers)");
+        }
+        if (at.type == hipMemoryTypeDevice && at.device != plan_device)
+            return fail(CM_ERR_INVALID, "an image buffer lives on HIP device " + std::to_string(at.device) + ", the plan on device " +
+                                            std::to_string(plan_device));
+        if (at.type == hipMemoryTypeHost || at.type == hipMemoryTypeUnregistered)
+            return fail(CM_ERR_INVALID, "an image buffer is host memory (the ABI takes device pointers)");
+    }
+#endif
+    return CM_OK;
+}
 #define HIP_TRY(expr, code)                                                                      \
     do {                                                                                         \
         hipError_t e_ = (expr);                                                                  \
@@ -733,6 +761,7 @@ int cm_demodulate_frames(const cm_plan *p, const float *composite, float *rgb, i
     if (!p || !composite || !rgb) return fail(CM_ERR_INVALID, "null argument");
     if (n_frames < 0 || first_frame < 0) return fail(CM_ERR_INVALID, "negative frame count / number");
     if (!p->fn && !p->secam) return fail(CM_ERR_UNSUPPORTED, p->demod_error);
+    if (int rc_ = check_device(p->device, composite, rgb)) return rc_;
     const cm_plan_desc &d = p->desc;
     const int W = d.width, H = d.height, D = d.demodulation_delay;
     const int wp = (W + 3) & ~3;
@@ -785,6 +814,7 @@ int cm_demodulate_frames_u8(const cm_plan *p, const uint8_t *composite8, uint8_t
     if (!p->secam && !p->fn_u8)
         return fail(CM_ERR_UNSUPPORTED, p->fn ? "no kernel instance with the fused uint8 boundary for this decoder (notch / minavg)"
                                               : p->demod_error);
+    if (int rc_ = check_device(p->device, composite8, rgb8)) return rc_;
     const cm_plan_desc &d = p->desc;
     const int W = d.width, H = d.height, D = d.demodulation_delay;
     Geom g;
@@ -834,6 +864,7 @@ int cm_demodulate_run(const cm_plan *p, const float *composite, float *rgb, int3
     if (n_calls == 0) return CM_OK;
     if (first_line < 0) return fail(CM_ERR_INVALID, "negative line number");
     if (!p->fn && !p->secam) return fail(CM_ERR_UNSUPPORTED, p->demod_error);
+    if (int rc_ = check_device(p->device, composite, rgb)) return rc_;
     const cm_plan_desc &d = p->desc;
     const int W = d.width, wp = (W + 3) & ~3;
     return with_pitched_rows(composite, n_calls, rgb, 3LL * n_calls, W, (hipStream_t)stream, [&](const float *in, float *out) -> int {
@@ -895,6 +926,7 @@ int cm_modulate_frames(const cm_plan *p, const float *rgb, float *composite, int
     if (!p || !rgb || !composite) return fail(CM_ERR_INVALID, "null argument");
     if (n_frames < 0 || first_frame < 0) return fail(CM_ERR_INVALID, "negative frame count / number");
     if (!p->mod_fn && !p->sm_lanes) return fail(CM_ERR_UNSUPPORTED, "this plan has no modulator");
+    if (int rc_ = check_device(p->device, rgb, composite)) return rc_;
     const cm_plan_desc &d = p->desc;
     const int W = d.width, H = d.height, D = d.modulation_delay;
     const int wp = (W + 3) & ~3;
@@ -932,6 +964,7 @@ int cm_modulate_frames_u8(const cm_plan *p, const uint8_t *rgb8, uint8_t *compos
     if (!p || !rgb8 || !composite8) return fail(CM_ERR_INVALID, "null argument");
     if (n_frames < 0 || first_frame < 0) return fail(CM_ERR_INVALID, "negative frame count / number");
     if (!p->mod_fn && !p->sm_lanes) return fail(CM_ERR_UNSUPPORTED, "this plan has no modulator");
+    if (int rc_ = check_device(p->device, rgb8, composite8)) return rc_;
     const cm_plan_desc &d = p->desc;
     const int W = d.width, H = d.height, D = d.modulation_delay;
     if (W % 16 != 0) return fail(CM_ERR_UNSUPPORTED, "the fused uint8 boundary of the encoders needs a width that is a multiple of 16");
@@ -967,6 +1000,7 @@ int cm_modulate_run(const cm_plan *p, const float *rgb, float *composite, int32_
     if (n_calls < 0 || frame < 0 || k0 < 0 || first_line < 0) return fail(CM_ERR_INVALID, "negative count / frame / line / k0");
     if (n_calls == 0) return CM_OK;
     if (!p->mod_fn && !p->sm_lanes) return fail(CM_ERR_UNSUPPORTED, "this plan has no modulator");
+    if (int rc_ = check_device(p->device, rgb, composite)) return rc_;
     const cm_plan_desc &d = p->desc;
     const int W = d.width, wp = (W + 3) & ~3;
     if (first_line + 2 * (n_calls - 1) >= p->mod_n_lines) return fail(CM_ERR_INVALID, "line number beyond the plan's phase tables");
@@ -998,6 +1032,7 @@ struct cm_mac_plan {
     cm_mac_desc desc;
     float *fir[4] = {nullptr, nullptr, nullptr, nullptr};   // device copies of luma_in, chroma_in, line_out, line_in
     bool tuned = false;                                      // 720-sample rows <-> 1080-sample lines
+    int device = 0;                                          // the device that was current in cm_mac_plan_create
 };
 
 namespace {
@@ -1019,6 +1054,7 @@ int mac_launch(const cm_mac_plan *p, bool demod, const float *in, float *out, in
     const cm_mac_desc *d = &p->desc;
     cm::MacArgs a;
     std::memset(&a, 0, sizeof a);
+    if (int rc_ = check_device(p->device, in, out)) return rc_;
     a.in = in;
     a.out = out;
     a.n_frames = n_frames;
@@ -1096,6 +1132,10 @@ int cm_mac_plan_create(const cm_mac_desc *desc, cm_mac_plan **out) {
     if (cm_device_count() <= 0) return fail(CM_ERR_NO_DEVICE, "no HIP device: the MAC path runs on the GPU only");
     cm_mac_plan *p = new cm_mac_plan();
     p->desc = *desc;
+    if (hipGetDevice(&p->device) != hipSuccess) {
+        delete p;
+        return fail(CM_ERR_NO_DEVICE, "hipGetDevice failed");
+    }
     p->tuned = desc->width == CM_MAC_LUMA_WIDTH && desc->line_width == CM_MAC_LINE_WIDTH;
     for (int i = 0; i < 4; ++i) {
         const cm_mac_fir &f = *mac_fir(*desc, i);

@@ -19,6 +19,50 @@ def _torch():
     return torch
 
 
+def _check_out(out, shape, dtype, device):
+    """A caller-supplied result tensor goes to the kernels as a raw pointer: refuse anything they would write out of bounds
+    or garble (wrong shape / dtype / device, or a non-contiguous view)."""
+    torch = _torch()
+    if not torch.is_tensor(out):
+        raise ValueError('out= must be a torch tensor on the input\'s device')
+    if tuple(out.shape) != tuple(shape):
+        raise ValueError('out= has shape %s, the result has shape %s' % (tuple(out.shape), tuple(shape)))
+    if out.dtype != dtype:
+        raise ValueError('out= has dtype %s, the result has dtype %s' % (out.dtype, dtype))
+    if out.device != device:
+        raise ValueError('out= lives on %s, the input on %s' % (out.device, device))
+    if not out.is_contiguous():
+        raise ValueError('out= must be contiguous')
+    return out
+
+
+class _DevicePlans(object):
+    """One native plan per HIP device, created on first use under that device (a plan's tables live on the device that
+    was current when it was created, and the library refuses to run it under another one)."""
+
+    def __init__(self, create, destroy):
+        self._create, self._destroy, self._plans = create, destroy, {}
+
+    def get(self, device):
+        torch = _torch()
+        index = device.index if device.index is not None else torch.cuda.current_device()
+        handle = self._plans.get(index)
+        if handle is None:
+            handle = ctypes.c_void_p()
+            with torch.cuda.device(index):
+                _native.check(self._create(ctypes.byref(handle)))
+            self._plans[index] = handle
+        return handle
+
+    def close(self):
+        plans, self._plans = self._plans, {}
+        if _native is None or getattr(_native, '_lib', None) is None:
+            return
+        for handle in plans.values():
+            if handle:
+                self._destroy(handle)
+
+
 def make_engine(modem, components=False, strip_chroma=True):
     """The engine of a modem stack: a cm_plan for the QAM / SECAM families, the plan-less MAC entry points for MacModem."""
     if modem._stack()['kind'] == 'mac':
@@ -26,7 +70,50 @@ def make_engine(modem, components=False, strip_chroma=True):
     return Engine(modem, components, strip_chroma)
 
 
-class Engine(object):
+class _EngineBase(object):
+    """Shared plumbing: input staging, result validation, and the launch on the input tensor's device and stream."""
+
+    def __del__(self):
+        plans = getattr(self, '_plans', None)
+        if plans is not None:
+            plans.close()
+
+    @property
+    def _plan(self):
+        """the plan of the current device (created on first use)"""
+        torch = _torch()
+        return self._plans.get(torch.device('cuda', torch.cuda.current_device()))
+
+    def _stage(self, x, dtype, shape_tail, what):
+        """numpy array or torch tensor -> contiguous tensor on a HIP device; (tensor, came from numpy)"""
+        torch = _torch()
+        was_numpy = isinstance(x, numpy.ndarray)
+        np_dtype = numpy.float32 if dtype == torch.float32 else numpy.uint8
+        t = torch.from_numpy(numpy.ascontiguousarray(x, dtype=np_dtype)) if was_numpy else x
+        if not torch.is_tensor(t):
+            raise ValueError('%s: numpy array or torch tensor expected' % what)
+        if t.dtype != dtype:
+            raise ValueError('%s: %s expected' % (what, 'float32' if dtype == torch.float32 else 'uint8'))
+        if t.dim() != len(shape_tail) + 1 or tuple(t.shape[1:]) != tuple(shape_tail):
+            raise ValueError('%s: expected shape [n, %s], got %s' % (what, ', '.join(map(str, shape_tail)), tuple(t.shape)))
+        if not t.is_cuda:
+            t = t.cuda()
+        return t.contiguous(), was_numpy
+
+    def _launch(self, fn, x, out, out_shape, out_dtype, was_numpy, *args):
+        torch = _torch()
+        if out is None:
+            out = torch.empty(out_shape, dtype=out_dtype, device=x.device)
+        else:
+            _check_out(out, out_shape, out_dtype, x.device)
+        plan_handle = self._plans.get(x.device)
+        with torch.cuda.device(x.device):
+            stream = torch.cuda.current_stream(x.device).cuda_stream
+            _native.check(fn(plan_handle, x.data_ptr(), out.data_ptr(), *(tuple(args) + (stream,))))
+        return out.cpu().numpy() if was_numpy else out
+
+
+class Engine(_EngineBase):
     def __init__(self, modem, components=False, strip_chroma=True):
         self.built = plan.build_plan(modem, components, strip_chroma)
         d = self.built.desc
@@ -37,15 +124,9 @@ class Engine(object):
         self.mod_depth = 1 if d.modulation_delay else 0
         self.demodulation_delay = d.demodulation_delay
         self.modulation_delay = d.modulation_delay
-        self._plan = ctypes.c_void_p()
-        _torch()
-        _native.check(_native.lib().cm_plan_create(ctypes.byref(d), ctypes.byref(self._plan)))
-
-    def __del__(self):
-        p = getattr(self, '_plan', None)
-        if p and _native is not None and getattr(_native, '_lib', None) is not None:
-            _native._lib.cm_plan_destroy(p)
-            self._plan = None
+        L = _native.lib()
+        self._plans = _DevicePlans(lambda out: L.cm_plan_create(ctypes.byref(d), out), L.cm_plan_destroy)
+        self._plan      # no usable device, or no kernel instance for this stack: fail at construction
 
     def describe(self):
         buf = ctypes.create_string_buffer(512)
@@ -53,99 +134,57 @@ class Engine(object):
         return buf.value.decode()
 
     # ---- frames -------------------------------------------------------------------------------
-    def _as_device(self, x, shape_tail):
-        torch = _torch()
-        was_numpy = isinstance(x, numpy.ndarray)
-        t = torch.from_numpy(numpy.ascontiguousarray(x, dtype=numpy.float32)) if was_numpy else x
-        if t.dtype != torch.float32:
-            raise ValueError('float32 expected')
-        if tuple(t.shape[1:]) != tuple(shape_tail):
-            raise ValueError('expected shape [frames, %s], got %s' % (', '.join(map(str, shape_tail)), tuple(t.shape)))
-        if not t.is_cuda:
-            t = t.cuda()
-        return t.contiguous(), was_numpy
-
     def demodulate_frames(self, composite, first_frame=0, out=None):
         """composite [F, H, W] float32 (numpy or cuda tensor) -> rgb [F, 3, H, W] of the same kind."""
         torch = _torch()
-        comp, was_numpy = self._as_device(composite, (self.height, self.width))
+        comp, was_numpy = self._stage(composite, torch.float32, (self.height, self.width), 'composite')
         n = comp.shape[0]
-        if out is None:
-            out = torch.empty((n, 3, self.height, self.width), dtype=torch.float32, device=comp.device)
-        stream = torch.cuda.current_stream(comp.device).cuda_stream
-        _native.check(_native.lib().cm_demodulate_frames(self._plan, comp.data_ptr(), out.data_ptr(), n,
-                                                         int(first_frame), stream))
-        return out.cpu().numpy() if was_numpy else out
+        return self._launch(_native.lib().cm_demodulate_frames, comp, out, (n, 3, self.height, self.width), torch.float32,
+                            was_numpy, n, int(first_frame))
 
     def demodulate_frames_u8(self, composite8, first_frame=0, out=None):
         """uint8 composite [F, H, W] -> interleaved uint8 rgb [F, H, W, 3] with ImageModem's level mapping and
         rounding fused into the kernel (every decoder except the notch / minavg instances: NotImplementedError there)."""
         torch = _torch()
-        was_numpy = isinstance(composite8, numpy.ndarray)
-        t = torch.from_numpy(numpy.ascontiguousarray(composite8, dtype=numpy.uint8)) if was_numpy else composite8
-        if t.dtype != torch.uint8 or tuple(t.shape[1:]) != (self.height, self.width):
-            raise ValueError('expected uint8 [frames, %d, %d]' % (self.height, self.width))
-        t = t.cuda().contiguous() if not t.is_cuda else t.contiguous()
+        t, was_numpy = self._stage(composite8, torch.uint8, (self.height, self.width), 'composite8')
         n = t.shape[0]
-        if out is None:
-            out = torch.empty((n, self.height, self.width, 3), dtype=torch.uint8, device=t.device)
-        stream = torch.cuda.current_stream(t.device).cuda_stream
-        _native.check(_native.lib().cm_demodulate_frames_u8(self._plan, t.data_ptr(), out.data_ptr(), n,
-                                                            int(first_frame), stream))
-        return out.cpu().numpy() if was_numpy else out
+        return self._launch(_native.lib().cm_demodulate_frames_u8, t, out, (n, self.height, self.width, 3), torch.uint8,
+                            was_numpy, n, int(first_frame))
 
     def modulate_frames(self, rgb, first_frame=0, out=None):
         torch = _torch()
-        x, was_numpy = self._as_device(rgb, (3, self.height, self.width))
+        x, was_numpy = self._stage(rgb, torch.float32, (3, self.height, self.width), 'rgb')
         n = x.shape[0]
-        if out is None:
-            out = torch.empty((n, self.height, self.width), dtype=torch.float32, device=x.device)
-        stream = torch.cuda.current_stream(x.device).cuda_stream
-        _native.check(_native.lib().cm_modulate_frames(self._plan, x.data_ptr(), out.data_ptr(), n,
-                                                       int(first_frame), stream))
-        return out.cpu().numpy() if was_numpy else out
+        return self._launch(_native.lib().cm_modulate_frames, x, out, (n, self.height, self.width), torch.float32,
+                            was_numpy, n, int(first_frame))
 
     def modulate_frames_u8(self, rgb8, first_frame=0, out=None):
         """interleaved uint8 rgb [F, H, W, 3] -> uint8 composite [F, H, W]: ImageModem.modulate's byte / 255 on the way in
         and encode_composite_level + clamp + rint on the way out fused into the kernel (widths that are multiples of 16)."""
         torch = _torch()
-        was_numpy = isinstance(rgb8, numpy.ndarray)
-        t = torch.from_numpy(numpy.ascontiguousarray(rgb8, dtype=numpy.uint8)) if was_numpy else rgb8
-        if t.dtype != torch.uint8 or tuple(t.shape[1:]) != (self.height, self.width, 3):
-            raise ValueError('expected uint8 [frames, %d, %d, 3]' % (self.height, self.width))
-        t = t.cuda().contiguous() if not t.is_cuda else t.contiguous()
+        t, was_numpy = self._stage(rgb8, torch.uint8, (self.height, self.width, 3), 'rgb8')
         n = t.shape[0]
-        if out is None:
-            out = torch.empty((n, self.height, self.width), dtype=torch.uint8, device=t.device)
-        stream = torch.cuda.current_stream(t.device).cuda_stream
-        _native.check(_native.lib().cm_modulate_frames_u8(self._plan, t.data_ptr(), out.data_ptr(), n,
-                                                          int(first_frame), stream))
-        return out.cpu().numpy() if was_numpy else out
+        return self._launch(_native.lib().cm_modulate_frames_u8, t, out, (n, self.height, self.width), torch.uint8,
+                            was_numpy, n, int(first_frame))
 
     # ---- runs (the per-row protocol) ----------------------------------------------------------
     def demodulate_run(self, rows, frame, first_line, k0):
-        """rows [n, W] float32 numpy -> [n, 3, W] float32 numpy: what calls k0 .. k0+n-1 of a run return."""
+        """rows [n, W] float32 (numpy or cuda tensor) -> [n, 3, W] of the same kind: what calls k0 .. k0+n-1 of a run return."""
         torch = _torch()
-        x = torch.from_numpy(numpy.ascontiguousarray(rows, dtype=numpy.float32)).cuda()
+        x, was_numpy = self._stage(rows, torch.float32, (self.width,), 'rows')
         n = x.shape[0]
-        out = torch.empty((n, 3, self.width), dtype=torch.float32, device=x.device)
-        stream = torch.cuda.current_stream(x.device).cuda_stream
-        _native.check(_native.lib().cm_demodulate_run(self._plan, x.data_ptr(), out.data_ptr(), n, int(frame),
-                                                      int(first_line), int(k0), stream))
-        return out.cpu().numpy()
+        return self._launch(_native.lib().cm_demodulate_run, x, None, (n, 3, self.width), torch.float32, was_numpy,
+                            n, int(frame), int(first_line), int(k0))
 
     def modulate_run(self, rows, frame, first_line, k0):
         torch = _torch()
-        x = torch.from_numpy(numpy.ascontiguousarray(rows, dtype=numpy.float32)).cuda()
+        x, was_numpy = self._stage(rows, torch.float32, (3, self.width), 'rows')
         n = x.shape[0]
-        out = torch.empty((n, self.width), dtype=torch.float32, device=x.device)
-        stream = torch.cuda.current_stream(x.device).cuda_stream
-        _native.check(_native.lib().cm_modulate_run(self._plan, x.data_ptr(), out.data_ptr(), n, int(frame),
-                                                    int(first_line), int(k0), stream))
-        return out.cpu().numpy()
+        return self._launch(_native.lib().cm_modulate_run, x, None, (n, self.width), torch.float32, was_numpy,
+                            n, int(frame), int(first_line), int(k0))
 
 
-class MacEngine(object):
+class MacEngine(_EngineBase):
     """MacModem / ColorAveragingModem(MacModem) on the cm_mac_* entry points (rows of 720 samples <-> lines of 1080)."""
 
     def __init__(self, modem, components=False):
@@ -153,6 +192,9 @@ class MacEngine(object):
         import scipy.signal
         from color_modem_amd.color import mac
         stack = modem._stack()
+        if stack.get('demod_wrapper'):
+            # the reference fails the same way: MacModem has no demodulate_components for a comb wrapper to call (comb.py:98)
+            raise AttributeError('MacModem has no demodulate_components: a comb wrapper cannot sit on it (ref comb.py:98, mac.py)')
         backend = stack['backend']
         lc = backend.line_config
         std = lc.line_standard
@@ -167,7 +209,7 @@ class MacEngine(object):
         eye = numpy.eye(3)
         d.decode_matrix[:] = list(numpy.asarray(eye if components else mac.DECODE).reshape(-1))
         d.encode_matrix[:] = list(numpy.asarray(eye if components else mac.ENCODE).reshape(-1))
-        self._keep = []
+        self._keep = []          # the tap arrays the descriptor points to (a plan per device is created on first use)
 
         def fir(n_to, n_from):
             """the filter scipy.signal.resample_poly(x, n_to, n_from) designs (its defaults), as mac.py:49-55, 71-74, 88-91 call it"""
@@ -193,109 +235,64 @@ class MacEngine(object):
         self.mod_depth = d.averaging
         self.demodulation_delay = 0
         self.modulation_delay = d.averaging
-        self._plan = ctypes.c_void_p()
-        _torch()
-        _native.check(_native.lib().cm_mac_plan_create(ctypes.byref(d), ctypes.byref(self._plan)))
-        self._keep = []
-
-    def __del__(self):
-        p = getattr(self, '_plan', None)
-        if p and _native is not None and getattr(_native, '_lib', None) is not None:
-            _native._lib.cm_mac_plan_destroy(p)
-            self._plan = None
+        L = _native.lib()
+        self._plans = _DevicePlans(lambda out: L.cm_mac_plan_create(ctypes.byref(d), out), L.cm_mac_plan_destroy)
+        self._plan
 
     def describe(self):
         if self.in_width == 720 and self.comp_width == 1080:
             return 'mac_demod_kernel / mac_mod_kernel: one workgroup of 256 threads per 8 rows of a field, threads along the row'
         return 'mac_demod_generic_kernel / mac_mod_generic_kernel (resampling rows / lines): one workgroup per call'
 
-    def _as_device(self, x, shape_tail):
-        torch = _torch()
-        was_numpy = isinstance(x, numpy.ndarray)
-        t = torch.from_numpy(numpy.ascontiguousarray(x, dtype=numpy.float32)) if was_numpy else x
-        if t.dtype != torch.float32:
-            raise ValueError('float32 expected')
-        if tuple(t.shape[1:]) != tuple(shape_tail):
-            raise ValueError('expected shape [frames, %s], got %s' % (', '.join(map(str, shape_tail)), tuple(t.shape)))
-        if not t.is_cuda:
-            t = t.cuda()
-        return t.contiguous(), was_numpy
+    def _needs_rows(self, n):
+        if self.height < 2 * self.modulation_delay and n:
+            raise IndexError('image.py:49-50 feeds row 1 ahead of a field under modulation_delay 1: the image has %d row(s)' % self.height)
 
     def demodulate_frames(self, composite, first_frame=0, out=None):
         """composite [F, H, 1080] float32 -> rgb [F, 3, H, 720] (numpy in -> numpy out, cuda tensor in -> cuda tensor out)."""
         torch = _torch()
-        comp, was_numpy = self._as_device(composite, (self.height, self.comp_width))
+        comp, was_numpy = self._stage(composite, torch.float32, (self.height, self.comp_width), 'composite')
         n = comp.shape[0]
-        if out is None:
-            out = torch.empty((n, 3, self.height, self.width), dtype=torch.float32, device=comp.device)
-        stream = torch.cuda.current_stream(comp.device).cuda_stream
-        _native.check(_native.lib().cm_mac_demodulate_frames(self._plan, comp.data_ptr(), out.data_ptr(), n,
-                                                             int(first_frame), stream))
-        return out.cpu().numpy() if was_numpy else out
+        return self._launch(_native.lib().cm_mac_demodulate_frames, comp, out, (n, 3, self.height, self.width), torch.float32,
+                            was_numpy, n, int(first_frame))
 
     def modulate_frames(self, rgb, first_frame=0, out=None):
         """rgb [F, 3, H, W] float32 -> composite [F, H, line width]."""
         torch = _torch()
-        x, was_numpy = self._as_device(rgb, (3, self.height, self.in_width))
+        x, was_numpy = self._stage(rgb, torch.float32, (3, self.height, self.in_width), 'rgb')
         n = x.shape[0]
-        if self.height < 2 * self.modulation_delay and n:
-            raise IndexError('image.py:49-50 feeds row 1 ahead of a field under modulation_delay 1: the image has %d row(s)' % self.height)
-        if out is None:
-            out = torch.empty((n, self.height, self.comp_width), dtype=torch.float32, device=x.device)
-        stream = torch.cuda.current_stream(x.device).cuda_stream
-        _native.check(_native.lib().cm_mac_modulate_frames(self._plan, x.data_ptr(), out.data_ptr(), n,
-                                                           int(first_frame), stream))
-        return out.cpu().numpy() if was_numpy else out
-
-    def _as_device_u8(self, x, shape_tail):
-        torch = _torch()
-        was_numpy = isinstance(x, numpy.ndarray)
-        t = torch.from_numpy(numpy.ascontiguousarray(x, dtype=numpy.uint8)) if was_numpy else x
-        if t.dtype != torch.uint8 or tuple(t.shape[1:]) != tuple(shape_tail):
-            raise ValueError('expected uint8 [frames, %s]' % ', '.join(map(str, shape_tail)))
-        return (t.cuda() if not t.is_cuda else t).contiguous(), was_numpy
+        self._needs_rows(n)
+        return self._launch(_native.lib().cm_mac_modulate_frames, x, out, (n, self.height, self.comp_width), torch.float32,
+                            was_numpy, n, int(first_frame))
 
     def demodulate_frames_u8(self, composite8, first_frame=0, out=None):
         """uint8 lines [F, H, line width] -> interleaved uint8 rgb [F, H, 720, 3], ImageModem's level mapping and rounding
         fused into the kernel (the resampling kernels serve every shape here)."""
         torch = _torch()
-        t, was_numpy = self._as_device_u8(composite8, (self.height, self.comp_width))
+        t, was_numpy = self._stage(composite8, torch.uint8, (self.height, self.comp_width), 'composite8')
         n = t.shape[0]
-        if out is None:
-            out = torch.empty((n, self.height, self.width, 3), dtype=torch.uint8, device=t.device)
-        stream = torch.cuda.current_stream(t.device).cuda_stream
-        _native.check(_native.lib().cm_mac_demodulate_frames_u8(self._plan, t.data_ptr(), out.data_ptr(), n, int(first_frame), stream))
-        return out.cpu().numpy() if was_numpy else out
+        return self._launch(_native.lib().cm_mac_demodulate_frames_u8, t, out, (n, self.height, self.width, 3), torch.uint8,
+                            was_numpy, n, int(first_frame))
 
     def modulate_frames_u8(self, rgb8, first_frame=0, out=None):
         """interleaved uint8 rgb [F, H, W, 3] -> uint8 lines [F, H, line width]."""
         torch = _torch()
-        t, was_numpy = self._as_device_u8(rgb8, (self.height, self.in_width, 3))
+        t, was_numpy = self._stage(rgb8, torch.uint8, (self.height, self.in_width, 3), 'rgb8')
         n = t.shape[0]
-        if self.height < 2 * self.modulation_delay and n:
-            raise IndexError('image.py:49-50 feeds row 1 ahead of a field under modulation_delay 1: the image has %d row(s)' % self.height)
-        if out is None:
-            out = torch.empty((n, self.height, self.comp_width), dtype=torch.uint8, device=t.device)
-        stream = torch.cuda.current_stream(t.device).cuda_stream
-        _native.check(_native.lib().cm_mac_modulate_frames_u8(self._plan, t.data_ptr(), out.data_ptr(), n, int(first_frame), stream))
-        return out.cpu().numpy() if was_numpy else out
+        self._needs_rows(n)
+        return self._launch(_native.lib().cm_mac_modulate_frames_u8, t, out, (n, self.height, self.comp_width), torch.uint8,
+                            was_numpy, n, int(first_frame))
 
     def demodulate_run(self, rows, frame, first_line, k0):
         torch = _torch()
-        x = torch.from_numpy(numpy.ascontiguousarray(rows, dtype=numpy.float32)).cuda()
+        x, was_numpy = self._stage(rows, torch.float32, (self.comp_width,), 'rows')
         n = x.shape[0]
-        out = torch.empty((n, 3, self.width), dtype=torch.float32, device=x.device)
-        stream = torch.cuda.current_stream(x.device).cuda_stream
-        _native.check(_native.lib().cm_mac_demodulate_run(self._plan, x.data_ptr(), out.data_ptr(), n,
-                                                          int(frame), int(first_line), int(k0), stream))
-        return out.cpu().numpy()
+        return self._launch(_native.lib().cm_mac_demodulate_run, x, None, (n, 3, self.width), torch.float32, was_numpy,
+                            n, int(frame), int(first_line), int(k0))
 
     def modulate_run(self, rows, frame, first_line, k0):
         torch = _torch()
-        x = torch.from_numpy(numpy.ascontiguousarray(rows, dtype=numpy.float32)).cuda()
+        x, was_numpy = self._stage(rows, torch.float32, (3, self.in_width), 'rows')
         n = x.shape[0]
-        out = torch.empty((n, self.comp_width), dtype=torch.float32, device=x.device)
-        stream = torch.cuda.current_stream(x.device).cuda_stream
-        _native.check(_native.lib().cm_mac_modulate_run(self._plan, x.data_ptr(), out.data_ptr(), n,
-                                                        int(frame), int(first_line), int(k0), stream))
-        return out.cpu().numpy()
+        return self._launch(_native.lib().cm_mac_modulate_run, x, None, (n, self.comp_width), torch.float32, was_numpy,
+                            n, int(frame), int(first_line), int(k0))

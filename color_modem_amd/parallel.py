@@ -5,8 +5,8 @@ Frames are independent units of work - every stateful class of the reference res
 change, including the "3D" combs - so the data path needs no exchange step: rank r
 demodulates a contiguous frame range with `first_frame` advanced accordingly, and results stay
 sharded in each GPU's HBM.  A gather over xGMI is offered for callers that want the whole batch on
-every rank; it is not part of the timed hot path (one root's inbound links are slower than one
-GPU's output rate).
+every rank; it is not part of the hot path and is timed on its own by bench.py (one root's inbound
+links are slower than one GPU's output rate).
 """
 
 
@@ -19,14 +19,48 @@ def frame_range(n_frames, world_size, rank):
     return lo, lo + base + (1 if rank < extra else 0)
 
 
+def _world(group):
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_world_size(group), dist.get_rank(group)
+    return 1, 0
+
+
+def gather_frames(local, n_frames, group=None):
+    """all_gather of the per-rank results of a batch of `n_frames` frames split by frame_range: every rank receives
+    the complete [n_frames, ...] tensor.  One collective (ranks may differ by one frame: shares are padded to the
+    largest one)."""
+    import torch
+    import torch.distributed as dist
+    world, rank = _world(group)
+    if world == 1:
+        return local
+    lo, hi = frame_range(n_frames, world, rank)
+    if local.shape[0] != hi - lo:
+        raise ValueError('rank %d holds %d frames, its share of %d is %d' % (rank, local.shape[0], n_frames, hi - lo))
+    per = -(-n_frames // world)
+    if (hi - lo) == per:
+        padded = local.contiguous()
+    else:
+        padded = torch.zeros((per,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+        padded[:hi - lo] = local
+    full = torch.empty((world * per,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(full, padded, group=group)
+    if n_frames == world * per:
+        return full
+    parts = []
+    for r in range(world):
+        rlo, rhi = frame_range(n_frames, world, r)
+        parts.append(full[r * per:r * per + (rhi - rlo)])
+    return torch.cat(parts, dim=0)
+
+
 def demodulate_frames_sharded(demodulate, composite, first_frame=0, group=None, gather=False):
     """Run `demodulate(composite[lo:hi], first_frame + lo)` on this rank's share of a batch that every
     rank holds (or can address) in full.  Returns the local rgb[hi-lo, 3, H, W], or with gather=True
     the complete rgb[F, 3, H, W] assembled with all_gather (torch tensors only)."""
     import torch
-    import torch.distributed as dist
-    world = dist.get_world_size(group) if dist.is_initialized() else 1
-    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    world, rank = _world(group)
     n = composite.shape[0]
     lo, hi = frame_range(n, world, rank)
     local = demodulate(composite[lo:hi], first_frame + lo)
@@ -34,13 +68,4 @@ def demodulate_frames_sharded(demodulate, composite, first_frame=0, group=None, 
         return local
     if not torch.is_tensor(local):
         local = torch.as_tensor(local)
-    per = -(-n // world)  # ranks may differ by one frame: pad to the largest share
-    padded = torch.zeros((per,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
-    padded[:hi - lo] = local
-    parts = [torch.empty_like(padded) for _ in range(world)]
-    dist.all_gather(parts, padded, group=group)
-    out = []
-    for r in range(world):
-        rlo, rhi = frame_range(n, world, r)
-        out.append(parts[r][:rhi - rlo])
-    return torch.cat(out, dim=0)
+    return gather_frames(local, n, group)

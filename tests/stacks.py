@@ -74,3 +74,22 @@ def rel_err(out, ref):
     out = numpy.asarray(out, dtype=numpy.float64)
     ref = numpy.asarray(ref, dtype=numpy.float64)
     return float(numpy.max(numpy.abs(out - ref)) / numpy.max(numpy.abs(ref)))
+
+
+def allclose_violations(out, ref, rtol=1e-5, atol=1e-6):
+    """Number of samples outside numpy.allclose(out, ref, rtol, atol) - the element-wise criterion SURVEY.md Appendix C
+    asks to be reported beside rel_err (pure relative error is ill-defined at zero crossings, hence atol)."""
+    out = numpy.asarray(out, dtype=numpy.float64)
+    ref = numpy.asarray(ref, dtype=numpy.float64)
+    return int(numpy.count_nonzero(numpy.abs(out - ref) > atol + rtol * numpy.abs(ref)))
+
+
+def parity_report(out, ref):
+    """Per plane of [..., 3, H, W] results: (rel_err, allclose violations, samples)."""
+    out = numpy.asarray(out)
+    ref = numpy.asarray(ref)
+    rows = []
+    for p in range(out.shape[-3]):
+        o, r = out[..., p, :, :], ref[..., p, :, :]
+        rows.append((rel_err(o, r), allclose_violations(o, r), int(o.size)))
+    return rows

@@ -51,6 +51,13 @@ def _worker(rank, world, port, result_path):
     dist.destroy_process_group()
 
 
+def test_gather_frames_uneven_shares():
+    """one process: gather_frames is the identity; its share check refuses a tensor of the wrong length"""
+    import torch
+    x = torch.arange(12.0).reshape(3, 4)
+    assert parallel.gather_frames(x, 3) is x
+
+
 def test_two_rank_gloo_sharding(tmp_path):
     import torch.multiprocessing as mp
     import stacks
