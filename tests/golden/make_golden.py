@@ -226,8 +226,27 @@ STACKS.update({
     'pal_s_60': lambda lc: pal.PalSModem(lc),
 })
 
+# one representative of every variant family that had no reference-generated vector ("what's weak" 2):
+# PAL-N, NTSC-N and NTSC 3.61 on 625 / 525 lines, SECAM III, M, N, A
+STACKS.update({
+    'pal_d_paln': lambda lc: pal.PalDModem(lc, pal.PalVariant.PAL_N),
+    'pal_s_paln': lambda lc: pal.PalSModem(lc, pal.PalVariant.PAL_N),
+    'ntsc_comb_n': lambda lc: ntsc.NtscCombModem(lc, ntsc.NtscVariant.NTSC_N),
+    'ntsc_n': lambda lc: ntsc.NtscModem(lc, ntsc.NtscVariant.NTSC_N),
+    'ntsc_comb_3d_361': lambda lc: comb.Simple3DCombModem(ntsc.NtscCombModem(lc, ntsc.NtscVariant.NTSC361)),
+    'ntsc_361': lambda lc: ntsc.NtscModem(lc, ntsc.NtscVariant.NTSC361),
+    'ntsc_comb_i': lambda lc: ntsc.NtscCombModem(lc, ntsc.NtscVariant.NTSC_I),
+    'ntsc_i': lambda lc: ntsc.NtscModem(lc, ntsc.NtscVariant.NTSC_I),
+    'secam_iii': lambda lc: secam.SecamModem(lc, secam.SecamVariant.SECAM_III),
+    'secam_m': lambda lc: secam.SecamModem(lc, secam.SecamVariant.SECAM_M),
+    'secam_n': lambda lc: secam.SecamModem(lc, secam.SecamVariant.SECAM_N),
+    'secam_a': lambda lc: secam.SecamModem(lc, secam.SecamVariant.SECAM_A),
+})
+
 STANDARD = {'pal': 'GERBER_625', 'ntsc': 'NTSC_525', 'secam': 'GERBER_625'}
-STANDARD_OF = {'pal_d_palm': 'NTSC_525', 'pal_s_palm': 'NTSC_525', 'pal_d_60': 'NTSC_525', 'pal_s_60': 'NTSC_525'}
+STANDARD_OF = {'pal_d_palm': 'NTSC_525', 'pal_s_palm': 'NTSC_525', 'pal_d_60': 'NTSC_525', 'pal_s_60': 'NTSC_525',
+               'ntsc_comb_n': 'GERBER_625', 'ntsc_n': 'GERBER_625', 'ntsc_comb_i': 'GERBER_625', 'ntsc_i': 'GERBER_625',
+               'secam_m': 'NTSC_525', 'secam_a': 'BAIRD_405'}
 
 
 def line_config(stack, size):
@@ -342,6 +361,42 @@ def width_cases():
         save('frames_demod_%s_w%d' % (stack, W), inp=comp, out=out, frames=numpy.array(frames), size=numpy.array([W, H]))
 
 
+def variant_cases(only=()):
+    """Reference vectors for the variant families and image widths that were checked HIP-vs-oracle only: W x 6 frames, a
+    valid signal from the matching encoder, both directions."""
+    H = 6
+    cases = [  # (decoder stack, encoder stack, width, frames)
+        ('pal_d_paln', 'pal_s_paln', 720, [0, 1, 2, 3]),
+        ('ntsc_comb_n', 'ntsc_n', 720, [0, 1, 2]),
+        ('ntsc_comb_3d_361', 'ntsc_361', 720, [0, 1, 5]),
+        ('ntsc_comb_i', 'ntsc_i', 720, [1, 2]),
+        ('secam_iii', 'secam_iii', 720, [0, 5]),
+        ('secam_m', 'secam_m', 720, [1, 2]),
+        ('secam_n', 'secam_n', 720, [0, 3]),
+        ('secam_a', 'secam_a', 720, [2, 3]),
+        ('pal_d', 'pal_s', 480, [1, 2]),
+        ('pal_d', 'pal_s', 960, [0, 3]),
+        ('ntsc_comb_3d', 'ntsc', 1280, [0, 1]),
+        ('pal_3d', 'pal_s', 1920, [2]),
+        ('secam', 'secam', 960, [0, 1]),
+        ('secam', 'secam', 1280, [3]),
+    ]
+    for stack, mod_stack, W, frames in cases:
+        tag = stack if W == 720 else '%s_w%d' % (stack, W)
+        mtag = mod_stack if W == 720 else '%s_w%d' % (mod_stack, W)
+        if only and tag not in only:
+            continue
+        lc = line_config(stack, (W, H))
+        enc = STACKS[mod_stack](lc)
+        rgb = testing.synthetic_rgb(len(frames), H, W, seed=900 + W + len(stack))
+        comp = numpy.stack([run_mod_frame(enc, rgb[i].astype(numpy.float64), f) for i, f in enumerate(frames)])
+        save('frames_mod_' + mtag, inp=rgb, out=comp, frames=numpy.array(frames), size=numpy.array([W, H]))
+        comp = comp.astype(numpy.float32)
+        modem = STACKS[stack](lc)
+        out = numpy.stack([run_demod_frame(modem, comp[i].astype(numpy.float64), f) for i, f in enumerate(frames)])
+        save('frames_demod_' + tag, inp=comp, out=out, frames=numpy.array(frames), size=numpy.array([W, H]))
+
+
 def row_cases():
     """Explicit (frame, line) sequences at the full-height geometry, fed to one modem object in order."""
     seqs = {
@@ -387,9 +442,13 @@ if __name__ == '__main__':
     if sys.argv[1:2] == ['widths']:
         width_cases()
         sys.exit(0)
+    if sys.argv[1:2] == ['variants']:
+        variant_cases(sys.argv[2:])
+        sys.exit(0)
     make_plans()
     frame_cases()
     option_cases()
     width_cases()
+    variant_cases()
     row_cases()
     image_cases()

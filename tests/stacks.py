@@ -45,8 +45,25 @@ STACKS.update({
     'pal_d_60': lambda lc: pal.PalDModem(lc),
     'pal_s_60': lambda lc: pal.PalSModem(lc),
 })
+# variant families pinned by tests/golden/make_golden.py: variant_cases
+STACKS.update({
+    'pal_d_paln': lambda lc: pal.PalDModem(lc, pal.PalVariant.PAL_N),
+    'pal_s_paln': lambda lc: pal.PalSModem(lc, pal.PalVariant.PAL_N),
+    'ntsc_comb_n': lambda lc: ntsc.NtscCombModem(lc, ntsc.NtscVariant.NTSC_N),
+    'ntsc_n': lambda lc: ntsc.NtscModem(lc, ntsc.NtscVariant.NTSC_N),
+    'ntsc_comb_3d_361': lambda lc: comb.Simple3DCombModem(ntsc.NtscCombModem(lc, ntsc.NtscVariant.NTSC361)),
+    'ntsc_361': lambda lc: ntsc.NtscModem(lc, ntsc.NtscVariant.NTSC361),
+    'ntsc_comb_i': lambda lc: ntsc.NtscCombModem(lc, ntsc.NtscVariant.NTSC_I),
+    'ntsc_i': lambda lc: ntsc.NtscModem(lc, ntsc.NtscVariant.NTSC_I),
+    'secam_iii': lambda lc: secam.SecamModem(lc, secam.SecamVariant.SECAM_III),
+    'secam_m': lambda lc: secam.SecamModem(lc, secam.SecamVariant.SECAM_M),
+    'secam_n': lambda lc: secam.SecamModem(lc, secam.SecamVariant.SECAM_N),
+    'secam_a': lambda lc: secam.SecamModem(lc, secam.SecamVariant.SECAM_A),
+})
 STANDARD = {'pal': 'GERBER_625', 'ntsc': 'NTSC_525', 'secam': 'GERBER_625'}
-STANDARD_OF = {'pal_d_palm': 'NTSC_525', 'pal_s_palm': 'NTSC_525', 'pal_d_60': 'NTSC_525', 'pal_s_60': 'NTSC_525'}
+STANDARD_OF = {'pal_d_palm': 'NTSC_525', 'pal_s_palm': 'NTSC_525', 'pal_d_60': 'NTSC_525', 'pal_s_60': 'NTSC_525',
+               'ntsc_comb_n': 'GERBER_625', 'ntsc_n': 'GERBER_625', 'ntsc_comb_i': 'GERBER_625', 'ntsc_i': 'GERBER_625',
+               'secam_m': 'NTSC_525', 'secam_a': 'BAIRD_405'}
 
 
 def line_config(stack, size, explicit=True):

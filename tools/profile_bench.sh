@@ -1,0 +1,19 @@
+#!/bin/bash
+# Round profiles of the headline benchmark ON THE DRIVER'S OWN COMMAND (python3 bench.py --gpus 1 --steps 20 --warmup 5):
+#   kernel trace + stats, then PMC passes (memory traffic, SQ issue / wait / instruction counters), each in its own run.
+# usage (on the GPU box, from the repository root):  tools/profile_bench.sh <tag>     -> gpurun_out/prof_<tag>/summary.txt
+set -euo pipefail
+ROOT="$(cd "$(dirname "$0")/.." && pwd)"
+TAG="${1:?tag}"
+OUT="$ROOT/gpurun_out/prof_$TAG"
+rm -rf "$OUT"; mkdir -p "$OUT"
+cd /tmp && export TMPDIR=/tmp && cd "$ROOT"
+ARGS="bench.py --gpus 1 --steps 20 --warmup 5 --cpu-sample 0"
+python3 $ARGS > "$OUT/bench_line.json" 2> "$OUT/bench.err"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt" -- python3 $ARGS > "$OUT/kt.log" 2>&1
+rocprofv3 --pmc FETCH_SIZE GRBM_GUI_ACTIVE --output-format csv -d "$OUT/m1" -- python3 $ARGS > "$OUT/m1.log" 2>&1
+rocprofv3 --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --output-format csv -d "$OUT/m2" -- python3 $ARGS > "$OUT/m2.log" 2>&1
+rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_LDS SQ_INSTS_VMEM --output-format csv -d "$OUT/s1" -- python3 $ARGS > "$OUT/s1.log" 2>&1
+rocprofv3 --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_INST_CYCLES_SALU --output-format csv -d "$OUT/s2" -- python3 $ARGS > "$OUT/s2.log" 2>&1
+python3 tools/profile_summary.py "$OUT" > "$OUT/summary.txt"
+cat "$OUT/summary.txt"
