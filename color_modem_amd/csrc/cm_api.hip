@@ -1221,8 +1221,13 @@ extern "C" void cm_diag_set_buffer(unsigned long long *dev) { g_diag = dev; }
 
 int cm_plan_describe(const cm_plan *p, char *buf, int32_t buf_len) {
     if (!p || !buf || buf_len < 1) return 0;
-    int n = snprintf(buf, buf_len, "%s; calls per workgroup 64 (%s), halo %d", p->main.name.c_str(),
-                     p->pair ? "two wavefronts: front end | detectors + back end" : "one wavefront", p->main.depth);
+#ifdef CM_EXPERIMENTS
+    const char *exp = "; EXPERIMENTS BUILD (-DCM_EXPERIMENTS: ablation switches may be active, results may be wrong)";
+#else
+    const char *exp = "";
+#endif
+    int n = snprintf(buf, buf_len, "%s; calls per workgroup 64 (%s), halo %d%s", p->main.name.c_str(),
+                     p->pair ? "two wavefronts: front end | detectors + back end" : "one wavefront", p->main.depth, exp);
     return n < buf_len ? n : buf_len - 1;
 }
 

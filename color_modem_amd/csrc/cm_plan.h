@@ -166,11 +166,11 @@ bool build_secam_demod_k(const cm_plan_desc &d, SecamDemodK<T> &k, std::string &
     for (int i = 0; i < 10; ++i) k.taps.c[i] = T(2.0 * d.resample_fir[2 * i + 1]);
     k.taps.c0 = T(2.0 * d.resample_fir[20]);
     double g_b, g_bell, g_l, g_y, g_d;
-    if (!convert_sos<T, 3>(s.chroma_bp, FORM_BP, k.bpf, g_b, err, "chroma_bp")) return false;
+    if (!convert_sos<T, 3>(s.chroma_bp, FORM_BP, k.bpf, g_b, err, "chroma_bp", true)) return false;   // lower orders at low sampling rates: identity-padded
     if (!convert_sos_optional<T, 1>(s.bell, FORM_BP, k.bell, g_bell, err, "bell")) return false;
     k.has_bell = s.bell.n_sections != 0;   // secam.py:167-170: variants with bell_kn == bell_kd have no bell filter
-    if (!convert_sos<T, 3>(s.fm_lp, FORM_SYM, k.lpf, g_l, err, "fm_lp")) return false;
-    if (!convert_sos<T, 3>(s.luma_bs, FORM_SYM, k.ybs, g_y, err, "luma_bs")) return false;
+    if (!convert_sos<T, 3>(s.fm_lp, FORM_SYM, k.lpf, g_l, err, "fm_lp", true)) return false;
+    if (!convert_sos<T, 3>(s.luma_bs, FORM_SYM, k.ybs, g_y, err, "luma_bs", true)) return false;
     if (!convert_sos_optional<T, 1>(s.lf_rev, FORM_GEN, k.deemph, g_d, err, "lf_rev")) return false;   // secam.py:173-177
     if (s.bell.shift != 0 || s.lf_rev.shift != 0 || s.fm_lp.shift < 0 || s.chroma_bp.shift < 0 || s.luma_bs.shift < 0) {
         err = "SECAM filter shifts outside what the kernel is built for (bell 0, de-emphasis 0)";
@@ -225,7 +225,7 @@ bool build_secam_mod_k(const cm_plan_desc &d, SecamModK<T, TD> &k, std::string &
     const cm_secam_desc &s = d.secam;
     if (!s.present) { err = "SECAM constants missing"; return false; }
     double g1, g2;
-    if (!convert_sos<TD, 2>(s.pre_lp, FORM_GEN, k.pre_lp, g1, err, "pre_lp")) return false;
+    if (!convert_sos<TD, 2>(s.pre_lp, FORM_GEN, k.pre_lp, g1, err, "pre_lp", true)) return false;   // order 2 at low sampling rates (SECAM-A on 405 lines)
     if (!convert_sos_optional<TD, 1>(s.lf_pre, FORM_GEN, k.lf_pre, g2, err, "lf_pre")) return false;
     if (s.lf_pre.shift != 0 || s.pre_lp.shift < 0) { err = "SECAM encoder filter shifts outside what the kernel is built for"; return false; }
     k.width = d.width;

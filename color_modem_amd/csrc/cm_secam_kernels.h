@@ -24,12 +24,24 @@ struct SecamDemodArgs {
 
 // U8: the ImageModem byte boundary fused in, as in the PAL / NTSC decoders (cm_kernels.h: PassCfg::U8): composite bytes
 // enter through (5 (byte / 255) - 1) / 3, interleaved RGB bytes leave; the tiles hold bytes and the strides count bytes.
+// Occupancy knobs of the one-wave decoder: CM_SECAM_WAVES waves per SIMD the register allocation aims at (3 needs <= 168
+// VGPRs: 2 spilled values) and CM_SECAM_TILE samples per float input tile row (8: 32-byte row segments, 2 KiB instead of 8,
+// so that 11 workgroups instead of 8 fit the LDS of a CU).  Measured (profiles/r02_secam_notes.md): 3 / 8 runs 3.66 ms per
+// 1000 frames against 3.45 ms for 2 / 32 - more resident waves do not pay on this kernel either; 2 / 32 stays.
+#ifndef CM_SECAM_WAVES
+#define CM_SECAM_WAVES 2
+#endif
+#ifndef CM_SECAM_TILE
+#define CM_SECAM_TILE 32
+#endif
 template <bool U8>
-__global__ __launch_bounds__(64, 2) void secam_demod_kernel(const SecamDemodArgs args) {
+__global__ __launch_bounds__(64, CM_SECAM_WAVES) void secam_demod_kernel(const SecamDemodArgs args) {
     constexpr int kTile = 16, DEPTH = 1;
-    __shared__ __attribute__((aligned(16))) float lds_store[U8 ? (kLdsIn + 3 * 64 * kTile) / 4 : kLdsIn + 3 * 64 * kTile];
+    constexpr int kIT = U8 ? kInTile : CM_SECAM_TILE;      // samples per input tile row (byte tiles stay 32 wide)
+    constexpr int kIn = 64 * kIT;                           // floats (U8: bytes)
+    __shared__ __attribute__((aligned(16))) float lds_store[U8 ? (kIn + 3 * 64 * kTile) / 4 : kIn + 3 * 64 * kTile];
     lds_float *itile = (lds_float *)lds_store;
-    lds_float *otile_base = itile + (U8 ? kLdsIn / 4 : kLdsIn);
+    lds_float *otile_base = itile + (U8 ? kIn / 4 : kIn);
     typedef __attribute__((address_space(3))) unsigned char lds_u8;
     typedef __attribute__((address_space(3))) unsigned lds_u32;
     const Geom &g = args.g;
@@ -63,8 +75,8 @@ __global__ __launch_bounds__(64, 2) void secam_demod_kernel(const SecamDemodArgs
     for (int j = 0; j < 14; ++j) chw[j] = 0.f;
     lds_float *otile = U8 ? (lds_float *)((lds_u8 *)otile_base + lane * 3 * kTile) : otile_base + lane * kTile;
     const int wpos = ((lane >> CM_TILE_SWZ) & (kTile / 4 - 1)) << 2;
-    const lds_float *xrow = itile + lane * kInTile;
-    const lds_u8 *xrow8 = (const lds_u8 *)itile + lane * kInTile;
+    const lds_float *xrow = itile + lane * kIT;
+    const lds_u8 *xrow8 = (const lds_u8 *)itile + lane * kIT;
 
     const int W = g.W, P = k.preroll, Lc = W + P;
     const int lat = SecamDemod<float>::latency(k);          // chroma sample n = m - lat (the packed form keeps the schedule)
@@ -73,30 +85,32 @@ __global__ __launch_bounds__(64, 2) void secam_demod_kernel(const SecamDemodArgs
     const int s_flush = (lat_out + 3) & 3;
     float own_prev = 0.f, nb_prev = 0.f;
 
-    // one step of the stream: cc = cc[m]; x_l = x[n' + s_y] for the luma filter
-    auto step = [&](int m, float cc, float x_l, int sub) {
+    // one step of the stream: cc = cc[m]; x_l = x[n' + s_y] for the luma filter.  EDGE = false: interior of the row - no
+    // stage touches a boundary, the table indices need no clamp, the output sample lies inside the row
+    auto step = [&](auto edge_tag, int m, float cc, float x_l, int sub) __attribute__((always_inline)) {
+        constexpr bool EDGE = decltype(edge_tag)::value;
         int m2 = m - k.s_b - 10;
-        m2 = m2 < 0 ? 0 : (m2 > Lc - 1 ? Lc - 1 : m2);
+        if (EDGE) m2 = m2 < 0 ? 0 : (m2 > Lc - 1 ? Lc - 1 : m2);
         f4 c = ((const_f4 *)g.carrier4)[m2];
         int m4 = m - lat + P;                               // row-stream sample the decimator completes in this step
-        m4 = m4 < 0 ? 0 : (m4 > Lc - 1 ? Lc - 1 : m4);
+        if (EDGE) m4 = m4 < 0 ? 0 : (m4 > Lc - 1 ? Lc - 1 : m4);
         const float dc = ((const __attribute__((address_space(4))) float *)g.carrier2)[m4];
         float ch_out;
-        float own = st.chroma_step(k, kp, lk, m, cc, chw[sub], pf2{c.x, c.y}, pf2{c.z, c.w}, dc, ch_out);
+        float own = st.template chroma_step<EDGE>(k, kp, lk, m, cc, chw[sub], pf2{c.x, c.y}, pf2{c.z, c.w}, dc, ch_out);
         chw[10 + sub] = ch_out;
         const int n = m - 1 - lat;                          // the back end runs one sample behind the exchange
-        float luma = st.luma_step(k, n, x_l);
+        float luma = st.template luma_step<EDGE>(k, n, x_l);
         Rgb<float> o = st.finish(k, lk, luma, own_prev, nb_prev);
         own_prev = own;
         nb_prev = lane_from(idx1, own);
-        if (n >= 0 && n < W) put_rgb<U8, kTile>(otile, wpos, n, o);
+        if (!EDGE || (n >= 0 && n < W)) put_rgb<U8, kTile>(otile, wpos, n, o);
     };
     auto shift_window = [&]() {
 #pragma unroll
         for (int j = 0; j < 10; ++j) chw[j] = chw[j + 4];
     };
 
-    if (U8) fill_tile_u8(g, itile, xp, 0, lane); else fill_tile(g, itile, xp, 0, lane);
+    if (U8) fill_tile_u8(g, itile, xp, 0, lane); else fill_tile<kIT>(g, itile, xp, 0, lane);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_wave_barrier();
     // ---- pre-roll: cc[m] = x[P - m] for m < P, in bodies of 4 steps so that the windows keep their phase
@@ -109,20 +123,20 @@ __global__ __launch_bounds__(64, 2) void secam_demod_kernel(const SecamDemodArgs
             if (m >= 0) {
                 int xi = P - m;
                 if (xi > W - 1) xi = W - 1;
-                if (P < kInTile)   // the mirrored samples lie in the first input tile
+                if (P < kIT)   // the mirrored samples lie in the first input tile
                     cc = U8 ? __builtin_fmaf((float)xrow8[xi], 5.0f / (255.0f * 3.0f), -1.0f / 3.0f) : xrow[xi];
                 else               // long pre-rolls (sampling rates above ~27 MHz): straight from the row, once per line
                     cc = U8 ? __builtin_fmaf((float)((const unsigned char *)xp)[xi], 5.0f / (255.0f * 3.0f), -1.0f / 3.0f) : xp[xi];
             }
-            step(m, cc, 0.f, s);
+            step(std::true_type(), m, cc, 0.f, s);
         }
         shift_window();
     }
     // ---- main loop over the row samples xi = m - P
     auto read_x = [&](int first) -> f4 {
         f4 v;
-        if (U8) v = decode_bytes(*(const lds_u32 *)(xrow8 + (first & (kInTile - 1))));
-        else v = *(const lds_f4 *)(xrow + (first & (kInTile - 1)));
+        if (U8) v = decode_bytes(*(const lds_u32 *)(xrow8 + (first & (kIT - 1))));
+        else v = *(const lds_f4 *)(xrow + (first & (kIT - 1)));
         if (first + 3 >= W) {
             if (first >= W) v.x = 0.f;
             if (first + 1 >= W) v.y = 0.f;
@@ -135,12 +149,18 @@ __global__ __launch_bounds__(64, 2) void secam_demod_kernel(const SecamDemodArgs
     const int T = (g.Wp + lat_out + 3) & ~3;
     f4 xv = read_x(0);
     f4 nl = read_luma(-d_luma);
-    for (int xb = 0; xb < T; xb += 4) {
+    // Interior bodies: every stage index of the four steps m = P + xb .. + 3 lies strictly inside its stream - the first
+    // output sample n = m - 1 - lat is >= 0 (so is every earlier stage's index) and the last input index m + 3 stays below
+    // the end-of-row latch at Lc - 1 (so does every later stage's, which run behind it).
+    int xb_mid0 = (lat + 1 - P + 3) & ~3, xb_mid1 = (W - 8) & ~3;
+    if (xb_mid0 < 0) xb_mid0 = 0;
+    if (xb_mid1 <= xb_mid0) xb_mid0 = xb_mid1 = 0;
+    auto body = [&](auto edge_tag, int xb) __attribute__((always_inline)) {   // (not inlined, the line's state would live in scratch memory)
         const f4 lw = nl;
         nl = read_luma(xb + 4 - d_luma);
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-            step(P + xb + s, xv[s], lw[s], s);
+            step(edge_tag, P + xb + s, xv[s], lw[s], s);
             if (s == s_flush) {
                 const int n = xb + s - lat_out;
                 if (n >= 0 && ((n & (kTile - 1)) == kTile - 1 || n == g.Wp - 1)) {
@@ -151,17 +171,21 @@ __global__ __launch_bounds__(64, 2) void secam_demod_kernel(const SecamDemodArgs
         }
         shift_window();
         const int nxt = xb + 4;
-        if ((nxt & (kInTile - 1)) == 0 && nxt < W) {
+        if ((nxt & (kIT - 1)) == 0 && nxt < W) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_wave_barrier();
         }
         xv = read_x(nxt);
-        if ((nxt & (kInTile - 1)) == kInTile - 4 && nxt + 4 < W) {
+        if ((nxt & (kIT - 1)) == kIT - 4 && nxt + 4 < W) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_wave_barrier();
-            if (U8) fill_tile_u8(g, itile, xp, (nxt >> 5) + 1, lane); else fill_tile(g, itile, xp, (nxt >> 5) + 1, lane);
+            if (U8) fill_tile_u8(g, itile, xp, nxt / kIT + 1, lane); else fill_tile<kIT>(g, itile, xp, nxt / kIT + 1, lane);
         }
-    }
+    };
+    int xb = 0;
+    for (; xb < xb_mid0; xb += 4) body(std::true_type(), xb);
+    for (; xb < xb_mid1; xb += 4) body(std::false_type(), xb);
+    for (; xb < T; xb += 4) body(std::true_type(), xb);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------

@@ -34,6 +34,17 @@
 #define CM_HD inline
 #endif
 
+// Experiment switches (CM_EXP_*: timing ablations whose results are wrong by design; CM_DEV_ROLE: one stage of the pair
+// only) exist for tools/dev_build.sh A/B builds.  They compile only together with -DCM_EXPERIMENTS, which
+// cm_plan_describe reports and __graft_entry__.build() never sets: a stray -D cannot ship a wrong library silently.
+#if !defined(CM_EXPERIMENTS) &&                                                                                              \
+    (defined(CM_EXP_NO_LUMA) || defined(CM_EXP_NO_STORE) || defined(CM_EXP_PLAIN_STORE) || defined(CM_EXP_NO_FILL_WAIT) ||   \
+     defined(CM_EXP_NO_BSKIP) || defined(CM_EXP_ROLE_SWAP) || defined(CM_EXP_NO_FIR) || defined(CM_EXP_NO_PKFIR) ||          \
+     defined(CM_EXP_NO_LPF) || defined(CM_EXP_SECAM_ALWAYS_FAST) || defined(CM_EXP_SECAM_NO_LPF) ||                          \
+     defined(CM_EXP_SECAM_NO_PHASE) || defined(CM_DEV_ROLE))
+#error "CM_EXP_* / CM_DEV_ROLE switches produce wrong results by design: build them with -DCM_EXPERIMENTS (tools/dev_build.sh)"
+#endif
+
 namespace cm {
 
 // Compile-time shape of one colour system's filter set: section counts of the extract band-pass,

@@ -479,19 +479,24 @@ struct SecamDemodPk {
         p_last = iq_prev = iq_hold = pf2{0.f, 0.f};
         have_prev = 0;
     }
-    // car_e / car_o: {cos, sin} of the FM reference at 2x samples 2 m2 and 2 m2 + 1 (SGPR pairs)
+    // car_e / car_o: {cos, sin} of the FM reference at 2x samples 2 m2 and 2 m2 + 1 (SGPR pairs).
+    // EDGE = false: the caller guarantees that no stage index of this step touches a row boundary (every guard below holds
+    // and no latch fires): the interior of a row runs without the wave-uniform branches.
+    template <bool EDGE = true>
     __device__ __forceinline__ float chroma_step(const SecamDemodK<float> &k, const SecamDemodKPk &kp, const SecamDemodLaneK<float> &lk, int m,
                                                  float cc_now, float ch_d10, pf2 car_e, pf2 car_o, float dc, float &ch_out) {
         const int W = k.width, Lc = k.width + k.preroll;
         const int m1 = m - k.s_b, m2 = m1 - 10, m3 = m2 - k.q_l, m4 = m3 - 9, n = m4 - k.preroll;
         float ch = 0.f;
-        if (m >= 0 && m < Lc + k.s_b) {
-            if (m == Lc - 1) cc_last = cc_now;
-            if (m >= Lc) cc_now = cc_last;
+        if (!EDGE || (m >= 0 && m < Lc + k.s_b)) {
+            if (EDGE) {
+                if (m == Lc - 1) cc_last = cc_now;
+                if (m >= Lc) cc_now = cc_last;
+            }
             float b = iir_bp<VP::VB>(bpf, k.bpf, cc_now);
-            if (m1 >= 0) ch = k.has_bell ? iir_bp<false>(bell, k.bell, b) : b;
+            if (!EDGE || m1 >= 0) ch = k.has_bell ? iir_bp<false>(bell, k.bell, b) : b;
         }
-        if (m1 < 0 || m1 >= Lc) ch = 0.f;
+        if (EDGE && (m1 < 0 || m1 >= Lc)) ch = 0.f;
         ch_out = ch;
         const float a_odd = up.template push<VP::VT>(k.taps, ch);
         const float a_even = k.taps.c0 * ch_d10;
@@ -500,9 +505,11 @@ struct SecamDemodPk {
         pf2 p_e = pk_mul(pk_mul_bs<0>(pf2{a_even, a_even}, car_e), sgn);
         pf2 p_o = pk_mul(pk_mul_bs<0>(pf2{a_odd, a_odd}, car_o), sgn);
         float f_e = 0.f, f_o = 0.f;
-        if (m2 >= 0 && m2 < Lc + k.q_l) {
-            if (m2 == Lc - 1) p_last = p_o;
-            if (m2 >= Lc) p_e = p_o = p_last;
+        if (!EDGE || (m2 >= 0 && m2 < Lc + k.q_l)) {
+            if (EDGE) {
+                if (m2 == Lc - 1) p_last = p_o;
+                if (m2 >= Lc) p_e = p_o = p_last;
+            }
             pf2 y0 = iir_sym_pk<0, 3>(lp, kp.lpf, p_e);
             pf2 y1 = iir_sym_pk<0, 3>(lp, kp.lpf, p_o);
             if (k.odd_l) {   // odd shift: pair m3 = (odd output of the previous pair, even output of this one)
@@ -511,8 +518,8 @@ struct SecamDemodPk {
                 y1 = y0;
                 y0 = h;
             }
-            if (m3 >= 0 && m3 < Lc) {
-                const float d_e = have_prev ? phase_step_fast(iq_prev.x, iq_prev.y, y0.x, y0.y) : 0.f;  // secam.py:147: first step is 0
+            if (!EDGE || (m3 >= 0 && m3 < Lc)) {
+                const float d_e = (!EDGE || have_prev) ? phase_step_fast(iq_prev.x, iq_prev.y, y0.x, y0.y) : 0.f;  // secam.py:147: first step is 0
                 const float d_o = phase_step_fast(y0.x, y0.y, y1.x, y1.y);
                 have_prev = 1;
                 iq_prev = y1;
@@ -522,19 +529,22 @@ struct SecamDemodPk {
         }
         const float g2 = dn.template push_pair<VP::VT>(k.taps, f_e, f_o);   // decimated deviation from fc (cm_stages.h: SecamDemodLaneK)
         float c = 0.f;
-        if (n >= 0 && n < W) {
+        if (!EDGE || (n >= 0 && n < W)) {
             float f2 = (g2 + dc) + lk.off2;                              // 2 (f - fsc)
             f2 = f2 < lk.lo ? lk.lo : (f2 > lk.hi ? lk.hi : f2);         // secam.py:290
             c = iir_gen<false>(deemph, k.deemph, f2 * lk.scale);         // secam.py:291-296
         }
         return c;
     }
+    template <bool EDGE = true>
     __device__ __forceinline__ float luma_step(const SecamDemodK<float> &k, int n, float x_in) {
         const int W = k.width, j = n + k.s_y;
         float y = 0.f;
-        if (j >= 0 && j < W + k.s_y) {
-            if (j == W - 1) x_last = x_in;
-            if (j >= W) x_in = x_last;
+        if (!EDGE || (j >= 0 && j < W + k.s_y)) {
+            if (EDGE) {
+                if (j == W - 1) x_last = x_in;
+                if (j >= W) x_in = x_last;
+            }
             y = iir_sym<false>(ybs, k.ybs, x_in);
         }
         return y * k.luma_gain;

@@ -63,11 +63,69 @@ class _DevicePlans(object):
                 self._destroy(handle)
 
 
-def make_engine(modem, components=False, strip_chroma=True):
+class RowSession(object):
+    """The per-row protocol (Modem.demodulate / Modem.modulate, one row per call) without re-sending history: the rows of
+    the current run stay on the device in call order, a call uploads ONE row from a pinned staging buffer, launches the
+    run entry point on the last depth + 1 rows and downloads the one result row into a pinned buffer - two small
+    asynchronous copies, one launch, one stream synchronisation (tools/row_api_bench.py).  A session that missed calls of
+    the run (the caller switched between demodulate() and demodulate_components(), which run on different plans) is
+    given the run's last rows again."""
+
+    SLOTS = 64     # rows of history buffer; when it is full the last `depth` rows move to its front
+
+    def __init__(self, eng, direction):
+        torch = _torch()
+        self.eng, self.direction = eng, direction
+        dev = torch.device('cuda', torch.cuda.current_device())
+        L = _native.lib()
+        if direction == 'demod':
+            self.in_shape, self.out_shape, self.depth = (eng.comp_width,), (3, eng.width), eng.demod_depth
+            self.fn = L.cm_mac_demodulate_run if isinstance(eng, MacEngine) else L.cm_demodulate_run
+        else:
+            self.in_shape, self.out_shape, self.depth = (3, eng.in_width), (eng.comp_width,), eng.mod_depth
+            self.fn = L.cm_mac_modulate_run if isinstance(eng, MacEngine) else L.cm_modulate_run
+        self.hist = torch.empty((self.SLOTS,) + self.in_shape, dtype=torch.float32, device=dev)
+        self.out = torch.empty((self.depth + 1,) + self.out_shape, dtype=torch.float32, device=dev)
+        self.pin_in = torch.empty((self.depth + 1,) + self.in_shape, dtype=torch.float32).pin_memory()
+        self.pin_out = torch.empty(self.out_shape, dtype=torch.float32).pin_memory()
+        self.np_in, self.np_out = self.pin_in.numpy(), self.pin_out.numpy()
+        self.pos = -1                  # slot of the newest row
+        self.held = (None, -1)         # (run token, k) of the newest row on the device
+        self.device = dev
+
+    def step(self, rows, token, frame, line, k):
+        """rows: the run's last rows (numpy float32 of in_shape each, newest last, at least min(k, depth) + 1 of them);
+        the newest is call k (k = 0: first after a reset) at `line` of `frame`; token identifies the run.  Returns the
+        call's result as a float64 numpy array of out_shape."""
+        torch = _torch()
+        n = min(k, self.depth) + 1                     # rows the kernels look at
+        fresh = n if self.held != (token, k - 1) else 1
+        with torch.cuda.device(self.device):
+            stream = torch.cuda.current_stream(self.device)
+            if fresh == n:
+                self.pos = -1
+            elif self.pos + 1 >= self.SLOTS:           # compact: the last n - 1 rows to the front
+                keep = n - 1
+                self.hist[:keep].copy_(self.hist[self.pos + 1 - keep:self.pos + 1].clone())
+                self.pos = keep - 1
+            for j in range(fresh):
+                self.np_in[j] = rows[len(rows) - fresh + j]
+            self.hist[self.pos + 1:self.pos + 1 + fresh].copy_(self.pin_in[:fresh], non_blocking=True)
+            self.pos += fresh
+            self.held = (token, k)
+            first = self.pos - (n - 1)
+            _native.check(self.fn(self.eng._plans.get(self.device), self.hist[first].data_ptr(), self.out.data_ptr(), n, int(frame),
+                                  int(line) - 2 * (n - 1), int(k) - (n - 1), stream.cuda_stream))
+            self.pin_out.copy_(self.out[n - 1], non_blocking=True)
+            stream.synchronize()
+        return self.np_out.astype(numpy.float64)
+
+
+def make_engine(modem, components=False, strip_chroma=True, min_lines=0):
     """The engine of a modem stack: a cm_plan for the QAM / SECAM families, the plan-less MAC entry points for MacModem."""
     if modem._stack()['kind'] == 'mac':
         return MacEngine(modem, components)
-    return Engine(modem, components, strip_chroma)
+    return Engine(modem, components, strip_chroma, min_lines)
 
 
 class _EngineBase(object):
@@ -114,8 +172,9 @@ class _EngineBase(object):
 
 
 class Engine(_EngineBase):
-    def __init__(self, modem, components=False, strip_chroma=True):
-        self.built = plan.build_plan(modem, components, strip_chroma)
+    def __init__(self, modem, components=False, strip_chroma=True, min_lines=0):
+        self.built = plan.build_plan(modem, components, strip_chroma, min_lines)
+        self.n_lines = int(self.built.desc.demod_main.n_lines or self.built.desc.mod_main.n_lines)
         d = self.built.desc
         self.width, self.height = d.width, d.height
         self.comp_width = d.width

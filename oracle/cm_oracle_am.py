@@ -1,0 +1,261 @@
+# -*- coding: utf-8 -*-
+"""float64 restatement of the reference's amplitude-modulated line-sequential standards - TEST INFRASTRUCTURE.
+
+Follows /root/reference/color_modem/color/protosecam.py (ProtoSecamModem) and niir.py (NiirModem,
+HueCorrectingNiirModem) in plain numpy: ``resample_poly`` written out (cm_oracle_mac.resample_poly), ``lfilter`` as the
+direct-form recurrence, ``FilterFunction.__call__`` (utils.py:28-36) with its tail padding.  The filter coefficients come
+from the color_modem_amd host classes (the same scipy design calls as the reference).  Pinned against vectors the
+reference itself produced (tests/golden/am_*.npz, made by tests/golden/make_golden_am.py) in tests/test_am_oracle.py.
+May be imported only by tests/ and by tools run by hand - never by color_modem_amd.
+"""
+
+import numpy
+
+from oracle.cm_oracle_mac import resample_poly
+
+
+def lfilter(b, a, x):
+    """scipy.signal.lfilter(b, a, x) from a zero state (direct form II transposed, like scipy)."""
+    b = numpy.asarray(b, dtype=numpy.float64) / a[0]
+    a = numpy.asarray(a, dtype=numpy.float64) / a[0]
+    n = max(len(a), len(b))
+    b = numpy.concatenate([b, numpy.zeros(n - len(b))])
+    a = numpy.concatenate([a, numpy.zeros(n - len(a))])
+    z = numpy.zeros(n)
+    y = numpy.empty(len(x))
+    for i, xi in enumerate(numpy.asarray(x, dtype=numpy.float64)):
+        yi = b[0] * xi + z[0]
+        for j in range(1, n):
+            z[j - 1] = b[j] * xi + z[j] - a[j] * yi
+        y[i] = yi
+    return y
+
+
+try:    # the same recurrence, compiled (scipy is test infrastructure too; the loop above is the definition)
+    import scipy.signal as _sig
+
+    def lfilter(b, a, x):   # noqa: F811
+        return _sig.lfilter(b, a, numpy.asarray(x, dtype=numpy.float64))
+except ImportError:   # pragma: no cover
+    pass
+
+
+def apply_filter(f, x):
+    """FilterFunction.__call__ (utils.py:28-36): the tail is padded with `shift` copies of the last sample, the first
+    `shift` outputs are dropped."""
+    x = numpy.asarray(x, dtype=numpy.float64)
+    s = int(f.shift)
+    if s == 0:
+        return lfilter(f.b, f.a, x)
+    if s > 0:
+        return lfilter(f.b, f.a, numpy.concatenate((x, x[-1] * numpy.ones(s))))[s:]
+    return lfilter(f.b, f.a, numpy.concatenate((x[0] * numpy.ones(-s), x)))[:s]
+
+
+def _phase_ramp(start, step, n):
+    """numpy.linspace(start, start + n step, n, endpoint=False) % 2 pi"""
+    return numpy.linspace(start, start + n * step, n, endpoint=False) % (2.0 * numpy.pi)
+
+
+class ProtoSecamOracle(object):
+    """protosecam.py:27-112 on a color_modem_amd.color.protosecam.ProtoSecamModem (filter designs, matrices, geometry)."""
+
+    def __init__(self, modem):
+        self.m = modem
+        self._last_frame = -1
+        self._last_line = -1
+        self._last_chroma = None
+
+    def modulate(self, frame, line, r, g, b):
+        return self.modulate_components(frame, line, *self.m.encode_components(r, g, b))
+
+    def modulate_components(self, frame, line, luma, dr, db):
+        m = self.m
+        chroma = db if m.line_config.is_alternate_line(frame, line) else dr          # protosecam.py:75-78
+        chroma = 0.125 * (1.0 + apply_filter(m._chroma_precorrect_lowpass, chroma))      # :79-80
+        if m._premod_luma_filter:                                                        # :82-85
+            up = resample_poly(luma, 3, 1)
+            luma = resample_poly(apply_filter(m._remove_chroma_up, up), 1, 3)
+        start = m.start_phase(frame, line)
+        phase = _phase_ramp(start, 2.0 * m._carrier_phase_step, len(chroma))            # :87-89
+        return luma + numpy.cos(phase) * chroma
+
+    def demodulate(self, frame, line, composite):
+        m = self.m
+        composite = numpy.asarray(composite, dtype=numpy.float64)
+        if frame != self._last_frame or line != self._last_line + 2 or self._last_chroma is None:
+            self._last_chroma = numpy.zeros(len(composite))                             # :93-94
+        up = resample_poly(composite, 3, 1)                                              # :96
+        chroma_up = apply_filter(m._extract_chroma_up, up)
+        chroma_up = 0.5 * numpy.pi * numpy.abs(chroma_up)                                # :98
+        chroma_up = apply_filter(m._chroma_up_post_demod_filter, chroma_up)
+        luma = resample_poly(apply_filter(m._remove_chroma_up, up), 1, 3)                # :100-101
+        chroma = 8.0 * resample_poly(chroma_up, 1, 3) - 1.0                               # :102-103
+        if not m.line_config.is_alternate_line(frame, line):                             # :105-108
+            self._last_chroma, dr, db = chroma, chroma, self._last_chroma
+        else:
+            self._last_chroma, dr, db = chroma, self._last_chroma, chroma
+        self._last_frame, self._last_line = frame, line
+        return m.decode_components(luma, dr, db)
+
+
+class NiirOracle(object):
+    """niir.py:10-202 (noise_level 0) on a color_modem_amd.color.niir.NiirModem / HueCorrectingNiirModem."""
+
+    def __init__(self, modem):
+        self.m = modem
+        self.hue_correcting = bool(getattr(modem, 'hue_correcting', False))
+        self.modulation_delay = 1 if self.hue_correcting else 0
+        self._last_frame = -1
+        self._last_line = -1
+        self._last_phasemod_up = None
+        self._last_modulated_frame = -1
+        self._last_modulated_line = -1
+        self._last_luma = self._last_db = self._last_dr = None
+
+    # ---- encoder ---------------------------------------------------------------------------------
+    @staticmethod
+    def _add_offset(db, dr):                                                             # niir.py:42-49, noise off
+        saturation = numpy.sqrt(db * db + dr * dr) + 0.1
+        hue = numpy.arctan2(db, dr)
+        return saturation * numpy.sin(hue), saturation * numpy.cos(hue)
+
+    def _modulate_precorrected_chroma(self, frame, line, updb, updr):                    # niir.py:69-76
+        m = self.m
+        start = m.start_phase(frame, line)
+        n = len(updb)
+        phase = _phase_ramp(start, m._carrier_phase_step, n)
+        if not m.line_config.is_alternate_line(frame, line):
+            return updb * numpy.sin(phase) + updr * numpy.cos(phase)
+        return -numpy.sqrt(updb * updb + updr * updr) * numpy.sin(phase)
+
+    def _modulate_offset_components(self, frame, line, luma, db, dr):                    # niir.py:85-90
+        m = self.m
+        db = apply_filter(m._chroma_precorrect_lowpass, db)
+        dr = apply_filter(m._chroma_precorrect_lowpass, dr)
+        return luma + self._modulate_precorrected_chroma(frame, line, db, dr)
+
+    def modulate(self, frame, line, r, g, b):
+        luma, db, dr = [numpy.asarray(c, dtype=numpy.float64) for c in self.m.encode_components(r, g, b)]
+        return self.modulate_components(frame, line, luma, db, dr)
+
+    def modulate_components(self, frame, line, luma, db, dr):
+        luma, db, dr = [numpy.asarray(c, dtype=numpy.float64) for c in (luma, db, dr)]
+        if not self.hue_correcting:
+            return self._modulate_offset_components(frame, line, luma, *self._add_offset(db, dr))   # niir.py:78-83
+        # niir.py:181-202
+        if frame != self._last_modulated_frame or line != self._last_modulated_line + 2 or self._last_db is None \
+                or self._last_dr is None:
+            self._last_luma, self._last_db, self._last_dr = luma, db, dr
+        self._last_luma, luma = luma, self._last_luma
+        last_saturation = numpy.sqrt(self._last_db * self._last_db + self._last_dr * self._last_dr)
+        saturation = numpy.sqrt(db * db + dr * dr)
+        divisor = last_saturation + saturation
+        divisor = numpy.where(divisor == 0.0, 1.0, divisor)
+        avgdb = (self._last_db * last_saturation + db * saturation) / divisor
+        avgdr = (self._last_dr * last_saturation + dr * saturation) / divisor
+        ep = last_saturation + 0.1
+        hue = numpy.arctan2(avgdb, avgdr)
+        dbep, drep = ep * numpy.sin(hue), ep * numpy.cos(hue)
+        self._last_db, self._last_dr = db, dr
+        self._last_modulated_frame, self._last_modulated_line = frame, line
+        return self._modulate_offset_components(frame, line - 2, luma, dbep, drep)
+
+    # ---- decoder ---------------------------------------------------------------------------------
+    @staticmethod
+    def _remove_offset(db, dr):                                                          # niir.py:63-67
+        saturation = numpy.maximum(numpy.sqrt(db * db + dr * dr) - 0.1, 0.0)
+        hue = numpy.arctan2(db, dr)
+        return saturation * numpy.sin(hue), saturation * numpy.cos(hue)
+
+    def demodulate(self, frame, line, composite):
+        return self.m.decode_components(*self.demodulate_components(frame, line, composite))
+
+    def demodulate_components(self, frame, line, composite, strip_chroma=True):
+        luma, db, dr = self._demodulate_offset_components(frame, line, composite, strip_chroma)
+        return (luma,) + self._remove_offset(db, dr)
+
+    def _demodulate_offset_components(self, frame, line, composite, strip_chroma=True):  # niir.py:106-164
+        m = self.m
+        composite = numpy.asarray(composite, dtype=numpy.float64)
+        n = len(composite)
+        f_up, f_base = m._demodulate_upsampled_filter, m._demodulate_upsampled_baseband_filter
+        if frame != self._last_frame or line != self._last_line + 2 or self._last_phasemod_up is None:
+            last_modulated = self._modulate_precorrected_chroma(frame, line - 2, numpy.ones(n), numpy.zeros(n))
+            self._last_phasemod_up = apply_filter(f_up, resample_poly(last_modulated, 3, 1))
+        modulated_up = apply_filter(f_up, resample_poly(composite, 3, 1))
+        demod_up = 0.5 * numpy.pi * numpy.abs(modulated_up)
+        saturation_up = apply_filter(f_base, demod_up)
+        with numpy.errstate(divide='ignore', invalid='ignore'):
+            phasemod_up = modulated_up / saturation_up
+        alt = m.line_config.is_alternate_line(frame, line)
+        if not alt:
+            carrier_up, huemod_up, shift = self._last_phasemod_up, phasemod_up, m.line_shift
+        else:
+            carrier_up, huemod_up, shift = phasemod_up, self._last_phasemod_up, -m.line_shift
+        shifted = 0.5 * (carrier_up[0:-1] + carrier_up[1:])
+        altcarrier_up = numpy.concatenate((numpy.zeros(1), numpy.diff(shifted), numpy.zeros(1))) * 3.0 / m._carrier_phase_step
+        sinphi = resample_poly(huemod_up * carrier_up, 1, 3)
+        cosphi = resample_poly(huemod_up * altcarrier_up, 1, 3)
+        with numpy.errstate(divide='ignore', invalid='ignore'):
+            normalizer = numpy.sqrt(cosphi * cosphi + sinphi * sinphi)
+            cosphi = cosphi / normalizer
+            sinphi = sinphi / normalizer
+        sinphi, cosphi = -cosphi * numpy.sin(shift) - sinphi * numpy.cos(shift), \
+            sinphi * numpy.sin(shift) - cosphi * numpy.cos(shift)
+        saturation = resample_poly(saturation_up, 1, 3)
+        db = saturation * sinphi
+        dr = saturation * cosphi
+        luma = composite
+        if strip_chroma:
+            sincarrier = resample_poly(carrier_up, 1, 3)
+            coscarrier = resample_poly(altcarrier_up, 1, 3)
+            if not alt:
+                phase_shift, u_signal, v_signal = m.line_shift, db, dr
+            else:
+                phase_shift, u_signal, v_signal = 0.0, -numpy.sqrt(db * db + dr * dr), 0.0
+            phase_shift += numpy.pi - f_up.phase_shift
+            u_signal, v_signal = (u_signal * numpy.cos(phase_shift) - v_signal * numpy.sin(phase_shift)), \
+                                 (u_signal * numpy.sin(phase_shift) + v_signal * numpy.cos(phase_shift))
+            luma = luma - (u_signal * sincarrier + v_signal * coscarrier)
+        self._last_phasemod_up = phasemod_up
+        self._last_frame, self._last_line = frame, line
+        return luma, db, dr
+
+
+def make(modem):
+    kind = modem._stack()['kind']
+    return ProtoSecamOracle(modem) if kind == 'protosecam' else NiirOracle(modem)
+
+
+# ---- frames: the row schedule of image.py:47-55, 75-83 ------------------------------------------------------------
+def modulate_frames(modem, rgb, first_frame=0):
+    rgb = numpy.asarray(rgb, dtype=numpy.float64)
+    n, _, height, width = rgb.shape
+    out = numpy.zeros((n, height, width))
+    for i in range(n):
+        orc = make(modem)
+        delay = getattr(orc, 'modulation_delay', 0)
+        frame = first_frame + i
+        for field in range(2):
+            for y in range(field, 2 * delay, 2):
+                orc.modulate(frame, y, rgb[i, 0, y], rgb[i, 1, y], rgb[i, 2, y])
+            for y in range(field, height, 2):
+                iy = y + 2 * delay
+                while iy >= height:
+                    iy -= 2
+                out[i, y] = orc.modulate(frame, y + 2 * delay, rgb[i, 0, iy], rgb[i, 1, iy], rgb[i, 2, iy])
+    return out
+
+
+def demodulate_frames(modem, comp, first_frame=0):
+    comp = numpy.asarray(comp, dtype=numpy.float64)
+    n, height, width = comp.shape
+    out = numpy.zeros((n, 3, height, width))
+    for i in range(n):
+        orc = make(modem)
+        for field in range(2):
+            for y in range(field, height, 2):
+                r, g, b = orc.demodulate(first_frame + i, y, comp[i, y])
+                out[i, 0, y], out[i, 1, y], out[i, 2, y] = r, g, b
+    return out

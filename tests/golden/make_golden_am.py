@@ -1,0 +1,123 @@
+# -*- coding: utf-8 -*-
+"""Golden vectors of the amplitude-modulated line-sequential standards (Proto-SECAM 1957 and
+NIIR / SECAM-IV), produced by running the REFERENCE (color_modem/color/protosecam.py, niir.py, comb.py:130-167) in the
+build container:
+
+    python tests/golden/make_golden_am.py      # writes tests/golden/am_*.npz
+
+Recorded: `inp` (float32, fed to the reference after a cast to float64) and `out` (float64, what it returned) for whole
+small frames run through the row schedule of image.py:47-55, 75-83 (our float restatement of that loop, as in
+make_golden.py), plus explicit (frame, line) row sequences at the full-height geometry.  NIIR runs with noise_level 0
+(the reference's default; its noise is numpy.random and cannot be pinned).  numpy / scipy versions as in plans.json.
+"""
+
+import os
+import sys
+import warnings
+
+import numpy
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, '/root/reference')
+warnings.simplefilter('ignore')
+
+from color_modem_amd import testing  # noqa: E402
+from color_modem import comb, line  # noqa: E402
+from color_modem.color import niir, pal, protosecam  # noqa: E402
+
+LS = line.LineStandard
+
+# name -> (line standard, factory)
+STACKS = {
+    'proto': ('FRENCH_819', lambda lc: protosecam.ProtoSecamModem(lc)),
+    'proto_avg': ('FRENCH_819', lambda lc: comb.ColorAveragingModem(protosecam.ProtoSecamModem(lc))),
+    'proto_nofilter': ('BELGIAN_819', lambda lc: protosecam.ProtoSecamModem(lc, premod_luma_filter=False)),
+    'proto_625': ('GERBER_625', lambda lc: protosecam.ProtoSecamModem(lc)),
+    'niir': ('GERBER_625', lambda lc: niir.NiirModem(lc)),
+    'niir_hue': ('GERBER_625', lambda lc: niir.HueCorrectingNiirModem(lc)),
+    'niir_525': ('NTSC_525', lambda lc: niir.NiirModem(lc)),     # PAL sub-carrier on 525 lines: a phase cycle of 4800 frames
+}
+
+
+def run_mod_frame(modem, rgb, frame):
+    _, height, width = rgb.shape
+    delay = getattr(modem, 'modulation_delay', 0)
+    out = numpy.zeros((height, width))
+    for field in range(2):
+        for y in range(field, 2 * delay, 2):
+            modem.modulate(frame, y, *[rgb[p, y].astype(numpy.float64) for p in range(3)])
+        for y in range(field, height, 2):
+            iy = y + 2 * delay
+            while iy >= height:
+                iy -= 2
+            out[y] = modem.modulate(frame, y + 2 * delay, *[rgb[p, iy].astype(numpy.float64) for p in range(3)])
+    return out
+
+
+def run_demod_frame(modem, comp, frame):
+    height, width = comp.shape
+    out = numpy.zeros((3, height, width))
+    for field in range(2):
+        for y in range(field, height, 2):
+            out[:, y] = numpy.stack(modem.demodulate(frame, y, comp[y].astype(numpy.float64)))
+    return out
+
+
+def save(name, **arrays):
+    path = os.path.join(HERE, name + '.npz')
+    numpy.savez_compressed(path, **arrays)
+    print('%-28s %8.1f KB' % (name, os.path.getsize(path) / 1024.0))
+
+
+def main():
+    cases = [  # (stack, decoder stack, width, height, frames)
+        ('proto', 'proto', 720, 8, [0, 1]),
+        ('proto_avg', 'proto', 720, 7, [1, 2]),
+        ('proto_nofilter', 'proto_nofilter', 720, 6, [0]),
+        ('proto_625', 'proto_625', 1024, 6, [3]),
+        ('niir', 'niir', 720, 8, [0, 1, 2, 3]),
+        ('niir_hue', 'niir_hue', 720, 7, [1, 2]),
+        ('niir_525', 'niir_525', 768, 6, [0, 4799]),
+    ]
+    for stack, dec, W, H, frames in cases:
+        std_name, make = STACKS[stack]
+        lc = line.LineConfig((W, H), getattr(LS, std_name))
+        rgb = testing.synthetic_rgb(len(frames), H, W, seed=1300 + W + H)
+        comp = numpy.stack([run_mod_frame(make(lc), rgb[i], f) for i, f in enumerate(frames)])
+        save('am_mod_' + stack, inp=rgb, out=comp, frames=numpy.array(frames), size=numpy.array([W, H]),
+             standard=numpy.array(std_name))
+        comp32 = comp.astype(numpy.float32)
+        dmake = STACKS[dec][1]
+        back = numpy.stack([run_demod_frame(dmake(lc), comp32[i], f) for i, f in enumerate(frames)])
+        save('am_demod_' + stack, inp=comp32, out=back, frames=numpy.array(frames), size=numpy.array([W, H]),
+             standard=numpy.array(std_name))
+    # explicit (frame, line) sequences at the full-height geometry, with a break in the run and a frame change
+    seqs = {
+        'proto': ((720, 720), 'FRENCH_819', [(0, 0), (0, 2), (0, 4), (1, 715), (1, 717), (1, 719), (2, 1), (2, 3)]),
+        'niir': ((720, 576), 'GERBER_625', [(1, 0), (1, 2), (1, 4), (3, 571), (3, 573), (3, 575), (2, 1), (2, 3)]),
+    }
+    for stack, (size, std_name, seq) in seqs.items():
+        lc = line.LineConfig(size, getattr(LS, std_name))
+        enc, modem = STACKS[stack][1](lc), STACKS[stack][1](lc)
+        rgb = testing.synthetic_rgb(1, len(seq), size[0], seed=1400)[0]
+        comp = numpy.stack([enc.modulate(f, y, *[rgb[c, i].astype(numpy.float64) for c in range(3)])
+                            for i, (f, y) in enumerate(seq)]).astype(numpy.float32)
+        out = numpy.stack([numpy.stack(modem.demodulate(f, y, comp[i].astype(numpy.float64))) for i, (f, y) in enumerate(seq)])
+        save('am_rows_' + stack, inp=comp, out=out, seq=numpy.array(seq), size=numpy.array(size), standard=numpy.array(std_name))
+    # NIIR component protocol with the chroma left in the luma (strip_chroma=False) and noise input
+    lc = line.LineConfig((720, 6), LS.GERBER_625)
+    noise = testing.synthetic_composite(2, 6, 720, seed=1500)
+    m = niir.NiirModem(lc)
+    rows = []
+    for i, f in enumerate((0, 3)):
+        for field in range(2):
+            for y in range(field, 6, 2):
+                rows.append(numpy.stack(m.demodulate_components(f, y, noise[i, y].astype(numpy.float64), strip_chroma=False)))
+    save('am_niir_components_noise', inp=noise, out=numpy.stack(rows), frames=numpy.array([0, 3]), size=numpy.array([720, 6]),
+         standard=numpy.array('GERBER_625'))
+
+
+if __name__ == '__main__':
+    main()

@@ -569,3 +569,57 @@ def test_baseline_sizes_allclose(stack, enc, size, first):
         assert err < TOL, (stack, report)
         # the FM discriminator divides by the deviation (x 25-30): SECAM samples near zero may sit a few 1e-7 outside atol
         assert bad <= (n // 1000 if stack == 'secam' else 0), (stack, report)
+
+
+# ---- the per-row protocol on device-resident history (engine.RowSession) ---------------------------------------------------
+def test_row_protocol_long_run_and_lines_beyond_the_image():
+    """Modem.demodulate row by row: a run longer than the session's history buffer (compaction), a switch between
+    demodulate() and demodulate_components() in mid-run (two plans, one run state), and line numbers far beyond the
+    image height (the reference takes any: line.py:57-65; the plan's per-line tables are grown on demand)."""
+    from oracle import cm_oracle
+    for stack in ('pal_d', 'ntsc_comb_3d', 'secam'):
+        size = (720, 8)
+        modem = stacks.make(stack, size)
+        orc = cm_oracle.OracleModem(modem)
+        comp = testing.synthetic_composite(1, 200, 720, seed=5)[0]
+        if stack == 'secam':   # a valid signal for the FM discriminator
+            rgb = testing.synthetic_rgb(1, 200, 720, seed=6)[0].astype(numpy.float64)
+            enc = cm_oracle.OracleModem(modem)
+            comp = numpy.stack([enc.modulate(3, 2 * i, rgb[0, i], rgb[1, i], rgb[2, i]) for i in range(200)]).astype(numpy.float32)
+        for i in range(150):                     # lines 0, 2, ..., 298 of frame 3: one run, far beyond 8 rows
+            line = 2 * i
+            want = orc.demodulate(3, line, comp[i].astype(numpy.float64))
+            if stack != 'secam' and i in (70, 71):
+                y, u, v = modem.demodulate_components(3, line, comp[i])
+                got = modem.decode_components(y, u, v)
+            else:
+                got = modem.demodulate(3, line, comp[i])
+            assert stacks.rel_err(numpy.stack(got), numpy.stack(want)) < TOL, (stack, line)
+
+
+def test_out_argument_is_validated():
+    import torch
+    modem = stacks.make('pal_d', (720, 8))
+    eng = image.ImageModem(modem)._engine()
+    comp = torch.zeros((2, 8, 720), dtype=torch.float32, device='cuda')
+    good = torch.empty((2, 3, 8, 720), dtype=torch.float32, device='cuda')
+    assert eng.demodulate_frames(comp, 0, out=good) is good
+    for bad in (torch.empty((2, 3, 8, 719), dtype=torch.float32, device='cuda'),
+                torch.empty((2, 3, 8, 720), dtype=torch.float64, device='cuda'),
+                torch.empty((2, 3, 8, 720), dtype=torch.float32),
+                torch.empty((2, 3, 8, 1440), dtype=torch.float32, device='cuda')[..., ::2]):
+        with pytest.raises(ValueError):
+            eng.demodulate_frames(comp, 0, out=bad)
+
+
+def test_plan_refuses_host_pointers():
+    """The C ABI takes device pointers; a host buffer must come back as CM_ERR_INVALID, not as a GPU fault."""
+    import ctypes
+    from color_modem_amd import _native
+    modem = stacks.make('pal_d', (720, 8))
+    eng = image.ImageModem(modem)._engine()
+    host_in = numpy.zeros((1, 8, 720), dtype=numpy.float32)
+    host_out = numpy.zeros((1, 3, 8, 720), dtype=numpy.float32)
+    rc = _native.lib().cm_demodulate_frames(eng._plan, host_in.ctypes.data, host_out.ctypes.data, 1, 0, None)
+    assert rc == _native.CM_ERR_INVALID
+    assert b'device' in _native.lib().cm_last_error()

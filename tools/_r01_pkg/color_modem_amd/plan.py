@@ -177,7 +177,7 @@ def resample_fir():
 class QamTables(object):
     """Per-line coefficient derivation for the QAM-family stacks."""
 
-    def __init__(self, stack, strip_chroma=True, min_lines=0):
+    def __init__(self, stack, strip_chroma=True):
         self.stack = stack
         self.strip_chroma = strip_chroma         # False: demodulate_components(..., strip_chroma=False)
         self.kind = stack['kind']
@@ -206,7 +206,6 @@ class QamTables(object):
                                           % self.carrier_cycle)
             self.table_frames = 2
         self.width, self.height = self.lc.size
-        self.min_lines = int(min_lines)
         # comb.py:9-15: which averaging function combines the two chroma estimates (wrapper, or Pal3DModem's two paths)
         from color_modem_amd import comb as comb_module
         fn = None
@@ -391,9 +390,7 @@ class QamTables(object):
         return theta
 
     def n_lines(self):
-        # the frame entry points need height + 2 delay lines; the per-row protocol takes any line number the caller
-        # passes (the reference's size only sets fs and the line shift): min_lines grows the tables for it
-        return max(self.height + 2 * max(self.demodulation_delay, self.modulation_delay) + 4, self.min_lines)
+        return self.height + 2 * max(self.demodulation_delay, self.modulation_delay) + 4
 
     def phase_free(self, lin, frame, line):
         """Re-express a combination over the base pairs B_{k-j} (detected at each line's own phase theta_j)
@@ -495,8 +492,8 @@ def _lane_table(arr, luma_prev_bits=0):
     return t
 
 
-def build_qam_plan(stack, components=False, strip_chroma=True, min_lines=0):
-    tb = QamTables(stack, strip_chroma, min_lines)
+def build_qam_plan(stack, components=False, strip_chroma=True):
+    tb = QamTables(stack, strip_chroma)
     b = tb.backend
     d = PlanDesc()
     d.abi_version = CM_ABI_VERSION
@@ -544,12 +541,11 @@ def build_qam_plan(stack, components=False, strip_chroma=True, min_lines=0):
     return BuiltPlan(d, [main, first, mod, rot], tb)
 
 
-def build_plan(modem, components=False, strip_chroma=True, min_lines=0):
+def build_plan(modem, components=False, strip_chroma=True):
     """components: (y, u, v) instead of (r, g, b) at the boundary (modulate_components / demodulate_components);
-    strip_chroma: the flag of demodulate_components (False: luma is returned unstripped); min_lines: line numbers
-    0 .. min_lines - 1 get table entries even beyond the image height (the per-row protocol)."""
+    strip_chroma: the flag of demodulate_components (False: luma is returned unstripped)."""
     stack = modem._stack()
     if stack['kind'] == 'secam':
         from color_modem_amd import plan_secam
-        return plan_secam.build_secam_plan(stack, components, min_lines)
-    return build_qam_plan(stack, components, strip_chroma, min_lines)
+        return plan_secam.build_secam_plan(stack, components)
+    return build_qam_plan(stack, components, strip_chroma)

@@ -6,7 +6,7 @@ import numpy
 from color_modem_amd import plan
 
 
-def build_secam_plan(stack, components=False, min_lines=0):
+def build_secam_plan(stack, components=False):
     m = stack['backend']
     if stack.get('demod_wrapper'):
         # the reference would fail at the first row: SecamModem has no demodulate_components
@@ -43,7 +43,7 @@ def build_secam_plan(stack, components=False, min_lines=0):
     s.luma_bs = plan.iir_desc(m._chroma_demod_luma_filter)
     s.fm_lp = plan.iir_desc(m._chroma_demod._lowpass)
 
-    n_lines = max(height + 2 * d.modulation_delay + 4, int(min_lines))
+    n_lines = height + 2 * d.modulation_delay + 4
     demod = numpy.zeros((2, 3, n_lines, plan.CM_LANE_DOUBLES))
     for f in range(2):
         for k in range(3):

@@ -4,25 +4,21 @@
 ``modulate(frame, line, r, g, b)`` / ``demodulate(frame, line, composite)`` keep the reference's
 stateful, one-row-per-call semantics: a call continues the current *run* when
 ``frame == last_frame and line == last_line + 2`` (ref comb.py:48,97,142; secam.py:279),
-otherwise every level of the stack starts over.  Each call is evaluated on the GPU on the last
-``depth + 1`` input rows of the run, which stay on the device between calls (engine.RowSession: one row up, one
-result row down per call).
+otherwise every level of the stack starts over.  Each call is evaluated on the GPU by handing
+the engine the last ``depth + 1`` input rows of the run.
 """
 
 import numpy
 
 
 class _Run(object):
-    __slots__ = ('frame', 'line', 'k', 'rows', 'token', 'sessions')
-    _tokens = [0]
+    __slots__ = ('frame', 'line', 'k', 'rows')
 
     def __init__(self):
         self.frame = -1
         self.line = -1
         self.k = -1
-        self.rows = []          # the run's last depth + 1 input rows (host copies: a session that missed calls needs them)
-        self.token = None       # identity of the current run
-        self.sessions = {}      # (engine id, direction) -> engine.RowSession holding the run's rows on the device
+        self.rows = []
 
 
 class RowApi(object):
@@ -34,45 +30,31 @@ class RowApi(object):
         self._demod_run = _Run()
         self._mod_run = _Run()
 
-    def _engine(self, components=False, strip_chroma=True, line=0):
-        """The engine of this stack for the given protocol flavour; its per-line tables are grown (the plan is rebuilt)
-        when a call names a line beyond them - the reference takes any line number (line.py:57-65)."""
+    def _engine(self, components=False, strip_chroma=True):
         key = (bool(components), bool(strip_chroma))
-        eng = self._engines.get(key)
-        if eng is None or line >= getattr(eng, 'n_lines', 1 << 30):
+        if key not in self._engines:
             from color_modem_amd import engine
-            need = 0 if eng is None else max(2 * eng.n_lines, line + 64)
-            eng = self._engines[key] = engine.make_engine(self, components=key[0], strip_chroma=key[1], min_lines=max(need, line + 1))
-        return eng
+            self._engines[key] = engine.make_engine(self, components=key[0], strip_chroma=key[1])
+        return self._engines[key]
 
     @staticmethod
     def _advance(run, frame, line, row, depth):
         if frame != run.frame or line != run.line + 2 or run.k < 0:
             run.k = 0
             run.rows = []
-            _Run._tokens[0] += 1
-            run.token = _Run._tokens[0]
         else:
             run.k += 1
         run.frame, run.line = frame, line
         run.rows.append(row)
         del run.rows[:-(depth + 1)]
 
-    @staticmethod
-    def _step(run, eng, direction, frame, line):
-        from color_modem_amd import engine
-        key = (id(eng), direction)
-        if key not in run.sessions:
-            run.sessions[key] = engine.RowSession(eng, direction)
-        return run.sessions[key].step(run.rows, run.token, frame, line, run.k)
-
     def demodulate(self, frame, line, composite):
-        return self._demodulate(self._engine(line=line), frame, line, composite)
+        return self._demodulate(self._engine(), frame, line, composite)
 
     def demodulate_components(self, frame, line, composite, strip_chroma=True):
         """(y, u, v) of one row (ref qam.py:43-58 behind pal.py:54-59 / ntsc.py:47-49, comb.py:47-59, 96-113,
         pal.py:180-234); shares the run state with demodulate(), which is this followed by decode_components."""
-        eng = self._engine(True, strip_chroma, line)
+        eng = self._engine(True, strip_chroma)
         if not strip_chroma and eng.built.desc.first_is_plain:
             # the first line of a run is the backend's own unstripped decode (comb.py:48-49); the plain pass of
             # the comb's plan only exists with band-stop luma, so that one call goes to the backend's plan
@@ -90,16 +72,18 @@ class RowApi(object):
             raise ValueError('composite must be one row of %d samples' % eng.comp_width)
         run = self._demod_run
         self._advance(run, frame, line, row, eng.demod_depth)
-        r, g, b = self._step(run, eng, 'demod', frame, line)
+        n = len(run.rows)
+        out = eng.demodulate_run(numpy.stack(run.rows), frame, line - 2 * (n - 1), run.k - (n - 1))
+        r, g, b = out[n - 1].astype(numpy.float64)
         return r, g, b
 
     def modulate(self, frame, line, r, g, b):
-        return self._modulate(self._engine(line=line), frame, line, r, g, b)
+        return self._modulate(self._engine(), frame, line, r, g, b)
 
     def modulate_components(self, frame, line, y, u, v):
         """Composite row from (y, u, v) / (luma, dr, db) (ref qam.py:28-32 behind pal.py:48-52 / ntsc.py:43-45,
         comb.py:141-152, secam.py:258-276); shares the run state with modulate()."""
-        return self._modulate(self._engine(True, True, line), frame, line, y, u, v)
+        return self._modulate(self._engine(True, True), frame, line, y, u, v)
 
     def _modulate(self, eng, frame, line, r, g, b):
         assert len(r) == len(g) == len(b)
@@ -108,4 +92,6 @@ class RowApi(object):
             raise ValueError('r, g, b must be rows of %d samples' % eng.in_width)
         run = self._mod_run
         self._advance(run, frame, line, row, eng.mod_depth)
-        return self._step(run, eng, 'mod', frame, line)
+        n = len(run.rows)
+        out = eng.modulate_run(numpy.stack(run.rows), frame, line - 2 * (n - 1), run.k - (n - 1))
+        return out[n - 1].astype(numpy.float64)

@@ -1,0 +1,153 @@
+# -*- coding: utf-8 -*-
+"""IIR design wrappers and carrier bookkeeping (host side).
+
+Mirrors the names of the reference's ``color_modem/utils.py`` (``FilterFunction``,
+``iirfilter``, ``iirdesign``, ``iirdesign_wc``, ``iirsplitter``, ``ConstantFrequencyCarrier``;
+/root/reference/color_modem/utils.py:9-88).  Design runs once per modem on the host with
+scipy.signal, exactly the third-party calls the reference makes; what differs is what a
+``FilterFunction`` *is* here: a design record (b, a, shift, phase_shift, second-order
+sections) that the device plan consumes.  Filtering itself happens in the HIP kernels.
+
+``iirdesign`` keeps the behaviour of the scipy release the reference was written against:
+scipy >= 1.12 rejects band edges <= 0, which the reference's NTSC-M set-up relies on
+(SURVEY.md D6).  We therefore call ``buttord`` + ``iirfilter`` directly - identical
+coefficients wherever current scipy accepts the request.
+"""
+
+import fractions
+
+import numpy
+import scipy.signal
+
+_BANDSTOP_NAMES = frozenset(('bs', 'bandstop', 'bands', 'stop'))
+
+
+class FilterFunction(object):
+    """Design record of one IIR filter plus the delay compensation of ref utils.py:9-26."""
+
+    def __init__(self, b, a, wp, btype, shift, sos=None):
+        self.b = numpy.array(b, dtype=numpy.float64)
+        self.a = numpy.array(a, dtype=numpy.float64)
+        self._sos = None if sos is None else numpy.array(sos, dtype=numpy.float64)
+        wp = numpy.atleast_1d(wp)
+        if len(wp) > 1 and btype.lower() not in _BANDSTOP_NAMES:
+            centre = float(numpy.average(wp))
+        else:
+            centre = 0.0
+        self.shift_frequency = centre
+        if shift:
+            delay = scipy.signal.group_delay((self.b, self.a), [centre], fs=2.0)[1]
+            self.shift = int(numpy.round(delay[0]))
+        else:
+            self.shift = 0
+        response = scipy.signal.freqz(self.b, self.a, worN=[centre], fs=2.0)[1][0]
+        self.phase_shift = float((numpy.angle(response) + self.shift * numpy.pi * centre) % (2.0 * numpy.pi))
+
+    # the reference keeps these as private attributes; expose both spellings
+    @property
+    def _b(self):
+        return self.b
+
+    @property
+    def _a(self):
+        return self.a
+
+    @property
+    def _shift(self):
+        return self.shift
+
+    @property
+    def order(self):
+        return max(len(self.a), len(self.b)) - 1
+
+    def sos(self):
+        """Second-order sections [n, 6].
+
+        Taken from the zero/pole form of the same design when the filter came from one of the
+        wrappers below (exact zeros at z = +-1 / on the unit circle; factoring (b, a) back would
+        smear repeated roots by ~1e-8), otherwise factored from (b, a)."""
+        if self._sos is not None:
+            return self._sos
+        return scipy.signal.tf2sos(self.b, self.a)
+
+    def __call__(self, x):
+        raise RuntimeError('FilterFunction is a design record in color_modem_amd; rows are filtered on the GPU '
+                           '(use the Modem / ImageModem entry points)')
+
+
+def notch(qam_modem, q):
+    """Luma notch at the sub-carrier (ref comb.py:18-20)."""
+    b, a = scipy.signal.iirnotch(2.0 * qam_modem.config.fsc / qam_modem.line_config.fs, q)
+    return FilterFunction(b, a, wp=0.0, btype='bandstop', shift=True)
+
+
+def iirfilter(N, Wn, rp=None, rs=None, btype='band', ftype='butter', shift=True):
+    b, a = scipy.signal.iirfilter(N, Wn, rp, rs, btype, ftype=ftype)
+    sos = scipy.signal.iirfilter(N, Wn, rp, rs, btype, ftype=ftype, output='sos')
+    return FilterFunction(b, a, Wn, btype, shift, sos=sos)
+
+
+def _legacy_scipy_iirdesign(wp, ws, gpass, gstop, ftype):
+    if ftype != 'butter':
+        raise ValueError('only Butterworth designs are requested on this path')
+    wp = numpy.atleast_1d(wp)
+    ws = numpy.atleast_1d(ws)
+    if len(wp) == 1:
+        btype = 'lowpass' if wp[0] < ws[0] else 'highpass'
+    else:
+        btype = 'bandstop' if wp[0] < ws[0] else 'bandpass'
+    order, natural = scipy.signal.buttord(wp, ws, gpass, gstop, analog=False)
+    ba = scipy.signal.iirfilter(order, natural, rp=gpass, rs=gstop, btype=btype, ftype='butter', output='ba')
+    sos = scipy.signal.iirfilter(order, natural, rp=gpass, rs=gstop, btype=btype, ftype='butter', output='sos')
+    return ba[0], ba[1], sos
+
+
+def iirdesign(wp, ws, gpass, gstop, ftype='butter', shift=True):
+    tiny = numpy.nextafter(0.0, 1.0)
+    below_one = numpy.nextafter(1.0, 0.0)
+    b, a, sos = _legacy_scipy_iirdesign(numpy.maximum(wp, tiny), numpy.minimum(ws, below_one), gpass, gstop, ftype)
+    wp_arr = numpy.atleast_1d(wp)
+    ws_arr = numpy.atleast_1d(ws)
+    btype = 'bandstop' if (len(wp_arr) > 1 and len(ws_arr) > 1 and ws_arr[0] > wp_arr[0]) else 'band'
+    return FilterFunction(b, a, wp, btype, shift, sos=sos)
+
+
+def iirdesign_wc(wc, wp, ws, gpass, gstop, ftype='butter', shift=True):
+    return iirdesign([wc - wp, wc + wp], [wc - ws, wc + ws], gpass, gstop, ftype, shift)
+
+
+def _complement_db(db):
+    return -(20.0 * numpy.log10(1.0 - 10.0 ** (-db / 20.0)))
+
+
+def iirsplitter(wc, wp, ws, gpass, gstop, ftype='butter', shift=True):
+    """Complementary band-pass / band-stop pair around `wc` (ref utils.py:58-64)."""
+    bandpass = iirdesign_wc(wc, wp, ws, gpass, gstop, ftype, shift)
+    bandstop = iirdesign_wc(wc, ws, wp, _complement_db(gstop), _complement_db(gpass), ftype, shift)
+    return bandpass, bandstop
+
+
+class ConstantFrequencyCarrier(object):
+    """Subcarrier phase bookkeeping; needs ``self.config.fsc`` and ``self.line_config`` (ref utils.py:67-88)."""
+
+    @property
+    def line_shift(self):
+        std = self.line_config.line_standard
+        return 2.0 * numpy.pi * ((self.config.fsc / (std.frame_rate * std.total_lines)) % 1.0)
+
+    @property
+    def frame_shift(self):
+        return 2.0 * numpy.pi * ((self.config.fsc / self.line_config.line_standard.frame_rate) % 1.0)
+
+    @property
+    def frame_cycle(self):
+        ratio = fractions.Fraction(self.config.fsc / self.line_config.line_standard.frame_rate)
+        return ratio.limit_denominator().denominator
+
+    def start_phase(self, frame, line):
+        std = self.line_config.line_standard
+        first_line = min(std.odd_field_first_active_line, std.even_field_first_active_line)
+        two_pi = 2.0 * numpy.pi
+        from_frame = ((frame % self.frame_cycle) * self.frame_shift) % two_pi
+        from_line = ((self.line_config.analog_line(line) - first_line) * self.line_shift) % two_pi
+        return (from_frame + from_line) % two_pi

@@ -1,18 +1,31 @@
+"""Per-row protocol cost (Modem.demodulate / Modem.modulate, one row per call): python tools/row_api_bench.py [package dir]
+The optional argument puts another checkout's color_modem_amd first on the path (before / after comparisons)."""
 import sys, time, numpy
-sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
+if len(sys.argv) > 1:
+    sys.path.insert(0, sys.argv[1])
+sys.path.insert(1, '.'); sys.path.insert(2, 'tests')
 import stacks
+import color_modem_amd
 from color_modem_amd import testing
-m = stacks.make('pal_d', (720, 576))
-comp = testing.synthetic_composite(1, 576, 720)[0]
-m.demodulate(0, 0, comp[0])
-t0 = time.time()
-for y in range(0, 576, 2): m.demodulate(0, y, comp[y])
-for y in range(1, 576, 2): m.demodulate(0, y, comp[y])
-dt = time.time() - t0
-print('per-row API: %.1f ms per frame, %.3f ms per row' % (dt * 1e3, dt / 576 * 1e3))
-enc = stacks.make('pal_s', (720, 576))
-rgb = testing.synthetic_rgb(1, 576, 720)[0]
-t0 = time.time()
-for y in range(0, 576, 2): enc.modulate(0, y, rgb[0, y], rgb[1, y], rgb[2, y])
-dt = time.time() - t0
-print('per-row modulate: %.3f ms per row' % (dt / 288 * 1e3))
+print('package:', color_modem_amd.__path__[0])
+for name, size in (('pal_d', (720, 576)), ('ntsc_comb_3d', (720, 480)), ('secam', (720, 576))):
+    m = stacks.make(name, size)
+    comp = testing.synthetic_composite(1, size[1], size[0])[0]
+    for y in range(0, 8, 2): m.demodulate(0, y, comp[y])          # plan creation, session buffers
+    best = 1e9
+    for rep in range(3):
+        t0 = time.time()
+        for y in range(0, size[1], 2): m.demodulate(1 + rep, y, comp[y])
+        for y in range(1, size[1], 2): m.demodulate(1 + rep, y, comp[y])
+        best = min(best, time.time() - t0)
+    print('%-14s demodulate: %.1f ms per frame, %.1f us per row' % (name, best * 1e3, best / size[1] * 1e6))
+for name, size in (('pal_s', (720, 576)), ('secam_avg', (720, 576))):
+    enc = stacks.make(name, size)
+    rgb = testing.synthetic_rgb(1, size[1], size[0])[0]
+    for y in range(0, 8, 2): enc.modulate(0, y, rgb[0, y], rgb[1, y], rgb[2, y])
+    best = 1e9
+    for rep in range(3):
+        t0 = time.time()
+        for y in range(0, size[1], 2): enc.modulate(1 + rep, y, rgb[0, y], rgb[1, y], rgb[2, y])
+        best = min(best, time.time() - t0)
+    print('%-14s modulate:   %.1f us per row' % (name, best / (size[1] // 2) * 1e6))
