@@ -1,0 +1,87 @@
+// cm_am_plan.h - host side: cm_am_desc (include/color_modem_hip.h) -> the uniform blocks of cm_am_stages.h.
+// Shared by the library (T = float) and by the host simulator of tests/sim (T = double / float).
+#ifndef CM_AM_PLAN_H
+#define CM_AM_PLAN_H
+
+#include <cmath>
+#include <string>
+
+#include "../../include/color_modem_hip.h"
+#include "cm_am_stages.h"
+#include "cm_plan.h"
+
+namespace cm {
+
+inline FFGeom ff_geom(int shift, int rate) {
+    FFGeom g;
+    g.shift = shift;
+    g.q = (shift + rate - 1) / rate;
+    g.r = rate * g.q - shift;
+    return g;
+}
+
+template <typename T>
+void load_taps3(const cm_am_desc &d, Taps3<T> &up, Taps3<T> &dn) {
+    for (int i = 0; i < kAmTaps; ++i) {
+        up.h[i] = T(3.0 * d.resample_fir3[i]);    // resample_poly scales the interpolator by `up`
+        dn.h[i] = T(d.resample_fir3[i]);
+    }
+}
+
+inline bool am_shifts_ok(const cm_am_desc &d, std::string &err) {
+    const cm_iir_desc *f[4] = {&d.precorrect, &d.bandpass_up, &d.bandstop_up, &d.lowpass_up};
+    for (const cm_iir_desc *x : f)
+        if (x->shift < 0) { err = "negative FilterFunction shift is not used on this path"; return false; }
+    return true;
+}
+
+template <typename T>
+bool build_proto_demod_k(const cm_am_desc &d, ProtoDemodK<T> &k, std::string &err) {
+    if (!am_shifts_ok(d, err)) return false;
+    k.width = d.width;
+    k.ge = ff_geom(d.bandpass_up.shift, 3);
+    k.gr = ff_geom(d.bandstop_up.shift, 3);
+    k.gp = ff_geom(d.lowpass_up.shift, 3);
+    load_taps3(d, k.up, k.dn);
+    double g_e, g_r, g_p;
+    if (!convert_sos<T, 3>(d.bandpass_up, FORM_BP, k.ext, g_e, err, "bandpass_up", true)) return false;
+    if (!convert_sos<T, 3>(d.bandstop_up, FORM_SYM, k.rem, g_r, err, "bandstop_up", true)) return false;
+    if (!convert_sos<T, 2>(d.lowpass_up, FORM_GEN, k.post, g_p, err, "lowpass_up", true)) return false;
+    k.chroma_gain = T(8.0 * 0.5 * M_PI * std::fabs(g_e) * g_p);     // protosecam.py:98, 103
+    k.luma_gain = T(g_r);
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) k.m[i][j] = T(d.decode_matrix[3 * i + j]);
+    return true;
+}
+
+template <typename T>
+bool build_proto_mod_k(const cm_am_desc &d, ProtoModK<T> &k, std::string &err) {
+    if (!am_shifts_ok(d, err)) return false;
+    k.width = d.width;
+    k.luma_filter = d.premod_luma_filter ? 1 : 0;
+    k.s_c = d.precorrect.shift;
+    k.gr = ff_geom(d.bandstop_up.shift, 3);
+    load_taps3(d, k.up, k.dn);
+    double g_c, g_r;
+    if (!convert_sos<T, 2>(d.precorrect, FORM_GEN, k.pre, g_c, err, "precorrect", true)) return false;
+    if (!convert_sos<T, 3>(d.bandstop_up, FORM_SYM, k.rem, g_r, err, "bandstop_up", true)) return false;
+    k.pre_gain = T(g_c);
+    k.luma_gain = T(g_r);
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) k.e[i][j] = T(d.encode_matrix[3 * i + j]);
+    return true;
+}
+
+inline AmLine am_line(const cm_am_desc &d) {
+    AmLine g;
+    g.line_shift = d.line_shift;
+    g.even_first = d.even_first;
+    g.odd_first = d.odd_first;
+    g.frame_cycle = d.frame_cycle < 1 ? 1 : d.frame_cycle;
+    g.frame_phase_shift = d.frame_phase_shift;
+    g.line_phase_shift = d.line_phase_shift;
+    return g;
+}
+
+}  // namespace cm
+#endif

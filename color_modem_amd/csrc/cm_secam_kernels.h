@@ -472,7 +472,12 @@ __global__ __launch_bounds__(64, 2) void secam_mod_kernel(const SecamModArgs arg
     const int T = (g.Wp + sp + 3) & ~3;
     f4 cur[3], nxt[3];
     first_tile3<U8>(g, itile, rp, lane, nxt);
-    for (int tb = 0; tb < T; tb += 4) {
+    // interior bodies: s_p < t and t + 3 < W - 1 for the four steps - no guard of SecamMod::step can fail and the output
+    // sample n7 = t - s_p lies inside the row
+    int tb_mid0 = (sp + 1 + 3) & ~3, tb_mid1 = (W - 5) & ~3;
+    if (tb_mid1 <= tb_mid0) tb_mid0 = tb_mid1 = 0;
+    auto body = [&](auto edge_tag, int tb) __attribute__((always_inline)) {
+        constexpr bool EDGE = decltype(edge_tag)::value;
         cur[0] = nxt[0]; cur[1] = nxt[1]; cur[2] = nxt[2];
         next_tile3x<U8>(g, itile, rp, lane, tb + 4, nxt);
 #pragma unroll
@@ -498,12 +503,16 @@ __global__ __launch_bounds__(64, 2) void secam_mod_kernel(const SecamModArgs arg
                 for (int j = 0; j < SP; ++j)
                     if (sp == j) y_d = yw[SP - j + s];
             }
-            float comp = st.step(k, lk, t, y_d, d);
+            float comp = st.template step<EDGE>(k, lk, t, y_d, d);
             put_composite<U8, kTile>(g, otile_base, op, lane, wpos, n7, comp);
         }
 #pragma unroll
         for (int j = 0; j < SP; ++j) yw[j] = yw[j + 4];
-    }
+    };
+    int tb = 0;
+    for (; tb < tb_mid0; tb += 4) body(std::true_type(), tb);
+    for (; tb < tb_mid1; tb += 4) body(std::false_type(), tb);
+    for (; tb < T; tb += 4) body(std::true_type(), tb);
 }
 
 }  // namespace cm

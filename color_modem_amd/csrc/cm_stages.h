@@ -838,17 +838,21 @@ struct SecamMod {
         pre_lp.reset(); lf_pre.reset();
         d_last = acc = TD(0);
     }
-    // d = colour-difference sample n of this line; luma_d = luma sample n7 = n - s_p
+    // d = colour-difference sample n of this line; luma_d = luma sample n7 = n - s_p.
+    // EDGE = false: the caller guarantees s_p < n < W - 1 (inside the row, behind the phase start, before the end latch)
+    template <bool EDGE = true>
     CM_HD T step(const SecamModK<T, TD> &k, const SecamModLaneK<T, TD> &lk, int n, T luma_d, T d) {
         const int W = k.width, n7 = n - k.s_p;
         TD dd = TD(d);
         TD w = TD(0);
-        if (n >= 0 && n < W + k.s_p) {
-            if (n == W - 1) d_last = dd;
-            if (n >= W) dd = d_last;
+        if (!EDGE || (n >= 0 && n < W + k.s_p)) {
+            if (EDGE) {
+                if (n == W - 1) d_last = dd;
+                if (n >= W) dd = d_last;
+            }
             w = iir_gen<false>(pre_lp, k.pre_lp, dd);
         }
-        if (n7 < 0 || n7 >= W) return T(0);
+        if (EDGE && (n7 < 0 || n7 >= W)) return T(0);
         TD x = iir_gen<false>(lf_pre, k.lf_pre, w);
         TD f = fmaf_(lk.fdev * k.gain, x, lk.fsc);                    // secam.py:266 / 271
         f = f < k.f_min ? k.f_min : (f > k.f_max ? k.f_max : f);      // secam.py:272
@@ -858,7 +862,7 @@ struct SecamMod {
         T den = T(1) + k.kd * k.kd * F * F;
         T re = k.m0 * (T(1) + k.kn * k.kd * F * F) / den;
         T im = k.m0 * F * (k.kn - k.kd) / den;
-        if (n7 == 0) {
+        if (EDGE && n7 == 0) {
             acc = TD(lk.start_phase) - TD(atan2_(im, re));             // secam.py:244: start - pi f[0] - arg G[0] + pi f[0]
         } else {
             acc += k.pi * f;                                          // cumsum(pi f)

@@ -22,7 +22,7 @@ import ctypes
 import numpy
 import scipy.signal
 
-CM_ABI_VERSION = 4
+CM_ABI_VERSION = 5
 CM_PIPE_QAM, CM_PIPE_PAL_D, CM_PIPE_SECAM = 1, 2, 3
 CM_MAX_SECTIONS = 4
 CM_LANE_DOUBLES = 32

@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define CM_ABI_VERSION 4
+#define CM_ABI_VERSION 5
 
 enum cm_status {
     CM_OK = 0,
@@ -252,6 +252,54 @@ int cm_mac_modulate_run(const cm_mac_plan *plan, const float *rgb, float *compos
                         int32_t first_line, int32_t k0, void *stream);
 int cm_mac_demodulate_run(const cm_mac_plan *plan, const float *composite, float *rgb, int32_t n_calls, int32_t frame,
                           int32_t first_line, int32_t k0, void *stream);
+
+
+/* ---- amplitude-modulated line-sequential standards ------------------------------------------------
+ * CM_AM_PROTO_SECAM: ProtoSecamModem, ref color_modem/color/protosecam.py:27-112 (the 1957 819-line prototype: one colour-
+ *   difference signal per line as the amplitude of a sub-carrier on a pedestal; decoder = envelope detector), optionally
+ *   inside ColorAveragingModem on the encoder side (comb.py:130-167, `averaging`).
+ * CM_AM_NIIR: NiirModem / HueCorrectingNiirModem, ref color_modem/color/niir.py:10-202 (SECAM-IV: saturation as amplitude,
+ *   hue as the phase against the previous line's reference), `averaging` = the hue-correcting encoder (niir.py:167-202).
+ * Both run every recursive filter of the decoder at three times the sampling rate between scipy.signal.resample_poly(x, 3, 1)
+ * and resample_poly(x, 1, 3) (61-tap Kaiser(5) FIR, `resample_fir3`).  Filters are given like in cm_plan_desc (second-order
+ * sections + FilterFunction shift).  The sub-carrier start phase of a line is computed on the device in float64 from
+ * frame_phase_shift / line_phase_shift / frame_cycle (utils.py:67-88) and the line geometry (line.py:57-65). */
+enum cm_am_kind { CM_AM_PROTO_SECAM = 1, CM_AM_NIIR = 2 };
+typedef struct cm_am_desc {
+    int32_t abi_version;          /* CM_ABI_VERSION */
+    int32_t kind;                 /* enum cm_am_kind */
+    int32_t width, height;
+    int32_t line_shift;           /* LineConfig._line_shift (line.py:53) */
+    int32_t even_first, odd_first;/* LineStandard.even_field_first_active_line / odd_... (line.py:56-60) */
+    int32_t averaging;            /* 1: encoder inside ColorAveragingModem (Proto-SECAM) / HueCorrectingNiirModem (NIIR): modulation_delay 1 */
+    int32_t premod_luma_filter;   /* Proto-SECAM encoder: protosecam.py:82-85 */
+    int32_t frame_cycle;          /* ConstantFrequencyCarrier.frame_cycle (utils.py:78-80) */
+    double frame_phase_shift;     /* ... .frame_shift (utils.py:74-76) */
+    double line_phase_shift;      /* ... .line_shift (utils.py:69-72) */
+    double carrier_phase_step;    /* radians per 1x sample: 2 * protosecam.py:31 _carrier_phase_step; niir.py:12 */
+    double resample_fir3[61];     /* scipy.signal.firwin(61, 1 / 3, window=('kaiser', 5.0)) */
+    cm_iir_desc precorrect;       /* chroma pre-correction low-pass at 1x (protosecam.py:33-34, niir.py:17-18) */
+    cm_iir_desc bandpass_up;      /* at 3x: _extract_chroma_up (protosecam.py:36-39) / _demodulate_upsampled_filter (niir.py:21-24) */
+    cm_iir_desc bandstop_up;      /* at 3x: _remove_chroma_up (protosecam.py:36-39); NIIR: unused */
+    cm_iir_desc lowpass_up;       /* at 3x: _chroma_up_post_demod_filter (protosecam.py:45-48) / _demodulate_upsampled_baseband_filter */
+    double bandpass_phase_shift;  /* NIIR: _demodulate_upsampled_filter.phase_shift (niir.py:157) */
+    double decode_matrix[9];      /* (r, g, b) = M (c0, c1, c2): protosecam.py:63-69 (luma, dr, db), niir.py:52-61 (luma, db, dr) */
+    double encode_matrix[9];
+} cm_am_desc;
+typedef struct cm_am_plan cm_am_plan;
+
+int cm_am_plan_create(const cm_am_desc *desc, cm_am_plan **out);
+void cm_am_plan_destroy(cm_am_plan *plan);
+/* rgb [n_frames][3][height][width] -> composite [n_frames][height][width] (image.py:47-55) and back (image.py:75-83) */
+int cm_am_modulate_frames(const cm_am_plan *plan, const float *rgb, float *composite, int64_t n_frames, int64_t first_frame,
+                          void *stream);
+int cm_am_demodulate_frames(const cm_am_plan *plan, const float *composite, float *rgb, int64_t n_frames, int64_t first_frame,
+                            void *stream);
+/* One run of n_calls consecutive calls, as cm_demodulate_run / cm_modulate_run (one row of history in front when k0 > 0). */
+int cm_am_modulate_run(const cm_am_plan *plan, const float *rgb, float *composite, int32_t n_calls, int32_t frame,
+                       int32_t first_line, int32_t k0, void *stream);
+int cm_am_demodulate_run(const cm_am_plan *plan, const float *composite, float *rgb, int32_t n_calls, int32_t frame,
+                         int32_t first_line, int32_t k0, void *stream);
 
 /* Name, main-loop instruction mix and launch geometry of the dominant kernel of the last
  * cm_demodulate_frames call on this plan (for bench.py / profiling); returns bytes written. */

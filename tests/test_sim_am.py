@@ -1,0 +1,84 @@
+# -*- coding: utf-8 -*-
+"""The streaming stages of csrc/cm_am_stages.h (Proto-SECAM, NIIR) compiled for the host (tests/sim/cm_sim_am.cpp) against
+the numpy oracle: float64 checks the schedule - resampler phases, FilterFunction shifts at the 3x rate, row edges - to
+1e-11, float32 predicts the rounding error of the device kernels.  CPU only."""
+import ctypes
+import os
+import subprocess
+
+import numpy
+import pytest
+
+import am_stacks
+from color_modem_amd import comb, line, plan_am, testing
+from color_modem_amd.color import niir, protosecam
+from oracle import cm_oracle_am as oa
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SIM = os.path.join(HERE, 'sim')
+
+
+def _lib():
+    so, src = os.path.join(SIM, 'libcm_sim_am.so'), os.path.join(SIM, 'cm_sim_am.cpp')
+    deps = [src] + [os.path.join(HERE, '..', 'color_modem_amd', 'csrc', f) for f in ('cm_am_stages.h', 'cm_am_plan.h', 'cm_stages.h', 'cm_plan.h')]
+    if not os.path.exists(so) or any(os.path.getmtime(p) > os.path.getmtime(so) for p in deps):
+        subprocess.check_call(['g++', '-O2', '-std=c++17', '-fPIC', '-shared', '-w', '-o', so, src])
+    L = ctypes.CDLL(so)
+    dp = ctypes.POINTER(ctypes.c_double)
+    for fn in (L.am_sim_demod_run, L.am_sim_mod_run):
+        fn.argtypes = [ctypes.POINTER(plan_am.AmDesc), ctypes.c_int, dp, dp, ctypes.c_int, ctypes.c_longlong, ctypes.c_int, ctypes.c_int]
+    L.am_sim_last_error.restype = ctypes.c_char_p
+    return L
+
+
+def _run(fn, desc, use_float, inp, out_shape, frame, first_line, k0):
+    inp = numpy.ascontiguousarray(inp, dtype=numpy.float64)
+    out = numpy.zeros(out_shape)
+    dp = ctypes.POINTER(ctypes.c_double)
+    rc = fn(ctypes.byref(desc), use_float, inp.ctypes.data_as(dp), out.ctypes.data_as(dp), inp.shape[0], frame, first_line, k0)
+    assert rc == 0, _lib().am_sim_last_error()
+    return out
+
+
+CASES = [('proto', (720, 10), 'FRENCH_819'), ('proto_nofilter', (720, 6), 'BELGIAN_819'), ('proto', (1024, 6), 'GERBER_625'),
+         ('proto', (480, 6), 'FRENCH_819'), ('proto_avg', (720, 8), 'FRENCH_819')]
+
+
+@pytest.mark.parametrize('stack,size,std', CASES)
+@pytest.mark.parametrize('use_float', [0, 1])
+def test_proto_runs_against_oracle(stack, size, std, use_float):
+    L = _lib()
+    lc = line.LineConfig(size, getattr(line.LineStandard, std))
+    modem = am_stacks.STACKS[stack](lc)
+    inner = modem.backend if stack == 'proto_avg' else modem
+    desc = plan_am.build_am_desc(modem)
+    W, H = size
+    n = H // 2
+    rgb = testing.synthetic_rgb(1, H, W, seed=17)[0].astype(numpy.float64)
+    tol = 3e-6 if use_float else 1e-11
+    for frame, field in ((3, 0), (4, 1)):
+        lines = list(range(field, H, 2))
+        # ---- encoder: the oracle object row by row (with the wrapper of comb.py:141-152 when averaging)
+        orc = oa.make(inner)
+        rows = numpy.stack([rgb[:, y] for y in lines])                      # [n][3][W]
+        want = []
+        state = {'y': None}
+        for i, y in enumerate(lines):
+            r, g, b = rows[i]
+            if stack == 'proto_avg':
+                yy, u, v = inner.encode_components(r, g, b)
+                if i == 0:
+                    state = {'y': yy, 'u': u, 'v': v}
+                py, pu, pv = state['y'], state['u'], state['v']
+                state = {'y': yy, 'u': u, 'v': v}
+                want.append(orc.modulate_components(frame, y - 2, py, 0.5 * (u + pu), 0.5 * (v + pv)))
+            else:
+                want.append(orc.modulate(frame, y, r, g, b))
+        want = numpy.stack(want)
+        got = _run(L.am_sim_mod_run, desc, use_float, rows, (len(lines), W), frame, field, 0)
+        assert numpy.abs(got - want).max() < tol * max(1.0, numpy.abs(want).max()), (stack, 'mod', frame)
+        # ---- decoder on the oracle's composite
+        dec = oa.make(inner)
+        back = numpy.stack([numpy.stack(dec.demodulate(frame, y, want[i])) for i, y in enumerate(lines)])
+        got = _run(L.am_sim_demod_run, desc, use_float, want, (len(lines), 3, W), frame, field, 0)
+        assert numpy.abs(got - back).max() < tol * max(1.0, numpy.abs(back).max()), (stack, 'demod', frame)
