@@ -22,7 +22,9 @@ SYMBOLS = ('cm_last_error', 'cm_abi_version', 'cm_device_count', 'cm_plan_create
            'cm_plan_describe',
            'cm_mac_plan_create', 'cm_mac_plan_destroy',
            'cm_mac_modulate_frames', 'cm_mac_demodulate_frames', 'cm_mac_modulate_frames_u8', 'cm_mac_demodulate_frames_u8',
-           'cm_mac_modulate_run', 'cm_mac_demodulate_run')
+           'cm_mac_modulate_run', 'cm_mac_demodulate_run',
+           'cm_am_plan_create', 'cm_am_plan_destroy', 'cm_am_modulate_frames', 'cm_am_demodulate_frames',
+           'cm_am_modulate_run', 'cm_am_demodulate_run')
 
 _lib = None
 
@@ -83,6 +85,14 @@ def lib():
     L.cm_mac_demodulate_frames_u8.argtypes = [md, vp, vp, ctypes.c_int64, ctypes.c_int64, vp]
     L.cm_mac_modulate_run.argtypes = [md, vp, vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, vp]
     L.cm_mac_demodulate_run.argtypes = [md, vp, vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, vp]
+    from color_modem_amd import plan_am
+    L.cm_am_plan_create.argtypes = [ctypes.POINTER(plan_am.AmDesc), ctypes.POINTER(vp)]
+    L.cm_am_plan_destroy.argtypes = [vp]
+    L.cm_am_plan_destroy.restype = None
+    L.cm_am_modulate_frames.argtypes = [vp, vp, vp, ctypes.c_int64, ctypes.c_int64, vp]
+    L.cm_am_demodulate_frames.argtypes = [vp, vp, vp, ctypes.c_int64, ctypes.c_int64, vp]
+    L.cm_am_modulate_run.argtypes = [vp, vp, vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, vp]
+    L.cm_am_demodulate_run.argtypes = [vp, vp, vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, vp]
     if L.cm_abi_version() != plan.CM_ABI_VERSION:
         raise NativeError('libcolor_modem_hip.so ABI %d, Python side expects %d - rebuild the library'
                           % (L.cm_abi_version(), plan.CM_ABI_VERSION))

@@ -21,11 +21,8 @@ inline FFGeom ff_geom(int shift, int rate) {
 }
 
 template <typename T>
-void load_taps3(const cm_am_desc &d, Taps3<T> &up, Taps3<T> &dn) {
-    for (int i = 0; i < kAmTaps; ++i) {
-        up.h[i] = T(3.0 * d.resample_fir3[i]);    // resample_poly scales the interpolator by `up`
-        dn.h[i] = T(d.resample_fir3[i]);
-    }
+void load_taps3(const cm_am_desc &d, Taps3<T> &taps) {
+    for (int i = 0; i < kAmTaps; ++i) taps.h[i] = T(3.0 * d.resample_fir3[i]);    // resample_poly scales the interpolator by `up`
 }
 
 inline bool am_shifts_ok(const cm_am_desc &d, std::string &err) {
@@ -42,13 +39,13 @@ bool build_proto_demod_k(const cm_am_desc &d, ProtoDemodK<T> &k, std::string &er
     k.ge = ff_geom(d.bandpass_up.shift, 3);
     k.gr = ff_geom(d.bandstop_up.shift, 3);
     k.gp = ff_geom(d.lowpass_up.shift, 3);
-    load_taps3(d, k.up, k.dn);
+    load_taps3(d, k.taps);
     double g_e, g_r, g_p;
     if (!convert_sos<T, 3>(d.bandpass_up, FORM_BP, k.ext, g_e, err, "bandpass_up", true)) return false;
     if (!convert_sos<T, 3>(d.bandstop_up, FORM_SYM, k.rem, g_r, err, "bandstop_up", true)) return false;
     if (!convert_sos<T, 2>(d.lowpass_up, FORM_GEN, k.post, g_p, err, "lowpass_up", true)) return false;
-    k.chroma_gain = T(8.0 * 0.5 * M_PI * std::fabs(g_e) * g_p);     // protosecam.py:98, 103
-    k.luma_gain = T(g_r);
+    k.chroma_gain = T(8.0 * 0.5 * M_PI * std::fabs(g_e) * g_p / 3.0);     // protosecam.py:98, 103; the decimator runs on 3 h
+    k.luma_gain = T(g_r / 3.0);
     for (int i = 0; i < 3; ++i)
         for (int j = 0; j < 3; ++j) k.m[i][j] = T(d.decode_matrix[3 * i + j]);
     return true;
@@ -61,15 +58,63 @@ bool build_proto_mod_k(const cm_am_desc &d, ProtoModK<T> &k, std::string &err) {
     k.luma_filter = d.premod_luma_filter ? 1 : 0;
     k.s_c = d.precorrect.shift;
     k.gr = ff_geom(d.bandstop_up.shift, 3);
-    load_taps3(d, k.up, k.dn);
+    load_taps3(d, k.taps);
     double g_c, g_r;
     if (!convert_sos<T, 2>(d.precorrect, FORM_GEN, k.pre, g_c, err, "precorrect", true)) return false;
     if (!convert_sos<T, 3>(d.bandstop_up, FORM_SYM, k.rem, g_r, err, "bandstop_up", true)) return false;
     k.pre_gain = T(g_c);
-    k.luma_gain = T(g_r);
+    k.luma_gain = T(g_r / 3.0);
     for (int i = 0; i < 3; ++i)
         for (int j = 0; j < 3; ++j) k.e[i][j] = T(d.encode_matrix[3 * i + j]);
     return true;
+}
+
+template <typename T>
+bool build_niir_demod_k(const cm_am_desc &d, NiirDemodK<T> &k, std::string &err) {
+    if (!am_shifts_ok(d, err)) return false;
+    k.width = d.width;
+    k.gb = ff_geom(d.bandpass_up.shift, 3);
+    k.gl = ff_geom(d.lowpass_up.shift, 3);
+    load_taps3(d, k.taps);
+    double g_b, g_l;
+    if (!convert_sos<T, 3>(d.bandpass_up, FORM_BP, k.bp, g_b, err, "bandpass_up", true)) return false;
+    if (!convert_sos<T, 2>(d.lowpass_up, FORM_GEN, k.lp, g_l, err, "lowpass_up", true)) return false;
+    const double sat_up = 0.5 * M_PI * std::fabs(g_b) * g_l;          // saturation_up = sat_up * S   (niir.py:113-114)
+    k.c_pm = T(g_b / sat_up);
+    k.g_b = T(g_b);
+    k.sat_gain = T(sat_up / 3.0);
+    k.alt_scale = T(0.5 * 3.0 / d.carrier_phase_step);                // niir.py:126-129
+    k.third = T(1.0 / 3.0);
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) k.m[i][j] = T(d.decode_matrix[3 * i + j]);
+    return true;
+}
+
+template <typename T>
+bool build_niir_mod_k(const cm_am_desc &d, NiirModK<T> &k, std::string &err) {
+    if (!am_shifts_ok(d, err)) return false;
+    k.width = d.width;
+    k.s_c = d.precorrect.shift;
+    double g_c;
+    if (!convert_sos<T, 2>(d.precorrect, FORM_GEN, k.pre, g_c, err, "precorrect", true)) return false;
+    k.pre_gain = T(g_c);
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) k.e[i][j] = T(d.encode_matrix[3 * i + j]);
+    return true;
+}
+
+// per-line constants of the NIIR decoder (niir.py:117-124, 148-157), float64
+template <typename T>
+NiirLineK<T> niir_line_k(const cm_am_desc &d, const AmLine &ln, long long frame, int line) {
+    NiirLineK<T> lk;
+    lk.alt = ln.alternate(frame, line);
+    const double shift = lk.alt ? -d.line_phase_shift : d.line_phase_shift;
+    const double ps = (lk.alt ? 0.0 : d.line_phase_shift) + M_PI - d.bandpass_phase_shift;
+    lk.sin_shift = T(std::sin(shift));
+    lk.cos_shift = T(std::cos(shift));
+    lk.sin_ps = T(std::sin(ps));
+    lk.cos_ps = T(std::cos(ps));
+    return lk;
 }
 
 inline AmLine am_line(const cm_am_desc &d) {

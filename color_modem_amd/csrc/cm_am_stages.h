@@ -47,7 +47,8 @@ struct Up3 {
     }
 };
 
-// resample_poly(z, 1, 3): y[n] = sum_i h[i] z[3 n + 30 - i].  push(z[3 q .. 3 q + 2]) completes y[q - 10].
+// resample_poly(z, 1, 3): y[n] = sum_i h[i] z[3 n + 30 - i].  push(z[3 q .. 3 q + 2]) completes y[q - 10] (times 3 when
+// given the interpolator's taps 3 h, as the stages below do).
 // s[d] = partial sum of y[q - 10 + d] from the triples before q.
 template <typename T>
 struct Dn3 {
@@ -151,7 +152,7 @@ template <typename T>
 struct ProtoDemodK {
     int32_t width;
     FFGeom ge, gr, gp;
-    Taps3<T> up, dn;             // 3 h and h
+    Taps3<T> taps;               // 3 h: the interpolator's taps; the decimators use them too (their 1 / 3 is in the gains)
     SosK<T, 3> ext;              // band-pass, numerators 1 - z^-2
     SosK<T, 3> rem;              // band-stop, numerators 1 + b1 z^-1 + z^-2
     SosK<T, 2> post;             // low-pass, general numerators (a first-order section when the order is odd)
@@ -174,14 +175,14 @@ struct ProtoDemod {
     CM_HD void step(const ProtoDemodK<T> &k, int t, T x_now, T &luma, T &chroma) {
         const int L = 3 * k.width, n1 = t - kAmHalf;
         T u[3], c1[3], c2[3], y1[3];
-        up.push(k.up, x_now, u);
+        up.push(k.taps, x_now, u);
         ext.template step<AM_FORM_BP>(k.ext, k.ge, L, n1, u, c1);
 #pragma unroll
         for (int j = 0; j < 3; ++j) c1[j] = c1[j] < T(0) ? -c1[j] : c1[j];     // protosecam.py:98 (the factor pi / 2 is in chroma_gain)
         post.template step<AM_FORM_GEN>(k.post, k.gp, L, n1 - k.ge.q, c1, c2);
-        chroma = fmaf_(k.chroma_gain, dn_c.push(k.dn, c2), T(-1));
+        chroma = fmaf_(k.chroma_gain, dn_c.push(k.taps, c2), T(-1));
         rem.template step<AM_FORM_SYM>(k.rem, k.gr, L, n1, u, y1);
-        luma = k.luma_gain * dn_y.push(k.dn, y1);
+        luma = k.luma_gain * dn_y.push(k.taps, y1);
     }
 };
 
@@ -198,7 +199,7 @@ struct ProtoModK {
     int32_t width, luma_filter;
     int32_t s_c;                 // shift of the pre-correction low-pass
     FFGeom gr;
-    Taps3<T> up, dn;
+    Taps3<T> taps;               // 3 h
     SosK<T, 2> pre;
     SosK<T, 3> rem;
     T pre_gain, luma_gain;
@@ -223,12 +224,238 @@ struct ProtoMod {
         chroma_out = fmaf_(T(0.125) * k.pre_gain, c, T(0.125));
         if (k.luma_filter) {
             T u[3], y1[3];
-            up.push(k.up, (i_y >= 0 && i_y < k.width) ? luma : T(0), u);
+            up.push(k.taps, (i_y >= 0 && i_y < k.width) ? luma : T(0), u);
             rem.template step<AM_FORM_SYM>(k.rem, k.gr, 3 * k.width, i_y - kAmHalf, u, y1);
-            luma_out = k.luma_gain * dn.push(k.dn, y1);
+            luma_out = k.luma_gain * dn.push(k.taps, y1);
         } else {
             luma_out = luma;
         }
+    }
+};
+
+// =============================================================================================
+// NIIR / SECAM-IV decoder (ref niir.py:106-164 + _remove_offset :63-67 + decode_components :52-61).
+// Streams at step t (x_now = composite[t], zero outside the row); L = 3 W:
+//   n1 = t - 10        U(n1) = resample_poly(x, 3, 1)
+//   n2 = n1 - q_b      M(n2) = _demodulate_upsampled_filter (band-pass), without its gain
+//   n3 = n2 - q_l      S(n3) = _demodulate_upsampled_baseband_filter(|M|), without the gains
+//                      P(n3) = phasemod_up = c_pm M(n3) / S(n3) (the caller delays M by q_l steps); the previous call's P
+//                      comes from the neighbouring lane, or, on the first line of a run, is the band-passed synthetic
+//                      reference carrier of niir.py:107-110 (NiirSyn below)
+//   n4 = n3 - 1        the carrier's derivative (niir.py:127-129) needs the next 3x sample: the products are formed one
+//                      triple late
+//   n5 = n4 - 10       the five decimated streams: sinphi, cosphi, saturation, sincarrier, coscarrier
+// so the output sample is n5 = t - lat, lat = 21 + q_b + q_l.
+// =============================================================================================
+template <typename T>
+struct NiirDemodK {
+    int32_t width;
+    FFGeom gb, gl;
+    Taps3<T> taps;               // 3 h
+    SosK<T, 3> bp;               // band-pass, numerators 1 - z^-2
+    SosK<T, 2> lp;               // low-pass, general numerators
+    T c_pm;                      // phasemod_up = c_pm * M / S
+    T g_b;                       // gain of the band-pass: the synthetic reference is g_b * M
+    T sat_gain;                  // saturation = sat_gain * decimated S
+    T alt_scale;                 // altcarrier_up[p] = alt_scale * (carrier_up[p + 1] - carrier_up[p - 1]) = 1.5 / carrier step
+    T third;                     // the decimators run on 3 h
+    T m[3][3];                   // (r, g, b) = m . (luma, db, dr)
+};
+
+// up3 -> band-pass -> |.| -> low-pass of one line
+template <typename T>
+struct NiirFront {
+    Up3<T> up;
+    FF3<T, 3> bp;
+    FF3<T, 2> lp;
+    CM_HD void reset() {
+        up.reset(); bp.reset(); lp.reset();
+    }
+    // m_out = M(n2), n2 = t - 10 - q_b;  s_out = S(n3), n3 = n2 - q_l   (both zero outside [0, L))
+    CM_HD void step(const NiirDemodK<T> &k, int t, T x_now, T m_out[3], T s_out[3]) {
+        const int L = 3 * k.width, n1 = t - kAmHalf;
+        T u[3], a[3];
+        up.push(k.taps, x_now, u);
+        bp.template step<AM_FORM_BP>(k.bp, k.gb, L, n1, u, m_out);
+#pragma unroll
+        for (int j = 0; j < 3; ++j) a[j] = m_out[j] < T(0) ? -m_out[j] : m_out[j];     // niir.py:113 (pi / 2 is in the constants)
+        lp.template step<AM_FORM_GEN>(k.lp, k.gl, L, n1 - k.gb.q, a, s_out);
+    }
+};
+
+// the synthetic phase reference of the first line of a run (niir.py:107-110): band-passed +-sin(phi + n step), not normalised
+template <typename T>
+struct NiirSyn {
+    Up3<T> up;
+    FF3<T, 3> bp;
+    CM_HD void reset() {
+        up.reset(); bp.reset();
+    }
+    CM_HD void step(const NiirDemodK<T> &k, int t, T x_syn, T m_out[3]) {
+        T u[3];
+        up.push(k.taps, x_syn, u);
+        bp.template step<AM_FORM_BP>(k.bp, k.gb, 3 * k.width, t - kAmHalf, u, m_out);
+    }
+};
+
+// phasemod_up of a triple: c_pm * M / S inside the sequence, zero outside (the decimators zero-extend)
+template <typename T>
+CM_HD void niir_phasemod(const NiirDemodK<T> &k, int n3, const T m[3], const T s[3], T p[3]) {
+    const int L = 3 * k.width;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const int q = 3 * n3 + j;
+        p[j] = (q >= 0 && q < L) ? k.c_pm * m[j] / s[j] : T(0);
+    }
+}
+
+template <typename T>
+struct NiirOut {
+    T sinphi, cosphi, sat, sinc, cosc;    // the decimated streams at sample n5 (saturation with its gain)
+};
+
+template <typename T>
+struct NiirBack {
+    Dn3<T> dn_s, dn_c, dn_sat, dn_sc, dn_cc;
+    T c1[3], h1[3], s1[3], c2_2;          // carrier, hue-modulated signal and S of the previous triple; carrier[3 n3 - 4]
+    CM_HD void reset() {
+        dn_s.reset(); dn_c.reset(); dn_sat.reset(); dn_sc.reset(); dn_cc.reset();
+#pragma unroll
+        for (int j = 0; j < 3; ++j) c1[j] = h1[j] = s1[j] = T(0);
+        c2_2 = T(0);
+    }
+    // own / prev: phasemod_up triples n3 of this call and of the previous one; s: S(n3); alt: is_alternate_line
+    CM_HD NiirOut<T> step(const NiirDemodK<T> &k, int n3, const T own[3], const T prev[3], const T s[3], bool alt) {
+        const int L = 3 * k.width, n4 = n3 - 1;
+        T c[3], h[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {                       // niir.py:117-124
+            c[j] = alt ? own[j] : prev[j];
+            h[j] = alt ? prev[j] : own[j];
+        }
+        T ac[3], su[3], cu[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int p = 3 * n4 + j;
+            const T before = j == 0 ? c2_2 : c1[j - 1], after = j == 2 ? c[0] : c1[j + 1];
+            ac[j] = (p >= 1 && p <= L - 2) ? k.alt_scale * (after - before) : T(0);       // niir.py:126-129
+            su[j] = h1[j] * c1[j];                                                         // niir.py:131-132
+            cu[j] = h1[j] * ac[j];
+        }
+        NiirOut<T> o;
+        o.sinphi = dn_s.push(k.taps, su);
+        o.cosphi = dn_c.push(k.taps, cu);
+        o.sat = k.sat_gain * dn_sat.push(k.taps, s1);
+        o.sinc = k.third * dn_sc.push(k.taps, c1);
+        o.cosc = k.third * dn_cc.push(k.taps, ac);
+        c2_2 = c1[2];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) { c1[j] = c[j]; h1[j] = h[j]; s1[j] = s[j]; }
+        return o;
+    }
+};
+
+// per-line constants of the decoder (computed in float64 by the caller from AmLine)
+template <typename T>
+struct NiirLineK {
+    T sin_shift, cos_shift;      // of +line_shift on ordinary lines, -line_shift on alternate ones (niir.py:120, 124)
+    T sin_ps, cos_ps;            // of the re-modulation phase (niir.py:151-157)
+    bool alt;
+};
+
+CM_HD float am_sqrt(float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_sqrtf(x);
+#else
+    return std::sqrt(x);
+#endif
+}
+CM_HD double am_sqrt(double x) { return std::sqrt(x); }
+
+// niir.py:134-163, 63-67, 52-61 on the decimated streams of one sample: comp = composite[n5]
+template <typename T>
+CM_HD Rgb<T> niir_finish(const NiirDemodK<T> &k, const NiirLineK<T> &lk, const NiirOut<T> &o, T comp, bool strip) {
+    const T nrm = am_sqrt(o.cosphi * o.cosphi + o.sinphi * o.sinphi);
+    const T c1 = o.cosphi / nrm, s1 = o.sinphi / nrm;
+    const T s2 = -c1 * lk.sin_shift - s1 * lk.cos_shift;                 // niir.py:139-140
+    const T c2 = s1 * lk.sin_shift - c1 * lk.cos_shift;
+    T db = o.sat * s2, dr = o.sat * c2;
+    const T r = am_sqrt(db * db + dr * dr);
+    T luma = comp;
+    if (strip) {
+        const T u = lk.alt ? -r : db, v = lk.alt ? T(0) : dr;             // niir.py:148-156
+        const T u2 = u * lk.cos_ps - v * lk.sin_ps, v2 = u * lk.sin_ps + v * lk.cos_ps;
+        luma = comp - (u2 * o.sinc + v2 * o.cosc);
+    }
+    // _remove_offset: the saturation loses its pedestal, the hue stays (atan2(0, 0) = 0 gives (0, 0))
+    const T keep = r > T(0) ? (r - T(0.1) > T(0) ? (r - T(0.1)) / r : T(0)) : T(0);
+    db *= keep;
+    dr *= keep;
+    Rgb<T> out;
+    out.r = fmaf_(k.m[0][0], luma, fmaf_(k.m[0][1], db, k.m[0][2] * dr));
+    out.g = fmaf_(k.m[1][0], luma, fmaf_(k.m[1][1], db, k.m[1][2] * dr));
+    out.b = fmaf_(k.m[2][0], luma, fmaf_(k.m[2][1], db, k.m[2][2] * dr));
+    return out;
+}
+
+// =============================================================================================
+// NIIR encoder (ref niir.py:78-90, 42-49, 69-76; HueCorrectingNiirModem :181-202).  The caller forms (luma, db, dr) of the
+// modulated line; add_offset / hue_correct give the two colour-difference signals their pedestal, both pass the
+// pre-correction low-pass (FilterFunction at 1x, shift s_c), and
+//   composite[n] = luma[n] + db[n] sin(phi + n step) + dr[n] cos(phi + n step)          ordinary lines
+//                = luma[n] - sqrt(db^2 + dr^2)[n] sin(phi + n step)                        alternate lines
+// =============================================================================================
+template <typename T>
+struct NiirModK {
+    int32_t width, s_c;
+    SosK<T, 2> pre;
+    T pre_gain;
+    T e[3][3];                   // (luma, db, dr) = e . (r, g, b)
+};
+
+// niir.py:42-49 (noise off): saturation + 0.1 at the same hue
+template <typename T>
+CM_HD void niir_add_offset(T &db, T &dr) {
+    const T r = am_sqrt(db * db + dr * dr);
+    if (r > T(0)) {
+        const T f = (r + T(0.1)) / r;
+        db *= f;
+        dr *= f;
+    } else {            // arctan2(0, 0) = 0: sin 0, cos 1
+        db = T(0);
+        dr = T(0.1);
+    }
+}
+// niir.py:187-198: saturation-weighted mean hue of this call (db, dr) and the previous one (pdb, pdr), the previous call's
+// saturation + 0.1
+template <typename T>
+CM_HD void niir_hue_correct(T db, T dr, T pdb, T pdr, T &odb, T &odr) {
+    const T ls = am_sqrt(pdb * pdb + pdr * pdr), s = am_sqrt(db * db + dr * dr);
+    T div = ls + s;
+    if (div == T(0)) div = T(1);
+    const T adb = (pdb * ls + db * s) / div, adr = (pdr * ls + dr * s) / div;
+    const T ra = am_sqrt(adb * adb + adr * adr), ep = ls + T(0.1);
+    if (ra > T(0)) {
+        odb = ep * adb / ra;
+        odr = ep * adr / ra;
+    } else {
+        odb = T(0);
+        odr = ep;
+    }
+}
+
+template <typename T>
+struct NiirMod {
+    FF1<T, 2> pre_b, pre_r;
+    CM_HD void reset() {
+        pre_b.reset(); pre_r.reset();
+    }
+    // i: index of the (offset) colour-difference samples fed now; returns the chroma of sample i - s_c given the carrier
+    // {sin, cos}(phi + (i - s_c) step)
+    CM_HD T step(const NiirModK<T> &k, int i, T db, T dr, bool alt, T sn, T cs) {
+        const T b = k.pre_gain * pre_b.template step<AM_FORM_GEN>(k.pre, k.s_c, k.width, i, db);
+        const T r = k.pre_gain * pre_r.template step<AM_FORM_GEN>(k.pre, k.s_c, k.width, i, dr);
+        return alt ? -am_sqrt(b * b + r * r) * sn : fmaf_(b, sn, r * cs);                 // niir.py:73-76
     }
 };
 

@@ -13,6 +13,8 @@
 #include "cm_secam_kernels.h"
 #include "cm_mac_kernels.h"
 #include "cm_plan.h"
+#include "cm_am_kernels.h"
+#include "cm_am_plan.h"
 
 constexpr int kModAnyShift = 12;   // luma delay window of the run-time-shape modulators (pre-correction shift <= 12)
 
@@ -1214,6 +1216,218 @@ int cm_mac_demodulate_run(const cm_mac_plan *p, const float *composite, float *r
     return mac_launch(p, true, composite, rgb, 1, n_calls, 1, first_line, frame, (hipStream_t)stream);
 }
 }
+
+// ---- amplitude-modulated line-sequential standards: Proto-SECAM, NIIR (cm_am_kernels.h) ------------------------------------
+struct cm_am_plan {
+    cm_am_desc desc;
+    int device = 0;
+    float *carrier = nullptr;          // {cos, sin}(n * carrier_phase_step), n < width
+    ProtoDemodK<float> pd;
+    ProtoModK<float> pm;
+    std::string demod_error, mod_error;
+};
+
+namespace {
+int am_geom(const cm_am_plan *p, int64_t first_frame, AmGeom &a) {
+    a.line = am_line(p->desc);
+    a.carrier = p->carrier;
+    a.frame_base = (int)(first_frame % (2LL * a.line.frame_cycle));
+    return CM_OK;
+}
+// the frames geometry of cm_demodulate_frames / cm_modulate_frames for a plan with `delay` lines of delay
+void am_frames_geom(Geom &g, int W, int wp, int H, int D, int64_t n_frames) {
+    g.W = W;
+    g.Wp = wp;
+    g.H = H;
+    const int rows0 = (H + 1) / 2, rows1 = H / 2;
+    g.calls_run0 = rows0 + D;
+    const int calls_run1 = rows1 > 0 ? rows1 + D : 0;
+    g.calls_per_frame = g.calls_run0 + calls_run1;
+    g.runs_per_frame = rows1 > 0 ? 2 : 1;
+    g.first_line[0] = 0;
+    g.first_line[1] = 1;
+    g.delay = D;
+    g.total_calls = n_frames * g.calls_per_frame;
+}
+int am_launch_demod(const cm_am_plan *p, Geom g, int64_t first_frame, hipStream_t stream) {
+    if (!p->demod_error.empty()) return fail(CM_ERR_UNSUPPORTED, p->demod_error);
+    long long blocks = (g.total_calls + 62) / 63;
+    if (blocks <= 0) return CM_OK;
+    if (blocks > 0x7fffffffLL) return fail(CM_ERR_INVALID, "batch too large for one launch");
+    ProtoDemodArgs a;
+    a.g = g;
+    am_geom(p, first_frame, a.a);
+    a.k = p->pd;
+    hipLaunchKernelGGL(proto_demod_kernel, dim3((int)blocks), dim3(64), 0, stream, a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(CM_ERR_LAUNCH, std::string("proto_demod_kernel launch: ") + hipGetErrorString(e));
+    return CM_OK;
+}
+int am_launch_mod(const cm_am_plan *p, Geom g, int64_t first_frame, hipStream_t stream) {
+    if (!p->mod_error.empty()) return fail(CM_ERR_UNSUPPORTED, p->mod_error);
+    const int depth = p->desc.averaging ? 1 : 0;
+    long long blocks = (g.total_calls + (64 - depth) - 1) / (64 - depth);
+    if (blocks <= 0) return CM_OK;
+    if (blocks > 0x7fffffffLL) return fail(CM_ERR_INVALID, "batch too large for one launch");
+    ProtoModArgs a;
+    a.g = g;
+    am_geom(p, first_frame, a.a);
+    a.k = p->pm;
+    a.averaging = depth;
+    if (depth) hipLaunchKernelGGL(proto_mod_kernel<1>, dim3((int)blocks), dim3(64), 0, stream, a);
+    else hipLaunchKernelGGL(proto_mod_kernel<0>, dim3((int)blocks), dim3(64), 0, stream, a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(CM_ERR_LAUNCH, std::string("proto_mod_kernel launch: ") + hipGetErrorString(e));
+    return CM_OK;
+}
+}  // namespace
+
+extern "C" {
+int cm_am_plan_create(const cm_am_desc *desc, cm_am_plan **out) {
+    if (!desc || !out) return fail(CM_ERR_INVALID, "null argument");
+    *out = nullptr;
+    if (desc->abi_version != CM_ABI_VERSION) return fail(CM_ERR_INVALID, "descriptor ABI version mismatch");
+    if (desc->width < 4) return fail(CM_ERR_UNSUPPORTED, "width must be at least 4");
+    if (desc->height < 1) return fail(CM_ERR_INVALID, "height must be positive");
+    if (desc->kind != CM_AM_PROTO_SECAM) return fail(CM_ERR_UNSUPPORTED, "only CM_AM_PROTO_SECAM has kernels in this build");
+    if (desc->frame_cycle < 1) return fail(CM_ERR_INVALID, "frame_cycle must be positive");
+    if (cm_device_count() < 1) return fail(CM_ERR_NO_DEVICE, "no HIP device available (this library has no CPU path)");
+    cm_am_plan *p = new cm_am_plan;
+    p->desc = *desc;
+    if (hipGetDevice(&p->device) != hipSuccess) {
+        delete p;
+        return fail(CM_ERR_NO_DEVICE, "hipGetDevice failed");
+    }
+    std::string err;
+    if (!build_proto_demod_k<float>(*desc, p->pd, err)) p->demod_error = err;
+    else {
+        const int dly = ProtoDemod<float>::lat_chroma(p->pd) - ProtoDemod<float>::lat_luma(p->pd);
+        if (dly < 0 || dly >= kAmRing) p->demod_error = "decoder: the luma delay does not fit the delay ring";
+    }
+    if (!build_proto_mod_k<float>(*desc, p->pm, err)) p->mod_error = err;
+    else {
+        const int ly = ProtoMod<float>::lat_luma(p->pm), lc = ProtoMod<float>::lat_chroma(p->pm);
+        const int dly = ly > lc ? ly - lc : lc - ly;
+        if (dly >= kAmRing) p->mod_error = "encoder: the path delay does not fit the delay ring";
+    }
+    if (!p->demod_error.empty() && !p->mod_error.empty()) {
+        err = p->demod_error;
+        delete p;
+        return fail(CM_ERR_UNSUPPORTED, err);
+    }
+    std::vector<float> car(2 * (size_t)desc->width);
+    for (int n = 0; n < desc->width; ++n) {
+        const double ph = (double)n * desc->carrier_phase_step;
+        car[2 * (size_t)n] = (float)std::cos(ph);
+        car[2 * (size_t)n + 1] = (float)std::sin(ph);
+    }
+    if (hipMalloc((void **)&p->carrier, car.size() * sizeof(float)) != hipSuccess ||
+        hipMemcpy(p->carrier, car.data(), car.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) {
+        cm_am_plan_destroy(p);
+        return fail(CM_ERR_NO_DEVICE, "device allocation / upload of the carrier table failed");
+    }
+    *out = p;
+    return CM_OK;
+}
+void cm_am_plan_destroy(cm_am_plan *p) {
+    if (!p) return;
+    if (p->carrier) (void)hipFree(p->carrier);
+    delete p;
+}
+int cm_am_demodulate_frames(const cm_am_plan *p, const float *composite, float *rgb, int64_t n_frames, int64_t first_frame, void *stream) {
+    if (p && n_frames == 0) return CM_OK;
+    if (!p || !composite || !rgb) return fail(CM_ERR_INVALID, "null argument");
+    if (n_frames < 0 || first_frame < 0) return fail(CM_ERR_INVALID, "negative frame count / number");
+    if (int rc_ = check_device(p->device, composite, rgb)) return rc_;
+    const int W = p->desc.width, H = p->desc.height, wp = (W + 3) & ~3;
+    return with_pitched_rows(composite, n_frames * H, rgb, n_frames * 3 * H, W, (hipStream_t)stream, [&](const float *in, float *out) -> int {
+        Geom g;
+        std::memset(&g, 0, sizeof g);
+        g.in = in;
+        g.out = out;
+        am_frames_geom(g, W, wp, H, 0, n_frames);
+        g.in_frame_stride = (long long)wp * H;
+        g.in_row_stride = wp;
+        g.out_plane_stride = (long long)wp * H;
+        g.out_frame_stride = 3LL * wp * H;
+        g.out_row_stride = wp;
+        return am_launch_demod(p, g, first_frame, (hipStream_t)stream);
+    });
+}
+int cm_am_modulate_frames(const cm_am_plan *p, const float *rgb, float *composite, int64_t n_frames, int64_t first_frame, void *stream) {
+    if (p && n_frames == 0) return CM_OK;
+    if (!p || !rgb || !composite) return fail(CM_ERR_INVALID, "null argument");
+    if (n_frames < 0 || first_frame < 0) return fail(CM_ERR_INVALID, "negative frame count / number");
+    if (int rc_ = check_device(p->device, rgb, composite)) return rc_;
+    const int W = p->desc.width, H = p->desc.height, wp = (W + 3) & ~3, D = p->desc.averaging ? 1 : 0;
+    return with_pitched_rows(rgb, n_frames * 3 * H, composite, n_frames * H, W, (hipStream_t)stream, [&](const float *in, float *out) -> int {
+        Geom g;
+        std::memset(&g, 0, sizeof g);
+        g.in = in;
+        g.out = out;
+        am_frames_geom(g, W, wp, H, D, n_frames);
+        g.in_frame_stride = 3LL * wp * H;
+        g.in_plane_stride = (long long)wp * H;
+        g.in_row_stride = wp;
+        g.out_frame_stride = (long long)wp * H;
+        g.out_row_stride = wp;
+        return am_launch_mod(p, g, first_frame, (hipStream_t)stream);
+    });
+}
+int cm_am_demodulate_run(const cm_am_plan *p, const float *composite, float *rgb, int32_t n_calls, int32_t frame, int32_t first_line,
+                         int32_t k0, void *stream) {
+    if (!p || !composite || !rgb) return fail(CM_ERR_INVALID, "null argument");
+    if (n_calls < 0 || frame < 0 || k0 < 0) return fail(CM_ERR_INVALID, "negative count / frame / k0");
+    if (n_calls == 0) return CM_OK;
+    if (int rc_ = check_device(p->device, composite, rgb)) return rc_;
+    const int W = p->desc.width, wp = (W + 3) & ~3;
+    return with_pitched_rows(composite, n_calls, rgb, 3LL * n_calls, W, (hipStream_t)stream, [&](const float *in, float *out) -> int {
+        Geom g;
+        std::memset(&g, 0, sizeof g);
+        g.in = in;
+        g.out = out;
+        g.W = W;
+        g.Wp = wp;
+        g.H = n_calls;
+        g.rows_mode = 1;
+        g.calls_run0 = g.calls_per_frame = n_calls;
+        g.runs_per_frame = 1;
+        g.first_line[0] = g.first_line[1] = first_line;
+        g.k0 = k0;
+        g.total_calls = n_calls;
+        g.out_plane_stride = wp;            // rows mode writes [call][plane][W]
+        g.out_row_stride = 3LL * wp;
+        return am_launch_demod(p, g, frame, (hipStream_t)stream);
+    });
+}
+int cm_am_modulate_run(const cm_am_plan *p, const float *rgb, float *composite, int32_t n_calls, int32_t frame, int32_t first_line,
+                       int32_t k0, void *stream) {
+    if (!p || !rgb || !composite) return fail(CM_ERR_INVALID, "null argument");
+    if (n_calls < 0 || frame < 0 || k0 < 0) return fail(CM_ERR_INVALID, "negative count / frame / k0");
+    if (n_calls == 0) return CM_OK;
+    if (int rc_ = check_device(p->device, rgb, composite)) return rc_;
+    const int W = p->desc.width, wp = (W + 3) & ~3;
+    return with_pitched_rows(rgb, 3LL * n_calls, composite, n_calls, W, (hipStream_t)stream, [&](const float *in, float *out) -> int {
+        Geom g;
+        std::memset(&g, 0, sizeof g);
+        g.in = in;
+        g.out = out;
+        g.W = W;
+        g.Wp = wp;
+        g.H = n_calls;
+        g.in_plane_stride = wp;             // rows mode reads [call][plane][W]
+        g.in_row_stride = 3LL * wp;
+        g.out_row_stride = wp;
+        g.rows_mode = 1;
+        g.calls_run0 = g.calls_per_frame = n_calls;
+        g.runs_per_frame = 1;
+        g.first_line[0] = g.first_line[1] = first_line;
+        g.k0 = k0;
+        g.total_calls = n_calls;
+        return am_launch_mod(p, g, frame, (hipStream_t)stream);
+    });
+}
+}  // extern "C"
 
 #ifdef CM_DIAG
 extern "C" void cm_diag_set_buffer(unsigned long long *dev) { g_diag = dev; }

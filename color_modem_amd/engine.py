@@ -78,12 +78,13 @@ class RowSession(object):
         self.eng, self.direction = eng, direction
         dev = torch.device('cuda', torch.cuda.current_device())
         L = _native.lib()
+        prefix = eng.abi_prefix
         if direction == 'demod':
             self.in_shape, self.out_shape, self.depth = (eng.comp_width,), (3, eng.width), eng.demod_depth
-            self.fn = L.cm_mac_demodulate_run if isinstance(eng, MacEngine) else L.cm_demodulate_run
+            self.fn = getattr(L, prefix + 'demodulate_run')
         else:
             self.in_shape, self.out_shape, self.depth = (3, eng.in_width), (eng.comp_width,), eng.mod_depth
-            self.fn = L.cm_mac_modulate_run if isinstance(eng, MacEngine) else L.cm_modulate_run
+            self.fn = getattr(L, prefix + 'modulate_run')
         self.hist = torch.empty((self.SLOTS,) + self.in_shape, dtype=torch.float32, device=dev)
         self.out = torch.empty((self.depth + 1,) + self.out_shape, dtype=torch.float32, device=dev)
         self.pin_in = torch.empty((self.depth + 1,) + self.in_shape, dtype=torch.float32).pin_memory()
@@ -123,13 +124,17 @@ class RowSession(object):
 
 def make_engine(modem, components=False, strip_chroma=True, min_lines=0):
     """The engine of a modem stack: a cm_plan for the QAM / SECAM families, the plan-less MAC entry points for MacModem."""
-    if modem._stack()['kind'] == 'mac':
+    kind = modem._stack()['kind']
+    if kind == 'mac':
         return MacEngine(modem, components)
+    if kind in ('protosecam', 'niir'):
+        return AmEngine(modem, components)
     return Engine(modem, components, strip_chroma, min_lines)
 
 
 class _EngineBase(object):
     """Shared plumbing: input staging, result validation, and the launch on the input tensor's device and stream."""
+    abi_prefix = 'cm_'       # entry point family of include/color_modem_hip.h: cm_*, cm_mac_*, cm_am_*
 
     def __del__(self):
         plans = getattr(self, '_plans', None)
@@ -245,6 +250,7 @@ class Engine(_EngineBase):
 
 class MacEngine(_EngineBase):
     """MacModem / ColorAveragingModem(MacModem) on the cm_mac_* entry points (rows of 720 samples <-> lines of 1080)."""
+    abi_prefix = 'cm_mac_'
 
     def __init__(self, modem, components=False):
         import fractions
@@ -354,4 +360,65 @@ class MacEngine(_EngineBase):
         x, was_numpy = self._stage(rows, torch.float32, (3, self.in_width), 'rows')
         n = x.shape[0]
         return self._launch(_native.lib().cm_mac_modulate_run, x, None, (n, self.comp_width), torch.float32, was_numpy,
+                            n, int(frame), int(first_line), int(k0))
+
+
+class AmEngine(_EngineBase):
+    """ProtoSecamModem / ColorAveragingModem(ProtoSecamModem) / NiirModem / HueCorrectingNiirModem on the cm_am_* entry
+    points (the amplitude-modulated line-sequential standards: x3 resampling around recursive filters)."""
+    abi_prefix = 'cm_am_'
+
+    def __init__(self, modem, components=False):
+        from color_modem_amd import plan_am
+        d = plan_am.build_am_desc(modem, components)
+        self.desc = d
+        self.width = self.comp_width = self.in_width = d.width
+        self.height = d.height
+        self.demod_depth = 1                     # the other colour-difference signal / the phase reference is the previous call's
+        self.mod_depth = 1 if d.averaging else 0
+        self.demodulation_delay = 0
+        self.modulation_delay = 1 if d.averaging else 0
+        self.n_lines = 1 << 30                   # no per-line tables: the line's phase is computed on the device
+        L = _native.lib()
+        self._plans = _DevicePlans(lambda out: L.cm_am_plan_create(ctypes.byref(d), out), L.cm_am_plan_destroy)
+        self._plan
+
+    def describe(self):
+        return 'proto_demod_kernel / proto_mod_kernel: one wavefront per 64 calls, x3 polyphase resamplers in registers'
+
+    def demodulate_frames(self, composite, first_frame=0, out=None):
+        """composite [F, H, W] float32 -> rgb [F, 3, H, W] (numpy in -> numpy out, cuda tensor in -> cuda tensor out)."""
+        torch = _torch()
+        comp, was_numpy = self._stage(composite, torch.float32, (self.height, self.width), 'composite')
+        n = comp.shape[0]
+        return self._launch(_native.lib().cm_am_demodulate_frames, comp, out, (n, 3, self.height, self.width), torch.float32,
+                            was_numpy, n, int(first_frame))
+
+    def modulate_frames(self, rgb, first_frame=0, out=None):
+        """rgb [F, 3, H, W] float32 -> composite [F, H, W]."""
+        torch = _torch()
+        x, was_numpy = self._stage(rgb, torch.float32, (3, self.height, self.width), 'rgb')
+        n = x.shape[0]
+        if self.height < 2 * self.modulation_delay and n:
+            raise IndexError('image.py:49-50 feeds row 1 ahead of a field under modulation_delay 1: the image has %d row(s)' % self.height)
+        return self._launch(_native.lib().cm_am_modulate_frames, x, out, (n, self.height, self.width), torch.float32,
+                            was_numpy, n, int(first_frame))
+
+    def demodulate_frames_u8(self, *args, **kwargs):
+        raise NotImplementedError('no fused byte boundary for this standard: the PIL entry points convert on the host')
+
+    modulate_frames_u8 = demodulate_frames_u8
+
+    def demodulate_run(self, rows, frame, first_line, k0):
+        torch = _torch()
+        x, was_numpy = self._stage(rows, torch.float32, (self.width,), 'rows')
+        n = x.shape[0]
+        return self._launch(_native.lib().cm_am_demodulate_run, x, None, (n, 3, self.width), torch.float32, was_numpy,
+                            n, int(frame), int(first_line), int(k0))
+
+    def modulate_run(self, rows, frame, first_line, k0):
+        torch = _torch()
+        x, was_numpy = self._stage(rows, torch.float32, (3, self.width), 'rows')
+        n = x.shape[0]
+        return self._launch(_native.lib().cm_am_modulate_run, x, None, (n, self.width), torch.float32, was_numpy,
                             n, int(frame), int(first_line), int(k0))

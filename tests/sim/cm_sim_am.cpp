@@ -107,11 +107,132 @@ static int proto_mod_run(const cm_am_desc &d, const double *rgb, double *comp, i
     return CM_OK;
 }
 
+
+// ---- NIIR ---------------------------------------------------------------------------------------------------------------
+template <typename T>
+static int niir_demod_run(const cm_am_desc &d, const double *comp, double *rgb, int n_calls, long long frame, int first_line, int k0,
+                          bool strip) {
+    NiirDemodK<T> k;
+    if (!build_niir_demod_k<T>(d, k, g_err)) return CM_ERR_UNSUPPORTED;
+    const AmLine ln = am_line(d);
+    const int W = d.width;
+    const int lat = 2 * kAmHalf + 1 + k.gb.q + k.gl.q;
+    const int steps = W + lat;
+    struct Tri { T v[3]; };
+    std::vector<std::vector<Tri>> P(n_calls, std::vector<Tri>(steps)), S(n_calls, std::vector<Tri>(steps));
+    auto run_front = [&](int i) {
+        NiirFront<T> f;
+        f.reset();
+        std::vector<Tri> mh(steps);
+        for (int t = 0; t < steps; ++t) {
+            T m[3], sv[3];
+            f.step(k, t, t < W ? T(comp[(size_t)i * W + t]) : T(0), m, sv);
+            for (int j = 0; j < 3; ++j) mh[t].v[j] = m[j];
+            T md[3] = {T(0), T(0), T(0)};
+            if (t - k.gl.q >= 0) for (int j = 0; j < 3; ++j) md[j] = mh[t - k.gl.q].v[j];
+            const int n3 = t - kAmHalf - k.gb.q - k.gl.q;
+            T p[3];
+            niir_phasemod(k, n3, md, sv, p);
+            for (int j = 0; j < 3; ++j) { P[i][t].v[j] = p[j]; S[i][t].v[j] = sv[j]; }
+        }
+    };
+    for (int i = 0; i < n_calls; ++i) run_front(i);
+    for (int i = 0; i < n_calls; ++i) {
+        const int line = first_line + 2 * i;
+        const NiirLineK<T> lk = niir_line_k<T>(d, ln, frame, line);
+        std::vector<Tri> prev(steps);
+        if (k0 + i == 0) {          // niir.py:107-110: the reference carrier of line - 2, band-passed, not normalised
+            const double phi = ln.start_phase(frame, line - 2);
+            const bool palt = ln.alternate(frame, line - 2);
+            NiirSyn<T> sy;
+            sy.reset();
+            std::vector<Tri> mh(steps);
+            for (int t = 0; t < steps; ++t) {
+                T x = T(0);
+                if (t < W) x = T((palt ? -1.0 : 1.0) * std::sin(phi + (double)t * d.carrier_phase_step));
+                T m[3];
+                sy.step(k, t, x, m);
+                for (int j = 0; j < 3; ++j) mh[t].v[j] = m[j];
+                for (int j = 0; j < 3; ++j) prev[t].v[j] = t - k.gl.q >= 0 ? k.g_b * mh[t - k.gl.q].v[j] : T(0);
+            }
+        } else if (i > 0) {
+            prev = P[i - 1];
+        } else {
+            for (auto &x : prev) x.v[0] = x.v[1] = x.v[2] = T(0);
+        }
+        NiirBack<T> b;
+        b.reset();
+        for (int t = 0; t < steps; ++t) {
+            const int n3 = t - kAmHalf - k.gb.q - k.gl.q;
+            const NiirOut<T> o = b.step(k, n3, P[i][t].v, prev[t].v, S[i][t].v, lk.alt);
+            const int n = t - lat;
+            if (n >= 0 && n < W) {
+                const Rgb<T> c = niir_finish(k, lk, o, T(comp[(size_t)i * W + n]), strip);
+                rgb[((size_t)i * 3 + 0) * W + n] = (double)c.r;
+                rgb[((size_t)i * 3 + 1) * W + n] = (double)c.g;
+                rgb[((size_t)i * 3 + 2) * W + n] = (double)c.b;
+            }
+        }
+    }
+    return CM_OK;
+}
+
+template <typename T>
+static int niir_mod_run(const cm_am_desc &d, const double *rgb, double *comp, int n_calls, long long frame, int first_line, int k0) {
+    NiirModK<T> k;
+    if (!build_niir_mod_k<T>(d, k, g_err)) return CM_ERR_UNSUPPORTED;
+    const AmLine ln = am_line(d);
+    const int W = d.width;
+    for (int i = 0; i < n_calls; ++i) {
+        const int call_line = first_line + 2 * i;
+        const int line = d.averaging ? call_line - 2 : call_line;        // niir.py:202
+        const bool alt = ln.alternate(frame, line);
+        const double phi = ln.start_phase(frame, line);
+        const bool have_prev = (k0 + i) > 0 && i > 0;
+        auto comps = [&](int row, int n, T &y, T &db, T &dr) {
+            const double *r = rgb + ((size_t)row * 3) * W;
+            const T R = T(r[n]), G = T(r[W + n]), B = T(r[2 * W + n]);
+            y = k.e[0][0] * R + k.e[0][1] * G + k.e[0][2] * B;
+            db = k.e[1][0] * R + k.e[1][1] * G + k.e[1][2] * B;
+            dr = k.e[2][0] * R + k.e[2][1] * G + k.e[2][2] * B;
+        };
+        NiirMod<T> st;
+        st.reset();
+        std::vector<T> lumas(W + k.s_c + 1, T(0));
+        for (int t = 0; t < W + k.s_c; ++t) {
+            T y = T(0), db = T(0), dr = T(0);
+            if (t < W) {
+                comps(i, t, y, db, dr);
+                if (d.averaging) {
+                    T py = y, pdb = db, pdr = dr;
+                    if (have_prev) comps(i - 1, t, py, pdb, pdr);
+                    T odb, odr;
+                    niir_hue_correct(db, dr, pdb, pdr, odb, odr);
+                    y = py;
+                    db = odb;
+                    dr = odr;
+                } else {
+                    niir_add_offset(db, dr);
+                }
+                lumas[t] = y;
+            }
+            const int n = t - k.s_c;
+            const double ph = phi + (double)n * d.carrier_phase_step;
+            const T c = st.step(k, t, db, dr, alt, T(std::sin(ph)), T(std::cos(ph)));
+            if (n >= 0 && n < W) comp[(size_t)i * W + n] = (double)(lumas[n] + c);
+        }
+    }
+    return CM_OK;
+}
+
 extern "C" int am_sim_demod_run(const cm_am_desc *d, int use_float, const double *comp, double *rgb, int n_calls, long long frame,
                                 int first_line, int k0) {
     if (d->kind == CM_AM_PROTO_SECAM)
         return use_float ? proto_demod_run<float>(*d, comp, rgb, n_calls, frame, first_line, k0)
                          : proto_demod_run<double>(*d, comp, rgb, n_calls, frame, first_line, k0);
+    if (d->kind == CM_AM_NIIR)      // use_float bit 1: strip_chroma = False
+        return (use_float & 1) ? niir_demod_run<float>(*d, comp, rgb, n_calls, frame, first_line, k0, !(use_float & 2))
+                               : niir_demod_run<double>(*d, comp, rgb, n_calls, frame, first_line, k0, !(use_float & 2));
     g_err = "kind not simulated";
     return CM_ERR_UNSUPPORTED;
 }
@@ -120,6 +241,9 @@ extern "C" int am_sim_mod_run(const cm_am_desc *d, int use_float, const double *
     if (d->kind == CM_AM_PROTO_SECAM)
         return use_float ? proto_mod_run<float>(*d, rgb, comp, n_calls, frame, first_line, k0)
                          : proto_mod_run<double>(*d, rgb, comp, n_calls, frame, first_line, k0);
+    if (d->kind == CM_AM_NIIR)
+        return use_float ? niir_mod_run<float>(*d, rgb, comp, n_calls, frame, first_line, k0)
+                         : niir_mod_run<double>(*d, rgb, comp, n_calls, frame, first_line, k0);
     g_err = "kind not simulated";
     return CM_ERR_UNSUPPORTED;
 }

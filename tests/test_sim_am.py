@@ -82,3 +82,42 @@ def test_proto_runs_against_oracle(stack, size, std, use_float):
         back = numpy.stack([numpy.stack(dec.demodulate(frame, y, want[i])) for i, y in enumerate(lines)])
         got = _run(L.am_sim_demod_run, desc, use_float, want, (len(lines), 3, W), frame, field, 0)
         assert numpy.abs(got - back).max() < tol * max(1.0, numpy.abs(back).max()), (stack, 'demod', frame)
+
+
+NIIR_CASES = [('niir', (720, 10), 'GERBER_625'), ('niir_hue', (720, 8), 'GERBER_625'), ('niir', (768, 6), 'NTSC_525'),
+              ('niir', (1024, 6), 'GERBER_625'), ('niir', (640, 6), 'GERBER_625')]
+
+
+@pytest.mark.parametrize('stack,size,std', NIIR_CASES)
+@pytest.mark.parametrize('use_float', [0, 1])
+def test_niir_runs_against_oracle(stack, size, std, use_float):
+    L = _lib()
+    lc = line.LineConfig(size, getattr(line.LineStandard, std))
+    modem = am_stacks.STACKS[stack](lc)
+    desc = plan_am.build_am_desc(modem)
+    comp_desc = plan_am.build_am_desc(modem, components=True)
+    W, H = size
+    rgb = testing.synthetic_rgb(1, H, W, seed=23)[0].astype(numpy.float64)
+    tol = 2e-5 if use_float else 1e-10
+    for frame, field in ((1, 0), (4798, 1)):
+        lines = list(range(field, H, 2))
+        rows = numpy.stack([rgb[:, y] for y in lines])
+        orc = oa.make(modem)
+        delay = 1 if stack == 'niir_hue' else 0
+        want = numpy.stack([orc.modulate(frame, y + 2 * delay, *rows[i]) for i, y in enumerate(lines)])
+        got = _run(L.am_sim_mod_run, desc, use_float, rows, (len(lines), W), frame, field + 2 * delay, 0)
+        assert numpy.abs(got - want).max() < tol * max(1.0, numpy.abs(want).max()), (stack, 'mod', frame)
+        dec = oa.make(modem)
+        back = numpy.stack([numpy.stack(dec.demodulate(frame, y, want[i])) for i, y in enumerate(lines)])
+        got = _run(L.am_sim_demod_run, desc, use_float, want, (len(lines), 3, W), frame, field, 0)
+        # the hue is the angle of a decimated product pair: where that pair is small (saturation near zero) single float32
+        # samples sit an order of magnitude above the rest - bound the bulk tightly and the isolated samples loosely
+        err = numpy.abs(got - back) / max(1.0, numpy.abs(back).max())
+        assert numpy.quantile(err, 0.999) < (5e-6 if use_float else 1e-10), (stack, 'demod', frame)
+        assert err.max() < (1e-4 if use_float else 1e-10), (stack, 'demod', frame, err.max())
+        # the component protocol with the chroma left in the luma
+        dec = oa.make(modem)
+        back = numpy.stack([numpy.stack(dec.demodulate_components(frame, y, want[i], strip_chroma=False)) for i, y in enumerate(lines)])
+        got = _run(L.am_sim_demod_run, comp_desc, use_float | 2, want, (len(lines), 3, W), frame, field, 0)
+        err = numpy.abs(got - back) / max(1.0, numpy.abs(back).max())
+        assert numpy.quantile(err, 0.999) < (5e-6 if use_float else 1e-10) and err.max() < (1e-4 if use_float else 1e-10), (stack, 'components', frame)
