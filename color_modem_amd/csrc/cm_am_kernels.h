@@ -170,5 +170,185 @@ __global__ __launch_bounds__(64, 2) void proto_mod_kernel(const ProtoModArgs arg
     }
 }
 
+// ---- NIIR / SECAM-IV ------------------------------------------------------------------------------------------------------
+struct NiirDemodArgs {
+    Geom g;
+    AmGeom a;
+    NiirDemodK<float> k;
+    double line_phase_shift, bandpass_phase_shift, carrier_phase_step;
+    int strip;                 // 0: demodulate_components(..., strip_chroma=False)
+};
+
+constexpr int kNiirRing = 8;   // triples of the band-pass output waiting for the low-pass (q_l <= 7, checked by the host)
+
+// FIRST = false: the main pass - the previous call's phase reference comes from the neighbouring lane; calls that open a run
+//                are computed (the next call needs them) but written by the other pass (Geom::skip_first).
+// FIRST = true:  one lane per run, its first call only (Geom::sparse): the phase reference is the synthetic carrier of
+//                niir.py:107-110, produced by a second interpolator + band-pass in the same lane.
+template <bool FIRST>
+__global__ __launch_bounds__(64, 1) void niir_demod_kernel(const NiirDemodArgs args) {
+    constexpr int kTile = 16, DEPTH = 1;
+    __shared__ __attribute__((aligned(16))) float lds_store[3 * 64 * kTile + (FIRST ? 2 : 1) * kNiirRing * 3 * 64];
+    lds_float *otile_base = (lds_float *)lds_store;
+    lds_float *ring = otile_base + 3 * 64 * kTile;
+    lds_float *ring_syn = ring + kNiirRing * 3 * 64;
+    const Geom &g = args.g;
+    NiirDemodK<float> k = args.k;
+    pin_taps3(k.taps);
+    const int lane = threadIdx.x;
+    const LaneCall lc = locate_call(g, blockIdx.x, DEPTH, lane);
+    const float *xp = g.in + lc.frame * g.in_frame_stride + (long long)lc.src_row * g.Wp;
+    const float *op = lc.store_ok ? g.out + lc.frame * g.out_frame_stride + (long long)lc.out_row * g.out_row_stride : nullptr;
+    const long long frame = (long long)args.a.frame_base + lc.frame;
+    NiirLineK<float> lk;
+    {   // niir.py:117-124, 148-157
+        lk.alt = args.a.line.alternate(frame, lc.line);
+        const double shift = lk.alt ? -args.line_phase_shift : args.line_phase_shift;
+        const double ps = (lk.alt ? 0.0 : args.line_phase_shift) + 3.14159265358979323846 - args.bandpass_phase_shift;
+        lk.sin_shift = (float)sin(shift);
+        lk.cos_shift = (float)cos(shift);
+        lk.sin_ps = (float)sin(ps);
+        lk.cos_ps = (float)cos(ps);
+    }
+    float syn_s = 0.f, syn_c = 0.f;       // +-(sin, cos) of the start phase of line - 2
+    if (FIRST) {
+        const double phi = args.a.line.start_phase(frame, lc.line - 2);
+        const float sg = args.a.line.alternate(frame, lc.line - 2) ? -1.f : 1.f;
+        syn_s = sg * (float)sin(phi);
+        syn_c = sg * (float)cos(phi);
+    }
+    const int idx1 = ((lane + 63) & 63) * 4;
+    NiirFront<float> front;
+    NiirBack<float> back;
+    NiirSyn<float> syn;
+    front.reset();
+    back.reset();
+    if (FIRST) syn.reset();
+    lds_float *otile = otile_base + lane * kTile;
+    const int wpos = ((lane >> CM_TILE_SWZ) & (kTile / 4 - 1)) << 2;
+    const int W = g.W;
+    const int q_l = k.gl.q;
+    const int lat = 2 * kAmHalf + 1 + k.gb.q + q_l;
+    const int T = (g.Wp + lat + 3) & ~3;
+    for (int j = 0; j < (FIRST ? 2 : 1) * kNiirRing * 3; ++j) ring[j * 64 + lane] = 0.f;
+    const bool strip = args.strip != 0;
+    f4 xv = load_luma<false>(xp, 0, true, W);
+    for (int tb = 0; tb < T; tb += 4) {
+        const f4 xn = load_luma<false>(xp, tb + 4, true, W);
+        const f4 cd = load_luma<false>(xp, tb - lat, true, W);        // composite[n5 ..]: the luma source of this body's outputs
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int t = tb + s;
+            float m[3], sv[3], md[3], p[3], pv[3];
+            front.step(k, t, xv[s], m, sv);
+            const int wr = (t & (kNiirRing - 1)) * 3, rd = ((t - q_l) & (kNiirRing - 1)) * 3;
+#pragma unroll
+            for (int j = 0; j < 3; ++j) ring[(wr + j) * 64 + lane] = m[j];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) md[j] = ring[(rd + j) * 64 + lane];
+            const int n3 = t - kAmHalf - k.gb.q - q_l;
+            niir_phasemod(k, n3, md, sv, p);
+            if (FIRST) {
+                float xs = 0.f;
+                if (t < W) {
+                    const f2 cs = ((const_f2 *)args.a.carrier)[t];
+                    xs = fmaf_(syn_s, cs.x, syn_c * cs.y);            // +-sin(phi + t step)
+                }
+                float ms[3];
+                syn.step(k, t, xs, ms);
+#pragma unroll
+                for (int j = 0; j < 3; ++j) ring_syn[(wr + j) * 64 + lane] = ms[j];
+#pragma unroll
+                for (int j = 0; j < 3; ++j) pv[j] = k.g_b * ring_syn[(rd + j) * 64 + lane];
+            } else {
+#pragma unroll
+                for (int j = 0; j < 3; ++j) pv[j] = lane_from(idx1, p[j]);
+            }
+            const NiirOut<float> o = back.step(k, n3, p, pv, sv, lk.alt);
+            const int n = t - lat;
+            if (n >= 0 && n < W) put_rgb<false, kTile>(otile, wpos, n, niir_finish(k, lk, o, cd[s], strip));
+            if (n >= 0 && ((n & (kTile - 1)) == kTile - 1 || n == g.Wp - 1)) flush_tile<kTile>(g, otile_base, op, n & ~(kTile - 1), lane);
+        }
+        xv = xn;
+    }
+}
+
+struct NiirModArgs {
+    Geom g;
+    AmGeom a;
+    NiirModK<float> k;
+};
+
+// DEPTH = 1: HueCorrectingNiirModem (niir.py:181-202): a call modulates line - 2 with the previous call's luma, the
+// saturation-weighted mean hue of both calls and the previous call's saturation (previous call = neighbouring lane)
+template <int DEPTH>
+__global__ __launch_bounds__(64, 2) void niir_mod_kernel(const NiirModArgs args) {
+    constexpr int kTile = 16;
+    __shared__ __attribute__((aligned(16))) float lds_store[64 * kTile + kAmRingFloats];
+    lds_float *otile_base = (lds_float *)lds_store;
+    lds_float *ring = otile_base + 64 * kTile;
+    const Geom &g = args.g;
+    const NiirModK<float> &k = args.k;
+    const int lane = threadIdx.x;
+    const LaneCall lc = locate_call(g, blockIdx.x, DEPTH, lane);
+    const float *rp, *op;
+    mod_rows<false>(g, lc, rp, op);
+    const long long frame = (long long)args.a.frame_base + lc.frame;
+    const int line = DEPTH ? lc.line - 2 : lc.line;       // the line that is modulated (niir.py:202)
+    const bool alt = args.a.line.alternate(frame, line);
+    float cph, sph;
+    {
+        const double phi = args.a.line.start_phase(frame, line);
+        cph = (float)cos(phi);
+        sph = (float)sin(phi);
+    }
+    const bool have_prev = lc.kk > 0;
+    const int idx1 = ((lane + 63) & 63) * 4;
+    NiirMod<float> st;
+    st.reset();
+    const int wpos = ((lane >> CM_TILE_SWZ) & (kTile / 4 - 1)) << 2;
+    const int W = g.W, s_c = k.s_c;
+    const int T = (g.Wp + s_c + 3) & ~3;
+    for (int j = 0; j < kAmRing; ++j) ring[j * 64 + lane] = 0.f;
+    f4 cur[3], nxt[3];
+#pragma unroll
+    for (int p = 0; p < 3; ++p) nxt[p] = load_luma<false>(rp + p * g.in_plane_stride, 0, true, W);
+    for (int tb = 0; tb < T; tb += 4) {
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+            cur[p] = nxt[p];
+            nxt[p] = load_luma<false>(rp + p * g.in_plane_stride, tb + 4, true, W);
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int t = tb + s;
+            const float r = cur[0][s], gg = cur[1][s], b = cur[2][s];
+            float y = fmaf_(k.e[0][0], r, fmaf_(k.e[0][1], gg, k.e[0][2] * b));
+            float db = fmaf_(k.e[1][0], r, fmaf_(k.e[1][1], gg, k.e[1][2] * b));
+            float dr = fmaf_(k.e[2][0], r, fmaf_(k.e[2][1], gg, k.e[2][2] * b));
+            if (DEPTH) {
+                float py = lane_from(idx1, y), pdb = lane_from(idx1, db), pdr = lane_from(idx1, dr);
+                if (!have_prev) { py = y; pdb = db; pdr = dr; }         // niir.py:182-186
+                float odb, odr;
+                niir_hue_correct(db, dr, pdb, pdr, odb, odr);
+                y = py;
+                db = odb;
+                dr = odr;
+            } else {
+                niir_add_offset(db, dr);
+            }
+            if (t >= W) db = dr = 0.f;                                    // beyond the row the filter is fed its last sample anyway
+            ring[(t & (kAmRing - 1)) * 64 + lane] = y;
+            const float y_d = ring[((t - s_c) & (kAmRing - 1)) * 64 + lane];
+            const int n = t - s_c;
+            int nc = n < 0 ? 0 : (n > W - 1 ? W - 1 : n);
+            const f2 cs = ((const_f2 *)args.a.carrier)[nc];
+            const float sn = fmaf_(sph, cs.x, cph * cs.y), cn = fmaf_(cph, cs.x, -(sph * cs.y));
+            const float c = st.step(k, t, db, dr, alt, sn, cn);
+            put_composite<false, kTile>(g, otile_base, op, lane, wpos, n, y_d + c);
+        }
+    }
+}
+
 }  // namespace cm
 #endif

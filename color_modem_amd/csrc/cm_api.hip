@@ -1224,6 +1224,8 @@ struct cm_am_plan {
     float *carrier = nullptr;          // {cos, sin}(n * carrier_phase_step), n < width
     ProtoDemodK<float> pd;
     ProtoModK<float> pm;
+    NiirDemodK<float> nd;
+    NiirModK<float> nm;
     std::string demod_error, mod_error;
 };
 
@@ -1249,8 +1251,39 @@ void am_frames_geom(Geom &g, int W, int wp, int H, int D, int64_t n_frames) {
     g.delay = D;
     g.total_calls = n_frames * g.calls_per_frame;
 }
+// NIIR: the main pass over every call plus the sparse pass over the calls that open a run (k0 == 0 in rows mode)
+int niir_launch_demod(const cm_am_plan *p, Geom g, int64_t first_frame, hipStream_t stream, bool strip) {
+    NiirDemodArgs a;
+    am_geom(p, first_frame, a.a);
+    a.k = p->nd;
+    a.line_phase_shift = p->desc.line_phase_shift;
+    a.bandpass_phase_shift = p->desc.bandpass_phase_shift;
+    a.carrier_phase_step = p->desc.carrier_phase_step;
+    a.strip = strip ? 1 : 0;
+    const bool with_first = g.k0 == 0;
+    g.skip_first = 1;
+    long long blocks = (g.total_calls + 62) / 63;
+    if (blocks > 0x7fffffffLL) return fail(CM_ERR_INVALID, "batch too large for one launch");
+    if (blocks > 0 && !(g.rows_mode && g.total_calls == 1 && with_first)) {     // a lone first call needs no main pass
+        a.g = g;
+        hipLaunchKernelGGL(niir_demod_kernel<false>, dim3((int)blocks), dim3(64), 0, stream, a);
+    }
+    if (with_first) {
+        Geom s = g;
+        s.sparse = 1;
+        s.skip_first = 0;
+        s.total_calls = g.rows_mode ? 1 : (g.total_calls / g.calls_per_frame) * g.runs_per_frame;
+        const long long fb = (s.total_calls + 63) / 64;
+        a.g = s;
+        if (fb > 0) hipLaunchKernelGGL(niir_demod_kernel<true>, dim3((int)fb), dim3(64), 0, stream, a);
+    }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(CM_ERR_LAUNCH, std::string("niir_demod_kernel launch: ") + hipGetErrorString(e));
+    return CM_OK;
+}
 int am_launch_demod(const cm_am_plan *p, Geom g, int64_t first_frame, hipStream_t stream) {
     if (!p->demod_error.empty()) return fail(CM_ERR_UNSUPPORTED, p->demod_error);
+    if (p->desc.kind == CM_AM_NIIR) return niir_launch_demod(p, g, first_frame, stream, p->desc.strip_chroma != 0);
     long long blocks = (g.total_calls + 62) / 63;
     if (blocks <= 0) return CM_OK;
     if (blocks > 0x7fffffffLL) return fail(CM_ERR_INVALID, "batch too large for one launch");
@@ -1269,15 +1302,24 @@ int am_launch_mod(const cm_am_plan *p, Geom g, int64_t first_frame, hipStream_t 
     long long blocks = (g.total_calls + (64 - depth) - 1) / (64 - depth);
     if (blocks <= 0) return CM_OK;
     if (blocks > 0x7fffffffLL) return fail(CM_ERR_INVALID, "batch too large for one launch");
-    ProtoModArgs a;
-    a.g = g;
-    am_geom(p, first_frame, a.a);
-    a.k = p->pm;
-    a.averaging = depth;
-    if (depth) hipLaunchKernelGGL(proto_mod_kernel<1>, dim3((int)blocks), dim3(64), 0, stream, a);
-    else hipLaunchKernelGGL(proto_mod_kernel<0>, dim3((int)blocks), dim3(64), 0, stream, a);
+    if (p->desc.kind == CM_AM_NIIR) {
+        NiirModArgs a;
+        a.g = g;
+        am_geom(p, first_frame, a.a);
+        a.k = p->nm;
+        if (depth) hipLaunchKernelGGL(niir_mod_kernel<1>, dim3((int)blocks), dim3(64), 0, stream, a);
+        else hipLaunchKernelGGL(niir_mod_kernel<0>, dim3((int)blocks), dim3(64), 0, stream, a);
+    } else {
+        ProtoModArgs a;
+        a.g = g;
+        am_geom(p, first_frame, a.a);
+        a.k = p->pm;
+        a.averaging = depth;
+        if (depth) hipLaunchKernelGGL(proto_mod_kernel<1>, dim3((int)blocks), dim3(64), 0, stream, a);
+        else hipLaunchKernelGGL(proto_mod_kernel<0>, dim3((int)blocks), dim3(64), 0, stream, a);
+    }
     hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return fail(CM_ERR_LAUNCH, std::string("proto_mod_kernel launch: ") + hipGetErrorString(e));
+    if (e != hipSuccess) return fail(CM_ERR_LAUNCH, std::string("cm_am modulator launch: ") + hipGetErrorString(e));
     return CM_OK;
 }
 }  // namespace
@@ -1289,7 +1331,7 @@ int cm_am_plan_create(const cm_am_desc *desc, cm_am_plan **out) {
     if (desc->abi_version != CM_ABI_VERSION) return fail(CM_ERR_INVALID, "descriptor ABI version mismatch");
     if (desc->width < 4) return fail(CM_ERR_UNSUPPORTED, "width must be at least 4");
     if (desc->height < 1) return fail(CM_ERR_INVALID, "height must be positive");
-    if (desc->kind != CM_AM_PROTO_SECAM) return fail(CM_ERR_UNSUPPORTED, "only CM_AM_PROTO_SECAM has kernels in this build");
+    if (desc->kind != CM_AM_PROTO_SECAM && desc->kind != CM_AM_NIIR) return fail(CM_ERR_INVALID, "unknown cm_am_kind");
     if (desc->frame_cycle < 1) return fail(CM_ERR_INVALID, "frame_cycle must be positive");
     if (cm_device_count() < 1) return fail(CM_ERR_NO_DEVICE, "no HIP device available (this library has no CPU path)");
     cm_am_plan *p = new cm_am_plan;
@@ -1299,12 +1341,18 @@ int cm_am_plan_create(const cm_am_desc *desc, cm_am_plan **out) {
         return fail(CM_ERR_NO_DEVICE, "hipGetDevice failed");
     }
     std::string err;
-    if (!build_proto_demod_k<float>(*desc, p->pd, err)) p->demod_error = err;
+    if (desc->kind == CM_AM_NIIR) {
+        if (!build_niir_demod_k<float>(*desc, p->nd, err)) p->demod_error = err;
+        else if (p->nd.gl.q >= kNiirRing) p->demod_error = "decoder: the low-pass delay does not fit the band-pass ring";
+        if (!build_niir_mod_k<float>(*desc, p->nm, err)) p->mod_error = err;
+        else if (p->nm.s_c >= kAmRing) p->mod_error = "encoder: the pre-correction shift does not fit the luma delay ring";
+    } else if (!build_proto_demod_k<float>(*desc, p->pd, err)) p->demod_error = err;
     else {
         const int dly = ProtoDemod<float>::lat_chroma(p->pd) - ProtoDemod<float>::lat_luma(p->pd);
         if (dly < 0 || dly >= kAmRing) p->demod_error = "decoder: the luma delay does not fit the delay ring";
     }
-    if (!build_proto_mod_k<float>(*desc, p->pm, err)) p->mod_error = err;
+    if (desc->kind == CM_AM_NIIR) {
+    } else if (!build_proto_mod_k<float>(*desc, p->pm, err)) p->mod_error = err;
     else {
         const int ly = ProtoMod<float>::lat_luma(p->pm), lc = ProtoMod<float>::lat_chroma(p->pm);
         const int dly = ly > lc ? ly - lc : lc - ly;

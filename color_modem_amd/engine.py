@@ -128,7 +128,7 @@ def make_engine(modem, components=False, strip_chroma=True, min_lines=0):
     if kind == 'mac':
         return MacEngine(modem, components)
     if kind in ('protosecam', 'niir'):
-        return AmEngine(modem, components)
+        return AmEngine(modem, components, strip_chroma)
     return Engine(modem, components, strip_chroma, min_lines)
 
 
@@ -368,9 +368,9 @@ class AmEngine(_EngineBase):
     points (the amplitude-modulated line-sequential standards: x3 resampling around recursive filters)."""
     abi_prefix = 'cm_am_'
 
-    def __init__(self, modem, components=False):
+    def __init__(self, modem, components=False, strip_chroma=True):
         from color_modem_amd import plan_am
-        d = plan_am.build_am_desc(modem, components)
+        d = plan_am.build_am_desc(modem, components, strip_chroma)
         self.desc = d
         self.width = self.comp_width = self.in_width = d.width
         self.height = d.height
@@ -384,7 +384,8 @@ class AmEngine(_EngineBase):
         self._plan
 
     def describe(self):
-        return 'proto_demod_kernel / proto_mod_kernel: one wavefront per 64 calls, x3 polyphase resamplers in registers'
+        name = 'proto' if self.desc.kind == 1 else 'niir'
+        return '%s_demod_kernel / %s_mod_kernel: one wavefront per 64 calls, x3 polyphase resamplers in registers' % (name, name)
 
     def demodulate_frames(self, composite, first_frame=0, out=None):
         """composite [F, H, W] float32 -> rgb [F, 3, H, W] (numpy in -> numpy out, cuda tensor in -> cuda tensor out)."""

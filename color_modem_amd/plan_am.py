@@ -17,6 +17,7 @@ class AmDesc(ctypes.Structure):
     _fields_ = [('abi_version', ctypes.c_int32), ('kind', ctypes.c_int32), ('width', ctypes.c_int32), ('height', ctypes.c_int32),
                 ('line_shift', ctypes.c_int32), ('even_first', ctypes.c_int32), ('odd_first', ctypes.c_int32),
                 ('averaging', ctypes.c_int32), ('premod_luma_filter', ctypes.c_int32), ('frame_cycle', ctypes.c_int32),
+                ('strip_chroma', ctypes.c_int32), ('reserved', ctypes.c_int32),
                 ('frame_phase_shift', ctypes.c_double), ('line_phase_shift', ctypes.c_double),
                 ('carrier_phase_step', ctypes.c_double), ('resample_fir3', ctypes.c_double * 61),
                 ('precorrect', plan.IirDesc), ('bandpass_up', plan.IirDesc), ('bandstop_up', plan.IirDesc),
@@ -29,7 +30,7 @@ def resample_fir3():
     return scipy.signal.firwin(61, 1.0 / 3.0, window=('kaiser', 5.0))
 
 
-def build_am_desc(modem, components=False):
+def build_am_desc(modem, components=False, strip_chroma=True):
     stack = modem._stack()
     kind = stack['kind']
     m = stack['backend']
@@ -44,6 +45,7 @@ def build_am_desc(modem, components=False):
     d.even_first = int(std.even_field_first_active_line)
     d.odd_first = int(std.odd_field_first_active_line)
     d.frame_cycle = int(m.frame_cycle)
+    d.strip_chroma = 1 if strip_chroma else 0
     d.frame_phase_shift = float(m.frame_shift)
     d.line_phase_shift = float(m.line_shift)
     d.resample_fir3[:] = list(resample_fir3())

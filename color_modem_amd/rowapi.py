@@ -73,7 +73,7 @@ class RowApi(object):
         """(y, u, v) of one row (ref qam.py:43-58 behind pal.py:54-59 / ntsc.py:47-49, comb.py:47-59, 96-113,
         pal.py:180-234); shares the run state with demodulate(), which is this followed by decode_components."""
         eng = self._engine(True, strip_chroma, line)
-        if not strip_chroma and eng.built.desc.first_is_plain:
+        if not strip_chroma and getattr(getattr(eng, 'built', None), 'desc', None) is not None and eng.built.desc.first_is_plain:
             # the first line of a run is the backend's own unstripped decode (comb.py:48-49); the plain pass of
             # the comb's plan only exists with band-stop luma, so that one call goes to the backend's plan
             run = self._demod_run

@@ -261,8 +261,8 @@ int cm_mac_demodulate_run(const cm_mac_plan *plan, const float *composite, float
  * CM_AM_NIIR: NiirModem / HueCorrectingNiirModem, ref color_modem/color/niir.py:10-202 (SECAM-IV: saturation as amplitude,
  *   hue as the phase against the previous line's reference), `averaging` = the hue-correcting encoder (niir.py:167-202).
  * Both run every recursive filter of the decoder at three times the sampling rate between scipy.signal.resample_poly(x, 3, 1)
- * and resample_poly(x, 1, 3) (61-tap Kaiser(5) FIR, `resample_fir3`).  Filters are given like in cm_plan_desc (second-order
- * sections + FilterFunction shift).  The sub-carrier start phase of a line is computed on the device in float64 from
+ * and resample_poly(x, 1, 3) (61-tap Kaiser(5) FIR, `resample_fir3`).  Filters are given as in the cm_plan_desc structure: second-order
+ * sections + FilterFunction shift.  The sub-carrier start phase of a line is computed on the device in float64 from
  * frame_phase_shift / line_phase_shift / frame_cycle (utils.py:67-88) and the line geometry (line.py:57-65). */
 enum cm_am_kind { CM_AM_PROTO_SECAM = 1, CM_AM_NIIR = 2 };
 typedef struct cm_am_desc {
@@ -274,6 +274,8 @@ typedef struct cm_am_desc {
     int32_t averaging;            /* 1: encoder inside ColorAveragingModem (Proto-SECAM) / HueCorrectingNiirModem (NIIR): modulation_delay 1 */
     int32_t premod_luma_filter;   /* Proto-SECAM encoder: protosecam.py:82-85 */
     int32_t frame_cycle;          /* ConstantFrequencyCarrier.frame_cycle (utils.py:78-80) */
+    int32_t strip_chroma;         /* NIIR decoder: 0 = demodulate_components(..., strip_chroma=False) (niir.py:145), else 1 */
+    int32_t reserved;
     double frame_phase_shift;     /* ... .frame_shift (utils.py:74-76) */
     double line_phase_shift;      /* ... .line_shift (utils.py:69-72) */
     double carrier_phase_step;    /* radians per 1x sample: 2 * protosecam.py:31 _carrier_phase_step; niir.py:12 */

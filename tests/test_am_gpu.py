@@ -12,7 +12,7 @@ from color_modem_amd import image, line, testing
 pytestmark = pytest.mark.gpu
 TOL = 1e-5
 
-PROTO = ['proto', 'proto_avg', 'proto_nofilter', 'proto_625']
+PROTO = ['proto', 'proto_avg', 'proto_nofilter', 'proto_625', 'niir', 'niir_hue', 'niir_525']
 
 
 @pytest.mark.parametrize('stack', PROTO)
@@ -38,7 +38,7 @@ def test_demodulate_frames_golden(stack):
             assert stacks.rel_err(out[i], z['out'][i]) < TOL
 
 
-@pytest.mark.parametrize('stack', ['proto'])
+@pytest.mark.parametrize('stack', ['proto', 'niir'])
 def test_row_sequences_golden(stack):
     """The stateful per-row protocol with a break in the run and a frame change, at full-height line numbers."""
     z = am_stacks.load('am_rows_' + stack)
@@ -71,3 +71,54 @@ def test_proto_round_trip_vs_oracle(stack, size, std, first):
     back_ref = oa.demodulate_frames(inner, comp32.astype(numpy.float64), first)
     for i in range(2):
         assert stacks.rel_err(back[i], back_ref[i]) < TOL, (stack, i)
+
+
+def test_niir_components_unstripped_noise():
+    """NiirModem.demodulate_components(..., strip_chroma=False) row by row on noise (a reference-generated vector)."""
+    z = am_stacks.load('am_niir_components_noise')
+    modem = am_stacks.make('niir', z)
+    k = 0
+    for i, f in enumerate(z['frames']):
+        for field in range(2):
+            for y in range(field, 6, 2):
+                got = numpy.stack(modem.demodulate_components(int(f), y, z['inp'][i, y], strip_chroma=False))
+                err = numpy.abs(got - z['out'][k]) / numpy.abs(z['out'][k]).max()
+                # noise input: the hue of single low-saturation samples is ill-conditioned in float32 (tests/test_sim_am.py)
+                assert numpy.quantile(err, 0.999) < TOL and err.max() < 1e-4, (int(f), y, err.max())
+                k += 1
+
+
+@pytest.mark.parametrize('stack,size,std,first', [('niir', (720, 64), 'GERBER_625', 2), ('niir_hue', (720, 33), 'GERBER_625', 1),
+                                                 ('niir', (768, 9), 'NTSC_525', 4798), ('niir', (718, 12), 'GERBER_625', 5)])
+def test_niir_round_trip_vs_oracle(stack, size, std, first):
+    from oracle import cm_oracle_am as oa
+    lc = line.LineConfig(size, getattr(line.LineStandard, std))
+    modem = am_stacks.STACKS[stack](lc)
+    rgb = testing.synthetic_rgb(2, size[1], size[0], seed=55 + size[1])
+    im = image.ImageModem(modem)
+    comp = im.modulate_frames(rgb, first_frame=first)
+    comp_ref = oa.modulate_frames(modem, rgb.astype(numpy.float64), first)
+    assert stacks.rel_err(comp, comp_ref) < TOL
+    comp32 = comp_ref.astype(numpy.float32)
+    back = im.demodulate_frames(comp32, first_frame=first)
+    back_ref = oa.demodulate_frames(modem, comp32.astype(numpy.float64), first)
+    for i in range(2):
+        err = numpy.abs(back[i] - back_ref[i]) / numpy.abs(back_ref[i]).max()
+        assert numpy.quantile(err, 0.9999) < TOL and err.max() < 1e-4, (stack, i, err.max())
+
+
+def test_pil_image_round_trip_proto_and_niir():
+    """ImageModem's PIL entry points (host byte conversion for these standards) against the oracle's frames."""
+    from PIL import Image
+    from oracle import cm_oracle_am as oa
+    for stack, std in (('proto', 'FRENCH_819'), ('niir_hue', 'GERBER_625')):
+        lc = line.LineConfig((720, 10), getattr(line.LineStandard, std))
+        modem = am_stacks.STACKS[stack](lc)
+        rgb8 = numpy.uint8(numpy.rint(255.0 * testing.synthetic_rgb(1, 10, 720, seed=9)[0])).transpose(1, 2, 0).copy()
+        img = Image.frombytes('RGB', (720, 10), rgb8.tobytes())
+        comp_img = image.ImageModem(modem).modulate(img, 1)
+        comp8 = numpy.frombuffer(comp_img.tobytes(), dtype=numpy.uint8).reshape(10, 720)
+        rgbf = (rgb8.astype(numpy.float64) / 255.0).transpose(2, 0, 1)[None]
+        want = numpy.uint8(numpy.rint(255.0 * numpy.clip(0.6 * oa.modulate_frames(modem, rgbf, 1)[0] + 0.2, 0.0, 1.0)))
+        diff = numpy.abs(comp8.astype(int) - want.astype(int))
+        assert diff.max() <= 1 and (diff > 0).mean() < 0.002, stack
