@@ -14,6 +14,7 @@
 #include "cm_mac_kernels.h"
 #include "cm_plan.h"
 #include "cm_am_kernels.h"
+#include "cm_wrap_kernels.h"
 #include "cm_am_plan.h"
 
 constexpr int kModAnyShift = 12;   // luma delay window of the run-time-shape modulators (pre-correction shift <= 12)
@@ -1474,6 +1475,40 @@ int cm_am_modulate_run(const cm_am_plan *p, const float *rgb, float *composite, 
         g.total_calls = n_calls;
         return am_launch_mod(p, g, frame, (hipStream_t)stream);
     });
+}
+}  // extern "C"
+
+extern "C" {
+int cm_comb_combine_run(const float *inner, float *uv, float *ysrc, int32_t n_calls, int32_t width, int32_t k0, int32_t own_delay,
+                        int32_t use_minavg, void *stream) {
+    if (!inner || !uv || !ysrc) return fail(CM_ERR_INVALID, "null argument");
+    if (n_calls < 0 || k0 < 0 || width < 4 || (width & 3)) return fail(CM_ERR_INVALID, "n_calls / k0 negative or width not a multiple of 4");
+    if (n_calls == 0) return CM_OK;
+    CombWrapArgs a;
+    std::memset(&a, 0, sizeof a);
+    a.inner = inner; a.uv = uv; a.ysrc = ysrc;
+    a.n = n_calls; a.Wp = width; a.k0 = k0; a.own_delay = own_delay ? 1 : 0; a.minavg = use_minavg ? 1 : 0;
+    const long long threads = (long long)n_calls * (width >> 2);
+    hipLaunchKernelGGL(comb_combine_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(CM_ERR_LAUNCH, std::string("comb_combine_kernel launch: ") + hipGetErrorString(e));
+    return CM_OK;
+}
+int cm_comb_finish_run(const float *uv, const float *ysrc, const float *remod, const double *decode_matrix, float *rgb,
+                       int32_t n_calls, int32_t width, int32_t k0, void *stream) {
+    if (!uv || !ysrc || !remod || !decode_matrix || !rgb) return fail(CM_ERR_INVALID, "null argument");
+    if (n_calls < 0 || k0 < 0 || width < 4 || (width & 3)) return fail(CM_ERR_INVALID, "n_calls / k0 negative or width not a multiple of 4");
+    if (n_calls == 0) return CM_OK;
+    CombWrapArgs a;
+    std::memset(&a, 0, sizeof a);
+    a.uv = const_cast<float *>(uv); a.ysrc = const_cast<float *>(ysrc); a.remod = remod; a.rgb = rgb;
+    a.n = n_calls; a.Wp = width; a.k0 = k0;
+    for (int i = 0; i < 9; ++i) a.m[i] = (float)decode_matrix[i];
+    const long long threads = (long long)n_calls * (width >> 2);
+    hipLaunchKernelGGL(comb_finish_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(CM_ERR_LAUNCH, std::string("comb_finish_kernel launch: ") + hipGetErrorString(e));
+    return CM_OK;
 }
 }  // extern "C"
 

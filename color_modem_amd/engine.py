@@ -124,7 +124,11 @@ class RowSession(object):
 
 def make_engine(modem, components=False, strip_chroma=True, min_lines=0):
     """The engine of a modem stack: a cm_plan for the QAM / SECAM families, the plan-less MAC entry points for MacModem."""
-    kind = modem._stack()['kind']
+    stack = modem._stack()
+    kind = stack['kind']
+    if stack.get('demod_wrapper') and kind in ('pal_d', 'pal_3d'):
+        from color_modem_amd import wrapped
+        return wrapped.WrappedCombEngine(modem, components, strip_chroma)
     if kind == 'mac':
         return MacEngine(modem, components)
     if kind in ('protosecam', 'niir'):

@@ -61,6 +61,10 @@ class RowApi(object):
     @staticmethod
     def _step(run, eng, direction, frame, line):
         from color_modem_amd import engine
+        if getattr(eng, 'composite', False):      # a composition of kernels (wrapped.py): the run's last rows go up as they are
+            n = len(run.rows)
+            fn = eng.demodulate_run if direction == 'demod' else eng.modulate_run
+            return numpy.asarray(fn(numpy.stack(run.rows), frame, line - 2 * (n - 1), run.k - (n - 1))[n - 1], dtype=numpy.float64)
         key = (id(eng), direction)
         if key not in run.sessions:
             run.sessions[key] = engine.RowSession(eng, direction)

@@ -303,6 +303,21 @@ int cm_am_modulate_run(const cm_am_plan *plan, const float *rgb, float *composit
 int cm_am_demodulate_run(const cm_am_plan *plan, const float *composite, float *rgb, int32_t n_calls, int32_t frame,
                          int32_t first_line, int32_t k0, void *stream);
 
+/* ---- SimpleCombModem / Simple3DCombModem around PalDModem or Pal3DModem (comb.py:96-113 over pal.py:79-234) ---------------
+ * These stacks run as a composition: the inner decoder through cm_demodulate_run in component mode with
+ * strip_chroma = False (what the wrapper asks its backend for), then the wrapper's own arithmetic - the two calls below -
+ * around the inner modulator's cm_modulate_run (the wrapper strips the luma by re-modulating the averaged chroma).
+ * All buffers are device pointers, rows of `width` samples (a multiple of 4), n_calls consecutive calls of one run, k0 the
+ * index of the first of them within the run.
+ *   combine: inner [n][3][width] = (y, u, v) the backend returned per call -> uv [n][3][width] = (0, u, v) with
+ *            u, v = avg / minavg(previous call, this call) (comb.py:103-104; call 0 of a run: its own), ysrc [n][width] = the
+ *            luma source (comb.py:102: the previous call's luma when own_delay, else this call's)
+ *   finish:  rgb [n][3][width] = decode_matrix . (ysrc - remod (not on call 0 of a run, comb.py:97-99), u, v) */
+int cm_comb_combine_run(const float *inner, float *uv, float *ysrc, int32_t n_calls, int32_t width, int32_t k0, int32_t own_delay,
+                        int32_t use_minavg, void *stream);
+int cm_comb_finish_run(const float *uv, const float *ysrc, const float *remod, const double *decode_matrix, float *rgb,
+                       int32_t n_calls, int32_t width, int32_t k0, void *stream);
+
 /* Name, main-loop instruction mix and launch geometry of the dominant kernel of the last
  * cm_demodulate_frames call on this plan (for bench.py / profiling); returns bytes written. */
 int cm_plan_describe(const cm_plan *plan, char *buf, int32_t buf_len);

@@ -243,7 +243,14 @@ STACKS.update({
     'secam_a': lambda lc: secam.SecamModem(lc, secam.SecamVariant.SECAM_A),
 })
 
-STANDARD = {'pal': 'GERBER_625', 'ntsc': 'NTSC_525', 'secam': 'GERBER_625'}
+# comb wrappers around the PAL delay-line decoders (22 of the 140 cells of the support matrix)
+STACKS.update({
+    'simple3d_pald': lambda lc: comb.Simple3DCombModem(pal.PalDModem(lc)),
+    'simple_pald': lambda lc: comb.SimpleCombModem(pal.PalDModem(lc)),
+    'simple3d_pal3d': lambda lc: comb.Simple3DCombModem(pal.Pal3DModem(lc)),
+    'simple3d_pald_minavg': lambda lc: comb.Simple3DCombModem(pal.PalDModem(lc), avg=comb.minavg),
+})
+STANDARD = {'pal': 'GERBER_625', 'ntsc': 'NTSC_525', 'secam': 'GERBER_625', 'simple3d': 'GERBER_625', 'simple': 'GERBER_625'}
 STANDARD_OF = {'pal_d_palm': 'NTSC_525', 'pal_s_palm': 'NTSC_525', 'pal_d_60': 'NTSC_525', 'pal_s_60': 'NTSC_525',
                'ntsc_comb_n': 'GERBER_625', 'ntsc_n': 'GERBER_625', 'ntsc_comb_i': 'GERBER_625', 'ntsc_i': 'GERBER_625',
                'secam_m': 'NTSC_525', 'secam_a': 'BAIRD_405'}
@@ -397,6 +404,18 @@ def variant_cases(only=()):
         save('frames_demod_' + tag, inp=comp, out=out, frames=numpy.array(frames), size=numpy.array([W, H]))
 
 
+def wrapper_cases():
+    """SimpleCombModem / Simple3DCombModem around PalDModem and Pal3DModem: 720 x 10 frames of a valid PAL signal."""
+    W, H = 720, 10
+    for stack, frames in (('simple3d_pald', [1, 2]), ('simple_pald', [1, 2]), ('simple3d_pal3d', [1, 2]), ('simple3d_pald_minavg', [0, 3])):
+        lc = line_config(stack, (W, H))
+        enc = STACKS['pal_s'](lc)
+        rgb = testing.synthetic_rgb(len(frames), H, W, seed=321)
+        comp = numpy.stack([run_mod_frame(enc, rgb[i].astype(numpy.float64), f) for i, f in enumerate(frames)]).astype(numpy.float32)
+        out = numpy.stack([run_demod_frame(STACKS[stack](lc), comp[i].astype(numpy.float64), f) for i, f in enumerate(frames)])
+        save('frames_demod_' + stack, inp=comp, out=out, frames=numpy.array(frames), size=numpy.array([W, H]))
+
+
 def row_cases():
     """Explicit (frame, line) sequences at the full-height geometry, fed to one modem object in order."""
     seqs = {
@@ -442,6 +461,9 @@ if __name__ == '__main__':
     if sys.argv[1:2] == ['widths']:
         width_cases()
         sys.exit(0)
+    if sys.argv[1:2] == ['wrappers']:
+        wrapper_cases()
+        sys.exit(0)
     if sys.argv[1:2] == ['variants']:
         variant_cases(sys.argv[2:])
         sys.exit(0)
@@ -450,5 +472,6 @@ if __name__ == '__main__':
     option_cases()
     width_cases()
     variant_cases()
+    wrapper_cases()
     row_cases()
     image_cases()

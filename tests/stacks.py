@@ -60,7 +60,14 @@ STACKS.update({
     'secam_n': lambda lc: secam.SecamModem(lc, secam.SecamVariant.SECAM_N),
     'secam_a': lambda lc: secam.SecamModem(lc, secam.SecamVariant.SECAM_A),
 })
-STANDARD = {'pal': 'GERBER_625', 'ntsc': 'NTSC_525', 'secam': 'GERBER_625'}
+# comb wrappers around the PAL delay-line decoders (a composition of kernels: color_modem_amd/wrapped.py)
+STACKS.update({
+    'simple3d_pald': lambda lc: comb.Simple3DCombModem(pal.PalDModem(lc)),
+    'simple_pald': lambda lc: comb.SimpleCombModem(pal.PalDModem(lc)),
+    'simple3d_pal3d': lambda lc: comb.Simple3DCombModem(pal.Pal3DModem(lc)),
+    'simple3d_pald_minavg': lambda lc: comb.Simple3DCombModem(pal.PalDModem(lc), avg=comb.minavg),
+})
+STANDARD = {'pal': 'GERBER_625', 'ntsc': 'NTSC_525', 'secam': 'GERBER_625', 'simple3d': 'GERBER_625', 'simple': 'GERBER_625'}
 STANDARD_OF = {'pal_d_palm': 'NTSC_525', 'pal_s_palm': 'NTSC_525', 'pal_d_60': 'NTSC_525', 'pal_s_60': 'NTSC_525',
                'ntsc_comb_n': 'GERBER_625', 'ntsc_n': 'GERBER_625', 'ntsc_comb_i': 'GERBER_625', 'ntsc_i': 'GERBER_625',
                'secam_m': 'NTSC_525', 'secam_a': 'BAIRD_405'}

@@ -623,3 +623,24 @@ def test_plan_refuses_host_pointers():
     rc = _native.lib().cm_demodulate_frames(eng._plan, host_in.ctypes.data, host_out.ctypes.data, 1, 0, None)
     assert rc == _native.CM_ERR_INVALID
     assert b'device' in _native.lib().cm_last_error()
+
+
+# ---- comb wrappers around the PAL delay-line decoders (color_modem_amd/wrapped.py) -----------------------------------------
+@pytest.mark.parametrize('stack,size,first', [('simple3d_pald', (720, 40), 1), ('simple_pald', (720, 21), 2), ('simple3d_pal3d', (720, 24), 3),
+                                              ('simple3d_pald_minavg', (704, 12), 0)])
+def test_wrapped_pal_comb_vs_oracle(stack, size, first):
+    from oracle import cm_oracle
+    modem = stacks.make(stack, size)
+    rgb = testing.synthetic_rgb(2, size[1], size[0], seed=12 + size[1])
+    comp = cm_oracle.modulate_frames_f32(stacks.make('pal_s', size), rgb, first_frame=first, n_threads=4)
+    got = image.ImageModem(modem).demodulate_frames(comp, first_frame=first)
+    want = cm_oracle.demodulate_frames_f32(modem, comp, first_frame=first, n_threads=4)
+    for i in range(2):
+        assert stacks.rel_err(got[i], want[i]) < TOL, (stack, i)
+    # the per-row protocol on the same stack, with a break in the run
+    orc = cm_oracle.OracleModem(modem)
+    for f, y in ((first, 0), (first, 2), (first, 4), (first, 6), (first, 11), (first, 13), (first + 1, 15)):
+        row = comp[0, y % size[1]]
+        got_row = numpy.stack(modem.demodulate(f, y, row))
+        want_row = numpy.stack(orc.demodulate(f, y, row.astype(numpy.float64)))
+        assert stacks.rel_err(got_row, want_row) < TOL, (stack, f, y)
