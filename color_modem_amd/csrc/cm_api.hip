@@ -15,6 +15,7 @@
 #include "cm_plan.h"
 #include "cm_am_kernels.h"
 #include "cm_wrap_kernels.h"
+#include "cm_blk_kernels.h"
 #include "cm_am_plan.h"
 
 constexpr int kModAnyShift = 12;   // luma delay window of the run-time-shape modulators (pre-correction shift <= 12)
@@ -90,6 +91,46 @@ int launch_demod(const Geom &gm, const void *km, const Geom &gf, const void *kf,
     return CM_OK;
 }
 
+// The blocked decoder (cm_blk_kernels.h) for the main pass; the plain first-line workgroups stay on the wave-pair kernel
+// (launched with an empty main pass).
+template <class Main, class First, int QE, int QL>
+int launch_demod_blk(const Geom &gm, const void *km, const Geom &gf, const void *kf, int n_first, int n_main, hipStream_t stream) {
+    typedef typename Main::S S;
+    PassArgs<S> am, af;
+    am.g = gm;
+    am.k = *static_cast<const DemodK<float, S> *>(km);
+    af.g = gf;
+    af.k = kf ? *static_cast<const DemodK<float, S> *>(kf) : am.k;
+    if (n_first > 0) hipLaunchKernelGGL((demod_pair_kernel<Main, First>), dim3(n_first), dim3(128), 0, stream, am, af, n_first);
+    if (n_main > 0)
+        hipLaunchKernelGGL((demod_blk_kernel<S, QE, QL>), dim3(n_main), dim3(64), 0, stream, am, (const BlkTiles *)gm.blk_tiles);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(CM_ERR_LAUNCH, std::string("demod_blk_kernel launch: ") + hipGetErrorString(e));
+    return CM_OK;
+}
+
+// Toeplitz tiles of y[t] = sum_j g[j] x[t - j] (g = the 20 odd taps of 2 h, symmetric) times kBlkScale, split into two
+// float16 pieces; layout: cm_blk_kernels.h: BlkTiles
+inline bool build_blk_tiles(const cm_plan_desc &d, void **out) {
+    std::vector<_Float16> t(64 * 6 * 8);
+    for (int l = 0; l < 64; ++l)
+        for (int c = 0; c < 3; ++c)
+            for (int j = 0; j < 8; ++j) {
+                const int tt = l & 31, s = 16 * c + 8 * (l >> 5) + j, kk = tt + 16 - s;
+                float v = 0.f;
+                if (kk >= 0 && kk < 20) {
+                    const int i = kk < 10 ? kk : 19 - kk;              // tap(I) = c[I < 10 ? I : 19 - I], c[i] = 2 h[2 i + 1]
+                    v = (float)(2.0 * d.resample_fir[2 * i + 1]) * kBlkScale;
+                }
+                const _Float16 hi = (_Float16)v;
+                const _Float16 lo = (_Float16)(v - (float)hi);
+                t[((size_t)l * 6 + c) * 8 + j] = hi;             // BlkTiles::hi[c]
+                t[((size_t)l * 6 + 3 + c) * 8 + j] = lo;         // BlkTiles::lo[c]
+            }
+    if (hipMalloc(out, t.size() * sizeof(_Float16)) != hipSuccess) return false;
+    return hipMemcpy(*out, t.data(), t.size() * sizeof(_Float16), hipMemcpyHostToDevice) == hipSuccess;
+}
+
 struct Pass {
     std::vector<unsigned char> k;  // DemodK<float, S> blob
     LaneK<float> *lanes = nullptr; // device
@@ -109,6 +150,7 @@ struct cm_plan {
     float *carrier4_base = nullptr, *carrier2_base = nullptr;   // the allocations
     float *frame_rot = nullptr;   // {cos, sin} per frame of the rotation cycle (long sub-carrier cycles), else null
     unsigned *simd_load = nullptr; // wave-pair kernels: live load per (XCC, CU, SIMD), kSimdLoadEntries counters (cm_kernels.h)
+    void *blk_tiles = nullptr;     // blocked decoder (cm_blk_kernels.h): Toeplitz tiles of the half-band FIR, [64 lanes] BlkTiles
     int rot_cycle = 0;
     LaunchFn fn = nullptr, fn_u8 = nullptr;
     bool has_first = false;
@@ -174,6 +216,24 @@ bool make_passes(cm_plan *p, const cm_plan_desc &d, bool pald, bool bsf, bool fi
     return true;
 }
 
+
+// The blocked decoder (cm_blk_kernels.h) replaces the wave pair for the PAL-D front end of an even-shift tuned shape when
+// CM_BLK is set in the environment at plan creation (A/B against the streaming kernel; see DESIGN.md for what it measures).
+template <class S, class First>
+bool maybe_select_blk(cm_plan *p, const cm_plan_desc &d) {
+    if constexpr (!S::ODD_E && !S::ODD_L && !S::RT) {
+        const char *env = getenv("CM_BLK");
+        if (!env || !*env || *env == '0') return false;
+        if (d.width % 4) return false;
+        const int q_e = pair_delay(d.extract2x.shift), q_l = pair_delay(d.pald_lp.shift);
+        if (q_e != 2 || q_l != 3) return false;          // the PAL-BG delays the instance is compiled for
+        if (!build_blk_tiles(d, &p->blk_tiles)) return false;
+        p->fn = launch_demod_blk<PassCfg<S, FRONT_PALD, false, 1, 16>, First, 2, 3>;
+        return true;
+    }
+    return false;
+}
+
 // Kernel instances of one filter-set shape S.  HAS_PALD / HAS_D1: whether the PAL-D front end and the one-line
 // comb behind the QAM front end (NTSC comb) exist for this shape.  The notch variants are float-only.
 template <class S, bool HAS_PALD, bool HAS_D1>
@@ -199,6 +259,7 @@ bool select_for_shape(cm_plan *p, const cm_plan_desc &d, const char *sys, std::s
             p->main.depth = 1;
             p->pair = CM_PAIR != 0;
             p->main.name = std::string(CM_PAIR ? "demod_pair_kernel<" : "demod_kernel<") + sys + ": pal-d front, depth 1 | plain first line>";
+            if (maybe_select_blk<S, First>(p, d)) p->main.name = std::string("demod_blk_kernel<") + sys + ": pal-d front, depth 1, FIRs on the matrix pipe | plain first line>";
             return make_passes<S>(p, d, pald, bsf, first, err);
         }
     }
@@ -220,6 +281,7 @@ bool select_for_shape(cm_plan *p, const cm_plan_desc &d, const char *sys, std::s
                 p->fn_u8 = launch_demod<PassCfg<S, FRONT_PALD, false, 1, 16, true>, FirstU8>;
             }
             p->main.depth = 1; what = "pal-d front, depth 1 | plain first line";
+            if (!notch && maybe_select_blk<S, First>(p, d)) what = "pal-d front, depth 1, FIRs on the matrix pipe (demod_blk_kernel) | plain first line";
         } else {
             err = std::string("no PAL-D front end for the ") + sys + " filter shapes";
             return false;
@@ -581,6 +643,7 @@ static unsigned long long *g_diag;
 int run_plan(const cm_plan *p, Geom gm, Geom gf, bool with_first, hipStream_t stream, bool u8 = false) {
     finish_geom(p, p->main, gm);
     gm.simd_load = p->simd_load;
+    gm.blk_tiles = p->blk_tiles;
 #ifdef CM_DIAG
     gm.diag = g_diag;
 #endif
@@ -747,6 +810,7 @@ void cm_plan_destroy(cm_plan *p) {
     if (p->carrier2_base) (void)hipFree(p->carrier2_base);
     if (p->frame_rot) (void)hipFree(p->frame_rot);
     if (p->simd_load) (void)hipFree(p->simd_load);
+    if (p->blk_tiles) (void)hipFree(p->blk_tiles);
     if (p->main.lanes) (void)hipFree(p->main.lanes);
     if (p->first.lanes) (void)hipFree(p->first.lanes);
     if (p->mod_lanes) (void)hipFree(p->mod_lanes);

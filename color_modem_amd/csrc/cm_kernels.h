@@ -59,6 +59,7 @@ struct Geom {
     int skip_first;      // 1: calls with k == 0 are written by the sparse pass, not by this one
     unsigned long long *diag;  // diagnostic builds only (-DCM_DIAG): per-workgroup cycle sums; null otherwise
     unsigned *simd_load;       // wave-pair kernels (CM_SIMD_BALANCE): live load per (XCC, CU, SIMD); null: waves keep their order
+    const void *blk_tiles;     // blocked decoder (cm_blk_kernels.h): the Toeplitz tiles of the half-band FIR, or null
 };
 
 // Long sub-carrier cycles: advance every phase a lane constant carries by the frame's angle (c, s) = {cos, sin}.

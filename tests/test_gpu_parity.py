@@ -644,3 +644,25 @@ def test_wrapped_pal_comb_vs_oracle(stack, size, first):
         got_row = numpy.stack(modem.demodulate(f, y, row))
         want_row = numpy.stack(orc.demodulate(f, y, row.astype(numpy.float64)))
         assert stacks.rel_err(got_row, want_row) < TOL, (stack, f, y)
+
+
+# ---- the time-blocked decoder with the half-band FIRs on the matrix pipe (csrc/cm_blk_kernels.h, opt-in: CM_BLK=1) ----------
+def test_blocked_mfma_decoder_parity(monkeypatch):
+    """demod_blk_kernel: split-float16 Toeplitz MFMAs for the five FIR chains, luma source added at the flush.  Same
+    goldens, same tolerance as the streaming kernel it is an alternative to."""
+    from oracle import cm_oracle
+    monkeypatch.setenv('CM_BLK', '1')
+    for name in ('frames_demod_pal_d', 'frames_demod_pal_d_noise_720x8', 'frames_demod_pal_d_noise_704x7'):
+        g = stacks.load(name)
+        im = image.ImageModem(stacks.make('pal_d', g['size']))
+        assert 'demod_blk_kernel' in im._engine().describe()
+        for i, f in enumerate(g['frames']):
+            out = im.demodulate_frames(g['inp'][i:i + 1], first_frame=int(f))[0]
+            assert stacks.rel_err(out, g['out'][i]) < TOL, (name, int(f))
+    modem = stacks.make('pal_d', (720, 576))
+    rgb = testing.synthetic_rgb(2, 576, 720, seed=4)
+    comp = cm_oracle.modulate_frames_f32(stacks.make('pal_s', (720, 576)), rgb, first_frame=6, n_threads=8)
+    got = image.ImageModem(modem).demodulate_frames(comp, first_frame=6)
+    want = cm_oracle.demodulate_frames_f32(modem, comp, first_frame=6, n_threads=8)
+    for err, bad, n in stacks.parity_report(got, want):
+        assert err < TOL and bad == 0, (err, bad)
