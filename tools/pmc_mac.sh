@@ -1,8 +1,10 @@
 #!/bin/bash
+set -euo pipefail
 # rocprofv3 kernel stats and FETCH / WRITE counters of the MAC kernels: tools/pmc_mac.sh <tag>  (on the GPU box)
-cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-OUT=gpurun_out/mac_$1
-rm -rf $OUT; mkdir -p $OUT
+ROOT="$(cd "$(dirname "$0")/.." && pwd)"      # the repository root, wherever the script is started from
+cd /tmp && export TMPDIR=/tmp && cd "$ROOT"
+OUT=gpurun_out/mac_${1:?tag}
+rm -rf "$OUT"; mkdir -p "$OUT"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python tools/quick_bench_mac.py 1000 > $OUT/stats.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/p1 -- python tools/quick_bench_mac.py 1000 > $OUT/p1.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/p2 -- python tools/quick_bench_mac.py 1000 > $OUT/p2.log 2>&1

@@ -1,8 +1,10 @@
 #!/bin/bash
+set -euo pipefail
 # usage: pmc_mem.sh <tag>  (CM_LIB may point at an experimental build)
-cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-OUT=gpurun_out/pmc_$1
-rm -rf $OUT; mkdir -p $OUT
+ROOT="$(cd "$(dirname "$0")/.." && pwd)"      # the repository root, wherever the script is started from
+cd /tmp && export TMPDIR=/tmp && cd "$ROOT"
+OUT=gpurun_out/pmc_${1:?tag}
+rm -rf "$OUT"; mkdir -p "$OUT"
 rocprofv3 --pmc FETCH_SIZE GRBM_GUI_ACTIVE --output-format csv -d $OUT/p3 -- python tools/quick_bench.py 1000 > $OUT/p3.log 2>&1
 rocprofv3 --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --output-format csv -d $OUT/p4 -- python tools/quick_bench.py 1000 > $OUT/p4.log 2>&1
 python - "$OUT" <<'PY'

@@ -1,6 +1,8 @@
 #!/bin/bash
+set -euo pipefail
 # Collect PMC counters for the PAL-D bench in separate passes (gpurun refuses --pmc with trace domains).
-cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+ROOT="$(cd "$(dirname "$0")/.." && pwd)"      # the repository root, wherever the script is started from
+cd /tmp && export TMPDIR=/tmp && cd "$ROOT"
 OUT=gpurun_out/pmc
 mkdir -p $OUT
 N=${1:-1000}
@@ -8,18 +10,5 @@ rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SA
 rocprofv3 --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_INST_CYCLES_SALU --output-format csv -d $OUT/p2 -- python tools/quick_bench.py $N > $OUT/p2.log 2>&1
 rocprofv3 --pmc FETCH_SIZE GRBM_GUI_ACTIVE --output-format csv -d $OUT/p3 -- python tools/quick_bench.py $N > $OUT/p3.log 2>&1
 rocprofv3 --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --output-format csv -d $OUT/p4 -- python tools/quick_bench.py $N > $OUT/p4.log 2>&1
-python tools/pmc_summary.py $2
-exit 0
-python - <<'PY'
-import csv, glob, collections
-for p in sorted(glob.glob('gpurun_out/pmc/p*/**/*counter_collection.csv', recursive=True)):
-    agg = collections.defaultdict(lambda: collections.defaultdict(list))
-    for r in csv.DictReader(open(p)):
-        agg[r['Kernel_Name'][:60]][r['Counter_Name']].append(float(r['Counter_Value']))
-    print(p)
-    for k, d in agg.items():
-        if 'demod_' not in k: continue
-        print('  ', k)
-        for c, v in d.items():
-            print('      %-22s n=%d  mean=%.4g' % (c, len(v), sum(v) / len(v)))
-PY
+python tools/pmc_summary.py ${2:-}
+# (tools/pmc_summary.py prints the per-kernel counter means of these passes)

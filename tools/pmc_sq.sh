@@ -1,7 +1,9 @@
 #!/bin/bash
-cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+set -euo pipefail
+ROOT="$(cd "$(dirname "$0")/.." && pwd)"      # the repository root, wherever the script is started from
+cd /tmp && export TMPDIR=/tmp && cd "$ROOT"
 OUT=gpurun_out/pmc_sq
-rm -rf $OUT; mkdir -p $OUT
+rm -rf "$OUT"; mkdir -p "$OUT"
 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_LDS SQ_INSTS_VMEM --output-format csv -d $OUT/p1 -- python tools/quick_bench.py 1000 > $OUT/p1.log 2>&1
 rocprofv3 --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_INST_CYCLES_SALU --output-format csv -d $OUT/p2 -- python tools/quick_bench.py 1000 > $OUT/p2.log 2>&1
 rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INST_LEVEL_VMEM SQ_INST_LEVEL_LDS SQ_INST_LEVEL_SMEM GRBM_GUI_ACTIVE --output-format csv -d $OUT/p3 -- python tools/quick_bench.py 1000 > $OUT/p3.log 2>&1

@@ -1,10 +1,12 @@
 #!/bin/bash
+set -euo pipefail
 # SQ counter passes on tools/quick_bench.py; usage: tools/pmc_sq2.sh TAG [CM_LIB path]
-TAG=$1
-[ -n "$2" ] && export CM_LIB=$2
-cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+TAG=${1:?tag}
+if [ -n "${2:-}" ]; then export CM_LIB=$2; fi
+ROOT="$(cd "$(dirname "$0")/.." && pwd)"      # the repository root, wherever the script is started from
+cd /tmp && export TMPDIR=/tmp && cd "$ROOT"
 OUT=gpurun_out/pmc_$TAG
-rm -rf $OUT; mkdir -p $OUT
+rm -rf "$OUT"; mkdir -p "$OUT"
 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_LDS SQ_INSTS_VMEM --output-format csv -d $OUT/p1 -- python tools/quick_bench.py 1000 > $OUT/p1.log 2>&1
 rocprofv3 --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_INST_CYCLES_SALU --output-format csv -d $OUT/p2 -- python tools/quick_bench.py 1000 > $OUT/p2.log 2>&1
 rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INST_LEVEL_VMEM SQ_INST_LEVEL_LDS SQ_INST_LEVEL_SMEM GRBM_GUI_ACTIVE --output-format csv -d $OUT/p3 -- python tools/quick_bench.py 1000 > $OUT/p3.log 2>&1

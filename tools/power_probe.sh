@@ -1,6 +1,8 @@
 #!/bin/bash
+set -euo pipefail
 # Board power and clocks while the headline kernel runs back to back (documentation of the clock give-back).
-cd $GRAFT_REPO_ROOT
+ROOT="$(cd "$(dirname "$0")/.." && pwd)"
+cd "$ROOT"
 rocm-smi --showmaxpower --showpower --showclocks 2>&1 | grep -E "Power|clock|Max" | head -12
 python tools/quick_bench_loop.py 6 > gpurun_out/power_loop.log 2>&1 &
 PID=$!

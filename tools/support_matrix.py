@@ -28,6 +28,7 @@ def stacks_for(system):
                 ('Pal3D', lambda lc, v: pal.Pal3DModem(lc, v)),
                 ('Simple(PalS)', lambda lc, v: comb.SimpleCombModem(pal.PalSModem(lc, v))),
                 ('Simple3D(PalD)', lambda lc, v: comb.Simple3DCombModem(pal.PalDModem(lc, v))),
+                ('Simple(Pal3D)', lambda lc, v: comb.SimpleCombModem(pal.Pal3DModem(lc, v))),
                 ('Avg(PalS)', lambda lc, v: comb.ColorAveragingModem(pal.PalSModem(lc, v)))]
     if system == 'ntsc':
         return [('Ntsc', lambda lc, v: ntsc.NtscModem(lc, v)),
@@ -83,6 +84,17 @@ def main():
                 for sname, make in stacks_for(system):
                     print('%-8s %-10s %-9s %-20s %s' % (system, vname, '%dx%d' % size, sname, try_pair(make, v, size)))
                     sys.stdout.flush()
+    # the amplitude-modulated line-sequential standards and D2-MAC (one variant each)
+    from color_modem_amd.color import mac, niir, protosecam
+    extra = [('ProtoSecam', (720, 736), lambda lc, v: protosecam.ProtoSecamModem(lc)),
+             ('Avg(ProtoSecam)', (720, 736), lambda lc, v: comb.ColorAveragingModem(protosecam.ProtoSecamModem(lc))),
+             ('Niir', (720, 576), lambda lc, v: niir.NiirModem(lc)),
+             ('HueCorrectingNiir', (720, 576), lambda lc, v: niir.HueCorrectingNiirModem(lc)),
+             ('Mac', (720, 576), lambda lc, v: mac.MacModem(lc)),
+             ('Avg(Mac)', (720, 576), lambda lc, v: comb.ColorAveragingModem(mac.MacModem(lc)))]
+    for sname, size, make in extra:
+        print('%-8s %-10s %-9s %-20s %s' % ('other', 'default', '%dx%d' % size, sname, try_pair(make, None, size)))
+        sys.stdout.flush()
 
 
 if __name__ == '__main__':
