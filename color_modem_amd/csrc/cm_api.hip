@@ -109,24 +109,23 @@ int launch_demod_blk(const Geom &gm, const void *km, const Geom &gf, const void 
     return CM_OK;
 }
 
-// Toeplitz tiles of y[t] = sum_j g[j] x[t - j] (g = the 20 odd taps of 2 h, symmetric) times kBlkScale, split into two
-// float16 pieces; layout: cm_blk_kernels.h: BlkTiles
+// Toeplitz operand of y[t] = sum_j g[j] x[t - j] (g = the 20 odd taps of 2 h, symmetric) times kBlkScale, split into two
+// float16 pieces; layout: cm_blk_fir.h: BlkTiles
 inline bool build_blk_tiles(const cm_plan_desc &d, void **out) {
-    std::vector<_Float16> t(64 * 6 * 8);
+    std::vector<_Float16> t(64 * 16);
     for (int l = 0; l < 64; ++l)
-        for (int c = 0; c < 3; ++c)
-            for (int j = 0; j < 8; ++j) {
-                const int tt = l & 31, s = 16 * c + 8 * (l >> 5) + j, kk = tt + 16 - s;
-                float v = 0.f;
-                if (kk >= 0 && kk < 20) {
-                    const int i = kk < 10 ? kk : 19 - kk;              // tap(I) = c[I < 10 ? I : 19 - I], c[i] = 2 h[2 i + 1]
-                    v = (float)(2.0 * d.resample_fir[2 * i + 1]) * kBlkScale;
-                }
-                const _Float16 hi = (_Float16)v;
-                const _Float16 lo = (_Float16)(v - (float)hi);
-                t[((size_t)l * 6 + c) * 8 + j] = hi;             // BlkTiles::hi[c]
-                t[((size_t)l * 6 + 3 + c) * 8 + j] = lo;         // BlkTiles::lo[c]
+        for (int j = 0; j < 8; ++j) {
+            const int kk = blk_tile_tap(l, j);
+            float v = 0.f;
+            if (kk >= 0) {
+                const int i = kk < 10 ? kk : 19 - kk;              // tap(I) = c[I < 10 ? I : 19 - I], c[i] = 2 h[2 i + 1]
+                v = (float)(2.0 * d.resample_fir[2 * i + 1]) * kBlkScale;
             }
+            const _Float16 hi = (_Float16)v;
+            const _Float16 lo = (_Float16)(v - (float)hi);
+            t[(size_t)l * 16 + j] = hi;             // BlkTiles::hi
+            t[(size_t)l * 16 + 8 + j] = lo;         // BlkTiles::lo
+        }
     if (hipMalloc(out, t.size() * sizeof(_Float16)) != hipSuccess) return false;
     return hipMemcpy(*out, t.data(), t.size() * sizeof(_Float16), hipMemcpyHostToDevice) == hipSuccess;
 }

@@ -1,175 +1,118 @@
 // cm_blk_kernels.h - time-blocked PAL delay-line decoder with the half-band FIRs on the matrix pipe (gfx950).
 //
 // Same arithmetic, same lane = scan line layout and the same per-sample schedule (stream indices, FilterFunction edges) as
-// the streaming decoder of cm_kernels.h / cm_stages.h, but a lane advances its line 32 samples at a time and holds the
+// the streaming decoder of cm_kernels.h / cm_stages.h, but a lane advances its line 16 samples at a time and holds the
 // block in registers:
-//   * the five 20-tap half-band FIR chains of the path (resample_poly up / down by 2) are Toeplitz products on
-//     v_mfma_f32_32x32x16_f16: time on M, the 64 lines of the wave on N in two halves, a 48-sample window on K.  Data and
-//     taps are split into two float16 pieces each (hi.hi + hi.lo + lo.hi, float32 accumulation; measured error 2.5e-7 of
-//     full scale, the same as the float32 fmaf chain: profiles/r02_ubench_mfma_f16_fir.txt); v_permlane32_swap moves a
-//     lane's samples into the operand layout and the results back.  Per chain and 32 samples: 18 MFMAs + about 100 vector
-//     instructions instead of 640 v_fma_f32;
+//   * the five 20-tap half-band FIR chains of the path (resample_poly up / down by 2) run on v_mfma_f32_16x16x32_f16 with
+//     their data operands staged through LDS (cm_blk_fir.h): per chain and 16 samples 12 MFMAs, 4 LDS stores, 8 LDS loads
+//     and about 60 vector instructions instead of 320 v_fma_f32;
 //   * the recursive filters walk the block sample by sample with their state in registers (the scalar / packed section
 //     code of cm_stages.h / cm_stages_pk.h);
-//   * one wavefront per 64 calls and ONE WAVE PER SIMD (the block and every filter state of a line need about 400 VGPRs):
-//     no hand-over, no barriers; the matrix pipe runs beside the vector pipe of the same wave;
-//   * the luma source sample x[n7] is not carried through the pipeline: the flush of an output tile re-reads the input row
-//     segment it covers (128-byte row segments, an L2 hit) and adds it, so no delay ring is needed and the output leaves as
-//     128-byte row segments.
-// Scales: every FIR runs on taps times kBlkScale (keeps the low float16 pieces of the small taps normal); the centre taps
-// carry the same factor, so stage outputs are kBlkScale^n times the streaming decoder's and the factor of the base pair
-// (kBlkScale^4) is divided out of the per-line combination coefficients when a lane loads them.
+//   * one wavefront per 64 calls, one wave per SIMD, no hand-over and no barriers;
+//   * the output tile is aligned to 16 samples (two outputs are carried to the next block), so a lane holds the 16 outputs
+//     of its row for each plane and stores them as 4 x 16 bytes into a one-plane LDS tile; the row-wise read-back adds the
+//     luma source (the same pixels of the input row, brought into LDS by global_load_lds at the start of the block) and
+//     stores 64-byte row segments.
+// LDS per wave: 6 operand slots (24 KiB) + input tile, luma tile, output tile (4 KiB each) = 36 KiB -> 4 waves per CU.
+// Scales: every FIR runs on taps times kBlkScale; the centre taps carry the same factor, so stage outputs are kBlkScale^n
+// times the streaming decoder's and the factor of the base pair (kBlkScale^4) is divided out of the per-line combination
+// coefficients when a lane loads them.
 #ifndef CM_BLK_KERNELS_H
 #define CM_BLK_KERNELS_H
 
 #include "cm_kernels.h"
+#include "cm_blk_fir.h"
 
 namespace cm {
 
-typedef _Float16 blk_h8 __attribute__((ext_vector_type(8)));
-typedef _Float16 blk_h2 __attribute__((ext_vector_type(2)));
-typedef float blk_f16v __attribute__((ext_vector_type(16)));
-typedef unsigned blk_u4 __attribute__((ext_vector_type(4)));
+// Development builds (-DCM_BLK_DIAG): cycles per stage of the interior block body, printed by one wave.
+#ifdef CM_BLK_DIAG
+#define CM_BLK_STAMP(i) do { if (!EDGE) { __builtin_amdgcn_sched_barrier(0); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); const unsigned long long now_ = __builtin_readcyclecounter(); diag_t[i] += now_ - diag_last; diag_last = now_; __builtin_amdgcn_sched_barrier(0); } } while (0)
+#else
+#define CM_BLK_STAMP(i) do { } while (0)
+#endif
 
-constexpr int kBlk = 32;                 // samples per block
-constexpr float kBlkScale = 1.f;         // taps enter the matrix pipe times this (the un-normalised sections of the recursive filters already lift the streams by 10 - 1000: a larger factor overflows float16 at the detector low-pass)
-
-// Toeplitz tiles of the 20-tap FIR y[t] = sum_j g[j] x[t - j] over the window [block start - 16, block start + 32):
-// k-step c, lane l (output t = l & 31, half h = l >> 5), element j: window sample s = 16 c + 8 h + j, tap index t + 16 - s.
-// [3 k-steps][hi, lo][64 lanes] fragments of 8 float16 = 6 KiB, built by the host (cm_api.hip: build_blk_tiles).
-struct BlkTiles {
-    blk_h8 hi[3], lo[3];
-};
-
-__device__ __forceinline__ blk_h8 blk_frag(unsigned a, unsigned b, unsigned c, unsigned d) {
-    blk_u4 v = {a, b, c, d};
-    return __builtin_bit_cast(blk_h8, v);
-}
-// two samples -> packed float16 high and low pieces
-__device__ __forceinline__ void blk_split2(float x0, float x1, unsigned &hi, unsigned &lo) {
-    const _Float16 h0 = (_Float16)x0, h1 = (_Float16)x1;
-    const _Float16 l0 = (_Float16)(x0 - (float)h0), l1 = (_Float16)(x1 - (float)h1);
-    blk_h2 ph = {h0, h1}, pl = {l0, l1};
-    hi = __builtin_bit_cast(unsigned, ph);
-    lo = __builtin_bit_cast(unsigned, pl);
-}
-
-// State of one FIR chain between blocks: the last k-step of the previous block in operand form and its samples 13 .. 15
-// (the 6 products that reach behind the 48-sample window are added on the vector pipe).
-struct BlkFir {
-    unsigned hi[8], lo[8];
-    float p13, p14, p15;
-    __device__ __forceinline__ void reset() {
+// Rows of a workgroup as 16-byte-unit offsets from a wave-uniform base: the lane that moves chunk (lane & 3) of row
+// lane / 4 + 16 q keeps that row's offset for q = 0 .. 3 (fetched once from the lane that owns the row).
+typedef __attribute__((address_space(1))) f4 blk_global_f4;
+struct BlkRows {
+    unsigned off[4];
+    __device__ __forceinline__ void init(const float *base, const float *mine, int lane) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) hi[i] = lo[i] = 0u;
-        p13 = p14 = p15 = 0.f;
-    }
-    // in[32] -> out[32] = kBlkScale * (FIR of the stream); g17 .. g19: the last three taps times kBlkScale
-    __device__ __forceinline__ void run(const float (&in)[kBlk], float (&out)[kBlk], const BlkTiles &tl, float g17, float g18, float g19) {
-        unsigned nhi[16], nlo[16];
-#pragma unroll
-        for (int i = 0; i < 16; ++i) blk_split2(in[2 * i], in[2 * i + 1], nhi[i], nlo[i]);
-        // operand form of the two new k-steps: registers [8 c .. 8 c + 3] <- lines 0-31, [8 c + 4 .. 8 c + 7] <- lines 32-63
-#pragma unroll
-        for (int c = 0; c < 2; ++c)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                auto r = __builtin_amdgcn_permlane32_swap(nhi[8 * c + i], nhi[8 * c + 4 + i], false, false);
-                nhi[8 * c + i] = r[0]; nhi[8 * c + 4 + i] = r[1];
-                auto q = __builtin_amdgcn_permlane32_swap(nlo[8 * c + i], nlo[8 * c + 4 + i], false, false);
-                nlo[8 * c + i] = q[0]; nlo[8 * c + 4 + i] = q[1];
-            }
-        blk_f16v dl, dh;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) dl[i] = dh[i] = 0.f;
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            const unsigned *wh = c == 0 ? hi : nhi + 8 * (c - 1), *wl = c == 0 ? lo : nlo + 8 * (c - 1);
-            const blk_h8 l_hi = blk_frag(wh[0], wh[1], wh[2], wh[3]), l_lo = blk_frag(wl[0], wl[1], wl[2], wl[3]);
-            const blk_h8 u_hi = blk_frag(wh[4], wh[5], wh[6], wh[7]), u_lo = blk_frag(wl[4], wl[5], wl[6], wl[7]);
-            dl = __builtin_amdgcn_mfma_f32_32x32x16_f16(tl.lo[c], l_hi, dl, 0, 0, 0);
-            dh = __builtin_amdgcn_mfma_f32_32x32x16_f16(tl.lo[c], u_hi, dh, 0, 0, 0);
-            dl = __builtin_amdgcn_mfma_f32_32x32x16_f16(tl.hi[c], l_lo, dl, 0, 0, 0);
-            dh = __builtin_amdgcn_mfma_f32_32x32x16_f16(tl.hi[c], u_lo, dh, 0, 0, 0);
-            dl = __builtin_amdgcn_mfma_f32_32x32x16_f16(tl.hi[c], l_hi, dl, 0, 0, 0);
-            dh = __builtin_amdgcn_mfma_f32_32x32x16_f16(tl.hi[c], u_hi, dh, 0, 0, 0);
+        for (int q = 0; q < 4; ++q) {
+            const float *r = ptr_from((lane / 4 + 16 * q) * 4, mine);
+            off[q] = r ? (unsigned)((r - base) >> 2) : 0xffffffffu;
         }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            // (clang folds __builtin_bit_cast of a vector ELEMENT expression to element 0: go through scalars)
-            const float lo_f = dl[r], hi_f = dh[r];
-            auto s = __builtin_amdgcn_permlane32_swap(__float_as_uint(lo_f), __float_as_uint(hi_f), false, false);
-            const int t = (r & 3) + 8 * (r >> 2);
-            out[t] = __uint_as_float(s[0]);
-            out[t + 4] = __uint_as_float(s[1]);
-        }
-        out[0] = __builtin_fmaf(g17, p15, __builtin_fmaf(g18, p14, __builtin_fmaf(g19, p13, out[0])));
-        out[1] = __builtin_fmaf(g18, p15, __builtin_fmaf(g19, p14, out[1]));
-        out[2] = __builtin_fmaf(g19, p15, out[2]);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) { hi[i] = nhi[8 + i]; lo[i] = nlo[8 + i]; }
-        p13 = in[13]; p14 = in[14]; p15 = in[15];
     }
 };
 
-struct BlkArgs {
-    Geom g;
-    const BlkTiles *tiles;      // [64 lanes]
-};
+// Tile c (samples 16 c .. 16 c + 15 of the 64 rows) straight into LDS, [row][16] floats.
+__device__ __forceinline__ void blk_fill(const Geom &g, lds_float *tile, const float *base, const BlkRows &rows, int c, int lane) {
+    int col = kBlk * c + 4 * (lane & 3);
+    if (col > g.Wp - 4) col = g.Wp - 4;  // never read past the (pitched) row; such samples are masked by the consumer
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const blk_global_f4 *src = (const blk_global_f4 *)base + rows.off[q] + (col >> 2);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                         (__attribute__((address_space(3))) void *)(tile + q * 256), 16, 0, 0);
+    }
+}
 
-// Row-wise read-back of the 32-sample output tile: 8 rows x 128 bytes per wave-instruction, with the luma source row segment
-// of the same pixels re-read from the input and added (m_y[p] = luma column of the colour matrix).
-__device__ __forceinline__ void blk_flush(const Geom &g, const lds_float *otile, const float *op, const float *xp, int first_col, int lane,
-                                          float my0, float my1, float my2) {
+// One plane of the 16-sample output tile: own row in (4 x ds_write_b128, chunks XOR-swizzled like flush_tile's), rows out
+// as 64-byte segments with the luma source added.  o[16]: this lane's outputs; xl[q]: the luma source of (row, chunk) =
+// (lane / 4 + 16 q, lane & 3); my: the luma column of the colour matrix for this plane.
+__device__ __forceinline__ void blk_store_plane(const Geom &g, lds_float *otile, float *plane, const BlkRows &rows, const float (&o)[kBlk],
+                                                const f4 (&xl)[4], float my, int first_col, int lane) {
+    constexpr int kChunks = kBlk / 4, kRows = 64 / kChunks;
+    lds_float *mine = otile + lane * kBlk;
+    const int sw = (lane >> CM_TILE_SWZ) & (kChunks - 1);
+#pragma unroll
+    for (int c = 0; c < kChunks; ++c) *(lds_f4 *)(mine + 4 * (c ^ sw)) = f4{o[4 * c], o[4 * c + 1], o[4 * c + 2], o[4 * c + 3]};
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    constexpr int kTile = kBlk, kChunks = kTile / 4, kRows = 64 / kChunks;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     const int chunk = lane & (kChunks - 1);
     const int col = first_col + 4 * chunk;
-#pragma nounroll
+#pragma unroll
     for (int q = 0; q < kChunks; ++q) {
         const int row = lane / kChunks + kRows * q;
-        typedef __attribute__((address_space(1))) f4 global_f4;
-        global_f4 *dst = (global_f4 *)(unsigned long long)ptr_from(row * 4, op);
-        const f4 *src = (const f4 *)ptr_from(row * 4, xp);
         const int quad = chunk ^ ((row >> CM_TILE_SWZ) & (kChunks - 1));
-        if (dst != nullptr && col < g.Wp) {
-            const f4 x = src[col >> 2];
-            dst += col >> 2;
-            f4 v0 = *(const lds_f4 *)(otile + 0 * 64 * kTile + row * kTile + 4 * quad);
-            f4 v1 = *(const lds_f4 *)(otile + 1 * 64 * kTile + row * kTile + 4 * quad);
-            f4 v2 = *(const lds_f4 *)(otile + 2 * 64 * kTile + row * kTile + 4 * quad);
-            v0 += my0 * x;
-            v1 += my1 * x;
-            v2 += my2 * x;
-            __builtin_nontemporal_store(v0, &dst[0]);
-            __builtin_nontemporal_store(v1, &dst[g.out_plane_stride >> 2]);
-            __builtin_nontemporal_store(v2, &dst[(2 * g.out_plane_stride) >> 2]);
-        }
+        f4 v = *(const lds_f4 *)(otile + row * kBlk + 4 * quad);
+        v += my * xl[q];
+        if (rows.off[q] != 0xffffffffu && col < g.Wp)
+            __builtin_nontemporal_store(v, (blk_global_f4 *)plane + rows.off[q] + (col >> 2));
     }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
 }
 
 // S: the tuned filter shape (even shifts of the band-pass and the detector low-pass: PAL-BG).  PAL-D front end, one line of
 // history (the comb), plain luma strip by re-modulation; no notch, no minavg, float32 rows whose width is a multiple of 4.
-// QE, QL: the pair delays of the band-pass and of the detector low-pass (compile-time here: the aligned flush of the output
-// tile falls on one fixed sample of a block; the host checks them against the plan).
+// QE, QL: the pair delays of the band-pass and of the detector low-pass (compile-time here: they fix how many outputs a
+// block carries over to the next output tile; the host checks them against the plan).
 template <class S, int QE, int QL>
 __global__ __launch_bounds__(64, 1) void demod_blk_kernel(const PassArgs<S> args, const BlkTiles *tiles) {
     static_assert(!S::ODD_E && !S::ODD_L && !S::RT, "the blocked decoder is built for the tuned even-shift shapes");
     typedef DemodK<float, S> K;
     constexpr int SP = S::SP, DEPTH = 1;
-    __shared__ __attribute__((aligned(16))) float lds_store[64 * kBlk + 3 * 64 * kBlk];
-    lds_float *itile = (lds_float *)lds_store;
-    lds_float *otile_base = itile + 64 * kBlk;
+    __shared__ __attribute__((aligned(16))) float lds_store[kBlkSlots * kBlkSlotBytes / 4 + 3 * 64 * kBlk];
+    blk_lds_byte *ops = (blk_lds_byte *)lds_store;
+    lds_float *itile = (lds_float *)lds_store + kBlkSlots * kBlkSlotBytes / 4;
+    lds_float *ltile = itile + 64 * kBlk;
+    lds_float *otile = ltile + 64 * kBlk;
     const Geom &g = args.g;
     const K &k = args.k;
     const int lane = threadIdx.x;
     const LaneCall lc = locate_call(g, blockIdx.x, DEPTH, lane);
     const float *xp = g.in + lc.frame * g.in_frame_stride + (long long)lc.src_row * g.Wp;
-    // luma source row of the flush: the own row, or the previous call's where the plan says so (cm_kernels.h: run_pair)
+    // luma source row: the own row, or the previous call's where the plan says so (cm_kernels.h: run_pair)
     const float *lp = g.in + lc.frame * g.in_frame_stride +
                       (long long)(((g.luma_prev_bits >> lc.regime) & 1) ? lc.prev_row : lc.src_row) * g.Wp;
     const float *op = lc.store_ok ? g.out + lc.frame * g.out_frame_stride + (long long)lc.out_row * g.out_row_stride : nullptr;
+    BlkRows xrows, lrows, orows;
+    xrows.init(g.in, xp, lane);
+    lrows.init(g.in, lp, lane);
+    orows.init(g.out, op, lane);
     StageBK<S> kb;
     kb.load(k);
     LaneKPk lk;
@@ -184,6 +127,11 @@ __global__ __launch_bounds__(64, 1) void demod_blk_kernel(const PassArgs<S> args
     }
     const int idx1 = ((lane + 63) & 63) * 4;
     const BlkTiles tl = tiles[lane];
+    BlkAddr ad;
+    ad.init(lane);
+    BlkSlots sl;
+    sl.init();
+    for (int i = lane * 16; i < kBlkSlots * kBlkSlotBytes; i += 64 * 16) *(blk_lds_u4 *)(ops + i) = (blk_u4){0u, 0u, 0u, 0u};
     // taps: g[j] = c[j < 10 ? j : 19 - j]; the products behind the window use g[17 .. 19] = c[2], c[1], c[0]
     const float g17 = kBlkScale * k.taps.c[2], g18 = kBlkScale * k.taps.c[1], g19 = kBlkScale * k.taps.c[0];
     const float c0s = kBlkScale * k.taps.c0;      // centre tap of the scaled chains
@@ -211,8 +159,6 @@ __global__ __launch_bounds__(64, 1) void demod_blk_kernel(const PassArgs<S> args
     FrontLatch<float> fla;
     fla.reset();
     pf2 p_last = {0.f, 0.f}, uv_last = {0.f, 0.f};
-    lds_float *otile = otile_base + lane * kBlk;
-    const int wpos = ((lane >> CM_TILE_SWZ) & (kBlk / 4 - 1)) << 2;
 
     // ---- stream geometry (cm_kernels.h: run_pair) --------------------------------------------------------------------------
     const int W = g.W, Wp = g.Wp;
@@ -220,19 +166,33 @@ __global__ __launch_bounds__(64, 1) void demod_blk_kernel(const PassArgs<S> args
     constexpr int front_off = 10 + q_e + 9 + 10;        // detector pair index nd = t - front_off
     constexpr int lat_front = front_off + q_l + 9;
     constexpr int lat_out = lat_front + 1 + SP;         // n7 = t - lat_out
-    const int T = (Wp + lat_out + kBlk - 1) & ~(kBlk - 1);
-    // interior blocks: tb >= lat_out keeps every stage index >= 0, tb + 31 <= W - 2 keeps them below every end-of-row latch
-    int t_mid0 = (lat_out + kBlk - 1) & ~(kBlk - 1), t_mid1 = W >= kBlk + 1 ? ((W - kBlk - 1) & ~(kBlk - 1)) + kBlk : 0;
+    constexpr int kCarry = (kBlk - (lat_out & (kBlk - 1))) & (kBlk - 1);   // outputs of a block that belong to the next output tile
+    constexpr int lat_tile = lat_out + kCarry;          // the tile flushed in block tb starts at tb - lat_tile
+    static_assert(kCarry <= 4, "more carried outputs than the kernel is laid out for");
+    float cr[kCarry > 0 ? kCarry : 1], cg[kCarry > 0 ? kCarry : 1], cb[kCarry > 0 ? kCarry : 1];
+#pragma unroll
+    for (int j = 0; j < (kCarry > 0 ? kCarry : 1); ++j) cr[j] = cg[j] = cb[j] = 0.f;
+    const int T = ((Wp - 1) & ~(kBlk - 1)) + lat_tile + kBlk;
+    // interior blocks: tb >= lat_tile keeps every stage index >= 0, tb + 15 <= W - 2 keeps them below every end-of-row latch
+    int t_mid0 = lat_tile, t_mid1 = W >= kBlk + 1 ? ((W - kBlk - 1) & ~(kBlk - 1)) + kBlk : 0;
     if (t_mid1 < t_mid0) t_mid0 = t_mid1 = 0;          // short rows: the guarded body runs everything
 
     const lds_float *xrow = itile + lane * kBlk;
-    fill_tile<kBlk>(g, itile, xp, 0, lane);
+    blk_fill(g, itile, g.in, xrows, 0, lane);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
+#ifdef CM_BLK_DIAG
+    unsigned long long diag_t[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, diag_last = 0;
+    int diag_n = 0;
+#endif
     auto block = [&](auto edge_tag, int tb) __attribute__((always_inline)) {
         constexpr bool EDGE = decltype(edge_tag)::value;
-        // ---- this block's input samples; the tile is refilled for the next block right away
+#ifdef CM_BLK_DIAG
+        if (!EDGE) { diag_last = __builtin_readcyclecounter(); ++diag_n; }
+#endif
+        // ---- this block's input samples; the tile is refilled for the next block right away, the luma tile for this block's flush
+        // (the tile is complete: every block waits for its fills before it stores)
         float xs[kBlk];
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int q = 0; q < kBlk / 4; ++q) {
@@ -246,11 +206,16 @@ __global__ __launch_bounds__(64, 1) void demod_blk_kernel(const PassArgs<S> args
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_wave_barrier();
-        if (tb + kBlk < W) fill_tile<kBlk>(g, itile, xp, (tb >> 5) + 1, lane);
+        if (!EDGE || tb + kBlk < W) blk_fill(g, itile, g.in, xrows, tb / kBlk + 1, lane);
+        const int tile0 = tb - lat_tile;                 // first column of the output tile this block completes
+        if (!EDGE || (tile0 >= 0 && tile0 < Wp)) blk_fill(g, ltile, g.in, lrows, tile0 / kBlk, lane);
 
+        CM_BLK_STAMP(0);
         // ---- up2(x): odd phase on the matrix pipe, even phase = centre tap of x[t - 10]
         float ao[kBlk];
-        fx.run(xs, ao, tl, g17, g18, g19);
+        fx.run(xs, ao, tl, g17, g18, g19, ops, ad, sl);
+        sl.next();
+        CM_BLK_STAMP(1);
         float bo[kBlk], be[kBlk];
 #pragma unroll
         for (int s = 0; s < kBlk; ++s) {
@@ -271,9 +236,12 @@ __global__ __launch_bounds__(64, 1) void demod_blk_kernel(const PassArgs<S> args
         }
 #pragma unroll
         for (int j = 0; j < 10; ++j) xh[j] = xs[kBlk - 10 + j];
+        CM_BLK_STAMP(2);
         // ---- dn2 -> e
         float ev[kBlk];
-        fb.run(bo, ev, tl, g17, g18, g19);
+        fb.run(bo, ev, tl, g17, g18, g19, ops, ad, sl);
+        sl.next();
+        CM_BLK_STAMP(3);
 #pragma unroll
         for (int s = 0; s < kBlk; ++s) {
             ev[s] = __builtin_fmaf(c0s, s < 9 ? beh[s] : be[s - 9], ev[s]);
@@ -286,7 +254,9 @@ __global__ __launch_bounds__(64, 1) void demod_blk_kernel(const PassArgs<S> args
         for (int j = 0; j < 9; ++j) beh[j] = be[kBlk - 9 + j];
         // ---- up2(e): the pair the product detectors multiply
         float mo[kBlk];
-        fe.run(ev, mo, tl, g17, g18, g19);
+        fe.run(ev, mo, tl, g17, g18, g19, ops, ad, sl);
+        sl.next();
+        CM_BLK_STAMP(4);
         // ---- detectors: products with the phase-free carriers, low-pass on the pair (cos, sin)
         pf2 qe[kBlk];
         float qoc[kBlk], qos[kBlk];
@@ -315,46 +285,78 @@ __global__ __launch_bounds__(64, 1) void demod_blk_kernel(const PassArgs<S> args
         }
 #pragma unroll
         for (int j = 0; j < 10; ++j) eh[j] = ev[kBlk - 10 + j];
+        CM_BLK_STAMP(5);
         // ---- dn2 of both channels -> the line's base pair
         float rc[kBlk], rs[kBlk];
-        fqc.run(qoc, rc, tl, g17, g18, g19);
-        fqs.run(qos, rs, tl, g17, g18, g19);
+        fqc.run(qoc, rc, tl, g17, g18, g19, ops, ad, sl);
+        sl.next();
+        fqs.run(qos, rs, tl, g17, g18, g19, ops, ad, sl);
+        sl.next();
+        CM_BLK_STAMP(6);
         // ---- back end: comb combination with the neighbouring lane's pair, pre-correction low-pass, re-modulation, matrix.
-        // As in the streaming decoder it handles the base pair of the step before (n6 = t - lat_front - 1).
+        // As in the streaming decoder it handles the base pair of the step before (n6 = t - lat_front - 1).  Outputs land in
+        // tile registers: positions 0 .. kCarry - 1 come from the previous block.
+        pf2 bases[kBlk], nbs[kBlk];
+#pragma unroll
+        for (int s = 0; s < kBlk; ++s) {
+            const pf2 qc = s < 9 ? qeh[s] : qe[s - 9];
+            bases[s] = pf2{__builtin_fmaf(c0s, qc.x, rc[s]), __builtin_fmaf(c0s, qc.y, rs[s])};
+            nbs[s] = pf2{lane_from(idx1, bases[s].x), lane_from(idx1, bases[s].y)};     // 32 exchanges in flight, one wait
+        }
+        CM_BLK_STAMP(7);
+        float o_r[kBlk], o_g[kBlk], o_b[kBlk];
+#pragma unroll
+        for (int j = 0; j < kCarry; ++j) { o_r[j] = cr[j]; o_g[j] = cg[j]; o_b[j] = cb[j]; }
 #pragma unroll
         for (int s = 0; s < kBlk; ++s) {
             const int t = tb + s;
-            const pf2 qc = s < 9 ? qeh[s] : qe[s - 9];
-            const pf2 base = pf2{__builtin_fmaf(c0s, qc.x, rc[s]), __builtin_fmaf(c0s, qc.y, rs[s])};
-            const pf2 nb = pf2{lane_from(idx1, base.x), lane_from(idx1, base.y)};
+            const pf2 base = bases[s], nb = nbs[s];
             const int n6 = t - lat_front - 1, n7 = n6 - SP;
             const pf2 uv = back.combine(lk, base_c, nb_c, nb_c);
             base_c = base;
             nb_c = nb;
             int ci = n7;
             if (EDGE) ci = n7 < 0 ? 0 : (n7 > W - 1 ? W - 1 : n7);
-            const f2 cb = ((const_f2 *)g.carrier2)[ci];
-            const pf2 sc = back.remod(lk, pf2{cb.x, cb.y});
+            const f2 cb2 = ((const_f2 *)g.carrier2)[ci];
+            const pf2 sc = back.remod(lk, pf2{cb2.x, cb2.y});
             const pf2 uv_d = SP > 0 ? uvd[SP > 0 ? SP - 1 : 0] : uv;
             const Rgb<float> o = back.template step<EDGE>(k, kb, lk, uv_last, n6, uv, uv_d, 0.f, sc);   // the luma source joins at the flush
 #pragma unroll
             for (int j = SP - 1; j > 0; --j) uvd[j] = uvd[j - 1];
             if (SP > 0) uvd[0] = uv;
-            if (!EDGE || (n7 >= 0 && n7 < W)) put_rgb<false, kBlk>(otile, wpos, n7, o);
-            if (((s - lat_out) & (kBlk - 1)) == kBlk - 1 && n7 >= 0)      // one fixed sample of a block completes an output tile
-                blk_flush(g, otile_base, op, lp, n7 & ~(kBlk - 1), lane, my0, my1, my2);
+            if (s + kCarry < kBlk) { o_r[s + kCarry] = o.r; o_g[s + kCarry] = o.g; o_b[s + kCarry] = o.b; }
+            else { cr[s + kCarry - kBlk] = o.r; cg[s + kCarry - kBlk] = o.g; cb[s + kCarry - kBlk] = o.b; }
         }
 #pragma unroll
         for (int j = 0; j < 9; ++j) qeh[j] = qe[kBlk - 9 + j];
+        CM_BLK_STAMP(8);
+        // ---- the output tile [tile0, tile0 + 16) of all 64 rows.  The fills of this block have landed before its stores go
+        // out, so the next block never waits behind stores.
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        if (!EDGE || (tile0 >= 0 && tile0 < Wp)) {
+            f4 xl[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) xl[q] = *(const lds_f4 *)(ltile + q * 256 + 4 * lane);
+            blk_store_plane(g, otile, g.out, orows, o_r, xl, my0, tile0, lane);
+            blk_store_plane(g, otile, g.out + g.out_plane_stride, orows, o_g, xl, my1, tile0, lane);
+            blk_store_plane(g, otile, g.out + 2 * g.out_plane_stride, orows, o_b, xl, my2, tile0, lane);
+        }
+        CM_BLK_STAMP(9);
     };
 
-    // one loop, two bodies (each body is some 5000 instructions: a third copy would not fit the instruction cache at all)
+    // one loop, two bodies
 #pragma nounroll
     for (int tb = 0; tb < T; tb += kBlk) {
         if (tb >= t_mid0 && tb < t_mid1) block(std::false_type(), tb);
         else block(std::true_type(), tb);
     }
-    if (Wp & (kBlk - 1)) blk_flush(g, otile_base, op, lp, Wp & ~(kBlk - 1), lane, my0, my1, my2);     // the row's last, partial tile
+#ifdef CM_BLK_DIAG
+    if (blockIdx.x == 4000 && lane == 0)
+        printf("blk diag: %d interior blocks; cycles per block: in %llu | fx %llu | bp %llu | fb %llu | fe %llu | det %llu | fq %llu | nb %llu | back %llu | flush %llu\n", diag_n,
+               diag_t[0] / diag_n, diag_t[1] / diag_n, diag_t[2] / diag_n, diag_t[3] / diag_n, diag_t[4] / diag_n, diag_t[5] / diag_n, diag_t[6] / diag_n,
+               diag_t[7] / diag_n, diag_t[8] / diag_n, diag_t[9] / diag_n);
+#endif
 }
 
 }  // namespace cm
