@@ -34,9 +34,26 @@ struct SecamDemodArgs {
 #ifndef CM_SECAM_TILE
 #define CM_SECAM_TILE 32
 #endif
+// 1: the interior bodies run their four steps stage by stage and take the eight phase steps together - one wave-uniform
+// branch to the library atan2f per body instead of one per phase step
+#ifndef CM_SECAM_BATCH_ANGLES
+#define CM_SECAM_BATCH_ANGLES 1
+#endif
+// samples per row of the float output tile (16: 64-byte row segments, 12 KiB; 8: 32-byte segments, 6 KiB)
+#ifndef CM_SECAM_OUT_TILE
+#define CM_SECAM_OUT_TILE 16
+#endif
+// samples per input tile row of the float32 wave pair
+#ifndef CM_SECAM_PAIR_IN_TILE
+#define CM_SECAM_PAIR_IN_TILE 16
+#endif
+// bodies (of 4 steps) the luma samples of the second row visit are asked for ahead of their use
+#ifndef CM_SECAM_LUMA_AHEAD
+#define CM_SECAM_LUMA_AHEAD 1
+#endif
 template <bool U8>
 __global__ __launch_bounds__(64, CM_SECAM_WAVES) void secam_demod_kernel(const SecamDemodArgs args) {
-    constexpr int kTile = 16, DEPTH = 1;
+    constexpr int kTile = U8 ? 16 : CM_SECAM_OUT_TILE, DEPTH = 1;
     constexpr int kIT = U8 ? kInTile : CM_SECAM_TILE;      // samples per input tile row (byte tiles stay 32 wide)
     constexpr int kIn = 64 * kIT;                           // floats (U8: bytes)
     __shared__ __attribute__((aligned(16))) float lds_store[U8 ? (kIn + 3 * 64 * kTile) / 4 : kIn + 3 * 64 * kTile];
@@ -149,6 +166,9 @@ __global__ __launch_bounds__(64, CM_SECAM_WAVES) void secam_demod_kernel(const S
     const int T = (g.Wp + lat_out + 3) & ~3;
     f4 xv = read_x(0);
     f4 nl = read_luma(-d_luma);
+#if CM_SECAM_LUMA_AHEAD == 2
+    f4 nl2 = read_luma(4 - d_luma);
+#endif
     // Interior bodies: every stage index of the four steps m = P + xb .. + 3 lies strictly inside its stream - the first
     // output sample n = m - 1 - lat is >= 0 (so is every earlier stage's index) and the last input index m + 3 stays below
     // the end-of-row latch at Lc - 1 (so does every later stage's, which run behind it).
@@ -156,17 +176,71 @@ __global__ __launch_bounds__(64, CM_SECAM_WAVES) void secam_demod_kernel(const S
     if (xb_mid0 < 0) xb_mid0 = 0;
     if (xb_mid1 <= xb_mid0) xb_mid0 = xb_mid1 = 0;
     auto body = [&](auto edge_tag, int xb) __attribute__((always_inline)) {   // (not inlined, the line's state would live in scratch memory)
+        constexpr bool EDGE = decltype(edge_tag)::value;
         const f4 lw = nl;
+#if CM_SECAM_LUMA_AHEAD == 2
+        nl = nl2;
+        nl2 = read_luma(xb + 8 - d_luma);
+#else
         nl = read_luma(xb + 4 - d_luma);
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            step(edge_tag, P + xb + s, xv[s], lw[s], s);
+#endif
+        auto flush_after = [&](int s) {
             if (s == s_flush) {
                 const int n = xb + s - lat_out;
                 if (n >= 0 && ((n & (kTile - 1)) == kTile - 1 || n == g.Wp - 1)) {
                     if (U8) flush_tile_u8(g, otile_base, op, n & ~(kTile - 1), lane);
                     else flush_tile<kTile>(g, otile_base, op, n & ~(kTile - 1), lane);
                 }
+            }
+        };
+        if (EDGE || !CM_SECAM_BATCH_ANGLES) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                step(edge_tag, P + xb + s, xv[s], lw[s], s);
+                flush_after(s);
+            }
+        } else {
+            // interior: the four steps stage by stage, so that their eight phase steps share one branch to the library atan2f
+            const int m0 = P + xb;
+            pf2 y0[4], y1[4];
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const f4 c = ((const_f4 *)g.carrier4)[m0 + s - k.s_b - 10];
+                float ch_out;
+                st.chroma_front_mid(k, kp, xv[s], chw[s], pf2{c.x, c.y}, pf2{c.z, c.w}, ch_out, y0[s], y1[s]);
+                chw[10 + s] = ch_out;
+            }
+            PhaseStep pe[4], po[4];
+            bool all_small = true;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const pf2 prev = s == 0 ? st.iq_prev : y1[s - 1];
+                pe[s].set(prev.x, prev.y, y0[s].x, y0[s].y);
+                po[s].set(y0[s].x, y0[s].y, y1[s].x, y1[s].y);
+                all_small = all_small && pe[s].small() && po[s].small();
+            }
+            st.iq_prev = y1[3];
+            st.have_prev = 1;
+            float d_e[4], d_o[4];
+            if (__builtin_expect(__builtin_amdgcn_ballot_w64(!all_small) == 0ull, 1)) {
+#pragma unroll
+                for (int s = 0; s < 4; ++s) { d_e[s] = pe[s].series(); d_o[s] = po[s].series(); }
+            } else {
+#pragma unroll
+                for (int s = 0; s < 4; ++s) { d_e[s] = pe[s].full(); d_o[s] = po[s].full(); }
+            }
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const int m = m0 + s;
+                const float dc = ((const __attribute__((address_space(4))) float *)g.carrier2)[m - lat + P];
+                const float own = st.chroma_back_mid(k, lk, d_e[s], d_o[s], dc);
+                const int n = m - 1 - lat;
+                const float luma = st.template luma_step<false>(k, n, lw[s]);
+                const Rgb<float> o = st.finish(k, lk, luma, own_prev, nb_prev);
+                own_prev = own;
+                nb_prev = lane_from(idx1, own);
+                put_rgb<U8, kTile>(otile, wpos, n, o);
+                flush_after(s);
             }
         }
         shift_window();
@@ -203,14 +277,26 @@ __global__ __launch_bounds__(64, CM_SECAM_WAVES) void secam_demod_kernel(const S
 #ifndef CM_SECAM_PAIR
 #define CM_SECAM_PAIR 0
 #endif
+// 1: both stages run the interior bodies of a row without guards (float32 stage A; the float64 stage A keeps them)
+#ifndef CM_SECAM_PAIR_MID
+#define CM_SECAM_PAIR_MID 1
+#endif
 // 1: the shapes whose float32 margin is thin (cm_api.hip: create_secam) run on the wave pair with stage A in float64
 #ifndef CM_SECAM_F64
 #define CM_SECAM_F64 1
 #endif
-constexpr int kSecamMid = 2 * 4 * 256;        // floats: [buffer][I0 | Q0 | I1 | Q1][lane][4 steps]
+#ifndef CM_SECAM_PAIR_LDS_PAD      /* occupancy experiments: unused floats of LDS per workgroup */
+#define CM_SECAM_PAIR_LDS_PAD 0
+#endif
+// hand-over buffers of the wave pair: 2 = stage A fills one while B reads the other (one barrier per body); 1 = a second
+// barrier per body (B has read) instead of the second buffer: 4 KiB less LDS
+#ifndef CM_SECAM_PAIR_MID_BUFS
+#define CM_SECAM_PAIR_MID_BUFS 2
+#endif
+constexpr int kSecamMid = CM_SECAM_PAIR_MID_BUFS * 4 * 256;        // floats: [buffer][I0 | Q0 | I1 | Q1][lane][4 steps]
 constexpr int kSecamPairMaxLumaDelay = 4 + 4 * 14 + 3;   // delay ring of at most 16 blocks of [lane][4 samples]
 template <bool U8> constexpr int secam_pair_lds_floats(int d_luma) {
-    return (U8 ? 64 * kInTile / 4 : 64 * 16) + kSecamMid + (U8 ? 64 * 3 * 16 / 4 : 3 * 64 * 16) + (((d_luma - 4) >> 2) + 2) * 256;
+    return (U8 ? 64 * kInTile / 4 : 64 * CM_SECAM_PAIR_IN_TILE) + kSecamMid + (U8 ? 64 * 3 * 16 / 4 : 3 * 64 * CM_SECAM_OUT_TILE) + (((d_luma - 4) >> 2) + 2) * 256 + CM_SECAM_PAIR_LDS_PAD;
 }
 
 struct SecamDemodArgs64 {
@@ -223,8 +309,12 @@ struct SecamDemodArgs64 {
 template <bool U8, bool F64, class Args>
 __device__ __forceinline__ void secam_demod_pair_body(const Args &args_in);
 
+// waves per SIMD the register allocation of the float32 pair aims at (3: <= 168 VGPRs)
+#ifndef CM_SECAM_PAIR_WAVES
+#define CM_SECAM_PAIR_WAVES 2
+#endif
 template <bool U8>
-__global__ __launch_bounds__(128, 2) void secam_demod_pair_kernel(const SecamDemodArgs args) {
+__global__ __launch_bounds__(128, CM_SECAM_PAIR_WAVES) void secam_demod_pair_kernel(const SecamDemodArgs args) {
     secam_demod_pair_body<U8, false>(args);
 }
 template <bool U8>
@@ -243,8 +333,8 @@ template <> struct SecamPairArgs<true> {
 template <bool U8, bool F64, class Args>
 __device__ __forceinline__ void secam_demod_pair_body(const Args &args_in) {
     const SecamDemodArgs &args = SecamPairArgs<F64>::base(args_in);
-    constexpr int kTile = 16, DEPTH = 1;
-    constexpr int kIT = U8 ? kInTile : 16;                                   // samples per input tile row
+    constexpr int kTile = U8 ? 16 : CM_SECAM_OUT_TILE, DEPTH = 1;
+    constexpr int kIT = U8 ? kInTile : CM_SECAM_PAIR_IN_TILE;                // samples per input tile row
     constexpr int kIn = U8 ? 64 * kInTile / 4 : 64 * kIT, kOut = U8 ? 64 * 3 * kTile / 4 : 3 * 64 * kTile;   // floats
     extern __shared__ __attribute__((aligned(16))) float secam_pair_lds[];   // kIn + kSecamMid + kOut + blocks * 256 floats
     lds_float *itile = (lds_float *)secam_pair_lds;
@@ -272,6 +362,11 @@ __device__ __forceinline__ void secam_demod_pair_body(const Args &args_in) {
     // A writes x[xb - 4 - lr_o .. + 3] (out of the samples of its last two bodies); B reads it lr_m bodies later
     const int lr_o = (d_luma - 4) & 3, lr_m = (d_luma - 4) >> 2;
     const int n_blocks = lr_m + 2;                          // delay ring blocks (the host sizes the LDS with the same number)
+    // interior bodies (secam_demod_kernel): every stage index of the four steps lies strictly inside its stream
+    int xb_mid0 = (lat + 1 - P + 3) & ~3, xb_mid1 = (W - 8) & ~3;
+    if (xb_mid0 < 0) xb_mid0 = 0;
+    if (xb_mid1 <= xb_mid0) xb_mid0 = xb_mid1 = 0;
+    const int b_mid0 = n_pre + (xb_mid0 >> 2), b_mid1 = n_pre + (xb_mid1 >> 2);
 
     if (role == 0) {
         // =================================== stage A ===========================================
@@ -297,7 +392,7 @@ __device__ __forceinline__ void secam_demod_pair_body(const Args &args_in) {
         if (U8) fill_tile_u8(g, itile, xp, 0, lane);
         else {
             fill_tile<kIT>(g, itile, xp, 0, lane);
-            if (P < kInTile) fill_tile<kInTile>(g, otile_base, xp, 0, lane);
+            if (P < kInTile && kTile >= 16) fill_tile<kInTile>(g, otile_base, xp, 0, lane);   // (3 planes x 16 samples hold the 32)
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_wave_barrier();
@@ -320,6 +415,22 @@ __device__ __forceinline__ void secam_demod_pair_body(const Args &args_in) {
             const int xb = (b - n_pre) << 2;
             if (b == n_pre) xv = read_x(0);
             float yi0[4], yq0[4], yi1[4], yq1[4];
+            const bool mid = !F64 && CM_SECAM_PAIR_MID && b >= b_mid0 && b < b_mid1;
+            if constexpr (!F64) {
+                if (mid) {
+                    const const_f4 *cp = (const_f4 *)g.carrier4 + (m_start + 4 * b - k.s_b - 10);
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) {
+                        const f4 c = cp[s];
+                        float ch_out;
+                        pf2 y0, y1;
+                        st.step_mid(k, kp, xv[s], chw[s], pf2{c.x, c.y}, pf2{c.z, c.w}, ch_out, y0, y1);
+                        chw[10 + s] = ch_out;
+                        yi0[s] = y0.x; yq0[s] = y0.y; yi1[s] = y1.x; yq1[s] = y1.y;
+                    }
+                }
+            }
+            if (!mid)
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
                 const int m = m_start + 4 * b + s;
@@ -328,7 +439,7 @@ __device__ __forceinline__ void secam_demod_pair_body(const Args &args_in) {
                     if (m >= 0) {      // cc[m] = x[P - m] (secam.py:283-284)
                         int xi = P - m;
                         if (xi > W - 1) xi = W - 1;
-                        if (P < kInTile)
+                        if (P < kInTile && (U8 || kTile >= 16))
                             cc = U8 ? __builtin_fmaf((float)xrow8[xi], 5.0f / (255.0f * 3.0f), -1.0f / 3.0f) : pre_row[xi];
                         else
                             cc = U8 ? __builtin_fmaf((float)((const unsigned char *)xp)[xi], 5.0f / (255.0f * 3.0f), -1.0f / 3.0f) : xp[xi];
@@ -375,7 +486,8 @@ __device__ __forceinline__ void secam_demod_pair_body(const Args &args_in) {
                     if (U8) fill_tile_u8(g, itile, xp, nxt / kIT + 1, lane); else fill_tile<kIT>(g, itile, xp, nxt / kIT + 1, lane);
                 }
             }
-            lds_float *slot = ring + (b & 1) * (kSecamMid / 2) + lane * 4;
+            lds_float *slot = ring + (CM_SECAM_PAIR_MID_BUFS == 2 ? (b & 1) * (kSecamMid / 2) : 0) + lane * 4;
+            if (CM_SECAM_PAIR_MID_BUFS == 1 && b > 0) asm volatile("s_barrier" ::: "memory");      // B has read body b - 1
             *(lds_f4 *)slot = f4{yi0[0], yi0[1], yi0[2], yi0[3]};
             *(lds_f4 *)(slot + 256) = f4{yq0[0], yq0[1], yq0[2], yq0[3]};
             *(lds_f4 *)(slot + 512) = f4{yi1[0], yi1[1], yi1[2], yi1[3]};
@@ -406,12 +518,79 @@ __device__ __forceinline__ void secam_demod_pair_body(const Args &args_in) {
     int xr = lr_m == 0 ? 0 : n_blocks - lr_m;    // delay ring block of body b: lr_m bodies behind A's
     for (int b = 0; b < n_bodies; ++b) {
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // block b of the ring is complete
-        const lds_float *slot = ring + (b & 1) * (kSecamMid / 2) + lane * 4;
+        const lds_float *slot = ring + (CM_SECAM_PAIR_MID_BUFS == 2 ? (b & 1) * (kSecamMid / 2) : 0) + lane * 4;
         const f4 i0 = *(const lds_f4 *)slot, q0 = *(const lds_f4 *)(slot + 256);
         const f4 i1 = *(const lds_f4 *)(slot + 512), q1 = *(const lds_f4 *)(slot + 768);
         const f4 lw = *(const lds_f4 *)(xring + xr * 256 + lane * 4);
+        if (CM_SECAM_PAIR_MID_BUFS == 1 && b + 1 < n_bodies) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // A may refill
         xr = xr + 1 == n_blocks ? 0 : xr + 1;
         const int xb = (b - n_pre) << 2;
+        auto flush_after = [&](int s) {
+            if (s == s_flush && b >= n_pre) {
+                const int nn = xb + s - lat_out;
+                if (nn >= 0 && ((nn & (kTile - 1)) == kTile - 1 || nn == g.Wp - 1)) {
+                    if (U8) flush_tile_u8(g, otile_base, op, nn & ~(kTile - 1), lane);
+                    else flush_tile<kTile>(g, otile_base, op, nn & ~(kTile - 1), lane);
+                }
+            }
+        };
+        if (CM_SECAM_PAIR_MID == 2 && b >= b_mid0 && b < b_mid1) {
+            // interior, step by step (fewer live registers than the batched form below)
+            const int m0 = m_start + 4 * b;
+            const __attribute__((address_space(4))) float *dcp = (const __attribute__((address_space(4))) float *)g.carrier2 + (m0 - lat + P);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const float d_e = phase_step_fast(st.iq_prev.x, st.iq_prev.y, i0[s], q0[s]);
+                const float d_o = phase_step_fast(i0[s], q0[s], i1[s], q1[s]);
+                st.iq_prev = pf2{i1[s], q1[s]};
+                const float own = st.chroma_back_mid(k, lk, d_e, d_o, dcp[s]);
+                const int n = m0 + s - 1 - lat;
+                const float luma = st.luma_step_mid(k, lw[s]);
+                const Rgb<float> o = st.finish(k, lk, luma, own_prev, nb_prev);
+                own_prev = own;
+                nb_prev = lane_from(idx1, own);
+                put_rgb<U8, kTile>(otile, wpos, n, o);
+                flush_after(s);
+            }
+            st.have_prev = 1;
+            continue;
+        }
+        if (CM_SECAM_PAIR_MID == 1 && b >= b_mid0 && b < b_mid1) {
+            // interior: the eight phase steps of the body together (one branch to the library atan2f), no guards
+            PhaseStep pe[4], po[4];
+            bool all_small = true;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const pf2 prev = s == 0 ? st.iq_prev : pf2{i1[s - 1], q1[s - 1]};
+                pe[s].set(prev.x, prev.y, i0[s], q0[s]);
+                po[s].set(i0[s], q0[s], i1[s], q1[s]);
+                all_small = all_small && pe[s].small() && po[s].small();
+            }
+            st.iq_prev = pf2{i1[3], q1[3]};
+            st.have_prev = 1;
+            float d_e[4], d_o[4];
+            if (__builtin_expect(__builtin_amdgcn_ballot_w64(!all_small) == 0ull, 1)) {
+#pragma unroll
+                for (int s = 0; s < 4; ++s) { d_e[s] = pe[s].series(); d_o[s] = po[s].series(); }
+            } else {
+#pragma unroll
+                for (int s = 0; s < 4; ++s) { d_e[s] = pe[s].full(); d_o[s] = po[s].full(); }
+            }
+            const int m0 = m_start + 4 * b;
+            const __attribute__((address_space(4))) float *dcp = (const __attribute__((address_space(4))) float *)g.carrier2 + (m0 - lat + P);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const float own = st.chroma_back_mid(k, lk, d_e[s], d_o[s], dcp[s]);
+                const int n = m0 + s - 1 - lat;
+                const float luma = st.luma_step_mid(k, lw[s]);
+                const Rgb<float> o = st.finish(k, lk, luma, own_prev, nb_prev);
+                own_prev = own;
+                nb_prev = lane_from(idx1, own);
+                put_rgb<U8, kTile>(otile, wpos, n, o);
+                flush_after(s);
+            }
+            continue;
+        }
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             const int m = m_start + 4 * b + s;
@@ -425,13 +604,7 @@ __device__ __forceinline__ void secam_demod_pair_body(const Args &args_in) {
             own_prev = own;
             nb_prev = lane_from(idx1, own);
             if (n >= 0 && n < W) put_rgb<U8, kTile>(otile, wpos, n, o);
-            if (s == s_flush && b >= n_pre) {
-                const int nn = xb + s - lat_out;
-                if (nn >= 0 && ((nn & (kTile - 1)) == kTile - 1 || nn == g.Wp - 1)) {
-                    if (U8) flush_tile_u8(g, otile_base, op, nn & ~(kTile - 1), lane);
-                    else flush_tile<kTile>(g, otile_base, op, nn & ~(kTile - 1), lane);
-                }
-            }
+            flush_after(s);
         }
     }
 }

@@ -78,6 +78,12 @@ struct Sys {
 #ifndef CM_V_SECAM
 #define CM_V_SECAM 1, 1, 1
 #endif
+#ifndef CM_V_SECAM_A       /* stage A of the SECAM wave pair */
+#define CM_V_SECAM_A CM_V_SECAM
+#endif
+#ifndef CM_V_SECAM_B       /* stage B of the SECAM wave pair (its decimator's taps) */
+#define CM_V_SECAM_B CM_V_SECAM
+#endif
 template <int VT_, int VL_, int VB_>
 struct VPolicy {
     static constexpr bool VT = VT_ != 0, VL = VL_ != 0, VB = VB_ != 0;

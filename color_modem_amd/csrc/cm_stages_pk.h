@@ -452,6 +452,28 @@ __device__ __forceinline__ float phase_step_fast(float i0, float q0, float i1, f
     return atan2f(cross, dot);
 }
 
+// The same step in two halves for a body that takes its eight phase steps together (the interior of a row): the small-angle
+// series for all of them, one wave-uniform branch to the library function when any lane of any of them falls outside.
+struct PhaseStep {
+    float cross, dot;
+    __device__ __forceinline__ void set(float i0, float q0, float i1, float q1) {
+        const float t = q0 * i1;
+        const float e = __builtin_fmaf(-q0, i1, t);
+        cross = __builtin_fmaf(i0, q1, -t) + e;
+        dot = __builtin_fmaf(i0, i1, q0 * q1);
+    }
+    __device__ __forceinline__ bool small() const { return dot > 0.f && __builtin_fabsf(cross) <= 0.25f * dot; }
+    __device__ __forceinline__ float series() const {
+        const float r = cross * __builtin_amdgcn_rcpf(dot);
+        const float z = r * r;
+        float p = __builtin_fmaf(z, 1.0f / 9.0f, -1.0f / 7.0f);
+        p = __builtin_fmaf(z, p, 1.0f / 5.0f);
+        p = __builtin_fmaf(z, p, -1.0f / 3.0f);
+        return __builtin_fmaf(r * z, p, r);
+    }
+    __device__ __forceinline__ float full() const { return small() ? series() : atan2f(cross, dot); }
+};
+
 struct SecamDemodKPk {   // uniform blocks of the chroma path in VGPR pairs
     TapsPk taps;
     SosPk<3> lpf;
@@ -536,6 +558,33 @@ struct SecamDemodPk {
         }
         return c;
     }
+    // chroma_step<false> in two halves (exactly its operations, in its order, per step): up to the low-passed (I, Q) of the
+    // pair, and from the two phase steps on.  Between them the caller turns y0 / y1 of several steps into phase steps.
+    __device__ __forceinline__ void chroma_front_mid(const SecamDemodK<float> &k, const SecamDemodKPk &kp, float cc_now, float ch_d10, pf2 car_e,
+                                                     pf2 car_o, float &ch_out, pf2 &y0, pf2 &y1) {
+        const float b = iir_bp<VP::VB>(bpf, k.bpf, cc_now);
+        const float ch = k.has_bell ? iir_bp<false>(bell, k.bell, b) : b;
+        ch_out = ch;
+        const float a_odd = up.template push<VP::VT>(k.taps, ch);
+        const float a_even = k.taps.c0 * ch_d10;
+        const pf2 sgn = {1.f, -1.f};
+        const pf2 p_e = pk_mul(pk_mul_bs<0>(pf2{a_even, a_even}, car_e), sgn);
+        const pf2 p_o = pk_mul(pk_mul_bs<0>(pf2{a_odd, a_odd}, car_o), sgn);
+        y0 = iir_sym_pk<0, 3>(lp, kp.lpf, p_e);
+        y1 = iir_sym_pk<0, 3>(lp, kp.lpf, p_o);
+        if (k.odd_l) {
+            const pf2 h = iq_hold;
+            iq_hold = y1;
+            y1 = y0;
+            y0 = h;
+        }
+    }
+    __device__ __forceinline__ float chroma_back_mid(const SecamDemodK<float> &k, const SecamDemodLaneK<float> &lk, float d_e, float d_o, float dc) {
+        const float g2 = dn.template push_pair<VP::VT>(k.taps, d_e * k.two_over_pi, d_o * k.two_over_pi);
+        float f2 = (g2 + dc) + lk.off2;
+        f2 = f2 < lk.lo ? lk.lo : (f2 > lk.hi ? lk.hi : f2);
+        return iir_gen<false>(deemph, k.deemph, f2 * lk.scale);
+    }
     template <bool EDGE = true>
     __device__ __forceinline__ float luma_step(const SecamDemodK<float> &k, int n, float x_in) {
         const int W = k.width, j = n + k.s_y;
@@ -567,7 +616,7 @@ struct SecamDemodPk {
 // execute exactly the operations of SecamDemodPk::chroma_step, in the same order.
 // =============================================================================================
 struct SecamDemodPkA {
-    typedef VPolicy<CM_V_SECAM> VP;
+    typedef VPolicy<CM_V_SECAM_A> VP;
     IirState<float, 3> bpf;
     IirState<float, 1> bell;
     IirStatePk<3> lp;               // (I, Q)
@@ -615,6 +664,26 @@ struct SecamDemodPkA {
                 y1 = y0;
                 y0 = h;
             }
+        }
+    }
+    // the same step where no stage index touches a row boundary (the interior bodies)
+    __device__ __forceinline__ void step_mid(const SecamDemodK<float> &k, const SecamDemodKPk &kp, float cc_now, float ch_d10, pf2 car_e, pf2 car_o,
+                                             float &ch_out, pf2 &y0, pf2 &y1) {
+        const float b = iir_bp<VP::VB>(bpf, k.bpf, cc_now);
+        const float ch = k.has_bell ? iir_bp<false>(bell, k.bell, b) : b;
+        ch_out = ch;
+        const float a_odd = up.template push<VP::VT>(k.taps, ch);
+        const float a_even = k.taps.c0 * ch_d10;
+        const pf2 sgn = {1.f, -1.f};
+        const pf2 p_e = pk_mul(pk_mul_bs<0>(pf2{a_even, a_even}, car_e), sgn);
+        const pf2 p_o = pk_mul(pk_mul_bs<0>(pf2{a_odd, a_odd}, car_o), sgn);
+        y0 = iir_sym_pk<0, 3>(lp, kp.lpf, p_e);
+        y1 = iir_sym_pk<0, 3>(lp, kp.lpf, p_o);
+        if (k.odd_l) {
+            const pf2 h = iq_hold;
+            iq_hold = y1;
+            y1 = y0;
+            y0 = h;
         }
     }
 };
@@ -671,7 +740,7 @@ struct SecamDemodA64 {
 };
 
 struct SecamDemodPkB {
-    typedef VPolicy<CM_V_SECAM> VP;
+    typedef VPolicy<CM_V_SECAM_B> VP;
     IirState<float, 3> ybs;
     IirState<float, 1> deemph;
     HalfbandChain<float> dn;
@@ -710,6 +779,14 @@ struct SecamDemodPkB {
         }
         return c;
     }
+    // interior bodies: from the phase steps d_e, d_o (taken by the caller, several steps at a time) on
+    __device__ __forceinline__ float chroma_back_mid(const SecamDemodK<float> &k, const SecamDemodLaneK<float> &lk, float d_e, float d_o, float dc) {
+        const float g2 = dn.template push_pair<VP::VT>(k.taps, d_e * k.two_over_pi, d_o * k.two_over_pi);
+        float f2 = (g2 + dc) + lk.off2;
+        f2 = f2 < lk.lo ? lk.lo : (f2 > lk.hi ? lk.hi : f2);
+        return iir_gen<false>(deemph, k.deemph, f2 * lk.scale);
+    }
+    __device__ __forceinline__ float luma_step_mid(const SecamDemodK<float> &k, float x_in) { return iir_sym<false>(ybs, k.ybs, x_in) * k.luma_gain; }
     __device__ __forceinline__ float luma_step(const SecamDemodK<float> &k, int n, float x_in) {
         const int W = k.width, j = n + k.s_y;
         float y = 0.f;
