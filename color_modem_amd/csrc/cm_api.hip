@@ -169,6 +169,7 @@ struct cm_plan {
     double *fm_ref64 = nullptr;   // the same in float64, for the float64 front end (sd_f64)
     SecamDemodK<double> sd_k64;
     bool sd_f64 = false;          // decoder shapes whose float32 margin is thin: stage A of the wave pair in float64
+    bool sd_pair = false;         // float rows run on secam_demod_pair_kernel
     float *fm_dc = nullptr;       // SECAM: decimator response to the constant fc beyond 2 fc (cm_plan.h: build_fm_dc)
     int sd_cycle = 0, sd_n_lines = 0;
     SecamModK<float, double> sm_k;
@@ -530,7 +531,7 @@ bool create_secam(cm_plan *p, const cm_plan_desc &d, std::string &err) {
         }
         const int d_luma = p->sd_k.s_b + 20 + p->sd_k.q_l - p->sd_k.s_y;
         const bool thin = d.secam.lf_rev.n_sections == 0 || 2.0 / fdev_min > 100.0;     // fdev is normalised to fs / 2
-        p->sd_f64 = CM_SECAM_F64 && thin && d_luma >= 4 && d_luma <= kSecamPairMaxLumaDelay;
+        p->sd_f64 = CM_SECAM_F64 && thin && d_luma >= 4 + 4 * CM_SECAM_PAIR_REG_DELAY && d_luma <= kSecamPairMaxLumaDelay;
         if (p->sd_f64) {
             if (!build_secam_demod_k<double>(d, p->sd_k64, err)) return false;
             std::vector<double> fm64 = build_fm_reference<double>(d.secam.fm_fc, d.width + d.secam.preroll);
@@ -550,7 +551,13 @@ bool create_secam(cm_plan *p, const cm_plan_desc &d, std::string &err) {
         p->mod_depth = d.modulation_delay ? 1 : 0;
     }
     p->main.depth = 1;
-    p->main.name = "secam_demod_kernel";
+    {
+        const int d_luma = p->sd_k.s_b + 20 + p->sd_k.q_l - p->sd_k.s_y;
+        const bool ring_ok = d_luma >= 4 + 4 * CM_SECAM_PAIR_REG_DELAY && d_luma <= kSecamPairMaxLumaDelay;
+        p->sd_pair = CM_SECAM_PAIR && ring_ok;
+        p->main.name = p->sd_f64 ? "secam_demod_pair64_kernel (stage A in float64)"
+                     : p->sd_pair ? "secam_demod_pair_kernel" : "secam_demod_kernel";
+    }
     return true;
 }
 
@@ -576,7 +583,7 @@ int run_secam_demod(const cm_plan *p, Geom g, hipStream_t stream, bool u8 = fals
         a64.fm_ref64 = p->fm_ref64;
         if (u8) hipLaunchKernelGGL(secam_demod_pair64_kernel<true>, dim3((int)blocks), dim3(128), sizeof(float) * secam_pair_lds_floats<true>(d_luma), stream, a64);
         else hipLaunchKernelGGL(secam_demod_pair64_kernel<false>, dim3((int)blocks), dim3(128), sizeof(float) * secam_pair_lds_floats<false>(d_luma), stream, a64);
-    } else if (CM_SECAM_PAIR && d_luma >= 4 && d_luma <= kSecamPairMaxLumaDelay) {
+    } else if (p->sd_pair && (!u8 || CM_SECAM_PAIR_U8)) {
         if (u8) hipLaunchKernelGGL(secam_demod_pair_kernel<true>, dim3((int)blocks), dim3(128), sizeof(float) * secam_pair_lds_floats<true>(d_luma), stream, a);
         else hipLaunchKernelGGL(secam_demod_pair_kernel<false>, dim3((int)blocks), dim3(128), sizeof(float) * secam_pair_lds_floats<false>(d_luma), stream, a);
     } else if (u8) hipLaunchKernelGGL(secam_demod_kernel<true>, dim3((int)blocks), dim3(64), 0, stream, a);

@@ -45,28 +45,40 @@ __device__ __forceinline__ void flush_tile1(const Geom &g, const lds_float *otil
     __builtin_amdgcn_wave_barrier();
 }
 
-// Three-plane input tile of the modulators: [3][64 rows][32 samples], filled like the demodulators' tile
-// (8 rows x 128 B per global_load_lds_dwordx4), single-buffered: refilled right after its last sample has
-// been read, waited for before the first sample of the next tile is read.
-constexpr int kLdsIn3 = 3 * kLdsIn;
+// Three-plane float input tile of the modulators: kModBufs buffers of [3][64 rows][kModIT samples], filled like the
+// demodulators' tile (global_load_lds_dwordx4: kModIT / 4 lanes per row).  One buffer: refilled right after its last
+// sample has been read, waited for before the first sample of the next tile is read (one body of 4 steps to land).  Two
+// buffers: tile c + 1 is asked for when tile c is first read (a whole tile of steps to land).
+#ifndef CM_MOD_IN_TILE
+#define CM_MOD_IN_TILE 32
+#endif
+#ifndef CM_MOD_IN_BUFS
+#define CM_MOD_IN_BUFS 1
+#endif
+constexpr int kModIT = CM_MOD_IN_TILE, kModBufs = CM_MOD_IN_BUFS;
+constexpr int kModPlane = 64 * kModIT;                 // floats per plane of one buffer
+constexpr int kLdsIn3 = kModBufs * 3 * kModPlane;
 __device__ __forceinline__ void fill_tile3(const Geom &g, lds_float *itile, const float *rp, int c, int lane) {
-    int col = kInTile * c + 4 * (lane & 7);
+    constexpr int kLanesPerRow = kModIT / 4, kRowsPerInstr = 64 / kLanesPerRow;
+    lds_float *buf = itile + (kModBufs == 2 ? (c & 1) * 3 * kModPlane : 0);
+    int col = kModIT * c + 4 * (lane & (kLanesPerRow - 1));
     if (col > g.Wp - 4) col = g.Wp - 4;
 #pragma nounroll
-    for (int q = 0; q < 8; ++q) {
-        const float *src = ptr_from((8 * q + (lane >> 3)) * 4, rp) + col;
+    for (int q = 0; q < kLanesPerRow; ++q) {
+        const float *src = ptr_from((kRowsPerInstr * q + lane / kLanesPerRow) * 4, rp) + col;
 #pragma unroll
         for (int p = 0; p < 3; ++p)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + p * g.in_plane_stride),
-                                             (__attribute__((address_space(3))) void *)(itile + p * kLdsIn + q * 256), 16, 0,
-                                             CM_FILL_AUX);
+                                             (__attribute__((address_space(3))) void *)(buf + p * kModPlane + q * 256), 16, 0,
+                                             kModIT == kInTile ? CM_FILL_AUX : 0);
     }
 }
 // r, g, b of samples first .. first + 3 of this lane's row out of the tile; zero beyond the row
 __device__ __forceinline__ void read_tile3(const lds_float *itile, int lane, int first, int W, f4 out[3]) {
+    const lds_float *buf = itile + (kModBufs == 2 ? ((first / kModIT) & 1) * 3 * kModPlane : 0);
 #pragma unroll
     for (int p = 0; p < 3; ++p) {
-        f4 v = *(const lds_f4 *)(itile + p * kLdsIn + lane * kInTile + (first & (kInTile - 1)));
+        f4 v = *(const lds_f4 *)(buf + p * kModPlane + lane * kModIT + (first & (kModIT - 1)));
         if (first + 3 >= W) {   // the last quad of a row may be partial (pitched rows)
             if (first >= W) v.x = 0.f;
             if (first + 1 >= W) v.y = 0.f;
@@ -78,15 +90,22 @@ __device__ __forceinline__ void read_tile3(const lds_float *itile, int lane, int
 }
 // Advance the input stream by one body: returns samples nxt .. nxt + 3 and keeps the tile protocol.
 __device__ __forceinline__ void next_tile3(const Geom &g, lds_float *itile, const float *rp, int lane, int nxt, f4 out[3]) {
-    if ((nxt & (kInTile - 1)) == 0 && nxt < g.W) {
+    const bool first_of_tile = (nxt & (kModIT - 1)) == 0 && nxt < g.W;
+    if (first_of_tile) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_wave_barrier();
     }
     read_tile3(itile, lane, nxt, g.W, out);
-    if ((nxt & (kInTile - 1)) == kInTile - 4 && nxt + 4 < g.W) {
+    if (kModBufs == 2) {
+        if (first_of_tile && nxt + kModIT < g.W) {      // the other buffer was last read a body ago
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+            fill_tile3(g, itile, rp, nxt / kModIT + 1, lane);
+        }
+    } else if ((nxt & (kModIT - 1)) == kModIT - 4 && nxt + 4 < g.W) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_wave_barrier();
-        fill_tile3(g, itile, rp, (nxt >> 5) + 1, lane);
+        fill_tile3(g, itile, rp, nxt / kModIT + 1, lane);
     }
 }
 
@@ -129,6 +148,7 @@ __device__ __forceinline__ void first_tile3(const Geom &g, lds_float *itile, con
     if (U8) fill_tile3_u8(g, itile, rp, 0, lane); else fill_tile3(g, itile, rp, 0, lane);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_wave_barrier();
+    if (!U8 && kModBufs == 2 && kModIT < g.W) fill_tile3(g, itile, rp, 1, lane);
     if (U8) read_tile3_u8(itile, lane, 0, g.W, out); else read_tile3(itile, lane, 0, g.W, out);
 }
 template <bool U8>
@@ -205,8 +225,11 @@ constexpr int kModLdsFloatsU8 = (kInTile3Bytes + 64 * kOutTileU8) / 4;    // byt
 // DEPTH = 1: encoder-side line averaging (ColorAveragingModem) needs the previous call's components.
 // U8: the ImageModem byte boundary fused in (interleaved RGB bytes in, composite bytes out)
 // RT: run-time shape - SP is the size of the luma delay window, the delay itself is k.s_p <= SP (any sampling rate)
+#ifndef CM_QAM_MOD_WAVES      /* waves per SIMD the register allocation of the QAM encoders aims at */
+#define CM_QAM_MOD_WAVES 2
+#endif
 template <int NP, int SP, int DEPTH, bool U8 = false, bool RT = false>
-__global__ __launch_bounds__(64, 2) void qam_mod_kernel(const ModArgs<NP> args) {
+__global__ __launch_bounds__(64, CM_QAM_MOD_WAVES) void qam_mod_kernel(const ModArgs<NP> args) {
     constexpr int kTile = kQamModTile;
     __shared__ __attribute__((aligned(16))) float lds_store[U8 ? kModLdsFloatsU8 : mod_lds_floats<kTile>()];
     lds_float *itile = (lds_float *)lds_store;

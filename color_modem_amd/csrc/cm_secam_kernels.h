@@ -45,7 +45,7 @@ struct SecamDemodArgs {
 #endif
 // samples per input tile row of the float32 wave pair
 #ifndef CM_SECAM_PAIR_IN_TILE
-#define CM_SECAM_PAIR_IN_TILE 16
+#define CM_SECAM_PAIR_IN_TILE 8
 #endif
 // bodies (of 4 steps) the luma samples of the second row visit are asked for ahead of their use
 #ifndef CM_SECAM_LUMA_AHEAD
@@ -272,18 +272,29 @@ __global__ __launch_bounds__(64, CM_SECAM_WAVES) void secam_demod_kernel(const S
 //                     colour-difference signal from the neighbouring lane, matrix, output tile and every global store
 // One s_barrier per body: A after writing block b, B before reading it.
 // ---------------------------------------------------------------------------------------------------------------------
-// Off by default: parity-green (the 36 SECAM GPU tests) but 4.0 - 4.1 ms against 3.5 ms per 1000 frames for the one-wave
-// kernel (profiles/r01_pair_notes.md section 10).  -DCM_SECAM_PAIR=1 selects it.
+// Round 1's form (guards in every step, 32 - 38 KiB of LDS) ran 4.0 - 4.1 ms per 1000 frames against 3.5 for the one-wave
+// kernel.  With edge-free interior bodies in both stages, stage A at 165 VGPRs and 26 KiB of LDS (8-sample input tile, four
+// bodies of the luma delay in stage B's registers: CM_SECAM_PAIR_REG_DELAY) six workgroups fit a CU and it runs 2.78 - 2.87
+// against 2.93 - 2.99 (profiles/r02_notes.md section 3): the default for float rows where the luma delay allows;
+// -DCM_SECAM_PAIR=0 brings the one-wave kernel back.  Byte rows: 2.75 - 2.78 against 2.85 - 2.90 ms (CM_SECAM_PAIR_U8).
 #ifndef CM_SECAM_PAIR
-#define CM_SECAM_PAIR 0
+#define CM_SECAM_PAIR 1
 #endif
 // 1: both stages run the interior bodies of a row without guards (float32 stage A; the float64 stage A keeps them)
+// 1: byte rows on the wave pair as well
+#ifndef CM_SECAM_PAIR_U8
+#define CM_SECAM_PAIR_U8 1
+#endif
 #ifndef CM_SECAM_PAIR_MID
 #define CM_SECAM_PAIR_MID 1
 #endif
 // 1: the shapes whose float32 margin is thin (cm_api.hip: create_secam) run on the wave pair with stage A in float64
 #ifndef CM_SECAM_F64
 #define CM_SECAM_F64 1
+#endif
+// bodies of luma delay stage B keeps in registers (a queue of float4) instead of the LDS delay ring: 1 KiB less LDS each
+#ifndef CM_SECAM_PAIR_REG_DELAY
+#define CM_SECAM_PAIR_REG_DELAY 4
 #endif
 #ifndef CM_SECAM_PAIR_LDS_PAD      /* occupancy experiments: unused floats of LDS per workgroup */
 #define CM_SECAM_PAIR_LDS_PAD 0
@@ -296,7 +307,7 @@ __global__ __launch_bounds__(64, CM_SECAM_WAVES) void secam_demod_kernel(const S
 constexpr int kSecamMid = CM_SECAM_PAIR_MID_BUFS * 4 * 256;        // floats: [buffer][I0 | Q0 | I1 | Q1][lane][4 steps]
 constexpr int kSecamPairMaxLumaDelay = 4 + 4 * 14 + 3;   // delay ring of at most 16 blocks of [lane][4 samples]
 template <bool U8> constexpr int secam_pair_lds_floats(int d_luma) {
-    return (U8 ? 64 * kInTile / 4 : 64 * CM_SECAM_PAIR_IN_TILE) + kSecamMid + (U8 ? 64 * 3 * 16 / 4 : 3 * 64 * CM_SECAM_OUT_TILE) + (((d_luma - 4) >> 2) + 2) * 256 + CM_SECAM_PAIR_LDS_PAD;
+    return (U8 ? 64 * kInTile / 4 : 64 * CM_SECAM_PAIR_IN_TILE) + kSecamMid + (U8 ? 64 * 3 * 16 / 4 : 3 * 64 * CM_SECAM_OUT_TILE) + (((d_luma - 4) >> 2) - CM_SECAM_PAIR_REG_DELAY + 2) * 256 + CM_SECAM_PAIR_LDS_PAD;
 }
 
 struct SecamDemodArgs64 {
@@ -311,7 +322,7 @@ __device__ __forceinline__ void secam_demod_pair_body(const Args &args_in);
 
 // waves per SIMD the register allocation of the float32 pair aims at (3: <= 168 VGPRs)
 #ifndef CM_SECAM_PAIR_WAVES
-#define CM_SECAM_PAIR_WAVES 2
+#define CM_SECAM_PAIR_WAVES 3
 #endif
 template <bool U8>
 __global__ __launch_bounds__(128, CM_SECAM_PAIR_WAVES) void secam_demod_pair_kernel(const SecamDemodArgs args) {
@@ -360,7 +371,7 @@ __device__ __forceinline__ void secam_demod_pair_body(const Args &args_in) {
     const int T = (g.Wp + lat_out + 3) & ~3;
     const int n_bodies = n_pre + (T >> 2);
     // A writes x[xb - 4 - lr_o .. + 3] (out of the samples of its last two bodies); B reads it lr_m bodies later
-    const int lr_o = (d_luma - 4) & 3, lr_m = (d_luma - 4) >> 2;
+    const int lr_o = (d_luma - 4) & 3, lr_m = ((d_luma - 4) >> 2) - CM_SECAM_PAIR_REG_DELAY;   // (the host checks lr_m >= 0)
     const int n_blocks = lr_m + 2;                          // delay ring blocks (the host sizes the LDS with the same number)
     // interior bodies (secam_demod_kernel): every stage index of the four steps lies strictly inside its stream
     int xb_mid0 = (lat + 1 - P + 3) & ~3, xb_mid1 = (W - 8) & ~3;
@@ -516,12 +527,23 @@ __device__ __forceinline__ void secam_demod_pair_body(const Args &args_in) {
     const int wpos = ((lane >> CM_TILE_SWZ) & (kTile / 4 - 1)) << 2;
     float own_prev = 0.f, nb_prev = 0.f;
     int xr = lr_m == 0 ? 0 : n_blocks - lr_m;    // delay ring block of body b: lr_m bodies behind A's
+    constexpr int kRegDelay = CM_SECAM_PAIR_REG_DELAY;
+    f4 lq[kRegDelay > 0 ? kRegDelay : 1];
+#pragma unroll
+    for (int j = 0; j < (kRegDelay > 0 ? kRegDelay : 1); ++j) lq[j] = f4{0.f, 0.f, 0.f, 0.f};
     for (int b = 0; b < n_bodies; ++b) {
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // block b of the ring is complete
         const lds_float *slot = ring + (CM_SECAM_PAIR_MID_BUFS == 2 ? (b & 1) * (kSecamMid / 2) : 0) + lane * 4;
         const f4 i0 = *(const lds_f4 *)slot, q0 = *(const lds_f4 *)(slot + 256);
         const f4 i1 = *(const lds_f4 *)(slot + 512), q1 = *(const lds_f4 *)(slot + 768);
-        const f4 lw = *(const lds_f4 *)(xring + xr * 256 + lane * 4);
+        f4 lw = *(const lds_f4 *)(xring + xr * 256 + lane * 4);
+        if (kRegDelay > 0) {      // the rest of the delay in registers
+            const f4 in = lw;
+            lw = lq[kRegDelay - 1];
+#pragma unroll
+            for (int j = kRegDelay - 1; j > 0; --j) lq[j] = lq[j - 1];
+            lq[0] = in;
+        }
         if (CM_SECAM_PAIR_MID_BUFS == 1 && b + 1 < n_bodies) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // A may refill
         xr = xr + 1 == n_blocks ? 0 : xr + 1;
         const int xb = (b - n_pre) << 2;

@@ -78,8 +78,8 @@ struct Sys {
 #ifndef CM_V_SECAM
 #define CM_V_SECAM 1, 1, 1
 #endif
-#ifndef CM_V_SECAM_A       /* stage A of the SECAM wave pair */
-#define CM_V_SECAM_A CM_V_SECAM
+#ifndef CM_V_SECAM_A       /* stage A of the SECAM wave pair: band-pass coefficients in SGPRs (165 instead of 172 VGPRs: 3 waves per SIMD) */
+#define CM_V_SECAM_A 1, 1, 0
 #endif
 #ifndef CM_V_SECAM_B       /* stage B of the SECAM wave pair (its decimator's taps) */
 #define CM_V_SECAM_B CM_V_SECAM
