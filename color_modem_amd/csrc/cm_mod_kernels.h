@@ -49,8 +49,11 @@ __device__ __forceinline__ void flush_tile1(const Geom &g, const lds_float *otil
 // demodulators' tile (global_load_lds_dwordx4: kModIT / 4 lanes per row).  One buffer: refilled right after its last
 // sample has been read, waited for before the first sample of the next tile is read (one body of 4 steps to land).  Two
 // buffers: tile c + 1 is asked for when tile c is first read (a whole tile of steps to land).
+// Measured (profiles/r02_mod_tile_ab.txt, ms per 1000 frames PAL-S / NTSC / SECAM): 32-sample tiles (32 KiB with the output
+// tile, 5 workgroups per CU) 2.02 / 1.70 / 2.61; 16-sample tiles (20 KiB, 8 per CU) 1.62 / 1.38 / 2.15; 8-sample tiles
+// (32-byte row segments) 2.3 - 2.8 whether double-buffered or not.
 #ifndef CM_MOD_IN_TILE
-#define CM_MOD_IN_TILE 32
+#define CM_MOD_IN_TILE 16
 #endif
 #ifndef CM_MOD_IN_BUFS
 #define CM_MOD_IN_BUFS 1
@@ -218,7 +221,10 @@ __device__ __forceinline__ void mod_rows(const Geom &g, const LaneCall &lc, cons
 // samples per output tile row of the encoders: the QAM encoders write 128-byte row segments (measured 2.31 -> 2.04 ms per
 // 1000 frames against 64-byte segments: they are bandwidth-bound and the tile is a single plane, 8 KiB), the SECAM
 // encoder keeps 64-byte segments (it is arithmetic-bound: the wider tile cost it 19 %)
-constexpr int kQamModTile = 32, kSecamModTile = 16;
+#ifndef CM_QAM_MOD_TILE
+#define CM_QAM_MOD_TILE 32
+#endif
+constexpr int kQamModTile = CM_QAM_MOD_TILE, kSecamModTile = 16;
 template <int kTile> constexpr int mod_lds_floats() { return kLdsIn3 + 64 * kTile; }   // float mode: 3-plane input tile + output tile
 constexpr int kModLdsFloatsU8 = (kInTile3Bytes + 64 * kOutTileU8) / 4;    // byte mode
 

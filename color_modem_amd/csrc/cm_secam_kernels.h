@@ -638,8 +638,11 @@ struct SecamModArgs {
 
 // SP = shift of the pre-correction low-pass (register window of the luma delay); DEPTH = 1: line averaging
 // RT: SP is the size of the luma delay window, the delay itself is k.s_p <= SP (other sampling rates)
+#ifndef CM_SECAM_MOD_WAVES     /* waves per SIMD the register allocation of the SECAM encoder aims at */
+#define CM_SECAM_MOD_WAVES 2
+#endif
 template <int SP, int DEPTH, bool U8 = false, bool RT = false>
-__global__ __launch_bounds__(64, 2) void secam_mod_kernel(const SecamModArgs args) {
+__global__ __launch_bounds__(64, CM_SECAM_MOD_WAVES) void secam_mod_kernel(const SecamModArgs args) {
     constexpr int kTile = kSecamModTile;
     __shared__ __attribute__((aligned(16))) float lds_store[U8 ? kModLdsFloatsU8 : mod_lds_floats<kTile>()];
     lds_float *itile = (lds_float *)lds_store;
