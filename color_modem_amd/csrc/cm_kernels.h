@@ -779,6 +779,10 @@ struct PairLds<NoPass> {
 #define PAIR_BARRIER(acc) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 #endif
 
+// 1: stage A of the PAL-D front end runs two of its three half-band chains as one packed chain (PalDFrontAPk)
+#ifndef CM_PALD_PK_FRONT
+#define CM_PALD_PK_FRONT 1
+#endif
 template <class Cfg>
 __device__ __forceinline__ void run_pair(const Geom &g, const DemodK<float, typename Cfg::S> &k_in, int block, lds_float *lds,
                                          int role) {
@@ -838,13 +842,25 @@ __device__ __forceinline__ void run_pair(const Geom &g, const DemodK<float, type
         const float *lp;
         if (U8) lp = (const float *)((const unsigned char *)g.in + frame * g.in_frame_stride + (long long)luma_row * g.W);
         else lp = g.in + frame * g.in_frame_stride + (long long)luma_row * g.Wp;
-        if (VP::VT) pin_block(k.taps);
+        // PAL-D front: two of the three chains packed (cm_stages_pk.h: PalDFrontAPk); its interpolator is fed x[t + 1]
+        constexpr bool PKF = PALD && CM_PALD_PK_FRONT != 0;
+        TapsPk tkp;
+        Taps<float> tks;
+        if constexpr (PKF) {
+            tkp.load(k.taps);
+#pragma unroll
+            for (int i = 0; i < 10; ++i) tks.c[i] = (i & 1) ? tkp.c2[i >> 1].y : tkp.c2[i >> 1].x;
+            tks.c0 = tkp.c0.x;
+        } else {
+            if (VP::VT) pin_block(k.taps);
+        }
         if (VP::VB) pin_block(k.ext, false);
         const float *xp;
         if (U8) xp = (const float *)((const unsigned char *)g.in + frame * g.in_frame_stride + (long long)lc.src_row * g.W);
         else xp = g.in + frame * g.in_frame_stride + (long long)lc.src_row * g.Wp;
-        StageA fa;
+        typename std::conditional<PKF, PalDFrontAPk<S>, StageA>::type fa;
         fa.reset();
+        f4 xq = {0.f, 0.f, 0.f, 0.f};          // PKF: x[tb + 4 .. tb + 7], read at the start of a body
         float xw[14], ew[PALD ? 14 : 1];
         float xo[kWinX >= 8 ? kWinX : 1];        // x[tb - 10 - kWinX ..]: older than xw
 #pragma unroll
@@ -886,12 +902,18 @@ __device__ __forceinline__ void run_pair(const Geom &g, const DemodK<float, type
         {
             f4 x0 = read_x(0);
             xw[10] = x0.x; xw[11] = x0.y; xw[12] = x0.z; xw[13] = x0.w;
+            if constexpr (PKF) fa.prime(tkp, x0.x);
         }
         auto sub_a = [&](auto sub_tag, auto edge_tag, FrontLatch<float> &fla, int tau, float &m_even, float &m_odd) {
             constexpr int SUB = decltype(sub_tag)::value;
             constexpr bool EDGE = decltype(edge_tag)::value;
             Mid<float> m;
-            if constexpr (PALD) {
+            if constexpr (PKF) {
+                float e_out;
+                const float x_next = SUB < 3 ? xw[SUB < 3 ? 11 + SUB : 0] : xq.x;
+                m = fa.template step<EDGE>(k, tkp, tks, fla, tau, x_next, xw[SUB], ew[PALD ? SUB : 0], e_out);
+                ew[PALD ? 10 + SUB : 0] = e_out;
+            } else if constexpr (PALD) {
                 float e_out;
                 m = fa.template step<EDGE>(k, fla, tau, xw[10 + SUB], xw[SUB], ew[PALD ? SUB : 0], e_out);
                 ew[PALD ? 10 + SUB : 0] = e_out;
@@ -914,12 +936,26 @@ __device__ __forceinline__ void run_pair(const Geom &g, const DemodK<float, type
                         : lr_o == 1 ? f4{xs[1], xs[2], xs[3], xs[4]}
                         : lr_o == 2 ? f4{xs[2], xs[3], xs[4], xs[5]} : f4{xs[3], xs[4], xs[5], xs[6]};
             }
+            const int nxt = tb + 4;
+            if constexpr (PKF) {   // the next quad now (the interpolator wants x[tb + 4] in the last sub-step); same tile protocol
+                if ((nxt & (kIT - 1)) == 0 && nxt < W) {
+                    CM_STAMP(t0);
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_wave_barrier();
+                    CM_ACC(d_other, t0);
+                }
+                xq = read_x(nxt);
+                if ((nxt & (kIT - 1)) == kIT - 4 && nxt + 4 < W) {
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_wave_barrier();
+                    if (U8) fill_tile_u8(g, itile, xp, nxt / kIT + 1, lane); else fill_tile<kIT>(g, itile, xp, nxt / kIT + 1, lane);
+                }
+            }
             float me[4], mo[4];
             sub_a(std::integral_constant<int, 0>(), edge_tag, fla, tb + 0, me[0], mo[0]);
             sub_a(std::integral_constant<int, 1>(), edge_tag, fla, tb + 1, me[1], mo[1]);
             sub_a(std::integral_constant<int, 2>(), edge_tag, fla, tb + 2, me[2], mo[2]);
             sub_a(std::integral_constant<int, 3>(), edge_tag, fla, tb + 3, me[3], mo[3]);
-            const int nxt = tb + 4;
             if (kWinX >= 8) {
 #pragma unroll
                 for (int j = 0; j + 4 < kWinX; ++j) xo[kWinX >= 8 ? j : 0] = xo[kWinX >= 8 ? j + 4 : 0];
@@ -928,20 +964,24 @@ __device__ __forceinline__ void run_pair(const Geom &g, const DemodK<float, type
             }
 #pragma unroll
             for (int j = 0; j < 10; ++j) xw[j] = xw[j + 4];
-            if ((nxt & (kIT - 1)) == 0 && nxt < W) {  // first read of a new tile: its fill was issued a body ago
-                CM_STAMP(t0);
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __builtin_amdgcn_wave_barrier();
-                CM_ACC(d_other, t0);
-            }
-            {
-                f4 xn = read_x(nxt);
-                xw[10] = xn.x; xw[11] = xn.y; xw[12] = xn.z; xw[13] = xn.w;
-            }
-            if ((nxt & (kIT - 1)) == kIT - 4 && nxt + 4 < W) {  // that was the last read of this tile: refill it
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                __builtin_amdgcn_wave_barrier();
-                if (U8) fill_tile_u8(g, itile, xp, nxt / kIT + 1, lane); else fill_tile<kIT>(g, itile, xp, nxt / kIT + 1, lane);
+            if constexpr (PKF) {
+                xw[10] = xq.x; xw[11] = xq.y; xw[12] = xq.z; xw[13] = xq.w;
+            } else {
+                if ((nxt & (kIT - 1)) == 0 && nxt < W) {  // first read of a new tile: its fill was issued a body ago
+                    CM_STAMP(t0);
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_wave_barrier();
+                    CM_ACC(d_other, t0);
+                }
+                {
+                    f4 xn = read_x(nxt);
+                    xw[10] = xn.x; xw[11] = xn.y; xw[12] = xn.z; xw[13] = xn.w;
+                }
+                if ((nxt & (kIT - 1)) == kIT - 4 && nxt + 4 < W) {  // that was the last read of this tile: refill it
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_wave_barrier();
+                    if (U8) fill_tile_u8(g, itile, xp, nxt / kIT + 1, lane); else fill_tile<kIT>(g, itile, xp, nxt / kIT + 1, lane);
+                }
             }
             if (PALD) {
 #pragma unroll

@@ -210,6 +210,64 @@ struct HalfbandChainPk {
     }
 };
 
+// =============================================================================================
+// Stage A of the PAL-D front end (cm_stages.h: PalDFrontA) with two of its three half-band chains in one packed chain:
+// lane x = up2(x), lane y = dn2 -> e.  The interpolator runs ONE SAMPLE AHEAD (it is fed x[t + 1] in step t and its
+// output is held for the next step), so that both lanes have their input at the same point of a step; each lane executes
+// exactly the scalar chain's operations in the scalar chain's order - the results are bit-identical.  Why: v_pk_fma_f32
+// does not care which register banks its sources sit in, a three-source v_fma_f32 does (3.0 instead of 2.1 cycles per
+// instruction at three waves per SIMD when two sources share a bank, which hipcc's allocation makes the case for two of
+// three: profiles/r02_ubench_bank.txt) - and 40 scalar FMAs per step become 20 packed ones.
+// =============================================================================================
+template <class S>
+struct PalDFrontAPk {
+    typedef DemodK<float, S> K;
+    typedef VPolicy<CM_V_PALD> VP;
+    HalfbandChainPk xe;               // (up2(x) one sample ahead, dn2 -> e)
+    HalfbandChain<float> up_e;
+    IirState<float, S::NE> bpf;
+    float hold_b, a_odd;              // a_odd: up2(x)'s odd output of the step to come
+
+    __device__ __forceinline__ void reset() {
+        xe.reset(); up_e.reset(); bpf.reset();
+        hold_b = a_odd = 0.f;
+    }
+    // before step 0: x0 = x[0]
+    __device__ __forceinline__ void prime(const TapsPk &kp, float x0) {
+        a_odd = xe.push_pair(kp, pf2{0.f, 0.f}, pf2{x0, 0.f}).x;
+    }
+    // x_next = x[t + 1] (0 beyond the row); the rest as PalDFrontA::step.  ts: the taps as scalars (halves of kp's pairs)
+    template <bool EDGE>
+    __device__ __forceinline__ Mid<float> step(const K &k, const TapsPk &kp, const Taps<float> &ts, FrontLatch<float> &la, int t, float x_next,
+                                               float x_d10, float e_d10, float &e_out) {
+        const int W = k.width;
+        const int n1 = t - 10, n2 = n1 - k.q_e, n3 = n2 - 9;
+        const bool ODD_E = S::RT ? k.odd_e != 0 : S::ODD_E;
+        float a_o = a_odd;
+        float a_even = ts.c0 * x_d10;
+        float b_even = 0.f, b_odd = 0.f;
+        if (!EDGE || (n1 >= 0 && n1 < W + k.q_e)) {
+            if (EDGE) {
+                if (n1 == W - 1) la.a_last = a_o;
+                if (n1 >= W) a_even = a_o = la.a_last;
+            }
+            const float y0 = iir_bp<VP::VB>(bpf, k.ext, a_even);
+            const float y1 = iir_bp<VP::VB>(bpf, k.ext, a_o);
+            if (ODD_E) { b_even = hold_b; b_odd = y0; hold_b = y1; } else { b_even = y0; b_odd = y1; }
+        }
+        if (EDGE && (n2 < 0 || n2 >= W)) b_even = b_odd = 0.f;
+        const pf2 out = xe.push_pair(kp, pf2{0.f, b_even}, pf2{x_next, b_odd});
+        a_odd = out.x;
+        float e = out.y;
+        if (EDGE && (n3 < 0 || n3 >= W)) e = 0.f;
+        e_out = e;
+        Mid<float> m;
+        m.odd = up_e.template push<true>(ts, e);
+        m.even = ts.c0 * e_d10;
+        return m;
+    }
+};
+
 template <int NSEC>
 struct IirStatePk {
     pf2 s1[NSEC], s2[NSEC];
