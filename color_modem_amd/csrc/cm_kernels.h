@@ -843,7 +843,7 @@ __device__ __forceinline__ void run_pair(const Geom &g, const DemodK<float, type
         if (U8) lp = (const float *)((const unsigned char *)g.in + frame * g.in_frame_stride + (long long)luma_row * g.W);
         else lp = g.in + frame * g.in_frame_stride + (long long)luma_row * g.Wp;
         // PAL-D front: two of the three chains packed (cm_stages_pk.h: PalDFrontAPk); its interpolator is fed x[t + 1]
-        constexpr bool PKF = PALD && CM_PALD_PK_FRONT != 0;
+        constexpr bool PKF = CM_PALD_PK_FRONT != 0 && (PALD || BSF);
         TapsPk tkp;
         Taps<float> tks;
         if constexpr (PKF) {
@@ -858,7 +858,7 @@ __device__ __forceinline__ void run_pair(const Geom &g, const DemodK<float, type
         const float *xp;
         if (U8) xp = (const float *)((const unsigned char *)g.in + frame * g.in_frame_stride + (long long)lc.src_row * g.W);
         else xp = g.in + frame * g.in_frame_stride + (long long)lc.src_row * g.Wp;
-        typename std::conditional<PKF, PalDFrontAPk<S>, StageA>::type fa;
+        typename std::conditional<PKF, typename std::conditional<PALD, PalDFrontAPk<S>, QamBsfFrontAPk<S>>::type, StageA>::type fa;
         fa.reset();
         f4 xq = {0.f, 0.f, 0.f, 0.f};          // PKF: x[tb + 4 .. tb + 7], read at the start of a body
         float xw[14], ew[PALD ? 14 : 1];
@@ -908,11 +908,16 @@ __device__ __forceinline__ void run_pair(const Geom &g, const DemodK<float, type
             constexpr int SUB = decltype(sub_tag)::value;
             constexpr bool EDGE = decltype(edge_tag)::value;
             Mid<float> m;
-            if constexpr (PKF) {
+            if constexpr (PKF && PALD) {
                 float e_out;
                 const float x_next = SUB < 3 ? xw[SUB < 3 ? 11 + SUB : 0] : xq.x;
                 m = fa.template step<EDGE>(k, tkp, tks, fla, tau, x_next, xw[SUB], ew[PALD ? SUB : 0], e_out);
                 ew[PALD ? 10 + SUB : 0] = e_out;
+            } else if constexpr (PKF) {
+                float luma_bsf = 0.f;
+                const float x_next = SUB < 3 ? xw[SUB < 3 ? 11 + SUB : 0] : xq.x;
+                m = fa.template step<EDGE>(k, tkp, fla, tau, x_next, xw[SUB], luma_bsf);
+                yring[((tau - lat_luma) & (kYSlots - 1)) * 64 + lane] = luma_bsf;
             } else if constexpr (PALD) {
                 float e_out;
                 m = fa.template step<EDGE>(k, fla, tau, xw[10 + SUB], xw[SUB], ew[PALD ? SUB : 0], e_out);

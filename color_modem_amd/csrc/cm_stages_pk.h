@@ -268,6 +268,57 @@ struct PalDFrontAPk {
     }
 };
 
+// The QAM front end with the band-stop luma (cm_stages.h: QamFrontA<.., true>) the same way: lane x = up2(x) one sample ahead,
+// lane y = the luma decimator.  Bit-identical to the scalar chains.
+template <class S>
+struct QamBsfFrontAPk {
+    typedef DemodK<float, S> K;
+    typedef VPolicy<CM_V_QAM> VP;
+    HalfbandChainPk xy;
+    IirState<float, S::NE> bpf;
+    IirState<float, S::NR> bsf;
+    float hold_b, hold_y, a_odd;
+
+    __device__ __forceinline__ void reset() {
+        xy.reset(); bpf.reset(); bsf.reset();
+        hold_b = hold_y = a_odd = 0.f;
+    }
+    __device__ __forceinline__ void prime(const TapsPk &kp, float x0) {
+        a_odd = xy.push_pair(kp, pf2{0.f, 0.f}, pf2{x0, 0.f}).x;
+    }
+    template <bool EDGE>
+    __device__ __forceinline__ Mid<float> step(const K &k, const TapsPk &kp, FrontLatch<float> &la, int t, float x_next, float x_d10, float &luma_out) {
+        const int W = k.width;
+        const int n1 = t - 10;
+        const bool ODD_E = S::RT ? k.odd_e != 0 : S::ODD_E, ODD_R = S::RT ? k.odd_r != 0 : S::ODD_R;
+        float a_o = a_odd;
+        float a_even = kp.c0.x * x_d10;
+        if (EDGE) {
+            if (n1 == W - 1) la.a_last = a_o;
+            if (n1 >= W) a_even = a_o = la.a_last;
+        }
+        Mid<float> m;
+        m.even = m.odd = 0.f;
+        if (!EDGE || (n1 >= 0 && n1 < W + k.q_e)) {
+            const float y0 = iir_bp<VP::VB>(bpf, k.ext, a_even);
+            const float y1 = iir_bp<VP::VB>(bpf, k.ext, a_o);
+            if (ODD_E) { m.even = hold_b; m.odd = y0; hold_b = y1; } else { m.even = y0; m.odd = y1; }
+        }
+        const int nr = n1 - k.q_r;
+        float r_even = 0.f, r_odd = 0.f;
+        if (!EDGE || (n1 >= 0 && n1 < W + k.q_r)) {
+            const float y0 = iir_sym<false>(bsf, k.rem, a_even);
+            const float y1 = iir_sym<false>(bsf, k.rem, a_o);
+            if (ODD_R) { r_even = hold_y; r_odd = y0; hold_y = y1; } else { r_even = y0; r_odd = y1; }
+        }
+        if (EDGE && (nr < 0 || nr >= W)) r_even = r_odd = 0.f;
+        const pf2 out = xy.push_pair(kp, pf2{0.f, r_even}, pf2{x_next, r_odd});
+        a_odd = out.x;
+        luma_out = out.y * k.luma_gain;
+        return m;
+    }
+};
+
 template <int NSEC>
 struct IirStatePk {
     pf2 s1[NSEC], s2[NSEC];
