@@ -747,11 +747,20 @@ constexpr int kMidRing = 2 * 2 * 64 * 4;    // floats: [buffer][even | odd][lane
 // for the tuned shapes, 64 for the run-time shape (high sampling rates; it runs 4 workgroups per CU, so the LDS is there)
 template <class S> constexpr int luma_ring_slots() { return S::RT ? 64 : 32; }
 
+#ifndef CM_QAM_SHORT_RING
+#define CM_QAM_SHORT_RING 1
+#endif
 constexpr int kLumaSlots = 2 * 64 * 4;      // floats: [buffer][lane][4 steps] luma source samples fetched by A for B
 // CM_LUMA_RING: blocks of [lane][4 steps] x samples; A writes x[tb - 10 + o .. + 3] at the end of body tb, B reads the block
 // m bodies later, lat_out = 4 m + 10 - o; A runs at most two blocks ahead of B's read, so m + 2 blocks are live
 // (the host checks lat_out against this: cm_api.hip).  11 KiB for PAL-BG (lat_out 46 = the limit), 12 KiB for the order-6 band-pass shapes, 20 KiB for the run-time shape.
-template <class S, int FRONT = 0> constexpr int luma_delay_blocks() { return S::RT ? 20 : (S::NE >= 3 ? 12 : 11 - ring_window<S, FRONT>() / 4); }
+// The QAM front end is shorter (lat_out 26 / 28 / 32 for the PAL-BG / NTSC / NTSC-A shapes against 46 / 47 behind the PAL-D
+// front end): its ring is sized for that, so that those instances fit six workgroups per CU as well (25 instead of 30 KiB).
+template <class S, int FRONT = 0> constexpr int luma_delay_blocks() {
+    if (S::RT) return 20;
+    if (FRONT == FRONT_QAM && CM_QAM_SHORT_RING) return ((S::NE >= 4 ? 32 : (S::NE == 3 ? 28 : 26)) - 10 - ring_window<S, FRONT>() + 3) / 4 + 2;
+    return S::NE >= 3 ? 12 : 11 - ring_window<S, FRONT>() / 4;
+}
 template <class S, int FRONT = 0> constexpr int luma_delay_max_latency() { return 4 * (luma_delay_blocks<S, FRONT>() - 2) + 10 + ring_window<S, FRONT>(); }
 
 template <class Cfg>
