@@ -179,7 +179,7 @@ struct cm_plan {
 namespace {
 
 template <class S>
-bool make_pass(const cm_plan_desc &d, bool pald, bool bsf, const cm_lane_table &tb, Pass &pass, std::string &err, bool pair) {
+bool make_pass(const cm_plan_desc &d, bool pald, bool bsf, const cm_lane_table &tb, Pass &pass, std::string &err, bool pair, int depth = 0) {
     DemodK<float, S> k;
     DemodScales sc;
     if (!build_demod_k<float, S>(d, pald, bsf, k, sc, err)) return false;
@@ -189,8 +189,11 @@ bool make_pass(const cm_plan_desc &d, bool pald, bool bsf, const cm_lane_table &
         if (lat_out + 8 > kCarrierPad) { err = "pipeline latency beyond the carrier table padding"; return false; }
         const int luma_lag = lat_out - (10 + k.q_r + 9);   // steps between the band-stop luma sample and its use
         if (bsf && (pair ? luma_lag + 12 > luma_ring_slots<S>() : luma_lag > 15)) { err = "band-stop luma delay beyond its LDS ring"; return false; }
-        if (CM_LUMA_RING && !bsf && pair && (pald ? lat_out > luma_delay_max_latency<S, 1>() : lat_out > luma_delay_max_latency<S, 0>())) { err = "pipeline latency beyond the luma delay ring"; return false; }
-        if (CM_LUMA_RING && !bsf && pair && lat_out < 10 + (pald ? ring_window<S, 1>() : ring_window<S, 0>())) { err = "pipeline latency below the luma window"; return false; }
+        const bool lcut = CM_QAM_LPF_IN_A != 0 && !pald && !bsf && depth >= 2 && !S::RT;     // PassCfg::kLcutCfg
+        const int ring_max = pald ? luma_delay_max_latency<S, 1>() : (lcut ? luma_delay_max_latency<S, 0, true>() : luma_delay_max_latency<S, 0>());
+        const int ring_win = pald ? ring_window<S, 1>() : (lcut ? ring_window<S, 0, true>() : ring_window<S, 0>());
+        if (CM_LUMA_RING && !bsf && pair && lat_out > ring_max) { err = "pipeline latency beyond the luma delay ring"; return false; }
+        if (CM_LUMA_RING && !bsf && pair && lat_out < 10 + ring_win) { err = "pipeline latency below the luma window"; return false; }
     }
     pass.k.resize(sizeof(k));
     std::memcpy(pass.k.data(), &k, sizeof(k));
@@ -210,7 +213,7 @@ bool make_pass(const cm_plan_desc &d, bool pald, bool bsf, const cm_lane_table &
 
 template <class S>
 bool make_passes(cm_plan *p, const cm_plan_desc &d, bool pald, bool bsf, bool first, std::string &err) {
-    if (!make_pass<S>(d, pald, bsf, d.demod_main, p->main, err, p->pair)) return false;
+    if (!make_pass<S>(d, pald, bsf, d.demod_main, p->main, err, p->pair, p->main.depth)) return false;
     if (first && !make_pass<S>(d, false, true, d.demod_first, p->first, err, p->pair)) return false;
     p->has_first = first;
     return true;

@@ -146,8 +146,13 @@ typedef const __attribute__((address_space(4))) f16u const_f16;
 // PAL-D front end on the PAL-BG filter shape: CM_RING_WINDOW; on the order-6 band-pass shapes its stage A has no registers
 // to spare.  QAM front end: CM_RING_WINDOW_QAM (16 brings the NTSC comb decoder to 26 KiB as well, measured without effect:
 // 2.165 ms either way - off).  Run-time shape: none (it runs 4 workgroups per CU).
-template <class S, int FRONT> constexpr int ring_window() {
-    return S::RT ? 0 : (FRONT == 1 ? (S::NE < 3 ? CM_RING_WINDOW : 0) : CM_RING_WINDOW_QAM);
+// LC: the instance cuts the pair behind the detector low-pass (two-line combs on the QAM front end: CM_QAM_LPF_IN_A); its
+// hand-over ring is 8 KiB instead of 4, and CM_RING_WINDOW_LCUT samples in stage A's registers bring it back to 25 - 26 KiB.
+#ifndef CM_RING_WINDOW_LCUT
+#define CM_RING_WINDOW_LCUT 12
+#endif
+template <class S, int FRONT, bool LC = false> constexpr int ring_window() {
+    return S::RT ? 0 : (FRONT == 1 ? (S::NE < 3 ? CM_RING_WINDOW : 0) : (LC ? CM_RING_WINDOW_LCUT : CM_RING_WINDOW_QAM));
 }
 // Output tiles are [row = lane][kTile samples]; the 16-byte quad a lane writes is XORed with lane bits CM_TILE_SWZ, +1 so that
 // the one ds_write_b32 per plane and step of 64 lanes spreads over more banks (rows are 64 bytes apart).
@@ -176,6 +181,12 @@ __device__ __forceinline__ const float *ptr_from(int byte_index, const float *p)
 // U8: the ImageModem byte boundary fused into the kernel (ref image.py:7-8, 24-25, 62, 65-71): composite is
 // uint8 [F][H][W] and enters through (5 * (byte / 255) - 1) / 3; the output is interleaved uint8 RGB
 // [F][H][W][3] = rint(255 * clip(x, 0, 1)).  The LDS tiles hold bytes in that mode (same float-sized budget).
+#ifndef CM_QAM_LPF_IN_A
+#define CM_QAM_LPF_IN_A 1
+#endif
+#ifndef CM_LCUT_DEPTH2_WAVES
+#define CM_LCUT_DEPTH2_WAVES 3
+#endif
 template <class S_, int FRONT_, bool BSF_, int DEPTH_, int TILE_, bool U8_ = false, bool NOTCH_ = false, bool MINAVG_ = false>
 struct PassCfg {
     typedef S_ S;
@@ -190,7 +201,11 @@ struct PassCfg {
     static constexpr int kPairLdsIn = U8_ ? 64 * kInTile / 4 : 64 * kPairInTile;   // floats
     // wave-pair kernels: 3 waves per SIMD need <= 168 VGPRs; the instances with more per-lane state in stage B (a second
     // line of history, the notch, the second combination of minavg) would spill there and get 2 waves per SIMD instead
-    static constexpr int kPairWaves = (DEPTH_ >= 2 || NOTCH_ || MINAVG_ || S_::NE >= 4 || S_::NP >= 2 || S_::RT) ? 2 : 3;
+    // (with the cut behind the detector low-pass, CM_QAM_LPF_IN_A, stage B of the two-line combs sheds the low-pass state and
+    // its coefficients: CM_LCUT_DEPTH2_WAVES = 3 asks for 168 VGPRs there too)
+    static constexpr bool kLcutCfg = CM_QAM_LPF_IN_A != 0 && FRONT_ == 0 && !BSF_ && DEPTH_ >= 2 && !S_::RT;
+    static constexpr int kPairWaves = (NOTCH_ || MINAVG_ || S_::NE >= 4 || S_::NP >= 2 || S_::RT) ? 2
+                                    : (DEPTH_ >= 2 ? (kLcutCfg ? CM_LCUT_DEPTH2_WAVES : 2) : 3);
     // which kernel structure runs this instance.  Since the luma delay ring (CM_LUMA_RING) every instance runs on the wave
     // pair - those with more per-lane state in stage B at 2 waves per SIMD (measured: Pal3D 2.92 -> 2.72 ms, Simple3DComb(
     // NtscComb) 2.43 -> 2.34 ms per 1000 frames against the one-wave kernel, profiles/r01_pair_notes.md section 9).
@@ -743,6 +758,13 @@ __device__ __forceinline__ void run_lane(const Geom &g, const DemodK<float, type
 // block i, B before reading it - so A runs at most one block ahead and B never reads a block that is not complete.
 // =============================================================================================
 constexpr int kMidRing = 2 * 2 * 64 * 4;    // floats: [buffer][even | odd][lane][4 steps]
+// 1: the instances on the QAM front end without band-stop luma (the combs: NtscComb, Pal3D, SimpleComb, Simple3DComb ...)
+// cut the pair BEHIND the detector low-pass: stage A there is only up2 + band-pass (about 45 FMA-equivalents per pixel
+// against 145 in stage B), so it takes the detector products and the packed low-pass as well (52 more) and hands over the
+// two low-passed pairs instead of one 2x-rate pair
+#ifndef CM_QAM_LPF_IN_A
+#define CM_QAM_LPF_IN_A 1
+#endif
 // band-stop luma ring of the pair kernels, written by A and read by B (lat_out - lat_luma + up to 12) steps later: 32 slots
 // for the tuned shapes, 64 for the run-time shape (high sampling rates; it runs 4 workgroups per CU, so the LDS is there)
 template <class S> constexpr int luma_ring_slots() { return S::RT ? 64 : 32; }
@@ -756,19 +778,25 @@ constexpr int kLumaSlots = 2 * 64 * 4;      // floats: [buffer][lane][4 steps] l
 // (the host checks lat_out against this: cm_api.hip).  11 KiB for PAL-BG (lat_out 46 = the limit), 12 KiB for the order-6 band-pass shapes, 20 KiB for the run-time shape.
 // The QAM front end is shorter (lat_out 26 / 28 / 32 for the PAL-BG / NTSC / NTSC-A shapes against 46 / 47 behind the PAL-D
 // front end): its ring is sized for that, so that those instances fit six workgroups per CU as well (25 instead of 30 KiB).
-template <class S, int FRONT = 0> constexpr int luma_delay_blocks() {
+template <class S, int FRONT = 0, bool LC = false> constexpr int luma_delay_blocks() {
     if (S::RT) return 20;
-    if (FRONT == FRONT_QAM && CM_QAM_SHORT_RING) return ((S::NE >= 4 ? 32 : (S::NE == 3 ? 28 : 26)) - 10 - ring_window<S, FRONT>() + 3) / 4 + 2;
-    return S::NE >= 3 ? 12 : 11 - ring_window<S, FRONT>() / 4;
+    if (FRONT == FRONT_QAM && CM_QAM_SHORT_RING) return ((S::NE >= 4 ? 32 : (S::NE == 3 ? 28 : 26)) - 10 - ring_window<S, FRONT, LC>() + 3) / 4 + 2;
+    return S::NE >= 3 ? 12 : 11 - ring_window<S, FRONT, LC>() / 4;
 }
-template <class S, int FRONT = 0> constexpr int luma_delay_max_latency() { return 4 * (luma_delay_blocks<S, FRONT>() - 2) + 10 + ring_window<S, FRONT>(); }
+template <class S, int FRONT = 0, bool LC = false> constexpr int luma_delay_max_latency() {
+    return 4 * (luma_delay_blocks<S, FRONT, LC>() - 2) + 10 + ring_window<S, FRONT, LC>();
+}
 
 template <class Cfg>
 struct PairLds {
     static constexpr int kIn = Cfg::kPairLdsIn, kOut = Cfg::kLdsOut;
     static constexpr int kY = Cfg::BSF ? luma_ring_slots<typename Cfg::S>() * 64
-                                       : (CM_LUMA_RING ? luma_delay_blocks<typename Cfg::S, Cfg::FRONT>() * 256 : kLumaSlots);
-    static constexpr int kFloats = kIn + kMidRing + kOut + kY;
+                                       : (CM_LUMA_RING ? luma_delay_blocks<typename Cfg::S, Cfg::FRONT, Cfg::kLcutCfg>() * 256 : kLumaSlots);
+    // hand-over ring: the 2x-rate pair (even, odd) per step, or - where stage A also takes the detector products and the
+    // low-pass (LCUT: the QAM front end without the band-stop luma) - the two low-passed pairs (q_e, q_o)
+    static constexpr bool kLcut = Cfg::kLcutCfg;
+    static constexpr int kMid = kLcut ? 2 * kMidRing : kMidRing;
+    static constexpr int kFloats = kIn + kMid + kOut + kY;
 };
 template <>
 struct PairLds<NoPass> {
@@ -802,8 +830,8 @@ __device__ __forceinline__ void run_pair(const Geom &g, const DemodK<float, type
     constexpr int kYSlots = luma_ring_slots<S>();
     constexpr bool LRING = CM_LUMA_RING && !BSF;         // luma source samples through the LDS delay ring
     constexpr int kIT = Cfg::kPairInTile;                // samples per input tile row
-    constexpr int kLB = luma_delay_blocks<S, FRONT>();
-    constexpr int kWinX = ring_window<S, FRONT>();        // extra x samples stage A keeps behind its window
+    constexpr int kLB = luma_delay_blocks<S, FRONT, Cfg::kLcutCfg>();
+    constexpr int kWinX = ring_window<S, FRONT, Cfg::kLcutCfg>();        // extra x samples stage A keeps behind its window
     typedef typename std::conditional<PALD, PalDFront<float, S>, QamFront<float, S, BSF>>::type Front;
     typedef typename Front::StageA StageA;
     typedef typename Front::StageB StageB;
@@ -813,7 +841,9 @@ __device__ __forceinline__ void run_pair(const Geom &g, const DemodK<float, type
 
     lds_float *itile = lds;
     lds_float *ring = lds + PairLds<Cfg>::kIn;
-    lds_float *otile_base = ring + kMidRing;
+    constexpr bool LCUT = PairLds<Cfg>::kLcut;
+    constexpr int kMid = PairLds<Cfg>::kMid;
+    lds_float *otile_base = ring + kMid;
     lds_float *yring = otile_base + PairLds<Cfg>::kOut;
 
     const int lane = threadIdx.x & 63;
@@ -869,6 +899,14 @@ __device__ __forceinline__ void run_pair(const Geom &g, const DemodK<float, type
         else xp = g.in + frame * g.in_frame_stride + (long long)lc.src_row * g.Wp;
         typename std::conditional<PKF, typename std::conditional<PALD, PalDFrontAPk<S>, QamBsfFrontAPk<S>>::type, StageA>::type fa;
         fa.reset();
+        // LCUT: detector products and low-pass in this stage
+        SosPk<S::NL> a_lpk;
+        DetectorLpfPk<S> a_lpf;
+        pf2 a_p_last = {0.f, 0.f};
+        if constexpr (LCUT) {
+            a_lpk.load(k.lpf, false);
+            a_lpf.reset();
+        }
         f4 xq = {0.f, 0.f, 0.f, 0.f};          // PKF: x[tb + 4 .. tb + 7], read at the start of a body
         float xw[14], ew[PALD ? 14 : 1];
         float xo[kWinX >= 8 ? kWinX : 1];        // x[tb - 10 - kWinX ..]: older than xw
@@ -1001,9 +1039,30 @@ __device__ __forceinline__ void run_pair(const Geom &g, const DemodK<float, type
 #pragma unroll
                 for (int j = 0; j < 10; ++j) ew[PALD ? j : 0] = ew[PALD ? j + 4 : 0];
             }
-            lds_float *slot = ring + ((tb >> 2) & 1) * (kMidRing / 2) + lane * 4;
-            *(lds_f4 *)slot = f4{me[0], me[1], me[2], me[3]};
-            *(lds_f4 *)(slot + 256) = f4{mo[0], mo[1], mo[2], mo[3]};
+            lds_float *slot = ring + ((tb >> 2) & 1) * (kMid / 2) + lane * 4;
+            if constexpr (LCUT) {
+                // products with the phase-free carriers of the four pairs nd = tb - front_off + s, low-pass on (cos, sin)
+                const f16u c4a = *(const_f16 *)(g.carrier4 + 4 * (long long)(tb - front_off));
+                pf2 qe[4], qo[4];
+                {
+                    const pf2 m0 = {me[0], mo[0]}, m1 = {me[1], mo[1]}, m2 = {me[2], mo[2]}, m3 = {me[3], mo[3]};
+                    a_lpf.template step<EDGE_A>(k, a_lpk, a_p_last, tb + 0 - front_off, pk_mul_bs<0>(m0, pf2{c4a[0], c4a[1]}),
+                                                pk_mul_bs<1>(m0, pf2{c4a[2], c4a[3]}), qe[0], qo[0]);
+                    a_lpf.template step<EDGE_A>(k, a_lpk, a_p_last, tb + 1 - front_off, pk_mul_bs<0>(m1, pf2{c4a[4], c4a[5]}),
+                                                pk_mul_bs<1>(m1, pf2{c4a[6], c4a[7]}), qe[1], qo[1]);
+                    a_lpf.template step<EDGE_A>(k, a_lpk, a_p_last, tb + 2 - front_off, pk_mul_bs<0>(m2, pf2{c4a[8], c4a[9]}),
+                                                pk_mul_bs<1>(m2, pf2{c4a[10], c4a[11]}), qe[2], qo[2]);
+                    a_lpf.template step<EDGE_A>(k, a_lpk, a_p_last, tb + 3 - front_off, pk_mul_bs<0>(m3, pf2{c4a[12], c4a[13]}),
+                                                pk_mul_bs<1>(m3, pf2{c4a[14], c4a[15]}), qe[3], qo[3]);
+                }
+                *(lds_f4 *)slot = f4{qe[0].x, qe[1].x, qe[2].x, qe[3].x};
+                *(lds_f4 *)(slot + 256) = f4{qe[0].y, qe[1].y, qe[2].y, qe[3].y};
+                *(lds_f4 *)(slot + 512) = f4{qo[0].x, qo[1].x, qo[2].x, qo[3].x};
+                *(lds_f4 *)(slot + 768) = f4{qo[0].y, qo[1].y, qo[2].y, qo[3].y};
+            } else {
+                *(lds_f4 *)slot = f4{me[0], me[1], me[2], me[3]};
+                *(lds_f4 *)(slot + 256) = f4{mo[0], mo[1], mo[2], mo[3]};
+            }
             if (LRING) {
                 *(lds_f4 *)(lring + lr_w * 256 + lane * 4) = lum_blk;
                 lr_w = lr_w + 1 == kLB ? 0 : lr_w + 1;
@@ -1038,7 +1097,7 @@ __device__ __forceinline__ void run_pair(const Geom &g, const DemodK<float, type
     // ======================================= stage B ===========================================
     // packed float32 throughout (cm_stages_pk.h): pairs (cos, sin) up to the base pair, (u, v) behind it
     StageBK<S> kb;
-    kb.load(k);
+    kb.load(k, !LCUT);
     const float *op;   // U8: strides count bytes; the pointer is carried as an opaque 64-bit value
     if (U8) op = lc.store_ok ? (const float *)((unsigned char *)g.out + frame * g.out_frame_stride + (long long)lc.out_row * g.out_row_stride)
                              : nullptr;
@@ -1089,7 +1148,9 @@ __device__ __forceinline__ void run_pair(const Geom &g, const DemodK<float, type
     auto sub_b = [&](auto sub_tag, auto edge_tag, pf2 &p_last, pf2 &uv_last, int tau, pf2 p_e, pf2 p_o, pf2 sc) {
         constexpr int SUB = decltype(sub_tag)::value;
         constexpr bool EDGE = decltype(edge_tag)::value;
-        pf2 base = det.template step<EDGE>(k, kb, p_last, tau - front_off, p_e, p_o);
+        pf2 base;
+        if constexpr (LCUT) base = det.dn.push_pair(kb.taps, p_e, p_o);      // (p_e, p_o) = stage A's low-passed pairs
+        else base = det.template step<EDGE>(k, kb, p_last, tau - front_off, p_e, p_o);
         // the back end handles the PREVIOUS step's base pair: its neighbours were requested then
         const int n6 = tau - lat_front - 1, n7 = n6 - sp;
         pf2 uv = back.combine(lk, base_prev, b1_prev, b2_prev);
@@ -1116,7 +1177,13 @@ __device__ __forceinline__ void run_pair(const Geom &g, const DemodK<float, type
     PAIR_BARRIER(d_bar);
     f4 me = *(const lds_f4 *)(ring + lane * 4);
     f4 mo = *(const lds_f4 *)(ring + lane * 4 + 256);
-    f16u c4 = load_c4(0);
+    f4 me2 = {0.f, 0.f, 0.f, 0.f}, mo2 = me2;      // LCUT: (me, mo) = q_e (cos, sin), (me2, mo2) = q_o
+    if constexpr (LCUT) {
+        me2 = *(const lds_f4 *)(ring + lane * 4 + 512);
+        mo2 = *(const lds_f4 *)(ring + lane * 4 + 768);
+    }
+    f16u c4;
+    if constexpr (!LCUT) c4 = load_c4(0);
     f8u c2 = load_c2(0);
     auto body_b = [&](int tb, auto edge_tag, pf2 &p_last, pf2 &uv_last) {
         constexpr bool EDGE = decltype(edge_tag)::value;
@@ -1128,23 +1195,38 @@ __device__ __forceinline__ void run_pair(const Geom &g, const DemodK<float, type
             lw = *(const lds_f4 *)(lring + ((tb >> 2) & 1) * (kLumaSlots / 2) + lane * 4);   // left there by A
         }
         // first half: detector products and re-modulation carriers of sub-steps 0, 1
-        pf2 pe0 = pk_mul_bs<0>(pf2{me.x, me.y}, pf2{c4[0], c4[1]}), po0 = pk_mul_bs<0>(pf2{mo.x, mo.y}, pf2{c4[2], c4[3]});
-        pf2 pe1 = pk_mul_bs<1>(pf2{me.x, me.y}, pf2{c4[4], c4[5]}), po1 = pk_mul_bs<1>(pf2{mo.x, mo.y}, pf2{c4[6], c4[7]});
+        pf2 pe0, po0, pe1, po1;
+        if constexpr (LCUT) {
+            pe0 = pf2{me.x, mo.x}; po0 = pf2{me2.x, mo2.x};
+            pe1 = pf2{me.y, mo.y}; po1 = pf2{me2.y, mo2.y};
+        } else {
+            pe0 = pk_mul_bs<0>(pf2{me.x, me.y}, pf2{c4[0], c4[1]}); po0 = pk_mul_bs<0>(pf2{mo.x, mo.y}, pf2{c4[2], c4[3]});
+            pe1 = pk_mul_bs<1>(pf2{me.x, me.y}, pf2{c4[4], c4[5]}); po1 = pk_mul_bs<1>(pf2{mo.x, mo.y}, pf2{c4[6], c4[7]});
+        }
         pf2 sc0 = back.remod(lk, pf2{c2[0], c2[1]}), sc1 = back.remod(lk, pf2{c2[2], c2[3]});
         sub_b(std::integral_constant<int, 0>(), edge_tag, p_last, uv_last, tb + 0, pe0, po0, sc0);
         if (s_flush == 0) maybe_flush(tb + 0);
         sub_b(std::integral_constant<int, 1>(), edge_tag, p_last, uv_last, tb + 1, pe1, po1, sc1);
         if (s_flush == 1) maybe_flush(tb + 1);
         // second half; once its products are formed this block and its carriers are dead: fetch the next ones
-        pf2 pe2 = pk_mul_bs<0>(pf2{me.z, me.w}, pf2{c4[8], c4[9]}), po2 = pk_mul_bs<0>(pf2{mo.z, mo.w}, pf2{c4[10], c4[11]});
-        pf2 pe3 = pk_mul_bs<1>(pf2{me.z, me.w}, pf2{c4[12], c4[13]}), po3 = pk_mul_bs<1>(pf2{mo.z, mo.w}, pf2{c4[14], c4[15]});
+        pf2 pe2, po2, pe3, po3;
+        if constexpr (LCUT) {
+            pe2 = pf2{me.z, mo.z}; po2 = pf2{me2.z, mo2.z};
+            pe3 = pf2{me.w, mo.w}; po3 = pf2{me2.w, mo2.w};
+        } else {
+            pe2 = pk_mul_bs<0>(pf2{me.z, me.w}, pf2{c4[8], c4[9]}); po2 = pk_mul_bs<0>(pf2{mo.z, mo.w}, pf2{c4[10], c4[11]});
+            pe3 = pk_mul_bs<1>(pf2{me.z, me.w}, pf2{c4[12], c4[13]}); po3 = pk_mul_bs<1>(pf2{mo.z, mo.w}, pf2{c4[14], c4[15]});
+        }
         pf2 sc2 = back.remod(lk, pf2{c2[4], c2[5]}), sc3 = back.remod(lk, pf2{c2[6], c2[7]});
         if (nxt < T) {
             PAIR_BARRIER(d_bar);   // block nxt / 4 of the ring is complete
-            const lds_float *slot = ring + ((nxt >> 2) & 1) * (kMidRing / 2) + lane * 4;
+            const lds_float *slot = ring + ((nxt >> 2) & 1) * (kMid / 2) + lane * 4;
             me = *(const lds_f4 *)slot;
             mo = *(const lds_f4 *)(slot + 256);
-            c4 = load_c4(nxt);
+            if constexpr (LCUT) {
+                me2 = *(const lds_f4 *)(slot + 512);
+                mo2 = *(const lds_f4 *)(slot + 768);
+            } else c4 = load_c4(nxt);
             c2 = load_c2(nxt);
         }
         sub_b(std::integral_constant<int, 2>(), edge_tag, p_last, uv_last, tb + 2, pe2, po2, sc2);
@@ -1165,10 +1247,13 @@ __device__ __forceinline__ void run_pair(const Geom &g, const DemodK<float, type
     int tb = 0;
     for (; tb < t_skip; tb += 4) {
         PAIR_BARRIER(d_bar);   // t_skip < T: block tb / 4 + 1 of the ring exists
-        const lds_float *slot = ring + (((tb + 4) >> 2) & 1) * (kMidRing / 2) + lane * 4;
+        const lds_float *slot = ring + (((tb + 4) >> 2) & 1) * (kMid / 2) + lane * 4;
         me = *(const lds_f4 *)slot;
         mo = *(const lds_f4 *)(slot + 256);
-        c4 = load_c4(tb + 4);
+        if constexpr (LCUT) {
+            me2 = *(const lds_f4 *)(slot + 512);
+            mo2 = *(const lds_f4 *)(slot + 768);
+        } else c4 = load_c4(tb + 4);
         c2 = load_c2(tb + 4);
         if (LRING) lr_r = lr_r + 1 == kLB ? 0 : lr_r + 1;
     }

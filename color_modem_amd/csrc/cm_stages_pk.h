@@ -382,15 +382,48 @@ struct StageBK {
     SosPkS<S::NP> pre;
     pf2 m_u, m_v;                  // colour matrix columns of u and v, rows (r, g): SGPR pairs
     float m_yr, m_yg, m_b[3];      // luma column of r and g; row of b
-    __device__ __forceinline__ void load(const DemodK<float, S> &k) {
+    __device__ __forceinline__ void load(const DemodK<float, S> &k, bool with_lpf = true) {
         taps.load(k.taps);
-        lpf.load(k.lpf, false);
+        if (with_lpf) lpf.load(k.lpf, false);
         pre.load(k.pre);
         m_u = pf2{take_s(k.m[0][1]), take_s(k.m[1][1])};
         m_v = pf2{take_s(k.m[0][2]), take_s(k.m[1][2])};
         m_yr = take_s(k.m[0][0]);
         m_yg = take_s(k.m[1][0]);
         m_b[0] = take_s(k.m[2][0]); m_b[1] = take_s(k.m[2][1]); m_b[2] = take_s(k.m[2][2]);
+    }
+};
+
+// =============================================================================================
+// The low-pass half of DetectorPk on its own: for the instances whose stage A takes the detector products and the low-pass
+// (cm_kernels.h: LCUT) and hands (q_e, q_o) over; stage B then only pushes them into its decimator.  Same operations, same
+// order as DetectorPk::step.
+// =============================================================================================
+template <class S>
+struct DetectorLpfPk {
+    typedef DemodK<float, S> K;
+    IirStatePk<S::NL> lpf;
+    pf2 hold;
+    __device__ __forceinline__ void reset() {
+        lpf.reset();
+        hold = pf2{0.f, 0.f};
+    }
+    template <bool EDGE>
+    __device__ __forceinline__ void step(const K &k, const SosPk<S::NL> &lk, pf2 &p_last, int nd, pf2 p_e, pf2 p_o, pf2 &q_e, pf2 &q_o) {
+        const int W = k.width;
+        const int n5 = nd - k.q_l;
+        const bool ODD_L = S::RT ? k.odd_l != 0 : S::ODD_L;
+        q_e = q_o = pf2{0.f, 0.f};
+        if (!EDGE || (nd >= 0 && nd < W + k.q_l)) {
+            if (EDGE) {
+                if (nd == W - 1) p_last = p_o;
+                if (nd >= W) p_e = p_o = p_last;
+            }
+            const pf2 y0 = iir_sym_pk<0, S::NL>(lpf, lk, p_e);
+            const pf2 y1 = iir_sym_pk<0, S::NL>(lpf, lk, p_o);
+            if (ODD_L) { q_e = hold; q_o = y0; hold = y1; } else { q_e = y0; q_o = y1; }
+        }
+        if (EDGE && (n5 < 0 || n5 >= W)) q_e = q_o = pf2{0.f, 0.f};
     }
 };
 
