@@ -82,8 +82,14 @@ int launch_demod(const Geom &gm, const void *km, const Geom &gf, const void *kf,
     af.g = gf;
     af.k = kf ? *static_cast<const DemodK<float, S> *>(kf) : am.k;
     // PassCfg::kUsePair: the wave pair for every instance unless the build asks for the earlier selection
-    if constexpr (CM_PAIR != 0 && Main::kUsePair)
-        hipLaunchKernelGGL((demod_pair_kernel<Main, First>), dim3(n_first + n_main), dim3(128), 0, stream, am, af, n_first);
+    if constexpr (CM_PAIR != 0 && Main::kUsePair) {
+        int floats = pair_lds_floats<Main>(am.k);
+        if constexpr (!std::is_same<First, NoPass>::value) {
+            const int ff = pair_lds_floats<First>(af.k);
+            if (ff > floats) floats = ff;
+        }
+        hipLaunchKernelGGL((demod_pair_kernel<Main, First>), dim3(n_first + n_main), dim3(128), sizeof(float) * (size_t)floats, stream, am, af, n_first);
+    }
     else
         hipLaunchKernelGGL((demod_kernel<Main, First>), dim3(n_first + n_main), dim3(64), 0, stream, am, af, n_first);
     hipError_t e = hipGetLastError();
@@ -101,7 +107,14 @@ int launch_demod_blk(const Geom &gm, const void *km, const Geom &gf, const void 
     am.k = *static_cast<const DemodK<float, S> *>(km);
     af.g = gf;
     af.k = kf ? *static_cast<const DemodK<float, S> *>(kf) : am.k;
-    if (n_first > 0) hipLaunchKernelGGL((demod_pair_kernel<Main, First>), dim3(n_first), dim3(128), 0, stream, am, af, n_first);
+    if (n_first > 0) {
+        int floats = pair_lds_floats<Main>(am.k);
+        if constexpr (!std::is_same<First, NoPass>::value) {
+            const int ff = pair_lds_floats<First>(af.k);
+            if (ff > floats) floats = ff;
+        }
+        hipLaunchKernelGGL((demod_pair_kernel<Main, First>), dim3(n_first), dim3(128), sizeof(float) * (size_t)floats, stream, am, af, n_first);
+    }
     if (n_main > 0)
         hipLaunchKernelGGL((demod_blk_kernel<S, QE, QL>), dim3(n_main), dim3(64), 0, stream, am, (const BlkTiles *)gm.blk_tiles);
     hipError_t e = hipGetLastError();

@@ -802,6 +802,18 @@ template <>
 struct PairLds<NoPass> {
     static constexpr int kFloats = 0;
 };
+// LDS floats of one pass of the pair kernel (the launch passes the larger of main and first pass as dynamic LDS): the tuned
+// shapes' constant, or - run-time shape, luma delay ring - what the plan's latency needs (run_pair: kLB = lr_m + 2 blocks)
+template <class Cfg>
+inline int pair_lds_floats(const DemodK<float, typename Cfg::S> &k) {
+    typedef typename Cfg::S S;
+    if (!S::RT || Cfg::BSF || !CM_LUMA_RING) return PairLds<Cfg>::kFloats;
+    const int lat_front = Cfg::FRONT == FRONT_PALD ? 10 + k.q_e + 9 + 10 + k.q_l + 9 : 10 + k.q_e + k.q_l + 9;
+    const int lat_out = lat_front + 1 + k.s_p;
+    constexpr int kWinX = ring_window<S, Cfg::FRONT, Cfg::kLcutCfg>();
+    const int lr_o = (10 + kWinX - lat_out) & 3, lr_m = (lat_out - 10 - kWinX + lr_o) >> 2;
+    return PairLds<Cfg>::kIn + PairLds<Cfg>::kMid + PairLds<Cfg>::kOut + (lr_m + 2) * 256;
+}
 
 #ifdef CM_DIAG
 // diagnostic builds: cycles spent waiting in the barrier are summed into acc
@@ -830,7 +842,7 @@ __device__ __forceinline__ void run_pair(const Geom &g, const DemodK<float, type
     constexpr int kYSlots = luma_ring_slots<S>();
     constexpr bool LRING = CM_LUMA_RING && !BSF;         // luma source samples through the LDS delay ring
     constexpr int kIT = Cfg::kPairInTile;                // samples per input tile row
-    constexpr int kLB = luma_delay_blocks<S, FRONT, Cfg::kLcutCfg>();
+    constexpr int kLBmax = luma_delay_blocks<S, FRONT, Cfg::kLcutCfg>();   // tuned shapes: the ring's size; run-time shape: its limit
     constexpr int kWinX = ring_window<S, FRONT, Cfg::kLcutCfg>();        // extra x samples stage A keeps behind its window
     typedef typename std::conditional<PALD, PalDFront<float, S>, QamFront<float, S, BSF>>::type Front;
     typedef typename Front::StageA StageA;
@@ -874,6 +886,8 @@ __device__ __forceinline__ void run_pair(const Geom &g, const DemodK<float, type
     // delay ring: A leaves x[tb - 10 + lr_o .. + 3] at the end of body tb, B needs x_l[tb - lat_out .. + 3] at the start of
     // body tb, i.e. the block A wrote lr_m bodies before: lat_out = 4 lr_m + 10 - lr_o
     const int lr_o = (10 + kWinX - lat_out) & 3, lr_m = (lat_out - 10 - kWinX + lr_o) >> 2;
+    // the run-time shape sizes its ring (the last region of the dynamic LDS) by the plan's latency: pair_lds_floats()
+    const int kLB = S::RT ? lr_m + 2 : kLBmax;
 
     if (role == 0) {
         // =================================== stage A ===========================================
@@ -1318,8 +1332,7 @@ template <class Main, class First>
 __global__ __launch_bounds__(128, CM_PAIR_WAVES_PER_SIMD) void demod_pair_kernel(const PassArgs<typename Main::S> main_args,
                                                                                  const PassArgs<typename Main::S> first_args,
                                                                                  const int n_first) {
-    constexpr int kFloats = PairLds<Main>::kFloats > PairLds<First>::kFloats ? PairLds<Main>::kFloats : PairLds<First>::kFloats;
-    __shared__ __attribute__((aligned(16))) float lds_store[kFloats];
+    extern __shared__ __attribute__((aligned(16))) float lds_store[];     // pair_lds_floats() of the larger pass
     lds_float *lds = (lds_float *)lds_store;
 #ifdef CM_DEV_ROLE   /* register-pressure experiments: compile one stage only (the result does not run) */
     const int role = CM_DEV_ROLE;
