@@ -772,6 +772,9 @@ template <class S> constexpr int luma_ring_slots() { return S::RT ? 64 : 32; }
 #ifndef CM_QAM_SHORT_RING
 #define CM_QAM_SHORT_RING 1
 #endif
+#ifndef CM_RT_UV_RING
+#define CM_RT_UV_RING 1
+#endif
 constexpr int kLumaSlots = 2 * 64 * 4;      // floats: [buffer][lane][4 steps] luma source samples fetched by A for B
 // CM_LUMA_RING: blocks of [lane][4 steps] x samples; A writes x[tb - 10 + o .. + 3] at the end of body tb, B reads the block
 // m bodies later, lat_out = 4 m + 10 - o; A runs at most two blocks ahead of B's read, so m + 2 blocks are live
@@ -796,7 +799,10 @@ struct PairLds {
     // low-pass (LCUT: the QAM front end without the band-stop luma) - the two low-passed pairs (q_e, q_o)
     static constexpr bool kLcut = Cfg::kLcutCfg;
     static constexpr int kMid = kLcut ? 2 * kMidRing : kMidRing;
-    static constexpr int kFloats = kIn + kMid + kOut + kY;
+    // run-time shape: the pre-correction delay of (u, v) (up to 12 steps, known at run time only) is an LDS ring of 16 slots
+    // instead of a register window with a chain of uniform selects (24 registers, 11 selects and 11 packed moves per step)
+    static constexpr int kUv = (Cfg::S::RT && CM_RT_UV_RING) ? 16 * 64 * 2 : 0;
+    static constexpr int kFloats = kIn + kMid + kOut + kUv + kY;
 };
 template <>
 struct PairLds<NoPass> {
@@ -812,7 +818,7 @@ inline int pair_lds_floats(const DemodK<float, typename Cfg::S> &k) {
     const int lat_out = lat_front + 1 + k.s_p;
     constexpr int kWinX = ring_window<S, Cfg::FRONT, Cfg::kLcutCfg>();
     const int lr_o = (10 + kWinX - lat_out) & 3, lr_m = (lat_out - 10 - kWinX + lr_o) >> 2;
-    return PairLds<Cfg>::kIn + PairLds<Cfg>::kMid + PairLds<Cfg>::kOut + (lr_m + 2) * 256;
+    return PairLds<Cfg>::kIn + PairLds<Cfg>::kMid + PairLds<Cfg>::kOut + PairLds<Cfg>::kUv + (lr_m + 2) * 256;
 }
 
 #ifdef CM_DIAG
@@ -856,7 +862,8 @@ __device__ __forceinline__ void run_pair(const Geom &g, const DemodK<float, type
     constexpr bool LCUT = PairLds<Cfg>::kLcut;
     constexpr int kMid = PairLds<Cfg>::kMid;
     lds_float *otile_base = ring + kMid;
-    lds_float *yring = otile_base + PairLds<Cfg>::kOut;
+    lds_float *uvring = otile_base + PairLds<Cfg>::kOut;            // run-time shape only (PairLds::kUv)
+    lds_float *yring = uvring + PairLds<Cfg>::kUv;
 
     const int lane = threadIdx.x & 63;
     const LaneCall lc = locate_call(g, block, DEPTH, lane);
@@ -1129,9 +1136,17 @@ __device__ __forceinline__ void run_pair(const Geom &g, const DemodK<float, type
     det.reset();
     back.reset();
     pf2 base_prev = {0.f, 0.f}, b1_prev = {0.f, 0.f}, b2_prev = {0.f, 0.f};
-    pf2 uvd[SP > 0 ? SP : 1];   // (u, v) of the last SP steps (newest first)
+    constexpr bool UVR = PairLds<Cfg>::kUv != 0;
+    constexpr int kUvd = UVR ? 1 : (SP > 0 ? SP : 1);
+    pf2 uvd[kUvd];   // (u, v) of the last SP steps (newest first); UVR: in LDS instead
 #pragma unroll
-    for (int j = 0; j < (SP > 0 ? SP : 1); ++j) uvd[j] = pf2{0.f, 0.f};
+    for (int j = 0; j < kUvd; ++j) uvd[j] = pf2{0.f, 0.f};
+    typedef __attribute__((address_space(3))) pf2 lds_pf2;
+    lds_pf2 *uvr = (lds_pf2 *)uvring + lane;
+    if constexpr (UVR) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) uvr[j * 64] = pf2{0.f, 0.f};
+    }
     // output tile address of this lane's row: row * 16 + (column ^ quad swizzle)
     lds_float *otile = U8 ? (lds_float *)((lds_u8 *)otile_base + lane * 3 * kTile) : otile_base + lane * kTile;
     const int wpos = ((lane >> CM_TILE_SWZ) & (kTile / 4 - 1)) << 2;
@@ -1174,17 +1189,25 @@ __device__ __forceinline__ void run_pair(const Geom &g, const DemodK<float, type
         float y_src;
         if (BSF) y_src = yring[(n7 & (kYSlots - 1)) * 64 + lane];
         else y_src = SUB == 0 ? lw.x : (SUB == 1 ? lw.y : (SUB == 2 ? lw.z : lw.w));
-        pf2 uv_d = SP > 0 ? uvd[SP > 0 ? SP - 1 : 0] : uv;
-        if (S::RT) {   // (u, v)[n6 - s_p] out of the window: a chain of uniform selects instead of a dynamic register index
-            if (sp == 0) uv_d = uv;
+        pf2 uv_d;
+        if constexpr (UVR) {   // (u, v)[n6 - s_p] out of the LDS ring (this lane's own slots: in order within the wave)
+            uvr[(n6 & 15) * 64] = uv;
+            uv_d = uvr[((n6 - sp) & 15) * 64];
+        } else {
+            uv_d = SP > 0 ? uvd[SP > 0 ? SP - 1 : 0] : uv;
+            if (S::RT) {   // (u, v)[n6 - s_p] out of the window: a chain of uniform selects instead of a dynamic register index
+                if (sp == 0) uv_d = uv;
 #pragma unroll
-            for (int j = 0; j + 1 < SP; ++j)
-                if (sp == j + 1) uv_d = uvd[j];
+                for (int j = 0; j + 1 < SP; ++j)
+                    if (sp == j + 1) uv_d = uvd[j];
+            }
         }
         Rgb<float> o = back.template step<EDGE>(k, kb, lk, uv_last, n6, uv, uv_d, y_src, sc);
+        if constexpr (!UVR) {
 #pragma unroll
-        for (int j = SP - 1; j > 0; --j) uvd[j] = uvd[j - 1];
-        if (SP > 0) uvd[0] = uv;
+            for (int j = SP - 1; j > 0; --j) uvd[j] = uvd[j - 1];
+            if (SP > 0) uvd[0] = uv;
+        }
         if (!EDGE || (n7 >= 0 && n7 < W)) put_rgb<U8, kTile>(otile, wpos, n7, o);
     };
     // the first block of the ring and the first body's carriers
