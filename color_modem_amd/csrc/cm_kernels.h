@@ -884,6 +884,9 @@ __device__ __forceinline__ void run_pair(const Geom &g, const DemodK<float, type
     int t_mid0 = (lat_out + 3) & ~3;           // every stage index >= 0 from here on
     int t_mid1 = (W - 4) & ~3;                 // bodies below this never touch the end of the row
     if (t_mid1 <= t_mid0) t_mid0 = t_mid1 = 0; // tiny rows: the guarded body runs everything
+#ifdef CM_EXP_ALL_EDGE   /* timing experiment: every body is a guarded one */
+    t_mid0 = t_mid1 = 0;
+#endif
 
 #ifdef CM_DIAG
     unsigned long long d_bar = 0, d_flush = 0, d_other = 0;
@@ -1280,6 +1283,9 @@ __device__ __forceinline__ void run_pair(const Geom &g, const DemodK<float, type
     const int t_skip = front_off & ~3;
     int t_mid0b = (lat_out + 3) & ~3, t_mid1b = (W - 1 + front_off) & ~3;
     if (t_mid1b <= t_mid0b) t_mid0b = t_mid1b = 0;   // tiny rows: the guarded body runs everything
+#ifdef CM_EXP_ALL_EDGE
+    t_mid0b = t_mid1b = 0;
+#endif
 #endif
     int tb = 0;
     for (; tb < t_skip; tb += 4) {
