@@ -410,6 +410,7 @@ bool select_kernels(cm_plan *p, const cm_plan_desc &d, std::string &err) {
 #ifndef CM_DEV_PALD_ONLY
     if (match(signature_of<SysNtsc>())) return select_for_shape<SysNtsc, true, true>(p, d, "ntsc (pal-m/n)", err);
     if (!pald && match(signature_of<SysNtscI>())) return select_for_shape<SysNtscI, false, true>(p, d, "ntsc-i", err);
+    if (!pald && match(signature_of<SysNtscSq>())) return select_for_shape<SysNtscSq, false, true>(p, d, "ntsc at 640 / 704 samples per line", err);
     if (!pald && match(signature_of<SysNtscA>())) return select_for_shape<SysNtscA, false, true>(p, d, "ntsc-a", err);
 #endif
     if (fits_any(want) && (!first || fits_any(want_first))) return select_any(p, d, err);
