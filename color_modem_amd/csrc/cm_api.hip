@@ -548,7 +548,11 @@ bool create_secam(cm_plan *p, const cm_plan_desc &d, std::string &err) {
         }
         const int d_luma = p->sd_k.s_b + 20 + p->sd_k.q_l - p->sd_k.s_y;
         const bool thin = d.secam.lf_rev.n_sections == 0 || 2.0 / fdev_min > 100.0;     // fdev is normalised to fs / 2
-        p->sd_f64 = CM_SECAM_F64 && thin && d_luma >= 4 + 4 * CM_SECAM_PAIR_REG_DELAY && d_luma <= kSecamPairMaxLumaDelay;
+        // CM_SECAM_F64=1 in the environment at plan creation: the float64 front end for every SECAM shape (about half the
+        // throughput; for callers who want the last of the float32 start-of-row margin gone)
+        const char *force = getenv("CM_SECAM_F64");
+        const bool want64 = thin || (force && *force == '1');
+        p->sd_f64 = CM_SECAM_F64 && want64 && d_luma >= 4 + 4 * CM_SECAM_PAIR_REG_DELAY && d_luma <= kSecamPairMaxLumaDelay;
         if (p->sd_f64) {
             if (!build_secam_demod_k<double>(d, p->sd_k64, err)) return false;
             std::vector<double> fm64 = build_fm_reference<double>(d.secam.fm_fc, d.width + d.secam.preroll);

@@ -647,6 +647,33 @@ def test_wrapped_pal_comb_vs_oracle(stack, size, first):
 
 
 # ---- the time-blocked decoder with the half-band FIRs on the matrix pipe (csrc/cm_blk_kernels.h, opt-in: CM_BLK=1) ----------
+@pytest.mark.gpu
+def test_secam_float32_margin_case_and_the_float64_switch(monkeypatch):
+    """A composite frame the round-2 fuzz campaign found (seed 301: SECAM III, 640x76, oracle-encoded): the float32 decoder
+    sits at 1.04e-5 of full scale in ONE start-of-row colour-difference sample there, which two rows use
+    - bounded here at 1.5e-5 with everything else inside 1e-5 - and CM_SECAM_F64=1 at plan creation (the float64 front end) brings the frame to 2e-6."""
+    from oracle import cm_oracle
+    from color_modem_amd import line
+    from color_modem_amd.color import secam
+    g = numpy.load(os.path.join(os.path.dirname(__file__), 'golden', 'secam_iii_640_margin.npz'))
+    size = [int(x) for x in g['size']]
+    comp, first = g['comp'], int(g['first'])
+
+    def run():
+        lc = line.LineConfig((size[0], size[1]), line.LineStandard.detect(size[2]))
+        modem = secam.SecamModem(lc, getattr(secam.SecamVariant, str(g['vname'])))
+        got = image.ImageModem(modem).demodulate_frames(comp, first_frame=first)
+        want = cm_oracle.demodulate_frames_f32(modem, comp, first_frame=first, n_threads=4)
+        return numpy.abs(numpy.asarray(got, dtype=numpy.float64) - want) / numpy.abs(want).max()
+
+    err = run()
+    over = (err > 1e-5).any(axis=1)          # pixels with any plane outside
+    assert err.max() < 1.5e-5 and over.sum() <= 4, (err.max(), int(over.sum()))   # the sample serves two rows (secam.py:297-300)
+    monkeypatch.setenv('CM_SECAM_F64', '1')
+    err64 = run()
+    assert err64.max() < 2e-6, err64.max()
+
+
 def test_blocked_mfma_decoder_parity(monkeypatch):
     """demod_blk_kernel: split-float16 Toeplitz MFMAs for the five FIR chains, luma source added at the flush.  Same
     goldens, same tolerance as the streaming kernel it is an alternative to."""
