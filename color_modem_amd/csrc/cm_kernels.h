@@ -159,6 +159,9 @@ template <class S, int FRONT, bool LC = false> constexpr int ring_window() {
 #ifndef CM_TILE_SWZ
 #define CM_TILE_SWZ 1
 #endif
+#ifndef CM_CVT_PK_U8
+#define CM_CVT_PK_U8 1
+#endif
 typedef __attribute__((address_space(3))) float lds_float;
 typedef __attribute__((address_space(3))) f4 lds_f4;
 constexpr int kInTile = 32;        // samples per input tile (one 128-byte line per row)
@@ -281,9 +284,18 @@ __device__ __forceinline__ void put_rgb(lds_float *otile, int wpos, int n7, cons
     if constexpr (U8) {
         typedef __attribute__((address_space(3))) unsigned char lds_u8;
         lds_u8 *tb = (lds_u8 *)otile + 3 * (n7 & (kTile - 1));   // otile: this lane's 48-byte row
+#if CM_CVT_PK_U8   /* v_cvt_pk_u8_f32: round to nearest even, saturate to 0 .. 255, pack - one instruction per byte (tools/ubench_cvt_u8.hip) */
+        unsigned w = __builtin_amdgcn_cvt_pk_u8_f32(255.f * o.r, 0, 0);
+        w = __builtin_amdgcn_cvt_pk_u8_f32(255.f * o.g, 1, w);
+        w = __builtin_amdgcn_cvt_pk_u8_f32(255.f * o.b, 2, w);
+        tb[0] = (unsigned char)w;
+        tb[1] = (unsigned char)(w >> 8);
+        tb[2] = (unsigned char)(w >> 16);
+#else
         tb[0] = (unsigned char)__builtin_rintf(255.f * __builtin_fminf(__builtin_fmaxf(o.r, 0.f), 1.f));
         tb[1] = (unsigned char)__builtin_rintf(255.f * __builtin_fminf(__builtin_fmaxf(o.g, 0.f), 1.f));
         tb[2] = (unsigned char)__builtin_rintf(255.f * __builtin_fminf(__builtin_fmaxf(o.b, 0.f), 1.f));
+#endif
     } else {
         lds_float *tp = otile + (wpos ^ (n7 & (kTile - 1)));
         tp[0] = o.r;

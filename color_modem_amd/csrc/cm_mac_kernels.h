@@ -409,9 +409,10 @@ __global__ __launch_bounds__(kMacThreads) void mac_demod_generic_kernel(const Ma
                 const float g = __builtin_fmaf(a.m[3], luma, __builtin_fmaf(a.m[4], dr, a.m[5] * db));
                 const float b = __builtin_fmaf(a.m[6], luma, __builtin_fmaf(a.m[7], dr, a.m[8] * db));
                 if (U8) {
-                    o8[3 * n] = (unsigned char)__builtin_rintf(255.f * __builtin_fminf(__builtin_fmaxf(r, 0.f), 1.f));
-                    o8[3 * n + 1] = (unsigned char)__builtin_rintf(255.f * __builtin_fminf(__builtin_fmaxf(g, 0.f), 1.f));
-                    o8[3 * n + 2] = (unsigned char)__builtin_rintf(255.f * __builtin_fminf(__builtin_fmaxf(b, 0.f), 1.f));
+                    // v_cvt_pk_u8_f32 = uint8(rint(255 clip(x, 0, 1))) exactly (tools/ubench_cvt_u8.hip)
+                    o8[3 * n] = (unsigned char)__builtin_amdgcn_cvt_pk_u8_f32(255.f * r, 0, 0);
+                    o8[3 * n + 1] = (unsigned char)__builtin_amdgcn_cvt_pk_u8_f32(255.f * g, 0, 0);
+                    o8[3 * n + 2] = (unsigned char)__builtin_amdgcn_cvt_pk_u8_f32(255.f * b, 0, 0);
                 } else {
                     o[n] = r;
                     o[plane + n] = g;
@@ -493,7 +494,7 @@ __global__ __launch_bounds__(kMacThreads) void mac_mod_generic_kernel(const MacG
     unsigned char *o8 = (unsigned char *)a.out + ((long long)f * a.H + out_row) * ga.CW;
     for (int m = t; m < ga.CW; m += kMacThreads) {
         const float v = mac_resample_at(lin, kMacLine, line_out, m);              // mac.py:71-74
-        if (U8) o8[m] = (unsigned char)__builtin_rintf(255.f * __builtin_fminf(__builtin_fmaxf(__builtin_fmaf(0.6f, v, 0.2f), 0.f), 1.f));
+        if (U8) o8[m] = (unsigned char)__builtin_amdgcn_cvt_pk_u8_f32(255.f * __builtin_fmaf(0.6f, v, 0.2f), 0, 0);
         else o[m] = v;
     }
 }

@@ -171,7 +171,11 @@ __device__ __forceinline__ void next_tile3x(const Geom &g, lds_float *itile, con
 // composite sample -> mode-'L' byte: encode_composite_level (image.py:20-21) then _as_bytes (image.py:7-8)
 __device__ __forceinline__ unsigned char composite_byte(float comp) {
     const float v = __builtin_fmaf(0.6f, comp, 0.2f);
+#if CM_CVT_PK_U8
+    return (unsigned char)__builtin_amdgcn_cvt_pk_u8_f32(255.f * v, 0, 0);
+#else
     return (unsigned char)__builtin_rintf(255.f * __builtin_fminf(__builtin_fmaxf(v, 0.f), 1.f));
+#endif
 }
 // byte output tile [64 rows][64 pixels] -> 64-byte row segments, 16 rows per wave-instruction
 __device__ __forceinline__ void flush_tile1_u8(const Geom &g, const lds_float *otile, const float *op, int first_col, int lane) {
