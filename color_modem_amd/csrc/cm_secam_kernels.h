@@ -280,7 +280,7 @@ __global__ __launch_bounds__(64, CM_SECAM_WAVES) void secam_demod_kernel(const S
 #ifndef CM_SECAM_PAIR
 #define CM_SECAM_PAIR 1
 #endif
-// 1: both stages run the interior bodies of a row without guards (float32 stage A; the float64 stage A keeps them)
+// 1: both stages run the interior bodies of a row without guards
 // 1: byte rows on the wave pair as well
 #ifndef CM_SECAM_PAIR_U8
 #define CM_SECAM_PAIR_U8 1
@@ -426,8 +426,21 @@ __device__ __forceinline__ void secam_demod_pair_body(const Args &args_in) {
             const int xb = (b - n_pre) << 2;
             if (b == n_pre) xv = read_x(0);
             float yi0[4], yq0[4], yi1[4], yq1[4];
-            const bool mid = !F64 && CM_SECAM_PAIR_MID && b >= b_mid0 && b < b_mid1;
-            if constexpr (!F64) {
+            const bool mid = CM_SECAM_PAIR_MID && b >= b_mid0 && b < b_mid1;
+            if constexpr (F64) {
+                if (mid) {
+                    const double *cp = args_in.fm_ref64 + 4 * (long long)(m_start + 4 * b - k.s_b - 10);
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) {
+                        const double car[4] = {cp[4 * s], cp[4 * s + 1], cp[4 * s + 2], cp[4 * s + 3]};
+                        double ch_out;
+                        pf2 y0, y1;
+                        st.step_mid(args_in.k64, (double)xv[s], chw[s], car, ch_out, y0, y1);
+                        chw[10 + s] = ch_out;
+                        yi0[s] = y0.x; yq0[s] = y0.y; yi1[s] = y1.x; yq1[s] = y1.y;
+                    }
+                }
+            } else {
                 if (mid) {
                     const const_f4 *cp = (const_f4 *)g.carrier4 + (m_start + 4 * b - k.s_b - 10);
 #pragma unroll

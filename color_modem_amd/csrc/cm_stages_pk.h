@@ -879,6 +879,27 @@ struct SecamDemodA64 {
             y1 = pf2{(float)i1, (float)q1};
         }
     }
+    // the same step where no stage index touches a row boundary (the interior bodies)
+    __device__ __forceinline__ void step_mid(const SecamDemodK<double> &k, double cc_now, double ch_d10, const double car[4], double &ch_out, pf2 &y0,
+                                             pf2 &y1) {
+        const double b = iir_bp<false>(bpf, k.bpf, cc_now);
+        const double ch = k.has_bell ? iir_bp<false>(bell, k.bell, b) : b;
+        ch_out = ch;
+        const double a_odd = up.template push<false>(k.taps, ch);
+        const double a_even = k.taps.c0 * ch_d10;
+        const double pi_e = a_even * car[0], pq_e = -(a_even * car[1]);
+        const double pi_o = a_odd * car[2], pq_o = -(a_odd * car[3]);
+        double i0 = iir_sym<false>(lp_i, k.lpf, pi_e), q0 = iir_sym<false>(lp_q, k.lpf, pq_e);
+        double i1 = iir_sym<false>(lp_i, k.lpf, pi_o), q1 = iir_sym<false>(lp_q, k.lpf, pq_o);
+        if (k.odd_l) {
+            const double ih = i_hold, qh = q_hold;
+            i_hold = i1; q_hold = q1;
+            i1 = i0; q1 = q0;
+            i0 = ih; q0 = qh;
+        }
+        y0 = pf2{(float)i0, (float)q0};
+        y1 = pf2{(float)i1, (float)q1};
+    }
 };
 
 struct SecamDemodPkB {
