@@ -63,13 +63,18 @@ __global__ __launch_bounds__(64, 2) void proto_demod_kernel(const ProtoDemodArgs
     const int T = (g.Wp + lat_c + 3) & ~3;
     for (int j = 0; j < kAmRing; ++j) ring[j * 64 + lane] = 0.f;
     f4 xv = load_luma<false>(xp, 0, true, W);
-    for (int tb = 0; tb < T; tb += 4) {
-        const f4 xn = load_luma<false>(xp, tb + 4, true, W);      // next body's samples: a body hides the latency
+    // interior bodies: every stage index of the four steps inside its sequence (t >= lat_c puts every filter behind its
+    // delay, t + 3 < W - 4 keeps the end-of-row latches away) - no guard, no clamp, no zero test
+    int t_mid0 = (lat_c + 3) & ~3, t_mid1 = (W - 8) & ~3;
+    if (t_mid1 <= t_mid0) t_mid0 = t_mid1 = 0;
+    auto body = [&](auto edge_tag, int tb) __attribute__((always_inline)) {
+        constexpr bool EDGE = decltype(edge_tag)::value;
+        const f4 xn = load_luma<false>(xp, tb + 4, EDGE, W);      // next body's samples: a body hides the latency
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             const int t = tb + s;
             float luma, chroma;
-            st.step(k, t, xv[s], luma, chroma);
+            st.template step<EDGE>(k, t, xv[s], luma, chroma);
             ring[(t & (kAmRing - 1)) * 64 + lane] = luma;
             const float luma_d = ring[((t - dly) & (kAmRing - 1)) * 64 + lane];
             const float prev = lane_from(idx1, chroma) * w_prev;
@@ -79,11 +84,15 @@ __global__ __launch_bounds__(64, 2) void proto_demod_kernel(const ProtoDemodArgs
             o.g = fmaf_(k.m[1][0], luma_d, fmaf_(k.m[1][1], dr, k.m[1][2] * db));
             o.b = fmaf_(k.m[2][0], luma_d, fmaf_(k.m[2][1], dr, k.m[2][2] * db));
             const int n = t - lat_c;
-            if (n >= 0 && n < W) put_rgb<false, kTile>(otile, wpos, n, o);
+            if (!EDGE || (n >= 0 && n < W)) put_rgb<false, kTile>(otile, wpos, n, o);
             if (n >= 0 && ((n & (kTile - 1)) == kTile - 1 || n == g.Wp - 1)) flush_tile<kTile>(g, otile_base, op, n & ~(kTile - 1), lane);
         }
         xv = xn;
-    }
+    };
+    int tb = 0;
+    for (; tb < t_mid0; tb += 4) body(std::true_type(), tb);
+    for (; tb < t_mid1; tb += 4) body(std::false_type(), tb);
+    for (; tb < T; tb += 4) body(std::true_type(), tb);
 }
 
 struct ProtoModArgs {
@@ -132,11 +141,15 @@ __global__ __launch_bounds__(64, 2) void proto_mod_kernel(const ProtoModArgs arg
     f4 cur[3], nxt[3];
 #pragma unroll
     for (int p = 0; p < 3; ++p) nxt[p] = load_luma<false>(rp + p * g.in_plane_stride, 0, true, W);
-    for (int tb = 0; tb < T; tb += 4) {
+    // interior bodies: t >= lat + 4 (both paths behind their delays), t + 3 < W - 4
+    int t_mid0 = (lat + 4 + 3) & ~3, t_mid1 = (W - 8) & ~3;
+    if (t_mid1 <= t_mid0) t_mid0 = t_mid1 = 0;
+    auto body = [&](auto edge_tag, int tb) __attribute__((always_inline)) {
+        constexpr bool EDGE = decltype(edge_tag)::value;
 #pragma unroll
         for (int p = 0; p < 3; ++p) {
             cur[p] = nxt[p];
-            nxt[p] = load_luma<false>(rp + p * g.in_plane_stride, tb + 4, true, W);
+            nxt[p] = load_luma<false>(rp + p * g.in_plane_stride, tb + 4, EDGE, W);
         }
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
@@ -160,14 +173,19 @@ __global__ __launch_bounds__(64, 2) void proto_mod_kernel(const ProtoModArgs arg
             const float waited = ring[((t - dly) & (kAmRing - 1)) * 64 + lane];
             const float d_in = d_c > 0 ? waited : d, y_in = d_c > 0 ? y : (d_y > 0 ? waited : y);
             float luma, chroma;
-            st.step(k, t - d_c, d_in, t - d_y, y_in, luma, chroma);
+            st.template step<EDGE>(k, t - d_c, d_in, t - d_y, y_in, luma, chroma);
             const int n = t - lat;
-            int nc = n < 0 ? 0 : (n > W - 1 ? W - 1 : n);
+            int nc = n;
+            if (EDGE) nc = n < 0 ? 0 : (n > W - 1 ? W - 1 : n);
             const f2 cs = ((const_f2 *)args.a.carrier)[nc];
             const float cosp = fmaf_(cph, cs.x, -(sph * cs.y));      // cos(phi + n step)
             put_composite<false, kTile>(g, otile_base, op, lane, wpos, n, fmaf_(cosp, chroma, luma));
         }
-    }
+    };
+    int tb = 0;
+    for (; tb < t_mid0; tb += 4) body(std::true_type(), tb);
+    for (; tb < t_mid1; tb += 4) body(std::false_type(), tb);
+    for (; tb < T; tb += 4) body(std::true_type(), tb);
 }
 
 // ---- NIIR / SECAM-IV ------------------------------------------------------------------------------------------------------
@@ -233,29 +251,33 @@ __global__ __launch_bounds__(64, 1) void niir_demod_kernel(const NiirDemodArgs a
     for (int j = 0; j < (FIRST ? 2 : 1) * kNiirRing * 3; ++j) ring[j * 64 + lane] = 0.f;
     const bool strip = args.strip != 0;
     f4 xv = load_luma<false>(xp, 0, true, W);
-    for (int tb = 0; tb < T; tb += 4) {
-        const f4 xn = load_luma<false>(xp, tb + 4, true, W);
-        const f4 cd = load_luma<false>(xp, tb - lat, true, W);        // composite[n5 ..]: the luma source of this body's outputs
+    // interior bodies (as in proto_demod_kernel): t >= lat + 4, t + 3 < W - 4
+    int t_mid0 = (lat + 4 + 3) & ~3, t_mid1 = (W - 8) & ~3;
+    if (t_mid1 <= t_mid0) t_mid0 = t_mid1 = 0;
+    auto body = [&](auto edge_tag, int tb) __attribute__((always_inline)) {
+        constexpr bool EDGE = decltype(edge_tag)::value;
+        const f4 xn = load_luma<false>(xp, tb + 4, EDGE, W);
+        const f4 cd = load_luma<false>(xp, tb - lat, EDGE, W);        // composite[n5 ..]: the luma source of this body's outputs
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             const int t = tb + s;
             float m[3], sv[3], md[3], p[3], pv[3];
-            front.step(k, t, xv[s], m, sv);
+            front.template step<EDGE>(k, t, xv[s], m, sv);
             const int wr = (t & (kNiirRing - 1)) * 3, rd = ((t - q_l) & (kNiirRing - 1)) * 3;
 #pragma unroll
             for (int j = 0; j < 3; ++j) ring[(wr + j) * 64 + lane] = m[j];
 #pragma unroll
             for (int j = 0; j < 3; ++j) md[j] = ring[(rd + j) * 64 + lane];
             const int n3 = t - kAmHalf - k.gb.q - q_l;
-            niir_phasemod(k, n3, md, sv, p);
+            niir_phasemod<EDGE>(k, n3, md, sv, p);
             if (FIRST) {
                 float xs = 0.f;
-                if (t < W) {
+                if (!EDGE || t < W) {
                     const f2 cs = ((const_f2 *)args.a.carrier)[t];
                     xs = fmaf_(syn_s, cs.x, syn_c * cs.y);            // +-sin(phi + t step)
                 }
                 float ms[3];
-                syn.step(k, t, xs, ms);
+                syn.template step<EDGE>(k, t, xs, ms);
 #pragma unroll
                 for (int j = 0; j < 3; ++j) ring_syn[(wr + j) * 64 + lane] = ms[j];
 #pragma unroll
@@ -264,13 +286,17 @@ __global__ __launch_bounds__(64, 1) void niir_demod_kernel(const NiirDemodArgs a
 #pragma unroll
                 for (int j = 0; j < 3; ++j) pv[j] = lane_from(idx1, p[j]);
             }
-            const NiirOut<float> o = back.step(k, n3, p, pv, sv, lk.alt);
+            const NiirOut<float> o = back.template step<EDGE>(k, n3, p, pv, sv, lk.alt);
             const int n = t - lat;
-            if (n >= 0 && n < W) put_rgb<false, kTile>(otile, wpos, n, niir_finish(k, lk, o, cd[s], strip));
+            if (!EDGE || (n >= 0 && n < W)) put_rgb<false, kTile>(otile, wpos, n, niir_finish(k, lk, o, cd[s], strip));
             if (n >= 0 && ((n & (kTile - 1)) == kTile - 1 || n == g.Wp - 1)) flush_tile<kTile>(g, otile_base, op, n & ~(kTile - 1), lane);
         }
         xv = xn;
-    }
+    };
+    int tb = 0;
+    for (; tb < t_mid0; tb += 4) body(std::true_type(), tb);
+    for (; tb < t_mid1; tb += 4) body(std::false_type(), tb);
+    for (; tb < T; tb += 4) body(std::true_type(), tb);
 }
 
 struct NiirModArgs {

@@ -94,16 +94,22 @@ struct FF3 {
         st.reset();
         last = h1 = h2 = T(0);
     }
-    template <int FORM>
+    // EDGE = false: the caller guarantees 0 <= 3 (n1 - q) and 3 n1 + 2 < L - 1 (the interior of a row: no latch, no clamp,
+    // every output inside the sequence)
+    template <int FORM, bool EDGE = true>
     CM_HD void step(const SosK<T, NSEC> &k, const FFGeom &g, int L, int n1, const T in[3], T out[3]) {
         T y[3];
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
-            const int m = 3 * n1 + j;
-            y[j] = T(0);
-            if (m >= 0 && m < L + g.shift) {
-                if (m == L - 1) last = in[j];
-                y[j] = am_iir<FORM>(st, k, m < L ? in[j] : last);
+            if (EDGE) {
+                const int m = 3 * n1 + j;
+                y[j] = T(0);
+                if (m >= 0 && m < L + g.shift) {
+                    if (m == L - 1) last = in[j];
+                    y[j] = am_iir<FORM>(st, k, m < L ? in[j] : last);
+                }
+            } else {
+                y[j] = am_iir<FORM>(st, k, in[j]);
             }
         }
         T o0, o1, o2;
@@ -112,10 +118,14 @@ struct FF3 {
         else { o0 = h2; o1 = h1; o2 = y[0]; }
         h2 = y[1];
         h1 = y[2];
-        const int p = 3 * (n1 - g.q);
-        out[0] = (p >= 0 && p < L) ? o0 : T(0);
-        out[1] = (p + 1 >= 0 && p + 1 < L) ? o1 : T(0);
-        out[2] = (p + 2 >= 0 && p + 2 < L) ? o2 : T(0);
+        if (EDGE) {
+            const int p = 3 * (n1 - g.q);
+            out[0] = (p >= 0 && p < L) ? o0 : T(0);
+            out[1] = (p + 1 >= 0 && p + 1 < L) ? o1 : T(0);
+            out[2] = (p + 2 >= 0 && p + 2 < L) ? o2 : T(0);
+        } else {
+            out[0] = o0; out[1] = o1; out[2] = o2;
+        }
     }
 };
 
@@ -128,8 +138,10 @@ struct FF1 {
         st.reset();
         last = T(0);
     }
-    template <int FORM>
+    // EDGE = false: the caller guarantees shift <= i < L - 1
+    template <int FORM, bool EDGE = true>
     CM_HD T step(const SosK<T, NSEC> &k, int shift, int L, int i, T in) {
+        if (!EDGE) return am_iir<FORM>(st, k, in);
         T y = T(0);
         if (i >= 0 && i < L + shift) {
             if (i == L - 1) last = in;
@@ -172,16 +184,17 @@ struct ProtoDemod {
     CM_HD static int lat_chroma(const ProtoDemodK<T> &k) { return 2 * kAmHalf + k.ge.q + k.gp.q; }
     CM_HD static int lat_luma(const ProtoDemodK<T> &k) { return 2 * kAmHalf + k.gr.q; }
     // luma = luma[t - lat_luma], chroma = chroma[t - lat_chroma] (meaningful inside the row)
+    template <bool EDGE = true>
     CM_HD void step(const ProtoDemodK<T> &k, int t, T x_now, T &luma, T &chroma) {
         const int L = 3 * k.width, n1 = t - kAmHalf;
         T u[3], c1[3], c2[3], y1[3];
         up.push(k.taps, x_now, u);
-        ext.template step<AM_FORM_BP>(k.ext, k.ge, L, n1, u, c1);
+        ext.template step<AM_FORM_BP, EDGE>(k.ext, k.ge, L, n1, u, c1);
 #pragma unroll
         for (int j = 0; j < 3; ++j) c1[j] = c1[j] < T(0) ? -c1[j] : c1[j];     // protosecam.py:98 (the factor pi / 2 is in chroma_gain)
-        post.template step<AM_FORM_GEN>(k.post, k.gp, L, n1 - k.ge.q, c1, c2);
+        post.template step<AM_FORM_GEN, EDGE>(k.post, k.gp, L, n1 - k.ge.q, c1, c2);
         chroma = fmaf_(k.chroma_gain, dn_c.push(k.taps, c2), T(-1));
-        rem.template step<AM_FORM_SYM>(k.rem, k.gr, L, n1, u, y1);
+        rem.template step<AM_FORM_SYM, EDGE>(k.rem, k.gr, L, n1, u, y1);
         luma = k.luma_gain * dn_y.push(k.taps, y1);
     }
 };
@@ -219,13 +232,14 @@ struct ProtoMod {
     CM_HD static int lat_chroma(const ProtoModK<T> &k) { return k.s_c; }
     // i_c, d: index and value of the colour-difference sample fed now; i_y, luma likewise.  Returns the filtered luma of
     // sample i_y - lat_luma through luma_out and 0.125 (1 + chroma) of sample i_c - lat_chroma through chroma_out.
+    template <bool EDGE = true>
     CM_HD void step(const ProtoModK<T> &k, int i_c, T d, int i_y, T luma, T &luma_out, T &chroma_out) {
-        const T c = pre.template step<AM_FORM_GEN>(k.pre, k.s_c, k.width, i_c, d);
+        const T c = pre.template step<AM_FORM_GEN, EDGE>(k.pre, k.s_c, k.width, i_c, d);
         chroma_out = fmaf_(T(0.125) * k.pre_gain, c, T(0.125));
         if (k.luma_filter) {
             T u[3], y1[3];
-            up.push(k.taps, (i_y >= 0 && i_y < k.width) ? luma : T(0), u);
-            rem.template step<AM_FORM_SYM>(k.rem, k.gr, 3 * k.width, i_y - kAmHalf, u, y1);
+            up.push(k.taps, (!EDGE || (i_y >= 0 && i_y < k.width)) ? luma : T(0), u);
+            rem.template step<AM_FORM_SYM, EDGE>(k.rem, k.gr, 3 * k.width, i_y - kAmHalf, u, y1);
             luma_out = k.luma_gain * dn.push(k.taps, y1);
         } else {
             luma_out = luma;
@@ -272,14 +286,15 @@ struct NiirFront {
         up.reset(); bp.reset(); lp.reset();
     }
     // m_out = M(n2), n2 = t - 10 - q_b;  s_out = S(n3), n3 = n2 - q_l   (both zero outside [0, L))
+    template <bool EDGE = true>
     CM_HD void step(const NiirDemodK<T> &k, int t, T x_now, T m_out[3], T s_out[3]) {
         const int L = 3 * k.width, n1 = t - kAmHalf;
         T u[3], a[3];
         up.push(k.taps, x_now, u);
-        bp.template step<AM_FORM_BP>(k.bp, k.gb, L, n1, u, m_out);
+        bp.template step<AM_FORM_BP, EDGE>(k.bp, k.gb, L, n1, u, m_out);
 #pragma unroll
         for (int j = 0; j < 3; ++j) a[j] = m_out[j] < T(0) ? -m_out[j] : m_out[j];     // niir.py:113 (pi / 2 is in the constants)
-        lp.template step<AM_FORM_GEN>(k.lp, k.gl, L, n1 - k.gb.q, a, s_out);
+        lp.template step<AM_FORM_GEN, EDGE>(k.lp, k.gl, L, n1 - k.gb.q, a, s_out);
     }
 };
 
@@ -291,21 +306,22 @@ struct NiirSyn {
     CM_HD void reset() {
         up.reset(); bp.reset();
     }
+    template <bool EDGE = true>
     CM_HD void step(const NiirDemodK<T> &k, int t, T x_syn, T m_out[3]) {
         T u[3];
         up.push(k.taps, x_syn, u);
-        bp.template step<AM_FORM_BP>(k.bp, k.gb, 3 * k.width, t - kAmHalf, u, m_out);
+        bp.template step<AM_FORM_BP, EDGE>(k.bp, k.gb, 3 * k.width, t - kAmHalf, u, m_out);
     }
 };
 
 // phasemod_up of a triple: c_pm * M / S inside the sequence, zero outside (the decimators zero-extend)
-template <typename T>
+template <bool EDGE = true, typename T>
 CM_HD void niir_phasemod(const NiirDemodK<T> &k, int n3, const T m[3], const T s[3], T p[3]) {
     const int L = 3 * k.width;
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
         const int q = 3 * n3 + j;
-        p[j] = (q >= 0 && q < L) ? k.c_pm * m[j] / s[j] : T(0);
+        p[j] = (!EDGE || (q >= 0 && q < L)) ? k.c_pm * m[j] / s[j] : T(0);
     }
 }
 
@@ -325,6 +341,7 @@ struct NiirBack {
         c2_2 = T(0);
     }
     // own / prev: phasemod_up triples n3 of this call and of the previous one; s: S(n3); alt: is_alternate_line
+    template <bool EDGE = true>
     CM_HD NiirOut<T> step(const NiirDemodK<T> &k, int n3, const T own[3], const T prev[3], const T s[3], bool alt) {
         const int L = 3 * k.width, n4 = n3 - 1;
         T c[3], h[3];
@@ -338,7 +355,7 @@ struct NiirBack {
         for (int j = 0; j < 3; ++j) {
             const int p = 3 * n4 + j;
             const T before = j == 0 ? c2_2 : c1[j - 1], after = j == 2 ? c[0] : c1[j + 1];
-            ac[j] = (p >= 1 && p <= L - 2) ? k.alt_scale * (after - before) : T(0);       // niir.py:126-129
+            ac[j] = (!EDGE || (p >= 1 && p <= L - 2)) ? k.alt_scale * (after - before) : T(0);       // niir.py:126-129
             su[j] = h1[j] * c1[j];                                                         // niir.py:131-132
             cu[j] = h1[j] * ac[j];
         }
