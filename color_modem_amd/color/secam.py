@@ -70,6 +70,9 @@ class SecamModem(RowApi):
     system = 'secam'
     encode_matrix = ENCODE
     decode_matrix = DECODE
+    # True (set it before the first call): the decoder's chroma front end in float64 whatever the shape - the library selects
+    # it by itself where float32 rounding noise would come near 1e-5 (cm_secam_desc.present | CM_SECAM_FLOAT64)
+    float64_front_end = False
 
     def __init__(self, line_config, variant=SecamVariant.SECAM, alternate_phases=False):
         RowApi.__init__(self)

@@ -177,6 +177,7 @@ struct cm_plan {
     // SECAM
     bool secam = false;
     SecamDemodK<float> sd_k;
+    SecamBp64 sd_e64;              // band-pass + bell of the guarded bodies in float64 (cm_stages.h)
     SecamDemodLaneK<float> *sd_lanes = nullptr;
     float *fm_ref = nullptr;      // SECAM discriminator reference {cos, sin} pairs
     double *fm_ref64 = nullptr;   // the same in float64, for the float64 front end (sd_f64)
@@ -524,6 +525,7 @@ bool upload_lanes(const cm_lane_table &tb, LaneT **dev, Conv conv, std::string &
 bool create_secam(cm_plan *p, const cm_plan_desc &d, std::string &err) {
     p->secam = true;
     if (!build_secam_demod_k<float>(d, p->sd_k, err)) return false;
+    if (!build_secam_bp64(d, p->sd_e64, err)) return false;
     if (!d.demod_main.table) { err = "demod_main table missing"; return false; }
     if (!upload_lanes(d.demod_main, &p->sd_lanes, [&](const double *e) { return convert_secam_demod_lane<float>(e, d.secam); }, err))
         return false;
@@ -538,8 +540,16 @@ bool create_secam(cm_plan *p, const cm_plan_desc &d, std::string &err) {
         err = "device allocation / upload of the FM reference failed";
         return false;
     }
-    {   // Where float32 is too thin for 1e-5: the discriminator divides by the deviation, so its error grows
-        // with fs / fdev; variants without de-emphasis show every row-end transient undamped.  lane entry e[1] = fdev.
+    {   // Where float32 is too thin for 1e-5.  With the band-pass + bell of the row ends in float64 (SecamBp64)
+        // the row-end transients are gone and what is left of the float32 error is (a) uniform rounding noise of the front
+        // end, which the discriminator divides by the deviation - it grows like (fs / fdev)^1.5: tests/sim over 7 variants x
+        // 10 widths x 16 seeds (profiles/r03_secam_sim_sweep.txt) gives 3e-6 at 1920 wide with de-emphasis, without 4.2e-6
+        // at 1280 (2 / fdev = 96), 5.5e-6 at 1440, 9.2e-6 at 1920 - and (b) isolated samples where the sub-carrier's
+        // envelope dips (sharp colour transitions; variants III / M / N): the angle of a small (I, Q) multiplies that noise by
+        // typical / momentary amplitude - 4 - 5 x the median error in 1 of 40 random frames at 720 wide, and 2.5e-4 in one
+        // SECAM-N frame at 1920 wide (profiles/r03_fuzz_summary.txt) where the float64 front end gives 2e-6.  So: float64 from
+        // 2 / fdev > 100 on (1280 wide and more), as in rounds 1 - 2; the variants without de-emphasis no longer need it
+        // below that (their misses were row-end transients).  lane entry e[1] = fdev / (fs / 2).
         double fdev_min = 1e9;
         const size_t n_lanes = (size_t)d.demod_main.frame_cycle * 3 * d.demod_main.n_lines;
         for (size_t i = 0; i < n_lanes; ++i) {
@@ -547,11 +557,9 @@ bool create_secam(cm_plan *p, const cm_plan_desc &d, std::string &err) {
             if (fd > 0.0 && fd < fdev_min) fdev_min = fd;
         }
         const int d_luma = p->sd_k.s_b + 20 + p->sd_k.q_l - p->sd_k.s_y;
-        const bool thin = d.secam.lf_rev.n_sections == 0 || 2.0 / fdev_min > 100.0;     // fdev is normalised to fs / 2
-        // CM_SECAM_F64=1 in the environment at plan creation: the float64 front end for every SECAM shape (about half the
-        // throughput; for callers who want the last of the float32 start-of-row margin gone)
-        const char *force = getenv("CM_SECAM_F64");
-        const bool want64 = thin || (force && *force == '1');
+        const bool thin = 2.0 / fdev_min > 100.0;
+        // the caller may ask for the float64 front end whatever the shape (cm_secam_desc.present & CM_SECAM_FLOAT64)
+        const bool want64 = thin || (d.secam.present & CM_SECAM_FLOAT64) != 0;
         p->sd_f64 = CM_SECAM_F64 && want64 && d_luma >= 4 + 4 * CM_SECAM_PAIR_REG_DELAY && d_luma <= kSecamPairMaxLumaDelay;
         if (p->sd_f64) {
             if (!build_secam_demod_k<double>(d, p->sd_k64, err)) return false;
@@ -595,6 +603,7 @@ int run_secam_demod(const cm_plan *p, Geom g, hipStream_t stream, bool u8 = fals
     SecamDemodArgs a;
     a.g = g;
     a.k = p->sd_k;
+    a.e64 = p->sd_e64;
     // the wave pair with the luma delay ring where the delay fits the ring (cm_secam_kernels.h), else one wave per 64 calls
     const int d_luma = p->sd_k.s_b + 20 + p->sd_k.q_l - p->sd_k.s_y;
     if (p->sd_f64) {

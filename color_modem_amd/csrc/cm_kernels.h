@@ -850,6 +850,10 @@ inline int pair_lds_floats(const DemodK<float, typename Cfg::S> &k) {
 #ifndef CM_PALD_PK_FRONT
 #define CM_PALD_PK_FRONT 1
 #endif
+// 1: ... and the third one (up2 of e) two steps at a time, packed along the accumulator index (HalfbandUp2Pk)
+#ifndef CM_PALD_UP2
+#define CM_PALD_UP2 1
+#endif
 template <class Cfg>
 __device__ __forceinline__ void run_pair(const Geom &g, const DemodK<float, typename Cfg::S> &k_in, int block, lds_float *lds,
                                          int role) {
@@ -920,7 +924,10 @@ __device__ __forceinline__ void run_pair(const Geom &g, const DemodK<float, type
         // PAL-D front: two of the three chains packed (cm_stages_pk.h: PalDFrontAPk); its interpolator is fed x[t + 1]
         constexpr bool PKF = CM_PALD_PK_FRONT != 0 && (PALD || BSF);
         TapsPk tkp;
+        TapsPkOdd tko;
         Taps<float> tks;
+        constexpr bool UP2 = PKF && PALD && CM_PALD_UP2 != 0;
+        if constexpr (UP2) tko.load(k.taps);
         if constexpr (PKF) {
             tkp.load(k.taps);
 #pragma unroll
@@ -1040,10 +1047,20 @@ __device__ __forceinline__ void run_pair(const Geom &g, const DemodK<float, type
                 }
             }
             float me[4], mo[4];
+            if constexpr (UP2) {
+                Mid<float> m0, m1, m2, m3;
+                fa.template step2<EDGE_A>(k, tkp, tko, tks, fla, tb, xw[11], xw[12], xw[0], xw[1], ew[PALD ? 0 : 0], ew[PALD ? 1 : 0],
+                                          ew[PALD ? 10 : 0], ew[PALD ? 11 : 0], m0, m1);
+                fa.template step2<EDGE_A>(k, tkp, tko, tks, fla, tb + 2, xw[13], xq.x, xw[2], xw[3], ew[PALD ? 2 : 0], ew[PALD ? 3 : 0],
+                                          ew[PALD ? 12 : 0], ew[PALD ? 13 : 0], m2, m3);
+                me[0] = m0.even; mo[0] = m0.odd; me[1] = m1.even; mo[1] = m1.odd;
+                me[2] = m2.even; mo[2] = m2.odd; me[3] = m3.even; mo[3] = m3.odd;
+            } else {
             sub_a(std::integral_constant<int, 0>(), edge_tag, fla, tb + 0, me[0], mo[0]);
             sub_a(std::integral_constant<int, 1>(), edge_tag, fla, tb + 1, me[1], mo[1]);
             sub_a(std::integral_constant<int, 2>(), edge_tag, fla, tb + 2, me[2], mo[2]);
             sub_a(std::integral_constant<int, 3>(), edge_tag, fla, tb + 3, me[3], mo[3]);
+            }
             if (kWinX >= 8) {
 #pragma unroll
                 for (int j = 0; j + 4 < kWinX; ++j) xo[kWinX >= 8 ? j : 0] = xo[kWinX >= 8 ? j + 4 : 0];

@@ -191,6 +191,23 @@ bool build_secam_demod_k(const cm_plan_desc &d, SecamDemodK<T> &k, std::string &
     return true;
 }
 
+// The float64 band-pass + bell of the row ends (cm_stages.h: SecamBp64): the same sections in float64 and the lengths of
+// head and tail from the slowest pole of the two filters (a2 = r^2: tau = -2 / ln(a2) samples).
+inline bool build_secam_bp64(const cm_plan_desc &d, SecamBp64 &e, std::string &err) {
+    const cm_secam_desc &s = d.secam;
+    double g_b, g_bell;
+    if (!convert_sos<double, 3>(s.chroma_bp, FORM_BP, e.bpf, g_b, err, "chroma_bp", true)) return false;
+    if (!convert_sos_optional<double, 1>(s.bell, FORM_BP, e.bell, g_bell, err, "bell")) return false;
+    double a2 = 0.0;
+    for (int j = 0; j < s.chroma_bp.n_sections && j < 3; ++j) a2 = std::fmax(a2, -e.bpf.na2[j]);
+    if (s.bell.n_sections) a2 = std::fmax(a2, -e.bell.na2[0]);
+    if (!(a2 > 0.0 && a2 < 1.0)) { err = "SECAM chroma band-pass: pole radius outside (0, 1)"; return false; }
+    const double tau = -2.0 / std::log(a2);
+    e.head = (int)std::ceil(4.0 * tau);
+    e.tail = (int)std::ceil(3.0 * tau);
+    return true;
+}
+
 // e = {fsc, fdev, own_is_db, w_prev} of the line (normalised frequencies)
 template <typename T>
 SecamDemodLaneK<T> convert_secam_demod_lane(const double *e, const cm_secam_desc &s) {

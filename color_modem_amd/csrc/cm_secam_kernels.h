@@ -20,6 +20,7 @@ struct SecamDemodArgs {
     Geom g;                    // g.lanes -> SecamDemodLaneK<float> table, g.carrier4 -> FM reference {cos, sin} pairs,
                                // g.carrier2 -> dc table (cm_plan.h: build_fm_dc)
     SecamDemodK<float> k;
+    SecamBp64 e64;             // band-pass + bell of the guarded bodies in float64 (cm_stages.h)
 };
 
 // U8: the ImageModem byte boundary fused in, as in the PAL / NTSC decoders (cm_kernels.h: PassCfg::U8): composite bytes
@@ -113,7 +114,7 @@ __global__ __launch_bounds__(64, CM_SECAM_WAVES) void secam_demod_kernel(const S
         if (EDGE) m4 = m4 < 0 ? 0 : (m4 > Lc - 1 ? Lc - 1 : m4);
         const float dc = ((const __attribute__((address_space(4))) float *)g.carrier2)[m4];
         float ch_out;
-        float own = st.template chroma_step<EDGE>(k, kp, lk, m, cc, chw[sub], pf2{c.x, c.y}, pf2{c.z, c.w}, dc, ch_out);
+        float own = st.template chroma_step<EDGE>(k, kp, lk, m, cc, chw[sub], pf2{c.x, c.y}, pf2{c.z, c.w}, dc, ch_out, args.e64);
         chw[10 + sub] = ch_out;
         const int n = m - 1 - lat;                          // the back end runs one sample behind the exchange
         float luma = st.template luma_step<EDGE>(k, n, x_l);
@@ -169,12 +170,9 @@ __global__ __launch_bounds__(64, CM_SECAM_WAVES) void secam_demod_kernel(const S
 #if CM_SECAM_LUMA_AHEAD == 2
     f4 nl2 = read_luma(4 - d_luma);
 #endif
-    // Interior bodies: every stage index of the four steps m = P + xb .. + 3 lies strictly inside its stream - the first
-    // output sample n = m - 1 - lat is >= 0 (so is every earlier stage's index) and the last input index m + 3 stays below
-    // the end-of-row latch at Lc - 1 (so does every later stage's, which run behind it).
-    int xb_mid0 = (lat + 1 - P + 3) & ~3, xb_mid1 = (W - 8) & ~3;
-    if (xb_mid0 < 0) xb_mid0 = 0;
-    if (xb_mid1 <= xb_mid0) xb_mid0 = xb_mid1 = 0;
+    // Interior bodies (cm_stages.h: secam_mid_bounds): no stage index touches a row boundary and the band-pass runs in float32
+    int xb_mid0, xb_mid1;
+    secam_mid_bounds(W, P, lat, args.e64, xb_mid0, xb_mid1);
     auto body = [&](auto edge_tag, int xb) __attribute__((always_inline)) {   // (not inlined, the line's state would live in scratch memory)
         constexpr bool EDGE = decltype(edge_tag)::value;
         const f4 lw = nl;
@@ -258,7 +256,9 @@ __global__ __launch_bounds__(64, CM_SECAM_WAVES) void secam_demod_kernel(const S
     };
     int xb = 0;
     for (; xb < xb_mid0; xb += 4) body(std::true_type(), xb);
+    st.to32();
     for (; xb < xb_mid1; xb += 4) body(std::false_type(), xb);
+    st.to64();
     for (; xb < T; xb += 4) body(std::true_type(), xb);
 }
 
@@ -373,11 +373,18 @@ __device__ __forceinline__ void secam_demod_pair_body(const Args &args_in) {
     // A writes x[xb - 4 - lr_o .. + 3] (out of the samples of its last two bodies); B reads it lr_m bodies later
     const int lr_o = (d_luma - 4) & 3, lr_m = ((d_luma - 4) >> 2) - CM_SECAM_PAIR_REG_DELAY;   // (the host checks lr_m >= 0)
     const int n_blocks = lr_m + 2;                          // delay ring blocks (the host sizes the LDS with the same number)
-    // interior bodies (secam_demod_kernel): every stage index of the four steps lies strictly inside its stream
-    int xb_mid0 = (lat + 1 - P + 3) & ~3, xb_mid1 = (W - 8) & ~3;
-    if (xb_mid0 < 0) xb_mid0 = 0;
-    if (xb_mid1 <= xb_mid0) xb_mid0 = xb_mid1 = 0;
+    // interior bodies (cm_stages.h: secam_mid_bounds): every stage index of the four steps lies strictly inside its stream;
+    // stage A of the float32 pair also keeps the float64 head and tail of its band-pass out of them
+    int xb_mid0, xb_mid1, xb_a0, xb_a1;
+    {
+        SecamBp64 none;
+        none.head = none.tail = 0;
+        secam_mid_bounds(W, P, lat, none, xb_mid0, xb_mid1);
+        if (F64) { xb_a0 = xb_mid0; xb_a1 = xb_mid1; }
+        else secam_mid_bounds(W, P, lat, args.e64, xb_a0, xb_a1);
+    }
     const int b_mid0 = n_pre + (xb_mid0 >> 2), b_mid1 = n_pre + (xb_mid1 >> 2);
+    const int b_a0 = CM_SECAM_PAIR_MID ? n_pre + (xb_a0 >> 2) : 0, b_a1 = CM_SECAM_PAIR_MID ? n_pre + (xb_a1 >> 2) : 0;
 
     if (role == 0) {
         // =================================== stage A ===========================================
@@ -421,12 +428,12 @@ __device__ __forceinline__ void secam_demod_pair_body(const Args &args_in) {
         };
         f4 xv = {0.f, 0.f, 0.f, 0.f}, xprev = xv, xprev2 = xv;
         int xw = 0;      // delay ring block of this body
-        for (int b = 0; b < n_bodies; ++b) {
+        auto body_a = [&](auto mid_tag, int b) __attribute__((always_inline)) {
+            constexpr bool mid = decltype(mid_tag)::value;
             const bool pre = b < n_pre;
             const int xb = (b - n_pre) << 2;
             if (b == n_pre) xv = read_x(0);
             float yi0[4], yq0[4], yi1[4], yq1[4];
-            const bool mid = CM_SECAM_PAIR_MID && b >= b_mid0 && b < b_mid1;
             if constexpr (F64) {
                 if (mid) {
                     const double *cp = args_in.fm_ref64 + 4 * (long long)(m_start + 4 * b - k.s_b - 10);
@@ -483,7 +490,7 @@ __device__ __forceinline__ void secam_demod_pair_body(const Args &args_in) {
                 } else {
                     const f4 c = ((const_f4 *)g.carrier4)[m2];
                     float ch_out;
-                    st.step(k, kp, m, cc, chw[s], pf2{c.x, c.y}, pf2{c.z, c.w}, ch_out, y0, y1);
+                    st.step(k, kp, m, cc, chw[s], pf2{c.x, c.y}, pf2{c.z, c.w}, ch_out, y0, y1, args.e64);
                     chw[10 + s] = ch_out;
                 }
                 yi0[s] = y0.x; yq0[s] = y0.y; yi1[s] = y1.x; yq1[s] = y1.y;
@@ -519,7 +526,14 @@ __device__ __forceinline__ void secam_demod_pair_body(const Args &args_in) {
             *(lds_f4 *)(xring + xw * 256 + lane * 4) = blk;
             xw = xw + 1 == n_blocks ? 0 : xw + 1;
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        }
+        };
+        // guarded bodies (band-pass + bell in float64 on the float32 pair) | interior | guarded bodies
+        int b = 0;
+        for (; b < b_a0; ++b) body_a(std::false_type(), b);
+        st.to32();
+        for (; b < b_a1; ++b) body_a(std::true_type(), b);
+        st.to64();
+        for (; b < n_bodies; ++b) body_a(std::false_type(), b);
         return;
     }
 

@@ -688,6 +688,40 @@ struct SecamDemodLaneK {
     T w_prev;         // 0 on the first call of a run (last_chroma = zeros), else 1
 };
 
+// Float32 is too thin for the band-pass + bell cascade near the row ends: the filter starts from zero state on a signal
+// with a luma step (its states are large while the band-passed sub-carrier is still small) and the sub-carrier collapses
+// again where the row ends; the rounding of the states then shows in the angle of (I, Q) - 1.04e-5 of full scale in a
+// start-of-row sample of SECAM III at 640 (tests/golden/secam_iii_640_margin.npz), 9.7e-6 in the
+// last column of SECAM II at 720.  So the float32 decoders carry these two filters (4 sections) in float64 over the first
+// `head` samples of the chroma stream (m < head) and over its last `tail` (m >= W + P - tail) and hand the states to the
+// float32 sections in between: the bodies there are the guarded ones anyway (cm_secam_kernels.h), which are extended to
+// cover head and tail.  head = 4 tau, tail = 3 tau of the slowest pole of the two filters (host: cm_plan.h).
+struct SecamBp64 {
+    SosK<double, 3> bpf;
+    SosK<double, 1> bell;
+    int32_t head, tail;
+};
+
+// Main-loop samples [xb0, xb1) (multiples of 4) whose bodies need no guard and run the band-pass in float32: every stage
+// index of the four steps m = P + xb .. + 3 lies strictly inside its stream - the first output sample n = m - 1 - lat is
+// >= 0 (so is every earlier stage's index), the last input index m + 3 stays below the end-of-row latch at W + P - 1 (so
+// does every later stage's, which run behind it) - and the float64 head / tail of SecamBp64 lie outside.
+CM_HD void secam_mid_bounds(int W, int P, int lat, const SecamBp64 &e, int &xb0, int &xb1) {
+    xb0 = (lat + 1 - P + 3) & ~3;
+    xb1 = (W - 8) & ~3;
+    const int h = (e.head - P + 3) & ~3, t = (W - e.tail) & ~3;
+    if (h > xb0) xb0 = h;
+    if (t < xb1) xb1 = t;
+    if (xb0 < 0) xb0 = 0;
+    if (xb1 <= xb0) xb0 = xb1 = 0;
+}
+
+template <typename A, typename B, int N>
+CM_HD void convert_state(IirState<A, N> &d, const IirState<B, N> &s) {
+#pragma unroll
+    for (int j = 0; j < N; ++j) { d.s1[j] = (A)s.s1[j]; d.s2[j] = (A)s.s2[j]; }
+}
+
 #if defined(__HIP_DEVICE_COMPILE__)
 __device__ __forceinline__ float atan2_(float y, float x) { return atan2f(y, x); }
 #else
@@ -700,6 +734,9 @@ struct SecamDemod {
     typedef VPolicy<CM_V_SECAM> VP;
     IirState<T, 3> bpf, ybs;
     IirState<T, 1> bell;
+    IirState<double, 3> bpf64;   // the band-pass + bell states while they run in float64 (SecamBp64)
+    IirState<double, 1> bell64;
+    int in64;
     IirState<T, 3> lp_i, lp_q;
     IirState<T, 1> deemph;
     HalfbandChain<T> up, dn;
@@ -710,6 +747,8 @@ struct SecamDemod {
 
     CM_HD void reset() {
         bpf.reset(); ybs.reset(); bell.reset(); lp_i.reset(); lp_q.reset(); deemph.reset();
+        bpf64.reset(); bell64.reset();
+        in64 = 0;
         up.reset(); dn.reset();
         cc_last = pi_last = pq_last = x_last = i_prev = q_prev = i_hold = q_hold = T(0);
         have_prev = 0;
@@ -730,15 +769,27 @@ struct SecamDemod {
     // reference at 2x samples 2 m2 and 2 m2 + 1.  Returns the de-emphasised colour-difference sample
     // c[n], n = m - latency (meaningful for 0 <= n < W), and ch[m1] through ch_out.
     // dc = the plan's table entry of row-stream sample m4 (see SecamDemodLaneK)
-    CM_HD T chroma_step(const SecamDemodK<T> &k, const SecamDemodLaneK<T> &lk, int m, T cc_now, T ch_d10, const T car[4], T dc, T &ch_out) {
+    // e64 != nullptr: this step runs the band-pass + bell in float64 (the guarded bodies of the float32 kernels, SecamBp64)
+    CM_HD T chroma_step(const SecamDemodK<T> &k, const SecamDemodLaneK<T> &lk, int m, T cc_now, T ch_d10, const T car[4], T dc, T &ch_out,
+                        const SecamBp64 *e64 = nullptr) {
         const int W = k.width, Lc = k.width + k.preroll;
         const int m1 = m - k.s_b, m2 = m1 - 10, m3 = m2 - k.q_l, m4 = m3 - 9, n = m4 - k.preroll;
         T ch = T(0);
+        if ((e64 != nullptr) != (in64 != 0)) {   // hand the states over (float32 -> float64 is exact)
+            if (e64) { convert_state(bpf64, bpf); convert_state(bell64, bell); }
+            else { convert_state(bpf, bpf64); convert_state(bell, bell64); }
+            in64 = e64 != nullptr;
+        }
         if (m >= 0 && m < Lc + k.s_b) {
             if (m == Lc - 1) cc_last = cc_now;
             if (m >= Lc) cc_now = cc_last;
-            T b = iir_bp<VP::VB>(bpf, k.bpf, cc_now);
-            if (m1 >= 0) ch = k.has_bell ? iir_bp<false>(bell, k.bell, b) : b;   // the bell sees the band-pass output from its sample 0 on
+            if (e64) {
+                double b = iir_bp<false>(bpf64, e64->bpf, (double)cc_now);
+                if (m1 >= 0) ch = T(k.has_bell ? iir_bp<false>(bell64, e64->bell, b) : b);
+            } else {
+                T b = iir_bp<VP::VB>(bpf, k.bpf, cc_now);
+                if (m1 >= 0) ch = k.has_bell ? iir_bp<false>(bell, k.bell, b) : b;   // the bell sees the band-pass output from its sample 0 on
+            }
         }
         if (m1 < 0 || m1 >= Lc) ch = T(0);
         ch_out = ch;

@@ -91,6 +91,44 @@ __device__ __forceinline__ pf2 pk_fma_bs(pf2 x, pf2 k, pf2 acc) {
 #endif
     return d;
 }
+// d = ksel(k) * x[XH] + acc: x broadcast from half XH of a VGPR pair; k a full coefficient pair - KSEL 0: (k.x, k.y),
+// 1: swapped (k.y, k.x), 2: (k.y, k.y) - in SGPRs (KS) or VGPRs
+template <int XH, int KSEL, bool KS>
+__device__ __forceinline__ pf2 pk_fma_xk(pf2 x, pf2 k, pf2 acc) {
+    pf2 d;
+#if defined(__HIP_DEVICE_COMPILE__)
+#define CM_PK_XK(OPS)                                                                                  \
+    if (KS) asm("v_pk_fma_f32 %0, %1, %2, %3 " OPS : "=v"(d) : "v"(x), "s"(k), "v"(acc));              \
+    else asm("v_pk_fma_f32 %0, %1, %2, %3 " OPS : "=v"(d) : "v"(x), "v"(k), "v"(acc));
+    if (XH == 0 && KSEL == 0) { CM_PK_XK("op_sel:[0,0,0] op_sel_hi:[0,1,1]") }
+    else if (XH == 0 && KSEL == 1) { CM_PK_XK("op_sel:[0,1,0] op_sel_hi:[0,0,1]") }
+    else if (XH == 0 && KSEL == 2) { CM_PK_XK("op_sel:[0,1,0] op_sel_hi:[0,1,1]") }
+    else if (XH == 1 && KSEL == 0) { CM_PK_XK("op_sel:[1,0,0] op_sel_hi:[1,1,1]") }
+    else if (XH == 1 && KSEL == 1) { CM_PK_XK("op_sel:[1,1,0] op_sel_hi:[1,0,1]") }
+    else { CM_PK_XK("op_sel:[1,1,0] op_sel_hi:[1,1,1]") }
+#undef CM_PK_XK
+#else
+    const float kx = KSEL == 0 ? k.x : k.y, ky = KSEL == 1 ? k.x : k.y;
+    d = pf2{kx * x[XH] + acc.x, ky * x[XH] + acc.y};
+#endif
+    return d;
+}
+template <int XH, bool KS>
+__device__ __forceinline__ pf2 pk_mul_xk(pf2 x, pf2 k) {   // d = k * x[XH]
+    pf2 d;
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (XH == 0) {
+        if (KS) asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1]" : "=v"(d) : "v"(x), "s"(k));
+        else asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1]" : "=v"(d) : "v"(x), "v"(k));
+    } else {
+        if (KS) asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,1]" : "=v"(d) : "v"(x), "s"(k));
+        else asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,1]" : "=v"(d) : "v"(x), "v"(k));
+    }
+#else
+    d = k * x[XH];
+#endif
+    return d;
+}
 __device__ __forceinline__ pf2 pk_add(pf2 a, pf2 b) {
     pf2 d;
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -210,6 +248,51 @@ struct HalfbandChainPk {
     }
 };
 
+// ---- transposed-form half-band interpolator, TWO pushes at a time, packed along the accumulator index -------------
+// HalfbandChain::push updates a[j] <- c[j + 1] x + a[j + 1] (a[-1] = the output, a[19] = 0, c symmetric, c[20] = 0).  Two
+// pushes x0, x1 move every accumulator by two:  a[j] <- c[j + 1] x1 + (c[j + 2] x0 + a[j + 2]).  With the accumulators in
+// pairs q[i] = (a[2i - 1], a[2i]):
+//     tmp   = (c[2i + 1], c[2i + 2]) x0 + q[i + 1]
+//     q[i] <- (c[2i],     c[2i + 1]) x1 + tmp
+// Each v_pk_fma_f32 performs exactly two of the scalar chain's FMAs, in the scalar chain's order: the results are
+// bit-identical, no extra line state, and 40 scalar FMAs per two steps become 20 packed ones + 1.  The coefficient pairs are
+// wave-uniform: the (even, odd) pairs are TapsPk's (the mirrored half of the symmetric taps by swapping the halves with
+// op_sel), the (odd, even) pairs sit in SGPR pairs; x0 / x1 are broadcast from one VGPR pair by op_sel.
+struct TapsPkOdd {      // SGPR pairs (c1, c2), (c3, c4), (c5, c6), (c7, c8) and (c0, 0)
+    pf2 a[5];
+    __device__ __forceinline__ void load(const Taps<float> &t) {
+        a[0] = pf2{take_s(t.c[1]), take_s(t.c[2])};
+        a[1] = pf2{take_s(t.c[3]), take_s(t.c[4])};
+        a[2] = pf2{take_s(t.c[5]), take_s(t.c[6])};
+        a[3] = pf2{take_s(t.c[7]), take_s(t.c[8])};
+        const float zero = 0.f;
+        a[4] = pf2{take_s(t.c[0]), take_s(zero)};
+    }
+};
+struct HalfbandUp2Pk {
+    pf2 q[10];          // q[i] = (s[2i - 1], s[2i]) of HalfbandChain; q[0].x is not state
+    __device__ __forceinline__ void reset() {
+#pragma unroll
+        for (int j = 0; j < 10; ++j) q[j] = pf2{0.f, 0.f};
+    }
+    // pushes x.x then x.y; returns (the output after the first push, the output after the second)
+    __device__ __forceinline__ pf2 push2(const TapsPk &ke, const TapsPkOdd &ko, pf2 x) {
+        const float out0 = __builtin_fmaf(ke.c2[0].x, x.x, q[0].y);
+        pf2 t;
+        t = pk_fma_xk<0, 0, true>(x, ko.a[0], q[1]);  q[0] = pk_fma_xk<1, 0, false>(x, ke.c2[0], t);
+        t = pk_fma_xk<0, 0, true>(x, ko.a[1], q[2]);  q[1] = pk_fma_xk<1, 0, false>(x, ke.c2[1], t);
+        t = pk_fma_xk<0, 0, true>(x, ko.a[2], q[3]);  q[2] = pk_fma_xk<1, 0, false>(x, ke.c2[2], t);
+        t = pk_fma_xk<0, 0, true>(x, ko.a[3], q[4]);  q[3] = pk_fma_xk<1, 0, false>(x, ke.c2[3], t);
+        t = pk_fma_xk<0, 2, false>(x, ke.c2[4], q[5]); q[4] = pk_fma_xk<1, 0, false>(x, ke.c2[4], t);   // (c9, c10 = c9)
+        t = pk_fma_xk<0, 1, true>(x, ko.a[3], q[6]);  q[5] = pk_fma_xk<1, 1, false>(x, ke.c2[4], t);    // (c11, c12) = (c8, c7)
+        t = pk_fma_xk<0, 1, true>(x, ko.a[2], q[7]);  q[6] = pk_fma_xk<1, 1, false>(x, ke.c2[3], t);
+        t = pk_fma_xk<0, 1, true>(x, ko.a[1], q[8]);  q[7] = pk_fma_xk<1, 1, false>(x, ke.c2[2], t);
+        t = pk_fma_xk<0, 1, true>(x, ko.a[0], q[9]);  q[8] = pk_fma_xk<1, 1, false>(x, ke.c2[1], t);
+        t = pk_mul_xk<0, true>(x, ko.a[4]);           q[9] = pk_fma_xk<1, 1, false>(x, ke.c2[0], t);    // (c19, c20) = (c0, 0)
+        return pf2{out0, q[0].x};
+    }
+};
+
 // =============================================================================================
 // Stage A of the PAL-D front end (cm_stages.h: PalDFrontA) with two of its three half-band chains in one packed chain:
 // lane x = up2(x), lane y = dn2 -> e.  The interpolator runs ONE SAMPLE AHEAD (it is fed x[t + 1] in step t and its
@@ -224,22 +307,23 @@ struct PalDFrontAPk {
     typedef DemodK<float, S> K;
     typedef VPolicy<CM_V_PALD> VP;
     HalfbandChainPk xe;               // (up2(x) one sample ahead, dn2 -> e)
-    HalfbandChain<float> up_e;
+    HalfbandChain<float> up_e;        // up2(e), one push per step (step) ...
+    HalfbandUp2Pk up_e2;              // ... or two pushes per packed update (step2); a kernel uses one of the two
     IirState<float, S::NE> bpf;
     float hold_b, a_odd;              // a_odd: up2(x)'s odd output of the step to come
 
     __device__ __forceinline__ void reset() {
-        xe.reset(); up_e.reset(); bpf.reset();
+        xe.reset(); up_e.reset(); up_e2.reset(); bpf.reset();
         hold_b = a_odd = 0.f;
     }
     // before step 0: x0 = x[0]
     __device__ __forceinline__ void prime(const TapsPk &kp, float x0) {
         a_odd = xe.push_pair(kp, pf2{0.f, 0.f}, pf2{x0, 0.f}).x;
     }
-    // x_next = x[t + 1] (0 beyond the row); the rest as PalDFrontA::step.  ts: the taps as scalars (halves of kp's pairs)
+    // x_next = x[t + 1] (0 beyond the row); the rest as PalDFrontA::step up to e[n3].  ts: the taps as scalars (halves of kp's pairs)
     template <bool EDGE>
-    __device__ __forceinline__ Mid<float> step(const K &k, const TapsPk &kp, const Taps<float> &ts, FrontLatch<float> &la, int t, float x_next,
-                                               float x_d10, float e_d10, float &e_out) {
+    __device__ __forceinline__ float front(const K &k, const TapsPk &kp, const Taps<float> &ts, FrontLatch<float> &la, int t, float x_next,
+                                           float x_d10) {
         const int W = k.width;
         const int n1 = t - 10, n2 = n1 - k.q_e, n3 = n2 - 9;
         const bool ODD_E = S::RT ? k.odd_e != 0 : S::ODD_E;
@@ -260,11 +344,32 @@ struct PalDFrontAPk {
         a_odd = out.x;
         float e = out.y;
         if (EDGE && (n3 < 0 || n3 >= W)) e = 0.f;
+        return e;
+    }
+    template <bool EDGE>
+    __device__ __forceinline__ Mid<float> step(const K &k, const TapsPk &kp, const Taps<float> &ts, FrontLatch<float> &la, int t, float x_next,
+                                               float x_d10, float e_d10, float &e_out) {
+        const float e = front<EDGE>(k, kp, ts, la, t, x_next, x_d10);
         e_out = e;
         Mid<float> m;
         m.odd = up_e.template push<true>(ts, e);
         m.even = ts.c0 * e_d10;
         return m;
+    }
+    // steps t and t + 1 together: the interpolator of e takes both pushes as one packed update (HalfbandUp2Pk: bit-identical)
+    template <bool EDGE>
+    __device__ __forceinline__ void step2(const K &k, const TapsPk &kp, const TapsPkOdd &ko, const Taps<float> &ts, FrontLatch<float> &la, int t,
+                                          float x_next0, float x_next1, float x_d10_0, float x_d10_1, float e_d10_0, float e_d10_1,
+                                          float &e_out0, float &e_out1, Mid<float> &m0, Mid<float> &m1) {
+        const float e0 = front<EDGE>(k, kp, ts, la, t, x_next0, x_d10_0);
+        const float e1 = front<EDGE>(k, kp, ts, la, t + 1, x_next1, x_d10_1);
+        e_out0 = e0;
+        e_out1 = e1;
+        const pf2 odd = up_e2.push2(kp, ko, pf2{e0, e1});
+        m0.odd = odd.x;
+        m1.odd = odd.y;
+        m0.even = ts.c0 * e_d10_0;
+        m1.even = ts.c0 * e_d10_1;
     }
 };
 
@@ -629,6 +734,8 @@ struct SecamDemodPk {
     typedef VPolicy<CM_V_SECAM> VP;
     IirState<float, 3> bpf, ybs;
     IirState<float, 1> bell;
+    IirState<double, 3> bpf64;      // band-pass + bell of the guarded bodies (cm_stages.h: SecamBp64)
+    IirState<double, 1> bell64;
     IirStatePk<3> lp;               // (I, Q)
     IirState<float, 1> deemph;
     HalfbandChain<float> up, dn;
@@ -636,8 +743,11 @@ struct SecamDemodPk {
     pf2 p_last, iq_prev, iq_hold;
     int have_prev;
 
+    __device__ __forceinline__ void to32() { convert_state(bpf, bpf64); convert_state(bell, bell64); }
+    __device__ __forceinline__ void to64() { convert_state(bpf64, bpf); convert_state(bell64, bell); }
     __device__ __forceinline__ void reset() {
         bpf.reset(); ybs.reset(); bell.reset(); lp.reset(); deemph.reset();
+        bpf64.reset(); bell64.reset();
         up.reset(); dn.reset();
         cc_last = x_last = 0.f;
         p_last = iq_prev = iq_hold = pf2{0.f, 0.f};
@@ -645,20 +755,24 @@ struct SecamDemodPk {
     }
     // car_e / car_o: {cos, sin} of the FM reference at 2x samples 2 m2 and 2 m2 + 1 (SGPR pairs).
     // EDGE = false: the caller guarantees that no stage index of this step touches a row boundary (every guard below holds
-    // and no latch fires): the interior of a row runs without the wave-uniform branches.
+    // and no latch fires): the interior of a row runs without the wave-uniform branches.  The guarded steps run the
+    // band-pass + bell in float64 (e64; the caller converts the states where the kind of body changes: to32 / to64).
     template <bool EDGE = true>
     __device__ __forceinline__ float chroma_step(const SecamDemodK<float> &k, const SecamDemodKPk &kp, const SecamDemodLaneK<float> &lk, int m,
-                                                 float cc_now, float ch_d10, pf2 car_e, pf2 car_o, float dc, float &ch_out) {
+                                                 float cc_now, float ch_d10, pf2 car_e, pf2 car_o, float dc, float &ch_out, const SecamBp64 &e64) {
         const int W = k.width, Lc = k.width + k.preroll;
         const int m1 = m - k.s_b, m2 = m1 - 10, m3 = m2 - k.q_l, m4 = m3 - 9, n = m4 - k.preroll;
         float ch = 0.f;
-        if (!EDGE || (m >= 0 && m < Lc + k.s_b)) {
-            if (EDGE) {
+        if (EDGE) {
+            if (m >= 0 && m < Lc + k.s_b) {
                 if (m == Lc - 1) cc_last = cc_now;
                 if (m >= Lc) cc_now = cc_last;
+                const double b = iir_bp<false>(bpf64, e64.bpf, (double)cc_now);
+                if (m1 >= 0) ch = (float)(k.has_bell ? iir_bp<false>(bell64, e64.bell, b) : b);
             }
+        } else {
             float b = iir_bp<VP::VB>(bpf, k.bpf, cc_now);
-            if (!EDGE || m1 >= 0) ch = k.has_bell ? iir_bp<false>(bell, k.bell, b) : b;
+            ch = k.has_bell ? iir_bp<false>(bell, k.bell, b) : b;
         }
         if (EDGE && (m1 < 0 || m1 >= Lc)) ch = 0.f;
         ch_out = ch;
@@ -761,27 +875,33 @@ struct SecamDemodPkA {
     typedef VPolicy<CM_V_SECAM_A> VP;
     IirState<float, 3> bpf;
     IirState<float, 1> bell;
+    IirState<double, 3> bpf64;      // band-pass + bell of the guarded bodies (cm_stages.h: SecamBp64)
+    IirState<double, 1> bell64;
     IirStatePk<3> lp;               // (I, Q)
     HalfbandChain<float> up;
     float cc_last;
     pf2 p_last, iq_hold;
 
+    __device__ __forceinline__ void to32() { convert_state(bpf, bpf64); convert_state(bell, bell64); }
+    __device__ __forceinline__ void to64() { convert_state(bpf64, bpf); convert_state(bell64, bell); }
     __device__ __forceinline__ void reset() {
         bpf.reset(); bell.reset(); lp.reset(); up.reset();
+        bpf64.reset(); bell64.reset();
         cc_last = 0.f;
         p_last = iq_hold = pf2{0.f, 0.f};
     }
-    // y0, y1: the low-passed (I, Q) of the pair m3 (meaningful where stage B's guards hold)
+    // y0, y1: the low-passed (I, Q) of the pair m3 (meaningful where stage B's guards hold).  The guarded step: band-pass
+    // + bell in float64 (the caller converts the states where the kind of body changes: to32 / to64)
     __device__ __forceinline__ void step(const SecamDemodK<float> &k, const SecamDemodKPk &kp, int m, float cc_now, float ch_d10, pf2 car_e,
-                                         pf2 car_o, float &ch_out, pf2 &y0, pf2 &y1) {
+                                         pf2 car_o, float &ch_out, pf2 &y0, pf2 &y1, const SecamBp64 &e64) {
         const int Lc = k.width + k.preroll;
         const int m1 = m - k.s_b, m2 = m1 - 10;
         float ch = 0.f;
         if (m >= 0 && m < Lc + k.s_b) {
             if (m == Lc - 1) cc_last = cc_now;
             if (m >= Lc) cc_now = cc_last;
-            float b = iir_bp<VP::VB>(bpf, k.bpf, cc_now);
-            if (m1 >= 0) ch = k.has_bell ? iir_bp<false>(bell, k.bell, b) : b;
+            const double b = iir_bp<false>(bpf64, e64.bpf, (double)cc_now);
+            if (m1 >= 0) ch = (float)(k.has_bell ? iir_bp<false>(bell64, e64.bell, b) : b);
         }
         if (m1 < 0 || m1 >= Lc) ch = 0.f;
         ch_out = ch;
@@ -840,6 +960,9 @@ struct SecamDemodA64 {
     IirState<double, 3> lp_i, lp_q;
     HalfbandChain<double> up;
     double cc_last, pi_last, pq_last, i_hold, q_hold;
+
+    __device__ __forceinline__ void to32() {}
+    __device__ __forceinline__ void to64() {}
 
     __device__ __forceinline__ void reset() {
         bpf.reset(); bell.reset(); lp_i.reset(); lp_q.reset(); up.reset();

@@ -28,7 +28,7 @@ def build_secam_plan(stack, components=False, min_lines=0):
     d.decode_matrix[:] = list(numpy.asarray(eye if components else m.decode_matrix).reshape(-1))
     d.encode_matrix[:] = list(numpy.asarray(eye if components else m.encode_matrix).reshape(-1))
     s = d.secam
-    s.present = 1
+    s.present = plan.CM_SECAM_PRESENT | (plan.CM_SECAM_FLOAT64 if getattr(m, 'float64_front_end', False) else 0)
     s.preroll = width // 40 - 1
     if s.preroll < 0:
         raise NotImplementedError('rows shorter than 40 samples have no chroma pre-roll')

@@ -104,8 +104,12 @@ typedef struct {
  *   mod_main:   [0] fsc, [1] fdev, [2] 1 = Db line, [3] start phase (0 or pi, secam.py:248-256, 273),
  *               [4] luma weight of the call's own row, [5] of the previous call's row, [6], [7] chroma
  *               weights likewise (comb.py:141-152); all for the line that is actually modulated */
+#define CM_SECAM_PRESENT 1  /* cm_secam_desc.present: the constants below are filled in */
+#define CM_SECAM_FLOAT64 2  /* ... | this: run the decoder's chroma front end (band-pass .. (I, Q) low-pass) in float64 whatever the
+                             * shape - the library selects it by itself where float32 rounding noise would come near 1e-5
+                             * (cm_api.hip: create_secam), at about half the throughput */
 typedef struct {
-    int32_t present;
+    int32_t present;       /* CM_SECAM_PRESENT [| CM_SECAM_FLOAT64] */
     int32_t preroll;       /* len(composite) // 40 - 1 mirrored samples in front of the chroma band-pass (secam.py:283) */
     double flimit_min, flimit_max, bell_f0, m0, bell_kn, bell_kd;
     double fm_fc;          /* FmDecoder centre (secam.py:179, 187) */

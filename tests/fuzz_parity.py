@@ -1,5 +1,5 @@
 """Randomised parity sweep: random (stack, variant, image size, frame count, first frame) against the float64 oracle,
-both directions.  TEST TOOL (uses oracle/): python tests/fuzz_parity.py [cases] [seed]"""
+both directions.  TEST TOOL (uses oracle/): python tests/fuzz_parity.py [cases] [seed] [pal|ntsc|secam]"""
 import sys, time, warnings
 import numpy
 sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
@@ -11,6 +11,7 @@ import stacks
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 rng = numpy.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+ONLY = sys.argv[3] if len(sys.argv) > 3 else None       # 'pal' / 'ntsc' / 'secam': only that system's stacks (and no MAC cases)
 PAL_V = ['PAL', 'PAL_M', 'PAL_N']
 NTSC_V = ['NTSC', 'NTSC_I', 'NTSC_N', 'NTSC361', 'NTSC443', 'NTSC_A']
 SECAM_V = ['SECAM', 'SECAM_I', 'SECAM_II', 'SECAM_III', 'SECAM_A', 'SECAM_M', 'SECAM_N']
@@ -54,7 +55,7 @@ bad = []
 t0 = time.time()
 done = 0
 while done < N:
-    if rng.random() < 0.08:
+    if ONLY is None and rng.random() < 0.08:
         tag, e_mod, e_dem = mac_case(rng)
         done += 1
         worst = max(worst, e_mod, e_dem)
@@ -64,6 +65,8 @@ while done < N:
         print('%s  mod %.1e demod %.1e%s' % (tag, e_mod, e_dem, flag))
         continue
     name, system, make = MAKERS[rng.integers(len(MAKERS))]
+    if ONLY is not None and system != ONLY:
+        continue
     vname = {'pal': PAL_V, 'ntsc': NTSC_V, 'secam': SECAM_V}[system][rng.integers({'pal': 3, 'ntsc': 6, 'secam': 7}[system])]
     v = getattr({'pal': pal.PalVariant, 'ntsc': ntsc.NtscVariant, 'secam': secam.SecamVariant}[system], vname)
     w = int(WIDTHS[rng.integers(len(WIDTHS))])

@@ -185,6 +185,12 @@ static int sim_secam_run(const cm_plan_desc *d, const double *comp, double *rgb,
     for (auto &x : st) x.reset();
     const int lat = SecamDemod<T>::latency(k);
     const int steps = Lc + lat + 2;
+    // the float32 kernels run the band-pass + bell of their guarded bodies in float64 (cm_stages.h: SecamBp64)
+    SecamBp64 e64;
+    if (!build_secam_bp64(*d, e64, g_err)) return CM_ERR_UNSUPPORTED;
+    int xb0, xb1;
+    secam_mid_bounds(W, P, lat, e64, xb0, xb1);
+    const bool f32 = std::is_same<T, float>::value;
     std::vector<std::vector<T>> ch_hist(n_calls, std::vector<T>(steps + 64, T(0)));
     std::vector<T> own(n_calls), prev_own(n_calls, T(0));
     auto xin = [&](int i, int s) -> T { return (s < 0 || s >= W) ? T(0) : T(comp[(size_t)i * W + s]); };
@@ -198,7 +204,8 @@ static int sim_secam_run(const cm_plan_desc *d, const double *comp, double *rgb,
             T ch_out;
             int m4 = m - lat + P;
             m4 = m4 < 0 ? 0 : (m4 > Lc - 1 ? Lc - 1 : m4);
-            own[i] = st[i].chroma_step(k, lk[i], m, cc, ch_d10, car, dc[m4], ch_out);
+            const bool guarded = m - P < xb0 || m - P >= xb1;
+            own[i] = st[i].chroma_step(k, lk[i], m, cc, ch_d10, car, dc[m4], ch_out, f32 && guarded ? &e64 : nullptr);
             if (m1 >= 0) ch_hist[i][m1] = ch_out;
         }
         // the back end runs one step behind (neighbour exchange), as on the device

@@ -117,3 +117,26 @@ def test_secam_streaming_matches_oracle(sim_secam, frame, first_line):
         assert fn(ctypes.byref(bp.desc), comp.ctypes.data_as(dp), out.ctypes.data_as(dp), n, frame, first_line, 0) == 0
         for i in range(n):
             assert stacks.rel_err(out[i], want[i]) < tol, i
+
+
+def test_secam_margin_frame_row_ends_in_float64(sim_secam):
+    """tests/golden/secam_iii_640_margin.npz (SECAM III, 640x76): all-float32 stages sat at 1.04e-5 in one start-of-row sample
+    (column 11).  With the band-pass + bell of the guarded bodies in float64 (cm_stages.h: SecamBp64) the float32 stage code
+    stays below 1e-6 on the whole frame - the bound the GPU test of the same frame holds the kernels to is 2e-6."""
+    import os
+    from color_modem_amd import line
+    from color_modem_amd.color import secam
+    dp = ctypes.POINTER(ctypes.c_double)
+    g = numpy.load(os.path.join(stacks.GOLDEN, 'secam_iii_640_margin.npz'))
+    size = [int(x) for x in g['size']]
+    lc = line.LineConfig((size[0], size[1]), line.LineStandard.detect(size[2]))
+    modem = secam.SecamModem(lc, getattr(secam.SecamVariant, str(g['vname'])))
+    bp = plan.build_plan(modem)
+    comp, first = g['comp'][0].astype(numpy.float64), int(g['first'])
+    for parity in (0, 1):
+        rows = numpy.ascontiguousarray(comp[parity::2])
+        n, w = rows.shape
+        o64, o32 = numpy.zeros((n, 3, w)), numpy.zeros((n, 3, w))
+        assert sim_secam.cm_sim_secam_demodulate_run_f64(ctypes.byref(bp.desc), rows.ctypes.data_as(dp), o64.ctypes.data_as(dp), n, first, parity, 0) == 0
+        assert sim_secam.cm_sim_secam_demodulate_run_f32(ctypes.byref(bp.desc), rows.ctypes.data_as(dp), o32.ctypes.data_as(dp), n, first, parity, 0) == 0
+        assert numpy.abs(o32 - o64).max() / numpy.abs(o64).max() < 1e-6
