@@ -172,7 +172,7 @@ struct cm_plan {
     ModLaunchFn mod_fn = nullptr, mod_fn_u8 = nullptr;
     std::vector<unsigned char> mod_k;
     ModLaneK<float> *mod_lanes = nullptr;
-    int mod_cycle = 0, mod_n_lines = 0, mod_depth = 0;
+    int mod_cycle = 0, mod_n_lines = 0, mod_depth = 0, mod_shape = 0;   // mod_shape: 1 = (1 section, shift 2), 2 = (2, 4), 0 = run-time shape
     std::string mod_name, demod_error;
     // SECAM
     bool secam = false;
@@ -495,6 +495,7 @@ bool select_modulator(cm_plan *p, const cm_plan_desc &d, std::string &err) {
     p->mod_cycle = tb.frame_cycle;
     p->mod_n_lines = tb.n_lines;
     p->mod_depth = d.modulation_delay ? 1 : 0;
+    p->mod_shape = shape_any ? 0 : (shape1 ? 1 : 2);
     if (shape_any) {
         p->mod_fn = p->mod_depth ? launch_qam_mod<2, kModAnyShift, 1, false, true> : launch_qam_mod<2, kModAnyShift, 0, false, true>;
         p->mod_fn_u8 = p->mod_depth ? launch_qam_mod<2, kModAnyShift, 1, true, true> : launch_qam_mod<2, kModAnyShift, 0, true, true>;
@@ -1578,37 +1579,232 @@ int cm_am_modulate_run(const cm_am_plan *p, const float *rgb, float *composite, 
 }
 }  // extern "C"
 
-extern "C" {
-int cm_comb_combine_run(const float *inner, float *uv, float *ysrc, int32_t n_calls, int32_t width, int32_t k0, int32_t own_delay,
-                        int32_t use_minavg, void *stream) {
-    if (!inner || !uv || !ysrc) return fail(CM_ERR_INVALID, "null argument");
-    if (n_calls < 0 || k0 < 0 || width < 4 || (width & 3)) return fail(CM_ERR_INVALID, "n_calls / k0 negative or width not a multiple of 4");
-    if (n_calls == 0) return CM_OK;
-    CombWrapArgs a;
-    std::memset(&a, 0, sizeof a);
-    a.inner = inner; a.uv = uv; a.ysrc = ysrc;
-    a.n = n_calls; a.Wp = width; a.k0 = k0; a.own_delay = own_delay ? 1 : 0; a.minavg = use_minavg ? 1 : 0;
-    const long long threads = (long long)n_calls * (width >> 2);
-    hipLaunchKernelGGL(comb_combine_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
+// ---- SimpleCombModem / Simple3DCombModem around PalDModem or Pal3DModem (cm_wrap_kernels.h) ------------------------------
+extern "C++" {
+namespace {
+template <int NP, int SP, bool U8, bool RT, bool MINAVG, bool NOTCH>
+int launch_wrap_back_i(const WrapBackArgs<NP> &a, int blocks, hipStream_t stream) {
+    hipLaunchKernelGGL((comb_wrap_back_kernel<NP, SP, U8, RT, MINAVG, NOTCH>), dim3(blocks), dim3(64), 0, stream, a);
     hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return fail(CM_ERR_LAUNCH, std::string("comb_combine_kernel launch: ") + hipGetErrorString(e));
+    if (e != hipSuccess) return fail(CM_ERR_LAUNCH, std::string("comb_wrap_back_kernel launch: ") + hipGetErrorString(e));
     return CM_OK;
 }
-int cm_comb_finish_run(const float *uv, const float *ysrc, const float *remod, const double *decode_matrix, float *rgb,
-                       int32_t n_calls, int32_t width, int32_t k0, void *stream) {
-    if (!uv || !ysrc || !remod || !decode_matrix || !rgb) return fail(CM_ERR_INVALID, "null argument");
-    if (n_calls < 0 || k0 < 0 || width < 4 || (width & 3)) return fail(CM_ERR_INVALID, "n_calls / k0 negative or width not a multiple of 4");
-    if (n_calls == 0) return CM_OK;
-    CombWrapArgs a;
+template <int NP, int SP, bool U8, bool RT>
+int launch_wrap_back(const Geom &g, const cm_plan *backend, const cm_comb_wrap_desc &w, hipStream_t stream) {
+    WrapBackArgs<NP> a;
     std::memset(&a, 0, sizeof a);
-    a.uv = const_cast<float *>(uv); a.ysrc = const_cast<float *>(ysrc); a.remod = remod; a.rgb = rgb;
-    a.n = n_calls; a.Wp = width; a.k0 = k0;
-    for (int i = 0; i < 9; ++i) a.m[i] = (float)decode_matrix[i];
-    const long long threads = (long long)n_calls * (width >> 2);
-    hipLaunchKernelGGL(comb_finish_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return fail(CM_ERR_LAUNCH, std::string("comb_finish_kernel launch: ") + hipGetErrorString(e));
+    a.g = g;
+    a.k = *reinterpret_cast<const ModK<float, NP> *>(backend->mod_k.data());
+    double g_n = 0.0;
+    std::string err;
+    if (!convert_sos_optional<float, 1>(w.notch, FORM_SYM, a.notch, g_n, err, "notch")) return fail(CM_ERR_UNSUPPORTED, err);
+    a.notch_gain = w.notch.n_sections ? (float)g_n : 0.f;
+    for (int i = 0; i < 9; ++i) a.m[i] = (float)w.matrix[i];
+    a.own_delay = w.own_delay ? 1 : 0;
+    a.minavg = w.minavg ? 1 : 0;
+    a.strip = w.strip_chroma ? 1 : 0;
+    const long long blocks = (g.total_calls + 62) / 63;
+    if (blocks <= 0) return CM_OK;
+    if (blocks > 0x7fffffffLL) return fail(CM_ERR_INVALID, "batch too large for one launch");
+    const bool notch = a.notch_gain != 0.f;
+    if (a.minavg) return notch ? launch_wrap_back_i<NP, SP, U8, RT, true, true>(a, (int)blocks, stream)
+                               : launch_wrap_back_i<NP, SP, U8, RT, true, false>(a, (int)blocks, stream);
+    return notch ? launch_wrap_back_i<NP, SP, U8, RT, false, true>(a, (int)blocks, stream)
+                 : launch_wrap_back_i<NP, SP, U8, RT, false, false>(a, (int)blocks, stream);
+}
+int run_wrap_back(Geom g, const cm_plan *backend, const cm_comb_wrap_desc &w, int64_t first_frame, bool u8, hipStream_t stream) {
+    g.lanes = reinterpret_cast<const LaneK<float> *>(backend->mod_lanes);
+    g.carrier4 = backend->carrier4;
+    g.carrier2 = backend->carrier2;
+    g.cycle = backend->mod_cycle;
+    g.n_lines = backend->mod_n_lines;
+    set_first_frame(backend, g, first_frame, backend->mod_cycle);
+    switch (backend->mod_shape) {
+    case 1: return u8 ? launch_wrap_back<1, 2, true, false>(g, backend, w, stream) : launch_wrap_back<1, 2, false, false>(g, backend, w, stream);
+    case 2: return u8 ? launch_wrap_back<2, 4, true, false>(g, backend, w, stream) : launch_wrap_back<2, 4, false, false>(g, backend, w, stream);
+    default: return u8 ? launch_wrap_back<2, kModAnyShift, true, true>(g, backend, w, stream)
+                       : launch_wrap_back<2, kModAnyShift, false, true>(g, backend, w, stream);
+    }
+}
+int check_wrap(const cm_plan *inner, const cm_plan *first, const cm_plan *backend, const cm_comb_wrap_desc *w) {
+    if (!inner || !backend || !w) return fail(CM_ERR_INVALID, "null argument");
+    if (inner->secam || backend->secam || (first && first->secam)) return fail(CM_ERR_INVALID, "comb wrappers take QAM-family plans");
+    if (!inner->fn) return fail(CM_ERR_UNSUPPORTED, inner->demod_error);
+    if (first && !first->fn) return fail(CM_ERR_UNSUPPORTED, first->demod_error);
+    if (!backend->mod_fn || backend->mod_depth) return fail(CM_ERR_UNSUPPORTED, "the backend plan needs a plain (not line-averaging) modulator");
+    const cm_plan_desc &d = inner->desc;
+    if (backend->desc.width != d.width || (first && first->desc.width != d.width)) return fail(CM_ERR_INVALID, "the plans differ in width");
+    if ((first != nullptr) != (d.first_is_plain != 0))
+        return fail(CM_ERR_INVALID, "a `first` plan is needed exactly when the inner decoder takes call 0 of a run from the plain decoder");
+    if (first && (first->has_first || first->desc.first_is_plain)) return fail(CM_ERR_INVALID, "the `first` plan must be a plain decoder");
+    if (w->notch.n_sections && (w->notch.n_sections != 1 || w->notch.shift != 0)) return fail(CM_ERR_UNSUPPORTED, "notch: one section, shift 0");
+    if (w->own_delay < 0 || w->own_delay > 1) return fail(CM_ERR_INVALID, "own_delay must be 0 or 1");
     return CM_OK;
+}
+// inner decoder over the calls of `g` into `scratch` ([frame][call][3][wp], or [call][3][wp] in rows mode), + the plain call 0s
+int run_wrap_inner(const cm_plan *inner, const cm_plan *first, Geom g, float *scratch, int64_t first_frame, bool with_first,
+                   hipStream_t stream) {
+    g.out = scratch;
+    g.out_plane_stride = g.Wp;
+    g.out_row_stride = 3LL * g.Wp;
+    g.out_frame_stride = 3LL * g.Wp * g.calls_per_frame;
+    g.out_calls = g.rows_mode ? 0 : 1;
+    g.skip_first = inner->desc.first_is_plain;
+    set_first_frame(inner, g, first_frame, inner->main.cycle);
+    Geom none = g;
+    int rc = run_plan(inner, g, none, false, stream);
+    if (rc || !first || !with_first) return rc;
+    Geom s = g;
+    s.sparse = 1;
+    s.skip_first = 0;
+    s.total_calls = g.rows_mode ? 1 : (g.total_calls / g.calls_per_frame) * g.runs_per_frame;
+    set_first_frame(first, s, first_frame, first->main.cycle);
+    return run_plan(first, s, none, false, stream);
+}
+struct AsyncBuf {
+    hipStream_t stream = nullptr;
+    void *p = nullptr;
+    ~AsyncBuf() { if (p) (void)hipFreeAsync(p, stream); }
+};
+int wrap_frames(const cm_plan *inner, const cm_plan *first, const cm_plan *backend, const cm_comb_wrap_desc *w, const float *in,
+                void *out, bool u8, int wp, int64_t n_frames, int64_t first_frame, hipStream_t stream) {
+    const cm_plan_desc &d = inner->desc;
+    const int W = d.width, H = d.height, D = d.demodulation_delay + (w->own_delay ? 1 : 0);
+    int rc = check_lines(inner, inner->main, H - 1 + 2 * D);
+    if (rc) return rc;
+    if (first && (rc = check_lines(first, first->main, H - 1))) return rc;
+    if (H - 1 + 2 * D >= backend->mod_n_lines) return fail(CM_ERR_INVALID, "line number beyond the backend plan's phase tables");
+    Geom g;
+    std::memset(&g, 0, sizeof g);
+    g.W = W;
+    g.Wp = wp;
+    g.H = H;
+    g.in_frame_stride = (long long)wp * H;
+    g.in_row_stride = wp;
+    const int rows0 = (H + 1) / 2, rows1 = H / 2;
+    g.calls_run0 = rows0 + D;
+    g.calls_per_frame = g.calls_run0 + (rows1 > 0 ? rows1 + D : 0);
+    g.runs_per_frame = rows1 > 0 ? 2 : 1;
+    g.first_line[0] = 0;
+    g.first_line[1] = 1;
+    g.delay = D;
+    // the component scratch: at most kChunk frames at a time (5 GB for 720 x 576).  Large on purpose: the plain first-line pass
+    // is one lane per run - 2 runs per frame, a handful of workgroups whose time is the latency of walking one row (0.23 ms) -
+    // and it is paid once per chunk (profiles/r03_wrapped_prof.txt: 256-frame chunks spent 17 % of the batch there)
+    const int64_t kChunk = 1024;
+    AsyncBuf scratch;
+    scratch.stream = stream;
+    const int64_t chunk = n_frames < kChunk ? n_frames : kChunk;
+    HIP_TRY(hipMallocAsync(&scratch.p, (size_t)chunk * g.calls_per_frame * 3 * wp * sizeof(float), stream), CM_ERR_LAUNCH);
+    for (int64_t f0 = 0; f0 < n_frames; f0 += chunk) {
+        const int64_t nf = n_frames - f0 < chunk ? n_frames - f0 : chunk;
+        Geom gi = g;
+        gi.in = in + f0 * g.in_frame_stride;
+        gi.total_calls = nf * g.calls_per_frame;
+        if ((rc = run_wrap_inner(inner, first, gi, (float *)scratch.p, first_frame + f0, true, stream))) return rc;
+        Geom gb = g;
+        gb.in = (const float *)scratch.p;
+        gb.in_plane_stride = wp;
+        gb.in_row_stride = 3LL * wp;
+        gb.in_frame_stride = 3LL * wp * g.calls_per_frame;
+        gb.in_calls = 1;
+        gb.total_calls = gi.total_calls;
+        if (u8) {   // interleaved bytes [F][H][W][3]: strides count bytes
+            gb.out = reinterpret_cast<float *>((unsigned char *)out + f0 * 3LL * W * H);
+            gb.out_frame_stride = 3LL * W * H;
+            gb.out_row_stride = 3LL * W;
+        } else {
+            gb.out = (float *)out + f0 * 3LL * wp * H;
+            gb.out_plane_stride = (long long)wp * H;
+            gb.out_frame_stride = 3LL * wp * H;
+            gb.out_row_stride = wp;
+        }
+        if ((rc = run_wrap_back(gb, backend, *w, first_frame + f0, u8, stream))) return rc;
+    }
+    return CM_OK;
+}
+}  // namespace
+}  // extern "C++"
+
+extern "C" {
+int cm_comb_wrap_demodulate_frames(const cm_plan *inner, const cm_plan *first, const cm_plan *backend, const cm_comb_wrap_desc *w,
+                                   const float *composite, float *rgb, int64_t n_frames, int64_t first_frame, void *stream) {
+    if (int rc = check_wrap(inner, first, backend, w)) return rc;
+    if (n_frames == 0) return CM_OK;
+    if (!composite || !rgb) return fail(CM_ERR_INVALID, "null argument");
+    if (n_frames < 0 || first_frame < 0) return fail(CM_ERR_INVALID, "negative frame count / number");
+    if (int rc_ = check_device(inner->device, composite, rgb)) return rc_;
+    const cm_plan_desc &d = inner->desc;
+    const int W = d.width, H = d.height, wp = (W + 3) & ~3;
+    return with_pitched_rows(composite, n_frames * H, rgb, n_frames * 3 * H, W, (hipStream_t)stream, [&](const float *in, float *out) -> int {
+        return wrap_frames(inner, first, backend, w, in, out, false, wp, n_frames, first_frame, (hipStream_t)stream);
+    });
+}
+
+int cm_comb_wrap_demodulate_frames_u8(const cm_plan *inner, const cm_plan *first, const cm_plan *backend, const cm_comb_wrap_desc *w,
+                                      const uint8_t *composite8, uint8_t *rgb8, int64_t n_frames, int64_t first_frame, void *stream) {
+    if (int rc = check_wrap(inner, first, backend, w)) return rc;
+    if (n_frames == 0) return CM_OK;
+    if (!composite8 || !rgb8) return fail(CM_ERR_INVALID, "null argument");
+    if (n_frames < 0 || first_frame < 0) return fail(CM_ERR_INVALID, "negative frame count / number");
+    if (int rc_ = check_device(inner->device, composite8, rgb8)) return rc_;
+    const cm_plan_desc &d = inner->desc;
+    const int W = d.width, H = d.height;
+    if (W % 4 != 0) return fail(CM_ERR_UNSUPPORTED, "the fused uint8 boundary needs a width that is a multiple of 4");
+    // the level-decoded composite (image.py:24-25, 62) once, as float rows: the inner decoder's component output has no byte form
+    AsyncBuf comp;
+    comp.stream = (hipStream_t)stream;
+    const long long quads = n_frames * H * (long long)(W / 4);
+    HIP_TRY(hipMallocAsync(&comp.p, (size_t)quads * 16, (hipStream_t)stream), CM_ERR_LAUNCH);
+    hipLaunchKernelGGL(decode_level_kernel, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, (hipStream_t)stream, composite8,
+                       (float *)comp.p, quads);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(CM_ERR_LAUNCH, std::string("decode_level_kernel launch: ") + hipGetErrorString(e));
+    return wrap_frames(inner, first, backend, w, (const float *)comp.p, rgb8, true, W, n_frames, first_frame, (hipStream_t)stream);
+}
+
+int cm_comb_wrap_demodulate_run(const cm_plan *inner, const cm_plan *first, const cm_plan *backend, const cm_comb_wrap_desc *w,
+                                const float *composite, float *rgb, int32_t n_calls, int32_t frame, int32_t first_line, int32_t k0,
+                                void *stream) {
+    if (int rc = check_wrap(inner, first, backend, w)) return rc;
+    if (n_calls == 0) return CM_OK;
+    if (!composite || !rgb) return fail(CM_ERR_INVALID, "null argument");
+    if (n_calls < 0 || frame < 0 || k0 < 0 || first_line < 0) return fail(CM_ERR_INVALID, "negative count / frame / line / k0");
+    if (int rc_ = check_device(inner->device, composite, rgb)) return rc_;
+    const cm_plan_desc &d = inner->desc;
+    const int W = d.width, wp = (W + 3) & ~3;
+    const int last_line = first_line + 2 * (n_calls - 1);
+    int rc = check_lines(inner, inner->main, last_line);
+    if (rc) return rc;
+    if (first && k0 == 0 && (rc = check_lines(first, first->main, first_line))) return rc;
+    if (last_line >= backend->mod_n_lines) return fail(CM_ERR_INVALID, "line number beyond the backend plan's phase tables");
+    return with_pitched_rows(composite, n_calls, rgb, 3LL * n_calls, W, (hipStream_t)stream, [&](const float *in, float *out) -> int {
+        Geom g;
+        std::memset(&g, 0, sizeof g);
+        g.in = in;
+        g.W = W;
+        g.Wp = wp;
+        g.H = n_calls;
+        g.rows_mode = 1;
+        g.calls_run0 = g.calls_per_frame = n_calls;
+        g.runs_per_frame = 1;
+        g.first_line[0] = g.first_line[1] = first_line;
+        g.k0 = k0;
+        g.total_calls = n_calls;
+        AsyncBuf scratch;
+        scratch.stream = (hipStream_t)stream;
+        HIP_TRY(hipMallocAsync(&scratch.p, (size_t)n_calls * 3 * wp * sizeof(float), (hipStream_t)stream), CM_ERR_LAUNCH);
+        int rc2 = run_wrap_inner(inner, first, g, (float *)scratch.p, frame, k0 == 0, (hipStream_t)stream);
+        if (rc2) return rc2;
+        Geom gb = g;
+        gb.in = (const float *)scratch.p;
+        gb.in_plane_stride = wp;
+        gb.in_row_stride = 3LL * wp;
+        gb.out = out;
+        gb.out_plane_stride = wp;            // rows mode writes [call][plane][W]
+        gb.out_row_stride = 3LL * wp;
+        return run_wrap_back(gb, backend, *w, frame, false, (hipStream_t)stream);
+    });
 }
 }  // extern "C"
 

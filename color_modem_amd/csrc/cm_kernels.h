@@ -56,6 +56,8 @@ struct Geom {
     int rows_mode;       // 1: input row i / output row i are the i-th submitted rows of one run
     int luma_prev_bits;  // bit r: regime r takes its luma from the previous call's input row
     int sparse;          // 1: one lane per run, call 0 of each run only (plain first-line pass)
+    int in_calls;        // frames geometry, but input row = the call's index within its frame ([frame][call] buffers: the comb
+    int out_calls;       // wrappers' scratch, cm_wrap_kernels.h); likewise the output row, and EVERY call is stored
     int skip_first;      // 1: calls with k == 0 are written by the sparse pass, not by this one
     unsigned long long *diag;  // diagnostic builds only (-DCM_DIAG): per-workgroup cycle sums; null otherwise
     unsigned *simd_load;       // wave-pair kernels (CM_SIMD_BALANCE): live load per (XCC, CU, SIMD); null: waves keep their order
@@ -474,6 +476,7 @@ __device__ __forceinline__ LaneCall locate_call(const Geom &g, int block, int de
     bool active;
     long long frame;
     int run, i;
+    int rem;     // index of the call within its frame
     if (g.sparse) {
         c = (long long)block * 64 + lane;
         active = c < g.total_calls;
@@ -481,13 +484,14 @@ __device__ __forceinline__ LaneCall locate_call(const Geom &g, int block, int de
         frame = c / g.runs_per_frame;
         run = (int)(c - frame * g.runs_per_frame);
         i = 0;
+        rem = run ? g.calls_run0 : 0;
     } else {
         c = (long long)block * (64 - depth) - depth + lane;
         active = lane >= depth && c < g.total_calls;
         if (c < 0) c = 0;
         if (c >= g.total_calls) c = g.total_calls - 1;
         frame = c / g.calls_per_frame;
-        int rem = (int)(c - frame * g.calls_per_frame);
+        rem = (int)(c - frame * g.calls_per_frame);
         run = rem >= g.calls_run0 ? 1 : 0;
         i = rem - (run ? g.calls_run0 : 0);
     }
@@ -507,8 +511,16 @@ __device__ __forceinline__ LaneCall locate_call(const Geom &g, int block, int de
         r.prev_row = r.line - 2;
         if (r.prev_row < 0) r.prev_row = r.src_row;
         if (r.prev_row >= g.H) r.prev_row -= 2 * ((r.prev_row - g.H) / 2 + 1);
-        r.out_row = r.line - 2 * g.delay;
-        r.store_ok = r.store_ok && i >= g.delay && r.out_row >= 0 && r.out_row < g.H;
+        if (g.in_calls) {
+            r.src_row = rem;
+            r.prev_row = i > 0 ? rem - 1 : rem;
+        }
+        if (g.out_calls) {
+            r.out_row = rem;
+        } else {
+            r.out_row = r.line - 2 * g.delay;
+            r.store_ok = r.store_ok && i >= g.delay && r.out_row >= 0 && r.out_row < g.H;
+        }
     }
     return r;
 }

@@ -272,9 +272,17 @@ __global__ __launch_bounds__(64, CM_QAM_MOD_WAVES) void qam_mod_kernel(const Mod
     const int T = (g.Wp + sp + 3) & ~3;
     f4 cur[3], nxt[3];
     first_tile3<U8>(g, itile, rp, lane, nxt);
-    for (int tb = 0; tb < T; tb += 4) {
+    // interior bodies (round 3; the SECAM encoder has had them since round 2): s_p <= t and t + 3 < W - 1 for the four steps - no
+    // guard of QamModCore::step can fail, no carrier index needs a clamp and the output sample n7 = t - s_p lies inside the row
+    int tb_mid0 = (sp + 3) & ~3, tb_mid1 = (W - 4) & ~3;
+    if (tb_mid1 <= tb_mid0) tb_mid0 = tb_mid1 = 0;
+    constexpr int kOT = U8 ? kOutTileU8 : kTile;          // pixels per output tile row
+    const int s_flush = (sp + 3) & 3;                     // the step of a body whose output sample ends a quad
+    auto body = [&](auto edge_tag, int tb) __attribute__((always_inline)) {
+        constexpr bool EDGE = decltype(edge_tag)::value;
         cur[0] = nxt[0]; cur[1] = nxt[1]; cur[2] = nxt[2];
         next_tile3x<U8>(g, itile, rp, lane, tb + 4, nxt);
+        const const_f2 *carp = (const_f2 *)g.carrier2 + (tb - sp);
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             const int t = tb + s;
@@ -290,8 +298,9 @@ __global__ __launch_bounds__(64, CM_QAM_MOD_WAVES) void qam_mod_kernel(const Mod
             }
             yw[SP + s] = y;
             const int n7 = t - sp;
-            int nc = n7 < 0 ? 0 : (n7 > W - 1 ? W - 1 : n7);
-            f2 cc = ((const_f2 *)g.carrier2)[nc];
+            f2 cc;
+            if (EDGE) cc = ((const_f2 *)g.carrier2)[n7 < 0 ? 0 : (n7 > W - 1 ? W - 1 : n7)];
+            else cc = carp[s];
             float car[2] = {cc.x, cc.y};
             float y_d = yw[s];                 // luma of sample n7 = t - SP
             if (RT) {                          // ... = t - s_p: a chain of uniform selects instead of a dynamic register index
@@ -299,12 +308,25 @@ __global__ __launch_bounds__(64, CM_QAM_MOD_WAVES) void qam_mod_kernel(const Mod
                 for (int j = 0; j < SP; ++j)
                     if (sp == j) y_d = yw[SP - j + s];
             }
-            float comp = core.step(k, lk, t, y_d, u, v, car);
-            put_composite<U8, kTile>(g, otile_base, op, lane, wpos, n7, comp);
+            float comp = core.template step<EDGE>(k, lk, t, y_d, u, v, car);
+            if (EDGE) {
+                put_composite<U8, kTile>(g, otile_base, op, lane, wpos, n7, comp);
+            } else {
+                if (U8) ((lds_byte *)otile_base)[lane * kOutTileU8 + (n7 & (kOutTileU8 - 1))] = composite_byte(comp);
+                else otile_base[lane * kTile + (wpos ^ (n7 & (kTile - 1)))] = comp;
+                if (s == s_flush && (n7 & (kOT - 1)) == kOT - 1) {
+                    if (U8) flush_tile1_u8(g, otile_base, op, n7 & ~(kOT - 1), lane);
+                    else flush_tile1<kTile>(g, otile_base, op, n7 & ~(kOT - 1), lane);
+                }
+            }
         }
 #pragma unroll
         for (int j = 0; j < SP; ++j) yw[j] = yw[j + 4];
-    }
+    };
+    int tb = 0;
+    for (; tb < tb_mid0; tb += 4) body(std::true_type(), tb);
+    for (; tb < tb_mid1; tb += 4) body(std::false_type(), tb);
+    for (; tb < T; tb += 4) body(std::true_type(), tb);
 }
 
 }  // namespace cm

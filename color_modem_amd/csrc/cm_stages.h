@@ -629,12 +629,16 @@ struct QamModCore {
         u_last = v_last = T(0);
     }
     // n: index of (u, v); y_d = luma at n - s_p; car = {C[2 (n - s_p)], S[2 (n - s_p)]}
+    // EDGE = false: the caller guarantees 0 <= n < W - 1 (no guard can fail, no latch fires): the interior of a row
+    template <bool EDGE = true>
     CM_HD T step(const ModK<T, NP> &k, const ModLaneK<T> &lk, int n, T y_d, T u, T v, const T car[2]) {
         const int W = k.width;
         T wu = T(0), wv = T(0);
-        if (n >= 0 && n < W + k.s_p) {
-            if (n == W - 1) { u_last = u; v_last = v; }
-            if (n >= W) { u = u_last; v = v_last; }
+        if (!EDGE || (n >= 0 && n < W + k.s_p)) {
+            if (EDGE) {
+                if (n == W - 1) { u_last = u; v_last = v; }
+                if (n >= W) { u = u_last; v = v_last; }
+            }
             wu = iir_gen<false>(pre_u, k.pre, u);
             wv = iir_gen<false>(pre_v, k.pre, v);
         }

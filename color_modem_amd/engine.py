@@ -128,7 +128,7 @@ def make_engine(modem, components=False, strip_chroma=True, min_lines=0):
     kind = stack['kind']
     if stack.get('demod_wrapper') and kind in ('pal_d', 'pal_3d'):
         from color_modem_amd import wrapped
-        return wrapped.WrappedCombEngine(modem, components, strip_chroma)
+        return wrapped.WrappedCombEngine(modem, components, strip_chroma, min_lines)
     if kind == 'mac':
         return MacEngine(modem, components)
     if kind in ('protosecam', 'niir'):

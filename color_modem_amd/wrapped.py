@@ -3,39 +3,47 @@
 
 These stacks do not fit the per-line coefficient tables of the fused decoders: on the second line of every run the wrapper
 averages the plain first-line decode (QAM front end) with the first delay-line decode (PAL-D front end), and around
-Pal3DModem it reaches back three lines.  They run as a composition of device kernels, call for call what the reference
-does (comb.py:96-113):
+Pal3DModem it reaches back three lines.  They run as two streaming kernels per batch behind ONE native call
+(`cm_comb_wrap_demodulate_frames` / `_frames_u8` / `_run`, csrc/cm_wrap_kernels.h), call for call what the reference does
+(comb.py:96-113):
 
-    backend.demodulate_components(frame, line, composite, strip_chroma=False)   the inner decoder's kernel in component mode
-    u, v = avg(last, curr); y = last / curr luma                                cm_comb_combine_run
-    backend.modulate_components(frame, line - 2 own_delay, 0, u, v)             the inner modulator's kernel
-    y - that; decode_components                                                 cm_comb_finish_run
+    backend.demodulate_components(frame, line, composite, strip_chroma=False)   the inner decoder's kernel in component mode,
+                                                                                every call of every run of the batch
+    u, v = avg(last, curr); y = last / curr luma                                |
+    y -= backend.modulate_components(frame, line - 2 own_delay, 0, u, v)        |  comb_wrap_back_kernel: one lane per call,
+    y = notch(y)                                                                |  the previous call = the neighbouring lane
+    decode_components                                                           |
 
-torch only owns the buffers and gathers the rows of a run.  Not built: a wrapper notch (comb.py:108-110 needs a recursive
-filter along the row between the last two steps) and avg= callables other than comb.avg / comb.minavg.
+This module only builds the three plans (inner decoder, plain first-line decoder, backend modulator) and the wrapper's
+descriptor.  Not built: avg= callables other than comb.avg / comb.minavg.
 """
 
 import ctypes
 
 import numpy
 
-from color_modem_amd import _native, engine
+from color_modem_amd import _native, engine, plan
+
+
+class CombWrapDesc(ctypes.Structure):
+    """cm_comb_wrap_desc (include/color_modem_hip.h)"""
+    _fields_ = [('own_delay', ctypes.c_int32), ('minavg', ctypes.c_int32), ('strip_chroma', ctypes.c_int32),
+                ('reserved', ctypes.c_int32), ('notch', plan.IirDesc), ('matrix', ctypes.c_double * 9)]
 
 
 class WrappedCombEngine(object):
     composite = True        # rowapi: no device-resident session, the run goes through demodulate_run
 
-    def __init__(self, modem, components=False, strip_chroma=True):
+    def __init__(self, modem, components=False, strip_chroma=True, min_lines=0):
         from color_modem_amd import comb as comb_module
         stack = modem._stack()
-        if stack.get('wrapper_notch') is not None:
-            raise NotImplementedError('notch= on a comb wrapper around PalDModem / Pal3DModem is not built')
         fn = stack.get('wrapper_avg')
         if fn is not comb_module.avg and fn is not comb_module.minavg:
             raise NotImplementedError('avg=%r: the device path implements comb.avg and comb.minavg' % (fn,))
-        if not strip_chroma:
-            raise NotImplementedError('demodulate_components(strip_chroma=False) on a wrapper around PalDModem / Pal3DModem is not built')
-        self.minavg = fn is comb_module.minavg
+        notch = stack.get('wrapper_notch')
+        if notch is not None and notch.shift != 0:
+            raise NotImplementedError('notch filters with a group delay at DC that rounds to %d samples (very low Q) '
+                                      'are not built; shift 0 is' % notch.shift)
         self.own_delay = 1 if stack['demod_wrapper'] == 'simple_3d' else 0
         self.inner_modem = stack['comb']                    # PalDModem / Pal3DModem
         self.backend = stack['backend']                     # PalSModem
@@ -45,90 +53,85 @@ class WrappedCombEngine(object):
         d_in = int(getattr(self.inner_modem, 'demodulation_delay', 0))
         self.demodulation_delay = d_in + self.own_delay
         self.modulation_delay = 0
-        need = self.height + 2 * self.demodulation_delay + 8
+        need = max(self.height + 2 * self.demodulation_delay + 8, int(min_lines))
         self.inner = engine.Engine(self.inner_modem, components=True, strip_chroma=False, min_lines=need)
         self.first = None
         if self.inner.built.desc.first_is_plain:
             # the first line of a run is the backend's own unstripped decode (comb.py:48-49): its plan
             self.first = engine.Engine(self.backend, components=True, strip_chroma=False, min_lines=need)
-        self.mod = engine.Engine(self.backend, components=True, min_lines=need)
+        self.mod = engine.Engine(self.backend, components=True, min_lines=need)       # the wrapper re-modulates through the backend
         self.encoder = engine.Engine(self.backend, components=components, min_lines=need)     # wrapper.modulate = backend.modulate
         self.demod_depth = self.inner.demod_depth + 1
         self.mod_depth = 0
-        self.n_lines = 1 << 30
+        self.n_lines = min(e.n_lines for e in (self.inner, self.first, self.mod, self.encoder) if e is not None)
+        w = CombWrapDesc()
+        w.own_delay = self.own_delay
+        w.minavg = 1 if fn is comb_module.minavg else 0
+        w.strip_chroma = 1 if strip_chroma else 0
+        w.notch = plan.iir_desc(notch)
         eye = numpy.eye(3)
-        self._matrix = numpy.ascontiguousarray(eye if components else self.backend.decode_matrix, dtype=numpy.float64).reshape(-1)
+        w.matrix[:] = list(numpy.asarray(eye if components else self.backend.decode_matrix, dtype=numpy.float64).reshape(-1))
+        self.desc = w
 
     def describe(self):
-        return 'composition: %s (components) | comb_combine_kernel | qam_mod_kernel | comb_finish_kernel' % self.inner.describe()
+        return 'composition: %s (components, every call of the batch) | comb_wrap_back_kernel' % self.inner.describe()
 
-    # ---- one run ------------------------------------------------------------------------------
-    def _run(self, rows, frame, first_line, k0):
-        """rows [n, W] cuda tensor: calls k0 .. k0 + n - 1 of one run at lines first_line, first_line + 2, ...
-        -> [n, 3, W] cuda tensor (rows whose history lies before the buffer are unspecified)."""
+    def _plans(self, device):
+        return (self.inner._plans.get(device), self.first._plans.get(device) if self.first is not None else None,
+                self.mod._plans.get(device))
+
+    def _call(self, fn, x, out, *args):
         import torch
-        n, W = rows.shape
-        L = _native.lib()
-        yuv = self.inner.demodulate_run(rows, frame, first_line, k0)
-        if k0 == 0 and self.first is not None:
-            yuv[0:1] = self.first.demodulate_run(rows[0:1], frame, first_line, 0)
-        uv = torch.empty_like(yuv)
-        ysrc = torch.empty((n, W), dtype=torch.float32, device=rows.device)
-        remod = torch.zeros((n, W), dtype=torch.float32, device=rows.device)
-        out = torch.empty_like(yuv)
-        with torch.cuda.device(rows.device):
-            stream = torch.cuda.current_stream(rows.device).cuda_stream
-            _native.check(L.cm_comb_combine_run(yuv.data_ptr(), uv.data_ptr(), ysrc.data_ptr(), n, W, int(k0), self.own_delay,
-                                                1 if self.minavg else 0, stream))
-            i0 = 1 if k0 == 0 else 0                      # call 0 of a run is not stripped (comb.py:97-99)
-            if n > i0:
-                remod[i0:] = self.mod.modulate_run(uv[i0:], frame, first_line + 2 * i0 - 2 * self.own_delay, 0)
-            m = (ctypes.c_double * 9)(*self._matrix)
-            _native.check(L.cm_comb_finish_run(uv.data_ptr(), ysrc.data_ptr(), remod.data_ptr(), m, out.data_ptr(), n, W, int(k0), stream))
-        return out
+        inner, first, mod = self._plans(x.device)
+        with torch.cuda.device(x.device):
+            stream = torch.cuda.current_stream(x.device).cuda_stream
+            _native.check(fn(inner, first, mod, ctypes.byref(self.desc), x.data_ptr(), out.data_ptr(), *(tuple(args) + (stream,))))
 
+    # ---- one run (rowapi) ----------------------------------------------------------------------
     def demodulate_run(self, rows, frame, first_line, k0):
+        """rows [n, W]: calls k0 .. k0 + n - 1 of one run at lines first_line, first_line + 2, ... -> [n, 3, W] (rows whose
+        history lies before the buffer are unspecified)."""
         import torch
         was_numpy = isinstance(rows, numpy.ndarray)
         t = torch.from_numpy(numpy.ascontiguousarray(rows, dtype=numpy.float32)).cuda() if was_numpy else rows.contiguous()
-        if self.width % 4:
-            raise NotImplementedError('wrappers around PalDModem / Pal3DModem need a width that is a multiple of 4')
-        out = self._run(t, int(frame), int(first_line), int(k0))
+        if t.dim() != 2 or t.shape[1] != self.width or t.dtype != torch.float32:
+            raise ValueError('rows: expected float32 [n, %d]' % self.width)
+        out = torch.empty((t.shape[0], 3, self.width), dtype=torch.float32, device=t.device)
+        self._call(_native.lib().cm_comb_wrap_demodulate_run, t, out, int(t.shape[0]), int(frame), int(first_line), int(k0))
         return out.cpu().numpy() if was_numpy else out
 
-    # ---- frames: the row schedule of image.py:75-83, one run per field -----------------------
-    def demodulate_frames(self, composite, first_frame=0, out=None):
+    # ---- frames: the row schedule of image.py:75-83 --------------------------------------------
+    def _frames(self, fn, composite, dtype, out, out_shape_of, first_frame):
         import torch
         was_numpy = isinstance(composite, numpy.ndarray)
-        comp = torch.from_numpy(numpy.ascontiguousarray(composite, dtype=numpy.float32)).cuda() if was_numpy else composite
-        if comp.dtype != torch.float32 or comp.dim() != 3 or tuple(comp.shape[1:]) != (self.height, self.width):
-            raise ValueError('composite: expected float32 [n, %d, %d]' % (self.height, self.width))
-        if self.width % 4:
-            raise NotImplementedError('wrappers around PalDModem / Pal3DModem need a width that is a multiple of 4')
-        n, H, D = comp.shape[0], self.height, self.demodulation_delay
-        shape = (n, 3, H, self.width)
+        np_dtype = numpy.float32 if dtype == torch.float32 else numpy.uint8
+        comp = torch.from_numpy(numpy.ascontiguousarray(composite, dtype=np_dtype)).cuda() if was_numpy else composite
+        if not torch.is_tensor(comp) or comp.dtype != dtype or comp.dim() != 3 or tuple(comp.shape[1:]) != (self.height, self.width):
+            raise ValueError('composite: expected %s [n, %d, %d]' % ('float32' if dtype == torch.float32 else 'uint8', self.height, self.width))
+        if not comp.is_cuda:
+            comp = comp.cuda()
+        comp = comp.contiguous()
+        shape = out_shape_of(comp.shape[0])
         if out is None:
-            out = torch.empty(shape, dtype=torch.float32, device=comp.device)
+            out = torch.empty(shape, dtype=dtype, device=comp.device)
         else:
-            engine._check_out(out, shape, torch.float32, comp.device)
-        for fi in range(n):
-            for field in range(2):
-                rows_out = list(range(field, H, 2))
-                if not rows_out:
-                    continue
-                lines = [field + 2 * k for k in range(len(rows_out) + D)]
-                src = []
-                for ln in lines:
-                    while ln >= H:                        # image.py:80-81
-                        ln -= 2
-                    src.append(ln)
-                idx = torch.tensor(src, dtype=torch.long, device=comp.device)
-                res = self._run(comp[fi].index_select(0, idx).contiguous(), int(first_frame) + fi, field, 0)
-                out[fi, :, field::2] = res[D:].permute(1, 0, 2)
+            engine._check_out(out, shape, dtype, comp.device)
+        self._call(fn, comp, out, int(comp.shape[0]), int(first_frame))
         return out.cpu().numpy() if was_numpy else out
 
-    def demodulate_frames_u8(self, *args, **kwargs):
-        raise NotImplementedError('no fused byte boundary for this stack: the PIL entry points convert on the host')
+    def demodulate_frames(self, composite, first_frame=0, out=None):
+        """composite [F, H, W] float32 (numpy or cuda tensor) -> rgb [F, 3, H, W] of the same kind."""
+        import torch
+        return self._frames(_native.lib().cm_comb_wrap_demodulate_frames, composite, torch.float32, out,
+                            lambda n: (n, 3, self.height, self.width), first_frame)
+
+    def demodulate_frames_u8(self, composite8, first_frame=0, out=None):
+        """'L' bytes [F, H, W] -> interleaved 'RGB' bytes [F, H, W, 3] (image.py:58-84 fused into the kernels)."""
+        import torch
+        if self.width % 4:
+            raise NotImplementedError('the fused uint8 boundary needs a width that is a multiple of 4')
+        return self._frames(_native.lib().cm_comb_wrap_demodulate_frames_u8, composite8, torch.uint8, out,
+                            lambda n: (n, self.height, self.width, 3), first_frame)
 
     # ---- the encoder side is the backend's (comb.py:90-94) ------------------------------------
     def modulate_frames(self, rgb, first_frame=0, out=None):

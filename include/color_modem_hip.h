@@ -307,20 +307,37 @@ int cm_am_modulate_run(const cm_am_plan *plan, const float *rgb, float *composit
 int cm_am_demodulate_run(const cm_am_plan *plan, const float *composite, float *rgb, int32_t n_calls, int32_t frame,
                          int32_t first_line, int32_t k0, void *stream);
 
-/* ---- SimpleCombModem / Simple3DCombModem around PalDModem or Pal3DModem (comb.py:96-113 over pal.py:79-234) ---------------
- * These stacks run as a composition: the inner decoder through cm_demodulate_run in component mode with
- * strip_chroma = False (what the wrapper asks its backend for), then the wrapper's own arithmetic - the two calls below -
- * around the inner modulator's cm_modulate_run (the wrapper strips the luma by re-modulating the averaged chroma).
- * All buffers are device pointers, rows of `width` samples (a multiple of 4), n_calls consecutive calls of one run, k0 the
- * index of the first of them within the run.
- *   combine: inner [n][3][width] = (y, u, v) the backend returned per call -> uv [n][3][width] = (0, u, v) with
- *            u, v = avg / minavg(previous call, this call) (comb.py:103-104; call 0 of a run: its own), ysrc [n][width] = the
- *            luma source (comb.py:102: the previous call's luma when own_delay, else this call's)
- *   finish:  rgb [n][3][width] = decode_matrix . (ysrc - remod (not on call 0 of a run, comb.py:97-99), u, v) */
-int cm_comb_combine_run(const float *inner, float *uv, float *ysrc, int32_t n_calls, int32_t width, int32_t k0, int32_t own_delay,
-                        int32_t use_minavg, void *stream);
-int cm_comb_finish_run(const float *uv, const float *ysrc, const float *remod, const double *decode_matrix, float *rgb,
-                       int32_t n_calls, int32_t width, int32_t k0, void *stream);
+/* ---- SimpleCombModem / Simple3DCombModem around PalDModem or Pal3DModem (comb.py:71-127 over pal.py:62-234) -----------------
+ * Replaces SimpleCombModem.demodulate_components / demodulate (comb.py:96-122) when the backend is a PAL delay-line decoder.
+ * These stacks run as two streaming kernels per batch (csrc/cm_wrap_kernels.h): the inner decoder in
+ * component mode with strip_chroma = False over all calls of the batch (what the wrapper asks its backend for, comb.py:97, 101),
+ * then the wrapper's own arithmetic - averaging of consecutive calls' chroma and the luma source (comb.py:102-104), the luma
+ * strip by re-modulating the averaged chroma (comb.py:105-107: the backend modulator's pre-correction filter and carrier), the
+ * notch (comb.py:108-110) and decode_components (comb.py:121-122).
+ *   inner    plan of the wrapped decoder (PalDModem / Pal3DModem) built for the component protocol with strip_chroma = False
+ *   first    plan of the plain decoder (PalSModem, components, strip_chroma = False) when the inner decoder takes call 0 of a
+ *            run from it (comb.py:48-49: cm_plan_desc.first_is_plain), else NULL
+ *   backend  plan of the plain modem (PalSModem, components): its modulator constants are used
+ * The plans' lane tables must cover line numbers up to height - 1 + 2 (inner demodulation_delay + own_delay). */
+typedef struct {
+    int32_t own_delay;      /* 1: Simple3DCombModem / SimpleCombModem(delay=True) (comb.py:74, 126) */
+    int32_t minavg;         /* 1: avg=comb.minavg (comb.py:13-15), 0: comb.avg (comb.py:9-10) */
+    int32_t strip_chroma;   /* the flag of demodulate_components (comb.py:96); 1 for demodulate */
+    int32_t reserved;
+    cm_iir_desc notch;      /* the wrapper's notch= (comb.py:18-20, 86-88): one section, shift 0; n_sections = 0: none */
+    double matrix[9];       /* decode_components (comb.py:121-122), row major; identity for the component protocol */
+} cm_comb_wrap_desc;
+/* composite [F][H][W] float32 -> rgb [F][3][H][W] float32, the row schedule of image.py:75-83 (device pointers) */
+int cm_comb_wrap_demodulate_frames(const cm_plan *inner, const cm_plan *first, const cm_plan *backend, const cm_comb_wrap_desc *wrap,
+                                   const float *composite, float *rgb, int64_t n_frames, int64_t first_frame, void *stream);
+/* the same with the ImageModem byte boundary (image.py:58-84): 'L' bytes [F][H][W] -> interleaved 'RGB' bytes [F][H][W][3] */
+int cm_comb_wrap_demodulate_frames_u8(const cm_plan *inner, const cm_plan *first, const cm_plan *backend, const cm_comb_wrap_desc *wrap,
+                                      const uint8_t *composite8, uint8_t *rgb8, int64_t n_frames, int64_t first_frame, void *stream);
+/* One run of n_calls consecutive calls as cm_demodulate_run: rows [n][W] -> [n][3][W]; a run submitted with k0 > 0 carries one
+ * call of history in front (inner depth + 1 calls before the first wanted result). */
+int cm_comb_wrap_demodulate_run(const cm_plan *inner, const cm_plan *first, const cm_plan *backend, const cm_comb_wrap_desc *wrap,
+                                const float *composite, float *rgb, int32_t n_calls, int32_t frame, int32_t first_line, int32_t k0,
+                                void *stream);
 
 /* Name, main-loop instruction mix and launch geometry of the dominant kernel of the last
  * cm_demodulate_frames call on this plan (for bench.py / profiling); returns bytes written. */

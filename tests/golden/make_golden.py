@@ -249,6 +249,8 @@ STACKS.update({
     'simple_pald': lambda lc: comb.SimpleCombModem(pal.PalDModem(lc)),
     'simple3d_pal3d': lambda lc: comb.Simple3DCombModem(pal.Pal3DModem(lc)),
     'simple3d_pald_minavg': lambda lc: comb.Simple3DCombModem(pal.PalDModem(lc), avg=comb.minavg),
+    'simple3d_pald_notch': lambda lc: comb.Simple3DCombModem(pal.PalDModem(lc), notch=6.0),
+    'simple_pal3d_notch': lambda lc: comb.SimpleCombModem(pal.Pal3DModem(lc), notch=3.0, avg=comb.minavg),
 })
 STANDARD = {'pal': 'GERBER_625', 'ntsc': 'NTSC_525', 'secam': 'GERBER_625', 'simple3d': 'GERBER_625', 'simple': 'GERBER_625'}
 STANDARD_OF = {'pal_d_palm': 'NTSC_525', 'pal_s_palm': 'NTSC_525', 'pal_d_60': 'NTSC_525', 'pal_s_60': 'NTSC_525',
@@ -404,10 +406,13 @@ def variant_cases(only=()):
         save('frames_demod_' + tag, inp=comp, out=out, frames=numpy.array(frames), size=numpy.array([W, H]))
 
 
-def wrapper_cases():
+def wrapper_cases(only=()):
     """SimpleCombModem / Simple3DCombModem around PalDModem and Pal3DModem: 720 x 10 frames of a valid PAL signal."""
     W, H = 720, 10
-    for stack, frames in (('simple3d_pald', [1, 2]), ('simple_pald', [1, 2]), ('simple3d_pal3d', [1, 2]), ('simple3d_pald_minavg', [0, 3])):
+    for stack, frames in (('simple3d_pald', [1, 2]), ('simple_pald', [1, 2]), ('simple3d_pal3d', [1, 2]), ('simple3d_pald_minavg', [0, 3]),
+                          ('simple3d_pald_notch', [0, 3]), ('simple_pal3d_notch', [1, 2])):
+        if only and stack not in only:
+            continue
         lc = line_config(stack, (W, H))
         enc = STACKS['pal_s'](lc)
         rgb = testing.synthetic_rgb(len(frames), H, W, seed=321)
@@ -462,7 +467,7 @@ if __name__ == '__main__':
         width_cases()
         sys.exit(0)
     if sys.argv[1:2] == ['wrappers']:
-        wrapper_cases()
+        wrapper_cases(sys.argv[2:])
         sys.exit(0)
     if sys.argv[1:2] == ['variants']:
         variant_cases(sys.argv[2:])

@@ -17,13 +17,15 @@ def timeit(fn, reps=5):
 for stack, size, direction in [('pal_d', (720, 576), 'demod'), ('pal_s', (720, 576), 'demod'), ('pal_3d', (720, 576), 'demod'),
                                ('ntsc', (720, 480), 'demod'), ('ntsc_comb', (720, 480), 'demod'), ('ntsc_comb_3d', (720, 480), 'demod'),
                                ('secam', (720, 576), 'demod'), ('secam', (720, 576), 'mod'), ('secam_avg', (720, 576), 'mod'),
-                               ('pal_s', (720, 576), 'mod'), ('ntsc', (720, 480), 'mod')]:
+                               ('pal_s', (720, 576), 'mod'), ('ntsc', (720, 480), 'mod'),
+                               ('simple3d_pald', (720, 576), 'demod'), ('simple3d_pal3d', (720, 576), 'demod')]:
     w, h = size
     modem = stacks.make(stack, size)
     im = image.ImageModem(modem); eng = im._engine()
     rgb2 = testing.synthetic_rgb(2, h, w, seed=3)
     base = stack.replace('_avg', '')
-    enc = stacks.make({'pal_d': 'pal_s', 'pal_3d': 'pal_s', 'ntsc_comb': 'ntsc', 'ntsc_comb_3d': 'ntsc'}.get(base, base), size)
+    enc = stacks.make({'pal_d': 'pal_s', 'pal_3d': 'pal_s', 'ntsc_comb': 'ntsc', 'ntsc_comb_3d': 'ntsc', 'simple3d_pald': 'pal_s',
+                       'simple3d_pal3d': 'pal_s'}.get(base, base), size)
     if direction == 'demod':
         comp2 = cm_oracle.modulate_frames_f32(enc, rgb2, 1, 8)
         got = eng.demodulate_frames(comp2, 1); want = cm_oracle.demodulate_frames_f32(modem, comp2, 1, 8)

@@ -66,6 +66,8 @@ STACKS.update({
     'simple_pald': lambda lc: comb.SimpleCombModem(pal.PalDModem(lc)),
     'simple3d_pal3d': lambda lc: comb.Simple3DCombModem(pal.Pal3DModem(lc)),
     'simple3d_pald_minavg': lambda lc: comb.Simple3DCombModem(pal.PalDModem(lc), avg=comb.minavg),
+    'simple3d_pald_notch': lambda lc: comb.Simple3DCombModem(pal.PalDModem(lc), notch=6.0),
+    'simple_pal3d_notch': lambda lc: comb.SimpleCombModem(pal.Pal3DModem(lc), notch=3.0, avg=comb.minavg),
 })
 STANDARD = {'pal': 'GERBER_625', 'ntsc': 'NTSC_525', 'secam': 'GERBER_625', 'simple3d': 'GERBER_625', 'simple': 'GERBER_625'}
 STANDARD_OF = {'pal_d_palm': 'NTSC_525', 'pal_s_palm': 'NTSC_525', 'pal_d_60': 'NTSC_525', 'pal_s_60': 'NTSC_525',

@@ -142,6 +142,410 @@ def test_secam_round_trip_on_device():
     assert stacks.rel_err(back, back_ref) <= stacks.rel_err(back_of_gpu_comp, back_ref) + TOL
 
 
+# ---- the PIL / uint8 boundary (ImageModem.modulate / demodulate, image.py:27-84) -------------------------
+@pytest.mark.parametrize('name', sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(stacks.GOLDEN, 'image_*.npz'))))
+def test_image_uint8_golden(name):
+    from PIL import Image
+    g = stacks.load(name)
+    h, w = g['comp8'].shape
+    im = image.ImageModem(stacks.make(name[len('image_'):], (w, h)))
+    img = Image.frombytes('RGB', (w, h), numpy.ascontiguousarray(g['rgb8']).tobytes())
+    comp = im.modulate(img, int(g['frame']))
+    assert comp.mode == 'L' and comp.size == (w, h)
+    comp8 = numpy.frombuffer(comp.tobytes(), dtype=numpy.uint8).reshape(h, w)
+    diff = numpy.abs(comp8.astype(int) - g['comp8'].astype(int))
+    assert diff.max() <= 1 and (diff > 0).mean() < 2e-3     # float32 vs float64 at the rounding knife edge
+    back = im.demodulate(Image.frombytes('L', (w, h), numpy.ascontiguousarray(g['comp8']).tobytes()), int(g['frame']))
+    back8 = numpy.frombuffer(back.tobytes(), dtype=numpy.uint8).reshape(h, w, 3)
+    diff = numpy.abs(back8.astype(int) - g['back8'].astype(int))
+    assert diff.max() <= 1 and (diff > 0).mean() < 2e-3
+
+
+# ---- size-independent properties at the benchmark's frame size ------------------------------------------
+def test_full_size_properties_pal_d():
+    import torch
+    modem = stacks.make('pal_d', (720, 576))
+    eng = image.ImageModem(modem)._engine()
+    n = 24
+    comp = torch.from_numpy(testing.synthetic_composite(n, 576, 720, seed=4321)).cuda()
+    out = eng.demodulate_frames(comp, first_frame=0)
+    # (1) frames are independent: any sub-batch gives bit-identical results
+    part = eng.demodulate_frames(comp[5:9].contiguous(), first_frame=5)
+    assert torch.equal(out[5:9], part)
+    # (2) the carrier phase repeats every 4 frames (PAL 8-field sequence)
+    again = eng.demodulate_frames(comp, first_frame=4)
+    assert torch.equal(out, again)
+    other = eng.demodulate_frames(comp, first_frame=1)
+    assert not torch.equal(out, other)
+    # (3) the decoder is linear in the composite signal
+    a, b = comp[:n // 2], comp[n // 2:]
+    lin = eng.demodulate_frames((0.5 * a - 0.25 * b).contiguous(), first_frame=0)
+    ref = 0.5 * out[:n // 2] - 0.25 * eng.demodulate_frames(b.contiguous(), first_frame=0)
+    err = float((lin - ref).abs().max() / ref.abs().max())
+    assert err < 5e-6, err
+    # (4) a constant composite carries no chroma: the decoder returns grey at that level away from the row edges
+    flat = torch.full((1, 576, 720), 0.4, dtype=torch.float32, device='cuda')
+    g = eng.demodulate_frames(flat, 0)[0, :, 8:, 100:620]
+    assert float((g - 0.4).abs().max()) < 1e-4
+
+
+def test_empty_batch_and_bad_shapes():
+    import torch
+    eng = image.ImageModem(stacks.make('pal_d', (720, 576)))._engine()
+    out = eng.demodulate_frames(torch.empty((0, 576, 720), dtype=torch.float32, device='cuda'))
+    assert tuple(out.shape) == (0, 3, 576, 720)
+    with pytest.raises(ValueError):
+        eng.demodulate_frames(numpy.zeros((1, 575, 720), dtype=numpy.float32))
+    with pytest.raises(ValueError):
+        stacks.make('pal_d', (720, 576)).demodulate(0, 0, numpy.zeros(719))
+
+
+# ---- other colour-system variants that share a built filter-set shape -----------------------------------
+def _variant_modem(kind, variant, size):
+    from color_modem_amd import comb, line
+    from color_modem_amd.color import ntsc, pal, secam
+    lc = line.LineConfig(size)
+    if kind == 'pal_s':
+        return pal.PalSModem(lc, getattr(pal.PalVariant, variant))
+    if kind == 'pal_d':
+        return pal.PalDModem(lc, getattr(pal.PalVariant, variant))
+    if kind == 'pal_3d':
+        return pal.Pal3DModem(lc, getattr(pal.PalVariant, variant))
+    if kind == 'secam_avg':
+        return comb.ColorAveragingModem(secam.SecamModem(lc, getattr(secam.SecamVariant, variant)))
+    if kind == 'ntsc':
+        return ntsc.NtscModem(lc, getattr(ntsc.NtscVariant, variant))
+    if kind == 'ntsc_comb':
+        return ntsc.NtscCombModem(lc, getattr(ntsc.NtscVariant, variant))
+    if kind == 'ntsc_comb_3d':
+        return comb.Simple3DCombModem(ntsc.NtscCombModem(lc, getattr(ntsc.NtscVariant, variant)))
+    if kind == 'secam':
+        return secam.SecamModem(lc, getattr(secam.SecamVariant, variant))
+    raise KeyError(kind)
+
+
+@pytest.mark.parametrize('kind,variant,size', [
+    ('pal_s', 'PAL_N', (720, 576)), ('pal_s', 'PAL_M', (720, 480)), ('ntsc_comb', 'NTSC_I', (720, 480)),
+    ('ntsc_comb_3d', 'NTSC443', (720, 576)), ('ntsc_comb', 'NTSC_N', (720, 576)), ('ntsc_comb', 'NTSC361', (720, 480)),
+    ('secam', 'SECAM_III', (720, 576)), ('secam', 'SECAM_M', (720, 480)), ('secam', 'SECAM_N', (720, 576)),
+    ('pal_d', 'PAL_M', (720, 480)), ('pal_d', 'PAL_N', (720, 576)), ('pal_3d', 'PAL_N', (720, 576)),
+    ('secam', 'SECAM_I', (720, 576)), ('secam', 'SECAM_II', (720, 576)), ('secam_avg', 'SECAM_A', (720, 576)),
+    ('ntsc', 'NTSC_A', (720, 480)), ('ntsc_comb', 'NTSC_A', (720, 480)), ('ntsc_comb_3d', 'NTSC_A', (720, 576)),
+])
+def test_variants_round_trip_vs_oracle(kind, variant, size):
+    from oracle import cm_oracle
+    modem = _variant_modem(kind, variant, size)
+    im = image.ImageModem(modem)
+    rgb = testing.synthetic_rgb(2, size[1], size[0], seed=123)
+    comp_ref = cm_oracle.modulate_frames_f32(modem, rgb, first_frame=1, n_threads=8)
+    comp = im.modulate_frames(rgb, first_frame=1)
+    assert stacks.rel_err(comp, comp_ref) < TOL
+    got = im.demodulate_frames(comp_ref, first_frame=1)
+    want = cm_oracle.demodulate_frames_f32(modem, comp_ref, first_frame=1, n_threads=8)
+    for i in range(2):
+        assert stacks.rel_err(got[i], want[i]) < TOL, i
+
+
+# ---- other sampling rates (= image widths): the run-time-shape kernel instances ----------------------------------------------
+@pytest.mark.parametrize('stack,size', [
+    ('pal_d', (768, 576)), ('pal_d', (640, 575)), ('pal_d', (1024, 40)), ('pal_s', (1920, 24)), ('pal_3d', (960, 33)), ('pal_d', (480, 576)),
+    ('ntsc', (640, 480)), ('ntsc_comb', (704, 480)), ('ntsc_comb_3d', (1280, 30)), ('ntsc_comb', (1440, 21)), ('ntsc_comb_simple', (768, 16)),
+])
+def test_other_widths_vs_oracle(stack, size):
+    """Filter sets whose section counts / shift parities / pre-correction shift differ from the tuned 13.5 MHz shapes run on
+    the run-time-shape instances (identity-padded cascades, parities and shift read at run time): both directions."""
+    from oracle import cm_oracle
+    modem = stacks.make(stack, size, explicit=False)
+    im = image.ImageModem(modem)
+    n = 2
+    enc = stacks.make({'pal_d': 'pal_s', 'pal_3d': 'pal_s', 'ntsc_comb': 'ntsc', 'ntsc_comb_3d': 'ntsc', 'ntsc_comb_simple': 'ntsc'}.get(stack, stack),
+                      size, explicit=False)
+    rgb = testing.synthetic_rgb(n, size[1], size[0], seed=77)
+    comp_ref = cm_oracle.modulate_frames_f32(enc, rgb, first_frame=1, n_threads=8)
+    comp = image.ImageModem(enc).modulate_frames(rgb, first_frame=1)
+    assert stacks.rel_err(comp, comp_ref) < TOL
+    got = im.demodulate_frames(comp_ref, first_frame=1)
+    want = cm_oracle.demodulate_frames_f32(modem, comp_ref, first_frame=1, n_threads=8)
+    for i in range(n):
+        assert stacks.rel_err(got[i], want[i]) < TOL, (stack, size, i)
+
+
+@pytest.mark.parametrize('stack,size', [('pal_d_notch', (768, 576)), ('pal_3d_notch', (1024, 576)), ('ntsc_comb_3d_notch', (640, 480)),
+                                        ('pal_3d_minavg', (960, 576)), ('ntsc_simple_minavg', (768, 480)), ('ntsc_comb_3d_minavg', (1280, 480))])
+def test_options_at_other_widths_vs_oracle(stack, size):
+    from oracle import cm_oracle
+    from color_modem_amd import line
+    comp = testing.synthetic_composite(2, 24, size[0], seed=91)
+    modem = stacks.STACKS[stack](line.LineConfig((size[0], 24), line.LineStandard.detect(size[1])))   # 24 rows of the full-height standard
+    got = image.ImageModem(modem).demodulate_frames(comp, first_frame=1)
+    want = cm_oracle.demodulate_frames_f32(modem, comp, first_frame=1, n_threads=8)
+    for i in range(2):
+        assert stacks.rel_err(got[i], want[i]) < TOL, (stack, size, i)
+
+
+@pytest.mark.parametrize('size', [(640, 576), (768, 576), (960, 40), (1024, 576), (1280, 31), (1440, 12), (1920, 9)])
+def test_secam_other_widths_vs_oracle(size):
+    """SECAM at other sampling rates: odd FM low-pass shifts (640, 960, 1024), other pre-correction / band-pass shifts."""
+    from oracle import cm_oracle
+    modem = stacks.make('secam', size, explicit=False)
+    im = image.ImageModem(modem)
+    rgb = testing.synthetic_rgb(2, size[1], size[0], seed=78)
+    comp_ref = cm_oracle.modulate_frames_f32(modem, rgb, first_frame=2, n_threads=8)
+    assert stacks.rel_err(im.modulate_frames(rgb, first_frame=2), comp_ref) < TOL
+    got = im.demodulate_frames(comp_ref, first_frame=2)
+    want = cm_oracle.demodulate_frames_f32(modem, comp_ref, first_frame=2, n_threads=8)
+    for i in range(2):
+        assert stacks.rel_err(got[i], want[i]) < TOL, (size, i)
+
+
+@pytest.mark.parametrize('stack,size', [('pal_d', (702, 576)), ('pal_s', (718, 21)), ('pal_3d', (721, 24)), ('ntsc_comb', (711, 480)),
+                                        ('ntsc_comb_3d', (642, 19)), ('secam', (702, 576)), ('secam_avg', (715, 12)), ('ntsc_avg', (1023, 9))])
+def test_widths_that_are_not_multiples_of_4(stack, size):
+    """Dense images of such widths are staged through pitched device buffers inside the library (cm_api.hip:
+    with_pitched_rows); frames and the per-row protocol, both directions."""
+    from oracle import cm_oracle
+    modem = stacks.make(stack, size, explicit=True)
+    im = image.ImageModem(modem)
+    rgb = testing.synthetic_rgb(2, size[1], size[0], seed=79)
+    comp_ref = cm_oracle.modulate_frames_f32(modem, rgb, first_frame=1, n_threads=8)
+    assert stacks.rel_err(im.modulate_frames(rgb, first_frame=1), comp_ref) < TOL
+    got = im.demodulate_frames(comp_ref, first_frame=1)
+    want = cm_oracle.demodulate_frames_f32(modem, comp_ref, first_frame=1, n_threads=8)
+    for i in range(2):
+        assert stacks.rel_err(got[i], want[i]) < TOL, (stack, size, i)
+    # the stateful per-row protocol on a fresh modem: the first rows of field 0 of frame 1
+    dev, orc = stacks.make(stack, size, explicit=True), cm_oracle.OracleModem(stacks.make(stack, size, explicit=True))
+    for y in range(0, min(size[1], 8), 2):
+        a = numpy.stack(dev.demodulate(1, y, comp_ref[0, y]))
+        b = numpy.stack(orc.demodulate(1, y, comp_ref[0, y].astype(numpy.float64)))
+        assert stacks.rel_err(a, b) < TOL, (stack, size, y)
+
+
+# ---- sub-carrier cycles too long to tabulate per frame: two parity frames + per-frame rotation ---------------------
+@pytest.mark.parametrize('kind,variant,size,first', [
+    ('ntsc_comb_3d', 'NTSC443', (720, 480), 4798),     # NTSC 4.43 on 525 lines: cycle 4800, batch wraps around it
+    ('pal_d', 'PAL', (720, 480), 1201),                # PAL-60
+    ('pal_3d', 'PAL_M', (720, 576), 284),              # cycle 286
+    ('ntsc_comb', 'NTSC361', (720, 576), 141),         # cycle 143 (odd)
+    ('pal_s', 'PAL_N', (720, 480), 1599),              # cycle 1600
+])
+def test_long_subcarrier_cycles_vs_oracle(kind, variant, size, first):
+    from oracle import cm_oracle
+    modem = _variant_modem(kind, variant, size)
+    im = image.ImageModem(modem)
+    assert im._engine().built.desc.frame_rotation_cycle > 64
+    rgb = testing.synthetic_rgb(4, size[1], size[0], seed=77)
+    comp_ref = cm_oracle.modulate_frames_f32(modem, rgb, first_frame=first, n_threads=8)
+    comp = im.modulate_frames(rgb, first_frame=first)
+    assert stacks.rel_err(comp, comp_ref) < TOL
+    got = im.demodulate_frames(comp_ref, first_frame=first)
+    want = cm_oracle.demodulate_frames_f32(modem, comp_ref, first_frame=first, n_threads=8)
+    for i in range(4):
+        assert stacks.rel_err(got[i], want[i]) < TOL, i
+
+
+@pytest.mark.parametrize('stack,size', [('pal_d', (720, 576)), ('ntsc_comb_3d', (720, 480)), ('pal_3d', (720, 34))])
+def test_rotating_tables_equal_per_frame_tables(stack, size, monkeypatch):
+    """The same stack through both table layouts: forcing the rotation path on a short-cycle system must not move
+    the output by more than float32 rounding of the lane constants."""
+    from color_modem_amd import plan
+    rgb = testing.synthetic_rgb(6, size[1], size[0], seed=78)
+    enc = stacks.make('pal_s' if stack.startswith('pal') else 'ntsc', size)
+    comp = image.ImageModem(enc).modulate_frames(rgb, first_frame=3)
+    want = image.ImageModem(stacks.make(stack, size)).demodulate_frames(comp, first_frame=3)
+    monkeypatch.setattr(plan, 'MAX_TABLE_CYCLE', 1)
+    im = image.ImageModem(stacks.make(stack, size))
+    assert im._engine().built.desc.frame_rotation_cycle in (2, 4)
+    got = im.demodulate_frames(comp, first_frame=3)
+    assert stacks.rel_err(got, want) < 2e-6
+    comp2 = image.ImageModem(stacks.make('pal_s' if stack.startswith('pal') else 'ntsc', size)).modulate_frames(
+        rgb, first_frame=3)
+    assert stacks.rel_err(comp2, comp) < 2e-6
+
+
+# ---- options at full geometry -----------------------------------------------------------------------------------
+def _option_modem(name):
+    from color_modem_amd import comb, line
+    from color_modem_amd.color import ntsc, pal
+    pal_lc, ntsc_lc = line.LineConfig((720, 576)), line.LineConfig((720, 480))
+    if name == 'pal_d_notch':
+        return pal.PalDModem(pal_lc, notch=4.0), pal.PalSModem(pal_lc)
+    if name == 'pal_3d_notch_minavg':
+        return pal.Pal3DModem(pal_lc, notch=10.0, avg=comb.minavg), pal.PalSModem(pal_lc)
+    if name == 'pal_3d_sin_only':
+        return pal.Pal3DModem(pal_lc, use_cos=False, avg=comb.minavg), pal.PalSModem(pal_lc)
+    if name == 'simple_pal_s_minavg':
+        return comb.SimpleCombModem(pal.PalSModem(pal_lc), avg=comb.minavg, notch=6.0), pal.PalSModem(pal_lc)
+    if name == 'ntsc_comb_notch':
+        return ntsc.NtscCombModem(ntsc_lc, notch=3.0), ntsc.NtscModem(ntsc_lc)
+    if name == 'ntsc_comb_3d_minavg':
+        return comb.Simple3DCombModem(ntsc.NtscCombModem(ntsc_lc), avg=comb.minavg), ntsc.NtscModem(ntsc_lc)
+    if name == 'ntsc_comb_in_phase':
+        # a sub-carrier at a multiple of the line rate: consecutive lines in phase, the comb switches itself off
+        # (ntsc.py:55-59, 70-71) and every line after the first is the plain decode with re-modulated luma
+        v = ntsc.NtscVariant(fsc=228.0 * 15750.0 * 1000.0 / 1001.0, bandwidth3db=1300000.0, bandwidth20db=3600000.0)
+        return ntsc.NtscCombModem(ntsc_lc, v), ntsc.NtscModem(ntsc_lc, v)
+    raise KeyError(name)
+
+
+@pytest.mark.parametrize('name', ['pal_d_notch', 'pal_3d_notch_minavg', 'pal_3d_sin_only', 'simple_pal_s_minavg',
+                                  'ntsc_comb_notch', 'ntsc_comb_3d_minavg', 'ntsc_comb_in_phase'])
+def test_options_vs_oracle(name):
+    from oracle import cm_oracle
+    modem, enc = _option_modem(name)
+    size = modem.line_config.size if hasattr(modem, 'line_config') else modem.backend.line_config.size
+    rgb = testing.synthetic_rgb(3, size[1], size[0], seed=91)
+    comp = cm_oracle.modulate_frames_f32(enc, rgb, first_frame=2, n_threads=8)
+    got = image.ImageModem(modem).demodulate_frames(comp, first_frame=2)
+    want = cm_oracle.demodulate_frames_f32(modem, comp, first_frame=2, n_threads=8)
+    for i in range(3):
+        assert stacks.rel_err(got[i], want[i]) < TOL, i
+
+
+def test_unsupported_variants_fail_loudly():
+    from color_modem_amd import line
+    from color_modem_amd.color import ntsc, pal, secam
+    with pytest.raises(NotImplementedError):   # PAL-A at 13.5 MHz: buttord asks for order 154; the reference returns NaN
+        image.ImageModem(pal.PalSModem(line.LineConfig((720, 576)), pal.PalVariant.PAL_A)).demodulate_frames(
+            numpy.zeros((1, 576, 720), 'f4'))
+    with pytest.raises(ValueError):     # same failure as the reference: the band edge is beyond Nyquist at 13.5 MHz
+        secam.SecamModem(line.LineConfig((720, 576)), secam.SecamVariant.SECAM_E)
+
+
+# ---- fused uint8 boundary (cm_demodulate_frames_u8) --------------------------------------------------------
+@pytest.mark.parametrize('stack,size,n_frames,first', [('pal_d', (720, 576), 2, 1), ('pal_s', (720, 40), 3, 0),
+                                                       ('pal_3d', (720, 33), 2, 2), ('ntsc_comb_3d', (720, 480), 2, 1),
+                                                       ('ntsc', (720, 18), 2, 0), ('pal_d', (704, 9), 2, 3),
+                                                       # the run-time filter shape (other image widths)
+                                                       ('pal_d', (768, 576), 2, 1), ('ntsc_comb', (640, 480), 2, 0), ('pal_3d', (1024, 576), 2, 2),
+                                                       ('pal_s', (1280, 576), 1, 3)])
+def test_fused_uint8_matches_float_path(stack, size, n_frames, first):
+    """uint8 in / uint8 out through the kernel == host-side level decode -> float kernel -> host-side _as_bytes,
+    up to float32 rounding of the level mapping at the knife edge of rint (<= 1 LSB on < 0.2 % of the samples)."""
+    from color_modem_amd.image import _as_bytes
+    modem = stacks.make(stack, size)
+    im = image.ImageModem(modem)
+    rgb = testing.synthetic_rgb(n_frames, size[1], size[0], seed=31)
+    enc = stacks.make('pal_s' if stack.startswith('pal') else 'ntsc', size)
+    comp = image.ImageModem(enc).modulate_frames(rgb, first_frame=first)
+    comp8 = _as_bytes(image.ImageModem.encode_composite_level(comp.astype(numpy.float64)))
+    got = im.demodulate_frames_u8(comp8, first_frame=first)
+    assert got.dtype == numpy.uint8 and got.shape == (n_frames, size[1], size[0], 3)
+    ref_in = image.ImageModem.decode_composite_level(comp8.astype(numpy.float64) / 255.0).astype(numpy.float32)
+    want = _as_bytes(im.demodulate_frames(ref_in, first_frame=first).astype(numpy.float64)).transpose(0, 2, 3, 1)
+    diff = numpy.abs(got.astype(int) - want.astype(int))
+    assert diff.max() <= 1 and (diff > 0).mean() < 2e-3, (diff.max(), (diff > 0).mean())
+
+
+@pytest.mark.parametrize('stack,size,n_frames,first', [('pal_s', (720, 576), 2, 1), ('ntsc', (720, 480), 2, 0), ('ntsc_avg', (720, 18), 3, 1),
+                                                       ('secam', (720, 576), 2, 3), ('secam_avg', (720, 17), 2, 2), ('pal_s', (704, 9), 2, 3),
+                                                       ('ntsc_a', (720, 24), 2, 1)])
+def test_fused_uint8_modulate_matches_float_path(stack, size, n_frames, first):
+    """cm_modulate_frames_u8 == host-side byte / 255 -> float kernel -> host-side encode_composite_level + _as_bytes (<= 1 LSB
+    at the knife edge of rint on < 0.2 % of the samples)."""
+    from color_modem_amd.image import _as_bytes
+    im = image.ImageModem(stacks.make(stack, size))
+    rgb8 = numpy.random.default_rng(5).integers(0, 256, size=(n_frames, size[1], size[0], 3), dtype=numpy.uint8)
+    rgb8[:, :, 1:] = (rgb8[:, :, 1:].astype(int) + rgb8[:, :, :-1]) // 2     # some horizontal correlation
+    got = im.modulate_frames_u8(rgb8, first_frame=first)
+    assert got.dtype == numpy.uint8 and got.shape == (n_frames, size[1], size[0])
+    rgb = (rgb8.astype(numpy.float64) / 255.0).astype(numpy.float32).transpose(0, 3, 1, 2)
+    comp = im.modulate_frames(numpy.ascontiguousarray(rgb), first_frame=first)
+    want = _as_bytes(image.ImageModem.encode_composite_level(comp.astype(numpy.float64)))
+    diff = numpy.abs(got.astype(int) - want.astype(int))
+    assert diff.max() <= 1 and (diff > 0).mean() < 2e-3, (diff.max(), (diff > 0).mean())
+
+
+def test_fused_uint8_modulate_needs_width_multiple_of_16():
+    im = image.ImageModem(stacks.make('pal_s', (712, 8)))
+    with pytest.raises(NotImplementedError):
+        im.modulate_frames_u8(numpy.zeros((1, 8, 712, 3), numpy.uint8))
+    from PIL import Image      # the PIL entry point falls back to the float kernel
+    out = im.modulate(Image.frombytes('RGB', (712, 8), bytes(712 * 8 * 3)), 0)
+    assert out.size == (712, 8)
+
+
+@pytest.mark.parametrize('size,n_frames,first', [((720, 576), 2, 1), ((720, 21), 3, 4)])
+def test_fused_uint8_secam_demodulate_matches_float_path(size, n_frames, first):
+    from color_modem_amd.image import _as_bytes
+    im = image.ImageModem(stacks.make('secam', size))
+    rgb = testing.synthetic_rgb(n_frames, size[1], size[0], seed=41)
+    comp = im.modulate_frames(rgb, first_frame=first)
+    comp8 = _as_bytes(image.ImageModem.encode_composite_level(comp.astype(numpy.float64)))
+    got = im.demodulate_frames_u8(comp8, first_frame=first)
+    ref_in = image.ImageModem.decode_composite_level(comp8.astype(numpy.float64) / 255.0).astype(numpy.float32)
+    want = _as_bytes(im.demodulate_frames(ref_in, first_frame=first).astype(numpy.float64)).transpose(0, 2, 3, 1)
+    diff = numpy.abs(got.astype(int) - want.astype(int))
+    assert diff.max() <= 1 and (diff > 0).mean() < 2e-3, (diff.max(), (diff > 0).mean())
+
+
+# ---- component-level protocol: modulate_components / demodulate_components ---------------------------------------------
+def _rows_through(fn_dev, fn_orc, seq, rows):
+    worst = 0.0
+    for (f, y), row in zip(seq, rows):
+        got = numpy.stack(fn_dev(f, y, row))
+        want = numpy.stack(fn_orc(f, y, row))
+        worst = max(worst, stacks.rel_err(got, want))
+    return worst
+
+
+@pytest.mark.parametrize('stack,size,strip', [
+    ('pal_s', (720, 576), True), ('pal_s', (720, 576), False), ('pal_d', (720, 576), True), ('pal_d', (720, 576), False),
+    ('pal_3d', (720, 576), True), ('pal_3d', (720, 576), False), ('ntsc_comb', (720, 480), False),
+    ('ntsc_comb_3d', (720, 480), True), ('ntsc_comb_3d', (720, 480), False), ('pal_d_notch', (720, 576), True),
+    ('ntsc_simple_minavg', (720, 480), True)])
+def test_demodulate_components_rows(stack, size, strip):
+    """(y, u, v) of the per-row protocol against the oracle's restatement of the same members (qam.py:43-58,
+    comb.py:47-59, 96-113, pal.py:180-234), including a run restart in the middle of the sequence."""
+    from oracle import cm_oracle
+    modem = stacks.make(stack, size, explicit=False)
+    enc = stacks.make('pal_s' if stack.startswith('pal') else 'ntsc', size, explicit=False)
+    orc = cm_oracle.OracleModem(stacks.make(stack, size, explicit=False))
+    seq = [(1, 3), (1, 5), (1, 7), (1, 9), (2, 0), (2, 2), (2, 4), (2, 8), (2, 10)]
+    rgb = testing.synthetic_rgb(1, len(seq), size[0], seed=17)[0]
+    rows = [cm_oracle.OracleModem(enc).modulate(f, y, rgb[0, i], rgb[1, i], rgb[2, i]).astype(numpy.float32)
+            for i, (f, y) in enumerate(seq)]
+    err = _rows_through(lambda f, y, r: modem.demodulate_components(f, y, r, strip_chroma=strip),
+                        lambda f, y, r: orc.demodulate_components(f, y, r.astype(numpy.float64), strip_chroma=strip),
+                        seq, rows)
+    assert err < TOL
+
+
+@pytest.mark.parametrize('stack,size', [('pal_s', (720, 576)), ('ntsc', (720, 480)), ('pal_avg', (720, 576)),
+                                        ('secam', (720, 576)), ('secam_avg', (720, 576)), ('pal_d', (720, 576))])
+def test_modulate_components_rows(stack, size):
+    from oracle import cm_oracle
+    modem = stacks.make(stack, size, explicit=False)
+    orc = cm_oracle.OracleModem(stacks.make(stack, size, explicit=False))
+    seq = [(0, 1), (0, 3), (0, 5), (4, 2), (4, 4), (4, 8)]
+    comps = testing.synthetic_rgb(1, len(seq), size[0], seed=19)[0]
+    comps[1:] -= 0.5     # colour-difference signals are signed
+    worst = 0.0
+    for i, (f, y) in enumerate(seq):
+        got = modem.modulate_components(f, y, comps[0, i], comps[1, i], comps[2, i])
+        want = orc.modulate_components(f, y, comps[0, i].astype(numpy.float64), comps[1, i].astype(numpy.float64),
+                                       comps[2, i].astype(numpy.float64))
+        worst = max(worst, stacks.rel_err(got, want))
+    assert worst < TOL
+
+
+@pytest.mark.parametrize('variant,width', [('SECAM_A', 1920), ('SECAM_I', 720), ('SECAM_M', 1280), ('SECAM_III', 1920)])
+def test_secam_thin_margin_shapes(variant, width):
+    """Shapes whose float32 decoder missed 1e-5 at isolated row-end samples (variants without de-emphasis, sampling rates from
+    about 24 MHz on): their chroma front end runs in float64 (cm_api.hip: create_secam) - well inside the bar now."""
+    from color_modem_amd import line
+    from color_modem_amd.color import secam
+    from oracle import cm_oracle
+    lc = line.LineConfig((width, 60), line.LineStandard.detect(576))
+    modem = secam.SecamModem(lc, getattr(secam.SecamVariant, variant))
+    rgb = testing.synthetic_rgb(2, 60, width, seed=5)
+    comp = cm_oracle.modulate_frames_f32(modem, rgb, first_frame=3, n_threads=8)
+    got = image.ImageModem(modem).demodulate_frames(comp, first_frame=3)
+    want = cm_oracle.demodulate_frames_f32(modem, comp, first_frame=3, n_threads=8)
+    for i in range(2):
+        assert stacks.rel_err(got[i], want[i]) < 3e-6, (variant, width, i)
+
+
 # ---- the BASELINE.json frame sizes under both criteria (SURVEY.md Appendix C) -------------------------------------------
 @pytest.mark.parametrize('stack,enc,size,first', [
     ('pal_d', 'pal_s', (720, 576), 1), ('ntsc_comb_3d', 'ntsc', (720, 480), 0), ('secam', 'secam', (720, 576), 2),
@@ -224,17 +628,20 @@ def test_plan_refuses_host_pointers():
     assert b'device' in _native.lib().cm_last_error()
 
 
-# ---- comb wrappers around the PAL delay-line decoders (color_modem_amd/wrapped.py) -----------------------------------------
+# ---- comb wrappers around the PAL delay-line decoders (color_modem_amd/wrapped.py, csrc/cm_wrap_kernels.h) -----------------
 @pytest.mark.parametrize('stack,size,first', [('simple3d_pald', (720, 40), 1), ('simple_pald', (720, 21), 2), ('simple3d_pal3d', (720, 24), 3),
-                                              ('simple3d_pald_minavg', (704, 12), 0)])
+                                              ('simple3d_pald_minavg', (704, 12), 0), ('simple3d_pald_notch', (720, 16), 2),
+                                              ('simple_pal3d_notch', (720, 13), 1), ('simple3d_pald', (722, 10), 0),
+                                              ('simple_pald', (768, 9), 3), ('simple3d_pald', (720, 576), 1)])
 def test_wrapped_pal_comb_vs_oracle(stack, size, first):
     from oracle import cm_oracle
     modem = stacks.make(stack, size)
-    rgb = testing.synthetic_rgb(2, size[1], size[0], seed=12 + size[1])
+    n = 2 if size[1] < 100 else 1
+    rgb = testing.synthetic_rgb(n, size[1], size[0], seed=12 + size[1])
     comp = cm_oracle.modulate_frames_f32(stacks.make('pal_s', size), rgb, first_frame=first, n_threads=4)
     got = image.ImageModem(modem).demodulate_frames(comp, first_frame=first)
     want = cm_oracle.demodulate_frames_f32(modem, comp, first_frame=first, n_threads=4)
-    for i in range(2):
+    for i in range(n):
         assert stacks.rel_err(got[i], want[i]) < TOL, (stack, i)
     # the per-row protocol on the same stack, with a break in the run
     orc = cm_oracle.OracleModem(modem)
@@ -243,6 +650,44 @@ def test_wrapped_pal_comb_vs_oracle(stack, size, first):
         got_row = numpy.stack(modem.demodulate(f, y, row))
         want_row = numpy.stack(orc.demodulate(f, y, row.astype(numpy.float64)))
         assert stacks.rel_err(got_row, want_row) < TOL, (stack, f, y)
+
+
+@pytest.mark.parametrize('stack', ['simple3d_pald', 'simple_pal3d_notch'])
+@pytest.mark.parametrize('strip', [True, False])
+def test_wrapped_pal_comb_components(stack, strip):
+    """demodulate_components(strip_chroma=...) of a wrapper around PalD / Pal3D, row by row with a reset in the run
+    (comb.py:96-113: the unstripped form returns the luma source itself, and no notch)."""
+    from oracle import cm_oracle
+    size = (720, 576)
+    modem = stacks.make(stack, size, explicit=False)
+    orc = cm_oracle.OracleModem(modem)
+    comp = testing.synthetic_composite(1, 8, 720, seed=77)[0]
+    for i, (f, y) in enumerate([(2, 1), (2, 3), (2, 5), (2, 7), (2, 11), (2, 13), (3, 15), (3, 17)]):
+        got = numpy.stack(modem.demodulate_components(f, y, comp[i], strip_chroma=strip))
+        want = numpy.stack(orc.demodulate_components(f, y, comp[i].astype(numpy.float64), strip))
+        assert stacks.rel_err(got, want) < TOL, (stack, strip, f, y)
+
+
+def test_wrapped_pal_comb_batches_and_bytes():
+    """One native call per batch: a batch equals its frames decoded one by one (bit for bit), numpy in -> numpy out equals
+    tensor in -> tensor out, and the fused byte boundary equals the host-side conversions around the float path (<= 1 LSB)."""
+    import torch
+    from color_modem_amd.image import _as_bytes
+    size = (720, 36)
+    modem = stacks.make('simple3d_pald', size)
+    im = image.ImageModem(modem)
+    comp = testing.synthetic_composite(5, size[1], size[0], seed=3)
+    whole = im.demodulate_frames(comp, first_frame=2)
+    for i in range(5):
+        assert numpy.array_equal(whole[i], im.demodulate_frames(comp[i:i + 1], first_frame=2 + i)[0]), i
+    dev = im.demodulate_frames(torch.from_numpy(comp).cuda(), first_frame=2)
+    assert torch.is_tensor(dev) and numpy.array_equal(dev.cpu().numpy(), whole)
+    comp8 = _as_bytes(image.ImageModem.encode_composite_level(comp.astype(numpy.float64)))
+    got8 = im._engine().demodulate_frames_u8(comp8, 2)
+    ref_in = image.ImageModem.decode_composite_level(comp8.astype(numpy.float64) / 255.0).astype(numpy.float32)
+    want8 = _as_bytes(im.demodulate_frames(ref_in, first_frame=2).astype(numpy.float64)).transpose(0, 2, 3, 1)
+    d8 = numpy.abs(got8.astype(int) - want8.astype(int))
+    assert d8.max() <= 1 and (d8 > 0).mean() < 5e-3, (d8.max(), (d8 > 0).mean())
 
 
 # ---- the time-blocked decoder with the half-band FIRs on the matrix pipe (csrc/cm_blk_kernels.h, opt-in: CM_BLK=1) ----------

@@ -35,16 +35,17 @@ def test_struct_layout_matches_header():
     import subprocess
     import tempfile
     src = ('#include <stdio.h>\n#include "color_modem_hip.h"\nint main(void){printf("%zu %zu %zu %zu %zu", sizeof(cm_plan_desc), '
-           'sizeof(cm_iir_desc), sizeof(cm_lane_table), sizeof(cm_am_desc), sizeof(cm_mac_desc));return 0;}\n')
+           'sizeof(cm_iir_desc), sizeof(cm_lane_table), sizeof(cm_am_desc), sizeof(cm_mac_desc));'
+           'printf(" %zu", sizeof(cm_comb_wrap_desc));return 0;}\n')
     with tempfile.TemporaryDirectory() as td:
         c = os.path.join(td, 't.c')
         open(c, 'w').write(src)
         exe = os.path.join(td, 't')
         subprocess.check_call(['gcc', '-I', os.path.join(ROOT, 'include'), c, '-o', exe])
         sizes = [int(v) for v in subprocess.check_output([exe]).split()]
-    from color_modem_amd import plan_am
+    from color_modem_amd import plan_am, wrapped
     assert sizes == [ctypes.sizeof(plan.PlanDesc), ctypes.sizeof(plan.IirDesc), ctypes.sizeof(plan.LaneTable),
-                     ctypes.sizeof(plan_am.AmDesc), ctypes.sizeof(_native.MacDesc)]
+                     ctypes.sizeof(plan_am.AmDesc), ctypes.sizeof(_native.MacDesc), ctypes.sizeof(wrapped.CombWrapDesc)]
 
 
 def test_no_gpu_means_loud_failure():
