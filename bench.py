@@ -123,11 +123,35 @@ def check_frames(torch, modem, comp, out, first_frame, picks):
     return worst, bad
 
 
+def count_gpus():
+    """GPUs this process could use, counted WITHOUT touching the HIP runtime (the parent of the ranks must not hold a
+    context on GPU 0): the KFD topology in sysfs lists every node, GPUs are the ones with SIMDs; HIP_VISIBLE_DEVICES /
+    ROCR_VISIBLE_DEVICES / CUDA_VISIBLE_DEVICES narrow the set.  Returns 0 when sysfs is not there (then the launch is a
+    gloo rehearsal unless CM_BENCH_BACKEND says otherwise)."""
+    n = 0
+    base = '/sys/class/kfd/kfd/topology/nodes'
+    try:
+        for node in os.listdir(base):
+            try:
+                with open(os.path.join(base, node, 'properties')) as fh:
+                    props = dict(ln.split()[:2] for ln in fh if len(ln.split()) >= 2)
+                if int(props.get('simd_count', '0')) > 0:
+                    n += 1
+            except (OSError, ValueError):
+                pass
+    except OSError:
+        return 0
+    for var in ('HIP_VISIBLE_DEVICES', 'ROCR_VISIBLE_DEVICES', 'CUDA_VISIBLE_DEVICES'):
+        v = os.environ.get(var)
+        if v is not None:
+            n = min(n, len([x for x in v.split(',') if x.strip() != '']))
+    return n
+
+
 def launch_ranks(args):
     """Plain `python bench.py --gpus N`: start torch.distributed.run as a child process (this process has not touched
     the GPU and never replaces itself), relay rank 0's JSON line, fail if any rank failed."""
-    import torch
-    n_dev = torch.cuda.device_count()       # counting devices does not initialise the GPU
+    n_dev = count_gpus()                    # from sysfs: the parent never loads the HIP runtime
     env = dict(os.environ)
     env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
     if n_dev < args.gpus and 'CM_BENCH_BACKEND' not in env:
@@ -263,7 +287,8 @@ def main():
         if os.path.exists(tpath):
             with open(tpath) as fh:
                 tj = json.load(fh)
-            if tj.get('frames') == frames:
+            # a PMC measurement of THIS kernel on THIS workload only: same frame count, same kernel description
+            if tj.get('frames') == frames and tj.get('kernel') == eng.describe():
                 traffic = tj.get('hbm_bytes_per_launch')
         res = {
             'metric': 'Mpixels/s demodulated (720x576 PAL, 2D comb)',
@@ -284,8 +309,9 @@ def main():
                               'frac': round(valu_tflops / VALU_PEAK_TFLOPS, 4),
                               'sustained_peak': VALU_SUSTAINED_TFLOPS, 'frac_of_sustained': round(valu_tflops / VALU_SUSTAINED_TFLOPS, 4),
                               'fma_equivalents_per_pixel': FMA_EQ_PER_PIXEL,
-                              'note': 'float32 vector instructions of the main loop per pixel x 2 flop; sustained_peak = a bare '
-                                      'v_fma_f32 loop under the 1400 W cap (profiles/r01_ubench_valu.txt)'},
+                              'note': 'an ESTIMATE of the arithmetic: float32 FMA-equivalents of the PAL-D main loops per pixel '
+                                      '(counted from the ISA in round 1; packing changes the instruction count, not this number) x 2 '
+                                      'flop; sustained_peak = a bare v_fma_f32 loop under the 1400 W cap (profiles/r01_ubench_valu.txt)'},
             'check': {'max_rel_err': float('%.3g' % worst), 'allclose_violations': bad, 'tolerance': 1e-5,
                       'frames': picks if world == 1 else 'rank 0: %s, other ranks: their last frame' % picks,
                       'what': 'timed output vs float64 CPU oracle: max |out - ref| / max |ref| per plane, and the count of '

@@ -31,9 +31,9 @@ class NiirModem(utils.ConstantFrequencyCarrier, RowApi):
 
     def __init__(self, line_config, config=pal.PalVariant.PAL, noise_level=0.0):
         RowApi.__init__(self)
-        if noise_level != 0.0:
-            raise NotImplementedError('noise_level != 0 adds numpy.random noise in the reference (niir.py:45-46): not reproducible, not built')
-        self._noise_level = 0.0
+        # niir.py:45-46 / 193-194: hue noise from numpy.random, drawn by the engine in the reference's call order (db, then dr,
+        # per modulate() call) - numpy.random.seed() reproduces the reference's output
+        self._noise_level = float(noise_level)
         self.line_config = line_config
         self.config = config
         fs = line_config.fs

@@ -303,6 +303,7 @@ struct NiirModArgs {
     Geom g;
     AmGeom a;
     NiirModK<float> k;
+    const float *noise;        // [call][2][W]: the (db, dr) noise of niir.py:45-46 / 193-194 per call, or null (noise_level 0)
 };
 
 // DEPTH = 1: HueCorrectingNiirModem (niir.py:181-202): a call modulates line - 2 with the previous call's luma, the
@@ -336,7 +337,8 @@ __global__ __launch_bounds__(64, 2) void niir_mod_kernel(const NiirModArgs args)
     const int W = g.W, s_c = k.s_c;
     const int T = (g.Wp + s_c + 3) & ~3;
     for (int j = 0; j < kAmRing; ++j) ring[j * 64 + lane] = 0.f;
-    f4 cur[3], nxt[3];
+    const float *np = args.noise ? args.noise + 2LL * lc.call * W : nullptr;
+    f4 cur[3], nxt[3], nz[2] = {f4{0.f, 0.f, 0.f, 0.f}, f4{0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
     for (int p = 0; p < 3; ++p) nxt[p] = load_luma<false>(rp + p * g.in_plane_stride, 0, true, W);
     for (int tb = 0; tb < T; tb += 4) {
@@ -344,6 +346,10 @@ __global__ __launch_bounds__(64, 2) void niir_mod_kernel(const NiirModArgs args)
         for (int p = 0; p < 3; ++p) {
             cur[p] = nxt[p];
             nxt[p] = load_luma<false>(rp + p * g.in_plane_stride, tb + 4, true, W);
+        }
+        if (np) {
+            nz[0] = load_luma<false>(np, tb, true, W);
+            nz[1] = load_luma<false>(np + W, tb, true, W);
         }
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
@@ -356,10 +362,12 @@ __global__ __launch_bounds__(64, 2) void niir_mod_kernel(const NiirModArgs args)
                 float py = lane_from(idx1, y), pdb = lane_from(idx1, db), pdr = lane_from(idx1, dr);
                 if (!have_prev) { py = y; pdb = db; pdr = dr; }         // niir.py:182-186
                 float odb, odr;
-                niir_hue_correct(db, dr, pdb, pdr, odb, odr);
+                niir_hue_correct(db, dr, pdb, pdr, odb, odr, nz[0][s], nz[1][s]);
                 y = py;
                 db = odb;
                 dr = odr;
+            } else if (np) {
+                niir_add_offset_noise(db, dr, nz[0][s], nz[1][s]);
             } else {
                 niir_add_offset(db, dr);
             }

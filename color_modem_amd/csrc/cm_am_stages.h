@@ -443,14 +443,30 @@ CM_HD void niir_add_offset(T &db, T &dr) {
         dr = T(0.1);
     }
 }
+// niir.py:42-49 with noise_level != 0: the pedestal comes from the clean saturation, the hue from the noisy pair
+// (n_b, n_r = (numpy.random.random_sample - 0.5) * noise_level, drawn by the host in the reference's call order)
+template <typename T>
+CM_HD void niir_add_offset_noise(T &db, T &dr, T n_b, T n_r) {
+    const T sat = am_sqrt(db * db + dr * dr) + T(0.1);
+    db += n_b;
+    dr += n_r;
+    const T r = am_sqrt(db * db + dr * dr);
+    if (r > T(0)) {
+        db = sat * db / r;
+        dr = sat * dr / r;
+    } else {
+        db = T(0);
+        dr = sat;
+    }
+}
 // niir.py:187-198: saturation-weighted mean hue of this call (db, dr) and the previous one (pdb, pdr), the previous call's
 // saturation + 0.1
 template <typename T>
-CM_HD void niir_hue_correct(T db, T dr, T pdb, T pdr, T &odb, T &odr) {
+CM_HD void niir_hue_correct(T db, T dr, T pdb, T pdr, T &odb, T &odr, T n_b = T(0), T n_r = T(0)) {
     const T ls = am_sqrt(pdb * pdb + pdr * pdr), s = am_sqrt(db * db + dr * dr);
     T div = ls + s;
     if (div == T(0)) div = T(1);
-    const T adb = (pdb * ls + db * s) / div, adr = (pdr * ls + dr * s) / div;
+    const T adb = (pdb * ls + db * s) / div + n_b, adr = (pdr * ls + dr * s) / div + n_r;   // niir.py:192-194: noise on the mean
     const T ra = am_sqrt(adb * adb + adr * adr), ep = ls + T(0.1);
     if (ra > T(0)) {
         odb = ep * adb / ra;

@@ -76,11 +76,14 @@ template <class Main, class First>
 int launch_demod(const Geom &gm, const void *km, const Geom &gf, const void *kf, int n_first, int n_main,
                  hipStream_t stream) {
     typedef typename Main::S S;
-    PassArgs<S> am, af;
+    typedef typename FirstSys<Main, First>::type SF;
+    PassArgs<S> am;
+    PassArgs<SF> af;
     am.g = gm;
     am.k = *static_cast<const DemodK<float, S> *>(km);
     af.g = gf;
-    af.k = kf ? *static_cast<const DemodK<float, S> *>(kf) : am.k;
+    if (kf) af.k = *static_cast<const DemodK<float, SF> *>(kf);
+    else std::memcpy(&af.k, &am.k, sizeof af.k < sizeof am.k ? sizeof af.k : sizeof am.k);   // not run: n_first = 0
     // PassCfg::kUsePair: the wave pair for every instance unless the build asks for the earlier selection
     if constexpr (CM_PAIR != 0 && Main::kUsePair) {
         int floats = pair_lds_floats<Main>(am.k);
@@ -166,6 +169,7 @@ struct cm_plan {
     int rot_cycle = 0;
     LaunchFn fn = nullptr, fn_u8 = nullptr;
     bool has_first = false;
+    int seg_warm = 1 << 30;        // samples a row segment enters the stream early (segment_warmup)
     bool pair = false;             // wave-pair kernel (two wavefronts per 64 calls)
     Pass main, first;
     // modulator
@@ -225,10 +229,10 @@ bool make_pass(const cm_plan_desc &d, bool pald, bool bsf, const cm_lane_table &
     return true;
 }
 
-template <class S>
+template <class S, class SF = S>
 bool make_passes(cm_plan *p, const cm_plan_desc &d, bool pald, bool bsf, bool first, std::string &err) {
     if (!make_pass<S>(d, pald, bsf, d.demod_main, p->main, err, p->pair, p->main.depth)) return false;
-    if (first && !make_pass<S>(d, false, true, d.demod_first, p->first, err, p->pair)) return false;
+    if (first && !make_pass<SF>(d, false, true, d.demod_first, p->first, err, p->pair)) return false;
     p->has_first = first;
     return true;
 }
@@ -287,12 +291,14 @@ bool select_for_shape(cm_plan *p, const cm_plan_desc &d, const char *sys, std::s
         // comb.py:13-15 behind SimpleCombModem / Pal3DModem: one instance per shape (depth 2, notch switchable)
         if (pald || bsf || first) { err = "minavg is built behind the QAM front end (SimpleCombModem, Pal3DModem)"; return false; }
         p->fn = launch_demod<PassCfg<S, FRONT_QAM, false, 2, 16, false, true, true>, NoPass>;
+        p->fn_u8 = launch_demod<PassCfg<S, FRONT_QAM, false, 2, 16, true, true, true>, NoPass>;
         p->main.depth = 2; what = "qam front, depth 2, minavg";
     } else if (pald) {
         if constexpr (HAS_PALD) {
             if (depth != 1 || !first) { err = "PAL-D front end is built with one line of history and a plain first line"; return false; }
             if (notch) {
                 p->fn = launch_demod<PassCfg<S, FRONT_PALD, false, 1, 16, false, true>, First>;
+                p->fn_u8 = launch_demod<PassCfg<S, FRONT_PALD, false, 1, 16, true, true>, FirstU8>;
             } else {
                 p->fn = launch_demod<PassCfg<S, FRONT_PALD, false, 1, 16>, First>;
                 p->fn_u8 = launch_demod<PassCfg<S, FRONT_PALD, false, 1, 16, true>, FirstU8>;
@@ -313,6 +319,7 @@ bool select_for_shape(cm_plan *p, const cm_plan_desc &d, const char *sys, std::s
             if (depth != 1) { err = "a comb with a plain first line is built with one line of history"; return false; }
             if (notch) {
                 p->fn = launch_demod<PassCfg<S, FRONT_QAM, false, 1, 16, false, true>, First>;
+                p->fn_u8 = launch_demod<PassCfg<S, FRONT_QAM, false, 1, 16, true, true>, FirstU8>;
             } else {
                 p->fn = launch_demod<PassCfg<S, FRONT_QAM, false, 1, 16>, First>;
                 p->fn_u8 = launch_demod<PassCfg<S, FRONT_QAM, false, 1, 16, true>, FirstU8>;
@@ -325,6 +332,7 @@ bool select_for_shape(cm_plan *p, const cm_plan_desc &d, const char *sys, std::s
     } else {
         if (notch) {
             p->fn = launch_demod<PassCfg<S, FRONT_QAM, false, 2, 16, false, true>, NoPass>;
+            p->fn_u8 = launch_demod<PassCfg<S, FRONT_QAM, false, 2, 16, true, true>, NoPass>;
         } else {
             p->fn = launch_demod<PassCfg<S, FRONT_QAM, false, 2, 16>, NoPass>;
             p->fn_u8 = launch_demod<PassCfg<S, FRONT_QAM, false, 2, 16, true>, NoPass>;
@@ -360,11 +368,14 @@ bool select_any(cm_plan *p, const cm_plan_desc &d, std::string &err) {
     if (minavg) {
         if (pald || bsf || first) { err = "minavg is built behind the QAM front end (SimpleCombModem, Pal3DModem)"; return false; }
         p->fn = launch_demod<PassCfg<S, FRONT_QAM, false, 2, 16, false, true, true>, NoPass>;
+        p->fn_u8 = launch_demod<PassCfg<S, FRONT_QAM, false, 2, 16, true, true, true>, NoPass>;
         p->main.depth = 2; what = "qam front, depth 2, minavg";
     } else if (pald) {
         if (depth != 1 || !first) { err = "PAL-D front end is built with one line of history and a plain first line"; return false; }
-        if (notch) p->fn = launch_demod<PassCfg<S, FRONT_PALD, false, 1, 16, false, true>, First>;
-        else {
+        if (notch) {
+            p->fn = launch_demod<PassCfg<S, FRONT_PALD, false, 1, 16, false, true>, First>;
+            p->fn_u8 = launch_demod<PassCfg<S, FRONT_PALD, false, 1, 16, true, true>, FirstU8>;
+        } else {
             p->fn = launch_demod<PassCfg<S, FRONT_PALD, false, 1, 16>, First>;
             p->fn_u8 = launch_demod<PassCfg<S, FRONT_PALD, false, 1, 16, true>, FirstU8>;
         }
@@ -376,15 +387,19 @@ bool select_any(cm_plan *p, const cm_plan_desc &d, std::string &err) {
         p->main.depth = 0; what = "qam front + band-stop, depth 0";
     } else if (first) {
         if (depth != 1) { err = "a comb with a plain first line is built with one line of history"; return false; }
-        if (notch) p->fn = launch_demod<PassCfg<S, FRONT_QAM, false, 1, 16, false, true>, First>;
-        else {
+        if (notch) {
+            p->fn = launch_demod<PassCfg<S, FRONT_QAM, false, 1, 16, false, true>, First>;
+            p->fn_u8 = launch_demod<PassCfg<S, FRONT_QAM, false, 1, 16, true, true>, FirstU8>;
+        } else {
             p->fn = launch_demod<PassCfg<S, FRONT_QAM, false, 1, 16>, First>;
             p->fn_u8 = launch_demod<PassCfg<S, FRONT_QAM, false, 1, 16, true>, FirstU8>;
         }
         p->main.depth = 1; what = "qam front, depth 1 | plain first line";
     } else {
-        if (notch) p->fn = launch_demod<PassCfg<S, FRONT_QAM, false, 2, 16, false, true>, NoPass>;
-        else {
+        if (notch) {
+            p->fn = launch_demod<PassCfg<S, FRONT_QAM, false, 2, 16, false, true>, NoPass>;
+            p->fn_u8 = launch_demod<PassCfg<S, FRONT_QAM, false, 2, 16, true, true>, NoPass>;
+        } else {
             p->fn = launch_demod<PassCfg<S, FRONT_QAM, false, 2, 16>, NoPass>;
             p->fn_u8 = launch_demod<PassCfg<S, FRONT_QAM, false, 2, 16, true>, NoPass>;
         }
@@ -393,6 +408,28 @@ bool select_any(cm_plan *p, const cm_plan_desc &d, std::string &err) {
     p->pair = CM_PAIR != 0;   // PassCfg::kUsePair: the run-time shape does not fit one wave's registers
     p->main.name = std::string(p->pair ? "demod_pair_kernel" : "demod_kernel") + "<run-time shape: " + what + (notch ? " + notch>" : ">");
     return make_passes<S>(p, d, pald, bsf, first, err);
+}
+
+// PalDModem on the 768-sample PAL raster (SysPalSq | SysPalSqFirst): the headline decoder's instances for the square-pixel
+// image size (round 3; on the run-time shape it ran at 113 Gpixel/s against 171 at 720 wide)
+bool select_pald_sq(cm_plan *p, const cm_plan_desc &d, std::string &err) {
+    typedef SysPalSq S;
+    typedef PassCfg<SysPalSqFirst, FRONT_QAM, true, 0, 8> First;
+    typedef PassCfg<SysPalSqFirst, FRONT_QAM, true, 0, 16, true> FirstU8;
+    const bool notch = d.notch.n_sections != 0;
+    p->fn = nullptr;
+    p->fn_u8 = nullptr;
+    if (notch) {
+        p->fn = launch_demod<PassCfg<S, FRONT_PALD, false, 1, 16, false, true>, First>;
+        p->fn_u8 = launch_demod<PassCfg<S, FRONT_PALD, false, 1, 16, true, true>, FirstU8>;
+    } else {
+        p->fn = launch_demod<PassCfg<S, FRONT_PALD, false, 1, 16>, First>;
+        p->fn_u8 = launch_demod<PassCfg<S, FRONT_PALD, false, 1, 16, true>, FirstU8>;
+    }
+    p->main.depth = 1;
+    p->pair = CM_PAIR != 0;
+    p->main.name = std::string("demod_pair_kernel<pal at 768 samples per line: pal-d front, depth 1 | plain first line") + (notch ? " + notch>" : ">");
+    return make_passes<S, SysPalSqFirst>(p, d, true, false, true, err);
 }
 
 // Pick the kernel instance (main pass + optional plain first-line pass in one launch).
@@ -409,6 +446,9 @@ bool select_kernels(cm_plan *p, const cm_plan_desc &d, std::string &err) {
     };
     if (match(signature_of<SysPal>())) return select_for_shape<SysPal, true, false>(p, d, "pal", err);
 #ifndef CM_DEV_PALD_ONLY
+    if (pald && first && d.depth == 1 && d.chroma_average != CM_AVG_MIN && same_signature(want, signature_of<SysPalSq>()) &&
+        same_signature(want_first, signature_of<SysPalSqFirst>()))
+        return select_pald_sq(p, d, err);
     if (match(signature_of<SysNtsc>())) return select_for_shape<SysNtsc, true, true>(p, d, "ntsc (pal-m/n)", err);
     if (!pald && match(signature_of<SysNtscI>())) return select_for_shape<SysNtscI, false, true>(p, d, "ntsc-i", err);
     if (!pald && match(signature_of<SysNtscSq>())) return select_for_shape<SysNtscSq, false, true>(p, d, "ntsc at 640 / 704 samples per line", err);
@@ -673,6 +713,55 @@ void finish_geom(const cm_plan *p, const Pass &pass, Geom &g) {
     g.luma_prev_bits = pass.luma_prev_bits;
 }
 
+// ---- small batches: rows cut into segments (cm_kernels.h: Geom::seg_len) ---------------------------------------------------
+// A lane walks its row sample by sample, so one launch lasts as long as ONE row takes (0.2 ms for 720 samples) however few
+// rows there are: a single frame fills 10 of 256 CUs for 0.2 ms, the per-row protocol one lane of one CU.  With few
+// workgroups the row is cut into segments and every workgroup walks one segment of its 64 calls, entering the stream
+// `warm` samples early from a zero state.  The recursive filters forget that state geometrically (slowest pole of the 2x-rate
+// filters r: r^2 per sample); warm is where the memory has decayed to 1e-8 (98 samples for PAL-BG, + the FIR windows).
+// Output differs from the unsegmented walk by < 1e-7 of full scale (tests: test_small_batches_run_in_row_segments).
+static double slowest_pole(const cm_iir_desc &d) {
+    double r = 0.0;
+    for (int j = 0; j < d.n_sections && j < CM_MAX_SECTIONS; ++j) {
+        const double a1 = d.sos[j][4], a2 = d.sos[j][5], disc = a1 * a1 - 4.0 * a2;
+        const double rj = disc < 0.0 ? std::sqrt(a2) : std::fmax(std::fabs((-a1 + std::sqrt(disc)) * 0.5), std::fabs((-a1 - std::sqrt(disc)) * 0.5));
+        r = std::fmax(r, rj);
+    }
+    return r;
+}
+static int segment_warmup(const cm_plan_desc &d) {
+    const double eps = 1e-8;
+    double n = 0.0;      // samples of the 1x rate
+    const cm_iir_desc *two_x[4] = {&d.extract2x, &d.remove2x, &d.demod_lp, &d.pald_lp};
+    for (const cm_iir_desc *f : two_x) {
+        const double r = slowest_pole(*f);
+        if (r >= 1.0) return 1 << 30;
+        if (r > 0.0) n = std::fmax(n, std::log(eps) / std::log(r * r));
+    }
+    const cm_iir_desc *one_x[2] = {&d.precorrect, &d.notch};
+    for (const cm_iir_desc *f : one_x) {
+        const double r = slowest_pole(*f);
+        if (r >= 1.0) return 1 << 30;
+        if (r > 0.0) n = std::fmax(n, std::log(eps) / std::log(r));
+    }
+    return ((int)std::ceil(n) + 24 + 31) & ~31;     // + the half-band windows, on an input tile boundary (32 samples: byte tiles)
+}
+// S = number of segments for a launch of `blocks` workgroups over rows of wp samples (1: not worth it)
+static int segment_geometry(const cm_plan *p, int wp, long long blocks, int &seg_len) {
+    seg_len = 0;
+    if (!CM_SEGMENTS || !p->pair || p->blk_tiles || blocks <= 0 || blocks > 384) return 1;
+    const int warm = p->seg_warm, lat = 56;
+    if (warm >= wp) return 1;
+    long long want = (1536 + blocks - 1) / blocks;              // about six workgroups per CU in all
+    int len = (int)((wp + want - 1) / want);
+    len = (len + 15) & ~15;
+    if (len < 48) len = 48;
+    const int S = (wp + len - 1) / len;
+    if (S < 2 || 10 * (warm + len + lat) > 7 * (wp + lat)) return 1;      // less than 30 % shorter: not worth the extra work
+    seg_len = len;
+    return S;
+}
+
 // gm: main-pass geometry (total_calls set); gf: first-line geometry (total_calls = number of runs) when the plan has one
 #ifdef CM_DIAG
 static unsigned long long *g_diag;
@@ -694,6 +783,16 @@ int run_plan(const cm_plan *p, Geom gm, Geom gf, bool with_first, hipStream_t st
     if (n_main + n_first > 0x7fffffffLL) return fail(CM_ERR_INVALID, "batch too large for one launch");
     LaunchFn fn = u8 ? p->fn_u8 : p->fn;
     if (!fn) return fail(CM_ERR_UNSUPPORTED, "no kernel instance for this request");
+    int seg_len = 0;
+    const int S = segment_geometry(p, gm.Wp, n_main + n_first, seg_len);
+    if (S > 1) {      // few workgroups: every one walks a segment of its rows (blocks [seg * n, (seg + 1) * n) of each pass)
+        gm.seg_len = gf.seg_len = seg_len;
+        gm.seg_warm = gf.seg_warm = p->seg_warm;
+        gm.seg_blocks = (int)n_main;
+        gf.seg_blocks = (int)n_first;
+        n_main *= S;
+        n_first *= S;
+    }
     return fn(gm, p->main.k.data(), gf, with_first ? p->first.k.data() : nullptr, (int)n_first, (int)n_main, stream);
 }
 
@@ -827,6 +926,7 @@ int cm_plan_create(const cm_plan_desc *desc, cm_plan **out) {
     }
     // a plan is usable in one direction when only the other one lacks a kernel instance
     std::string mod_err;
+    p->seg_warm = segment_warmup(*desc);
     const bool have_demod = select_kernels(p, *desc, err);
     const bool have_mod = select_modulator(p, *desc, mod_err) && p->mod_fn;
     if (!have_demod) {
@@ -916,7 +1016,7 @@ int cm_demodulate_frames_u8(const cm_plan *p, const uint8_t *composite8, uint8_t
     if (!p || !composite8 || !rgb8) return fail(CM_ERR_INVALID, "null argument");
     if (n_frames < 0 || first_frame < 0) return fail(CM_ERR_INVALID, "negative frame count / number");
     if (!p->secam && !p->fn_u8)
-        return fail(CM_ERR_UNSUPPORTED, p->fn ? "no kernel instance with the fused uint8 boundary for this decoder (notch / minavg)"
+        return fail(CM_ERR_UNSUPPORTED, p->fn ? "no kernel instance with the fused uint8 boundary for this decoder"
                                               : p->demod_error);
     if (int rc_ = check_device(p->device, composite8, rgb8)) return rc_;
     const cm_plan_desc &d = p->desc;
@@ -1398,7 +1498,7 @@ int am_launch_demod(const cm_am_plan *p, Geom g, int64_t first_frame, hipStream_
     if (e != hipSuccess) return fail(CM_ERR_LAUNCH, std::string("proto_demod_kernel launch: ") + hipGetErrorString(e));
     return CM_OK;
 }
-int am_launch_mod(const cm_am_plan *p, Geom g, int64_t first_frame, hipStream_t stream) {
+int am_launch_mod(const cm_am_plan *p, Geom g, int64_t first_frame, hipStream_t stream, const float *noise = nullptr) {
     if (!p->mod_error.empty()) return fail(CM_ERR_UNSUPPORTED, p->mod_error);
     const int depth = p->desc.averaging ? 1 : 0;
     long long blocks = (g.total_calls + (64 - depth) - 1) / (64 - depth);
@@ -1409,9 +1509,11 @@ int am_launch_mod(const cm_am_plan *p, Geom g, int64_t first_frame, hipStream_t 
         a.g = g;
         am_geom(p, first_frame, a.a);
         a.k = p->nm;
+        a.noise = noise;
         if (depth) hipLaunchKernelGGL(niir_mod_kernel<1>, dim3((int)blocks), dim3(64), 0, stream, a);
         else hipLaunchKernelGGL(niir_mod_kernel<0>, dim3((int)blocks), dim3(64), 0, stream, a);
     } else {
+        if (noise) return fail(CM_ERR_INVALID, "noise planes are a NIIR encoder input (niir.py:45-46)");
         ProtoModArgs a;
         a.g = g;
         am_geom(p, first_frame, a.a);
@@ -1504,7 +1606,8 @@ int cm_am_demodulate_frames(const cm_am_plan *p, const float *composite, float *
         return am_launch_demod(p, g, first_frame, (hipStream_t)stream);
     });
 }
-int cm_am_modulate_frames(const cm_am_plan *p, const float *rgb, float *composite, int64_t n_frames, int64_t first_frame, void *stream) {
+static int am_modulate_frames_core(const cm_am_plan *p, const float *rgb, const float *noise, float *composite, int64_t n_frames,
+                                   int64_t first_frame, void *stream) {
     if (p && n_frames == 0) return CM_OK;
     if (!p || !rgb || !composite) return fail(CM_ERR_INVALID, "null argument");
     if (n_frames < 0 || first_frame < 0) return fail(CM_ERR_INVALID, "negative frame count / number");
@@ -1521,8 +1624,17 @@ int cm_am_modulate_frames(const cm_am_plan *p, const float *rgb, float *composit
         g.in_row_stride = wp;
         g.out_frame_stride = (long long)wp * H;
         g.out_row_stride = wp;
-        return am_launch_mod(p, g, first_frame, (hipStream_t)stream);
+        return am_launch_mod(p, g, first_frame, (hipStream_t)stream, noise);
     });
+}
+int cm_am_modulate_frames(const cm_am_plan *p, const float *rgb, float *composite, int64_t n_frames, int64_t first_frame, void *stream) {
+    return am_modulate_frames_core(p, rgb, nullptr, composite, n_frames, first_frame, stream);
+}
+int cm_am_modulate_frames_noise(const cm_am_plan *p, const float *rgb, const float *noise, float *composite, int64_t n_frames,
+                                int64_t first_frame, void *stream) {
+    if (p && n_frames == 0) return CM_OK;
+    if (!noise) return fail(CM_ERR_INVALID, "null argument");
+    return am_modulate_frames_core(p, rgb, noise, composite, n_frames, first_frame, stream);
 }
 int cm_am_demodulate_run(const cm_am_plan *p, const float *composite, float *rgb, int32_t n_calls, int32_t frame, int32_t first_line,
                          int32_t k0, void *stream) {
@@ -1550,8 +1662,8 @@ int cm_am_demodulate_run(const cm_am_plan *p, const float *composite, float *rgb
         return am_launch_demod(p, g, frame, (hipStream_t)stream);
     });
 }
-int cm_am_modulate_run(const cm_am_plan *p, const float *rgb, float *composite, int32_t n_calls, int32_t frame, int32_t first_line,
-                       int32_t k0, void *stream) {
+static int am_modulate_run_core(const cm_am_plan *p, const float *rgb, const float *noise, float *composite, int32_t n_calls, int32_t frame,
+                                int32_t first_line, int32_t k0, void *stream) {
     if (!p || !rgb || !composite) return fail(CM_ERR_INVALID, "null argument");
     if (n_calls < 0 || frame < 0 || k0 < 0) return fail(CM_ERR_INVALID, "negative count / frame / k0");
     if (n_calls == 0) return CM_OK;
@@ -1574,8 +1686,18 @@ int cm_am_modulate_run(const cm_am_plan *p, const float *rgb, float *composite, 
         g.first_line[0] = g.first_line[1] = first_line;
         g.k0 = k0;
         g.total_calls = n_calls;
-        return am_launch_mod(p, g, frame, (hipStream_t)stream);
+        return am_launch_mod(p, g, frame, (hipStream_t)stream, noise);
     });
+}
+int cm_am_modulate_run(const cm_am_plan *p, const float *rgb, float *composite, int32_t n_calls, int32_t frame, int32_t first_line,
+                       int32_t k0, void *stream) {
+    return am_modulate_run_core(p, rgb, nullptr, composite, n_calls, frame, first_line, k0, stream);
+}
+int cm_am_modulate_run_noise(const cm_am_plan *p, const float *rgb, const float *noise, float *composite, int32_t n_calls, int32_t frame,
+                             int32_t first_line, int32_t k0, void *stream) {
+    if (n_calls == 0) return CM_OK;
+    if (!noise) return fail(CM_ERR_INVALID, "null argument");
+    return am_modulate_run_core(p, rgb, noise, composite, n_calls, frame, first_line, k0, stream);
 }
 }  // extern "C"
 

@@ -56,6 +56,9 @@ struct Geom {
     int rows_mode;       // 1: input row i / output row i are the i-th submitted rows of one run
     int luma_prev_bits;  // bit r: regime r takes its luma from the previous call's input row
     int sparse;          // 1: one lane per run, call 0 of each run only (plain first-line pass)
+    int seg_len;         // > 0: small batches - the row is cut into segments of seg_len samples (a multiple of 16) and every
+    int seg_blocks;      // workgroup walks ONE segment of its 64 calls, starting seg_warm samples early from a zero state (the
+    int seg_warm;        // recursive filters forget it: cm_api.hip: segment_geometry); blocks [seg * seg_blocks, ...) own segment seg
     int in_calls;        // frames geometry, but input row = the call's index within its frame ([frame][call] buffers: the comb
     int out_calls;       // wrappers' scratch, cm_wrap_kernels.h); likewise the output row, and EVERY call is stored
     int skip_first;      // 1: calls with k == 0 are written by the sparse pass, not by this one
@@ -468,6 +471,7 @@ __device__ __forceinline__ void fill_tile(const Geom &g, lds_float *itile, const
 // Which call of the flattened [frame][run][call] list a lane owns, and where its rows live.
 struct LaneCall {
     long long frame;
+    long long call;     // index of the call in the flattened [frame][run][call] list of the batch (the order the reference makes them in)
     int line, kk, regime, src_row, prev_row, out_row;
     bool store_ok;
 };
@@ -497,6 +501,7 @@ __device__ __forceinline__ LaneCall locate_call(const Geom &g, int block, int de
     }
     LaneCall r;
     r.frame = frame;
+    r.call = frame * g.calls_per_frame + rem;
     r.line = g.first_line[run] + 2 * i;
     r.kk = g.k0 + i;
     r.regime = r.kk < 2 ? r.kk : 2;
@@ -866,6 +871,9 @@ inline int pair_lds_floats(const DemodK<float, typename Cfg::S> &k) {
 #ifndef CM_PALD_UP2
 #define CM_PALD_UP2 1
 #endif
+#ifndef CM_SEGMENTS          /* 0: never cut rows into segments (host: cm_api.hip: segment_geometry) */
+#define CM_SEGMENTS 1
+#endif
 template <class Cfg>
 __device__ __forceinline__ void run_pair(const Geom &g, const DemodK<float, typename Cfg::S> &k_in, int block, lds_float *lds,
                                          int role) {
@@ -894,6 +902,11 @@ __device__ __forceinline__ void run_pair(const Geom &g, const DemodK<float, type
     lds_float *yring = uvring + PairLds<Cfg>::kUv;
 
     const int lane = threadIdx.x & 63;
+    int seg = 0;
+    if (g.seg_len) {
+        seg = block / g.seg_blocks;
+        block -= seg * g.seg_blocks;
+    }
     const LaneCall lc = locate_call(g, block, DEPTH, lane);
     const long long frame = lc.frame;
     const int regime = lc.regime;
@@ -914,6 +927,22 @@ __device__ __forceinline__ void run_pair(const Geom &g, const DemodK<float, type
     if (t_mid1 <= t_mid0) t_mid0 = t_mid1 = 0; // tiny rows: the guarded body runs everything
 #ifdef CM_EXP_ALL_EDGE   /* timing experiment: every body is a guarded one */
     t_mid0 = t_mid1 = 0;
+#endif
+    // Row segments (small batches, Geom::seg_len): this workgroup produces the output samples [x_lo, x_hi) only.  It enters
+    // the stream at tb0 = x_lo - seg_warm (on an input tile boundary) with every filter state zero - the start-of-row state when
+    // tb0 = 0, else a state the recursive filters have forgotten by x_lo (to 1e-8) - and leaves it once sample x_hi - 1 is out.
+#if CM_SEGMENTS
+    int x_lo = 0, tb0 = 0, T_end = T;
+    if (g.seg_len) {
+        x_lo = seg * g.seg_len;
+        const int x_hi = x_lo + g.seg_len;
+        tb0 = x_lo - g.seg_warm;
+        tb0 = tb0 < 0 ? 0 : tb0 & ~(kIT - 1);
+        if (x_hi < Wp) T_end = (x_hi - 1 + lat_out + 4) & ~3;
+    }
+#else     /* -DCM_SEGMENTS=0: whole rows only (A/B of what the segment windows cost the large-batch kernel) */
+    const int x_lo = 0, tb0 = 0, T_end = T;
+    (void)seg;
 #endif
 
 #ifdef CM_DIAG
@@ -938,7 +967,7 @@ __device__ __forceinline__ void run_pair(const Geom &g, const DemodK<float, type
         TapsPk tkp;
         TapsPkOdd tko;
         Taps<float> tks;
-        constexpr bool UP2 = PKF && PALD && CM_PALD_UP2 != 0;
+        constexpr bool UP2 = PKF && PALD && CM_PALD_UP2 != 0 && S::NE < 3;   // (the three-section band-pass has no registers for it: it would spill)
         if constexpr (UP2) tko.load(k.taps);
         if constexpr (PKF) {
             tkp.load(k.taps);
@@ -993,8 +1022,8 @@ __device__ __forceinline__ void run_pair(const Geom &g, const DemodK<float, type
             if (BSF || LRING) return f4{0.f, 0.f, 0.f, 0.f};
             return load_luma<U8>(lp, first, check, W);
         };
-        if (U8) fill_tile_u8(g, itile, xp, 0, lane); else fill_tile<kIT>(g, itile, xp, 0, lane);
-        f4 lum_cur = read_luma(-lat_out, true);   // luma source of B's block 0
+        if (U8) fill_tile_u8(g, itile, xp, tb0 / kInTile, lane); else fill_tile<kIT>(g, itile, xp, tb0 / kIT, lane);
+        f4 lum_cur = read_luma(tb0 - lat_out, true);   // luma source of B's first block
         if (LRING) {   // blocks B reads before A has written them lie before the row: zeros
             for (int j = 0; j < kLB; ++j) *(lds_f4 *)(lring + j * 256 + lane * 4) = f4{0.f, 0.f, 0.f, 0.f};
         }
@@ -1002,7 +1031,7 @@ __device__ __forceinline__ void run_pair(const Geom &g, const DemodK<float, type
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_wave_barrier();
         {
-            f4 x0 = read_x(0);
+            f4 x0 = read_x(tb0);
             xw[10] = x0.x; xw[11] = x0.y; xw[12] = x0.z; xw[13] = x0.w;
             if constexpr (PKF) fa.prime(tkp, x0.x);
         }
@@ -1052,7 +1081,7 @@ __device__ __forceinline__ void run_pair(const Geom &g, const DemodK<float, type
                     CM_ACC(d_other, t0);
                 }
                 xq = read_x(nxt);
-                if ((nxt & (kIT - 1)) == kIT - 4 && nxt + 4 < W) {
+                if ((nxt & (kIT - 1)) == kIT - 4 && nxt + 4 < W && nxt + 4 < T_end) {
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                     __builtin_amdgcn_wave_barrier();
                     if (U8) fill_tile_u8(g, itile, xp, nxt / kIT + 1, lane); else fill_tile<kIT>(g, itile, xp, nxt / kIT + 1, lane);
@@ -1094,7 +1123,7 @@ __device__ __forceinline__ void run_pair(const Geom &g, const DemodK<float, type
                     f4 xn = read_x(nxt);
                     xw[10] = xn.x; xw[11] = xn.y; xw[12] = xn.z; xw[13] = xn.w;
                 }
-                if ((nxt & (kIT - 1)) == kIT - 4 && nxt + 4 < W) {  // that was the last read of this tile: refill it
+                if ((nxt & (kIT - 1)) == kIT - 4 && nxt + 4 < W && nxt + 4 < T_end) {  // that was the last read of this tile: refill it
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                     __builtin_amdgcn_wave_barrier();
                     if (U8) fill_tile_u8(g, itile, xp, nxt / kIT + 1, lane); else fill_tile<kIT>(g, itile, xp, nxt / kIT + 1, lane);
@@ -1137,16 +1166,17 @@ __device__ __forceinline__ void run_pair(const Geom &g, const DemodK<float, type
             lum_cur = lum_next;
             PAIR_BARRIER(d_bar);
         };
-        int tb = 0;
+        int tb = tb0;
         {
             FrontLatch<float> fla;
             fla.reset();
-            for (; tb < t_mid0; tb += 4) body_a(tb, std::true_type(), fla);
-            for (; tb < t_mid1; tb += 4) body_a(tb, std::false_type(), fla);
+            for (; tb < t_mid0 && tb < T_end; tb += 4) body_a(tb, std::true_type(), fla);
+            for (; tb < t_mid1 && tb < T_end; tb += 4) body_a(tb, std::false_type(), fla);
         }
         FrontLatch<float> fla;
         fla.reset();
-        for (; tb < T; tb += 4) body_a(tb, std::true_type(), fla);
+        for (; tb < T_end; tb += 4) body_a(tb, std::true_type(), fla);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // no tile fill may be in flight when the workgroup's LDS is released
 #ifdef CM_DIAG
         if (g.diag && lane == 0 && !g.sparse) {
             unsigned long long *d = g.diag + 16ull * block;
@@ -1204,7 +1234,7 @@ __device__ __forceinline__ void run_pair(const Geom &g, const DemodK<float, type
     const int s_flush = (lat_out + 3) & 3;
     auto maybe_flush = [&](int t) {
         const int n7 = t - lat_out;
-        if (n7 >= 0 && ((n7 & (kTile - 1)) == kTile - 1 || n7 == Wp - 1)) {
+        if (n7 >= x_lo && ((n7 & (kTile - 1)) == kTile - 1 || n7 == Wp - 1)) {      // (x_lo = 0 unless the row is cut into segments)
             CM_STAMP(t0);
             if (U8) flush_tile_u8(g, otile_base, op, n7 & ~(kTile - 1), lane);
             else flush_tile<kTile>(g, otile_base, op, n7 & ~(kTile - 1), lane);
@@ -1256,16 +1286,17 @@ __device__ __forceinline__ void run_pair(const Geom &g, const DemodK<float, type
     };
     // the first block of the ring and the first body's carriers
     PAIR_BARRIER(d_bar);
-    f4 me = *(const lds_f4 *)(ring + lane * 4);
-    f4 mo = *(const lds_f4 *)(ring + lane * 4 + 256);
+    const lds_float *slot0 = ring + ((tb0 >> 2) & 1) * (kMid / 2) + lane * 4;
+    f4 me = *(const lds_f4 *)slot0;
+    f4 mo = *(const lds_f4 *)(slot0 + 256);
     f4 me2 = {0.f, 0.f, 0.f, 0.f}, mo2 = me2;      // LCUT: (me, mo) = q_e (cos, sin), (me2, mo2) = q_o
     if constexpr (LCUT) {
-        me2 = *(const lds_f4 *)(ring + lane * 4 + 512);
-        mo2 = *(const lds_f4 *)(ring + lane * 4 + 768);
+        me2 = *(const lds_f4 *)(slot0 + 512);
+        mo2 = *(const lds_f4 *)(slot0 + 768);
     }
     f16u c4;
-    if constexpr (!LCUT) c4 = load_c4(0);
-    f8u c2 = load_c2(0);
+    if constexpr (!LCUT) c4 = load_c4(tb0);
+    f8u c2 = load_c2(tb0);
     auto body_b = [&](int tb, auto edge_tag, pf2 &p_last, pf2 &uv_last) {
         constexpr bool EDGE = decltype(edge_tag)::value;
         const int nxt = tb + 4;
@@ -1299,7 +1330,7 @@ __device__ __forceinline__ void run_pair(const Geom &g, const DemodK<float, type
             pe3 = pk_mul_bs<1>(pf2{me.z, me.w}, pf2{c4[12], c4[13]}); po3 = pk_mul_bs<1>(pf2{mo.z, mo.w}, pf2{c4[14], c4[15]});
         }
         pf2 sc2 = back.remod(lk, pf2{c2[4], c2[5]}), sc3 = back.remod(lk, pf2{c2[6], c2[7]});
-        if (nxt < T) {
+        if (nxt < T_end) {
             PAIR_BARRIER(d_bar);   // block nxt / 4 of the ring is complete
             const lds_float *slot = ring + ((nxt >> 2) & 1) * (kMid / 2) + lane * 4;
             me = *(const lds_f4 *)slot;
@@ -1328,9 +1359,9 @@ __device__ __forceinline__ void run_pair(const Geom &g, const DemodK<float, type
     t_mid0b = t_mid1b = 0;
 #endif
 #endif
-    int tb = 0;
+    int tb = tb0;
     for (; tb < t_skip; tb += 4) {
-        PAIR_BARRIER(d_bar);   // t_skip < T: block tb / 4 + 1 of the ring exists
+        PAIR_BARRIER(d_bar);   // t_skip < T_end: block tb / 4 + 1 of the ring exists
         const lds_float *slot = ring + (((tb + 4) >> 2) & 1) * (kMid / 2) + lane * 4;
         me = *(const lds_f4 *)slot;
         mo = *(const lds_f4 *)(slot + 256);
@@ -1343,11 +1374,11 @@ __device__ __forceinline__ void run_pair(const Geom &g, const DemodK<float, type
     }
     {
         pf2 p_last = {0.f, 0.f}, uv_last = {0.f, 0.f};
-        for (; tb < t_mid0b; tb += 4) body_b(tb, std::true_type(), p_last, uv_last);
-        for (; tb < t_mid1b; tb += 4) body_b(tb, std::false_type(), p_last, uv_last);
+        for (; tb < t_mid0b && tb < T_end; tb += 4) body_b(tb, std::true_type(), p_last, uv_last);
+        for (; tb < t_mid1b && tb < T_end; tb += 4) body_b(tb, std::false_type(), p_last, uv_last);
     }
     pf2 p_last = {0.f, 0.f}, uv_last = {0.f, 0.f};
-    for (; tb < T; tb += 4) body_b(tb, std::true_type(), p_last, uv_last);
+    for (; tb < T_end; tb += 4) body_b(tb, std::true_type(), p_last, uv_last);
 #ifdef CM_DIAG
     if (g.diag && lane == 0 && !g.sparse) {
         unsigned long long *d = g.diag + 16ull * block + 8;
@@ -1364,11 +1395,14 @@ struct PassArgs {
     Geom g;
     DemodK<float, S> k;
 };
+// the filter-set shape of the first-line pass of a launch (usually the main pass's; SysPalSq: another shift parity)
+template <class Main, class First> struct FirstSys { typedef typename First::S type; };
+template <class Main> struct FirstSys<Main, NoPass> { typedef typename Main::S type; };
 
 // One launch runs the plain first-line pass (workgroups [0, n_first)) and the main pass.
 template <class Main, class First>
 __global__ __launch_bounds__(64, 2) void demod_kernel(const PassArgs<typename Main::S> main_args,
-                                                      const PassArgs<typename Main::S> first_args, const int n_first) {
+                                                      const PassArgs<typename FirstSys<Main, First>::type> first_args, const int n_first) {
     constexpr int kFloats = Main::kLdsFloats > First::kLdsFloats ? Main::kLdsFloats : First::kLdsFloats;
     __shared__ __attribute__((aligned(16))) float lds_store[kFloats];
     lds_float *lds = (lds_float *)lds_store;
@@ -1400,7 +1434,7 @@ constexpr unsigned kLoadA = 4, kLoadB = 7;
 // Wave-pair variant: 128 threads, wave 0 = stage A, wave 1 = stage B of the same 64 calls.
 template <class Main, class First>
 __global__ __launch_bounds__(128, CM_PAIR_WAVES_PER_SIMD) void demod_pair_kernel(const PassArgs<typename Main::S> main_args,
-                                                                                 const PassArgs<typename Main::S> first_args,
+                                                                                 const PassArgs<typename FirstSys<Main, First>::type> first_args,
                                                                                  const int n_first) {
     extern __shared__ __attribute__((aligned(16))) float lds_store[];     // pair_lds_floats() of the larger pass
     lds_float *lds = (lds_float *)lds_store;

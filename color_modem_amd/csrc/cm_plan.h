@@ -293,6 +293,11 @@ typedef Sys<2, 2, 3, 1, false, false, false, 2> SysPal;   // PAL-BG @ 13.5 MHz: 
 typedef Sys<3, 3, 3, 1, false, true, false, 2> SysNtsc;   // NTSC-M @ 13.5 MHz: shifts 6 / 5 / 4 / 2 (also NTSC-N, NTSC 3.61, PAL-M, PAL-N)
 typedef Sys<3, 2, 3, 1, false, true, false, 2> SysNtscI;  // NTSC-I, NTSC 4.43 on 625 lines: narrower band-stop
 typedef Sys<3, 2, 3, 1, false, true, true, 2> SysNtscSq; // NTSC-M with 640 / 704 samples per line (12.27 / 13.2 MHz): shifts 6 / 5 / 3 / 2 - an odd band-stop shift
+// PAL-BG with 768 samples per line (14.75 MHz, the square-pixel raster): band-pass of three sections with shift 7, PAL-D low-pass
+// shift 7 - and the plain first line of a field runs the detector low-pass with shift 4: the two passes of one launch differ
+// in one parity, so this shape is a pair (main pass, first-line pass)
+typedef Sys<3, 2, 3, 1, true, true, false, 2> SysPalSq;
+typedef Sys<3, 2, 3, 1, true, false, false, 2> SysPalSqFirst;
 typedef Sys<4, 3, 3, 2, true, true, true, 4> SysNtscA;    // NTSC-A (405 lines, 2.66 MHz sub-carrier): shifts 9 / 7 / 5 / 4
 typedef Sys<4, 3, 3, 2, false, false, false, 12, true> SysAny;   // run-time shape: up to 4 / 3 / 3 / 2 sections, pre shift <= 12
 

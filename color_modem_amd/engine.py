@@ -113,13 +113,21 @@ class RowSession(object):
                 self.np_in[j] = rows[len(rows) - fresh + j]
             self.hist[self.pos + 1:self.pos + 1 + fresh].copy_(self.pin_in[:fresh], non_blocking=True)
             self.pos += fresh
-            self.held = (token, k)
+            self.held = (None, -1)                     # until the call has gone through: a failed call re-sends its rows
             first = self.pos - (n - 1)
-            _native.check(self.fn(self.eng._plans.get(self.device), self.hist[first].data_ptr(), self.out.data_ptr(), n, int(frame),
-                                  int(line) - 2 * (n - 1), int(k) - (n - 1), stream.cuda_stream))
-            self.pin_out.copy_(self.out[n - 1], non_blocking=True)
-            stream.synchronize()
+            try:
+                _native.check(self.fn(self.eng._plans.get(self.device), self.hist[first].data_ptr(), self.out.data_ptr(), n, int(frame),
+                                      int(line) - 2 * (n - 1), int(k) - (n - 1), stream.cuda_stream))
+                self.pin_out.copy_(self.out[n - 1], non_blocking=True)
+            finally:
+                stream.synchronize()                   # also when the call is refused: the upload from pin_in must have landed
+            self.held = (token, k)
         return self.np_out.astype(numpy.float64)
+
+
+def stack_backend(modem):
+    """the innermost modem of a stack (the one that owns the filters)"""
+    return modem._stack().get('backend', modem)
 
 
 def make_engine(modem, components=False, strip_chroma=True, min_lines=0):
@@ -383,9 +391,27 @@ class AmEngine(_EngineBase):
         self.demodulation_delay = 0
         self.modulation_delay = 1 if d.averaging else 0
         self.n_lines = 1 << 30                   # no per-line tables: the line's phase is computed on the device
+        # NiirModem(noise_level != 0): niir.py:45-46 perturbs the hue in modulate() (not in the plain modem's
+        # modulate_components, niir.py:82-83); HueCorrectingNiirModem does it in both (niir.py:176-177, 193-194)
+        level = float(getattr(stack_backend(modem), '_noise_level', 0.0))
+        hue = bool(getattr(stack_backend(modem), 'hue_correcting', False))
+        self.noise_level = level if (level != 0.0 and (hue or not components)) else 0.0
+        self.composite_mod = self.noise_level != 0.0     # rowapi: the noisy encoder takes its run through modulate_run
         L = _native.lib()
         self._plans = _DevicePlans(lambda out: L.cm_am_plan_create(ctypes.byref(d), out), L.cm_am_plan_destroy)
         self._plan
+
+    def _noise(self, calls, newest_only=False):
+        """(numpy.random.random_sample(W) - 0.5) * noise_level for db, then dr, per call in call order - exactly the
+        reference's draws (niir.py:45-46), so numpy.random.seed() reproduces its output.  newest_only: a run submitted with
+        history re-computes older calls whose results are dropped; only the newest call draws."""
+        torch = _torch()
+        z = numpy.zeros((calls, 2, self.width), dtype=numpy.float32)
+        if newest_only:
+            z[-1] = (numpy.random.random_sample((2, self.width)) - 0.5) * self.noise_level
+        else:
+            z[:] = (numpy.random.random_sample((calls, 2, self.width)) - 0.5) * self.noise_level
+        return torch.from_numpy(z)
 
     def describe(self):
         name = 'proto' if self.desc.kind == 1 else 'niir'
@@ -406,6 +432,13 @@ class AmEngine(_EngineBase):
         n = x.shape[0]
         if self.height < 2 * self.modulation_delay and n:
             raise IndexError('image.py:49-50 feeds row 1 ahead of a field under modulation_delay 1: the image has %d row(s)' % self.height)
+        if self.noise_level != 0.0 and n:
+            d = self.modulation_delay
+            calls = n * (((self.height + 1) // 2 + d) + ((self.height // 2 + d) if self.height > 1 else 0))
+            noise = self._noise(calls).to(x.device)
+            fn = _native.lib().cm_am_modulate_frames_noise
+            return self._launch(lambda plan, a, b, *rest: fn(plan, a, noise.data_ptr(), b, *rest), x, out, (n, self.height, self.width),
+                                torch.float32, was_numpy, n, int(first_frame))
         return self._launch(_native.lib().cm_am_modulate_frames, x, out, (n, self.height, self.width), torch.float32,
                             was_numpy, n, int(first_frame))
 
@@ -425,5 +458,10 @@ class AmEngine(_EngineBase):
         torch = _torch()
         x, was_numpy = self._stage(rows, torch.float32, (3, self.width), 'rows')
         n = x.shape[0]
+        if self.noise_level != 0.0 and n:
+            noise = self._noise(n, newest_only=True).to(x.device)
+            fn = _native.lib().cm_am_modulate_run_noise
+            return self._launch(lambda plan, a, b, *rest: fn(plan, a, noise.data_ptr(), b, *rest), x, None, (n, self.width),
+                                torch.float32, was_numpy, n, int(frame), int(first_line), int(k0))
         return self._launch(_native.lib().cm_am_modulate_run, x, None, (n, self.width), torch.float32, was_numpy,
                             n, int(frame), int(first_line), int(k0))

@@ -9,12 +9,14 @@ otherwise every level of the stack starts over.  Each call is evaluated on the G
 result row down per call).
 """
 
+import itertools
+
 import numpy
 
 
 class _Run(object):
     __slots__ = ('frame', 'line', 'k', 'rows', 'token', 'sessions')
-    _tokens = [0]
+    _tokens = itertools.count(1)        # run identities (next() is atomic under the GIL)
 
     def __init__(self):
         self.frame = -1
@@ -42,6 +44,10 @@ class RowApi(object):
         if eng is None or line >= getattr(eng, 'n_lines', 1 << 30):
             from color_modem_amd import engine
             need = 0 if eng is None else max(2 * eng.n_lines, line + 64)
+            if eng is not None:      # the replaced engine's device sessions (history buffer, pinned staging, its plans) go with it
+                for run in (self._demod_run, self._mod_run):
+                    for skey in [k for k in run.sessions if k[0] == id(eng)]:
+                        del run.sessions[skey]
             eng = self._engines[key] = engine.make_engine(self, components=key[0], strip_chroma=key[1], min_lines=max(need, line + 1))
         return eng
 
@@ -50,8 +56,7 @@ class RowApi(object):
         if frame != run.frame or line != run.line + 2 or run.k < 0:
             run.k = 0
             run.rows = []
-            _Run._tokens[0] += 1
-            run.token = _Run._tokens[0]
+            run.token = next(_Run._tokens)
         else:
             run.k += 1
         run.frame, run.line = frame, line
@@ -61,7 +66,8 @@ class RowApi(object):
     @staticmethod
     def _step(run, eng, direction, frame, line):
         from color_modem_amd import engine
-        if getattr(eng, 'composite', False):      # a composition of kernels (wrapped.py): the run's last rows go up as they are
+        if getattr(eng, 'composite', False) or (direction == 'mod' and getattr(eng, 'composite_mod', False)):
+            # a composition of kernels (wrapped.py) / an encoder with per-call host input (NIIR noise): the run's last rows go up as they are
             n = len(run.rows)
             fn = eng.demodulate_run if direction == 'demod' else eng.modulate_run
             return numpy.asarray(fn(numpy.stack(run.rows), frame, line - 2 * (n - 1), run.k - (n - 1))[n - 1], dtype=numpy.float64)

@@ -306,6 +306,15 @@ int cm_am_modulate_run(const cm_am_plan *plan, const float *rgb, float *composit
                        int32_t first_line, int32_t k0, void *stream);
 int cm_am_demodulate_run(const cm_am_plan *plan, const float *composite, float *rgb, int32_t n_calls, int32_t frame,
                          int32_t first_line, int32_t k0, void *stream);
+/* NiirModem(noise_level != 0) (niir.py:45-46; HueCorrectingNiirModem: niir.py:193-194): the encoder perturbs the hue with
+ * (numpy.random.random_sample(W) - 0.5) * noise_level, drawn for db, then for dr, once per modulate() call.  The caller draws
+ * them in the reference's call order - the order of the flattened [frame][field][call] list, the warm-up calls of
+ * modulation_delay included - and passes them as noise [calls][2][width] float32 (device memory); everything else as above.
+ * (modulate_components of the plain NiirModem adds no noise: niir.py:82-83.) */
+int cm_am_modulate_frames_noise(const cm_am_plan *plan, const float *rgb, const float *noise, float *composite, int64_t n_frames,
+                                int64_t first_frame, void *stream);
+int cm_am_modulate_run_noise(const cm_am_plan *plan, const float *rgb, const float *noise, float *composite, int32_t n_calls,
+                             int32_t frame, int32_t first_line, int32_t k0, void *stream);
 
 /* ---- SimpleCombModem / Simple3DCombModem around PalDModem or Pal3DModem (comb.py:71-127 over pal.py:62-234) -----------------
  * Replaces SimpleCombModem.demodulate_components / demodulate (comb.py:96-122) when the backend is a PAL delay-line decoder.

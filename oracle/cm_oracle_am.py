@@ -100,7 +100,7 @@ class ProtoSecamOracle(object):
 
 
 class NiirOracle(object):
-    """niir.py:10-202 (noise_level 0) on a color_modem_amd.color.niir.NiirModem / HueCorrectingNiirModem."""
+    """niir.py:10-202 on a color_modem_amd.color.niir.NiirModem / HueCorrectingNiirModem (noise_level: the reference's numpy.random draws)."""
 
     def __init__(self, modem):
         self.m = modem
@@ -114,9 +114,13 @@ class NiirOracle(object):
         self._last_luma = self._last_db = self._last_dr = None
 
     # ---- encoder ---------------------------------------------------------------------------------
-    @staticmethod
-    def _add_offset(db, dr):                                                             # niir.py:42-49, noise off
+    def _add_offset(self, db, dr, noise_level=None):                                     # niir.py:42-49
+        if noise_level is None:
+            noise_level = float(getattr(self.m, '_noise_level', 0.0))
         saturation = numpy.sqrt(db * db + dr * dr) + 0.1
+        if noise_level != 0.0:      # the draws of niir.py:45-46, in its order (numpy.random.seed pins them)
+            db = db + (numpy.random.random_sample(len(db)) - 0.5) * noise_level
+            dr = dr + (numpy.random.random_sample(len(dr)) - 0.5) * noise_level
         hue = numpy.arctan2(db, dr)
         return saturation * numpy.sin(hue), saturation * numpy.cos(hue)
 
@@ -137,12 +141,14 @@ class NiirOracle(object):
 
     def modulate(self, frame, line, r, g, b):
         luma, db, dr = [numpy.asarray(c, dtype=numpy.float64) for c in self.m.encode_components(r, g, b)]
+        if not self.hue_correcting:
+            return self._modulate_offset_components(frame, line, luma, *self._add_offset(db, dr))   # niir.py:78-80 (with noise)
         return self.modulate_components(frame, line, luma, db, dr)
 
     def modulate_components(self, frame, line, luma, db, dr):
         luma, db, dr = [numpy.asarray(c, dtype=numpy.float64) for c in (luma, db, dr)]
         if not self.hue_correcting:
-            return self._modulate_offset_components(frame, line, luma, *self._add_offset(db, dr))   # niir.py:78-83
+            return self._modulate_offset_components(frame, line, luma, *self._add_offset(db, dr, 0.0))   # niir.py:82-83 (no noise)
         # niir.py:181-202
         if frame != self._last_modulated_frame or line != self._last_modulated_line + 2 or self._last_db is None \
                 or self._last_dr is None:
@@ -154,6 +160,10 @@ class NiirOracle(object):
         divisor = numpy.where(divisor == 0.0, 1.0, divisor)
         avgdb = (self._last_db * last_saturation + db * saturation) / divisor
         avgdr = (self._last_dr * last_saturation + dr * saturation) / divisor
+        level = float(getattr(self.m, '_noise_level', 0.0))
+        if level != 0.0:                                                                   # niir.py:192-194
+            avgdb = avgdb + (numpy.random.random_sample(len(db)) - 0.5) * level
+            avgdr = avgdr + (numpy.random.random_sample(len(dr)) - 0.5) * level
         ep = last_saturation + 0.1
         hue = numpy.arctan2(avgdb, avgdr)
         dbep, drep = ep * numpy.sin(hue), ep * numpy.cos(hue)
@@ -199,6 +209,7 @@ class NiirOracle(object):
         cosphi = resample_poly(huemod_up * altcarrier_up, 1, 3)
         with numpy.errstate(divide='ignore', invalid='ignore'):
             normalizer = numpy.sqrt(cosphi * cosphi + sinphi * sinphi)
+            self.last_normalizer = normalizer      # (for tests: the hue is the angle of this decimated pair - ill-conditioned where it is short)
             cosphi = cosphi / normalizer
             sinphi = sinphi / normalizer
         sinphi, cosphi = -cosphi * numpy.sin(shift) - sinphi * numpy.cos(shift), \

@@ -17,6 +17,8 @@ STACKS = {
     'niir': lambda lc: niir.NiirModem(lc),
     'niir_hue': lambda lc: niir.HueCorrectingNiirModem(lc),
     'niir_525': lambda lc: niir.NiirModem(lc),
+    'niir_noise': lambda lc: niir.NiirModem(lc, noise_level=0.05),
+    'niir_hue_noise': lambda lc: niir.HueCorrectingNiirModem(lc, noise_level=0.08),
 }
 DECODER_OF = {'proto_avg': 'proto'}
 

@@ -71,6 +71,22 @@ def save(name, **arrays):
     print('%-28s %8.1f KB' % (name, os.path.getsize(path) / 1024.0))
 
 
+def noise_cases():
+    """NiirModem / HueCorrectingNiirModem with noise_level != 0 (niir.py:45-46, 193-194): the noise is numpy.random.random_sample,
+    pinned here by numpy.random.seed(7) before each frame batch (the engine and the oracle draw in the same order)."""
+    for name, make in (('niir_noise', lambda lc: niir.NiirModem(lc, noise_level=0.05)),
+                       ('niir_hue_noise', lambda lc: niir.HueCorrectingNiirModem(lc, noise_level=0.08))):
+        W, H, frames = 720, 7, [0, 3]
+        lc = line.LineConfig((W, H), LS.GERBER_625)
+        rgb = testing.synthetic_rgb(len(frames), H, W, seed=1600)
+        outs = []
+        for i, f in enumerate(frames):        # one seeded batch per frame: a test can replay any of them alone
+            numpy.random.seed(7 + i)
+            outs.append(run_mod_frame(make(lc), rgb[i], f))
+        save('am_mod_' + name, inp=rgb, out=numpy.stack(outs), frames=numpy.array(frames), size=numpy.array([W, H]),
+             standard=numpy.array('GERBER_625'), seeds=numpy.array([7, 8]))
+
+
 def main():
     cases = [  # (stack, decoder stack, width, height, frames)
         ('proto', 'proto', 720, 8, [0, 1]),
@@ -106,6 +122,7 @@ def main():
                             for i, (f, y) in enumerate(seq)]).astype(numpy.float32)
         out = numpy.stack([numpy.stack(modem.demodulate(f, y, comp[i].astype(numpy.float64))) for i, (f, y) in enumerate(seq)])
         save('am_rows_' + stack, inp=comp, out=out, seq=numpy.array(seq), size=numpy.array(size), standard=numpy.array(std_name))
+    noise_cases()
     # NIIR component protocol with the chroma left in the luma (strip_chroma=False) and noise input
     lc = line.LineConfig((720, 6), LS.GERBER_625)
     noise = testing.synthetic_composite(2, 6, 720, seed=1500)
@@ -120,4 +137,7 @@ def main():
 
 
 if __name__ == '__main__':
-    main()
+    if sys.argv[1:2] == ['noise']:
+        noise_cases()
+    else:
+        main()

@@ -24,6 +24,34 @@ def test_modulate_frames_golden(stack):
         assert stacks.rel_err(out, z['out'][i]) < TOL, (stack, int(f))
 
 
+@pytest.mark.parametrize('stack', ['niir_noise', 'niir_hue_noise'])
+def test_niir_noise_level_golden(stack):
+    """NiirModem(noise_level != 0) (niir.py:45-46, 193-194): the engine draws numpy.random.random_sample in the reference's call
+    order - under the seed the golden was made with, frames and the per-row protocol reproduce the reference."""
+    z = am_stacks.load('am_mod_' + stack)
+    modem = am_stacks.make(stack, z)
+    im = image.ImageModem(modem)
+    height = int(z['size'][1])
+    for i, f in enumerate(z['frames']):
+        numpy.random.seed(int(z['seeds'][i]))
+        out = im.modulate_frames(z['inp'][i:i + 1], first_frame=int(f))[0]
+        assert stacks.rel_err(out, z['out'][i]) < TOL, (stack, int(f))
+        # the same frame row by row (image.py:47-55): the same draws in the same order
+        numpy.random.seed(int(z['seeds'][i]))
+        m2 = am_stacks.make(stack, z)
+        delay = getattr(m2, 'modulation_delay', 0)
+        rows = numpy.zeros((height, int(z['size'][0])))
+        for field in range(2):
+            for y in range(field, 2 * delay, 2):
+                m2.modulate(int(f), y, *[z['inp'][i, p, y] for p in range(3)])
+            for y in range(field, height, 2):
+                iy = y + 2 * delay
+                while iy >= height:
+                    iy -= 2
+                rows[y] = m2.modulate(int(f), y + 2 * delay, *[z['inp'][i, p, iy] for p in range(3)])
+        assert stacks.rel_err(rows, z['out'][i]) < TOL, (stack, int(f), 'rows')
+
+
 @pytest.mark.parametrize('stack', PROTO)
 def test_demodulate_frames_golden(stack):
     z = am_stacks.load('am_demod_' + stack)
@@ -103,8 +131,34 @@ def test_niir_round_trip_vs_oracle(stack, size, std, first):
     back = im.demodulate_frames(comp32, first_frame=first)
     back_ref = oa.demodulate_frames(modem, comp32.astype(numpy.float64), first)
     for i in range(2):
-        err = numpy.abs(back[i] - back_ref[i]) / numpy.abs(back_ref[i]).max()
-        assert numpy.quantile(err, 0.9999) < TOL and err.max() < 1e-4, (stack, i, err.max())
+        assert stacks.rel_err(back[i], back_ref[i]) < TOL, (stack, i)        # strict on a valid signal (measured 0.9 - 4.6e-6)
+
+
+def test_niir_full_frame_hue_conditioning():
+    """A full 720x576 frame of a valid signal: everything inside 1e-5 except isolated samples where the hue is
+    ill-conditioned IN THE ALGORITHM - niir.py:131-137 takes the hue as the angle of a decimated product pair and divides by its
+    length; where the hue turns quickly inside the decimator's window that pair gets short (the oracle's `last_normalizer`)
+    and float32 rounding of ~1e-6 of full scale is divided by it.  Asserted: all but 1e-5 of the samples hold the tolerance, the
+    worst stays below 3e-5, and EVERY sample above the tolerance sits where the oracle's pair is shorter than a fifth of its
+    median length."""
+    from oracle import cm_oracle_am as oa
+    size, first = (720, 576), 3
+    lc = line.LineConfig(size, line.LineStandard.GERBER_625)
+    modem = am_stacks.STACKS['niir'](lc)
+    rgb = testing.synthetic_rgb(1, size[1], size[0], seed=55 + size[1])
+    comp32 = oa.modulate_frames(modem, rgb.astype(numpy.float64), first).astype(numpy.float32)
+    back = image.ImageModem(modem).demodulate_frames(comp32, first_frame=first)[0]
+    want = numpy.zeros((3, size[1], size[0]))
+    norm = numpy.zeros((size[1], size[0]))
+    orc = oa.make(modem)
+    for field in range(2):
+        for y in range(field, size[1], 2):
+            want[:, y] = numpy.stack(orc.demodulate(first, y, comp32[0, y].astype(numpy.float64)))
+            norm[y] = orc.last_normalizer
+    err = numpy.abs(back - want) / numpy.abs(want).max()
+    assert numpy.quantile(err, 1.0 - 1e-5) < TOL and err.max() < 3e-5, (err.max(), numpy.quantile(err, 1.0 - 1e-5))
+    over = (err > TOL).any(axis=0)
+    assert over.sum() < 20 and (norm[over] < 0.2 * numpy.median(norm)).all(), (int(over.sum()), norm[over] / numpy.median(norm))
 
 
 def test_pil_image_round_trip_proto_and_niir():

@@ -51,6 +51,18 @@ def test_modulate_frames_golden(stack):
         assert numpy.abs(got - z['out'][i]).max() < 1e-11, (stack, int(f))
 
 
+@pytest.mark.parametrize('stack', ['niir_noise', 'niir_hue_noise'])
+def test_modulate_frames_with_noise_golden(stack):
+    """NiirModem(noise_level != 0): the reference draws numpy.random.random_sample for db, then dr, per modulate() call
+    (niir.py:45-46, 193-194); the goldens were made under numpy.random.seed(seeds[i]) per frame."""
+    z = am_stacks.load('am_mod_' + stack)
+    modem = am_stacks.make(stack, z)
+    for i, f in enumerate(z['frames']):
+        numpy.random.seed(int(z['seeds'][i]))
+        got = oa.modulate_frames(modem, z['inp'][i:i + 1].astype(numpy.float64), int(f))[0]
+        assert numpy.abs(got - z['out'][i]).max() < 1e-11, (stack, int(f))
+
+
 @pytest.mark.parametrize('stack', MOD)
 def test_demodulate_frames_golden(stack):
     z = am_stacks.load('am_demod_' + stack)

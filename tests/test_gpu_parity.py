@@ -169,10 +169,12 @@ def test_full_size_properties_pal_d():
     n = 24
     comp = torch.from_numpy(testing.synthetic_composite(n, 576, 720, seed=4321)).cuda()
     out = eng.demodulate_frames(comp, first_frame=0)
-    # (1) frames are independent: any sub-batch gives bit-identical results
+    # (1) frames are independent: any sub-batch gives the same results - to float32 resolution: small batches run their rows in
+    #     segments (cm_api.hip: segment_geometry) whose number depends on the batch, and a segment enters the row from a state
+    #     the filters have forgotten to 1e-8
     part = eng.demodulate_frames(comp[5:9].contiguous(), first_frame=5)
-    assert torch.equal(out[5:9], part)
-    # (2) the carrier phase repeats every 4 frames (PAL 8-field sequence)
+    assert float((out[5:9] - part).abs().max() / out.abs().max()) < 2e-7
+    # (2) the carrier phase repeats every 4 frames (PAL 8-field sequence): bit for bit (same batch geometry)
     again = eng.demodulate_frames(comp, first_frame=4)
     assert torch.equal(out, again)
     other = eng.demodulate_frames(comp, first_frame=1)
@@ -418,7 +420,13 @@ def test_unsupported_variants_fail_loudly():
                                                        ('ntsc', (720, 18), 2, 0), ('pal_d', (704, 9), 2, 3),
                                                        # the run-time filter shape (other image widths)
                                                        ('pal_d', (768, 576), 2, 1), ('ntsc_comb', (640, 480), 2, 0), ('pal_3d', (1024, 576), 2, 2),
-                                                       ('pal_s', (1280, 576), 1, 3)])
+                                                       ('pal_s', (1280, 576), 1, 3),
+                                                       # notch / minavg instances and the wrapped PAL combs (round 3)
+                                                       ('pal_d_notch', (720, 24), 2, 1), ('pal_3d_notch', (720, 21), 2, 0),
+                                                       ('ntsc_comb_3d_notch', (720, 24), 2, 1), ('pal_3d_minavg', (720, 24), 2, 3),
+                                                       ('ntsc_simple_minavg', (720, 20), 2, 0), ('pal_d_notch', (768, 20), 2, 2),
+                                                       ('ntsc_comb_3d_minavg', (640, 22), 2, 1), ('simple3d_pald_notch', (720, 24), 2, 1),
+                                                       ('simple3d_pal3d', (720, 25), 2, 2)])
 def test_fused_uint8_matches_float_path(stack, size, n_frames, first):
     """uint8 in / uint8 out through the kernel == host-side level decode -> float kernel -> host-side _as_bytes,
     up to float32 rounding of the level mapping at the knife edge of rint (<= 1 LSB on < 0.2 % of the samples)."""
@@ -426,7 +434,7 @@ def test_fused_uint8_matches_float_path(stack, size, n_frames, first):
     modem = stacks.make(stack, size)
     im = image.ImageModem(modem)
     rgb = testing.synthetic_rgb(n_frames, size[1], size[0], seed=31)
-    enc = stacks.make('pal_s' if stack.startswith('pal') else 'ntsc', size)
+    enc = stacks.make('ntsc' if stack.startswith('ntsc') else 'pal_s', size)
     comp = image.ImageModem(enc).modulate_frames(rgb, first_frame=first)
     comp8 = _as_bytes(image.ImageModem.encode_composite_level(comp.astype(numpy.float64)))
     got = im.demodulate_frames_u8(comp8, first_frame=first)
@@ -628,6 +636,39 @@ def test_plan_refuses_host_pointers():
     assert b'device' in _native.lib().cm_last_error()
 
 
+# ---- small batches: rows cut into segments (cm_api.hip: segment_geometry, cm_kernels.h: Geom::seg_len) ----------------------
+@pytest.mark.parametrize('stack,enc,size', [('pal_d', 'pal_s', (720, 576)), ('pal_3d', 'pal_s', (720, 576)), ('ntsc_comb_3d', 'ntsc', (720, 480)),
+                                            ('pal_d', 'pal_s', (768, 576)), ('ntsc_comb', 'ntsc', (640, 480)), ('pal_s', 'pal_s', (1024, 60)),
+                                            ('pal_d', 'pal_s', (722, 40))])
+def test_small_batches_run_in_row_segments(stack, enc, size):
+    """One frame (or a few) is a handful of workgroups; each then walks ONE segment of its rows, entering it from a zero state
+    a warm-up length earlier.  Against the float64 oracle at the usual tolerance, against the same frames inside a batch large
+    enough to run unsegmented at float32 resolution, and through the fused byte boundary."""
+    import torch
+    from oracle import cm_oracle
+    from color_modem_amd.image import _as_bytes
+    modem = stacks.make(stack, size, explicit=False)
+    im = image.ImageModem(modem)
+    rgb = testing.synthetic_rgb(2, size[1], size[0], seed=8 + size[0])
+    comp = cm_oracle.modulate_frames_f32(stacks.make(enc, size, explicit=False), rgb, first_frame=1, n_threads=8)
+    want = cm_oracle.demodulate_frames_f32(modem, comp, first_frame=1, n_threads=8)
+    one = [im.demodulate_frames(comp[i:i + 1], first_frame=1 + i)[0] for i in range(2)]
+    for i in range(2):
+        assert stacks.rel_err(one[i], want[i]) < TOL, (stack, i)
+    if size[1] >= 400:      # the same two frames at the head of a batch of 48 (too many workgroups to be cut)
+        big = torch.from_numpy(comp).cuda().repeat(24, 1, 1).contiguous()
+        out = im.demodulate_frames(big, first_frame=1)
+        for i in range(2):
+            assert stacks.rel_err(one[i], out[i].cpu().numpy()) < 2e-7, (stack, i)
+    if size[0] % 4 == 0:
+        comp8 = _as_bytes(image.ImageModem.encode_composite_level(comp[:1].astype(numpy.float64)))
+        got8 = im.demodulate_frames_u8(comp8, first_frame=1)
+        ref_in = image.ImageModem.decode_composite_level(comp8.astype(numpy.float64) / 255.0).astype(numpy.float32)
+        want8 = _as_bytes(cm_oracle.demodulate_frames_f32(modem, ref_in, first_frame=1, n_threads=8).astype(numpy.float64)).transpose(0, 2, 3, 1)
+        d8 = numpy.abs(got8.astype(int) - want8.astype(int))
+        assert d8.max() <= 1 and (d8 > 0).mean() < 5e-3, (stack, d8.max(), (d8 > 0).mean())
+
+
 # ---- comb wrappers around the PAL delay-line decoders (color_modem_amd/wrapped.py, csrc/cm_wrap_kernels.h) -----------------
 @pytest.mark.parametrize('stack,size,first', [('simple3d_pald', (720, 40), 1), ('simple_pald', (720, 21), 2), ('simple3d_pal3d', (720, 24), 3),
                                               ('simple3d_pald_minavg', (704, 12), 0), ('simple3d_pald_notch', (720, 16), 2),
@@ -678,8 +719,9 @@ def test_wrapped_pal_comb_batches_and_bytes():
     im = image.ImageModem(modem)
     comp = testing.synthetic_composite(5, size[1], size[0], seed=3)
     whole = im.demodulate_frames(comp, first_frame=2)
-    for i in range(5):
-        assert numpy.array_equal(whole[i], im.demodulate_frames(comp[i:i + 1], first_frame=2 + i)[0]), i
+    for i in range(5):     # (to float32 resolution: the number of row segments of a small batch depends on its size)
+        assert stacks.rel_err(whole[i], im.demodulate_frames(comp[i:i + 1], first_frame=2 + i)[0]) < 2e-7 or \
+            numpy.array_equal(whole[i], im.demodulate_frames(comp[i:i + 1], first_frame=2 + i)[0]), i
     dev = im.demodulate_frames(torch.from_numpy(comp).cuda(), first_frame=2)
     assert torch.is_tensor(dev) and numpy.array_equal(dev.cpu().numpy(), whole)
     comp8 = _as_bytes(image.ImageModem.encode_composite_level(comp.astype(numpy.float64)))

@@ -59,7 +59,9 @@ def test_two_ranks_hip_path_equals_single_process(tmp_path, stack, size, n_frame
     got = numpy.load(result)
     comp = testing.synthetic_composite(n_frames, size[1], size[0], seed=77)
     want = image.ImageModem(stacks.make(stack, size)).demodulate_frames(comp, first_frame=first)
-    assert numpy.array_equal(got, want)
+    # the ranks' shares equal the single-process result to float32 resolution (bit for bit on batches large enough to run
+    # unsegmented; these few frames run in row segments whose number depends on the batch size: cm_api.hip: segment_geometry)
+    assert numpy.abs(got - want).max() < 2e-7 * numpy.abs(want).max()
 
 
 def _bench(*args):

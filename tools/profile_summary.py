@@ -60,6 +60,11 @@ if 'FETCH_SIZE' in m and 'WRITE_SIZE' in m:
           'hbm_bytes_per_launch': int(round(hbm, -6)),
           'correction': 'hbm = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 (MI355X_MICROARCH.md: FETCH_SIZE tallies 128-B requests at 64 B)',
           'algorithmic_bytes_per_launch': 16 * PIXELS}
+    try:      # the kernel description bench.py compares with its own (config.kernel of the line of the same run)
+        with open(os.path.join(out, 'bench_line.json')) as fh:
+            tj['kernel'] = json.loads([ln for ln in fh if ln.startswith('{')][-1])['config']['kernel']
+    except (OSError, ValueError, KeyError, IndexError):
+        pass
     if 'TCC_HIT_sum' in m:
         tj['l2_hit_rate'] = round(m['TCC_HIT_sum'] / (m['TCC_HIT_sum'] + m['TCC_MISS_sum']), 3)
     with open(os.path.join(out, 'traffic.json'), 'w') as fh:
