@@ -16,6 +16,9 @@
 
 namespace cm {
 
+#ifndef CM_NIIR_PAIR          /* 1: the NIIR decoder on the wave pair (niir_demod_pair_kernel); 0: the one-wave kernels of round 2 */
+#define CM_NIIR_PAIR 1
+#endif
 constexpr int kAmRing = 32;                    // slots of the delay rings: delays up to 31 samples (checked by the host)
 constexpr int kAmRingFloats = kAmRing * 64;
 
@@ -297,6 +300,217 @@ __global__ __launch_bounds__(64, 1) void niir_demod_kernel(const NiirDemodArgs a
     for (; tb < t_mid0; tb += 4) body(std::true_type(), tb);
     for (; tb < t_mid1; tb += 4) body(std::false_type(), tb);
     for (; tb < T; tb += 4) body(std::true_type(), tb);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Wave-pair form of the NIIR decoder (round 3; the structure of cm_kernels.h: run_pair).  Two wavefronts walk the same 64
+// calls, two steps per body:
+//   wave 0 (stage A)  every global load (8-sample input tiles through global_load_lds, two buffers), up3 -> band-pass -> |.| ->
+//                     low-pass (NiirFront), the band-pass triples delayed by the low-pass delay (LDS ring of its own), the phasor
+//                     phasemod = M / S, the saturation decimator, on the first line of a run also the synthetic phase reference
+//                     (NiirSyn); per body it leaves (phasor[3], saturation[, reference[3]]) of both steps in a double-buffered
+//                     hand-over ring and the two row samples in the luma source delay ring
+//   wave 1 (stage B)  the previous call's phasor from the neighbouring lane, the four phase decimators as two packed pairs
+//                     (NiirBackPk, taps in 16 VGPR pairs), normalisation / rotation / offset / matrix (niir_finish), output
+//                     tile and every global store
+// The cut balances the stages (about 210 | 200 vector instructions per pixel; with phasemod and all five decimators in
+// stage B it was 135 | 330 and ran 34 instead of 22 Gpixel/s, profiles/r03_am_notes.txt).
+// One s_barrier per body.  Both stages fit 2 waves per SIMD without parking registers (the one-wave kernel: 256 VGPRs + up to
+// 168 AGPRs, one wave per SIMD, 840 vector instructions per pixel); the main pass and the sparse first-line pass share ONE
+// launch (workgroups [0, n_first) are the first-line ones).
+// ---------------------------------------------------------------------------------------------------------------------
+struct NiirPairArgs {
+    NiirDemodArgs m;           // m.g: the main pass
+    Geom gf;                   // the first-line pass (sparse), when n_first > 0
+    int n_first;
+};
+constexpr int kNiirIT = 8;                                 // samples per input tile row
+constexpr int kNiirHandQ = 4, kNiirHandQFirst = 7;          // hand-over quantities per step: phasor[3], saturation (, reference[3])
+// floats of dynamic LDS: input tile (two buffers) | M delay ring (x 2 with the reference) | hand-over (2 buffers) | luma source ring | output tile
+// slots of the M delay ring: the power of two that holds q_l + 1 triples (q_l = 3 at 13.5 MHz: 4 slots, 3 KiB)
+inline __host__ __device__ int niir_mring_slots(int q_l) { return q_l < 2 ? 2 : (q_l < 4 ? 4 : 8); }
+inline int niir_pair_lds_floats(int lat, int q_l, bool first) {
+    const int hb = (lat + 1) >> 1;
+    return 2 * 64 * kNiirIT + (first ? 2 : 1) * niir_mring_slots(q_l) * 3 * 64 + 2 * (first ? kNiirHandQFirst : kNiirHandQ) * 128 + (hb + 3) * 128 +
+           3 * 64 * 16;
+}
+
+template <bool FIRST>
+__device__ __forceinline__ void niir_pair_body(const NiirDemodArgs &args, const Geom &g, int block, lds_float *lds, int role) {
+    constexpr int kTile = 16, DEPTH = 1, Q = FIRST ? kNiirHandQFirst : kNiirHandQ;
+    typedef __attribute__((address_space(3))) f2 lds_f2;
+    const NiirDemodK<float> &k = args.k;
+    const int lane = threadIdx.x & 63;
+    const LaneCall lc = locate_call(g, block, DEPTH, lane);
+    const int W = g.W;
+    const int q_l = k.gl.q;
+    const int lat = 2 * kAmHalf + 1 + k.gb.q + q_l;
+    const int T = (g.Wp + lat + 1) & ~1;
+    const int hb = (lat + 1) >> 1, NB = hb + 3;            // luma source ring: blocks of 2 samples, hb bodies of delay
+    lds_float *itile = lds;                                 // two buffers of [64][kNiirIT]: tile c lives in buffer c & 1
+    lds_float *mring = itile + 2 * 64 * kNiirIT;
+    const int nring = niir_mring_slots(q_l);
+    lds_float *hand = mring + (FIRST ? 2 : 1) * nring * 3 * 64;
+    lds_float *xring = hand + 2 * Q * 128;
+    lds_float *otile_base = xring + NB * 128;
+    // interior bodies (as in the one-wave kernel): t >= lat + 4, t + 1 < W - 6
+    int t_mid0 = (lat + 4 + 1) & ~1, t_mid1 = (W - 8) & ~1;
+    if (t_mid1 <= t_mid0) t_mid0 = t_mid1 = 0;
+    const long long frame = (long long)args.a.frame_base + lc.frame;
+
+    if (role == 0) {
+        // =================================== stage A ===========================================
+        NiirDemodK<float> ka = k;
+        pin_taps3(ka.taps);
+        const float *xp = g.in + lc.frame * g.in_frame_stride + (long long)lc.src_row * g.Wp;
+        float syn_s = 0.f, syn_c = 0.f;       // +-(sin, cos) of the start phase of line - 2
+        if (FIRST) {
+            const double phi = args.a.line.start_phase(frame, lc.line - 2);
+            const float sg = args.a.line.alternate(frame, lc.line - 2) ? -1.f : 1.f;
+            syn_s = sg * (float)sin(phi);
+            syn_c = sg * (float)cos(phi);
+        }
+        NiirFront<float> front;
+        NiirSyn<float> syn;
+        Dn3<float> dn_sat;
+        float s_prev[3] = {0.f, 0.f, 0.f};                  // S of the previous triple (the decimators run one triple late)
+        front.reset();
+        dn_sat.reset();
+        if (FIRST) syn.reset();
+        lds_float *ring_syn = mring + nring * 3 * 64;
+        for (int j = 0; j < (FIRST ? 2 : 1) * nring * 3; ++j) mring[j * 64 + lane] = 0.f;
+        for (int j = 0; j < NB; ++j) *(lds_f2 *)(xring + j * 128 + lane * 2) = f2{0.f, 0.f};
+        fill_tile<kNiirIT>(g, itile, xp, 0, lane);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        if (kNiirIT < W) fill_tile<kNiirIT>(g, itile + 64 * kNiirIT, xp, 1, lane);      // tile c + 1 is asked for when tile c is first read
+        auto read_x = [&](int first) -> f2 {
+            f2 v = *(const lds_f2 *)(itile + ((first / kNiirIT) & 1) * (64 * kNiirIT) + lane * kNiirIT + (first & (kNiirIT - 1)));
+            if (first >= W) v.x = 0.f;
+            if (first + 1 >= W) v.y = 0.f;
+            return v;
+        };
+        f2 xv = read_x(0);
+        int wx = 0;
+        auto body = [&](auto edge_tag, int tb) __attribute__((always_inline)) {
+            constexpr bool EDGE = decltype(edge_tag)::value;
+            float hq[Q][2];
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const int t = tb + s;
+                float m[3], sv[3];
+                front.template step<EDGE>(ka, t, xv[s], m, sv);
+                const int wr = (t & (nring - 1)) * 3, rd = ((t - q_l) & (nring - 1)) * 3;
+#pragma unroll
+                for (int j = 0; j < 3; ++j) mring[(wr + j) * 64 + lane] = m[j];
+                float md[3], ph[3];
+#pragma unroll
+                for (int j = 0; j < 3; ++j) md[j] = mring[(rd + j) * 64 + lane];
+                niir_phasemod<EDGE>(ka, t - kAmHalf - ka.gb.q - q_l, md, sv, ph);
+#pragma unroll
+                for (int j = 0; j < 3; ++j) hq[j][s] = ph[j];
+                hq[3][s] = ka.sat_gain * dn_sat.push(ka.taps, s_prev);
+#pragma unroll
+                for (int j = 0; j < 3; ++j) s_prev[j] = sv[j];
+                if (FIRST) {
+                    float xs = 0.f;
+                    if (!EDGE || t < W) {
+                        const f2 cs = ((const_f2 *)args.a.carrier)[t];
+                        xs = fmaf_(syn_s, cs.x, syn_c * cs.y);            // +-sin(phi + t step)
+                    }
+                    float ms[3];
+                    syn.template step<EDGE>(ka, t, xs, ms);
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) ring_syn[(wr + j) * 64 + lane] = ms[j];
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) hq[FIRST ? 4 + j : 0][s] = ka.g_b * ring_syn[(rd + j) * 64 + lane];
+                }
+            }
+            lds_float *slot = hand + ((tb >> 1) & 1) * (Q * 128) + lane * 2;
+#pragma unroll
+            for (int q = 0; q < Q; ++q) *(lds_f2 *)(slot + q * 128) = f2{hq[q][0], hq[q][1]};
+            *(lds_f2 *)(xring + wx * 128 + lane * 2) = xv;
+            wx = wx + 1 == NB ? 0 : wx + 1;
+            const int nxt = tb + 2;
+            if ((nxt & (kNiirIT - 1)) == 0 && nxt < W) {
+                // first read of tile c = nxt / 8: its fill was issued a tile (four bodies) ago; the other buffer was last read a
+                // body ago (lgkmcnt(0) at the barrier below) and takes tile c + 1 now
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_wave_barrier();
+                const int c = nxt / kNiirIT;
+                if ((c + 1) * kNiirIT < W) fill_tile<kNiirIT>(g, itile + ((c + 1) & 1) * (64 * kNiirIT), xp, c + 1, lane);
+            }
+            xv = read_x(nxt);
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        };
+        int tb = 0;
+        for (; tb < t_mid0; tb += 2) body(std::true_type(), tb);
+        for (; tb < t_mid1; tb += 2) body(std::false_type(), tb);
+        for (; tb < T; tb += 2) body(std::true_type(), tb);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        return;
+    }
+
+    // ======================================= stage B ===========================================
+    const float *op = lc.store_ok ? g.out + lc.frame * g.out_frame_stride + (long long)lc.out_row * g.out_row_stride : nullptr;
+    NiirLineK<float> lk;
+    {   // niir.py:117-124, 148-157
+        lk.alt = args.a.line.alternate(frame, lc.line);
+        const double shift = lk.alt ? -args.line_phase_shift : args.line_phase_shift;
+        const double ps = (lk.alt ? 0.0 : args.line_phase_shift) + 3.14159265358979323846 - args.bandpass_phase_shift;
+        lk.sin_shift = (float)sin(shift);
+        lk.cos_shift = (float)cos(shift);
+        lk.sin_ps = (float)sin(ps);
+        lk.cos_ps = (float)cos(ps);
+    }
+    TapsPk3 kp;
+    kp.load(k.taps);
+    const int idx1 = ((lane + 63) & 63) * 4;
+    NiirBackPk back;
+    back.reset();
+    lds_float *otile = otile_base + lane * kTile;
+    const int wpos = ((lane >> CM_TILE_SWZ) & (kTile / 4 - 1)) << 2;
+    const bool strip = args.strip != 0;
+    const bool odd = (lat & 1) != 0;
+    int ra = NB - hb, rb = NB - hb + 1;         // luma source blocks of bodies b - hb and b - hb + 1
+    if (rb >= NB) rb -= NB;
+    auto body = [&](auto edge_tag, int tb) __attribute__((always_inline)) {
+        constexpr bool EDGE = decltype(edge_tag)::value;
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // the hand-over of this body is complete
+        const lds_float *slot = hand + ((tb >> 1) & 1) * (Q * 128) + lane * 2;
+        f2 hq[Q];
+#pragma unroll
+        for (int q = 0; q < Q; ++q) hq[q] = *(const lds_f2 *)(slot + q * 128);
+        const f2 xa = *(const lds_f2 *)(xring + ra * 128 + lane * 2), xb = *(const lds_f2 *)(xring + rb * 128 + lane * 2);
+        ra = ra + 1 == NB ? 0 : ra + 1;
+        rb = rb + 1 == NB ? 0 : rb + 1;
+        const float cd[2] = {odd ? xa.y : xa.x, odd ? xb.x : xa.y};      // composite[t - lat] of the two steps
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const int t = tb + s;
+            const float p[3] = {hq[0][s], hq[1][s], hq[2][s]};
+            float pv[3];
+            const int n3 = t - kAmHalf - k.gb.q - q_l;
+#pragma unroll
+            for (int j = 0; j < 3; ++j) pv[j] = FIRST ? hq[FIRST ? 4 + j : 0][s] : lane_from(idx1, p[j]);
+            const NiirOut<float> o = back.template step<EDGE>(k, kp, n3, p, pv, hq[3][s], lk.alt);
+            const int n = t - lat;
+            if (!EDGE || (n >= 0 && n < W)) put_rgb<false, kTile>(otile, wpos, n, niir_finish(k, lk, o, cd[s], strip));
+            if (n >= 0 && ((n & (kTile - 1)) == kTile - 1 || n == g.Wp - 1)) flush_tile<kTile>(g, otile_base, op, n & ~(kTile - 1), lane);
+        }
+    };
+    int tb = 0;
+    for (; tb < t_mid0; tb += 2) body(std::true_type(), tb);
+    for (; tb < t_mid1; tb += 2) body(std::false_type(), tb);
+    for (; tb < T; tb += 2) body(std::true_type(), tb);
+}
+
+__global__ __launch_bounds__(128, 2) void niir_demod_pair_kernel(const NiirPairArgs args) {
+    extern __shared__ __attribute__((aligned(16))) float niir_pair_lds[];
+    lds_float *lds = (lds_float *)niir_pair_lds;
+    const int role = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    if ((int)blockIdx.x < args.n_first) niir_pair_body<true>(args.m, args.gf, blockIdx.x, lds, role);
+    else niir_pair_body<false>(args.m, args.m.g, (int)blockIdx.x - args.n_first, lds, role);
 }
 
 struct NiirModArgs {

@@ -37,11 +37,12 @@ struct Up3 {
 #pragma unroll
         for (int e = 0; e < 58; ++e) s[e] = T(0);
     }
+    // (fma3: the three-address form - with the two-address v_fmac hipcc rotates the 55 partial sums through one v_mov each)
     CM_HD void push(const Taps3<T> &k, T x, T out[3]) {
 #pragma unroll
-        for (int j = 0; j < 3; ++j) out[j] = fmaf_(k.h[j], x, s[j]);
+        for (int j = 0; j < 3; ++j) out[j] = fma3<true>(k.h[j], x, s[j]);
 #pragma unroll
-        for (int e = 3; e < 58; ++e) s[e - 3] = fmaf_(k.h[e], x, s[e]);
+        for (int e = 3; e < 58; ++e) s[e - 3] = fma3<true>(k.h[e], x, s[e]);
 #pragma unroll
         for (int e = 58; e < 61; ++e) s[e - 3] = k.h[e] * x;
     }
@@ -57,12 +58,19 @@ struct Dn3 {
 #pragma unroll
         for (int d = 0; d < 20; ++d) s[d] = T(0);
     }
+    // Every pending output takes its three products in the order z[2], z[1], z[0]; the passes below run that order across all
+    // of them, so that no instruction reads the result of the one right before it (and the three-address form: no v_mov).
     CM_HD T push(const Taps3<T> &k, const T z[3]) {
-        const T out = fmaf_(k.h[0], z[0], s[0]);
+        const T out = fma3<true>(k.h[0], z[0], s[0]);
 #pragma unroll
-        for (int d = 1; d < 20; ++d)
-            s[d - 1] = fmaf_(k.h[3 * d], z[0], fmaf_(k.h[3 * d - 1], z[1], fmaf_(k.h[3 * d - 2], z[2], s[d])));
-        s[19] = fmaf_(k.h[60], z[0], fmaf_(k.h[59], z[1], k.h[58] * z[2]));
+        for (int d = 1; d < 20; ++d) s[d] = fma3<true>(k.h[3 * d - 2], z[2], s[d]);
+        const T last = k.h[58] * z[2];
+#pragma unroll
+        for (int d = 1; d < 20; ++d) s[d] = fma3<true>(k.h[3 * d - 1], z[1], s[d]);
+        const T last2 = fma3<true>(k.h[59], z[1], last);
+#pragma unroll
+        for (int d = 1; d < 20; ++d) s[d - 1] = fma3<true>(k.h[3 * d], z[0], s[d]);
+        s[19] = fma3<true>(k.h[60], z[0], last2);
         return out;
     }
 };
@@ -314,6 +322,26 @@ struct NiirSyn {
     }
 };
 
+// a / b and 1 / sqrt(x).  On the device: v_rcp_f32 / v_rsq_f32 (1 ulp) instead of the IEEE sequences (10 - 12 instructions
+// each, six divisions and two square roots per pixel in the NIIR decoder).  Where they are used a relative error of the
+// quotient scales a phasor or a (sin, cos) pair as a whole - the angle, which is what the decoder is after, does not see it.
+CM_HD float am_div(float a, float b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return a * __builtin_amdgcn_rcpf(b);
+#else
+    return a / b;
+#endif
+}
+CM_HD double am_div(double a, double b) { return a / b; }
+CM_HD float am_rsqrt(float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_rsqf(x);
+#else
+    return 1.0f / std::sqrt(x);
+#endif
+}
+CM_HD double am_rsqrt(double x) { return 1.0 / std::sqrt(x); }
+
 // phasemod_up of a triple: c_pm * M / S inside the sequence, zero outside (the decimators zero-extend)
 template <bool EDGE = true, typename T>
 CM_HD void niir_phasemod(const NiirDemodK<T> &k, int n3, const T m[3], const T s[3], T p[3]) {
@@ -321,7 +349,7 @@ CM_HD void niir_phasemod(const NiirDemodK<T> &k, int n3, const T m[3], const T s
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
         const int q = 3 * n3 + j;
-        p[j] = (!EDGE || (q >= 0 && q < L)) ? k.c_pm * m[j] / s[j] : T(0);
+        p[j] = (!EDGE || (q >= 0 && q < L)) ? am_div(k.c_pm * m[j], s[j]) : T(0);
     }
 }
 
@@ -382,7 +410,7 @@ struct NiirLineK {
 
 CM_HD float am_sqrt(float x) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    return __builtin_sqrtf(x);
+    return __builtin_amdgcn_sqrtf(x);      // v_sqrt_f32 (1 ulp) instead of the correctly rounded sequence (about 10 instructions)
 #else
     return std::sqrt(x);
 #endif
@@ -392,12 +420,13 @@ CM_HD double am_sqrt(double x) { return std::sqrt(x); }
 // niir.py:134-163, 63-67, 52-61 on the decimated streams of one sample: comp = composite[n5]
 template <typename T>
 CM_HD Rgb<T> niir_finish(const NiirDemodK<T> &k, const NiirLineK<T> &lk, const NiirOut<T> &o, T comp, bool strip) {
-    const T nrm = am_sqrt(o.cosphi * o.cosphi + o.sinphi * o.sinphi);
-    const T c1 = o.cosphi / nrm, s1 = o.sinphi / nrm;
+    const T inv = am_rsqrt(o.cosphi * o.cosphi + o.sinphi * o.sinphi);
+    const T c1 = o.cosphi * inv, s1 = o.sinphi * inv;
     const T s2 = -c1 * lk.sin_shift - s1 * lk.cos_shift;                 // niir.py:139-140
     const T c2 = s1 * lk.sin_shift - c1 * lk.cos_shift;
     T db = o.sat * s2, dr = o.sat * c2;
-    const T r = am_sqrt(db * db + dr * dr);
+    const T r2 = db * db + dr * dr;
+    const T r = am_sqrt(r2);
     T luma = comp;
     if (strip) {
         const T u = lk.alt ? -r : db, v = lk.alt ? T(0) : dr;             // niir.py:148-156
@@ -405,7 +434,7 @@ CM_HD Rgb<T> niir_finish(const NiirDemodK<T> &k, const NiirLineK<T> &lk, const N
         luma = comp - (u2 * o.sinc + v2 * o.cosc);
     }
     // _remove_offset: the saturation loses its pedestal, the hue stays (atan2(0, 0) = 0 gives (0, 0))
-    const T keep = r > T(0) ? (r - T(0.1) > T(0) ? (r - T(0.1)) / r : T(0)) : T(0);
+    const T keep = r > T(0) ? (r - T(0.1) > T(0) ? am_div(r - T(0.1), r) : T(0)) : T(0);
     db *= keep;
     dr *= keep;
     Rgb<T> out;
@@ -491,6 +520,136 @@ struct NiirMod {
         return alt ? -am_sqrt(b * b + r * r) * sn : fmaf_(b, sn, r * cs);                 // niir.py:73-76
     }
 };
+
+// =============================================================================================
+// Packed float32 forms for the wave-pair decoders (cm_am_kernels.h: niir_demod_pair_kernel, proto_demod_pair_kernel; device
+// only).  The 61-tap FIR is symmetric: its 31 distinct taps sit in 16 VGPR pairs, tap(i) = c[i' >> 1][i' & 1] with
+// i' = min(i, 60 - i); a decimator that runs on a PAIR of signals (sin / cos products, the two re-modulation carriers, chroma /
+// luma) executes exactly the scalar decimator's FMAs, two at a time (v_pk_fma_f32, op_sel picks the tap out of its pair).
+// =============================================================================================
+#if defined(__HIPCC__)
+}  // namespace cm
+#include "cm_stages_pk.h"
+namespace cm {
+struct TapsPk3 {
+    pf2 c[16];
+    template <int J>
+    __device__ __forceinline__ void load_j(const Taps3<float> &t) {
+        c[J] = pf2{take(t.h[2 * J]), take(t.h[2 * J + 1 <= 30 ? 2 * J + 1 : 30])};
+        pin_pair(c[J]);
+        if constexpr (J + 1 < 16) load_j<J + 1>(t);
+    }
+    __device__ __forceinline__ void load(const Taps3<float> &t) { load_j<0>(t); }
+};
+template <int I> __device__ __forceinline__ pf2 tap3_fma(const TapsPk3 &k, pf2 x, pf2 acc) {
+    constexpr int i = I <= 30 ? I : 60 - I;
+    return pk_fma_c<i & 1>(k.c[i >> 1], x, acc);
+}
+template <int I> __device__ __forceinline__ pf2 tap3_mul(const TapsPk3 &k, pf2 x) {
+    constexpr int i = I <= 30 ? I : 60 - I;
+    return pk_mul_c<i & 1>(k.c[i >> 1], x);
+}
+template <int I> __device__ __forceinline__ float tap3(const TapsPk3 &k) {
+    constexpr int i = I <= 30 ? I : 60 - I;
+    return (i & 1) ? k.c[i >> 1].y : k.c[i >> 1].x;
+}
+// Dn3 on a pair of signals
+struct Dn3Pk {
+    pf2 s[20];
+    __device__ __forceinline__ void reset() {
+#pragma unroll
+        for (int d = 0; d < 20; ++d) s[d] = pf2{0.f, 0.f};
+    }
+    // three passes over the pending outputs (z2, then z1, then z0: the scalar decimator's order per output, and no packed
+    // instruction reads the result of the one right before it - hipcc pads such pairs with an s_nop)
+    template <int D> __device__ __forceinline__ void pass2(const TapsPk3 &k, pf2 z2) {
+        s[D] = tap3_fma<3 * D - 2>(k, z2, s[D]);
+        if constexpr (D < 19) pass2<D + 1>(k, z2);
+    }
+    template <int D> __device__ __forceinline__ void pass1(const TapsPk3 &k, pf2 z1) {
+        s[D] = tap3_fma<3 * D - 1>(k, z1, s[D]);
+        if constexpr (D < 19) pass1<D + 1>(k, z1);
+    }
+    template <int D> __device__ __forceinline__ void pass0(const TapsPk3 &k, pf2 z0) {
+        s[D - 1] = tap3_fma<3 * D>(k, z0, s[D]);
+        if constexpr (D < 19) pass0<D + 1>(k, z0);
+    }
+    __device__ __forceinline__ pf2 push(const TapsPk3 &k, pf2 z0, pf2 z1, pf2 z2) {
+        const pf2 out = tap3_fma<0>(k, z0, s[0]);
+        pass2<1>(k, z2);
+        const pf2 last = tap3_mul<58>(k, z2);
+        pass1<1>(k, z1);
+        const pf2 last2 = tap3_fma<59>(k, z1, last);
+        pass0<1>(k, z0);
+        s[19] = tap3_fma<60>(k, z0, last2);
+        return out;
+    }
+};
+// Dn3 on one signal with the taps out of the pairs
+struct Dn3S {
+    float s[20];
+    __device__ __forceinline__ void reset() {
+#pragma unroll
+        for (int d = 0; d < 20; ++d) s[d] = 0.f;
+    }
+    template <int D>
+    __device__ __forceinline__ void upd(const TapsPk3 &k, float z0, float z1, float z2) {
+        s[D - 1] = fma3<true>(tap3<3 * D>(k), z0, fma3<true>(tap3<3 * D - 1>(k), z1, fma3<true>(tap3<3 * D - 2>(k), z2, s[D])));
+        if constexpr (D < 19) upd<D + 1>(k, z0, z1, z2);
+    }
+    __device__ __forceinline__ float push(const TapsPk3 &k, const float z[3]) {
+        const float out = fma3<true>(tap3<0>(k), z[0], s[0]);
+        upd<1>(k, z[0], z[1], z[2]);
+        s[19] = fma3<true>(tap3<60>(k), z[0], fma3<true>(tap3<59>(k), z[1], tap3<58>(k) * z[2]));
+        return out;
+    }
+};
+// NiirBack for stage B of the wave pair: the four phase decimators as two packed pairs - (sin, cos) products | (carrier, its
+// derivative); the fifth (saturation) runs in stage A, which has the low-passed envelope at hand
+struct NiirBackPk {
+    Dn3Pk dn_sc, dn_car;
+    float c1[3], h1[3], c2_2;
+    __device__ __forceinline__ void reset() {
+        dn_sc.reset(); dn_car.reset();
+#pragma unroll
+        for (int j = 0; j < 3; ++j) c1[j] = h1[j] = 0.f;
+        c2_2 = 0.f;
+    }
+    // sat: stage A's k.sat_gain * Dn3(S of the previous triple) of this step
+    template <bool EDGE = true>
+    __device__ __forceinline__ NiirOut<float> step(const NiirDemodK<float> &k, const TapsPk3 &kp, int n3, const float own[3], const float prev[3],
+                                                    float sat, bool alt) {
+        const int L = 3 * k.width, n4 = n3 - 1;
+        float c[3], h[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {                       // niir.py:117-124
+            c[j] = alt ? own[j] : prev[j];
+            h[j] = alt ? prev[j] : own[j];
+        }
+        pf2 sc[3], car[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int p = 3 * n4 + j;
+            const float before = j == 0 ? c2_2 : c1[j - 1], after = j == 2 ? c[0] : c1[j + 1];
+            const float ac = (!EDGE || (p >= 1 && p <= L - 2)) ? k.alt_scale * (after - before) : 0.f;       // niir.py:126-129
+            sc[j] = pf2{h1[j] * c1[j], h1[j] * ac};                                                           // niir.py:131-132
+            car[j] = pf2{c1[j], ac};
+        }
+        NiirOut<float> o;
+        const pf2 r1 = dn_sc.push(kp, sc[0], sc[1], sc[2]);
+        const pf2 r2 = dn_car.push(kp, car[0], car[1], car[2]);
+        o.sinphi = r1.x;
+        o.cosphi = r1.y;
+        o.sat = sat;
+        o.sinc = k.third * r2.x;
+        o.cosc = k.third * r2.y;
+        c2_2 = c1[2];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) { c1[j] = c[j]; h1[j] = h[j]; }
+        return o;
+    }
+};
+#endif
 
 // ---- line geometry and sub-carrier start phase, float64 (line.py:57-65, utils.py:82-88) ----------------------------------
 struct AmLine {

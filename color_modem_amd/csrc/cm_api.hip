@@ -1466,7 +1466,27 @@ int niir_launch_demod(const cm_am_plan *p, Geom g, int64_t first_frame, hipStrea
     g.skip_first = 1;
     long long blocks = (g.total_calls + 62) / 63;
     if (blocks > 0x7fffffffLL) return fail(CM_ERR_INVALID, "batch too large for one launch");
-    if (blocks > 0 && !(g.rows_mode && g.total_calls == 1 && with_first)) {     // a lone first call needs no main pass
+    if (g.rows_mode && g.total_calls == 1 && with_first) blocks = 0;      // a lone first call needs no main pass
+#if CM_NIIR_PAIR
+    {   // the wave pair: main pass and sparse first-line pass in one launch (cm_am_kernels.h: niir_demod_pair_kernel)
+        NiirPairArgs pa;
+        a.g = g;
+        pa.m = a;
+        pa.gf = g;
+        pa.n_first = 0;
+        if (with_first) {
+            pa.gf.sparse = 1;
+            pa.gf.skip_first = 0;
+            pa.gf.total_calls = g.rows_mode ? 1 : (g.total_calls / g.calls_per_frame) * g.runs_per_frame;
+            pa.n_first = (int)((pa.gf.total_calls + 63) / 64);
+        }
+        if (blocks + pa.n_first <= 0) return CM_OK;
+        const int lat = 2 * kAmHalf + 1 + p->nd.gb.q + p->nd.gl.q;
+        const size_t lds = sizeof(float) * (size_t)niir_pair_lds_floats(lat, p->nd.gl.q, pa.n_first > 0);
+        hipLaunchKernelGGL(niir_demod_pair_kernel, dim3((int)blocks + pa.n_first), dim3(128), lds, stream, pa);
+    }
+#else
+    if (blocks > 0) {
         a.g = g;
         hipLaunchKernelGGL(niir_demod_kernel<false>, dim3((int)blocks), dim3(64), 0, stream, a);
     }
@@ -1479,6 +1499,7 @@ int niir_launch_demod(const cm_am_plan *p, Geom g, int64_t first_frame, hipStrea
         a.g = s;
         if (fb > 0) hipLaunchKernelGGL(niir_demod_kernel<true>, dim3((int)fb), dim3(64), 0, stream, a);
     }
+#endif
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(CM_ERR_LAUNCH, std::string("niir_demod_kernel launch: ") + hipGetErrorString(e));
     return CM_OK;

@@ -502,7 +502,7 @@ __device__ __forceinline__ LaneCall locate_call(const Geom &g, int block, int de
     LaneCall r;
     r.frame = frame;
     r.call = frame * g.calls_per_frame + rem;
-    r.line = g.first_line[run] + 2 * i;
+    r.line = (run ? g.first_line[1] : g.first_line[0]) + 2 * i;
     r.kk = g.k0 + i;
     r.regime = r.kk < 2 ? r.kk : 2;
     r.store_ok = active && !(g.skip_first && r.kk == 0);
