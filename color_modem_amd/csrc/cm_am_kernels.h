@@ -16,6 +16,9 @@
 
 namespace cm {
 
+#ifndef CM_PROTO_PAIR         /* 1: the Proto-SECAM decoder on the wave pair (proto_demod_pair_kernel); 0: the one-wave kernel of round 2 */
+#define CM_PROTO_PAIR 1
+#endif
 #ifndef CM_NIIR_PAIR          /* 1: the NIIR decoder on the wave pair (niir_demod_pair_kernel); 0: the one-wave kernels of round 2 */
 #define CM_NIIR_PAIR 1
 #endif
@@ -96,6 +99,148 @@ __global__ __launch_bounds__(64, 2) void proto_demod_kernel(const ProtoDemodArgs
     for (; tb < t_mid0; tb += 4) body(std::true_type(), tb);
     for (; tb < t_mid1; tb += 4) body(std::false_type(), tb);
     for (; tb < T; tb += 4) body(std::true_type(), tb);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Wave-pair form of the Proto-SECAM decoder (round 3; as niir_demod_pair_kernel below):
+//   wave 0 (stage A)  every global load (8-sample input tiles through global_load_lds, two buffers), up3, the band-pass with
+//                     |.| (chroma) and the band-stop (luma) at the 3x rate; per body of two steps it leaves the two triples of
+//                     each step in a double-buffered hand-over ring
+//   wave 1 (stage B)  the chroma low-pass at the 3x rate, BOTH decimators as one packed pair (chroma | luma: Dn3Pk), the luma
+//                     delay (LDS ring), the other colour-difference signal from the neighbouring lane, matrix, output tile and
+//                     every global store
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int kProtoIT = 8;
+inline __host__ __device__ int proto_ring_slots(int dly) { return dly < 8 ? 8 : (dly < 16 ? 16 : 32); }
+// floats of dynamic LDS: input tile (two buffers) | hand-over (2 buffers x 6 quantities) | luma delay ring | output tile
+inline int proto_pair_lds_floats(int dly) { return 2 * 64 * kProtoIT + 2 * 6 * 128 + proto_ring_slots(dly) * 64 + 3 * 64 * 16; }
+
+__global__ __launch_bounds__(128, 2) void proto_demod_pair_kernel(const ProtoDemodArgs args) {
+    constexpr int kTile = 16, DEPTH = 1, Q = 6;
+    extern __shared__ __attribute__((aligned(16))) float proto_pair_lds[];
+    typedef __attribute__((address_space(3))) f2 lds_f2;
+    lds_float *lds = (lds_float *)proto_pair_lds;
+    const int role = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    const Geom &g = args.g;
+    const ProtoDemodK<float> &k = args.k;
+    const int lane = threadIdx.x & 63;
+    const LaneCall lc = locate_call(g, blockIdx.x, DEPTH, lane);
+    const int W = g.W, L = 3 * W;
+    const int lat_c = ProtoDemod<float>::lat_chroma(k), lat_y = ProtoDemod<float>::lat_luma(k);
+    const int dly = lat_c - lat_y;                       // luma waits for the chroma path
+    const int nring = proto_ring_slots(dly);
+    const int T = (g.Wp + lat_c + 1) & ~1;
+    lds_float *itile = lds;                              // two buffers of [64][kProtoIT]: tile c lives in buffer c & 1
+    lds_float *hand = itile + 2 * 64 * kProtoIT;
+    lds_float *ring = hand + 2 * Q * 128;
+    lds_float *otile_base = ring + nring * 64;
+    // interior bodies (as in proto_demod_kernel): t >= lat_c, t + 1 < W - 6
+    int t_mid0 = (lat_c + 1) & ~1, t_mid1 = (W - 8) & ~1;
+    if (t_mid1 <= t_mid0) t_mid0 = t_mid1 = 0;
+
+    if (role == 0) {
+        // =================================== stage A ===========================================
+        ProtoDemodK<float> ka = k;
+        pin_taps3(ka.taps);
+        const float *xp = g.in + lc.frame * g.in_frame_stride + (long long)lc.src_row * g.Wp;
+        Up3<float> up;
+        FF3<float, 3> ext, rem;
+        up.reset(); ext.reset(); rem.reset();
+        fill_tile<kProtoIT>(g, itile, xp, 0, lane);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        if (kProtoIT < W) fill_tile<kProtoIT>(g, itile + 64 * kProtoIT, xp, 1, lane);      // tile c + 1 is asked for when tile c is first read
+        auto read_x = [&](int first) -> f2 {
+            f2 v = *(const lds_f2 *)(itile + ((first / kProtoIT) & 1) * (64 * kProtoIT) + lane * kProtoIT + (first & (kProtoIT - 1)));
+            if (first >= W) v.x = 0.f;
+            if (first + 1 >= W) v.y = 0.f;
+            return v;
+        };
+        f2 xv = read_x(0);
+        auto body = [&](auto edge_tag, int tb) __attribute__((always_inline)) {
+            constexpr bool EDGE = decltype(edge_tag)::value;
+            float hq[Q][2];
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const int n1 = tb + s - kAmHalf;
+                float u[3], c1[3], y1[3];
+                up.push(ka.taps, xv[s], u);
+                ext.template step<AM_FORM_BP, EDGE>(ka.ext, ka.ge, L, n1, u, c1);
+                rem.template step<AM_FORM_SYM, EDGE>(ka.rem, ka.gr, L, n1, u, y1);
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    hq[j][s] = c1[j] < 0.f ? -c1[j] : c1[j];     // protosecam.py:98 (the factor pi / 2 is in chroma_gain)
+                    hq[3 + j][s] = y1[j];
+                }
+            }
+            lds_float *slot = hand + ((tb >> 1) & 1) * (Q * 128) + lane * 2;
+#pragma unroll
+            for (int q = 0; q < Q; ++q) *(lds_f2 *)(slot + q * 128) = f2{hq[q][0], hq[q][1]};
+            const int nxt = tb + 2;
+            if ((nxt & (kProtoIT - 1)) == 0 && nxt < W) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_wave_barrier();
+                const int c = nxt / kProtoIT;
+                if ((c + 1) * kProtoIT < W) fill_tile<kProtoIT>(g, itile + ((c + 1) & 1) * (64 * kProtoIT), xp, c + 1, lane);
+            }
+            xv = read_x(nxt);
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        };
+        int tb = 0;
+        for (; tb < t_mid0; tb += 2) body(std::true_type(), tb);
+        for (; tb < t_mid1; tb += 2) body(std::false_type(), tb);
+        for (; tb < T; tb += 2) body(std::true_type(), tb);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        return;
+    }
+
+    // ======================================= stage B ===========================================
+    const float *op = lc.store_ok ? g.out + lc.frame * g.out_frame_stride + (long long)lc.out_row * g.out_row_stride : nullptr;
+    const long long frame = (long long)args.a.frame_base + lc.frame;
+    const bool alt = args.a.line.alternate(frame, lc.line);
+    const float w_prev = lc.kk > 0 ? 1.f : 0.f;          // protosecam.py:93-94: the first line of a run has no previous chroma
+    const int idx1 = ((lane + 63) & 63) * 4;
+    TapsPk3 kp;
+    kp.load(k.taps);
+    FF3<float, 2> post;
+    Dn3Pk dn;                                             // (chroma, luma)
+    post.reset();
+    dn.reset();
+    for (int j = 0; j < nring; ++j) ring[j * 64 + lane] = 0.f;
+    lds_float *otile = otile_base + lane * kTile;
+    const int wpos = ((lane >> CM_TILE_SWZ) & (kTile / 4 - 1)) << 2;
+    auto body = [&](auto edge_tag, int tb) __attribute__((always_inline)) {
+        constexpr bool EDGE = decltype(edge_tag)::value;
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // the hand-over of this body is complete
+        const lds_float *slot = hand + ((tb >> 1) & 1) * (Q * 128) + lane * 2;
+        f2 hq[Q];
+#pragma unroll
+        for (int q = 0; q < Q; ++q) hq[q] = *(const lds_f2 *)(slot + q * 128);
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const int t = tb + s, n1 = t - kAmHalf;
+            const float c1[3] = {hq[0][s], hq[1][s], hq[2][s]};
+            float c2[3];
+            post.template step<AM_FORM_GEN, EDGE>(k.post, k.gp, L, n1 - k.ge.q, c1, c2);
+            const pf2 d = dn.push(kp, pf2{c2[0], hq[3][s]}, pf2{c2[1], hq[4][s]}, pf2{c2[2], hq[5][s]});
+            const float chroma = fmaf_(k.chroma_gain, d.x, -1.f), luma = k.luma_gain * d.y;
+            ring[(t & (nring - 1)) * 64 + lane] = luma;
+            const float luma_d = ring[((t - dly) & (nring - 1)) * 64 + lane];
+            const float prev = lane_from(idx1, chroma) * w_prev;
+            const float dr = alt ? prev : chroma, db = alt ? chroma : prev;             // protosecam.py:105-108
+            Rgb<float> o;
+            o.r = fmaf_(k.m[0][0], luma_d, fmaf_(k.m[0][1], dr, k.m[0][2] * db));
+            o.g = fmaf_(k.m[1][0], luma_d, fmaf_(k.m[1][1], dr, k.m[1][2] * db));
+            o.b = fmaf_(k.m[2][0], luma_d, fmaf_(k.m[2][1], dr, k.m[2][2] * db));
+            const int n = t - lat_c;
+            if (!EDGE || (n >= 0 && n < W)) put_rgb<false, kTile>(otile, wpos, n, o);
+            if (n >= 0 && ((n & (kTile - 1)) == kTile - 1 || n == g.Wp - 1)) flush_tile<kTile>(g, otile_base, op, n & ~(kTile - 1), lane);
+        }
+    };
+    int tb = 0;
+    for (; tb < t_mid0; tb += 2) body(std::true_type(), tb);
+    for (; tb < t_mid1; tb += 2) body(std::false_type(), tb);
+    for (; tb < T; tb += 2) body(std::true_type(), tb);
 }
 
 struct ProtoModArgs {
@@ -183,6 +328,156 @@ __global__ __launch_bounds__(64, 2) void proto_mod_kernel(const ProtoModArgs arg
             const f2 cs = ((const_f2 *)args.a.carrier)[nc];
             const float cosp = fmaf_(cph, cs.x, -(sph * cs.y));      // cos(phi + n step)
             put_composite<false, kTile>(g, otile_base, op, lane, wpos, n, fmaf_(cosp, chroma, luma));
+        }
+    };
+    int tb = 0;
+    for (; tb < t_mid0; tb += 4) body(std::true_type(), tb);
+    for (; tb < t_mid1; tb += 4) body(std::false_type(), tb);
+    for (; tb < T; tb += 4) body(std::true_type(), tb);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Wave-pair form of the Proto-SECAM encoder (round 3):
+//   wave 0 (stage A)  every global load (three-plane 16-sample input tiles through global_load_lds, as the QAM encoders), the
+//                     colour matrix, the previous call's components (ColorAveragingModem), the delay of the shorter path's
+//                     input (LDS ring), the pre-correction low-pass at the 1x rate and up3 of the luma; per body of four steps
+//                     it leaves (U[3], chroma, plain luma) in a double-buffered hand-over ring
+//   wave 1 (stage B)  the band-stop at the 3x rate, the decimator, the carrier, the composite sample, output tile and every
+//                     global store
+// ---------------------------------------------------------------------------------------------------------------------
+#ifndef CM_PROTO_MOD_PAIR
+#define CM_PROTO_MOD_PAIR 1
+#endif
+inline int proto_mod_pair_lds_floats(int dly) { return kLdsIn3 + proto_ring_slots(dly) * 64 + 2 * 5 * 256 + 64 * 16; }
+
+template <int DEPTH>
+__global__ __launch_bounds__(128, 2) void proto_mod_pair_kernel(const ProtoModArgs args) {
+    constexpr int kTile = 16, Q = 5;
+    extern __shared__ __attribute__((aligned(16))) float proto_mod_lds[];
+    lds_float *lds = (lds_float *)proto_mod_lds;
+    const int role = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    const Geom &g = args.g;
+    const ProtoModK<float> &k = args.k;
+    const int lane = threadIdx.x & 63;
+    const LaneCall lc = locate_call(g, blockIdx.x, DEPTH, lane);
+    const int W = g.W;
+    const int lat_y = ProtoMod<float>::lat_luma(k), lat_c = ProtoMod<float>::lat_chroma(k);
+    const int lat = lat_y > lat_c ? lat_y : lat_c;
+    const int d_c = lat - lat_c, d_y = lat - lat_y;      // one of them is 0: the shorter path's input waits in the ring
+    const int dly = d_c > d_y ? d_c : d_y;
+    const int nring = proto_ring_slots(dly);
+    const int T = (g.Wp + lat + 3) & ~3;
+    lds_float *itile = lds;
+    lds_float *ring = itile + kLdsIn3;
+    lds_float *hand = ring + nring * 64;
+    lds_float *otile_base = hand + 2 * Q * 256;
+    // interior bodies: t >= lat + 4 (both paths behind their delays), t + 3 < W - 4
+    int t_mid0 = (lat + 4 + 3) & ~3, t_mid1 = (W - 8) & ~3;
+    if (t_mid1 <= t_mid0) t_mid0 = t_mid1 = 0;
+    const float *rp, *op;
+    mod_rows<false>(g, lc, rp, op);
+
+    if (role == 0) {
+        // =================================== stage A ===========================================
+        ProtoModK<float> ka = k;
+        pin_taps3(ka.taps);
+        const long long frame = (long long)args.a.frame_base + lc.frame;
+        const int line = DEPTH ? lc.line - 2 : lc.line;       // the line that is modulated
+        const bool alt = args.a.line.alternate(frame, line);
+        const bool have_prev = lc.kk > 0;
+        const int idx1 = ((lane + 63) & 63) * 4;
+        FF1<float, 2> pre;
+        Up3<float> up;
+        pre.reset();
+        up.reset();
+        for (int j = 0; j < nring; ++j) ring[j * 64 + lane] = 0.f;
+        f4 cur[3], nxt[3];
+        first_tile3<false>(g, itile, rp, lane, nxt);
+        auto body = [&](auto edge_tag, int tb) __attribute__((always_inline)) {
+            constexpr bool EDGE = decltype(edge_tag)::value;
+            cur[0] = nxt[0]; cur[1] = nxt[1]; cur[2] = nxt[2];
+            next_tile3x<false>(g, itile, rp, lane, tb + 4, nxt);
+            float hq[Q][4];
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const int t = tb + s;
+                const float r = cur[0][s], gg = cur[1][s], b = cur[2][s];
+                float y = fmaf_(ka.e[0][0], r, fmaf_(ka.e[0][1], gg, ka.e[0][2] * b));
+                float dr = fmaf_(ka.e[1][0], r, fmaf_(ka.e[1][1], gg, ka.e[1][2] * b));
+                float db = fmaf_(ka.e[2][0], r, fmaf_(ka.e[2][1], gg, ka.e[2][2] * b));
+                if (DEPTH) {
+                    const float yp = lane_from(idx1, y), drp = lane_from(idx1, dr), dbp = lane_from(idx1, db);
+                    if (have_prev) {
+                        y = yp;                                  // comb.py:147
+                        dr = 0.5f * (dr + drp);                  // comb.py:148-149
+                        db = 0.5f * (db + dbp);
+                    }
+                }
+                const float d = alt ? db : dr;                   // protosecam.py:75-78
+                const float late = d_c > 0 ? d : y;              // the shorter path's input waits dly samples
+                ring[(t & (nring - 1)) * 64 + lane] = late;
+                const float waited = ring[((t - dly) & (nring - 1)) * 64 + lane];
+                const float d_in = d_c > 0 ? waited : d, y_in = d_c > 0 ? y : (d_y > 0 ? waited : y);
+                const float c = pre.template step<AM_FORM_GEN, EDGE>(ka.pre, ka.s_c, ka.width, t - d_c, d_in);
+                hq[3][s] = fmaf_(0.125f * ka.pre_gain, c, 0.125f);
+                hq[4][s] = y_in;
+                float u[3] = {0.f, 0.f, 0.f};
+                const int i_y = t - d_y;
+                if (ka.luma_filter) up.push(ka.taps, (!EDGE || (i_y >= 0 && i_y < ka.width)) ? y_in : 0.f, u);
+                hq[0][s] = u[0]; hq[1][s] = u[1]; hq[2][s] = u[2];
+            }
+            lds_float *slot = hand + ((tb >> 2) & 1) * (Q * 256) + lane * 4;
+#pragma unroll
+            for (int q = 0; q < Q; ++q) *(lds_f4 *)(slot + q * 256) = f4{hq[q][0], hq[q][1], hq[q][2], hq[q][3]};
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        };
+        int tb = 0;
+        for (; tb < t_mid0; tb += 4) body(std::true_type(), tb);
+        for (; tb < t_mid1; tb += 4) body(std::false_type(), tb);
+        for (; tb < T; tb += 4) body(std::true_type(), tb);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        return;
+    }
+
+    // ======================================= stage B ===========================================
+    ProtoModK<float> kb = k;
+    pin_taps3(kb.taps);
+    const long long frame = (long long)args.a.frame_base + lc.frame;
+    const int line = DEPTH ? lc.line - 2 : lc.line;
+    float cph, sph;
+    {
+        const double phi = args.a.line.start_phase(frame, line);
+        cph = (float)cos(phi);
+        sph = (float)sin(phi);
+    }
+    FF3<float, 3> rem;
+    Dn3<float> dn;
+    rem.reset();
+    dn.reset();
+    const int wpos = ((lane >> CM_TILE_SWZ) & (kTile / 4 - 1)) << 2;
+    auto body = [&](auto edge_tag, int tb) __attribute__((always_inline)) {
+        constexpr bool EDGE = decltype(edge_tag)::value;
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // the hand-over of this body is complete
+        const lds_float *slot = hand + ((tb >> 2) & 1) * (Q * 256) + lane * 4;
+        f4 hq[Q];
+#pragma unroll
+        for (int q = 0; q < Q; ++q) hq[q] = *(const lds_f4 *)(slot + q * 256);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int t = tb + s;
+            float luma = hq[4][s];
+            if (kb.luma_filter) {
+                const float u[3] = {hq[0][s], hq[1][s], hq[2][s]};
+                float y1[3];
+                rem.template step<AM_FORM_SYM, EDGE>(kb.rem, kb.gr, 3 * kb.width, t - d_y - kAmHalf, u, y1);
+                luma = kb.luma_gain * dn.push(kb.taps, y1);
+            }
+            const int n = t - lat;
+            int nc = n;
+            if (EDGE) nc = n < 0 ? 0 : (n > W - 1 ? W - 1 : n);
+            const f2 cs = ((const_f2 *)args.a.carrier)[nc];
+            const float cosp = fmaf_(cph, cs.x, -(sph * cs.y));      // cos(phi + n step)
+            put_composite<false, kTile>(g, otile_base, op, lane, wpos, n, fmaf_(cosp, hq[3][s], luma));
         }
     };
     int tb = 0;

@@ -1514,7 +1514,14 @@ int am_launch_demod(const cm_am_plan *p, Geom g, int64_t first_frame, hipStream_
     a.g = g;
     am_geom(p, first_frame, a.a);
     a.k = p->pd;
+#if CM_PROTO_PAIR
+    {
+        const int dly = ProtoDemod<float>::lat_chroma(p->pd) - ProtoDemod<float>::lat_luma(p->pd);
+        hipLaunchKernelGGL(proto_demod_pair_kernel, dim3((int)blocks), dim3(128), sizeof(float) * (size_t)proto_pair_lds_floats(dly), stream, a);
+    }
+#else
     hipLaunchKernelGGL(proto_demod_kernel, dim3((int)blocks), dim3(64), 0, stream, a);
+#endif
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(CM_ERR_LAUNCH, std::string("proto_demod_kernel launch: ") + hipGetErrorString(e));
     return CM_OK;
@@ -1540,8 +1547,18 @@ int am_launch_mod(const cm_am_plan *p, Geom g, int64_t first_frame, hipStream_t 
         am_geom(p, first_frame, a.a);
         a.k = p->pm;
         a.averaging = depth;
+#if CM_PROTO_MOD_PAIR
+        {
+            const int lat_y = ProtoMod<float>::lat_luma(p->pm), lat_c = ProtoMod<float>::lat_chroma(p->pm);
+            const int dly = lat_y > lat_c ? lat_y - lat_c : lat_c - lat_y;
+            const size_t lds = sizeof(float) * (size_t)proto_mod_pair_lds_floats(dly);
+            if (depth) hipLaunchKernelGGL(proto_mod_pair_kernel<1>, dim3((int)blocks), dim3(128), lds, stream, a);
+            else hipLaunchKernelGGL(proto_mod_pair_kernel<0>, dim3((int)blocks), dim3(128), lds, stream, a);
+        }
+#else
         if (depth) hipLaunchKernelGGL(proto_mod_kernel<1>, dim3((int)blocks), dim3(64), 0, stream, a);
         else hipLaunchKernelGGL(proto_mod_kernel<0>, dim3((int)blocks), dim3(64), 0, stream, a);
+#endif
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(CM_ERR_LAUNCH, std::string("cm_am modulator launch: ") + hipGetErrorString(e));
