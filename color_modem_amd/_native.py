@@ -25,6 +25,7 @@ SYMBOLS = ('cm_last_error', 'cm_abi_version', 'cm_device_count', 'cm_plan_create
            'cm_mac_modulate_run', 'cm_mac_demodulate_run',
            'cm_am_plan_create', 'cm_am_plan_destroy', 'cm_am_modulate_frames', 'cm_am_demodulate_frames',
            'cm_am_modulate_run', 'cm_am_demodulate_run', 'cm_am_modulate_frames_noise', 'cm_am_modulate_run_noise',
+           'cm_am_modulate_frames_u8', 'cm_am_demodulate_frames_u8',
            'cm_comb_wrap_demodulate_frames', 'cm_comb_wrap_demodulate_frames_u8', 'cm_comb_wrap_demodulate_run')
 
 _lib = None
@@ -92,6 +93,8 @@ def lib():
     L.cm_am_plan_destroy.restype = None
     L.cm_am_modulate_frames.argtypes = [vp, vp, vp, ctypes.c_int64, ctypes.c_int64, vp]
     L.cm_am_demodulate_frames.argtypes = [vp, vp, vp, ctypes.c_int64, ctypes.c_int64, vp]
+    L.cm_am_modulate_frames_u8.argtypes = [vp, vp, vp, ctypes.c_int64, ctypes.c_int64, vp]
+    L.cm_am_demodulate_frames_u8.argtypes = [vp, vp, vp, ctypes.c_int64, ctypes.c_int64, vp]
     L.cm_am_modulate_run.argtypes = [vp, vp, vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, vp]
     L.cm_am_demodulate_run.argtypes = [vp, vp, vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, vp]
     i32 = ctypes.c_int32

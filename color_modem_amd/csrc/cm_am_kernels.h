@@ -110,13 +110,55 @@ __global__ __launch_bounds__(64, 2) void proto_demod_kernel(const ProtoDemodArgs
 //                     delay (LDS ring), the other colour-difference signal from the neighbouring lane, matrix, output tile and
 //                     every global store
 // ---------------------------------------------------------------------------------------------------------------------
+// Input rows of the pair decoders.  float: tiles of 8 samples, two buffers, tile c in buffer c & 1 (fill_tile<8>).  U8: the
+// ImageModem byte boundary fused in (image.py:24-25, 62): composite bytes, tiles of 32 samples (fill_tile_u8), level-decoded
+// on the way out of the tile; the output tile then holds interleaved RGB bytes (put_rgb<true>, flush_tile_u8).
+template <bool U8> struct AmInTile { static constexpr int kIT = U8 ? kInTile : 8, kBufFloats = U8 ? 64 * kInTile / 4 : 64 * 8; };
+template <bool U8>
+__device__ __forceinline__ void am_fill(const Geom &g, lds_float *itile, const float *xp, int c, int lane) {
+    lds_float *buf = itile + (c & 1) * AmInTile<U8>::kBufFloats;
+    if (U8) fill_tile_u8(g, buf, xp, c, lane); else fill_tile<8>(g, buf, xp, c, lane);
+}
+template <bool U8>
+__device__ __forceinline__ f2 am_read2(const lds_float *itile, int lane, int first, int W) {
+    constexpr int IT = AmInTile<U8>::kIT;
+    const lds_float *buf = itile + ((first / IT) & 1) * AmInTile<U8>::kBufFloats;
+    f2 v;
+    if (U8) {
+        typedef __attribute__((address_space(3))) unsigned short lds_u16;
+        const unsigned w = *(const lds_u16 *)((const __attribute__((address_space(3))) unsigned char *)buf + lane * IT + (first & (IT - 1)));
+        const f4 d = decode_bytes(w);
+        v = f2{d.x, d.y};
+    } else {
+        typedef __attribute__((address_space(3))) f2 lds_f2_;
+        v = *(const lds_f2_ *)(buf + lane * IT + (first & (IT - 1)));
+    }
+    if (first >= W) v.x = 0.f;
+    if (first + 1 >= W) v.y = 0.f;
+    return v;
+}
+template <bool U8>
+__device__ __forceinline__ const float *am_in_row(const Geom &g, const LaneCall &lc) {
+    if (U8) return (const float *)((const unsigned char *)g.in + lc.frame * g.in_frame_stride + (long long)lc.src_row * g.W);
+    return g.in + lc.frame * g.in_frame_stride + (long long)lc.src_row * g.Wp;
+}
+template <bool U8>
+__device__ __forceinline__ const float *am_out_row(const Geom &g, const LaneCall &lc) {
+    if (!lc.store_ok) return nullptr;
+    if (U8) return (const float *)((unsigned char *)g.out + lc.frame * g.out_frame_stride + (long long)lc.out_row * g.out_row_stride);
+    return g.out + lc.frame * g.out_frame_stride + (long long)lc.out_row * g.out_row_stride;
+}
 constexpr int kProtoIT = 8;
 inline __host__ __device__ int proto_ring_slots(int dly) { return dly < 8 ? 8 : (dly < 16 ? 16 : 32); }
 // floats of dynamic LDS: input tile (two buffers) | hand-over (2 buffers x 6 quantities) | luma delay ring | output tile
-inline int proto_pair_lds_floats(int dly) { return 2 * 64 * kProtoIT + 2 * 6 * 128 + proto_ring_slots(dly) * 64 + 3 * 64 * 16; }
+template <bool U8> inline int proto_pair_lds_floats(int dly) {
+    return 2 * AmInTile<U8>::kBufFloats + 2 * 6 * 128 + proto_ring_slots(dly) * 64 + (U8 ? 64 * 3 * 16 / 4 : 3 * 64 * 16);
+}
 
+template <bool U8>
 __global__ __launch_bounds__(128, 2) void proto_demod_pair_kernel(const ProtoDemodArgs args) {
     constexpr int kTile = 16, DEPTH = 1, Q = 6;
+    constexpr int kIT = AmInTile<U8>::kIT;
     extern __shared__ __attribute__((aligned(16))) float proto_pair_lds[];
     typedef __attribute__((address_space(3))) f2 lds_f2;
     lds_float *lds = (lds_float *)proto_pair_lds;
@@ -130,8 +172,8 @@ __global__ __launch_bounds__(128, 2) void proto_demod_pair_kernel(const ProtoDem
     const int dly = lat_c - lat_y;                       // luma waits for the chroma path
     const int nring = proto_ring_slots(dly);
     const int T = (g.Wp + lat_c + 1) & ~1;
-    lds_float *itile = lds;                              // two buffers of [64][kProtoIT]: tile c lives in buffer c & 1
-    lds_float *hand = itile + 2 * 64 * kProtoIT;
+    lds_float *itile = lds;                              // two buffers: tile c lives in buffer c & 1
+    lds_float *hand = itile + 2 * AmInTile<U8>::kBufFloats;
     lds_float *ring = hand + 2 * Q * 128;
     lds_float *otile_base = ring + nring * 64;
     // interior bodies (as in proto_demod_kernel): t >= lat_c, t + 1 < W - 6
@@ -142,20 +184,15 @@ __global__ __launch_bounds__(128, 2) void proto_demod_pair_kernel(const ProtoDem
         // =================================== stage A ===========================================
         ProtoDemodK<float> ka = k;
         pin_taps3(ka.taps);
-        const float *xp = g.in + lc.frame * g.in_frame_stride + (long long)lc.src_row * g.Wp;
+        const float *xp = am_in_row<U8>(g, lc);
         Up3<float> up;
         FF3<float, 3> ext, rem;
         up.reset(); ext.reset(); rem.reset();
-        fill_tile<kProtoIT>(g, itile, xp, 0, lane);
+        am_fill<U8>(g, itile, xp, 0, lane);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_wave_barrier();
-        if (kProtoIT < W) fill_tile<kProtoIT>(g, itile + 64 * kProtoIT, xp, 1, lane);      // tile c + 1 is asked for when tile c is first read
-        auto read_x = [&](int first) -> f2 {
-            f2 v = *(const lds_f2 *)(itile + ((first / kProtoIT) & 1) * (64 * kProtoIT) + lane * kProtoIT + (first & (kProtoIT - 1)));
-            if (first >= W) v.x = 0.f;
-            if (first + 1 >= W) v.y = 0.f;
-            return v;
-        };
+        if (kIT < W) am_fill<U8>(g, itile, xp, 1, lane);      // tile c + 1 is asked for when tile c is first read
+        auto read_x = [&](int first) -> f2 { return am_read2<U8>(itile, lane, first, W); };
         f2 xv = read_x(0);
         auto body = [&](auto edge_tag, int tb) __attribute__((always_inline)) {
             constexpr bool EDGE = decltype(edge_tag)::value;
@@ -177,11 +214,11 @@ __global__ __launch_bounds__(128, 2) void proto_demod_pair_kernel(const ProtoDem
 #pragma unroll
             for (int q = 0; q < Q; ++q) *(lds_f2 *)(slot + q * 128) = f2{hq[q][0], hq[q][1]};
             const int nxt = tb + 2;
-            if ((nxt & (kProtoIT - 1)) == 0 && nxt < W) {
+            if ((nxt & (kIT - 1)) == 0 && nxt < W) {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __builtin_amdgcn_wave_barrier();
-                const int c = nxt / kProtoIT;
-                if ((c + 1) * kProtoIT < W) fill_tile<kProtoIT>(g, itile + ((c + 1) & 1) * (64 * kProtoIT), xp, c + 1, lane);
+                const int c = nxt / kIT;
+                if ((c + 1) * kIT < W) am_fill<U8>(g, itile, xp, c + 1, lane);
             }
             xv = read_x(nxt);
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -195,7 +232,7 @@ __global__ __launch_bounds__(128, 2) void proto_demod_pair_kernel(const ProtoDem
     }
 
     // ======================================= stage B ===========================================
-    const float *op = lc.store_ok ? g.out + lc.frame * g.out_frame_stride + (long long)lc.out_row * g.out_row_stride : nullptr;
+    const float *op = am_out_row<U8>(g, lc);
     const long long frame = (long long)args.a.frame_base + lc.frame;
     const bool alt = args.a.line.alternate(frame, lc.line);
     const float w_prev = lc.kk > 0 ? 1.f : 0.f;          // protosecam.py:93-94: the first line of a run has no previous chroma
@@ -207,7 +244,7 @@ __global__ __launch_bounds__(128, 2) void proto_demod_pair_kernel(const ProtoDem
     post.reset();
     dn.reset();
     for (int j = 0; j < nring; ++j) ring[j * 64 + lane] = 0.f;
-    lds_float *otile = otile_base + lane * kTile;
+    lds_float *otile = U8 ? (lds_float *)((__attribute__((address_space(3))) unsigned char *)otile_base + lane * 3 * kTile) : otile_base + lane * kTile;
     const int wpos = ((lane >> CM_TILE_SWZ) & (kTile / 4 - 1)) << 2;
     auto body = [&](auto edge_tag, int tb) __attribute__((always_inline)) {
         constexpr bool EDGE = decltype(edge_tag)::value;
@@ -233,8 +270,10 @@ __global__ __launch_bounds__(128, 2) void proto_demod_pair_kernel(const ProtoDem
             o.g = fmaf_(k.m[1][0], luma_d, fmaf_(k.m[1][1], dr, k.m[1][2] * db));
             o.b = fmaf_(k.m[2][0], luma_d, fmaf_(k.m[2][1], dr, k.m[2][2] * db));
             const int n = t - lat_c;
-            if (!EDGE || (n >= 0 && n < W)) put_rgb<false, kTile>(otile, wpos, n, o);
-            if (n >= 0 && ((n & (kTile - 1)) == kTile - 1 || n == g.Wp - 1)) flush_tile<kTile>(g, otile_base, op, n & ~(kTile - 1), lane);
+            if (!EDGE || (n >= 0 && n < W)) put_rgb<U8, kTile>(otile, wpos, n, o);
+            if (n >= 0 && ((n & (kTile - 1)) == kTile - 1 || n == g.Wp - 1)) {
+                if (U8) flush_tile_u8(g, otile_base, op, n & ~(kTile - 1), lane); else flush_tile<kTile>(g, otile_base, op, n & ~(kTile - 1), lane);
+            }
         }
     };
     int tb = 0;
@@ -348,9 +387,12 @@ __global__ __launch_bounds__(64, 2) void proto_mod_kernel(const ProtoModArgs arg
 #ifndef CM_PROTO_MOD_PAIR
 #define CM_PROTO_MOD_PAIR 1
 #endif
-inline int proto_mod_pair_lds_floats(int dly) { return kLdsIn3 + proto_ring_slots(dly) * 64 + 2 * 5 * 256 + 64 * 16; }
+template <bool U8> inline int proto_mod_pair_lds_floats(int dly) {
+    return (U8 ? kInTile3Bytes / 4 : kLdsIn3) + proto_ring_slots(dly) * 64 + 2 * 5 * 256 + (U8 ? 64 * kOutTileU8 / 4 : 64 * 16);
+}
 
-template <int DEPTH>
+// U8: the ImageModem byte boundary fused in (image.py:27-56): interleaved RGB bytes in, composite bytes out (as the QAM encoders)
+template <int DEPTH, bool U8 = false>
 __global__ __launch_bounds__(128, 2) void proto_mod_pair_kernel(const ProtoModArgs args) {
     constexpr int kTile = 16, Q = 5;
     extern __shared__ __attribute__((aligned(16))) float proto_mod_lds[];
@@ -368,14 +410,14 @@ __global__ __launch_bounds__(128, 2) void proto_mod_pair_kernel(const ProtoModAr
     const int nring = proto_ring_slots(dly);
     const int T = (g.Wp + lat + 3) & ~3;
     lds_float *itile = lds;
-    lds_float *ring = itile + kLdsIn3;
+    lds_float *ring = itile + (U8 ? kInTile3Bytes / 4 : kLdsIn3);
     lds_float *hand = ring + nring * 64;
     lds_float *otile_base = hand + 2 * Q * 256;
     // interior bodies: t >= lat + 4 (both paths behind their delays), t + 3 < W - 4
     int t_mid0 = (lat + 4 + 3) & ~3, t_mid1 = (W - 8) & ~3;
     if (t_mid1 <= t_mid0) t_mid0 = t_mid1 = 0;
     const float *rp, *op;
-    mod_rows<false>(g, lc, rp, op);
+    mod_rows<U8>(g, lc, rp, op);
 
     if (role == 0) {
         // =================================== stage A ===========================================
@@ -392,11 +434,11 @@ __global__ __launch_bounds__(128, 2) void proto_mod_pair_kernel(const ProtoModAr
         up.reset();
         for (int j = 0; j < nring; ++j) ring[j * 64 + lane] = 0.f;
         f4 cur[3], nxt[3];
-        first_tile3<false>(g, itile, rp, lane, nxt);
+        first_tile3<U8>(g, itile, rp, lane, nxt);
         auto body = [&](auto edge_tag, int tb) __attribute__((always_inline)) {
             constexpr bool EDGE = decltype(edge_tag)::value;
             cur[0] = nxt[0]; cur[1] = nxt[1]; cur[2] = nxt[2];
-            next_tile3x<false>(g, itile, rp, lane, tb + 4, nxt);
+            next_tile3x<U8>(g, itile, rp, lane, tb + 4, nxt);
             float hq[Q][4];
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
@@ -477,7 +519,7 @@ __global__ __launch_bounds__(128, 2) void proto_mod_pair_kernel(const ProtoModAr
             if (EDGE) nc = n < 0 ? 0 : (n > W - 1 ? W - 1 : n);
             const f2 cs = ((const_f2 *)args.a.carrier)[nc];
             const float cosp = fmaf_(cph, cs.x, -(sph * cs.y));      // cos(phi + n step)
-            put_composite<false, kTile>(g, otile_base, op, lane, wpos, n, fmaf_(cosp, hq[3][s], luma));
+            put_composite<U8, kTile>(g, otile_base, op, lane, wpos, n, fmaf_(cosp, hq[3][s], luma));
         }
     };
     int tb = 0;
@@ -624,15 +666,16 @@ constexpr int kNiirHandQ = 4, kNiirHandQFirst = 7;          // hand-over quantit
 // floats of dynamic LDS: input tile (two buffers) | M delay ring (x 2 with the reference) | hand-over (2 buffers) | luma source ring | output tile
 // slots of the M delay ring: the power of two that holds q_l + 1 triples (q_l = 3 at 13.5 MHz: 4 slots, 3 KiB)
 inline __host__ __device__ int niir_mring_slots(int q_l) { return q_l < 2 ? 2 : (q_l < 4 ? 4 : 8); }
-inline int niir_pair_lds_floats(int lat, int q_l, bool first) {
+template <bool U8> inline int niir_pair_lds_floats(int lat, int q_l, bool first) {
     const int hb = (lat + 1) >> 1;
-    return 2 * 64 * kNiirIT + (first ? 2 : 1) * niir_mring_slots(q_l) * 3 * 64 + 2 * (first ? kNiirHandQFirst : kNiirHandQ) * 128 + (hb + 3) * 128 +
-           3 * 64 * 16;
+    return 2 * AmInTile<U8>::kBufFloats + (first ? 2 : 1) * niir_mring_slots(q_l) * 3 * 64 + 2 * (first ? kNiirHandQFirst : kNiirHandQ) * 128 +
+           (hb + 3) * 128 + (U8 ? 64 * 3 * 16 / 4 : 3 * 64 * 16);
 }
 
-template <bool FIRST>
+template <bool FIRST, bool U8>
 __device__ __forceinline__ void niir_pair_body(const NiirDemodArgs &args, const Geom &g, int block, lds_float *lds, int role) {
     constexpr int kTile = 16, DEPTH = 1, Q = FIRST ? kNiirHandQFirst : kNiirHandQ;
+    constexpr int kIT = AmInTile<U8>::kIT;
     typedef __attribute__((address_space(3))) f2 lds_f2;
     const NiirDemodK<float> &k = args.k;
     const int lane = threadIdx.x & 63;
@@ -642,8 +685,8 @@ __device__ __forceinline__ void niir_pair_body(const NiirDemodArgs &args, const 
     const int lat = 2 * kAmHalf + 1 + k.gb.q + q_l;
     const int T = (g.Wp + lat + 1) & ~1;
     const int hb = (lat + 1) >> 1, NB = hb + 3;            // luma source ring: blocks of 2 samples, hb bodies of delay
-    lds_float *itile = lds;                                 // two buffers of [64][kNiirIT]: tile c lives in buffer c & 1
-    lds_float *mring = itile + 2 * 64 * kNiirIT;
+    lds_float *itile = lds;                                 // two buffers: tile c lives in buffer c & 1
+    lds_float *mring = itile + 2 * AmInTile<U8>::kBufFloats;
     const int nring = niir_mring_slots(q_l);
     lds_float *hand = mring + (FIRST ? 2 : 1) * nring * 3 * 64;
     lds_float *xring = hand + 2 * Q * 128;
@@ -657,7 +700,7 @@ __device__ __forceinline__ void niir_pair_body(const NiirDemodArgs &args, const 
         // =================================== stage A ===========================================
         NiirDemodK<float> ka = k;
         pin_taps3(ka.taps);
-        const float *xp = g.in + lc.frame * g.in_frame_stride + (long long)lc.src_row * g.Wp;
+        const float *xp = am_in_row<U8>(g, lc);
         float syn_s = 0.f, syn_c = 0.f;       // +-(sin, cos) of the start phase of line - 2
         if (FIRST) {
             const double phi = args.a.line.start_phase(frame, lc.line - 2);
@@ -675,16 +718,11 @@ __device__ __forceinline__ void niir_pair_body(const NiirDemodArgs &args, const 
         lds_float *ring_syn = mring + nring * 3 * 64;
         for (int j = 0; j < (FIRST ? 2 : 1) * nring * 3; ++j) mring[j * 64 + lane] = 0.f;
         for (int j = 0; j < NB; ++j) *(lds_f2 *)(xring + j * 128 + lane * 2) = f2{0.f, 0.f};
-        fill_tile<kNiirIT>(g, itile, xp, 0, lane);
+        am_fill<U8>(g, itile, xp, 0, lane);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_wave_barrier();
-        if (kNiirIT < W) fill_tile<kNiirIT>(g, itile + 64 * kNiirIT, xp, 1, lane);      // tile c + 1 is asked for when tile c is first read
-        auto read_x = [&](int first) -> f2 {
-            f2 v = *(const lds_f2 *)(itile + ((first / kNiirIT) & 1) * (64 * kNiirIT) + lane * kNiirIT + (first & (kNiirIT - 1)));
-            if (first >= W) v.x = 0.f;
-            if (first + 1 >= W) v.y = 0.f;
-            return v;
-        };
+        if (kIT < W) am_fill<U8>(g, itile, xp, 1, lane);      // tile c + 1 is asked for when tile c is first read
+        auto read_x = [&](int first) -> f2 { return am_read2<U8>(itile, lane, first, W); };
         f2 xv = read_x(0);
         int wx = 0;
         auto body = [&](auto edge_tag, int tb) __attribute__((always_inline)) {
@@ -727,13 +765,13 @@ __device__ __forceinline__ void niir_pair_body(const NiirDemodArgs &args, const 
             *(lds_f2 *)(xring + wx * 128 + lane * 2) = xv;
             wx = wx + 1 == NB ? 0 : wx + 1;
             const int nxt = tb + 2;
-            if ((nxt & (kNiirIT - 1)) == 0 && nxt < W) {
-                // first read of tile c = nxt / 8: its fill was issued a tile (four bodies) ago; the other buffer was last read a
-                // body ago (lgkmcnt(0) at the barrier below) and takes tile c + 1 now
+            if ((nxt & (kIT - 1)) == 0 && nxt < W) {
+                // first read of tile c = nxt / kIT: its fill was issued a tile ago; the other buffer was last read a body ago
+                // (lgkmcnt(0) at the barrier below) and takes tile c + 1 now
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __builtin_amdgcn_wave_barrier();
-                const int c = nxt / kNiirIT;
-                if ((c + 1) * kNiirIT < W) fill_tile<kNiirIT>(g, itile + ((c + 1) & 1) * (64 * kNiirIT), xp, c + 1, lane);
+                const int c = nxt / kIT;
+                if ((c + 1) * kIT < W) am_fill<U8>(g, itile, xp, c + 1, lane);
             }
             xv = read_x(nxt);
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -747,7 +785,7 @@ __device__ __forceinline__ void niir_pair_body(const NiirDemodArgs &args, const 
     }
 
     // ======================================= stage B ===========================================
-    const float *op = lc.store_ok ? g.out + lc.frame * g.out_frame_stride + (long long)lc.out_row * g.out_row_stride : nullptr;
+    const float *op = am_out_row<U8>(g, lc);
     NiirLineK<float> lk;
     {   // niir.py:117-124, 148-157
         lk.alt = args.a.line.alternate(frame, lc.line);
@@ -763,7 +801,7 @@ __device__ __forceinline__ void niir_pair_body(const NiirDemodArgs &args, const 
     const int idx1 = ((lane + 63) & 63) * 4;
     NiirBackPk back;
     back.reset();
-    lds_float *otile = otile_base + lane * kTile;
+    lds_float *otile = U8 ? (lds_float *)((__attribute__((address_space(3))) unsigned char *)otile_base + lane * 3 * kTile) : otile_base + lane * kTile;
     const int wpos = ((lane >> CM_TILE_SWZ) & (kTile / 4 - 1)) << 2;
     const bool strip = args.strip != 0;
     const bool odd = (lat & 1) != 0;
@@ -790,8 +828,10 @@ __device__ __forceinline__ void niir_pair_body(const NiirDemodArgs &args, const 
             for (int j = 0; j < 3; ++j) pv[j] = FIRST ? hq[FIRST ? 4 + j : 0][s] : lane_from(idx1, p[j]);
             const NiirOut<float> o = back.template step<EDGE>(k, kp, n3, p, pv, hq[3][s], lk.alt);
             const int n = t - lat;
-            if (!EDGE || (n >= 0 && n < W)) put_rgb<false, kTile>(otile, wpos, n, niir_finish(k, lk, o, cd[s], strip));
-            if (n >= 0 && ((n & (kTile - 1)) == kTile - 1 || n == g.Wp - 1)) flush_tile<kTile>(g, otile_base, op, n & ~(kTile - 1), lane);
+            if (!EDGE || (n >= 0 && n < W)) put_rgb<U8, kTile>(otile, wpos, n, niir_finish(k, lk, o, cd[s], strip));
+            if (n >= 0 && ((n & (kTile - 1)) == kTile - 1 || n == g.Wp - 1)) {
+                if (U8) flush_tile_u8(g, otile_base, op, n & ~(kTile - 1), lane); else flush_tile<kTile>(g, otile_base, op, n & ~(kTile - 1), lane);
+            }
         }
     };
     int tb = 0;
@@ -800,12 +840,13 @@ __device__ __forceinline__ void niir_pair_body(const NiirDemodArgs &args, const 
     for (; tb < T; tb += 2) body(std::true_type(), tb);
 }
 
+template <bool U8>
 __global__ __launch_bounds__(128, 2) void niir_demod_pair_kernel(const NiirPairArgs args) {
     extern __shared__ __attribute__((aligned(16))) float niir_pair_lds[];
     lds_float *lds = (lds_float *)niir_pair_lds;
     const int role = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
-    if ((int)blockIdx.x < args.n_first) niir_pair_body<true>(args.m, args.gf, blockIdx.x, lds, role);
-    else niir_pair_body<false>(args.m, args.m.g, (int)blockIdx.x - args.n_first, lds, role);
+    if ((int)blockIdx.x < args.n_first) niir_pair_body<true, U8>(args.m, args.gf, blockIdx.x, lds, role);
+    else niir_pair_body<false, U8>(args.m, args.m.g, (int)blockIdx.x - args.n_first, lds, role);
 }
 
 struct NiirModArgs {
@@ -816,19 +857,23 @@ struct NiirModArgs {
 };
 
 // DEPTH = 1: HueCorrectingNiirModem (niir.py:181-202): a call modulates line - 2 with the previous call's luma, the
-// saturation-weighted mean hue of both calls and the previous call's saturation (previous call = neighbouring lane)
-template <int DEPTH>
+// saturation-weighted mean hue of both calls and the previous call's saturation (previous call = neighbouring lane).
+// The three input planes arrive through 16-sample LDS tiles (global_load_lds, as the QAM encoders; round 2 read them with one
+// 16-byte load per lane and plane).  U8: the ImageModem byte boundary fused in (interleaved RGB bytes in, composite bytes out).
+template <int DEPTH, bool U8 = false>
 __global__ __launch_bounds__(64, 2) void niir_mod_kernel(const NiirModArgs args) {
     constexpr int kTile = 16;
-    __shared__ __attribute__((aligned(16))) float lds_store[64 * kTile + kAmRingFloats];
-    lds_float *otile_base = (lds_float *)lds_store;
-    lds_float *ring = otile_base + 64 * kTile;
+    constexpr int kIn = U8 ? kInTile3Bytes / 4 : kLdsIn3, kOut = U8 ? 64 * kOutTileU8 / 4 : 64 * kTile;
+    __shared__ __attribute__((aligned(16))) float lds_store[kIn + kOut + kAmRingFloats];
+    lds_float *itile = (lds_float *)lds_store;
+    lds_float *otile_base = itile + kIn;
+    lds_float *ring = otile_base + kOut;
     const Geom &g = args.g;
     const NiirModK<float> &k = args.k;
     const int lane = threadIdx.x;
     const LaneCall lc = locate_call(g, blockIdx.x, DEPTH, lane);
     const float *rp, *op;
-    mod_rows<false>(g, lc, rp, op);
+    mod_rows<U8>(g, lc, rp, op);
     const long long frame = (long long)args.a.frame_base + lc.frame;
     const int line = DEPTH ? lc.line - 2 : lc.line;       // the line that is modulated (niir.py:202)
     const bool alt = args.a.line.alternate(frame, line);
@@ -848,14 +893,10 @@ __global__ __launch_bounds__(64, 2) void niir_mod_kernel(const NiirModArgs args)
     for (int j = 0; j < kAmRing; ++j) ring[j * 64 + lane] = 0.f;
     const float *np = args.noise ? args.noise + 2LL * lc.call * W : nullptr;
     f4 cur[3], nxt[3], nz[2] = {f4{0.f, 0.f, 0.f, 0.f}, f4{0.f, 0.f, 0.f, 0.f}};
-#pragma unroll
-    for (int p = 0; p < 3; ++p) nxt[p] = load_luma<false>(rp + p * g.in_plane_stride, 0, true, W);
+    first_tile3<U8>(g, itile, rp, lane, nxt);
     for (int tb = 0; tb < T; tb += 4) {
-#pragma unroll
-        for (int p = 0; p < 3; ++p) {
-            cur[p] = nxt[p];
-            nxt[p] = load_luma<false>(rp + p * g.in_plane_stride, tb + 4, true, W);
-        }
+        cur[0] = nxt[0]; cur[1] = nxt[1]; cur[2] = nxt[2];
+        next_tile3x<U8>(g, itile, rp, lane, tb + 4, nxt);
         if (np) {
             nz[0] = load_luma<false>(np, tb, true, W);
             nz[1] = load_luma<false>(np + W, tb, true, W);
@@ -888,7 +929,7 @@ __global__ __launch_bounds__(64, 2) void niir_mod_kernel(const NiirModArgs args)
             const f2 cs = ((const_f2 *)args.a.carrier)[nc];
             const float sn = fmaf_(sph, cs.x, cph * cs.y), cn = fmaf_(cph, cs.x, -(sph * cs.y));
             const float c = st.step(k, t, db, dr, alt, sn, cn);
-            put_composite<false, kTile>(g, otile_base, op, lane, wpos, n, y_d + c);
+            put_composite<U8, kTile>(g, otile_base, op, lane, wpos, n, y_d + c);
         }
     }
 }

@@ -1454,7 +1454,7 @@ void am_frames_geom(Geom &g, int W, int wp, int H, int D, int64_t n_frames) {
     g.total_calls = n_frames * g.calls_per_frame;
 }
 // NIIR: the main pass over every call plus the sparse pass over the calls that open a run (k0 == 0 in rows mode)
-int niir_launch_demod(const cm_am_plan *p, Geom g, int64_t first_frame, hipStream_t stream, bool strip) {
+int niir_launch_demod(const cm_am_plan *p, Geom g, int64_t first_frame, hipStream_t stream, bool strip, bool u8 = false) {
     NiirDemodArgs a;
     am_geom(p, first_frame, a.a);
     a.k = p->nd;
@@ -1482,10 +1482,16 @@ int niir_launch_demod(const cm_am_plan *p, Geom g, int64_t first_frame, hipStrea
         }
         if (blocks + pa.n_first <= 0) return CM_OK;
         const int lat = 2 * kAmHalf + 1 + p->nd.gb.q + p->nd.gl.q;
-        const size_t lds = sizeof(float) * (size_t)niir_pair_lds_floats(lat, p->nd.gl.q, pa.n_first > 0);
-        hipLaunchKernelGGL(niir_demod_pair_kernel, dim3((int)blocks + pa.n_first), dim3(128), lds, stream, pa);
+        if (u8) {
+            const size_t lds = sizeof(float) * (size_t)niir_pair_lds_floats<true>(lat, p->nd.gl.q, pa.n_first > 0);
+            hipLaunchKernelGGL(niir_demod_pair_kernel<true>, dim3((int)blocks + pa.n_first), dim3(128), lds, stream, pa);
+        } else {
+            const size_t lds = sizeof(float) * (size_t)niir_pair_lds_floats<false>(lat, p->nd.gl.q, pa.n_first > 0);
+            hipLaunchKernelGGL(niir_demod_pair_kernel<false>, dim3((int)blocks + pa.n_first), dim3(128), lds, stream, pa);
+        }
     }
 #else
+    if (u8) return fail(CM_ERR_UNSUPPORTED, "the fused uint8 boundary of the NIIR decoder lives in the wave-pair kernel");
     if (blocks > 0) {
         a.g = g;
         hipLaunchKernelGGL(niir_demod_kernel<false>, dim3((int)blocks), dim3(64), 0, stream, a);
@@ -1504,9 +1510,9 @@ int niir_launch_demod(const cm_am_plan *p, Geom g, int64_t first_frame, hipStrea
     if (e != hipSuccess) return fail(CM_ERR_LAUNCH, std::string("niir_demod_kernel launch: ") + hipGetErrorString(e));
     return CM_OK;
 }
-int am_launch_demod(const cm_am_plan *p, Geom g, int64_t first_frame, hipStream_t stream) {
+int am_launch_demod(const cm_am_plan *p, Geom g, int64_t first_frame, hipStream_t stream, bool u8 = false) {
     if (!p->demod_error.empty()) return fail(CM_ERR_UNSUPPORTED, p->demod_error);
-    if (p->desc.kind == CM_AM_NIIR) return niir_launch_demod(p, g, first_frame, stream, p->desc.strip_chroma != 0);
+    if (p->desc.kind == CM_AM_NIIR) return niir_launch_demod(p, g, first_frame, stream, p->desc.strip_chroma != 0, u8);
     long long blocks = (g.total_calls + 62) / 63;
     if (blocks <= 0) return CM_OK;
     if (blocks > 0x7fffffffLL) return fail(CM_ERR_INVALID, "batch too large for one launch");
@@ -1517,16 +1523,18 @@ int am_launch_demod(const cm_am_plan *p, Geom g, int64_t first_frame, hipStream_
 #if CM_PROTO_PAIR
     {
         const int dly = ProtoDemod<float>::lat_chroma(p->pd) - ProtoDemod<float>::lat_luma(p->pd);
-        hipLaunchKernelGGL(proto_demod_pair_kernel, dim3((int)blocks), dim3(128), sizeof(float) * (size_t)proto_pair_lds_floats(dly), stream, a);
+        if (u8) hipLaunchKernelGGL(proto_demod_pair_kernel<true>, dim3((int)blocks), dim3(128), sizeof(float) * (size_t)proto_pair_lds_floats<true>(dly), stream, a);
+        else hipLaunchKernelGGL(proto_demod_pair_kernel<false>, dim3((int)blocks), dim3(128), sizeof(float) * (size_t)proto_pair_lds_floats<false>(dly), stream, a);
     }
 #else
+    if (u8) return fail(CM_ERR_UNSUPPORTED, "the fused uint8 boundary of the Proto-SECAM decoder lives in the wave-pair kernel");
     hipLaunchKernelGGL(proto_demod_kernel, dim3((int)blocks), dim3(64), 0, stream, a);
 #endif
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(CM_ERR_LAUNCH, std::string("proto_demod_kernel launch: ") + hipGetErrorString(e));
     return CM_OK;
 }
-int am_launch_mod(const cm_am_plan *p, Geom g, int64_t first_frame, hipStream_t stream, const float *noise = nullptr) {
+int am_launch_mod(const cm_am_plan *p, Geom g, int64_t first_frame, hipStream_t stream, const float *noise = nullptr, bool u8 = false) {
     if (!p->mod_error.empty()) return fail(CM_ERR_UNSUPPORTED, p->mod_error);
     const int depth = p->desc.averaging ? 1 : 0;
     long long blocks = (g.total_calls + (64 - depth) - 1) / (64 - depth);
@@ -1538,8 +1546,11 @@ int am_launch_mod(const cm_am_plan *p, Geom g, int64_t first_frame, hipStream_t 
         am_geom(p, first_frame, a.a);
         a.k = p->nm;
         a.noise = noise;
-        if (depth) hipLaunchKernelGGL(niir_mod_kernel<1>, dim3((int)blocks), dim3(64), 0, stream, a);
-        else hipLaunchKernelGGL(niir_mod_kernel<0>, dim3((int)blocks), dim3(64), 0, stream, a);
+        if (u8) {
+            if (depth) hipLaunchKernelGGL((niir_mod_kernel<1, true>), dim3((int)blocks), dim3(64), 0, stream, a);
+            else hipLaunchKernelGGL((niir_mod_kernel<0, true>), dim3((int)blocks), dim3(64), 0, stream, a);
+        } else if (depth) hipLaunchKernelGGL((niir_mod_kernel<1, false>), dim3((int)blocks), dim3(64), 0, stream, a);
+        else hipLaunchKernelGGL((niir_mod_kernel<0, false>), dim3((int)blocks), dim3(64), 0, stream, a);
     } else {
         if (noise) return fail(CM_ERR_INVALID, "noise planes are a NIIR encoder input (niir.py:45-46)");
         ProtoModArgs a;
@@ -1551,11 +1562,18 @@ int am_launch_mod(const cm_am_plan *p, Geom g, int64_t first_frame, hipStream_t 
         {
             const int lat_y = ProtoMod<float>::lat_luma(p->pm), lat_c = ProtoMod<float>::lat_chroma(p->pm);
             const int dly = lat_y > lat_c ? lat_y - lat_c : lat_c - lat_y;
-            const size_t lds = sizeof(float) * (size_t)proto_mod_pair_lds_floats(dly);
-            if (depth) hipLaunchKernelGGL(proto_mod_pair_kernel<1>, dim3((int)blocks), dim3(128), lds, stream, a);
-            else hipLaunchKernelGGL(proto_mod_pair_kernel<0>, dim3((int)blocks), dim3(128), lds, stream, a);
+            if (u8) {
+                const size_t lds = sizeof(float) * (size_t)proto_mod_pair_lds_floats<true>(dly);
+                if (depth) hipLaunchKernelGGL((proto_mod_pair_kernel<1, true>), dim3((int)blocks), dim3(128), lds, stream, a);
+                else hipLaunchKernelGGL((proto_mod_pair_kernel<0, true>), dim3((int)blocks), dim3(128), lds, stream, a);
+            } else {
+                const size_t lds = sizeof(float) * (size_t)proto_mod_pair_lds_floats<false>(dly);
+                if (depth) hipLaunchKernelGGL((proto_mod_pair_kernel<1, false>), dim3((int)blocks), dim3(128), lds, stream, a);
+                else hipLaunchKernelGGL((proto_mod_pair_kernel<0, false>), dim3((int)blocks), dim3(128), lds, stream, a);
+            }
         }
 #else
+        if (u8) return fail(CM_ERR_UNSUPPORTED, "the fused uint8 boundary of the Proto-SECAM encoder lives in the wave-pair kernel");
         if (depth) hipLaunchKernelGGL(proto_mod_kernel<1>, dim3((int)blocks), dim3(64), 0, stream, a);
         else hipLaunchKernelGGL(proto_mod_kernel<0>, dim3((int)blocks), dim3(64), 0, stream, a);
 #endif
@@ -1673,6 +1691,46 @@ int cm_am_modulate_frames_noise(const cm_am_plan *p, const float *rgb, const flo
     if (p && n_frames == 0) return CM_OK;
     if (!noise) return fail(CM_ERR_INVALID, "null argument");
     return am_modulate_frames_core(p, rgb, noise, composite, n_frames, first_frame, stream);
+}
+// the ImageModem byte boundary fused into the kernels (image.py:27-56, 58-84), as cm_demodulate_frames_u8 / cm_modulate_frames_u8
+int cm_am_demodulate_frames_u8(const cm_am_plan *p, const uint8_t *composite8, uint8_t *rgb8, int64_t n_frames, int64_t first_frame, void *stream) {
+    if (p && n_frames == 0) return CM_OK;
+    if (!p || !composite8 || !rgb8) return fail(CM_ERR_INVALID, "null argument");
+    if (n_frames < 0 || first_frame < 0) return fail(CM_ERR_INVALID, "negative frame count / number");
+    if (int rc_ = check_device(p->device, composite8, rgb8)) return rc_;
+    const int W = p->desc.width, H = p->desc.height;
+    if (W % 4 != 0) return fail(CM_ERR_UNSUPPORTED, "the fused uint8 boundary needs a width that is a multiple of 4");
+    Geom g;
+    std::memset(&g, 0, sizeof g);
+    g.in = reinterpret_cast<const float *>(composite8);     // strides below count bytes
+    g.out = reinterpret_cast<float *>(rgb8);
+    am_frames_geom(g, W, W, H, 0, n_frames);
+    g.in_frame_stride = (long long)W * H;
+    g.in_row_stride = W;
+    g.out_plane_stride = 0;
+    g.out_frame_stride = 3LL * W * H;
+    g.out_row_stride = 3LL * W;
+    return am_launch_demod(p, g, first_frame, (hipStream_t)stream, true);
+}
+int cm_am_modulate_frames_u8(const cm_am_plan *p, const uint8_t *rgb8, uint8_t *composite8, int64_t n_frames, int64_t first_frame, void *stream) {
+    if (p && n_frames == 0) return CM_OK;
+    if (!p || !rgb8 || !composite8) return fail(CM_ERR_INVALID, "null argument");
+    if (n_frames < 0 || first_frame < 0) return fail(CM_ERR_INVALID, "negative frame count / number");
+    if (int rc_ = check_device(p->device, rgb8, composite8)) return rc_;
+    const int W = p->desc.width, H = p->desc.height, D = p->desc.averaging ? 1 : 0;
+    if (W % 16 != 0) return fail(CM_ERR_UNSUPPORTED, "the fused uint8 boundary of the encoders needs a width that is a multiple of 16");
+    if (H < 2 * D) return fail(CM_ERR_INVALID, "the image has too few rows for the modulation delay");
+    Geom g;
+    std::memset(&g, 0, sizeof g);
+    g.in = reinterpret_cast<const float *>(rgb8);            // strides below count bytes
+    g.out = reinterpret_cast<float *>(composite8);
+    am_frames_geom(g, W, W, H, D, n_frames);
+    g.in_frame_stride = 3LL * W * H;
+    g.in_plane_stride = 0;
+    g.in_row_stride = 3LL * W;
+    g.out_frame_stride = (long long)W * H;
+    g.out_row_stride = W;
+    return am_launch_mod(p, g, first_frame, (hipStream_t)stream, nullptr, true);
 }
 int cm_am_demodulate_run(const cm_am_plan *p, const float *composite, float *rgb, int32_t n_calls, int32_t frame, int32_t first_line,
                          int32_t k0, void *stream) {

@@ -442,10 +442,29 @@ class AmEngine(_EngineBase):
         return self._launch(_native.lib().cm_am_modulate_frames, x, out, (n, self.height, self.width), torch.float32,
                             was_numpy, n, int(first_frame))
 
-    def demodulate_frames_u8(self, *args, **kwargs):
-        raise NotImplementedError('no fused byte boundary for this standard: the PIL entry points convert on the host')
+    def demodulate_frames_u8(self, composite8, first_frame=0, out=None):
+        """'L' bytes [F, H, W] -> interleaved 'RGB' bytes [F, H, W, 3] (image.py:58-84 fused into the kernel)."""
+        torch = _torch()
+        if self.width % 4:
+            raise NotImplementedError('the fused uint8 boundary needs a width that is a multiple of 4')
+        t, was_numpy = self._stage(composite8, torch.uint8, (self.height, self.width), 'composite8')
+        n = t.shape[0]
+        return self._launch(_native.lib().cm_am_demodulate_frames_u8, t, out, (n, self.height, self.width, 3), torch.uint8,
+                            was_numpy, n, int(first_frame))
 
-    modulate_frames_u8 = demodulate_frames_u8
+    def modulate_frames_u8(self, rgb8, first_frame=0, out=None):
+        """interleaved 'RGB' bytes [F, H, W, 3] -> 'L' bytes [F, H, W] (image.py:27-56 fused into the kernel)."""
+        torch = _torch()
+        if self.width % 16:
+            raise NotImplementedError('the fused uint8 boundary of the encoders needs a width that is a multiple of 16')
+        if self.noise_level != 0.0:
+            raise NotImplementedError('the noisy NIIR encoder has no byte form: the PIL entry points convert on the host')
+        t, was_numpy = self._stage(rgb8, torch.uint8, (self.height, self.width, 3), 'rgb8')
+        n = t.shape[0]
+        if self.height < 2 * self.modulation_delay and n:
+            raise IndexError('image.py:49-50 feeds row 1 ahead of a field under modulation_delay 1: the image has %d row(s)' % self.height)
+        return self._launch(_native.lib().cm_am_modulate_frames_u8, t, out, (n, self.height, self.width), torch.uint8,
+                            was_numpy, n, int(first_frame))
 
     def demodulate_run(self, rows, frame, first_line, k0):
         torch = _torch()

@@ -301,6 +301,13 @@ int cm_am_modulate_frames(const cm_am_plan *plan, const float *rgb, float *compo
                           void *stream);
 int cm_am_demodulate_frames(const cm_am_plan *plan, const float *composite, float *rgb, int64_t n_frames, int64_t first_frame,
                             void *stream);
+/* ImageModem's byte boundary fused into the kernels, as cm_modulate_frames_u8 / cm_demodulate_frames_u8 (image.py:27-56,
+ * 58-84): interleaved 'RGB' bytes [n_frames][height][width][3] <-> 'L' bytes [n_frames][height][width].  The decoders need
+ * width % 4 == 0, the encoders width % 16 == 0 (CM_ERR_UNSUPPORTED otherwise); the noisy NIIR encoder has no byte form. */
+int cm_am_modulate_frames_u8(const cm_am_plan *plan, const uint8_t *rgb8, uint8_t *composite8, int64_t n_frames,
+                             int64_t first_frame, void *stream);
+int cm_am_demodulate_frames_u8(const cm_am_plan *plan, const uint8_t *composite8, uint8_t *rgb8, int64_t n_frames,
+                               int64_t first_frame, void *stream);
 /* One run of n_calls consecutive calls, as cm_demodulate_run / cm_modulate_run (one row of history in front when k0 > 0). */
 int cm_am_modulate_run(const cm_am_plan *plan, const float *rgb, float *composite, int32_t n_calls, int32_t frame,
                        int32_t first_line, int32_t k0, void *stream);

@@ -176,3 +176,77 @@ def test_pil_image_round_trip_proto_and_niir():
         want = numpy.uint8(numpy.rint(255.0 * numpy.clip(0.6 * oa.modulate_frames(modem, rgbf, 1)[0] + 0.2, 0.0, 1.0)))
         diff = numpy.abs(comp8.astype(int) - want.astype(int))
         assert diff.max() <= 1 and (diff > 0).mean() < 0.002, stack
+
+
+# ---- ImageModem's byte boundary fused into the kernels (cm_am_*_frames_u8) ----------------------------------------------
+U8_CASES = [('proto', (720, 64), 'FRENCH_819', 2, 1), ('proto_avg', (720, 33), 'BELGIAN_819', 2, 0), ('proto_625', (768, 20), 'GERBER_625', 3, 2),
+            ('niir', (720, 64), 'GERBER_625', 2, 1), ('niir_hue', (720, 21), 'GERBER_625', 2, 3), ('niir_525', (640, 24), 'NTSC_525', 2, 0),
+            ('proto_nofilter', (1024, 18), 'FRENCH_819', 1, 4), ('niir', (1280, 9), 'GERBER_625', 2, 5)]
+
+
+def _am_modem(stack, size, std):
+    lc = line.LineConfig(size, getattr(line.LineStandard, std))
+    return am_stacks.STACKS[stack](lc)
+
+
+@pytest.mark.parametrize('stack,size,std,n_frames,first', U8_CASES)
+def test_fused_uint8_modulate_matches_float_path(stack, size, std, n_frames, first):
+    """cm_am_modulate_frames_u8 == host-side byte / 255 -> float kernel -> host-side encode_composite_level + _as_bytes
+    (<= 1 LSB at the knife edge of rint on < 0.2 % of the samples)."""
+    from color_modem_amd.image import _as_bytes
+    im = image.ImageModem(_am_modem(stack, size, std))
+    rgb8 = numpy.random.default_rng(5).integers(0, 256, size=(n_frames, size[1], size[0], 3), dtype=numpy.uint8)
+    rgb8[:, :, 1:] = (rgb8[:, :, 1:].astype(int) + rgb8[:, :, :-1]) // 2
+    got = im.modulate_frames_u8(rgb8, first_frame=first)
+    assert got.dtype == numpy.uint8 and got.shape == (n_frames, size[1], size[0])
+    rgb = (rgb8.astype(numpy.float64) / 255.0).astype(numpy.float32).transpose(0, 3, 1, 2)
+    comp = im.modulate_frames(numpy.ascontiguousarray(rgb), first_frame=first)
+    want = _as_bytes(image.ImageModem.encode_composite_level(comp.astype(numpy.float64)))
+    diff = numpy.abs(got.astype(int) - want.astype(int))
+    if stack == 'niir_hue':
+        # the hue-correcting encoder divides by the length of the chroma phasor (niir.py:181-191): where that is short the
+        # reference itself turns one float32 ulp of input into > 1 LSB of output.  Those samples are named by the float64
+        # oracle (byte / 255 rounded to float32 vs byte * float32(1 / 255)) and left out of the 1-LSB bound.
+        from oracle import cm_oracle_am as oa
+        a = (rgb8.astype(numpy.float64) / 255.0).astype(numpy.float32).astype(numpy.float64).transpose(0, 3, 1, 2)
+        b = (rgb8.astype(numpy.float32) * numpy.float32(1.0 / 255.0)).astype(numpy.float64).transpose(0, 3, 1, 2)
+        modem = _am_modem(stack, size, std)
+        shaky = numpy.abs(oa.modulate_frames(modem, a, first) - oa.modulate_frames(modem, b, first)) > 1e-4
+        assert shaky.mean() < 1e-3
+        assert diff[~shaky].max() <= 1 and diff.max() <= 255 * 0.6 * 0.1, (diff[~shaky].max(), diff.max())
+    else:
+        assert diff.max() <= 1, diff.max()
+    assert (diff > 0).mean() < 2e-3, (diff > 0).mean()
+
+
+@pytest.mark.parametrize('stack,size,std,n_frames,first', U8_CASES)
+def test_fused_uint8_demodulate_matches_float_path(stack, size, std, n_frames, first):
+    """cm_am_demodulate_frames_u8 == host-side level decode -> float kernel -> host-side _as_bytes (<= 1 LSB, < 0.2 %)."""
+    from color_modem_amd.image import _as_bytes
+    im = image.ImageModem(_am_modem(stack, size, std))
+    rgb = testing.synthetic_rgb(n_frames, size[1], size[0], seed=31)
+    comp = im.modulate_frames(rgb, first_frame=first)
+    comp8 = _as_bytes(image.ImageModem.encode_composite_level(comp.astype(numpy.float64)))
+    got = im.demodulate_frames_u8(comp8, first_frame=first)
+    assert got.dtype == numpy.uint8 and got.shape == (n_frames, size[1], size[0], 3)
+    ref_in = image.ImageModem.decode_composite_level(comp8.astype(numpy.float64) / 255.0).astype(numpy.float32)
+    want = _as_bytes(im.demodulate_frames(ref_in, first_frame=first).astype(numpy.float64)).transpose(0, 2, 3, 1)
+    diff = numpy.abs(got.astype(int) - want.astype(int))
+    assert diff.max() <= 1 and (diff > 0).mean() < 2e-3, (diff.max(), (diff > 0).mean())
+
+
+def test_fused_uint8_am_limits():
+    """widths the byte tiles do not cover and the noisy encoder raise; the PIL entry points then convert on the host."""
+    from PIL import Image
+    im = image.ImageModem(_am_modem('proto', (712, 8), 'FRENCH_819'))
+    with pytest.raises(NotImplementedError):
+        im.modulate_frames_u8(numpy.zeros((1, 8, 712, 3), numpy.uint8))
+    assert im.demodulate_frames_u8(numpy.zeros((1, 8, 712), numpy.uint8)).shape == (1, 8, 712, 3)
+    assert im.modulate(Image.frombytes('RGB', (712, 8), bytes(712 * 8 * 3)), 0).size == (712, 8)
+    noisy = image.ImageModem(_am_modem('niir_noise', (720, 8), 'GERBER_625'))
+    with pytest.raises(NotImplementedError):
+        noisy.modulate_frames_u8(numpy.zeros((1, 8, 720, 3), numpy.uint8))
+    assert noisy.modulate(Image.frombytes('RGB', (720, 8), bytes(720 * 8 * 3)), 0).size == (720, 8)
+    im2 = image.ImageModem(_am_modem('niir', (722, 8), 'GERBER_625'))
+    with pytest.raises(NotImplementedError):
+        im2.demodulate_frames_u8(numpy.zeros((1, 8, 722), numpy.uint8))

@@ -13,7 +13,13 @@ for stack, size, std in (('proto', (720, 736), 'FRENCH_819'), ('proto_avg', (720
     comp = torch.empty((F, H, W), dtype=torch.float32, device='cuda')
     out = torch.empty((F, 3, H, W), dtype=torch.float32, device='cuda')
     res = []
-    for name, fn in (('mod', lambda: eng.modulate_frames(rgb, 0, out=comp)), ('demod', lambda: eng.demodulate_frames(comp, 0, out=out))):
+    rgb8 = torch.randint(0, 256, (F, H, W, 3), dtype=torch.uint8, device='cuda')
+    comp8 = torch.empty((F, H, W), dtype=torch.uint8, device='cuda')
+    out8 = torch.empty((F, H, W, 3), dtype=torch.uint8, device='cuda')
+    cases = [('mod', lambda: eng.modulate_frames(rgb, 0, out=comp)), ('demod', lambda: eng.demodulate_frames(comp, 0, out=out))]
+    if W % 16 == 0:
+        cases += [('mod_u8', lambda: eng.modulate_frames_u8(rgb8, 0, out=comp8)), ('demod_u8', lambda: eng.demodulate_frames_u8(comp8, 0, out=out8))]
+    for name, fn in cases:
         for _ in range(2): fn()
         torch.cuda.synchronize()
         ts = []
