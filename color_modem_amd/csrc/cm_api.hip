@@ -91,6 +91,9 @@ int launch_demod(const Geom &gm, const void *km, const Geom &gf, const void *kf,
             const int ff = pair_lds_floats<First>(af.k);
             if (ff > floats) floats = ff;
         }
+#ifdef CM_EXPERIMENTS
+        if (const char *pad = std::getenv("CM_EXP_LDS_PAD_KIB")) floats += 256 * std::atoi(pad);   // fewer workgroups per CU (occupancy study)
+#endif
         hipLaunchKernelGGL((demod_pair_kernel<Main, First>), dim3(n_first + n_main), dim3(128), sizeof(float) * (size_t)floats, stream, am, af, n_first);
     }
     else
