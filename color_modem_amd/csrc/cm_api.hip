@@ -15,6 +15,7 @@
 #include "cm_plan.h"
 #include "cm_am_kernels.h"
 #include "cm_wrap_kernels.h"
+#include "cm_scan_kernels.h"
 #include "cm_blk_kernels.h"
 #include "cm_am_plan.h"
 
@@ -173,6 +174,10 @@ struct cm_plan {
     LaunchFn fn = nullptr, fn_u8 = nullptr;
     bool has_first = false;
     int seg_warm = 1 << 30;        // samples a row segment enters the stream early (segment_warmup)
+    // small batches: one wavefront per scan line (cm_scan_kernels.h); null / 0 where the plan's shape does not fit it
+    ScanK *scan_main = nullptr, *scan_first = nullptr;
+    int scan_c1 = 0, scan_depth = 0;
+    mutable int small_batch = CM_SMALL_BATCH_AUTO;   // cm_plan_set_small_batch
     bool pair = false;             // wave-pair kernel (two wavefronts per 64 calls)
     Pass main, first;
     // modulator
@@ -765,6 +770,108 @@ static int segment_geometry(const cm_plan *p, int wp, long long blocks, int &seg
     return S;
 }
 
+// ---- small batches: one wavefront per scan line (cm_scan_kernels.h) ------------------------------------------------------
+// The scan's chunk-to-chunk transitions: A^(chunk 2^k) of every section, A = [[-a1, 1], [-a2, 0]] with the float32-rounded
+// coefficients the kernel filters with (float64 products, rounded once).
+static void fill_scan_filter(const cm_iir_desc &d, const float *na1, const float *na2, const float *b1, const float *b2, int chunk, ScanFilter &f) {
+    std::memset(&f, 0, sizeof f);
+    f.nsec = d.n_sections;
+    f.shift = d.shift;
+    for (int j = 0; j < d.n_sections && j < kScanSec; ++j) {
+        f.na1[j] = na1[j]; f.na2[j] = na2[j]; f.b1[j] = b1[j]; f.b2[j] = b2[j];
+        double a[4] = {(double)na1[j], 1.0, (double)na2[j], 0.0}, m[4] = {1.0, 0.0, 0.0, 1.0};
+        for (int e = chunk; e > 0; e >>= 1) {      // m = a^chunk
+            if (e & 1) { const double t[4] = {m[0] * a[0] + m[1] * a[2], m[0] * a[1] + m[1] * a[3], m[2] * a[0] + m[3] * a[2], m[2] * a[1] + m[3] * a[3]}; std::memcpy(m, t, sizeof t); }
+            const double q[4] = {a[0] * a[0] + a[1] * a[2], a[0] * a[1] + a[1] * a[3], a[2] * a[0] + a[3] * a[2], a[2] * a[1] + a[3] * a[3]};
+            std::memcpy(a, q, sizeof q);
+        }
+        f.steps[j] = kScanSteps;
+        for (int k = 0; k < kScanSteps; ++k) {
+            double big = 0.0;
+            for (int e = 0; e < 4; ++e) { f.m[j][k][e] = (float)m[e]; big = std::fmax(big, std::fabs(m[e])); }
+            if (big < 1e-12 && f.steps[j] == kScanSteps) f.steps[j] = k;
+            const double q[4] = {m[0] * m[0] + m[1] * m[2], m[0] * m[1] + m[1] * m[3], m[2] * m[0] + m[3] * m[2], m[2] * m[1] + m[3] * m[3]};
+            std::memcpy(m, q, sizeof q);
+        }
+    }
+}
+static bool build_scan_k(const cm_plan_desc &d, bool pald, bool bsf, int depth, bool minavg, bool notch, int c1, ScanK &s, std::string &err) {
+    DemodK<float, SysAny> k;
+    DemodScales sc;
+    if (!fits_any(signature_wanted(d, pald))) { err = "filter shape beyond the run-time maxima"; return false; }
+    if (!build_demod_k<float, SysAny>(d, pald, bsf, k, sc, err)) return false;
+    std::memset(&s, 0, sizeof s);
+    s.width = d.width; s.pald = pald; s.bsf = bsf; s.depth = depth; s.minavg = minavg; s.c1 = c1;
+    for (int i = 0; i < 10; ++i) s.taps[i] = k.taps.c[i];
+    s.c0 = k.taps.c0;
+    const cm_iir_desc &lp = pald ? d.pald_lp : d.demod_lp;
+    fill_scan_filter(d.extract2x, k.ext.na1, k.ext.na2, k.ext.b1, k.ext.b2, 2 * c1, s.ext);
+    if (bsf) fill_scan_filter(d.remove2x, k.rem.na1, k.rem.na2, k.rem.b1, k.rem.b2, 2 * c1, s.rem);
+    fill_scan_filter(lp, k.lpf.na1, k.lpf.na2, k.lpf.b1, k.lpf.b2, 2 * c1, s.lpf);
+    fill_scan_filter(d.precorrect, k.pre.na1, k.pre.na2, k.pre.b1, k.pre.b2, c1, s.pre);
+    if (notch && d.notch.n_sections) fill_scan_filter(d.notch, k.notch.na1, k.notch.na2, k.notch.b1, k.notch.b2, c1, s.notch);
+    s.luma_gain = k.luma_gain;
+    s.notch_gain = notch ? k.notch_gain : 0.f;
+    for (int i = 0; i < 9; ++i) s.m[i] = k.m[i / 3][i % 3];
+    const int s2 = std::max(std::max(s.ext.shift, s.lpf.shift), bsf ? s.rem.shift : 0);
+    if (s2 > kScanMaxShift || s.pre.shift > kScanMaxShift) { err = "FilterFunction shift beyond the scan kernel's margins"; return false; }
+    if (2 * d.width + s2 > 128 * c1 || d.width + s.pre.shift > 64 * c1) { err = "row longer than the scan kernel's chunks"; return false; }
+    return true;
+}
+// which chunk size serves a width (0: none compiled)
+static int scan_chunk_for(const cm_plan_desc &d) {
+    const int lp = d.pipeline == CM_PIPE_PAL_D ? d.pald_lp.shift : d.demod_lp.shift;
+    const int s2 = std::max(std::max(d.extract2x.shift, lp), d.remove2x.shift);
+    for (int c1 : {12, 16})
+        if (2 * d.width + s2 <= 128 * c1 && d.width + d.precorrect.shift <= 64 * c1) return c1;
+    return 0;
+}
+static void make_scan(cm_plan *p, const cm_plan_desc &d) {
+    if (p->secam || !p->fn) return;
+    const int c1 = scan_chunk_for(d);
+    if (!c1) return;
+    const bool pald = d.pipeline == CM_PIPE_PAL_D, bsf = d.main_luma_bandstop != 0, minavg = d.chroma_average == CM_AVG_MIN;
+    const int depth = p->main.depth;        // the halo of the instance the lane tables were made for
+    if (depth > 2 || (p->main.luma_prev_bits && depth < 1)) return;
+    std::string err;
+    ScanK km, kf;
+    if (!build_scan_k(d, pald, bsf, depth, minavg, true, c1, km, err)) return;
+    if (p->has_first && !build_scan_k(d, false, true, 0, false, false, c1, kf, err)) return;
+    if (hipMalloc((void **)&p->scan_main, sizeof km) != hipSuccess || hipMemcpy(p->scan_main, &km, sizeof km, hipMemcpyHostToDevice) != hipSuccess) {
+        p->scan_main = nullptr;
+        return;
+    }
+    if (p->has_first && (hipMalloc((void **)&p->scan_first, sizeof kf) != hipSuccess || hipMemcpy(p->scan_first, &kf, sizeof kf, hipMemcpyHostToDevice) != hipSuccess)) {
+        (void)hipFree(p->scan_main);
+        p->scan_main = p->scan_first = nullptr;
+        return;
+    }
+    p->scan_c1 = c1;
+    p->scan_depth = depth;
+}
+template <int C1, int NW>
+static int launch_scan(const cm_plan *p, const Geom &gm, const Geom &gf, bool with_first, hipStream_t stream) {
+    const size_t lds = sizeof(float) * (size_t)NW * scan_wave_floats<C1>();
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void *)demod_scan_kernel<C1, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return fail(CM_ERR_LAUNCH, "hipFuncSetAttribute(max dynamic LDS) failed for the scan kernel");
+        attr_set = true;
+    }
+    const long long n_first = with_first ? (gf.total_calls + NW - 1) / NW : 0;
+    const int per = gm.sparse ? NW : NW - p->scan_depth;      // calls per workgroup behind the halo waves
+    const long long n_main = (gm.total_calls + per - 1) / per;
+    hipLaunchKernelGGL((demod_scan_kernel<C1, NW>), dim3((int)(n_first + n_main)), dim3(64 * NW), lds, stream, gm, gf, p->scan_main,
+                       with_first ? p->scan_first : p->scan_main, (int)n_first);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(CM_ERR_LAUNCH, std::string("demod_scan_kernel launch: ") + hipGetErrorString(e));
+    return CM_OK;
+}
+// calls up to which the scan kernel beats the streaming kernels (profiles/r03_batch_curve.txt)
+#ifndef CM_SCAN_MAX_CALLS
+#define CM_SCAN_MAX_CALLS 6000
+#endif
+
 // gm: main-pass geometry (total_calls set); gf: first-line geometry (total_calls = number of runs) when the plan has one
 #ifdef CM_DIAG
 static unsigned long long *g_diag;
@@ -786,8 +893,14 @@ int run_plan(const cm_plan *p, Geom gm, Geom gf, bool with_first, hipStream_t st
     if (n_main + n_first > 0x7fffffffLL) return fail(CM_ERR_INVALID, "batch too large for one launch");
     LaunchFn fn = u8 ? p->fn_u8 : p->fn;
     if (!fn) return fail(CM_ERR_UNSUPPORTED, "no kernel instance for this request");
+    const int mode = p->small_batch;
+    if (!u8 && p->scan_main && (mode == CM_SMALL_BATCH_SCAN || (mode == CM_SMALL_BATCH_AUTO && gm.total_calls <= CM_SCAN_MAX_CALLS))) {
+        if (p->scan_c1 == 12) return launch_scan<12, 4>(p, gm, gf, with_first, stream);
+        return launch_scan<16, 4>(p, gm, gf, with_first, stream);
+    }
+    if (mode == CM_SMALL_BATCH_SCAN) return fail(CM_ERR_UNSUPPORTED, "the scan kernel does not serve this plan / this entry point");
     int seg_len = 0;
-    const int S = segment_geometry(p, gm.Wp, n_main + n_first, seg_len);
+    const int S = mode == CM_SMALL_BATCH_ROWS ? 1 : segment_geometry(p, gm.Wp, n_main + n_first, seg_len);
     if (S > 1) {      // few workgroups: every one walks a segment of its rows (blocks [seg * n, (seg + 1) * n) of each pass)
         gm.seg_len = gf.seg_len = seg_len;
         gm.seg_warm = gf.seg_warm = p->seg_warm;
@@ -935,6 +1048,8 @@ int cm_plan_create(const cm_plan_desc *desc, cm_plan **out) {
     if (!have_demod) {
         p->fn = nullptr;
         p->demod_error = err;
+    } else {
+        make_scan(p, *desc);
     }
     if (!have_demod && !have_mod) {
         cm_plan_destroy(p);
@@ -951,6 +1066,8 @@ void cm_plan_destroy(cm_plan *p) {
     if (p->frame_rot) (void)hipFree(p->frame_rot);
     if (p->simd_load) (void)hipFree(p->simd_load);
     if (p->blk_tiles) (void)hipFree(p->blk_tiles);
+    if (p->scan_main) (void)hipFree(p->scan_main);
+    if (p->scan_first) (void)hipFree(p->scan_first);
     if (p->main.lanes) (void)hipFree(p->main.lanes);
     if (p->first.lanes) (void)hipFree(p->first.lanes);
     if (p->mod_lanes) (void)hipFree(p->mod_lanes);
@@ -2033,6 +2150,13 @@ int cm_comb_wrap_demodulate_run(const cm_plan *inner, const cm_plan *first, cons
 extern "C" void cm_diag_set_buffer(unsigned long long *dev) { g_diag = dev; }
 #endif
 
+int cm_plan_set_small_batch(const cm_plan *p, int32_t mode) {
+    if (!p) return fail(CM_ERR_INVALID, "null argument");
+    if (mode < CM_SMALL_BATCH_AUTO || mode > CM_SMALL_BATCH_SCAN) return fail(CM_ERR_INVALID, "unknown small-batch mode");
+    if (mode == CM_SMALL_BATCH_SCAN && !p->scan_main) return fail(CM_ERR_UNSUPPORTED, "the scan kernel does not serve this plan");
+    p->small_batch = mode;
+    return CM_OK;
+}
 int cm_plan_describe(const cm_plan *p, char *buf, int32_t buf_len) {
     if (!p || !buf || buf_len < 1) return 0;
 #ifdef CM_EXPERIMENTS

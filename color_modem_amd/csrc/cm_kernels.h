@@ -475,23 +475,19 @@ struct LaneCall {
     int line, kk, regime, src_row, prev_row, out_row;
     bool store_ok;
 };
-__device__ __forceinline__ LaneCall locate_call(const Geom &g, int block, int depth, int lane) {
-    long long c;
-    bool active;
+// c: index of the call in the launch's list (sparse pass: of the run), already known to be wanted or not (active)
+__device__ __forceinline__ LaneCall locate_call_at(const Geom &g, long long c, bool active) {
     long long frame;
     int run, i;
     int rem;     // index of the call within its frame
     if (g.sparse) {
-        c = (long long)block * 64 + lane;
-        active = c < g.total_calls;
-        if (!active) c = g.total_calls - 1;
+        if (c >= g.total_calls) { active = false; c = g.total_calls - 1; }
         frame = c / g.runs_per_frame;
         run = (int)(c - frame * g.runs_per_frame);
         i = 0;
         rem = run ? g.calls_run0 : 0;
     } else {
-        c = (long long)block * (64 - depth) - depth + lane;
-        active = lane >= depth && c < g.total_calls;
+        if (c >= g.total_calls) active = false;
         if (c < 0) c = 0;
         if (c >= g.total_calls) c = g.total_calls - 1;
         frame = c / g.calls_per_frame;
@@ -528,6 +524,11 @@ __device__ __forceinline__ LaneCall locate_call(const Geom &g, int block, int de
         }
     }
     return r;
+}
+// one lane per call, 64 - depth calls per workgroup behind depth halo lanes
+__device__ __forceinline__ LaneCall locate_call(const Geom &g, int block, int depth, int lane) {
+    if (g.sparse) return locate_call_at(g, (long long)block * 64 + lane, true);
+    return locate_call_at(g, (long long)block * (64 - depth) - depth + lane, lane >= depth);
 }
 
 // Byte variant: rows of W bytes; a tile row is 32 bytes, 8 lanes x 4 bytes per row, 8 rows per instruction.

@@ -1,0 +1,535 @@
+// cm_scan_kernels.h - the QAM-family decoders with ONE WAVEFRONT PER SCAN LINE, lanes along the row: the kernel of SMALL batches.
+//
+// The streaming kernels (cm_kernels.h) give a scan line to a lane and walk it sample by sample: a launch lasts as long as one
+// row takes however few rows there are (0.2 ms for 720 samples; 68 us with the row cut into segments).  The reference's own
+// caller lives exactly there - one frame, one row at a time - so this file restates the same chain of array operations
+// (ref qam.py:34-58, pal.py:71-77, 117-125, comb.py:47-59, utils.py:28-36) with the ROW spread over the 64 lanes of a wavefront:
+//
+//   lane l owns the samples [l C1, (l + 1) C1) of every 1x-rate signal of the row and [2 l C1, 2 (l + 1) C1) of every 2x-rate one,
+//   in registers; C1 = 12 (rows up to ~740 samples), 16 (~1000), 24, 32 (1920 at 2 waves per workgroup).
+//
+//   * resample_poly up / down by 2 (41-tap half-band FIR): every lane reads its window (+- 10 / 19 samples into the neighbours'
+//     chunks) from an LDS copy of the row with zero margins and evaluates its outputs directly - 20 FMAs per output, no state;
+//   * lfilter + FilterFunction (utils.py:28-36): a chunked SCAN per second-order section -
+//       1. every lane runs the section over its chunk from a zero state and keeps the final state (s1, s2);
+//       2. the state a lane must START from is sum over the lanes before it of A^(chunk (l - 1 - j)) (s1, s2)_j, A the section's
+//          2 x 2 state transition: an exclusive Hillis-Steele scan over the lanes, log2(64) = 6 steps of ds_bpermute + a 2 x 2
+//          matrix (A^(chunk 2^k), float64 on the host; steps beyond the point where the power has decayed below 1e-12 are skipped);
+//       3. every lane runs the section again from that state - the same recurrence, the same operation order as the streaming
+//          kernels, so the only difference to a serial walk is the rounding of the carried-in state (~1e-7 of its magnitude);
+//     FilterFunction's tail (shift copies of the last sample) is part of the scanned sequence, its output offset is the index
+//     the chunk is written back to LDS at;
+//   * the comb filter's previous lines are the neighbouring WAVES of the workgroup (NW waves = NW - depth calls + depth halo
+//     waves, base pairs exchanged through LDS once per row), the first line of a run is the plain decoder on workgroups of its own.
+//
+// One kernel serves every filter shape: section counts, shifts, front end, comb depth, minavg and notch are run-time
+// (wave-uniform) parameters of ScanK, built per plan; the lane tables, carrier tables and the row geometry (Geom, locate_call_at)
+// are the streaming kernels'.  A row costs one wavefront about 10 us; a frame's ~580 calls run side by side.
+#ifndef CM_SCAN_KERNELS_H
+#define CM_SCAN_KERNELS_H
+
+#include "cm_kernels.h"
+
+namespace cm {
+
+constexpr int kScanSec = 4;        // CM_MAX_SECTIONS
+constexpr int kScanSteps = 6;      // log2(64)
+constexpr int kScanMargin = 64;    // zero floats before and after every LDS row (>= the largest FilterFunction shift, >= 20)
+constexpr int kScanMaxShift = 48;
+
+struct ScanFilter {                // one cascade in the general form 1 + b1 z^-1 + b2 z^-2 over 1 - na1 z^-1 - na2 z^-2
+    int32_t nsec, shift;
+    float na1[kScanSec], na2[kScanSec], b1[kScanSec], b2[kScanSec];
+    float m[kScanSec][kScanSteps][4];   // m[j][k] = A_j^(chunk 2^k), row-major, A = [[na1, 1], [na2, 0]] acting on (s1, s2)
+    int32_t steps[kScanSec];            // scan steps that still carry anything (<= 6)
+};
+struct ScanK {                     // constants of one pass (device memory, one per plan and pass)
+    int32_t width, pald, bsf, depth, minavg, c1;
+    float taps[10], c0;            // Taps<float>
+    ScanFilter ext, rem, lpf;      // 2x rate: chunk = 2 c1
+    ScanFilter pre, notch;         // 1x rate: chunk = c1
+    float luma_gain, notch_gain;
+    float m[9];
+};
+typedef const __attribute__((address_space(4))) ScanK const_ScanK;
+typedef const __attribute__((address_space(4))) ScanFilter const_ScanFilter;
+
+// value of lane - d (0 for the first d lanes)
+__device__ __forceinline__ float scan_up(float v, int d, int lane) {
+    const float r = lane_from(((lane - d) & 63) * 4, v);
+    return lane >= d ? r : 0.f;
+}
+
+// One cascade over a chunk per lane, in place: the sequence is the concatenation of the lanes' chunks, from a zero state.
+template <int CN>
+__device__ __forceinline__ void scan_iir(float (&v)[CN], const_ScanFilter &f, int lane) {
+    const int nsec = f.nsec;
+    for (int j = 0; j < nsec; ++j) {
+        const float na1 = f.na1[j], na2 = f.na2[j], b1 = f.b1[j], b2 = f.b2[j];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < CN; ++i) {
+            const float x = v[i], y = x + s1;
+            s1 = fmaf_(na1, y, fmaf_(b1, x, s2));
+            s2 = fmaf_(na2, y, b2 * x);
+        }
+        float e1 = scan_up(s1, 1, lane), e2 = scan_up(s2, 1, lane);
+        const int steps = f.steps[j];
+        for (int k = 0; k < steps; ++k) {
+            const float t1 = scan_up(e1, 1 << k, lane), t2 = scan_up(e2, 1 << k, lane);
+            e1 = fmaf_(f.m[j][k][0], t1, fmaf_(f.m[j][k][1], t2, e1));
+            e2 = fmaf_(f.m[j][k][2], t1, fmaf_(f.m[j][k][3], t2, e2));
+        }
+        s1 = e1;
+        s2 = e2;
+#pragma unroll
+        for (int i = 0; i < CN; ++i) {
+            const float x = v[i], y = x + s1;
+            s1 = fmaf_(na1, y, fmaf_(b1, x, s2));
+            s2 = fmaf_(na2, y, b2 * x);
+            v[i] = y;
+        }
+    }
+}
+// the same for two signals that share the filter (the two detector channels, (u, v))
+__device__ __forceinline__ f2 fma2(float a, f2 x, f2 c) { return __builtin_elementwise_fma(f2{a, a}, x, c); }
+template <int CN>
+__device__ __forceinline__ void scan_iir2(f2 (&v)[CN], const_ScanFilter &f, int lane) {
+    const int nsec = f.nsec;
+    for (int j = 0; j < nsec; ++j) {
+        const float na1 = f.na1[j], na2 = f.na2[j], b1 = f.b1[j], b2 = f.b2[j];
+        f2 s1 = {0.f, 0.f}, s2 = {0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < CN; ++i) {
+            const f2 x = v[i], y = x + s1;
+            s1 = fma2(na1, y, fma2(b1, x, s2));
+            s2 = fma2(na2, y, b2 * x);
+        }
+        f2 e1 = {scan_up(s1.x, 1, lane), scan_up(s1.y, 1, lane)}, e2 = {scan_up(s2.x, 1, lane), scan_up(s2.y, 1, lane)};
+        const int steps = f.steps[j];
+        for (int k = 0; k < steps; ++k) {
+            const int d = 1 << k;
+            const f2 t1 = {scan_up(e1.x, d, lane), scan_up(e1.y, d, lane)}, t2 = {scan_up(e2.x, d, lane), scan_up(e2.y, d, lane)};
+            e1 = fma2(f.m[j][k][0], t1, fma2(f.m[j][k][1], t2, e1));
+            e2 = fma2(f.m[j][k][2], t1, fma2(f.m[j][k][3], t2, e2));
+        }
+        s1 = e1;
+        s2 = e2;
+#pragma unroll
+        for (int i = 0; i < CN; ++i) {
+            const f2 x = v[i], y = x + s1;
+            s1 = fma2(na1, y, fma2(b1, x, s2));
+            s2 = fma2(na2, y, b2 * x);
+            v[i] = y;
+        }
+    }
+}
+
+struct ScanTaps {
+    float c[10], c0;
+    __device__ __forceinline__ float tap(int k) const { return c[k < 10 ? k : 19 - k]; }
+};
+
+// resample_poly(x, 2, 1) over this lane's chunk: out[2 i] = c0 x[n0 + i], out[2 i + 1] = sum_k c_k x[n0 + i + 10 - k]
+// (HalfbandChain::push, cm_stages.h).  src: the 1x-rate row in LDS, zero outside [0, W); n0 a multiple of 4.
+template <int C1>
+__device__ __forceinline__ void scan_up2(const lds_float *src, int n0, const ScanTaps &tp, float (&out)[2 * C1]) {
+    float win[C1 + 24];       // x[n0 - 12 .. n0 + C1 + 12)
+#pragma unroll
+    for (int q = 0; q < (C1 + 24) / 4; ++q) {
+        const f4 t = *(const lds_f4 *)(src + n0 - 12 + 4 * q);
+        win[4 * q] = t.x; win[4 * q + 1] = t.y; win[4 * q + 2] = t.z; win[4 * q + 3] = t.w;
+    }
+#pragma unroll
+    for (int i = 0; i < C1; ++i) {
+        float acc = tp.tap(0) * win[22 + i];
+#pragma unroll
+        for (int k = 1; k < 20; ++k) acc = fmaf_(tp.tap(k), win[22 + i - k], acc);
+        out[2 * i] = tp.c0 * win[12 + i];
+        out[2 * i + 1] = acc;
+    }
+}
+// the odd output of the same interpolator at one sample n, by every lane (FilterFunction pads with the last sample: n = W - 1)
+__device__ __forceinline__ float scan_up2_odd_at(const lds_float *src, int n, const ScanTaps &tp) {
+    float acc = tp.tap(0) * src[n + 10];
+#pragma unroll
+    for (int k = 1; k < 20; ++k) acc = fmaf_(tp.tap(k), src[n + 10 - k], acc);
+    return acc;
+}
+// 2 resample_poly(z, 1, 2) over this lane's chunk: out[i] = c0 z[2 n] + sum_k c_k z[2 n + 19 - 2 k], n = n0 + i
+// (HalfbandChain::push_pair).  src: the 2x-rate row in LDS, zero outside [0, 2 W).
+template <int C1>
+__device__ __forceinline__ void scan_dn2(const lds_float *src, int n0, const ScanTaps &tp, float (&out)[C1]) {
+    float win[2 * C1 + 40];   // z[2 n0 - 20 .. 2 n0 + 2 C1 + 20)
+#pragma unroll
+    for (int q = 0; q < (2 * C1 + 40) / 4; ++q) {
+        const f4 t = *(const lds_f4 *)(src + 2 * n0 - 20 + 4 * q);
+        win[4 * q] = t.x; win[4 * q + 1] = t.y; win[4 * q + 2] = t.z; win[4 * q + 3] = t.w;
+    }
+#pragma unroll
+    for (int i = 0; i < C1; ++i) {
+        float acc = tp.tap(0) * win[39 + 2 * i];
+#pragma unroll
+        for (int k = 1; k < 20; ++k) acc = fmaf_(tp.tap(k), win[39 + 2 * i - 2 * k], acc);
+        out[i] = fmaf_(tp.c0, win[20 + 2 * i], acc);
+    }
+}
+
+// FilterFunction (utils.py:28-36) around a cascade, 2x or 1x rate: v holds in[t0 .. t0 + CN) (anything beyond the row), the
+// sequence is in[0 .. len) followed by copies of `last` (= in[len - 1]); the filtered chunk goes to dst[t - shift] - the
+// first `shift` outputs land in the margin before dst[0], what lies beyond dst[len) is zeroed again (the decimators read zeros there).
+template <int CN>
+__device__ __forceinline__ void scan_pad(float (&v)[CN], int t0, int len, float last) {
+    if (t0 + CN > len) {
+#pragma unroll
+        for (int i = 0; i < CN; ++i) v[i] = t0 + i >= len ? last : v[i];
+    }
+}
+template <int CN>
+__device__ __forceinline__ void scan_put(lds_float *dst, const float (&v)[CN], int t0, int shift) {
+    typedef float f2u __attribute__((ext_vector_type(2), aligned(4)));
+    typedef __attribute__((address_space(3))) f2u lds_f2u;
+#pragma unroll
+    for (int i = 0; i < CN; i += 2) *(lds_f2u *)(dst + t0 - shift + i) = f2u{v[i], v[i + 1]};
+}
+__device__ __forceinline__ void scan_trim(lds_float *dst, int len, int lane) {
+    dst[lane - kScanMargin] = 0.f;
+    dst[len + lane] = 0.f;
+}
+
+// gf where first, else gm, field by field (scalar selects: a reference picked at run time would send both kernel arguments
+// through scratch memory)
+__device__ __forceinline__ Geom select_geom(const Geom &gm, const Geom &gf, bool first) {
+    Geom g;
+#define CM_PICK(f) g.f = first ? gf.f : gm.f
+    CM_PICK(in); CM_PICK(out); CM_PICK(lanes); CM_PICK(carrier4); CM_PICK(carrier2);
+    CM_PICK(in_frame_stride); CM_PICK(in_plane_stride); CM_PICK(in_row_stride);
+    CM_PICK(out_frame_stride); CM_PICK(out_plane_stride); CM_PICK(out_row_stride);
+    CM_PICK(total_calls); CM_PICK(first_frame); CM_PICK(cycle); CM_PICK(n_lines);
+    CM_PICK(frame_rot); CM_PICK(rot_first); CM_PICK(rot_cycle);
+    CM_PICK(W); CM_PICK(H); CM_PICK(Wp); CM_PICK(calls_per_frame); CM_PICK(calls_run0); CM_PICK(runs_per_frame);
+    CM_PICK(first_line[0]); CM_PICK(first_line[1]); CM_PICK(k0); CM_PICK(delay); CM_PICK(rows_mode); CM_PICK(luma_prev_bits);
+    CM_PICK(sparse); CM_PICK(seg_len); CM_PICK(seg_blocks); CM_PICK(seg_warm); CM_PICK(in_calls); CM_PICK(out_calls);
+    CM_PICK(skip_first); CM_PICK(diag); CM_PICK(simd_load); CM_PICK(blk_tiles);
+#undef CM_PICK
+    return g;
+}
+
+// One launch: workgroups [0, n_first) run the plain first-line pass (NW sparse calls each), the others the main pass
+// (NW - depth calls behind depth halo waves).  Dynamic LDS: NW * scan_wave_floats<C1>() floats.
+template <int C1> constexpr int scan_wave_floats() { return (64 * C1 + 2 * kScanMargin) + 2 * (128 * C1 + 2 * kScanMargin); }
+
+template <int C1, int NW>
+__global__ __launch_bounds__(64 * NW) void demod_scan_kernel(const Geom gm, const Geom gf, const ScanK *km, const ScanK *kf, int n_first) {
+    constexpr int C2 = 2 * C1, N1 = 64 * C1, MG = kScanMargin;
+    constexpr int kX = N1 + 2 * MG, kP = 2 * N1 + 2 * MG;
+    extern __shared__ __attribute__((aligned(16))) float scan_lds[];
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    const bool is_first = (int)blockIdx.x < n_first;
+    const Geom g = select_geom(gm, gf, is_first);
+    const_ScanK &k = *(const_ScanK *)(is_first ? kf : km);
+    const int depth = g.sparse ? 0 : k.depth;     // a sparse pass runs call 0 of every run: no line before it
+    const long long c = g.sparse ? (long long)blockIdx.x * NW + w : (long long)((int)blockIdx.x - n_first) * (NW - depth) - depth + w;
+    const LaneCall lc = locate_call_at(g, c, w >= depth);
+    const bool alive = c >= 0 && c < g.total_calls;     // halo waves included: their base pairs are read by the waves behind them
+
+    lds_float *wave = (lds_float *)scan_lds + w * scan_wave_floats<C1>();
+    lds_float *X = wave + MG, *P = wave + kX + MG, *Q = P + kP;
+    lds_float *BS = Q, *BC = Q + N1;                      // base pairs (Ps, Pc)[n]: in the place of Q once it has been read
+    const int W = g.W, L = 2 * W;
+    const int n0 = lane * C1, t0 = 2 * n0;
+    ScanTaps tp;
+#pragma unroll
+    for (int i = 0; i < 10; ++i) tp.c[i] = k.taps[i];
+    tp.c0 = k.c0;
+#ifdef CM_DIAG   /* cycle stamps of the stages of one wave (tools/scan_diag.py) */
+    unsigned long long st[16];
+    int sti = 0;
+    const unsigned long long rt0 = cm_realtime();
+#define CM_SCAN_STAMP() st[sti++] = cm_stamp()
+#else
+#define CM_SCAN_STAMP()
+#endif
+    CM_SCAN_STAMP();
+
+    // ---- the row: registers + LDS copy with zero margins ---------------------------------------------------------------
+    float u[C1], v[C1];          // later: the combined chroma of this lane's samples
+    LaneK<float> lk;             // the call's constants: asked for here, needed behind the front end
+    {
+        const int fmod = (int)((g.first_frame + lc.frame) % g.cycle);
+        lk = g.lanes[((long long)fmod * 3 + lc.regime) * g.n_lines + lc.line];
+    }
+    {
+        const float *xp = g.in + lc.frame * g.in_frame_stride + (long long)lc.src_row * g.Wp;
+        X[lane - MG] = 0.f;
+        X[N1 + lane] = 0.f;
+        P[lane - MG] = 0.f;
+        Q[lane - MG] = 0.f;
+#pragma unroll
+        for (int q = 0; q < C1 / 4; ++q) {
+            const int n = n0 + 4 * q;
+            f4 t = {0.f, 0.f, 0.f, 0.f};
+            if (alive && n < g.Wp) t = *(const f4 *)(xp + n);
+            if (n + 3 >= W) {
+                if (n >= W) t.x = 0.f;
+                if (n + 1 >= W) t.y = 0.f;
+                if (n + 2 >= W) t.z = 0.f;
+                if (n + 3 >= W) t.w = 0.f;
+            }
+            *(lds_f4 *)(X + n) = t;
+        }
+    }
+    CM_SCAN_STAMP();   // row in LDS
+    // ---- front end: the pair the product detectors multiply, then the detectors -----------------------------------------
+    f2 pq[C2];                  // (ps, pc)[t]: detector products, then their low-passed versions
+    {
+        float a[C2];
+        scan_up2<C1>(X, n0, tp, a);
+        const float a_last = scan_up2_odd_at(X, W - 1, tp);
+        if (k.bsf) {            // luma = dn2(band-stop(up2 x)) * gain (qam.py:57): through Q, kept in v[] until the back end
+            float r[C2];
+#pragma unroll
+            for (int i = 0; i < C2; ++i) r[i] = a[i];
+            scan_pad<C2>(r, t0, L, a_last);
+            scan_iir<C2>(r, k.rem, lane);
+            scan_put<C2>(Q, r, t0, k.rem.shift);
+            scan_trim(Q, L, lane);
+            scan_dn2<C1>(Q, n0, tp, v);
+        }
+        CM_SCAN_STAMP();   // up2 (+ band-stop luma)
+        // the detector carriers of this lane's samples, asked for ahead of the band-pass that hides their latency
+        f4 car4[C1];
+#pragma unroll
+        for (int i = 0; i < C1; ++i) car4[i] = *(const f4 *)(g.carrier4 + 4 * (n0 + i < W ? n0 + i : W - 1));
+        const f4 car_last = *(const f4 *)(g.carrier4 + 4 * (W - 1));
+        scan_pad<C2>(a, t0, L, a_last);
+        scan_iir<C2>(a, k.ext, lane);
+        CM_SCAN_STAMP();   // band-pass
+        scan_put<C2>(P, a, t0, k.ext.shift);
+        scan_trim(P, L, lane);
+        float m[C2];            // the 2x-rate signal the detectors see: b (QAM front) or up2(dn2(b)) (PAL-D front)
+        float m_last;
+        if (k.pald) {
+            float e[C1];
+            scan_dn2<C1>(P, n0, tp, e);
+            lds_float *E = Q;           // 1x-rate row in the place of Q (free here)
+            E[lane - MG] = 0.f;
+            E[N1 + lane] = 0.f;
+#pragma unroll
+            for (int q = 0; q < C1 / 4; ++q) {
+                f4 t;
+                t.x = n0 + 4 * q < W ? e[4 * q] : 0.f;
+                t.y = n0 + 4 * q + 1 < W ? e[4 * q + 1] : 0.f;
+                t.z = n0 + 4 * q + 2 < W ? e[4 * q + 2] : 0.f;
+                t.w = n0 + 4 * q + 3 < W ? e[4 * q + 3] : 0.f;
+                *(lds_f4 *)(E + n0 + 4 * q) = t;
+            }
+            scan_up2<C1>(E, n0, tp, m);
+            m_last = scan_up2_odd_at(E, W - 1, tp);
+        } else {
+#pragma unroll
+            for (int q = 0; q < C2 / 4; ++q) {
+                const f4 t = *(const lds_f4 *)(P + t0 + 4 * q);
+                m[4 * q] = t.x; m[4 * q + 1] = t.y; m[4 * q + 2] = t.z; m[4 * q + 3] = t.w;
+            }
+            m_last = P[L - 1];
+        }
+        CM_SCAN_STAMP();   // dn2 / up2 of e
+        // product detectors against the phase-free carriers (Detector::step): car = {C[2 n], S[2 n], C[2 n + 1], S[2 n + 1]}
+#pragma unroll
+        for (int i = 0; i < C1; ++i) {
+            const f4 car = car4[i];
+            pq[2 * i] = f2{m[2 * i] * car.y, m[2 * i] * car.x};
+            pq[2 * i + 1] = f2{m[2 * i + 1] * car.w, m[2 * i + 1] * car.z};
+        }
+        if (t0 + C2 > L) {
+            const f2 last = {m_last * car_last.w, m_last * car_last.z};
+#pragma unroll
+            for (int i = 0; i < C2; ++i) pq[i] = t0 + i >= L ? last : pq[i];
+        }
+    }
+    CM_SCAN_STAMP();   // detector products
+    scan_iir2<C2>(pq, k.lpf, lane);
+    {
+        float s[C2];
+#pragma unroll
+        for (int i = 0; i < C2; ++i) s[i] = pq[i].x;
+        scan_put<C2>(P, s, t0, k.lpf.shift);
+        scan_trim(P, L, lane);
+#pragma unroll
+        for (int i = 0; i < C2; ++i) s[i] = pq[i].y;
+        scan_put<C2>(Q, s, t0, k.lpf.shift);
+        scan_trim(Q, L, lane);
+    }
+    CM_SCAN_STAMP();   // low-pass + put
+    float bs[C1], bc[C1];       // this line's base pair
+    scan_dn2<C1>(P, n0, tp, bs);
+    scan_dn2<C1>(Q, n0, tp, bc);
+#pragma unroll
+    for (int q = 0; q < C1 / 4; ++q) {
+        *(lds_f4 *)(BS + n0 + 4 * q) = f4{bs[4 * q], bs[4 * q + 1], bs[4 * q + 2], bs[4 * q + 3]};
+        *(lds_f4 *)(BC + n0 + 4 * q) = f4{bc[4 * q], bc[4 * q + 1], bc[4 * q + 2], bc[4 * q + 3]};
+    }
+    CM_SCAN_STAMP();   // dn2 x 2, base pairs out
+    __syncthreads();
+    if (w < depth || !alive) return;
+
+    // ---- comb combination (DemodBack::combine) --------------------------------------------------------------------------
+    apply_frame_rotation(g, lc.frame, lk);
+    CM_SCAN_STAMP();   // barrier + lane constants
+    float y[C1];
+    if (k.bsf) {
+#pragma unroll
+        for (int i = 0; i < C1; ++i) y[i] = v[i] * k.luma_gain;
+    }
+    const int minavg = k.minavg;
+    auto combine_at = [&](const lds_float *b0s, const lds_float *b0c, int n, float &uo, float &vo) {
+        // the base pairs of this call and of the depth calls before it (the waves before this one) at sample n
+        const int wf = scan_wave_floats<C1>();
+        float u1 = fmaf_(lk.cu[0][0], b0s[n], lk.cu[0][1] * b0c[n]);
+        float v1 = fmaf_(lk.cv[0][0], b0s[n], lk.cv[0][1] * b0c[n]);
+        float u2 = 0.f, v2 = 0.f;
+        if (minavg) {
+            u2 = fmaf_(lk.cu2[0][0], b0s[n], lk.cu2[0][1] * b0c[n]);
+            v2 = fmaf_(lk.cv2[0][0], b0s[n], lk.cv2[0][1] * b0c[n]);
+        }
+#pragma unroll
+        for (int j = 1; j < 3; ++j) {
+            if (j > depth) continue;
+            const float ps = b0s[n - j * wf], pc = b0c[n - j * wf];
+            u1 = fmaf_(lk.cu[j][0], ps, fmaf_(lk.cu[j][1], pc, u1));
+            v1 = fmaf_(lk.cv[j][0], ps, fmaf_(lk.cv[j][1], pc, v1));
+            if (minavg) {
+                u2 = fmaf_(lk.cu2[j][0], ps, fmaf_(lk.cu2[j][1], pc, u2));
+                v2 = fmaf_(lk.cv2[j][0], ps, fmaf_(lk.cv2[j][1], pc, v2));
+            }
+        }
+        uo = minavg ? minavg_(u1, u2) : u1;
+        vo = minavg ? minavg_(v1, v2) : v1;
+    };
+#pragma unroll
+    for (int q = 0; q < C1 / 4; ++q) {
+        f4 ps[3], pc[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            ps[j] = pc[j] = f4{0.f, 0.f, 0.f, 0.f};
+            if (j <= depth) {
+                ps[j] = *(const lds_f4 *)(BS - j * scan_wave_floats<C1>() + n0 + 4 * q);
+                pc[j] = *(const lds_f4 *)(BC - j * scan_wave_floats<C1>() + n0 + 4 * q);
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float u1 = fmaf_(lk.cu[0][0], ps[0][e], lk.cu[0][1] * pc[0][e]);
+            float v1 = fmaf_(lk.cv[0][0], ps[0][e], lk.cv[0][1] * pc[0][e]);
+            float u2 = 0.f, v2 = 0.f;
+            if (minavg) {
+                u2 = fmaf_(lk.cu2[0][0], ps[0][e], lk.cu2[0][1] * pc[0][e]);
+                v2 = fmaf_(lk.cv2[0][0], ps[0][e], lk.cv2[0][1] * pc[0][e]);
+            }
+#pragma unroll
+            for (int j = 1; j < 3; ++j) {
+                if (j <= depth) {
+                    u1 = fmaf_(lk.cu[j][0], ps[j][e], fmaf_(lk.cu[j][1], pc[j][e], u1));
+                    v1 = fmaf_(lk.cv[j][0], ps[j][e], fmaf_(lk.cv[j][1], pc[j][e], v1));
+                    if (minavg) {
+                        u2 = fmaf_(lk.cu2[j][0], ps[j][e], fmaf_(lk.cu2[j][1], pc[j][e], u2));
+                        v2 = fmaf_(lk.cv2[j][0], ps[j][e], fmaf_(lk.cv2[j][1], pc[j][e], v2));
+                    }
+                }
+            }
+            u[4 * q + e] = minavg ? minavg_(u1, u2) : u1;
+            v[4 * q + e] = minavg ? minavg_(v1, v2) : v1;
+        }
+    }
+    CM_SCAN_STAMP();   // combination
+    // ---- back end (DemodBack::step): pre-correction low-pass of (u, v), re-modulation, notch, matrix ----------------------
+    {
+        // re-modulation carriers and the luma source row, asked for ahead of the pre-correction filter
+        f2 car2[C1];
+#pragma unroll
+        for (int i = 0; i < C1; ++i) car2[i] = *(const f2 *)(g.carrier2 + 2 * (n0 + i < W ? n0 + i : W - 1));
+        if (!k.bsf) {      // luma source: this call's row or the previous call's (comb.py:102), straight from memory
+            const int luma_row = ((g.luma_prev_bits >> lc.regime) & 1) ? lc.prev_row : lc.src_row;
+            const float *lp = g.in + lc.frame * g.in_frame_stride + (long long)luma_row * g.Wp;
+#pragma unroll
+            for (int q = 0; q < C1 / 4; ++q) {
+                f4 t = {0.f, 0.f, 0.f, 0.f};
+                if (n0 + 4 * q < g.Wp) t = *(const f4 *)(lp + n0 + 4 * q);
+                y[4 * q] = t.x; y[4 * q + 1] = t.y; y[4 * q + 2] = t.z; y[4 * q + 3] = t.w;
+            }
+        }
+        f2 wuv[C1];
+        float u_last, v_last;
+        combine_at(BS, BC, W - 1, u_last, v_last);
+#pragma unroll
+        for (int i = 0; i < C1; ++i) wuv[i] = n0 + i >= W ? f2{u_last, v_last} : f2{u[i], v[i]};
+        scan_iir2<C1>(wuv, k.pre, lane);
+        // the filtered pair of sample n7 is output n7 + s_p of the cascade: through P (two 1x-rate rows)
+        lds_float *PU = P, *PV = P + N1 + MG;
+        {
+            float s[C1];
+#pragma unroll
+            for (int i = 0; i < C1; ++i) s[i] = wuv[i].x;
+            scan_put<C1>(PU, s, n0, k.pre.shift);
+#pragma unroll
+            for (int i = 0; i < C1; ++i) s[i] = wuv[i].y;
+            scan_put<C1>(PV, s, n0, k.pre.shift);
+        }
+        CM_SCAN_STAMP();   // pre-correction low-pass + put
+        const bool strip = lk.sph != 0.f || lk.cph != 0.f;
+#pragma unroll
+        for (int q = 0; q < C1 / 4; ++q) {
+            const f4 tu = *(const lds_f4 *)(PU + n0 + 4 * q), tv = *(const lds_f4 *)(PV + n0 + 4 * q);
+            const float wu[4] = {tu.x, tu.y, tu.z, tu.w}, wv[4] = {tv.x, tv.y, tv.z, tv.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int i = 4 * q + e;
+                const f2 car = car2[i];
+                const float sn = fmaf_(lk.sph, car.x, lk.cph * car.y);
+                const float cs = fmaf_(lk.vcph, car.x, -(lk.vsph * car.y));
+                y[i] = y[i] - fmaf_(sn, wu[e], cs * wv[e]);
+            }
+        }
+        if (k.notch_gain != 0.f) {     // comb.py:54-55: luma[0 .. W) from a zero state, where the line re-modulates
+            float yn[C1];
+#pragma unroll
+            for (int i = 0; i < C1; ++i) yn[i] = n0 + i < W ? y[i] : 0.f;
+            scan_iir<C1>(yn, k.notch, lane);
+            if (strip) {
+#pragma unroll
+                for (int i = 0; i < C1; ++i) y[i] = yn[i] * k.notch_gain;
+            }
+        }
+    }
+    CM_SCAN_STAMP();   // re-modulation, notch
+    if (!lc.store_ok) return;
+    float *op = g.out + lc.frame * g.out_frame_stride + (long long)lc.out_row * g.out_row_stride;
+#pragma unroll
+    for (int q = 0; q < C1 / 4; ++q) {
+        if (n0 + 4 * q >= g.Wp) continue;
+        f4 o[3];
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+            o[p].x = fmaf_(k.m[3 * p], y[4 * q], fmaf_(k.m[3 * p + 1], u[4 * q], k.m[3 * p + 2] * v[4 * q]));
+            o[p].y = fmaf_(k.m[3 * p], y[4 * q + 1], fmaf_(k.m[3 * p + 1], u[4 * q + 1], k.m[3 * p + 2] * v[4 * q + 1]));
+            o[p].z = fmaf_(k.m[3 * p], y[4 * q + 2], fmaf_(k.m[3 * p + 1], u[4 * q + 2], k.m[3 * p + 2] * v[4 * q + 2]));
+            o[p].w = fmaf_(k.m[3 * p], y[4 * q + 3], fmaf_(k.m[3 * p + 1], u[4 * q + 3], k.m[3 * p + 2] * v[4 * q + 3]));
+            *(f4 *)(op + p * g.out_plane_stride + n0 + 4 * q) = o[p];
+        }
+    }
+#ifdef CM_DIAG
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    CM_SCAN_STAMP();
+    if (g.diag && lane == 0 && (int)blockIdx.x < 512) {
+        unsigned long long *d = g.diag + ((long long)blockIdx.x * NW + w) * 16;
+        for (int i = 0; i < sti && i < 14; ++i) d[i] = st[i];
+        d[14] = cm_realtime() - rt0;
+        d[15] = sti;
+    }
+#endif
+}
+
+}  // namespace cm
+#endif

@@ -42,6 +42,7 @@ class _DevicePlans(object):
 
     def __init__(self, create, destroy):
         self._create, self._destroy, self._plans = create, destroy, {}
+        self.on_create = None     # called with every new plan handle (Engine.set_small_batch re-applies its mode)
 
     def get(self, device):
         torch = _torch()
@@ -52,7 +53,12 @@ class _DevicePlans(object):
             with torch.cuda.device(index):
                 _native.check(self._create(ctypes.byref(handle)))
             self._plans[index] = handle
+            if self.on_create is not None:
+                self.on_create(handle)
         return handle
+
+    def handles(self):
+        return list(self._plans.values())
 
     def close(self):
         plans, self._plans = self._plans, {}
@@ -208,6 +214,17 @@ class Engine(_EngineBase):
         buf = ctypes.create_string_buffer(512)
         _native.lib().cm_plan_describe(self._plan, buf, 512)
         return buf.value.decode()
+
+    SMALL_BATCH = {'auto': 0, 'rows': 1, 'segments': 2, 'scan': 3}
+
+    def set_small_batch(self, mode):
+        """Pin how the decoder runs small batches (cm_plan_set_small_batch): 'auto' (default: the row-parallel scan kernel
+        below a few frames where the plan has one, else row segments), 'rows' (the streaming kernel on whole rows),
+        'segments', 'scan' (NotImplementedError where the plan's shape does not fit the scan kernel)."""
+        code = self.SMALL_BATCH[mode]
+        for handle in self._plans.handles():
+            _native.check(_native.lib().cm_plan_set_small_batch(handle, code))
+        self._plans.on_create = (lambda h: _native.check(_native.lib().cm_plan_set_small_batch(h, code))) if code else None
 
     # ---- frames -------------------------------------------------------------------------------
     def demodulate_frames(self, composite, first_frame=0, out=None):

@@ -355,6 +355,14 @@ int cm_comb_wrap_demodulate_run(const cm_plan *inner, const cm_plan *first, cons
                                 const float *composite, float *rgb, int32_t n_calls, int32_t frame, int32_t first_line, int32_t k0,
                                 void *stream);
 
+/* Small batches.  The streaming kernels give a scan line to a lane, so one launch lasts as long as one row takes however few
+ * rows there are.  Below CM_SCAN_MAX_CALLS calls per launch (a few frames; the per-row protocol) the library therefore runs
+ * the row-parallel kernel - one wavefront per scan line, the recursive filters as a scan over the lanes (csrc/cm_scan_kernels.h) -
+ * where the plan's shape fits it (float rows up to ~1000 samples), else it cuts the rows into segments that workgroups walk
+ * side by side.  Results agree with the row walk to ~1e-7 of full scale (tests: test_small_batch_modes).  This switch pins
+ * one of the three for tests and measurements; CM_ERR_UNSUPPORTED when the plan has no scan kernel. */
+enum { CM_SMALL_BATCH_AUTO = 0, CM_SMALL_BATCH_ROWS = 1, CM_SMALL_BATCH_SEGMENTS = 2, CM_SMALL_BATCH_SCAN = 3 };
+int cm_plan_set_small_batch(const cm_plan *plan, int32_t mode);
 /* Name, main-loop instruction mix and launch geometry of the dominant kernel of the last
  * cm_demodulate_frames call on this plan (for bench.py / profiling); returns bytes written. */
 int cm_plan_describe(const cm_plan *plan, char *buf, int32_t buf_len);
