@@ -822,6 +822,8 @@ static bool build_scan_k(const cm_plan_desc &d, bool pald, bool bsf, int depth, 
 static int scan_chunk_for(const cm_plan_desc &d) {
     const int lp = d.pipeline == CM_PIPE_PAL_D ? d.pald_lp.shift : d.demod_lp.shift;
     const int s2 = std::max(std::max(d.extract2x.shift, lp), d.remove2x.shift);
+    // chunks of 24 and 32 samples (rows up to 1920) compile to more than 256 VGPRs and measured wrong results on the device
+    // (profiles/r03_scan_notes.txt): not instantiated - such rows run in segments
     for (int c1 : {12, 16})
         if (2 * d.width + s2 <= 128 * c1 && d.width + d.precorrect.shift <= 64 * c1) return c1;
     return 0;

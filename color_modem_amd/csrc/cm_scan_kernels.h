@@ -6,7 +6,7 @@
 // (ref qam.py:34-58, pal.py:71-77, 117-125, comb.py:47-59, utils.py:28-36) with the ROW spread over the 64 lanes of a wavefront:
 //
 //   lane l owns the samples [l C1, (l + 1) C1) of every 1x-rate signal of the row and [2 l C1, 2 (l + 1) C1) of every 2x-rate one,
-//   in registers; C1 = 12 (rows up to ~740 samples), 16 (~1000), 24, 32 (1920 at 2 waves per workgroup).
+//   in registers; C1 = 12 (rows up to ~740 samples) or 16 (~1000).
 //
 //   * resample_poly up / down by 2 (41-tap half-band FIR): every lane reads its window (+- 10 / 19 samples into the neighbours'
 //     chunks) from an LDS copy of the row with zero margins and evaluates its outputs directly - 20 FMAs per output, no state;

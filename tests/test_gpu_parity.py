@@ -701,6 +701,24 @@ def test_scan_kernel_batches():
         assert float((out - ref[:n]).abs().max() / ref.abs().max()) < 2e-6, n
 
 
+@pytest.mark.parametrize('size', [(720, 256), (960, 128)])
+def test_scan_kernel_ignores_stale_lds(size):
+    """The scan kernel keeps every signal of a row in LDS rows with margins it must have written itself: a launch that leaves
+    NaNs all over the LDS of every CU (the streaming kernel on NaN frames) in front of it must not change a bit of its result."""
+    import torch
+    eng = image.ImageModem(stacks.make('pal_d', size))._engine()
+    comp = torch.from_numpy(testing.synthetic_composite(1, size[1], size[0], seed=5)).cuda()
+    eng.set_small_batch('scan')
+    clean = eng.demodulate_frames(comp, first_frame=1).cpu().numpy()
+    assert numpy.isfinite(clean).all()
+    poison = torch.full((64, size[1], size[0]), float('nan'), device='cuda')
+    for _ in range(3):
+        eng.set_small_batch('rows')
+        eng.demodulate_frames(poison, first_frame=0)
+        eng.set_small_batch('scan')
+        assert numpy.array_equal(eng.demodulate_frames(comp, first_frame=1).cpu().numpy(), clean)
+
+
 # ---- comb wrappers around the PAL delay-line decoders (color_modem_amd/wrapped.py, csrc/cm_wrap_kernels.h) -----------------
 @pytest.mark.parametrize('stack,size,first', [('simple3d_pald', (720, 40), 1), ('simple_pald', (720, 21), 2), ('simple3d_pal3d', (720, 24), 3),
                                               ('simple3d_pald_minavg', (704, 12), 0), ('simple3d_pald_notch', (720, 16), 2),
