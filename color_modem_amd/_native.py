@@ -19,7 +19,7 @@ CM_OK, CM_ERR_INVALID, CM_ERR_UNSUPPORTED, CM_ERR_NO_DEVICE, CM_ERR_LAUNCH = 0, 
 SYMBOLS = ('cm_last_error', 'cm_abi_version', 'cm_device_count', 'cm_plan_create', 'cm_plan_destroy',
            'cm_demodulate_frames', 'cm_modulate_frames', 'cm_demodulate_frames_u8', 'cm_modulate_frames_u8', 'cm_demodulate_run',
            'cm_modulate_run',
-           'cm_plan_describe', 'cm_plan_set_small_batch',
+           'cm_plan_describe', 'cm_plan_set_small_batch', 'cm_set_pointer_check',
            'cm_mac_plan_create', 'cm_mac_plan_destroy',
            'cm_mac_modulate_frames', 'cm_mac_demodulate_frames', 'cm_mac_modulate_frames_u8', 'cm_mac_demodulate_frames_u8',
            'cm_mac_modulate_run', 'cm_mac_demodulate_run',
@@ -78,6 +78,8 @@ def lib():
     L.cm_modulate_run.argtypes = [vp, vp, vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, vp]
     L.cm_plan_describe.argtypes = [vp, ctypes.c_char_p, ctypes.c_int32]
     L.cm_plan_set_small_batch.argtypes = [vp, ctypes.c_int32]
+    L.cm_set_pointer_check.argtypes = [ctypes.c_int32]
+    L.cm_set_pointer_check.restype = None
     L.cm_mac_plan_create.argtypes = [ctypes.POINTER(MacDesc), ctypes.POINTER(vp)]
     L.cm_mac_plan_destroy.argtypes = [vp]
     L.cm_mac_plan_destroy.restype = None

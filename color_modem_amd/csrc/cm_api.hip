@@ -38,7 +38,11 @@ int fail(int code, const std::string &msg) {
 // A plan's tables live on the device that was current in cm_*_plan_create.  Every compute entry point checks that this
 // device is still the current one and that both image buffers are device memory of it: a plan used under another current
 // device, or fed another GPU's pointers, would otherwise fault inside the kernel (or run over peer access) instead of
-// returning an error.  -DCM_NO_POINTER_CHECK drops the two hipPointerGetAttributes calls (a few microseconds per call).
+// returning an error.  Rejected: device memory of another GPU, pageable host memory, pointers the runtime cannot classify
+// (a kernel fault takes more than the process down on a shared node).  Pinned / mapped host memory and managed memory are
+// device-accessible and pass.  cm_set_pointer_check(0) drops the two hipPointerGetAttributes calls for callers whose
+// allocator the runtime does not know (a few microseconds per call less, too); -DCM_NO_POINTER_CHECK compiles them out.
+static bool g_pointer_check = true;
 int check_device(int plan_device, const void *a, const void *b) {
     int cur = -1;
     if (hipGetDevice(&cur) != hipSuccess) return fail(CM_ERR_NO_DEVICE, "hipGetDevice failed");
@@ -48,17 +52,18 @@ int check_device(int plan_device, const void *a, const void *b) {
 #ifndef CM_NO_POINTER_CHECK
     const void *ptrs[2] = {a, b};
     for (const void *ptr : ptrs) {
-        if (!ptr) continue;
+        if (!ptr || !g_pointer_check) continue;
         hipPointerAttribute_t at;
         if (hipPointerGetAttributes(&at, ptr) != hipSuccess) {
             (void)hipGetLastError();
-            return fail(CM_ERR_INVALID, "an image buffer is not device memory (the ABI takes device pointers)");
+            return fail(CM_ERR_INVALID, "an image buffer is not memory the HIP runtime knows as device-accessible (the ABI takes device "
+                                        "pointers; cm_set_pointer_check(0) skips this check)");
         }
         if (at.type == hipMemoryTypeDevice && at.device != plan_device)
             return fail(CM_ERR_INVALID, "an image buffer lives on HIP device " + std::to_string(at.device) + ", the plan on device " +
                                             std::to_string(plan_device));
-        if (at.type == hipMemoryTypeHost || at.type == hipMemoryTypeUnregistered)
-            return fail(CM_ERR_INVALID, "an image buffer is host memory (the ABI takes device pointers)");
+        if (at.type == hipMemoryTypeUnregistered)
+            return fail(CM_ERR_INVALID, "an image buffer is pageable host memory (the ABI takes device pointers)");
     }
 #endif
     return CM_OK;
@@ -2152,6 +2157,7 @@ int cm_comb_wrap_demodulate_run(const cm_plan *inner, const cm_plan *first, cons
 extern "C" void cm_diag_set_buffer(unsigned long long *dev) { g_diag = dev; }
 #endif
 
+void cm_set_pointer_check(int32_t on) { g_pointer_check = on != 0; }
 int cm_plan_set_small_batch(const cm_plan *p, int32_t mode) {
     if (!p) return fail(CM_ERR_INVALID, "null argument");
     if (mode < CM_SMALL_BATCH_AUTO || mode > CM_SMALL_BATCH_SCAN) return fail(CM_ERR_INVALID, "unknown small-batch mode");

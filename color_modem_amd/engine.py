@@ -188,9 +188,15 @@ class _EngineBase(object):
         else:
             _check_out(out, out_shape, out_dtype, x.device)
         plan_handle = self._plans.get(x.device)
-        with torch.cuda.device(x.device):
-            stream = torch.cuda.current_stream(x.device).cuda_stream
-            _native.check(fn(plan_handle, x.data_ptr(), out.data_ptr(), *(tuple(args) + (stream,))))
+        if x.device.index == torch.cuda.current_device():      # (the usual case: no device switch around the launch)
+            stream = torch.cuda.current_stream().cuda_stream
+            rc = fn(plan_handle, x.data_ptr(), out.data_ptr(), *args, stream)
+        else:
+            with torch.cuda.device(x.device):
+                stream = torch.cuda.current_stream(x.device).cuda_stream
+                rc = fn(plan_handle, x.data_ptr(), out.data_ptr(), *args, stream)
+        if rc:
+            _native.check(rc)
         return out.cpu().numpy() if was_numpy else out
 
 

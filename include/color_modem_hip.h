@@ -355,6 +355,11 @@ int cm_comb_wrap_demodulate_run(const cm_plan *inner, const cm_plan *first, cons
                                 const float *composite, float *rgb, int32_t n_calls, int32_t frame, int32_t first_line, int32_t k0,
                                 void *stream);
 
+/* Every compute entry point checks that the plan's device is the current one and that both image buffers are memory the HIP
+ * runtime knows as accessible from it (CM_ERR_INVALID for another GPU's memory, pageable host memory and pointers the runtime
+ * cannot classify; pinned / mapped host memory and managed memory pass).  cm_set_pointer_check(0) switches the pointer
+ * classification off for the process - for allocators the runtime does not know - and cm_set_pointer_check(1) on again. */
+void cm_set_pointer_check(int32_t on);
 /* Small batches.  The streaming kernels give a scan line to a lane, so one launch lasts as long as one row takes however few
  * rows there are.  Below CM_SCAN_MAX_CALLS calls per launch (a few frames; the per-row protocol) the library therefore runs
  * the row-parallel kernel - one wavefront per scan line, the recursive filters as a scan over the lanes (csrc/cm_scan_kernels.h) -

@@ -14,7 +14,7 @@ def timeit(fn, reps=5):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(); fn(); e1.record(); torch.cuda.synchronize(); ts.append(e0.elapsed_time(e1))
     return sorted(ts)[len(ts) // 2]
-for stack, size, direction in [('pal_d', (720, 576), 'demod'), ('pal_s', (720, 576), 'demod'), ('pal_3d', (720, 576), 'demod'),
+for stack, size, direction in [('pal_d', (720, 576), 'demod'), ('pal_d', (768, 576), 'demod'), ('pal_s', (720, 576), 'demod'), ('pal_3d', (720, 576), 'demod'),
                                ('ntsc', (720, 480), 'demod'), ('ntsc_comb', (720, 480), 'demod'), ('ntsc_comb_3d', (720, 480), 'demod'),
                                ('secam', (720, 576), 'demod'), ('secam', (720, 576), 'mod'), ('secam_avg', (720, 576), 'mod'),
                                ('pal_s', (720, 576), 'mod'), ('ntsc', (720, 480), 'mod'),

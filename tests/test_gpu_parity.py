@@ -634,6 +634,15 @@ def test_plan_refuses_host_pointers():
     rc = _native.lib().cm_demodulate_frames(eng._plan, host_in.ctypes.data, host_out.ctypes.data, 1, 0, None)
     assert rc == _native.CM_ERR_INVALID
     assert b'device' in _native.lib().cm_last_error()
+    # pinned host memory is device-accessible: it passes the check and the kernel runs on it over the bus
+    import torch
+    comp = testing.synthetic_composite(1, 8, 720, seed=2)
+    pin_in = torch.from_numpy(comp).pin_memory()
+    pin_out = torch.zeros((1, 3, 8, 720), dtype=torch.float32).pin_memory()
+    rc = _native.lib().cm_demodulate_frames(eng._plan, pin_in.data_ptr(), pin_out.data_ptr(), 1, 0, None)
+    torch.cuda.synchronize()
+    assert rc == _native.CM_OK, _native.lib().cm_last_error()
+    assert numpy.array_equal(pin_out.numpy(), eng.demodulate_frames(comp, 0))
 
 
 # ---- small batches (cm_plan_set_small_batch): the row-parallel scan kernel (csrc/cm_scan_kernels.h), rows cut into segments

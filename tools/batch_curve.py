@@ -43,6 +43,13 @@ for F in FRAMES:
     except Exception as e:
         print('graph capture failed:', e)
     print('%6d %10.4f %12.1f %10.2f %12.4f' % (F, ms, ms * 1e3 / F, F * W * H / ms / 1e6, gms), flush=True)
+# what the host pays per call (no synchronisation: the launch queue absorbs the kernels)
+comp = base[:1].contiguous(); out = torch.empty((1, 3, H, W), dtype=torch.float32, device='cuda')
+for _ in range(50): eng.demodulate_frames(comp, 0, out=out)
+torch.cuda.synchronize(); t0 = time.perf_counter()
+for _ in range(2000): eng.demodulate_frames(comp, 0, out=out)
+t1 = time.perf_counter(); torch.cuda.synchronize(); t2 = time.perf_counter()
+print('one frame, 2000 calls back to back: host %.1f us per call to enqueue, %.1f us per call until the last one has finished' % ((t1 - t0) / 2000 * 1e6, (t2 - t0) / 2000 * 1e6))
 # host-visible latency of one frame: numpy in -> numpy out (pageable memory, includes both PCIe copies), and the PIL image path
 comp1 = testing.synthetic_composite(1, H, W)
 for _ in range(3): im.demodulate_frames(comp1, 0)
