@@ -22,7 +22,7 @@ import ctypes
 import numpy
 import scipy.signal
 
-CM_ABI_VERSION = 5
+CM_ABI_VERSION = 6
 CM_SECAM_PRESENT, CM_SECAM_FLOAT64 = 1, 2      # cm_secam_desc.present (include/color_modem_hip.h)
 CM_PIPE_QAM, CM_PIPE_PAL_D, CM_PIPE_SECAM = 1, 2, 3
 CM_MAX_SECTIONS = 4

@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define CM_ABI_VERSION 5
+#define CM_ABI_VERSION 6
 
 enum cm_status {
     CM_OK = 0,
