@@ -181,6 +181,8 @@ struct cm_plan {
     int seg_warm = 1 << 30;        // samples a row segment enters the stream early (segment_warmup)
     // small batches: one wavefront per scan line (cm_scan_kernels.h); null / 0 where the plan's shape does not fit it
     ScanK *scan_main = nullptr, *scan_first = nullptr;
+    ScanModK *scan_mod = nullptr;  // the QAM modulator's (qam_mod_scan_kernel)
+    int scan_mod_c1 = 0;
     int scan_c1 = 0, scan_depth = 0;
     mutable int small_batch = CM_SMALL_BATCH_AUTO;   // cm_plan_set_small_batch
     bool pair = false;             // wave-pair kernel (two wavefronts per 64 calls)
@@ -856,6 +858,30 @@ static void make_scan(cm_plan *p, const cm_plan_desc &d) {
     p->scan_c1 = c1;
     p->scan_depth = depth;
 }
+// the row-parallel modulator of small batches (cm_scan_kernels.h: qam_mod_scan_kernel)
+static void make_scan_mod(cm_plan *p, const cm_plan_desc &d) {
+    if (p->secam || !p->mod_fn || d.precorrect.n_sections > 2 || d.precorrect.shift < 0 || d.precorrect.shift > kScanMaxShift) return;
+    int c1 = 0;
+    for (int c : {12, 16, 24, 32})
+        if (d.width + d.precorrect.shift <= 64 * c) { c1 = c; break; }
+    if (!c1) return;
+    SosK<float, 2> pre;
+    double g_pre;
+    std::string err;
+    if (!convert_sos<float, 2>(d.precorrect, FORM_GEN, pre, g_pre, err, "precorrect", true)) return;
+    ScanModK k;
+    std::memset(&k, 0, sizeof k);
+    k.width = d.width;
+    k.depth = p->mod_depth;
+    k.c1 = c1;
+    for (int i = 0; i < 9; ++i) k.e[i] = (float)d.encode_matrix[i];
+    fill_scan_filter(d.precorrect, pre.na1, pre.na2, pre.b1, pre.b2, c1, k.pre);
+    if (hipMalloc((void **)&p->scan_mod, sizeof k) != hipSuccess || hipMemcpy(p->scan_mod, &k, sizeof k, hipMemcpyHostToDevice) != hipSuccess) {
+        p->scan_mod = nullptr;
+        return;
+    }
+    p->scan_mod_c1 = c1;
+}
 template <int C1, int NW>
 static int launch_scan(const cm_plan *p, const Geom &gm, const Geom &gf, bool with_first, hipStream_t stream) {
     const size_t lds = sizeof(float) * (size_t)NW * scan_wave_floats<C1>();
@@ -1058,6 +1084,7 @@ int cm_plan_create(const cm_plan_desc *desc, cm_plan **out) {
     } else {
         make_scan(p, *desc);
     }
+    if (have_mod) make_scan_mod(p, *desc);
     if (!have_demod && !have_mod) {
         cm_plan_destroy(p);
         return fail(CM_ERR_UNSUPPORTED, err);
@@ -1075,6 +1102,7 @@ void cm_plan_destroy(cm_plan *p) {
     if (p->blk_tiles) (void)hipFree(p->blk_tiles);
     if (p->scan_main) (void)hipFree(p->scan_main);
     if (p->scan_first) (void)hipFree(p->scan_first);
+    if (p->scan_mod) (void)hipFree(p->scan_mod);
     if (p->main.lanes) (void)hipFree(p->main.lanes);
     if (p->first.lanes) (void)hipFree(p->first.lanes);
     if (p->mod_lanes) (void)hipFree(p->mod_lanes);
@@ -1237,6 +1265,26 @@ int cm_demodulate_run(const cm_plan *p, const float *composite, float *rgb, int3
     });
 }
 
+extern "C++" {
+template <int C1, int NW>
+static int launch_scan_mod(const cm_plan *p, const Geom &g, hipStream_t stream) {
+    const size_t lds = sizeof(float) * (size_t)NW * scan_mod_wave_floats<C1>();
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void *)qam_mod_scan_kernel<C1, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return fail(CM_ERR_LAUNCH, "hipFuncSetAttribute(max dynamic LDS) failed for the modulator's scan kernel");
+        attr_set = true;
+    }
+    const long long blocks = (g.total_calls + NW - 1) / NW;
+    hipLaunchKernelGGL((qam_mod_scan_kernel<C1, NW>), dim3((int)blocks), dim3(64 * NW), lds, stream, g, p->scan_mod);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(CM_ERR_LAUNCH, std::string("qam_mod_scan_kernel launch: ") + hipGetErrorString(e));
+    return CM_OK;
+}
+}  // extern "C++"
+#ifndef CM_SCAN_MOD_MAX_CALLS
+#define CM_SCAN_MOD_MAX_CALLS 40000
+#endif
 static int run_mod(const cm_plan *p, Geom g, hipStream_t stream, bool u8 = false) {
     if (p->secam) return run_secam_mod(p, g, stream, u8);
     if (!p->mod_fn) return fail(CM_ERR_UNSUPPORTED, "this plan has no modulator");
@@ -1248,6 +1296,15 @@ static int run_mod(const cm_plan *p, Geom g, hipStream_t stream, bool u8 = false
     long long blocks = (g.total_calls + (64 - p->mod_depth) - 1) / (64 - p->mod_depth);
     if (blocks <= 0) return CM_OK;
     if (blocks > 0x7fffffffLL) return fail(CM_ERR_INVALID, "batch too large for one launch");
+    const int mode = p->small_batch;
+    if (!u8 && p->scan_mod && (mode == CM_SMALL_BATCH_SCAN || (mode == CM_SMALL_BATCH_AUTO && g.total_calls <= CM_SCAN_MOD_MAX_CALLS))) {
+        switch (p->scan_mod_c1) {
+            case 12: return launch_scan_mod<12, 4>(p, g, stream);
+            case 16: return launch_scan_mod<16, 4>(p, g, stream);
+            case 24: return launch_scan_mod<24, 4>(p, g, stream);
+            default: return launch_scan_mod<32, 4>(p, g, stream);
+        }
+    }
     return (u8 ? p->mod_fn_u8 : p->mod_fn)(g, p->mod_k.data(), (int)blocks, stream);
 }
 
@@ -2161,7 +2218,7 @@ void cm_set_pointer_check(int32_t on) { g_pointer_check = on != 0; }
 int cm_plan_set_small_batch(const cm_plan *p, int32_t mode) {
     if (!p) return fail(CM_ERR_INVALID, "null argument");
     if (mode < CM_SMALL_BATCH_AUTO || mode > CM_SMALL_BATCH_SCAN) return fail(CM_ERR_INVALID, "unknown small-batch mode");
-    if (mode == CM_SMALL_BATCH_SCAN && !p->scan_main) return fail(CM_ERR_UNSUPPORTED, "the scan kernel does not serve this plan");
+    if (mode == CM_SMALL_BATCH_SCAN && !p->scan_main && !p->scan_mod) return fail(CM_ERR_UNSUPPORTED, "the scan kernels do not serve this plan");
     p->small_batch = mode;
     return CM_OK;
 }

@@ -531,5 +531,123 @@ __global__ __launch_bounds__(64 * NW) void demod_scan_kernel(const Geom gm, cons
 #endif
 }
 
+// =============================================================================================================================
+// The QAM modulators (ref qam.py:20-32 behind pal.py:48-52 / ntsc.py:43-45, comb.py:141-152) the same way: one wavefront per call,
+// NW independent calls per workgroup.  (y, u, v) = e (r, g, b) of this lane's samples straight from memory - with the previous
+// call's row mixed in for ColorAveragingModem (row weights of ModLaneK) -, the pre-correction low-pass of (u, v) as one packed
+// scan, its output offset through LDS, composite[n] = y[n] + sin(phi + 2 n cps) F(u)[n] + (+-cos) F(v)[n] (QamModCore::step).
+// =============================================================================================================================
+struct ScanModK {
+    int32_t width, depth, c1, pad;
+    float e[9];
+    ScanFilter pre;                // 1x rate: chunk = c1
+};
+typedef const __attribute__((address_space(4))) ScanModK const_ScanModK;
+template <int C1> constexpr int scan_mod_wave_floats() { return 2 * (64 * C1 + 2 * kScanMargin); }
+
+template <int C1, int NW>
+__global__ __launch_bounds__(64 * NW) void qam_mod_scan_kernel(const Geom g, const ScanModK *km) {
+    constexpr int N1 = 64 * C1, MG = kScanMargin;
+    extern __shared__ __attribute__((aligned(16))) float scan_lds[];
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    const_ScanModK &k = *(const_ScanModK *)km;
+    const long long c = (long long)blockIdx.x * NW + w;
+    if (c >= g.total_calls) return;                       // (no barrier in this kernel)
+    const LaneCall lc = locate_call_at(g, c, true);
+    const LaneCall lp = locate_call_at(g, c > 0 ? c - 1 : 0, true);      // the previous call of the list (line averaging)
+    lds_float *PU = (lds_float *)scan_lds + w * scan_mod_wave_floats<C1>() + MG, *PV = PU + N1 + 2 * MG;
+    const int W = g.W, n0 = lane * C1;
+    ModLaneK<float> lk;
+    {
+        const int fmod = (int)((g.first_frame + lc.frame) % g.cycle);
+        lk = ((const ModLaneK<float> *)g.lanes)[((long long)fmod * 3 + lc.regime) * g.n_lines + lc.line];
+        float rc, rs;
+        if (frame_turn(g, lc.frame, rc, rs)) {
+            turn(lk.cph, lk.sph, rc, rs);
+            turn(lk.vcph, lk.vsph, rc, rs);
+        }
+    }
+    const long long row_stride = g.in_row_stride ? g.in_row_stride : g.W;
+    const float *rp = g.in + lc.frame * g.in_frame_stride + (long long)lc.src_row * row_stride;
+    const float *rq = g.in + lp.frame * g.in_frame_stride + (long long)lp.src_row * row_stride;
+    const int depth = k.depth;
+    f2 car2[C1];
+#pragma unroll
+    for (int i = 0; i < C1; ++i) car2[i] = *(const f2 *)(g.carrier2 + 2 * (n0 + i < W ? n0 + i : W - 1));
+    // (y, u, v) of one sample of the call (QamModCore's caller, cm_mod_kernels.h: the same operation order)
+    auto yuv_of = [&](float r, float gg, float b, float rr, float gr, float br, float &y, float &u, float &v) {
+        y = fmaf_(k.e[0], r, fmaf_(k.e[1], gg, k.e[2] * b));
+        u = fmaf_(k.e[3], r, fmaf_(k.e[4], gg, k.e[5] * b));
+        v = fmaf_(k.e[6], r, fmaf_(k.e[7], gg, k.e[8] * b));
+        if (depth >= 1) {
+            const float yp = fmaf_(k.e[0], rr, fmaf_(k.e[1], gr, k.e[2] * br));
+            const float up = fmaf_(k.e[3], rr, fmaf_(k.e[4], gr, k.e[5] * br));
+            const float vp = fmaf_(k.e[6], rr, fmaf_(k.e[7], gr, k.e[8] * br));
+            y = fmaf_(lk.wy0, y, lk.wy1 * yp);
+            u = fmaf_(lk.wc0, u, lk.wc1 * up);
+            v = fmaf_(lk.wc0, v, lk.wc1 * vp);
+        }
+    };
+    float y[C1];
+    f2 uv[C1];
+#pragma unroll
+    for (int q = 0; q < C1 / 4; ++q) {
+        const int n = n0 + 4 * q;
+        f4 a[3], b[3];
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+            a[p] = b[p] = f4{0.f, 0.f, 0.f, 0.f};
+            if (n < g.Wp) {
+                a[p] = *(const f4 *)(rp + p * g.in_plane_stride + n);
+                if (depth >= 1) b[p] = *(const f4 *)(rq + p * g.in_plane_stride + n);
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float yy, uu, vv;
+            yuv_of(a[0][e], a[1][e], a[2][e], b[0][e], b[1][e], b[2][e], yy, uu, vv);
+            y[4 * q + e] = yy;
+            uv[4 * q + e] = f2{uu, vv};
+        }
+    }
+    {   // FilterFunction pads with the last sample (utils.py:31-33): (u, v)[W - 1], by every lane
+        float yl, ul, vl;
+        const float *a = rp + (W - 1), *b = rq + (W - 1);
+        yuv_of(a[0], a[g.in_plane_stride], a[2 * g.in_plane_stride], depth >= 1 ? b[0] : 0.f, depth >= 1 ? b[g.in_plane_stride] : 0.f,
+               depth >= 1 ? b[2 * g.in_plane_stride] : 0.f, yl, ul, vl);
+        if (n0 + C1 > W) {
+#pragma unroll
+            for (int i = 0; i < C1; ++i) uv[i] = n0 + i >= W ? f2{ul, vl} : uv[i];
+        }
+    }
+    scan_iir2<C1>(uv, k.pre, lane);
+    {
+        float s[C1];
+#pragma unroll
+        for (int i = 0; i < C1; ++i) s[i] = uv[i].x;
+        scan_put<C1>(PU, s, n0, k.pre.shift);
+#pragma unroll
+        for (int i = 0; i < C1; ++i) s[i] = uv[i].y;
+        scan_put<C1>(PV, s, n0, k.pre.shift);
+    }
+    if (!lc.store_ok) return;
+    float *op = g.out + lc.frame * g.out_frame_stride + (long long)lc.out_row * g.out_row_stride;
+#pragma unroll
+    for (int q = 0; q < C1 / 4; ++q) {
+        if (n0 + 4 * q >= g.Wp) continue;
+        const f4 tu = *(const lds_f4 *)(PU + n0 + 4 * q), tv = *(const lds_f4 *)(PV + n0 + 4 * q);
+        f4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const f2 car = car2[4 * q + e];
+            const float sn = fmaf_(lk.sph, car.x, lk.cph * car.y);
+            const float cs = fmaf_(lk.vcph, car.x, -(lk.vsph * car.y));
+            o[e] = y[4 * q + e] + fmaf_(sn, tu[e], cs * tv[e]);
+        }
+        *(f4 *)(op + n0 + 4 * q) = o;
+    }
+}
+
 }  // namespace cm
 #endif

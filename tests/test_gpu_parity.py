@@ -671,10 +671,10 @@ def test_small_batch_modes(stack, enc, size):
     for mode in ('rows', 'segments', 'scan', 'auto'):
         try:
             eng.set_small_batch(mode)
+            got[mode] = [im.demodulate_frames(comp[i:i + 1], first_frame=1 + i)[0] for i in range(2)]
         except NotImplementedError:
             assert mode == 'scan' and 2 * size[0] > 2040, (stack, size)     # rows beyond the chunk sizes this build carries
             continue
-        got[mode] = [im.demodulate_frames(comp[i:i + 1], first_frame=1 + i)[0] for i in range(2)]
         for i in range(2):
             assert stacks.rel_err(got[mode][i], want[i]) < TOL, (stack, mode, i)
             assert stacks.rel_err(got[mode][i], got['rows'][i]) < 2e-6, (stack, mode, i)
@@ -708,6 +708,34 @@ def test_scan_kernel_batches():
     for n in (1, 3, 37, 100):
         out = eng.demodulate_frames(comp[:n].contiguous(), first_frame=3)
         assert float((out - ref[:n]).abs().max() / ref.abs().max()) < 2e-6, n
+
+
+@pytest.mark.parametrize('stack,size', [('pal_s', (720, 576)), ('ntsc', (720, 480)), ('pal_avg', (720, 64)), ('ntsc_avg', (704, 16)),
+                                        ('ntsc_a', (720, 40)), ('pal_s', (1280, 32)), ('ntsc', (1920, 16)), ('pal_s', (722, 20)),
+                                        ('pal_d', (768, 33))])
+def test_small_batch_modes_modulate(stack, size):
+    """The encoders of small batches: one wavefront per call (qam_mod_scan_kernel) against the streaming modulator on whole rows
+    and the float64 oracle; 3 frames, and the same through a batch of 70 frames (beyond the hand-over point)."""
+    import torch
+    from oracle import cm_oracle
+    modem = stacks.make(stack, size)
+    eng = image.ImageModem(modem)._engine()
+    rgb = testing.synthetic_rgb(3, size[1], size[0], seed=21 + size[0])
+    want = cm_oracle.modulate_frames_f32(modem, rgb, first_frame=2, n_threads=8)
+    got = {}
+    for mode in ('rows', 'scan', 'auto'):
+        eng.set_small_batch(mode)
+        got[mode] = eng.modulate_frames(rgb, first_frame=2)
+        for i in range(3):
+            assert stacks.rel_err(got[mode][i], want[i]) < TOL, (stack, mode, i)
+            assert stacks.rel_err(got[mode][i], got['rows'][i]) < 1e-6, (stack, mode, i)
+    if size[1] <= 64:
+        big = torch.from_numpy(rgb).cuda().repeat(24, 1, 1, 1)[:70].contiguous()
+        eng.set_small_batch('scan')
+        a = eng.modulate_frames(big, first_frame=2)
+        eng.set_small_batch('rows')
+        b = eng.modulate_frames(big, first_frame=2)
+        assert float((a - b).abs().max() / b.abs().max()) < 1e-6
 
 
 @pytest.mark.parametrize('size', [(720, 256), (960, 128)])
