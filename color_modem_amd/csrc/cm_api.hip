@@ -829,9 +829,7 @@ static bool build_scan_k(const cm_plan_desc &d, bool pald, bool bsf, int depth, 
 static int scan_chunk_for(const cm_plan_desc &d) {
     const int lp = d.pipeline == CM_PIPE_PAL_D ? d.pald_lp.shift : d.demod_lp.shift;
     const int s2 = std::max(std::max(d.extract2x.shift, lp), d.remove2x.shift);
-    // chunks of 24 and 32 samples (rows up to 1920) compile to more than 256 VGPRs and measured wrong results on the device
-    // (profiles/r03_scan_notes.txt): not instantiated - such rows run in segments
-    for (int c1 : {12, 16})
+    for (int c1 : {12, 16, 24, 32})
         if (2 * d.width + s2 <= 128 * c1 && d.width + d.precorrect.shift <= 64 * c1) return c1;
     return 0;
 }
@@ -929,7 +927,9 @@ int run_plan(const cm_plan *p, Geom gm, Geom gf, bool with_first, hipStream_t st
     const int mode = p->small_batch;
     if (!u8 && p->scan_main && (mode == CM_SMALL_BATCH_SCAN || (mode == CM_SMALL_BATCH_AUTO && gm.total_calls <= CM_SCAN_MAX_CALLS))) {
         if (p->scan_c1 == 12) return launch_scan<12, 4>(p, gm, gf, with_first, stream);
-        return launch_scan<16, 4>(p, gm, gf, with_first, stream);
+        if (p->scan_c1 == 16) return launch_scan<16, 4>(p, gm, gf, with_first, stream);
+        if (p->scan_c1 == 24) return launch_scan<24, 3>(p, gm, gf, with_first, stream);
+        return launch_scan<32, 3>(p, gm, gf, with_first, stream);
     }
     if (mode == CM_SMALL_BATCH_SCAN) return fail(CM_ERR_UNSUPPORTED, "the scan kernel does not serve this plan / this entry point");
     int seg_len = 0;

@@ -6,7 +6,7 @@
 // (ref qam.py:34-58, pal.py:71-77, 117-125, comb.py:47-59, utils.py:28-36) with the ROW spread over the 64 lanes of a wavefront:
 //
 //   lane l owns the samples [l C1, (l + 1) C1) of every 1x-rate signal of the row and [2 l C1, 2 (l + 1) C1) of every 2x-rate one,
-//   in registers; C1 = 12 (rows up to ~740 samples) or 16 (~1000).
+//   in registers; C1 = 12 (rows up to ~740 samples), 16 (~1000), 24 (~1500), 32 (~2030).
 //
 //   * resample_poly up / down by 2 (41-tap half-band FIR): every lane reads its window (+- 10 / 19 samples into the neighbours'
 //     chunks) from an LDS copy of the row with zero margins and evaluates its outputs directly - 20 FMAs per output, no state;
@@ -219,8 +219,11 @@ __device__ __forceinline__ Geom select_geom(const Geom &gm, const Geom &gf, bool
 // (NW - depth calls behind depth halo waves).  Dynamic LDS: NW * scan_wave_floats<C1>() floats.
 template <int C1> constexpr int scan_wave_floats() { return (64 * C1 + 2 * kScanMargin) + 2 * (128 * C1 + 2 * kScanMargin); }
 
+// amdgpu_waves_per_eu(2, 2): at most 256 registers per lane.  Left alone the compiler takes 256 VGPRs + 21 / 102 AGPRs for the long
+// chunks and parks values in the AGPRs - and those builds gave wrong, run-to-run different results on the device
+// (profiles/r03_scan_notes.txt item 4); with the cap the same values go through 92 / 460 B of scratch per lane and the results are exact.
 template <int C1, int NW>
-__global__ __launch_bounds__(64 * NW) void demod_scan_kernel(const Geom gm, const Geom gf, const ScanK *km, const ScanK *kf, int n_first) {
+__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2))) void demod_scan_kernel(const Geom gm, const Geom gf, const ScanK *km, const ScanK *kf, int n_first) {
     constexpr int C2 = 2 * C1, N1 = 64 * C1, MG = kScanMargin;
     constexpr int kX = N1 + 2 * MG, kP = 2 * N1 + 2 * MG;
     extern __shared__ __attribute__((aligned(16))) float scan_lds[];
@@ -282,12 +285,24 @@ __global__ __launch_bounds__(64 * NW) void demod_scan_kernel(const Geom gm, cons
     }
     CM_SCAN_STAMP();   // row in LDS
     // ---- front end: the pair the product detectors multiply, then the detectors -----------------------------------------
-    f2 pq[C2];                  // (ps, pc)[t]: detector products, then their low-passed versions
+    // kLean (chunks of 24 / 32 samples): the same operations ordered for registers - the band-stop luma before the band-pass input
+    // exists, the two detector channels one after the other, carriers loaded where they are used (the packed order needs > 256 VGPRs)
+    constexpr bool kLean = C1 > 16;
+    f2 pq[kLean ? 1 : C2];      // (ps, pc)[t]: detector products, then their low-passed versions
     {
+        const float a_last = scan_up2_odd_at(X, W - 1, tp);
+        if (kLean && k.bsf) {
+            float r[C2];
+            scan_up2<C1>(X, n0, tp, r);
+            scan_pad<C2>(r, t0, L, a_last);
+            scan_iir<C2>(r, k.rem, lane);
+            scan_put<C2>(Q, r, t0, k.rem.shift);
+            scan_trim(Q, L, lane);
+            scan_dn2<C1>(Q, n0, tp, v);
+        }
         float a[C2];
         scan_up2<C1>(X, n0, tp, a);
-        const float a_last = scan_up2_odd_at(X, W - 1, tp);
-        if (k.bsf) {            // luma = dn2(band-stop(up2 x)) * gain (qam.py:57): through Q, kept in v[] until the back end
+        if (!kLean && k.bsf) {  // luma = dn2(band-stop(up2 x)) * gain (qam.py:57): through Q, kept in v[] until the back end
             float r[C2];
 #pragma unroll
             for (int i = 0; i < C2; ++i) r[i] = a[i];
@@ -299,9 +314,11 @@ __global__ __launch_bounds__(64 * NW) void demod_scan_kernel(const Geom gm, cons
         }
         CM_SCAN_STAMP();   // up2 (+ band-stop luma)
         // the detector carriers of this lane's samples, asked for ahead of the band-pass that hides their latency
-        f4 car4[C1];
+        f4 car4[kLean ? 1 : C1];
+        if constexpr (!kLean) {
 #pragma unroll
-        for (int i = 0; i < C1; ++i) car4[i] = *(const f4 *)(g.carrier4 + 4 * (n0 + i < W ? n0 + i : W - 1));
+            for (int i = 0; i < C1; ++i) car4[i] = *(const f4 *)(g.carrier4 + 4 * (n0 + i < W ? n0 + i : W - 1));
+        }
         const f4 car_last = *(const f4 *)(g.carrier4 + 4 * (W - 1));
         scan_pad<C2>(a, t0, L, a_last);
         scan_iir<C2>(a, k.ext, lane);
@@ -337,21 +354,38 @@ __global__ __launch_bounds__(64 * NW) void demod_scan_kernel(const Geom gm, cons
         }
         CM_SCAN_STAMP();   // dn2 / up2 of e
         // product detectors against the phase-free carriers (Detector::step): car = {C[2 n], S[2 n], C[2 n + 1], S[2 n + 1]}
+        if constexpr (!kLean) {
 #pragma unroll
-        for (int i = 0; i < C1; ++i) {
-            const f4 car = car4[i];
-            pq[2 * i] = f2{m[2 * i] * car.y, m[2 * i] * car.x};
-            pq[2 * i + 1] = f2{m[2 * i + 1] * car.w, m[2 * i + 1] * car.z};
-        }
-        if (t0 + C2 > L) {
-            const f2 last = {m_last * car_last.w, m_last * car_last.z};
+            for (int i = 0; i < C1; ++i) {
+                const f4 car = car4[i];
+                pq[2 * i] = f2{m[2 * i] * car.y, m[2 * i] * car.x};
+                pq[2 * i + 1] = f2{m[2 * i + 1] * car.w, m[2 * i + 1] * car.z};
+            }
+            if (t0 + C2 > L) {
+                const f2 last = {m_last * car_last.w, m_last * car_last.z};
 #pragma unroll
-            for (int i = 0; i < C2; ++i) pq[i] = t0 + i >= L ? last : pq[i];
+                for (int i = 0; i < C2; ++i) pq[i] = t0 + i >= L ? last : pq[i];
+            }
+        } else {
+#pragma unroll
+            for (int ch = 0; ch < 2; ++ch) {          // 0: against sin (-> P), 1: against cos (-> Q)
+                float d[C2];
+#pragma unroll
+                for (int i = 0; i < C1; ++i) {
+                    const f4 car = *(const f4 *)(g.carrier4 + 4 * (n0 + i < W ? n0 + i : W - 1));
+                    d[2 * i] = m[2 * i] * (ch ? car.x : car.y);
+                    d[2 * i + 1] = m[2 * i + 1] * (ch ? car.z : car.w);
+                }
+                scan_pad<C2>(d, t0, L, m_last * (ch ? car_last.z : car_last.w));
+                scan_iir<C2>(d, k.lpf, lane);
+                scan_put<C2>(ch ? Q : P, d, t0, k.lpf.shift);
+                scan_trim(ch ? Q : P, L, lane);
+            }
         }
     }
     CM_SCAN_STAMP();   // detector products
-    scan_iir2<C2>(pq, k.lpf, lane);
-    {
+    if constexpr (!kLean) {
+        scan_iir2<C2>(pq, k.lpf, lane);
         float s[C2];
 #pragma unroll
         for (int i = 0; i < C2; ++i) s[i] = pq[i].x;

@@ -651,7 +651,8 @@ def test_plan_refuses_host_pointers():
                                             ('pal_d', 'pal_s', (768, 576)), ('ntsc_comb', 'ntsc', (640, 480)), ('pal_s', 'pal_s', (1024, 60)),
                                             ('pal_d', 'pal_s', (722, 40)), ('ntsc', 'ntsc', (720, 30)), ('pal_d_notch', 'pal_s', (720, 576)),
                                             ('ntsc_simple_minavg', 'ntsc', (704, 24)), ('pal_3d_minavg', 'pal_s', (720, 21)),
-                                            ('ntsc_a', 'ntsc_a', (720, 20)), ('pal_s', 'pal_s', (960, 18))])
+                                            ('ntsc_a', 'ntsc_a', (720, 20)), ('pal_s', 'pal_s', (960, 18)), ('pal_d', 'pal_s', (1280, 576)),
+                                            ('ntsc_comb_3d', 'ntsc', (1920, 480)), ('pal_3d', 'pal_s', (1440, 576))])
 def test_small_batch_modes(stack, enc, size):
     """One frame (or a few) is a handful of workgroups of the streaming kernels.  Below a few frames the library runs one
     WAVEFRONT per scan line instead (the recursive filters as a scan over the lanes), or - where the plan's shape does not fit
@@ -673,17 +674,17 @@ def test_small_batch_modes(stack, enc, size):
             eng.set_small_batch(mode)
             got[mode] = [im.demodulate_frames(comp[i:i + 1], first_frame=1 + i)[0] for i in range(2)]
         except NotImplementedError:
-            assert mode == 'scan' and 2 * size[0] > 2040, (stack, size)     # rows beyond the chunk sizes this build carries
+            assert mode == 'scan' and 2 * size[0] > 4080, (stack, size)     # rows beyond the chunk sizes this build carries
             continue
         for i in range(2):
             assert stacks.rel_err(got[mode][i], want[i]) < TOL, (stack, mode, i)
             assert stacks.rel_err(got[mode][i], got['rows'][i]) < 2e-6, (stack, mode, i)
-    assert 'scan' in got or size[0] > 1000
-    if size[1] >= 400:      # the same two frames at the head of a batch of 48 (the streaming kernel on whole rows)
+    assert 'scan' in got
+    if size[1] >= 400:      # the same two frames at the head of a batch of 48 (the streaming kernel: whole rows, or segments for wide rows)
         big = torch.from_numpy(comp).cuda().repeat(24, 1, 1).contiguous()
         out = im.demodulate_frames(big, first_frame=1)
         for i in range(2):
-            assert stacks.rel_err(got['rows'][i], out[i].cpu().numpy()) < 2e-7, (stack, i)
+            assert stacks.rel_err(got['rows'][i], out[i].cpu().numpy()) < (2e-7 if size[0] <= 1000 else 2e-6), (stack, i)
             assert stacks.rel_err(got['auto'][i], out[i].cpu().numpy()) < 2e-6, (stack, i)
     if size[0] % 4 == 0:
         comp8 = _as_bytes(image.ImageModem.encode_composite_level(comp[:1].astype(numpy.float64)))
@@ -738,7 +739,7 @@ def test_small_batch_modes_modulate(stack, size):
         assert float((a - b).abs().max() / b.abs().max()) < 1e-6
 
 
-@pytest.mark.parametrize('size', [(720, 256), (960, 128)])
+@pytest.mark.parametrize('size', [(720, 256), (960, 128), (1280, 128), (1920, 64)])
 def test_scan_kernel_ignores_stale_lds(size):
     """The scan kernel keeps every signal of a row in LDS rows with margins it must have written itself: a launch that leaves
     NaNs all over the LDS of every CU (the streaming kernel on NaN frames) in front of it must not change a bit of its result."""
