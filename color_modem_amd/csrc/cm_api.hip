@@ -767,7 +767,8 @@ static int segment_geometry(const cm_plan *p, int wp, long long blocks, int &seg
     if (!CM_SEGMENTS || !p->pair || p->blk_tiles || blocks <= 0 || blocks > 384) return 1;
     const int warm = p->seg_warm, lat = 56;
     if (warm >= wp) return 1;
-    long long want = (1536 + blocks - 1) / blocks;              // about six workgroups per CU in all
+    long long want = 1536 / blocks;                             // six workgroups per CU in all: ONE round of resident workgroups
+    if (want < 2) return 1;
     int len = (int)((wp + want - 1) / want);
     len = (len + 15) & ~15;
     if (len < 48) len = 48;
