@@ -127,57 +127,94 @@ __device__ __forceinline__ void scan_iir2(f2 (&v)[CN], const_ScanFilter &f, int 
 
 struct ScanTaps {
     float c[10], c0;
-    __device__ __forceinline__ float tap(int k) const { return c[k < 10 ? k : 19 - k]; }
+    __device__ __forceinline__ float tap(int k) const { return k < 0 || k > 19 ? 0.f : c[k < 10 ? k : 19 - k]; }
 };
 
-// resample_poly(x, 2, 1) over this lane's chunk: out[2 i] = c0 x[n0 + i], out[2 i + 1] = sum_k c_k x[n0 + i + 10 - k]
-// (HalfbandChain::push, cm_stages.h).  src: the 1x-rate row in LDS, zero outside [0, W); n0 a multiple of 4.
-template <int C1>
-__device__ __forceinline__ void scan_up2(const lds_float *src, int n0, const ScanTaps &tp, float (&out)[2 * C1]) {
-    float win[C1 + 24];       // x[n0 - 12 .. n0 + C1 + 12)
+// The 20-tap half of the half-band FIR over a chunk, two taps per instruction: out[i] = sum_k c_k w[OFF + i - k], w[j] = the
+// window's sample j (aligned pairs wp[q] = (w[2 q], w[2 q + 1]) as they come out of LDS).  The products are summed in two lanes -
+// a pair (w[j], w[j + 1]) with j even meets the taps (k, k - 1), k = OFF + i - j, which runs over the even k for an even OFF + i
+// (11 pairs, taps -1 and 20 being zero) and over the odd k otherwise (10 pairs) - and the lanes are added at the end.
+template <int C1, int OFF, int STRIDE, int FIRST, int NW2, int NOUT>    // results to out[FIRST + STRIDE i]
+__device__ __forceinline__ void scan_fir20(const f2 (&wp)[NW2], const ScanTaps &tp, float (&out)[NOUT]) {
+    if constexpr (C1 > 16) {     // the long chunks have no registers for the tap pairs: one tap per instruction, taps in SGPRs
 #pragma unroll
-    for (int q = 0; q < (C1 + 24) / 4; ++q) {
-        const f4 t = *(const lds_f4 *)(src + n0 - 12 + 4 * q);
-        win[4 * q] = t.x; win[4 * q + 1] = t.y; win[4 * q + 2] = t.z; win[4 * q + 3] = t.w;
+        for (int i = 0; i < C1; ++i) {
+            float acc = 0.f;
+#pragma unroll
+            for (int k = 0; k < 20; ++k) {
+                const int j = OFF + i - k;
+                acc = fmaf_(tp.tap(k), (j & 1) ? wp[j >> 1].y : wp[j >> 1].x, acc);
+            }
+            out[FIRST + STRIDE * i] = acc;
+        }
+        return;
     }
 #pragma unroll
     for (int i = 0; i < C1; ++i) {
-        float acc = tp.tap(0) * win[22 + i];
+        const int par = (OFF + i) & 1;
+        f2 acc = {0.f, 0.f};
 #pragma unroll
-        for (int k = 1; k < 20; ++k) acc = fmaf_(tp.tap(k), win[22 + i - k], acc);
-        out[2 * i] = tp.c0 * win[12 + i];
-        out[2 * i + 1] = acc;
+        for (int k = par; k <= 20; k += 2) {          // j = OFF + i - k is even
+            const int j = OFF + i - k;
+            const f2 taps = {tp.tap(k), tp.tap(k - 1)};
+            acc = __builtin_elementwise_fma(wp[j >> 1], taps, acc);
+        }
+        out[FIRST + STRIDE * i] = acc.x + acc.y;
+    }
+}
+// the window w[0 .. 4 Q) = src[first .. first + 4 Q), first a multiple of 4, as aligned pairs
+template <int Q>
+__device__ __forceinline__ void scan_window(const lds_float *src, int first, f2 (&wp)[2 * Q]) {
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+        const f4 t = *(const lds_f4 *)(src + first + 4 * q);
+        wp[2 * q] = f2{t.x, t.y};
+        wp[2 * q + 1] = f2{t.z, t.w};
+    }
+}
+
+// resample_poly(x, 2, 1) over this lane's chunk: even[i] = c0 x[n0 + i], odd[i] = sum_k c_k x[n0 + i + 10 - k]
+// (HalfbandChain::push, cm_stages.h), interleaved into out[2 i], out[2 i + 1].  src: the 1x-rate row in LDS, zero outside [0, W).
+template <int C1>
+__device__ __forceinline__ void scan_up2(const lds_float *src, int n0, const ScanTaps &tp, float (&out)[2 * C1]) {
+    f2 wp[(C1 + 24) / 2];     // x[n0 - 12 .. n0 + C1 + 12)
+    scan_window<(C1 + 24) / 4>(src, n0 - 12, wp);
+    scan_fir20<C1, 22, 2, 1>(wp, tp, out);
+#pragma unroll
+    for (int i = 0; i < C1; ++i) {
+        const f2 w = wp[(12 + i) >> 1];
+        out[2 * i] = tp.c0 * ((i & 1) ? w.y : w.x);
     }
 }
 // the odd output of the same interpolator at one sample n, by every lane (FilterFunction pads with the last sample: n = W - 1)
+// (one tap per instruction whatever the chunks do: a packed version of this scalar-addressed sum measured garbage on the device,
+// and the last ulp of the padding value is nobody's business)
 __device__ __forceinline__ float scan_up2_odd_at(const lds_float *src, int n, const ScanTaps &tp) {
-    float acc = tp.tap(0) * src[n + 10];
+    float acc = 0.f;
 #pragma unroll
-    for (int k = 1; k < 20; ++k) acc = fmaf_(tp.tap(k), src[n + 10 - k], acc);
+    for (int k = 0; k < 20; ++k) acc = fmaf_(tp.tap(k), src[n + 10 - k], acc);
     return acc;
 }
-// 2 resample_poly(z, 1, 2) over this lane's chunk: out[i] = c0 z[2 n] + sum_k c_k z[2 n + 19 - 2 k], n = n0 + i
-// (HalfbandChain::push_pair).  src: the 2x-rate row in LDS, zero outside [0, 2 W).
+// 2 resample_poly(z, 1, 2) over this lane's chunk: out[i] = c0 z[2 n] + sum_k c_k z[2 n + 19 - 2 k] = c0 ev[n] + sum_k c_k od[n + 9 - k],
+// n = n0 + i (HalfbandChain::push_pair).  The 2x-rate rows live in LDS as their even and odd samples (ev, od), zero outside [0, W).
 template <int C1>
-__device__ __forceinline__ void scan_dn2(const lds_float *src, int n0, const ScanTaps &tp, float (&out)[C1]) {
-    float win[2 * C1 + 40];   // z[2 n0 - 20 .. 2 n0 + 2 C1 + 20)
+__device__ __forceinline__ void scan_dn2(const lds_float *ev, const lds_float *od, int n0, const ScanTaps &tp, float (&out)[C1]) {
+    f2 wp[(C1 + 24) / 2];     // od[n0 - 12 .. n0 + C1 + 12)
+    scan_window<(C1 + 24) / 4>(od, n0 - 12, wp);
+    scan_fir20<C1, 21, 1, 0>(wp, tp, out);
 #pragma unroll
-    for (int q = 0; q < (2 * C1 + 40) / 4; ++q) {
-        const f4 t = *(const lds_f4 *)(src + 2 * n0 - 20 + 4 * q);
-        win[4 * q] = t.x; win[4 * q + 1] = t.y; win[4 * q + 2] = t.z; win[4 * q + 3] = t.w;
-    }
-#pragma unroll
-    for (int i = 0; i < C1; ++i) {
-        float acc = tp.tap(0) * win[39 + 2 * i];
-#pragma unroll
-        for (int k = 1; k < 20; ++k) acc = fmaf_(tp.tap(k), win[39 + 2 * i - 2 * k], acc);
-        out[i] = fmaf_(tp.c0, win[20 + 2 * i], acc);
+    for (int q = 0; q < C1 / 4; ++q) {
+        const f4 t = *(const lds_f4 *)(ev + n0 + 4 * q);
+        out[4 * q] = fmaf_(tp.c0, t.x, out[4 * q]);
+        out[4 * q + 1] = fmaf_(tp.c0, t.y, out[4 * q + 1]);
+        out[4 * q + 2] = fmaf_(tp.c0, t.z, out[4 * q + 2]);
+        out[4 * q + 3] = fmaf_(tp.c0, t.w, out[4 * q + 3]);
     }
 }
 
-// FilterFunction (utils.py:28-36) around a cascade, 2x or 1x rate: v holds in[t0 .. t0 + CN) (anything beyond the row), the
-// sequence is in[0 .. len) followed by copies of `last` (= in[len - 1]); the filtered chunk goes to dst[t - shift] - the
-// first `shift` outputs land in the margin before dst[0], what lies beyond dst[len) is zeroed again (the decimators read zeros there).
+// FilterFunction (utils.py:28-36) around a cascade: v holds in[t0 .. t0 + CN) (anything beyond the row), the sequence is
+// in[0 .. len) followed by copies of `last` (= in[len - 1]); the filtered chunk goes back to LDS `shift` samples earlier - the
+// first `shift` outputs land in the margin before sample 0, what lies beyond the row is zeroed again (the decimators read zeros there).
 template <int CN>
 __device__ __forceinline__ void scan_pad(float (&v)[CN], int t0, int len, float last) {
     if (t0 + CN > len) {
@@ -185,16 +222,33 @@ __device__ __forceinline__ void scan_pad(float (&v)[CN], int t0, int len, float 
         for (int i = 0; i < CN; ++i) v[i] = t0 + i >= len ? last : v[i];
     }
 }
+typedef float f2u __attribute__((ext_vector_type(2), aligned(4)));
+typedef __attribute__((address_space(3))) f2u lds_f2u;
+// a 1x-rate chunk: dst[n0 + i - shift] = v[i]
 template <int CN>
-__device__ __forceinline__ void scan_put(lds_float *dst, const float (&v)[CN], int t0, int shift) {
-    typedef float f2u __attribute__((ext_vector_type(2), aligned(4)));
-    typedef __attribute__((address_space(3))) f2u lds_f2u;
+__device__ __forceinline__ void scan_put(lds_float *dst, const float (&v)[CN], int n0, int shift) {
 #pragma unroll
-    for (int i = 0; i < CN; i += 2) *(lds_f2u *)(dst + t0 - shift + i) = f2u{v[i], v[i + 1]};
+    for (int i = 0; i < CN; i += 2) *(lds_f2u *)(dst + n0 - shift + i) = f2u{v[i], v[i + 1]};
 }
-__device__ __forceinline__ void scan_trim(lds_float *dst, int len, int lane) {
-    dst[lane - kScanMargin] = 0.f;
-    dst[len + lane] = 0.f;
+// a 2x-rate chunk (v[i] = sample 2 n0 + i) into the row's even / odd halves: sample m = 2 n0 + i - shift
+template <int C1>
+__device__ __forceinline__ void scan_put2(lds_float *ev, lds_float *od, const float (&v)[2 * C1], int n0, int shift) {
+    const int h = shift >> 1;
+    // even shift: v[2 j] -> ev[n0 - h + j], v[2 j + 1] -> od[n0 - h + j];  odd: v[2 j] -> od[n0 - h - 1 + j], v[2 j + 1] -> ev[n0 - h + j]
+    lds_float *a = (shift & 1) ? od + (n0 - h - 1) : ev + (n0 - h);
+    lds_float *b = (shift & 1) ? ev + (n0 - h) : od + (n0 - h);
+#pragma unroll
+    for (int j = 0; j < C1; j += 2) {
+        *(lds_f2u *)(a + j) = f2u{v[2 * j], v[2 * j + 2]};
+        *(lds_f2u *)(b + j) = f2u{v[2 * j + 1], v[2 * j + 3]};
+    }
+}
+// zero what lies before sample 0 and from sample len on (1x units) of both halves
+__device__ __forceinline__ void scan_trim2(lds_float *ev, lds_float *od, int len, int lane) {
+    ev[lane - kScanMargin] = 0.f;
+    od[lane - kScanMargin] = 0.f;
+    ev[len + lane] = 0.f;
+    od[len + lane] = 0.f;
 }
 
 // gf where first, else gm, field by field (scalar selects: a reference picked at run time would send both kernel arguments
@@ -217,7 +271,7 @@ __device__ __forceinline__ Geom select_geom(const Geom &gm, const Geom &gf, bool
 
 // One launch: workgroups [0, n_first) run the plain first-line pass (NW sparse calls each), the others the main pass
 // (NW - depth calls behind depth halo waves).  Dynamic LDS: NW * scan_wave_floats<C1>() floats.
-template <int C1> constexpr int scan_wave_floats() { return (64 * C1 + 2 * kScanMargin) + 2 * (128 * C1 + 2 * kScanMargin); }
+template <int C1> constexpr int scan_wave_floats() { return 5 * (64 * C1 + 2 * kScanMargin); }      // x and the two halves of P and Q
 
 // amdgpu_waves_per_eu(2, 2): at most 256 registers per lane.  Left alone the compiler takes 256 VGPRs + 21 / 102 AGPRs for the long
 // chunks and parks values in the AGPRs - and those builds gave wrong, run-to-run different results on the device
@@ -225,7 +279,7 @@ template <int C1> constexpr int scan_wave_floats() { return (64 * C1 + 2 * kScan
 template <int C1, int NW>
 __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2))) void demod_scan_kernel(const Geom gm, const Geom gf, const ScanK *km, const ScanK *kf, int n_first) {
     constexpr int C2 = 2 * C1, N1 = 64 * C1, MG = kScanMargin;
-    constexpr int kX = N1 + 2 * MG, kP = 2 * N1 + 2 * MG;
+    constexpr int kX = N1 + 2 * MG;       // one 1x-rate row with its margins; a 2x-rate row is two of them (even / odd samples)
     extern __shared__ __attribute__((aligned(16))) float scan_lds[];
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
@@ -238,8 +292,8 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
     const bool alive = c >= 0 && c < g.total_calls;     // halo waves included: their base pairs are read by the waves behind them
 
     lds_float *wave = (lds_float *)scan_lds + w * scan_wave_floats<C1>();
-    lds_float *X = wave + MG, *P = wave + kX + MG, *Q = P + kP;
-    lds_float *BS = Q, *BC = Q + N1;                      // base pairs (Ps, Pc)[n]: in the place of Q once it has been read
+    lds_float *X = wave + MG, *PE = X + kX, *PO = PE + kX, *QE = PO + kX, *QO = QE + kX;
+    lds_float *BS = QE, *BC = QO;                         // base pairs (Ps, Pc)[n]: in the place of Q once it has been read
     const int W = g.W, L = 2 * W;
     const int n0 = lane * C1, t0 = 2 * n0;
     ScanTaps tp;
@@ -267,8 +321,10 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
         const float *xp = g.in + lc.frame * g.in_frame_stride + (long long)lc.src_row * g.Wp;
         X[lane - MG] = 0.f;
         X[N1 + lane] = 0.f;
-        P[lane - MG] = 0.f;
-        Q[lane - MG] = 0.f;
+        PE[lane - MG] = 0.f;
+        PO[lane - MG] = 0.f;
+        QE[lane - MG] = 0.f;
+        QO[lane - MG] = 0.f;
 #pragma unroll
         for (int q = 0; q < C1 / 4; ++q) {
             const int n = n0 + 4 * q;
@@ -296,9 +352,9 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
             scan_up2<C1>(X, n0, tp, r);
             scan_pad<C2>(r, t0, L, a_last);
             scan_iir<C2>(r, k.rem, lane);
-            scan_put<C2>(Q, r, t0, k.rem.shift);
-            scan_trim(Q, L, lane);
-            scan_dn2<C1>(Q, n0, tp, v);
+            scan_put2<C1>(QE, QO, r, n0, k.rem.shift);
+            scan_trim2(QE, QO, W, lane);
+            scan_dn2<C1>(QE, QO, n0, tp, v);
         }
         float a[C2];
         scan_up2<C1>(X, n0, tp, a);
@@ -308,9 +364,9 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
             for (int i = 0; i < C2; ++i) r[i] = a[i];
             scan_pad<C2>(r, t0, L, a_last);
             scan_iir<C2>(r, k.rem, lane);
-            scan_put<C2>(Q, r, t0, k.rem.shift);
-            scan_trim(Q, L, lane);
-            scan_dn2<C1>(Q, n0, tp, v);
+            scan_put2<C1>(QE, QO, r, n0, k.rem.shift);
+            scan_trim2(QE, QO, W, lane);
+            scan_dn2<C1>(QE, QO, n0, tp, v);
         }
         CM_SCAN_STAMP();   // up2 (+ band-stop luma)
         // the detector carriers of this lane's samples, asked for ahead of the band-pass that hides their latency
@@ -323,14 +379,14 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
         scan_pad<C2>(a, t0, L, a_last);
         scan_iir<C2>(a, k.ext, lane);
         CM_SCAN_STAMP();   // band-pass
-        scan_put<C2>(P, a, t0, k.ext.shift);
-        scan_trim(P, L, lane);
+        scan_put2<C1>(PE, PO, a, n0, k.ext.shift);
+        scan_trim2(PE, PO, W, lane);
         float m[C2];            // the 2x-rate signal the detectors see: b (QAM front) or up2(dn2(b)) (PAL-D front)
         float m_last;
         if (k.pald) {
             float e[C1];
-            scan_dn2<C1>(P, n0, tp, e);
-            lds_float *E = Q;           // 1x-rate row in the place of Q (free here)
+            scan_dn2<C1>(PE, PO, n0, tp, e);
+            lds_float *E = QE;          // 1x-rate row in the place of Q's first half (free here)
             E[lane - MG] = 0.f;
             E[N1 + lane] = 0.f;
 #pragma unroll
@@ -346,11 +402,12 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
             m_last = scan_up2_odd_at(E, W - 1, tp);
         } else {
 #pragma unroll
-            for (int q = 0; q < C2 / 4; ++q) {
-                const f4 t = *(const lds_f4 *)(P + t0 + 4 * q);
-                m[4 * q] = t.x; m[4 * q + 1] = t.y; m[4 * q + 2] = t.z; m[4 * q + 3] = t.w;
+            for (int q = 0; q < C1 / 4; ++q) {
+                const f4 te = *(const lds_f4 *)(PE + n0 + 4 * q), to = *(const lds_f4 *)(PO + n0 + 4 * q);
+                m[8 * q] = te.x; m[8 * q + 1] = to.x; m[8 * q + 2] = te.y; m[8 * q + 3] = to.y;
+                m[8 * q + 4] = te.z; m[8 * q + 5] = to.z; m[8 * q + 6] = te.w; m[8 * q + 7] = to.w;
             }
-            m_last = P[L - 1];
+            m_last = PO[W - 1];
         }
         CM_SCAN_STAMP();   // dn2 / up2 of e
         // product detectors against the phase-free carriers (Detector::step): car = {C[2 n], S[2 n], C[2 n + 1], S[2 n + 1]}
@@ -378,8 +435,8 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
                 }
                 scan_pad<C2>(d, t0, L, m_last * (ch ? car_last.z : car_last.w));
                 scan_iir<C2>(d, k.lpf, lane);
-                scan_put<C2>(ch ? Q : P, d, t0, k.lpf.shift);
-                scan_trim(ch ? Q : P, L, lane);
+                scan_put2<C1>(ch ? QE : PE, ch ? QO : PO, d, n0, k.lpf.shift);
+                scan_trim2(ch ? QE : PE, ch ? QO : PO, W, lane);
             }
         }
     }
@@ -389,17 +446,17 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
         float s[C2];
 #pragma unroll
         for (int i = 0; i < C2; ++i) s[i] = pq[i].x;
-        scan_put<C2>(P, s, t0, k.lpf.shift);
-        scan_trim(P, L, lane);
+        scan_put2<C1>(PE, PO, s, n0, k.lpf.shift);
+        scan_trim2(PE, PO, W, lane);
 #pragma unroll
         for (int i = 0; i < C2; ++i) s[i] = pq[i].y;
-        scan_put<C2>(Q, s, t0, k.lpf.shift);
-        scan_trim(Q, L, lane);
+        scan_put2<C1>(QE, QO, s, n0, k.lpf.shift);
+        scan_trim2(QE, QO, W, lane);
     }
     CM_SCAN_STAMP();   // low-pass + put
     float bs[C1], bc[C1];       // this line's base pair
-    scan_dn2<C1>(P, n0, tp, bs);
-    scan_dn2<C1>(Q, n0, tp, bc);
+    scan_dn2<C1>(PE, PO, n0, tp, bs);
+    scan_dn2<C1>(QE, QO, n0, tp, bc);
 #pragma unroll
     for (int q = 0; q < C1 / 4; ++q) {
         *(lds_f4 *)(BS + n0 + 4 * q) = f4{bs[4 * q], bs[4 * q + 1], bs[4 * q + 2], bs[4 * q + 3]};
@@ -442,41 +499,45 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
         uo = minavg ? minavg_(u1, u2) : u1;
         vo = minavg ? minavg_(v1, v2) : v1;
     };
+    // (the lines beyond the plan's depth enter as zeros: no branch per sample)
+    auto combine_chunk = [&](auto minavg_tag) __attribute__((always_inline)) {
+        constexpr bool MA = decltype(minavg_tag)::value;
 #pragma unroll
-    for (int q = 0; q < C1 / 4; ++q) {
-        f4 ps[3], pc[3];
+        for (int q = 0; q < C1 / 4; ++q) {
+            f4 ps[3], pc[3];
 #pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            ps[j] = pc[j] = f4{0.f, 0.f, 0.f, 0.f};
-            if (j <= depth) {
-                ps[j] = *(const lds_f4 *)(BS - j * scan_wave_floats<C1>() + n0 + 4 * q);
-                pc[j] = *(const lds_f4 *)(BC - j * scan_wave_floats<C1>() + n0 + 4 * q);
-            }
-        }
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            float u1 = fmaf_(lk.cu[0][0], ps[0][e], lk.cu[0][1] * pc[0][e]);
-            float v1 = fmaf_(lk.cv[0][0], ps[0][e], lk.cv[0][1] * pc[0][e]);
-            float u2 = 0.f, v2 = 0.f;
-            if (minavg) {
-                u2 = fmaf_(lk.cu2[0][0], ps[0][e], lk.cu2[0][1] * pc[0][e]);
-                v2 = fmaf_(lk.cv2[0][0], ps[0][e], lk.cv2[0][1] * pc[0][e]);
-            }
-#pragma unroll
-            for (int j = 1; j < 3; ++j) {
+            for (int j = 0; j < 3; ++j) {
+                ps[j] = pc[j] = f4{0.f, 0.f, 0.f, 0.f};
                 if (j <= depth) {
+                    ps[j] = *(const lds_f4 *)(BS - j * scan_wave_floats<C1>() + n0 + 4 * q);
+                    pc[j] = *(const lds_f4 *)(BC - j * scan_wave_floats<C1>() + n0 + 4 * q);
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float u1 = fmaf_(lk.cu[0][0], ps[0][e], lk.cu[0][1] * pc[0][e]);
+                float v1 = fmaf_(lk.cv[0][0], ps[0][e], lk.cv[0][1] * pc[0][e]);
+                float u2 = 0.f, v2 = 0.f;
+                if (MA) {
+                    u2 = fmaf_(lk.cu2[0][0], ps[0][e], lk.cu2[0][1] * pc[0][e]);
+                    v2 = fmaf_(lk.cv2[0][0], ps[0][e], lk.cv2[0][1] * pc[0][e]);
+                }
+#pragma unroll
+                for (int j = 1; j < 3; ++j) {
                     u1 = fmaf_(lk.cu[j][0], ps[j][e], fmaf_(lk.cu[j][1], pc[j][e], u1));
                     v1 = fmaf_(lk.cv[j][0], ps[j][e], fmaf_(lk.cv[j][1], pc[j][e], v1));
-                    if (minavg) {
+                    if (MA) {
                         u2 = fmaf_(lk.cu2[j][0], ps[j][e], fmaf_(lk.cu2[j][1], pc[j][e], u2));
                         v2 = fmaf_(lk.cv2[j][0], ps[j][e], fmaf_(lk.cv2[j][1], pc[j][e], v2));
                     }
                 }
+                u[4 * q + e] = MA ? minavg_(u1, u2) : u1;
+                v[4 * q + e] = MA ? minavg_(v1, v2) : v1;
             }
-            u[4 * q + e] = minavg ? minavg_(u1, u2) : u1;
-            v[4 * q + e] = minavg ? minavg_(v1, v2) : v1;
         }
-    }
+    };
+    if (minavg) combine_chunk(std::true_type());
+    else combine_chunk(std::false_type());
     CM_SCAN_STAMP();   // combination
     // ---- back end (DemodBack::step): pre-correction low-pass of (u, v), re-modulation, notch, matrix ----------------------
     {
@@ -501,7 +562,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
         for (int i = 0; i < C1; ++i) wuv[i] = n0 + i >= W ? f2{u_last, v_last} : f2{u[i], v[i]};
         scan_iir2<C1>(wuv, k.pre, lane);
         // the filtered pair of sample n7 is output n7 + s_p of the cascade: through P (two 1x-rate rows)
-        lds_float *PU = P, *PV = P + N1 + MG;
+        lds_float *PU = PE, *PV = PO;
         {
             float s[C1];
 #pragma unroll
@@ -539,18 +600,19 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
     }
     CM_SCAN_STAMP();   // re-modulation, notch
     if (!lc.store_ok) return;
-    float *op = g.out + lc.frame * g.out_frame_stride + (long long)lc.out_row * g.out_row_stride;
+    float *op = g.out + lc.frame * g.out_frame_stride + (long long)lc.out_row * g.out_row_stride + n0;
 #pragma unroll
-    for (int q = 0; q < C1 / 4; ++q) {
-        if (n0 + 4 * q >= g.Wp) continue;
-        f4 o[3];
+    for (int p = 0; p < 3; ++p) {
+        float *pp = op + p * g.out_plane_stride;
+        const float m0 = k.m[3 * p], m1 = k.m[3 * p + 1], m2 = k.m[3 * p + 2];
 #pragma unroll
-        for (int p = 0; p < 3; ++p) {
-            o[p].x = fmaf_(k.m[3 * p], y[4 * q], fmaf_(k.m[3 * p + 1], u[4 * q], k.m[3 * p + 2] * v[4 * q]));
-            o[p].y = fmaf_(k.m[3 * p], y[4 * q + 1], fmaf_(k.m[3 * p + 1], u[4 * q + 1], k.m[3 * p + 2] * v[4 * q + 1]));
-            o[p].z = fmaf_(k.m[3 * p], y[4 * q + 2], fmaf_(k.m[3 * p + 1], u[4 * q + 2], k.m[3 * p + 2] * v[4 * q + 2]));
-            o[p].w = fmaf_(k.m[3 * p], y[4 * q + 3], fmaf_(k.m[3 * p + 1], u[4 * q + 3], k.m[3 * p + 2] * v[4 * q + 3]));
-            *(f4 *)(op + p * g.out_plane_stride + n0 + 4 * q) = o[p];
+        for (int q = 0; q < C1 / 4; ++q) {
+            f4 o;
+            o.x = fmaf_(m0, y[4 * q], fmaf_(m1, u[4 * q], m2 * v[4 * q]));
+            o.y = fmaf_(m0, y[4 * q + 1], fmaf_(m1, u[4 * q + 1], m2 * v[4 * q + 1]));
+            o.z = fmaf_(m0, y[4 * q + 2], fmaf_(m1, u[4 * q + 2], m2 * v[4 * q + 2]));
+            o.w = fmaf_(m0, y[4 * q + 3], fmaf_(m1, u[4 * q + 3], m2 * v[4 * q + 3]));
+            if (n0 + 4 * q < g.Wp) *(f4 *)(pp + 4 * q) = o;
         }
     }
 #ifdef CM_DIAG
