@@ -69,6 +69,17 @@ class _DevicePlans(object):
                 self._destroy(handle)
 
 
+class _NoContext(object):
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        return False
+
+
+_NO_CONTEXT = _NoContext()
+
+
 class RowSession(object):
     """The per-row protocol (Modem.demodulate / Modem.modulate, one row per call) without re-sending history: the rows of
     the current run stay on the device in call order, a call uploads ONE row from a pinned staging buffer, launches the
@@ -78,6 +89,7 @@ class RowSession(object):
     given the run's last rows again."""
 
     SLOTS = 64     # rows of history buffer; when it is full the last `depth` rows move to its front
+    ZERO_COPY = True
 
     def __init__(self, eng, direction):
         torch = _torch()
@@ -91,11 +103,22 @@ class RowSession(object):
         else:
             self.in_shape, self.out_shape, self.depth = (3, eng.in_width), (eng.comp_width,), eng.mod_depth
             self.fn = getattr(L, prefix + 'modulate_run')
-        self.hist = torch.empty((self.SLOTS,) + self.in_shape, dtype=torch.float32, device=dev)
-        self.out = torch.empty((self.depth + 1,) + self.out_shape, dtype=torch.float32, device=dev)
-        self.pin_in = torch.empty((self.depth + 1,) + self.in_shape, dtype=torch.float32).pin_memory()
-        self.pin_out = torch.empty(self.out_shape, dtype=torch.float32).pin_memory()
-        self.np_in, self.np_out = self.pin_in.numpy(), self.pin_out.numpy()
+        # ZERO_COPY: history and result rows live in pinned host memory, which the device reads and writes over the bus -
+        # a call is one kernel launch and one synchronisation, no copy is enqueued (a row is 3 - 9 KB: latency, not
+        # bandwidth).  Otherwise: device-resident history, one small upload and one download per call.
+        self.zero_copy = bool(self.ZERO_COPY)
+        if self.zero_copy:
+            self.hist = torch.empty((self.SLOTS,) + self.in_shape, dtype=torch.float32).pin_memory()
+            self.out = torch.empty((self.depth + 1,) + self.out_shape, dtype=torch.float32).pin_memory()
+            self.np_hist, self.np_outs = self.hist.numpy(), self.out.numpy()
+            self.hist_ptr, self.out_ptr = self.hist.data_ptr(), self.out.data_ptr()
+            self.row_bytes = self.hist[0].numel() * 4
+        else:
+            self.hist = torch.empty((self.SLOTS,) + self.in_shape, dtype=torch.float32, device=dev)
+            self.out = torch.empty((self.depth + 1,) + self.out_shape, dtype=torch.float32, device=dev)
+            self.pin_in = torch.empty((self.depth + 1,) + self.in_shape, dtype=torch.float32).pin_memory()
+            self.pin_out = torch.empty(self.out_shape, dtype=torch.float32).pin_memory()
+            self.np_in, self.np_out = self.pin_in.numpy(), self.pin_out.numpy()
         self.pos = -1                  # slot of the newest row
         self.held = (None, -1)         # (run token, k) of the newest row on the device
         self.device = dev
@@ -107,6 +130,29 @@ class RowSession(object):
         torch = _torch()
         n = min(k, self.depth) + 1                     # rows the kernels look at
         fresh = n if self.held != (token, k - 1) else 1
+        if self.zero_copy:
+            if fresh == n:
+                self.pos = -1
+            elif self.pos + 1 >= self.SLOTS:           # compact: the last n - 1 rows to the front
+                keep = n - 1
+                self.np_hist[:keep] = self.np_hist[self.pos + 1 - keep:self.pos + 1].copy()
+                self.pos = keep - 1
+            for j in range(fresh):
+                self.np_hist[self.pos + 1 + j] = rows[len(rows) - fresh + j]
+            self.pos += fresh
+            self.held = (None, -1)
+            first = self.pos - (n - 1)
+            current = torch.cuda.current_device() == self.device.index
+            ctx = _NO_CONTEXT if current else torch.cuda.device(self.device)
+            with ctx:
+                stream = torch.cuda.current_stream(self.device)
+                try:
+                    _native.check(self.fn(self.eng._plans.get(self.device), self.hist_ptr + first * self.row_bytes, self.out_ptr, n,
+                                          int(frame), int(line) - 2 * (n - 1), int(k) - (n - 1), stream.cuda_stream))
+                finally:
+                    stream.synchronize()
+            self.held = (token, k)
+            return self.np_outs[n - 1].astype(numpy.float64)
         with torch.cuda.device(self.device):
             stream = torch.cuda.current_stream(self.device)
             if fresh == n:

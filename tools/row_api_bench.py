@@ -7,6 +7,10 @@ sys.path.insert(1, '.'); sys.path.insert(2, 'tests')
 import stacks
 import color_modem_amd
 from color_modem_amd import testing
+import os
+if os.environ.get('CM_ROW_COPY'):      # device-resident history with one upload / download per call instead of pinned zero-copy rows
+    from color_modem_amd import engine
+    engine.RowSession.ZERO_COPY = False
 print('package:', color_modem_amd.__path__[0])
 for name, size in (('pal_d', (720, 576)), ('ntsc_comb_3d', (720, 480)), ('secam', (720, 576))):
     m = stacks.make(name, size)
