@@ -183,6 +183,8 @@ struct cm_plan {
     ScanK *scan_main = nullptr, *scan_first = nullptr;
     ScanModK *scan_mod = nullptr;  // the QAM modulator's (qam_mod_scan_kernel)
     int scan_mod_c1 = 0;
+    ScanSecamModK *scan_smod = nullptr;   // the SECAM modulator's (secam_mod_scan_kernel)
+    int scan_smod_c1 = 0;
     int scan_c1 = 0, scan_depth = 0;
     mutable int small_batch = CM_SMALL_BATCH_AUTO;   // cm_plan_set_small_batch
     bool pair = false;             // wave-pair kernel (two wavefronts per 64 calls)
@@ -578,6 +580,7 @@ bool upload_lanes(const cm_lane_table &tb, LaneT **dev, Conv conv, std::string &
     return true;
 }
 
+void make_scan_secam_mod(cm_plan *p, const cm_plan_desc &d);      // small batches: secam_mod_scan_kernel (below)
 bool create_secam(cm_plan *p, const cm_plan_desc &d, std::string &err) {
     p->secam = true;
     if (!build_secam_demod_k<float>(d, p->sd_k, err)) return false;
@@ -634,6 +637,7 @@ bool create_secam(cm_plan *p, const cm_plan_desc &d, std::string &err) {
         p->mod_cycle = d.mod_main.frame_cycle;
         p->mod_n_lines = d.mod_main.n_lines;
         p->mod_depth = d.modulation_delay ? 1 : 0;
+        make_scan_secam_mod(p, d);
     }
     p->main.depth = 1;
     {
@@ -679,6 +683,7 @@ int run_secam_demod(const cm_plan *p, Geom g, hipStream_t stream, bool u8 = fals
     return CM_OK;
 }
 
+int scan_secam_mod(const cm_plan *p, const Geom &g, hipStream_t stream);      // small batches: secam_mod_scan_kernel (below)
 int run_secam_mod(const cm_plan *p, Geom g, hipStream_t stream, bool u8 = false) {
     if (!p->sm_lanes) return fail(CM_ERR_UNSUPPORTED, "this plan has no modulator");
     g.lanes = reinterpret_cast<const LaneK<float> *>(p->sm_lanes);
@@ -687,6 +692,8 @@ int run_secam_mod(const cm_plan *p, Geom g, hipStream_t stream, bool u8 = false)
     long long blocks = (g.total_calls + (64 - p->mod_depth) - 1) / (64 - p->mod_depth);
     if (blocks <= 0) return CM_OK;
     if (blocks > 0x7fffffffLL) return fail(CM_ERR_INVALID, "batch too large for one launch");
+    if (!u8 && p->scan_smod && (p->small_batch == CM_SMALL_BATCH_SCAN || (p->small_batch == CM_SMALL_BATCH_AUTO && g.total_calls <= 40000)))
+        return scan_secam_mod(p, g, stream);
     SecamModArgs a;
     a.g = g;
     a.k = p->sm_k;
@@ -880,6 +887,77 @@ static void make_scan_mod(cm_plan *p, const cm_plan_desc &d) {
         return;
     }
     p->scan_mod_c1 = c1;
+}
+void fill_scan_filter_d(const cm_iir_desc &d, const SosK<double, 2> &k, int chunk, ScanFilterD &f) {
+    std::memset(&f, 0, sizeof f);
+    f.nsec = d.n_sections;
+    f.shift = d.shift;
+    for (int j = 0; j < d.n_sections && j < 2; ++j) {
+        f.na1[j] = k.na1[j]; f.na2[j] = k.na2[j]; f.b1[j] = k.b1[j]; f.b2[j] = k.b2[j];
+        double a[4] = {k.na1[j], 1.0, k.na2[j], 0.0}, m[4] = {1.0, 0.0, 0.0, 1.0};
+        for (int e = chunk; e > 0; e >>= 1) {
+            if (e & 1) { const double t[4] = {m[0] * a[0] + m[1] * a[2], m[0] * a[1] + m[1] * a[3], m[2] * a[0] + m[3] * a[2], m[2] * a[1] + m[3] * a[3]}; std::memcpy(m, t, sizeof t); }
+            const double q[4] = {a[0] * a[0] + a[1] * a[2], a[0] * a[1] + a[1] * a[3], a[2] * a[0] + a[3] * a[2], a[2] * a[1] + a[3] * a[3]};
+            std::memcpy(a, q, sizeof q);
+        }
+        f.steps[j] = kScanSteps;
+        for (int kk = 0; kk < kScanSteps; ++kk) {
+            double big = 0.0;
+            for (int e = 0; e < 4; ++e) { f.m[j][kk][e] = m[e]; big = std::fmax(big, std::fabs(m[e])); }
+            if (big < 1e-20 && f.steps[j] == kScanSteps) f.steps[j] = kk;
+            const double q[4] = {m[0] * m[0] + m[1] * m[2], m[0] * m[1] + m[1] * m[3], m[2] * m[0] + m[3] * m[2], m[2] * m[1] + m[3] * m[3]};
+            std::memcpy(m, q, sizeof q);
+        }
+    }
+}
+// the SECAM modulator's scan constants (called from create_secam once the streaming modulator's constants exist)
+void make_scan_secam_mod(cm_plan *p, const cm_plan_desc &d) {
+    const cm_secam_desc &sd = d.secam;
+    if (!p->sm_lanes || sd.pre_lp.n_sections > 2 || sd.lf_pre.n_sections > 1 || sd.pre_lp.shift > kScanMaxShift) return;
+    int c1 = 0;
+    for (int c : {12, 16, 24, 32})
+        if (d.width + sd.pre_lp.shift <= 64 * c) { c1 = c; break; }
+    if (!c1) return;
+    ScanSecamModK k;
+    std::memset(&k, 0, sizeof k);
+    const SecamModK<float, double> &m = p->sm_k;
+    k.width = d.width; k.depth = p->mod_depth; k.c1 = c1;
+    fill_scan_filter_d(sd.pre_lp, m.pre_lp, c1, k.pre_lp);
+    SosK<double, 2> lf;
+    std::memset(&lf, 0, sizeof lf);
+    lf.na1[0] = m.lf_pre.na1[0]; lf.na2[0] = m.lf_pre.na2[0]; lf.b1[0] = m.lf_pre.b1[0]; lf.b2[0] = m.lf_pre.b2[0];
+    fill_scan_filter_d(sd.lf_pre, lf, c1, k.lf_pre);
+    k.gain = m.gain; k.f_min = m.f_min; k.f_max = m.f_max; k.f0 = m.f0; k.pi = m.pi; k.two_pi = m.two_pi;
+    k.m0 = m.m0; k.kn = m.kn; k.kd = m.kd;
+    for (int i = 0; i < 9; ++i) k.e[i] = m.e[i / 3][i % 3];
+    if (hipMalloc((void **)&p->scan_smod, sizeof k) != hipSuccess || hipMemcpy(p->scan_smod, &k, sizeof k, hipMemcpyHostToDevice) != hipSuccess) {
+        p->scan_smod = nullptr;
+        return;
+    }
+    p->scan_smod_c1 = c1;
+}
+template <int C1, int NW>
+int launch_scan_secam_mod(const cm_plan *p, const Geom &g, hipStream_t stream) {
+    const size_t lds = sizeof(float) * (size_t)NW * scan_secam_mod_wave_floats<C1>();
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void *)secam_mod_scan_kernel<C1, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return fail(CM_ERR_LAUNCH, "hipFuncSetAttribute(max dynamic LDS) failed for the SECAM modulator's scan kernel");
+        attr_set = true;
+    }
+    const long long blocks = (g.total_calls + NW - 1) / NW;
+    hipLaunchKernelGGL((secam_mod_scan_kernel<C1, NW>), dim3((int)blocks), dim3(64 * NW), lds, stream, g, p->scan_smod);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(CM_ERR_LAUNCH, std::string("secam_mod_scan_kernel launch: ") + hipGetErrorString(e));
+    return CM_OK;
+}
+int scan_secam_mod(const cm_plan *p, const Geom &g, hipStream_t stream) {
+    switch (p->scan_smod_c1) {
+        case 12: return launch_scan_secam_mod<12, 4>(p, g, stream);
+        case 16: return launch_scan_secam_mod<16, 4>(p, g, stream);
+        case 24: return launch_scan_secam_mod<24, 4>(p, g, stream);
+        default: return launch_scan_secam_mod<32, 4>(p, g, stream);
+    }
 }
 template <int C1, int NW>
 static int launch_scan(const cm_plan *p, const Geom &gm, const Geom &gf, bool with_first, hipStream_t stream) {
@@ -1104,6 +1182,7 @@ void cm_plan_destroy(cm_plan *p) {
     if (p->scan_main) (void)hipFree(p->scan_main);
     if (p->scan_first) (void)hipFree(p->scan_first);
     if (p->scan_mod) (void)hipFree(p->scan_mod);
+    if (p->scan_smod) (void)hipFree(p->scan_smod);
     if (p->main.lanes) (void)hipFree(p->main.lanes);
     if (p->first.lanes) (void)hipFree(p->first.lanes);
     if (p->mod_lanes) (void)hipFree(p->mod_lanes);
@@ -2219,7 +2298,7 @@ void cm_set_pointer_check(int32_t on) { g_pointer_check = on != 0; }
 int cm_plan_set_small_batch(const cm_plan *p, int32_t mode) {
     if (!p) return fail(CM_ERR_INVALID, "null argument");
     if (mode < CM_SMALL_BATCH_AUTO || mode > CM_SMALL_BATCH_SCAN) return fail(CM_ERR_INVALID, "unknown small-batch mode");
-    if (mode == CM_SMALL_BATCH_SCAN && !p->scan_main && !p->scan_mod) return fail(CM_ERR_UNSUPPORTED, "the scan kernels do not serve this plan");
+    if (mode == CM_SMALL_BATCH_SCAN && !p->scan_main && !p->scan_mod && !p->scan_smod) return fail(CM_ERR_UNSUPPORTED, "the scan kernels do not serve this plan");
     p->small_batch = mode;
     return CM_OK;
 }

@@ -29,6 +29,7 @@
 #define CM_SCAN_KERNELS_H
 
 #include "cm_kernels.h"
+#include "cm_secam_kernels.h"
 
 namespace cm {
 
@@ -742,6 +743,197 @@ __global__ __launch_bounds__(64 * NW) void qam_mod_scan_kernel(const Geom g, con
             o[e] = y[4 * q + e] + fmaf_(sn, tu[e], cs * tv[e]);
         }
         *(f4 *)(op + n0 + 4 * q) = o;
+    }
+}
+
+// =============================================================================================================================
+// The SECAM modulator (ref secam.py:240-276; SecamMod::step, cm_stages.h) with one wavefront per call.  Its colour-difference
+// path runs in float64 on the device (the phase is an integral over the whole line), so the scans here carry doubles:
+//   d -> pre-correction low-pass (two sections, FilterFunction shift s_p) -> LF pre-emphasis (one section, from sample 0) ->
+//   f = fsc + fdev x, clipped -> bell pre-emphasis G(f) -> phase[n] = start - arg G[0] + pi sum_{i=1..n} f[i] (numpy.cumsum: a
+//   prefix sum over the lanes) -> composite[n] = luma[n] + Re(G e^{j phase}).
+// =============================================================================================================================
+struct ScanFilterD {               // ScanFilter in float64 (at most two sections)
+    int32_t nsec, shift;
+    double na1[2], na2[2], b1[2], b2[2];
+    double m[2][kScanSteps][4];
+    int32_t steps[2], pad[2];
+};
+struct ScanSecamModK {
+    int32_t width, depth, c1, pad;
+    ScanFilterD pre_lp, lf_pre;    // 1x rate: chunk = c1
+    double gain, f_min, f_max, f0, pi, two_pi;
+    float m0, kn, kd, pad2;
+    float e[9];
+};
+typedef const __attribute__((address_space(4))) ScanSecamModK const_ScanSecamModK;
+typedef const __attribute__((address_space(4))) ScanFilterD const_ScanFilterD;
+
+__device__ __forceinline__ double scan_up_d(double v, int d, int lane) {
+    const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
+    const int idx = ((lane - d) & 63) * 4;
+    const unsigned lo = (unsigned)__builtin_amdgcn_ds_bpermute(idx, (int)(unsigned)b);
+    const unsigned hi = (unsigned)__builtin_amdgcn_ds_bpermute(idx, (int)(unsigned)(b >> 32));
+    const double r = __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+    return lane >= d ? r : 0.0;
+}
+template <int CN>
+__device__ __forceinline__ void scan_iir_d(double (&v)[CN], const_ScanFilterD &f, int lane) {
+    const int nsec = f.nsec;
+    for (int j = 0; j < nsec; ++j) {
+        const double na1 = f.na1[j], na2 = f.na2[j], b1 = f.b1[j], b2 = f.b2[j];
+        double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+        for (int i = 0; i < CN; ++i) {           // iir_gen (cm_stages.h) in float64
+            const double x = v[i], y = x + s1;
+            s1 = fmaf_(na1, y, fmaf_(b1, x, s2));
+            s2 = fmaf_(na2, y, b2 * x);
+        }
+        double e1 = scan_up_d(s1, 1, lane), e2 = scan_up_d(s2, 1, lane);
+        const int steps = f.steps[j];
+        for (int k = 0; k < steps; ++k) {
+            const double t1 = scan_up_d(e1, 1 << k, lane), t2 = scan_up_d(e2, 1 << k, lane);
+            e1 = fmaf_(f.m[j][k][0], t1, fmaf_(f.m[j][k][1], t2, e1));
+            e2 = fmaf_(f.m[j][k][2], t1, fmaf_(f.m[j][k][3], t2, e2));
+        }
+        s1 = e1;
+        s2 = e2;
+#pragma unroll
+        for (int i = 0; i < CN; ++i) {
+            const double x = v[i], y = x + s1;
+            s1 = fmaf_(na1, y, fmaf_(b1, x, s2));
+            s2 = fmaf_(na2, y, b2 * x);
+            v[i] = y;
+        }
+    }
+}
+template <int C1> constexpr int scan_secam_mod_wave_floats() { return 2 * (64 * C1 + 2 * kScanMargin); }    // one row of doubles
+
+template <int C1, int NW>
+__global__ __launch_bounds__(64 * NW) void secam_mod_scan_kernel(const Geom g, const ScanSecamModK *km) {
+    constexpr int N1 = 64 * C1, MG = kScanMargin;
+    extern __shared__ __attribute__((aligned(16))) float scan_lds[];
+    typedef __attribute__((address_space(3))) double lds_double;
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    const_ScanSecamModK &k = *(const_ScanSecamModK *)km;
+    const long long c = (long long)blockIdx.x * NW + w;
+    if (c >= g.total_calls) return;                       // (no barrier in this kernel)
+    const LaneCall lc = locate_call_at(g, c, true);
+    const LaneCall lp = locate_call_at(g, c > 0 ? c - 1 : 0, true);
+    lds_double *PW = (lds_double *)((lds_float *)scan_lds + w * scan_secam_mod_wave_floats<C1>()) + MG;
+    const int W = g.W, n0 = lane * C1;
+    SecamModLaneK<float, double> lk;
+    {
+        const int fmod = (int)((g.first_frame + lc.frame) % g.cycle);
+        lk = ((const SecamModLaneK<float, double> *)g.lanes)[((long long)fmod * 3 + lc.regime) * g.n_lines + lc.line];
+    }
+    const long long row_stride = g.in_row_stride ? g.in_row_stride : g.W;
+    const float *rp = g.in + lc.frame * g.in_frame_stride + (long long)lc.src_row * row_stride;
+    const float *rq = g.in + lp.frame * g.in_frame_stride + (long long)lp.src_row * row_stride;
+    const int depth = k.depth;
+    const bool own_db = lk.own_is_db != 0.f;
+    // (luma, d) of one sample (secam_mod_kernel's body, cm_secam_kernels.h: the same operation order)
+    auto yd_of = [&](float r, float gg, float b, float rr, float gr, float br, float &y, float &d) {
+        y = fmaf_(k.e[0], r, fmaf_(k.e[1], gg, k.e[2] * b));
+        const float dr = fmaf_(k.e[3], r, fmaf_(k.e[4], gg, k.e[5] * b));
+        const float db = fmaf_(k.e[6], r, fmaf_(k.e[7], gg, k.e[8] * b));
+        d = own_db ? db : dr;
+        if (depth >= 1) {
+            const float yp = fmaf_(k.e[0], rr, fmaf_(k.e[1], gr, k.e[2] * br));
+            const float drp = fmaf_(k.e[3], rr, fmaf_(k.e[4], gr, k.e[5] * br));
+            const float dbp = fmaf_(k.e[6], rr, fmaf_(k.e[7], gr, k.e[8] * br));
+            y = fmaf_(lk.wy0, y, lk.wy1 * yp);
+            d = fmaf_(lk.wc0, d, lk.wc1 * (own_db ? dbp : drp));
+        }
+    };
+    float y[C1];
+    double dd[C1];
+#pragma unroll
+    for (int q = 0; q < C1 / 4; ++q) {
+        const int n = n0 + 4 * q;
+        f4 a[3], b[3];
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+            a[p] = b[p] = f4{0.f, 0.f, 0.f, 0.f};
+            if (n < g.Wp) {
+                a[p] = *(const f4 *)(rp + p * g.in_plane_stride + n);
+                if (depth >= 1) b[p] = *(const f4 *)(rq + p * g.in_plane_stride + n);
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float yy, d;
+            yd_of(a[0][e], a[1][e], a[2][e], b[0][e], b[1][e], b[2][e], yy, d);
+            y[4 * q + e] = yy;
+            dd[4 * q + e] = (double)d;
+        }
+    }
+    {   // FilterFunction pads with the last sample (utils.py:31-33): d[W - 1], by every lane
+        float yl, dl;
+        const float *a = rp + (W - 1), *b = rq + (W - 1);
+        yd_of(a[0], a[g.in_plane_stride], a[2 * g.in_plane_stride], depth >= 1 ? b[0] : 0.f, depth >= 1 ? b[g.in_plane_stride] : 0.f,
+              depth >= 1 ? b[2 * g.in_plane_stride] : 0.f, yl, dl);
+        if (n0 + C1 > W) {
+#pragma unroll
+            for (int i = 0; i < C1; ++i) dd[i] = n0 + i >= W ? (double)dl : dd[i];
+        }
+    }
+    scan_iir_d<C1>(dd, k.pre_lp, lane);
+    // the filtered sample of n7 is output n7 + s_p of the cascade: through LDS
+    PW[lane - MG] = 0.0;
+#pragma unroll
+    for (int i = 0; i < C1; ++i) PW[n0 - k.pre_lp.shift + i] = dd[i];
+    double x[C1];
+#pragma unroll
+    for (int i = 0; i < C1; ++i) x[i] = PW[n0 + i];
+    scan_iir_d<C1>(x, k.lf_pre, lane);                    // from sample 0 of the row, no shift (secam.py:175-177)
+    // frequency, bell pre-emphasis, phase increments
+    float re[C1], im[C1];
+    double ph[C1];
+    const double fg = lk.fdev * k.gain;
+    const float f0 = (float)k.f0;
+#pragma unroll
+    for (int i = 0; i < C1; ++i) {
+        double f = fmaf_(fg, x[i], lk.fsc);                                   // secam.py:266 / 271
+        f = f < k.f_min ? k.f_min : (f > k.f_max ? k.f_max : f);               // secam.py:272
+        const float ff = (float)f;
+        const float F = (float)(f - k.f0) * (ff + f0) / (ff * f0);
+        const float den = 1.f + k.kd * k.kd * F * F;
+        re[i] = k.m0 * (1.f + k.kn * k.kd * F * F) / den;
+        im[i] = k.m0 * F * (k.kn - k.kd) / den;
+        ph[i] = k.pi * f;
+        if (n0 + i == 0) ph[i] = (double)lk.start_phase - (double)atan2f(im[i], re[i]);   // secam.py:244
+    }
+    // numpy.cumsum: prefix sum within the chunk, exclusive sum of the chunk totals over the lanes before
+    {
+        double run = 0.0;
+#pragma unroll
+        for (int i = 0; i < C1; ++i) {
+            run += ph[i];
+            ph[i] = run;
+        }
+        double tot = scan_up_d(run, 1, lane);
+#pragma unroll
+        for (int kk = 0; kk < kScanSteps; ++kk) tot += scan_up_d(tot, 1 << kk, lane);
+#pragma unroll
+        for (int i = 0; i < C1; ++i) ph[i] += tot;
+    }
+    if (!lc.store_ok) return;
+    float *op = g.out + lc.frame * g.out_frame_stride + (long long)lc.out_row * g.out_row_stride + n0;
+    const double inv_two_pi = 1.0 / k.two_pi;
+#pragma unroll
+    for (int q = 0; q < C1 / 4; ++q) {
+        f4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int i = 4 * q + e;
+            const double acc = ph[i] - k.two_pi * __builtin_floor(ph[i] * inv_two_pi);   // the running sum wrapped to [0, 2 pi)
+            float sn, cs;
+            sincosf((float)acc, &sn, &cs);
+            o[e] = y[i] + (re[i] * cs - im[i] * sn);                                      // secam.py:246, 276
+        }
+        if (n0 + 4 * q < g.Wp) *(f4 *)(op + 4 * q) = o;
     }
 }
 

@@ -713,9 +713,10 @@ def test_scan_kernel_batches():
 
 @pytest.mark.parametrize('stack,size', [('pal_s', (720, 576)), ('ntsc', (720, 480)), ('pal_avg', (720, 64)), ('ntsc_avg', (704, 16)),
                                         ('ntsc_a', (720, 40)), ('pal_s', (1280, 32)), ('ntsc', (1920, 16)), ('pal_s', (722, 20)),
-                                        ('pal_d', (768, 33))])
+                                        ('pal_d', (768, 33)), ('secam', (720, 576)), ('secam_avg', (720, 64)), ('secam_a', (720, 40)),
+                                        ('secam', (1280, 32)), ('secam_m', (704, 24))])
 def test_small_batch_modes_modulate(stack, size):
-    """The encoders of small batches: one wavefront per call (qam_mod_scan_kernel) against the streaming modulator on whole rows
+    """The encoders of small batches: one wavefront per call (qam_mod_scan_kernel, secam_mod_scan_kernel) against the streaming modulator on whole rows
     and the float64 oracle; 3 frames, and the same through a batch of 70 frames (beyond the hand-over point)."""
     import torch
     from oracle import cm_oracle
