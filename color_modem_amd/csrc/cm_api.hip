@@ -167,6 +167,11 @@ struct Pass {
 
 typedef int (*ModLaunchFn)(const Geom &g, const void *k, int blocks, hipStream_t);
 
+// calls up to which the decoders' scan kernels beat the streaming kernels (profiles/r03_batch_curve.txt)
+#ifndef CM_SCAN_MAX_CALLS
+#define CM_SCAN_MAX_CALLS 6000
+#endif
+
 struct cm_plan {
     cm_plan_desc desc;
     int device = 0;
@@ -185,6 +190,8 @@ struct cm_plan {
     int scan_mod_c1 = 0;
     ScanSecamModK *scan_smod = nullptr;   // the SECAM modulator's (secam_mod_scan_kernel)
     int scan_smod_c1 = 0;
+    ScanSecamK *scan_sdem = nullptr;      // the SECAM decoder's (secam_demod_scan_kernel)
+    int scan_sdem_c1 = 0;
     int scan_c1 = 0, scan_depth = 0;
     mutable int small_batch = CM_SMALL_BATCH_AUTO;   // cm_plan_set_small_batch
     bool pair = false;             // wave-pair kernel (two wavefronts per 64 calls)
@@ -581,6 +588,7 @@ bool upload_lanes(const cm_lane_table &tb, LaneT **dev, Conv conv, std::string &
 }
 
 void make_scan_secam_mod(cm_plan *p, const cm_plan_desc &d);      // small batches: secam_mod_scan_kernel (below)
+void make_scan_secam_demod(cm_plan *p, const cm_plan_desc &d);    // ... secam_demod_scan_kernel
 bool create_secam(cm_plan *p, const cm_plan_desc &d, std::string &err) {
     p->secam = true;
     if (!build_secam_demod_k<float>(d, p->sd_k, err)) return false;
@@ -647,9 +655,11 @@ bool create_secam(cm_plan *p, const cm_plan_desc &d, std::string &err) {
         p->main.name = p->sd_f64 ? "secam_demod_pair64_kernel (stage A in float64)"
                      : p->sd_pair ? "secam_demod_pair_kernel" : "secam_demod_kernel";
     }
+    make_scan_secam_demod(p, d);
     return true;
 }
 
+int scan_secam_demod(const cm_plan *p, const Geom &g, hipStream_t stream);    // small batches: secam_demod_scan_kernel (below)
 int run_secam_demod(const cm_plan *p, Geom g, hipStream_t stream, bool u8 = false) {
     g.lanes = reinterpret_cast<const LaneK<float> *>(p->sd_lanes);
     g.carrier4 = p->fm_ref;
@@ -660,6 +670,9 @@ int run_secam_demod(const cm_plan *p, Geom g, hipStream_t stream, bool u8 = fals
     long long blocks = (g.total_calls + 62) / 63;
     if (blocks <= 0) return CM_OK;
     if (blocks > 0x7fffffffLL) return fail(CM_ERR_INVALID, "batch too large for one launch");
+    if (!u8 && p->scan_sdem && (p->small_batch == CM_SMALL_BATCH_SCAN || (p->small_batch == CM_SMALL_BATCH_AUTO && g.total_calls <= 9000)))       // (no row segments on this path: the hand-over comes later)
+        return scan_secam_demod(p, g, stream);
+    if (p->small_batch == CM_SMALL_BATCH_SCAN && !u8) return fail(CM_ERR_UNSUPPORTED, "the scan kernel does not serve this plan");
     SecamDemodArgs a;
     a.g = g;
     a.k = p->sd_k;
@@ -951,6 +964,80 @@ int launch_scan_secam_mod(const cm_plan *p, const Geom &g, hipStream_t stream) {
     if (e != hipSuccess) return fail(CM_ERR_LAUNCH, std::string("secam_mod_scan_kernel launch: ") + hipGetErrorString(e));
     return CM_OK;
 }
+// the SECAM decoder's scan constants: band-pass + bell in float64 (SecamBp64's sections), the rest as the streaming kernel has it
+void make_scan_secam_demod(cm_plan *p, const cm_plan_desc &d) {
+    const cm_secam_desc &sd = d.secam;
+    if (p->sd_f64 || !p->sd_lanes) return;               // (the thin-margin shapes keep their float64 front end: streaming kernel)
+    const int Lc = d.width + sd.preroll;
+    if (sd.chroma_bp.shift > kScanMaxShift || sd.fm_lp.shift > kScanMaxShift || sd.luma_bs.shift > kScanMaxShift || sd.preroll > kScanMaxShift ||
+        sd.bell.shift != 0 || sd.lf_rev.shift != 0)
+        return;
+    int c1 = 0;
+    for (int c : {12, 16})
+        if (Lc + sd.chroma_bp.shift <= 64 * c && 2 * Lc + sd.fm_lp.shift <= 128 * c && d.width + sd.luma_bs.shift <= 64 * c) { c1 = c; break; }
+    if (!c1) return;
+    ScanSecamK k;
+    std::memset(&k, 0, sizeof k);
+    const SecamDemodK<float> &m = p->sd_k;
+    k.width = d.width; k.preroll = sd.preroll; k.c1 = c1; k.has_bell = m.has_bell;
+    for (int i = 0; i < 10; ++i) k.taps[i] = m.taps.c[i];
+    k.c0 = m.taps.c0;
+    k.two_over_pi = m.two_over_pi;
+    auto fill_d = [&](const cm_iir_desc &desc, const double *na1, const double *na2, const double *b1, const double *b2, ScanFilterD &f) {
+        std::memset(&f, 0, sizeof f);
+        f.nsec = desc.n_sections;
+        f.shift = desc.shift;
+        for (int j = 0; j < desc.n_sections && j < kScanSec; ++j) {
+            f.na1[j] = na1[j]; f.na2[j] = na2[j]; f.b1[j] = b1[j]; f.b2[j] = b2[j];
+            double a[4] = {na1[j], 1.0, na2[j], 0.0}, mm[4] = {1.0, 0.0, 0.0, 1.0};
+            for (int e = c1; e > 0; e >>= 1) {
+                if (e & 1) { const double t[4] = {mm[0] * a[0] + mm[1] * a[2], mm[0] * a[1] + mm[1] * a[3], mm[2] * a[0] + mm[3] * a[2], mm[2] * a[1] + mm[3] * a[3]}; std::memcpy(mm, t, sizeof t); }
+                const double q[4] = {a[0] * a[0] + a[1] * a[2], a[0] * a[1] + a[1] * a[3], a[2] * a[0] + a[3] * a[2], a[2] * a[1] + a[3] * a[3]};
+                std::memcpy(a, q, sizeof q);
+            }
+            f.steps[j] = kScanSteps;
+            for (int kk = 0; kk < kScanSteps; ++kk) {
+                double big = 0.0;
+                for (int e = 0; e < 4; ++e) { f.m[j][kk][e] = mm[e]; big = std::fmax(big, std::fabs(mm[e])); }
+                if (big < 1e-20 && f.steps[j] == kScanSteps) f.steps[j] = kk;
+                const double q[4] = {mm[0] * mm[0] + mm[1] * mm[2], mm[0] * mm[1] + mm[1] * mm[3], mm[2] * mm[0] + mm[3] * mm[2], mm[2] * mm[1] + mm[3] * mm[3]};
+                std::memcpy(mm, q, sizeof q);
+            }
+        }
+    };
+    const SecamBp64 &e64 = p->sd_e64;
+    fill_d(sd.chroma_bp, e64.bpf.na1, e64.bpf.na2, e64.bpf.b1, e64.bpf.b2, k.bpf);
+    fill_d(sd.bell, e64.bell.na1, e64.bell.na2, e64.bell.b1, e64.bell.b2, k.bell);
+    fill_scan_filter(sd.fm_lp, m.lpf.na1, m.lpf.na2, m.lpf.b1, m.lpf.b2, 2 * c1, k.lpf);
+    fill_scan_filter(sd.luma_bs, m.ybs.na1, m.ybs.na2, m.ybs.b1, m.ybs.b2, c1, k.ybs);
+    fill_scan_filter(sd.lf_rev, m.deemph.na1, m.deemph.na2, m.deemph.b1, m.deemph.b2, c1, k.deemph);
+    k.luma_gain = m.luma_gain;
+    for (int i = 0; i < 9; ++i) k.m[i] = m.m[i / 3][i % 3];
+    if (hipMalloc((void **)&p->scan_sdem, sizeof k) != hipSuccess || hipMemcpy(p->scan_sdem, &k, sizeof k, hipMemcpyHostToDevice) != hipSuccess) {
+        p->scan_sdem = nullptr;
+        return;
+    }
+    p->scan_sdem_c1 = c1;
+}
+template <int C1, int NW>
+int launch_scan_secam_demod(const cm_plan *p, const Geom &g, hipStream_t stream) {
+    const size_t lds = sizeof(float) * (size_t)NW * scan_secam_wave_floats<C1>();
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void *)secam_demod_scan_kernel<C1, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return fail(CM_ERR_LAUNCH, "hipFuncSetAttribute(max dynamic LDS) failed for the SECAM decoder's scan kernel");
+        attr_set = true;
+    }
+    const long long blocks = (g.total_calls + (NW - 1) - 1) / (NW - 1);
+    hipLaunchKernelGGL((secam_demod_scan_kernel<C1, NW>), dim3((int)blocks), dim3(64 * NW), lds, stream, g, p->scan_sdem);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(CM_ERR_LAUNCH, std::string("secam_demod_scan_kernel launch: ") + hipGetErrorString(e));
+    return CM_OK;
+}
+int scan_secam_demod(const cm_plan *p, const Geom &g, hipStream_t stream) {
+    if (p->scan_sdem_c1 == 12) return launch_scan_secam_demod<12, 4>(p, g, stream);
+    return launch_scan_secam_demod<16, 4>(p, g, stream);
+}
 int scan_secam_mod(const cm_plan *p, const Geom &g, hipStream_t stream) {
     switch (p->scan_smod_c1) {
         case 12: return launch_scan_secam_mod<12, 4>(p, g, stream);
@@ -977,10 +1064,6 @@ static int launch_scan(const cm_plan *p, const Geom &gm, const Geom &gf, bool wi
     if (e != hipSuccess) return fail(CM_ERR_LAUNCH, std::string("demod_scan_kernel launch: ") + hipGetErrorString(e));
     return CM_OK;
 }
-// calls up to which the scan kernel beats the streaming kernels (profiles/r03_batch_curve.txt)
-#ifndef CM_SCAN_MAX_CALLS
-#define CM_SCAN_MAX_CALLS 6000
-#endif
 
 // gm: main-pass geometry (total_calls set); gf: first-line geometry (total_calls = number of runs) when the plan has one
 #ifdef CM_DIAG
@@ -1183,6 +1266,7 @@ void cm_plan_destroy(cm_plan *p) {
     if (p->scan_first) (void)hipFree(p->scan_first);
     if (p->scan_mod) (void)hipFree(p->scan_mod);
     if (p->scan_smod) (void)hipFree(p->scan_smod);
+    if (p->scan_sdem) (void)hipFree(p->scan_sdem);
     if (p->main.lanes) (void)hipFree(p->main.lanes);
     if (p->first.lanes) (void)hipFree(p->first.lanes);
     if (p->mod_lanes) (void)hipFree(p->mod_lanes);
@@ -2298,7 +2382,7 @@ void cm_set_pointer_check(int32_t on) { g_pointer_check = on != 0; }
 int cm_plan_set_small_batch(const cm_plan *p, int32_t mode) {
     if (!p) return fail(CM_ERR_INVALID, "null argument");
     if (mode < CM_SMALL_BATCH_AUTO || mode > CM_SMALL_BATCH_SCAN) return fail(CM_ERR_INVALID, "unknown small-batch mode");
-    if (mode == CM_SMALL_BATCH_SCAN && !p->scan_main && !p->scan_mod && !p->scan_smod) return fail(CM_ERR_UNSUPPORTED, "the scan kernels do not serve this plan");
+    if (mode == CM_SMALL_BATCH_SCAN && !p->scan_main && !p->scan_mod && !p->scan_smod && !p->scan_sdem) return fail(CM_ERR_UNSUPPORTED, "the scan kernels do not serve this plan");
     p->small_batch = mode;
     return CM_OK;
 }

@@ -753,11 +753,11 @@ __global__ __launch_bounds__(64 * NW) void qam_mod_scan_kernel(const Geom g, con
 //   f = fsc + fdev x, clipped -> bell pre-emphasis G(f) -> phase[n] = start - arg G[0] + pi sum_{i=1..n} f[i] (numpy.cumsum: a
 //   prefix sum over the lanes) -> composite[n] = luma[n] + Re(G e^{j phase}).
 // =============================================================================================================================
-struct ScanFilterD {               // ScanFilter in float64 (at most two sections)
+struct ScanFilterD {               // ScanFilter in float64
     int32_t nsec, shift;
-    double na1[2], na2[2], b1[2], b2[2];
-    double m[2][kScanSteps][4];
-    int32_t steps[2], pad[2];
+    double na1[kScanSec], na2[kScanSec], b1[kScanSec], b2[kScanSec];
+    double m[kScanSec][kScanSteps][4];
+    int32_t steps[kScanSec];
 };
 struct ScanSecamModK {
     int32_t width, depth, c1, pad;
@@ -934,6 +934,203 @@ __global__ __launch_bounds__(64 * NW) void secam_mod_scan_kernel(const Geom g, c
             o[e] = y[i] + (re[i] * cs - im[i] * sn);                                      // secam.py:246, 276
         }
         if (n0 + 4 * q < g.Wp) *(f4 *)(op + 4 * q) = o;
+    }
+}
+
+// =============================================================================================================================
+// The SECAM decoder (ref secam.py:278-304 with the FmDecoder of secam.py:127-149; SecamDemod, cm_stages.h) with one wavefront
+// per call, the plans whose float32 discriminator has its margin (rows below 1280 samples).  Array operations of a row:
+//   cc[m] (the row behind its mirrored pre-roll, Lc = W + P samples) -> band-pass (FilterFunction shift s_b) -> bell, both in
+//   FLOAT64 (the streaming kernels carry them in float64 at the row ends, where float32 loses the sub-carrier's phase: here the
+//   whole row) -> up2 -> x FM reference -> low-pass of (I, Q) (packed scan, FilterFunction shift) -> phase step of consecutive
+//   samples (atan2 of cross and dot product) -> dn2 -> + dc table, clip, scale -> de-emphasis (scan, from sample 0 of the row) ;
+//   luma = band-stop of the row (scan, FilterFunction shift s_y) ; (dr, db) = this call's and the previous call's c.
+// NW waves = NW - 1 calls behind one halo wave.
+// =============================================================================================================================
+struct ScanSecamK {
+    int32_t width, preroll, c1, has_bell;
+    float taps[10], c0, two_over_pi;
+    ScanFilterD bpf, bell;         // chunk = c1 (the chroma stream m)
+    ScanFilter lpf;                // 2x rate: chunk = 2 c1
+    ScanFilter ybs, deemph;        // 1x rate: chunk = c1
+    float luma_gain, pad;
+    float m[9];
+};
+typedef const __attribute__((address_space(4))) ScanSecamK const_ScanSecamK;
+template <int C1> constexpr int scan_secam_wave_floats() { return 7 * (64 * C1 + 2 * kScanMargin); }
+
+template <int C1, int NW>
+__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2))) void secam_demod_scan_kernel(const Geom g, const ScanSecamK *km) {
+    constexpr int C2 = 2 * C1, N1 = 64 * C1, MG = kScanMargin, kRow = N1 + 2 * MG;
+    extern __shared__ __attribute__((aligned(16))) float scan_lds[];
+    typedef __attribute__((address_space(3))) double lds_double;
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    const_ScanSecamK &k = *(const_ScanSecamK *)km;
+    const long long c = (long long)blockIdx.x * (NW - 1) - 1 + w;
+    const LaneCall lc = locate_call_at(g, c, w >= 1);
+    const bool alive = c >= 0 && c < g.total_calls;
+    lds_float *wave = (lds_float *)scan_lds + w * scan_secam_wave_floats<C1>();
+    lds_float *X = wave + MG, *PE = X + kRow, *PO = PE + kRow, *QE = PO + kRow, *QO = QE + kRow, *COWN = QO + kRow, *YROW = COWN + kRow;
+    lds_double *BD = (lds_double *)(PE - MG) + MG;       // the band-passed stream in float64: in the place of PE and PO
+    lds_float *CH = QE;                                    // ch[m1], float: in the place of QE
+    const int W = g.W, P = k.preroll, Lc = W + P;
+    const int n0 = lane * C1;
+    ScanTaps tp;
+#pragma unroll
+    for (int i = 0; i < 10; ++i) tp.c[i] = k.taps[i];
+    tp.c0 = k.c0;
+    SecamDemodLaneK<float> lk;
+    {
+        const int fmod = (int)((g.first_frame + lc.frame) % g.cycle);
+        lk = ((const SecamDemodLaneK<float> *)g.lanes)[((long long)fmod * 3 + lc.regime) * g.n_lines + lc.line];
+    }
+    // ---- the row ------------------------------------------------------------------------------------------------------------
+    float xr[C1];
+    {
+        const float *xp = g.in + lc.frame * g.in_frame_stride + (long long)lc.src_row * g.Wp;
+        X[lane - MG] = 0.f;
+        X[N1 + lane] = 0.f;
+#pragma unroll
+        for (int q = 0; q < C1 / 4; ++q) {
+            const int n = n0 + 4 * q;
+            f4 t = {0.f, 0.f, 0.f, 0.f};
+            if (alive && n < g.Wp) t = *(const f4 *)(xp + n);
+            if (n + 3 >= W) {
+                if (n >= W) t.x = 0.f;
+                if (n + 1 >= W) t.y = 0.f;
+                if (n + 2 >= W) t.z = 0.f;
+                if (n + 3 >= W) t.w = 0.f;
+            }
+            *(lds_f4 *)(X + n) = t;
+            xr[4 * q] = t.x; xr[4 * q + 1] = t.y; xr[4 * q + 2] = t.z; xr[4 * q + 3] = t.w;
+        }
+    }
+    const float x_last = X[W - 1];
+    // ---- luma: band-stop of the row with FilterFunction's tail, output s_y samples earlier (SecamDemod::luma_step) -----------
+    {
+        scan_pad<C1>(xr, n0, W, x_last);
+        scan_iir<C1>(xr, k.ybs, lane);
+        YROW[lane - MG] = 0.f;
+        scan_put<C1>(YROW, xr, n0, k.ybs.shift);
+    }
+    // ---- chroma stream cc[m]: band-pass + bell in float64 --------------------------------------------------------------------
+    float ch[C1];
+    {
+        double b[C1];
+#pragma unroll
+        for (int i = 0; i < C1; ++i) {
+            const int m = n0 + i;
+            const int idx = m < P ? P - m : (m < Lc ? m - P : W - 1);      // secam.py:283-284: the mirrored start; the tail repeats cc[Lc - 1]
+            b[i] = (double)X[idx];
+        }
+        scan_iir_d<C1>(b, k.bpf, lane);
+        BD[lane - MG] = 0.0;
+#pragma unroll
+        for (int i = 0; i < C1; ++i) BD[n0 - k.bpf.shift + i] = b[i];
+#pragma unroll
+        for (int i = 0; i < C1; ++i) b[i] = BD[n0 + i];
+        if (k.has_bell) scan_iir_d<C1>(b, k.bell, lane);   // the bell sees the band-pass output from its sample 0 on
+#pragma unroll
+        for (int i = 0; i < C1; ++i) ch[i] = n0 + i < Lc ? (float)b[i] : 0.f;
+    }
+    CH[lane - MG] = 0.f;
+    CH[N1 + lane] = 0.f;
+#pragma unroll
+    for (int q = 0; q < C1 / 4; ++q) *(lds_f4 *)(CH + n0 + 4 * q) = f4{ch[4 * q], ch[4 * q + 1], ch[4 * q + 2], ch[4 * q + 3]};
+    // ---- up2, products with the FM reference, low-pass of (I, Q) ---------------------------------------------------------------
+    f2 iq[C2];
+    {
+        float a[C2];
+        scan_up2<C1>(CH, n0, tp, a);
+        const float a_last = scan_up2_odd_at(CH, Lc - 1, tp);
+#pragma unroll
+        for (int i = 0; i < C1; ++i) {
+            const f4 car = *(const f4 *)(g.carrier4 + 4 * (n0 + i < Lc ? n0 + i : Lc - 1));
+            iq[2 * i] = f2{a[2 * i] * car.x, -(a[2 * i] * car.y)};             // data_up = cos part - j sin part (secam.py:143)
+            iq[2 * i + 1] = f2{a[2 * i + 1] * car.z, -(a[2 * i + 1] * car.w)};
+        }
+        if (2 * n0 + C2 > 2 * Lc) {
+            const f4 car = *(const f4 *)(g.carrier4 + 4 * (Lc - 1));
+            const f2 last = {a_last * car.z, -(a_last * car.w)};
+#pragma unroll
+            for (int i = 0; i < C2; ++i) iq[i] = 2 * n0 + i >= 2 * Lc ? last : iq[i];
+        }
+    }
+    scan_iir2<C2>(iq, k.lpf, lane);
+    {
+        float s[C2];
+#pragma unroll
+        for (int i = 0; i < C2; ++i) s[i] = iq[i].x;
+        PE[lane - MG] = 0.f;
+        PO[lane - MG] = 0.f;
+        scan_put2<C1>(PE, PO, s, n0, k.lpf.shift);
+#pragma unroll
+        for (int i = 0; i < C2; ++i) s[i] = iq[i].y;
+        QO[lane - MG] = 0.f;
+        scan_put2<C1>(QE, QO, s, n0, k.lpf.shift);
+    }
+    // ---- phase steps of consecutive (I, Q) samples (SecamDemod::phase_step), as the deviation from the discriminator centre -----
+    float f[C2];
+    {
+        f2 prev = {PO[n0 - 1], QO[n0 - 1]};              // sample 2 n0 - 1
+#pragma unroll
+        for (int q = 0; q < C1 / 4; ++q) {
+            const f4 ie = *(const lds_f4 *)(PE + n0 + 4 * q), io = *(const lds_f4 *)(PO + n0 + 4 * q);
+            const f4 qe = *(const lds_f4 *)(QE + n0 + 4 * q), qo = *(const lds_f4 *)(QO + n0 + 4 * q);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const f2 s0 = {ie[e], qe[e]}, s1 = {io[e], qo[e]};
+                const int m3 = n0 + 4 * q + e;
+                float d_e = SecamDemod<float>::phase_step(prev.x, prev.y, s0.x, s0.y);
+                float d_o = SecamDemod<float>::phase_step(s0.x, s0.y, s1.x, s1.y);
+                if (m3 == 0) d_e = 0.f;                  // secam.py:147: the first step is 0
+                if (m3 >= Lc) d_e = d_o = 0.f;
+                f[8 * q + 2 * e] = d_e * k.two_over_pi;
+                f[8 * q + 2 * e + 1] = d_o * k.two_over_pi;
+                prev = s1;
+            }
+        }
+    }
+    scan_put2<C1>(PE, PO, f, n0, 0);
+    scan_trim2(PE, PO, Lc, lane);
+    float g2[C1];
+    scan_dn2<C1>(PE, PO, n0, tp, g2);
+    // ---- frequency -> colour difference, de-emphasis from sample 0 of the row (n = m4 - P) ----------------------------------------
+    {
+#pragma unroll
+        for (int i = 0; i < C1; ++i) {
+            const int m4 = n0 + i, n = m4 - P;
+            const float dc = g.carrier2[m4 < Lc ? m4 : Lc - 1];
+            float v2 = (g2[i] + dc) + lk.off2;                                   // 2 (f - fsc)
+            v2 = v2 < lk.lo ? lk.lo : (v2 > lk.hi ? lk.hi : v2);                 // secam.py:290
+            g2[i] = n >= 0 && n < W ? v2 * lk.scale : 0.f;
+        }
+        scan_iir<C1>(g2, k.deemph, lane);                                       // secam.py:291-296
+        COWN[lane - MG] = 0.f;
+        scan_put<C1>(COWN, g2, n0, P);
+    }
+    __syncthreads();
+    if (w < 1 || !alive || !lc.store_ok) return;
+    // ---- finish (SecamDemod::finish): this call's and the previous call's colour difference, matrix ---------------------------------
+    const lds_float *CPREV = COWN - scan_secam_wave_floats<C1>();
+    float *op = g.out + lc.frame * g.out_frame_stride + (long long)lc.out_row * g.out_row_stride + n0;
+    const bool own_db = lk.own_is_db != 0.f;
+#pragma unroll
+    for (int q = 0; q < C1 / 4; ++q) {
+        const f4 yv = *(const lds_f4 *)(YROW + n0 + 4 * q), own = *(const lds_f4 *)(COWN + n0 + 4 * q), pv = *(const lds_f4 *)(CPREV + n0 + 4 * q);
+        f4 o[3];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float luma = yv[e] * k.luma_gain, prev = pv[e] * lk.w_prev;
+            const float dr = own_db ? prev : own[e], db = own_db ? own[e] : prev;   // secam.py:297-300
+#pragma unroll
+            for (int p = 0; p < 3; ++p) o[p][e] = fmaf_(k.m[3 * p], luma, fmaf_(k.m[3 * p + 1], dr, k.m[3 * p + 2] * db));
+        }
+        if (n0 + 4 * q < g.Wp) {
+#pragma unroll
+            for (int p = 0; p < 3; ++p) *(f4 *)(op + p * g.out_plane_stride + 4 * q) = o[p];
+        }
     }
 }
 

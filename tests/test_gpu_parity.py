@@ -652,7 +652,9 @@ def test_plan_refuses_host_pointers():
                                             ('pal_d', 'pal_s', (722, 40)), ('ntsc', 'ntsc', (720, 30)), ('pal_d_notch', 'pal_s', (720, 576)),
                                             ('ntsc_simple_minavg', 'ntsc', (704, 24)), ('pal_3d_minavg', 'pal_s', (720, 21)),
                                             ('ntsc_a', 'ntsc_a', (720, 20)), ('pal_s', 'pal_s', (960, 18)), ('pal_d', 'pal_s', (1280, 576)),
-                                            ('ntsc_comb_3d', 'ntsc', (1920, 480)), ('pal_3d', 'pal_s', (1440, 576))])
+                                            ('ntsc_comb_3d', 'ntsc', (1920, 480)), ('pal_3d', 'pal_s', (1440, 576)),
+                                            ('secam', 'secam', (720, 576)), ('secam', 'secam', (768, 576)), ('secam_a', 'secam_a', (720, 405)),
+                                            ('secam', 'secam', (640, 480)), ('secam_avg', 'secam_avg', (720, 576))])
 def test_small_batch_modes(stack, enc, size):
     """One frame (or a few) is a handful of workgroups of the streaming kernels.  Below a few frames the library runs one
     WAVEFRONT per scan line instead (the recursive filters as a scan over the lanes), or - where the plan's shape does not fit
@@ -678,14 +680,14 @@ def test_small_batch_modes(stack, enc, size):
             continue
         for i in range(2):
             assert stacks.rel_err(got[mode][i], want[i]) < TOL, (stack, mode, i)
-            assert stacks.rel_err(got[mode][i], got['rows'][i]) < 2e-6, (stack, mode, i)
+            assert stacks.rel_err(got[mode][i], got['rows'][i]) < (6e-6 if stack.startswith('secam') else 2e-6), (stack, mode, i)
     assert 'scan' in got
     if size[1] >= 400:      # the same two frames at the head of a batch of 48 (the streaming kernel: whole rows, or segments for wide rows)
         big = torch.from_numpy(comp).cuda().repeat(24, 1, 1).contiguous()
         out = im.demodulate_frames(big, first_frame=1)
         for i in range(2):
             assert stacks.rel_err(got['rows'][i], out[i].cpu().numpy()) < (2e-7 if size[0] <= 1000 else 2e-6), (stack, i)
-            assert stacks.rel_err(got['auto'][i], out[i].cpu().numpy()) < 2e-6, (stack, i)
+            assert stacks.rel_err(got['auto'][i], out[i].cpu().numpy()) < (6e-6 if stack.startswith('secam') else 2e-6), (stack, i)
     if size[0] % 4 == 0:
         comp8 = _as_bytes(image.ImageModem.encode_composite_level(comp[:1].astype(numpy.float64)))
         got8 = im.demodulate_frames_u8(comp8, first_frame=1)

@@ -12,6 +12,8 @@ F = int(sys.argv[4]) if len(sys.argv) > 4 else 1
 im = image.ImageModem(stacks.make(stack, (W, H)))
 eng = im._engine()
 comp = torch.from_numpy(testing.synthetic_composite(F, H, W)).cuda()
+if 'secam' in stack:      # the FM discriminator is ill-conditioned on noise: a valid signal from the library's own encoder
+    comp = eng.modulate_frames(torch.from_numpy(testing.synthetic_rgb(F, H, W)).cuda(), 1)
 outs = {}
 for mode in ('rows', 'segments', 'scan'):
     try:
