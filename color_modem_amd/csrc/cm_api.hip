@@ -801,25 +801,31 @@ static int segment_geometry(const cm_plan *p, int wp, long long blocks, int &seg
 // ---- small batches: one wavefront per scan line (cm_scan_kernels.h) ------------------------------------------------------
 // The scan's chunk-to-chunk transitions: A^(chunk 2^k) of every section, A = [[-a1, 1], [-a2, 0]] with the float32-rounded
 // coefficients the kernel filters with (float64 products, rounded once).
-static void fill_scan_filter(const cm_iir_desc &d, const float *na1, const float *na2, const float *b1, const float *b2, int chunk, ScanFilter &f) {
+template <typename T, class Filter>      // Filter = ScanFilter (T = float) or ScanFilterD (T = double); cut: where a power counts as decayed
+static void fill_scan_filter(const cm_iir_desc &d, const T *na1, const T *na2, const T *b1, const T *b2, int chunk, Filter &f, double cut = 1e-12) {
     std::memset(&f, 0, sizeof f);
     f.nsec = d.n_sections;
     f.shift = d.shift;
+    auto mul = [](const double (&x)[4], const double (&y)[4], double (&r)[4]) {
+        const double t[4] = {x[0] * y[0] + x[1] * y[2], x[0] * y[1] + x[1] * y[3], x[2] * y[0] + x[3] * y[2], x[2] * y[1] + x[3] * y[3]};
+        std::memcpy(r, t, sizeof t);
+    };
     for (int j = 0; j < d.n_sections && j < kScanSec; ++j) {
         f.na1[j] = na1[j]; f.na2[j] = na2[j]; f.b1[j] = b1[j]; f.b2[j] = b2[j];
         double a[4] = {(double)na1[j], 1.0, (double)na2[j], 0.0}, m[4] = {1.0, 0.0, 0.0, 1.0};
         for (int e = chunk; e > 0; e >>= 1) {      // m = a^chunk
-            if (e & 1) { const double t[4] = {m[0] * a[0] + m[1] * a[2], m[0] * a[1] + m[1] * a[3], m[2] * a[0] + m[3] * a[2], m[2] * a[1] + m[3] * a[3]}; std::memcpy(m, t, sizeof t); }
-            const double q[4] = {a[0] * a[0] + a[1] * a[2], a[0] * a[1] + a[1] * a[3], a[2] * a[0] + a[3] * a[2], a[2] * a[1] + a[3] * a[3]};
-            std::memcpy(a, q, sizeof q);
+            if (e & 1) mul(m, a, m);
+            mul(a, a, a);
         }
         f.steps[j] = kScanSteps;
         for (int k = 0; k < kScanSteps; ++k) {
             double big = 0.0;
-            for (int e = 0; e < 4; ++e) { f.m[j][k][e] = (float)m[e]; big = std::fmax(big, std::fabs(m[e])); }
-            if (big < 1e-12 && f.steps[j] == kScanSteps) f.steps[j] = k;
-            const double q[4] = {m[0] * m[0] + m[1] * m[2], m[0] * m[1] + m[1] * m[3], m[2] * m[0] + m[3] * m[2], m[2] * m[1] + m[3] * m[3]};
-            std::memcpy(m, q, sizeof q);
+            for (int e = 0; e < 4; ++e) {
+                f.m[j][k][e] = (T)m[e];
+                big = std::fmax(big, std::fabs(m[e]));
+            }
+            if (big < cut && f.steps[j] == kScanSteps) f.steps[j] = k;
+            mul(m, m, m);
         }
     }
 }
@@ -901,28 +907,6 @@ static void make_scan_mod(cm_plan *p, const cm_plan_desc &d) {
     }
     p->scan_mod_c1 = c1;
 }
-void fill_scan_filter_d(const cm_iir_desc &d, const SosK<double, 2> &k, int chunk, ScanFilterD &f) {
-    std::memset(&f, 0, sizeof f);
-    f.nsec = d.n_sections;
-    f.shift = d.shift;
-    for (int j = 0; j < d.n_sections && j < 2; ++j) {
-        f.na1[j] = k.na1[j]; f.na2[j] = k.na2[j]; f.b1[j] = k.b1[j]; f.b2[j] = k.b2[j];
-        double a[4] = {k.na1[j], 1.0, k.na2[j], 0.0}, m[4] = {1.0, 0.0, 0.0, 1.0};
-        for (int e = chunk; e > 0; e >>= 1) {
-            if (e & 1) { const double t[4] = {m[0] * a[0] + m[1] * a[2], m[0] * a[1] + m[1] * a[3], m[2] * a[0] + m[3] * a[2], m[2] * a[1] + m[3] * a[3]}; std::memcpy(m, t, sizeof t); }
-            const double q[4] = {a[0] * a[0] + a[1] * a[2], a[0] * a[1] + a[1] * a[3], a[2] * a[0] + a[3] * a[2], a[2] * a[1] + a[3] * a[3]};
-            std::memcpy(a, q, sizeof q);
-        }
-        f.steps[j] = kScanSteps;
-        for (int kk = 0; kk < kScanSteps; ++kk) {
-            double big = 0.0;
-            for (int e = 0; e < 4; ++e) { f.m[j][kk][e] = m[e]; big = std::fmax(big, std::fabs(m[e])); }
-            if (big < 1e-20 && f.steps[j] == kScanSteps) f.steps[j] = kk;
-            const double q[4] = {m[0] * m[0] + m[1] * m[2], m[0] * m[1] + m[1] * m[3], m[2] * m[0] + m[3] * m[2], m[2] * m[1] + m[3] * m[3]};
-            std::memcpy(m, q, sizeof q);
-        }
-    }
-}
 // the SECAM modulator's scan constants (called from create_secam once the streaming modulator's constants exist)
 void make_scan_secam_mod(cm_plan *p, const cm_plan_desc &d) {
     const cm_secam_desc &sd = d.secam;
@@ -935,11 +919,8 @@ void make_scan_secam_mod(cm_plan *p, const cm_plan_desc &d) {
     std::memset(&k, 0, sizeof k);
     const SecamModK<float, double> &m = p->sm_k;
     k.width = d.width; k.depth = p->mod_depth; k.c1 = c1;
-    fill_scan_filter_d(sd.pre_lp, m.pre_lp, c1, k.pre_lp);
-    SosK<double, 2> lf;
-    std::memset(&lf, 0, sizeof lf);
-    lf.na1[0] = m.lf_pre.na1[0]; lf.na2[0] = m.lf_pre.na2[0]; lf.b1[0] = m.lf_pre.b1[0]; lf.b2[0] = m.lf_pre.b2[0];
-    fill_scan_filter_d(sd.lf_pre, lf, c1, k.lf_pre);
+    fill_scan_filter(sd.pre_lp, m.pre_lp.na1, m.pre_lp.na2, m.pre_lp.b1, m.pre_lp.b2, c1, k.pre_lp, 1e-20);
+    fill_scan_filter(sd.lf_pre, m.lf_pre.na1, m.lf_pre.na2, m.lf_pre.b1, m.lf_pre.b2, c1, k.lf_pre, 1e-20);
     k.gain = m.gain; k.f_min = m.f_min; k.f_max = m.f_max; k.f0 = m.f0; k.pi = m.pi; k.two_pi = m.two_pi;
     k.m0 = m.m0; k.kn = m.kn; k.kd = m.kd;
     for (int i = 0; i < 9; ++i) k.e[i] = m.e[i / 3][i % 3];
@@ -983,31 +964,9 @@ void make_scan_secam_demod(cm_plan *p, const cm_plan_desc &d) {
     for (int i = 0; i < 10; ++i) k.taps[i] = m.taps.c[i];
     k.c0 = m.taps.c0;
     k.two_over_pi = m.two_over_pi;
-    auto fill_d = [&](const cm_iir_desc &desc, const double *na1, const double *na2, const double *b1, const double *b2, ScanFilterD &f) {
-        std::memset(&f, 0, sizeof f);
-        f.nsec = desc.n_sections;
-        f.shift = desc.shift;
-        for (int j = 0; j < desc.n_sections && j < kScanSec; ++j) {
-            f.na1[j] = na1[j]; f.na2[j] = na2[j]; f.b1[j] = b1[j]; f.b2[j] = b2[j];
-            double a[4] = {na1[j], 1.0, na2[j], 0.0}, mm[4] = {1.0, 0.0, 0.0, 1.0};
-            for (int e = c1; e > 0; e >>= 1) {
-                if (e & 1) { const double t[4] = {mm[0] * a[0] + mm[1] * a[2], mm[0] * a[1] + mm[1] * a[3], mm[2] * a[0] + mm[3] * a[2], mm[2] * a[1] + mm[3] * a[3]}; std::memcpy(mm, t, sizeof t); }
-                const double q[4] = {a[0] * a[0] + a[1] * a[2], a[0] * a[1] + a[1] * a[3], a[2] * a[0] + a[3] * a[2], a[2] * a[1] + a[3] * a[3]};
-                std::memcpy(a, q, sizeof q);
-            }
-            f.steps[j] = kScanSteps;
-            for (int kk = 0; kk < kScanSteps; ++kk) {
-                double big = 0.0;
-                for (int e = 0; e < 4; ++e) { f.m[j][kk][e] = mm[e]; big = std::fmax(big, std::fabs(mm[e])); }
-                if (big < 1e-20 && f.steps[j] == kScanSteps) f.steps[j] = kk;
-                const double q[4] = {mm[0] * mm[0] + mm[1] * mm[2], mm[0] * mm[1] + mm[1] * mm[3], mm[2] * mm[0] + mm[3] * mm[2], mm[2] * mm[1] + mm[3] * mm[3]};
-                std::memcpy(mm, q, sizeof q);
-            }
-        }
-    };
     const SecamBp64 &e64 = p->sd_e64;
-    fill_d(sd.chroma_bp, e64.bpf.na1, e64.bpf.na2, e64.bpf.b1, e64.bpf.b2, k.bpf);
-    fill_d(sd.bell, e64.bell.na1, e64.bell.na2, e64.bell.b1, e64.bell.b2, k.bell);
+    fill_scan_filter(sd.chroma_bp, e64.bpf.na1, e64.bpf.na2, e64.bpf.b1, e64.bpf.b2, c1, k.bpf, 1e-20);
+    fill_scan_filter(sd.bell, e64.bell.na1, e64.bell.na2, e64.bell.b1, e64.bell.b2, c1, k.bell, 1e-20);
     fill_scan_filter(sd.fm_lp, m.lpf.na1, m.lpf.na2, m.lpf.b1, m.lpf.b2, 2 * c1, k.lpf);
     fill_scan_filter(sd.luma_bs, m.ybs.na1, m.ybs.na2, m.ybs.b1, m.ybs.b2, c1, k.ybs);
     fill_scan_filter(sd.lf_rev, m.deemph.na1, m.deemph.na2, m.deemph.b1, m.deemph.b2, c1, k.deemph);
