@@ -4,6 +4,8 @@
 
 #include <cstdio>
 #include <cstring>
+#include <mutex>
+#include <set>
 #include <string>
 #include <vector>
 
@@ -34,6 +36,17 @@ thread_local std::string g_error;
 int fail(int code, const std::string &msg) {
     g_error = msg;
     return code;
+}
+// Dynamic LDS beyond 64 KB has to be allowed per kernel and per device: done once for each (kernel, device) of the process.
+int allow_dynamic_lds(const void *kernel, int device, size_t bytes, const char *what) {
+    static std::mutex mu;
+    static std::set<std::pair<const void *, int>> done;
+    std::lock_guard<std::mutex> lock(mu);
+    if (done.count({kernel, device})) return CM_OK;
+    if (hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess)
+        return fail(CM_ERR_LAUNCH, std::string("hipFuncSetAttribute(max dynamic LDS) failed for ") + what);
+    done.insert({kernel, device});
+    return CM_OK;
 }
 // A plan's tables live on the device that was current in cm_*_plan_create.  Every compute entry point checks that this
 // device is still the current one and that both image buffers are device memory of it: a plan used under another current
@@ -933,12 +946,7 @@ void make_scan_secam_mod(cm_plan *p, const cm_plan_desc &d) {
 template <int C1, int NW>
 int launch_scan_secam_mod(const cm_plan *p, const Geom &g, hipStream_t stream) {
     const size_t lds = sizeof(float) * (size_t)NW * scan_secam_mod_wave_floats<C1>();
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute((const void *)secam_mod_scan_kernel<C1, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-            return fail(CM_ERR_LAUNCH, "hipFuncSetAttribute(max dynamic LDS) failed for the SECAM modulator's scan kernel");
-        attr_set = true;
-    }
+    if (int rc = allow_dynamic_lds((const void *)secam_mod_scan_kernel<C1, NW>, p->device, lds, "the SECAM modulator's scan kernel")) return rc;
     const long long blocks = (g.total_calls + NW - 1) / NW;
     hipLaunchKernelGGL((secam_mod_scan_kernel<C1, NW>), dim3((int)blocks), dim3(64 * NW), lds, stream, g, p->scan_smod);
     hipError_t e = hipGetLastError();
@@ -981,12 +989,7 @@ void make_scan_secam_demod(cm_plan *p, const cm_plan_desc &d) {
 template <int C1, int NW>
 int launch_scan_secam_demod(const cm_plan *p, const Geom &g, hipStream_t stream) {
     const size_t lds = sizeof(float) * (size_t)NW * scan_secam_wave_floats<C1>();
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute((const void *)secam_demod_scan_kernel<C1, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-            return fail(CM_ERR_LAUNCH, "hipFuncSetAttribute(max dynamic LDS) failed for the SECAM decoder's scan kernel");
-        attr_set = true;
-    }
+    if (int rc = allow_dynamic_lds((const void *)secam_demod_scan_kernel<C1, NW>, p->device, lds, "the SECAM decoder's scan kernel")) return rc;
     const long long blocks = (g.total_calls + (NW - 1) - 1) / (NW - 1);
     hipLaunchKernelGGL((secam_demod_scan_kernel<C1, NW>), dim3((int)blocks), dim3(64 * NW), lds, stream, g, p->scan_sdem);
     hipError_t e = hipGetLastError();
@@ -1008,12 +1011,7 @@ int scan_secam_mod(const cm_plan *p, const Geom &g, hipStream_t stream) {
 template <int C1, int NW>
 static int launch_scan(const cm_plan *p, const Geom &gm, const Geom &gf, bool with_first, hipStream_t stream) {
     const size_t lds = sizeof(float) * (size_t)NW * scan_wave_floats<C1>();
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute((const void *)demod_scan_kernel<C1, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-            return fail(CM_ERR_LAUNCH, "hipFuncSetAttribute(max dynamic LDS) failed for the scan kernel");
-        attr_set = true;
-    }
+    if (int rc = allow_dynamic_lds((const void *)demod_scan_kernel<C1, NW>, p->device, lds, "the scan kernel")) return rc;
     const long long n_first = with_first ? (gf.total_calls + NW - 1) / NW : 0;
     const int per = gm.sparse ? NW : NW - p->scan_depth;      // calls per workgroup behind the halo waves
     const long long n_main = (gm.total_calls + per - 1) / per;
@@ -1392,12 +1390,7 @@ extern "C++" {
 template <int C1, int NW>
 static int launch_scan_mod(const cm_plan *p, const Geom &g, hipStream_t stream) {
     const size_t lds = sizeof(float) * (size_t)NW * scan_mod_wave_floats<C1>();
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute((const void *)qam_mod_scan_kernel<C1, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-            return fail(CM_ERR_LAUNCH, "hipFuncSetAttribute(max dynamic LDS) failed for the modulator's scan kernel");
-        attr_set = true;
-    }
+    if (int rc = allow_dynamic_lds((const void *)qam_mod_scan_kernel<C1, NW>, p->device, lds, "the modulator's scan kernel")) return rc;
     const long long blocks = (g.total_calls + NW - 1) / NW;
     hipLaunchKernelGGL((qam_mod_scan_kernel<C1, NW>), dim3((int)blocks), dim3(64 * NW), lds, stream, g, p->scan_mod);
     hipError_t e = hipGetLastError();
