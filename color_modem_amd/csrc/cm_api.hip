@@ -672,7 +672,7 @@ bool create_secam(cm_plan *p, const cm_plan_desc &d, std::string &err) {
     return true;
 }
 
-int scan_secam_demod(const cm_plan *p, const Geom &g, hipStream_t stream);    // small batches: secam_demod_scan_kernel (below)
+int scan_secam_demod(const cm_plan *p, const Geom &g, hipStream_t stream, bool u8);    // small batches: secam_demod_scan_kernel (below)
 int run_secam_demod(const cm_plan *p, Geom g, hipStream_t stream, bool u8 = false) {
     g.lanes = reinterpret_cast<const LaneK<float> *>(p->sd_lanes);
     g.carrier4 = p->fm_ref;
@@ -683,9 +683,9 @@ int run_secam_demod(const cm_plan *p, Geom g, hipStream_t stream, bool u8 = fals
     long long blocks = (g.total_calls + 62) / 63;
     if (blocks <= 0) return CM_OK;
     if (blocks > 0x7fffffffLL) return fail(CM_ERR_INVALID, "batch too large for one launch");
-    if (!u8 && p->scan_sdem && (p->small_batch == CM_SMALL_BATCH_SCAN || (p->small_batch == CM_SMALL_BATCH_AUTO && g.total_calls <= 9000)))       // (no row segments on this path: the hand-over comes later)
-        return scan_secam_demod(p, g, stream);
-    if (p->small_batch == CM_SMALL_BATCH_SCAN && !u8) return fail(CM_ERR_UNSUPPORTED, "the scan kernel does not serve this plan");
+    if (p->scan_sdem && (p->small_batch == CM_SMALL_BATCH_SCAN || (p->small_batch == CM_SMALL_BATCH_AUTO && g.total_calls <= 9000)))       // (no row segments on this path: the hand-over comes later)
+        return scan_secam_demod(p, g, stream, u8);
+    if (p->small_batch == CM_SMALL_BATCH_SCAN) return fail(CM_ERR_UNSUPPORTED, "the scan kernel does not serve this plan");
     SecamDemodArgs a;
     a.g = g;
     a.k = p->sd_k;
@@ -709,7 +709,7 @@ int run_secam_demod(const cm_plan *p, Geom g, hipStream_t stream, bool u8 = fals
     return CM_OK;
 }
 
-int scan_secam_mod(const cm_plan *p, const Geom &g, hipStream_t stream);      // small batches: secam_mod_scan_kernel (below)
+int scan_secam_mod(const cm_plan *p, const Geom &g, hipStream_t stream, bool u8);      // small batches: secam_mod_scan_kernel (below)
 int run_secam_mod(const cm_plan *p, Geom g, hipStream_t stream, bool u8 = false) {
     if (!p->sm_lanes) return fail(CM_ERR_UNSUPPORTED, "this plan has no modulator");
     g.lanes = reinterpret_cast<const LaneK<float> *>(p->sm_lanes);
@@ -718,8 +718,8 @@ int run_secam_mod(const cm_plan *p, Geom g, hipStream_t stream, bool u8 = false)
     long long blocks = (g.total_calls + (64 - p->mod_depth) - 1) / (64 - p->mod_depth);
     if (blocks <= 0) return CM_OK;
     if (blocks > 0x7fffffffLL) return fail(CM_ERR_INVALID, "batch too large for one launch");
-    if (!u8 && p->scan_smod && (p->small_batch == CM_SMALL_BATCH_SCAN || (p->small_batch == CM_SMALL_BATCH_AUTO && g.total_calls <= 40000)))
-        return scan_secam_mod(p, g, stream);
+    if (p->scan_smod && (p->small_batch == CM_SMALL_BATCH_SCAN || (p->small_batch == CM_SMALL_BATCH_AUTO && g.total_calls <= 40000)))
+        return scan_secam_mod(p, g, stream, u8);
     SecamModArgs a;
     a.g = g;
     a.k = p->sm_k;
@@ -943,12 +943,12 @@ void make_scan_secam_mod(cm_plan *p, const cm_plan_desc &d) {
     }
     p->scan_smod_c1 = c1;
 }
-template <int C1, int NW>
+template <int C1, int NW, bool U8>
 int launch_scan_secam_mod(const cm_plan *p, const Geom &g, hipStream_t stream) {
     const size_t lds = sizeof(float) * (size_t)NW * scan_secam_mod_wave_floats<C1>();
-    if (int rc = allow_dynamic_lds((const void *)secam_mod_scan_kernel<C1, NW>, p->device, lds, "the SECAM modulator's scan kernel")) return rc;
+    if (int rc = allow_dynamic_lds((const void *)secam_mod_scan_kernel<C1, NW, U8>, p->device, lds, "the SECAM modulator's scan kernel")) return rc;
     const long long blocks = (g.total_calls + NW - 1) / NW;
-    hipLaunchKernelGGL((secam_mod_scan_kernel<C1, NW>), dim3((int)blocks), dim3(64 * NW), lds, stream, g, p->scan_smod);
+    hipLaunchKernelGGL((secam_mod_scan_kernel<C1, NW, U8>), dim3((int)blocks), dim3(64 * NW), lds, stream, g, p->scan_smod);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(CM_ERR_LAUNCH, std::string("secam_mod_scan_kernel launch: ") + hipGetErrorString(e));
     return CM_OK;
@@ -986,40 +986,51 @@ void make_scan_secam_demod(cm_plan *p, const cm_plan_desc &d) {
     }
     p->scan_sdem_c1 = c1;
 }
-template <int C1, int NW>
+template <int C1, int NW, bool U8>
 int launch_scan_secam_demod(const cm_plan *p, const Geom &g, hipStream_t stream) {
     const size_t lds = sizeof(float) * (size_t)NW * scan_secam_wave_floats<C1>();
-    if (int rc = allow_dynamic_lds((const void *)secam_demod_scan_kernel<C1, NW>, p->device, lds, "the SECAM decoder's scan kernel")) return rc;
+    if (int rc = allow_dynamic_lds((const void *)secam_demod_scan_kernel<C1, NW, U8>, p->device, lds, "the SECAM decoder's scan kernel")) return rc;
     const long long blocks = (g.total_calls + (NW - 1) - 1) / (NW - 1);
-    hipLaunchKernelGGL((secam_demod_scan_kernel<C1, NW>), dim3((int)blocks), dim3(64 * NW), lds, stream, g, p->scan_sdem);
+    hipLaunchKernelGGL((secam_demod_scan_kernel<C1, NW, U8>), dim3((int)blocks), dim3(64 * NW), lds, stream, g, p->scan_sdem);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(CM_ERR_LAUNCH, std::string("secam_demod_scan_kernel launch: ") + hipGetErrorString(e));
     return CM_OK;
 }
-int scan_secam_demod(const cm_plan *p, const Geom &g, hipStream_t stream) {
-    if (p->scan_sdem_c1 == 12) return launch_scan_secam_demod<12, 4>(p, g, stream);
-    return launch_scan_secam_demod<16, 4>(p, g, stream);
+int scan_secam_demod(const cm_plan *p, const Geom &g, hipStream_t stream, bool u8) {
+    if (p->scan_sdem_c1 == 12) return u8 ? launch_scan_secam_demod<12, 4, true>(p, g, stream) : launch_scan_secam_demod<12, 4, false>(p, g, stream);
+    return u8 ? launch_scan_secam_demod<16, 4, true>(p, g, stream) : launch_scan_secam_demod<16, 4, false>(p, g, stream);
 }
-int scan_secam_mod(const cm_plan *p, const Geom &g, hipStream_t stream) {
+template <bool U8>
+int scan_secam_mod_as(const cm_plan *p, const Geom &g, hipStream_t stream) {
     switch (p->scan_smod_c1) {
-        case 12: return launch_scan_secam_mod<12, 4>(p, g, stream);
-        case 16: return launch_scan_secam_mod<16, 4>(p, g, stream);
-        case 24: return launch_scan_secam_mod<24, 4>(p, g, stream);
-        default: return launch_scan_secam_mod<32, 4>(p, g, stream);
+        case 12: return launch_scan_secam_mod<12, 4, U8>(p, g, stream);
+        case 16: return launch_scan_secam_mod<16, 4, U8>(p, g, stream);
+        case 24: return launch_scan_secam_mod<24, 4, U8>(p, g, stream);
+        default: return launch_scan_secam_mod<32, 4, U8>(p, g, stream);
     }
 }
-template <int C1, int NW>
+int scan_secam_mod(const cm_plan *p, const Geom &g, hipStream_t stream, bool u8) {
+    return u8 ? scan_secam_mod_as<true>(p, g, stream) : scan_secam_mod_as<false>(p, g, stream);
+}
+template <int C1, int NW, bool U8>
 static int launch_scan(const cm_plan *p, const Geom &gm, const Geom &gf, bool with_first, hipStream_t stream) {
     const size_t lds = sizeof(float) * (size_t)NW * scan_wave_floats<C1>();
-    if (int rc = allow_dynamic_lds((const void *)demod_scan_kernel<C1, NW>, p->device, lds, "the scan kernel")) return rc;
+    if (int rc = allow_dynamic_lds((const void *)demod_scan_kernel<C1, NW, U8>, p->device, lds, "the scan kernel")) return rc;
     const long long n_first = with_first ? (gf.total_calls + NW - 1) / NW : 0;
     const int per = gm.sparse ? NW : NW - p->scan_depth;      // calls per workgroup behind the halo waves
     const long long n_main = (gm.total_calls + per - 1) / per;
-    hipLaunchKernelGGL((demod_scan_kernel<C1, NW>), dim3((int)(n_first + n_main)), dim3(64 * NW), lds, stream, gm, gf, p->scan_main,
+    hipLaunchKernelGGL((demod_scan_kernel<C1, NW, U8>), dim3((int)(n_first + n_main)), dim3(64 * NW), lds, stream, gm, gf, p->scan_main,
                        with_first ? p->scan_first : p->scan_main, (int)n_first);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(CM_ERR_LAUNCH, std::string("demod_scan_kernel launch: ") + hipGetErrorString(e));
     return CM_OK;
+}
+template <bool U8>
+static int launch_scan_as(const cm_plan *p, const Geom &gm, const Geom &gf, bool with_first, hipStream_t stream) {
+    if (p->scan_c1 == 12) return launch_scan<12, 4, U8>(p, gm, gf, with_first, stream);
+    if (p->scan_c1 == 16) return launch_scan<16, 4, U8>(p, gm, gf, with_first, stream);
+    if (p->scan_c1 == 24) return launch_scan<24, 3, U8>(p, gm, gf, with_first, stream);
+    return launch_scan<32, 3, U8>(p, gm, gf, with_first, stream);
 }
 
 // gm: main-pass geometry (total_calls set); gf: first-line geometry (total_calls = number of runs) when the plan has one
@@ -1044,12 +1055,8 @@ int run_plan(const cm_plan *p, Geom gm, Geom gf, bool with_first, hipStream_t st
     LaunchFn fn = u8 ? p->fn_u8 : p->fn;
     if (!fn) return fail(CM_ERR_UNSUPPORTED, "no kernel instance for this request");
     const int mode = p->small_batch;
-    if (!u8 && p->scan_main && (mode == CM_SMALL_BATCH_SCAN || (mode == CM_SMALL_BATCH_AUTO && gm.total_calls <= CM_SCAN_MAX_CALLS))) {
-        if (p->scan_c1 == 12) return launch_scan<12, 4>(p, gm, gf, with_first, stream);
-        if (p->scan_c1 == 16) return launch_scan<16, 4>(p, gm, gf, with_first, stream);
-        if (p->scan_c1 == 24) return launch_scan<24, 3>(p, gm, gf, with_first, stream);
-        return launch_scan<32, 3>(p, gm, gf, with_first, stream);
-    }
+    if (p->scan_main && (mode == CM_SMALL_BATCH_SCAN || (mode == CM_SMALL_BATCH_AUTO && gm.total_calls <= CM_SCAN_MAX_CALLS)))
+        return u8 ? launch_scan_as<true>(p, gm, gf, with_first, stream) : launch_scan_as<false>(p, gm, gf, with_first, stream);
     if (mode == CM_SMALL_BATCH_SCAN) return fail(CM_ERR_UNSUPPORTED, "the scan kernel does not serve this plan / this entry point");
     int seg_len = 0;
     const int S = mode == CM_SMALL_BATCH_ROWS ? 1 : segment_geometry(p, gm.Wp, n_main + n_first, seg_len);
@@ -1387,15 +1394,24 @@ int cm_demodulate_run(const cm_plan *p, const float *composite, float *rgb, int3
 }
 
 extern "C++" {
-template <int C1, int NW>
+template <int C1, int NW, bool U8>
 static int launch_scan_mod(const cm_plan *p, const Geom &g, hipStream_t stream) {
     const size_t lds = sizeof(float) * (size_t)NW * scan_mod_wave_floats<C1>();
-    if (int rc = allow_dynamic_lds((const void *)qam_mod_scan_kernel<C1, NW>, p->device, lds, "the modulator's scan kernel")) return rc;
+    if (int rc = allow_dynamic_lds((const void *)qam_mod_scan_kernel<C1, NW, U8>, p->device, lds, "the modulator's scan kernel")) return rc;
     const long long blocks = (g.total_calls + NW - 1) / NW;
-    hipLaunchKernelGGL((qam_mod_scan_kernel<C1, NW>), dim3((int)blocks), dim3(64 * NW), lds, stream, g, p->scan_mod);
+    hipLaunchKernelGGL((qam_mod_scan_kernel<C1, NW, U8>), dim3((int)blocks), dim3(64 * NW), lds, stream, g, p->scan_mod);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(CM_ERR_LAUNCH, std::string("qam_mod_scan_kernel launch: ") + hipGetErrorString(e));
     return CM_OK;
+}
+template <bool U8>
+static int launch_scan_mod_as(const cm_plan *p, const Geom &g, hipStream_t stream) {
+    switch (p->scan_mod_c1) {
+        case 12: return launch_scan_mod<12, 4, U8>(p, g, stream);
+        case 16: return launch_scan_mod<16, 4, U8>(p, g, stream);
+        case 24: return launch_scan_mod<24, 4, U8>(p, g, stream);
+        default: return launch_scan_mod<32, 4, U8>(p, g, stream);
+    }
 }
 }  // extern "C++"
 #ifndef CM_SCAN_MOD_MAX_CALLS
@@ -1413,14 +1429,8 @@ static int run_mod(const cm_plan *p, Geom g, hipStream_t stream, bool u8 = false
     if (blocks <= 0) return CM_OK;
     if (blocks > 0x7fffffffLL) return fail(CM_ERR_INVALID, "batch too large for one launch");
     const int mode = p->small_batch;
-    if (!u8 && p->scan_mod && (mode == CM_SMALL_BATCH_SCAN || (mode == CM_SMALL_BATCH_AUTO && g.total_calls <= CM_SCAN_MOD_MAX_CALLS))) {
-        switch (p->scan_mod_c1) {
-            case 12: return launch_scan_mod<12, 4>(p, g, stream);
-            case 16: return launch_scan_mod<16, 4>(p, g, stream);
-            case 24: return launch_scan_mod<24, 4>(p, g, stream);
-            default: return launch_scan_mod<32, 4>(p, g, stream);
-        }
-    }
+    if (p->scan_mod && (mode == CM_SMALL_BATCH_SCAN || (mode == CM_SMALL_BATCH_AUTO && g.total_calls <= CM_SCAN_MOD_MAX_CALLS)))
+        return u8 ? launch_scan_mod_as<true>(p, g, stream) : launch_scan_mod_as<false>(p, g, stream);
     return (u8 ? p->mod_fn_u8 : p->mod_fn)(g, p->mod_k.data(), (int)blocks, stream);
 }
 

@@ -270,6 +270,72 @@ __device__ __forceinline__ Geom select_geom(const Geom &gm, const Geom &gf, bool
     return g;
 }
 
+// ---- the ImageModem byte boundary (image.py:7-8, 20-25, 43-45, 62-71) at the edges of the scan kernels ----------------------
+// U8: `row` points at bytes (Geom's strides count bytes then) - composite rows hold one byte per sample, picture rows interleaved
+// R, G, B; the same conversions as the streaming kernels' (decode_bytes, read_tile3_u8, put_rgb, composite_byte).
+typedef unsigned scan_u32u __attribute__((aligned(1)));
+template <bool U8>
+__device__ __forceinline__ const float *scan_row(const float *base, long long frame, long long frame_stride, long long row, long long row_stride) {
+    if (U8) return (const float *)((const unsigned char *)base + frame * frame_stride + row * row_stride);
+    return base + frame * frame_stride + row * row_stride;
+}
+// composite samples n .. n + 3 of a row
+template <bool U8>
+__device__ __forceinline__ f4 scan_load4(const float *row, int n) {
+    if (U8) return decode_bytes(*(const scan_u32u *)((const unsigned char *)row + n));
+    return *(const f4 *)(row + n);
+}
+// (r, g, b) of pixels n .. n + 3
+template <bool U8>
+__device__ __forceinline__ void scan_load_rgb4(const float *row, long long plane, int n, f4 out[3]) {
+    if (U8) {
+        const scan_u32u *p = (const scan_u32u *)((const unsigned char *)row + 3 * n);
+        const unsigned w0 = p[0], w1 = p[1], w2 = p[2];      // R0 G0 B0 R1 | G1 B1 R2 G2 | B2 R3 G3 B3
+        const float s = 1.0f / 255.0f;
+        out[0] = f4{(float)(w0 & 0xffu) * s, (float)(w0 >> 24) * s, (float)((w1 >> 16) & 0xffu) * s, (float)((w2 >> 8) & 0xffu) * s};
+        out[1] = f4{(float)((w0 >> 8) & 0xffu) * s, (float)(w1 & 0xffu) * s, (float)(w1 >> 24) * s, (float)((w2 >> 16) & 0xffu) * s};
+        out[2] = f4{(float)((w0 >> 16) & 0xffu) * s, (float)((w1 >> 8) & 0xffu) * s, (float)(w2 & 0xffu) * s, (float)(w2 >> 24) * s};
+    } else {
+#pragma unroll
+        for (int p = 0; p < 3; ++p) out[p] = *(const f4 *)(row + p * plane + n);
+    }
+}
+// (r, g, b) of pixel n
+template <bool U8>
+__device__ __forceinline__ void scan_load_rgb1(const float *row, long long plane, int n, float &r, float &g, float &b) {
+    if (U8) {
+        const unsigned char *p = (const unsigned char *)row + 3 * n;
+        const float s = 1.0f / 255.0f;
+        r = (float)p[0] * s; g = (float)p[1] * s; b = (float)p[2] * s;
+    } else {
+        r = row[n]; g = row[plane + n]; b = row[2 * plane + n];
+    }
+}
+// four composite samples out
+template <bool U8>
+__device__ __forceinline__ void scan_store4(float *row, int n, const f4 &o) {
+    if (U8) {
+        const unsigned w = (unsigned)composite_byte(o.x) | (unsigned)composite_byte(o.y) << 8 | (unsigned)composite_byte(o.z) << 16 |
+                           (unsigned)composite_byte(o.w) << 24;
+        *(scan_u32u *)((unsigned char *)row + n) = w;
+    } else {
+        *(f4 *)(row + n) = o;
+    }
+}
+// four interleaved RGB pixels out: bytes = uint8(rint(255 * clip(x, 0, 1)))
+__device__ __forceinline__ void scan_store_rgb4_u8(float *row, int n, const f4 &r, const f4 &g, const f4 &b) {
+    auto pk = [](float a, float b2, float c, float d) {
+        unsigned w = __builtin_amdgcn_cvt_pk_u8_f32(255.f * a, 0, 0);
+        w = __builtin_amdgcn_cvt_pk_u8_f32(255.f * b2, 1, w);
+        w = __builtin_amdgcn_cvt_pk_u8_f32(255.f * c, 2, w);
+        return __builtin_amdgcn_cvt_pk_u8_f32(255.f * d, 3, w);
+    };
+    scan_u32u *p = (scan_u32u *)((unsigned char *)row + 3 * n);
+    p[0] = pk(r.x, g.x, b.x, r.y);
+    p[1] = pk(g.y, b.y, r.z, g.z);
+    p[2] = pk(b.z, r.w, g.w, b.w);
+}
+
 // One launch: workgroups [0, n_first) run the plain first-line pass (NW sparse calls each), the others the main pass
 // (NW - depth calls behind depth halo waves).  Dynamic LDS: NW * scan_wave_floats<C1>() floats.
 template <int C1> constexpr int scan_wave_floats() { return 5 * (64 * C1 + 2 * kScanMargin); }      // x and the two halves of P and Q
@@ -277,7 +343,7 @@ template <int C1> constexpr int scan_wave_floats() { return 5 * (64 * C1 + 2 * k
 // amdgpu_waves_per_eu(2, 2): at most 256 registers per lane.  Left alone the compiler takes 256 VGPRs + 21 / 102 AGPRs for the long
 // chunks and parks values in the AGPRs - and those builds gave wrong, run-to-run different results on the device
 // (profiles/r03_scan_notes.txt item 4); with the cap the same values go through 92 / 460 B of scratch per lane and the results are exact.
-template <int C1, int NW>
+template <int C1, int NW, bool U8 = false>
 __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2))) void demod_scan_kernel(const Geom gm, const Geom gf, const ScanK *km, const ScanK *kf, int n_first) {
     constexpr int C2 = 2 * C1, N1 = 64 * C1, MG = kScanMargin;
     constexpr int kX = N1 + 2 * MG;       // one 1x-rate row with its margins; a 2x-rate row is two of them (even / odd samples)
@@ -319,7 +385,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
         lk = g.lanes[((long long)fmod * 3 + lc.regime) * g.n_lines + lc.line];
     }
     {
-        const float *xp = g.in + lc.frame * g.in_frame_stride + (long long)lc.src_row * g.Wp;
+        const float *xp = scan_row<U8>(g.in, lc.frame, g.in_frame_stride, lc.src_row, g.Wp);
         X[lane - MG] = 0.f;
         X[N1 + lane] = 0.f;
         PE[lane - MG] = 0.f;
@@ -330,7 +396,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
         for (int q = 0; q < C1 / 4; ++q) {
             const int n = n0 + 4 * q;
             f4 t = {0.f, 0.f, 0.f, 0.f};
-            if (alive && n < g.Wp) t = *(const f4 *)(xp + n);
+            if (alive && n < g.Wp) t = scan_load4<U8>(xp, n);
             if (n + 3 >= W) {
                 if (n >= W) t.x = 0.f;
                 if (n + 1 >= W) t.y = 0.f;
@@ -548,11 +614,11 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
         for (int i = 0; i < C1; ++i) car2[i] = *(const f2 *)(g.carrier2 + 2 * (n0 + i < W ? n0 + i : W - 1));
         if (!k.bsf) {      // luma source: this call's row or the previous call's (comb.py:102), straight from memory
             const int luma_row = ((g.luma_prev_bits >> lc.regime) & 1) ? lc.prev_row : lc.src_row;
-            const float *lp = g.in + lc.frame * g.in_frame_stride + (long long)luma_row * g.Wp;
+            const float *lp = scan_row<U8>(g.in, lc.frame, g.in_frame_stride, luma_row, g.Wp);
 #pragma unroll
             for (int q = 0; q < C1 / 4; ++q) {
                 f4 t = {0.f, 0.f, 0.f, 0.f};
-                if (n0 + 4 * q < g.Wp) t = *(const f4 *)(lp + n0 + 4 * q);
+                if (n0 + 4 * q < g.Wp) t = scan_load4<U8>(lp, n0 + 4 * q);
                 y[4 * q] = t.x; y[4 * q + 1] = t.y; y[4 * q + 2] = t.z; y[4 * q + 3] = t.w;
             }
         }
@@ -601,6 +667,21 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
     }
     CM_SCAN_STAMP();   // re-modulation, notch
     if (!lc.store_ok) return;
+    if (U8) {      // interleaved bytes: the three planes of a quad of pixels together
+        float *ob = (float *)scan_row<true>(g.out, lc.frame, g.out_frame_stride, lc.out_row, g.out_row_stride);
+#pragma unroll
+        for (int q = 0; q < C1 / 4; ++q) {
+            f4 o[3];
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+                const float m0 = k.m[3 * p], m1 = k.m[3 * p + 1], m2 = k.m[3 * p + 2];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[p][e] = fmaf_(m0, y[4 * q + e], fmaf_(m1, u[4 * q + e], m2 * v[4 * q + e]));
+            }
+            if (n0 + 4 * q < g.Wp) scan_store_rgb4_u8(ob, n0 + 4 * q, o[0], o[1], o[2]);
+        }
+        return;
+    }
     float *op = g.out + lc.frame * g.out_frame_stride + (long long)lc.out_row * g.out_row_stride + n0;
 #pragma unroll
     for (int p = 0; p < 3; ++p) {
@@ -642,7 +723,7 @@ struct ScanModK {
 typedef const __attribute__((address_space(4))) ScanModK const_ScanModK;
 template <int C1> constexpr int scan_mod_wave_floats() { return 2 * (64 * C1 + 2 * kScanMargin); }
 
-template <int C1, int NW>
+template <int C1, int NW, bool U8 = false>
 __global__ __launch_bounds__(64 * NW) void qam_mod_scan_kernel(const Geom g, const ScanModK *km) {
     constexpr int N1 = 64 * C1, MG = kScanMargin;
     extern __shared__ __attribute__((aligned(16))) float scan_lds[];
@@ -666,8 +747,8 @@ __global__ __launch_bounds__(64 * NW) void qam_mod_scan_kernel(const Geom g, con
         }
     }
     const long long row_stride = g.in_row_stride ? g.in_row_stride : g.W;
-    const float *rp = g.in + lc.frame * g.in_frame_stride + (long long)lc.src_row * row_stride;
-    const float *rq = g.in + lp.frame * g.in_frame_stride + (long long)lp.src_row * row_stride;
+    const float *rp = scan_row<U8>(g.in, lc.frame, g.in_frame_stride, lc.src_row, row_stride);
+    const float *rq = scan_row<U8>(g.in, lp.frame, g.in_frame_stride, lp.src_row, row_stride);
     const int depth = k.depth;
     f2 car2[C1];
 #pragma unroll
@@ -693,12 +774,10 @@ __global__ __launch_bounds__(64 * NW) void qam_mod_scan_kernel(const Geom g, con
         const int n = n0 + 4 * q;
         f4 a[3], b[3];
 #pragma unroll
-        for (int p = 0; p < 3; ++p) {
-            a[p] = b[p] = f4{0.f, 0.f, 0.f, 0.f};
-            if (n < g.Wp) {
-                a[p] = *(const f4 *)(rp + p * g.in_plane_stride + n);
-                if (depth >= 1) b[p] = *(const f4 *)(rq + p * g.in_plane_stride + n);
-            }
+        for (int p = 0; p < 3; ++p) a[p] = b[p] = f4{0.f, 0.f, 0.f, 0.f};
+        if (n < g.Wp) {
+            scan_load_rgb4<U8>(rp, g.in_plane_stride, n, a);
+            if (depth >= 1) scan_load_rgb4<U8>(rq, g.in_plane_stride, n, b);
         }
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -710,9 +789,10 @@ __global__ __launch_bounds__(64 * NW) void qam_mod_scan_kernel(const Geom g, con
     }
     {   // FilterFunction pads with the last sample (utils.py:31-33): (u, v)[W - 1], by every lane
         float yl, ul, vl;
-        const float *a = rp + (W - 1), *b = rq + (W - 1);
-        yuv_of(a[0], a[g.in_plane_stride], a[2 * g.in_plane_stride], depth >= 1 ? b[0] : 0.f, depth >= 1 ? b[g.in_plane_stride] : 0.f,
-               depth >= 1 ? b[2 * g.in_plane_stride] : 0.f, yl, ul, vl);
+        float ar, ag, ab, br = 0.f, bg = 0.f, bb = 0.f;
+        scan_load_rgb1<U8>(rp, g.in_plane_stride, W - 1, ar, ag, ab);
+        if (depth >= 1) scan_load_rgb1<U8>(rq, g.in_plane_stride, W - 1, br, bg, bb);
+        yuv_of(ar, ag, ab, br, bg, bb, yl, ul, vl);
         if (n0 + C1 > W) {
 #pragma unroll
             for (int i = 0; i < C1; ++i) uv[i] = n0 + i >= W ? f2{ul, vl} : uv[i];
@@ -729,7 +809,7 @@ __global__ __launch_bounds__(64 * NW) void qam_mod_scan_kernel(const Geom g, con
         scan_put<C1>(PV, s, n0, k.pre.shift);
     }
     if (!lc.store_ok) return;
-    float *op = g.out + lc.frame * g.out_frame_stride + (long long)lc.out_row * g.out_row_stride;
+    float *op = (float *)scan_row<U8>(g.out, lc.frame, g.out_frame_stride, lc.out_row, g.out_row_stride);
 #pragma unroll
     for (int q = 0; q < C1 / 4; ++q) {
         if (n0 + 4 * q >= g.Wp) continue;
@@ -742,7 +822,7 @@ __global__ __launch_bounds__(64 * NW) void qam_mod_scan_kernel(const Geom g, con
             const float cs = fmaf_(lk.vcph, car.x, -(lk.vsph * car.y));
             o[e] = y[4 * q + e] + fmaf_(sn, tu[e], cs * tv[e]);
         }
-        *(f4 *)(op + n0 + 4 * q) = o;
+        scan_store4<U8>(op, n0 + 4 * q, o);
     }
 }
 
@@ -809,7 +889,7 @@ __device__ __forceinline__ void scan_iir_d(double (&v)[CN], const_ScanFilterD &f
 }
 template <int C1> constexpr int scan_secam_mod_wave_floats() { return 2 * (64 * C1 + 2 * kScanMargin); }    // one row of doubles
 
-template <int C1, int NW>
+template <int C1, int NW, bool U8 = false>
 __global__ __launch_bounds__(64 * NW) void secam_mod_scan_kernel(const Geom g, const ScanSecamModK *km) {
     constexpr int N1 = 64 * C1, MG = kScanMargin;
     extern __shared__ __attribute__((aligned(16))) float scan_lds[];
@@ -829,8 +909,8 @@ __global__ __launch_bounds__(64 * NW) void secam_mod_scan_kernel(const Geom g, c
         lk = ((const SecamModLaneK<float, double> *)g.lanes)[((long long)fmod * 3 + lc.regime) * g.n_lines + lc.line];
     }
     const long long row_stride = g.in_row_stride ? g.in_row_stride : g.W;
-    const float *rp = g.in + lc.frame * g.in_frame_stride + (long long)lc.src_row * row_stride;
-    const float *rq = g.in + lp.frame * g.in_frame_stride + (long long)lp.src_row * row_stride;
+    const float *rp = scan_row<U8>(g.in, lc.frame, g.in_frame_stride, lc.src_row, row_stride);
+    const float *rq = scan_row<U8>(g.in, lp.frame, g.in_frame_stride, lp.src_row, row_stride);
     const int depth = k.depth;
     const bool own_db = lk.own_is_db != 0.f;
     // (luma, d) of one sample (secam_mod_kernel's body, cm_secam_kernels.h: the same operation order)
@@ -854,12 +934,10 @@ __global__ __launch_bounds__(64 * NW) void secam_mod_scan_kernel(const Geom g, c
         const int n = n0 + 4 * q;
         f4 a[3], b[3];
 #pragma unroll
-        for (int p = 0; p < 3; ++p) {
-            a[p] = b[p] = f4{0.f, 0.f, 0.f, 0.f};
-            if (n < g.Wp) {
-                a[p] = *(const f4 *)(rp + p * g.in_plane_stride + n);
-                if (depth >= 1) b[p] = *(const f4 *)(rq + p * g.in_plane_stride + n);
-            }
+        for (int p = 0; p < 3; ++p) a[p] = b[p] = f4{0.f, 0.f, 0.f, 0.f};
+        if (n < g.Wp) {
+            scan_load_rgb4<U8>(rp, g.in_plane_stride, n, a);
+            if (depth >= 1) scan_load_rgb4<U8>(rq, g.in_plane_stride, n, b);
         }
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -871,9 +949,10 @@ __global__ __launch_bounds__(64 * NW) void secam_mod_scan_kernel(const Geom g, c
     }
     {   // FilterFunction pads with the last sample (utils.py:31-33): d[W - 1], by every lane
         float yl, dl;
-        const float *a = rp + (W - 1), *b = rq + (W - 1);
-        yd_of(a[0], a[g.in_plane_stride], a[2 * g.in_plane_stride], depth >= 1 ? b[0] : 0.f, depth >= 1 ? b[g.in_plane_stride] : 0.f,
-              depth >= 1 ? b[2 * g.in_plane_stride] : 0.f, yl, dl);
+        float ar, ag, ab, br = 0.f, bg = 0.f, bb = 0.f;
+        scan_load_rgb1<U8>(rp, g.in_plane_stride, W - 1, ar, ag, ab);
+        if (depth >= 1) scan_load_rgb1<U8>(rq, g.in_plane_stride, W - 1, br, bg, bb);
+        yd_of(ar, ag, ab, br, bg, bb, yl, dl);
         if (n0 + C1 > W) {
 #pragma unroll
             for (int i = 0; i < C1; ++i) dd[i] = n0 + i >= W ? (double)dl : dd[i];
@@ -920,7 +999,7 @@ __global__ __launch_bounds__(64 * NW) void secam_mod_scan_kernel(const Geom g, c
         for (int i = 0; i < C1; ++i) ph[i] += tot;
     }
     if (!lc.store_ok) return;
-    float *op = g.out + lc.frame * g.out_frame_stride + (long long)lc.out_row * g.out_row_stride + n0;
+    float *op = (float *)scan_row<U8>(g.out, lc.frame, g.out_frame_stride, lc.out_row, g.out_row_stride);
     const double inv_two_pi = 1.0 / k.two_pi;
 #pragma unroll
     for (int q = 0; q < C1 / 4; ++q) {
@@ -933,7 +1012,7 @@ __global__ __launch_bounds__(64 * NW) void secam_mod_scan_kernel(const Geom g, c
             sincosf((float)acc, &sn, &cs);
             o[e] = y[i] + (re[i] * cs - im[i] * sn);                                      // secam.py:246, 276
         }
-        if (n0 + 4 * q < g.Wp) *(f4 *)(op + 4 * q) = o;
+        if (n0 + 4 * q < g.Wp) scan_store4<U8>(op, n0 + 4 * q, o);
     }
 }
 
@@ -959,7 +1038,7 @@ struct ScanSecamK {
 typedef const __attribute__((address_space(4))) ScanSecamK const_ScanSecamK;
 template <int C1> constexpr int scan_secam_wave_floats() { return 7 * (64 * C1 + 2 * kScanMargin); }
 
-template <int C1, int NW>
+template <int C1, int NW, bool U8 = false>
 __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2))) void secam_demod_scan_kernel(const Geom g, const ScanSecamK *km) {
     constexpr int C2 = 2 * C1, N1 = 64 * C1, MG = kScanMargin, kRow = N1 + 2 * MG;
     extern __shared__ __attribute__((aligned(16))) float scan_lds[];
@@ -988,14 +1067,14 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
     // ---- the row ------------------------------------------------------------------------------------------------------------
     float xr[C1];
     {
-        const float *xp = g.in + lc.frame * g.in_frame_stride + (long long)lc.src_row * g.Wp;
+        const float *xp = scan_row<U8>(g.in, lc.frame, g.in_frame_stride, lc.src_row, g.Wp);
         X[lane - MG] = 0.f;
         X[N1 + lane] = 0.f;
 #pragma unroll
         for (int q = 0; q < C1 / 4; ++q) {
             const int n = n0 + 4 * q;
             f4 t = {0.f, 0.f, 0.f, 0.f};
-            if (alive && n < g.Wp) t = *(const f4 *)(xp + n);
+            if (alive && n < g.Wp) t = scan_load4<U8>(xp, n);
             if (n + 3 >= W) {
                 if (n >= W) t.x = 0.f;
                 if (n + 1 >= W) t.y = 0.f;
@@ -1114,7 +1193,8 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
     if (w < 1 || !alive || !lc.store_ok) return;
     // ---- finish (SecamDemod::finish): this call's and the previous call's colour difference, matrix ---------------------------------
     const lds_float *CPREV = COWN - scan_secam_wave_floats<C1>();
-    float *op = g.out + lc.frame * g.out_frame_stride + (long long)lc.out_row * g.out_row_stride + n0;
+    float *op = U8 ? (float *)scan_row<true>(g.out, lc.frame, g.out_frame_stride, lc.out_row, g.out_row_stride)
+                   : g.out + lc.frame * g.out_frame_stride + (long long)lc.out_row * g.out_row_stride + n0;
     const bool own_db = lk.own_is_db != 0.f;
 #pragma unroll
     for (int q = 0; q < C1 / 4; ++q) {
@@ -1128,8 +1208,11 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
             for (int p = 0; p < 3; ++p) o[p][e] = fmaf_(k.m[3 * p], luma, fmaf_(k.m[3 * p + 1], dr, k.m[3 * p + 2] * db));
         }
         if (n0 + 4 * q < g.Wp) {
+            if (U8) scan_store_rgb4_u8(op, n0 + 4 * q, o[0], o[1], o[2]);
+            else {
 #pragma unroll
-            for (int p = 0; p < 3; ++p) *(f4 *)(op + p * g.out_plane_stride + 4 * q) = o[p];
+                for (int p = 0; p < 3; ++p) *(f4 *)(op + p * g.out_plane_stride + 4 * q) = o[p];
+            }
         }
     }
 }

@@ -660,7 +660,7 @@ def test_small_batch_modes(stack, enc, size):
     WAVEFRONT per scan line instead (the recursive filters as a scan over the lanes), or - where the plan's shape does not fit
     that kernel - cuts the rows into segments entered from a zero state a warm-up length earlier.  Every mode against the float64
     oracle at the usual tolerance, against the streaming kernel on whole rows at float32 resolution, and through the fused byte
-    boundary (which runs in segments)."""
+    boundary in every mode."""
     import torch
     from oracle import cm_oracle
     from color_modem_amd.image import _as_bytes
@@ -690,11 +690,13 @@ def test_small_batch_modes(stack, enc, size):
             assert stacks.rel_err(got['auto'][i], out[i].cpu().numpy()) < (6e-6 if stack.startswith('secam') else 2e-6), (stack, i)
     if size[0] % 4 == 0:
         comp8 = _as_bytes(image.ImageModem.encode_composite_level(comp[:1].astype(numpy.float64)))
-        got8 = im.demodulate_frames_u8(comp8, first_frame=1)
         ref_in = image.ImageModem.decode_composite_level(comp8.astype(numpy.float64) / 255.0).astype(numpy.float32)
         want8 = _as_bytes(cm_oracle.demodulate_frames_f32(modem, ref_in, first_frame=1, n_threads=8).astype(numpy.float64)).transpose(0, 2, 3, 1)
-        d8 = numpy.abs(got8.astype(int) - want8.astype(int))
-        assert d8.max() <= 1 and (d8 > 0).mean() < 5e-3, (stack, d8.max(), (d8 > 0).mean())
+        for mode in got:
+            eng.set_small_batch(mode)
+            got8 = im.demodulate_frames_u8(comp8, first_frame=1)
+            d8 = numpy.abs(got8.astype(int) - want8.astype(int))
+            assert d8.max() <= 1 and (d8 > 0).mean() < 5e-3, (stack, mode, d8.max(), (d8 > 0).mean())
 
 
 def test_scan_kernel_batches():
@@ -733,6 +735,16 @@ def test_small_batch_modes_modulate(stack, size):
         for i in range(3):
             assert stacks.rel_err(got[mode][i], want[i]) < TOL, (stack, mode, i)
             assert stacks.rel_err(got[mode][i], got['rows'][i]) < 1e-6, (stack, mode, i)
+    if size[0] % 16 == 0:       # the fused byte boundary in every mode
+        from color_modem_amd.image import _as_bytes
+        rgb8 = _as_bytes(rgb.astype(numpy.float64)).transpose(0, 2, 3, 1).copy()
+        rgbq = (rgb8.astype(numpy.float64) / 255.0).astype(numpy.float32).transpose(0, 3, 1, 2).copy()
+        want8 = _as_bytes(image.ImageModem.encode_composite_level(cm_oracle.modulate_frames_f32(modem, rgbq, first_frame=2, n_threads=8).astype(numpy.float64)))
+        for mode in ('rows', 'scan', 'auto'):
+            eng.set_small_batch(mode)
+            got8 = eng.modulate_frames_u8(rgb8, first_frame=2)
+            d8 = numpy.abs(got8.astype(int) - want8.astype(int))
+            assert d8.max() <= 1 and (d8 > 0).mean() < 5e-3, (stack, mode, d8.max(), (d8 > 0).mean())
     if size[1] <= 64:
         big = torch.from_numpy(rgb).cuda().repeat(24, 1, 1, 1)[:70].contiguous()
         eng.set_small_batch('scan')
