@@ -1012,25 +1012,27 @@ int scan_secam_mod_as(const cm_plan *p, const Geom &g, hipStream_t stream) {
 int scan_secam_mod(const cm_plan *p, const Geom &g, hipStream_t stream, bool u8) {
     return u8 ? scan_secam_mod_as<true>(p, g, stream) : scan_secam_mod_as<false>(p, g, stream);
 }
+// km / kf: the constants of the main pass and of the plain first-line pass (two plans' in the wrapped combs); depth: the main pass's comb depth
 template <int C1, int NW, bool U8>
-static int launch_scan(const cm_plan *p, const Geom &gm, const Geom &gf, bool with_first, hipStream_t stream) {
+static int launch_scan(int device, const ScanK *km, const ScanK *kf, int depth, const Geom &gm, const Geom &gf, bool with_first, hipStream_t stream) {
     const size_t lds = sizeof(float) * (size_t)NW * scan_wave_floats<C1>();
-    if (int rc = allow_dynamic_lds((const void *)demod_scan_kernel<C1, NW, U8>, p->device, lds, "the scan kernel")) return rc;
+    if (int rc = allow_dynamic_lds((const void *)demod_scan_kernel<C1, NW, U8>, device, lds, "the scan kernel")) return rc;
     const long long n_first = with_first ? (gf.total_calls + NW - 1) / NW : 0;
-    const int per = gm.sparse ? NW : NW - p->scan_depth;      // calls per workgroup behind the halo waves
+    const int per = gm.sparse ? NW : NW - depth;      // calls per workgroup behind the halo waves
     const long long n_main = (gm.total_calls + per - 1) / per;
-    hipLaunchKernelGGL((demod_scan_kernel<C1, NW, U8>), dim3((int)(n_first + n_main)), dim3(64 * NW), lds, stream, gm, gf, p->scan_main,
-                       with_first ? p->scan_first : p->scan_main, (int)n_first);
+    hipLaunchKernelGGL((demod_scan_kernel<C1, NW, U8>), dim3((int)(n_first + n_main)), dim3(64 * NW), lds, stream, gm, gf, km,
+                       with_first ? kf : km, (int)n_first);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(CM_ERR_LAUNCH, std::string("demod_scan_kernel launch: ") + hipGetErrorString(e));
     return CM_OK;
 }
 template <bool U8>
-static int launch_scan_as(const cm_plan *p, const Geom &gm, const Geom &gf, bool with_first, hipStream_t stream) {
-    if (p->scan_c1 == 12) return launch_scan<12, 4, U8>(p, gm, gf, with_first, stream);
-    if (p->scan_c1 == 16) return launch_scan<16, 4, U8>(p, gm, gf, with_first, stream);
-    if (p->scan_c1 == 24) return launch_scan<24, 3, U8>(p, gm, gf, with_first, stream);
-    return launch_scan<32, 3, U8>(p, gm, gf, with_first, stream);
+static int launch_scan_as(int c1, int device, const ScanK *km, const ScanK *kf, int depth, const Geom &gm, const Geom &gf, bool with_first,
+                          hipStream_t stream) {
+    if (c1 == 12) return launch_scan<12, 4, U8>(device, km, kf, depth, gm, gf, with_first, stream);
+    if (c1 == 16) return launch_scan<16, 4, U8>(device, km, kf, depth, gm, gf, with_first, stream);
+    if (c1 == 24) return launch_scan<24, 3, U8>(device, km, kf, depth, gm, gf, with_first, stream);
+    return launch_scan<32, 3, U8>(device, km, kf, depth, gm, gf, with_first, stream);
 }
 
 // gm: main-pass geometry (total_calls set); gf: first-line geometry (total_calls = number of runs) when the plan has one
@@ -1056,7 +1058,8 @@ int run_plan(const cm_plan *p, Geom gm, Geom gf, bool with_first, hipStream_t st
     if (!fn) return fail(CM_ERR_UNSUPPORTED, "no kernel instance for this request");
     const int mode = p->small_batch;
     if (p->scan_main && (mode == CM_SMALL_BATCH_SCAN || (mode == CM_SMALL_BATCH_AUTO && gm.total_calls <= CM_SCAN_MAX_CALLS)))
-        return u8 ? launch_scan_as<true>(p, gm, gf, with_first, stream) : launch_scan_as<false>(p, gm, gf, with_first, stream);
+        return u8 ? launch_scan_as<true>(p->scan_c1, p->device, p->scan_main, p->scan_first, p->scan_depth, gm, gf, with_first, stream)
+                  : launch_scan_as<false>(p->scan_c1, p->device, p->scan_main, p->scan_first, p->scan_depth, gm, gf, with_first, stream);
     if (mode == CM_SMALL_BATCH_SCAN) return fail(CM_ERR_UNSUPPORTED, "the scan kernel does not serve this plan / this entry point");
     int seg_len = 0;
     const int S = mode == CM_SMALL_BATCH_ROWS ? 1 : segment_geometry(p, gm.Wp, n_main + n_first, seg_len);
@@ -1078,6 +1081,17 @@ int check_lines(const cm_plan *p, const Pass &pass, int max_line) {
 }
 
 
+// Scratch under stream capture: hipMallocAsync / hipFreeAsync on a capturing stream become memory nodes of the graph, and graphs of
+// wrapped-comb calls with such nodes faulted on replay on ROCm 7.2, at 512 and at 256 frames per call, run-to-run differently
+// (profiles/r03_wrapped_small_batch.txt) - the same calls made eagerly are exact at every size.  The entry points that need scratch
+// (the wrapped combs; widths that are not a multiple of 4) refuse a capturing stream instead of leaving it to the runtime.
+static int refuse_capture(hipStream_t stream, const char *what) {
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(stream, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone)
+        return fail(CM_ERR_UNSUPPORTED, std::string(what) + " needs stream-ordered scratch memory and cannot be captured into a HIP graph");
+    return CM_OK;
+}
+
 // ---- widths that are not multiples of 4 ---------------------------------------------------------------------------------
 // The kernels move rows as 16-byte vectors and need every row 16-byte aligned.  Dense float images of such a width go
 // through device buffers whose rows are pitched to the next multiple of 4 samples: one strided copy in, one out, both on
@@ -1096,6 +1110,7 @@ template <class F>
 int with_pitched_rows(const float *in, long long in_rows, float *out, long long out_rows, int W, hipStream_t stream, F run) {
     const int wp = (W + 3) & ~3;
     if (wp == W) return run(in, out);
+    if (int rc_ = refuse_capture(stream, "an image width that is not a multiple of 4")) return rc_;
     PitchedIO io;
     io.stream = stream;
     HIP_TRY(hipMallocAsync((void **)&io.in, (size_t)in_rows * wp * sizeof(float), stream), CM_ERR_LAUNCH);
@@ -2140,6 +2155,44 @@ int launch_wrap_back(const Geom &g, const cm_plan *backend, const cm_comb_wrap_d
     return notch ? launch_wrap_back_i<NP, SP, U8, RT, false, true>(a, (int)blocks, stream)
                  : launch_wrap_back_i<NP, SP, U8, RT, false, false>(a, (int)blocks, stream);
 }
+// small batches: one wavefront per call (wrap_back_scan_kernel), the pre-correction constants are the backend modulator's
+template <int C1, int NW, bool U8>
+int launch_wrap_back_scan(const Geom &g, const cm_plan *backend, const ScanWrapArgs &a, hipStream_t stream) {
+    const size_t lds = sizeof(float) * (size_t)NW * scan_mod_wave_floats<C1>();
+    if (int rc = allow_dynamic_lds((const void *)wrap_back_scan_kernel<C1, NW, U8>, backend->device, lds, "the wrapped combs' scan kernel")) return rc;
+    const long long blocks = (g.total_calls + NW - 1) / NW;
+    hipLaunchKernelGGL((wrap_back_scan_kernel<C1, NW, U8>), dim3((int)blocks), dim3(64 * NW), lds, stream, g, backend->scan_mod, a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(CM_ERR_LAUNCH, std::string("wrap_back_scan_kernel launch: ") + hipGetErrorString(e));
+    return CM_OK;
+}
+template <bool U8>
+int wrap_back_scan(const Geom &g, const cm_plan *backend, const cm_comb_wrap_desc &w, hipStream_t stream) {
+    ScanWrapArgs a;
+    std::memset(&a, 0, sizeof a);
+    SosK<float, 1> notch;
+    double g_n = 0.0;
+    std::string err;
+    if (!convert_sos_optional<float, 1>(w.notch, FORM_SYM, notch, g_n, err, "notch")) return fail(CM_ERR_UNSUPPORTED, err);
+    if (w.notch.n_sections) {
+        ScanFilter f;
+        fill_scan_filter(w.notch, notch.na1, notch.na2, notch.b1, notch.b2, backend->scan_mod_c1, f);
+        a.na1 = f.na1[0]; a.na2 = f.na2[0]; a.b1 = f.b1[0]; a.b2 = f.b2[0];
+        a.notch_steps = f.steps[0];
+        std::memcpy(a.nm, f.m[0], sizeof a.nm);
+        a.notch_gain = (float)g_n;
+    }
+    for (int i = 0; i < 9; ++i) a.m[i] = (float)w.matrix[i];
+    a.own_delay = w.own_delay ? 1 : 0;
+    a.minavg = w.minavg ? 1 : 0;
+    a.strip = w.strip_chroma ? 1 : 0;
+    switch (backend->scan_mod_c1) {
+        case 12: return launch_wrap_back_scan<12, 4, U8>(g, backend, a, stream);
+        case 16: return launch_wrap_back_scan<16, 4, U8>(g, backend, a, stream);
+        case 24: return launch_wrap_back_scan<24, 4, U8>(g, backend, a, stream);
+        default: return launch_wrap_back_scan<32, 4, U8>(g, backend, a, stream);
+    }
+}
 int run_wrap_back(Geom g, const cm_plan *backend, const cm_comb_wrap_desc &w, int64_t first_frame, bool u8, hipStream_t stream) {
     g.lanes = reinterpret_cast<const LaneK<float> *>(backend->mod_lanes);
     g.carrier4 = backend->carrier4;
@@ -2147,6 +2200,12 @@ int run_wrap_back(Geom g, const cm_plan *backend, const cm_comb_wrap_desc &w, in
     g.cycle = backend->mod_cycle;
     g.n_lines = backend->mod_n_lines;
     set_first_frame(backend, g, first_frame, backend->mod_cycle);
+    {
+        const int mode = backend->small_batch;
+        if (backend->scan_mod && (mode == CM_SMALL_BATCH_SCAN || (mode == CM_SMALL_BATCH_AUTO && g.total_calls <= CM_SCAN_MOD_MAX_CALLS)))
+            return u8 ? wrap_back_scan<true>(g, backend, w, stream) : wrap_back_scan<false>(g, backend, w, stream);
+        if (mode == CM_SMALL_BATCH_SCAN) return fail(CM_ERR_UNSUPPORTED, "the scan kernel does not serve this backend plan");
+    }
     switch (backend->mod_shape) {
     case 1: return u8 ? launch_wrap_back<1, 2, true, false>(g, backend, w, stream) : launch_wrap_back<1, 2, false, false>(g, backend, w, stream);
     case 2: return u8 ? launch_wrap_back<2, 4, true, false>(g, backend, w, stream) : launch_wrap_back<2, 4, false, false>(g, backend, w, stream);
@@ -2180,13 +2239,23 @@ int run_wrap_inner(const cm_plan *inner, const cm_plan *first, Geom g, float *sc
     g.skip_first = inner->desc.first_is_plain;
     set_first_frame(inner, g, first_frame, inner->main.cycle);
     Geom none = g;
+    Geom s = g;
+    if (first && with_first) {
+        s.sparse = 1;
+        s.skip_first = 0;
+        s.total_calls = g.rows_mode ? 1 : (g.total_calls / g.calls_per_frame) * g.runs_per_frame;
+        set_first_frame(first, s, first_frame, first->main.cycle);
+        // small batches: both passes in ONE launch of the scan kernel, as a plan with a first-line pass of its own has them
+        const int mode = inner->small_batch;
+        if (inner->scan_main && first->scan_main && inner->scan_c1 == first->scan_c1 && first->small_batch == mode && g.total_calls > 0 &&
+            (mode == CM_SMALL_BATCH_SCAN || (mode == CM_SMALL_BATCH_AUTO && g.total_calls <= CM_SCAN_MAX_CALLS))) {
+            finish_geom(inner, inner->main, g);
+            finish_geom(first, first->main, s);
+            return launch_scan_as<false>(inner->scan_c1, inner->device, inner->scan_main, first->scan_main, inner->scan_depth, g, s, true, stream);
+        }
+    }
     int rc = run_plan(inner, g, none, false, stream);
     if (rc || !first || !with_first) return rc;
-    Geom s = g;
-    s.sparse = 1;
-    s.skip_first = 0;
-    s.total_calls = g.rows_mode ? 1 : (g.total_calls / g.calls_per_frame) * g.runs_per_frame;
-    set_first_frame(first, s, first_frame, first->main.cycle);
     return run_plan(first, s, none, false, stream);
 }
 struct AsyncBuf {
@@ -2223,6 +2292,7 @@ int wrap_frames(const cm_plan *inner, const cm_plan *first, const cm_plan *backe
     AsyncBuf scratch;
     scratch.stream = stream;
     const int64_t chunk = n_frames < kChunk ? n_frames : kChunk;
+    if (int rc_ = refuse_capture(stream, "a wrapped comb decoder")) return rc_;
     HIP_TRY(hipMallocAsync(&scratch.p, (size_t)chunk * g.calls_per_frame * 3 * wp * sizeof(float), stream), CM_ERR_LAUNCH);
     for (int64_t f0 = 0; f0 < n_frames; f0 += chunk) {
         const int64_t nf = n_frames - f0 < chunk ? n_frames - f0 : chunk;
@@ -2280,6 +2350,7 @@ int cm_comb_wrap_demodulate_frames_u8(const cm_plan *inner, const cm_plan *first
     const int W = d.width, H = d.height;
     if (W % 4 != 0) return fail(CM_ERR_UNSUPPORTED, "the fused uint8 boundary needs a width that is a multiple of 4");
     // the level-decoded composite (image.py:24-25, 62) once, as float rows: the inner decoder's component output has no byte form
+    if (int rc_ = refuse_capture((hipStream_t)stream, "a wrapped comb decoder")) return rc_;
     AsyncBuf comp;
     comp.stream = (hipStream_t)stream;
     const long long quads = n_frames * H * (long long)(W / 4);
@@ -2319,6 +2390,7 @@ int cm_comb_wrap_demodulate_run(const cm_plan *inner, const cm_plan *first, cons
         g.first_line[0] = g.first_line[1] = first_line;
         g.k0 = k0;
         g.total_calls = n_calls;
+        if (int rc_ = refuse_capture((hipStream_t)stream, "a wrapped comb decoder")) return rc_;
         AsyncBuf scratch;
         scratch.stream = (hipStream_t)stream;
         HIP_TRY(hipMallocAsync(&scratch.p, (size_t)n_calls * 3 * wp * sizeof(float), (hipStream_t)stream), CM_ERR_LAUNCH);

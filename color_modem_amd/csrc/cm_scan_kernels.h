@@ -827,6 +827,160 @@ __global__ __launch_bounds__(64 * NW) void qam_mod_scan_kernel(const Geom g, con
 }
 
 // =============================================================================================================================
+// The back end of the wrapped PAL combs (SimpleCombModem / Simple3DCombModem around PalDModem / Pal3DModem, ref comb.py:96-113;
+// comb_wrap_back_kernel, cm_wrap_kernels.h) with one wavefront per call: the components of this call and of the call before it
+// straight from the scratch of the inner decoder, (u, v) = avg / minavg, the backend modulator's pre-correction low-pass as one
+// packed scan (its constants: the backend plan's ScanModK), re-modulation at line - 2 own_delay, notch, matrix.
+// =============================================================================================================================
+struct ScanWrapArgs {              // by value: a few scalars + the wrapper's notch (one section, shift 0) in the scan form
+    int32_t own_delay, minavg, strip, notch_steps;
+    float na1, na2, b1, b2, notch_gain;      // notch_gain 0: no notch
+    float nm[kScanSteps][4];
+    float m[9];
+};
+
+template <int C1, int NW, bool U8 = false>
+__global__ __launch_bounds__(64 * NW) void wrap_back_scan_kernel(const Geom g, const ScanModK *km, const ScanWrapArgs a) {
+    constexpr int N1 = 64 * C1, MG = kScanMargin;
+    extern __shared__ __attribute__((aligned(16))) float scan_lds[];
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    const_ScanModK &k = *(const_ScanModK *)km;
+    const long long c = (long long)blockIdx.x * NW + w;
+    if (c >= g.total_calls) return;                       // (no barrier in this kernel)
+    const LaneCall lc = locate_call_at(g, c, true);
+    lds_float *PU = (lds_float *)scan_lds + w * scan_mod_wave_floats<C1>() + MG, *PV = PU + N1 + 2 * MG;
+    const int W = g.W, n0 = lane * C1;
+    const bool first = lc.kk == 0;                        // call 0 of a run: (y, u, v) = curr, not stripped (comb.py:97-99)
+    const bool strip = a.strip != 0 && !first;
+    const float strip_f = strip ? 1.f : 0.f;
+    const bool take_prev_y = a.own_delay != 0 && !first;
+    ModLaneK<float> lk;
+    {
+        int lm = lc.line - 2 * a.own_delay;               // the line the wrapper re-modulates at; unused where first
+        if (lm < 0) lm &= 1;
+        const int fmod = (int)((g.first_frame + lc.frame) % g.cycle);
+        lk = ((const ModLaneK<float> *)g.lanes)[((long long)fmod * 3 + lc.regime) * g.n_lines + lm];
+        float rc, rs;
+        if (frame_turn(g, lc.frame, rc, rs)) {
+            turn(lk.cph, lk.sph, rc, rs);
+            turn(lk.vcph, lk.vsph, rc, rs);
+        }
+    }
+    const long long row_stride = g.in_row_stride ? g.in_row_stride : g.W;
+    const float *rp = g.in + lc.frame * g.in_frame_stride + (long long)lc.src_row * row_stride;
+    const float *rq = g.in + lc.frame * g.in_frame_stride + (long long)lc.prev_row * row_stride;
+    f2 car2[C1];
+#pragma unroll
+    for (int i = 0; i < C1; ++i) car2[i] = *(const f2 *)(g.carrier2 + 2 * (n0 + i < W ? n0 + i : W - 1));
+    auto mix = [&](float cy, float cu, float cv, float py, float pu, float pv, float &ys, float &u, float &v) {
+        u = a.minavg ? minavg_(pu, cu) : 0.5f * (pu + cu);                     // comb.py:102-104
+        v = a.minavg ? minavg_(pv, cv) : 0.5f * (pv + cv);
+        if (first) { u = cu; v = cv; }
+        ys = take_prev_y ? py : cy;
+    };
+    float y[C1], ud[C1], vd[C1];
+    f2 uv[C1];
+#pragma unroll
+    for (int q = 0; q < C1 / 4; ++q) {
+        const int n = n0 + 4 * q;
+        f4 cur[3], prv[3];
+#pragma unroll
+        for (int p = 0; p < 3; ++p) cur[p] = prv[p] = f4{0.f, 0.f, 0.f, 0.f};
+        if (n < g.Wp) {
+            scan_load_rgb4<false>(rp, g.in_plane_stride, n, cur);
+            scan_load_rgb4<false>(rq, g.in_plane_stride, n, prv);
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float ys, u, v;
+            mix(cur[0][e], cur[1][e], cur[2][e], prv[0][e], prv[1][e], prv[2][e], ys, u, v);
+            y[4 * q + e] = ys;
+            ud[4 * q + e] = u;
+            vd[4 * q + e] = v;
+            uv[4 * q + e] = f2{u, v};
+        }
+    }
+    {   // FilterFunction pads with the last sample (utils.py:31-33): (u, v)[W - 1], by every lane
+        float cy, cu, cv, py, pu, pv, ys, ul, vl;
+        scan_load_rgb1<false>(rp, g.in_plane_stride, W - 1, cy, cu, cv);
+        scan_load_rgb1<false>(rq, g.in_plane_stride, W - 1, py, pu, pv);
+        mix(cy, cu, cv, py, pu, pv, ys, ul, vl);
+        if (n0 + C1 > W) {
+#pragma unroll
+            for (int i = 0; i < C1; ++i) uv[i] = n0 + i >= W ? f2{ul, vl} : uv[i];
+        }
+    }
+    scan_iir2<C1>(uv, k.pre, lane);
+    {
+        float s[C1];
+#pragma unroll
+        for (int i = 0; i < C1; ++i) s[i] = uv[i].x;
+        scan_put<C1>(PU, s, n0, k.pre.shift);
+#pragma unroll
+        for (int i = 0; i < C1; ++i) s[i] = uv[i].y;
+        scan_put<C1>(PV, s, n0, k.pre.shift);
+    }
+#pragma unroll
+    for (int q = 0; q < C1 / 4; ++q) {
+        const f4 tu = *(const lds_f4 *)(PU + n0 + 4 * q), tv = *(const lds_f4 *)(PV + n0 + 4 * q);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int i = 4 * q + e;
+            const f2 car = car2[i];
+            const float sn = fmaf_(lk.sph, car.x, lk.cph * car.y);
+            const float cs = fmaf_(lk.vcph, car.x, -(lk.vsph * car.y));
+            y[i] = fmaf_(-strip_f, fmaf_(sn, tu[e], cs * tv[e]), y[i]);       // comb.py:105-107
+        }
+    }
+    if (a.notch_gain != 0.f) {     // comb.py:108-110: luma[0 .. W) from a zero state (one section, shift 0), where the wrapper strips
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < C1; ++i) {
+            const float x = n0 + i < W ? y[i] : 0.f, yy = x + s1;
+            s1 = fmaf_(a.na1, yy, fmaf_(a.b1, x, s2));
+            s2 = fmaf_(a.na2, yy, a.b2 * x);
+        }
+        float e1 = scan_up(s1, 1, lane), e2 = scan_up(s2, 1, lane);
+#pragma unroll
+        for (int kk = 0; kk < kScanSteps; ++kk) {
+            if (kk < a.notch_steps) {
+                const float t1 = scan_up(e1, 1 << kk, lane), t2 = scan_up(e2, 1 << kk, lane);
+                e1 = fmaf_(a.nm[kk][0], t1, fmaf_(a.nm[kk][1], t2, e1));
+                e2 = fmaf_(a.nm[kk][2], t1, fmaf_(a.nm[kk][3], t2, e2));
+            }
+        }
+        s1 = e1;
+        s2 = e2;
+#pragma unroll
+        for (int i = 0; i < C1; ++i) {
+            const float x = n0 + i < W ? y[i] : 0.f, yy = x + s1;
+            s1 = fmaf_(a.na1, yy, fmaf_(a.b1, x, s2));
+            s2 = fmaf_(a.na2, yy, a.b2 * x);
+            if (strip) y[i] = yy * a.notch_gain;
+        }
+    }
+    if (!lc.store_ok) return;
+    float *op = (float *)scan_row<U8>(g.out, lc.frame, g.out_frame_stride, lc.out_row, g.out_row_stride);
+#pragma unroll
+    for (int q = 0; q < C1 / 4; ++q) {
+        f4 o[3];
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                o[p][e] = fmaf_(a.m[3 * p], y[4 * q + e], fmaf_(a.m[3 * p + 1], ud[4 * q + e], a.m[3 * p + 2] * vd[4 * q + e]));
+        }
+        if (n0 + 4 * q >= g.Wp) continue;
+        if (U8) scan_store_rgb4_u8(op, n0 + 4 * q, o[0], o[1], o[2]);
+        else {
+#pragma unroll
+            for (int p = 0; p < 3; ++p) *(f4 *)(op + p * g.out_plane_stride + n0 + 4 * q) = o[p];
+        }
+    }
+}
+
+// =============================================================================================================================
 // The SECAM modulator (ref secam.py:240-276; SecamMod::step, cm_stages.h) with one wavefront per call.  Its colour-difference
 // path runs in float64 on the device (the phase is an integral over the whole line), so the scans here carry doubles:
 //   d -> pre-correction low-pass (two sections, FilterFunction shift s_p) -> LF pre-emphasis (one section, from sample 0) ->

@@ -74,7 +74,13 @@ class WrappedCombEngine(object):
         self.desc = w
 
     def describe(self):
-        return 'composition: %s (components, every call of the batch) | comb_wrap_back_kernel' % self.inner.describe()
+        return 'composition: %s (components, every call of the batch) | comb_wrap_back_kernel (small batches: wrap_back_scan_kernel)' % self.inner.describe()
+
+    def set_small_batch(self, mode):
+        """Engine.set_small_batch for the three plans a wrapped decode runs through (inner decoder, plain first line, back end)."""
+        for e in (self.inner, self.first, self.mod):
+            if e is not None:
+                e.set_small_batch(mode)
 
     def _plans(self, device):
         return (self.inner._plans.get(device), self.first._plans.get(device) if self.first is not None else None,

@@ -835,6 +835,81 @@ def test_wrapped_pal_comb_batches_and_bytes():
     assert d8.max() <= 1 and (d8 > 0).mean() < 5e-3, (d8.max(), (d8 > 0).mean())
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize('stack,size', [('simple3d_pald', (720, 576)), ('simple_pald', (768, 40)), ('simple3d_pal3d', (720, 64)),
+                                        ('simple3d_pald_minavg', (720, 33)), ('simple3d_pald_notch', (720, 576)), ('simple_pal3d_notch', (704, 24)),
+                                        ('simple3d_pald', (1280, 32)), ('simple_pald', (722, 20))])
+def test_wrapped_pal_comb_small_batch_modes(stack, size):
+    """Small batches of the wrapped combs: the inner decoder, the plain first lines and the wrapper's back end on one wavefront per
+    call (demod_scan_kernel twice, wrap_back_scan_kernel) against the three streaming kernels on whole rows and the float64 oracle,
+    floats and bytes; the per-row protocol runs on the same kernels."""
+    import torch
+    from oracle import cm_oracle
+    from color_modem_amd.image import _as_bytes
+    modem = stacks.make(stack, size)
+    im = image.ImageModem(modem)
+    eng = im._engine()
+    rgb = testing.synthetic_rgb(2, size[1], size[0], seed=3 + size[1])
+    comp = cm_oracle.modulate_frames_f32(stacks.make('pal_s', size), rgb, first_frame=1, n_threads=8)
+    want = cm_oracle.demodulate_frames_f32(modem, comp, first_frame=1, n_threads=8)
+    got = {}
+    for mode in ('rows', 'scan', 'auto'):
+        eng.set_small_batch(mode)
+        got[mode] = im.demodulate_frames(comp, first_frame=1)
+        for i in range(2):
+            assert stacks.rel_err(got[mode][i], want[i]) < TOL, (stack, mode, i)
+            assert stacks.rel_err(got[mode][i], got['rows'][i]) < 2e-6, (stack, mode, i)
+    if size[1] <= 64:       # 75 frames in one launch of each kernel
+        big = torch.from_numpy(comp).cuda().repeat(40, 1, 1)[:75].contiguous()
+        eng.set_small_batch('scan')
+        a = eng.demodulate_frames(big, first_frame=1)
+        eng.set_small_batch('rows')
+        b = eng.demodulate_frames(big, first_frame=1)
+        assert float((a - b).abs().max() / b.abs().max()) < 2e-6
+    if size[0] % 4 == 0:
+        comp8 = _as_bytes(image.ImageModem.encode_composite_level(comp[:1].astype(numpy.float64)))
+        ref_in = image.ImageModem.decode_composite_level(comp8.astype(numpy.float64) / 255.0).astype(numpy.float32)
+        want8 = _as_bytes(cm_oracle.demodulate_frames_f32(modem, ref_in, first_frame=1, n_threads=8).astype(numpy.float64)).transpose(0, 2, 3, 1)
+        for mode in ('rows', 'scan'):
+            eng.set_small_batch(mode)
+            d8 = numpy.abs(eng.demodulate_frames_u8(comp8, 1).astype(int) - want8.astype(int))
+            assert d8.max() <= 1 and (d8 > 0).mean() < 5e-3, (stack, mode, d8.max(), (d8 > 0).mean())
+
+
+@pytest.mark.gpu
+def test_hip_graph_capture():
+    """A plan's launch captured into a HIP graph replays bit for bit (small batches: the scan kernel); the entry points that need
+    stream-ordered scratch - the wrapped combs - refuse a capturing stream (cm_api.hip: refuse_capture)."""
+    import torch
+    comp = torch.from_numpy(testing.synthetic_composite(2, 64, 720, seed=9)).cuda()
+    out = torch.empty((2, 3, 64, 720), dtype=torch.float32, device='cuda')
+    eng = image.ImageModem(stacks.make('pal_d', (720, 64)))._engine()
+    want = eng.demodulate_frames(comp, 1).clone()
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        eng.demodulate_frames(comp, 1, out=out)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=side):
+            eng.demodulate_frames(comp, 1, out=out)
+    torch.cuda.synchronize()
+    out.zero_()
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out, want)
+    weng = image.ImageModem(stacks.make('simple3d_pald', (720, 64)))._engine()
+    wwant = weng.demodulate_frames(comp, 1).clone()
+    g2 = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(side):
+        g2.capture_begin()
+        try:
+            with pytest.raises(NotImplementedError):
+                weng.demodulate_frames(comp, 1, out=out)
+        finally:
+            g2.capture_end()
+    torch.cuda.synchronize()
+    assert torch.equal(weng.demodulate_frames(comp, 1), wwant)
+
+
 # ---- the time-blocked decoder with the half-band FIRs on the matrix pipe (csrc/cm_blk_kernels.h, opt-in: CM_BLK=1) ----------
 @pytest.mark.gpu
 def test_secam_float32_margin_case_and_the_float64_switch():
