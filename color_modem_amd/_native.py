@@ -25,7 +25,7 @@ SYMBOLS = ('cm_last_error', 'cm_abi_version', 'cm_device_count', 'cm_plan_create
            'cm_mac_modulate_run', 'cm_mac_demodulate_run',
            'cm_am_plan_create', 'cm_am_plan_destroy', 'cm_am_modulate_frames', 'cm_am_demodulate_frames',
            'cm_am_modulate_run', 'cm_am_demodulate_run', 'cm_am_modulate_frames_noise', 'cm_am_modulate_run_noise',
-           'cm_am_modulate_frames_u8', 'cm_am_demodulate_frames_u8',
+           'cm_am_modulate_frames_u8', 'cm_am_demodulate_frames_u8', 'cm_am_plan_set_small_batch',
            'cm_comb_wrap_demodulate_frames', 'cm_comb_wrap_demodulate_frames_u8', 'cm_comb_wrap_demodulate_run')
 
 _lib = None
@@ -78,6 +78,7 @@ def lib():
     L.cm_modulate_run.argtypes = [vp, vp, vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, vp]
     L.cm_plan_describe.argtypes = [vp, ctypes.c_char_p, ctypes.c_int32]
     L.cm_plan_set_small_batch.argtypes = [vp, ctypes.c_int32]
+    L.cm_am_plan_set_small_batch.argtypes = [vp, ctypes.c_int32]
     L.cm_set_pointer_check.argtypes = [ctypes.c_int32]
     L.cm_set_pointer_check.restype = None
     L.cm_mac_plan_create.argtypes = [ctypes.POINTER(MacDesc), ctypes.POINTER(vp)]

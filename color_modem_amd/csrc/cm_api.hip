@@ -18,6 +18,7 @@
 #include "cm_am_kernels.h"
 #include "cm_wrap_kernels.h"
 #include "cm_scan_kernels.h"
+#include "cm_am_scan_kernels.h"
 #include "cm_blk_kernels.h"
 #include "cm_am_plan.h"
 
@@ -1754,7 +1755,18 @@ struct cm_am_plan {
     NiirDemodK<float> nd;
     NiirModK<float> nm;
     std::string demod_error, mod_error;
+    // small batches: one wavefront per call (cm_am_scan_kernels.h); null where the plan's shape does not fit
+    ScanProtoK *scan_pd = nullptr;
+    ScanProtoModK *scan_pm = nullptr;
+    int scan_pd_c1 = 0, scan_pm_c1 = 0;
+    mutable int small_batch = CM_SMALL_BATCH_AUTO;     // cm_am_plan_set_small_batch
 };
+#ifndef CM_AM_SCAN_MAX_CALLS
+#define CM_AM_SCAN_MAX_CALLS 6000
+#endif
+#ifndef CM_AM_SCAN_MOD_MAX_CALLS
+#define CM_AM_SCAN_MOD_MAX_CALLS 12000
+#endif
 
 namespace {
 int am_geom(const cm_am_plan *p, int64_t first_frame, AmGeom &a) {
@@ -1835,12 +1847,107 @@ int niir_launch_demod(const cm_am_plan *p, Geom g, int64_t first_frame, hipStrea
     if (e != hipSuccess) return fail(CM_ERR_LAUNCH, std::string("niir_demod_kernel launch: ") + hipGetErrorString(e));
     return CM_OK;
 }
+// ---- Proto-SECAM in small batches: the scan kernels' constants and launchers ---------------------------------------------------
+static bool taps3_sparse(const float *h) {
+    for (int q = 0; 3 * q < kAmTaps; ++q)
+        if (q != kAmHalf && h[3 * q] != 0.f) return false;
+    return true;
+}
+static int am_scan_chunk(int width, std::initializer_list<int> shifts3) {      // chunk of 1x-rate samples per lane, or 0
+    int q = 0;
+    for (int s : shifts3) q = std::max(q, (s + 2) / 3);
+    if (q > kScanMaxShift) return 0;
+    for (int c : {12, 16})
+        if (width + q <= 64 * c) return c;
+    return 0;
+}
+void make_scan_proto(cm_am_plan *p) {
+    const cm_am_desc &d = p->desc;
+    if (d.kind != CM_AM_PROTO_SECAM) return;
+    if (p->demod_error.empty()) {
+        const int c1 = am_scan_chunk(d.width, {d.bandpass_up.shift, d.bandstop_up.shift, d.lowpass_up.shift});
+        if (c1) {
+            ScanProtoK k;
+            std::memset(&k, 0, sizeof k);
+            const ProtoDemodK<float> &m = p->pd;
+            k.width = d.width; k.c1 = c1;
+            for (int i = 0; i < kAmTaps; ++i) k.h[i] = m.taps.h[i];
+            k.sparse_taps = taps3_sparse(k.h) ? 1 : 0;
+            fill_scan_filter(d.bandpass_up, m.ext.na1, m.ext.na2, m.ext.b1, m.ext.b2, 3 * c1, k.ext);
+            fill_scan_filter(d.bandstop_up, m.rem.na1, m.rem.na2, m.rem.b1, m.rem.b2, 3 * c1, k.rem);
+            fill_scan_filter(d.lowpass_up, m.post.na1, m.post.na2, m.post.b1, m.post.b2, 3 * c1, k.post);
+            k.chroma_gain = m.chroma_gain; k.luma_gain = m.luma_gain;
+            for (int i = 0; i < 9; ++i) k.m[i] = m.m[i / 3][i % 3];
+            if (hipMalloc((void **)&p->scan_pd, sizeof k) == hipSuccess && hipMemcpy(p->scan_pd, &k, sizeof k, hipMemcpyHostToDevice) == hipSuccess)
+                p->scan_pd_c1 = c1;
+            else p->scan_pd = nullptr;
+        }
+    }
+    if (p->mod_error.empty() && d.precorrect.shift <= kScanMaxShift) {
+        const int c1 = am_scan_chunk(d.width + d.precorrect.shift, {d.premod_luma_filter ? d.bandstop_up.shift : 0});
+        if (c1) {
+            ScanProtoModK k;
+            std::memset(&k, 0, sizeof k);
+            const ProtoModK<float> &m = p->pm;
+            k.width = d.width; k.c1 = c1; k.luma_filter = m.luma_filter; k.averaging = d.averaging ? 1 : 0;
+            for (int i = 0; i < kAmTaps; ++i) k.h[i] = m.taps.h[i];
+            k.sparse_taps = taps3_sparse(k.h) ? 1 : 0;
+            fill_scan_filter(d.precorrect, m.pre.na1, m.pre.na2, m.pre.b1, m.pre.b2, c1, k.pre);
+            fill_scan_filter(d.bandstop_up, m.rem.na1, m.rem.na2, m.rem.b1, m.rem.b2, 3 * c1, k.rem);
+            k.pre_gain = m.pre_gain; k.luma_gain = m.luma_gain;
+            for (int i = 0; i < 9; ++i) k.e[i] = m.e[i / 3][i % 3];
+            if (hipMalloc((void **)&p->scan_pm, sizeof k) == hipSuccess && hipMemcpy(p->scan_pm, &k, sizeof k, hipMemcpyHostToDevice) == hipSuccess)
+                p->scan_pm_c1 = c1;
+            else p->scan_pm = nullptr;
+        }
+    }
+}
+extern "C++" {
+template <int C1, int NW, bool U8>
+int launch_scan_proto_demod(const cm_am_plan *p, const Geom &g, const AmGeom &a, hipStream_t stream) {
+    const size_t lds = sizeof(float) * (size_t)NW * scan_proto_wave_floats<C1>();
+    if (int rc = allow_dynamic_lds((const void *)proto_demod_scan_kernel<C1, NW, U8>, p->device, lds, "the Proto-SECAM decoder's scan kernel")) return rc;
+    const long long blocks = (g.total_calls + (NW - 1) - 1) / (NW - 1);
+    hipLaunchKernelGGL((proto_demod_scan_kernel<C1, NW, U8>), dim3((int)blocks), dim3(64 * NW), lds, stream, g, a, p->scan_pd);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(CM_ERR_LAUNCH, std::string("proto_demod_scan_kernel launch: ") + hipGetErrorString(e));
+    return CM_OK;
+}
+template <int C1, int NW, bool U8>
+int launch_scan_proto_mod(const cm_am_plan *p, const Geom &g, const AmGeom &a, hipStream_t stream) {
+    const size_t lds = sizeof(float) * (size_t)NW * scan_proto_wave_floats<C1>();
+    if (int rc = allow_dynamic_lds((const void *)proto_mod_scan_kernel<C1, NW, U8>, p->device, lds, "the Proto-SECAM encoder's scan kernel")) return rc;
+    const long long blocks = (g.total_calls + NW - 1) / NW;
+    hipLaunchKernelGGL((proto_mod_scan_kernel<C1, NW, U8>), dim3((int)blocks), dim3(64 * NW), lds, stream, g, a, p->scan_pm);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(CM_ERR_LAUNCH, std::string("proto_mod_scan_kernel launch: ") + hipGetErrorString(e));
+    return CM_OK;
+}
+}  // extern "C++"
+// 1: launched on the scan kernel (rc holds the status); 0: the streaming kernel's turn
+static bool am_scan_wanted(const cm_am_plan *p, const void *scan, long long calls, long long max_calls, int &rc) {
+    rc = CM_OK;
+    const int mode = p->small_batch;
+    if (scan && (mode == CM_SMALL_BATCH_SCAN || (mode == CM_SMALL_BATCH_AUTO && calls <= max_calls))) return true;
+    if (mode == CM_SMALL_BATCH_SCAN) rc = fail(CM_ERR_UNSUPPORTED, "the scan kernel does not serve this plan / this direction");
+    return false;
+}
 int am_launch_demod(const cm_am_plan *p, Geom g, int64_t first_frame, hipStream_t stream, bool u8 = false) {
     if (!p->demod_error.empty()) return fail(CM_ERR_UNSUPPORTED, p->demod_error);
     if (p->desc.kind == CM_AM_NIIR) return niir_launch_demod(p, g, first_frame, stream, p->desc.strip_chroma != 0, u8);
     long long blocks = (g.total_calls + 62) / 63;
     if (blocks <= 0) return CM_OK;
     if (blocks > 0x7fffffffLL) return fail(CM_ERR_INVALID, "batch too large for one launch");
+    {
+        int rc;
+        if (am_scan_wanted(p, p->scan_pd, g.total_calls, CM_AM_SCAN_MAX_CALLS, rc)) {
+            AmGeom ag;
+            am_geom(p, first_frame, ag);
+            if (p->scan_pd_c1 == 12) return u8 ? launch_scan_proto_demod<12, 4, true>(p, g, ag, stream) : launch_scan_proto_demod<12, 4, false>(p, g, ag, stream);
+            return u8 ? launch_scan_proto_demod<16, 4, true>(p, g, ag, stream) : launch_scan_proto_demod<16, 4, false>(p, g, ag, stream);
+        }
+        if (rc) return rc;
+    }
     ProtoDemodArgs a;
     a.g = g;
     am_geom(p, first_frame, a.a);
@@ -1878,6 +1985,16 @@ int am_launch_mod(const cm_am_plan *p, Geom g, int64_t first_frame, hipStream_t 
         else hipLaunchKernelGGL((niir_mod_kernel<0, false>), dim3((int)blocks), dim3(64), 0, stream, a);
     } else {
         if (noise) return fail(CM_ERR_INVALID, "noise planes are a NIIR encoder input (niir.py:45-46)");
+        {
+            int rc;
+            if (am_scan_wanted(p, p->scan_pm, g.total_calls, CM_AM_SCAN_MOD_MAX_CALLS, rc)) {
+                AmGeom ag;
+                am_geom(p, first_frame, ag);
+                if (p->scan_pm_c1 == 12) return u8 ? launch_scan_proto_mod<12, 4, true>(p, g, ag, stream) : launch_scan_proto_mod<12, 4, false>(p, g, ag, stream);
+                return u8 ? launch_scan_proto_mod<16, 4, true>(p, g, ag, stream) : launch_scan_proto_mod<16, 4, false>(p, g, ag, stream);
+            }
+            if (rc) return rc;
+        }
         ProtoModArgs a;
         a.g = g;
         am_geom(p, first_frame, a.a);
@@ -1959,13 +2076,24 @@ int cm_am_plan_create(const cm_am_desc *desc, cm_am_plan **out) {
         cm_am_plan_destroy(p);
         return fail(CM_ERR_NO_DEVICE, "device allocation / upload of the carrier table failed");
     }
+    make_scan_proto(p);
     *out = p;
     return CM_OK;
 }
 void cm_am_plan_destroy(cm_am_plan *p) {
     if (!p) return;
     if (p->carrier) (void)hipFree(p->carrier);
+    if (p->scan_pd) (void)hipFree(p->scan_pd);
+    if (p->scan_pm) (void)hipFree(p->scan_pm);
     delete p;
+}
+int cm_am_plan_set_small_batch(const cm_am_plan *p, int32_t mode) {
+    if (!p) return fail(CM_ERR_INVALID, "null argument");
+    if (mode < CM_SMALL_BATCH_AUTO || mode > CM_SMALL_BATCH_SCAN) return fail(CM_ERR_INVALID, "unknown small-batch mode");
+    if (mode == CM_SMALL_BATCH_SEGMENTS) return fail(CM_ERR_UNSUPPORTED, "the Proto-SECAM / NIIR kernels have no row segments");
+    if (mode == CM_SMALL_BATCH_SCAN && !p->scan_pd && !p->scan_pm) return fail(CM_ERR_UNSUPPORTED, "the scan kernels do not serve this plan");
+    p->small_batch = mode;
+    return CM_OK;
 }
 int cm_am_demodulate_frames(const cm_am_plan *p, const float *composite, float *rgb, int64_t n_frames, int64_t first_frame, void *stream) {
     if (p && n_frames == 0) return CM_OK;

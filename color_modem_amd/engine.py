@@ -482,6 +482,14 @@ class AmEngine(_EngineBase):
             z[:] = (numpy.random.random_sample((calls, 2, self.width)) - 0.5) * self.noise_level
         return torch.from_numpy(z)
 
+    def set_small_batch(self, mode):
+        """Engine.set_small_batch for a Proto-SECAM plan (cm_am_plan_set_small_batch: 'auto', 'rows', 'scan'; NIIR plans have
+        no scan kernel: NotImplementedError for 'scan')."""
+        code = Engine.SMALL_BATCH[mode]
+        for handle in self._plans.handles():
+            _native.check(_native.lib().cm_am_plan_set_small_batch(handle, code))
+        self._plans.on_create = (lambda h: _native.check(_native.lib().cm_am_plan_set_small_batch(h, code))) if code else None
+
     def describe(self):
         name = 'proto' if self.desc.kind == 1 else 'niir'
         return '%s_demod_kernel / %s_mod_kernel: one wavefront per 64 calls, x3 polyphase resamplers in registers' % (name, name)

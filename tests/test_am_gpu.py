@@ -178,15 +178,64 @@ def test_pil_image_round_trip_proto_and_niir():
         assert diff.max() <= 1 and (diff > 0).mean() < 0.002, stack
 
 
+def _am_modem(stack, size, std):
+    lc = line.LineConfig(size, getattr(line.LineStandard, std))
+    return am_stacks.STACKS[stack](lc)
+
+
+# ---- small batches: one wavefront per scan line (csrc/cm_am_scan_kernels.h, cm_am_plan_set_small_batch) -------------------------
+@pytest.mark.parametrize('stack,size,std,first', [('proto', (720, 576), 'FRENCH_819', 2), ('proto_avg', (720, 64), 'BELGIAN_819', 1),
+                                                 ('proto_625', (768, 40), 'GERBER_625', 3), ('proto_nofilter', (1000, 18), 'FRENCH_819', 0),
+                                                 ('proto', (718, 21), 'FRENCH_819', 5), ('proto_avg', (640, 33), 'FRENCH_819', 4)])
+def test_proto_small_batch_modes(stack, size, std, first):
+    """Proto-SECAM encoder and decoder of a few frames: proto_mod_scan_kernel / proto_demod_scan_kernel (one wavefront per call,
+    the 3x-rate filters as scans over the lanes) against the streaming kernels on whole rows and the float64 oracle, floats and
+    bytes at the boundary; the per-row protocol runs on the same kernels (test_row_sequences_golden)."""
+    from oracle import cm_oracle_am as oa
+    from color_modem_amd.image import _as_bytes
+    import test_am_oracle
+    modem = _am_modem(stack, size, std)
+    inner = modem.backend if stack == 'proto_avg' else modem
+    rgb = testing.synthetic_rgb(2, size[1], size[0], seed=7 + size[1])
+    if stack == 'proto_avg':
+        comp_ref = test_am_oracle._averaging_frames(modem, rgb.astype(numpy.float64), first)
+    else:
+        comp_ref = oa.modulate_frames(modem, rgb.astype(numpy.float64), first)
+    comp32 = comp_ref.astype(numpy.float32)
+    back_ref = oa.demodulate_frames(inner, comp32.astype(numpy.float64), first)
+    im, im_dec = image.ImageModem(modem), image.ImageModem(inner)
+    enc, dec = im._engine(), im_dec._engine()
+    got_m, got_d = {}, {}
+    for mode in ('rows', 'scan', 'auto'):
+        enc.set_small_batch(mode)
+        dec.set_small_batch(mode)
+        got_m[mode] = enc.modulate_frames(rgb, first_frame=first)
+        got_d[mode] = dec.demodulate_frames(comp32, first_frame=first)
+        assert stacks.rel_err(got_m[mode], comp_ref) < TOL, (stack, mode)
+        assert stacks.rel_err(got_m[mode], got_m['rows']) < 2e-6, (stack, mode)
+        for i in range(2):
+            assert stacks.rel_err(got_d[mode][i], back_ref[i]) < TOL, (stack, mode, i)
+            assert stacks.rel_err(got_d[mode][i], got_d['rows'][i]) < 4e-6, (stack, mode, i)      # (float32 resolution: 2.2e-6 at 1000 samples)
+    if size[0] % 16 == 0:
+        rgb8 = _as_bytes(rgb.astype(numpy.float64)).transpose(0, 2, 3, 1).copy()
+        comp8 = _as_bytes(image.ImageModem.encode_composite_level(comp_ref))
+        want_m, want_d = {}, {}
+        for mode in ('rows', 'scan'):
+            enc.set_small_batch(mode)
+            dec.set_small_batch(mode)
+            want_m[mode] = enc.modulate_frames_u8(rgb8, first_frame=first)
+            want_d[mode] = dec.demodulate_frames_u8(comp8, first_frame=first)
+        for a in (want_m, want_d):
+            d8 = numpy.abs(a['scan'].astype(int) - a['rows'].astype(int))
+            assert d8.max() <= 1 and (d8 > 0).mean() < 2e-3, (stack, d8.max(), (d8 > 0).mean())
+    with pytest.raises(NotImplementedError):
+        image.ImageModem(_am_modem('niir', (720, 16), 'GERBER_625'))._engine().set_small_batch('scan')
+
+
 # ---- ImageModem's byte boundary fused into the kernels (cm_am_*_frames_u8) ----------------------------------------------
 U8_CASES = [('proto', (720, 64), 'FRENCH_819', 2, 1), ('proto_avg', (720, 33), 'BELGIAN_819', 2, 0), ('proto_625', (768, 20), 'GERBER_625', 3, 2),
             ('niir', (720, 64), 'GERBER_625', 2, 1), ('niir_hue', (720, 21), 'GERBER_625', 2, 3), ('niir_525', (640, 24), 'NTSC_525', 2, 0),
             ('proto_nofilter', (1024, 18), 'FRENCH_819', 1, 4), ('niir', (1280, 9), 'GERBER_625', 2, 5)]
-
-
-def _am_modem(stack, size, std):
-    lc = line.LineConfig(size, getattr(line.LineStandard, std))
-    return am_stacks.STACKS[stack](lc)
 
 
 @pytest.mark.parametrize('stack,size,std,n_frames,first', U8_CASES)
