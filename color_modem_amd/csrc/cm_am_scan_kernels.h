@@ -135,6 +135,7 @@ __device__ __forceinline__ void scan_put3(lds_float *R0, lds_float *R1, lds_floa
     else scan_put3_r<C1, 2>(R0, R1, R2, v, n0 - q);
     R0[lane - kScanMargin] = 0.f; R1[lane - kScanMargin] = 0.f; R2[lane - kScanMargin] = 0.f;
     R0[len + lane] = 0.f; R1[len + lane] = 0.f; R2[len + lane] = 0.f;
+    scan_fence();
 }
 // this lane's chunk of a 3x-rate sequence out of the phase rows
 template <int C1>
@@ -187,6 +188,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
             }
             *(lds_f4 *)(X + n) = t;
         }
+        scan_fence();
     }
     float u[C3], v[C3];
     if (sparse) scan_up3<C1, true>(X, n0, k.h, u);
@@ -214,6 +216,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
     for (int i = 0; i < C1; ++i) chroma[i] = fmaf_(k.chroma_gain, chroma[i], -1.f);
 #pragma unroll
     for (int q = 0; q < C1 / 4; ++q) *(lds_f4 *)(COWN + n0 + 4 * q) = f4{chroma[4 * q], chroma[4 * q + 1], chroma[4 * q + 2], chroma[4 * q + 3]};
+    scan_fence();
     // ---- luma: band-stop at the 3x rate -> decimator (protosecam.py:110-111) ---------------------------------------------------
     scan_iir<C3>(u, k.rem, lane);
     scan_put3<C1>(R0, R1, R2, u, n0, k.rem.shift, W, lane);
@@ -335,6 +338,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
         X[N1 + lane] = 0.f;
 #pragma unroll
         for (int q = 0; q < C1 / 4; ++q) *(lds_f4 *)(X + n0 + 4 * q) = f4{y[4 * q], y[4 * q + 1], y[4 * q + 2], y[4 * q + 3]};
+        scan_fence();
         float u[C3];
         const bool sparse = k.sparse_taps != 0;
         if (sparse) scan_up3<C1, true>(X, n0, k.h, u);
@@ -363,6 +367,332 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
             const float cosp = fmaf_(cph, cs.x, -(sph * cs.y));                  // cos(phi + n step)
             const float chroma = fmaf_(0.125f * k.pre_gain, tc[e], 0.125f);
             o[e] = fmaf_(cosp, chroma, y[4 * q + e]);                            // protosecam.py:87-90
+        }
+        scan_store4<U8>(op, n0 + 4 * q, o);
+    }
+}
+
+// =============================================================================================================================
+// NIIR / SECAM-IV decoder (ref niir.py:106-164; NiirFront / NiirSyn / NiirBack / niir_finish, cm_am_stages.h) with one wavefront per
+// call, NW - 1 calls behind one halo wave.  3x-rate signals of a call in LDS (three phase rows each):
+//   P  band-pass output M, then phasemod_up = c_pm M / S       S  low-pass of |M|       T  products on their way to the decimators;
+//                                                                                          on the first line of a run first the band-passed
+//                                                                                          synthetic reference (niir.py:107-110)
+// The previous call's phasemod_up is the neighbouring wave's P (one barrier).  The carrier's derivative (niir.py:127-129) reads its
+// two neighbours out of the rows, so the one-triple delay of the streaming form is not needed.
+// =============================================================================================================================
+struct ScanNiirK {
+    int32_t width, c1, sparse_taps, pad0;
+    float h[kAmTaps + 3];
+    ScanFilter bp, lp;             // 3x rate: chunk = 3 c1
+    float c_pm, g_b, sat_gain, alt_scale, third, pad1, pad2, pad3;
+    float m[9];
+};
+typedef const __attribute__((address_space(4))) ScanNiirK const_ScanNiirK;
+template <int C1> constexpr int scan_niir_wave_floats() { return 10 * (64 * C1 + 2 * kScanMargin); }
+
+template <int C1, int NW, bool U8 = false>
+__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2))) void niir_demod_scan_kernel(const Geom g, const AmGeom am, const ScanNiirK *km,
+                                                                                                            double line_phase_shift, double bandpass_phase_shift, int strip_i) {
+    constexpr int C3 = 3 * C1, N1 = 64 * C1, MG = kScanMargin, kRow = N1 + 2 * MG;
+    extern __shared__ __attribute__((aligned(16))) float scan_lds[];
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    const_ScanNiirK &k = *(const_ScanNiirK *)km;
+    const long long c = (long long)blockIdx.x * (NW - 1) - 1 + w;
+    const LaneCall lc = locate_call_at(g, c, w >= 1);
+    const bool alive = c >= 0 && c < g.total_calls;
+    lds_float *wave = (lds_float *)scan_lds + w * scan_niir_wave_floats<C1>();
+    lds_float *X = wave + MG, *P0 = X + kRow, *P1 = P0 + kRow, *P2 = P1 + kRow, *S0 = P2 + kRow, *S1 = S0 + kRow, *S2 = S1 + kRow,
+              *T0 = S2 + kRow, *T1 = T0 + kRow, *T2 = T1 + kRow;
+    const int W = g.W, L = 3 * W;
+    const int n0 = lane * C1, m0 = 3 * n0;
+    const bool sparse = k.sparse_taps != 0;
+    const bool first = __builtin_amdgcn_readfirstlane(lc.kk) == 0;     // the first line of a run: its phase reference is synthetic
+    // ---- the row ------------------------------------------------------------------------------------------------------------
+    float xr[C1];
+    {
+        const float *xp = scan_row<U8>(g.in, lc.frame, g.in_frame_stride, lc.src_row, g.Wp);
+        X[lane - MG] = 0.f;
+        X[N1 + lane] = 0.f;
+#pragma unroll
+        for (int q = 0; q < C1 / 4; ++q) {
+            const int n = n0 + 4 * q;
+            f4 t = {0.f, 0.f, 0.f, 0.f};
+            if (alive && n < g.Wp) t = scan_load4<U8>(xp, n);
+            if (n + 3 >= W) {
+                if (n >= W) t.x = 0.f;
+                if (n + 1 >= W) t.y = 0.f;
+                if (n + 2 >= W) t.z = 0.f;
+                if (n + 3 >= W) t.w = 0.f;
+            }
+            *(lds_f4 *)(X + n) = t;
+            xr[4 * q] = t.x; xr[4 * q + 1] = t.y; xr[4 * q + 2] = t.z; xr[4 * q + 3] = t.w;
+        }
+        scan_fence();
+    }
+    {
+        float v[C3];
+        // ---- M = band-pass of the interpolated row; S = low-pass of |M| (niir.py:111-114) ------------------------------------
+        if (sparse) scan_up3<C1, true>(X, n0, k.h, v);
+        else scan_up3<C1, false>(X, n0, k.h, v);
+        const float u_last = scan_up3_last(X, W, k.h);
+#pragma unroll
+        for (int i = 0; i < C3; ++i) v[i] = m0 + i >= L ? u_last : v[i];
+        scan_iir<C3>(v, k.bp, lane);
+        scan_put3<C1>(P0, P1, P2, v, n0, k.bp.shift, W, lane);
+        float mm[C3];
+        scan_get3<C1>(P0, P1, P2, n0, mm);
+        {
+            const float a_last = __builtin_fabsf(P2[W - 1]);
+#pragma unroll
+            for (int i = 0; i < C3; ++i) v[i] = m0 + i >= L ? a_last : __builtin_fabsf(mm[i]);
+        }
+        scan_iir<C3>(v, k.lp, lane);
+        scan_put3<C1>(S0, S1, S2, v, n0, k.lp.shift, W, lane);
+        // ---- phasemod_up = c_pm M / S inside the row, zero outside (niir_phasemod) ----------------------------------------------
+        scan_get3<C1>(S0, S1, S2, n0, v);
+#pragma unroll
+        for (int i = 0; i < C3; ++i) mm[i] = m0 + i < L ? am_div(k.c_pm * mm[i], v[i]) : 0.f;
+        scan_put3<C1>(P0, P1, P2, mm, n0, 0, W, lane);
+        // ---- the synthetic reference of a run's first line: g_b * band-pass of +-sin(phi + n step) (NiirSyn) ---------------------
+        if (first && w >= 1) {
+            const long long frame = (long long)am.frame_base + lc.frame;
+            const double phi = am.line.start_phase(frame, lc.line - 2);
+            const float sg = am.line.alternate(frame, lc.line - 2) ? -1.f : 1.f;
+            const float syn_s = sg * (float)sin(phi), syn_c = sg * (float)cos(phi);
+#pragma unroll
+            for (int q = 0; q < C1 / 4; ++q) {
+                f4 t;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int n = n0 + 4 * q + e;
+                    const f2 cs = ((const_f2 *)am.carrier)[n < W ? n : W - 1];
+                    t[e] = n < W ? fmaf_(syn_s, cs.x, syn_c * cs.y) : 0.f;
+                }
+                *(lds_f4 *)(X + n0 + 4 * q) = t;
+            }
+            scan_fence();
+            if (sparse) scan_up3<C1, true>(X, n0, k.h, v);
+            else scan_up3<C1, false>(X, n0, k.h, v);
+            const float s_last = scan_up3_last(X, W, k.h);
+#pragma unroll
+            for (int i = 0; i < C3; ++i) v[i] = m0 + i >= L ? s_last : v[i];
+            scan_iir<C3>(v, k.bp, lane);
+#pragma unroll
+            for (int i = 0; i < C3; ++i) v[i] *= k.g_b;
+            scan_put3<C1>(T0, T1, T2, v, n0, k.bp.shift, W, lane);
+        }
+    }
+    __syncthreads();
+    if (w < 1 || !alive || !lc.store_ok) return;
+    // ---- back end (NiirBack::step) ----------------------------------------------------------------------------------------------
+    const long long frame = (long long)am.frame_base + lc.frame;
+    const bool alt = am.line.alternate(frame, lc.line);
+    float sin_shift, cos_shift, sin_ps, cos_ps;
+    {   // niir.py:117-124, 148-157
+        const double shift = alt ? -line_phase_shift : line_phase_shift;
+        const double ps = (alt ? 0.0 : line_phase_shift) + 3.14159265358979323846 - bandpass_phase_shift;
+        sin_shift = (float)sin(shift); cos_shift = (float)cos(shift);
+        sin_ps = (float)sin(ps); cos_ps = (float)cos(ps);
+    }
+    const lds_float *V0 = first ? T0 : P0 - scan_niir_wave_floats<C1>(), *V1 = V0 + kRow, *V2 = V1 + kRow;    // the previous call's phasemod_up
+    const lds_float *CR0 = alt ? P0 : V0, *CR1 = CR0 + kRow, *CR2 = CR1 + kRow;      // carrier_up (niir.py:117-124)
+    const lds_float *HR0 = alt ? V0 : P0, *HR1 = HR0 + kRow, *HR2 = HR1 + kRow;      // the hue-modulated signal
+    float sinc[C1], sat[C1], sinphi[C1], cosphi[C1], cosc[C1];
+    if (sparse) {
+        scan_dn3<C1, true>(CR0, CR1, CR2, n0, k.h, sinc);
+        scan_dn3<C1, true>(S0, S1, S2, n0, k.h, sat);
+    } else {
+        scan_dn3<C1, false>(CR0, CR1, CR2, n0, k.h, sinc);
+        scan_dn3<C1, false>(S0, S1, S2, n0, k.h, sat);
+    }
+    {
+        float cc[C3], hh[C3], t[C3];
+        scan_get3<C1>(CR0, CR1, CR2, n0, cc);
+        scan_get3<C1>(HR0, HR1, HR2, n0, hh);
+        const float c_before = CR2[n0 - 1], c_after = CR0[n0 + C1];
+        auto ac = [&](int i) __attribute__((always_inline)) {               // altcarrier_up[p], p = m0 + i (niir.py:126-129)
+            const int p = m0 + i;
+            const float before = i == 0 ? c_before : cc[i > 0 ? i - 1 : 0], after = i == C3 - 1 ? c_after : cc[i < C3 - 1 ? i + 1 : 0];
+            return (p >= 1 && p <= L - 2) ? k.alt_scale * (after - before) : 0.f;
+        };
+#pragma unroll
+        for (int i = 0; i < C3; ++i) t[i] = hh[i] * cc[i];                  // niir.py:131
+        scan_put3<C1>(T0, T1, T2, t, n0, 0, W, lane);
+        if (sparse) scan_dn3<C1, true>(T0, T1, T2, n0, k.h, sinphi);
+        else scan_dn3<C1, false>(T0, T1, T2, n0, k.h, sinphi);
+#pragma unroll
+        for (int i = 0; i < C3; ++i) t[i] = hh[i] * ac(i);                  // niir.py:132
+        scan_put3<C1>(T0, T1, T2, t, n0, 0, W, lane);
+        if (sparse) scan_dn3<C1, true>(T0, T1, T2, n0, k.h, cosphi);
+        else scan_dn3<C1, false>(T0, T1, T2, n0, k.h, cosphi);
+#pragma unroll
+        for (int i = 0; i < C3; ++i) t[i] = ac(i);
+        scan_put3<C1>(T0, T1, T2, t, n0, 0, W, lane);
+        if (sparse) scan_dn3<C1, true>(T0, T1, T2, n0, k.h, cosc);
+        else scan_dn3<C1, false>(T0, T1, T2, n0, k.h, cosc);
+    }
+    // ---- niir_finish: niir.py:134-163, 63-67, 52-61 -------------------------------------------------------------------------------
+    const bool strip = strip_i != 0;
+    float *op = U8 ? (float *)scan_row<true>(g.out, lc.frame, g.out_frame_stride, lc.out_row, g.out_row_stride)
+                   : g.out + lc.frame * g.out_frame_stride + (long long)lc.out_row * g.out_row_stride + n0;
+#pragma unroll
+    for (int q = 0; q < C1 / 4; ++q) {
+        f4 o[3];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int i = 4 * q + e;
+            const float o_sat = k.sat_gain * sat[i], o_sinc = k.third * sinc[i], o_cosc = k.third * cosc[i];
+            const float inv = am_rsqrt(cosphi[i] * cosphi[i] + sinphi[i] * sinphi[i]);
+            const float c1 = cosphi[i] * inv, s1 = sinphi[i] * inv;
+            const float s2 = -c1 * sin_shift - s1 * cos_shift;
+            const float c2 = s1 * sin_shift - c1 * cos_shift;
+            float db = o_sat * s2, dr = o_sat * c2;
+            const float r = am_sqrt(db * db + dr * dr);
+            float luma = xr[i];
+            if (strip) {
+                const float u = alt ? -r : db, v = alt ? 0.f : dr;
+                const float u2 = u * cos_ps - v * sin_ps, v2 = u * sin_ps + v * cos_ps;
+                luma = xr[i] - (u2 * o_sinc + v2 * o_cosc);
+            }
+            const float keep = r > 0.f ? (r - 0.1f > 0.f ? am_div(r - 0.1f, r) : 0.f) : 0.f;
+            db *= keep;
+            dr *= keep;
+#pragma unroll
+            for (int p = 0; p < 3; ++p) o[p][e] = fmaf_(k.m[3 * p], luma, fmaf_(k.m[3 * p + 1], db, k.m[3 * p + 2] * dr));
+        }
+        if (n0 + 4 * q < g.Wp) {
+            if (U8) scan_store_rgb4_u8(op, n0 + 4 * q, o[0], o[1], o[2]);
+            else {
+#pragma unroll
+                for (int p = 0; p < 3; ++p) *(f4 *)(op + p * g.out_plane_stride + 4 * q) = o[p];
+            }
+        }
+    }
+}
+
+// =============================================================================================================================
+// NIIR encoder (ref niir.py:78-90, 42-49, 69-76; HueCorrectingNiirModem :181-202; niir_mod_kernel): one wavefront per call, NW
+// independent calls per workgroup; the pre-correction low-pass of (db, dr) as one packed scan.
+// =============================================================================================================================
+struct ScanNiirModK {
+    int32_t width, c1, averaging, pad0;
+    ScanFilter pre;                // 1x rate: chunk = c1
+    float pre_gain, pad1, pad2, pad3;
+    float e[9];
+};
+typedef const __attribute__((address_space(4))) ScanNiirModK const_ScanNiirModK;
+
+template <int C1, int NW, bool U8 = false>
+__global__ __launch_bounds__(64 * NW) void niir_mod_scan_kernel(const Geom g, const AmGeom am, const ScanNiirModK *km, const float *noise) {
+    constexpr int N1 = 64 * C1, MG = kScanMargin;
+    extern __shared__ __attribute__((aligned(16))) float scan_lds[];
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    const_ScanNiirModK &k = *(const_ScanNiirModK *)km;
+    const long long c = (long long)blockIdx.x * NW + w;
+    if (c >= g.total_calls) return;                       // (no barrier in this kernel)
+    const LaneCall lc = locate_call_at(g, c, true);
+    const LaneCall lp = locate_call_at(g, c > 0 ? c - 1 : 0, true);
+    lds_float *PB = (lds_float *)scan_lds + w * scan_mod_wave_floats<C1>() + MG, *PR = PB + N1 + 2 * MG;
+    const int W = g.W, n0 = lane * C1;
+    const int depth = k.averaging;
+    const long long frame = (long long)am.frame_base + lc.frame;
+    const int line = depth ? lc.line - 2 : lc.line;       // the line that is modulated (niir.py:202)
+    const bool alt = am.line.alternate(frame, line);
+    float cph, sph;
+    {
+        const double phi = am.line.start_phase(frame, line);
+        cph = (float)cos(phi);
+        sph = (float)sin(phi);
+    }
+    const bool have_prev = lc.kk > 0;
+    const long long row_stride = g.in_row_stride ? g.in_row_stride : g.W;
+    const float *rp = scan_row<U8>(g.in, lc.frame, g.in_frame_stride, lc.src_row, row_stride);
+    const float *rq = have_prev ? scan_row<U8>(g.in, lp.frame, g.in_frame_stride, lp.src_row, row_stride) : rp;      // niir.py:182-186
+    const float *np = noise ? noise + 2LL * lc.call * W : nullptr;
+    // (luma, db, dr) with the pedestal of one sample: niir_mod_kernel's body, the same operation order
+    auto ybr_of = [&](float r, float gg, float b, float rr, float gr, float br, float nb, float nr, float &y, float &db, float &dr) {
+        y = fmaf_(k.e[0], r, fmaf_(k.e[1], gg, k.e[2] * b));
+        db = fmaf_(k.e[3], r, fmaf_(k.e[4], gg, k.e[5] * b));
+        dr = fmaf_(k.e[6], r, fmaf_(k.e[7], gg, k.e[8] * b));
+        if (depth) {
+            const float py = fmaf_(k.e[0], rr, fmaf_(k.e[1], gr, k.e[2] * br));
+            const float pdb = fmaf_(k.e[3], rr, fmaf_(k.e[4], gr, k.e[5] * br));
+            const float pdr = fmaf_(k.e[6], rr, fmaf_(k.e[7], gr, k.e[8] * br));
+            float odb, odr;
+            niir_hue_correct(db, dr, pdb, pdr, odb, odr, nb, nr);
+            y = py;
+            db = odb;
+            dr = odr;
+        } else if (np) {
+            niir_add_offset_noise(db, dr, nb, nr);
+        } else {
+            niir_add_offset(db, dr);
+        }
+    };
+    float y[C1];
+    f2 br2[C1];
+#pragma unroll
+    for (int q = 0; q < C1 / 4; ++q) {
+        const int n = n0 + 4 * q;
+        f4 a[3], b[3], nz[2];
+#pragma unroll
+        for (int p = 0; p < 3; ++p) a[p] = b[p] = f4{0.f, 0.f, 0.f, 0.f};
+        nz[0] = nz[1] = f4{0.f, 0.f, 0.f, 0.f};
+        if (n < g.Wp) {
+            scan_load_rgb4<U8>(rp, g.in_plane_stride, n, a);
+            if (depth) scan_load_rgb4<U8>(rq, g.in_plane_stride, n, b);
+        }
+        if (np) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (n + e < W) { nz[0][e] = np[n + e]; nz[1][e] = np[W + n + e]; }
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float yy, db, dr;
+            ybr_of(a[0][e], a[1][e], a[2][e], b[0][e], b[1][e], b[2][e], nz[0][e], nz[1][e], yy, db, dr);
+            y[4 * q + e] = yy;
+            br2[4 * q + e] = f2{db, dr};
+        }
+    }
+    {   // FilterFunction pads with the last sample (utils.py:31-33): (db, dr)[W - 1], by every lane
+        float ar, ag, ab, pr = 0.f, pg = 0.f, pb = 0.f, yl, dbl, drl;
+        scan_load_rgb1<U8>(rp, g.in_plane_stride, W - 1, ar, ag, ab);
+        if (depth) scan_load_rgb1<U8>(rq, g.in_plane_stride, W - 1, pr, pg, pb);
+        ybr_of(ar, ag, ab, pr, pg, pb, np ? np[W - 1] : 0.f, np ? np[2 * W - 1] : 0.f, yl, dbl, drl);
+        if (n0 + C1 > W) {
+#pragma unroll
+            for (int i = 0; i < C1; ++i) br2[i] = n0 + i >= W ? f2{dbl, drl} : br2[i];
+        }
+    }
+    scan_iir2<C1>(br2, k.pre, lane);
+    {
+        float s[C1];
+#pragma unroll
+        for (int i = 0; i < C1; ++i) s[i] = br2[i].x;
+        scan_put<C1>(PB, s, n0, k.pre.shift);
+#pragma unroll
+        for (int i = 0; i < C1; ++i) s[i] = br2[i].y;
+        scan_put<C1>(PR, s, n0, k.pre.shift);
+    }
+    if (!lc.store_ok) return;
+    float *op = (float *)scan_row<U8>(g.out, lc.frame, g.out_frame_stride, lc.out_row, g.out_row_stride);
+#pragma unroll
+    for (int q = 0; q < C1 / 4; ++q) {
+        if (n0 + 4 * q >= g.Wp) continue;
+        const f4 tb = *(const lds_f4 *)(PB + n0 + 4 * q), tr = *(const lds_f4 *)(PR + n0 + 4 * q);
+        f4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int n = n0 + 4 * q + e;
+            const f2 cs = ((const_f2 *)am.carrier)[n < W ? n : W - 1];
+            const float sn = fmaf_(sph, cs.x, cph * cs.y), cn = fmaf_(cph, cs.x, -(sph * cs.y));
+            const float b = k.pre_gain * tb[e], r = k.pre_gain * tr[e];
+            const float chroma = alt ? -am_sqrt(b * b + r * r) * sn : fmaf_(b, sn, r * cn);      // niir.py:73-76
+            o[e] = y[4 * q + e] + chroma;
         }
         scan_store4<U8>(op, n0 + 4 * q, o);
     }

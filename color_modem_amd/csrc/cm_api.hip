@@ -1758,15 +1758,21 @@ struct cm_am_plan {
     // small batches: one wavefront per call (cm_am_scan_kernels.h); null where the plan's shape does not fit
     ScanProtoK *scan_pd = nullptr;
     ScanProtoModK *scan_pm = nullptr;
-    int scan_pd_c1 = 0, scan_pm_c1 = 0;
+    ScanNiirK *scan_nd = nullptr;
+    ScanNiirModK *scan_nm = nullptr;
+    int scan_pd_c1 = 0, scan_pm_c1 = 0, scan_nd_c1 = 0, scan_nm_c1 = 0;
     mutable int small_batch = CM_SMALL_BATCH_AUTO;     // cm_am_plan_set_small_batch
 };
 #ifndef CM_AM_SCAN_MAX_CALLS
-#define CM_AM_SCAN_MAX_CALLS 6000
+#define CM_AM_SCAN_MAX_CALLS 30000
 #endif
 #ifndef CM_AM_SCAN_MOD_MAX_CALLS
-#define CM_AM_SCAN_MOD_MAX_CALLS 12000
+#define CM_AM_SCAN_MOD_MAX_CALLS 36000
 #endif
+// (NIIR: the decoder's five decimators make a wave's row expensive - hand-over near 33 frames of 720 x 576; the encoder is one packed
+// scan - the scan kernel keeps up with the streaming one beyond 100 frames; profiles/r03_am_small_batch.txt)
+#define CM_NIIR_SCAN_MAX_CALLS 18000
+#define CM_NIIR_SCAN_MOD_MAX_CALLS 60000
 
 namespace {
 int am_geom(const cm_am_plan *p, int64_t first_frame, AmGeom &a) {
@@ -1791,62 +1797,6 @@ void am_frames_geom(Geom &g, int W, int wp, int H, int D, int64_t n_frames) {
     g.total_calls = n_frames * g.calls_per_frame;
 }
 // NIIR: the main pass over every call plus the sparse pass over the calls that open a run (k0 == 0 in rows mode)
-int niir_launch_demod(const cm_am_plan *p, Geom g, int64_t first_frame, hipStream_t stream, bool strip, bool u8 = false) {
-    NiirDemodArgs a;
-    am_geom(p, first_frame, a.a);
-    a.k = p->nd;
-    a.line_phase_shift = p->desc.line_phase_shift;
-    a.bandpass_phase_shift = p->desc.bandpass_phase_shift;
-    a.carrier_phase_step = p->desc.carrier_phase_step;
-    a.strip = strip ? 1 : 0;
-    const bool with_first = g.k0 == 0;
-    g.skip_first = 1;
-    long long blocks = (g.total_calls + 62) / 63;
-    if (blocks > 0x7fffffffLL) return fail(CM_ERR_INVALID, "batch too large for one launch");
-    if (g.rows_mode && g.total_calls == 1 && with_first) blocks = 0;      // a lone first call needs no main pass
-#if CM_NIIR_PAIR
-    {   // the wave pair: main pass and sparse first-line pass in one launch (cm_am_kernels.h: niir_demod_pair_kernel)
-        NiirPairArgs pa;
-        a.g = g;
-        pa.m = a;
-        pa.gf = g;
-        pa.n_first = 0;
-        if (with_first) {
-            pa.gf.sparse = 1;
-            pa.gf.skip_first = 0;
-            pa.gf.total_calls = g.rows_mode ? 1 : (g.total_calls / g.calls_per_frame) * g.runs_per_frame;
-            pa.n_first = (int)((pa.gf.total_calls + 63) / 64);
-        }
-        if (blocks + pa.n_first <= 0) return CM_OK;
-        const int lat = 2 * kAmHalf + 1 + p->nd.gb.q + p->nd.gl.q;
-        if (u8) {
-            const size_t lds = sizeof(float) * (size_t)niir_pair_lds_floats<true>(lat, p->nd.gl.q, pa.n_first > 0);
-            hipLaunchKernelGGL(niir_demod_pair_kernel<true>, dim3((int)blocks + pa.n_first), dim3(128), lds, stream, pa);
-        } else {
-            const size_t lds = sizeof(float) * (size_t)niir_pair_lds_floats<false>(lat, p->nd.gl.q, pa.n_first > 0);
-            hipLaunchKernelGGL(niir_demod_pair_kernel<false>, dim3((int)blocks + pa.n_first), dim3(128), lds, stream, pa);
-        }
-    }
-#else
-    if (u8) return fail(CM_ERR_UNSUPPORTED, "the fused uint8 boundary of the NIIR decoder lives in the wave-pair kernel");
-    if (blocks > 0) {
-        a.g = g;
-        hipLaunchKernelGGL(niir_demod_kernel<false>, dim3((int)blocks), dim3(64), 0, stream, a);
-    }
-    if (with_first) {
-        Geom s = g;
-        s.sparse = 1;
-        s.skip_first = 0;
-        s.total_calls = g.rows_mode ? 1 : (g.total_calls / g.calls_per_frame) * g.runs_per_frame;
-        const long long fb = (s.total_calls + 63) / 64;
-        a.g = s;
-        if (fb > 0) hipLaunchKernelGGL(niir_demod_kernel<true>, dim3((int)fb), dim3(64), 0, stream, a);
-    }
-#endif
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return fail(CM_ERR_LAUNCH, std::string("niir_demod_kernel launch: ") + hipGetErrorString(e));
-    return CM_OK;
-}
 // ---- Proto-SECAM in small batches: the scan kernels' constants and launchers ---------------------------------------------------
 static bool taps3_sparse(const float *h) {
     for (int q = 0; 3 * q < kAmTaps; ++q)
@@ -1932,6 +1882,142 @@ static bool am_scan_wanted(const cm_am_plan *p, const void *scan, long long call
     if (mode == CM_SMALL_BATCH_SCAN) rc = fail(CM_ERR_UNSUPPORTED, "the scan kernel does not serve this plan / this direction");
     return false;
 }
+void make_scan_niir(cm_am_plan *p) {
+    const cm_am_desc &d = p->desc;
+    if (d.kind != CM_AM_NIIR) return;
+    if (p->demod_error.empty()) {
+        const int c1 = am_scan_chunk(d.width, {d.bandpass_up.shift, d.lowpass_up.shift});
+        if (c1) {
+            ScanNiirK k;
+            std::memset(&k, 0, sizeof k);
+            const NiirDemodK<float> &m = p->nd;
+            k.width = d.width; k.c1 = c1;
+            for (int i = 0; i < kAmTaps; ++i) k.h[i] = m.taps.h[i];
+            k.sparse_taps = taps3_sparse(k.h) ? 1 : 0;
+            fill_scan_filter(d.bandpass_up, m.bp.na1, m.bp.na2, m.bp.b1, m.bp.b2, 3 * c1, k.bp);
+            fill_scan_filter(d.lowpass_up, m.lp.na1, m.lp.na2, m.lp.b1, m.lp.b2, 3 * c1, k.lp);
+            k.c_pm = m.c_pm; k.g_b = m.g_b; k.sat_gain = m.sat_gain; k.alt_scale = m.alt_scale; k.third = m.third;
+            for (int i = 0; i < 9; ++i) k.m[i] = m.m[i / 3][i % 3];
+            if (hipMalloc((void **)&p->scan_nd, sizeof k) == hipSuccess && hipMemcpy(p->scan_nd, &k, sizeof k, hipMemcpyHostToDevice) == hipSuccess)
+                p->scan_nd_c1 = c1;
+            else p->scan_nd = nullptr;
+        }
+    }
+    if (p->mod_error.empty() && d.precorrect.shift <= kScanMaxShift) {
+        int c1 = 0;
+        for (int c : {12, 16, 24, 32})
+            if (d.width + d.precorrect.shift <= 64 * c) { c1 = c; break; }
+        if (c1) {
+            ScanNiirModK k;
+            std::memset(&k, 0, sizeof k);
+            const NiirModK<float> &m = p->nm;
+            k.width = d.width; k.c1 = c1; k.averaging = d.averaging ? 1 : 0;
+            fill_scan_filter(d.precorrect, m.pre.na1, m.pre.na2, m.pre.b1, m.pre.b2, c1, k.pre);
+            k.pre_gain = m.pre_gain;
+            for (int i = 0; i < 9; ++i) k.e[i] = m.e[i / 3][i % 3];
+            if (hipMalloc((void **)&p->scan_nm, sizeof k) == hipSuccess && hipMemcpy(p->scan_nm, &k, sizeof k, hipMemcpyHostToDevice) == hipSuccess)
+                p->scan_nm_c1 = c1;
+            else p->scan_nm = nullptr;
+        }
+    }
+}
+extern "C++" {
+template <int C1, int NW, bool U8>
+int launch_scan_niir_demod(const cm_am_plan *p, const Geom &g, const AmGeom &a, bool strip, hipStream_t stream) {
+    const size_t lds = sizeof(float) * (size_t)NW * scan_niir_wave_floats<C1>();
+    if (int rc = allow_dynamic_lds((const void *)niir_demod_scan_kernel<C1, NW, U8>, p->device, lds, "the NIIR decoder's scan kernel")) return rc;
+    const long long blocks = (g.total_calls + (NW - 1) - 1) / (NW - 1);
+    hipLaunchKernelGGL((niir_demod_scan_kernel<C1, NW, U8>), dim3((int)blocks), dim3(64 * NW), lds, stream, g, a, p->scan_nd, p->desc.line_phase_shift,
+                       p->desc.bandpass_phase_shift, strip ? 1 : 0);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(CM_ERR_LAUNCH, std::string("niir_demod_scan_kernel launch: ") + hipGetErrorString(e));
+    return CM_OK;
+}
+template <int C1, int NW, bool U8>
+int launch_scan_niir_mod(const cm_am_plan *p, const Geom &g, const AmGeom &a, const float *noise, hipStream_t stream) {
+    const size_t lds = sizeof(float) * (size_t)NW * scan_mod_wave_floats<C1>();
+    if (int rc = allow_dynamic_lds((const void *)niir_mod_scan_kernel<C1, NW, U8>, p->device, lds, "the NIIR encoder's scan kernel")) return rc;
+    const long long blocks = (g.total_calls + NW - 1) / NW;
+    hipLaunchKernelGGL((niir_mod_scan_kernel<C1, NW, U8>), dim3((int)blocks), dim3(64 * NW), lds, stream, g, a, p->scan_nm, noise);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(CM_ERR_LAUNCH, std::string("niir_mod_scan_kernel launch: ") + hipGetErrorString(e));
+    return CM_OK;
+}
+template <bool U8>
+int scan_niir_mod_as(const cm_am_plan *p, const Geom &g, const AmGeom &a, const float *noise, hipStream_t stream) {
+    switch (p->scan_nm_c1) {
+        case 12: return launch_scan_niir_mod<12, 4, U8>(p, g, a, noise, stream);
+        case 16: return launch_scan_niir_mod<16, 4, U8>(p, g, a, noise, stream);
+        case 24: return launch_scan_niir_mod<24, 4, U8>(p, g, a, noise, stream);
+        default: return launch_scan_niir_mod<32, 4, U8>(p, g, a, noise, stream);
+    }
+}
+}  // extern "C++"
+int niir_launch_demod(const cm_am_plan *p, Geom g, int64_t first_frame, hipStream_t stream, bool strip, bool u8 = false) {
+    NiirDemodArgs a;
+    am_geom(p, first_frame, a.a);
+    a.k = p->nd;
+    a.line_phase_shift = p->desc.line_phase_shift;
+    a.bandpass_phase_shift = p->desc.bandpass_phase_shift;
+    a.carrier_phase_step = p->desc.carrier_phase_step;
+    a.strip = strip ? 1 : 0;
+    const bool with_first = g.k0 == 0;
+    {   // small batches: one wavefront per call, the first lines of the runs in the same pass (cm_am_scan_kernels.h)
+        int rc;
+        if (am_scan_wanted(p, p->scan_nd, g.total_calls, CM_NIIR_SCAN_MAX_CALLS, rc)) {
+            if (g.total_calls <= 0) return CM_OK;
+            if (p->scan_nd_c1 == 12) return u8 ? launch_scan_niir_demod<12, 4, true>(p, g, a.a, strip, stream) : launch_scan_niir_demod<12, 4, false>(p, g, a.a, strip, stream);
+            return u8 ? launch_scan_niir_demod<16, 3, true>(p, g, a.a, strip, stream) : launch_scan_niir_demod<16, 3, false>(p, g, a.a, strip, stream);
+        }
+        if (rc) return rc;
+    }
+    g.skip_first = 1;
+    long long blocks = (g.total_calls + 62) / 63;
+    if (blocks > 0x7fffffffLL) return fail(CM_ERR_INVALID, "batch too large for one launch");
+    if (g.rows_mode && g.total_calls == 1 && with_first) blocks = 0;      // a lone first call needs no main pass
+#if CM_NIIR_PAIR
+    {   // the wave pair: main pass and sparse first-line pass in one launch (cm_am_kernels.h: niir_demod_pair_kernel)
+        NiirPairArgs pa;
+        a.g = g;
+        pa.m = a;
+        pa.gf = g;
+        pa.n_first = 0;
+        if (with_first) {
+            pa.gf.sparse = 1;
+            pa.gf.skip_first = 0;
+            pa.gf.total_calls = g.rows_mode ? 1 : (g.total_calls / g.calls_per_frame) * g.runs_per_frame;
+            pa.n_first = (int)((pa.gf.total_calls + 63) / 64);
+        }
+        if (blocks + pa.n_first <= 0) return CM_OK;
+        const int lat = 2 * kAmHalf + 1 + p->nd.gb.q + p->nd.gl.q;
+        if (u8) {
+            const size_t lds = sizeof(float) * (size_t)niir_pair_lds_floats<true>(lat, p->nd.gl.q, pa.n_first > 0);
+            hipLaunchKernelGGL(niir_demod_pair_kernel<true>, dim3((int)blocks + pa.n_first), dim3(128), lds, stream, pa);
+        } else {
+            const size_t lds = sizeof(float) * (size_t)niir_pair_lds_floats<false>(lat, p->nd.gl.q, pa.n_first > 0);
+            hipLaunchKernelGGL(niir_demod_pair_kernel<false>, dim3((int)blocks + pa.n_first), dim3(128), lds, stream, pa);
+        }
+    }
+#else
+    if (u8) return fail(CM_ERR_UNSUPPORTED, "the fused uint8 boundary of the NIIR decoder lives in the wave-pair kernel");
+    if (blocks > 0) {
+        a.g = g;
+        hipLaunchKernelGGL(niir_demod_kernel<false>, dim3((int)blocks), dim3(64), 0, stream, a);
+    }
+    if (with_first) {
+        Geom s = g;
+        s.sparse = 1;
+        s.skip_first = 0;
+        s.total_calls = g.rows_mode ? 1 : (g.total_calls / g.calls_per_frame) * g.runs_per_frame;
+        const long long fb = (s.total_calls + 63) / 64;
+        a.g = s;
+        if (fb > 0) hipLaunchKernelGGL(niir_demod_kernel<true>, dim3((int)fb), dim3(64), 0, stream, a);
+    }
+#endif
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(CM_ERR_LAUNCH, std::string("niir_demod_kernel launch: ") + hipGetErrorString(e));
+    return CM_OK;
+}
 int am_launch_demod(const cm_am_plan *p, Geom g, int64_t first_frame, hipStream_t stream, bool u8 = false) {
     if (!p->demod_error.empty()) return fail(CM_ERR_UNSUPPORTED, p->demod_error);
     if (p->desc.kind == CM_AM_NIIR) return niir_launch_demod(p, g, first_frame, stream, p->desc.strip_chroma != 0, u8);
@@ -1973,6 +2059,15 @@ int am_launch_mod(const cm_am_plan *p, Geom g, int64_t first_frame, hipStream_t 
     if (blocks <= 0) return CM_OK;
     if (blocks > 0x7fffffffLL) return fail(CM_ERR_INVALID, "batch too large for one launch");
     if (p->desc.kind == CM_AM_NIIR) {
+        {
+            int rc;
+            if (am_scan_wanted(p, p->scan_nm, g.total_calls, CM_NIIR_SCAN_MOD_MAX_CALLS, rc)) {
+                AmGeom ag;
+                am_geom(p, first_frame, ag);
+                return u8 ? scan_niir_mod_as<true>(p, g, ag, noise, stream) : scan_niir_mod_as<false>(p, g, ag, noise, stream);
+            }
+            if (rc) return rc;
+        }
         NiirModArgs a;
         a.g = g;
         am_geom(p, first_frame, a.a);
@@ -2077,6 +2172,7 @@ int cm_am_plan_create(const cm_am_desc *desc, cm_am_plan **out) {
         return fail(CM_ERR_NO_DEVICE, "device allocation / upload of the carrier table failed");
     }
     make_scan_proto(p);
+    make_scan_niir(p);
     *out = p;
     return CM_OK;
 }
@@ -2085,13 +2181,15 @@ void cm_am_plan_destroy(cm_am_plan *p) {
     if (p->carrier) (void)hipFree(p->carrier);
     if (p->scan_pd) (void)hipFree(p->scan_pd);
     if (p->scan_pm) (void)hipFree(p->scan_pm);
+    if (p->scan_nd) (void)hipFree(p->scan_nd);
+    if (p->scan_nm) (void)hipFree(p->scan_nm);
     delete p;
 }
 int cm_am_plan_set_small_batch(const cm_am_plan *p, int32_t mode) {
     if (!p) return fail(CM_ERR_INVALID, "null argument");
     if (mode < CM_SMALL_BATCH_AUTO || mode > CM_SMALL_BATCH_SCAN) return fail(CM_ERR_INVALID, "unknown small-batch mode");
     if (mode == CM_SMALL_BATCH_SEGMENTS) return fail(CM_ERR_UNSUPPORTED, "the Proto-SECAM / NIIR kernels have no row segments");
-    if (mode == CM_SMALL_BATCH_SCAN && !p->scan_pd && !p->scan_pm) return fail(CM_ERR_UNSUPPORTED, "the scan kernels do not serve this plan");
+    if (mode == CM_SMALL_BATCH_SCAN && !p->scan_pd && !p->scan_pm && !p->scan_nd && !p->scan_nm) return fail(CM_ERR_UNSUPPORTED, "the scan kernels do not serve this plan");
     p->small_batch = mode;
     return CM_OK;
 }

@@ -225,11 +225,21 @@ __device__ __forceinline__ void scan_pad(float (&v)[CN], int t0, int len, float 
 }
 typedef float f2u __attribute__((ext_vector_type(2), aligned(4)));
 typedef __attribute__((address_space(3))) f2u lds_f2u;
+// The rows in LDS are exchanged between the lanes of ONE wavefront: it runs in lockstep and its LDS operations execute in order, so no
+// hardware barrier is needed.  The compiler, however, reasons per thread: a load from an address THIS lane has not stored to may be
+// hoisted above the lane's stores or merged with an earlier load of the same address (measured: niir_demod_scan_kernel, which fills
+// its x row a second time - the window loads of the second pass came back with the first pass's values for the neighbouring lanes'
+// samples).  Every writer of a row ends with this fence (no instruction: a compiler-level ordering point).
+__device__ __forceinline__ void scan_fence() {
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+}
 // a 1x-rate chunk: dst[n0 + i - shift] = v[i]
 template <int CN>
 __device__ __forceinline__ void scan_put(lds_float *dst, const float (&v)[CN], int n0, int shift) {
 #pragma unroll
     for (int i = 0; i < CN; i += 2) *(lds_f2u *)(dst + n0 - shift + i) = f2u{v[i], v[i + 1]};
+    scan_fence();
 }
 // a 2x-rate chunk (v[i] = sample 2 n0 + i) into the row's even / odd halves: sample m = 2 n0 + i - shift
 template <int C1>
@@ -243,6 +253,7 @@ __device__ __forceinline__ void scan_put2(lds_float *ev, lds_float *od, const fl
         *(lds_f2u *)(a + j) = f2u{v[2 * j], v[2 * j + 2]};
         *(lds_f2u *)(b + j) = f2u{v[2 * j + 1], v[2 * j + 3]};
     }
+    scan_fence();
 }
 // zero what lies before sample 0 and from sample len on (1x units) of both halves
 __device__ __forceinline__ void scan_trim2(lds_float *ev, lds_float *od, int len, int lane) {
@@ -250,6 +261,7 @@ __device__ __forceinline__ void scan_trim2(lds_float *ev, lds_float *od, int len
     od[lane - kScanMargin] = 0.f;
     ev[len + lane] = 0.f;
     od[len + lane] = 0.f;
+    scan_fence();
 }
 
 // gf where first, else gm, field by field (scalar selects: a reference picked at run time would send both kernel arguments
@@ -405,6 +417,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
             }
             *(lds_f4 *)(X + n) = t;
         }
+        scan_fence();
     }
     CM_SCAN_STAMP();   // row in LDS
     // ---- front end: the pair the product detectors multiply, then the detectors -----------------------------------------
@@ -465,6 +478,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
                 t.w = n0 + 4 * q + 3 < W ? e[4 * q + 3] : 0.f;
                 *(lds_f4 *)(E + n0 + 4 * q) = t;
             }
+            scan_fence();
             scan_up2<C1>(E, n0, tp, m);
             m_last = scan_up2_odd_at(E, W - 1, tp);
         } else {
@@ -1117,6 +1131,7 @@ __global__ __launch_bounds__(64 * NW) void secam_mod_scan_kernel(const Geom g, c
     PW[lane - MG] = 0.0;
 #pragma unroll
     for (int i = 0; i < C1; ++i) PW[n0 - k.pre_lp.shift + i] = dd[i];
+    scan_fence();
     double x[C1];
 #pragma unroll
     for (int i = 0; i < C1; ++i) x[i] = PW[n0 + i];
@@ -1238,6 +1253,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
             *(lds_f4 *)(X + n) = t;
             xr[4 * q] = t.x; xr[4 * q + 1] = t.y; xr[4 * q + 2] = t.z; xr[4 * q + 3] = t.w;
         }
+        scan_fence();
     }
     const float x_last = X[W - 1];
     // ---- luma: band-stop of the row with FilterFunction's tail, output s_y samples earlier (SecamDemod::luma_step) -----------
@@ -1261,6 +1277,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
         BD[lane - MG] = 0.0;
 #pragma unroll
         for (int i = 0; i < C1; ++i) BD[n0 - k.bpf.shift + i] = b[i];
+        scan_fence();
 #pragma unroll
         for (int i = 0; i < C1; ++i) b[i] = BD[n0 + i];
         if (k.has_bell) scan_iir_d<C1>(b, k.bell, lane);   // the bell sees the band-pass output from its sample 0 on
@@ -1271,6 +1288,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
     CH[N1 + lane] = 0.f;
 #pragma unroll
     for (int q = 0; q < C1 / 4; ++q) *(lds_f4 *)(CH + n0 + 4 * q) = f4{ch[4 * q], ch[4 * q + 1], ch[4 * q + 2], ch[4 * q + 3]};
+    scan_fence();
     // ---- up2, products with the FM reference, low-pass of (I, Q) ---------------------------------------------------------------
     f2 iq[C2];
     {

@@ -369,7 +369,7 @@ void cm_set_pointer_check(int32_t on);
 enum { CM_SMALL_BATCH_AUTO = 0, CM_SMALL_BATCH_ROWS = 1, CM_SMALL_BATCH_SEGMENTS = 2, CM_SMALL_BATCH_SCAN = 3 };
 int cm_plan_set_small_batch(const cm_plan *plan, int32_t mode);
 /* The same for a Proto-SECAM plan (csrc/cm_am_scan_kernels.h: protosecam.py:74-112 with one wavefront per scan line, rows up to
- * ~1000 samples, floats or bytes at the boundary); CM_SMALL_BATCH_SEGMENTS does not exist there, NIIR plans have no scan kernel yet. */
+ * ~1000 samples, floats or bytes at the boundary) or a NIIR plan (niir.py:78-164 the same way); CM_SMALL_BATCH_SEGMENTS does not exist there. */
 int cm_am_plan_set_small_batch(const cm_am_plan *plan, int32_t mode);
 /* Name, main-loop instruction mix and launch geometry of the dominant kernel of the last
  * cm_demodulate_frames call on this plan (for bench.py / profiling); returns bytes written. */

@@ -228,8 +228,55 @@ def test_proto_small_batch_modes(stack, size, std, first):
         for a in (want_m, want_d):
             d8 = numpy.abs(a['scan'].astype(int) - a['rows'].astype(int))
             assert d8.max() <= 1 and (d8 > 0).mean() < 2e-3, (stack, d8.max(), (d8 > 0).mean())
-    with pytest.raises(NotImplementedError):
-        image.ImageModem(_am_modem('niir', (720, 16), 'GERBER_625'))._engine().set_small_batch('scan')
+
+
+@pytest.mark.parametrize('stack,size,std,first', [('niir', (720, 64), 'GERBER_625', 2), ('niir_hue', (720, 33), 'GERBER_625', 1),
+                                                 ('niir_525', (640, 24), 'NTSC_525', 4798), ('niir', (768, 40), 'GERBER_625', 3),
+                                                 ('niir', (718, 12), 'GERBER_625', 5), ('niir_hue', (1000, 9), 'GERBER_625', 0)])
+def test_niir_small_batch_modes(stack, size, std, first):
+    """NIIR encoder and decoder of a few frames: niir_mod_scan_kernel / niir_demod_scan_kernel (one wavefront per call; the first
+    line of a run builds its synthetic phase reference in the same pass) against the streaming kernels and the float64 oracle,
+    floats and bytes, stripped and unstripped components."""
+    from oracle import cm_oracle_am as oa
+    from color_modem_amd.image import _as_bytes
+    modem = _am_modem(stack, size, std)
+    rgb = testing.synthetic_rgb(2, size[1], size[0], seed=55 + size[1])
+    comp_ref = oa.modulate_frames(modem, rgb.astype(numpy.float64), first)
+    comp32 = comp_ref.astype(numpy.float32)
+    back_ref = oa.demodulate_frames(modem, comp32.astype(numpy.float64), first)
+    eng = image.ImageModem(modem)._engine()
+    got_m, got_d = {}, {}
+    for mode in ('rows', 'scan', 'auto'):
+        eng.set_small_batch(mode)
+        got_m[mode] = eng.modulate_frames(rgb, first_frame=first)
+        got_d[mode] = eng.demodulate_frames(comp32, first_frame=first)
+        assert stacks.rel_err(got_m[mode], comp_ref) < TOL, (stack, mode)
+        assert stacks.rel_err(got_m[mode], got_m['rows']) < 2e-6, (stack, mode)
+        for i in range(2):      # (isolated samples where the hue is ill-conditioned in the algorithm: test_niir_full_frame_hue_conditioning)
+            err = numpy.abs(got_d[mode][i] - back_ref[i]) / numpy.abs(back_ref[i]).max()
+            assert numpy.quantile(err, 1.0 - 1e-3) < TOL and err.max() < 3e-5, (stack, mode, i, err.max())
+    if size[0] % 16 == 0:
+        rgb8 = _as_bytes(rgb.astype(numpy.float64)).transpose(0, 2, 3, 1).copy()
+        comp8 = _as_bytes(image.ImageModem.encode_composite_level(comp_ref))
+        res = {}
+        for mode in ('rows', 'scan'):
+            eng.set_small_batch(mode)
+            res[mode] = (eng.modulate_frames_u8(rgb8, first_frame=first), eng.demodulate_frames_u8(comp8, first_frame=first))
+        for j in range(2):
+            d8 = numpy.abs(res['scan'][j].astype(int) - res['rows'][j].astype(int))
+            if stack == 'niir_hue' and j == 0:      # (the hue-correcting encoder amplifies float32 rounding where the chroma phasor is short:
+                assert (d8 > 1).mean() < 1e-3       #  test_fused_uint8_modulate_matches_float_path)
+            else:
+                assert d8.max() <= 1, (stack, j, d8.max())
+            assert (d8 > 0).mean() < 3e-3, (stack, j, (d8 > 0).mean())
+    # demodulate_components(strip_chroma=False), row by row with a reset in the run
+    plain = _am_modem(stack, size, std)
+    orc = oa.make(plain)
+    for f, y in ((first, 1), (first, 3), (first, 5), (first, 9), (first + 1, 11)):
+        row = comp32[0, y % size[1]]
+        got = numpy.stack(plain.demodulate_components(f, y, row, strip_chroma=False))
+        want = numpy.stack(orc.demodulate_components(f, y, row.astype(numpy.float64), False))
+        assert stacks.rel_err(got, want) < TOL, (stack, f, y)
 
 
 # ---- ImageModem's byte boundary fused into the kernels (cm_am_*_frames_u8) ----------------------------------------------

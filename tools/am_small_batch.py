@@ -15,9 +15,9 @@ for stack, size, std in (('proto', (720, 736), 'FRENCH_819'), ('niir', (720, 576
     lc = line.LineConfig(size, getattr(line.LineStandard, std))
     eng = image.ImageModem(am_stacks.STACKS[stack](lc))._engine()
     W, H = size
-    for F in (1, 4, 16) if stack == 'proto' else (1,):
+    for F in (1, 4, 16, 32, 48):
         rgb = torch.rand((F, 3, H, W), device='cuda'); comp = eng.modulate_frames(rgb, 0)
-        for mode in ('rows', 'auto') if stack == 'proto' else ('auto',):
+        for mode in ('rows', 'scan', 'auto'):
             eng.set_small_batch(mode)
             print('%-9s %2d frame(s) %dx%d %-5s: modulate %.0f us, demodulate %.0f us' % (stack, F, W, H, mode, timeit(lambda: eng.modulate_frames(rgb, 0)), timeit(lambda: eng.demodulate_frames(comp, 0))), flush=True)
 lc = line.LineConfig((720, 576))
