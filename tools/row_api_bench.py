@@ -33,3 +33,24 @@ for name, size in (('pal_s', (720, 576)), ('secam_avg', (720, 576))):
         for y in range(0, size[1], 2): enc.modulate(1 + rep, y, rgb[0, y], rgb[1, y], rgb[2, y])
         best = min(best, time.time() - t0)
     print('%-14s modulate:   %.1f us per row' % (name, best / (size[1] // 2) * 1e6))
+# the other families: wrapped PAL combs, Proto-SECAM, NIIR, D2-MAC (decoders and encoders, one row per call)
+import am_stacks
+from color_modem_amd import line
+from color_modem_amd.color import mac
+lc625 = line.LineConfig((720, 576))
+others = [('simple3d_pald', stacks.make('simple3d_pald', (720, 576))), ('proto', am_stacks.STACKS['proto'](line.LineConfig((720, 576), line.LineStandard.FRENCH_819))),
+          ('niir', am_stacks.STACKS['niir'](lc625)), ('niir_hue', am_stacks.STACKS['niir_hue'](lc625)), ('mac', mac.MacModem(lc625))]
+for name, m in others:
+    H = 576
+    rgb = testing.synthetic_rgb(1, H, 720)[0]
+    enc_rows = [numpy.asarray(m.modulate(0, y, rgb[0, y], rgb[1, y], rgb[2, y])) for y in range(0, 16, 2)]
+    def per_row(fn):      # median over the rows of a field (a call that grows the plan's per-line tables rebuilds the plan: tens of ms, once)
+        ts = []
+        for y in range(0, H, 2):
+            t0 = time.time(); fn(y); ts.append(time.time() - t0)
+        return float(numpy.median(ts))
+    t_mod = per_row(lambda y: m.modulate(1, y, rgb[0, y], rgb[1, y], rgb[2, y]))
+    row = enc_rows[-1]
+    for y in range(0, 8, 2): m.demodulate(0, y, row)
+    t_dem = per_row(lambda y: m.demodulate(1, y, row))
+    print('%-14s modulate %.1f us per row, demodulate %.1f us per row (medians)' % (name, t_mod * 1e6, t_dem * 1e6), flush=True)
