@@ -96,13 +96,15 @@ class RowSession(object):
         self.eng, self.direction = eng, direction
         dev = torch.device('cuda', torch.cuda.current_device())
         L = _native.lib()
-        prefix = eng.abi_prefix
+        prefix = getattr(eng, 'abi_prefix', None)
+        hook = getattr(eng, 'row_call', None)          # a composition of plans (wrapped.py) brings its own entry point
         if direction == 'demod':
             self.in_shape, self.out_shape, self.depth = (eng.comp_width,), (3, eng.width), eng.demod_depth
-            self.fn = getattr(L, prefix + 'demodulate_run')
+            self.fn = hook(direction) if hook else getattr(L, prefix + 'demodulate_run')
         else:
             self.in_shape, self.out_shape, self.depth = (3, eng.in_width), (eng.comp_width,), eng.mod_depth
-            self.fn = getattr(L, prefix + 'modulate_run')
+            self.fn = hook(direction) if hook else getattr(L, prefix + 'modulate_run')
+        self.plans_of = eng._plans.get if hasattr(eng._plans, 'get') else eng._plans
         # ZERO_COPY: history and result rows live in pinned host memory, which the device reads and writes over the bus -
         # a call is one kernel launch and one synchronisation, no copy is enqueued (a row is 3 - 9 KB: latency, not
         # bandwidth).  Otherwise: device-resident history, one small upload and one download per call.
@@ -147,7 +149,7 @@ class RowSession(object):
             with ctx:
                 stream = torch.cuda.current_stream(self.device)
                 try:
-                    _native.check(self.fn(self.eng._plans.get(self.device), self.hist_ptr + first * self.row_bytes, self.out_ptr, n,
+                    _native.check(self.fn(self.plans_of(self.device), self.hist_ptr + first * self.row_bytes, self.out_ptr, n,
                                           int(frame), int(line) - 2 * (n - 1), int(k) - (n - 1), stream.cuda_stream))
                 finally:
                     stream.synchronize()
@@ -168,7 +170,7 @@ class RowSession(object):
             self.held = (None, -1)                     # until the call has gone through: a failed call re-sends its rows
             first = self.pos - (n - 1)
             try:
-                _native.check(self.fn(self.eng._plans.get(self.device), self.hist[first].data_ptr(), self.out.data_ptr(), n, int(frame),
+                _native.check(self.fn(self.plans_of(self.device), self.hist[first].data_ptr(), self.out.data_ptr(), n, int(frame),
                                       int(line) - 2 * (n - 1), int(k) - (n - 1), stream.cuda_stream))
                 self.pin_out.copy_(self.out[n - 1], non_blocking=True)
             finally:

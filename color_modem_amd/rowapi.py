@@ -66,6 +66,8 @@ class RowApi(object):
     @staticmethod
     def _step(run, eng, direction, frame, line):
         from color_modem_amd import engine
+        if direction == 'mod' and getattr(eng, 'encoder', None) is not None:
+            eng = eng.encoder          # a comb wrapper encodes through its backend (comb.py:90-94): that engine's own session
         if getattr(eng, 'composite', False) or (direction == 'mod' and getattr(eng, 'composite_mod', False)):
             # a composition of kernels (wrapped.py) / an encoder with per-call host input (NIIR noise): the run's last rows go up as they are
             n = len(run.rows)

@@ -32,7 +32,7 @@ class CombWrapDesc(ctypes.Structure):
 
 
 class WrappedCombEngine(object):
-    composite = True        # rowapi: no device-resident session, the run goes through demodulate_run
+    composite = False       # rowapi: the run lives in an engine.RowSession (pinned zero-copy rows) through row_call below
 
     def __init__(self, modem, components=False, strip_chroma=True, min_lines=0):
         from color_modem_amd import comb as comb_module
@@ -85,6 +85,12 @@ class WrappedCombEngine(object):
     def _plans(self, device):
         return (self.inner._plans.get(device), self.first._plans.get(device) if self.first is not None else None,
                 self.mod._plans.get(device))
+
+    def row_call(self, direction):
+        """engine.RowSession's entry point for one run: (plans, in, out, n_calls, frame, first_line, k0, stream) -> status."""
+        assert direction == 'demod'       # the encoder side is the backend's own engine (rowapi._step)
+        fn, desc = _native.lib().cm_comb_wrap_demodulate_run, self.desc
+        return lambda plans, src, dst, n, frame, line, k0, stream: fn(plans[0], plans[1], plans[2], ctypes.byref(desc), src, dst, n, frame, line, k0, stream)
 
     def _call(self, fn, x, out, *args):
         import torch
