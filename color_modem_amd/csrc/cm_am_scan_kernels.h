@@ -389,11 +389,86 @@ struct ScanNiirK {
     float m[9];
 };
 typedef const __attribute__((address_space(4))) ScanNiirK const_ScanNiirK;
-template <int C1> constexpr int scan_niir_wave_floats() { return 10 * (64 * C1 + 2 * kScanMargin); }
+// F64 (cm_am_desc.flags & CM_AM_FLOAT64): the decoder's 3x-rate front end - interpolator, band-pass, low-pass - in float64.  In float32
+// its rounding is divided by the length of a decimated product pair further down (niir.py:131-137): on random pictures 40 % of the
+// frames have isolated samples beyond 1e-5 of full scale; the host simulator of the stage code names the front end as the place where
+// the precision goes (interpolator + both recursive filters in float64: 0 of 3.5e6 samples beyond 2.7e-6; any one of them in float32:
+// violations again; the division and everything behind it may stay in float32 - profiles/r03_niir_precision.txt).
+struct ScanNiirK64 {
+    double h[kAmTaps + 3];
+    ScanFilterD bp, lp;
+};
+typedef const __attribute__((address_space(4))) ScanNiirK64 const_ScanNiirK64;
+typedef const __attribute__((address_space(4))) double const_double;
+typedef __attribute__((address_space(3))) double lds_double;
+template <int C1, bool F64 = false> constexpr int scan_niir_wave_floats() { return (F64 ? 13 : 10) * (64 * C1 + 2 * kScanMargin); }
 
-template <int C1, int NW, bool U8 = false>
+template <int C1, bool SPARSE>
+__device__ __forceinline__ void scan_up3_d(const lds_float *X, int n0, const_double *h, double (&u)[3 * C1]) {
+    double w[C1 + 24];             // w[k] = x[n0 - 12 + k]
+#pragma unroll
+    for (int q = 0; q < (C1 + 24) / 4; ++q) {
+        const f4 t = *(const lds_f4 *)(X + n0 - 12 + 4 * q);
+        w[4 * q] = (double)t.x; w[4 * q + 1] = (double)t.y; w[4 * q + 2] = (double)t.z; w[4 * q + 3] = (double)t.w;
+    }
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        if (SPARSE && j == 0) {
+#pragma unroll
+            for (int i = 0; i < C1; ++i) u[3 * i] = h[30] * w[i + 12];
+            continue;
+        }
+        double acc[C1];
+#pragma unroll
+        for (int i = 0; i < C1; ++i) acc[i] = 0.0;
+#pragma unroll
+        for (int q = 0; 3 * q + j < kAmTaps; ++q) {
+            const double t = h[3 * q + j];
+#pragma unroll
+            for (int i = 0; i < C1; ++i) acc[i] = fmaf_(t, w[i + 22 - q], acc[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < C1; ++i) u[3 * i + j] = acc[i];
+    }
+}
+__device__ __forceinline__ double scan_up3_last_d(const lds_float *X, int W, const_double *h) {
+    double acc = 0.0;
+#pragma unroll
+    for (int q = 0; 3 * q + 2 < kAmTaps; ++q) acc = fmaf_(h[3 * q + 2], (double)X[W - 1 + 10 - q], acc);
+    return acc;
+}
+template <int C1, int R>
+__device__ __forceinline__ void scan_put3_d_r(lds_double *R0, lds_double *R1, lds_double *R2, const double (&v)[3 * C1], int base) {
+#pragma unroll
+    for (int k = 0; k < 3 * C1; ++k) {
+        lds_double *row = (k + R) % 3 == 0 ? R0 : ((k + R) % 3 == 1 ? R1 : R2);
+        row[base + (k + R) / 3] = v[k];
+    }
+}
+template <int C1>
+__device__ __forceinline__ void scan_put3_d(lds_double *R0, lds_double *R1, lds_double *R2, const double (&v)[3 * C1], int n0, int shift, int len, int lane) {
+    const int q = (shift + 2) / 3, r = 3 * q - shift;
+    if (r == 0) scan_put3_d_r<C1, 0>(R0, R1, R2, v, n0 - q);
+    else if (r == 1) scan_put3_d_r<C1, 1>(R0, R1, R2, v, n0 - q);
+    else scan_put3_d_r<C1, 2>(R0, R1, R2, v, n0 - q);
+    R0[lane - kScanMargin] = 0.0; R1[lane - kScanMargin] = 0.0; R2[lane - kScanMargin] = 0.0;
+    R0[len + lane] = 0.0; R1[len + lane] = 0.0; R2[len + lane] = 0.0;
+    scan_fence();
+}
+template <int C1>
+__device__ __forceinline__ void scan_get3_d(const lds_double *R0, const lds_double *R1, const lds_double *R2, int n0, double (&v)[3 * C1]) {
+#pragma unroll
+    for (int i = 0; i < C1; ++i) {
+        v[3 * i] = R0[n0 + i];
+        v[3 * i + 1] = R1[n0 + i];
+        v[3 * i + 2] = R2[n0 + i];
+    }
+}
+
+template <int C1, int NW, bool U8 = false, bool F64 = false>
 __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2))) void niir_demod_scan_kernel(const Geom g, const AmGeom am, const ScanNiirK *km,
-                                                                                                            double line_phase_shift, double bandpass_phase_shift, int strip_i) {
+                                                                                                            const ScanNiirK64 *km64, double line_phase_shift,
+                                                                                                            double bandpass_phase_shift, int strip_i) {
     constexpr int C3 = 3 * C1, N1 = 64 * C1, MG = kScanMargin, kRow = N1 + 2 * MG;
     extern __shared__ __attribute__((aligned(16))) float scan_lds[];
     const int lane = threadIdx.x & 63;
@@ -402,9 +477,13 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
     const long long c = (long long)blockIdx.x * (NW - 1) - 1 + w;
     const LaneCall lc = locate_call_at(g, c, w >= 1);
     const bool alive = c >= 0 && c < g.total_calls;
-    lds_float *wave = (lds_float *)scan_lds + w * scan_niir_wave_floats<C1>();
+    lds_float *wave = (lds_float *)scan_lds + w * scan_niir_wave_floats<C1, F64>();
     lds_float *X = wave + MG, *P0 = X + kRow, *P1 = P0 + kRow, *P2 = P1 + kRow, *S0 = P2 + kRow, *S1 = S0 + kRow, *S2 = S1 + kRow,
               *T0 = S2 + kRow, *T1 = T0 + kRow, *T2 = T1 + kRow;
+    // F64: M and S as three rows of doubles each, in the place of (P, S) and of (T + three more rows); the float rows P, S are written
+    // when every lane has its own chunk of both in registers
+    lds_double *DM0 = (lds_double *)(P0 - MG) + MG, *DM1 = DM0 + kRow, *DM2 = DM1 + kRow;
+    lds_double *DS0 = (lds_double *)(T0 - MG) + MG, *DS1 = DS0 + kRow, *DS2 = DS1 + kRow;
     const int W = g.W, L = 3 * W;
     const int n0 = lane * C1, m0 = 3 * n0;
     const bool sparse = k.sparse_taps != 0;
@@ -433,6 +512,34 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
     }
     {
         float v[C3];
+        if constexpr (F64) {
+            const_ScanNiirK64 &k64 = *(const_ScanNiirK64 *)km64;
+            double d[C3], mm[C3];
+            if (sparse) scan_up3_d<C1, true>(X, n0, k64.h, d);
+            else scan_up3_d<C1, false>(X, n0, k64.h, d);
+            const double u_last = scan_up3_last_d(X, W, k64.h);
+#pragma unroll
+            for (int i = 0; i < C3; ++i) d[i] = m0 + i >= L ? u_last : d[i];
+            scan_iir_d<C3>(d, k64.bp, lane);
+            scan_put3_d<C1>(DM0, DM1, DM2, d, n0, k64.bp.shift, W, lane);
+            scan_get3_d<C1>(DM0, DM1, DM2, n0, mm);
+            {
+                const double a_last = __builtin_fabs(DM2[W - 1]);
+#pragma unroll
+                for (int i = 0; i < C3; ++i) d[i] = m0 + i >= L ? a_last : __builtin_fabs(mm[i]);
+            }
+            scan_iir_d<C3>(d, k64.lp, lane);
+            scan_put3_d<C1>(DS0, DS1, DS2, d, n0, k64.lp.shift, W, lane);
+            scan_get3_d<C1>(DS0, DS1, DS2, n0, d);
+            float sf[C3];
+#pragma unroll
+            for (int i = 0; i < C3; ++i) {
+                sf[i] = m0 + i < L ? (float)d[i] : 0.f;
+                v[i] = m0 + i < L ? am_div(k.c_pm * (float)mm[i], sf[i]) : 0.f;
+            }
+            scan_put3<C1>(P0, P1, P2, v, n0, 0, W, lane);
+            scan_put3<C1>(S0, S1, S2, sf, n0, 0, W, lane);
+        } else {
         // ---- M = band-pass of the interpolated row; S = low-pass of |M| (niir.py:111-114) ------------------------------------
         if (sparse) scan_up3<C1, true>(X, n0, k.h, v);
         else scan_up3<C1, false>(X, n0, k.h, v);
@@ -455,6 +562,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
 #pragma unroll
         for (int i = 0; i < C3; ++i) mm[i] = m0 + i < L ? am_div(k.c_pm * mm[i], v[i]) : 0.f;
         scan_put3<C1>(P0, P1, P2, mm, n0, 0, W, lane);
+        }
         // ---- the synthetic reference of a run's first line: g_b * band-pass of +-sin(phi + n step) (NiirSyn) ---------------------
         if (first && w >= 1) {
             const long long frame = (long long)am.frame_base + lc.frame;
@@ -473,14 +581,27 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
                 *(lds_f4 *)(X + n0 + 4 * q) = t;
             }
             scan_fence();
-            if (sparse) scan_up3<C1, true>(X, n0, k.h, v);
-            else scan_up3<C1, false>(X, n0, k.h, v);
-            const float s_last = scan_up3_last(X, W, k.h);
+            if constexpr (F64) {
+                const_ScanNiirK64 &k64 = *(const_ScanNiirK64 *)km64;
+                double d[C3];
+                if (sparse) scan_up3_d<C1, true>(X, n0, k64.h, d);
+                else scan_up3_d<C1, false>(X, n0, k64.h, d);
+                const double s_last = scan_up3_last_d(X, W, k64.h);
 #pragma unroll
-            for (int i = 0; i < C3; ++i) v[i] = m0 + i >= L ? s_last : v[i];
-            scan_iir<C3>(v, k.bp, lane);
+                for (int i = 0; i < C3; ++i) d[i] = m0 + i >= L ? s_last : d[i];
+                scan_iir_d<C3>(d, k64.bp, lane);
 #pragma unroll
-            for (int i = 0; i < C3; ++i) v[i] *= k.g_b;
+                for (int i = 0; i < C3; ++i) v[i] = (float)(d[i] * (double)k.g_b);
+            } else {
+                if (sparse) scan_up3<C1, true>(X, n0, k.h, v);
+                else scan_up3<C1, false>(X, n0, k.h, v);
+                const float s_last = scan_up3_last(X, W, k.h);
+#pragma unroll
+                for (int i = 0; i < C3; ++i) v[i] = m0 + i >= L ? s_last : v[i];
+                scan_iir<C3>(v, k.bp, lane);
+#pragma unroll
+                for (int i = 0; i < C3; ++i) v[i] *= k.g_b;
+            }
             scan_put3<C1>(T0, T1, T2, v, n0, k.bp.shift, W, lane);
         }
     }
@@ -496,7 +617,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
         sin_shift = (float)sin(shift); cos_shift = (float)cos(shift);
         sin_ps = (float)sin(ps); cos_ps = (float)cos(ps);
     }
-    const lds_float *V0 = first ? T0 : P0 - scan_niir_wave_floats<C1>(), *V1 = V0 + kRow, *V2 = V1 + kRow;    // the previous call's phasemod_up
+    const lds_float *V0 = first ? T0 : P0 - scan_niir_wave_floats<C1, F64>(), *V1 = V0 + kRow, *V2 = V1 + kRow;    // the previous call's phasemod_up
     const lds_float *CR0 = alt ? P0 : V0, *CR1 = CR0 + kRow, *CR2 = CR1 + kRow;      // carrier_up (niir.py:117-124)
     const lds_float *HR0 = alt ? V0 : P0, *HR1 = HR0 + kRow, *HR2 = HR1 + kRow;      // the hue-modulated signal
     float sinc[C1], sat[C1], sinphi[C1], cosphi[C1], cosc[C1];

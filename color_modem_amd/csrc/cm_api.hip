@@ -1759,6 +1759,7 @@ struct cm_am_plan {
     ScanProtoK *scan_pd = nullptr;
     ScanProtoModK *scan_pm = nullptr;
     ScanNiirK *scan_nd = nullptr;
+    ScanNiirK64 *scan_nd64 = nullptr;   // CM_AM_FLOAT64: the float64 front end's constants
     ScanNiirModK *scan_nm = nullptr;
     int scan_pd_c1 = 0, scan_pm_c1 = 0, scan_nd_c1 = 0, scan_nm_c1 = 0;
     mutable int small_batch = CM_SMALL_BATCH_AUTO;     // cm_am_plan_set_small_batch
@@ -1901,6 +1902,19 @@ void make_scan_niir(cm_am_plan *p) {
             if (hipMalloc((void **)&p->scan_nd, sizeof k) == hipSuccess && hipMemcpy(p->scan_nd, &k, sizeof k, hipMemcpyHostToDevice) == hipSuccess)
                 p->scan_nd_c1 = c1;
             else p->scan_nd = nullptr;
+            if (p->scan_nd && (d.flags & CM_AM_FLOAT64)) {
+                NiirDemodK<double> md;
+                std::string err;
+                ScanNiirK64 k64;
+                std::memset(&k64, 0, sizeof k64);
+                if (build_niir_demod_k<double>(d, md, err)) {
+                    for (int i = 0; i < kAmTaps; ++i) k64.h[i] = md.taps.h[i];
+                    fill_scan_filter(d.bandpass_up, md.bp.na1, md.bp.na2, md.bp.b1, md.bp.b2, 3 * c1, k64.bp, 1e-20);
+                    fill_scan_filter(d.lowpass_up, md.lp.na1, md.lp.na2, md.lp.b1, md.lp.b2, 3 * c1, k64.lp, 1e-20);
+                    if (hipMalloc((void **)&p->scan_nd64, sizeof k64) != hipSuccess || hipMemcpy(p->scan_nd64, &k64, sizeof k64, hipMemcpyHostToDevice) != hipSuccess)
+                        p->scan_nd64 = nullptr;
+                }
+            }
         }
     }
     if (p->mod_error.empty() && d.precorrect.shift <= kScanMaxShift) {
@@ -1922,13 +1936,13 @@ void make_scan_niir(cm_am_plan *p) {
     }
 }
 extern "C++" {
-template <int C1, int NW, bool U8>
+template <int C1, int NW, bool U8, bool F64 = false>
 int launch_scan_niir_demod(const cm_am_plan *p, const Geom &g, const AmGeom &a, bool strip, hipStream_t stream) {
-    const size_t lds = sizeof(float) * (size_t)NW * scan_niir_wave_floats<C1>();
-    if (int rc = allow_dynamic_lds((const void *)niir_demod_scan_kernel<C1, NW, U8>, p->device, lds, "the NIIR decoder's scan kernel")) return rc;
+    const size_t lds = sizeof(float) * (size_t)NW * scan_niir_wave_floats<C1, F64>();
+    if (int rc = allow_dynamic_lds((const void *)niir_demod_scan_kernel<C1, NW, U8, F64>, p->device, lds, "the NIIR decoder's scan kernel")) return rc;
     const long long blocks = (g.total_calls + (NW - 1) - 1) / (NW - 1);
-    hipLaunchKernelGGL((niir_demod_scan_kernel<C1, NW, U8>), dim3((int)blocks), dim3(64 * NW), lds, stream, g, a, p->scan_nd, p->desc.line_phase_shift,
-                       p->desc.bandpass_phase_shift, strip ? 1 : 0);
+    hipLaunchKernelGGL((niir_demod_scan_kernel<C1, NW, U8, F64>), dim3((int)blocks), dim3(64 * NW), lds, stream, g, a, p->scan_nd, p->scan_nd64,
+                       p->desc.line_phase_shift, p->desc.bandpass_phase_shift, strip ? 1 : 0);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(CM_ERR_LAUNCH, std::string("niir_demod_scan_kernel launch: ") + hipGetErrorString(e));
     return CM_OK;
@@ -1962,6 +1976,12 @@ int niir_launch_demod(const cm_am_plan *p, Geom g, int64_t first_frame, hipStrea
     a.carrier_phase_step = p->desc.carrier_phase_step;
     a.strip = strip ? 1 : 0;
     const bool with_first = g.k0 == 0;
+    if (p->desc.flags & CM_AM_FLOAT64) {      // the float64 front end lives in the scan kernel: every batch size runs there
+        if (g.total_calls <= 0) return CM_OK;
+        if (g.total_calls > 0x3fffffffLL) return fail(CM_ERR_INVALID, "batch too large for one launch");
+        if (p->scan_nd_c1 == 12) return u8 ? launch_scan_niir_demod<12, 3, true, true>(p, g, a.a, strip, stream) : launch_scan_niir_demod<12, 3, false, true>(p, g, a.a, strip, stream);
+        return u8 ? launch_scan_niir_demod<16, 2, true, true>(p, g, a.a, strip, stream) : launch_scan_niir_demod<16, 2, false, true>(p, g, a.a, strip, stream);
+    }
     {   // small batches: one wavefront per call, the first lines of the runs in the same pass (cm_am_scan_kernels.h)
         int rc;
         if (am_scan_wanted(p, p->scan_nd, g.total_calls, CM_NIIR_SCAN_MAX_CALLS, rc)) {
@@ -2173,6 +2193,8 @@ int cm_am_plan_create(const cm_am_desc *desc, cm_am_plan **out) {
     }
     make_scan_proto(p);
     make_scan_niir(p);
+    if (desc->kind == CM_AM_NIIR && (desc->flags & CM_AM_FLOAT64) && p->demod_error.empty() && !p->scan_nd64)
+        p->demod_error = "CM_AM_FLOAT64: the float64 front end runs on the row-parallel kernel, which does not serve this shape (rows up to ~1000 samples)";
     *out = p;
     return CM_OK;
 }
@@ -2182,6 +2204,7 @@ void cm_am_plan_destroy(cm_am_plan *p) {
     if (p->scan_pd) (void)hipFree(p->scan_pd);
     if (p->scan_pm) (void)hipFree(p->scan_pm);
     if (p->scan_nd) (void)hipFree(p->scan_nd);
+    if (p->scan_nd64) (void)hipFree(p->scan_nd64);
     if (p->scan_nm) (void)hipFree(p->scan_nm);
     delete p;
 }

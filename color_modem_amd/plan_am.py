@@ -9,6 +9,7 @@ import scipy.signal
 
 from color_modem_amd import plan
 
+CM_AM_FLOAT64 = 1        # cm_am_desc.flags (include/color_modem_hip.h)
 CM_AM_PROTO_SECAM, CM_AM_NIIR = 1, 2
 
 
@@ -17,7 +18,7 @@ class AmDesc(ctypes.Structure):
     _fields_ = [('abi_version', ctypes.c_int32), ('kind', ctypes.c_int32), ('width', ctypes.c_int32), ('height', ctypes.c_int32),
                 ('line_shift', ctypes.c_int32), ('even_first', ctypes.c_int32), ('odd_first', ctypes.c_int32),
                 ('averaging', ctypes.c_int32), ('premod_luma_filter', ctypes.c_int32), ('frame_cycle', ctypes.c_int32),
-                ('strip_chroma', ctypes.c_int32), ('reserved', ctypes.c_int32),
+                ('strip_chroma', ctypes.c_int32), ('flags', ctypes.c_int32),
                 ('frame_phase_shift', ctypes.c_double), ('line_phase_shift', ctypes.c_double),
                 ('carrier_phase_step', ctypes.c_double), ('resample_fir3', ctypes.c_double * 61),
                 ('precorrect', plan.IirDesc), ('bandpass_up', plan.IirDesc), ('bandstop_up', plan.IirDesc),
@@ -73,6 +74,8 @@ def build_am_desc(modem, components=False, strip_chroma=True):
         d.bandstop_up = plan.iir_desc(None)
         d.lowpass_up = plan.iir_desc(m._demodulate_upsampled_baseband_filter)
         d.bandpass_phase_shift = float(m._demodulate_upsampled_filter.phase_shift)
+        # modem.float64_front_end = True (on the modem the caller holds or on its backend): the decoder's 3x-rate front end in float64
+        d.flags = CM_AM_FLOAT64 if (getattr(modem, 'float64_front_end', False) or getattr(m, 'float64_front_end', False)) else 0
         dec, enc = niir.DECODE, niir.ENCODE
     else:
         raise ValueError(kind)

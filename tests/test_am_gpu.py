@@ -279,6 +279,44 @@ def test_niir_small_batch_modes(stack, size, std, first):
         assert stacks.rel_err(got, want) < TOL, (stack, f, y)
 
 
+def test_niir_float64_front_end():
+    """`modem.float64_front_end = True` (cm_am_desc.flags | CM_AM_FLOAT64): interpolator, band-pass and low-pass of the NIIR decoder's 3x-rate
+    front end in float64.  On these pictures the float32 decoder leaves isolated samples beyond 1e-5 (the hue of niir.py:131-137 is the
+    angle of a decimated product pair divided by its length; profiles/r03_niir_precision.txt); with the flag EVERY sample holds the
+    tolerance, at one frame and in a batch beyond the float32 kernels' hand-over point, floats and bytes."""
+    from oracle import cm_oracle_am as oa
+    from color_modem_amd.image import _as_bytes
+    size = (960, 40)
+    worst64, bad32, n = 0.0, 0, 0
+    for seed in range(1000, 1006):
+        rgb = testing.synthetic_rgb(1, size[1], size[0], seed=seed).astype(numpy.float64)
+        first = 705 + seed - 1000
+        plain, precise = _am_modem('niir', size, 'GERBER_625'), _am_modem('niir', size, 'GERBER_625')
+        precise.float64_front_end = True
+        comp = oa.modulate_frames(plain, rgb, first).astype(numpy.float32)
+        want = oa.demodulate_frames(plain, comp.astype(numpy.float64), first)
+        got32 = image.ImageModem(plain).demodulate_frames(comp, first_frame=first)
+        got64 = image.ImageModem(precise).demodulate_frames(comp, first_frame=first)
+        scale = numpy.abs(want).max()
+        bad32 += int((numpy.abs(got32 - want) / scale > TOL).sum())
+        worst64 = max(worst64, float((numpy.abs(got64 - want) / scale).max()))
+        n += want.size
+        assert numpy.quantile(numpy.abs(got32 - want) / scale, 1.0 - 1e-3) < TOL
+    assert worst64 < TOL, worst64
+    print('float32 front end: %d of %d samples beyond 1e-5; float64 front end: worst %.2e' % (bad32, n, worst64))
+    # a long batch (the float32 decoder would hand over to the streaming kernel; the float64 front end stays on the scan kernel) and bytes
+    import torch
+    eng = image.ImageModem(precise)._engine()
+    big = torch.from_numpy(comp).cuda().repeat(600, 1, 1).contiguous()
+    out = eng.demodulate_frames(big, first_frame=first)
+    assert stacks.rel_err(out[0].cpu().numpy(), want[0]) < TOL and torch.equal(out[0], out[4 * 149])      # the phase cycle of 4 frames
+    comp8 = _as_bytes(image.ImageModem.encode_composite_level(comp.astype(numpy.float64)))
+    ref_in = image.ImageModem.decode_composite_level(comp8.astype(numpy.float64) / 255.0).astype(numpy.float32)
+    want8 = _as_bytes(oa.demodulate_frames(plain, ref_in.astype(numpy.float64), first)).transpose(0, 2, 3, 1)
+    d8 = numpy.abs(eng.demodulate_frames_u8(comp8, first_frame=first).astype(int) - want8.astype(int))
+    assert d8.max() <= 1 and (d8 > 0).mean() < 2e-3, (d8.max(), (d8 > 0).mean())
+
+
 # ---- ImageModem's byte boundary fused into the kernels (cm_am_*_frames_u8) ----------------------------------------------
 U8_CASES = [('proto', (720, 64), 'FRENCH_819', 2, 1), ('proto_avg', (720, 33), 'BELGIAN_819', 2, 0), ('proto_625', (768, 20), 'GERBER_625', 3, 2),
             ('niir', (720, 64), 'GERBER_625', 2, 1), ('niir_hue', (720, 21), 'GERBER_625', 2, 3), ('niir_525', (640, 24), 'NTSC_525', 2, 0),
