@@ -49,7 +49,12 @@ class NiirModem(utils.ConstantFrequencyCarrier, RowApi):
     @staticmethod
     def encode_components(r, g, b):
         assert len(r) == len(g) == len(b)
-        luma, db, dr = ENCODE @ numpy.stack([numpy.asarray(c, dtype=numpy.float64) for c in (r, g, b)])
+        # Term by term in the reference's own order (niir.py:34-36), not as a matrix product: on grey and nearly grey pixels (db, dr) are
+        # rounding residues of these very sums, and the hue of the 0.1 pedestal (niir.py:42-49) is their angle.
+        r, g, b = [numpy.asarray(c, dtype=numpy.float64) for c in (r, g, b)]
+        luma = ENCODE[0, 0] * r + ENCODE[0, 1] * g + ENCODE[0, 2] * b
+        db = ENCODE[1, 0] * r + ENCODE[1, 1] * g - (-ENCODE[1, 2]) * b
+        dr = ENCODE[2, 0] * r - (-ENCODE[2, 1]) * g - (-ENCODE[2, 2]) * b
         return luma, db, dr
 
     @staticmethod

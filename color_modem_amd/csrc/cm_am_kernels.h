@@ -910,16 +910,15 @@ __global__ __launch_bounds__(64, 2) void niir_mod_kernel(const NiirModArgs args)
             float dr = fmaf_(k.e[2][0], r, fmaf_(k.e[2][1], gg, k.e[2][2] * b));
             if (DEPTH) {
                 float py = lane_from(idx1, y), pdb = lane_from(idx1, db), pdr = lane_from(idx1, dr);
-                if (!have_prev) { py = y; pdb = db; pdr = dr; }         // niir.py:182-186
+                float pr = lane_from(idx1, r), pg = lane_from(idx1, gg), pb = lane_from(idx1, b);
+                if (!have_prev) { py = y; pdb = db; pdr = dr; pr = r; pg = gg; pb = b; }         // niir.py:182-186
                 float odb, odr;
-                niir_hue_correct(db, dr, pdb, pdr, odb, odr, nz[0][s], nz[1][s]);
+                niir_hue_pixel<U8>(k.ed, r, gg, b, pr, pg, pb, db, dr, pdb, pdr, nz[0][s], nz[1][s], odb, odr);
                 y = py;
                 db = odb;
                 dr = odr;
-            } else if (np) {
-                niir_add_offset_noise(db, dr, nz[0][s], nz[1][s]);
             } else {
-                niir_add_offset(db, dr);
+                niir_offset_pixel<U8>(k.ed, r, gg, b, db, dr, nz[0][s], nz[1][s], np != nullptr);
             }
             if (t >= W) db = dr = 0.f;                                    // beyond the row the filter is fed its last sample anyway
             ring[(t & (kAmRing - 1)) * 64 + lane] = y;

@@ -100,6 +100,7 @@ bool build_niir_mod_k(const cm_am_desc &d, NiirModK<T> &k, std::string &err) {
     k.pre_gain = T(g_c);
     for (int i = 0; i < 3; ++i)
         for (int j = 0; j < 3; ++j) k.e[i][j] = T(d.encode_matrix[3 * i + j]);
+    for (int i = 0; i < 6; ++i) k.ed[i] = d.encode_matrix[3 + i];
     return true;
 }
 

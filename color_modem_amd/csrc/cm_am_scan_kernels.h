@@ -701,7 +701,8 @@ struct ScanNiirModK {
     int32_t width, c1, averaging, pad0;
     ScanFilter pre;                // 1x rate: chunk = c1
     float pre_gain, pad1, pad2, pad3;
-    float e[9];
+    float e[9], pad4;
+    double ed[6];                  // the db and dr rows of the matrix in float64 (niir_chroma_f64, cm_am_stages.h)
 };
 typedef const __attribute__((address_space(4))) ScanNiirModK const_ScanNiirModK;
 
@@ -743,14 +744,18 @@ __global__ __launch_bounds__(64 * NW) void niir_mod_scan_kernel(const Geom g, co
             const float pdb = fmaf_(k.e[3], rr, fmaf_(k.e[4], gr, k.e[5] * br));
             const float pdr = fmaf_(k.e[6], rr, fmaf_(k.e[7], gr, k.e[8] * br));
             float odb, odr;
-            niir_hue_correct(db, dr, pdb, pdr, odb, odr, nb, nr);
+            double ed[6];
+#pragma unroll
+            for (int i = 0; i < 6; ++i) ed[i] = k.ed[i];
+            niir_hue_pixel<U8>(ed, r, gg, b, rr, gr, br, db, dr, pdb, pdr, nb, nr, odb, odr);
             y = py;
             db = odb;
             dr = odr;
-        } else if (np) {
-            niir_add_offset_noise(db, dr, nb, nr);
         } else {
-            niir_add_offset(db, dr);
+            double ed[6];
+#pragma unroll
+            for (int i = 0; i < 6; ++i) ed[i] = k.ed[i];
+            niir_offset_pixel<U8>(ed, r, gg, b, db, dr, nb, nr, np != nullptr);
         }
     };
     float y[C1];

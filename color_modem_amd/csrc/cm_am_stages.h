@@ -457,6 +457,7 @@ struct NiirModK {
     SosK<T, 2> pre;
     T pre_gain;
     T e[3][3];                   // (luma, db, dr) = e . (r, g, b)
+    double ed[6];                // the db and dr rows in float64 (niir_chroma_f64)
 };
 
 // niir.py:42-49 (noise off): saturation + 0.1 at the same hue
@@ -503,6 +504,95 @@ CM_HD void niir_hue_correct(T db, T dr, T pdb, T pdr, T &odb, T &odr, T n_b = T(
     } else {
         odb = T(0);
         odr = ep;
+    }
+}
+
+// ---- small saturation: the pedestal's hue in float64 ---------------------------------------------------------------------------
+// The encoder gives every pixel the saturation r + 0.1 AT THE HUE OF (db, dr) (niir.py:42-49, 187-198).  On grey pixels (db, dr) =
+// niir.py:35-36 are rounding residues of ~1e-17 of three products, on nearly grey ones small differences of them - and the pedestal,
+// a tenth of full scale, points where THEY point.  In float32 that angle is noise below a saturation of ~1e-3 (6e-8 of the products
+// against r), and no arithmetic but the reference's own reproduces the residues: (db, dr) are therefore formed again in float64, term
+// by term in the reference's order (c0 r + c1 g - c2 b as written: every product and sum rounded on its own, no contraction), and the
+// pedestal with them, wherever the float32 saturation is below 1e-2 (reference-generated vectors: tests/golden/am_mod_niir*_grey.npz).
+// BYTES: the pixel came in as bytes (ImageModem.modulate, image.py:43-45): the reference forms byte / 255.0 in float64, and so does this
+// (x is the kernel's float32 byte / 255: the byte comes back exactly)
+template <bool BYTES>
+CM_HD void niir_chroma_f64(const double *ed, float rf, float gf, float bf, double &db, double &dr) {
+#if defined(__clang__)
+#pragma clang fp contract(off)
+#endif
+    double r = (double)rf, g = (double)gf, b = (double)bf;
+    if (BYTES) {
+        r = (double)(int)(rf * 255.f + 0.5f) / 255.0;
+        g = (double)(int)(gf * 255.f + 0.5f) / 255.0;
+        b = (double)(int)(bf * 255.f + 0.5f) / 255.0;
+    }
+    const double p0 = ed[0] * r, p1 = ed[1] * g, p2 = ed[2] * b;
+    const double q0 = ed[3] * r, q1 = ed[4] * g, q2 = ed[5] * b;
+    db = (p0 + p1) + p2;
+    dr = (q0 + q1) + q2;
+}
+// niir.py:42-49 in float64 (sin / cos of arctan2(db, dr) = db / r, dr / r; arctan2(0, 0) = 0)
+// (no contraction in these two either: where two nearly grey pixels of opposite hue meet, the mean of niir.py:190-191 cancels down to the
+// rounding residue of its own products and sums - measured on the device: 6e-5 with fused multiply-adds, 7e-8 without)
+CM_HD void niir_add_offset_f64(double db, double dr, double nb, double nr, bool noisy, double &odb, double &odr) {
+#if defined(__clang__)
+#pragma clang fp contract(off)
+#endif
+    const double sat = sqrt(db * db + dr * dr) + 0.1;
+    if (noisy) { db += nb; dr += nr; }
+    const double r = sqrt(db * db + dr * dr);
+    if (r > 0.0) { odb = sat * db / r; odr = sat * dr / r; }
+    else { odb = 0.0; odr = sat; }
+}
+// niir.py:187-198 in float64
+CM_HD void niir_hue_correct_f64(double db, double dr, double pdb, double pdr, double nb, double nr, double &odb, double &odr) {
+#if defined(__clang__)
+#pragma clang fp contract(off)
+#endif
+    const double ls = sqrt(pdb * pdb + pdr * pdr), s = sqrt(db * db + dr * dr);
+    double div = ls + s;
+    if (div == 0.0) div = 1.0;
+    const double adb = (pdb * ls + db * s) / div + nb, adr = (pdr * ls + dr * s) / div + nr;
+    const double ra = sqrt(adb * adb + adr * adr), ep = ls + 0.1;
+    if (ra > 0.0) { odb = ep * adb / ra; odr = ep * adr / ra; }
+    else { odb = 0.0; odr = ep; }
+}
+#ifndef CM_NIIR_SMALL_SAT2
+#define CM_NIIR_SMALL_SAT2 1e-4f
+#endif
+constexpr float kNiirSmallSat2 = CM_NIIR_SMALL_SAT2;      // (saturation 1e-2)^2
+// the plain / noisy encoder's pair of one pixel: (db, dr) in, the pair with its pedestal out; (r, g, b): the pixel itself
+template <bool BYTES = false, typename T>
+CM_HD void niir_offset_pixel(const double *ed, float r, float g, float b, T &db, T &dr, T nb, T nr, bool noisy) {
+    const T qb = noisy ? db + nb : db, qr = noisy ? dr + nr : dr;
+    const bool small = qb * qb + qr * qr < T(kNiirSmallSat2);
+    if (noisy) niir_add_offset_noise(db, dr, nb, nr);
+    else niir_add_offset(db, dr);
+    if (small) {
+        double d0, d1, o0, o1;
+        niir_chroma_f64<BYTES>(ed, r, g, b, d0, d1);
+        niir_add_offset_f64(d0, d1, (double)nb, (double)nr, noisy, o0, o1);
+        db = T(o0);
+        dr = T(o1);
+    }
+}
+// the hue-correcting encoder's: (db, dr) of this call and (pdb, pdr) of the previous one in; (pr, pg, pb): the previous call's pixel
+template <bool BYTES = false, typename T>
+CM_HD void niir_hue_pixel(const double *ed, float r, float g, float b, float pr, float pg, float pb, T db, T dr, T pdb, T pdr, T nb, T nr, T &odb,
+                          T &odr) {
+    niir_hue_correct(db, dr, pdb, pdr, odb, odr, nb, nr);
+    const T ls = am_sqrt(pdb * pdb + pdr * pdr), s = am_sqrt(db * db + dr * dr);
+    T div = ls + s;
+    if (div == T(0)) div = T(1);
+    const T adb = (pdb * ls + db * s) / div + nb, adr = (pdr * ls + dr * s) / div + nr;
+    if (adb * adb + adr * adr < T(kNiirSmallSat2)) {
+        double d0, d1, p0, p1, o0, o1;
+        niir_chroma_f64<BYTES>(ed, r, g, b, d0, d1);
+        niir_chroma_f64<BYTES>(ed, pr, pg, pb, p0, p1);
+        niir_hue_correct_f64(d0, d1, p0, p1, (double)nb, (double)nr, o0, o1);
+        odb = T(o0);
+        odr = T(o1);
     }
 }
 

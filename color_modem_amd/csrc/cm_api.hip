@@ -1929,6 +1929,7 @@ void make_scan_niir(cm_am_plan *p) {
             fill_scan_filter(d.precorrect, m.pre.na1, m.pre.na2, m.pre.b1, m.pre.b2, c1, k.pre);
             k.pre_gain = m.pre_gain;
             for (int i = 0; i < 9; ++i) k.e[i] = m.e[i / 3][i % 3];
+            for (int i = 0; i < 6; ++i) k.ed[i] = m.ed[i];
             if (hipMalloc((void **)&p->scan_nm, sizeof k) == hipSuccess && hipMemcpy(p->scan_nm, &k, sizeof k, hipMemcpyHostToDevice) == hipSuccess)
                 p->scan_nm_c1 = c1;
             else p->scan_nm = nullptr;

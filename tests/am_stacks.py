@@ -20,6 +20,10 @@ STACKS = {
     'niir_noise': lambda lc: niir.NiirModem(lc, noise_level=0.05),
     'niir_hue_noise': lambda lc: niir.HueCorrectingNiirModem(lc, noise_level=0.08),
 }
+STACKS['niir_grey'] = STACKS['niir']             # the same modems on pictures with grey / nearly grey areas (goldens am_mod_*_grey)
+STACKS['niir_hue_grey'] = STACKS['niir_hue']
+STACKS['niir_grey'] = STACKS['niir']             # the same modems on pictures with grey / nearly grey areas (goldens am_mod_*_grey)
+STACKS['niir_hue_grey'] = STACKS['niir_hue']
 DECODER_OF = {'proto_avg': 'proto'}
 
 

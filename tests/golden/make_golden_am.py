@@ -87,7 +87,40 @@ def noise_cases():
              standard=numpy.array('GERBER_625'), seeds=numpy.array([7, 8]))
 
 
+def grey_cases():
+    """NiirModem / HueCorrectingNiirModem on pictures with EXACTLY grey and nearly grey areas (byte / 255 levels, as ImageModem feeds them):
+    there (db, dr) = niir.py:35-36 are rounding residues of ~1e-17 or small numbers, and the hue of the 0.1 pedestal (niir.py:42-49,
+    187-198) is THEIR angle - the device evaluates these sums in float64 in the reference's own operation order where the saturation is
+    small (cm_am_stages.h: niir_chroma_f64)."""
+    W, H, frames = 720, 8, [0, 3]
+    lc = line.LineConfig((W, H), LS.GERBER_625)
+    rng = numpy.random.default_rng(1700)
+    rgb8 = numpy.zeros((len(frames), 3, H, W), dtype=numpy.uint8)
+    x = 0
+    while x < W:                                   # runs of grey, nearly grey (+-1 .. 2 LSB per channel), coloured and black pixels
+        n = int(rng.integers(4, 40))
+        kind = int(rng.integers(4))
+        v = rng.integers(0, 256, size=(len(frames), 1, H, 1))
+        if kind == 0:
+            blk = numpy.broadcast_to(v, (len(frames), 3, H, n)).copy()
+        elif kind == 1:
+            blk = numpy.clip(v + rng.integers(-2, 3, size=(len(frames), 3, H, n)), 0, 255)
+        elif kind == 2:
+            blk = rng.integers(0, 256, size=(len(frames), 3, H, n))
+        else:
+            blk = numpy.zeros((len(frames), 3, H, n), dtype=int)
+        rgb8[:, :, :, x:x + n] = blk[:, :, :, :W - x]
+        x += n
+    rgb = (rgb8.astype(numpy.float64) / 255.0).astype(numpy.float32)
+    for name, make in (('niir_grey', lambda lc: niir.NiirModem(lc)), ('niir_hue_grey', lambda lc: niir.HueCorrectingNiirModem(lc))):
+        comp = numpy.stack([run_mod_frame(make(lc), rgb[i], f) for i, f in enumerate(frames)])
+        save('am_mod_' + name, inp=rgb, out=comp, frames=numpy.array(frames), size=numpy.array([W, H]), standard=numpy.array('GERBER_625'))
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == 'grey':      # only the sets added last (the others stay as they were made)
+        grey_cases()
+        return
     cases = [  # (stack, decoder stack, width, height, frames)
         ('proto', 'proto', 720, 8, [0, 1]),
         ('proto_avg', 'proto', 720, 7, [1, 2]),
@@ -123,6 +156,7 @@ def main():
         out = numpy.stack([numpy.stack(modem.demodulate(f, y, comp[i].astype(numpy.float64))) for i, (f, y) in enumerate(seq)])
         save('am_rows_' + stack, inp=comp, out=out, seq=numpy.array(seq), size=numpy.array(size), standard=numpy.array(std_name))
     noise_cases()
+    grey_cases()
     # NIIR component protocol with the chroma left in the luma (strip_chroma=False) and noise input
     lc = line.LineConfig((720, 6), LS.GERBER_625)
     noise = testing.synthetic_composite(2, 6, 720, seed=1500)

@@ -203,16 +203,18 @@ static int niir_mod_run(const cm_am_desc &d, const double *rgb, double *comp, in
             T y = T(0), db = T(0), dr = T(0);
             if (t < W) {
                 comps(i, t, y, db, dr);
+                const double *px = rgb + ((size_t)i * 3) * W, *pp = rgb + ((size_t)(have_prev ? i - 1 : i) * 3) * W;
                 if (d.averaging) {
                     T py = y, pdb = db, pdr = dr;
                     if (have_prev) comps(i - 1, t, py, pdb, pdr);
                     T odb, odr;
-                    niir_hue_correct(db, dr, pdb, pdr, odb, odr);
+                    niir_hue_pixel(k.ed, (float)px[t], (float)px[W + t], (float)px[2 * W + t], (float)pp[t], (float)pp[W + t], (float)pp[2 * W + t], db, dr,
+                                   pdb, pdr, T(0), T(0), odb, odr);
                     y = py;
                     db = odb;
                     dr = odr;
                 } else {
-                    niir_add_offset(db, dr);
+                    niir_offset_pixel(k.ed, (float)px[t], (float)px[W + t], (float)px[2 * W + t], db, dr, T(0), T(0), false);
                 }
                 lumas[t] = y;
             }

@@ -15,7 +15,7 @@ TOL = 1e-5
 PROTO = ['proto', 'proto_avg', 'proto_nofilter', 'proto_625', 'niir', 'niir_hue', 'niir_525']
 
 
-@pytest.mark.parametrize('stack', PROTO)
+@pytest.mark.parametrize('stack', PROTO + ['niir_grey', 'niir_hue_grey'])
 def test_modulate_frames_golden(stack):
     z = am_stacks.load('am_mod_' + stack)
     im = image.ImageModem(am_stacks.make(stack, z))
@@ -367,6 +367,27 @@ def test_fused_uint8_demodulate_matches_float_path(stack, size, std, n_frames, f
     want = _as_bytes(im.demodulate_frames(ref_in, first_frame=first).astype(numpy.float64)).transpose(0, 2, 3, 1)
     diff = numpy.abs(got.astype(int) - want.astype(int))
     assert diff.max() <= 1 and (diff > 0).mean() < 2e-3, (diff.max(), (diff > 0).mean())
+
+
+@pytest.mark.parametrize('stack', ['niir', 'niir_hue'])
+def test_niir_bytes_on_grey_pictures(stack):
+    """The fused byte boundary of the NIIR encoders on the grey / nearly grey pictures of tests/golden/am_mod_niir*_grey.npz: the reference
+    forms byte / 255.0 in float64 (image.py:43-45) and the pedestal's hue from the rounding residues of niir.py:35-36 - the kernels do the
+    same from the bytes (cm_am_stages.h: niir_chroma_f64<BYTES>).  Against the oracle (bit-exact with the reference on these pictures:
+    tests/test_am_oracle.py) fed byte / 255.0 in float64: <= 1 LSB."""
+    from oracle import cm_oracle_am as oa
+    from color_modem_amd.image import _as_bytes
+    z = am_stacks.load('am_mod_%s_grey' % stack)
+    modem = am_stacks.make(stack, z)
+    rgb8 = numpy.rint(z['inp'] * 255.0).astype(numpy.uint8).transpose(0, 2, 3, 1).copy()
+    first = int(z['frames'][0])
+    want = oa.modulate_frames(modem, rgb8.astype(numpy.float64).transpose(0, 3, 1, 2) / 255.0, first)
+    want8 = _as_bytes(image.ImageModem.encode_composite_level(want))
+    eng = image.ImageModem(modem)._engine()
+    for mode in ('rows', 'scan'):
+        eng.set_small_batch(mode)
+        d8 = numpy.abs(eng.modulate_frames_u8(rgb8, first_frame=first).astype(int) - want8.astype(int))
+        assert d8.max() <= 1 and (d8 > 0).mean() < 2e-3, (stack, mode, d8.max(), (d8 > 0).mean())
 
 
 def test_fused_uint8_am_limits():

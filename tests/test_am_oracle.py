@@ -41,7 +41,7 @@ def _averaging_frames(modem, rgb, first_frame):
     return out
 
 
-@pytest.mark.parametrize('stack', MOD)
+@pytest.mark.parametrize('stack', MOD + ['niir_grey', 'niir_hue_grey'])
 def test_modulate_frames_golden(stack):
     z = am_stacks.load('am_mod_' + stack)
     modem = am_stacks.make(stack, z)

@@ -121,3 +121,28 @@ def test_niir_runs_against_oracle(stack, size, std, use_float):
         got = _run(L.am_sim_demod_run, comp_desc, use_float | 2, want, (len(lines), 3, W), frame, field, 0)
         err = numpy.abs(got - back) / max(1.0, numpy.abs(back).max())
         assert numpy.quantile(err, 0.999) < (1e-5 if use_float else 1e-10) and err.max() < (1e-4 if use_float else 1e-10), (stack, 'components', frame)
+
+
+@pytest.mark.parametrize('stack', ['niir', 'niir_hue'])
+@pytest.mark.parametrize('use_float', [0, 1])
+def test_niir_encoder_on_grey_pictures(stack, use_float):
+    """Grey and nearly grey pixels (tests/golden/am_mod_niir*_grey.npz, made by the reference): the pedestal's hue is the angle of the
+    rounding residues of niir.py:35-36 - the stage code forms them in float64 in the reference's own operation order wherever the
+    saturation is small (cm_am_stages.h: niir_chroma_f64), so the float32 build holds 1e-5 there too."""
+    L = _lib()
+    z = am_stacks.load('am_mod_%s_grey' % stack)
+    modem = am_stacks.make(stack, z)
+    desc = plan_am.build_am_desc(modem)
+    W, H = [int(v) for v in z['size']]
+    delay = 1 if stack == 'niir_hue' else 0
+    for i, frame in enumerate(int(f) for f in z['frames']):
+        rgb = z['inp'][i].astype(numpy.float64)
+        for field in (0, 1):
+            lines = list(range(field, H, 2))
+            # the row schedule of image.py:47-55: `delay` warm-up calls, then rows clamped into the picture
+            calls = [y for y in range(field, 2 * delay, 2)] + [y + 2 * delay for y in lines]
+            src = [min(y, H - 1 - ((H - 1 - y) % 2)) if y < H else y - 2 * ((y - H) // 2 + 1) for y in calls]
+            rows = numpy.stack([rgb[:, y] for y in src])
+            got = _run(L.am_sim_mod_run, desc, use_float, rows, (len(calls), W), frame, calls[0], 0)[len(calls) - len(lines):]
+            want = z['out'][i][lines]
+            assert numpy.abs(got - want).max() < (1e-5 if use_float else 1e-11), (stack, frame, field, numpy.abs(got - want).max())
