@@ -1,6 +1,6 @@
 """Degenerate inputs against the float64 oracle (TEST TOOL, uses oracle/): all-zero / constant / grey pictures through every encoder, all-zero /
 constant composite rows through every decoder - the places where an algorithm divides by an amplitude or takes the angle of a vanishing pair.
-python tools/degenerate_inputs.py"""
+python tests/degenerate_inputs.py"""
 import sys, warnings, numpy
 sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
 warnings.filterwarnings('ignore')
