@@ -910,6 +910,21 @@ def test_hip_graph_capture():
     assert torch.equal(weng.demodulate_frames(comp, 1), wwant)
 
 
+@pytest.mark.gpu
+def test_degenerate_inputs():
+    """Black / white / grey / saturated pictures through every encoder and all-zero / constant composites through every decoder of every family
+    (tests/degenerate_inputs.py): float32 resolution against the oracle - NIIR returns NaN exactly where the reference divides 0 / 0, its encoders
+    hold the grey pictures through their float64 small-saturation path - except the one case that is the angle of rounding residues in the
+    reference itself: SECAM decoding a constant, carrier-free row."""
+    import degenerate_inputs
+    rows = degenerate_inputs.run()
+    assert len(rows) >= 60
+    for name, direction, tag, e, note in rows:
+        if (name, direction, tag) in degenerate_inputs.KNOWN:
+            continue
+        assert e < TOL, (name, direction, tag, e, note)
+
+
 # ---- the time-blocked decoder with the half-band FIRs on the matrix pipe (csrc/cm_blk_kernels.h, opt-in: CM_BLK=1) ----------
 @pytest.mark.gpu
 def test_secam_float32_margin_case_and_the_float64_switch():
