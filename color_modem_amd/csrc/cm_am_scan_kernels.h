@@ -1,4 +1,4 @@
-// cm_am_scan_kernels.h - Proto-SECAM (ref protosecam.py:74-112) in small batches: one WAVEFRONT per scan line, as cm_scan_kernels.h does
+// cm_am_scan_kernels.h - Proto-SECAM (ref protosecam.py:74-112) and NIIR / SECAM-IV (ref niir.py:78-164) in small batches: one WAVEFRONT per scan line, as cm_scan_kernels.h does
 // for the QAM family and SECAM.  The streaming kernels of cm_am_kernels.h walk a row with one lane (~790 dependent steps: 0.3 - 0.4 ms
 // however few rows there are); here lane l owns samples [l C1, (l + 1) C1) of the row - 3 C1 samples of the 3x-rate signals - and
 //   * resample_poly(x, 3, 1) / (., 1, 3) (scipy.signal, 61 taps) are polyphase sums over 1x-rate windows of LDS rows: a 3x-rate
