@@ -9,18 +9,39 @@
 #include <string>
 #include <vector>
 
+// CM_PART: this file compiles as one translation unit (0, the default) or as two that __graft_entry__.build() compiles side by side and
+// links into the one library - 1: everything but the cm_am_* entry points, 2: the cm_am_* entry points (Proto-SECAM / NIIR: a third of
+// the device code).  The helpers at the top are in both parts; the process-wide state (last error, pointer check) lives in part 1.
+#ifndef CM_PART
+#define CM_PART 0
+#endif
+#define CM_MAIN_PART (CM_PART != 2)
+#define CM_AM_PART (CM_PART != 1)
+
 #include "../../include/color_modem_hip.h"
 #include "cm_kernels.h"
 #include "cm_mod_kernels.h"
 #include "cm_secam_kernels.h"
+#if CM_MAIN_PART
 #include "cm_mac_kernels.h"
+#endif
 #include "cm_plan.h"
+#if CM_AM_PART
 #include "cm_am_kernels.h"
+#endif
+#if CM_MAIN_PART
 #include "cm_wrap_kernels.h"
+#endif
 #include "cm_scan_kernels.h"
+#if CM_AM_PART
 #include "cm_am_scan_kernels.h"
+#endif
+#if CM_MAIN_PART
 #include "cm_blk_kernels.h"
+#endif
+#if CM_AM_PART
 #include "cm_am_plan.h"
+#endif
 
 constexpr int kModAnyShift = 12;   // luma delay window of the run-time-shape modulators (pre-correction shift <= 12)
 
@@ -30,9 +51,19 @@ constexpr int kModAnyShift = 12;   // luma delay window of the run-time-shape mo
 
 using namespace cm;
 
-namespace {
-
+namespace cm_host {      // process-wide state shared by the parts
+#if CM_PART == 2
+extern thread_local std::string g_error;
+extern bool g_pointer_check;
+#else
 thread_local std::string g_error;
+bool g_pointer_check = true;
+#endif
+}  // namespace cm_host
+using cm_host::g_error;
+using cm_host::g_pointer_check;
+
+namespace {
 
 int fail(int code, const std::string &msg) {
     g_error = msg;
@@ -56,7 +87,6 @@ int allow_dynamic_lds(const void *kernel, int device, size_t bytes, const char *
 // (a kernel fault takes more than the process down on a shared node).  Pinned / mapped host memory and managed memory are
 // device-accessible and pass.  cm_set_pointer_check(0) drops the two hipPointerGetAttributes calls for callers whose
 // allocator the runtime does not know (a few microseconds per call less, too); -DCM_NO_POINTER_CHECK compiles them out.
-static bool g_pointer_check = true;
 int check_device(int plan_device, const void *a, const void *b) {
     int cur = -1;
     if (hipGetDevice(&cur) != hipSuccess) return fail(CM_ERR_NO_DEVICE, "hipGetDevice failed");
@@ -88,6 +118,7 @@ int check_device(int plan_device, const void *a, const void *b) {
         if (e_ != hipSuccess) return fail(code, std::string(#expr) + ": " + hipGetErrorString(e_)); \
     } while (0)
 
+#if CM_MAIN_PART
 // One launch = first-line workgroups [0, n_first) followed by the main pass's workgroups.
 typedef int (*LaunchFn)(const Geom &gm, const void *km, const Geom &gf, const void *kf, int n_first, int n_main,
                         hipStream_t);
@@ -176,9 +207,11 @@ struct Pass {
     int depth = 0;                 // halo lanes of the kernel instance
     std::string name;
 };
+#endif  // CM_MAIN_PART
 
 }  // namespace
 
+#if CM_MAIN_PART
 typedef int (*ModLaunchFn)(const Geom &g, const void *k, int blocks, hipStream_t);
 
 // calls up to which the decoders' scan kernels beat the streaming kernels (profiles/r03_batch_curve.txt)
@@ -232,7 +265,9 @@ struct cm_plan {
     SecamModLaneK<float, double> *sm_lanes = nullptr;
 };
 
+#endif  // CM_MAIN_PART
 namespace {
+#if CM_MAIN_PART
 
 template <class S>
 bool make_pass(const cm_plan_desc &d, bool pald, bool bsf, const cm_lane_table &tb, Pass &pass, std::string &err, bool pair, int depth = 0) {
@@ -812,6 +847,7 @@ static int segment_geometry(const cm_plan *p, int wp, long long blocks, int &seg
     return S;
 }
 
+#endif  // CM_MAIN_PART
 // ---- small batches: one wavefront per scan line (cm_scan_kernels.h) ------------------------------------------------------
 // The scan's chunk-to-chunk transitions: A^(chunk 2^k) of every section, A = [[-a1, 1], [-a2, 0]] with the float32-rounded
 // coefficients the kernel filters with (float64 products, rounded once).
@@ -843,6 +879,7 @@ static void fill_scan_filter(const cm_iir_desc &d, const T *na1, const T *na2, c
         }
     }
 }
+#if CM_MAIN_PART
 static bool build_scan_k(const cm_plan_desc &d, bool pald, bool bsf, int depth, bool minavg, bool notch, int c1, ScanK &s, std::string &err) {
     DemodK<float, SysAny> k;
     DemodScales sc;
@@ -1082,6 +1119,7 @@ int check_lines(const cm_plan *p, const Pass &pass, int max_line) {
 }
 
 
+#endif  // CM_MAIN_PART
 // Scratch under stream capture: hipMallocAsync / hipFreeAsync on a capturing stream become memory nodes of the graph, and graphs of
 // wrapped-comb calls with such nodes faulted on replay on ROCm 7.2, at 512 and at 256 frames per call, run-to-run differently
 // (profiles/r03_wrapped_small_batch.txt) - the same calls made eagerly are exact at every size.  The entry points that need scratch
@@ -1127,6 +1165,7 @@ int with_pitched_rows(const float *in, long long in_rows, float *out, long long 
 
 }  // namespace
 
+#if CM_MAIN_PART
 extern "C" {
 
 const char *cm_last_error(void) { return g_error.c_str(); }
@@ -1745,6 +1784,8 @@ int cm_mac_demodulate_run(const cm_mac_plan *p, const float *composite, float *r
 }
 }
 
+#endif  // CM_MAIN_PART
+#if CM_AM_PART
 // ---- amplitude-modulated line-sequential standards: Proto-SECAM, NIIR (cm_am_kernels.h) ------------------------------------
 struct cm_am_plan {
     cm_am_desc desc;
@@ -2372,6 +2413,8 @@ int cm_am_modulate_run_noise(const cm_am_plan *p, const float *rgb, const float 
 }
 }  // extern "C"
 
+#endif  // CM_AM_PART
+#if CM_MAIN_PART
 // ---- SimpleCombModem / Simple3DCombModem around PalDModem or Pal3DModem (cm_wrap_kernels.h) ------------------------------
 extern "C++" {
 namespace {
@@ -2683,3 +2726,5 @@ int cm_plan_describe(const cm_plan *p, char *buf, int32_t buf_len) {
 }
 
 }  // extern "C"
+
+#endif  // CM_MAIN_PART
