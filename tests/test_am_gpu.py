@@ -279,6 +279,35 @@ def test_niir_small_batch_modes(stack, size, std, first):
         assert stacks.rel_err(got, want) < TOL, (stack, f, y)
 
 
+@pytest.mark.parametrize('stack,size,std', [('proto', (720, 64), 'FRENCH_819'), ('niir', (720, 64), 'GERBER_625'), ('niir_hue', (960, 32), 'GERBER_625'),
+                                            ('proto_avg', (1000, 24), 'FRENCH_819')])
+def test_am_scan_kernels_ignore_stale_lds(stack, size, std):
+    """The Proto-SECAM / NIIR scan kernels keep every signal of a row in LDS rows whose margins they must have written themselves: launches
+    that leave NaNs all over the LDS of every CU (the streaming kernels on NaN frames) in front of them must not change a bit of their results."""
+    import torch
+    modem = _am_modem(stack, size, std)
+    inner = modem.backend if stack == 'proto_avg' else modem
+    enc, dec = image.ImageModem(modem)._engine(), image.ImageModem(inner)._engine()
+    rgb = torch.from_numpy(testing.synthetic_rgb(1, size[1], size[0], seed=5)).cuda()
+    for e in (enc, dec):
+        e.set_small_batch('scan')
+    comp = enc.modulate_frames(rgb, first_frame=1)
+    back = dec.demodulate_frames(comp, first_frame=1)
+    clean_m, clean_d = comp.cpu().numpy(), back.cpu().numpy()
+    assert numpy.isfinite(clean_m).all() and numpy.isfinite(clean_d).all()
+    poison_rgb = torch.full((48, 3, size[1], size[0]), float('nan'), device='cuda')
+    poison_comp = torch.full((48, size[1], size[0]), float('nan'), device='cuda')
+    for _ in range(2):
+        for e in (enc, dec):
+            e.set_small_batch('rows')
+        enc.modulate_frames(poison_rgb, first_frame=0)
+        dec.demodulate_frames(poison_comp, first_frame=0)
+        for e in (enc, dec):
+            e.set_small_batch('scan')
+        assert numpy.array_equal(enc.modulate_frames(rgb, first_frame=1).cpu().numpy(), clean_m)
+        assert numpy.array_equal(dec.demodulate_frames(comp, first_frame=1).cpu().numpy(), clean_d)
+
+
 def test_niir_float64_front_end():
     """`modem.float64_front_end = True` (cm_am_desc.flags | CM_AM_FLOAT64): interpolator, band-pass and low-pass of the NIIR decoder's 3x-rate
     front end in float64.  On these pictures the float32 decoder leaves isolated samples beyond 1e-5 (the hue of niir.py:131-137 is the
