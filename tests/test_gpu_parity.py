@@ -911,6 +911,34 @@ def test_hip_graph_capture():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('stack,enc,size', [('secam', 'secam', (720, 64)), ('secam_avg', 'secam_avg', (768, 32)), ('simple3d_pald', 'pal_s', (720, 64)),
+                                            ('simple_pal3d_notch', 'pal_avg', (704, 48)), ('ntsc_comb_3d', 'ntsc', (1280, 32))])
+def test_other_scan_kernels_ignore_stale_lds(stack, enc, size):
+    """As test_scan_kernel_ignores_stale_lds, for the SECAM scan kernels, the wrapped combs' back end and the encoders' scan kernels: NaNs
+    left in LDS by the streaming kernels on NaN frames must not change a bit of what the scan kernels return."""
+    import torch
+    dec_e = image.ImageModem(stacks.make(stack, size))._engine()
+    enc_e = image.ImageModem(stacks.make(enc, size))._engine()
+    rgb = torch.from_numpy(testing.synthetic_rgb(1, size[1], size[0], seed=6)).cuda()
+    for e in (enc_e, dec_e):
+        e.set_small_batch('scan')
+    comp = enc_e.modulate_frames(rgb, first_frame=1)
+    clean_m, clean_d = comp.cpu().numpy(), dec_e.demodulate_frames(comp, first_frame=1).cpu().numpy()
+    assert numpy.isfinite(clean_m).all() and numpy.isfinite(clean_d).all()
+    poison_rgb = torch.full((48, 3, size[1], size[0]), float('nan'), device='cuda')
+    poison_comp = torch.full((48, size[1], size[0]), float('nan'), device='cuda')
+    for _ in range(2):
+        for e in (enc_e, dec_e):
+            e.set_small_batch('rows')
+        enc_e.modulate_frames(poison_rgb, first_frame=0)
+        dec_e.demodulate_frames(poison_comp, first_frame=0)
+        for e in (enc_e, dec_e):
+            e.set_small_batch('scan')
+        assert numpy.array_equal(enc_e.modulate_frames(rgb, first_frame=1).cpu().numpy(), clean_m)
+        assert numpy.array_equal(dec_e.demodulate_frames(comp, first_frame=1).cpu().numpy(), clean_d)
+
+
+@pytest.mark.gpu
 def test_degenerate_inputs():
     """Black / white / grey / saturated pictures through every encoder and all-zero / constant composites through every decoder of every family
     (tests/degenerate_inputs.py): float32 resolution against the oracle - NIIR returns NaN exactly where the reference divides 0 / 0, its encoders
