@@ -273,7 +273,8 @@ enum cm_am_kind { CM_AM_PROTO_SECAM = 1, CM_AM_NIIR = 2 };
  * front end leaves isolated samples beyond 1e-5 of full scale where the decoder divides by a short phasor (niir.py:131-137): 4e-5 of the
  * samples of random pictures, worst 4e-3; with this flag 1 sample of 1.5e7 (2.3e-5) in the same campaign (profiles/r03_niir_precision.txt).
  * The decoder then runs on the row-parallel kernel of csrc/cm_am_scan_kernels.h at every batch size (rows up to ~1000 samples; 9.5 Gpixel/s
- * on long batches against 72 for the float32 wave pair). */
+ * on long batches against 72 for the float32 wave pair; cm_am_plan_set_small_batch has no effect on such a decoder).  The NIIR ENCODERS need no
+ * flag: where a pixel's saturation is below 1e-2 they form (db, dr) and the pedestal in float64 in the reference's own operation order. */
 #define CM_AM_FLOAT64 1
 typedef struct cm_am_desc {
     int32_t abi_version;          /* CM_ABI_VERSION */
