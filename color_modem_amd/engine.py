@@ -12,11 +12,18 @@ import numpy
 from color_modem_amd import _native, plan
 
 
+_TORCH = None
+
+
 def _torch():
-    import torch
-    if not torch.cuda.is_available():
-        raise _native.NativeError('no HIP device visible to torch: color_modem_amd runs on the GPU only')
-    return torch
+    """torch, once a HIP device has been seen (the check is a driver call: made once, not on every row of the per-row protocol)"""
+    global _TORCH
+    if _TORCH is None:
+        import torch
+        if not torch.cuda.is_available():
+            raise _native.NativeError('no HIP device visible to torch: color_modem_amd runs on the GPU only')
+        _TORCH = torch
+    return _TORCH
 
 
 def _check_out(out, shape, dtype, device):
