@@ -16,12 +16,6 @@
 
 namespace cm {
 
-#ifndef CM_PROTO_PAIR         /* 1: the Proto-SECAM decoder on the wave pair (proto_demod_pair_kernel); 0: the one-wave kernel of round 2 */
-#define CM_PROTO_PAIR 1
-#endif
-#ifndef CM_NIIR_PAIR          /* 1: the NIIR decoder on the wave pair (niir_demod_pair_kernel); 0: the one-wave kernels of round 2 */
-#define CM_NIIR_PAIR 1
-#endif
 constexpr int kAmRing = 32;                    // slots of the delay rings: delays up to 31 samples (checked by the host)
 constexpr int kAmRingFloats = kAmRing * 64;
 
@@ -42,64 +36,6 @@ struct ProtoDemodArgs {
     AmGeom a;
     ProtoDemodK<float> k;
 };
-
-__global__ __launch_bounds__(64, 2) void proto_demod_kernel(const ProtoDemodArgs args) {
-    constexpr int kTile = 16, DEPTH = 1;
-    __shared__ __attribute__((aligned(16))) float lds_store[3 * 64 * kTile + kAmRingFloats];
-    lds_float *otile_base = (lds_float *)lds_store;
-    lds_float *ring = otile_base + 3 * 64 * kTile;
-    const Geom &g = args.g;
-    ProtoDemodK<float> k = args.k;
-    pin_taps3(k.taps);
-    const int lane = threadIdx.x;
-    const LaneCall lc = locate_call(g, blockIdx.x, DEPTH, lane);
-    const float *xp = g.in + lc.frame * g.in_frame_stride + (long long)lc.src_row * g.Wp;
-    const float *op = lc.store_ok ? g.out + lc.frame * g.out_frame_stride + (long long)lc.out_row * g.out_row_stride : nullptr;
-    const long long frame = (long long)args.a.frame_base + lc.frame;
-    const bool alt = args.a.line.alternate(frame, lc.line);
-    const float w_prev = lc.kk > 0 ? 1.f : 0.f;          // protosecam.py:93-94: the first line of a run has no previous chroma
-    const int idx1 = ((lane + 63) & 63) * 4;
-    ProtoDemod<float> st;
-    st.reset();
-    lds_float *otile = otile_base + lane * kTile;
-    const int wpos = ((lane >> CM_TILE_SWZ) & (kTile / 4 - 1)) << 2;
-    const int W = g.W;
-    const int lat_c = ProtoDemod<float>::lat_chroma(k), lat_y = ProtoDemod<float>::lat_luma(k);
-    const int dly = lat_c - lat_y;                       // luma waits for the chroma path (0 .. kAmRing - 1)
-    const int T = (g.Wp + lat_c + 3) & ~3;
-    for (int j = 0; j < kAmRing; ++j) ring[j * 64 + lane] = 0.f;
-    f4 xv = load_luma<false>(xp, 0, true, W);
-    // interior bodies: every stage index of the four steps inside its sequence (t >= lat_c puts every filter behind its
-    // delay, t + 3 < W - 4 keeps the end-of-row latches away) - no guard, no clamp, no zero test
-    int t_mid0 = (lat_c + 3) & ~3, t_mid1 = (W - 8) & ~3;
-    if (t_mid1 <= t_mid0) t_mid0 = t_mid1 = 0;
-    auto body = [&](auto edge_tag, int tb) __attribute__((always_inline)) {
-        constexpr bool EDGE = decltype(edge_tag)::value;
-        const f4 xn = load_luma<false>(xp, tb + 4, EDGE, W);      // next body's samples: a body hides the latency
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            const int t = tb + s;
-            float luma, chroma;
-            st.template step<EDGE>(k, t, xv[s], luma, chroma);
-            ring[(t & (kAmRing - 1)) * 64 + lane] = luma;
-            const float luma_d = ring[((t - dly) & (kAmRing - 1)) * 64 + lane];
-            const float prev = lane_from(idx1, chroma) * w_prev;
-            const float dr = alt ? prev : chroma, db = alt ? chroma : prev;             // protosecam.py:105-108
-            Rgb<float> o;
-            o.r = fmaf_(k.m[0][0], luma_d, fmaf_(k.m[0][1], dr, k.m[0][2] * db));
-            o.g = fmaf_(k.m[1][0], luma_d, fmaf_(k.m[1][1], dr, k.m[1][2] * db));
-            o.b = fmaf_(k.m[2][0], luma_d, fmaf_(k.m[2][1], dr, k.m[2][2] * db));
-            const int n = t - lat_c;
-            if (!EDGE || (n >= 0 && n < W)) put_rgb<false, kTile>(otile, wpos, n, o);
-            if (n >= 0 && ((n & (kTile - 1)) == kTile - 1 || n == g.Wp - 1)) flush_tile<kTile>(g, otile_base, op, n & ~(kTile - 1), lane);
-        }
-        xv = xn;
-    };
-    int tb = 0;
-    for (; tb < t_mid0; tb += 4) body(std::true_type(), tb);
-    for (; tb < t_mid1; tb += 4) body(std::false_type(), tb);
-    for (; tb < T; tb += 4) body(std::true_type(), tb);
-}
 
 // ---------------------------------------------------------------------------------------------------------------------
 // Wave-pair form of the Proto-SECAM decoder (round 3; as niir_demod_pair_kernel below):
@@ -150,9 +86,10 @@ __device__ __forceinline__ const float *am_out_row(const Geom &g, const LaneCall
 }
 constexpr int kProtoIT = 8;
 inline __host__ __device__ int proto_ring_slots(int dly) { return dly < 8 ? 8 : (dly < 16 ? 16 : 32); }
-// floats of dynamic LDS: input tile (two buffers) | hand-over (2 buffers x 6 quantities) | luma delay ring | output tile
+// floats of dynamic LDS: input tile (two buffers) | hand-over (2 buffers x 6 quantities) | luma delay ring | the row's last 16 samples (the
+// interpolator's phase 0 is x[t - 10]) | output tile
 template <bool U8> inline int proto_pair_lds_floats(int dly) {
-    return 2 * AmInTile<U8>::kBufFloats + 2 * 6 * 128 + proto_ring_slots(dly) * 64 + (U8 ? 64 * 3 * 16 / 4 : 3 * 64 * 16);
+    return 2 * AmInTile<U8>::kBufFloats + 2 * 6 * 128 + proto_ring_slots(dly) * 64 + 8 * 128 + (U8 ? 64 * 3 * 16 / 4 : 3 * 64 * 16);
 }
 
 template <bool U8>
@@ -175,8 +112,9 @@ __global__ __launch_bounds__(128, 2) void proto_demod_pair_kernel(const ProtoDem
     lds_float *itile = lds;                              // two buffers: tile c lives in buffer c & 1
     lds_float *hand = itile + 2 * AmInTile<U8>::kBufFloats;
     lds_float *ring = hand + 2 * Q * 128;
-    lds_float *otile_base = ring + nring * 64;
-    // interior bodies (as in proto_demod_kernel): t >= lat_c, t + 1 < W - 6
+    lds_float *xdel = ring + nring * 64;                 // 8 blocks of 2 samples per lane: stage A's own delay of the row
+    lds_float *otile_base = xdel + 8 * 128;
+    // interior bodies: t >= lat_c (every filter behind its delay), t + 1 < W - 6 (the end-of-row latches stay away)
     int t_mid0 = (lat_c + 1) & ~1, t_mid1 = (W - 8) & ~1;
     if (t_mid1 <= t_mid0) t_mid0 = t_mid1 = 0;
 
@@ -188,6 +126,7 @@ __global__ __launch_bounds__(128, 2) void proto_demod_pair_kernel(const ProtoDem
         Up3<float> up;
         FF3<float, 3> ext, rem;
         up.reset(); ext.reset(); rem.reset();
+        for (int j = 0; j < 8; ++j) *(lds_f2 *)(xdel + j * 128 + lane * 2) = f2{0.f, 0.f};
         am_fill<U8>(g, itile, xp, 0, lane);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_wave_barrier();
@@ -197,11 +136,13 @@ __global__ __launch_bounds__(128, 2) void proto_demod_pair_kernel(const ProtoDem
         auto body = [&](auto edge_tag, int tb) __attribute__((always_inline)) {
             constexpr bool EDGE = decltype(edge_tag)::value;
             float hq[Q][2];
+            const f2 xd = *(const lds_f2 *)(xdel + (((tb >> 1) + 3) & 7) * 128 + lane * 2);       // x[tb - 10], x[tb - 9]: written five bodies ago
+            *(lds_f2 *)(xdel + ((tb >> 1) & 7) * 128 + lane * 2) = xv;
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
                 const int n1 = tb + s - kAmHalf;
                 float u[3], c1[3], y1[3];
-                up.push(ka.taps, xv[s], u);
+                up.push(ka.taps, xv[s], xd[s], u);
                 ext.template step<AM_FORM_BP, EDGE>(ka.ext, ka.ge, L, n1, u, c1);
                 rem.template step<AM_FORM_SYM, EDGE>(ka.rem, ka.gr, L, n1, u, y1);
 #pragma unroll
@@ -289,92 +230,6 @@ struct ProtoModArgs {
     int averaging;
 };
 
-// DEPTH = 1: the encoder sits inside ColorAveragingModem (comb.py:141-152): a call modulates line - 2 with the previous
-// call's luma and the mean of both calls' colour-difference signals (previous call = neighbouring lane)
-template <int DEPTH>
-__global__ __launch_bounds__(64, 2) void proto_mod_kernel(const ProtoModArgs args) {
-    constexpr int kTile = 16;
-    __shared__ __attribute__((aligned(16))) float lds_store[64 * kTile + kAmRingFloats];
-    lds_float *otile_base = (lds_float *)lds_store;
-    lds_float *ring = otile_base + 64 * kTile;
-    const Geom &g = args.g;
-    ProtoModK<float> k = args.k;
-    pin_taps3(k.taps);
-    const int lane = threadIdx.x;
-    const LaneCall lc = locate_call(g, blockIdx.x, DEPTH, lane);
-    const float *rp, *op;
-    mod_rows<false>(g, lc, rp, op);
-    const long long frame = (long long)args.a.frame_base + lc.frame;
-    const int line = DEPTH ? lc.line - 2 : lc.line;       // the line that is modulated
-    const bool alt = args.a.line.alternate(frame, line);
-    float cph, sph;
-    {
-        const double phi = args.a.line.start_phase(frame, line);
-        cph = (float)cos(phi);
-        sph = (float)sin(phi);
-    }
-    const bool have_prev = lc.kk > 0;
-    const int idx1 = ((lane + 63) & 63) * 4;
-    ProtoMod<float> st;
-    st.reset();
-    const int wpos = ((lane >> CM_TILE_SWZ) & (kTile / 4 - 1)) << 2;
-    const int W = g.W;
-    const int lat_y = ProtoMod<float>::lat_luma(k), lat_c = ProtoMod<float>::lat_chroma(k);
-    const int lat = lat_y > lat_c ? lat_y : lat_c;
-    const int d_c = lat - lat_c, d_y = lat - lat_y;      // one of them is 0: the shorter path's input waits in the ring
-    const int dly = d_c > d_y ? d_c : d_y;
-    const int T = (g.Wp + lat + 3) & ~3;
-    for (int j = 0; j < kAmRing; ++j) ring[j * 64 + lane] = 0.f;
-    f4 cur[3], nxt[3];
-#pragma unroll
-    for (int p = 0; p < 3; ++p) nxt[p] = load_luma<false>(rp + p * g.in_plane_stride, 0, true, W);
-    // interior bodies: t >= lat + 4 (both paths behind their delays), t + 3 < W - 4
-    int t_mid0 = (lat + 4 + 3) & ~3, t_mid1 = (W - 8) & ~3;
-    if (t_mid1 <= t_mid0) t_mid0 = t_mid1 = 0;
-    auto body = [&](auto edge_tag, int tb) __attribute__((always_inline)) {
-        constexpr bool EDGE = decltype(edge_tag)::value;
-#pragma unroll
-        for (int p = 0; p < 3; ++p) {
-            cur[p] = nxt[p];
-            nxt[p] = load_luma<false>(rp + p * g.in_plane_stride, tb + 4, EDGE, W);
-        }
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            const int t = tb + s;
-            const float r = cur[0][s], gg = cur[1][s], b = cur[2][s];
-            float y = fmaf_(k.e[0][0], r, fmaf_(k.e[0][1], gg, k.e[0][2] * b));
-            float dr = fmaf_(k.e[1][0], r, fmaf_(k.e[1][1], gg, k.e[1][2] * b));
-            float db = fmaf_(k.e[2][0], r, fmaf_(k.e[2][1], gg, k.e[2][2] * b));
-            if (DEPTH) {
-                const float yp = lane_from(idx1, y), drp = lane_from(idx1, dr), dbp = lane_from(idx1, db);
-                if (have_prev) {
-                    y = yp;                                  // comb.py:147
-                    dr = 0.5f * (dr + drp);                  // comb.py:148-149
-                    db = 0.5f * (db + dbp);
-                }
-            }
-            const float d = alt ? db : dr;                   // protosecam.py:75-78
-            // the shorter path's input waits dly samples
-            const float late = d_c > 0 ? d : y;
-            ring[(t & (kAmRing - 1)) * 64 + lane] = late;
-            const float waited = ring[((t - dly) & (kAmRing - 1)) * 64 + lane];
-            const float d_in = d_c > 0 ? waited : d, y_in = d_c > 0 ? y : (d_y > 0 ? waited : y);
-            float luma, chroma;
-            st.template step<EDGE>(k, t - d_c, d_in, t - d_y, y_in, luma, chroma);
-            const int n = t - lat;
-            int nc = n;
-            if (EDGE) nc = n < 0 ? 0 : (n > W - 1 ? W - 1 : n);
-            const f2 cs = ((const_f2 *)args.a.carrier)[nc];
-            const float cosp = fmaf_(cph, cs.x, -(sph * cs.y));      // cos(phi + n step)
-            put_composite<false, kTile>(g, otile_base, op, lane, wpos, n, fmaf_(cosp, chroma, luma));
-        }
-    };
-    int tb = 0;
-    for (; tb < t_mid0; tb += 4) body(std::true_type(), tb);
-    for (; tb < t_mid1; tb += 4) body(std::false_type(), tb);
-    for (; tb < T; tb += 4) body(std::true_type(), tb);
-}
-
 // ---------------------------------------------------------------------------------------------------------------------
 // Wave-pair form of the Proto-SECAM encoder (round 3):
 //   wave 0 (stage A)  every global load (three-plane 16-sample input tiles through global_load_lds, as the QAM encoders), the
@@ -384,11 +239,8 @@ __global__ __launch_bounds__(64, 2) void proto_mod_kernel(const ProtoModArgs arg
 //   wave 1 (stage B)  the band-stop at the 3x rate, the decimator, the carrier, the composite sample, output tile and every
 //                     global store
 // ---------------------------------------------------------------------------------------------------------------------
-#ifndef CM_PROTO_MOD_PAIR
-#define CM_PROTO_MOD_PAIR 1
-#endif
 template <bool U8> inline int proto_mod_pair_lds_floats(int dly) {
-    return (U8 ? kInTile3Bytes / 4 : kLdsIn3) + proto_ring_slots(dly) * 64 + 2 * 5 * 256 + (U8 ? 64 * kOutTileU8 / 4 : 64 * 16);
+    return (U8 ? kInTile3Bytes / 4 : kLdsIn3) + proto_ring_slots(dly) * 64 + 16 * 64 + 2 * 5 * 256 + (U8 ? 64 * kOutTileU8 / 4 : 64 * 16);
 }
 
 // U8: the ImageModem byte boundary fused in (image.py:27-56): interleaved RGB bytes in, composite bytes out (as the QAM encoders)
@@ -411,7 +263,8 @@ __global__ __launch_bounds__(128, 2) void proto_mod_pair_kernel(const ProtoModAr
     const int T = (g.Wp + lat + 3) & ~3;
     lds_float *itile = lds;
     lds_float *ring = itile + (U8 ? kInTile3Bytes / 4 : kLdsIn3);
-    lds_float *hand = ring + nring * 64;
+    lds_float *ydel = ring + nring * 64;                 // the luma fed to the interpolator, 16 steps back (its phase 0 is the sample of ten steps ago)
+    lds_float *hand = ydel + 16 * 64;
     lds_float *otile_base = hand + 2 * Q * 256;
     // interior bodies: t >= lat + 4 (both paths behind their delays), t + 3 < W - 4
     int t_mid0 = (lat + 4 + 3) & ~3, t_mid1 = (W - 8) & ~3;
@@ -433,6 +286,7 @@ __global__ __launch_bounds__(128, 2) void proto_mod_pair_kernel(const ProtoModAr
         pre.reset();
         up.reset();
         for (int j = 0; j < nring; ++j) ring[j * 64 + lane] = 0.f;
+        for (int j = 0; j < 16; ++j) ydel[j * 64 + lane] = 0.f;
         f4 cur[3], nxt[3];
         first_tile3<U8>(g, itile, rp, lane, nxt);
         auto body = [&](auto edge_tag, int tb) __attribute__((always_inline)) {
@@ -465,7 +319,12 @@ __global__ __launch_bounds__(128, 2) void proto_mod_pair_kernel(const ProtoModAr
                 hq[4][s] = y_in;
                 float u[3] = {0.f, 0.f, 0.f};
                 const int i_y = t - d_y;
-                if (ka.luma_filter) up.push(ka.taps, (!EDGE || (i_y >= 0 && i_y < ka.width)) ? y_in : 0.f, u);
+                if (ka.luma_filter) {
+                    const float y_fed = (!EDGE || (i_y >= 0 && i_y < ka.width)) ? y_in : 0.f;
+                    const float y_del = ydel[((t - kAmHalf) & 15) * 64 + lane];
+                    ydel[(t & 15) * 64 + lane] = y_fed;
+                    up.push(ka.taps, y_fed, y_del, u);
+                }
                 hq[0][s] = u[0]; hq[1][s] = u[1]; hq[2][s] = u[2];
             }
             lds_float *slot = hand + ((tb >> 2) & 1) * (Q * 256) + lane * 4;
@@ -533,128 +392,36 @@ struct NiirDemodArgs {
     Geom g;
     AmGeom a;
     NiirDemodK<float> k;
+    NiirDemodK<double> kd;     // the float64 hue path: taps, band-pass, low-pass, c_pm, alt_scale (cm_am_stages.h: NiirHue)
+    const double *syn;         // [2][3 W]: the band-passed reference carriers of niir.py:107-110 for cos / sin(n step) (cm_am_plan.h: build_niir_syn)
     double line_phase_shift, bandpass_phase_shift, carrier_phase_step;
     int strip;                 // 0: demodulate_components(..., strip_chroma=False)
 };
 
-constexpr int kNiirRing = 8;   // triples of the band-pass output waiting for the low-pass (q_l <= 7, checked by the host)
-
-// FIRST = false: the main pass - the previous call's phase reference comes from the neighbouring lane; calls that open a run
-//                are computed (the next call needs them) but written by the other pass (Geom::skip_first).
-// FIRST = true:  one lane per run, its first call only (Geom::sparse): the phase reference is the synthetic carrier of
-//                niir.py:107-110, produced by a second interpolator + band-pass in the same lane.
-template <bool FIRST>
-__global__ __launch_bounds__(64, 1) void niir_demod_kernel(const NiirDemodArgs args) {
-    constexpr int kTile = 16, DEPTH = 1;
-    __shared__ __attribute__((aligned(16))) float lds_store[3 * 64 * kTile + (FIRST ? 2 : 1) * kNiirRing * 3 * 64];
-    lds_float *otile_base = (lds_float *)lds_store;
-    lds_float *ring = otile_base + 3 * 64 * kTile;
-    lds_float *ring_syn = ring + kNiirRing * 3 * 64;
-    const Geom &g = args.g;
-    NiirDemodK<float> k = args.k;
-    pin_taps3(k.taps);
-    const int lane = threadIdx.x;
-    const LaneCall lc = locate_call(g, blockIdx.x, DEPTH, lane);
-    const float *xp = g.in + lc.frame * g.in_frame_stride + (long long)lc.src_row * g.Wp;
-    const float *op = lc.store_ok ? g.out + lc.frame * g.out_frame_stride + (long long)lc.out_row * g.out_row_stride : nullptr;
-    const long long frame = (long long)args.a.frame_base + lc.frame;
-    NiirLineK<float> lk;
-    {   // niir.py:117-124, 148-157
-        lk.alt = args.a.line.alternate(frame, lc.line);
-        const double shift = lk.alt ? -args.line_phase_shift : args.line_phase_shift;
-        const double ps = (lk.alt ? 0.0 : args.line_phase_shift) + 3.14159265358979323846 - args.bandpass_phase_shift;
-        lk.sin_shift = (float)sin(shift);
-        lk.cos_shift = (float)cos(shift);
-        lk.sin_ps = (float)sin(ps);
-        lk.cos_ps = (float)cos(ps);
-    }
-    float syn_s = 0.f, syn_c = 0.f;       // +-(sin, cos) of the start phase of line - 2
-    if (FIRST) {
-        const double phi = args.a.line.start_phase(frame, lc.line - 2);
-        const float sg = args.a.line.alternate(frame, lc.line - 2) ? -1.f : 1.f;
-        syn_s = sg * (float)sin(phi);
-        syn_c = sg * (float)cos(phi);
-    }
-    const int idx1 = ((lane + 63) & 63) * 4;
-    NiirFront<float> front;
-    NiirBack<float> back;
-    NiirSyn<float> syn;
-    front.reset();
-    back.reset();
-    if (FIRST) syn.reset();
-    lds_float *otile = otile_base + lane * kTile;
-    const int wpos = ((lane >> CM_TILE_SWZ) & (kTile / 4 - 1)) << 2;
-    const int W = g.W;
-    const int q_l = k.gl.q;
-    const int lat = 2 * kAmHalf + 1 + k.gb.q + q_l;
-    const int T = (g.Wp + lat + 3) & ~3;
-    for (int j = 0; j < (FIRST ? 2 : 1) * kNiirRing * 3; ++j) ring[j * 64 + lane] = 0.f;
-    const bool strip = args.strip != 0;
-    f4 xv = load_luma<false>(xp, 0, true, W);
-    // interior bodies (as in proto_demod_kernel): t >= lat + 4, t + 3 < W - 4
-    int t_mid0 = (lat + 4 + 3) & ~3, t_mid1 = (W - 8) & ~3;
-    if (t_mid1 <= t_mid0) t_mid0 = t_mid1 = 0;
-    auto body = [&](auto edge_tag, int tb) __attribute__((always_inline)) {
-        constexpr bool EDGE = decltype(edge_tag)::value;
-        const f4 xn = load_luma<false>(xp, tb + 4, EDGE, W);
-        const f4 cd = load_luma<false>(xp, tb - lat, EDGE, W);        // composite[n5 ..]: the luma source of this body's outputs
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            const int t = tb + s;
-            float m[3], sv[3], md[3], p[3], pv[3];
-            front.template step<EDGE>(k, t, xv[s], m, sv);
-            const int wr = (t & (kNiirRing - 1)) * 3, rd = ((t - q_l) & (kNiirRing - 1)) * 3;
-#pragma unroll
-            for (int j = 0; j < 3; ++j) ring[(wr + j) * 64 + lane] = m[j];
-#pragma unroll
-            for (int j = 0; j < 3; ++j) md[j] = ring[(rd + j) * 64 + lane];
-            const int n3 = t - kAmHalf - k.gb.q - q_l;
-            niir_phasemod<EDGE>(k, n3, md, sv, p);
-            if (FIRST) {
-                float xs = 0.f;
-                if (!EDGE || t < W) {
-                    const f2 cs = ((const_f2 *)args.a.carrier)[t];
-                    xs = fmaf_(syn_s, cs.x, syn_c * cs.y);            // +-sin(phi + t step)
-                }
-                float ms[3];
-                syn.template step<EDGE>(k, t, xs, ms);
-#pragma unroll
-                for (int j = 0; j < 3; ++j) ring_syn[(wr + j) * 64 + lane] = ms[j];
-#pragma unroll
-                for (int j = 0; j < 3; ++j) pv[j] = k.g_b * ring_syn[(rd + j) * 64 + lane];
-            } else {
-#pragma unroll
-                for (int j = 0; j < 3; ++j) pv[j] = lane_from(idx1, p[j]);
-            }
-            const NiirOut<float> o = back.template step<EDGE>(k, n3, p, pv, sv, lk.alt);
-            const int n = t - lat;
-            if (!EDGE || (n >= 0 && n < W)) put_rgb<false, kTile>(otile, wpos, n, niir_finish(k, lk, o, cd[s], strip));
-            if (n >= 0 && ((n & (kTile - 1)) == kTile - 1 || n == g.Wp - 1)) flush_tile<kTile>(g, otile_base, op, n & ~(kTile - 1), lane);
-        }
-        xv = xn;
-    };
-    int tb = 0;
-    for (; tb < t_mid0; tb += 4) body(std::true_type(), tb);
-    for (; tb < t_mid1; tb += 4) body(std::false_type(), tb);
-    for (; tb < T; tb += 4) body(std::true_type(), tb);
+__device__ __forceinline__ double lane_from(int byte_index, double v) {
+    const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_ds_bpermute(byte_index, (int)(unsigned)u);
+    const unsigned hi = (unsigned)__builtin_amdgcn_ds_bpermute(byte_index, (int)(unsigned)(u >> 32));
+    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// Wave-pair form of the NIIR decoder (round 3; the structure of cm_kernels.h: run_pair).  Two wavefronts walk the same 64
-// calls, two steps per body:
+// Wave-pair form of the NIIR decoder (round 3; the structure of cm_kernels.h: run_pair), HUE PATH IN FLOAT64 since round 4
+// (cm_am_stages.h: NiirHue - the float32 front end left isolated samples beyond 1e-5 wherever the decimated hue pair gets short).
+// Two wavefronts walk the same 64 calls, two steps per body:
 //   wave 0 (stage A)  every global load (8-sample input tiles through global_load_lds, two buffers), up3 -> band-pass -> |.| ->
-//                     low-pass (NiirFront), the band-pass triples delayed by the low-pass delay (LDS ring of its own), the phasor
-//                     phasemod = M / S, the saturation decimator, on the first line of a run also the synthetic phase reference
-//                     (NiirSyn); per body it leaves (phasor[3], saturation[, reference[3]]) of both steps in a double-buffered
-//                     hand-over ring and the two row samples in the luma source delay ring
-//   wave 1 (stage B)  the previous call's phasor from the neighbouring lane, the four phase decimators as two packed pairs
-//                     (NiirBackPk, taps in 16 VGPR pairs), normalisation / rotation / offset / matrix (niir_finish), output
-//                     tile and every global store
-// The cut balances the stages (about 210 | 200 vector instructions per pixel; with phasemod and all five decimators in
-// stage B it was 135 | 330 and ran 34 instead of 22 Gpixel/s, profiles/r03_am_notes.txt).
-// One s_barrier per body.  Both stages fit 2 waves per SIMD without parking registers (the one-wave kernel: 256 VGPRs + up to
-// 168 AGPRs, one wave per SIMD, 840 vector instructions per pixel); the main pass and the sparse first-line pass share ONE
-// launch (workgroups [0, n_first) are the first-line ones).
+//                     low-pass in float64 (NiirFront<double>; the interpolator's phase 0 is the row sample of ten steps ago, read
+//                     back from the luma source ring), the band-pass triples delayed by the low-pass delay (LDS ring of doubles),
+//                     the phasor phasemod = M / S (float64, reciprocal seed + Newton), the saturation decimator (float32); per body
+//                     it leaves (phasor[3] as doubles, saturation) of both steps in a double-buffered hand-over ring and the two
+//                     row samples in the luma source delay ring
+//   wave 1 (stage B)  the previous call's phasor from the neighbouring lane (on the first line of a run: the synthetic reference of
+//                     niir.py:107-110 - linear in (sin, cos) of the line's start phase, so two float64 tables of the plan replace
+//                     the second interpolator + band-pass round 3 carried), the hue products and their two decimators in float64
+//                     (NiirHue<double>), the two re-modulation decimators as one packed float32 pair, normalisation / rotation /
+//                     offset / matrix (niir_finish), output tile and every global store
+// One s_barrier per body; the main pass and the sparse first-line pass share ONE launch (workgroups [0, n_first) are the first-line
+// ones; they differ in stage B only).
 // ---------------------------------------------------------------------------------------------------------------------
 struct NiirPairArgs {
     NiirDemodArgs m;           // m.g: the main pass
@@ -662,21 +429,22 @@ struct NiirPairArgs {
     int n_first;
 };
 constexpr int kNiirIT = 8;                                 // samples per input tile row
-constexpr int kNiirHandQ = 4, kNiirHandQFirst = 7;          // hand-over quantities per step: phasor[3], saturation (, reference[3])
-// floats of dynamic LDS: input tile (two buffers) | M delay ring (x 2 with the reference) | hand-over (2 buffers) | luma source ring | output tile
-// slots of the M delay ring: the power of two that holds q_l + 1 triples (q_l = 3 at 13.5 MHz: 4 slots, 3 KiB)
+constexpr int kNiirHandQ = 7;                              // hand-over quantities per body, 8 bytes per lane each: phasor[3] x 2 steps (doubles), saturation x 2 steps
+// floats of dynamic LDS: input tile (two buffers) | M delay ring (doubles) | hand-over (2 buffers) | luma source ring | output tile
+// slots of the M delay ring: the power of two that holds q_l + 1 triples (q_l = 3 at 13.5 MHz: 4 slots, 6 KiB)
 inline __host__ __device__ int niir_mring_slots(int q_l) { return q_l < 2 ? 2 : (q_l < 4 ? 4 : 8); }
-template <bool U8> inline int niir_pair_lds_floats(int lat, int q_l, bool first) {
+constexpr int kNiirRing = 8;   // (q_l <= 7, checked by the host)
+template <bool U8> inline int niir_pair_lds_floats(int lat, int q_l) {
     const int hb = (lat + 1) >> 1;
-    return 2 * AmInTile<U8>::kBufFloats + (first ? 2 : 1) * niir_mring_slots(q_l) * 3 * 64 + 2 * (first ? kNiirHandQFirst : kNiirHandQ) * 128 +
-           (hb + 3) * 128 + (U8 ? 64 * 3 * 16 / 4 : 3 * 64 * 16);
+    return 2 * AmInTile<U8>::kBufFloats + niir_mring_slots(q_l) * 3 * 128 + 2 * kNiirHandQ * 128 + (hb + 3) * 128 + (U8 ? 64 * 3 * 16 / 4 : 3 * 64 * 16);
 }
 
 template <bool FIRST, bool U8>
 __device__ __forceinline__ void niir_pair_body(const NiirDemodArgs &args, const Geom &g, int block, lds_float *lds, int role) {
-    constexpr int kTile = 16, DEPTH = 1, Q = FIRST ? kNiirHandQFirst : kNiirHandQ;
+    constexpr int kTile = 16, DEPTH = 1, Q = kNiirHandQ;
     constexpr int kIT = AmInTile<U8>::kIT;
     typedef __attribute__((address_space(3))) f2 lds_f2;
+    typedef __attribute__((address_space(3))) double lds_double;
     const NiirDemodK<float> &k = args.k;
     const int lane = threadIdx.x & 63;
     const LaneCall lc = locate_call(g, block, DEPTH, lane);
@@ -686,37 +454,32 @@ __device__ __forceinline__ void niir_pair_body(const NiirDemodArgs &args, const 
     const int T = (g.Wp + lat + 1) & ~1;
     const int hb = (lat + 1) >> 1, NB = hb + 3;            // luma source ring: blocks of 2 samples, hb bodies of delay
     lds_float *itile = lds;                                 // two buffers: tile c lives in buffer c & 1
-    lds_float *mring = itile + 2 * AmInTile<U8>::kBufFloats;
+    lds_double *mring = (lds_double *)(itile + 2 * AmInTile<U8>::kBufFloats);
     const int nring = niir_mring_slots(q_l);
-    lds_float *hand = mring + (FIRST ? 2 : 1) * nring * 3 * 64;
+    lds_float *hand = (lds_float *)(mring + nring * 3 * 64);
     lds_float *xring = hand + 2 * Q * 128;
     lds_float *otile_base = xring + NB * 128;
-    // interior bodies (as in the one-wave kernel): t >= lat + 4, t + 1 < W - 6
+    // interior bodies: t >= lat + 4, t + 1 < W - 6
     int t_mid0 = (lat + 4 + 1) & ~1, t_mid1 = (W - 8) & ~1;
     if (t_mid1 <= t_mid0) t_mid0 = t_mid1 = 0;
     const long long frame = (long long)args.a.frame_base + lc.frame;
 
     if (role == 0) {
         // =================================== stage A ===========================================
-        NiirDemodK<float> ka = k;
-        pin_taps3(ka.taps);
+        NiirDemodK<double> kd = args.kd;       // taps in scalar registers (21 distinct values), the sections' 14 coefficients in vector ones
+#pragma unroll
+        for (int j = 0; j < 3; ++j) { pin_vgpr(kd.bp.na1[j]); pin_vgpr(kd.bp.na2[j]); }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) { pin_vgpr(kd.lp.na1[j]); pin_vgpr(kd.lp.na2[j]); pin_vgpr(kd.lp.b1[j]); pin_vgpr(kd.lp.b2[j]); }
+        TapsPk3 kp;
+        kp.load(k.taps);
         const float *xp = am_in_row<U8>(g, lc);
-        float syn_s = 0.f, syn_c = 0.f;       // +-(sin, cos) of the start phase of line - 2
-        if (FIRST) {
-            const double phi = args.a.line.start_phase(frame, lc.line - 2);
-            const float sg = args.a.line.alternate(frame, lc.line - 2) ? -1.f : 1.f;
-            syn_s = sg * (float)sin(phi);
-            syn_c = sg * (float)cos(phi);
-        }
-        NiirFront<float> front;
-        NiirSyn<float> syn;
-        Dn3<float> dn_sat;
+        NiirFront<double> front;
+        Dn3S dn_sat;
         float s_prev[3] = {0.f, 0.f, 0.f};                  // S of the previous triple (the decimators run one triple late)
         front.reset();
         dn_sat.reset();
-        if (FIRST) syn.reset();
-        lds_float *ring_syn = mring + nring * 3 * 64;
-        for (int j = 0; j < (FIRST ? 2 : 1) * nring * 3; ++j) mring[j * 64 + lane] = 0.f;
+        for (int j = 0; j < nring * 3; ++j) mring[j * 64 + lane] = 0.0;
         for (int j = 0; j < NB; ++j) *(lds_f2 *)(xring + j * 128 + lane * 2) = f2{0.f, 0.f};
         am_fill<U8>(g, itile, xp, 0, lane);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -724,44 +487,32 @@ __device__ __forceinline__ void niir_pair_body(const NiirDemodArgs &args, const 
         if (kIT < W) am_fill<U8>(g, itile, xp, 1, lane);      // tile c + 1 is asked for when tile c is first read
         auto read_x = [&](int first) -> f2 { return am_read2<U8>(itile, lane, first, W); };
         f2 xv = read_x(0);
-        int wx = 0;
+        int wx = 0, rx = NB - kAmHalf / 2;                     // rx: the block written five bodies ago = x[tb - 10], x[tb - 9]
         auto body = [&](auto edge_tag, int tb) __attribute__((always_inline)) {
             constexpr bool EDGE = decltype(edge_tag)::value;
-            float hq[Q][2];
+            const f2 xd = *(const lds_f2 *)(xring + rx * 128 + lane * 2);
+            rx = rx + 1 == NB ? 0 : rx + 1;
+            lds_float *slot = hand + ((tb >> 1) & 1) * (Q * 128) + lane * 2;
+            float sat2[2];
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
                 const int t = tb + s;
-                float m[3], sv[3];
-                front.template step<EDGE>(ka, t, xv[s], m, sv);
+                double m[3], sv[3];
+                front.template step<EDGE, false, true>(kd, t, (double)xv[s], (double)xd[s], m, sv);
                 const int wr = (t & (nring - 1)) * 3, rd = ((t - q_l) & (nring - 1)) * 3;
 #pragma unroll
                 for (int j = 0; j < 3; ++j) mring[(wr + j) * 64 + lane] = m[j];
-                float md[3], ph[3];
+                double md[3], ph[3];
 #pragma unroll
                 for (int j = 0; j < 3; ++j) md[j] = mring[(rd + j) * 64 + lane];
-                niir_phasemod<EDGE>(ka, t - kAmHalf - ka.gb.q - q_l, md, sv, ph);
+                niir_phasemod<EDGE>(kd, t - kAmHalf - kd.gb.q - q_l, md, sv, ph);
 #pragma unroll
-                for (int j = 0; j < 3; ++j) hq[j][s] = ph[j];
-                hq[3][s] = ka.sat_gain * dn_sat.push(ka.taps, s_prev);
+                for (int j = 0; j < 3; ++j) *(lds_double *)(slot + (2 * j + s) * 128) = ph[j];
+                sat2[s] = k.sat_gain * dn_sat.push(kp, s_prev);
 #pragma unroll
-                for (int j = 0; j < 3; ++j) s_prev[j] = sv[j];
-                if (FIRST) {
-                    float xs = 0.f;
-                    if (!EDGE || t < W) {
-                        const f2 cs = ((const_f2 *)args.a.carrier)[t];
-                        xs = fmaf_(syn_s, cs.x, syn_c * cs.y);            // +-sin(phi + t step)
-                    }
-                    float ms[3];
-                    syn.template step<EDGE>(ka, t, xs, ms);
-#pragma unroll
-                    for (int j = 0; j < 3; ++j) ring_syn[(wr + j) * 64 + lane] = ms[j];
-#pragma unroll
-                    for (int j = 0; j < 3; ++j) hq[FIRST ? 4 + j : 0][s] = ka.g_b * ring_syn[(rd + j) * 64 + lane];
-                }
+                for (int j = 0; j < 3; ++j) s_prev[j] = (float)sv[j];
             }
-            lds_float *slot = hand + ((tb >> 1) & 1) * (Q * 128) + lane * 2;
-#pragma unroll
-            for (int q = 0; q < Q; ++q) *(lds_f2 *)(slot + q * 128) = f2{hq[q][0], hq[q][1]};
+            *(lds_f2 *)(slot + 6 * 128) = f2{sat2[0], sat2[1]};
             *(lds_f2 *)(xring + wx * 128 + lane * 2) = xv;
             wx = wx + 1 == NB ? 0 : wx + 1;
             const int nxt = tb + 2;
@@ -796,24 +547,39 @@ __device__ __forceinline__ void niir_pair_body(const NiirDemodArgs &args, const 
         lk.sin_ps = (float)sin(ps);
         lk.cos_ps = (float)cos(ps);
     }
+    double syn_s = 0.0, syn_c = 0.0;          // the reference of the first line of a run: +-sin(phi + n step) = syn_s cos(n step) + syn_c sin(n step)
+    if (FIRST) {
+        const double phi = args.a.line.start_phase(frame, lc.line - 2);
+        const double sg = args.a.line.alternate(frame, lc.line - 2) ? -1.0 : 1.0;
+        syn_s = sg * sin(phi);
+        syn_c = sg * cos(phi);
+    }
+    const NiirDemodK<double> &kd = args.kd;
     TapsPk3 kp;
     kp.load(k.taps);
     const int idx1 = ((lane + 63) & 63) * 4;
-    NiirBackPk back;
-    back.reset();
+    NiirHue<double> hue;
+    Dn3Pk dn_car;
+    hue.reset();
+    dn_car.reset();
     lds_float *otile = U8 ? (lds_float *)((__attribute__((address_space(3))) unsigned char *)otile_base + lane * 3 * kTile) : otile_base + lane * kTile;
     const int wpos = ((lane >> CM_TILE_SWZ) & (kTile / 4 - 1)) << 2;
     const bool strip = args.strip != 0;
     const bool odd = (lat & 1) != 0;
+    const int L = 3 * W;
     int ra = NB - hb, rb = NB - hb + 1;         // luma source blocks of bodies b - hb and b - hb + 1
     if (rb >= NB) rb -= NB;
     auto body = [&](auto edge_tag, int tb) __attribute__((always_inline)) {
         constexpr bool EDGE = decltype(edge_tag)::value;
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // the hand-over of this body is complete
         const lds_float *slot = hand + ((tb >> 1) & 1) * (Q * 128) + lane * 2;
-        f2 hq[Q];
+        double pq[3][2];
 #pragma unroll
-        for (int q = 0; q < Q; ++q) hq[q] = *(const lds_f2 *)(slot + q * 128);
+        for (int j = 0; j < 3; ++j) {
+            pq[j][0] = *(const lds_double *)(slot + (2 * j) * 128);
+            pq[j][1] = *(const lds_double *)(slot + (2 * j + 1) * 128);
+        }
+        const f2 sat2 = *(const lds_f2 *)(slot + 6 * 128);
         const f2 xa = *(const lds_f2 *)(xring + ra * 128 + lane * 2), xb = *(const lds_f2 *)(xring + rb * 128 + lane * 2);
         ra = ra + 1 == NB ? 0 : ra + 1;
         rb = rb + 1 == NB ? 0 : rb + 1;
@@ -821,12 +587,28 @@ __device__ __forceinline__ void niir_pair_body(const NiirDemodArgs &args, const 
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             const int t = tb + s;
-            const float p[3] = {hq[0][s], hq[1][s], hq[2][s]};
-            float pv[3];
+            const double p[3] = {pq[0][s], pq[1][s], pq[2][s]};
+            double pv[3];
             const int n3 = t - kAmHalf - k.gb.q - q_l;
+            if (FIRST) {
 #pragma unroll
-            for (int j = 0; j < 3; ++j) pv[j] = FIRST ? hq[FIRST ? 4 + j : 0][s] : lane_from(idx1, p[j]);
-            const NiirOut<float> o = back.template step<EDGE>(k, kp, n3, p, pv, hq[3][s], lk.alt);
+                for (int j = 0; j < 3; ++j) {
+                    const int q = 3 * n3 + j;
+                    pv[j] = (q >= 0 && q < L) ? __builtin_fma(syn_s, args.syn[q], syn_c * args.syn[L + q]) : 0.0;
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 3; ++j) pv[j] = lane_from(idx1, p[j]);
+            }
+            double sp, cp, car[3], acar[3];
+            hue.template step<EDGE, false>(kd.taps, kd.alt_scale, W, n3, p, pv, lk.alt, sp, cp, car, acar);
+            const pf2 r2 = dn_car.push(kp, pf2{(float)car[0], (float)acar[0]}, pf2{(float)car[1], (float)acar[1]}, pf2{(float)car[2], (float)acar[2]});
+            NiirOut<float> o;
+            o.sinphi = (float)sp;
+            o.cosphi = (float)cp;
+            o.sat = sat2[s];
+            o.sinc = k.third * r2.x;
+            o.cosc = k.third * r2.y;
             const int n = t - lat;
             if (!EDGE || (n >= 0 && n < W)) put_rgb<U8, kTile>(otile, wpos, n, niir_finish(k, lk, o, cd[s], strip));
             if (n >= 0 && ((n & (kTile - 1)) == kTile - 1 || n == g.Wp - 1)) {

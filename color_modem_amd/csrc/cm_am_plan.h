@@ -5,6 +5,7 @@
 
 #include <cmath>
 #include <string>
+#include <vector>
 
 #include "../../include/color_modem_hip.h"
 #include "cm_am_stages.h"
@@ -32,9 +33,19 @@ inline bool am_shifts_ok(const cm_am_desc &d, std::string &err) {
     return true;
 }
 
+// firwin(61, 1 / 3) as the streaming forms use it (cm_am_stages.h: Up3, Dn3): symmetric, and zero at 30 + 3 k, k != 0
+inline bool taps3_third_band(const cm_am_desc &d, std::string &err) {
+    const double c = std::fabs(d.resample_fir3[30]);
+    for (int i = 0; i < kAmTaps; ++i) {
+        if (i % 3 == 0 && i != 30 && std::fabs(d.resample_fir3[i]) > 1e-12 * c) { err = "resample_fir3 is not a third-band filter (taps 30 + 3 k must vanish)"; return false; }
+        if (std::fabs(d.resample_fir3[i] - d.resample_fir3[kAmTaps - 1 - i]) > 1e-12 * c) { err = "resample_fir3 is not symmetric"; return false; }
+    }
+    return true;
+}
+
 template <typename T>
 bool build_proto_demod_k(const cm_am_desc &d, ProtoDemodK<T> &k, std::string &err) {
-    if (!am_shifts_ok(d, err)) return false;
+    if (!am_shifts_ok(d, err) || !taps3_third_band(d, err)) return false;
     k.width = d.width;
     k.ge = ff_geom(d.bandpass_up.shift, 3);
     k.gr = ff_geom(d.bandstop_up.shift, 3);
@@ -53,7 +64,7 @@ bool build_proto_demod_k(const cm_am_desc &d, ProtoDemodK<T> &k, std::string &er
 
 template <typename T>
 bool build_proto_mod_k(const cm_am_desc &d, ProtoModK<T> &k, std::string &err) {
-    if (!am_shifts_ok(d, err)) return false;
+    if (!am_shifts_ok(d, err) || !taps3_third_band(d, err)) return false;
     k.width = d.width;
     k.luma_filter = d.premod_luma_filter ? 1 : 0;
     k.s_c = d.precorrect.shift;
@@ -71,7 +82,7 @@ bool build_proto_mod_k(const cm_am_desc &d, ProtoModK<T> &k, std::string &err) {
 
 template <typename T>
 bool build_niir_demod_k(const cm_am_desc &d, NiirDemodK<T> &k, std::string &err) {
-    if (!am_shifts_ok(d, err)) return false;
+    if (!am_shifts_ok(d, err) || !taps3_third_band(d, err)) return false;
     k.width = d.width;
     k.gb = ff_geom(d.bandpass_up.shift, 3);
     k.gl = ff_geom(d.lowpass_up.shift, 3);
@@ -87,6 +98,31 @@ bool build_niir_demod_k(const cm_am_desc &d, NiirDemodK<T> &k, std::string &err)
     k.third = T(1.0 / 3.0);
     for (int i = 0; i < 3; ++i)
         for (int j = 0; j < 3; ++j) k.m[i][j] = T(d.decode_matrix[3 * i + j]);
+    return true;
+}
+
+// The phase reference of the first line of a run (niir.py:107-110): _demodulate_upsampled_filter(resample_poly(+-sin(phi + n step), 3, 1)).
+// The chain is linear - FilterFunction's tail padding too - and +-sin(phi + n step) = +-(sin(phi) cos(n step) + cos(phi) sin(n step)), so the
+// reference of ANY line is +-(sin(phi) R_c + cos(phi) R_s) with two sequences of the plan: out = [R_c | R_s], 3 W samples each, float64.
+inline bool build_niir_syn(const cm_am_desc &d, std::vector<double> &out, std::string &err) {
+    NiirDemodK<double> k;
+    if (!build_niir_demod_k<double>(d, k, err)) return false;
+    const int W = d.width, L = 3 * W;
+    out.assign(2 * (size_t)L, 0.0);
+    for (int which = 0; which < 2; ++which) {
+        auto x = [&](int t) { return (t < 0 || t >= W) ? 0.0 : (which ? std::sin((double)t * d.carrier_phase_step) : std::cos((double)t * d.carrier_phase_step)); };
+        NiirSyn<double> sy;
+        sy.reset();
+        for (int t = 0; t < W + kAmHalf + k.gb.q; ++t) {
+            double m[3];
+            sy.step(k, t, x(t), x(t - kAmHalf), m);
+            const int n2 = t - kAmHalf - k.gb.q;
+            for (int j = 0; j < 3; ++j) {
+                const int q = 3 * n2 + j;
+                if (q >= 0 && q < L) out[(size_t)which * L + q] = k.g_b * m[j];
+            }
+        }
+    }
     return true;
 }
 

@@ -27,24 +27,34 @@ template <typename T>
 struct Taps3 {
     T h[kAmTaps];
 };
+constexpr int tap3i(int i) { return i <= 30 ? i : 60 - i; }      // h[i] = h[60 - i] (checked by the host: cm_am_plan.h: taps3_third_band)
 
-// resample_poly(x, 3, 1): y[m] = sum_i 3 h[i] xu[m + 30 - i], xu[3 n] = x[n].  push(x[t]) completes y[3 (t - 10) + j], j = 0..2.
-// s[e] = partial sum of y[3 t - 30 + e] from the inputs before x[t].  k.h holds 3 h.
+// firwin(61, 1 / 3) is a THIRD-BAND filter: h[30 + 3 k] = sinc(k) = 0 for k != 0 (numerically ~1e-17; the host refuses a tap set where
+// they are not below 1e-12 of the centre tap, cm_am_plan.h: taps3_third_band).  The streaming forms below never touch those 20 taps
+// (round 4): the interpolator's phase 0 is the input delayed by 10 samples times 3 h[30], the decimator skips the samples z[3 q] but one.
+
+// resample_poly(x, 3, 1): y[m] = sum_i 3 h[i] xu[m + 30 - i], xu[3 n] = x[n].  push(x[t], x[t - 10]) completes y[3 (t - 10) + j], j = 0..2.
+// s(e) = partial sum of y[3 t - 30 + e] from the inputs before x[t], kept for e = 1, 2 mod 3 only (e = 3 i + r -> s[2 i + r - 1]); k.h holds 3 h.
 template <typename T>
 struct Up3 {
-    T s[58];
+    T s[38];
     CM_HD void reset() {
 #pragma unroll
-        for (int e = 0; e < 58; ++e) s[e] = T(0);
+        for (int e = 0; e < 38; ++e) s[e] = T(0);
     }
-    // (fma3: the three-address form - with the two-address v_fmac hipcc rotates the 55 partial sums through one v_mov each)
-    CM_HD void push(const Taps3<T> &k, T x, T out[3]) {
+    static constexpr int slot(int e) { return 2 * (e / 3) + (e % 3) - 1; }
+    // (fma3: the three-address form - with the two-address v_fmac hipcc rotates the partial sums through one v_mov each; V: the taps sit
+    // in vector registers (pin_taps3) or in scalar ones; tap3i: h is symmetric, the device keeps 21 values, not 41)
+    template <bool V = true>
+    CM_HD void push(const Taps3<T> &k, T x, T x_del, T out[3]) {
+        out[0] = k.h[30] * x_del;
+        out[1] = fma3<V>(k.h[1], x, s[slot(1)]);
+        out[2] = fma3<V>(k.h[2], x, s[slot(2)]);
 #pragma unroll
-        for (int j = 0; j < 3; ++j) out[j] = fma3<true>(k.h[j], x, s[j]);
-#pragma unroll
-        for (int e = 3; e < 58; ++e) s[e - 3] = fma3<true>(k.h[e], x, s[e]);
-#pragma unroll
-        for (int e = 58; e < 61; ++e) s[e - 3] = k.h[e] * x;
+        for (int e = 4; e < 58; ++e)
+            if (e % 3 != 0) s[slot(e - 3)] = fma3<V>(k.h[tap3i(e)], x, s[slot(e)]);
+        s[slot(55)] = k.h[2] * x;
+        s[slot(56)] = k.h[1] * x;
     }
 };
 
@@ -58,30 +68,29 @@ struct Dn3 {
 #pragma unroll
         for (int d = 0; d < 20; ++d) s[d] = T(0);
     }
-    // Every pending output takes its three products in the order z[2], z[1], z[0]; the passes below run that order across all
-    // of them, so that no instruction reads the result of the one right before it (and the three-address form: no v_mov).
+    // Every pending output takes its products in the order z[2], z[1] (, z[0]: the centre tap only); the passes below run that
+    // order across all of them, so that no instruction reads the result of the one right before it (three-address form: no v_mov).
+    template <bool V = true>
     CM_HD T push(const Taps3<T> &k, const T z[3]) {
-        const T out = fma3<true>(k.h[0], z[0], s[0]);
+        const T out = s[0];
 #pragma unroll
-        for (int d = 1; d < 20; ++d) s[d] = fma3<true>(k.h[3 * d - 2], z[2], s[d]);
-        const T last = k.h[58] * z[2];
+        for (int d = 1; d < 20; ++d) s[d] = fma3<V>(k.h[tap3i(3 * d - 2)], z[2], s[d]);
+        const T last = k.h[2] * z[2];
+        s[10] = fma3<V>(k.h[30], z[0], s[10]);
 #pragma unroll
-        for (int d = 1; d < 20; ++d) s[d] = fma3<true>(k.h[3 * d - 1], z[1], s[d]);
-        const T last2 = fma3<true>(k.h[59], z[1], last);
-#pragma unroll
-        for (int d = 1; d < 20; ++d) s[d - 1] = fma3<true>(k.h[3 * d], z[0], s[d]);
-        s[19] = fma3<true>(k.h[60], z[0], last2);
+        for (int d = 1; d < 20; ++d) s[d - 1] = fma3<V>(k.h[tap3i(3 * d - 1)], z[1], s[d]);
+        s[19] = fma3<V>(k.h[1], z[1], last);
         return out;
     }
 };
 
 enum { AM_FORM_BP = 0, AM_FORM_SYM = 1, AM_FORM_GEN = 2 };
 
-template <int FORM, typename T, int NSEC>
+template <int FORM, bool V = false, typename T, int NSEC>
 CM_HD T am_iir(IirState<T, NSEC> &st, const SosK<T, NSEC> &k, T x) {
-    if (FORM == AM_FORM_BP) return iir_bp<false>(st, k, x);
-    if (FORM == AM_FORM_SYM) return iir_sym<false>(st, k, x);
-    return iir_gen<false>(st, k, x);
+    if (FORM == AM_FORM_BP) return iir_bp<V>(st, k, x);
+    if (FORM == AM_FORM_SYM) return iir_sym<V>(st, k, x);
+    return iir_gen<V>(st, k, x);
 }
 
 // Delay bookkeeping of one FilterFunction whose sequence runs at `rate` samples per step.
@@ -104,7 +113,7 @@ struct FF3 {
     }
     // EDGE = false: the caller guarantees 0 <= 3 (n1 - q) and 3 n1 + 2 < L - 1 (the interior of a row: no latch, no clamp,
     // every output inside the sequence)
-    template <int FORM, bool EDGE = true>
+    template <int FORM, bool EDGE = true, bool V = false>
     CM_HD void step(const SosK<T, NSEC> &k, const FFGeom &g, int L, int n1, const T in[3], T out[3]) {
         T y[3];
 #pragma unroll
@@ -114,10 +123,10 @@ struct FF3 {
                 y[j] = T(0);
                 if (m >= 0 && m < L + g.shift) {
                     if (m == L - 1) last = in[j];
-                    y[j] = am_iir<FORM>(st, k, m < L ? in[j] : last);
+                    y[j] = am_iir<FORM, V>(st, k, m < L ? in[j] : last);
                 }
             } else {
-                y[j] = am_iir<FORM>(st, k, in[j]);
+                y[j] = am_iir<FORM, V>(st, k, in[j]);
             }
         }
         T o0, o1, o2;
@@ -191,12 +200,12 @@ struct ProtoDemod {
     }
     CM_HD static int lat_chroma(const ProtoDemodK<T> &k) { return 2 * kAmHalf + k.ge.q + k.gp.q; }
     CM_HD static int lat_luma(const ProtoDemodK<T> &k) { return 2 * kAmHalf + k.gr.q; }
-    // luma = luma[t - lat_luma], chroma = chroma[t - lat_chroma] (meaningful inside the row)
+    // luma = luma[t - lat_luma], chroma = chroma[t - lat_chroma] (meaningful inside the row); x_del = x[t - 10] (zero outside the row)
     template <bool EDGE = true>
-    CM_HD void step(const ProtoDemodK<T> &k, int t, T x_now, T &luma, T &chroma) {
+    CM_HD void step(const ProtoDemodK<T> &k, int t, T x_now, T x_del, T &luma, T &chroma) {
         const int L = 3 * k.width, n1 = t - kAmHalf;
         T u[3], c1[3], c2[3], y1[3];
-        up.push(k.taps, x_now, u);
+        up.push(k.taps, x_now, x_del, u);
         ext.template step<AM_FORM_BP, EDGE>(k.ext, k.ge, L, n1, u, c1);
 #pragma unroll
         for (int j = 0; j < 3; ++j) c1[j] = c1[j] < T(0) ? -c1[j] : c1[j];     // protosecam.py:98 (the factor pi / 2 is in chroma_gain)
@@ -240,13 +249,15 @@ struct ProtoMod {
     CM_HD static int lat_chroma(const ProtoModK<T> &k) { return k.s_c; }
     // i_c, d: index and value of the colour-difference sample fed now; i_y, luma likewise.  Returns the filtered luma of
     // sample i_y - lat_luma through luma_out and 0.125 (1 + chroma) of sample i_c - lat_chroma through chroma_out.
+    // luma_del: the luma sample fed ten steps ago (index i_y - 10; zero outside the row).
     template <bool EDGE = true>
-    CM_HD void step(const ProtoModK<T> &k, int i_c, T d, int i_y, T luma, T &luma_out, T &chroma_out) {
+    CM_HD void step(const ProtoModK<T> &k, int i_c, T d, int i_y, T luma, T luma_del, T &luma_out, T &chroma_out) {
         const T c = pre.template step<AM_FORM_GEN, EDGE>(k.pre, k.s_c, k.width, i_c, d);
         chroma_out = fmaf_(T(0.125) * k.pre_gain, c, T(0.125));
         if (k.luma_filter) {
             T u[3], y1[3];
-            up.push(k.taps, (!EDGE || (i_y >= 0 && i_y < k.width)) ? luma : T(0), u);
+            up.push(k.taps, (!EDGE || (i_y >= 0 && i_y < k.width)) ? luma : T(0),
+                    (!EDGE || (i_y - kAmHalf >= 0 && i_y - kAmHalf < k.width)) ? luma_del : T(0), u);
             rem.template step<AM_FORM_SYM, EDGE>(k.rem, k.gr, 3 * k.width, i_y - kAmHalf, u, y1);
             luma_out = k.luma_gain * dn.push(k.taps, y1);
         } else {
@@ -293,16 +304,17 @@ struct NiirFront {
     CM_HD void reset() {
         up.reset(); bp.reset(); lp.reset();
     }
-    // m_out = M(n2), n2 = t - 10 - q_b;  s_out = S(n3), n3 = n2 - q_l   (both zero outside [0, L))
-    template <bool EDGE = true>
-    CM_HD void step(const NiirDemodK<T> &k, int t, T x_now, T m_out[3], T s_out[3]) {
+    // m_out = M(n2), n2 = t - 10 - q_b;  s_out = S(n3), n3 = n2 - q_l   (both zero outside [0, L)); x_del = x[t - 10] (zero outside the row)
+    // VT / VI: the taps / the sections' coefficients sit in vector registers (the float64 instance: taps scalar, sections vector)
+    template <bool EDGE = true, bool VT = true, bool VI = false>
+    CM_HD void step(const NiirDemodK<T> &k, int t, T x_now, T x_del, T m_out[3], T s_out[3]) {
         const int L = 3 * k.width, n1 = t - kAmHalf;
         T u[3], a[3];
-        up.push(k.taps, x_now, u);
-        bp.template step<AM_FORM_BP, EDGE>(k.bp, k.gb, L, n1, u, m_out);
+        up.template push<VT>(k.taps, x_now, x_del, u);
+        bp.template step<AM_FORM_BP, EDGE, VI>(k.bp, k.gb, L, n1, u, m_out);
 #pragma unroll
         for (int j = 0; j < 3; ++j) a[j] = m_out[j] < T(0) ? -m_out[j] : m_out[j];     // niir.py:113 (pi / 2 is in the constants)
-        lp.template step<AM_FORM_GEN, EDGE>(k.lp, k.gl, L, n1 - k.gb.q, a, s_out);
+        lp.template step<AM_FORM_GEN, EDGE, VI>(k.lp, k.gl, L, n1 - k.gb.q, a, s_out);
     }
 };
 
@@ -315,9 +327,9 @@ struct NiirSyn {
         up.reset(); bp.reset();
     }
     template <bool EDGE = true>
-    CM_HD void step(const NiirDemodK<T> &k, int t, T x_syn, T m_out[3]) {
+    CM_HD void step(const NiirDemodK<T> &k, int t, T x_syn, T x_syn_del, T m_out[3]) {
         T u[3];
-        up.push(k.taps, x_syn, u);
+        up.push(k.taps, x_syn, x_syn_del, u);
         bp.template step<AM_FORM_BP, EDGE>(k.bp, k.gb, 3 * k.width, t - kAmHalf, u, m_out);
     }
 };
@@ -332,7 +344,18 @@ CM_HD float am_div(float a, float b) {
     return a / b;
 #endif
 }
-CM_HD double am_div(double a, double b) { return a / b; }
+// float64: the reciprocal from v_rcp_f32 and one Newton step (relative error ~1e-14; the IEEE sequence is ~30 instructions).  A zero or
+// infinite divisor keeps the seed (+-inf / 0): a * seed is numpy's inf / nan / 0 there, where the reference divides by zero (niir.py:115)
+CM_HD double am_div(double a, double b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const float rf = __builtin_amdgcn_rcpf((float)b);
+    const double r = (double)rf;
+    const double rn = __builtin_fma(__builtin_fma(-b, r, 1.0), r, r);
+    return a * (__builtin_amdgcn_classf(rf, 0x204 | 0x060) ? r : rn);      // class: +-inf | +-0
+#else
+    return a / b;
+#endif
+}
 CM_HD float am_rsqrt(float x) {
 #if defined(__HIP_DEVICE_COMPILE__)
     return __builtin_amdgcn_rsqf(x);
@@ -397,6 +420,54 @@ struct NiirBack {
 #pragma unroll
         for (int j = 0; j < 3; ++j) { c1[j] = c[j]; h1[j] = h[j]; s1[j] = s[j]; }
         return o;
+    }
+};
+
+// ---- round 4: the hue path in float64 ------------------------------------------------------------------------------------------
+// The decoder takes the hue as the ANGLE of the decimated pair (sinphi, cosphi) = resample_poly(huemod_up * {carrier_up, altcarrier_up}, 1, 3)
+// (niir.py:131-137).  Where the hue turns quickly inside the decimator's window that pair gets short - every absolute error in it is
+// divided by its length - and float32 rounding of the 3x-rate front end (interpolator, band-pass, low-pass: ~1e-7 of full scale) showed as
+// isolated samples beyond 1e-5 (round 3: 4e-5 of all decoded samples on random pictures, worst 4e-3).  So everything whose ABSOLUTE error
+// reaches that pair runs in float64: NiirFront<double>, the quotient M / S, the products and these two decimators.  What only scales an
+// amplitude - the saturation, the re-modulation carriers, niir_finish - stays float32.  (TP = double on the device; the host simulator
+// also instantiates TP = float to show what the split buys: tests/test_sim_am.py.)
+template <typename TP>
+struct NiirHue {
+    Dn3<TP> dn_s, dn_c;
+    TP c1[3], h1[3], c2_2;                // carrier and hue-modulated signal of the previous triple; carrier[3 n3 - 4]
+    CM_HD void reset() {
+        dn_s.reset(); dn_c.reset();
+#pragma unroll
+        for (int j = 0; j < 3; ++j) c1[j] = h1[j] = TP(0);
+        c2_2 = TP(0);
+    }
+    // own / prev: phasemod_up triples n3 of this call and of the previous one.  Returns the decimated pair at sample n5 = n3 - 11 and the
+    // carrier / its derivative of triple n4 = n3 - 1 (the inputs of the two re-modulation decimators, niir.py:145-146).
+    template <bool EDGE = true, bool V = true>
+    CM_HD void step(const Taps3<TP> &taps, TP alt_scale, int width, int n3, const TP own[3], const TP prev[3], bool alt, TP &sinphi, TP &cosphi,
+                    TP car[3], TP acar[3]) {
+        const int L = 3 * width, n4 = n3 - 1;
+        TP c[3], h[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {                       // niir.py:117-124
+            c[j] = alt ? own[j] : prev[j];
+            h[j] = alt ? prev[j] : own[j];
+        }
+        TP su[3], cu[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int p = 3 * n4 + j;
+            const TP before = j == 0 ? c2_2 : c1[j - 1], after = j == 2 ? c[0] : c1[j + 1];
+            acar[j] = (!EDGE || (p >= 1 && p <= L - 2)) ? alt_scale * (after - before) : TP(0);       // niir.py:126-129
+            car[j] = c1[j];
+            su[j] = h1[j] * c1[j];                                                                      // niir.py:131-132
+            cu[j] = h1[j] * acar[j];
+        }
+        sinphi = dn_s.template push<V>(taps, su);
+        cosphi = dn_c.template push<V>(taps, cu);
+        c2_2 = c1[2];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) { c1[j] = c[j]; h1[j] = h[j]; }
     }
 };
 
@@ -621,26 +692,29 @@ struct NiirMod {
 }  // namespace cm
 #include "cm_stages_pk.h"
 namespace cm {
+// (third-band: the 21 taps that are not zero - i <= 30, i mod 3 != 0, and the centre tap - in 11 pairs)
+constexpr int tap3_slot(int I) { return (I <= 30 ? I : 60 - I) == 30 ? 20 : 2 * ((I <= 30 ? I : 60 - I) / 3) + ((I <= 30 ? I : 60 - I) % 3) - 1; }
 struct TapsPk3 {
-    pf2 c[16];
+    pf2 c[11];
     template <int J>
     __device__ __forceinline__ void load_j(const Taps3<float> &t) {
-        c[J] = pf2{take(t.h[2 * J]), take(t.h[2 * J + 1 <= 30 ? 2 * J + 1 : 30])};
+        constexpr int i0 = J == 10 ? 30 : 3 * J + 1, i1 = J == 10 ? 30 : 3 * J + 2;      // slots 2 J, 2 J + 1
+        c[J] = pf2{take(t.h[i0]), take(t.h[i1])};
         pin_pair(c[J]);
-        if constexpr (J + 1 < 16) load_j<J + 1>(t);
+        if constexpr (J + 1 < 11) load_j<J + 1>(t);
     }
     __device__ __forceinline__ void load(const Taps3<float> &t) { load_j<0>(t); }
 };
 template <int I> __device__ __forceinline__ pf2 tap3_fma(const TapsPk3 &k, pf2 x, pf2 acc) {
-    constexpr int i = I <= 30 ? I : 60 - I;
+    constexpr int i = tap3_slot(I);
     return pk_fma_c<i & 1>(k.c[i >> 1], x, acc);
 }
 template <int I> __device__ __forceinline__ pf2 tap3_mul(const TapsPk3 &k, pf2 x) {
-    constexpr int i = I <= 30 ? I : 60 - I;
+    constexpr int i = tap3_slot(I);
     return pk_mul_c<i & 1>(k.c[i >> 1], x);
 }
 template <int I> __device__ __forceinline__ float tap3(const TapsPk3 &k) {
-    constexpr int i = I <= 30 ? I : 60 - I;
+    constexpr int i = tap3_slot(I);
     return (i & 1) ? k.c[i >> 1].y : k.c[i >> 1].x;
 }
 // Dn3 on a pair of signals
@@ -650,28 +724,23 @@ struct Dn3Pk {
 #pragma unroll
         for (int d = 0; d < 20; ++d) s[d] = pf2{0.f, 0.f};
     }
-    // three passes over the pending outputs (z2, then z1, then z0: the scalar decimator's order per output, and no packed
-    // instruction reads the result of the one right before it - hipcc pads such pairs with an s_nop)
+    // two passes over the pending outputs (z2, then z1 - the scalar decimator's order per output - and the centre tap on z0 in between;
+    // no packed instruction reads the result of the one right before it - hipcc pads such pairs with an s_nop)
     template <int D> __device__ __forceinline__ void pass2(const TapsPk3 &k, pf2 z2) {
         s[D] = tap3_fma<3 * D - 2>(k, z2, s[D]);
         if constexpr (D < 19) pass2<D + 1>(k, z2);
     }
     template <int D> __device__ __forceinline__ void pass1(const TapsPk3 &k, pf2 z1) {
-        s[D] = tap3_fma<3 * D - 1>(k, z1, s[D]);
+        s[D - 1] = tap3_fma<3 * D - 1>(k, z1, s[D]);
         if constexpr (D < 19) pass1<D + 1>(k, z1);
     }
-    template <int D> __device__ __forceinline__ void pass0(const TapsPk3 &k, pf2 z0) {
-        s[D - 1] = tap3_fma<3 * D>(k, z0, s[D]);
-        if constexpr (D < 19) pass0<D + 1>(k, z0);
-    }
     __device__ __forceinline__ pf2 push(const TapsPk3 &k, pf2 z0, pf2 z1, pf2 z2) {
-        const pf2 out = tap3_fma<0>(k, z0, s[0]);
+        const pf2 out = s[0];
         pass2<1>(k, z2);
         const pf2 last = tap3_mul<58>(k, z2);
+        s[10] = tap3_fma<30>(k, z0, s[10]);
         pass1<1>(k, z1);
-        const pf2 last2 = tap3_fma<59>(k, z1, last);
-        pass0<1>(k, z0);
-        s[19] = tap3_fma<60>(k, z0, last2);
+        s[19] = tap3_fma<59>(k, z1, last);
         return out;
     }
 };
@@ -684,13 +753,15 @@ struct Dn3S {
     }
     template <int D>
     __device__ __forceinline__ void upd(const TapsPk3 &k, float z0, float z1, float z2) {
-        s[D - 1] = fma3<true>(tap3<3 * D>(k), z0, fma3<true>(tap3<3 * D - 1>(k), z1, fma3<true>(tap3<3 * D - 2>(k), z2, s[D])));
+        float a = fma3<true>(tap3<3 * D - 2>(k), z2, s[D]);
+        if constexpr (D == 10) a = fma3<true>(tap3<30>(k), z0, a);
+        s[D - 1] = fma3<true>(tap3<3 * D - 1>(k), z1, a);
         if constexpr (D < 19) upd<D + 1>(k, z0, z1, z2);
     }
     __device__ __forceinline__ float push(const TapsPk3 &k, const float z[3]) {
-        const float out = fma3<true>(tap3<0>(k), z[0], s[0]);
+        const float out = s[0];
         upd<1>(k, z[0], z[1], z[2]);
-        s[19] = fma3<true>(tap3<60>(k), z[0], fma3<true>(tap3<59>(k), z[1], tap3<58>(k) * z[2]));
+        s[19] = fma3<true>(tap3<59>(k), z[1], tap3<58>(k) * z[2]);
         return out;
     }
 };

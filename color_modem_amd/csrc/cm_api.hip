@@ -1794,6 +1794,8 @@ struct cm_am_plan {
     ProtoDemodK<float> pd;
     ProtoModK<float> pm;
     NiirDemodK<float> nd;
+    NiirDemodK<double> ndd;            // the decoder's float64 hue path (cm_am_stages.h: NiirHue)
+    double *niir_syn = nullptr;        // [2][3 width]: the first lines' phase reference for cos / sin(n step) (cm_am_plan.h: build_niir_syn)
     NiirModK<float> nm;
     std::string demod_error, mod_error;
     // small batches: one wavefront per call (cm_am_scan_kernels.h); null where the plan's shape does not fit
@@ -2013,6 +2015,8 @@ int niir_launch_demod(const cm_am_plan *p, Geom g, int64_t first_frame, hipStrea
     NiirDemodArgs a;
     am_geom(p, first_frame, a.a);
     a.k = p->nd;
+    a.kd = p->ndd;
+    a.syn = p->niir_syn;
     a.line_phase_shift = p->desc.line_phase_shift;
     a.bandpass_phase_shift = p->desc.bandpass_phase_shift;
     a.carrier_phase_step = p->desc.carrier_phase_step;
@@ -2037,7 +2041,6 @@ int niir_launch_demod(const cm_am_plan *p, Geom g, int64_t first_frame, hipStrea
     long long blocks = (g.total_calls + 62) / 63;
     if (blocks > 0x7fffffffLL) return fail(CM_ERR_INVALID, "batch too large for one launch");
     if (g.rows_mode && g.total_calls == 1 && with_first) blocks = 0;      // a lone first call needs no main pass
-#if CM_NIIR_PAIR
     {   // the wave pair: main pass and sparse first-line pass in one launch (cm_am_kernels.h: niir_demod_pair_kernel)
         NiirPairArgs pa;
         a.g = g;
@@ -2053,29 +2056,13 @@ int niir_launch_demod(const cm_am_plan *p, Geom g, int64_t first_frame, hipStrea
         if (blocks + pa.n_first <= 0) return CM_OK;
         const int lat = 2 * kAmHalf + 1 + p->nd.gb.q + p->nd.gl.q;
         if (u8) {
-            const size_t lds = sizeof(float) * (size_t)niir_pair_lds_floats<true>(lat, p->nd.gl.q, pa.n_first > 0);
+            const size_t lds = sizeof(float) * (size_t)niir_pair_lds_floats<true>(lat, p->nd.gl.q);
             hipLaunchKernelGGL(niir_demod_pair_kernel<true>, dim3((int)blocks + pa.n_first), dim3(128), lds, stream, pa);
         } else {
-            const size_t lds = sizeof(float) * (size_t)niir_pair_lds_floats<false>(lat, p->nd.gl.q, pa.n_first > 0);
+            const size_t lds = sizeof(float) * (size_t)niir_pair_lds_floats<false>(lat, p->nd.gl.q);
             hipLaunchKernelGGL(niir_demod_pair_kernel<false>, dim3((int)blocks + pa.n_first), dim3(128), lds, stream, pa);
         }
     }
-#else
-    if (u8) return fail(CM_ERR_UNSUPPORTED, "the fused uint8 boundary of the NIIR decoder lives in the wave-pair kernel");
-    if (blocks > 0) {
-        a.g = g;
-        hipLaunchKernelGGL(niir_demod_kernel<false>, dim3((int)blocks), dim3(64), 0, stream, a);
-    }
-    if (with_first) {
-        Geom s = g;
-        s.sparse = 1;
-        s.skip_first = 0;
-        s.total_calls = g.rows_mode ? 1 : (g.total_calls / g.calls_per_frame) * g.runs_per_frame;
-        const long long fb = (s.total_calls + 63) / 64;
-        a.g = s;
-        if (fb > 0) hipLaunchKernelGGL(niir_demod_kernel<true>, dim3((int)fb), dim3(64), 0, stream, a);
-    }
-#endif
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(CM_ERR_LAUNCH, std::string("niir_demod_kernel launch: ") + hipGetErrorString(e));
     return CM_OK;
@@ -2100,16 +2087,11 @@ int am_launch_demod(const cm_am_plan *p, Geom g, int64_t first_frame, hipStream_
     a.g = g;
     am_geom(p, first_frame, a.a);
     a.k = p->pd;
-#if CM_PROTO_PAIR
     {
         const int dly = ProtoDemod<float>::lat_chroma(p->pd) - ProtoDemod<float>::lat_luma(p->pd);
         if (u8) hipLaunchKernelGGL(proto_demod_pair_kernel<true>, dim3((int)blocks), dim3(128), sizeof(float) * (size_t)proto_pair_lds_floats<true>(dly), stream, a);
         else hipLaunchKernelGGL(proto_demod_pair_kernel<false>, dim3((int)blocks), dim3(128), sizeof(float) * (size_t)proto_pair_lds_floats<false>(dly), stream, a);
     }
-#else
-    if (u8) return fail(CM_ERR_UNSUPPORTED, "the fused uint8 boundary of the Proto-SECAM decoder lives in the wave-pair kernel");
-    hipLaunchKernelGGL(proto_demod_kernel, dim3((int)blocks), dim3(64), 0, stream, a);
-#endif
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(CM_ERR_LAUNCH, std::string("proto_demod_kernel launch: ") + hipGetErrorString(e));
     return CM_OK;
@@ -2157,7 +2139,6 @@ int am_launch_mod(const cm_am_plan *p, Geom g, int64_t first_frame, hipStream_t 
         am_geom(p, first_frame, a.a);
         a.k = p->pm;
         a.averaging = depth;
-#if CM_PROTO_MOD_PAIR
         {
             const int lat_y = ProtoMod<float>::lat_luma(p->pm), lat_c = ProtoMod<float>::lat_chroma(p->pm);
             const int dly = lat_y > lat_c ? lat_y - lat_c : lat_c - lat_y;
@@ -2171,11 +2152,6 @@ int am_launch_mod(const cm_am_plan *p, Geom g, int64_t first_frame, hipStream_t 
                 else hipLaunchKernelGGL((proto_mod_pair_kernel<0, false>), dim3((int)blocks), dim3(128), lds, stream, a);
             }
         }
-#else
-        if (u8) return fail(CM_ERR_UNSUPPORTED, "the fused uint8 boundary of the Proto-SECAM encoder lives in the wave-pair kernel");
-        if (depth) hipLaunchKernelGGL(proto_mod_kernel<1>, dim3((int)blocks), dim3(64), 0, stream, a);
-        else hipLaunchKernelGGL(proto_mod_kernel<0>, dim3((int)blocks), dim3(64), 0, stream, a);
-#endif
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(CM_ERR_LAUNCH, std::string("cm_am modulator launch: ") + hipGetErrorString(e));
@@ -2201,7 +2177,7 @@ int cm_am_plan_create(const cm_am_desc *desc, cm_am_plan **out) {
     }
     std::string err;
     if (desc->kind == CM_AM_NIIR) {
-        if (!build_niir_demod_k<float>(*desc, p->nd, err)) p->demod_error = err;
+        if (!build_niir_demod_k<float>(*desc, p->nd, err) || !build_niir_demod_k<double>(*desc, p->ndd, err)) p->demod_error = err;
         else if (p->nd.gl.q >= kNiirRing) p->demod_error = "decoder: the low-pass delay does not fit the band-pass ring";
         if (!build_niir_mod_k<float>(*desc, p->nm, err)) p->mod_error = err;
         else if (p->nm.s_c >= kAmRing) p->mod_error = "encoder: the pre-correction shift does not fit the luma delay ring";
@@ -2233,6 +2209,15 @@ int cm_am_plan_create(const cm_am_desc *desc, cm_am_plan **out) {
         cm_am_plan_destroy(p);
         return fail(CM_ERR_NO_DEVICE, "device allocation / upload of the carrier table failed");
     }
+    if (desc->kind == CM_AM_NIIR && p->demod_error.empty()) {
+        std::vector<double> syn;
+        if (!build_niir_syn(*desc, syn, err)) p->demod_error = err;
+        else if (hipMalloc((void **)&p->niir_syn, syn.size() * sizeof(double)) != hipSuccess ||
+                 hipMemcpy(p->niir_syn, syn.data(), syn.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) {
+            cm_am_plan_destroy(p);
+            return fail(CM_ERR_NO_DEVICE, "device allocation / upload of the NIIR reference tables failed");
+        }
+    }
     make_scan_proto(p);
     make_scan_niir(p);
     if (desc->kind == CM_AM_NIIR && (desc->flags & CM_AM_FLOAT64) && p->demod_error.empty() && !p->scan_nd64)
@@ -2243,6 +2228,7 @@ int cm_am_plan_create(const cm_am_desc *desc, cm_am_plan **out) {
 void cm_am_plan_destroy(cm_am_plan *p) {
     if (!p) return;
     if (p->carrier) (void)hipFree(p->carrier);
+    if (p->niir_syn) (void)hipFree(p->niir_syn);
     if (p->scan_pd) (void)hipFree(p->scan_pd);
     if (p->scan_pm) (void)hipFree(p->scan_pm);
     if (p->scan_nd) (void)hipFree(p->scan_nd);

@@ -102,7 +102,18 @@ CM_HD float fma3(float c, float x, float acc) {
 #endif
 }
 template <bool V>
-CM_HD double fma3(double c, double x, double acc) { return c * x + acc; }
+CM_HD double fma3(double c, double x, double acc) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    double d;
+    if (V)
+        asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(c), "v"(x), "v"(acc));
+    else
+        asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "s"(c), "v"(x), "v"(acc));
+    return d;
+#else
+    return c * x + acc;
+#endif
+}
 // keep a value in a vector register (no-op on the host)
 CM_HD void pin_vgpr(float &v) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -111,7 +122,13 @@ CM_HD void pin_vgpr(float &v) {
     (void)v;
 #endif
 }
-CM_HD void pin_vgpr(double &) {}
+CM_HD void pin_vgpr(double &v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" : "+v"(v));
+#else
+    (void)v;
+#endif
+}
 CM_HD float fmaf_(float a, float b, float c) {
 #if defined(__HIP_DEVICE_COMPILE__)
     return __builtin_fmaf(a, b, c);
@@ -119,7 +136,13 @@ CM_HD float fmaf_(float a, float b, float c) {
     return std::fma(a, b, c);
 #endif
 }
-CM_HD double fmaf_(double a, double b, double c) { return a * b + c; }
+CM_HD double fmaf_(double a, double b, double c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_fma(a, b, c);
+#else
+    return a * b + c;
+#endif
+}
 
 // ---- uniform coefficient blocks -----------------------------------------------------------
 template <typename T>

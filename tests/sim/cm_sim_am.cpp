@@ -30,7 +30,7 @@ static int proto_demod_run(const cm_am_desc &d, const double *comp, double *rgb,
         st.reset();
         for (int t = 0; t < W + lat_c; ++t) {
             T l, c;
-            st.step(k, t, t < W ? T(comp[(size_t)i * W + t]) : T(0), l, c);
+            st.step(k, t, t < W ? T(comp[(size_t)i * W + t]) : T(0), (t >= 10 && t - 10 < W) ? T(comp[(size_t)i * W + t - 10]) : T(0), l, c);
             if (t - lat_y >= 0 && t - lat_y < W) luma[i][t - lat_y] = l;
             if (t - lat_c >= 0 && t - lat_c < W) chroma[i][t - lat_c] = c;
         }
@@ -92,11 +92,12 @@ static int proto_mod_run(const cm_am_desc &d, const double *rgb, double *comp, i
         st.reset();
         for (int t = 0; t < W + lat; ++t) {
             const int i_c = t - (lat - lat_c), i_y = t - (lat - lat_y);
-            T yc, dc, yy, dy;
+            T yc, dc, yy, dy, yd, dd10;
             source(i_c, yc, dc);
             source(i_y, yy, dy);
+            source(i_y - kAmHalf, yd, dd10);
             T lo, co;
-            st.step(k, i_c, dc, i_y, yy, lo, co);
+            st.step(k, i_c, dc, i_y, yy, yd, lo, co);
             const int n = t - lat;
             if (n >= 0 && n < W) {
                 const double ph = phi + (double)n * d.carrier_phase_step;
@@ -126,7 +127,7 @@ static int niir_demod_run(const cm_am_desc &d, const double *comp, double *rgb, 
         std::vector<Tri> mh(steps);
         for (int t = 0; t < steps; ++t) {
             T m[3], sv[3];
-            f.step(k, t, t < W ? T(comp[(size_t)i * W + t]) : T(0), m, sv);
+            f.step(k, t, t < W ? T(comp[(size_t)i * W + t]) : T(0), (t >= 10 && t - 10 < W) ? T(comp[(size_t)i * W + t - 10]) : T(0), m, sv);
             for (int j = 0; j < 3; ++j) mh[t].v[j] = m[j];
             T md[3] = {T(0), T(0), T(0)};
             if (t - k.gl.q >= 0) for (int j = 0; j < 3; ++j) md[j] = mh[t - k.gl.q].v[j];
@@ -148,10 +149,11 @@ static int niir_demod_run(const cm_am_desc &d, const double *comp, double *rgb, 
             sy.reset();
             std::vector<Tri> mh(steps);
             for (int t = 0; t < steps; ++t) {
-                T x = T(0);
+                T x = T(0), xd = T(0);
                 if (t < W) x = T((palt ? -1.0 : 1.0) * std::sin(phi + (double)t * d.carrier_phase_step));
+                if (t >= 10 && t - 10 < W) xd = T((palt ? -1.0 : 1.0) * std::sin(phi + (double)(t - 10) * d.carrier_phase_step));
                 T m[3];
-                sy.step(k, t, x, m);
+                sy.step(k, t, x, xd, m);
                 for (int j = 0; j < 3; ++j) mh[t].v[j] = m[j];
                 for (int j = 0; j < 3; ++j) prev[t].v[j] = t - k.gl.q >= 0 ? k.g_b * mh[t - k.gl.q].v[j] : T(0);
             }
@@ -165,6 +167,87 @@ static int niir_demod_run(const cm_am_desc &d, const double *comp, double *rgb, 
         for (int t = 0; t < steps; ++t) {
             const int n3 = t - kAmHalf - k.gb.q - k.gl.q;
             const NiirOut<T> o = b.step(k, n3, P[i][t].v, prev[t].v, S[i][t].v, lk.alt);
+            const int n = t - lat;
+            if (n >= 0 && n < W) {
+                const Rgb<T> c = niir_finish(k, lk, o, T(comp[(size_t)i * W + n]), strip);
+                rgb[((size_t)i * 3 + 0) * W + n] = (double)c.r;
+                rgb[((size_t)i * 3 + 1) * W + n] = (double)c.g;
+                rgb[((size_t)i * 3 + 2) * W + n] = (double)c.b;
+            }
+        }
+    }
+    return CM_OK;
+}
+
+// The precision split of the device decoder (round 4; cm_am_stages.h: NiirHue): front end, phasor quotient, hue products and their two
+// decimators in TP, the saturation / re-modulation decimators and niir_finish in T.  <double, float> is what the kernels compute.
+template <typename TP, typename T>
+static int niir_demod_run_split(const cm_am_desc &d, const double *comp, double *rgb, int n_calls, long long frame, int first_line, int k0,
+                                bool strip) {
+    NiirDemodK<TP> kd;
+    NiirDemodK<T> k;
+    if (!build_niir_demod_k<TP>(d, kd, g_err) || !build_niir_demod_k<T>(d, k, g_err)) return CM_ERR_UNSUPPORTED;
+    const AmLine ln = am_line(d);
+    const int W = d.width;
+    const int lat = 2 * kAmHalf + 1 + k.gb.q + k.gl.q;
+    const int steps = W + lat;
+    struct Tri { TP v[3]; };
+    std::vector<std::vector<Tri>> P(n_calls, std::vector<Tri>(steps)), S(n_calls, std::vector<Tri>(steps));
+    auto x_at = [&](int i, int t) { return (t >= 0 && t < W) ? TP(comp[(size_t)i * W + t]) : TP(0); };
+    for (int i = 0; i < n_calls; ++i) {
+        NiirFront<TP> f;
+        f.reset();
+        std::vector<Tri> mh(steps);
+        for (int t = 0; t < steps; ++t) {
+            TP m[3], sv[3];
+            f.step(kd, t, x_at(i, t), x_at(i, t - kAmHalf), m, sv);
+            for (int j = 0; j < 3; ++j) mh[t].v[j] = m[j];
+            TP md[3] = {TP(0), TP(0), TP(0)};
+            if (t - kd.gl.q >= 0) for (int j = 0; j < 3; ++j) md[j] = mh[t - kd.gl.q].v[j];
+            TP p[3];
+            niir_phasemod(kd, t - kAmHalf - kd.gb.q - kd.gl.q, md, sv, p);
+            for (int j = 0; j < 3; ++j) { P[i][t].v[j] = p[j]; S[i][t].v[j] = sv[j]; }
+        }
+    }
+    for (int i = 0; i < n_calls; ++i) {
+        const int line = first_line + 2 * i;
+        const NiirLineK<T> lk = niir_line_k<T>(d, ln, frame, line);
+        std::vector<Tri> prev(steps);
+        if (k0 + i == 0) {          // niir.py:107-110
+            const double phi = ln.start_phase(frame, line - 2);
+            const double sg = ln.alternate(frame, line - 2) ? -1.0 : 1.0;
+            auto xs = [&](int t) { return (t >= 0 && t < W) ? TP(sg * std::sin(phi + (double)t * d.carrier_phase_step)) : TP(0); };
+            NiirSyn<TP> sy;
+            sy.reset();
+            std::vector<Tri> mh(steps);
+            for (int t = 0; t < steps; ++t) {
+                TP m[3];
+                sy.step(kd, t, xs(t), xs(t - kAmHalf), m);
+                for (int j = 0; j < 3; ++j) mh[t].v[j] = m[j];
+                for (int j = 0; j < 3; ++j) prev[t].v[j] = t - kd.gl.q >= 0 ? kd.g_b * mh[t - kd.gl.q].v[j] : TP(0);
+            }
+        } else if (i > 0) {
+            prev = P[i - 1];
+        } else {
+            for (auto &x : prev) x.v[0] = x.v[1] = x.v[2] = TP(0);
+        }
+        NiirHue<TP> hue;
+        Dn3<T> dn_sat, dn_sc, dn_cc;
+        hue.reset(); dn_sat.reset(); dn_sc.reset(); dn_cc.reset();
+        T s1[3] = {T(0), T(0), T(0)};
+        for (int t = 0; t < steps; ++t) {
+            const int n3 = t - kAmHalf - kd.gb.q - kd.gl.q;
+            TP sp, cp, car[3], acar[3];
+            hue.step(kd.taps, kd.alt_scale, W, n3, P[i][t].v, prev[t].v, lk.alt, sp, cp, car, acar);
+            T cf[3], af[3];
+            for (int j = 0; j < 3; ++j) { cf[j] = T(car[j]); af[j] = T(acar[j]); }
+            NiirOut<T> o;
+            o.sinphi = T(sp);
+            o.cosphi = T(cp);
+            o.sat = k.sat_gain * dn_sat.push(k.taps, s1);
+            o.sinc = k.third * dn_sc.push(k.taps, cf);
+            o.cosc = k.third * dn_cc.push(k.taps, af);
+            for (int j = 0; j < 3; ++j) s1[j] = T(S[i][t].v[j]);
             const int n = t - lat;
             if (n >= 0 && n < W) {
                 const Rgb<T> c = niir_finish(k, lk, o, T(comp[(size_t)i * W + n]), strip);
@@ -232,9 +315,11 @@ extern "C" int am_sim_demod_run(const cm_am_desc *d, int use_float, const double
     if (d->kind == CM_AM_PROTO_SECAM)
         return use_float ? proto_demod_run<float>(*d, comp, rgb, n_calls, frame, first_line, k0)
                          : proto_demod_run<double>(*d, comp, rgb, n_calls, frame, first_line, k0);
-    if (d->kind == CM_AM_NIIR)      // use_float bit 1: strip_chroma = False
+    if (d->kind == CM_AM_NIIR) {    // use_float bit 1: strip_chroma = False; bit 2: the device's precision split (hue path float64, the rest float32)
+        if (use_float & 4) return niir_demod_run_split<double, float>(*d, comp, rgb, n_calls, frame, first_line, k0, !(use_float & 2));
         return (use_float & 1) ? niir_demod_run<float>(*d, comp, rgb, n_calls, frame, first_line, k0, !(use_float & 2))
                                : niir_demod_run<double>(*d, comp, rgb, n_calls, frame, first_line, k0, !(use_float & 2));
+    }
     g_err = "kind not simulated";
     return CM_ERR_UNSUPPORTED;
 }
