@@ -3,9 +3,10 @@
 /root/reference/color_modem/color/niir.py:10-202).
 
 Host side: constructor arguments, colour matrices and the three filter designs (the same scipy calls as the reference).
-The per-line work runs in ``niir_demod_kernel`` / ``niir_mod_kernel`` (csrc/cm_am_kernels.h) behind ``cm_am_*``.
-``noise_level`` other than 0 draws from numpy.random in the reference (niir.py:45-46, 189-191): a result that cannot be
-reproduced; only ``noise_level=0.0`` is built.
+The per-line work runs in ``niir_demod_pair_kernel`` / ``niir_mod_kernel`` (csrc/cm_am_kernels.h; small batches: the scan
+kernels of csrc/cm_am_scan_kernels.h) behind ``cm_am_*``; the decoder's hue path is float64 (csrc/cm_am_stages.h: NiirHue).
+``noise_level`` other than 0 draws from numpy.random in the reference (niir.py:45-46, 189-191): the engine draws the same samples
+in the reference's call order and hands them to the kernel as a plane, so ``numpy.random.seed`` reproduces the reference.
 """
 
 import numpy

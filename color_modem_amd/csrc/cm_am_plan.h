@@ -103,14 +103,17 @@ bool build_niir_demod_k(const cm_am_desc &d, NiirDemodK<T> &k, std::string &err)
 
 // The phase reference of the first line of a run (niir.py:107-110): _demodulate_upsampled_filter(resample_poly(+-sin(phi + n step), 3, 1)).
 // The chain is linear - FilterFunction's tail padding too - and +-sin(phi + n step) = +-(sin(phi) cos(n step) + cos(phi) sin(n step)), so the
-// reference of ANY line is +-(sin(phi) R_c + cos(phi) R_s) with two sequences of the plan: out = [R_c | R_s], 3 W samples each, float64.
+// reference of ANY line is +-(sin(phi) R_c + cos(phi) R_s) with two sequences of the plan, and so are the two decimations the decoder takes of it
+// where it is the carrier (niir.py:145-146): D = Dn3(R), A = Dn3(altcarrier(R)) (taps 3 h, as the kernels' decimators).
+// out = [R_c | R_s] 3 W samples each, then [D_c | D_s | A_c | A_s] W each; float64.
 inline bool build_niir_syn(const cm_am_desc &d, std::vector<double> &out, std::string &err) {
     NiirDemodK<double> k;
     if (!build_niir_demod_k<double>(d, k, err)) return false;
     const int W = d.width, L = 3 * W;
-    out.assign(2 * (size_t)L, 0.0);
+    out.assign(10 * (size_t)W, 0.0);
     for (int which = 0; which < 2; ++which) {
         auto x = [&](int t) { return (t < 0 || t >= W) ? 0.0 : (which ? std::sin((double)t * d.carrier_phase_step) : std::cos((double)t * d.carrier_phase_step)); };
+        double *R = out.data() + (size_t)which * L;
         NiirSyn<double> sy;
         sy.reset();
         for (int t = 0; t < W + kAmHalf + k.gb.q; ++t) {
@@ -119,8 +122,20 @@ inline bool build_niir_syn(const cm_am_desc &d, std::vector<double> &out, std::s
             const int n2 = t - kAmHalf - k.gb.q;
             for (int j = 0; j < 3; ++j) {
                 const int q = 3 * n2 + j;
-                if (q >= 0 && q < L) out[(size_t)which * L + q] = k.g_b * m[j];
+                if (q >= 0 && q < L) R[q] = k.g_b * m[j];
             }
+        }
+        auto r_at = [&](int q) { return (q >= 0 && q < L) ? R[q] : 0.0; };
+        auto a_at = [&](int q) { return (q >= 1 && q <= L - 2) ? k.alt_scale * (r_at(q + 1) - r_at(q - 1)) : 0.0; };     // niir.py:126-129
+        double *D = out.data() + 2 * (size_t)L + (size_t)which * W, *A = D + 2 * (size_t)W;
+        for (int n = 0; n < W; ++n) {
+            double sd = 0.0, sa = 0.0;
+            for (int i = 0; i < kAmTaps; ++i) {
+                sd += k.taps.h[i] * r_at(3 * n + 30 - i);
+                sa += k.taps.h[i] * a_at(3 * n + 30 - i);
+            }
+            D[n] = sd;
+            A[n] = sa;
         }
     }
     return true;

@@ -389,21 +389,20 @@ struct ScanNiirK {
     float m[9];
 };
 typedef const __attribute__((address_space(4))) ScanNiirK const_ScanNiirK;
-// F64 (cm_am_desc.flags & CM_AM_FLOAT64): the decoder's 3x-rate front end - interpolator, band-pass, low-pass - in float64.  In float32
-// its rounding is divided by the length of a decimated product pair further down (niir.py:131-137): on random pictures 40 % of the
-// frames have isolated samples beyond 1e-5 of full scale; the host simulator of the stage code names the front end as the place where
-// the precision goes (interpolator + both recursive filters in float64: 0 of 3.5e6 samples beyond 2.7e-6; any one of them in float32:
-// violations again; the division and everything behind it may stay in float32 - profiles/r03_niir_precision.txt).
+// The decoder's HUE PATH IS FLOAT64 (round 4; cm_am_stages.h: NiirHue has the reasons): interpolator, band-pass, low-pass, the quotient
+// M / S, the hue products and the decimators that read them.  The saturation and niir_finish stay float32.
 struct ScanNiirK64 {
     double h[kAmTaps + 3];
     ScanFilterD bp, lp;
+    double c_pm, alt_scale;
 };
 typedef const __attribute__((address_space(4))) ScanNiirK64 const_ScanNiirK64;
 typedef const __attribute__((address_space(4))) double const_double;
 typedef __attribute__((address_space(3))) double lds_double;
-template <int C1, bool F64 = false> constexpr int scan_niir_wave_floats() { return (F64 ? 13 : 10) * (64 * C1 + 2 * kScanMargin); }
+// rows of a wave, in floats: the row x | M, then P (phasemod_up) as three phase rows of doubles | S, then the hue products as three rows of doubles
+template <int C1> constexpr int scan_niir_wave_floats() { return 13 * (64 * C1 + 2 * kScanMargin); }
 
-template <int C1, bool SPARSE>
+template <int C1>
 __device__ __forceinline__ void scan_up3_d(const lds_float *X, int n0, const_double *h, double (&u)[3 * C1]) {
     double w[C1 + 24];             // w[k] = x[n0 - 12 + k]
 #pragma unroll
@@ -412,12 +411,9 @@ __device__ __forceinline__ void scan_up3_d(const lds_float *X, int n0, const_dou
         w[4 * q] = (double)t.x; w[4 * q + 1] = (double)t.y; w[4 * q + 2] = (double)t.z; w[4 * q + 3] = (double)t.w;
     }
 #pragma unroll
-    for (int j = 0; j < 3; ++j) {
-        if (SPARSE && j == 0) {
+    for (int i = 0; i < C1; ++i) u[3 * i] = h[30] * w[i + 12];          // third-band taps: phase 0 is the centre tap alone
 #pragma unroll
-            for (int i = 0; i < C1; ++i) u[3 * i] = h[30] * w[i + 12];
-            continue;
-        }
+    for (int j = 1; j < 3; ++j) {
         double acc[C1];
 #pragma unroll
         for (int i = 0; i < C1; ++i) acc[i] = 0.0;
@@ -437,6 +433,31 @@ __device__ __forceinline__ double scan_up3_last_d(const lds_float *X, int W, con
     for (int q = 0; 3 * q + 2 < kAmTaps; ++q) acc = fmaf_(h[3 * q + 2], (double)X[W - 1 + 10 - q], acc);
     return acc;
 }
+// scan_dn3 on phase rows of doubles (third-band taps: of row 0 the centre tap alone)
+template <int C1>
+__device__ __forceinline__ void scan_dn3_d(const lds_double *R0, const lds_double *R1, const lds_double *R2, int n0, const_double *h, double (&y)[C1]) {
+    double w[C1 + 22];             // w[k] = R[n0 - 11 + k]
+    auto window = [&](const lds_double *R) __attribute__((always_inline)) {
+#pragma unroll
+        for (int q = 0; q < C1 + 22; ++q) w[q] = R[n0 - 11 + q];
+    };
+#pragma unroll
+    for (int i = 0; i < C1; ++i) y[i] = h[30] * R0[n0 + i];
+    window(R2);
+#pragma unroll
+    for (int q = 0; 3 * q + 1 < kAmTaps; ++q) {
+        const double t = h[3 * q + 1];
+#pragma unroll
+        for (int i = 0; i < C1; ++i) y[i] = fmaf_(t, w[i + 20 - q], y[i]);
+    }
+    window(R1);
+#pragma unroll
+    for (int q = 0; 3 * q + 2 < kAmTaps; ++q) {
+        const double t = h[3 * q + 2];
+#pragma unroll
+        for (int i = 0; i < C1; ++i) y[i] = fmaf_(t, w[i + 20 - q], y[i]);
+    }
+}
 template <int C1, int R>
 __device__ __forceinline__ void scan_put3_d_r(lds_double *R0, lds_double *R1, lds_double *R2, const double (&v)[3 * C1], int base) {
 #pragma unroll
@@ -446,14 +467,18 @@ __device__ __forceinline__ void scan_put3_d_r(lds_double *R0, lds_double *R1, ld
     }
 }
 template <int C1>
+__device__ __forceinline__ void scan_margins_d(lds_double *R0, lds_double *R1, lds_double *R2, int len, int lane) {
+    R0[lane - kScanMargin] = 0.0; R1[lane - kScanMargin] = 0.0; R2[lane - kScanMargin] = 0.0;
+    R0[len + lane] = 0.0; R1[len + lane] = 0.0; R2[len + lane] = 0.0;
+    scan_fence();
+}
+template <int C1>
 __device__ __forceinline__ void scan_put3_d(lds_double *R0, lds_double *R1, lds_double *R2, const double (&v)[3 * C1], int n0, int shift, int len, int lane) {
     const int q = (shift + 2) / 3, r = 3 * q - shift;
     if (r == 0) scan_put3_d_r<C1, 0>(R0, R1, R2, v, n0 - q);
     else if (r == 1) scan_put3_d_r<C1, 1>(R0, R1, R2, v, n0 - q);
     else scan_put3_d_r<C1, 2>(R0, R1, R2, v, n0 - q);
-    R0[lane - kScanMargin] = 0.0; R1[lane - kScanMargin] = 0.0; R2[lane - kScanMargin] = 0.0;
-    R0[len + lane] = 0.0; R1[len + lane] = 0.0; R2[len + lane] = 0.0;
-    scan_fence();
+    scan_margins_d<C1>(R0, R1, R2, len, lane);
 }
 template <int C1>
 __device__ __forceinline__ void scan_get3_d(const lds_double *R0, const lds_double *R1, const lds_double *R2, int n0, double (&v)[3 * C1]) {
@@ -465,28 +490,29 @@ __device__ __forceinline__ void scan_get3_d(const lds_double *R0, const lds_doub
     }
 }
 
-template <int C1, int NW, bool U8 = false, bool F64 = false>
+// syn: the plan's float64 tables of the first lines' phase reference (cm_am_plan.h: build_niir_syn): [R_c | R_s] 3 W each, then
+// [D_c | D_s | A_c | A_s] W each - the reference, its decimation and the decimation of its derivative for cos / sin(n step); the reference of a
+// line is linear in (sin, cos) of its start phase, so a first line needs no second front end and no rows of its own.
+template <int C1, int NW, bool U8 = false>
 __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2))) void niir_demod_scan_kernel(const Geom g, const AmGeom am, const ScanNiirK *km,
-                                                                                                            const ScanNiirK64 *km64, double line_phase_shift,
-                                                                                                            double bandpass_phase_shift, int strip_i) {
+                                                                                                            const ScanNiirK64 *km64, const double *syn,
+                                                                                                            double line_phase_shift, double bandpass_phase_shift,
+                                                                                                            int strip_i) {
     constexpr int C3 = 3 * C1, N1 = 64 * C1, MG = kScanMargin, kRow = N1 + 2 * MG;
     extern __shared__ __attribute__((aligned(16))) float scan_lds[];
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
     const_ScanNiirK &k = *(const_ScanNiirK *)km;
+    const_ScanNiirK64 &k64 = *(const_ScanNiirK64 *)km64;
     const long long c = (long long)blockIdx.x * (NW - 1) - 1 + w;
     const LaneCall lc = locate_call_at(g, c, w >= 1);
     const bool alive = c >= 0 && c < g.total_calls;
-    lds_float *wave = (lds_float *)scan_lds + w * scan_niir_wave_floats<C1, F64>();
-    lds_float *X = wave + MG, *P0 = X + kRow, *P1 = P0 + kRow, *P2 = P1 + kRow, *S0 = P2 + kRow, *S1 = S0 + kRow, *S2 = S1 + kRow,
-              *T0 = S2 + kRow, *T1 = T0 + kRow, *T2 = T1 + kRow;
-    // F64: M and S as three rows of doubles each, in the place of (P, S) and of (T + three more rows); the float rows P, S are written
-    // when every lane has its own chunk of both in registers
-    lds_double *DM0 = (lds_double *)(P0 - MG) + MG, *DM1 = DM0 + kRow, *DM2 = DM1 + kRow;
-    lds_double *DS0 = (lds_double *)(T0 - MG) + MG, *DS1 = DS0 + kRow, *DS2 = DS1 + kRow;
+    lds_float *wave = (lds_float *)scan_lds + w * scan_niir_wave_floats<C1>();
+    lds_float *X = wave + MG;
+    lds_double *PD0 = (lds_double *)(wave + kRow) + MG, *PD1 = PD0 + kRow, *PD2 = PD1 + kRow;        // M, then P = phasemod_up
+    lds_double *QD0 = (lds_double *)(wave + 7 * kRow) + MG, *QD1 = QD0 + kRow, *QD2 = QD1 + kRow;    // S, later the hue products
     const int W = g.W, L = 3 * W;
     const int n0 = lane * C1, m0 = 3 * n0;
-    const bool sparse = k.sparse_taps != 0;
     const bool first = __builtin_amdgcn_readfirstlane(lc.kk) == 0;     // the first line of a run: its phase reference is synthetic
     // ---- the row ------------------------------------------------------------------------------------------------------------
     float xr[C1];
@@ -511,103 +537,34 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
         scan_fence();
     }
     {
-        float v[C3];
-        if constexpr (F64) {
-            const_ScanNiirK64 &k64 = *(const_ScanNiirK64 *)km64;
-            double d[C3], mm[C3];
-            if (sparse) scan_up3_d<C1, true>(X, n0, k64.h, d);
-            else scan_up3_d<C1, false>(X, n0, k64.h, d);
-            const double u_last = scan_up3_last_d(X, W, k64.h);
+        // ---- M = band-pass of the interpolated row; S = low-pass of |M| (niir.py:111-114); phasemod_up = c_pm M / S inside the row --------
+        double d[C3];
+        scan_up3_d<C1>(X, n0, k64.h, d);
+        const double u_last = scan_up3_last_d(X, W, k64.h);
 #pragma unroll
-            for (int i = 0; i < C3; ++i) d[i] = m0 + i >= L ? u_last : d[i];
-            scan_iir_d<C3>(d, k64.bp, lane);
-            scan_put3_d<C1>(DM0, DM1, DM2, d, n0, k64.bp.shift, W, lane);
-            scan_get3_d<C1>(DM0, DM1, DM2, n0, mm);
-            {
-                const double a_last = __builtin_fabs(DM2[W - 1]);
-#pragma unroll
-                for (int i = 0; i < C3; ++i) d[i] = m0 + i >= L ? a_last : __builtin_fabs(mm[i]);
-            }
-            scan_iir_d<C3>(d, k64.lp, lane);
-            scan_put3_d<C1>(DS0, DS1, DS2, d, n0, k64.lp.shift, W, lane);
-            scan_get3_d<C1>(DS0, DS1, DS2, n0, d);
-            float sf[C3];
-#pragma unroll
-            for (int i = 0; i < C3; ++i) {
-                sf[i] = m0 + i < L ? (float)d[i] : 0.f;
-                v[i] = m0 + i < L ? am_div(k.c_pm * (float)mm[i], sf[i]) : 0.f;
-            }
-            scan_put3<C1>(P0, P1, P2, v, n0, 0, W, lane);
-            scan_put3<C1>(S0, S1, S2, sf, n0, 0, W, lane);
-        } else {
-        // ---- M = band-pass of the interpolated row; S = low-pass of |M| (niir.py:111-114) ------------------------------------
-        if (sparse) scan_up3<C1, true>(X, n0, k.h, v);
-        else scan_up3<C1, false>(X, n0, k.h, v);
-        const float u_last = scan_up3_last(X, W, k.h);
-#pragma unroll
-        for (int i = 0; i < C3; ++i) v[i] = m0 + i >= L ? u_last : v[i];
-        scan_iir<C3>(v, k.bp, lane);
-        scan_put3<C1>(P0, P1, P2, v, n0, k.bp.shift, W, lane);
-        float mm[C3];
-        scan_get3<C1>(P0, P1, P2, n0, mm);
+        for (int i = 0; i < C3; ++i) d[i] = m0 + i >= L ? u_last : d[i];
+        scan_iir_d<C3>(d, k64.bp, lane);
+        scan_put3_d<C1>(PD0, PD1, PD2, d, n0, k64.bp.shift, W, lane);
+        scan_get3_d<C1>(PD0, PD1, PD2, n0, d);
         {
-            const float a_last = __builtin_fabsf(P2[W - 1]);
+            const double a_last = __builtin_fabs(PD2[W - 1]);
 #pragma unroll
-            for (int i = 0; i < C3; ++i) v[i] = m0 + i >= L ? a_last : __builtin_fabsf(mm[i]);
+            for (int i = 0; i < C3; ++i) d[i] = m0 + i >= L ? a_last : __builtin_fabs(d[i]);
         }
-        scan_iir<C3>(v, k.lp, lane);
-        scan_put3<C1>(S0, S1, S2, v, n0, k.lp.shift, W, lane);
-        // ---- phasemod_up = c_pm M / S inside the row, zero outside (niir_phasemod) ----------------------------------------------
-        scan_get3<C1>(S0, S1, S2, n0, v);
+        scan_iir_d<C3>(d, k64.lp, lane);
+        scan_put3_d<C1>(QD0, QD1, QD2, d, n0, k64.lp.shift, W, lane);
+        // P over M, a lane's own samples in place (M and S come back out of the rows: nothing of the chunk stays in registers)
 #pragma unroll
-        for (int i = 0; i < C3; ++i) mm[i] = m0 + i < L ? am_div(k.c_pm * mm[i], v[i]) : 0.f;
-        scan_put3<C1>(P0, P1, P2, mm, n0, 0, W, lane);
+        for (int i = 0; i < C3; ++i) {
+            lds_double *pr = (i % 3 == 0 ? PD0 : (i % 3 == 1 ? PD1 : PD2)) + n0 + i / 3;
+            const lds_double *sr = (i % 3 == 0 ? QD0 : (i % 3 == 1 ? QD1 : QD2)) + n0 + i / 3;
+            *pr = m0 + i < L ? am_div(k64.c_pm * *pr, *sr) : 0.0;
         }
-        // ---- the synthetic reference of a run's first line: g_b * band-pass of +-sin(phi + n step) (NiirSyn) ---------------------
-        if (first && w >= 1) {
-            const long long frame = (long long)am.frame_base + lc.frame;
-            const double phi = am.line.start_phase(frame, lc.line - 2);
-            const float sg = am.line.alternate(frame, lc.line - 2) ? -1.f : 1.f;
-            const float syn_s = sg * (float)sin(phi), syn_c = sg * (float)cos(phi);
-#pragma unroll
-            for (int q = 0; q < C1 / 4; ++q) {
-                f4 t;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int n = n0 + 4 * q + e;
-                    const f2 cs = ((const_f2 *)am.carrier)[n < W ? n : W - 1];
-                    t[e] = n < W ? fmaf_(syn_s, cs.x, syn_c * cs.y) : 0.f;
-                }
-                *(lds_f4 *)(X + n0 + 4 * q) = t;
-            }
-            scan_fence();
-            if constexpr (F64) {
-                const_ScanNiirK64 &k64 = *(const_ScanNiirK64 *)km64;
-                double d[C3];
-                if (sparse) scan_up3_d<C1, true>(X, n0, k64.h, d);
-                else scan_up3_d<C1, false>(X, n0, k64.h, d);
-                const double s_last = scan_up3_last_d(X, W, k64.h);
-#pragma unroll
-                for (int i = 0; i < C3; ++i) d[i] = m0 + i >= L ? s_last : d[i];
-                scan_iir_d<C3>(d, k64.bp, lane);
-#pragma unroll
-                for (int i = 0; i < C3; ++i) v[i] = (float)(d[i] * (double)k.g_b);
-            } else {
-                if (sparse) scan_up3<C1, true>(X, n0, k.h, v);
-                else scan_up3<C1, false>(X, n0, k.h, v);
-                const float s_last = scan_up3_last(X, W, k.h);
-#pragma unroll
-                for (int i = 0; i < C3; ++i) v[i] = m0 + i >= L ? s_last : v[i];
-                scan_iir<C3>(v, k.bp, lane);
-#pragma unroll
-                for (int i = 0; i < C3; ++i) v[i] *= k.g_b;
-            }
-            scan_put3<C1>(T0, T1, T2, v, n0, k.bp.shift, W, lane);
-        }
+        scan_fence();
     }
     __syncthreads();
     if (w < 1 || !alive || !lc.store_ok) return;
-    // ---- back end (NiirBack::step) ----------------------------------------------------------------------------------------------
+    // ---- back end (NiirHue::step + the re-modulation decimators) ------------------------------------------------------------------
     const long long frame = (long long)am.frame_base + lc.frame;
     const bool alt = am.line.alternate(frame, lc.line);
     float sin_shift, cos_shift, sin_ps, cos_ps;
@@ -617,42 +574,80 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
         sin_shift = (float)sin(shift); cos_shift = (float)cos(shift);
         sin_ps = (float)sin(ps); cos_ps = (float)cos(ps);
     }
-    const lds_float *V0 = first ? T0 : P0 - scan_niir_wave_floats<C1, F64>(), *V1 = V0 + kRow, *V2 = V1 + kRow;    // the previous call's phasemod_up
-    const lds_float *CR0 = alt ? P0 : V0, *CR1 = CR0 + kRow, *CR2 = CR1 + kRow;      // carrier_up (niir.py:117-124)
-    const lds_float *HR0 = alt ? V0 : P0, *HR1 = HR0 + kRow, *HR2 = HR1 + kRow;      // the hue-modulated signal
-    float sinc[C1], sat[C1], sinphi[C1], cosphi[C1], cosc[C1];
-    if (sparse) {
-        scan_dn3<C1, true>(CR0, CR1, CR2, n0, k.h, sinc);
-        scan_dn3<C1, true>(S0, S1, S2, n0, k.h, sat);
-    } else {
-        scan_dn3<C1, false>(CR0, CR1, CR2, n0, k.h, sinc);
-        scan_dn3<C1, false>(S0, S1, S2, n0, k.h, sat);
+    double syn_s = 0.0, syn_c = 0.0;          // the reference of a first line: syn_s R_c + syn_c R_s
+    if (first) {
+        const double phi = am.line.start_phase(frame, lc.line - 2);
+        const double sg = am.line.alternate(frame, lc.line - 2) ? -1.0 : 1.0;
+        syn_s = sg * sin(phi);
+        syn_c = sg * cos(phi);
     }
-    {
-        float cc[C3], hh[C3], t[C3];
-        scan_get3<C1>(CR0, CR1, CR2, n0, cc);
-        scan_get3<C1>(HR0, HR1, HR2, n0, hh);
-        const float c_before = CR2[n0 - 1], c_after = CR0[n0 + C1];
-        auto ac = [&](int i) __attribute__((always_inline)) {               // altcarrier_up[p], p = m0 + i (niir.py:126-129)
-            const int p = m0 + i;
-            const float before = i == 0 ? c_before : cc[i > 0 ? i - 1 : 0], after = i == C3 - 1 ? c_after : cc[i < C3 - 1 ? i + 1 : 0];
-            return (p >= 1 && p <= L - 2) ? k.alt_scale * (after - before) : 0.f;
-        };
+    const lds_double *VD0 = PD0 - scan_niir_wave_floats<C1>() / 2, *VD1 = VD0 + kRow, *VD2 = VD1 + kRow;      // the previous call's phasemod_up
+    // sample m of the previous call's phasor / of this call's
+    auto prev_at = [&](int m) __attribute__((always_inline)) -> double {
+        if (first) return (m >= 0 && m < L) ? fmaf_(syn_s, syn[m], syn_c * syn[L + m]) : 0.0;
+        const int i = m >= 0 ? m / 3 : -1, j = m - 3 * i;
+        return (j == 0 ? VD0 : (j == 1 ? VD1 : VD2))[i];
+    };
+    auto own_at = [&](int m) __attribute__((always_inline)) -> double {
+        const int i = m >= 0 ? m / 3 : -1, j = m - 3 * i;
+        return (j == 0 ? PD0 : (j == 1 ? PD1 : PD2))[i];
+    };
+    auto car_at = [&](int m) __attribute__((always_inline)) -> double { return alt ? own_at(m) : prev_at(m); };      // carrier_up (niir.py:117-124)
+    auto hue_at = [&](int m) __attribute__((always_inline)) -> double { return alt ? prev_at(m) : own_at(m); };      // the hue-modulated signal
+    float sinc[C1], sat[C1], sinphi[C1], cosphi[C1], cosc[C1];
+    const bool car_syn = first && !alt;        // the carrier is the synthetic reference: its decimations are tables of the plan
+    if (car_syn) {
+        const double *Dc = syn + 2 * (size_t)L, *Ds = Dc + W, *Ac = Ds + W, *As = Ac + W;
 #pragma unroll
-        for (int i = 0; i < C3; ++i) t[i] = hh[i] * cc[i];                  // niir.py:131
-        scan_put3<C1>(T0, T1, T2, t, n0, 0, W, lane);
-        if (sparse) scan_dn3<C1, true>(T0, T1, T2, n0, k.h, sinphi);
-        else scan_dn3<C1, false>(T0, T1, T2, n0, k.h, sinphi);
+        for (int i = 0; i < C1; ++i) {
+            const int n = n0 + i < W ? n0 + i : W - 1;
+            sinc[i] = (float)fmaf_(syn_s, Dc[n], syn_c * Ds[n]);
+            cosc[i] = (float)fmaf_(syn_s, Ac[n], syn_c * As[n]);
+        }
+    }
+    // Five decimations - saturation (S), sincarrier (the carrier's rows), then three signals that are formed into the rows S leaves free:
+    // sinphi (hue x carrier), cosphi (hue x the carrier's derivative), coscarrier (the derivative; niir.py:126-146) - as ONE loop around one
+    // decimator (inlined five times the kernel outgrows the instruction cache: 215 instead of ~100 us per frame)
+#pragma unroll 1
+    for (int r = 0; r < 5; ++r) {
+        if (car_syn && (r == 1 || r == 4)) continue;
+        const lds_double *R0 = r == 1 ? (alt ? PD0 : VD0) : QD0;
+        if (r >= 2) {
+            scan_fence();                            // the rows' last readers are done
+#pragma unroll 1
+            for (int ii = 0; ii < C1; ++ii) {
+                double cb = car_at(m0 + 3 * ii - 1), cm = car_at(m0 + 3 * ii);
 #pragma unroll
-        for (int i = 0; i < C3; ++i) t[i] = hh[i] * ac(i);                  // niir.py:132
-        scan_put3<C1>(T0, T1, T2, t, n0, 0, W, lane);
-        if (sparse) scan_dn3<C1, true>(T0, T1, T2, n0, k.h, cosphi);
-        else scan_dn3<C1, false>(T0, T1, T2, n0, k.h, cosphi);
+                for (int j = 0; j < 3; ++j) {
+                    const int p = m0 + 3 * ii + j;
+                    const double ca = car_at(p + 1);
+                    const double ac = (p >= 1 && p <= L - 2) ? k64.alt_scale * (ca - cb) : 0.0;       // the carrier's derivative needs its neighbours
+                    const double hh = r == 4 ? 1.0 : hue_at(p);
+                    (j == 0 ? QD0 : (j == 1 ? QD1 : QD2))[n0 + ii] = hh * (r == 2 ? cm : ac);
+                    cb = cm;
+                    cm = ca;
+                }
+            }
+            scan_margins_d<C1>(QD0, QD1, QD2, W, lane);
+        }
+        double y[C1];
+        scan_dn3_d<C1>(R0, R0 + kRow, R0 + 2 * kRow, n0, k64.h, y);
+        if (r == 0) {
 #pragma unroll
-        for (int i = 0; i < C3; ++i) t[i] = ac(i);
-        scan_put3<C1>(T0, T1, T2, t, n0, 0, W, lane);
-        if (sparse) scan_dn3<C1, true>(T0, T1, T2, n0, k.h, cosc);
-        else scan_dn3<C1, false>(T0, T1, T2, n0, k.h, cosc);
+            for (int i = 0; i < C1; ++i) sat[i] = (float)y[i];
+        } else if (r == 1) {
+#pragma unroll
+            for (int i = 0; i < C1; ++i) sinc[i] = (float)y[i];
+        } else if (r == 2) {
+#pragma unroll
+            for (int i = 0; i < C1; ++i) sinphi[i] = (float)y[i];
+        } else if (r == 3) {
+#pragma unroll
+            for (int i = 0; i < C1; ++i) cosphi[i] = (float)y[i];
+        } else {
+#pragma unroll
+            for (int i = 0; i < C1; ++i) cosc[i] = (float)y[i];
+        }
     }
     // ---- niir_finish: niir.py:134-163, 63-67, 52-61 -------------------------------------------------------------------------------
     const bool strip = strip_i != 0;

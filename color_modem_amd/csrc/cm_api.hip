@@ -9,14 +9,16 @@
 #include <string>
 #include <vector>
 
-// CM_PART: this file compiles as one translation unit (0, the default) or as two that __graft_entry__.build() compiles side by side and
-// links into the one library - 1: everything but the cm_am_* entry points, 2: the cm_am_* entry points (Proto-SECAM / NIIR: a third of
-// the device code).  The helpers at the top are in both parts; the process-wide state (last error, pointer check) lives in part 1.
+// CM_PART: this file compiles as one translation unit (0, the default) or as three that __graft_entry__.build() compiles side by side and
+// links into the one library - 1: the QAM / SECAM / MAC / wrapped-comb entry points and their streaming kernels, 2: the cm_am_* entry points
+// (Proto-SECAM / NIIR, streaming and scan kernels), 3: the row-parallel scan kernels of part 1's families behind five launch functions
+// (cm_host::scan_launch_*).  The helpers at the top are in every part; the process-wide state (last error, pointer check) lives in part 1.
 #ifndef CM_PART
 #define CM_PART 0
 #endif
-#define CM_MAIN_PART (CM_PART != 2)
-#define CM_AM_PART (CM_PART != 1)
+#define CM_MAIN_PART (CM_PART == 0 || CM_PART == 1)
+#define CM_AM_PART (CM_PART == 0 || CM_PART == 2)
+#define CM_SCAN_PART (CM_PART == 0 || CM_PART == 3)
 
 #include "../../include/color_modem_hip.h"
 #include "cm_kernels.h"
@@ -36,8 +38,8 @@
 #if CM_AM_PART
 #include "cm_am_scan_kernels.h"
 #endif
-#if CM_MAIN_PART
-#include "cm_blk_kernels.h"
+#if CM_MAIN_PART && defined(CM_EXPERIMENTS)
+#include "cm_blk_kernels.h"      // the time-blocked decoder with the FIRs on the matrix pipe (round 2's experiment)
 #endif
 #if CM_AM_PART
 #include "cm_am_plan.h"
@@ -52,13 +54,20 @@ constexpr int kModAnyShift = 12;   // luma delay window of the run-time-shape mo
 using namespace cm;
 
 namespace cm_host {      // process-wide state shared by the parts
-#if CM_PART == 2
+#if CM_PART >= 2
 extern thread_local std::string g_error;
 extern bool g_pointer_check;
 #else
 thread_local std::string g_error;
 bool g_pointer_check = true;
 #endif
+// the scan kernels of the QAM / SECAM families (CM_PART 3): c1 = samples per lane, the constants are device pointers of the plan
+int scan_launch_demod(int c1, bool u8, int device, const ScanK *km, const ScanK *kf, int depth, const Geom &gm, const Geom &gf, bool with_first,
+                      hipStream_t stream);
+int scan_launch_qam_mod(int c1, bool u8, int device, const ScanModK *k, const Geom &g, hipStream_t stream);
+int scan_launch_secam_mod(int c1, bool u8, int device, const ScanSecamModK *k, const Geom &g, hipStream_t stream);
+int scan_launch_secam_demod(int c1, bool u8, int device, const ScanSecamK *k, const Geom &g, hipStream_t stream);
+int scan_launch_wrap_back(int c1, bool u8, int device, const ScanModK *k, const ScanWrapArgs &a, const Geom &g, hipStream_t stream);
 }  // namespace cm_host
 using cm_host::g_error;
 using cm_host::g_pointer_check;
@@ -154,6 +163,7 @@ int launch_demod(const Geom &gm, const void *km, const Geom &gf, const void *kf,
     return CM_OK;
 }
 
+#ifdef CM_EXPERIMENTS
 // The blocked decoder (cm_blk_kernels.h) for the main pass; the plain first-line workgroups stay on the wave-pair kernel
 // (launched with an empty main pass).
 template <class Main, class First, int QE, int QL>
@@ -199,6 +209,8 @@ inline bool build_blk_tiles(const cm_plan_desc &d, void **out) {
     if (hipMalloc(out, t.size() * sizeof(_Float16)) != hipSuccess) return false;
     return hipMemcpy(*out, t.data(), t.size() * sizeof(_Float16), hipMemcpyHostToDevice) == hipSuccess;
 }
+
+#endif  // CM_EXPERIMENTS
 
 struct Pass {
     std::vector<unsigned char> k;  // DemodK<float, S> blob
@@ -311,8 +323,9 @@ bool make_passes(cm_plan *p, const cm_plan_desc &d, bool pald, bool bsf, bool fi
 }
 
 
-// The blocked decoder (cm_blk_kernels.h) replaces the wave pair for the PAL-D front end of an even-shift tuned shape when
-// CM_BLK is set in the environment at plan creation (A/B against the streaming kernel; see DESIGN.md for what it measures).
+// The blocked decoder (cm_blk_kernels.h: round 2's experiment with the FIRs on the matrix pipe) replaces the wave pair
+// for the PAL-D front end of an even-shift tuned shape - in -DCM_EXPERIMENTS builds only, when CM_BLK is set in the environment at plan creation.
+#ifdef CM_EXPERIMENTS
 template <class S, class First>
 bool maybe_select_blk(cm_plan *p, const cm_plan_desc &d) {
     if constexpr (!S::ODD_E && !S::ODD_L && !S::RT) {
@@ -327,6 +340,10 @@ bool maybe_select_blk(cm_plan *p, const cm_plan_desc &d) {
     }
     return false;
 }
+#else
+template <class S, class First>
+bool maybe_select_blk(cm_plan *, const cm_plan_desc &) { return false; }
+#endif
 
 // Kernel instances of one filter-set shape S.  HAS_PALD / HAS_D1: whether the PAL-D front end and the one-line
 // comb behind the QAM front end (NTSC comb) exist for this shape.  The notch variants are float-only.
@@ -981,16 +998,6 @@ void make_scan_secam_mod(cm_plan *p, const cm_plan_desc &d) {
     }
     p->scan_smod_c1 = c1;
 }
-template <int C1, int NW, bool U8>
-int launch_scan_secam_mod(const cm_plan *p, const Geom &g, hipStream_t stream) {
-    const size_t lds = sizeof(float) * (size_t)NW * scan_secam_mod_wave_floats<C1>();
-    if (int rc = allow_dynamic_lds((const void *)secam_mod_scan_kernel<C1, NW, U8>, p->device, lds, "the SECAM modulator's scan kernel")) return rc;
-    const long long blocks = (g.total_calls + NW - 1) / NW;
-    hipLaunchKernelGGL((secam_mod_scan_kernel<C1, NW, U8>), dim3((int)blocks), dim3(64 * NW), lds, stream, g, p->scan_smod);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return fail(CM_ERR_LAUNCH, std::string("secam_mod_scan_kernel launch: ") + hipGetErrorString(e));
-    return CM_OK;
-}
 // the SECAM decoder's scan constants: band-pass + bell in float64 (SecamBp64's sections), the rest as the streaming kernel has it
 void make_scan_secam_demod(cm_plan *p, const cm_plan_desc &d) {
     const cm_secam_desc &sd = d.secam;
@@ -1024,53 +1031,17 @@ void make_scan_secam_demod(cm_plan *p, const cm_plan_desc &d) {
     }
     p->scan_sdem_c1 = c1;
 }
-template <int C1, int NW, bool U8>
-int launch_scan_secam_demod(const cm_plan *p, const Geom &g, hipStream_t stream) {
-    const size_t lds = sizeof(float) * (size_t)NW * scan_secam_wave_floats<C1>();
-    if (int rc = allow_dynamic_lds((const void *)secam_demod_scan_kernel<C1, NW, U8>, p->device, lds, "the SECAM decoder's scan kernel")) return rc;
-    const long long blocks = (g.total_calls + (NW - 1) - 1) / (NW - 1);
-    hipLaunchKernelGGL((secam_demod_scan_kernel<C1, NW, U8>), dim3((int)blocks), dim3(64 * NW), lds, stream, g, p->scan_sdem);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return fail(CM_ERR_LAUNCH, std::string("secam_demod_scan_kernel launch: ") + hipGetErrorString(e));
-    return CM_OK;
-}
 int scan_secam_demod(const cm_plan *p, const Geom &g, hipStream_t stream, bool u8) {
-    if (p->scan_sdem_c1 == 12) return u8 ? launch_scan_secam_demod<12, 4, true>(p, g, stream) : launch_scan_secam_demod<12, 4, false>(p, g, stream);
-    return u8 ? launch_scan_secam_demod<16, 4, true>(p, g, stream) : launch_scan_secam_demod<16, 4, false>(p, g, stream);
-}
-template <bool U8>
-int scan_secam_mod_as(const cm_plan *p, const Geom &g, hipStream_t stream) {
-    switch (p->scan_smod_c1) {
-        case 12: return launch_scan_secam_mod<12, 4, U8>(p, g, stream);
-        case 16: return launch_scan_secam_mod<16, 4, U8>(p, g, stream);
-        case 24: return launch_scan_secam_mod<24, 4, U8>(p, g, stream);
-        default: return launch_scan_secam_mod<32, 4, U8>(p, g, stream);
-    }
+    return cm_host::scan_launch_secam_demod(p->scan_sdem_c1, u8, p->device, p->scan_sdem, g, stream);
 }
 int scan_secam_mod(const cm_plan *p, const Geom &g, hipStream_t stream, bool u8) {
-    return u8 ? scan_secam_mod_as<true>(p, g, stream) : scan_secam_mod_as<false>(p, g, stream);
+    return cm_host::scan_launch_secam_mod(p->scan_smod_c1, u8, p->device, p->scan_smod, g, stream);
 }
 // km / kf: the constants of the main pass and of the plain first-line pass (two plans' in the wrapped combs); depth: the main pass's comb depth
-template <int C1, int NW, bool U8>
-static int launch_scan(int device, const ScanK *km, const ScanK *kf, int depth, const Geom &gm, const Geom &gf, bool with_first, hipStream_t stream) {
-    const size_t lds = sizeof(float) * (size_t)NW * scan_wave_floats<C1>();
-    if (int rc = allow_dynamic_lds((const void *)demod_scan_kernel<C1, NW, U8>, device, lds, "the scan kernel")) return rc;
-    const long long n_first = with_first ? (gf.total_calls + NW - 1) / NW : 0;
-    const int per = gm.sparse ? NW : NW - depth;      // calls per workgroup behind the halo waves
-    const long long n_main = (gm.total_calls + per - 1) / per;
-    hipLaunchKernelGGL((demod_scan_kernel<C1, NW, U8>), dim3((int)(n_first + n_main)), dim3(64 * NW), lds, stream, gm, gf, km,
-                       with_first ? kf : km, (int)n_first);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return fail(CM_ERR_LAUNCH, std::string("demod_scan_kernel launch: ") + hipGetErrorString(e));
-    return CM_OK;
-}
 template <bool U8>
 static int launch_scan_as(int c1, int device, const ScanK *km, const ScanK *kf, int depth, const Geom &gm, const Geom &gf, bool with_first,
                           hipStream_t stream) {
-    if (c1 == 12) return launch_scan<12, 4, U8>(device, km, kf, depth, gm, gf, with_first, stream);
-    if (c1 == 16) return launch_scan<16, 4, U8>(device, km, kf, depth, gm, gf, with_first, stream);
-    if (c1 == 24) return launch_scan<24, 3, U8>(device, km, kf, depth, gm, gf, with_first, stream);
-    return launch_scan<32, 3, U8>(device, km, kf, depth, gm, gf, with_first, stream);
+    return cm_host::scan_launch_demod(c1, U8, device, km, kf, depth, gm, gf, with_first, stream);
 }
 
 // gm: main-pass geometry (total_calls set); gf: first-line geometry (total_calls = number of runs) when the plan has one
@@ -1448,27 +1419,6 @@ int cm_demodulate_run(const cm_plan *p, const float *composite, float *rgb, int3
     });
 }
 
-extern "C++" {
-template <int C1, int NW, bool U8>
-static int launch_scan_mod(const cm_plan *p, const Geom &g, hipStream_t stream) {
-    const size_t lds = sizeof(float) * (size_t)NW * scan_mod_wave_floats<C1>();
-    if (int rc = allow_dynamic_lds((const void *)qam_mod_scan_kernel<C1, NW, U8>, p->device, lds, "the modulator's scan kernel")) return rc;
-    const long long blocks = (g.total_calls + NW - 1) / NW;
-    hipLaunchKernelGGL((qam_mod_scan_kernel<C1, NW, U8>), dim3((int)blocks), dim3(64 * NW), lds, stream, g, p->scan_mod);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return fail(CM_ERR_LAUNCH, std::string("qam_mod_scan_kernel launch: ") + hipGetErrorString(e));
-    return CM_OK;
-}
-template <bool U8>
-static int launch_scan_mod_as(const cm_plan *p, const Geom &g, hipStream_t stream) {
-    switch (p->scan_mod_c1) {
-        case 12: return launch_scan_mod<12, 4, U8>(p, g, stream);
-        case 16: return launch_scan_mod<16, 4, U8>(p, g, stream);
-        case 24: return launch_scan_mod<24, 4, U8>(p, g, stream);
-        default: return launch_scan_mod<32, 4, U8>(p, g, stream);
-    }
-}
-}  // extern "C++"
 #ifndef CM_SCAN_MOD_MAX_CALLS
 #define CM_SCAN_MOD_MAX_CALLS 40000
 #endif
@@ -1485,7 +1435,7 @@ static int run_mod(const cm_plan *p, Geom g, hipStream_t stream, bool u8 = false
     if (blocks > 0x7fffffffLL) return fail(CM_ERR_INVALID, "batch too large for one launch");
     const int mode = p->small_batch;
     if (p->scan_mod && (mode == CM_SMALL_BATCH_SCAN || (mode == CM_SMALL_BATCH_AUTO && g.total_calls <= CM_SCAN_MOD_MAX_CALLS)))
-        return u8 ? launch_scan_mod_as<true>(p, g, stream) : launch_scan_mod_as<false>(p, g, stream);
+        return cm_host::scan_launch_qam_mod(p->scan_mod_c1, u8, p->device, p->scan_mod, g, stream);
     return (u8 ? p->mod_fn_u8 : p->mod_fn)(g, p->mod_k.data(), (int)blocks, stream);
 }
 
@@ -1802,7 +1752,7 @@ struct cm_am_plan {
     ScanProtoK *scan_pd = nullptr;
     ScanProtoModK *scan_pm = nullptr;
     ScanNiirK *scan_nd = nullptr;
-    ScanNiirK64 *scan_nd64 = nullptr;   // CM_AM_FLOAT64: the float64 front end's constants
+    ScanNiirK64 *scan_nd64 = nullptr;   // the float64 hue path's constants
     ScanNiirModK *scan_nm = nullptr;
     int scan_pd_c1 = 0, scan_pm_c1 = 0, scan_nd_c1 = 0, scan_nm_c1 = 0;
     mutable int small_batch = CM_SMALL_BATCH_AUTO;     // cm_am_plan_set_small_batch
@@ -1813,9 +1763,10 @@ struct cm_am_plan {
 #ifndef CM_AM_SCAN_MOD_MAX_CALLS
 #define CM_AM_SCAN_MOD_MAX_CALLS 36000
 #endif
-// (NIIR: the decoder's five decimators make a wave's row expensive - hand-over near 33 frames of 720 x 576; the encoder is one packed
-// scan - the scan kernel keeps up with the streaming one beyond 100 frames; profiles/r03_am_small_batch.txt)
-#define CM_NIIR_SCAN_MAX_CALLS 18000
+// (NIIR: the decoder's five float64 decimators make a wave's row expensive - one 720 x 576 frame 142 us, 16 frames 74 us each, against 650 us for
+// any batch up to 16 frames on the streaming pair: hand-over near 8 frames; the encoder is one packed scan - the scan kernel keeps up with the
+// streaming one beyond 100 frames; profiles/r04_am_small_batch.txt)
+#define CM_NIIR_SCAN_MAX_CALLS 4600
 #define CM_NIIR_SCAN_MOD_MAX_CALLS 60000
 
 namespace {
@@ -1945,17 +1896,20 @@ void make_scan_niir(cm_am_plan *p) {
             if (hipMalloc((void **)&p->scan_nd, sizeof k) == hipSuccess && hipMemcpy(p->scan_nd, &k, sizeof k, hipMemcpyHostToDevice) == hipSuccess)
                 p->scan_nd_c1 = c1;
             else p->scan_nd = nullptr;
-            if (p->scan_nd && (d.flags & CM_AM_FLOAT64)) {
-                NiirDemodK<double> md;
-                std::string err;
+            if (p->scan_nd) {      // the hue path's float64 constants; without them the plan has no scan decoder
+                const NiirDemodK<double> &md = p->ndd;
                 ScanNiirK64 k64;
                 std::memset(&k64, 0, sizeof k64);
-                if (build_niir_demod_k<double>(d, md, err)) {
-                    for (int i = 0; i < kAmTaps; ++i) k64.h[i] = md.taps.h[i];
-                    fill_scan_filter(d.bandpass_up, md.bp.na1, md.bp.na2, md.bp.b1, md.bp.b2, 3 * c1, k64.bp, 1e-20);
-                    fill_scan_filter(d.lowpass_up, md.lp.na1, md.lp.na2, md.lp.b1, md.lp.b2, 3 * c1, k64.lp, 1e-20);
-                    if (hipMalloc((void **)&p->scan_nd64, sizeof k64) != hipSuccess || hipMemcpy(p->scan_nd64, &k64, sizeof k64, hipMemcpyHostToDevice) != hipSuccess)
-                        p->scan_nd64 = nullptr;
+                for (int i = 0; i < kAmTaps; ++i) k64.h[i] = md.taps.h[i];
+                fill_scan_filter(d.bandpass_up, md.bp.na1, md.bp.na2, md.bp.b1, md.bp.b2, 3 * c1, k64.bp, 1e-20);
+                fill_scan_filter(d.lowpass_up, md.lp.na1, md.lp.na2, md.lp.b1, md.lp.b2, 3 * c1, k64.lp, 1e-20);
+                k64.c_pm = md.c_pm;
+                k64.alt_scale = md.alt_scale;
+                if (hipMalloc((void **)&p->scan_nd64, sizeof k64) != hipSuccess || hipMemcpy(p->scan_nd64, &k64, sizeof k64, hipMemcpyHostToDevice) != hipSuccess) {
+                    p->scan_nd64 = nullptr;
+                    (void)hipFree(p->scan_nd);
+                    p->scan_nd = nullptr;
+                    p->scan_nd_c1 = 0;
                 }
             }
         }
@@ -1980,12 +1934,12 @@ void make_scan_niir(cm_am_plan *p) {
     }
 }
 extern "C++" {
-template <int C1, int NW, bool U8, bool F64 = false>
+template <int C1, int NW, bool U8>
 int launch_scan_niir_demod(const cm_am_plan *p, const Geom &g, const AmGeom &a, bool strip, hipStream_t stream) {
-    const size_t lds = sizeof(float) * (size_t)NW * scan_niir_wave_floats<C1, F64>();
-    if (int rc = allow_dynamic_lds((const void *)niir_demod_scan_kernel<C1, NW, U8, F64>, p->device, lds, "the NIIR decoder's scan kernel")) return rc;
+    const size_t lds = sizeof(float) * (size_t)NW * scan_niir_wave_floats<C1>();
+    if (int rc = allow_dynamic_lds((const void *)niir_demod_scan_kernel<C1, NW, U8>, p->device, lds, "the NIIR decoder's scan kernel")) return rc;
     const long long blocks = (g.total_calls + (NW - 1) - 1) / (NW - 1);
-    hipLaunchKernelGGL((niir_demod_scan_kernel<C1, NW, U8, F64>), dim3((int)blocks), dim3(64 * NW), lds, stream, g, a, p->scan_nd, p->scan_nd64,
+    hipLaunchKernelGGL((niir_demod_scan_kernel<C1, NW, U8>), dim3((int)blocks), dim3(64 * NW), lds, stream, g, a, p->scan_nd, p->scan_nd64, p->niir_syn,
                        p->desc.line_phase_shift, p->desc.bandpass_phase_shift, strip ? 1 : 0);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(CM_ERR_LAUNCH, std::string("niir_demod_scan_kernel launch: ") + hipGetErrorString(e));
@@ -2022,18 +1976,12 @@ int niir_launch_demod(const cm_am_plan *p, Geom g, int64_t first_frame, hipStrea
     a.carrier_phase_step = p->desc.carrier_phase_step;
     a.strip = strip ? 1 : 0;
     const bool with_first = g.k0 == 0;
-    if (p->desc.flags & CM_AM_FLOAT64) {      // the float64 front end lives in the scan kernel: every batch size runs there
-        if (g.total_calls <= 0) return CM_OK;
-        if (g.total_calls > 0x3fffffffLL) return fail(CM_ERR_INVALID, "batch too large for one launch");
-        if (p->scan_nd_c1 == 12) return u8 ? launch_scan_niir_demod<12, 3, true, true>(p, g, a.a, strip, stream) : launch_scan_niir_demod<12, 3, false, true>(p, g, a.a, strip, stream);
-        return u8 ? launch_scan_niir_demod<16, 2, true, true>(p, g, a.a, strip, stream) : launch_scan_niir_demod<16, 2, false, true>(p, g, a.a, strip, stream);
-    }
     {   // small batches: one wavefront per call, the first lines of the runs in the same pass (cm_am_scan_kernels.h)
         int rc;
         if (am_scan_wanted(p, p->scan_nd, g.total_calls, CM_NIIR_SCAN_MAX_CALLS, rc)) {
             if (g.total_calls <= 0) return CM_OK;
-            if (p->scan_nd_c1 == 12) return u8 ? launch_scan_niir_demod<12, 4, true>(p, g, a.a, strip, stream) : launch_scan_niir_demod<12, 4, false>(p, g, a.a, strip, stream);
-            return u8 ? launch_scan_niir_demod<16, 3, true>(p, g, a.a, strip, stream) : launch_scan_niir_demod<16, 3, false>(p, g, a.a, strip, stream);
+            if (p->scan_nd_c1 == 12) return u8 ? launch_scan_niir_demod<12, 3, true>(p, g, a.a, strip, stream) : launch_scan_niir_demod<12, 3, false>(p, g, a.a, strip, stream);
+            return u8 ? launch_scan_niir_demod<16, 2, true>(p, g, a.a, strip, stream) : launch_scan_niir_demod<16, 2, false>(p, g, a.a, strip, stream);
         }
         if (rc) return rc;
     }
@@ -2220,8 +2168,6 @@ int cm_am_plan_create(const cm_am_desc *desc, cm_am_plan **out) {
     }
     make_scan_proto(p);
     make_scan_niir(p);
-    if (desc->kind == CM_AM_NIIR && (desc->flags & CM_AM_FLOAT64) && p->demod_error.empty() && !p->scan_nd64)
-        p->demod_error = "CM_AM_FLOAT64: the float64 front end runs on the row-parallel kernel, which does not serve this shape (rows up to ~1000 samples)";
     *out = p;
     return CM_OK;
 }
@@ -2434,17 +2380,6 @@ int launch_wrap_back(const Geom &g, const cm_plan *backend, const cm_comb_wrap_d
     return notch ? launch_wrap_back_i<NP, SP, U8, RT, false, true>(a, (int)blocks, stream)
                  : launch_wrap_back_i<NP, SP, U8, RT, false, false>(a, (int)blocks, stream);
 }
-// small batches: one wavefront per call (wrap_back_scan_kernel), the pre-correction constants are the backend modulator's
-template <int C1, int NW, bool U8>
-int launch_wrap_back_scan(const Geom &g, const cm_plan *backend, const ScanWrapArgs &a, hipStream_t stream) {
-    const size_t lds = sizeof(float) * (size_t)NW * scan_mod_wave_floats<C1>();
-    if (int rc = allow_dynamic_lds((const void *)wrap_back_scan_kernel<C1, NW, U8>, backend->device, lds, "the wrapped combs' scan kernel")) return rc;
-    const long long blocks = (g.total_calls + NW - 1) / NW;
-    hipLaunchKernelGGL((wrap_back_scan_kernel<C1, NW, U8>), dim3((int)blocks), dim3(64 * NW), lds, stream, g, backend->scan_mod, a);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return fail(CM_ERR_LAUNCH, std::string("wrap_back_scan_kernel launch: ") + hipGetErrorString(e));
-    return CM_OK;
-}
 template <bool U8>
 int wrap_back_scan(const Geom &g, const cm_plan *backend, const cm_comb_wrap_desc &w, hipStream_t stream) {
     ScanWrapArgs a;
@@ -2465,12 +2400,7 @@ int wrap_back_scan(const Geom &g, const cm_plan *backend, const cm_comb_wrap_des
     a.own_delay = w.own_delay ? 1 : 0;
     a.minavg = w.minavg ? 1 : 0;
     a.strip = w.strip_chroma ? 1 : 0;
-    switch (backend->scan_mod_c1) {
-        case 12: return launch_wrap_back_scan<12, 4, U8>(g, backend, a, stream);
-        case 16: return launch_wrap_back_scan<16, 4, U8>(g, backend, a, stream);
-        case 24: return launch_wrap_back_scan<24, 4, U8>(g, backend, a, stream);
-        default: return launch_wrap_back_scan<32, 4, U8>(g, backend, a, stream);
-    }
+    return cm_host::scan_launch_wrap_back(backend->scan_mod_c1, U8, backend->device, backend->scan_mod, a, g, stream);
 }
 int run_wrap_back(Geom g, const cm_plan *backend, const cm_comb_wrap_desc &w, int64_t first_frame, bool u8, hipStream_t stream) {
     g.lanes = reinterpret_cast<const LaneK<float> *>(backend->mod_lanes);
@@ -2499,7 +2429,11 @@ int check_wrap(const cm_plan *inner, const cm_plan *first, const cm_plan *backen
     if (first && !first->fn) return fail(CM_ERR_UNSUPPORTED, first->demod_error);
     if (!backend->mod_fn || backend->mod_depth) return fail(CM_ERR_UNSUPPORTED, "the backend plan needs a plain (not line-averaging) modulator");
     const cm_plan_desc &d = inner->desc;
+    // one device for the three plans: their lane / carrier / scan tables are that device's memory, and check_device() below looks at inner's only
+    if (backend->device != inner->device || (first && first->device != inner->device))
+        return fail(CM_ERR_INVALID, "the inner, first and backend plans of a wrapped comb belong to different devices");
     if (backend->desc.width != d.width || (first && first->desc.width != d.width)) return fail(CM_ERR_INVALID, "the plans differ in width");
+    if (backend->desc.height != d.height || (first && first->desc.height != d.height)) return fail(CM_ERR_INVALID, "the plans differ in height");
     if ((first != nullptr) != (d.first_is_plain != 0))
         return fail(CM_ERR_INVALID, "a `first` plan is needed exactly when the inner decoder takes call 0 of a run from the plain decoder");
     if (first && (first->has_first || first->desc.first_is_plain)) return fail(CM_ERR_INVALID, "the `first` plan must be a plain decoder");
@@ -2542,8 +2476,13 @@ struct AsyncBuf {
     void *p = nullptr;
     ~AsyncBuf() { if (p) (void)hipFreeAsync(p, stream); }
 };
+#ifndef CM_WRAP_SCRATCH_BYTES
+#define CM_WRAP_SCRATCH_BYTES ((size_t)1 << 30)
+#endif
+// in: float rows (pitch wp), or in8: composite bytes (width = wp, a multiple of 4) with bytes out as well
 int wrap_frames(const cm_plan *inner, const cm_plan *first, const cm_plan *backend, const cm_comb_wrap_desc *w, const float *in,
-                void *out, bool u8, int wp, int64_t n_frames, int64_t first_frame, hipStream_t stream) {
+                const uint8_t *in8, void *out, int wp, int64_t n_frames, int64_t first_frame, hipStream_t stream) {
+    const bool u8 = in8 != nullptr;
     const cm_plan_desc &d = inner->desc;
     const int W = d.width, H = d.height, D = d.demodulation_delay + (w->own_delay ? 1 : 0);
     int rc = check_lines(inner, inner->main, H - 1 + 2 * D);
@@ -2564,18 +2503,31 @@ int wrap_frames(const cm_plan *inner, const cm_plan *first, const cm_plan *backe
     g.first_line[0] = 0;
     g.first_line[1] = 1;
     g.delay = D;
-    // the component scratch: at most kChunk frames at a time (5 GB for 720 x 576).  Large on purpose: the plain first-line pass
-    // is one lane per run - 2 runs per frame, a handful of workgroups whose time is the latency of walking one row (0.23 ms) -
-    // and it is paid once per chunk (profiles/r03_wrapped_prof.txt: 256-frame chunks spent 17 % of the batch there)
-    const int64_t kChunk = 1024;
-    AsyncBuf scratch;
-    scratch.stream = stream;
-    const int64_t chunk = n_frames < kChunk ? n_frames : kChunk;
+    // the component scratch: a byte budget (CM_WRAP_SCRATCH_BYTES, 1 GiB: 200 frames of 720 x 576 at a time; the header documents the peak).
+    // Not smaller: the plain first-line pass is one lane per run - 2 runs per frame, a handful of workgroups whose time is the latency of
+    // walking one row (0.23 ms) - and it is paid once per chunk.  With bytes at the boundary the level-decoded composite is a second,
+    // chunk-sized buffer (`in8`: the whole batch's bytes; round 3 decoded them all at once).
+    const size_t frame_bytes = (size_t)g.calls_per_frame * 3 * wp * sizeof(float);
+    int64_t chunk = (int64_t)(CM_WRAP_SCRATCH_BYTES / frame_bytes);
+    if (chunk < 1) chunk = 1;
+    if (chunk > n_frames) chunk = n_frames;
+    AsyncBuf scratch, comp;
+    scratch.stream = comp.stream = stream;
     if (int rc_ = refuse_capture(stream, "a wrapped comb decoder")) return rc_;
-    HIP_TRY(hipMallocAsync(&scratch.p, (size_t)chunk * g.calls_per_frame * 3 * wp * sizeof(float), stream), CM_ERR_LAUNCH);
+    HIP_TRY(hipMallocAsync(&scratch.p, (size_t)chunk * frame_bytes, stream), CM_ERR_LAUNCH);
+    const long long frame_quads = (long long)H * (wp / 4);
+    if (in8) HIP_TRY(hipMallocAsync(&comp.p, (size_t)chunk * frame_quads * 16, stream), CM_ERR_LAUNCH);
     for (int64_t f0 = 0; f0 < n_frames; f0 += chunk) {
         const int64_t nf = n_frames - f0 < chunk ? n_frames - f0 : chunk;
         Geom gi = g;
+        if (in8) {      // image.py:24-25, 62: the inner decoder's component output has no byte form, so it reads float rows
+            const long long quads = nf * frame_quads;
+            hipLaunchKernelGGL(decode_level_kernel, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, stream, in8 + f0 * (long long)wp * H,
+                               (float *)comp.p, quads);
+            hipError_t e = hipGetLastError();
+            if (e != hipSuccess) return fail(CM_ERR_LAUNCH, std::string("decode_level_kernel launch: ") + hipGetErrorString(e));
+            gi.in = (const float *)comp.p;
+        } else
         gi.in = in + f0 * g.in_frame_stride;
         gi.total_calls = nf * g.calls_per_frame;
         if ((rc = run_wrap_inner(inner, first, gi, (float *)scratch.p, first_frame + f0, true, stream))) return rc;
@@ -2614,7 +2566,7 @@ int cm_comb_wrap_demodulate_frames(const cm_plan *inner, const cm_plan *first, c
     const cm_plan_desc &d = inner->desc;
     const int W = d.width, H = d.height, wp = (W + 3) & ~3;
     return with_pitched_rows(composite, n_frames * H, rgb, n_frames * 3 * H, W, (hipStream_t)stream, [&](const float *in, float *out) -> int {
-        return wrap_frames(inner, first, backend, w, in, out, false, wp, n_frames, first_frame, (hipStream_t)stream);
+        return wrap_frames(inner, first, backend, w, in, nullptr, out, wp, n_frames, first_frame, (hipStream_t)stream);
     });
 }
 
@@ -2628,17 +2580,7 @@ int cm_comb_wrap_demodulate_frames_u8(const cm_plan *inner, const cm_plan *first
     const cm_plan_desc &d = inner->desc;
     const int W = d.width, H = d.height;
     if (W % 4 != 0) return fail(CM_ERR_UNSUPPORTED, "the fused uint8 boundary needs a width that is a multiple of 4");
-    // the level-decoded composite (image.py:24-25, 62) once, as float rows: the inner decoder's component output has no byte form
-    if (int rc_ = refuse_capture((hipStream_t)stream, "a wrapped comb decoder")) return rc_;
-    AsyncBuf comp;
-    comp.stream = (hipStream_t)stream;
-    const long long quads = n_frames * H * (long long)(W / 4);
-    HIP_TRY(hipMallocAsync(&comp.p, (size_t)quads * 16, (hipStream_t)stream), CM_ERR_LAUNCH);
-    hipLaunchKernelGGL(decode_level_kernel, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, (hipStream_t)stream, composite8,
-                       (float *)comp.p, quads);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return fail(CM_ERR_LAUNCH, std::string("decode_level_kernel launch: ") + hipGetErrorString(e));
-    return wrap_frames(inner, first, backend, w, (const float *)comp.p, rgb8, true, W, n_frames, first_frame, (hipStream_t)stream);
+    return wrap_frames(inner, first, backend, w, nullptr, composite8, rgb8, W, n_frames, first_frame, (hipStream_t)stream);
 }
 
 int cm_comb_wrap_demodulate_run(const cm_plan *inner, const cm_plan *first, const cm_plan *backend, const cm_comb_wrap_desc *w,
@@ -2714,3 +2656,89 @@ int cm_plan_describe(const cm_plan *p, char *buf, int32_t buf_len) {
 }  // extern "C"
 
 #endif  // CM_MAIN_PART
+
+#if CM_SCAN_PART
+// ---- CM_PART 3: the row-parallel scan kernels of the QAM / SECAM families (cm_scan_kernels.h) behind five launch functions ----------------
+namespace {
+template <int C1, int NW, bool U8>
+int scan_demod_i(int device, const ScanK *km, const ScanK *kf, int depth, const Geom &gm, const Geom &gf, bool with_first, hipStream_t stream) {
+    const size_t lds = sizeof(float) * (size_t)NW * scan_wave_floats<C1>();
+    if (int rc = allow_dynamic_lds((const void *)demod_scan_kernel<C1, NW, U8>, device, lds, "the scan kernel")) return rc;
+    const long long n_first = with_first ? (gf.total_calls + NW - 1) / NW : 0;
+    const int per = gm.sparse ? NW : NW - depth;      // calls per workgroup behind the halo waves
+    const long long n_main = (gm.total_calls + per - 1) / per;
+    hipLaunchKernelGGL((demod_scan_kernel<C1, NW, U8>), dim3((int)(n_first + n_main)), dim3(64 * NW), lds, stream, gm, gf, km,
+                       with_first ? kf : km, (int)n_first);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(CM_ERR_LAUNCH, std::string("demod_scan_kernel launch: ") + hipGetErrorString(e));
+    return CM_OK;
+}
+template <int C1, int NW, bool U8>
+int scan_qam_mod_i(int device, const ScanModK *k, const Geom &g, hipStream_t stream) {
+    const size_t lds = sizeof(float) * (size_t)NW * scan_mod_wave_floats<C1>();
+    if (int rc = allow_dynamic_lds((const void *)qam_mod_scan_kernel<C1, NW, U8>, device, lds, "the modulator's scan kernel")) return rc;
+    const long long blocks = (g.total_calls + NW - 1) / NW;
+    hipLaunchKernelGGL((qam_mod_scan_kernel<C1, NW, U8>), dim3((int)blocks), dim3(64 * NW), lds, stream, g, k);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(CM_ERR_LAUNCH, std::string("qam_mod_scan_kernel launch: ") + hipGetErrorString(e));
+    return CM_OK;
+}
+template <int C1, int NW, bool U8>
+int scan_secam_mod_i(int device, const ScanSecamModK *k, const Geom &g, hipStream_t stream) {
+    const size_t lds = sizeof(float) * (size_t)NW * scan_secam_mod_wave_floats<C1>();
+    if (int rc = allow_dynamic_lds((const void *)secam_mod_scan_kernel<C1, NW, U8>, device, lds, "the SECAM modulator's scan kernel")) return rc;
+    const long long blocks = (g.total_calls + NW - 1) / NW;
+    hipLaunchKernelGGL((secam_mod_scan_kernel<C1, NW, U8>), dim3((int)blocks), dim3(64 * NW), lds, stream, g, k);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(CM_ERR_LAUNCH, std::string("secam_mod_scan_kernel launch: ") + hipGetErrorString(e));
+    return CM_OK;
+}
+template <int C1, int NW, bool U8>
+int scan_secam_demod_i(int device, const ScanSecamK *k, const Geom &g, hipStream_t stream) {
+    const size_t lds = sizeof(float) * (size_t)NW * scan_secam_wave_floats<C1>();
+    if (int rc = allow_dynamic_lds((const void *)secam_demod_scan_kernel<C1, NW, U8>, device, lds, "the SECAM decoder's scan kernel")) return rc;
+    const long long blocks = (g.total_calls + (NW - 1) - 1) / (NW - 1);
+    hipLaunchKernelGGL((secam_demod_scan_kernel<C1, NW, U8>), dim3((int)blocks), dim3(64 * NW), lds, stream, g, k);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(CM_ERR_LAUNCH, std::string("secam_demod_scan_kernel launch: ") + hipGetErrorString(e));
+    return CM_OK;
+}
+// the wrapped combs' back end: one wavefront per call (wrap_back_scan_kernel), the pre-correction constants are the backend modulator's
+template <int C1, int NW, bool U8>
+int scan_wrap_back_i(int device, const ScanModK *k, const ScanWrapArgs &a, const Geom &g, hipStream_t stream) {
+    const size_t lds = sizeof(float) * (size_t)NW * scan_mod_wave_floats<C1>();
+    if (int rc = allow_dynamic_lds((const void *)wrap_back_scan_kernel<C1, NW, U8>, device, lds, "the wrapped combs' scan kernel")) return rc;
+    const long long blocks = (g.total_calls + NW - 1) / NW;
+    hipLaunchKernelGGL((wrap_back_scan_kernel<C1, NW, U8>), dim3((int)blocks), dim3(64 * NW), lds, stream, g, k, a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(CM_ERR_LAUNCH, std::string("wrap_back_scan_kernel launch: ") + hipGetErrorString(e));
+    return CM_OK;
+}
+}  // namespace
+// (chunks of 24 / 32 samples run three waves per workgroup in the decoder: its rows are twice as long)
+#define CM_SCAN_DISPATCH(fn, nw_long, ...)                                                                                  \
+    switch (c1) {                                                                                                           \
+        case 12: return u8 ? fn<12, 4, true>(__VA_ARGS__) : fn<12, 4, false>(__VA_ARGS__);                                  \
+        case 16: return u8 ? fn<16, 4, true>(__VA_ARGS__) : fn<16, 4, false>(__VA_ARGS__);                                  \
+        case 24: return u8 ? fn<24, nw_long, true>(__VA_ARGS__) : fn<24, nw_long, false>(__VA_ARGS__);                      \
+        default: return u8 ? fn<32, nw_long, true>(__VA_ARGS__) : fn<32, nw_long, false>(__VA_ARGS__);                      \
+    }
+int cm_host::scan_launch_demod(int c1, bool u8, int device, const ScanK *km, const ScanK *kf, int depth, const Geom &gm, const Geom &gf,
+                               bool with_first, hipStream_t stream) {
+    CM_SCAN_DISPATCH(scan_demod_i, 3, device, km, kf, depth, gm, gf, with_first, stream)
+}
+int cm_host::scan_launch_qam_mod(int c1, bool u8, int device, const ScanModK *k, const Geom &g, hipStream_t stream) {
+    CM_SCAN_DISPATCH(scan_qam_mod_i, 4, device, k, g, stream)
+}
+int cm_host::scan_launch_secam_mod(int c1, bool u8, int device, const ScanSecamModK *k, const Geom &g, hipStream_t stream) {
+    CM_SCAN_DISPATCH(scan_secam_mod_i, 4, device, k, g, stream)
+}
+int cm_host::scan_launch_secam_demod(int c1, bool u8, int device, const ScanSecamK *k, const Geom &g, hipStream_t stream) {
+    if (c1 == 12) return u8 ? scan_secam_demod_i<12, 4, true>(device, k, g, stream) : scan_secam_demod_i<12, 4, false>(device, k, g, stream);
+    return u8 ? scan_secam_demod_i<16, 4, true>(device, k, g, stream) : scan_secam_demod_i<16, 4, false>(device, k, g, stream);
+}
+int cm_host::scan_launch_wrap_back(int c1, bool u8, int device, const ScanModK *k, const ScanWrapArgs &a, const Geom &g, hipStream_t stream) {
+    CM_SCAN_DISPATCH(scan_wrap_back_i, 4, device, k, a, g, stream)
+}
+#undef CM_SCAN_DISPATCH
+#endif  // CM_SCAN_PART

@@ -492,16 +492,21 @@ class AmEngine(_EngineBase):
         return torch.from_numpy(z)
 
     def set_small_batch(self, mode):
-        """Engine.set_small_batch for a Proto-SECAM plan (cm_am_plan_set_small_batch: 'auto', 'rows', 'scan'; NIIR plans have
-        no scan kernel: NotImplementedError for 'scan')."""
+        """Engine.set_small_batch for a Proto-SECAM / NIIR plan (cm_am_plan_set_small_batch): 'auto' (the row-parallel scan kernels of
+        csrc/cm_am_scan_kernels.h below a few frames, where the plan's shape fits them), 'rows' (the streaming wave pairs on whole rows),
+        'scan' (NotImplementedError where no scan kernel serves the plan: rows beyond ~1000 samples)."""
         code = Engine.SMALL_BATCH[mode]
         for handle in self._plans.handles():
             _native.check(_native.lib().cm_am_plan_set_small_batch(handle, code))
         self._plans.on_create = (lambda h: _native.check(_native.lib().cm_am_plan_set_small_batch(h, code))) if code else None
+        self._mode = mode
 
     def describe(self):
         name = 'proto' if self.desc.kind == 1 else 'niir'
-        return '%s_demod_kernel / %s_mod_kernel: one wavefront per 64 calls, x3 polyphase resamplers in registers' % (name, name)
+        hue = ', hue path float64' if name == 'niir' else ''
+        return ('%s_demod_pair_kernel / %s_mod%s_kernel (wave pairs, one lane per call, x3 polyphase resamplers in registers%s); small batches: '
+                '%s_demod_scan_kernel / %s_mod_scan_kernel (one wavefront per call); small-batch mode: %s'
+                % (name, name, '' if name == 'niir' else '_pair', hue, name, name, getattr(self, '_mode', 'auto')))
 
     def demodulate_frames(self, composite, first_frame=0, out=None):
         """composite [F, H, W] float32 -> rgb [F, 3, H, W] (numpy in -> numpy out, cuda tensor in -> cuda tensor out)."""

@@ -74,7 +74,7 @@ class ImageModem(object):
         if img.mode != 'L':
             img = img.convert('L')
         comp8 = numpy.frombuffer(img.tobytes(), dtype=numpy.uint8).reshape(img.height, img.width).copy()
-        try:  # byte boundary fused into the kernel where this stack has an instance (all but notch / minavg)
+        try:  # byte boundary fused into the kernel (widths that are multiples of 4; every stack has an instance since round 3)
             rgb8 = self._engine().demodulate_frames_u8(comp8[None], frame)[0]
             return Image.frombytes('RGB', (rgb8.shape[1], rgb8.shape[0]), numpy.ascontiguousarray(rgb8).tobytes())
         except NotImplementedError:

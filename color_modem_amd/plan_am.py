@@ -74,7 +74,7 @@ def build_am_desc(modem, components=False, strip_chroma=True):
         d.bandstop_up = plan.iir_desc(None)
         d.lowpass_up = plan.iir_desc(m._demodulate_upsampled_baseband_filter)
         d.bandpass_phase_shift = float(m._demodulate_upsampled_filter.phase_shift)
-        # modem.float64_front_end = True (on the modem the caller holds or on its backend): the decoder's 3x-rate front end in float64
+        # (modem.float64_front_end, round 3's opt-in: every NIIR decoder runs its hue path in float64 now; the flag is accepted and ignored)
         d.flags = CM_AM_FLOAT64 if (getattr(modem, 'float64_front_end', False) or getattr(m, 'float64_front_end', False)) else 0
         dec, enc = niir.DECODE, niir.ENCODE
     else:

@@ -35,6 +35,14 @@ class RowApi(object):
         self._engines = {}
         self._demod_run = _Run()
         self._mod_run = _Run()
+        self._small_batch = None
+
+    def set_small_batch(self, mode):
+        """Pin the kernel family of the per-row protocol ('auto', 'rows', 'scan': Engine.set_small_batch) on every engine this modem has
+        made and will make (a test / diagnosis aid: results differ between the families at float32 resolution only)."""
+        self._small_batch = None if mode == 'auto' else mode
+        for eng in self._engines.values():
+            eng.set_small_batch(mode)
 
     def _engine(self, components=False, strip_chroma=True, line=0):
         """The engine of this stack for the given protocol flavour; its per-line tables are grown (the plan is rebuilt)
@@ -44,11 +52,14 @@ class RowApi(object):
         if eng is None or line >= getattr(eng, 'n_lines', 1 << 30):
             from color_modem_amd import engine
             need = 0 if eng is None else max(2 * eng.n_lines, line + 64)
-            if eng is not None:      # the replaced engine's device sessions (history buffer, pinned staging, its plans) go with it
+            if eng is not None:      # the replaced engine's device sessions (history buffer, pinned staging, its plans) go with it - also the
+                gone = (id(eng), id(getattr(eng, 'encoder', None)))      # one of a comb wrapper's encoder, which _step keys on that engine
                 for run in (self._demod_run, self._mod_run):
-                    for skey in [k for k in run.sessions if k[0] == id(eng)]:
+                    for skey in [k for k in run.sessions if k[0] in gone]:
                         del run.sessions[skey]
             eng = self._engines[key] = engine.make_engine(self, components=key[0], strip_chroma=key[1], min_lines=max(need, line + 1))
+            if self._small_batch is not None:
+                eng.set_small_batch(self._small_batch)
         return eng
 
     @staticmethod

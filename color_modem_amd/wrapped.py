@@ -77,8 +77,8 @@ class WrappedCombEngine(object):
         return 'composition: %s (components, every call of the batch) | comb_wrap_back_kernel (small batches: wrap_back_scan_kernel)' % self.inner.describe()
 
     def set_small_batch(self, mode):
-        """Engine.set_small_batch for the three plans a wrapped decode runs through (inner decoder, plain first line, back end)."""
-        for e in (self.inner, self.first, self.mod):
+        """Engine.set_small_batch for the plans a wrapped decode runs through (inner decoder, plain first line, back end) and the encoder's."""
+        for e in (self.inner, self.first, self.mod, self.encoder):
             if e is not None:
                 e.set_small_batch(mode)
 

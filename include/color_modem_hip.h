@@ -269,12 +269,13 @@ int cm_mac_demodulate_run(const cm_mac_plan *plan, const float *composite, float
  * sections + FilterFunction shift.  The sub-carrier start phase of a line is computed on the device in float64 from
  * frame_phase_shift / line_phase_shift / frame_cycle (utils.py:67-88) and the line geometry (line.py:57-65). */
 enum cm_am_kind { CM_AM_PROTO_SECAM = 1, CM_AM_NIIR = 2 };
-/* cm_am_desc.flags.  CM_AM_FLOAT64 (NIIR decoder): interpolator, band-pass and low-pass of the 3x-rate front end in float64.  The float32
- * front end leaves isolated samples beyond 1e-5 of full scale where the decoder divides by a short phasor (niir.py:131-137): 4e-5 of the
- * samples of random pictures, worst 4e-3; with this flag 1 sample of 1.5e7 (2.3e-5) in the same campaign (profiles/r03_niir_precision.txt).
- * The decoder then runs on the row-parallel kernel of csrc/cm_am_scan_kernels.h at every batch size (rows up to ~1000 samples; 9.5 Gpixel/s
- * on long batches against 72 for the float32 wave pair; cm_am_plan_set_small_batch has no effect on such a decoder).  The NIIR ENCODERS need no
- * flag: where a pixel's saturation is below 1e-2 they form (db, dr) and the pedestal in float64 in the reference's own operation order. */
+/* cm_am_desc.flags.  CM_AM_FLOAT64: accepted and ignored since ABI v6 / round 4.  The NIIR decoder takes the hue as the angle of a decimated
+ * product pair and divides by its length (niir.py:131-137); with a float32 front end that left isolated samples beyond 1e-5 of full scale
+ * wherever the pair gets short (4e-5 of the samples of random pictures, worst 4e-3), and round 3 offered a float64 front end behind this flag
+ * (row-parallel kernel only, 9.5 Gpixel/s).  Now EVERY NIIR decoder - the streaming wave pair and the row-parallel kernel, floats or bytes -
+ * runs the whole hue path in float64 (interpolator, band-pass, low-pass, the quotient M / S, the hue products and their decimators;
+ * csrc/cm_am_stages.h: NiirHue): worst sample 5e-7 of full scale, 63 Gpixel/s on long batches (profiles/r04_niir_notes.txt).  The NIIR
+ * ENCODERS form (db, dr) and the pedestal in float64 in the reference's own operation order where a pixel's saturation is below 1e-2. */
 #define CM_AM_FLOAT64 1
 typedef struct cm_am_desc {
     int32_t abi_version;          /* CM_ABI_VERSION */
@@ -286,7 +287,7 @@ typedef struct cm_am_desc {
     int32_t premod_luma_filter;   /* Proto-SECAM encoder: protosecam.py:82-85 */
     int32_t frame_cycle;          /* ConstantFrequencyCarrier.frame_cycle (utils.py:78-80) */
     int32_t strip_chroma;         /* NIIR decoder: 0 = demodulate_components(..., strip_chroma=False) (niir.py:145), else 1 */
-    int32_t flags;                /* CM_AM_FLOAT64 or 0 */
+    int32_t flags;                /* 0 (CM_AM_FLOAT64 is accepted and ignored) */
     double frame_phase_shift;     /* ... .frame_shift (utils.py:74-76) */
     double line_phase_shift;      /* ... .line_shift (utils.py:69-72) */
     double carrier_phase_step;    /* radians per 1x sample: 2 * protosecam.py:31 _carrier_phase_step; niir.py:12 */

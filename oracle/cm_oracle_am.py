@@ -58,7 +58,23 @@ def _phase_ramp(start, step, n):
 
 
 class ProtoSecamOracle(object):
-    """protosecam.py:27-112 on a color_modem_amd.color.protosecam.ProtoSecamModem (filter designs, matrices, geometry)."""
+    """protosecam.py:27-112 on a color_modem_amd.color.protosecam.ProtoSecamModem (filter designs, geometry); the colour matrices are restated here
+    term by term in the reference's operation order (protosecam.py:54-69), not taken from the product."""
+
+    @staticmethod
+    def encode_components(r, g, b):                                                      # protosecam.py:54-60
+        r, g, b = [numpy.asarray(c, dtype=numpy.float64) for c in (r, g, b)]
+        luma = 0.3 * r + 0.59 * g + 0.11 * b
+        dr = 1.001 * r - 0.8437 * g - 0.1573 * b
+        db = -0.336 * r - 0.6608 * g + 0.9968 * b
+        return luma, dr, db
+
+    @staticmethod
+    def decode_components(luma, dr, db):                                                 # protosecam.py:62-69
+        r = luma + 0.6993006993006993 * dr
+        g = luma - 0.3555766267630674 * dr - 0.1664648910411622 * db
+        b = luma + 0.8928571428571429 * db
+        return r, g, b
 
     def __init__(self, modem):
         self.m = modem
@@ -67,7 +83,7 @@ class ProtoSecamOracle(object):
         self._last_chroma = None
 
     def modulate(self, frame, line, r, g, b):
-        return self.modulate_components(frame, line, *self.m.encode_components(r, g, b))
+        return self.modulate_components(frame, line, *self.encode_components(r, g, b))
 
     def modulate_components(self, frame, line, luma, dr, db):
         m = self.m
@@ -96,11 +112,28 @@ class ProtoSecamOracle(object):
         else:
             self._last_chroma, dr, db = chroma, self._last_chroma, chroma
         self._last_frame, self._last_line = frame, line
-        return m.decode_components(luma, dr, db)
+        return self.decode_components(luma, dr, db)
 
 
 class NiirOracle(object):
-    """niir.py:10-202 on a color_modem_amd.color.niir.NiirModem / HueCorrectingNiirModem (noise_level: the reference's numpy.random draws)."""
+    """niir.py:10-202 on a color_modem_amd.color.niir.NiirModem / HueCorrectingNiirModem (noise_level: the reference's numpy.random draws); the
+    colour matrices restated term by term in the reference's operation order (niir.py:31-61) - on grey pixels (db, dr) are the rounding residues
+    of exactly these sums and the pedestal's hue is THEIR angle."""
+
+    @staticmethod
+    def encode_components(r, g, b):                                                      # niir.py:31-40
+        r, g, b = [numpy.asarray(c, dtype=numpy.float64) for c in (r, g, b)]
+        luma = 0.299 * r + 0.587 * g + 0.114 * b
+        db = 0.1472906403940887 * r + 0.2891625615763547 * g - 0.4364532019704434 * b
+        dr = 0.6149122807017545 * r - 0.5149122807017544 * g - 0.1 * b
+        return luma, db, dr
+
+    @staticmethod
+    def decode_components(luma, db, dr):                                                 # niir.py:52-61
+        r = luma + 1.14 * dr
+        g = luma + 0.3942419080068143 * db - 0.5806814310051107 * dr
+        b = luma - 2.03 * db
+        return r, g, b
 
     def __init__(self, modem):
         self.m = modem
@@ -140,7 +173,7 @@ class NiirOracle(object):
         return luma + self._modulate_precorrected_chroma(frame, line, db, dr)
 
     def modulate(self, frame, line, r, g, b):
-        luma, db, dr = [numpy.asarray(c, dtype=numpy.float64) for c in self.m.encode_components(r, g, b)]
+        luma, db, dr = self.encode_components(r, g, b)
         if not self.hue_correcting:
             return self._modulate_offset_components(frame, line, luma, *self._add_offset(db, dr))   # niir.py:78-80 (with noise)
         return self.modulate_components(frame, line, luma, db, dr)
@@ -179,7 +212,7 @@ class NiirOracle(object):
         return saturation * numpy.sin(hue), saturation * numpy.cos(hue)
 
     def demodulate(self, frame, line, composite):
-        return self.m.decode_components(*self.demodulate_components(frame, line, composite))
+        return self.decode_components(*self.demodulate_components(frame, line, composite))
 
     def demodulate_components(self, frame, line, composite, strip_chroma=True):
         luma, db, dr = self._demodulate_offset_components(frame, line, composite, strip_chroma)

@@ -12,13 +12,23 @@ import numpy
 
 LUMA_W, CHROMA_W, LINE_W = 720, 360, 1080
 
-# mac.py:29-32 / 38-41
-ENCODE = numpy.array([[0.299, 0.587, 0.114],
-                      [0.649827, -0.544149, -0.105678],
-                      [-0.219167, -0.430271, 0.649438]])
-DECODE = numpy.array([[1.0, 1.0787486515641855, 0.0],
-                      [1.0, -0.5494818514781797, -0.2649492993950324],
-                      [1.0, 0.0, 1.364256480218281]])
+
+
+def encode_components(r, g, b):
+    """mac.py:28-34, term by term in the reference's operation order"""
+    r, g, b = [numpy.asarray(c, dtype=numpy.float64) for c in (r, g, b)]
+    luma = 0.299 * r + 0.587 * g + 0.114 * b
+    dr = 0.649827 * r - 0.544149 * g - 0.105678 * b
+    db = -0.219167 * r - 0.430271 * g + 0.649438 * b
+    return luma, dr, db
+
+
+def decode_components(luma, dr, db):
+    """mac.py:36-43"""
+    r = luma + 1.0787486515641855 * dr
+    g = luma - 0.5494818514781797 * dr - 0.2649492993950324 * db
+    b = luma + 1.364256480218281 * db
+    return r, g, b
 
 
 def firwin41():
@@ -152,10 +162,10 @@ class OracleMac(object):
         else:
             dr, db = lc_, up
         self._last = (frame, line, up)
-        return tuple(DECODE @ numpy.stack([luma, dr, db]))
+        return decode_components(luma, dr, db)
 
     def modulate(self, frame, line, r, g, b):
-        y, u, v = ENCODE @ numpy.stack([numpy.asarray(c, dtype=numpy.float64) for c in (r, g, b)])
+        y, u, v = encode_components(r, g, b)
         return self.modulate_components(frame, line, y, u, v)
 
     def modulate_components(self, frame, line, y, u, v):

@@ -421,6 +421,31 @@ def wrapper_cases(only=()):
         save('frames_demod_' + stack, inp=comp, out=out, frames=numpy.array(frames), size=numpy.array([W, H]))
 
 
+def degenerate_pictures(W, H):
+    """The inputs of the degenerate_* sets (shared with make_golden_am.py / make_golden_mac.py): black / white / mid-grey / saturated red pictures
+    and all-zero / constant composites - where an algorithm divides by an amplitude or takes the angle of a vanishing pair."""
+    one, zero = numpy.ones((H, W), numpy.float32), numpy.zeros((H, W), numpy.float32)
+    pics = numpy.stack([numpy.stack([zero, zero, zero]), numpy.stack([one, one, one]),
+                        numpy.full((3, H, W), numpy.float32(200 / 255.0)), numpy.stack([one, zero, zero])])
+    comps = numpy.stack([zero, numpy.full((H, W), numpy.float32(0.3))])
+    return pics, ['black', 'white', 'grey 200/255', 'red'], comps, ['zero', 'constant 0.3']
+
+
+def degenerate_cases():
+    """One tiny reference-generated set per family on degenerate inputs (until round 4 these were checked GPU-vs-oracle
+    only, and the oracle borrows its coefficients from the product): every picture through the encoder, every composite through the decoder,
+    720 x 12, frame 1, the image.py row schedule."""
+    W, H, frame = 720, 12, 1
+    pics, pic_names, comps, comp_names = degenerate_pictures(W, H)
+    for stack in ('pal_s', 'pal_d', 'pal_3d', 'ntsc', 'ntsc_comb_3d', 'secam', 'secam_avg', 'simple3d_pald'):
+        lc = line_config(stack, (W, H))
+        mod_out = numpy.stack([run_mod_frame(STACKS[stack](lc), pics[i].astype(numpy.float64), frame) for i in range(len(pics))])
+        with numpy.errstate(all='ignore'):
+            demod_out = numpy.stack([run_demod_frame(STACKS[stack](lc), comps[i].astype(numpy.float64), frame) for i in range(len(comps))])
+        save('degenerate_' + stack, pics=pics, pic_names=numpy.array(pic_names), mod_out=mod_out, comps=comps, comp_names=numpy.array(comp_names),
+             demod_out=demod_out, frame=numpy.array(frame), size=numpy.array([W, H]))
+
+
 def row_cases():
     """Explicit (frame, line) sequences at the full-height geometry, fed to one modem object in order."""
     seqs = {
@@ -472,11 +497,15 @@ if __name__ == '__main__':
     if sys.argv[1:2] == ['variants']:
         variant_cases(sys.argv[2:])
         sys.exit(0)
+    if sys.argv[1:2] == ['degenerate']:
+        degenerate_cases()
+        sys.exit(0)
     make_plans()
     frame_cases()
     option_cases()
     width_cases()
     variant_cases()
     wrapper_cases()
+    degenerate_cases()
     row_cases()
     image_cases()

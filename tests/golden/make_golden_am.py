@@ -117,6 +117,23 @@ def grey_cases():
         save('am_mod_' + name, inp=rgb, out=comp, frames=numpy.array(frames), size=numpy.array([W, H]), standard=numpy.array('GERBER_625'))
 
 
+def degenerate_cases():
+    """Proto-SECAM / NIIR / hue-correcting NIIR on the degenerate inputs of make_golden.py: degenerate_pictures (black / white / grey / red pictures,
+    all-zero / constant composites; 720 x 12, frame 1).  The NIIR decoder divides 0 / 0 on such composites: the reference's NaNs are recorded."""
+    sys.path.insert(0, HERE)
+    import make_golden
+    W, H, frame = 720, 12, 1
+    pics, pic_names, comps, comp_names = make_golden.degenerate_pictures(W, H)
+    for name in ('proto', 'niir', 'niir_hue'):
+        make = STACKS[name][1]
+        lc = line.LineConfig((W, H), LS.GERBER_625)
+        mod_out = numpy.stack([run_mod_frame(make(lc), pics[i], frame) for i in range(len(pics))])
+        with numpy.errstate(all='ignore'):
+            demod_out = numpy.stack([run_demod_frame(make(lc), comps[i], frame) for i in range(len(comps))])
+        save('degenerate_am_' + name, pics=pics, pic_names=numpy.array(pic_names), mod_out=mod_out, comps=comps, comp_names=numpy.array(comp_names),
+             demod_out=demod_out, frame=numpy.array(frame), size=numpy.array([W, H]))
+
+
 def main():
     if len(sys.argv) > 1 and sys.argv[1] == 'grey':      # only the sets added last (the others stay as they were made)
         grey_cases()
@@ -171,7 +188,9 @@ def main():
 
 
 if __name__ == '__main__':
-    if sys.argv[1:2] == ['noise']:
+    if sys.argv[1:2] == ['degenerate']:
+        degenerate_cases()
+    elif sys.argv[1:2] == ['noise']:
         noise_cases()
     else:
         main()

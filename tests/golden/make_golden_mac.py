@@ -108,5 +108,22 @@ def main():
          back8=numpy.frombuffer(back.tobytes(), dtype=numpy.uint8).reshape(H, 720, 3), frame=numpy.array(1))
 
 
+def degenerate_cases():
+    """MacModem on the degenerate pictures of make_golden.py: degenerate_pictures and on all-zero / constant lines (720 x 12, frame 1)."""
+    sys.path.insert(0, HERE)
+    import make_golden
+    W, H, frame = 720, 12, 1
+    pics, pic_names, _, comp_names = make_golden.degenerate_pictures(W, H)
+    lc = line.LineConfig((W, H))
+    mod_out = numpy.stack([run_mod_frame(mac.MacModem(lc), pics[i], frame) for i in range(len(pics))])
+    comps = numpy.stack([numpy.zeros((H, 1080), numpy.float32), numpy.full((H, 1080), numpy.float32(0.3))])
+    demod_out = numpy.stack([run_demod_frame(mac.MacModem(lc), comps[i], frame) for i in range(len(comps))])
+    save('degenerate_mac', pics=pics, pic_names=numpy.array(pic_names), mod_out=mod_out, comps=comps, comp_names=numpy.array(comp_names),
+         demod_out=demod_out, frame=numpy.array(frame), size=numpy.array([W, H]))
+
+
 if __name__ == '__main__':
-    main()
+    if sys.argv[1:2] == ['degenerate']:
+        degenerate_cases()
+    else:
+        main()

@@ -119,3 +119,28 @@ def parity_report(out, ref):
         o, r = out[..., p, :, :], ref[..., p, :, :]
         rows.append((rel_err(o, r), allclose_violations(o, r), int(o.size)))
     return rows
+
+
+# ---- the kernel family a golden test runs on ('rows': the streaming kernels on whole rows - what bench.py times; 'scan': the row-parallel kernels) ----
+MODES = ['rows', 'scan']
+
+
+def pinned(target, mode):
+    """target.set_small_batch(mode) (an engine or a modem); a plan whose shape no scan kernel serves skips 'scan'."""
+    import pytest
+    try:
+        target.set_small_batch(mode)
+    except NotImplementedError as e:
+        pytest.skip('%s: %s' % (mode, str(e)[:80]))
+    return target
+
+
+def skip_unserved(mode, fn):
+    """fn(), skipping the test where a 'scan' pin meets a direction / entry point the scan kernels do not serve"""
+    import pytest
+    try:
+        return fn()
+    except NotImplementedError as e:
+        if mode == 'scan' and 'scan' in str(e):
+            pytest.skip('scan: %s' % str(e)[:80])
+        raise

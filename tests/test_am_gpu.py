@@ -15,10 +15,16 @@ TOL = 1e-5
 PROTO = ['proto', 'proto_avg', 'proto_nofilter', 'proto_625', 'niir', 'niir_hue', 'niir_525']
 
 
+MODES = stacks.MODES      # every golden on the streaming wave pairs AND on the row-parallel scan kernels ('auto' would pick the latter for all of them)
+
+
+@pytest.mark.parametrize('mode', MODES)
 @pytest.mark.parametrize('stack', PROTO + ['niir_grey', 'niir_hue_grey'])
-def test_modulate_frames_golden(stack):
+def test_modulate_frames_golden(stack, mode):
     z = am_stacks.load('am_mod_' + stack)
     im = image.ImageModem(am_stacks.make(stack, z))
+    stacks.pinned(im._engine(), mode)
+    stacks.skip_unserved(mode, lambda: im.modulate_frames(z['inp'][:1], first_frame=int(z['frames'][0])))
     for i, f in enumerate(z['frames']):
         out = im.modulate_frames(z['inp'][i:i + 1], first_frame=int(f))[0]
         assert stacks.rel_err(out, z['out'][i]) < TOL, (stack, int(f))
@@ -52,10 +58,13 @@ def test_niir_noise_level_golden(stack):
         assert stacks.rel_err(rows, z['out'][i]) < TOL, (stack, int(f), 'rows')
 
 
+@pytest.mark.parametrize('mode', MODES)
 @pytest.mark.parametrize('stack', PROTO)
-def test_demodulate_frames_golden(stack):
+def test_demodulate_frames_golden(stack, mode):
     z = am_stacks.load('am_demod_' + stack)
     im = image.ImageModem(am_stacks.make(am_stacks.DECODER_OF.get(stack, stack), z))
+    stacks.pinned(im._engine(), mode)
+    stacks.skip_unserved(mode, lambda: im.demodulate_frames(z['inp'][:1], first_frame=int(z['frames'][0])))
     for i, f in enumerate(z['frames']):
         out = im.demodulate_frames(z['inp'][i:i + 1], first_frame=int(f))[0]
         assert stacks.rel_err(out, z['out'][i]) < TOL, (stack, int(f))
@@ -66,11 +75,13 @@ def test_demodulate_frames_golden(stack):
             assert stacks.rel_err(out[i], z['out'][i]) < TOL
 
 
+@pytest.mark.parametrize('mode', MODES)
 @pytest.mark.parametrize('stack', ['proto', 'niir'])
-def test_row_sequences_golden(stack):
+def test_row_sequences_golden(stack, mode):
     """The stateful per-row protocol with a break in the run and a frame change, at full-height line numbers."""
     z = am_stacks.load('am_rows_' + stack)
     modem = am_stacks.make(stack, z)
+    stacks.pinned(modem, mode)
     for i, (f, y) in enumerate(z['seq']):
         out = numpy.stack(modem.demodulate(int(f), int(y), z['inp'][i]))
         assert stacks.rel_err(out, z['out'][i]) < TOL, (stack, int(f), int(y))
@@ -111,8 +122,8 @@ def test_niir_components_unstripped_noise():
             for y in range(field, 6, 2):
                 got = numpy.stack(modem.demodulate_components(int(f), y, z['inp'][i, y], strip_chroma=False))
                 err = numpy.abs(got - z['out'][k]) / numpy.abs(z['out'][k]).max()
-                # noise input: the hue of single low-saturation samples is ill-conditioned in float32 (tests/test_sim_am.py)
-                assert numpy.quantile(err, 0.999) < TOL and err.max() < 1e-4, (int(f), y, err.max())
+                # (noise input: until round 4 the float32 hue path left single samples near 1e-4 here; the float64 one holds the tolerance)
+                assert err.max() < TOL, (int(f), y, err.max())
                 k += 1
 
 
@@ -135,19 +146,17 @@ def test_niir_round_trip_vs_oracle(stack, size, std, first):
 
 
 def test_niir_full_frame_hue_conditioning():
-    """A full 720x576 frame of a valid signal: everything inside 1e-5 except isolated samples where the hue is
-    ill-conditioned IN THE ALGORITHM - niir.py:131-137 takes the hue as the angle of a decimated product pair and divides by its
-    length; where the hue turns quickly inside the decimator's window that pair gets short (the oracle's `last_normalizer`)
-    and float32 rounding of ~1e-6 of full scale is divided by it.  Asserted: all but 1e-5 of the samples hold the tolerance, the
-    worst stays below 3e-5, and EVERY sample above the tolerance sits where the oracle's pair is shorter than a fifth of its
-    median length."""
+    """A full 720x576 frame of a valid signal, EVERY sample inside 1e-5.  niir.py:131-137 takes the hue as the angle of a decimated product
+    pair and divides by its length; where the hue turns quickly inside the decimator's window that pair gets short (the oracle's
+    `last_normalizer`) and every absolute error in it is divided by it: with the float32 front end of rounds 2 - 3 this frame had samples at
+    3e-5 exactly there (and random pictures up to 4e-3).  The hue path is float64 now (csrc/cm_am_stages.h: NiirHue); the test keeps the
+    oracle's normaliser to show the frame does contain such places and that they are as exact as the rest."""
     from oracle import cm_oracle_am as oa
     size, first = (720, 576), 3
     lc = line.LineConfig(size, line.LineStandard.GERBER_625)
     modem = am_stacks.STACKS['niir'](lc)
     rgb = testing.synthetic_rgb(1, size[1], size[0], seed=55 + size[1])
     comp32 = oa.modulate_frames(modem, rgb.astype(numpy.float64), first).astype(numpy.float32)
-    back = image.ImageModem(modem).demodulate_frames(comp32, first_frame=first)[0]
     want = numpy.zeros((3, size[1], size[0]))
     norm = numpy.zeros((size[1], size[0]))
     orc = oa.make(modem)
@@ -155,10 +164,15 @@ def test_niir_full_frame_hue_conditioning():
         for y in range(field, size[1], 2):
             want[:, y] = numpy.stack(orc.demodulate(first, y, comp32[0, y].astype(numpy.float64)))
             norm[y] = orc.last_normalizer
-    err = numpy.abs(back - want) / numpy.abs(want).max()
-    assert numpy.quantile(err, 1.0 - 1e-5) < TOL and err.max() < 3e-5, (err.max(), numpy.quantile(err, 1.0 - 1e-5))
-    over = (err > TOL).any(axis=0)
-    assert over.sum() < 20 and (norm[over] < 0.2 * numpy.median(norm)).all(), (int(over.sum()), norm[over] / numpy.median(norm))
+    short = norm < 0.05 * numpy.median(norm)
+    assert short.sum() > 50, int(short.sum())           # the frame has places where float32 used to lose the tolerance
+    eng = image.ImageModem(modem)._engine()
+    for mode in ('rows', 'scan'):
+        eng.set_small_batch(mode)
+        back = eng.demodulate_frames(comp32, first_frame=first)[0]
+        err = numpy.abs(back - want) / numpy.abs(want).max()
+        assert err.max() < TOL, (mode, err.max())
+        assert err[:, short].max() < 2e-6, (mode, err[:, short].max())
 
 
 def test_pil_image_round_trip_proto_and_niir():
@@ -252,9 +266,9 @@ def test_niir_small_batch_modes(stack, size, std, first):
         got_d[mode] = eng.demodulate_frames(comp32, first_frame=first)
         assert stacks.rel_err(got_m[mode], comp_ref) < TOL, (stack, mode)
         assert stacks.rel_err(got_m[mode], got_m['rows']) < 2e-6, (stack, mode)
-        for i in range(2):      # (isolated samples where the hue is ill-conditioned in the algorithm: test_niir_full_frame_hue_conditioning)
+        for i in range(2):
             err = numpy.abs(got_d[mode][i] - back_ref[i]) / numpy.abs(back_ref[i]).max()
-            assert numpy.quantile(err, 1.0 - 1e-3) < TOL and err.max() < 3e-5, (stack, mode, i, err.max())
+            assert err.max() < TOL, (stack, mode, i, err.max())
     if size[0] % 16 == 0:
         rgb8 = _as_bytes(rgb.astype(numpy.float64)).transpose(0, 2, 3, 1).copy()
         comp8 = _as_bytes(image.ImageModem.encode_composite_level(comp_ref))
@@ -308,34 +322,33 @@ def test_am_scan_kernels_ignore_stale_lds(stack, size, std):
         assert numpy.array_equal(dec.demodulate_frames(comp, first_frame=1).cpu().numpy(), clean_d)
 
 
-def test_niir_float64_front_end():
-    """`modem.float64_front_end = True` (cm_am_desc.flags | CM_AM_FLOAT64): interpolator, band-pass and low-pass of the NIIR decoder's 3x-rate
-    front end in float64.  On these pictures the float32 decoder leaves isolated samples beyond 1e-5 (the hue of niir.py:131-137 is the
-    angle of a decimated product pair divided by its length; profiles/r03_niir_precision.txt); with the flag EVERY sample holds the
-    tolerance, at one frame and in a batch beyond the float32 kernels' hand-over point, floats and bytes."""
+def test_niir_hue_path_is_float64():
+    """Six 960x40 pictures on which the float32 decoder of round 3 left 10 of 691200 samples beyond 1e-5 (profiles/r03_niir_precision.txt): on
+    the DEFAULT modem every sample holds the tolerance in every kernel - scan, rows (the streaming wave pair), a long batch past the hand-over of
+    the two - floats and bytes; `float64_front_end`, round 3's opt-in, is accepted and changes nothing."""
     from oracle import cm_oracle_am as oa
     from color_modem_amd.image import _as_bytes
     size = (960, 40)
-    worst64, bad32, n = 0.0, 0, 0
+    worst = {}
     for seed in range(1000, 1006):
         rgb = testing.synthetic_rgb(1, size[1], size[0], seed=seed).astype(numpy.float64)
         first = 705 + seed - 1000
-        plain, precise = _am_modem('niir', size, 'GERBER_625'), _am_modem('niir', size, 'GERBER_625')
-        precise.float64_front_end = True
+        plain, flagged = _am_modem('niir', size, 'GERBER_625'), _am_modem('niir', size, 'GERBER_625')
+        flagged.float64_front_end = True
         comp = oa.modulate_frames(plain, rgb, first).astype(numpy.float32)
         want = oa.demodulate_frames(plain, comp.astype(numpy.float64), first)
-        got32 = image.ImageModem(plain).demodulate_frames(comp, first_frame=first)
-        got64 = image.ImageModem(precise).demodulate_frames(comp, first_frame=first)
         scale = numpy.abs(want).max()
-        bad32 += int((numpy.abs(got32 - want) / scale > TOL).sum())
-        worst64 = max(worst64, float((numpy.abs(got64 - want) / scale).max()))
-        n += want.size
-        assert numpy.quantile(numpy.abs(got32 - want) / scale, 1.0 - 1e-3) < TOL
-    assert worst64 < TOL, worst64
-    print('float32 front end: %d of %d samples beyond 1e-5; float64 front end: worst %.2e' % (bad32, n, worst64))
-    # a long batch (the float32 decoder would hand over to the streaming kernel; the float64 front end stays on the scan kernel) and bytes
+        eng = image.ImageModem(plain)._engine()
+        for mode in ('scan', 'rows'):
+            eng.set_small_batch(mode)
+            got = eng.demodulate_frames(comp, first_frame=first)
+            worst[mode] = max(worst.get(mode, 0.0), float((numpy.abs(got - want) / scale).max()))
+        assert numpy.array_equal(image.ImageModem(flagged).demodulate_frames(comp, first_frame=first), image.ImageModem(plain).demodulate_frames(comp, first_frame=first))
+    assert max(worst.values()) < 2e-6, worst
+    print('NIIR decoder, worst sample of six pictures: %s' % worst)
+    # a long batch (auto mode hands over to the streaming kernel) and bytes
     import torch
-    eng = image.ImageModem(precise)._engine()
+    eng = image.ImageModem(plain)._engine()
     big = torch.from_numpy(comp).cuda().repeat(600, 1, 1).contiguous()
     out = eng.demodulate_frames(big, first_frame=first)
     assert stacks.rel_err(out[0].cpu().numpy(), want[0]) < TOL and torch.equal(out[0], out[4 * 149])      # the phase cycle of 4 frames

@@ -67,3 +67,17 @@ def test_image_uint8(name):
     back8 = orc.image_demodulate(int(g['frame']), g['comp8'])
     diff = numpy.abs(back8.astype(int) - g['back8'].astype(int))
     assert diff.max() <= 1 and (diff > 0).mean() < 1e-3
+
+
+def test_degenerate_inputs():
+    """Black / white / grey / saturated pictures and all-zero / constant composites through every family of the ORACLE (the C++ one and the numpy
+    ones of MAC / Proto-SECAM / NIIR) against vectors the reference produced on exactly these inputs (tests/golden/degenerate_*.npz): until round
+    4 the oracle was pinned on random pictures only - and had once been 0.07 off the reference on grey ones (NIIR, round 3).  NIIR: NaN in exactly
+    the samples where the reference divides 0 / 0.  One case is excluded by name (degenerate_inputs.KNOWN)."""
+    import degenerate_inputs
+    rows = degenerate_inputs.run('oracle')
+    assert len(rows) >= 70
+    for name, direction, tag, e, note in rows:
+        if (name, direction, tag) in degenerate_inputs.KNOWN:
+            continue
+        assert e < 1e-9, (name, direction, tag, e, note)

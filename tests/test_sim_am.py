@@ -123,6 +123,34 @@ def test_niir_runs_against_oracle(stack, size, std, use_float):
         assert numpy.quantile(err, 0.999) < (1e-5 if use_float else 1e-10) and err.max() < (1e-4 if use_float else 1e-10), (stack, 'components', frame)
 
 
+@pytest.mark.parametrize('stack,size,std', NIIR_CASES)
+def test_niir_decoder_precision_split(stack, size, std):
+    """What the device decoders compute since round 4 (cm_am_stages.h: NiirHue; the simulator's mode 4): the hue path - interpolator,
+    band-pass, low-pass, M / S, the hue products and their two decimators - in float64, saturation / re-modulation / niir_finish in float32.
+    EVERY sample inside 2e-6 of full scale on pictures where the all-float32 build (mode 1, above) needs its quantile."""
+    L = _lib()
+    lc = line.LineConfig(size, getattr(line.LineStandard, std))
+    modem = am_stacks.STACKS[stack](lc)
+    desc = plan_am.build_am_desc(modem)
+    comp_desc = plan_am.build_am_desc(modem, components=True)
+    W, H = size
+    rgb = testing.synthetic_rgb(1, H, W, seed=23)[0].astype(numpy.float64)
+    for frame, field in ((1, 0), (4798, 1)):
+        lines = list(range(field, H, 2))
+        rows = numpy.stack([rgb[:, y] for y in lines])
+        orc = oa.make(modem)
+        delay = 1 if stack == 'niir_hue' else 0
+        comp = numpy.stack([orc.modulate(frame, y + 2 * delay, *rows[i]) for i, y in enumerate(lines)])
+        dec = oa.make(modem)
+        back = numpy.stack([numpy.stack(dec.demodulate(frame, y, comp[i])) for i, y in enumerate(lines)])
+        got = _run(L.am_sim_demod_run, desc, 4, comp, (len(lines), 3, W), frame, field, 0)
+        assert (numpy.abs(got - back) / max(1.0, numpy.abs(back).max())).max() < 2e-6, (stack, 'demod', frame)
+        dec = oa.make(modem)
+        back = numpy.stack([numpy.stack(dec.demodulate_components(frame, y, comp[i], strip_chroma=False)) for i, y in enumerate(lines)])
+        got = _run(L.am_sim_demod_run, comp_desc, 4 | 2, comp, (len(lines), 3, W), frame, field, 0)
+        assert (numpy.abs(got - back) / max(1.0, numpy.abs(back).max())).max() < 2e-6, (stack, 'components', frame)
+
+
 @pytest.mark.parametrize('stack', ['niir', 'niir_hue'])
 @pytest.mark.parametrize('use_float', [0, 1])
 def test_niir_encoder_on_grey_pictures(stack, use_float):

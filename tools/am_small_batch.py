@@ -20,14 +20,13 @@ for stack, size, std in (('proto', (720, 736), 'FRENCH_819'), ('niir', (720, 576
         for mode in ('rows', 'scan', 'auto'):
             eng.set_small_batch(mode)
             print('%-9s %2d frame(s) %dx%d %-5s: modulate %.0f us, demodulate %.0f us' % (stack, F, W, H, mode, timeit(lambda: eng.modulate_frames(rgb, 0)), timeit(lambda: eng.demodulate_frames(comp, 0))), flush=True)
-# the NIIR decoder with its float64 front end (cm_am_desc.flags | CM_AM_FLOAT64): the scan kernel at every batch size
+# the NIIR decoder (hue path in float64) in auto mode over the hand-over point of the two kernels
 lc = line.LineConfig((720, 576), line.LineStandard.GERBER_625)
-m64 = am_stacks.STACKS['niir'](lc); m64.float64_front_end = True
-eng = image.ImageModem(m64)._engine()
+eng = image.ImageModem(am_stacks.STACKS['niir'](lc))._engine()
 for F in (1, 4, 16, 64, 256):
     comp = eng.modulate_frames(torch.rand((F, 3, 576, 720), device='cuda'), 0)
     t = timeit(lambda: eng.demodulate_frames(comp, 0))
-    print('niir f64  %3d frame(s) 720x576: demodulate %.0f us  (%.1f Gpixel/s)' % (F, t, F * 720 * 576 / t / 1e3), flush=True)
+    print('niir auto %3d frame(s) 720x576: demodulate %.0f us  (%.1f Gpixel/s)' % (F, t, F * 720 * 576 / t / 1e3), flush=True)
 lc = line.LineConfig((720, 576))
 eng = image.ImageModem(mac.MacModem(lc))._engine()
 rgb = torch.rand((1, 3, 576, 720), device='cuda'); comp = eng.modulate_frames(rgb, 0)
