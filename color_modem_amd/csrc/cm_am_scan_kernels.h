@@ -156,7 +156,7 @@ __device__ __forceinline__ void scan_get3(const lds_float *R0, const lds_float *
 // Proto-SECAM decoder (ProtoDemod::step + proto_demod_kernel's finish): workgroup = NW - 1 calls behind one halo wave.
 // =============================================================================================================================
 template <int C1, int NW, bool U8 = false>
-__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2))) void proto_demod_scan_kernel(const Geom g, const AmGeom am, const ScanProtoK *km) {
+__global__ __launch_bounds__(64 * NW) void proto_demod_scan_kernel(const Geom g, const AmGeom am, const ScanProtoK *km) {
     constexpr int C3 = 3 * C1, N1 = 64 * C1, MG = kScanMargin, kRow = N1 + 2 * MG;
     extern __shared__ __attribute__((aligned(16))) float scan_lds[];
     const int lane = threadIdx.x & 63;
@@ -258,7 +258,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
 // no barrier - inside ColorAveragingModem (comb.py:141-152) the previous call's row comes straight from memory.
 // =============================================================================================================================
 template <int C1, int NW, bool U8 = false>
-__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2))) void proto_mod_scan_kernel(const Geom g, const AmGeom am, const ScanProtoModK *km) {
+__global__ __launch_bounds__(64 * NW) void proto_mod_scan_kernel(const Geom g, const AmGeom am, const ScanProtoModK *km) {
     constexpr int C3 = 3 * C1, N1 = 64 * C1, MG = kScanMargin, kRow = N1 + 2 * MG;
     extern __shared__ __attribute__((aligned(16))) float scan_lds[];
     const int lane = threadIdx.x & 63;
@@ -494,7 +494,7 @@ __device__ __forceinline__ void scan_get3_d(const lds_double *R0, const lds_doub
 // [D_c | D_s | A_c | A_s] W each - the reference, its decimation and the decimation of its derivative for cos / sin(n step); the reference of a
 // line is linear in (sin, cos) of its start phase, so a first line needs no second front end and no rows of its own.
 template <int C1, int NW, bool U8 = false>
-__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2))) void niir_demod_scan_kernel(const Geom g, const AmGeom am, const ScanNiirK *km,
+__global__ __launch_bounds__(64 * NW) void niir_demod_scan_kernel(const Geom g, const AmGeom am, const ScanNiirK *km,
                                                                                                             const ScanNiirK64 *km64, const double *syn,
                                                                                                             double line_phase_shift, double bandpass_phase_shift,
                                                                                                             int strip_i) {

@@ -352,11 +352,15 @@ __device__ __forceinline__ void scan_store_rgb4_u8(float *row, int n, const f4 &
 // (NW - depth calls behind depth halo waves).  Dynamic LDS: NW * scan_wave_floats<C1>() floats.
 template <int C1> constexpr int scan_wave_floats() { return 5 * (64 * C1 + 2 * kScanMargin); }      // x and the two halves of P and Q
 
-// amdgpu_waves_per_eu(2, 2): at most 256 registers per lane.  Left alone the compiler takes 256 VGPRs + 21 / 102 AGPRs for the long
-// chunks and parks values in the AGPRs - and those builds gave wrong, run-to-run different results on the device
-// (profiles/r03_scan_notes.txt item 4); with the cap the same values go through 92 / 460 B of scratch per lane and the results are exact.
+// Registers: the chunks of 24 / 32 samples need more than 256 per lane; the compiler takes 256 VGPRs + 42 / 104 AGPRs and parks values in the
+// AGPRs (one wave per SIMD - the LDS rows allow one workgroup per CU at these chunks anyway).  Round 3 capped the kernel at 256 registers
+// (amdgpu_waves_per_eu(2, 2): 92 / 460 B of scratch per lane) because its AGPR builds had given wrong, run-to-run different results; round 4 went
+// back with a register poison (tests/poison.py: NaNs in every VGPR / AGPR / LDS byte before the launch) and found the uncapped build of the
+// CURRENT source exact, bit-identical under every poison and green on the whole GPU suite: the fault was the LDS ordering hazard found later in
+// round 3 - lanes of a wavefront exchanging rows without a compiler-level fence, fixed by scan_fence() behind every row writer - which another
+// register allocation had merely exposed.  Without the cap: 1280 x 576 84 -> 73 us, 1920 x 576 156 -> 125 us per frame (profiles/r04_scan_notes.txt).
 template <int C1, int NW, bool U8 = false>
-__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2))) void demod_scan_kernel(const Geom gm, const Geom gf, const ScanK *km, const ScanK *kf, int n_first) {
+__global__ __launch_bounds__(64 * NW) void demod_scan_kernel(const Geom gm, const Geom gf, const ScanK *km, const ScanK *kf, int n_first) {
     constexpr int C2 = 2 * C1, N1 = 64 * C1, MG = kScanMargin;
     constexpr int kX = N1 + 2 * MG;       // one 1x-rate row with its margins; a 2x-rate row is two of them (even / odd samples)
     extern __shared__ __attribute__((aligned(16))) float scan_lds[];
@@ -1208,7 +1212,7 @@ typedef const __attribute__((address_space(4))) ScanSecamK const_ScanSecamK;
 template <int C1> constexpr int scan_secam_wave_floats() { return 7 * (64 * C1 + 2 * kScanMargin); }
 
 template <int C1, int NW, bool U8 = false>
-__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2))) void secam_demod_scan_kernel(const Geom g, const ScanSecamK *km) {
+__global__ __launch_bounds__(64 * NW) void secam_demod_scan_kernel(const Geom g, const ScanSecamK *km) {
     constexpr int C2 = 2 * C1, N1 = 64 * C1, MG = kScanMargin, kRow = N1 + 2 * MG;
     extern __shared__ __attribute__((aligned(16))) float scan_lds[];
     typedef __attribute__((address_space(3))) double lds_double;

@@ -297,8 +297,10 @@ def test_niir_small_batch_modes(stack, size, std, first):
                                             ('proto_avg', (1000, 24), 'FRENCH_819')])
 def test_am_scan_kernels_ignore_stale_lds(stack, size, std):
     """The Proto-SECAM / NIIR scan kernels keep every signal of a row in LDS rows whose margins they must have written themselves: launches
-    that leave NaNs all over the LDS of every CU (the streaming kernels on NaN frames) in front of them must not change a bit of their results."""
+    that leave NaNs all over the LDS of every CU (the streaming kernels on NaN frames), then a NaN / a huge finite pattern in every vector and
+    accumulator register and every LDS byte of the device (tests/poison.py), in front of them must not change a bit of their results."""
     import torch
+    import poison as reg
     modem = _am_modem(stack, size, std)
     inner = modem.backend if stack == 'proto_avg' else modem
     enc, dec = image.ImageModem(modem)._engine(), image.ImageModem(inner)._engine()
@@ -311,15 +313,19 @@ def test_am_scan_kernels_ignore_stale_lds(stack, size, std):
     assert numpy.isfinite(clean_m).all() and numpy.isfinite(clean_d).all()
     poison_rgb = torch.full((48, 3, size[1], size[0]), float('nan'), device='cuda')
     poison_comp = torch.full((48, size[1], size[0]), float('nan'), device='cuda')
-    for _ in range(2):
+    for pattern in (None, 0x7fc0babe, 0x7f7fffff):
         for e in (enc, dec):
             e.set_small_batch('rows')
         enc.modulate_frames(poison_rgb, first_frame=0)
         dec.demodulate_frames(poison_comp, first_frame=0)
         for e in (enc, dec):
             e.set_small_batch('scan')
-        assert numpy.array_equal(enc.modulate_frames(rgb, first_frame=1).cpu().numpy(), clean_m)
-        assert numpy.array_equal(dec.demodulate_frames(comp, first_frame=1).cpu().numpy(), clean_d)
+        if pattern is not None:
+            reg.poison(pattern)
+        assert numpy.array_equal(enc.modulate_frames(rgb, first_frame=1).cpu().numpy(), clean_m), pattern
+        if pattern is not None:
+            reg.poison(pattern)
+        assert numpy.array_equal(dec.demodulate_frames(comp, first_frame=1).cpu().numpy(), clean_d), pattern
 
 
 def test_niir_hue_path_is_float64():

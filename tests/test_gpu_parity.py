@@ -770,20 +770,26 @@ def test_small_batch_modes_modulate(stack, size):
 
 @pytest.mark.parametrize('size', [(720, 256), (960, 128), (1280, 128), (1920, 64)])
 def test_scan_kernel_ignores_stale_lds(size):
-    """The scan kernel keeps every signal of a row in LDS rows with margins it must have written itself: a launch that leaves
-    NaNs all over the LDS of every CU (the streaming kernel on NaN frames) in front of it must not change a bit of its result."""
+    """The scan kernel keeps every signal of a row in LDS rows with margins it must have written itself, and its chunks in registers it
+    must have written itself: launches that leave NaNs all over the LDS of every CU (the streaming kernel on NaN frames), and then a NaN / a
+    huge finite pattern in EVERY vector and accumulator register and LDS byte of the device (tests/poison.py, round 4), in front of it must
+    not change a bit of its result.  (Chunks of 24 / 32 samples - the 1280 / 1920 cases - spill: the register poison is what would show a
+    value read back that was never written.)"""
     import torch
+    import poison as reg
     eng = image.ImageModem(stacks.make('pal_d', size))._engine()
     comp = torch.from_numpy(testing.synthetic_composite(1, size[1], size[0], seed=5)).cuda()
     eng.set_small_batch('scan')
     clean = eng.demodulate_frames(comp, first_frame=1).cpu().numpy()
     assert numpy.isfinite(clean).all()
     poison = torch.full((64, size[1], size[0]), float('nan'), device='cuda')
-    for _ in range(3):
+    for pattern in (None, 0x7fc0babe, 0x7f7fffff):
         eng.set_small_batch('rows')
         eng.demodulate_frames(poison, first_frame=0)
+        if pattern is not None:
+            reg.poison(pattern)
         eng.set_small_batch('scan')
-        assert numpy.array_equal(eng.demodulate_frames(comp, first_frame=1).cpu().numpy(), clean)
+        assert numpy.array_equal(eng.demodulate_frames(comp, first_frame=1).cpu().numpy(), clean), pattern
 
 
 # ---- comb wrappers around the PAL delay-line decoders (color_modem_amd/wrapped.py, csrc/cm_wrap_kernels.h) -----------------
@@ -929,8 +935,10 @@ def test_hip_graph_capture():
                                             ('simple_pal3d_notch', 'pal_avg', (704, 48)), ('ntsc_comb_3d', 'ntsc', (1280, 32))])
 def test_other_scan_kernels_ignore_stale_lds(stack, enc, size):
     """As test_scan_kernel_ignores_stale_lds, for the SECAM scan kernels, the wrapped combs' back end and the encoders' scan kernels: NaNs
-    left in LDS by the streaming kernels on NaN frames must not change a bit of what the scan kernels return."""
+    left in LDS by the streaming kernels on NaN frames, then NaNs / huge values in every register and LDS byte of the device (tests/poison.py),
+    must not change a bit of what the scan kernels return."""
     import torch
+    import poison as reg
     dec_e = image.ImageModem(stacks.make(stack, size))._engine()
     enc_e = image.ImageModem(stacks.make(enc, size))._engine()
     rgb = torch.from_numpy(testing.synthetic_rgb(1, size[1], size[0], seed=6)).cuda()
@@ -941,15 +949,19 @@ def test_other_scan_kernels_ignore_stale_lds(stack, enc, size):
     assert numpy.isfinite(clean_m).all() and numpy.isfinite(clean_d).all()
     poison_rgb = torch.full((48, 3, size[1], size[0]), float('nan'), device='cuda')
     poison_comp = torch.full((48, size[1], size[0]), float('nan'), device='cuda')
-    for _ in range(2):
+    for pattern in (None, 0x7fc0babe, 0x7f7fffff):
         for e in (enc_e, dec_e):
             e.set_small_batch('rows')
         enc_e.modulate_frames(poison_rgb, first_frame=0)
         dec_e.demodulate_frames(poison_comp, first_frame=0)
         for e in (enc_e, dec_e):
             e.set_small_batch('scan')
-        assert numpy.array_equal(enc_e.modulate_frames(rgb, first_frame=1).cpu().numpy(), clean_m)
-        assert numpy.array_equal(dec_e.demodulate_frames(comp, first_frame=1).cpu().numpy(), clean_d)
+        if pattern is not None:
+            reg.poison(pattern)
+        assert numpy.array_equal(enc_e.modulate_frames(rgb, first_frame=1).cpu().numpy(), clean_m), pattern
+        if pattern is not None:
+            reg.poison(pattern)
+        assert numpy.array_equal(dec_e.demodulate_frames(comp, first_frame=1).cpu().numpy(), clean_d), pattern
 
 
 @pytest.mark.gpu
