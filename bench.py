@@ -39,10 +39,11 @@ if ROOT not in sys.path:
 WIDTH, HEIGHT = 720, 576
 HBM_PEAK_GBPS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 BYTES_PER_PIXEL = 16        # float32: one composite sample read, R, G, B written
-# vector-pipe side of the same kernel: float32 FMA-equivalents the kernel executes per pixel
-# (instruction count of the main loop, cm_plan_describe) against the chip's vector float32 peak and against what a bare
-# v_fma_f32 loop sustains under the board's power cap (profiles/r01_ubench_valu.txt)
-FMA_EQ_PER_PIXEL = 229
+# vector-pipe side of the same kernel: float32 FMA-equivalents the kernel executes per pixel, counted
+# from the ISA of the interior bodies of this tree (tools/isa_fma_census.py: 1 per scalar float instruction, 2 per v_pk_*_f32;
+# stage A 76.5 + stage B 129.0, the per-stage table in profiles/r04_headline_bound.txt), against the chip's vector float32
+# peak and against what a bare v_fma_f32 loop sustains under the board's power cap (profiles/r01_ubench_valu.txt)
+FMA_EQ_PER_PIXEL = 205.5
 VALU_PEAK_TFLOPS = 157.3
 VALU_SUSTAINED_TFLOPS = 119.0
 
@@ -309,8 +310,8 @@ def main():
                               'frac': round(valu_tflops / VALU_PEAK_TFLOPS, 4),
                               'sustained_peak': VALU_SUSTAINED_TFLOPS, 'frac_of_sustained': round(valu_tflops / VALU_SUSTAINED_TFLOPS, 4),
                               'fma_equivalents_per_pixel': FMA_EQ_PER_PIXEL,
-                              'note': 'an ESTIMATE of the arithmetic: float32 FMA-equivalents of the PAL-D main loops per pixel '
-                                      '(counted from the ISA in round 1; packing changes the instruction count, not this number) x 2 '
+                              'note': 'float32 FMA-equivalents of the PAL-D interior bodies per pixel '
+                                      '(counted from the ISA of the interior bodies, tools/isa_fma_census.py, profiles/r04_headline_bound.txt) x 2 '
                                       'flop; sustained_peak = a bare v_fma_f32 loop under the 1400 W cap (profiles/r01_ubench_valu.txt)'},
             'check': {'max_rel_err': float('%.3g' % worst), 'allclose_violations': bad, 'tolerance': 1e-5,
                       'frames': picks if world == 1 else 'rank 0: %s, other ranks: their last frame' % picks,
