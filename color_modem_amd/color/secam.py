@@ -9,7 +9,7 @@ The per-sample encode/decode (secam.py:127-149, 240-304) runs in the HIP kernels
 import collections
 
 import numpy
-import scipy.signal
+from color_modem_amd import design
 
 from color_modem_amd import utils
 from color_modem_amd.rowapi import RowApi
@@ -131,7 +131,7 @@ class SecamModem(RowApi):
     def _chroma_precorrect_design(wc, k):
         """LF pre-emphasis 1 + (k - 1) * highpass and its exact inverse (ref secam.py:211-221)."""
         assert k != 1.0
-        hp_b, hp_a = scipy.signal.iirfilter(1, k * wc, btype='highpass', ftype='butter')
+        hp_b, hp_a = design.iirfilter(1, k * wc, btype='highpass', ftype='butter')
         assert hp_a[0] == 1.0
         fwd_b = numpy.array([(k - 1.0) * hp_b[0] + 1.0, (k - 1.0) * hp_b[1] + hp_a[1]])
         fwd_a = numpy.array(hp_a, dtype=numpy.float64)

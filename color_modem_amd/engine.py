@@ -344,7 +344,7 @@ class MacEngine(_EngineBase):
 
     def __init__(self, modem, components=False):
         import fractions
-        import scipy.signal
+        from color_modem_amd import design
         from color_modem_amd.color import mac
         stack = modem._stack()
         if stack.get('demod_wrapper'):
@@ -373,7 +373,7 @@ class MacEngine(_EngineBase):
             f.up, f.down = fr.numerator, fr.denominator
             if f.up != f.down:
                 max_rate = max(f.up, f.down)
-                h = f.up * scipy.signal.firwin(2 * 10 * max_rate + 1, 1.0 / max_rate, window=('kaiser', 5.0))
+                h = f.up * design.resample_poly_fir(max_rate)
                 h = numpy.ascontiguousarray(h, dtype=numpy.float64)
                 self._keep.append(h)
                 f.n_taps = len(h)

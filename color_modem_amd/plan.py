@@ -20,7 +20,7 @@ symbolic objects (`Lin`), in float64.
 import ctypes
 
 import numpy
-import scipy.signal
+from color_modem_amd import design
 
 CM_ABI_VERSION = 6
 CM_SECAM_PRESENT, CM_SECAM_FLOAT64 = 1, 2      # cm_secam_desc.present (include/color_modem_hip.h)
@@ -170,7 +170,7 @@ def iir_desc(filt, bandpass=False):
 
 def resample_fir():
     # the filter scipy.signal.resample_poly designs for up/down = 2 (ref qam.py:35 etc.)
-    return scipy.signal.firwin(41, 0.5, window=('kaiser', 5.0))
+    return design.resample_poly_fir(2)
 
 
 # ---------------------------------------------------------------------------------------------

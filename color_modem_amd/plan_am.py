@@ -5,7 +5,7 @@ ColorAveragingModem(ProtoSecamModem), NiirModem, HueCorrectingNiirModem."""
 import ctypes
 
 import numpy
-import scipy.signal
+from color_modem_amd import design
 
 from color_modem_amd import plan
 
@@ -28,7 +28,7 @@ class AmDesc(ctypes.Structure):
 
 def resample_fir3():
     """the filter scipy.signal.resample_poly designs for up / down = 3 (protosecam.py:83, 85, 96, 101, 102; niir.py:109 ...)"""
-    return scipy.signal.firwin(61, 1.0 / 3.0, window=('kaiser', 5.0))
+    return design.resample_poly_fir(3)
 
 
 def build_am_desc(modem, components=False, strip_chroma=True):

@@ -3,21 +3,24 @@
 
 Mirrors the names of the reference's ``color_modem/utils.py`` (``FilterFunction``,
 ``iirfilter``, ``iirdesign``, ``iirdesign_wc``, ``iirsplitter``, ``ConstantFrequencyCarrier``;
-/root/reference/color_modem/utils.py:9-88).  Design runs once per modem on the host with
-scipy.signal, exactly the third-party calls the reference makes; what differs is what a
-``FilterFunction`` *is* here: a design record (b, a, shift, phase_shift, second-order
-sections) that the device plan consumes.  Filtering itself happens in the HIP kernels.
+/root/reference/color_modem/utils.py:9-88).  Design runs once per modem on the host with the
+package's own design code (``color_modem_amd/design.py``: the algorithms behind the
+scipy.signal calls the reference makes, held to scipy's results by tests/test_design.py - no
+scipy at run time since round 4); what differs is what a ``FilterFunction`` *is* here: a design
+record (b, a, shift, phase_shift, second-order sections) that the device plan consumes.
+Filtering itself happens in the HIP kernels.
 
 ``iirdesign`` keeps the behaviour of the scipy release the reference was written against:
 scipy >= 1.12 rejects band edges <= 0, which the reference's NTSC-M set-up relies on
-(SURVEY.md D6).  We therefore call ``buttord`` + ``iirfilter`` directly - identical
-coefficients wherever current scipy accepts the request.
+(SURVEY.md D6).  ``design.buttord`` + ``design.iirfilter`` take the request as it is - identical
+coefficients wherever current scipy accepts it.
 """
 
 import fractions
 
 import numpy
-import scipy.signal
+
+from color_modem_amd import design
 
 _BANDSTOP_NAMES = frozenset(('bs', 'bandstop', 'bands', 'stop'))
 
@@ -36,11 +39,10 @@ class FilterFunction(object):
             centre = 0.0
         self.shift_frequency = centre
         if shift:
-            delay = scipy.signal.group_delay((self.b, self.a), [centre], fs=2.0)[1]
-            self.shift = int(numpy.round(delay[0]))
+            self.shift = int(numpy.round(design.group_delay_at(self.b, self.a, centre)))
         else:
             self.shift = 0
-        response = scipy.signal.freqz(self.b, self.a, worN=[centre], fs=2.0)[1][0]
+        response = design.freqz_at(self.b, self.a, centre)
         self.phase_shift = float((numpy.angle(response) + self.shift * numpy.pi * centre) % (2.0 * numpy.pi))
 
     # the reference keeps these as private attributes; expose both spellings
@@ -68,7 +70,7 @@ class FilterFunction(object):
         smear repeated roots by ~1e-8), otherwise factored from (b, a)."""
         if self._sos is not None:
             return self._sos
-        return scipy.signal.tf2sos(self.b, self.a)
+        return design.tf2sos(self.b, self.a)
 
     def __call__(self, x):
         raise RuntimeError('FilterFunction is a design record in color_modem_amd; rows are filtered on the GPU '
@@ -77,13 +79,13 @@ class FilterFunction(object):
 
 def notch(qam_modem, q):
     """Luma notch at the sub-carrier (ref comb.py:18-20)."""
-    b, a = scipy.signal.iirnotch(2.0 * qam_modem.config.fsc / qam_modem.line_config.fs, q)
+    b, a = design.iirnotch(2.0 * qam_modem.config.fsc / qam_modem.line_config.fs, q)
     return FilterFunction(b, a, wp=0.0, btype='bandstop', shift=True)
 
 
 def iirfilter(N, Wn, rp=None, rs=None, btype='band', ftype='butter', shift=True):
-    b, a = scipy.signal.iirfilter(N, Wn, rp, rs, btype, ftype=ftype)
-    sos = scipy.signal.iirfilter(N, Wn, rp, rs, btype, ftype=ftype, output='sos')
+    b, a = design.iirfilter(N, Wn, rp, rs, btype, ftype=ftype)
+    sos = design.iirfilter(N, Wn, rp, rs, btype, ftype=ftype, output='sos')
     return FilterFunction(b, a, Wn, btype, shift, sos=sos)
 
 
@@ -96,9 +98,9 @@ def _legacy_scipy_iirdesign(wp, ws, gpass, gstop, ftype):
         btype = 'lowpass' if wp[0] < ws[0] else 'highpass'
     else:
         btype = 'bandstop' if wp[0] < ws[0] else 'bandpass'
-    order, natural = scipy.signal.buttord(wp, ws, gpass, gstop, analog=False)
-    ba = scipy.signal.iirfilter(order, natural, rp=gpass, rs=gstop, btype=btype, ftype='butter', output='ba')
-    sos = scipy.signal.iirfilter(order, natural, rp=gpass, rs=gstop, btype=btype, ftype='butter', output='sos')
+    order, natural = design.buttord(wp, ws, gpass, gstop)
+    ba = design.iirfilter(order, natural, rp=gpass, rs=gstop, btype=btype, ftype='butter', output='ba')
+    sos = design.iirfilter(order, natural, rp=gpass, rs=gstop, btype=btype, ftype='butter', output='sos')
     return ba[0], ba[1], sos
 
 

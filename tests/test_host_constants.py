@@ -80,7 +80,7 @@ def test_resample_fir_matches_scipy_and_oracle():
     import ctypes
     from oracle import cm_oracle
     h_ref = numpy.array([float(v) for v in PLANS['resample_fir']])
-    numpy.testing.assert_allclose(plan.resample_fir(), h_ref, rtol=0, atol=1e-17)
+    numpy.testing.assert_allclose(plan.resample_fir(), h_ref, rtol=0, atol=2e-16)  # color_modem_amd/design.py's own Kaiser / I0 series vs the reference's scipy: 1 ulp of the centre tap
     h = numpy.empty(41)
     cm_oracle.lib().orc_firwin41(h.ctypes.data_as(ctypes.POINTER(ctypes.c_double)))
     numpy.testing.assert_allclose(h, h_ref, rtol=0, atol=1e-15)  # own Kaiser/I0 evaluation vs scipy: 1-2 ulp
