@@ -246,8 +246,11 @@ def main():
     rccl_ranks, gather = None, None
     if dist is not None:
         t = torch.tensor([elapsed, worst, float(bad)], dtype=torch.float64, device=device if backend == 'nccl' else 'cpu')
+        tmin = t[0:1].clone()
+        dist.all_reduce(tmin, op=dist.ReduceOp.MIN)       # the fastest rank's wall time beside the slowest (the reported one)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed, worst, bad = float(t[0]), float(t[1]), int(t[2])
+        rank_ms = {'min': round(float(tmin[0]) / args.steps * 1e3, 4), 'max': round(elapsed / args.steps * 1e3, 4)}
         ones = torch.ones(1, dtype=torch.int32, device=device if backend == 'nccl' else 'cpu')
         dist.all_reduce(ones, op=dist.ReduceOp.SUM)      # one element per rank through the collective library itself
         if backend == 'nccl':
@@ -320,6 +323,7 @@ def main():
         }
         if world > 1:
             res['rccl_ranks'] = rccl_ranks
+            res['ms_per_step_ranks'] = rank_ms
             res['gather'] = gather
             if backend != 'nccl':
                 res['rehearsal'] = 'backend %s, %d ranks on %d GPU(s): launch-path rehearsal, not a scaling measurement' \

@@ -1148,6 +1148,74 @@ int cm_device_count(void) {
     return n;
 }
 
+// ---- FilterFunction.__call__ (utils.py:28-36) as a callable of its own: float64, one lane per row -------------------------------
+}  // extern "C"
+namespace {
+struct FilterRowsArgs {
+    double b[CM_FILTER_MAX_TAPS], a[CM_FILTER_MAX_TAPS];     // a[0] = 1 (normalised on the host), zero-padded
+    int n_taps, shift, width;
+    long long rows;
+    const double *x;
+    double *y;
+};
+// scipy.signal.lfilter's recurrence (transposed direct form II: y = z0 + b0 x; z_i = z_{i+1} + b_{i+1} x - a_{i+1} y), unfused
+// multiply / add / subtract in its order, on the row padded as utils.py:31-35 pads it: `shift` copies of the last sample behind it and the
+// first `shift` results dropped (shift > 0), or -shift copies of the first sample in front and the last -shift results dropped (shift < 0).
+__global__ __launch_bounds__(64) void filter_rows_kernel(const FilterRowsArgs k) {
+    const long long row = (long long)blockIdx.x * 64 + threadIdx.x;
+    if (row >= k.rows) return;
+    const double *x = k.x + row * k.width;
+    double *y = k.y + row * k.width;
+    double z[CM_FILTER_MAX_TAPS];
+#pragma unroll
+    for (int i = 0; i < CM_FILTER_MAX_TAPS; ++i) z[i] = 0.0;
+    const int W = k.width, s = k.shift, lead = s < 0 ? -s : 0, drop = s > 0 ? s : 0;
+    const int total = W + lead + drop;
+    for (int t = 0; t < total; ++t) {
+        int j = t - lead;
+        j = j < 0 ? 0 : (j > W - 1 ? W - 1 : j);
+        const double xin = x[j];
+        const double out = __dadd_rn(z[0], __dmul_rn(k.b[0], xin));
+#pragma unroll
+        for (int i = 0; i < CM_FILTER_MAX_TAPS - 1; ++i)
+            if (i + 1 < k.n_taps) z[i] = __dsub_rn(__dadd_rn(z[i + 1], __dmul_rn(xin, k.b[i + 1])), __dmul_rn(out, k.a[i + 1]));
+        const int o = t - drop;
+        if (o >= 0 && o < W) y[o] = out;
+    }
+}
+}  // namespace
+extern "C" {
+int cm_filter_rows_f64(const double *b, int32_t n_b, const double *a, int32_t n_a, int32_t shift, const double *x, double *y, int64_t n_rows,
+                       int32_t width, void *stream) {
+    if (!b || !a || n_b < 1 || n_a < 1) return fail(CM_ERR_INVALID, "null or empty coefficient array");
+    if (n_b > CM_FILTER_MAX_TAPS || n_a > CM_FILTER_MAX_TAPS)
+        return fail(CM_ERR_UNSUPPORTED, "filter order beyond CM_FILTER_MAX_TAPS - 1 = " + std::to_string(CM_FILTER_MAX_TAPS - 1));
+    if (a[0] == 0.0) return fail(CM_ERR_INVALID, "a[0] must not be zero");
+    if (n_rows < 0 || width < 1) return fail(CM_ERR_INVALID, "rows must not be negative, width must be positive");
+    if (shift <= -width || shift >= (1 << 20)) return fail(CM_ERR_INVALID, "shift out of range");
+    if (n_rows == 0) return CM_OK;
+    if (!x || !y) return fail(CM_ERR_INVALID, "null argument");
+    int cur = -1;
+    if (hipGetDevice(&cur) != hipSuccess) return fail(CM_ERR_NO_DEVICE, "hipGetDevice failed");
+    if (int rc_ = check_device(cur, x, y)) return rc_;
+    FilterRowsArgs k;
+    std::memset(&k, 0, sizeof k);
+    k.n_taps = n_b > n_a ? n_b : n_a;
+    for (int i = 0; i < n_b; ++i) k.b[i] = b[i] / a[0];      // lfilter normalises by a[0] first
+    for (int i = 0; i < n_a; ++i) k.a[i] = a[i] / a[0];
+    k.shift = shift;
+    k.width = width;
+    k.rows = n_rows;
+    k.x = x;
+    k.y = y;
+    const long long blocks = (n_rows + 63) / 64;
+    if (blocks > 0x7fffffffLL) return fail(CM_ERR_INVALID, "batch too large for one launch");
+    hipLaunchKernelGGL(filter_rows_kernel, dim3((unsigned)blocks), dim3(64), 0, (hipStream_t)stream, k);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(CM_ERR_LAUNCH, std::string("filter_rows_kernel launch: ") + hipGetErrorString(e));
+    return CM_OK;
+}
+
 int cm_plan_create(const cm_plan_desc *desc, cm_plan **out) {
     if (!desc || !out) return fail(CM_ERR_INVALID, "null argument");
     *out = nullptr;
@@ -2441,6 +2509,18 @@ int check_wrap(const cm_plan *inner, const cm_plan *first, const cm_plan *backen
     if (w->own_delay < 0 || w->own_delay > 1) return fail(CM_ERR_INVALID, "own_delay must be 0 or 1");
     return CM_OK;
 }
+// one non-blocking side stream per device, created on first use (the wrapped combs' first-line pass runs on it)
+hipStream_t wrap_side_stream(int device) {
+    static std::mutex mu;
+    static hipStream_t streams[64] = {};
+    if (device < 0 || device >= 64) return nullptr;
+    std::lock_guard<std::mutex> lock(mu);
+    if (!streams[device] && hipStreamCreateWithFlags(&streams[device], hipStreamNonBlocking) != hipSuccess) {
+        (void)hipGetLastError();
+        streams[device] = nullptr;
+    }
+    return streams[device];
+}
 // inner decoder over the calls of `g` into `scratch` ([frame][call][3][wp], or [call][3][wp] in rows mode), + the plain call 0s
 int run_wrap_inner(const cm_plan *inner, const cm_plan *first, Geom g, float *scratch, int64_t first_frame, bool with_first,
                    hipStream_t stream) {
@@ -2467,9 +2547,30 @@ int run_wrap_inner(const cm_plan *inner, const cm_plan *first, Geom g, float *sc
             return launch_scan_as<false>(inner->scan_c1, inner->device, inner->scan_main, first->scan_main, inner->scan_depth, g, s, true, stream);
         }
     }
-    int rc = run_plan(inner, g, none, false, stream);
-    if (rc || !first || !with_first) return rc;
-    return run_plan(first, s, none, false, stream);
+    if (!first || !with_first) return run_plan(inner, g, none, false, stream);
+    // The plain first-line pass is one lane per run: a handful of workgroups whose launch lasts as long as walking one row (0.23 ms at 720
+    // samples).  Behind the main pass on one stream that latency is paid per chunk; on a side stream of the device it runs beside the main
+    // pass (forked after everything queued on `stream` - the previous chunk's back end still reads this scratch - and joined before the back end).
+    hipStream_t side = wrap_side_stream(inner->device);
+    hipEvent_t forked = nullptr, joined = nullptr;
+    if (side && (hipEventCreateWithFlags(&forked, hipEventDisableTiming) != hipSuccess ||
+                 hipEventCreateWithFlags(&joined, hipEventDisableTiming) != hipSuccess)) side = nullptr;
+    int rc = CM_OK;
+    if (side) {
+        HIP_TRY(hipEventRecord(forked, stream), CM_ERR_LAUNCH);
+        HIP_TRY(hipStreamWaitEvent(side, forked, 0), CM_ERR_LAUNCH);
+        rc = run_plan(first, s, none, false, side);
+        if (!rc) HIP_TRY(hipEventRecord(joined, side), CM_ERR_LAUNCH);
+        const int rc_main = run_plan(inner, g, none, false, stream);
+        if (!rc) HIP_TRY(hipStreamWaitEvent(stream, joined, 0), CM_ERR_LAUNCH);
+        if (!rc) rc = rc_main;
+    } else {
+        rc = run_plan(inner, g, none, false, stream);
+        if (!rc) rc = run_plan(first, s, none, false, stream);
+    }
+    if (forked) (void)hipEventDestroy(forked);      // released by the runtime once the queued record / wait have completed
+    if (joined) (void)hipEventDestroy(joined);
+    return rc;
 }
 struct AsyncBuf {
     hipStream_t stream = nullptr;

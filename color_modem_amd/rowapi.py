@@ -116,6 +116,45 @@ class RowApi(object):
         r, g, b = self._step(run, eng, 'demod', frame, line)
         return r, g, b
 
+    # ---- several rows of a field per call (an addition to the reference's protocol: one launch and one synchronisation
+    # for the whole group instead of one per row; the run state is the same, so single-row calls may precede and follow) ----
+    def demodulate_rows(self, frame, line, composite_rows):
+        """What ``[demodulate(frame, line + 2 * i, composite_rows[i]) for i in range(n)]`` returns (image.py:75-83 feeds the
+        rows of a field in exactly this order), as one float64 array [n, 3, W], from ONE launch."""
+        rows = numpy.ascontiguousarray(composite_rows, dtype=numpy.float32)
+        eng = self._engine(line=line + 2 * (max(len(rows), 1) - 1))
+        if rows.ndim != 2 or rows.shape[1] != eng.comp_width:
+            raise ValueError('composite_rows must be [n, %d]' % eng.comp_width)
+        return self._rows(self._demod_run, eng, 'demod', eng.demod_depth, frame, line, rows)
+
+    def modulate_rows(self, frame, line, r, g, b):
+        """What ``[modulate(frame, line + 2 * i, r[i], g[i], b[i]) for i in range(n)]`` returns, as one float64 array [n, W]."""
+        rows = numpy.ascontiguousarray(numpy.stack([r, g, b], axis=1), dtype=numpy.float32)       # [n, 3, W]
+        eng = self._engine(line=line + 2 * (max(len(rows), 1) - 1))
+        if rows.ndim != 3 or rows.shape[2] != eng.in_width:
+            raise ValueError('r, g, b must be [n, %d] each' % eng.in_width)
+        return self._rows(self._mod_run, eng, 'mod', eng.mod_depth, frame, line, rows)
+
+    def _rows(self, run, eng, direction, depth, frame, line, rows):
+        n = len(rows)
+        if n == 0:
+            return numpy.zeros((0,) + ((3, eng.width) if direction == 'demod' else (eng.comp_width,)))
+        if direction == 'mod' and getattr(eng, 'encoder', None) is not None:
+            eng = eng.encoder
+        continuing = frame == run.frame and line == run.line + 2 and run.k >= 0
+        k_first = run.k + 1 if continuing else 0
+        n_hist = min(k_first, depth)
+        hist = run.rows[len(run.rows) - n_hist:] if n_hist else []
+        stacked = numpy.concatenate([numpy.stack(hist), rows]) if hist else rows
+        fn = eng.demodulate_run if direction == 'demod' else eng.modulate_run
+        out = numpy.asarray(fn(stacked, frame, line - 2 * n_hist, k_first - n_hist), dtype=numpy.float64)[n_hist:]
+        if not continuing:
+            run.token = next(_Run._tokens)
+        run.k = k_first + n - 1
+        run.frame, run.line = frame, line + 2 * (n - 1)
+        run.rows = (hist + [rows[i] for i in range(max(0, n - depth - 1), n)])[-(depth + 1):]
+        return out
+
     def modulate(self, frame, line, r, g, b):
         return self._modulate(self._engine(line=line), frame, line, r, g, b)
 

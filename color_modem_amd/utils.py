@@ -73,8 +73,28 @@ class FilterFunction(object):
         return design.tf2sos(self.b, self.a)
 
     def __call__(self, x):
-        raise RuntimeError('FilterFunction is a design record in color_modem_amd; rows are filtered on the GPU '
-                           '(use the Modem / ImageModem entry points)')
+        """The filter applied to a row (or to every row of a 2-D array) with the reference's delay compensation (ref utils.py:28-36:
+        the row padded with ``shift`` copies of its last sample, the first ``shift`` results dropped), float64 on the GPU
+        (``cm_filter_rows_f64``: lfilter's own recurrence, one lane per row).  The modems do not come through here - their filters
+        are stages of the fused kernels; this is the reference's REPL-level callable."""
+        import ctypes
+        from color_modem_amd import _native
+        from color_modem_amd.engine import _torch
+        torch = _torch()
+        rows = numpy.atleast_2d(numpy.ascontiguousarray(x, dtype=numpy.float64))
+        if rows.ndim != 2 or rows.shape[1] < 1:
+            raise ValueError('a row or an array of rows expected')
+        dev_in = torch.from_numpy(rows).cuda()
+        dev_out = torch.empty_like(dev_in)
+        b = numpy.ascontiguousarray(self.b, dtype=numpy.float64)
+        a = numpy.ascontiguousarray(self.a, dtype=numpy.float64)
+        dp = ctypes.POINTER(ctypes.c_double)
+        stream = torch.cuda.current_stream()
+        _native.check(_native.lib().cm_filter_rows_f64(b.ctypes.data_as(dp), len(b), a.ctypes.data_as(dp), len(a), int(self.shift),
+                                                       dev_in.data_ptr(), dev_out.data_ptr(), rows.shape[0], rows.shape[1],
+                                                       stream.cuda_stream))
+        out = dev_out.cpu().numpy()
+        return out[0] if numpy.ndim(x) == 1 else out
 
 
 def notch(qam_modem, q):

@@ -363,6 +363,15 @@ int cm_comb_wrap_demodulate_run(const cm_plan *inner, const cm_plan *first, cons
                                 const float *composite, float *rgb, int32_t n_calls, int32_t frame, int32_t first_line, int32_t k0,
                                 void *stream);
 
+/* FilterFunction.__call__ (/root/reference/color_modem/utils.py:28-36) on rows of float64 in device memory: y = lfilter(b, a, x padded
+ * with `shift` copies of its last sample)[shift:] for shift > 0, lfilter(b, a, -shift copies of the first sample + x)[:shift] for
+ * shift < 0, lfilter(b, a, x) for 0 - scipy.signal.lfilter's own recurrence (transposed direct form II, zero initial state, a[0]
+ * normalised, unfused float64), one lane per row: a callable for REPL use (README.md:8-10 of the reference), not a throughput path.
+ * x, y: [n_rows][width] doubles on the current device, not overlapping; b, a: host arrays of up to CM_FILTER_MAX_TAPS coefficients. */
+#define CM_FILTER_MAX_TAPS 25
+int cm_filter_rows_f64(const double *b, int32_t n_b, const double *a, int32_t n_a, int32_t shift, const double *x, double *y,
+                       int64_t n_rows, int32_t width, void *stream);
+
 /* Every compute entry point checks that the plan's device is the current one and that both image buffers are memory the HIP
  * runtime knows as accessible from it (CM_ERR_INVALID for another GPU's memory, pageable host memory and pointers the runtime
  * cannot classify; pinned / mapped host memory and managed memory pass).  cm_set_pointer_check(0) switches the pointer

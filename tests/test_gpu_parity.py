@@ -622,6 +622,74 @@ def test_row_protocol_long_run_and_lines_beyond_the_image():
             assert stacks.rel_err(numpy.stack(got), numpy.stack(want)) < TOL, (stack, line)
 
 
+def test_rows_protocol_several_rows_per_call():
+    """Modem.demodulate_rows / modulate_rows (one launch for a group of rows of a field) against the float64 oracle's row-by-row
+    protocol (the reference's own: comb.py:47-59, 96-113, secam.py:278-304) AND against this library's one-row calls, with
+    single-row calls before and after the group in the same run (the run state is shared)."""
+    from oracle import cm_oracle
+    for stack in ('pal_d', 'pal_3d', 'ntsc_comb_3d', 'secam', 'simple3d_pald', 'pal_s'):
+        modem = stacks.make(stack, (720, 8))
+        again = stacks.make(stack, (720, 8))
+        orc = cm_oracle.OracleModem(modem)
+        rgb = testing.synthetic_rgb(1, 60, 720, seed=16)[0].astype(numpy.float64)
+        enc = cm_oracle.OracleModem(stacks.make('secam' if stack == 'secam' else 'pal_s' if 'pal' in stack else 'ntsc', (720, 8)))
+        comp = numpy.stack([enc.modulate(2, 1 + 2 * i, rgb[0, i], rgb[1, i], rgb[2, i]) for i in range(60)]).astype(numpy.float32)
+        want = numpy.stack([numpy.stack(orc.demodulate(2, 1 + 2 * i, comp[i].astype(numpy.float64))) for i in range(60)])
+        one = numpy.stack([numpy.stack(again.demodulate(2, 1 + 2 * i, comp[i])) for i in range(60)])
+        got = numpy.concatenate([
+            numpy.stack([numpy.stack(modem.demodulate(2, 1 + 2 * i, comp[i])) for i in range(3)]),     # single rows open the run
+            modem.demodulate_rows(2, 7, comp[3:40]),                                                  # 37 rows in one launch
+            numpy.stack(modem.demodulate(2, 81, comp[40]))[None],                                     # a single row continues it
+            modem.demodulate_rows(2, 83, comp[41:60])])
+        assert got.shape == (60, 3, 720)
+        assert stacks.rel_err(got, want) < TOL, stack
+        assert stacks.rel_err(got, one) < 2e-6, stack
+        fresh = stacks.make(stack, (720, 8)).demodulate_rows(2, 1, comp)                             # a group that starts the run itself
+        assert stacks.rel_err(fresh, want) < TOL, stack
+    for stack in ('pal_s', 'secam_avg', 'ntsc_avg'):
+        modem = stacks.make(stack, (720, 8))
+        orc = cm_oracle.OracleModem(modem)
+        rgb = testing.synthetic_rgb(1, 40, 720, seed=17)[0].astype(numpy.float64)
+        want = numpy.stack([orc.modulate(1, 2 * i, rgb[0, i], rgb[1, i], rgb[2, i]) for i in range(40)])
+        got = numpy.concatenate([
+            numpy.stack([modem.modulate(1, 2 * i, rgb[0, i], rgb[1, i], rgb[2, i]) for i in range(2)]),
+            modem.modulate_rows(1, 4, rgb[0, 2:30], rgb[1, 2:30], rgb[2, 2:30]),
+            modem.modulate_rows(1, 60, rgb[0, 30:40], rgb[1, 30:40], rgb[2, 30:40])])
+        assert got.shape == (40, 720)
+        assert stacks.rel_err(got, want) < TOL, stack
+
+
+def test_filter_function_is_callable():
+    """FilterFunction.__call__ (ref utils.py:28-36) on the device against scipy.signal.lfilter on the host, for filters of every
+    family the modems design, both signs of the shift, one row and a batch of rows."""
+    import scipy.signal
+    from color_modem_amd import utils
+    rng = numpy.random.default_rng(21)
+    modem = stacks.make('pal_d', (720, 8))
+    sec = stacks.make('secam', (720, 8))
+    filters = [modem.backend.qam._chroma_precorrect_lowpass, modem.backend.qam._extract_chroma2x, modem.backend.qam._remove_chroma2x,
+               modem.backend.qam._demod_lowpass, modem._filter, sec._chroma_demod_chroma_filter, sec._chroma_demod_luma_filter,
+               utils.notch(modem.backend, 5.0)]
+    for f in filters:
+        for shift in (f.shift, 0, -3):
+            g = utils.FilterFunction(f.b, f.a, 0.0, 'lowpass', False)
+            g.shift = shift
+            x = rng.uniform(-1, 1, (5, 737))
+            if shift == 0:
+                want = scipy.signal.lfilter(f.b, f.a, x, axis=1)
+            elif shift > 0:
+                want = scipy.signal.lfilter(f.b, f.a, numpy.concatenate([x, numpy.repeat(x[:, -1:], shift, axis=1)], axis=1), axis=1)[:, shift:]
+            else:
+                want = scipy.signal.lfilter(f.b, f.a, numpy.concatenate([numpy.repeat(x[:, :1], -shift, axis=1), x], axis=1), axis=1)[:, :shift]
+            got = g(x)
+            assert got.shape == want.shape and got.dtype == numpy.float64
+            assert float(numpy.max(numpy.abs(got - want))) < 1e-12 * max(1.0, float(numpy.max(numpy.abs(want)))), (f.order, shift)
+            one = g(x[2])
+            assert one.shape == (737,) and numpy.array_equal(one, got[2])
+    with pytest.raises(NotImplementedError):
+        utils.FilterFunction(numpy.ones(40), numpy.ones(40), 0.0, 'lowpass', False)(numpy.zeros(16))
+
+
 def test_out_argument_is_validated():
     import torch
     modem = stacks.make('pal_d', (720, 8))

@@ -54,3 +54,20 @@ for name, m in others:
     for y in range(0, 8, 2): m.demodulate(0, y, row)
     t_dem = per_row(lambda y: m.demodulate(1, y, row))
     print('%-14s modulate %.1f us per row, demodulate %.1f us per row (medians)' % (name, t_mod * 1e6, t_dem * 1e6), flush=True)
+# several rows per call (round 4: Modem.demodulate_rows / modulate_rows - one launch and one synchronisation per group)
+print('rows per call | us per row (host wall, numpy in -> numpy out), a field of 288 rows fed in groups')
+for name, size in (('pal_d', (720, 576)), ('ntsc_comb_3d', (720, 480)), ('secam', (720, 576)), ('simple3d_pald', (720, 576))):
+    m = stacks.make(name, size)
+    comp = testing.synthetic_composite(1, size[1], size[0])[0]
+    field = comp[0::2]
+    cells = []
+    for group in (1, 4, 16, 72, len(field)):
+        best = 1e9
+        for rep in range(4):
+            t0 = time.time()
+            for i in range(0, len(field), group):
+                if group == 1: m.demodulate(rep, 2 * i, field[i])
+                else: m.demodulate_rows(rep, 2 * i, field[i:i + group])
+            best = min(best, time.time() - t0)
+        cells.append('%4d: %6.2f' % (group, best / len(field) * 1e6))
+    print('%-14s demodulate  %s' % (name, '   '.join(cells)), flush=True)
