@@ -377,7 +377,28 @@ bool select_for_shape(cm_plan *p, const cm_plan_desc &d, const char *sys, std::s
     err = "development build: PAL-D only";
     return false;
 #else
-    if (minavg) {
+    if (pald && depth == 2 && !first) {
+        // SimpleCombModem / Simple3DCombModem around PalDModem, the calls k >= 2 of every run (comb.py:96-113 over pal.py:79-127: both
+        // chroma estimates come from the PAL-D front end there, two lines of history; cm_comb_wrap_demodulate_frames_fused supplies
+        // the calls k < 2, which mix in the plain first-line decode)
+        if constexpr (HAS_PALD) {
+            if (d.skip_calls != 2) { err = "the PAL-D front end with two lines of history serves the fused wrapped combs (skip_calls = 2)"; return false; }
+            if (minavg) {
+                p->fn = launch_demod<PassCfg<S, FRONT_PALD, false, 2, 16, false, true, true>, NoPass>;
+                p->fn_u8 = launch_demod<PassCfg<S, FRONT_PALD, false, 2, 16, true, true, true>, NoPass>;
+            } else if (notch) {
+                p->fn = launch_demod<PassCfg<S, FRONT_PALD, false, 2, 16, false, true>, NoPass>;
+                p->fn_u8 = launch_demod<PassCfg<S, FRONT_PALD, false, 2, 16, true, true>, NoPass>;
+            } else {
+                p->fn = launch_demod<PassCfg<S, FRONT_PALD, false, 2, 16>, NoPass>;
+                p->fn_u8 = launch_demod<PassCfg<S, FRONT_PALD, false, 2, 16, true>, NoPass>;
+            }
+            p->main.depth = 2; what = minavg ? "pal-d front, depth 2, minavg (wrapped comb, calls k >= 2)" : "pal-d front, depth 2 (wrapped comb, calls k >= 2)";
+        } else {
+            err = std::string("no PAL-D front end for the ") + sys + " filter shapes";
+            return false;
+        }
+    } else if (minavg) {
         // comb.py:13-15 behind SimpleCombModem / Pal3DModem: one instance per shape (depth 2, notch switchable)
         if (pald || bsf || first) { err = "minavg is built behind the QAM front end (SimpleCombModem, Pal3DModem)"; return false; }
         p->fn = launch_demod<PassCfg<S, FRONT_QAM, false, 2, 16, false, true, true>, NoPass>;
@@ -929,7 +950,7 @@ static int scan_chunk_for(const cm_plan_desc &d) {
     return 0;
 }
 static void make_scan(cm_plan *p, const cm_plan_desc &d) {
-    if (p->secam || !p->fn) return;
+    if (p->secam || !p->fn || d.skip_calls) return;      // (the fused wrapped comb's plan runs long batches only)
     const int c1 = scan_chunk_for(d);
     if (!c1) return;
     const bool pald = d.pipeline == CM_PIPE_PAL_D, bsf = d.main_luma_bandstop != 0, minavg = d.chroma_average == CM_AVG_MIN;
@@ -1225,6 +1246,7 @@ int cm_plan_create(const cm_plan_desc *desc, cm_plan **out) {
     if (desc->pipeline != CM_PIPE_QAM && desc->pipeline != CM_PIPE_PAL_D && desc->pipeline != CM_PIPE_SECAM)
         return fail(CM_ERR_INVALID, "unknown pipeline");
     if (desc->depth < 0 || desc->depth > 2) return fail(CM_ERR_INVALID, "depth must be 0..2");
+    if (desc->skip_calls != 0 && desc->skip_calls != 2) return fail(CM_ERR_INVALID, "skip_calls must be 0 or 2");
     if (!desc->demod_main.table || desc->demod_main.frame_cycle < 1 || desc->demod_main.n_lines < 1)
         return fail(CM_ERR_INVALID, "demod_main table missing");
     if (desc->first_is_plain && (!desc->demod_first.table || desc->demod_first.n_lines != desc->demod_main.n_lines))
@@ -1369,7 +1391,7 @@ int cm_demodulate_frames(const cm_plan *p, const float *composite, float *rgb, i
         g.first_line[1] = 1;
         g.delay = D;
         g.total_calls = n_frames * g.calls_per_frame;
-        g.skip_first = d.first_is_plain;
+        g.skip_first = d.skip_calls ? d.skip_calls : d.first_is_plain;
         if (p->secam) {
             if (H - 1 >= p->sd_n_lines) return fail(CM_ERR_INVALID, "line number beyond the plan's tables");
             return run_secam_demod(p, g, (hipStream_t)stream);
@@ -1421,7 +1443,7 @@ int cm_demodulate_frames_u8(const cm_plan *p, const uint8_t *composite8, uint8_t
     g.first_line[1] = 1;
     g.delay = D;
     g.total_calls = n_frames * g.calls_per_frame;
-    g.skip_first = d.first_is_plain;
+    g.skip_first = d.skip_calls ? d.skip_calls : d.first_is_plain;
     if (p->secam) {
         if (H - 1 >= p->sd_n_lines) return fail(CM_ERR_INVALID, "line number beyond the plan's tables");
         return run_secam_demod(p, g, (hipStream_t)stream, true);
@@ -1466,7 +1488,7 @@ int cm_demodulate_run(const cm_plan *p, const float *composite, float *rgb, int3
         g.first_line[0] = g.first_line[1] = first_line;
         g.k0 = k0;
         g.total_calls = n_calls;
-        g.skip_first = d.first_is_plain;
+        g.skip_first = d.skip_calls ? d.skip_calls : d.first_is_plain;
         g.out_plane_stride = wp;            // rows mode writes [call][plane][W]
         g.out_row_stride = 3LL * wp;
         if (p->secam) {
@@ -2580,12 +2602,15 @@ struct AsyncBuf {
 #ifndef CM_WRAP_SCRATCH_BYTES
 #define CM_WRAP_SCRATCH_BYTES ((size_t)1 << 30)
 #endif
-// in: float rows (pitch wp), or in8: composite bytes (width = wp, a multiple of 4) with bytes out as well
+// in: float rows (pitch wp), or in8: composite bytes (width = wp, a multiple of 4) with bytes out as well.
+// h_top > 0: only the top h_top rows of every frame are decoded (frames stay full_H rows apart in both buffers) and only the calls with
+// k < keep_calls of every run are stored - the share of a fused wrapped comb that mixes two front ends (wrap_frames_fused).
 int wrap_frames(const cm_plan *inner, const cm_plan *first, const cm_plan *backend, const cm_comb_wrap_desc *w, const float *in,
-                const uint8_t *in8, void *out, int wp, int64_t n_frames, int64_t first_frame, hipStream_t stream) {
+                const uint8_t *in8, void *out, int wp, int64_t n_frames, int64_t first_frame, hipStream_t stream, int h_top = 0,
+                int keep_calls = 0) {
     const bool u8 = in8 != nullptr;
     const cm_plan_desc &d = inner->desc;
-    const int W = d.width, H = d.height, D = d.demodulation_delay + (w->own_delay ? 1 : 0);
+    const int W = d.width, full_H = d.height, H = h_top > 0 ? h_top : full_H, D = d.demodulation_delay + (w->own_delay ? 1 : 0);
     int rc = check_lines(inner, inner->main, H - 1 + 2 * D);
     if (rc) return rc;
     if (first && (rc = check_lines(first, first->main, H - 1))) return rc;
@@ -2595,7 +2620,7 @@ int wrap_frames(const cm_plan *inner, const cm_plan *first, const cm_plan *backe
     g.W = W;
     g.Wp = wp;
     g.H = H;
-    g.in_frame_stride = (long long)wp * H;
+    g.in_frame_stride = (long long)wp * full_H;
     g.in_row_stride = wp;
     const int rows0 = (H + 1) / 2, rows1 = H / 2;
     g.calls_run0 = rows0 + D;
@@ -2623,11 +2648,12 @@ int wrap_frames(const cm_plan *inner, const cm_plan *first, const cm_plan *backe
         Geom gi = g;
         if (in8) {      // image.py:24-25, 62: the inner decoder's component output has no byte form, so it reads float rows
             const long long quads = nf * frame_quads;
-            hipLaunchKernelGGL(decode_level_kernel, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, stream, in8 + f0 * (long long)wp * H,
-                               (float *)comp.p, quads);
+            hipLaunchKernelGGL(decode_level_kernel, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, stream, in8 + f0 * (long long)wp * full_H,
+                               (float *)comp.p, quads, frame_quads, (long long)wp * full_H);
             hipError_t e = hipGetLastError();
             if (e != hipSuccess) return fail(CM_ERR_LAUNCH, std::string("decode_level_kernel launch: ") + hipGetErrorString(e));
             gi.in = (const float *)comp.p;
+            gi.in_frame_stride = (long long)wp * H;      // the decoded copy holds the decoded rows only
         } else
         gi.in = in + f0 * g.in_frame_stride;
         gi.total_calls = nf * g.calls_per_frame;
@@ -2639,19 +2665,83 @@ int wrap_frames(const cm_plan *inner, const cm_plan *first, const cm_plan *backe
         gb.in_frame_stride = 3LL * wp * g.calls_per_frame;
         gb.in_calls = 1;
         gb.total_calls = gi.total_calls;
+        gb.keep_calls = keep_calls;
         if (u8) {   // interleaved bytes [F][H][W][3]: strides count bytes
-            gb.out = reinterpret_cast<float *>((unsigned char *)out + f0 * 3LL * W * H);
-            gb.out_frame_stride = 3LL * W * H;
+            gb.out = reinterpret_cast<float *>((unsigned char *)out + f0 * 3LL * W * full_H);
+            gb.out_frame_stride = 3LL * W * full_H;
             gb.out_row_stride = 3LL * W;
         } else {
-            gb.out = (float *)out + f0 * 3LL * wp * H;
-            gb.out_plane_stride = (long long)wp * H;
-            gb.out_frame_stride = 3LL * wp * H;
+            gb.out = (float *)out + f0 * 3LL * wp * full_H;
+            gb.out_plane_stride = (long long)wp * full_H;
+            gb.out_frame_stride = 3LL * wp * full_H;
             gb.out_row_stride = wp;
         }
         if ((rc = run_wrap_back(gb, backend, *w, first_frame + f0, u8, stream))) return rc;
     }
     return CM_OK;
+}
+// SimpleCombModem / Simple3DCombModem around PalDModem without the component scratch (40 -> 16 B per pixel through HBM): from its third
+// call on, a run's two chroma estimates (comb.py:103-104) both come from the PAL-D front end, so the average, the re-modulation at the
+// wrapper's line (comb.py:105-106) and the notch are one more line of history of the fused decoder - `fused`: PAL-D front end, depth 2,
+// the lane tables of plan.py (QamTables: fused_main) - which stores every call with k >= 2.  The calls k < 2 of every run mix in the
+// plain first-line decode (the QAM front end): they are the top four rows of every frame, and go through the composition above.
+bool wrap_fused_applies(const cm_plan *fused, const cm_plan *inner, int64_t n_frames) {
+    if (!fused || !fused->fn || fused->desc.skip_calls != 2) return false;
+    const cm_plan_desc &d = inner->desc;
+    if (d.height < 8 || d.width % 4 != 0) return false;
+    if (inner->small_batch != CM_SMALL_BATCH_AUTO) return false;          // a pinned kernel family: the composition honours it
+    return n_frames * (long long)(d.height + 4) > 4LL * CM_SCAN_MAX_CALLS;   // below: the scan kernels' regime
+}
+int check_fused(const cm_plan *fused, const cm_plan *inner, const cm_comb_wrap_desc *w) {
+    if (!fused) return CM_OK;
+    if (fused->secam) return fail(CM_ERR_INVALID, "comb wrappers take QAM-family plans");
+    if (fused->device != inner->device) return fail(CM_ERR_INVALID, "the fused and inner plans of a wrapped comb belong to different devices");
+    if (fused->desc.width != inner->desc.width || fused->desc.height != inner->desc.height) return fail(CM_ERR_INVALID, "the plans differ in size");
+    if (fused->desc.demodulation_delay != inner->desc.demodulation_delay + (w->own_delay ? 1 : 0))
+        return fail(CM_ERR_INVALID, "the fused plan's demodulation delay is not the inner decoder's plus the wrapper's");
+    return CM_OK;
+}
+int wrap_frames_fused(const cm_plan *fused, const cm_plan *inner, const cm_plan *first, const cm_plan *backend, const cm_comb_wrap_desc *w,
+                      const float *in, const uint8_t *in8, void *out, int wp, int64_t n_frames, int64_t first_frame, hipStream_t stream) {
+    const cm_plan_desc &d = fused->desc;
+    const int W = d.width, H = d.height, D = d.demodulation_delay;
+    int rc = check_lines(fused, fused->main, H - 1 + 2 * D);
+    if (rc) return rc;
+    Geom g;
+    std::memset(&g, 0, sizeof g);
+    g.W = W;
+    g.H = H;
+    if (in8) {      // strides count bytes (PassCfg::U8)
+        g.in = reinterpret_cast<const float *>(in8);
+        g.out = reinterpret_cast<float *>(out);
+        g.Wp = W;
+        g.in_frame_stride = (long long)W * H;
+        g.in_row_stride = W;
+        g.out_frame_stride = 3LL * W * H;
+        g.out_row_stride = 3LL * W;
+    } else {
+        g.in = in;
+        g.out = (float *)out;
+        g.Wp = wp;
+        g.in_frame_stride = (long long)wp * H;
+        g.in_row_stride = wp;
+        g.out_plane_stride = (long long)wp * H;
+        g.out_frame_stride = 3LL * wp * H;
+        g.out_row_stride = wp;
+    }
+    set_first_frame(fused, g, first_frame, fused->main.cycle);
+    const int rows0 = (H + 1) / 2, rows1 = H / 2;
+    g.calls_run0 = rows0 + D;
+    g.calls_per_frame = g.calls_run0 + (rows1 > 0 ? rows1 + D : 0);
+    g.runs_per_frame = rows1 > 0 ? 2 : 1;
+    g.first_line[0] = 0;
+    g.first_line[1] = 1;
+    g.delay = D;
+    g.total_calls = n_frames * g.calls_per_frame;
+    g.skip_first = 2;
+    Geom none = g;
+    if ((rc = run_plan(fused, g, none, false, stream, in8 != nullptr))) return rc;
+    return wrap_frames(inner, first, backend, w, in, in8, out, wp, n_frames, first_frame, stream, 4, 2);
 }
 }  // namespace
 }  // extern "C++"
@@ -2682,6 +2772,32 @@ int cm_comb_wrap_demodulate_frames_u8(const cm_plan *inner, const cm_plan *first
     const int W = d.width, H = d.height;
     if (W % 4 != 0) return fail(CM_ERR_UNSUPPORTED, "the fused uint8 boundary needs a width that is a multiple of 4");
     return wrap_frames(inner, first, backend, w, nullptr, composite8, rgb8, W, n_frames, first_frame, (hipStream_t)stream);
+}
+
+int cm_comb_wrap_demodulate_frames_fused(const cm_plan *fused, const cm_plan *inner, const cm_plan *first, const cm_plan *backend,
+                                         const cm_comb_wrap_desc *w, const float *composite, float *rgb, int64_t n_frames, int64_t first_frame,
+                                         void *stream) {
+    if (int rc = check_wrap(inner, first, backend, w)) return rc;
+    if (int rc = check_fused(fused, inner, w)) return rc;
+    if (!wrap_fused_applies(fused, inner, n_frames))
+        return cm_comb_wrap_demodulate_frames(inner, first, backend, w, composite, rgb, n_frames, first_frame, stream);
+    if (!composite || !rgb) return fail(CM_ERR_INVALID, "null argument");
+    if (n_frames < 0 || first_frame < 0) return fail(CM_ERR_INVALID, "negative frame count / number");
+    if (int rc_ = check_device(inner->device, composite, rgb)) return rc_;
+    return wrap_frames_fused(fused, inner, first, backend, w, composite, nullptr, rgb, inner->desc.width, n_frames, first_frame, (hipStream_t)stream);
+}
+
+int cm_comb_wrap_demodulate_frames_fused_u8(const cm_plan *fused, const cm_plan *inner, const cm_plan *first, const cm_plan *backend,
+                                            const cm_comb_wrap_desc *w, const uint8_t *composite8, uint8_t *rgb8, int64_t n_frames,
+                                            int64_t first_frame, void *stream) {
+    if (int rc = check_wrap(inner, first, backend, w)) return rc;
+    if (int rc = check_fused(fused, inner, w)) return rc;
+    if (!wrap_fused_applies(fused, inner, n_frames) || !fused->fn_u8)
+        return cm_comb_wrap_demodulate_frames_u8(inner, first, backend, w, composite8, rgb8, n_frames, first_frame, stream);
+    if (!composite8 || !rgb8) return fail(CM_ERR_INVALID, "null argument");
+    if (n_frames < 0 || first_frame < 0) return fail(CM_ERR_INVALID, "negative frame count / number");
+    if (int rc_ = check_device(inner->device, composite8, rgb8)) return rc_;
+    return wrap_frames_fused(fused, inner, first, backend, w, nullptr, composite8, rgb8, inner->desc.width, n_frames, first_frame, (hipStream_t)stream);
 }
 
 int cm_comb_wrap_demodulate_run(const cm_plan *inner, const cm_plan *first, const cm_plan *backend, const cm_comb_wrap_desc *w,

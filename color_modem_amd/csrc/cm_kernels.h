@@ -61,7 +61,9 @@ struct Geom {
     int seg_warm;        // recursive filters forget it: cm_api.hip: segment_geometry); blocks [seg * seg_blocks, ...) own segment seg
     int in_calls;        // frames geometry, but input row = the call's index within its frame ([frame][call] buffers: the comb
     int out_calls;       // wrappers' scratch, cm_wrap_kernels.h); likewise the output row, and EVERY call is stored
-    int skip_first;      // 1: calls with k == 0 are written by the sparse pass, not by this one
+    int skip_first;      // n: the calls with k < n of every run are written by another launch (1: the sparse plain first-line pass;
+                         // 2: the fused wrapped comb, whose first two calls mix two front ends - cm_api.hip: wrap_frames_fused)
+    int keep_calls;      // n > 0: ONLY the calls with k < n are stored (the launch that supplies what skip_first = n leaves out)
     unsigned long long *diag;  // diagnostic builds only (-DCM_DIAG): per-workgroup cycle sums; null otherwise
     unsigned *simd_load;       // wave-pair kernels (CM_SIMD_BALANCE): live load per (XCC, CU, SIMD); null: waves keep their order
     const void *blk_tiles;     // blocked decoder (cm_blk_kernels.h): the Toeplitz tiles of the half-band FIR, or null
@@ -501,7 +503,7 @@ __device__ __forceinline__ LaneCall locate_call_at(const Geom &g, long long c, b
     r.line = (run ? g.first_line[1] : g.first_line[0]) + 2 * i;
     r.kk = g.k0 + i;
     r.regime = r.kk < 2 ? r.kk : 2;
-    r.store_ok = active && !(g.skip_first && r.kk == 0);
+    r.store_ok = active && r.kk >= g.skip_first && (g.keep_calls == 0 || r.kk < g.keep_calls);
     if (g.rows_mode) {
         r.src_row = i;
         r.prev_row = i - 1 < 0 ? i : i - 1;

@@ -277,7 +277,7 @@ __device__ __forceinline__ Geom select_geom(const Geom &gm, const Geom &gf, bool
     CM_PICK(W); CM_PICK(H); CM_PICK(Wp); CM_PICK(calls_per_frame); CM_PICK(calls_run0); CM_PICK(runs_per_frame);
     CM_PICK(first_line[0]); CM_PICK(first_line[1]); CM_PICK(k0); CM_PICK(delay); CM_PICK(rows_mode); CM_PICK(luma_prev_bits);
     CM_PICK(sparse); CM_PICK(seg_len); CM_PICK(seg_blocks); CM_PICK(seg_warm); CM_PICK(in_calls); CM_PICK(out_calls);
-    CM_PICK(skip_first); CM_PICK(diag); CM_PICK(simd_load); CM_PICK(blk_tiles);
+    CM_PICK(skip_first); CM_PICK(keep_calls); CM_PICK(diag); CM_PICK(simd_load); CM_PICK(blk_tiles);
 #undef CM_PICK
     return g;
 }

@@ -157,10 +157,13 @@ __global__ __launch_bounds__(64, 2) void comb_wrap_back_kernel(const WrapBackArg
 
 // composite bytes -> level-decoded float rows (image.py:24-25, 62): the wrapped combs' byte entry point decodes the frame once
 // (the inner decoder's component output has no byte form), 1 + 4 bytes per pixel
-__global__ __launch_bounds__(256) void decode_level_kernel(const unsigned char *in, float *out, long long n_quads) {
+// (the top `quads_per_frame` quads of frames in_frame_bytes apart -> compact float frames: the whole frame when the two agree)
+__global__ __launch_bounds__(256) void decode_level_kernel(const unsigned char *in, float *out, long long n_quads, long long quads_per_frame,
+                                                           long long in_frame_bytes) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i >= n_quads) return;
-    ((f4 *)out)[i] = decode_bytes(((const unsigned *)in)[i]);
+    const long long frame = i / quads_per_frame, q = i - frame * quads_per_frame;
+    ((f4 *)out)[i] = decode_bytes(*(const unsigned *)(in + frame * in_frame_bytes + 4 * q));
 }
 
 }  // namespace cm

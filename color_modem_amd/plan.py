@@ -22,7 +22,7 @@ import ctypes
 import numpy
 from color_modem_amd import design
 
-CM_ABI_VERSION = 6
+CM_ABI_VERSION = 7
 CM_SECAM_PRESENT, CM_SECAM_FLOAT64 = 1, 2      # cm_secam_desc.present (include/color_modem_hip.h)
 CM_PIPE_QAM, CM_PIPE_PAL_D, CM_PIPE_SECAM = 1, 2, 3
 CM_MAX_SECTIONS = 4
@@ -57,7 +57,7 @@ class PlanDesc(ctypes.Structure):
                 ('width', ctypes.c_int32), ('height', ctypes.c_int32),
                 ('demodulation_delay', ctypes.c_int32), ('modulation_delay', ctypes.c_int32),
                 ('depth', ctypes.c_int32), ('first_is_plain', ctypes.c_int32),
-                ('main_luma_bandstop', ctypes.c_int32), ('reserved0', ctypes.c_int32),
+                ('main_luma_bandstop', ctypes.c_int32), ('skip_calls', ctypes.c_int32),
                 ('carrier_phase_step', ctypes.c_double),
                 ('resample_fir', ctypes.c_double * 41),
                 ('extract2x', IirDesc), ('remove2x', IirDesc), ('demod_lp', IirDesc),
@@ -186,6 +186,10 @@ class QamTables(object):
         self.comb = stack.get('comb')            # PalDModem / Pal3DModem / NtscCombModem or None
         self.demod_wrapper = stack.get('demod_wrapper')
         self.mod_wrapper = stack.get('mod_wrapper')
+        # SimpleCombModem / Simple3DCombModem around PalDModem, calls k >= 2 of a run only (wrapped.py: the fused plan): there both
+        # chroma estimates of comb.py:103-104 are PAL-D decodes, i.e. combinations of this front end's base pairs over three lines;
+        # the calls k < 2 mix in the plain decode of the first line and are left to the composition (skip_calls = 2)
+        self.fused_main = bool(stack.get('fused_main'))
         b = self.backend
         self.lc = b.line_config
         self.LS = b.line_shift
@@ -344,7 +348,11 @@ class QamTables(object):
             if self.kind == 'pal_3d':
                 raise NotImplementedError('SimpleCombModem around Pal3DModem reaches back 3 lines; not built')
             if self.kind == 'pal_d':
-                raise NotImplementedError('SimpleCombModem around PalDModem mixes two front ends; not built')
+                if not self.fused_main:
+                    raise NotImplementedError('SimpleCombModem around PalDModem mixes two front ends on the first two calls of a run; '
+                                              'wrapped.py composes it (and fuses the calls k >= 2)')
+                if k < 2:         # never stored (skip_calls = 2): no combination to tabulate
+                    return Lin(), Lin(), None, False, None, None
             cu, cv = self.backend_uv(frame, line, k)
             if k == 0:                                # comb.py:97-99: luma left unstripped
                 return cu, cv, None, False, None, None
@@ -507,6 +515,7 @@ def build_qam_plan(stack, components=False, strip_chroma=True, min_lines=0):
     d.modulation_delay = tb.modulation_delay
     d.depth = tb.depth
     d.first_is_plain = 1 if tb.first_is_plain else 0
+    d.skip_calls = 2 if tb.fused_main else 0
     d.main_luma_bandstop = 1 if tb.plain_stack else 0
     d.carrier_phase_step = float(b.qam.carrier_phase_step)
     d.resample_fir[:] = list(resample_fir())

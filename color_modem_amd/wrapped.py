@@ -16,6 +16,12 @@ Pal3DModem it reaches back three lines.  They run as two streaming kernels per b
 
 This module only builds the three plans (inner decoder, plain first-line decoder, backend modulator) and the wrapper's
 descriptor.  Not built: avg= callables other than comb.avg / comb.minavg.
+
+Round 4: around PalDModem a fourth plan removes the component scratch from long batches.  From the third call of a run on, both
+chroma estimates the wrapper averages are PAL-D decodes - combinations of the PAL-D front end's base pairs of three consecutive
+lines - so the whole wrapper is one more line of history in the fused decoder's lane tables (plan.QamTables: fused_main; kernel
+instance: PAL-D front end, depth 2).  Only the first two calls of a run (the top four rows of a frame) mix in the plain decode and
+still go through the composition (`cm_comb_wrap_demodulate_frames_fused`: 16 instead of 40 bytes per pixel through HBM).
 """
 
 import ctypes
@@ -29,6 +35,16 @@ class CombWrapDesc(ctypes.Structure):
     """cm_comb_wrap_desc (include/color_modem_hip.h)"""
     _fields_ = [('own_delay', ctypes.c_int32), ('minavg', ctypes.c_int32), ('strip_chroma', ctypes.c_int32),
                 ('reserved', ctypes.c_int32), ('notch', plan.IirDesc), ('matrix', ctypes.c_double * 9)]
+
+
+class _FusedStack(object):
+    """The wrapper's stack marked for the fused plan (plan.QamTables: fused_main), in the shape engine.Engine takes a modem in."""
+
+    def __init__(self, stack):
+        self._marked = dict(stack, fused_main=True)
+
+    def _stack(self):
+        return self._marked
 
 
 class WrappedCombEngine(object):
@@ -61,6 +77,12 @@ class WrappedCombEngine(object):
             self.first = engine.Engine(self.backend, components=True, strip_chroma=False, min_lines=need)
         self.mod = engine.Engine(self.backend, components=True, min_lines=need)       # the wrapper re-modulates through the backend
         self.encoder = engine.Engine(self.backend, components=components, min_lines=need)     # wrapper.modulate = backend.modulate
+        self.fused = None
+        if stack['kind'] == 'pal_d':
+            try:
+                self.fused = engine.Engine(_FusedStack(stack), components=components, strip_chroma=strip_chroma, min_lines=need)
+            except NotImplementedError:      # no PAL-D depth-2 instance for this filter-set shape: the composition serves every batch
+                self.fused = None
         self.demod_depth = self.inner.demod_depth + 1
         self.mod_depth = 0
         self.n_lines = min(e.n_lines for e in (self.inner, self.first, self.mod, self.encoder) if e is not None)
@@ -74,13 +96,16 @@ class WrappedCombEngine(object):
         self.desc = w
 
     def describe(self):
-        return 'composition: %s (components, every call of the batch) | comb_wrap_back_kernel (small batches: wrap_back_scan_kernel)' % self.inner.describe()
+        text = 'composition: %s (components, every call of the batch) | comb_wrap_back_kernel (small batches: wrap_back_scan_kernel)' % self.inner.describe()
+        if self.fused is not None:
+            text = 'long batches: %s + the composition on the top four rows; otherwise %s' % (self.fused.describe(), text)
+        return text
 
     def set_small_batch(self, mode):
         """Engine.set_small_batch for the plans a wrapped decode runs through (inner decoder, plain first line, back end) and the encoder's."""
         for e in (self.inner, self.first, self.mod, self.encoder):
             if e is not None:
-                e.set_small_batch(mode)
+                e.set_small_batch(mode)       # (a pinned mode on the inner plan also keeps long batches on the composition)
 
     def _plans(self, device):
         return (self.inner._plans.get(device), self.first._plans.get(device) if self.first is not None else None,
@@ -92,12 +117,13 @@ class WrappedCombEngine(object):
         fn, desc = _native.lib().cm_comb_wrap_demodulate_run, self.desc
         return lambda plans, src, dst, n, frame, line, k0, stream: fn(plans[0], plans[1], plans[2], ctypes.byref(desc), src, dst, n, frame, line, k0, stream)
 
-    def _call(self, fn, x, out, *args):
+    def _call(self, fn, x, out, *args, **kw):
         import torch
         inner, first, mod = self._plans(x.device)
+        lead = (self.fused._plans.get(x.device) if self.fused is not None else None,) if kw.get('fused') else ()
         with torch.cuda.device(x.device):
             stream = torch.cuda.current_stream(x.device).cuda_stream
-            _native.check(fn(inner, first, mod, ctypes.byref(self.desc), x.data_ptr(), out.data_ptr(), *(tuple(args) + (stream,))))
+            _native.check(fn(*(lead + (inner, first, mod, ctypes.byref(self.desc), x.data_ptr(), out.data_ptr()) + tuple(args) + (stream,))))
 
     # ---- one run (rowapi) ----------------------------------------------------------------------
     def demodulate_run(self, rows, frame, first_line, k0):
@@ -128,13 +154,13 @@ class WrappedCombEngine(object):
             out = torch.empty(shape, dtype=dtype, device=comp.device)
         else:
             engine._check_out(out, shape, dtype, comp.device)
-        self._call(fn, comp, out, int(comp.shape[0]), int(first_frame))
+        self._call(fn, comp, out, int(comp.shape[0]), int(first_frame), fused=True)
         return out.cpu().numpy() if was_numpy else out
 
     def demodulate_frames(self, composite, first_frame=0, out=None):
         """composite [F, H, W] float32 (numpy or cuda tensor) -> rgb [F, 3, H, W] of the same kind."""
         import torch
-        return self._frames(_native.lib().cm_comb_wrap_demodulate_frames, composite, torch.float32, out,
+        return self._frames(_native.lib().cm_comb_wrap_demodulate_frames_fused, composite, torch.float32, out,
                             lambda n: (n, 3, self.height, self.width), first_frame)
 
     def demodulate_frames_u8(self, composite8, first_frame=0, out=None):
@@ -142,7 +168,7 @@ class WrappedCombEngine(object):
         import torch
         if self.width % 4:
             raise NotImplementedError('the fused uint8 boundary needs a width that is a multiple of 4')
-        return self._frames(_native.lib().cm_comb_wrap_demodulate_frames_u8, composite8, torch.uint8, out,
+        return self._frames(_native.lib().cm_comb_wrap_demodulate_frames_fused_u8, composite8, torch.uint8, out,
                             lambda n: (n, self.height, self.width, 3), first_frame)
 
     # ---- the encoder side is the backend's (comb.py:90-94) ------------------------------------

@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define CM_ABI_VERSION 6
+#define CM_ABI_VERSION 7
 
 enum cm_status {
     CM_OK = 0,
@@ -131,7 +131,8 @@ typedef struct {
     int32_t depth;         /* how many previous calls of a run a demodulated line depends on (0..2) */
     int32_t first_is_plain;/* 1: calls with k == 0 come from the plain band-stop decoder (comb.py:48-49), table demod_first */
     int32_t main_luma_bandstop; /* 1: the main pass takes luma from the band-stop path (qam.py:57): plain PAL-S / NTSC */
-    int32_t reserved0;
+    int32_t skip_calls;    /* 0, or 2: the main pass leaves the calls k < 2 of every run to another launch - the fused wrapped combs
+                              (cm_comb_wrap_demodulate_frames_fused: PAL-D front end, depth 2, first_is_plain 0) */
     double carrier_phase_step; /* qam.py:15 */
     double resample_fir[41];   /* scipy.signal.firwin(41, 0.5, window=('kaiser', 5.0)) */
     cm_iir_desc extract2x;  /* qam.py:17 band-pass */
@@ -357,6 +358,19 @@ int cm_comb_wrap_demodulate_frames(const cm_plan *inner, const cm_plan *first, c
 /* the same with the ImageModem byte boundary (image.py:58-84): 'L' bytes [F][H][W] -> interleaved 'RGB' bytes [F][H][W][3] */
 int cm_comb_wrap_demodulate_frames_u8(const cm_plan *inner, const cm_plan *first, const cm_plan *backend, const cm_comb_wrap_desc *wrap,
                                       const uint8_t *composite8, uint8_t *rgb8, int64_t n_frames, int64_t first_frame, void *stream);
+/* The two entry points above with a fourth plan for long batches around PalDModem: `fused` = the PAL-D front end with TWO lines of history
+ * (cm_plan_desc: pipeline CM_PIPE_PAL_D, depth 2, first_is_plain 0, skip_calls 2, the wrapper's average / notch / delay folded into its lane
+ * tables), which decodes every call k >= 2 of every run in ONE pass over the frames - no component scratch, 16 instead of 40 bytes per pixel
+ * through HBM; the calls k < 2 (the top four rows of a frame: comb.py:97-99 and the first average, which mix in the plain decode) still go
+ * through the composition.  Same results (both halves are the reference's arithmetic, comb.py:96-113 over pal.py:79-127).  Falls back to
+ * the composition for short batches (the scan kernels' regime), pinned small-batch modes, heights < 8, widths that are not multiples
+ * of 4, and when `fused` is NULL. */
+int cm_comb_wrap_demodulate_frames_fused(const cm_plan *fused, const cm_plan *inner, const cm_plan *first, const cm_plan *backend,
+                                         const cm_comb_wrap_desc *wrap, const float *composite, float *rgb, int64_t n_frames,
+                                         int64_t first_frame, void *stream);
+int cm_comb_wrap_demodulate_frames_fused_u8(const cm_plan *fused, const cm_plan *inner, const cm_plan *first, const cm_plan *backend,
+                                            const cm_comb_wrap_desc *wrap, const uint8_t *composite8, uint8_t *rgb8, int64_t n_frames,
+                                            int64_t first_frame, void *stream);
 /* One run of n_calls consecutive calls as cm_demodulate_run: rows [n][W] -> [n][3][W]; a run submitted with k0 > 0 carries one
  * call of history in front (inner depth + 1 calls before the first wanted result). */
 int cm_comb_wrap_demodulate_run(const cm_plan *inner, const cm_plan *first, const cm_plan *backend, const cm_comb_wrap_desc *wrap,
