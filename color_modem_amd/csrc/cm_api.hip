@@ -2,6 +2,7 @@
 // kernel launches.  There is deliberately no host fallback in this file.
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstdio>
 #include <cstring>
 #include <mutex>
@@ -252,7 +253,7 @@ struct cm_plan {
     ScanSecamK *scan_sdem = nullptr;      // the SECAM decoder's (secam_demod_scan_kernel)
     int scan_sdem_c1 = 0;
     int scan_c1 = 0, scan_depth = 0;
-    mutable int small_batch = CM_SMALL_BATCH_AUTO;   // cm_plan_set_small_batch
+    mutable std::atomic<int> small_batch{CM_SMALL_BATCH_AUTO};   // cm_plan_set_small_batch (the one field that changes after creation: atomic)
     bool pair = false;             // wave-pair kernel (two wavefronts per 64 calls)
     Pass main, first;
     // modulator
@@ -1845,7 +1846,7 @@ struct cm_am_plan {
     ScanNiirK64 *scan_nd64 = nullptr;   // the float64 hue path's constants
     ScanNiirModK *scan_nm = nullptr;
     int scan_pd_c1 = 0, scan_pm_c1 = 0, scan_nd_c1 = 0, scan_nm_c1 = 0;
-    mutable int small_batch = CM_SMALL_BATCH_AUTO;     // cm_am_plan_set_small_batch
+    mutable std::atomic<int> small_batch{CM_SMALL_BATCH_AUTO};     // cm_am_plan_set_small_batch
 };
 #ifndef CM_AM_SCAN_MAX_CALLS
 #define CM_AM_SCAN_MAX_CALLS 30000

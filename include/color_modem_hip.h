@@ -396,7 +396,8 @@ void cm_set_pointer_check(int32_t on);
  * the row-parallel kernel - one wavefront per scan line, the recursive filters as a scan over the lanes (csrc/cm_scan_kernels.h) -
  * where the plan's shape fits it (rows up to ~2000 samples, SECAM decoders below 1280; floats or bytes at the boundary; encoders up to
  * 40000 calls), else it cuts the rows into segments that workgroups walk side by side.  Results agree with the row walk to ~1e-7 of full scale (tests: test_small_batch_modes).  This switch pins
- * one of the three for tests and measurements; CM_ERR_UNSUPPORTED when the plan has no scan kernel. */
+ * one of the three for tests and measurements; CM_ERR_UNSUPPORTED when the plan has no scan kernel.  It is the one call that changes a plan
+ * after its creation (an atomic field: safe beside running calls, which pick the mode up at their next launch); production code leaves it alone. */
 enum { CM_SMALL_BATCH_AUTO = 0, CM_SMALL_BATCH_ROWS = 1, CM_SMALL_BATCH_SEGMENTS = 2, CM_SMALL_BATCH_SCAN = 3 };
 int cm_plan_set_small_batch(const cm_plan *plan, int32_t mode);
 /* The same for a Proto-SECAM plan (csrc/cm_am_scan_kernels.h: protosecam.py:74-112 with one wavefront per scan line, rows up to
