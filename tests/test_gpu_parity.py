@@ -925,6 +925,35 @@ def test_wrapped_pal_comb_fused_long_batches(stack, size, frames):
     assert int(d8.max()) <= 1 and float((d8 > 0).float().mean()) < 1e-3, (stack, int(d8.max()))
 
 
+@pytest.mark.parametrize('variant,std,size,frames', [('PAL_M', 'NTSC_525', (720, 14), 1900), ('PAL_N', 'GERBER_625', (720, 10), 2500)])
+def test_wrapped_pal_comb_fused_variants(variant, std, size, frames):
+    """The fused plan on the other PAL shapes: PAL-M (4800-frame sub-carrier cycle: two-frame tables turned by the frame's angle,
+    cm_plan_desc::frame_rotation) and PAL-N, late frame numbers, the 3D and the plain wrapper."""
+    import torch
+    from oracle import cm_oracle
+    from color_modem_amd import comb, line
+    from color_modem_amd.color import pal
+    lc = line.LineConfig(size, getattr(line.LineStandard, std))
+    v = getattr(pal.PalVariant, variant)
+    for make in (lambda: comb.Simple3DCombModem(pal.PalDModem(lc, v)), lambda: comb.SimpleCombModem(pal.PalDModem(lc, v), avg=comb.minavg)):
+        modem = make()
+        eng = image.ImageModem(modem)._engine()
+        assert eng.fused is not None, variant
+        w, h = size
+        few = testing.synthetic_rgb(2, h, w, seed=7 + h)
+        comp2 = cm_oracle.modulate_frames_f32(pal.PalSModem(lc, v), few, first_frame=0, n_threads=4)
+        comp = torch.from_numpy(comp2).cuda().repeat((frames + 1) // 2, 1, 1)[:frames].contiguous()
+        first = 4797
+        got = eng.demodulate_frames(comp, first_frame=first)
+        for i in (0, 1, 5, frames - 2, frames - 1):
+            want = cm_oracle.demodulate_frames_f32(modem, comp2[i % 2][None], first_frame=first + i, n_threads=4)[0]
+            assert stacks.rel_err(got[i].cpu().numpy(), want) < TOL, (variant, i)
+        pinned = image.ImageModem(make())._engine()
+        pinned.set_small_batch('rows')
+        ref = pinned.demodulate_frames(comp, first_frame=first)
+        assert float((got - ref).abs().max() / ref.abs().max()) < 2e-6, variant
+
+
 @pytest.mark.parametrize('stack', ['simple3d_pald', 'simple_pal3d_notch'])
 @pytest.mark.parametrize('strip', [True, False])
 def test_wrapped_pal_comb_components(stack, strip):
