@@ -27,7 +27,9 @@ SYMBOLS = ('cm_last_error', 'cm_abi_version', 'cm_device_count', 'cm_plan_create
            'cm_am_modulate_run', 'cm_am_demodulate_run', 'cm_am_modulate_frames_noise', 'cm_am_modulate_run_noise',
            'cm_am_modulate_frames_u8', 'cm_am_demodulate_frames_u8', 'cm_am_plan_set_small_batch',
            'cm_comb_wrap_demodulate_frames', 'cm_comb_wrap_demodulate_frames_u8', 'cm_comb_wrap_demodulate_run', 'cm_filter_rows_f64',
-           'cm_comb_wrap_demodulate_frames_fused', 'cm_comb_wrap_demodulate_frames_fused_u8')
+           'cm_comb_wrap_demodulate_frames_fused', 'cm_comb_wrap_demodulate_frames_fused_u8',
+           'cm_comb_wrap_calls_per_frame', 'cm_comb_wrap_components_frames', 'cm_comb_wrap_finish_frames', 'cm_comb_wrap_components_run',
+           'cm_comb_wrap_finish_run')
 
 _lib = None
 
@@ -111,6 +113,11 @@ def lib():
     L.cm_comb_wrap_demodulate_run.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]
     L.cm_comb_wrap_demodulate_frames_fused.argtypes = [vp, vp, vp, vp, vp, vp, vp, i64, i64, vp]
     L.cm_comb_wrap_demodulate_frames_fused_u8.argtypes = [vp, vp, vp, vp, vp, vp, vp, i64, i64, vp]
+    L.cm_comb_wrap_calls_per_frame.argtypes = [vp, vp]
+    L.cm_comb_wrap_components_frames.argtypes = [vp, vp, vp, vp, vp, vp, i64, i64, vp]
+    L.cm_comb_wrap_finish_frames.argtypes = [vp, vp, vp, vp, vp, vp, i64, i64, vp]
+    L.cm_comb_wrap_components_run.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]
+    L.cm_comb_wrap_finish_run.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]
     dp = ctypes.POINTER(ctypes.c_double)
     L.cm_filter_rows_f64.argtypes = [dp, i32, dp, i32, i32, vp, vp, i64, i32, vp]
     if L.cm_abi_version() != plan.CM_ABI_VERSION:

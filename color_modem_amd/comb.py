@@ -81,9 +81,8 @@ class SimpleCombModem(RowApi):
             # - 2 (own_delay - 1); the flattened plan has no such path.  ColorAveragingModem(SimpleCombModem(x)) is the
             # supported order (the comb then re-modulates through x itself).
             raise NotImplementedError('SimpleCombModem around ColorAveragingModem is not supported; wrap the other way round')
-        if self._avg is not globals()['avg'] and self._avg is not globals()['minavg']:
-            raise NotImplementedError('avg=%r: the device path implements comb.avg and comb.minavg, not arbitrary '
-                                      'callables' % (self._avg,))
+        # avg= callables other than comb.avg / comb.minavg (ref comb.py:72, 81-84): the composition of wrapped.py applies them to the
+        # component planes of consecutive calls between its two kernels (engine.make_engine routes the stack there)
         inner['demod_wrapper'] = 'simple_3d' if self._own_delay else 'simple'
         inner['wrapper_notch'] = self._notch
         inner['wrapper_avg'] = self._avg

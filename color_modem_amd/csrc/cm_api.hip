@@ -2460,13 +2460,13 @@ int launch_wrap_back(const Geom &g, const cm_plan *backend, const cm_comb_wrap_d
     a.notch_gain = w.notch.n_sections ? (float)g_n : 0.f;
     for (int i = 0; i < 9; ++i) a.m[i] = (float)w.matrix[i];
     a.own_delay = w.own_delay ? 1 : 0;
-    a.minavg = w.minavg ? 1 : 0;
+    a.minavg = w.minavg;
     a.strip = w.strip_chroma ? 1 : 0;
     const long long blocks = (g.total_calls + 62) / 63;
     if (blocks <= 0) return CM_OK;
     if (blocks > 0x7fffffffLL) return fail(CM_ERR_INVALID, "batch too large for one launch");
     const bool notch = a.notch_gain != 0.f;
-    if (a.minavg) return notch ? launch_wrap_back_i<NP, SP, U8, RT, true, true>(a, (int)blocks, stream)
+    if (a.minavg == 1) return notch ? launch_wrap_back_i<NP, SP, U8, RT, true, true>(a, (int)blocks, stream)
                                : launch_wrap_back_i<NP, SP, U8, RT, true, false>(a, (int)blocks, stream);
     return notch ? launch_wrap_back_i<NP, SP, U8, RT, false, true>(a, (int)blocks, stream)
                  : launch_wrap_back_i<NP, SP, U8, RT, false, false>(a, (int)blocks, stream);
@@ -2489,7 +2489,7 @@ int wrap_back_scan(const Geom &g, const cm_plan *backend, const cm_comb_wrap_des
     }
     for (int i = 0; i < 9; ++i) a.m[i] = (float)w.matrix[i];
     a.own_delay = w.own_delay ? 1 : 0;
-    a.minavg = w.minavg ? 1 : 0;
+    a.minavg = w.minavg;
     a.strip = w.strip_chroma ? 1 : 0;
     return cm_host::scan_launch_wrap_back(backend->scan_mod_c1, U8, backend->device, backend->scan_mod, a, g, stream);
 }
@@ -2530,6 +2530,7 @@ int check_wrap(const cm_plan *inner, const cm_plan *first, const cm_plan *backen
     if (first && (first->has_first || first->desc.first_is_plain)) return fail(CM_ERR_INVALID, "the `first` plan must be a plain decoder");
     if (w->notch.n_sections && (w->notch.n_sections != 1 || w->notch.shift != 0)) return fail(CM_ERR_UNSUPPORTED, "notch: one section, shift 0");
     if (w->own_delay < 0 || w->own_delay > 1) return fail(CM_ERR_INVALID, "own_delay must be 0 or 1");
+    if (w->minavg < 0 || w->minavg > 2) return fail(CM_ERR_INVALID, "minavg must be 0 (comb.avg), 1 (comb.minavg) or 2 (averaged by the caller)");
     return CM_OK;
 }
 // one non-blocking side stream per device, created on first use (the wrapped combs' first-line pass runs on it)
@@ -2608,7 +2609,9 @@ struct AsyncBuf {
 // k < keep_calls of every run are stored - the share of a fused wrapped comb that mixes two front ends (wrap_frames_fused).
 int wrap_frames(const cm_plan *inner, const cm_plan *first, const cm_plan *backend, const cm_comb_wrap_desc *w, const float *in,
                 const uint8_t *in8, void *out, int wp, int64_t n_frames, int64_t first_frame, hipStream_t stream, int h_top = 0,
-                int keep_calls = 0) {
+                int keep_calls = 0, float *components = nullptr, int phase = 0) {
+    // components != null: the caller's [frame][call][3][wp] buffer takes the place of the scratch, whole batch at once; phase 1 stops behind
+    // the inner decoder (the buffer is the result), phase 2 starts at the back end (the buffer is the input) - avg= callables average in between
     const bool u8 = in8 != nullptr;
     const cm_plan_desc &d = inner->desc;
     const int W = d.width, full_H = d.height, H = h_top > 0 ? h_top : full_H, D = d.demodulation_delay + (w->own_delay ? 1 : 0);
@@ -2637,11 +2640,12 @@ int wrap_frames(const cm_plan *inner, const cm_plan *first, const cm_plan *backe
     const size_t frame_bytes = (size_t)g.calls_per_frame * 3 * wp * sizeof(float);
     int64_t chunk = (int64_t)(CM_WRAP_SCRATCH_BYTES / frame_bytes);
     if (chunk < 1) chunk = 1;
-    if (chunk > n_frames) chunk = n_frames;
+    if (chunk > n_frames || components) chunk = n_frames;
     AsyncBuf scratch, comp;
     scratch.stream = comp.stream = stream;
     if (int rc_ = refuse_capture(stream, "a wrapped comb decoder")) return rc_;
-    HIP_TRY(hipMallocAsync(&scratch.p, (size_t)chunk * frame_bytes, stream), CM_ERR_LAUNCH);
+    if (!components) HIP_TRY(hipMallocAsync(&scratch.p, (size_t)chunk * frame_bytes, stream), CM_ERR_LAUNCH);
+    float *const sc = components ? components : (float *)scratch.p;
     const long long frame_quads = (long long)H * (wp / 4);
     if (in8) HIP_TRY(hipMallocAsync(&comp.p, (size_t)chunk * frame_quads * 16, stream), CM_ERR_LAUNCH);
     for (int64_t f0 = 0; f0 < n_frames; f0 += chunk) {
@@ -2658,9 +2662,10 @@ int wrap_frames(const cm_plan *inner, const cm_plan *first, const cm_plan *backe
         } else
         gi.in = in + f0 * g.in_frame_stride;
         gi.total_calls = nf * g.calls_per_frame;
-        if ((rc = run_wrap_inner(inner, first, gi, (float *)scratch.p, first_frame + f0, true, stream))) return rc;
+        if (phase != 2 && (rc = run_wrap_inner(inner, first, gi, sc, first_frame + f0, true, stream))) return rc;
+        if (phase == 1) continue;
         Geom gb = g;
-        gb.in = (const float *)scratch.p;
+        gb.in = sc;
         gb.in_plane_stride = wp;
         gb.in_row_stride = 3LL * wp;
         gb.in_frame_stride = 3LL * wp * g.calls_per_frame;
@@ -2801,16 +2806,19 @@ int cm_comb_wrap_demodulate_frames_fused_u8(const cm_plan *fused, const cm_plan 
     return wrap_frames_fused(fused, inner, first, backend, w, nullptr, composite8, rgb8, inner->desc.width, n_frames, first_frame, (hipStream_t)stream);
 }
 
-int cm_comb_wrap_demodulate_run(const cm_plan *inner, const cm_plan *first, const cm_plan *backend, const cm_comb_wrap_desc *w,
-                                const float *composite, float *rgb, int32_t n_calls, int32_t frame, int32_t first_line, int32_t k0,
-                                void *stream) {
+// phase 0: composite rows -> rgb rows; 1: composite rows -> `components` [n][3][W]; 2: `components` -> rgb rows (widths that are multiples of 4)
+static int wrap_run(const cm_plan *inner, const cm_plan *first, const cm_plan *backend, const cm_comb_wrap_desc *w, const float *composite,
+                    float *components, float *rgb, int32_t n_calls, int32_t frame, int32_t first_line, int32_t k0, void *stream, int phase) {
     if (int rc = check_wrap(inner, first, backend, w)) return rc;
     if (n_calls == 0) return CM_OK;
-    if (!composite || !rgb) return fail(CM_ERR_INVALID, "null argument");
+    if ((phase != 2 && !composite) || (phase != 1 && !rgb) || (phase != 0 && !components)) return fail(CM_ERR_INVALID, "null argument");
     if (n_calls < 0 || frame < 0 || k0 < 0 || first_line < 0) return fail(CM_ERR_INVALID, "negative count / frame / line / k0");
-    if (int rc_ = check_device(inner->device, composite, rgb)) return rc_;
+    if (int rc_ = check_device(inner->device, phase == 2 ? components : composite, phase == 1 ? components : rgb)) return rc_;
     const cm_plan_desc &d = inner->desc;
     const int W = d.width, wp = (W + 3) & ~3;
+    if (phase != 0 && wp != W) return fail(CM_ERR_UNSUPPORTED, "the component buffer form needs a width that is a multiple of 4");
+    if (phase == 2) composite = components;      // (any valid rows: with_pitched_rows passes aligned rows through untouched)
+    if (phase == 1) rgb = components;
     const int last_line = first_line + 2 * (n_calls - 1);
     int rc = check_lines(inner, inner->main, last_line);
     if (rc) return rc;
@@ -2832,11 +2840,14 @@ int cm_comb_wrap_demodulate_run(const cm_plan *inner, const cm_plan *first, cons
         if (int rc_ = refuse_capture((hipStream_t)stream, "a wrapped comb decoder")) return rc_;
         AsyncBuf scratch;
         scratch.stream = (hipStream_t)stream;
-        HIP_TRY(hipMallocAsync(&scratch.p, (size_t)n_calls * 3 * wp * sizeof(float), (hipStream_t)stream), CM_ERR_LAUNCH);
-        int rc2 = run_wrap_inner(inner, first, g, (float *)scratch.p, frame, k0 == 0, (hipStream_t)stream);
-        if (rc2) return rc2;
+        if (phase == 0) HIP_TRY(hipMallocAsync(&scratch.p, (size_t)n_calls * 3 * wp * sizeof(float), (hipStream_t)stream), CM_ERR_LAUNCH);
+        float *const sc = phase == 0 ? (float *)scratch.p : components;
+        if (phase != 2) {
+            int rc2 = run_wrap_inner(inner, first, g, sc, frame, k0 == 0, (hipStream_t)stream);
+            if (rc2 || phase == 1) return rc2;
+        }
         Geom gb = g;
-        gb.in = (const float *)scratch.p;
+        gb.in = sc;
         gb.in_plane_stride = wp;
         gb.in_row_stride = 3LL * wp;
         gb.out = out;
@@ -2844,6 +2855,46 @@ int cm_comb_wrap_demodulate_run(const cm_plan *inner, const cm_plan *first, cons
         gb.out_row_stride = 3LL * wp;
         return run_wrap_back(gb, backend, *w, frame, false, (hipStream_t)stream);
     });
+}
+int cm_comb_wrap_demodulate_run(const cm_plan *inner, const cm_plan *first, const cm_plan *backend, const cm_comb_wrap_desc *w,
+                                const float *composite, float *rgb, int32_t n_calls, int32_t frame, int32_t first_line, int32_t k0,
+                                void *stream) {
+    return wrap_run(inner, first, backend, w, composite, nullptr, rgb, n_calls, frame, first_line, k0, stream, 0);
+}
+// The composition cut in two for avg= callables (comb.py:72, 81-84, 103-104): the caller averages the (u, v) planes of consecutive calls of the
+// component buffer between the halves (cm_comb_wrap_desc.minavg = 2: the back end takes them as they are).
+int cm_comb_wrap_components_run(const cm_plan *inner, const cm_plan *first, const cm_plan *backend, const cm_comb_wrap_desc *w,
+                                const float *composite, float *components, int32_t n_calls, int32_t frame, int32_t first_line, int32_t k0,
+                                void *stream) {
+    return wrap_run(inner, first, backend, w, composite, components, nullptr, n_calls, frame, first_line, k0, stream, 1);
+}
+int cm_comb_wrap_finish_run(const cm_plan *inner, const cm_plan *first, const cm_plan *backend, const cm_comb_wrap_desc *w,
+                            float *components, float *rgb, int32_t n_calls, int32_t frame, int32_t first_line, int32_t k0, void *stream) {
+    return wrap_run(inner, first, backend, w, nullptr, components, rgb, n_calls, frame, first_line, k0, stream, 2);
+}
+int cm_comb_wrap_calls_per_frame(const cm_plan *inner, const cm_comb_wrap_desc *w) {
+    if (!inner || !w) return fail(CM_ERR_INVALID, "null argument");
+    const int H = inner->desc.height, D = inner->desc.demodulation_delay + (w->own_delay ? 1 : 0);
+    return (H + 1) / 2 + D + (H / 2 > 0 ? H / 2 + D : 0);
+}
+static int wrap_frames_split(const cm_plan *inner, const cm_plan *first, const cm_plan *backend, const cm_comb_wrap_desc *w, const float *composite,
+                             float *components, float *rgb, int64_t n_frames, int64_t first_frame, void *stream, int phase) {
+    if (int rc = check_wrap(inner, first, backend, w)) return rc;
+    if (n_frames == 0) return CM_OK;
+    if ((phase == 1 && !composite) || (phase == 2 && !rgb) || !components) return fail(CM_ERR_INVALID, "null argument");
+    if (n_frames < 0 || first_frame < 0) return fail(CM_ERR_INVALID, "negative frame count / number");
+    if (int rc_ = check_device(inner->device, phase == 1 ? composite : components, phase == 1 ? components : rgb)) return rc_;
+    const int W = inner->desc.width;
+    if (W % 4 != 0) return fail(CM_ERR_UNSUPPORTED, "the component buffer form needs a width that is a multiple of 4");
+    return wrap_frames(inner, first, backend, w, composite, nullptr, rgb, W, n_frames, first_frame, (hipStream_t)stream, 0, 0, components, phase);
+}
+int cm_comb_wrap_components_frames(const cm_plan *inner, const cm_plan *first, const cm_plan *backend, const cm_comb_wrap_desc *w,
+                                   const float *composite, float *components, int64_t n_frames, int64_t first_frame, void *stream) {
+    return wrap_frames_split(inner, first, backend, w, composite, components, nullptr, n_frames, first_frame, stream, 1);
+}
+int cm_comb_wrap_finish_frames(const cm_plan *inner, const cm_plan *first, const cm_plan *backend, const cm_comb_wrap_desc *w,
+                               float *components, float *rgb, int64_t n_frames, int64_t first_frame, void *stream) {
+    return wrap_frames_split(inner, first, backend, w, nullptr, components, rgb, n_frames, first_frame, stream, 2);
 }
 }  // extern "C"
 

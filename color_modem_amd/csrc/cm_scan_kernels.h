@@ -892,9 +892,9 @@ __global__ __launch_bounds__(64 * NW) void wrap_back_scan_kernel(const Geom g, c
 #pragma unroll
     for (int i = 0; i < C1; ++i) car2[i] = *(const f2 *)(g.carrier2 + 2 * (n0 + i < W ? n0 + i : W - 1));
     auto mix = [&](float cy, float cu, float cv, float py, float pu, float pv, float &ys, float &u, float &v) {
-        u = a.minavg ? minavg_(pu, cu) : 0.5f * (pu + cu);                     // comb.py:102-104
-        v = a.minavg ? minavg_(pv, cv) : 0.5f * (pv + cv);
-        if (first) { u = cu; v = cv; }
+        u = a.minavg == 1 ? minavg_(pu, cu) : 0.5f * (pu + cu);                // comb.py:102-104
+        v = a.minavg == 1 ? minavg_(pv, cv) : 0.5f * (pv + cv);
+        if (first || a.minavg == 2) { u = cu; v = cv; }          // (2: the caller has averaged the component buffer itself - avg= callables)
         ys = take_prev_y ? py : cy;
     };
     float y[C1], ud[C1], vd[C1];

@@ -31,7 +31,7 @@ struct WrapBackArgs {
     float notch_gain;         // 0: no notch
     float m[9];               // decode matrix (identity in component mode)
     int own_delay;            // 1: luma source = the previous call's luma, re-modulation at line - 2 (comb.py:102, 105)
-    int minavg;               // comb.py:13-15 instead of comb.py:9-10
+    int minavg;               // 1: comb.py:13-15 instead of comb.py:9-10; 2: (u, v) of the component buffer are final (avg= callables, averaged by the caller)
     int strip;                // 0: demodulate_components(strip_chroma = False)
 };
 
@@ -103,7 +103,7 @@ __global__ __launch_bounds__(64, 2) void comb_wrap_back_kernel(const WrapBackArg
             const float py = lane_from(idx1, cy), pu = lane_from(idx1, cu), pv = lane_from(idx1, cv);
             float u = MINAVG ? minavg_(pu, cu) : 0.5f * (pu + cu);
             float v = MINAVG ? minavg_(pv, cv) : 0.5f * (pv + cv);
-            if (first) { u = cu; v = cv; }
+            if (first || args.minavg == 2) { u = cu; v = cv; }
             const float ys = take_prev_y ? py : cy;
             yw[SP + s] = ys; uw[SP + s] = u; vw[SP + s] = v;
             const int n7 = t - sp;

@@ -191,11 +191,18 @@ def stack_backend(modem):
     return modem._stack().get('backend', modem)
 
 
+def _custom_avg(stack):
+    """a comb wrapper with an avg= callable of the caller's own (ref comb.py:72, 81-84): not one of the two the fused tables express"""
+    from color_modem_amd import comb
+    fn = stack.get('wrapper_avg')
+    return fn is not None and fn is not comb.avg and fn is not comb.minavg
+
+
 def make_engine(modem, components=False, strip_chroma=True, min_lines=0):
     """The engine of a modem stack: a cm_plan for the QAM / SECAM families, the plan-less MAC entry points for MacModem."""
     stack = modem._stack()
     kind = stack['kind']
-    if stack.get('demod_wrapper') and kind in ('pal_d', 'pal_3d'):
+    if stack.get('demod_wrapper') and (kind in ('pal_d', 'pal_3d') or (kind in ('pal_s', 'ntsc', 'ntsc_comb') and _custom_avg(stack) and not stack.get('mod_wrapper'))):
         from color_modem_amd import wrapped
         return wrapped.WrappedCombEngine(modem, components, strip_chroma, min_lines)
     if kind == 'mac':

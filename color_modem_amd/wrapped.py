@@ -15,7 +15,14 @@ Pal3DModem it reaches back three lines.  They run as two streaming kernels per b
     decode_components                                                           |
 
 This module only builds the three plans (inner decoder, plain first-line decoder, backend modulator) and the wrapper's
-descriptor.  Not built: avg= callables other than comb.avg / comb.minavg.
+descriptor.
+
+avg= callables other than comb.avg / comb.minavg (comb.py:72, 81-84) run through the same composition, cut in two
+(`cm_comb_wrap_components_*` / `cm_comb_wrap_finish_*`): the caller's function is applied between the kernels to the (u, v) planes of
+consecutive calls - as float32 torch tensors ON THE DEVICE, a whole batch at a time ([frames, calls - 1, W] per run), where the reference
+hands it one float64 numpy row per call; elementwise functions of two arrays (the only kind that makes sense there) behave the same.
+That also serves the wrappers around the plain decoders (NtscModem, PalSModem, NtscCombModem), whose comb.avg / comb.minavg forms are
+fused into lane tables instead.
 
 Round 4: around PalDModem a fourth plan removes the component scratch from long batches.  From the third call of a run on, both
 chroma estimates the wrapper averages are PAL-D decodes - combinations of the PAL-D front end's base pairs of three consecutive
@@ -54,14 +61,17 @@ class WrappedCombEngine(object):
         from color_modem_amd import comb as comb_module
         stack = modem._stack()
         fn = stack.get('wrapper_avg')
-        if fn is not comb_module.avg and fn is not comb_module.minavg:
-            raise NotImplementedError('avg=%r: the device path implements comb.avg and comb.minavg' % (fn,))
+        self.custom_avg = fn if (fn is not comb_module.avg and fn is not comb_module.minavg) else None
+        if self.custom_avg is not None and not callable(self.custom_avg):
+            raise TypeError('avg=%r is not callable' % (fn,))
+        if self.custom_avg is not None:
+            self.composite = True      # rowapi: runs go through demodulate_run below (the callable sits between two native calls)
         notch = stack.get('wrapper_notch')
         if notch is not None and notch.shift != 0:
             raise NotImplementedError('notch filters with a group delay at DC that rounds to %d samples (very low Q) '
                                       'are not built; shift 0 is' % notch.shift)
         self.own_delay = 1 if stack['demod_wrapper'] == 'simple_3d' else 0
-        self.inner_modem = stack['comb']                    # PalDModem / Pal3DModem
+        self.inner_modem = stack.get('comb') or stack['backend']      # PalDModem / Pal3DModem (avg= callables: any QAM-family decoder)
         self.backend = stack['backend']                     # PalSModem
         lc = self.backend.line_config
         self.width, self.height = int(lc.size[0]), int(lc.size[1])
@@ -78,7 +88,7 @@ class WrappedCombEngine(object):
         self.mod = engine.Engine(self.backend, components=True, min_lines=need)       # the wrapper re-modulates through the backend
         self.encoder = engine.Engine(self.backend, components=components, min_lines=need)     # wrapper.modulate = backend.modulate
         self.fused = None
-        if stack['kind'] == 'pal_d':
+        if stack['kind'] == 'pal_d' and self.custom_avg is None:
             try:
                 self.fused = engine.Engine(_FusedStack(stack), components=components, strip_chroma=strip_chroma, min_lines=need)
             except NotImplementedError:      # no PAL-D depth-2 instance for this filter-set shape: the composition serves every batch
@@ -88,7 +98,7 @@ class WrappedCombEngine(object):
         self.n_lines = min(e.n_lines for e in (self.inner, self.first, self.mod, self.encoder) if e is not None)
         w = CombWrapDesc()
         w.own_delay = self.own_delay
-        w.minavg = 1 if fn is comb_module.minavg else 0
+        w.minavg = 2 if self.custom_avg is not None else (1 if fn is comb_module.minavg else 0)
         w.strip_chroma = 1 if strip_chroma else 0
         w.notch = plan.iir_desc(notch)
         eye = numpy.eye(3)
@@ -134,9 +144,65 @@ class WrappedCombEngine(object):
         t = torch.from_numpy(numpy.ascontiguousarray(rows, dtype=numpy.float32)).cuda() if was_numpy else rows.contiguous()
         if t.dim() != 2 or t.shape[1] != self.width or t.dtype != torch.float32:
             raise ValueError('rows: expected float32 [n, %d]' % self.width)
+        if not t.is_cuda:
+            t = t.cuda()
         out = torch.empty((t.shape[0], 3, self.width), dtype=torch.float32, device=t.device)
-        self._call(_native.lib().cm_comb_wrap_demodulate_run, t, out, int(t.shape[0]), int(frame), int(first_line), int(k0))
+        args = (int(t.shape[0]), int(frame), int(first_line), int(k0))
+        if self.custom_avg is None:
+            self._call(_native.lib().cm_comb_wrap_demodulate_run, t, out, *args)
+        else:
+            self._need_quads()
+            buf = torch.empty((t.shape[0], 3, self.width), dtype=torch.float32, device=t.device)
+            self._call(_native.lib().cm_comb_wrap_components_run, t, buf, *args)
+            self._average(buf[None], [(0, int(t.shape[0]))])
+            self._call(_native.lib().cm_comb_wrap_finish_run, buf, out, *args)
         return out.cpu().numpy() if was_numpy else out
+
+    # ---- avg= callables: between the two halves of the composition ------------------------------
+    def _need_quads(self):
+        if self.width % 4:
+            raise NotImplementedError('avg= callables need a width that is a multiple of 4 (the component buffer form of the composition)')
+
+    def _average(self, buf, runs):
+        """buf [frames, calls, 3, W] as the inner decoder left it; runs: [lo, hi) call ranges of one frame.  (u, v) of every call but a
+        run's first become avg(previous call's, this call's) - comb.py:103-104 - both taken from the buffer as it was."""
+        import torch
+        fn = self.custom_avg
+        for lo, hi in runs:
+            if hi - lo < 2:
+                continue
+            done = []
+            for plane in (1, 2):
+                last, curr = buf[:, lo:hi - 1, plane], buf[:, lo + 1:hi, plane]
+                try:
+                    res = fn(last, curr)
+                except TypeError as e:
+                    raise TypeError('avg=%r is applied to float32 torch tensors on the device (a whole batch at a time); it must be '
+                                    'an elementwise function of two arrays that works on them: %s' % (fn, e))
+                if not torch.is_tensor(res):
+                    res = torch.as_tensor(res, dtype=torch.float32, device=buf.device)
+                if tuple(res.shape) != tuple(curr.shape):
+                    raise ValueError('avg=%r returned shape %s for inputs of shape %s' % (fn, tuple(res.shape), tuple(curr.shape)))
+                done.append(res.to(device=buf.device, dtype=torch.float32).clone())
+            buf[:, lo + 1:hi, 1] = done[0]
+            buf[:, lo + 1:hi, 2] = done[1]
+
+    def _frames_custom(self, comp, out, first_frame):
+        import torch
+        self._need_quads()
+        L = _native.lib()
+        inner = self.inner._plans.get(comp.device)
+        calls = int(L.cm_comb_wrap_calls_per_frame(inner, ctypes.byref(self.desc)))
+        if calls <= 0:
+            _native.check(calls)
+        run0 = (self.height + 1) // 2 + self.demodulation_delay
+        budget = max(1, (1 << 30) // (calls * 3 * self.width * 4))        # frames per pass: the component buffer stays within 1 GiB
+        for f0 in range(0, comp.shape[0], budget):
+            part = comp[f0:f0 + budget]
+            buf = torch.empty((part.shape[0], calls, 3, self.width), dtype=torch.float32, device=comp.device)
+            self._call(L.cm_comb_wrap_components_frames, part, buf, int(part.shape[0]), int(first_frame) + f0)
+            self._average(buf, [(0, run0), (run0, calls)])
+            self._call(L.cm_comb_wrap_finish_frames, buf, out[f0:f0 + budget], int(part.shape[0]), int(first_frame) + f0)
 
     # ---- frames: the row schedule of image.py:75-83 --------------------------------------------
     def _frames(self, fn, composite, dtype, out, out_shape_of, first_frame):
@@ -154,7 +220,12 @@ class WrappedCombEngine(object):
             out = torch.empty(shape, dtype=dtype, device=comp.device)
         else:
             engine._check_out(out, shape, dtype, comp.device)
-        self._call(fn, comp, out, int(comp.shape[0]), int(first_frame), fused=True)
+        if self.custom_avg is not None:
+            if dtype != torch.float32:
+                raise NotImplementedError('avg= callables run on float rows (the PIL entry points convert on the host)')
+            self._frames_custom(comp, out, first_frame)
+        else:
+            self._call(fn, comp, out, int(comp.shape[0]), int(first_frame), fused=True)
         return out.cpu().numpy() if was_numpy else out
 
     def demodulate_frames(self, composite, first_frame=0, out=None):

@@ -346,7 +346,8 @@ int cm_am_modulate_run_noise(const cm_am_plan *plan, const float *rgb, const flo
  * The plans' lane tables must cover line numbers up to height - 1 + 2 (inner demodulation_delay + own_delay). */
 typedef struct {
     int32_t own_delay;      /* 1: Simple3DCombModem / SimpleCombModem(delay=True) (comb.py:74, 126) */
-    int32_t minavg;         /* 1: avg=comb.minavg (comb.py:13-15), 0: comb.avg (comb.py:9-10) */
+    int32_t minavg;         /* 1: avg=comb.minavg (comb.py:13-15), 0: comb.avg (comb.py:9-10), 2: the caller averaged the component buffer
+                               (cm_comb_wrap_finish_*: avg= callables) */
     int32_t strip_chroma;   /* the flag of demodulate_components (comb.py:96); 1 for demodulate */
     int32_t reserved;
     cm_iir_desc notch;      /* the wrapper's notch= (comb.py:18-20, 86-88): one section, shift 0; n_sections = 0: none */
@@ -385,6 +386,23 @@ int cm_comb_wrap_demodulate_run(const cm_plan *inner, const cm_plan *first, cons
 #define CM_FILTER_MAX_TAPS 25
 int cm_filter_rows_f64(const double *b, int32_t n_b, const double *a, int32_t n_a, int32_t shift, const double *x, double *y,
                        int64_t n_rows, int32_t width, void *stream);
+
+/* avg= callables (comb.py:72, 81-84: SimpleCombModem(avg=f) combines the chroma of consecutive calls with the caller's own function,
+ * comb.py:103-104).  The composition cut in two: `components` receives what the inner decoder returns for every call of every run,
+ * [frame][call][3 = y, u, v][W] floats in call order (frames entry points: cm_comb_wrap_calls_per_frame() calls per frame - both fields, each
+ * with its delay calls; run entry points: [n_calls][3][W]); the caller replaces (u, v) of every call k >= 1 of a run by f(previous call's,
+ * this call's) - taken from the buffer as it was filled - and hands the buffer to the second half with cm_comb_wrap_desc.minavg = 2, which
+ * does the rest of comb.py:101-110 (luma source, re-modulation, strip, notch, matrix).  Widths that are multiples of 4; float rows only. */
+int cm_comb_wrap_calls_per_frame(const cm_plan *inner, const cm_comb_wrap_desc *wrap);
+int cm_comb_wrap_components_frames(const cm_plan *inner, const cm_plan *first, const cm_plan *backend, const cm_comb_wrap_desc *wrap,
+                                   const float *composite, float *components, int64_t n_frames, int64_t first_frame, void *stream);
+int cm_comb_wrap_finish_frames(const cm_plan *inner, const cm_plan *first, const cm_plan *backend, const cm_comb_wrap_desc *wrap,
+                               float *components, float *rgb, int64_t n_frames, int64_t first_frame, void *stream);
+int cm_comb_wrap_components_run(const cm_plan *inner, const cm_plan *first, const cm_plan *backend, const cm_comb_wrap_desc *wrap,
+                                const float *composite, float *components, int32_t n_calls, int32_t frame, int32_t first_line, int32_t k0,
+                                void *stream);
+int cm_comb_wrap_finish_run(const cm_plan *inner, const cm_plan *first, const cm_plan *backend, const cm_comb_wrap_desc *wrap,
+                            float *components, float *rgb, int32_t n_calls, int32_t frame, int32_t first_line, int32_t k0, void *stream);
 
 /* Every compute entry point checks that the plan's device is the current one and that both image buffers are memory the HIP
  * runtime knows as accessible from it (CM_ERR_INVALID for another GPU's memory, pageable host memory and pointers the runtime

@@ -252,10 +252,27 @@ STACKS.update({
     'simple3d_pald_notch': lambda lc: comb.Simple3DCombModem(pal.PalDModem(lc), notch=6.0),
     'simple_pal3d_notch': lambda lc: comb.SimpleCombModem(pal.Pal3DModem(lc), notch=3.0, avg=comb.minavg),
 })
+
+
+# avg= callables of the caller's own (comb.py:72, 81-84) - the same two functions in tests/stacks.py and tests/golden/make_golden.py
+def weighted_avg(last, curr):
+    return 0.25 * last + 0.75 * curr
+
+
+def smaller_of(last, curr):
+    return (abs(last) < abs(curr)) * last + (abs(last) >= abs(curr)) * curr
+
+
+STACKS.update({
+    'simple3d_pald_favg': lambda lc: comb.Simple3DCombModem(pal.PalDModem(lc), avg=weighted_avg),
+    'simple_pal3d_favg': lambda lc: comb.SimpleCombModem(pal.Pal3DModem(lc), avg=smaller_of, notch=4.0),
+    'simple_ntsc_favg': lambda lc: comb.SimpleCombModem(ntsc.NtscModem(lc), avg=smaller_of),
+    'simple3d_ntsccomb_favg': lambda lc: comb.Simple3DCombModem(ntsc.NtscCombModem(lc), avg=weighted_avg),
+})
 STANDARD = {'pal': 'GERBER_625', 'ntsc': 'NTSC_525', 'secam': 'GERBER_625', 'simple3d': 'GERBER_625', 'simple': 'GERBER_625'}
 STANDARD_OF = {'pal_d_palm': 'NTSC_525', 'pal_s_palm': 'NTSC_525', 'pal_d_60': 'NTSC_525', 'pal_s_60': 'NTSC_525',
                'ntsc_comb_n': 'GERBER_625', 'ntsc_n': 'GERBER_625', 'ntsc_comb_i': 'GERBER_625', 'ntsc_i': 'GERBER_625',
-               'secam_m': 'NTSC_525', 'secam_a': 'BAIRD_405'}
+               'secam_m': 'NTSC_525', 'secam_a': 'BAIRD_405', 'simple_ntsc_favg': 'NTSC_525', 'simple3d_ntsccomb_favg': 'NTSC_525'}
 
 
 def line_config(stack, size):
@@ -421,6 +438,18 @@ def wrapper_cases(only=()):
         save('frames_demod_' + stack, inp=comp, out=out, frames=numpy.array(frames), size=numpy.array([W, H]))
 
 
+def callable_cases():
+    """SimpleCombModem / Simple3DCombModem with an avg= callable of the caller's own (comb.py:72, 81-84, 103-104)."""
+    W, H = 720, 10
+    for stack, frames in (('simple3d_pald_favg', [1, 2]), ('simple_pal3d_favg', [0, 3]), ('simple_ntsc_favg', [1, 2]), ('simple3d_ntsccomb_favg', [0, 1])):
+        lc = line_config(stack, (W, H))
+        enc = STACKS['ntsc' if 'ntsc' in stack else 'pal_s'](lc)
+        rgb = testing.synthetic_rgb(len(frames), H, W, seed=654)
+        comp = numpy.stack([run_mod_frame(enc, rgb[i].astype(numpy.float64), f) for i, f in enumerate(frames)]).astype(numpy.float32)
+        out = numpy.stack([run_demod_frame(STACKS[stack](lc), comp[i].astype(numpy.float64), f) for i, f in enumerate(frames)])
+        save('frames_demod_' + stack, inp=comp, out=out, frames=numpy.array(frames), size=numpy.array([W, H]))
+
+
 def degenerate_pictures(W, H):
     """The inputs of the degenerate_* sets (shared with make_golden_am.py / make_golden_mac.py): black / white / mid-grey / saturated red pictures
     and all-zero / constant composites - where an algorithm divides by an amplitude or takes the angle of a vanishing pair."""
@@ -500,12 +529,16 @@ if __name__ == '__main__':
     if sys.argv[1:2] == ['degenerate']:
         degenerate_cases()
         sys.exit(0)
+    if sys.argv[1:2] == ['callables']:
+        callable_cases()
+        sys.exit(0)
     make_plans()
     frame_cases()
     option_cases()
     width_cases()
     variant_cases()
     wrapper_cases()
+    callable_cases()
     degenerate_cases()
     row_cases()
     image_cases()

@@ -69,10 +69,27 @@ STACKS.update({
     'simple3d_pald_notch': lambda lc: comb.Simple3DCombModem(pal.PalDModem(lc), notch=6.0),
     'simple_pal3d_notch': lambda lc: comb.SimpleCombModem(pal.Pal3DModem(lc), notch=3.0, avg=comb.minavg),
 })
+
+
+# avg= callables of the caller's own (comb.py:72, 81-84) - the same two functions in tests/stacks.py and tests/golden/make_golden.py
+def weighted_avg(last, curr):
+    return 0.25 * last + 0.75 * curr
+
+
+def smaller_of(last, curr):
+    return (abs(last) < abs(curr)) * last + (abs(last) >= abs(curr)) * curr
+
+
+STACKS.update({
+    'simple3d_pald_favg': lambda lc: comb.Simple3DCombModem(pal.PalDModem(lc), avg=weighted_avg),
+    'simple_pal3d_favg': lambda lc: comb.SimpleCombModem(pal.Pal3DModem(lc), avg=smaller_of, notch=4.0),
+    'simple_ntsc_favg': lambda lc: comb.SimpleCombModem(ntsc.NtscModem(lc), avg=smaller_of),
+    'simple3d_ntsccomb_favg': lambda lc: comb.Simple3DCombModem(ntsc.NtscCombModem(lc), avg=weighted_avg),
+})
 STANDARD = {'pal': 'GERBER_625', 'ntsc': 'NTSC_525', 'secam': 'GERBER_625', 'simple3d': 'GERBER_625', 'simple': 'GERBER_625'}
 STANDARD_OF = {'pal_d_palm': 'NTSC_525', 'pal_s_palm': 'NTSC_525', 'pal_d_60': 'NTSC_525', 'pal_s_60': 'NTSC_525',
                'ntsc_comb_n': 'GERBER_625', 'ntsc_n': 'GERBER_625', 'ntsc_comb_i': 'GERBER_625', 'ntsc_i': 'GERBER_625',
-               'secam_m': 'NTSC_525', 'secam_a': 'BAIRD_405'}
+               'secam_m': 'NTSC_525', 'secam_a': 'BAIRD_405', 'simple_ntsc_favg': 'NTSC_525', 'simple3d_ntsccomb_favg': 'NTSC_525'}
 
 
 def line_config(stack, size, explicit=True):
