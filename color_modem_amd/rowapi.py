@@ -141,6 +141,9 @@ class RowApi(object):
             return numpy.zeros((0,) + ((3, eng.width) if direction == 'demod' else (eng.comp_width,)))
         if direction == 'mod' and getattr(eng, 'encoder', None) is not None:
             eng = eng.encoder
+        if direction == 'mod' and getattr(eng, 'noise_level', 0.0):
+            # niir.py:45-46: every modulate() call draws its own numpy.random samples, in call order; the run entry point draws for its newest row only
+            raise NotImplementedError('modulate_rows is not built for NiirModem(noise_level != 0): call modulate() row by row')
         continuing = frame == run.frame and line == run.line + 2 and run.k >= 0
         k_first = run.k + 1 if continuing else 0
         n_hist = min(k_first, depth)
