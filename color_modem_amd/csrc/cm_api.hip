@@ -10,16 +10,19 @@
 #include <string>
 #include <vector>
 
-// CM_PART: this file compiles as one translation unit (0, the default) or as three that __graft_entry__.build() compiles side by side and
-// links into the one library - 1: the QAM / SECAM / MAC / wrapped-comb entry points and their streaming kernels, 2: the cm_am_* entry points
-// (Proto-SECAM / NIIR, streaming and scan kernels), 3: the row-parallel scan kernels of part 1's families behind five launch functions
-// (cm_host::scan_launch_*).  The helpers at the top are in every part; the process-wide state (last error, pointer check) lives in part 1.
+// CM_PART: this file compiles as one translation unit (0, the default) or as four that __graft_entry__.build() compiles side by side and
+// links into the one library - 1: the QAM / SECAM / MAC / wrapped-comb entry points and their streaming kernels (decoder instances of the
+// PAL-BG filter shapes), 2: the cm_am_* entry points (Proto-SECAM / NIIR, streaming and scan kernels), 3: the row-parallel scan kernels of
+// part 1's families behind five launch functions (cm_host::scan_launch_*), 4: the decoder instances of every other filter-set shape (NTSC /
+// PAL-M/N, NTSC-I, NTSC-A, the 640 / 704 / 768 sample rasters, the run-time shape) behind cm_host::select_other_shapes.  The helpers at the
+// top are in every part; the process-wide state (last error, pointer check) lives in part 1.
 #ifndef CM_PART
 #define CM_PART 0
 #endif
 #define CM_MAIN_PART (CM_PART == 0 || CM_PART == 1)
 #define CM_AM_PART (CM_PART == 0 || CM_PART == 2)
 #define CM_SCAN_PART (CM_PART == 0 || CM_PART == 3)
+#define CM_SHAPES_PART (CM_PART == 0 || CM_PART == 4)
 
 #include "../../include/color_modem_hip.h"
 #include "cm_kernels.h"
@@ -39,7 +42,7 @@
 #if CM_AM_PART
 #include "cm_am_scan_kernels.h"
 #endif
-#if CM_MAIN_PART && defined(CM_EXPERIMENTS)
+#if (CM_MAIN_PART || CM_SHAPES_PART) && defined(CM_EXPERIMENTS)
 #include "cm_blk_kernels.h"      // the time-blocked decoder with the FIRs on the matrix pipe (round 2's experiment)
 #endif
 #if CM_AM_PART
@@ -69,6 +72,8 @@ int scan_launch_qam_mod(int c1, bool u8, int device, const ScanModK *k, const Ge
 int scan_launch_secam_mod(int c1, bool u8, int device, const ScanSecamModK *k, const Geom &g, hipStream_t stream);
 int scan_launch_secam_demod(int c1, bool u8, int device, const ScanSecamK *k, const Geom &g, hipStream_t stream);
 int scan_launch_wrap_back(int c1, bool u8, int device, const ScanModK *k, const ScanWrapArgs &a, const Geom &g, hipStream_t stream);
+// the decoder instances of every filter-set shape but PAL-BG's (CM_PART 4)
+bool select_other_shapes(cm_plan *p, const cm_plan_desc &d, std::string &err);
 }  // namespace cm_host
 using cm_host::g_error;
 using cm_host::g_pointer_check;
@@ -128,7 +133,7 @@ int check_device(int plan_device, const void *a, const void *b) {
         if (e_ != hipSuccess) return fail(code, std::string(#expr) + ": " + hipGetErrorString(e_)); \
     } while (0)
 
-#if CM_MAIN_PART
+#if CM_MAIN_PART || CM_SHAPES_PART
 // One launch = first-line workgroups [0, n_first) followed by the main pass's workgroups.
 typedef int (*LaunchFn)(const Geom &gm, const void *km, const Geom &gf, const void *kf, int n_first, int n_main,
                         hipStream_t);
@@ -220,11 +225,11 @@ struct Pass {
     int depth = 0;                 // halo lanes of the kernel instance
     std::string name;
 };
-#endif  // CM_MAIN_PART
+#endif  // CM_MAIN_PART || CM_SHAPES_PART
 
 }  // namespace
 
-#if CM_MAIN_PART
+#if CM_MAIN_PART || CM_SHAPES_PART
 typedef int (*ModLaunchFn)(const Geom &g, const void *k, int blocks, hipStream_t);
 
 // calls up to which the decoders' scan kernels beat the streaming kernels (profiles/r03_batch_curve.txt)
@@ -278,9 +283,9 @@ struct cm_plan {
     SecamModLaneK<float, double> *sm_lanes = nullptr;
 };
 
-#endif  // CM_MAIN_PART
+#endif  // CM_MAIN_PART || CM_SHAPES_PART
 namespace {
-#if CM_MAIN_PART
+#if CM_MAIN_PART || CM_SHAPES_PART
 
 template <class S>
 bool make_pass(const cm_plan_desc &d, bool pald, bool bsf, const cm_lane_table &tb, Pass &pass, std::string &err, bool pair, int depth = 0) {
@@ -462,6 +467,8 @@ bool select_for_shape(cm_plan *p, const cm_plan_desc &d, const char *sys, std::s
 #endif
 }
 
+#endif  // CM_MAIN_PART || CM_SHAPES_PART
+#if CM_SHAPES_PART
 // Run-time shape (SysAny): any sampling rate whose filters fit 4 / 3 / 3 / 2 sections and a pre-correction shift <= 12.
 // The fused byte boundary exists where the tuned shapes have it (not with notch / minavg).
 bool select_any(cm_plan *p, const cm_plan_desc &d, std::string &err) {
@@ -544,8 +551,9 @@ bool select_pald_sq(cm_plan *p, const cm_plan_desc &d, std::string &err) {
     return make_passes<S, SysPalSqFirst>(p, d, true, false, true, err);
 }
 
-// Pick the kernel instance (main pass + optional plain first-line pass in one launch).
-bool select_kernels(cm_plan *p, const cm_plan_desc &d, std::string &err) {
+}  // namespace
+namespace cm_host {
+bool select_other_shapes(cm_plan *p, const cm_plan_desc &d, std::string &err) {
     const bool pald = d.pipeline == CM_PIPE_PAL_D;
     const bool bsf = d.main_luma_bandstop != 0;
     const bool first = d.first_is_plain != 0;
@@ -556,7 +564,6 @@ bool select_kernels(cm_plan *p, const cm_plan_desc &d, std::string &err) {
         if (!bsf && !first) { have.nr = want.nr; have.odd_r = want.odd_r; }
         return same_signature(want, have);
     };
-    if (match(signature_of<SysPal>())) return select_for_shape<SysPal, true, false>(p, d, "pal", err);
 #ifndef CM_DEV_PALD_ONLY
     if (pald && first && d.depth == 1 && d.chroma_average != CM_AVG_MIN && same_signature(want, signature_of<SysPalSq>()) &&
         same_signature(want_first, signature_of<SysPalSqFirst>()))
@@ -574,6 +581,23 @@ bool select_kernels(cm_plan *p, const cm_plan_desc &d, std::string &err) {
              want.ne, want.nr, want.nl, want.np, want.odd_e, want.odd_l, want.odd_r, want.sp);
     err = buf;
     return false;
+}
+}  // namespace cm_host
+namespace {
+#endif  // CM_SHAPES_PART
+#if CM_MAIN_PART
+// Pick the kernel instance (main pass + optional plain first-line pass in one launch): the PAL-BG shapes here, every other shape in CM_PART 4.
+bool select_kernels(cm_plan *p, const cm_plan_desc &d, std::string &err) {
+    const bool pald = d.pipeline == CM_PIPE_PAL_D;
+    const bool bsf = d.main_luma_bandstop != 0;
+    const bool first = d.first_is_plain != 0;
+    SysSignature want = signature_wanted(d, pald);
+    const SysSignature want_first = signature_wanted(d, false);   // the plain first-line pass runs the QAM front + band-stop
+    SysSignature have = signature_of<SysPal>();
+    if (!bsf && !first) { have.nr = want.nr; have.odd_r = want.odd_r; }
+    if ((!first || same_signature(want_first, signature_of<SysPal>())) && same_signature(want, have))
+        return select_for_shape<SysPal, true, false>(p, d, "pal", err);
+    return cm_host::select_other_shapes(p, d, err);
 }
 
 template <int NP, int SP, int DEPTH, bool U8 = false, bool RT = false>

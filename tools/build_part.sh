@@ -2,7 +2,7 @@
 # tools/build_part.sh PART [extra flags]: compile one CM_PART of cm_api.hip into color_modem_amd/_build (ISA + resource log in /tmp/cm_build/pPART), then link the library
 set -e
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
-PART=$1; shift
+PART=$1; shift   # 1 .. 4
 mkdir -p /tmp/cm_build/p$PART $ROOT/color_modem_amd/_build
 cd /tmp/cm_build/p$PART
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-slp-vectorize -DCM_PART=$PART "$@" -save-temps -Rpass-analysis=kernel-resource-usage -c \
