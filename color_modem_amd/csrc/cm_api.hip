@@ -484,7 +484,14 @@ bool select_any(cm_plan *p, const cm_plan_desc &d, std::string &err) {
     p->fn = nullptr;
     p->fn_u8 = nullptr;
     std::string what;
-    if (minavg) {
+    if (pald && depth == 2 && !first) {
+        // the fused wrapped combs (select_for_shape) at the other sampling rates: the comb.avg form only - minavg / notch stay on the composition
+        if (d.skip_calls != 2) { err = "the PAL-D front end with two lines of history serves the fused wrapped combs (skip_calls = 2)"; return false; }
+        if (minavg || notch) { err = "the run-time shape fuses the plain average only (minavg / notch: the composition)"; return false; }
+        p->fn = launch_demod<PassCfg<S, FRONT_PALD, false, 2, 16>, NoPass>;
+        p->fn_u8 = launch_demod<PassCfg<S, FRONT_PALD, false, 2, 16, true>, NoPass>;
+        p->main.depth = 2; what = "pal-d front, depth 2 (wrapped comb, calls k >= 2)";
+    } else if (minavg) {
         if (pald || bsf || first) { err = "minavg is built behind the QAM front end (SimpleCombModem, Pal3DModem)"; return false; }
         p->fn = launch_demod<PassCfg<S, FRONT_QAM, false, 2, 16, false, true, true>, NoPass>;
         p->fn_u8 = launch_demod<PassCfg<S, FRONT_QAM, false, 2, 16, true, true, true>, NoPass>;

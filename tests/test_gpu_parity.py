@@ -886,7 +886,8 @@ def test_wrapped_pal_comb_vs_oracle(stack, size, first):
 
 @pytest.mark.parametrize('stack,size,frames', [('simple3d_pald', (720, 16), 1700), ('simple_pald', (720, 21), 1300),
                                                ('simple3d_pald_minavg', (720, 12), 2100), ('simple3d_pald_notch', (720, 576), 48),
-                                               ('simple_pald', (720, 576), 45)])
+                                               ('simple_pald', (720, 576), 45), ('simple3d_pald', (768, 16), 1700), ('simple_pald', (1280, 10), 2500),
+                                               ('simple3d_pald', (960, 12), 2100)])
 def test_wrapped_pal_comb_fused_long_batches(stack, size, frames):
     """Long batches around PalDModem run the fused plan (PAL-D front end, two lines of history: every call k >= 2 of a run in one
     pass over the frames) plus the composition on the top four rows (cm_comb_wrap_demodulate_frames_fused).  Against the float64
