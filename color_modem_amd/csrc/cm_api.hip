@@ -2633,7 +2633,7 @@ struct AsyncBuf {
     ~AsyncBuf() { if (p) (void)hipFreeAsync(p, stream); }
 };
 #ifndef CM_WRAP_SCRATCH_BYTES
-#define CM_WRAP_SCRATCH_BYTES ((size_t)1 << 30)
+#define CM_WRAP_SCRATCH_BYTES ((size_t)2 << 30)
 #endif
 // in: float rows (pitch wp), or in8: composite bytes (width = wp, a multiple of 4) with bytes out as well.
 // h_top > 0: only the top h_top rows of every frame are decoded (frames stay full_H rows apart in both buffers) and only the calls with
@@ -2664,7 +2664,8 @@ int wrap_frames(const cm_plan *inner, const cm_plan *first, const cm_plan *backe
     g.first_line[0] = 0;
     g.first_line[1] = 1;
     g.delay = D;
-    // the component scratch: a byte budget (CM_WRAP_SCRATCH_BYTES, 1 GiB: 200 frames of 720 x 576 at a time; the header documents the peak).
+    // the component scratch: a byte budget (CM_WRAP_SCRATCH_BYTES, 2 GiB: 400 frames of 720 x 576 at a time; the header documents the peak;
+    // every chunk costs the tails of two launches: 1 / 2 / 3 GiB measured 64 / 72 / 73 Gpixel/s at 1000 frames, round 3's 5 GB chunks 75).
     // Not smaller: the plain first-line pass is one lane per run - 2 runs per frame, a handful of workgroups whose time is the latency of
     // walking one row (0.23 ms) - and it is paid once per chunk.  With bytes at the boundary the level-decoded composite is a second,
     // chunk-sized buffer (`in8`: the whole batch's bytes; round 3 decoded them all at once).

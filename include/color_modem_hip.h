@@ -353,7 +353,9 @@ typedef struct {
     cm_iir_desc notch;      /* the wrapper's notch= (comb.py:18-20, 86-88): one section, shift 0; n_sections = 0: none */
     double matrix[9];       /* decode_components (comb.py:121-122), row major; identity for the component protocol */
 } cm_comb_wrap_desc;
-/* composite [F][H][W] float32 -> rgb [F][3][H][W] float32, the row schedule of image.py:75-83 (device pointers) */
+/* composite [F][H][W] float32 -> rgb [F][3][H][W] float32, the row schedule of image.py:75-83 (device pointers).  Stream-ordered scratch of the
+ * call's lifetime: the component buffer of up to 2 GiB (the batch is walked in chunks of that many frames), with bytes at the boundary the
+ * level-decoded composite of one chunk beside it (+ a third). */
 int cm_comb_wrap_demodulate_frames(const cm_plan *inner, const cm_plan *first, const cm_plan *backend, const cm_comb_wrap_desc *wrap,
                                    const float *composite, float *rgb, int64_t n_frames, int64_t first_frame, void *stream);
 /* the same with the ImageModem byte boundary (image.py:58-84): 'L' bytes [F][H][W] -> interleaved 'RGB' bytes [F][H][W][3] */
