@@ -27,6 +27,9 @@ MAKERS = [
     ('Avg(Ntsc)', 'ntsc', lambda lc, v: comb.ColorAveragingModem(ntsc.NtscModem(lc, v))),
     ('Simple3D(PalD)', 'pal', lambda lc, v: comb.Simple3DCombModem(pal.PalDModem(lc, v))),
     ('Simple(Pal3D) notch minavg', 'pal', lambda lc, v: comb.SimpleCombModem(pal.Pal3DModem(lc, v), notch=3.0, avg=comb.minavg)),
+    ('Simple3D(PalD) f', 'pal', lambda lc, v: comb.Simple3DCombModem(pal.PalDModem(lc, v), avg=stacks.weighted_avg)),      # avg= callables (wrapped.py)
+    ('Simple(NtscComb) f', 'ntsc', lambda lc, v: comb.SimpleCombModem(ntsc.NtscCombModem(lc, v), avg=stacks.damped_avg)),
+    ('Simple(Pal3D) f', 'pal', lambda lc, v: comb.SimpleCombModem(pal.Pal3DModem(lc, v), avg=stacks.damped_avg, notch=5.0)),
     ('Secam', 'secam', lambda lc, v: secam.SecamModem(lc, v)), ('Avg(Secam)', 'secam', lambda lc, v: comb.ColorAveragingModem(secam.SecamModem(lc, v))),
 ]
 WIDTHS = [480, 544, 640, 704, 720, 720, 720, 768, 960, 1024, 1280, 1440, 1920]

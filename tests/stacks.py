@@ -76,14 +76,14 @@ def weighted_avg(last, curr):
     return 0.25 * last + 0.75 * curr
 
 
-def smaller_of(last, curr):
-    return (abs(last) < abs(curr)) * last + (abs(last) >= abs(curr)) * curr
+def damped_avg(last, curr):      # non-linear and continuous (a discontinuous pick turns float32 rounding of its inputs into a different branch)
+    return 0.5 * (last + curr) / (1.0 + 4.0 * abs(last - curr))
 
 
 STACKS.update({
     'simple3d_pald_favg': lambda lc: comb.Simple3DCombModem(pal.PalDModem(lc), avg=weighted_avg),
-    'simple_pal3d_favg': lambda lc: comb.SimpleCombModem(pal.Pal3DModem(lc), avg=smaller_of, notch=4.0),
-    'simple_ntsc_favg': lambda lc: comb.SimpleCombModem(ntsc.NtscModem(lc), avg=smaller_of),
+    'simple_pal3d_favg': lambda lc: comb.SimpleCombModem(pal.Pal3DModem(lc), avg=damped_avg, notch=4.0),
+    'simple_ntsc_favg': lambda lc: comb.SimpleCombModem(ntsc.NtscModem(lc), avg=damped_avg),
     'simple3d_ntsccomb_favg': lambda lc: comb.Simple3DCombModem(ntsc.NtscCombModem(lc), avg=weighted_avg),
 })
 STANDARD = {'pal': 'GERBER_625', 'ntsc': 'NTSC_525', 'secam': 'GERBER_625', 'simple3d': 'GERBER_625', 'simple': 'GERBER_625'}
