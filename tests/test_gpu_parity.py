@@ -690,6 +690,49 @@ def test_filter_function_is_callable():
         utils.FilterFunction(numpy.ones(40), numpy.ones(40), 0.0, 'lowpass', False)(numpy.zeros(16))
 
 
+@pytest.mark.parametrize('stack,size,frames', [('pal_d', (720, 64), 150), ('secam', (720, 48), 200), ('simple3d_pal3d', (720, 32), 260),
+                                               ('simple3d_pald', (720, 16), 1700), ('pal_s', (720, 64), 150)])
+def test_one_plan_many_host_threads(stack, size, frames):
+    """include/color_modem_hip.h: plans are immutable after creation and may be shared by threads, batch calls are thread-safe per
+    (device, stream).  Four host threads share ONE engine (one cm_plan per stack level), each on a stream of its own, decoding (pal_s:
+    encoding) different batches at the same time - the streaming kernels, the SECAM pair, the wrapped composition (stream-ordered scratch,
+    the shared side stream, events) and the fused wrapped plan; every result equals the one the same call gives alone, bit for bit."""
+    import threading
+    import torch
+    modem = stacks.make(stack, size)
+    eng = image.ImageModem(modem)._engine()
+    w, h = size
+    encode = stack == 'pal_s'
+    gen = torch.Generator(device='cuda')
+    gen.manual_seed(99)
+    shape = (frames, 3, h, w) if encode else (frames, h, w)
+    inputs = [(torch.rand(shape, generator=gen, device='cuda') * 0.7 + 0.1).contiguous() for _ in range(4)]
+    call = eng.modulate_frames if encode else eng.demodulate_frames
+    alone = [call(x, 7 + 3 * i) for i, x in enumerate(inputs)]
+    torch.cuda.synchronize()
+    results, errors = [None] * 4, []
+
+    def work(i):
+        try:
+            stream = torch.cuda.Stream()
+            with torch.cuda.stream(stream):
+                for _ in range(4):
+                    out = call(inputs[i], 7 + 3 * i)
+                stream.synchronize()
+            results[i] = out
+        except Exception as e:      # noqa: BLE001 - reported below
+            errors.append((i, repr(e)))
+
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(4)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    for i in range(4):
+        assert torch.equal(results[i], alone[i]), (stack, i)
+
+
 def test_out_argument_is_validated():
     import torch
     modem = stacks.make('pal_d', (720, 8))
