@@ -100,7 +100,9 @@ class FilterFunction(object):
 def notch(qam_modem, q):
     """Luma notch at the sub-carrier (ref comb.py:18-20)."""
     b, a = design.iirnotch(2.0 * qam_modem.config.fsc / qam_modem.line_config.fs, q)
-    return FilterFunction(b, a, wp=0.0, btype='bandstop', shift=True)
+    f = FilterFunction(b, a, wp=0.0, btype='bandstop', shift=True)
+    f.q = float(q)          # the request itself (the oracle designs its own copy from it)
+    return f
 
 
 def iirfilter(N, Wn, rp=None, rs=None, btype='band', ftype='butter', shift=True):

@@ -3,14 +3,16 @@
 
 Follows /root/reference/color_modem/color/protosecam.py (ProtoSecamModem) and niir.py (NiirModem,
 HueCorrectingNiirModem) in plain numpy: ``resample_poly`` written out (cm_oracle_mac.resample_poly), ``lfilter`` as the
-direct-form recurrence, ``FilterFunction.__call__`` (utils.py:28-36) with its tail padding.  The filter coefficients come
-from the color_modem_amd host classes (the same scipy design calls as the reference).  Pinned against vectors the
+direct-form recurrence, ``FilterFunction.__call__`` (utils.py:28-36) with its tail padding.  The filter coefficients are the
+oracle's own scipy designs (oracle/cm_oracle_design.py: the reference's design calls restated); the host classes of color_modem_amd supply the variant
+constants and the line geometry only.  Pinned against vectors the
 reference itself produced (tests/golden/am_*.npz, made by tests/golden/make_golden_am.py) in tests/test_am_oracle.py.
 May be imported only by tests/ and by tools run by hand - never by color_modem_amd.
 """
 
 import numpy
 
+from oracle import cm_oracle_design as design
 from oracle.cm_oracle_mac import resample_poly
 
 
@@ -78,6 +80,8 @@ class ProtoSecamOracle(object):
 
     def __init__(self, modem):
         self.m = modem
+        # the oracle's own scipy designs of protosecam.py:32-50 (oracle/cm_oracle_design.py), not the product's filter objects
+        self.f = design.proto_filters(modem.line_config.fs, modem.config)
         self._last_frame = -1
         self._last_line = -1
         self._last_chroma = None
@@ -88,12 +92,12 @@ class ProtoSecamOracle(object):
     def modulate_components(self, frame, line, luma, dr, db):
         m = self.m
         chroma = db if m.line_config.is_alternate_line(frame, line) else dr          # protosecam.py:75-78
-        chroma = 0.125 * (1.0 + apply_filter(m._chroma_precorrect_lowpass, chroma))      # :79-80
+        chroma = 0.125 * (1.0 + apply_filter(self.f['pre'], chroma))      # :79-80
         if m._premod_luma_filter:                                                        # :82-85
             up = resample_poly(luma, 3, 1)
-            luma = resample_poly(apply_filter(m._remove_chroma_up, up), 1, 3)
+            luma = resample_poly(apply_filter(self.f['remove_up'], up), 1, 3)
         start = m.start_phase(frame, line)
-        phase = _phase_ramp(start, 2.0 * m._carrier_phase_step, len(chroma))            # :87-89
+        phase = _phase_ramp(start, 2.0 * self.f['carrier_phase_step'], len(chroma))            # :87-89
         return luma + numpy.cos(phase) * chroma
 
     def demodulate(self, frame, line, composite):
@@ -102,10 +106,10 @@ class ProtoSecamOracle(object):
         if frame != self._last_frame or line != self._last_line + 2 or self._last_chroma is None:
             self._last_chroma = numpy.zeros(len(composite))                             # :93-94
         up = resample_poly(composite, 3, 1)                                              # :96
-        chroma_up = apply_filter(m._extract_chroma_up, up)
+        chroma_up = apply_filter(self.f['extract_up'], up)
         chroma_up = 0.5 * numpy.pi * numpy.abs(chroma_up)                                # :98
-        chroma_up = apply_filter(m._chroma_up_post_demod_filter, chroma_up)
-        luma = resample_poly(apply_filter(m._remove_chroma_up, up), 1, 3)                # :100-101
+        chroma_up = apply_filter(self.f['post_demod'], chroma_up)
+        luma = resample_poly(apply_filter(self.f['remove_up'], up), 1, 3)                # :100-101
         chroma = 8.0 * resample_poly(chroma_up, 1, 3) - 1.0                               # :102-103
         if not m.line_config.is_alternate_line(frame, line):                             # :105-108
             self._last_chroma, dr, db = chroma, chroma, self._last_chroma
@@ -137,6 +141,8 @@ class NiirOracle(object):
 
     def __init__(self, modem):
         self.m = modem
+        # the oracle's own scipy designs of niir.py:11-23, 90-93 (oracle/cm_oracle_design.py), not the product's filter objects
+        self.f = design.niir_filters(modem.line_config.fs, modem.config)
         self.hue_correcting = bool(getattr(modem, 'hue_correcting', False))
         self.modulation_delay = 1 if self.hue_correcting else 0
         self._last_frame = -1
@@ -161,15 +167,15 @@ class NiirOracle(object):
         m = self.m
         start = m.start_phase(frame, line)
         n = len(updb)
-        phase = _phase_ramp(start, m._carrier_phase_step, n)
+        phase = _phase_ramp(start, self.f['carrier_phase_step'], n)
         if not m.line_config.is_alternate_line(frame, line):
             return updb * numpy.sin(phase) + updr * numpy.cos(phase)
         return -numpy.sqrt(updb * updb + updr * updr) * numpy.sin(phase)
 
     def _modulate_offset_components(self, frame, line, luma, db, dr):                    # niir.py:85-90
         m = self.m
-        db = apply_filter(m._chroma_precorrect_lowpass, db)
-        dr = apply_filter(m._chroma_precorrect_lowpass, dr)
+        db = apply_filter(self.f['pre'], db)
+        dr = apply_filter(self.f['pre'], dr)
         return luma + self._modulate_precorrected_chroma(frame, line, db, dr)
 
     def modulate(self, frame, line, r, g, b):
@@ -222,7 +228,7 @@ class NiirOracle(object):
         m = self.m
         composite = numpy.asarray(composite, dtype=numpy.float64)
         n = len(composite)
-        f_up, f_base = m._demodulate_upsampled_filter, m._demodulate_upsampled_baseband_filter
+        f_up, f_base = self.f['bandpass_up'], self.f['baseband_up']
         if frame != self._last_frame or line != self._last_line + 2 or self._last_phasemod_up is None:
             last_modulated = self._modulate_precorrected_chroma(frame, line - 2, numpy.ones(n), numpy.zeros(n))
             self._last_phasemod_up = apply_filter(f_up, resample_poly(last_modulated, 3, 1))
@@ -237,7 +243,7 @@ class NiirOracle(object):
         else:
             carrier_up, huemod_up, shift = phasemod_up, self._last_phasemod_up, -m.line_shift
         shifted = 0.5 * (carrier_up[0:-1] + carrier_up[1:])
-        altcarrier_up = numpy.concatenate((numpy.zeros(1), numpy.diff(shifted), numpy.zeros(1))) * 3.0 / m._carrier_phase_step
+        altcarrier_up = numpy.concatenate((numpy.zeros(1), numpy.diff(shifted), numpy.zeros(1))) * 3.0 / self.f['carrier_phase_step']
         sinphi = resample_poly(huemod_up * carrier_up, 1, 3)
         cosphi = resample_poly(huemod_up * altcarrier_up, 1, 3)
         with numpy.errstate(divide='ignore', invalid='ignore'):
