@@ -29,7 +29,7 @@ SYMBOLS = ('cm_last_error', 'cm_abi_version', 'cm_device_count', 'cm_plan_create
            'cm_comb_wrap_demodulate_frames', 'cm_comb_wrap_demodulate_frames_u8', 'cm_comb_wrap_demodulate_run', 'cm_filter_rows_f64',
            'cm_comb_wrap_demodulate_frames_fused', 'cm_comb_wrap_demodulate_frames_fused_u8',
            'cm_comb_wrap_calls_per_frame', 'cm_comb_wrap_components_frames', 'cm_comb_wrap_finish_frames', 'cm_comb_wrap_components_run',
-           'cm_comb_wrap_finish_run')
+           'cm_comb_wrap_finish_run', 'cm_notch_luma_f32')
 
 _lib = None
 
@@ -120,6 +120,7 @@ def lib():
     L.cm_comb_wrap_finish_run.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]
     dp = ctypes.POINTER(ctypes.c_double)
     L.cm_filter_rows_f64.argtypes = [dp, i32, dp, i32, i32, vp, vp, i64, i32, vp]
+    L.cm_notch_luma_f32.argtypes = [dp, i32, dp, i32, i32, vp, vp, i64, i64, i32, i32, dp, vp]
     if L.cm_abi_version() != plan.CM_ABI_VERSION:
         raise NativeError('libcolor_modem_hip.so ABI %d, Python side expects %d - rebuild the library'
                           % (L.cm_abi_version(), plan.CM_ABI_VERSION))

@@ -1206,66 +1206,130 @@ int cm_device_count(void) {
 namespace {
 struct FilterRowsArgs {
     double b[CM_FILTER_MAX_TAPS], a[CM_FILTER_MAX_TAPS];     // a[0] = 1 (normalised on the host), zero-padded
-    int n_taps, shift, width;
-    long long rows;
-    const double *x;
-    double *y;
+    int n_taps, shift, width, skip_inner;
+    long long rows, n_inner, outer_stride, inner_stride;      // row r = (outer, inner) = (r / n_inner, r % n_inner), in elements
+    const void *x;
+    void *y;
 };
 // scipy.signal.lfilter's recurrence (transposed direct form II: y = z0 + b0 x; z_i = z_{i+1} + b_{i+1} x - a_{i+1} y), unfused
 // multiply / add / subtract in its order, on the row padded as utils.py:31-35 pads it: `shift` copies of the last sample behind it and the
 // first `shift` results dropped (shift > 0), or -shift copies of the first sample in front and the last -shift results dropped (shift < 0).
+// T: the rows' element type (the arithmetic is float64 either way); rows with inner index < skip_inner are copied unfiltered.
+template <typename T>
 __global__ __launch_bounds__(64) void filter_rows_kernel(const FilterRowsArgs k) {
     const long long row = (long long)blockIdx.x * 64 + threadIdx.x;
     if (row >= k.rows) return;
-    const double *x = k.x + row * k.width;
-    double *y = k.y + row * k.width;
+    const long long outer = row / k.n_inner, inner = row - outer * k.n_inner;
+    const T *x = (const T *)k.x + outer * k.outer_stride + inner * k.inner_stride;
+    T *y = (T *)k.y + outer * k.outer_stride + inner * k.inner_stride;
+    const int W = k.width;
+    if (inner < k.skip_inner) {
+        if (x != y)
+            for (int t = 0; t < W; ++t) y[t] = x[t];
+        return;
+    }
     double z[CM_FILTER_MAX_TAPS];
 #pragma unroll
     for (int i = 0; i < CM_FILTER_MAX_TAPS; ++i) z[i] = 0.0;
-    const int W = k.width, s = k.shift, lead = s < 0 ? -s : 0, drop = s > 0 ? s : 0;
+    const int s = k.shift, lead = s < 0 ? -s : 0, drop = s > 0 ? s : 0;
     const int total = W + lead + drop;
     for (int t = 0; t < total; ++t) {
         int j = t - lead;
         j = j < 0 ? 0 : (j > W - 1 ? W - 1 : j);
-        const double xin = x[j];
+        const double xin = (double)x[j];
         const double out = __dadd_rn(z[0], __dmul_rn(k.b[0], xin));
 #pragma unroll
         for (int i = 0; i < CM_FILTER_MAX_TAPS - 1; ++i)
             if (i + 1 < k.n_taps) z[i] = __dsub_rn(__dadd_rn(z[i + 1], __dmul_rn(xin, k.b[i + 1])), __dmul_rn(out, k.a[i + 1]));
         const int o = t - drop;
-        if (o >= 0 && o < W) y[o] = out;
+        if (o >= 0 && o < W) y[o] = (T)out;
     }
 }
-}  // namespace
-extern "C" {
-int cm_filter_rows_f64(const double *b, int32_t n_b, const double *a, int32_t n_a, int32_t shift, const double *x, double *y, int64_t n_rows,
-                       int32_t width, void *stream) {
+// (r, g, b) = M (y, u, v) on [group][3][plane] floats, in place or not (decode_components after the luma notch of cm_notch_luma_f32)
+__global__ __launch_bounds__(256) void matrix_planes_kernel(const float *in, float *out, long long n, long long plane, float m00, float m01, float m02,
+                                                            float m10, float m11, float m12, float m20, float m21, float m22) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const long long g = i / plane, o = g * 3 * plane + (i - g * plane);
+    const float y = in[o], u = in[o + plane], v = in[o + 2 * plane];
+    out[o] = fmaf_(m00, y, fmaf_(m01, u, m02 * v));
+    out[o + plane] = fmaf_(m10, y, fmaf_(m11, u, m12 * v));
+    out[o + 2 * plane] = fmaf_(m20, y, fmaf_(m21, u, m22 * v));
+}
+int fill_filter_args(FilterRowsArgs &k, const double *b, int32_t n_b, const double *a, int32_t n_a, int32_t shift, int32_t width) {
     if (!b || !a || n_b < 1 || n_a < 1) return fail(CM_ERR_INVALID, "null or empty coefficient array");
     if (n_b > CM_FILTER_MAX_TAPS || n_a > CM_FILTER_MAX_TAPS)
         return fail(CM_ERR_UNSUPPORTED, "filter order beyond CM_FILTER_MAX_TAPS - 1 = " + std::to_string(CM_FILTER_MAX_TAPS - 1));
     if (a[0] == 0.0) return fail(CM_ERR_INVALID, "a[0] must not be zero");
-    if (n_rows < 0 || width < 1) return fail(CM_ERR_INVALID, "rows must not be negative, width must be positive");
+    if (width < 1) return fail(CM_ERR_INVALID, "width must be positive");
     if (shift <= -width || shift >= (1 << 20)) return fail(CM_ERR_INVALID, "shift out of range");
-    if (n_rows == 0) return CM_OK;
-    if (!x || !y) return fail(CM_ERR_INVALID, "null argument");
-    int cur = -1;
-    if (hipGetDevice(&cur) != hipSuccess) return fail(CM_ERR_NO_DEVICE, "hipGetDevice failed");
-    if (int rc_ = check_device(cur, x, y)) return rc_;
-    FilterRowsArgs k;
     std::memset(&k, 0, sizeof k);
     k.n_taps = n_b > n_a ? n_b : n_a;
     for (int i = 0; i < n_b; ++i) k.b[i] = b[i] / a[0];      // lfilter normalises by a[0] first
     for (int i = 0; i < n_a; ++i) k.a[i] = a[i] / a[0];
     k.shift = shift;
     k.width = width;
-    k.rows = n_rows;
-    k.x = x;
-    k.y = y;
-    const long long blocks = (n_rows + 63) / 64;
+    return CM_OK;
+}
+template <typename T>
+int launch_filter_rows(const FilterRowsArgs &k, void *stream) {
+    const long long blocks = (k.rows + 63) / 64;
     if (blocks > 0x7fffffffLL) return fail(CM_ERR_INVALID, "batch too large for one launch");
-    hipLaunchKernelGGL(filter_rows_kernel, dim3((unsigned)blocks), dim3(64), 0, (hipStream_t)stream, k);
+    hipLaunchKernelGGL(filter_rows_kernel<T>, dim3((unsigned)blocks), dim3(64), 0, (hipStream_t)stream, k);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(CM_ERR_LAUNCH, std::string("filter_rows_kernel launch: ") + hipGetErrorString(e));
+    return CM_OK;
+}
+}  // namespace
+extern "C" {
+int cm_filter_rows_f64(const double *b, int32_t n_b, const double *a, int32_t n_a, int32_t shift, const double *x, double *y, int64_t n_rows,
+                       int32_t width, void *stream) {
+    FilterRowsArgs k;
+    if (int rc = fill_filter_args(k, b, n_b, a, n_a, shift, width)) return rc;
+    if (n_rows < 0) return fail(CM_ERR_INVALID, "rows must not be negative");
+    if (n_rows == 0) return CM_OK;
+    if (!x || !y) return fail(CM_ERR_INVALID, "null argument");
+    int cur = -1;
+    if (hipGetDevice(&cur) != hipSuccess) return fail(CM_ERR_NO_DEVICE, "hipGetDevice failed");
+    if (int rc_ = check_device(cur, x, y)) return rc_;
+    k.rows = n_rows;
+    k.n_inner = n_rows;
+    k.inner_stride = width;
+    k.x = x;
+    k.y = y;
+    return launch_filter_rows<double>(k, stream);
+}
+
+int cm_notch_luma_f32(const double *b, int32_t n_b, const double *a, int32_t n_a, int32_t shift, const float *yuv_in, float *yuv_out,
+                      int64_t n_groups, int64_t rows_per_group, int32_t width, int32_t skip_rows, const double *matrix, void *stream) {
+    FilterRowsArgs k;
+    if (int rc = fill_filter_args(k, b, n_b, a, n_a, shift, width)) return rc;
+    if (n_groups < 0 || rows_per_group < 1 || skip_rows < 0) return fail(CM_ERR_INVALID, "negative count");
+    if (n_groups == 0) return CM_OK;
+    if (!yuv_in || !yuv_out || yuv_in == yuv_out || !matrix) return fail(CM_ERR_INVALID, "null argument, or input and output are the same buffer");
+    int cur = -1;
+    if (hipGetDevice(&cur) != hipSuccess) return fail(CM_ERR_NO_DEVICE, "hipGetDevice failed");
+    if (int rc_ = check_device(cur, yuv_in, yuv_out)) return rc_;
+    const long long plane = rows_per_group * (long long)width;
+    // the luma plane of every group through the notch (rows below skip_rows as they are), the two chroma planes carried over
+    k.rows = n_groups * rows_per_group;
+    k.n_inner = rows_per_group;
+    k.outer_stride = 3 * plane;
+    k.inner_stride = width;
+    k.skip_inner = skip_rows;
+    k.x = yuv_in;
+    k.y = yuv_out;
+    if (int rc = launch_filter_rows<float>(k, stream)) return rc;
+    for (int c = 1; c < 3; ++c)
+        HIP_TRY(hipMemcpy2DAsync(yuv_out + c * plane, 3 * plane * sizeof(float), yuv_in + c * plane, 3 * plane * sizeof(float), plane * sizeof(float),
+                                 (size_t)n_groups, hipMemcpyDeviceToDevice, (hipStream_t)stream), CM_ERR_LAUNCH);
+    const long long n = n_groups * plane;
+    if ((n + 255) / 256 > 0x7fffffffLL) return fail(CM_ERR_INVALID, "batch too large for one launch");
+    const double *m = matrix;
+    hipLaunchKernelGGL(matrix_planes_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, yuv_out, yuv_out, n, plane, (float)m[0],
+                       (float)m[1], (float)m[2], (float)m[3], (float)m[4], (float)m[5], (float)m[6], (float)m[7], (float)m[8]);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(CM_ERR_LAUNCH, std::string("matrix_planes_kernel launch: ") + hipGetErrorString(e));
     return CM_OK;
 }
 

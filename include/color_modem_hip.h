@@ -389,6 +389,15 @@ int cm_comb_wrap_demodulate_run(const cm_plan *inner, const cm_plan *first, cons
 int cm_filter_rows_f64(const double *b, int32_t n_b, const double *a, int32_t n_a, int32_t shift, const double *x, double *y,
                        int64_t n_rows, int32_t width, void *stream);
 
+/* The luma notch of a comb decoder as a pass of its own, for notch= values whose FilterFunction shift is not 0 (comb.py:18-20 with utils.py:9-26:
+ * round(group delay at DC) is 1 for q = 1.0, and other values, also negative ones, below that; the fused kernels carry the notch at shift 0 only).
+ * yuv_in: what the decoder returns in component form WITHOUT its notch, [group][3][rows_per_group][width] floats; yuv_out (another buffer)
+ * receives decode_components(notch(y), u, v) (comb.py:54-55, 108-110, 121-122; pal.py:225-228): the luma rows with index >= skip_rows of
+ * every group through FilterFunction.__call__ (utils.py:28-36, float64 inside), the other rows as they are (the first call of a run is never
+ * notched: comb.py:48-49, 97-99), then `matrix` (row major; identity for the component protocol). */
+int cm_notch_luma_f32(const double *b, int32_t n_b, const double *a, int32_t n_a, int32_t shift, const float *yuv_in, float *yuv_out,
+                      int64_t n_groups, int64_t rows_per_group, int32_t width, int32_t skip_rows, const double *matrix, void *stream);
+
 /* avg= callables (comb.py:72, 81-84: SimpleCombModem(avg=f) combines the chroma of consecutive calls with the caller's own function,
  * comb.py:103-104).  The composition cut in two: `components` receives what the inner decoder returns for every call of every run,
  * [frame][call][3 = y, u, v][W] floats in call order (frames entry points: cm_comb_wrap_calls_per_frame() calls per frame - both fields, each

@@ -263,6 +263,13 @@ def damped_avg(last, curr):      # non-linear and continuous (a discontinuous pi
     return 0.5 * (last + curr) / (1.0 + 4.0 * abs(last - curr))
 
 
+# notch= values whose FilterFunction shift is not 0 (comb.py:18-20 over utils.py:9-26): +1 at q = 1.0, +7 at q = 0.7 (PAL at 13.5 MHz; the values with a negative shift are unstable filters: the reference's own output overflows)
+STACKS.update({
+    'pal_d_notchq1': lambda lc: pal.PalDModem(lc, notch=1.0),
+    'pal_3d_notchq07': lambda lc: pal.Pal3DModem(lc, notch=0.7),
+    'ntsc_comb_3d_notchq1': lambda lc: comb.Simple3DCombModem(ntsc.NtscCombModem(lc), notch=1.0),
+    'simple_pald_notchq1': lambda lc: comb.SimpleCombModem(pal.PalDModem(lc), notch=1.0),
+})
 STACKS.update({
     'simple3d_pald_favg': lambda lc: comb.Simple3DCombModem(pal.PalDModem(lc), avg=weighted_avg),
     'simple_pal3d_favg': lambda lc: comb.SimpleCombModem(pal.Pal3DModem(lc), avg=damped_avg, notch=4.0),
@@ -450,6 +457,22 @@ def callable_cases():
         save('frames_demod_' + stack, inp=comp, out=out, frames=numpy.array(frames), size=numpy.array([W, H]))
 
 
+def notch_shift_cases():
+    """notch= values whose FilterFunction comes out with a shift other than 0."""
+    W, H = 720, 10
+    for stack, frames in (('pal_d_notchq1', [1, 2]), ('pal_3d_notchq07', [0, 3]), ('ntsc_comb_3d_notchq1', [0, 1]), ('simple_pald_notchq1', [2, 3])):
+        lc = line_config(stack, (W, H))
+        modem = STACKS[stack](lc)
+        notch = getattr(modem, 'notch', None) or getattr(modem, '_notch', None)
+        print('   %s: notch shift %d' % (stack, notch._shift))
+        assert notch._shift != 0
+        enc = STACKS['ntsc' if 'ntsc' in stack else 'pal_s'](lc)
+        rgb = testing.synthetic_rgb(len(frames), H, W, seed=777)
+        comp = numpy.stack([run_mod_frame(enc, rgb[i].astype(numpy.float64), f) for i, f in enumerate(frames)]).astype(numpy.float32)
+        out = numpy.stack([run_demod_frame(STACKS[stack](lc), comp[i].astype(numpy.float64), f) for i, f in enumerate(frames)])
+        save('frames_demod_' + stack, inp=comp, out=out, frames=numpy.array(frames), size=numpy.array([W, H]))
+
+
 def degenerate_pictures(W, H):
     """The inputs of the degenerate_* sets (shared with make_golden_am.py / make_golden_mac.py): black / white / mid-grey / saturated red pictures
     and all-zero / constant composites - where an algorithm divides by an amplitude or takes the angle of a vanishing pair."""
@@ -529,6 +552,9 @@ if __name__ == '__main__':
     if sys.argv[1:2] == ['degenerate']:
         degenerate_cases()
         sys.exit(0)
+    if sys.argv[1:2] == ['notch_shift']:
+        notch_shift_cases()
+        sys.exit(0)
     if sys.argv[1:2] == ['callables']:
         callable_cases()
         sys.exit(0)
@@ -539,6 +565,7 @@ if __name__ == '__main__':
     variant_cases()
     wrapper_cases()
     callable_cases()
+    notch_shift_cases()
     degenerate_cases()
     row_cases()
     image_cases()

@@ -80,6 +80,13 @@ def damped_avg(last, curr):      # non-linear and continuous (a discontinuous pi
     return 0.5 * (last + curr) / (1.0 + 4.0 * abs(last - curr))
 
 
+# notch= values whose FilterFunction shift is not 0 (comb.py:18-20 over utils.py:9-26): +1 at q = 1.0, +7 at q = 0.7 (PAL at 13.5 MHz; the values with a negative shift are unstable filters: the reference's own output overflows)
+STACKS.update({
+    'pal_d_notchq1': lambda lc: pal.PalDModem(lc, notch=1.0),
+    'pal_3d_notchq07': lambda lc: pal.Pal3DModem(lc, notch=0.7),
+    'ntsc_comb_3d_notchq1': lambda lc: comb.Simple3DCombModem(ntsc.NtscCombModem(lc), notch=1.0),
+    'simple_pald_notchq1': lambda lc: comb.SimpleCombModem(pal.PalDModem(lc), notch=1.0),
+})
 STACKS.update({
     'simple3d_pald_favg': lambda lc: comb.Simple3DCombModem(pal.PalDModem(lc), avg=weighted_avg),
     'simple_pal3d_favg': lambda lc: comb.SimpleCombModem(pal.Pal3DModem(lc), avg=damped_avg, notch=4.0),

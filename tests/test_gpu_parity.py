@@ -733,6 +733,39 @@ def test_one_plan_many_host_threads(stack, size, frames):
         assert torch.equal(results[i], alone[i]), (stack, i)
 
 
+@pytest.mark.parametrize('stack,size', [('pal_d_notchq1', (720, 32)), ('pal_3d_notchq07', (720, 21)), ('ntsc_comb_3d_notchq1', (720, 480)),
+                                        ('simple_pald_notchq1', (720, 16))])
+def test_notch_with_a_filter_shift(stack, size):
+    """notch= values whose FilterFunction shift is not 0 (q = 1.0: +1, q = 0.7 at PAL: +7; comb.py:18-20 over utils.py:9-36; the q with a negative shift design unstable filters): the notch as
+    a pass of its own behind the decoder (color_modem_amd/notched.py, cm_notch_luma_f32).  Frames, the per-row protocol with a break in the
+    run, row groups and the component protocol against the float64 oracle (pinned by the reference's own vectors frames_demod_*_notchq*.npz,
+    which test_frames_demod_golden runs through the device as well)."""
+    from oracle import cm_oracle
+    modem = stacks.make(stack, size)
+    assert 'notch, shift' in image.ImageModem(modem)._engine().describe()
+    n = 2 if size[1] < 100 else 1
+    rgb = testing.synthetic_rgb(n, size[1], size[0], seed=50 + size[1])
+    comp = cm_oracle.modulate_frames_f32(stacks.make('ntsc' if 'ntsc' in stack else 'pal_s', size), rgb, first_frame=1, n_threads=4)
+    got = image.ImageModem(modem).demodulate_frames(comp, first_frame=1)
+    want = cm_oracle.demodulate_frames_f32(modem, comp, first_frame=1, n_threads=4)
+    for i in range(n):
+        assert stacks.rel_err(got[i], want[i]) < TOL, (stack, i)
+    orc = cm_oracle.OracleModem(modem)
+    for f, y in ((1, 0), (1, 2), (1, 4), (1, 6), (1, 11), (1, 13), (2, 15)):
+        row = comp[0, y % size[1]]
+        assert stacks.rel_err(numpy.stack(modem.demodulate(f, y, row)), numpy.stack(orc.demodulate(f, y, row.astype(numpy.float64)))) < TOL, (stack, f, y)
+    fresh, orc2 = stacks.make(stack, size), cm_oracle.OracleModem(modem)
+    group = fresh.demodulate_rows(1, 1, comp[0, 1:size[1]:2][:7])
+    want_group = numpy.stack([numpy.stack(orc2.demodulate(1, 1 + 2 * i, comp[0, 1 + 2 * i].astype(numpy.float64))) for i in range(len(group))])
+    assert stacks.rel_err(group, want_group) < TOL, stack
+    comp_modem, orc3 = stacks.make(stack, size), cm_oracle.OracleModem(modem)
+    for i, y in enumerate((0, 2, 4, 6)):
+        for strip in (True,):
+            got_c = numpy.stack(comp_modem.demodulate_components(3, y, comp[0, y], strip_chroma=strip))
+            want_c = numpy.stack(orc3.demodulate_components(3, y, comp[0, y].astype(numpy.float64), strip))
+            assert stacks.rel_err(got_c, want_c) < TOL, (stack, y, strip)
+
+
 def test_out_argument_is_validated():
     import torch
     modem = stacks.make('pal_d', (720, 8))
