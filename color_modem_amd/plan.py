@@ -547,9 +547,8 @@ def build_qam_plan(stack, components=False, strip_chroma=True, min_lines=0):
     notch = stack.get('wrapper_notch') if tb.demod_wrapper else stack.get('comb_notch')
     if not strip_chroma:
         notch = None
-    if notch is not None and notch.shift != 0:
-        raise NotImplementedError('notch filters with a group delay at DC that rounds to %d samples (very low Q) '
-                                  'are not built; shift 0 is' % notch.shift)
+    if notch is not None and notch.shift != 0:      # (engine.make_engine sends such stacks to notched.ShiftedNotchEngine, which builds this plan without the notch)
+        raise NotImplementedError('the fused kernels carry the notch at FilterFunction shift 0; shift %d goes through color_modem_amd/notched.py' % notch.shift)
     d.notch = iir_desc(notch)
     return BuiltPlan(d, [main, first, mod, rot], tb)
 

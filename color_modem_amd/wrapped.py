@@ -66,10 +66,9 @@ class WrappedCombEngine(object):
             raise TypeError('avg=%r is not callable' % (fn,))
         if self.custom_avg is not None:
             self.composite = True      # rowapi: runs go through demodulate_run below (the callable sits between two native calls)
-        notch = stack.get('wrapper_notch')
-        if notch is not None and notch.shift != 0:
-            raise NotImplementedError('notch filters with a group delay at DC that rounds to %d samples (very low Q) '
-                                      'are not built; shift 0 is' % notch.shift)
+        notch = stack.get('wrapper_notch') if strip_chroma else None      # comb.py:105-110: the notch follows the strip
+        if notch is not None and notch.shift != 0:      # (engine.make_engine sends such stacks to notched.ShiftedNotchEngine, which builds this engine without the notch)
+            raise NotImplementedError('the back end carries the notch at FilterFunction shift 0; shift %d goes through color_modem_amd/notched.py' % notch.shift)
         self.own_delay = 1 if stack['demod_wrapper'] == 'simple_3d' else 0
         self.inner_modem = stack.get('comb') or stack['backend']      # PalDModem / Pal3DModem (avg= callables: any QAM-family decoder)
         self.backend = stack['backend']                     # PalSModem
