@@ -270,7 +270,7 @@ int cm_mac_demodulate_run(const cm_mac_plan *plan, const float *composite, float
  * sections + FilterFunction shift.  The sub-carrier start phase of a line is computed on the device in float64 from
  * frame_phase_shift / line_phase_shift / frame_cycle (utils.py:67-88) and the line geometry (line.py:57-65). */
 enum cm_am_kind { CM_AM_PROTO_SECAM = 1, CM_AM_NIIR = 2 };
-/* cm_am_desc.flags.  CM_AM_FLOAT64: accepted and ignored since ABI v6 / round 4.  The NIIR decoder takes the hue as the angle of a decimated
+/* cm_am_desc.flags.  CM_AM_FLOAT64: accepted and ignored since round 4 (ABI v7).  The NIIR decoder takes the hue as the angle of a decimated
  * product pair and divides by its length (niir.py:131-137); with a float32 front end that left isolated samples beyond 1e-5 of full scale
  * wherever the pair gets short (4e-5 of the samples of random pictures, worst 4e-3), and round 3 offered a float64 front end behind this flag
  * (row-parallel kernel only, 9.5 Gpixel/s).  Now EVERY NIIR decoder - the streaming wave pair and the row-parallel kernel, floats or bytes -
