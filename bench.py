@@ -201,6 +201,8 @@ def main():
         raise SystemExit('bench.py needs a GPU: the product path has no CPU implementation')
     backend = os.environ.get('CM_BENCH_BACKEND', 'nccl')     # 'gloo': rehearsal of the N > 1 path on a box with fewer GPUs than ranks
     n_dev = torch.cuda.device_count()
+    if backend == 'nccl' and world > max(n_dev, 1):
+        backend = 'gloo'      # more ranks than GPUs on this box (every rank sees the same count): the launch-path rehearsal, reported as such
     dev_index = local_rank if backend == 'nccl' else local_rank % max(n_dev, 1)
     torch.cuda.set_device(dev_index)
     device = torch.device('cuda', dev_index)
