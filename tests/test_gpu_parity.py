@@ -766,6 +766,30 @@ def test_notch_with_a_filter_shift(stack, size):
             assert stacks.rel_err(got_c, want_c) < TOL, (stack, y, strip)
 
 
+@pytest.mark.parametrize('stack', ['simple3d_pald_favg', 'pal_d_notchq1', 'simple_ntsc_favg'])
+def test_pil_images_through_the_composed_engines(stack):
+    """ImageModem.modulate / demodulate on PIL images (image.py:47-84) for the stacks that run as compositions without a fused byte boundary
+    (avg= callables, notches with a FilterFunction shift): the host-side level conversions around the float path, within 1 LSB of the
+    oracle's float64 result on all but a handful of rounding ties."""
+    from PIL import Image
+    from oracle import cm_oracle
+    from color_modem_amd.image import _as_bytes
+    size = (720, 480) if 'ntsc' in stack else (720, 576)
+    modem = stacks.make(stack, size, explicit=False)
+    rng = numpy.random.default_rng(4)
+    rgb8 = (numpy.clip(numpy.cumsum(rng.normal(0, 6, (size[1], size[0], 3)), axis=1) + 128, 0, 255)).astype(numpy.uint8)
+    im = image.ImageModem(modem)
+    comp_img = im.modulate(Image.frombytes('RGB', size, rgb8.tobytes()), 2)
+    back = im.demodulate(comp_img, 2)
+    assert back.mode == 'RGB' and back.size == size
+    comp8 = numpy.frombuffer(comp_img.tobytes(), dtype=numpy.uint8).reshape(size[1], size[0])
+    comp = image.ImageModem.decode_composite_level(comp8.astype(numpy.float64) / 255.0)
+    want = _as_bytes(cm_oracle.demodulate_frames_f32(modem, comp[None].astype(numpy.float32), first_frame=2)[0].astype(numpy.float64)).transpose(1, 2, 0)
+    got = numpy.frombuffer(back.tobytes(), dtype=numpy.uint8).reshape(size[1], size[0], 3)
+    d = numpy.abs(got.astype(int) - want.astype(int))
+    assert d.max() <= 1 and (d > 0).mean() < 2e-3, (stack, d.max(), (d > 0).mean())
+
+
 def test_out_argument_is_validated():
     import torch
     modem = stacks.make('pal_d', (720, 8))
