@@ -176,6 +176,7 @@ bool build_secam_demod_k(const cm_plan_desc &d, SecamDemodK<T> &k, std::string &
         err = "SECAM filter shifts outside what the kernel is built for (bell 0, de-emphasis 0)";
         return false;
     }
+    if (k.deemph.na2[0] != T(0) || k.deemph.b2[0] != T(0)) { err = "SECAM de-emphasis: a first-order section is what the kernels carry (secam.py:173-177)"; return false; }
     if (g_b * g_bell * g_l <= 0.0) { err = "SECAM chroma path gain must be positive (the discriminator drops it)"; return false; }
     k.s_b = s.chroma_bp.shift;
     k.q_l = pair_delay(s.fm_lp.shift);

@@ -414,11 +414,11 @@ __device__ __forceinline__ void secam_demod_pair_body(const Args &args_in) {
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_wave_barrier();
-        auto read_x = [&](int first) -> f4 {
+        auto read_x = [&](int first, bool inside = false) -> f4 {   // inside: first + 3 < W is the caller's knowledge (the interior bodies)
             f4 v;
             if (U8) v = decode_bytes(*(const lds_u32 *)(xrow8 + (first & (kInTile - 1))));
             else v = *(const lds_f4 *)(xrow + (first & (kIT - 1)));
-            if (first + 3 >= W) {
+            if (!inside && first + 3 >= W) {
                 if (first >= W) v.x = 0.f;
                 if (first + 1 >= W) v.y = 0.f;
                 if (first + 2 >= W) v.z = 0.f;
@@ -433,7 +433,7 @@ __device__ __forceinline__ void secam_demod_pair_body(const Args &args_in) {
             const bool pre = b < n_pre;
             const int xb = (b - n_pre) << 2;
             if (b == n_pre) xv = read_x(0);
-            float yi0[4], yq0[4], yi1[4], yq1[4];
+            pf2 y0[4], y1[4];      // the low-passed (I, Q) of the steps' two 2x-rate samples
             if constexpr (F64) {
                 if (mid) {
                     const double *cp = args_in.fm_ref64 + 4 * (long long)(m_start + 4 * b - k.s_b - 10);
@@ -441,10 +441,8 @@ __device__ __forceinline__ void secam_demod_pair_body(const Args &args_in) {
                     for (int s = 0; s < 4; ++s) {
                         const double car[4] = {cp[4 * s], cp[4 * s + 1], cp[4 * s + 2], cp[4 * s + 3]};
                         double ch_out;
-                        pf2 y0, y1;
-                        st.step_mid(args_in.k64, (double)xv[s], chw[s], car, ch_out, y0, y1);
+                        st.step_mid(args_in.k64, (double)xv[s], chw[s], car, ch_out, y0[s], y1[s]);
                         chw[10 + s] = ch_out;
-                        yi0[s] = y0.x; yq0[s] = y0.y; yi1[s] = y1.x; yq1[s] = y1.y;
                     }
                 }
             } else {
@@ -454,10 +452,8 @@ __device__ __forceinline__ void secam_demod_pair_body(const Args &args_in) {
                     for (int s = 0; s < 4; ++s) {
                         const f4 c = cp[s];
                         float ch_out;
-                        pf2 y0, y1;
-                        st.step_mid(k, kp, xv[s], chw[s], pf2{c.x, c.y}, pf2{c.z, c.w}, ch_out, y0, y1);
+                        st.step_mid(k, kp, xv[s], chw[s], pf2{c.x, c.y}, pf2{c.z, c.w}, ch_out, y0[s], y1[s]);
                         chw[10 + s] = ch_out;
-                        yi0[s] = y0.x; yq0[s] = y0.y; yi1[s] = y1.x; yq1[s] = y1.y;
                     }
                 }
             }
@@ -480,20 +476,18 @@ __device__ __forceinline__ void secam_demod_pair_body(const Args &args_in) {
                 }
                 int m2 = m - k.s_b - 10;
                 m2 = m2 < 0 ? 0 : (m2 > Lc - 1 ? Lc - 1 : m2);
-                pf2 y0, y1;
                 if constexpr (F64) {
                     const double *cp = args_in.fm_ref64 + 4 * (long long)m2;
                     const double car[4] = {cp[0], cp[1], cp[2], cp[3]};
                     double ch_out;
-                    st.step(args_in.k64, m, (double)cc, chw[s], car, ch_out, y0, y1);
+                    st.step(args_in.k64, m, (double)cc, chw[s], car, ch_out, y0[s], y1[s]);
                     chw[10 + s] = ch_out;
                 } else {
                     const f4 c = ((const_f4 *)g.carrier4)[m2];
                     float ch_out;
-                    st.step(k, kp, m, cc, chw[s], pf2{c.x, c.y}, pf2{c.z, c.w}, ch_out, y0, y1, args.e64);
+                    st.step(k, kp, m, cc, chw[s], pf2{c.x, c.y}, pf2{c.z, c.w}, ch_out, y0[s], y1[s], args.e64);
                     chw[10 + s] = ch_out;
                 }
-                yi0[s] = y0.x; yq0[s] = y0.y; yi1[s] = y1.x; yq1[s] = y1.y;
             }
 #pragma unroll
             for (int j = 0; j < 10; ++j) chw[j] = chw[j + 4];
@@ -510,7 +504,7 @@ __device__ __forceinline__ void secam_demod_pair_body(const Args &args_in) {
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     __builtin_amdgcn_wave_barrier();
                 }
-                xv = read_x(nxt);
+                xv = read_x(nxt, mid);      // (interior: xb < (W - 8) & ~3, so nxt + 3 < W)
                 if ((nxt & (kIT - 1)) == kIT - 4 && nxt + 4 < W) {   // that was the last read of this tile: refill it
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                     __builtin_amdgcn_wave_barrier();
@@ -519,10 +513,25 @@ __device__ __forceinline__ void secam_demod_pair_body(const Args &args_in) {
             }
             lds_float *slot = ring + (CM_SECAM_PAIR_MID_BUFS == 2 ? (b & 1) * (kSecamMid / 2) : 0) + lane * 4;
             if (CM_SECAM_PAIR_MID_BUFS == 1 && b > 0) asm volatile("s_barrier" ::: "memory");      // B has read body b - 1
-            *(lds_f4 *)slot = f4{yi0[0], yi0[1], yi0[2], yi0[3]};
-            *(lds_f4 *)(slot + 256) = f4{yq0[0], yq0[1], yq0[2], yq0[3]};
-            *(lds_f4 *)(slot + 512) = f4{yi1[0], yi1[1], yi1[2], yi1[3]};
-            *(lds_f4 *)(slot + 768) = f4{yq1[0], yq1[1], yq1[2], yq1[3]};
+            // the body's eight 2x-rate samples z[0 .. 7] = (y0[0], y1[0], y0[1], ...) as the pairs (z[j], z[j + 4]) stage B's packed phase
+            // steps take: I as (z0, z4, z1, z5 | z2, z6, z3, z7), Q likewise
+            // (real parts | imaginary parts of two samples: one v_pk_mov_b32 each)
+            auto put_iq = [&](lds_float *at, pf2 a, pf2 b, pf2 c, pf2 d) __attribute__((always_inline)) {
+                const pf2 i_ab = pk_lolo(a, b), i_cd = pk_lolo(c, d), q_ab = pk_hihi(a, b), q_cd = pk_hihi(c, d);
+                *(lds_f4 *)at = f4{i_ab.x, i_ab.y, i_cd.x, i_cd.y};
+                *(lds_f4 *)(at + 512) = f4{q_ab.x, q_ab.y, q_cd.x, q_cd.y};
+            };
+            if (mid && k.odd_l) {
+                // odd low-pass shift: the stream one 2x-rate sample later - z'[0] = the sample held from the body before, z'[j] = z[j - 1]
+                // (the guarded steps do this themselves, pair by pair: SecamDemodPkA::step)
+                const pf2 h = st.hold();
+                st.set_hold(y1[3]);
+                put_iq(slot, h, y1[1], y0[0], y0[2]);               // (z'0, z'4, z'1, z'5) = (h, z3, z0, z4)
+                put_iq(slot + 256, y1[0], y1[2], y0[1], y0[3]);     // (z'2, z'6, z'3, z'7) = (z1, z5, z2, z6)
+            } else {
+                put_iq(slot, y0[0], y0[2], y1[0], y1[2]);           // (z0, z4, z1, z5)
+                put_iq(slot + 256, y0[1], y0[3], y1[1], y1[3]);     // (z2, z6, z3, z7)
+            }
             *(lds_f4 *)(xring + xw * 256 + lane * 4) = blk;
             xw = xw + 1 == n_blocks ? 0 : xw + 1;
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -546,7 +555,14 @@ __device__ __forceinline__ void secam_demod_pair_body(const Args &args_in) {
         int fmod = (int)((g.first_frame + lc.frame) % g.cycle);
         lk = ((const SecamDemodLaneK<float> *)g.lanes)[((long long)fmod * 3 + lc.regime) * g.n_lines + lc.line];
     }
-    if (SecamDemodPkB::VP::VT) pin_block(k.taps);
+    TapsPk kp;              // the decimator's taps: (even, odd) pairs in VGPRs, (odd, even) pairs in SGPRs (HalfbandDn2Pk)
+    kp.load(k.taps);
+    TapsPkOdd ko;
+    ko.load(k.taps);
+    PhaseKPk kph;
+    kph.load(k.two_over_pi);
+    SecamFinishK fk;
+    fk.load(k, lk);
     const int idx1 = ((lane + 63) & 63) * 4;
     SecamDemodPkB st;
     st.reset();
@@ -561,8 +577,8 @@ __device__ __forceinline__ void secam_demod_pair_body(const Args &args_in) {
     for (int b = 0; b < n_bodies; ++b) {
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // block b of the ring is complete
         const lds_float *slot = ring + (CM_SECAM_PAIR_MID_BUFS == 2 ? (b & 1) * (kSecamMid / 2) : 0) + lane * 4;
-        const f4 i0 = *(const lds_f4 *)slot, q0 = *(const lds_f4 *)(slot + 256);
-        const f4 i1 = *(const lds_f4 *)(slot + 512), q1 = *(const lds_f4 *)(slot + 768);
+        const f4 ia = *(const lds_f4 *)slot, ib = *(const lds_f4 *)(slot + 256);         // I: (z0, z4, z1, z5), (z2, z6, z3, z7)
+        const f4 qa = *(const lds_f4 *)(slot + 512), qb = *(const lds_f4 *)(slot + 768);   // Q likewise
         f4 lw = *(const lds_f4 *)(xring + xr * 256 + lane * 4);
         if (kRegDelay > 0) {      // the rest of the delay in registers
             const f4 in = lw;
@@ -583,56 +599,40 @@ __device__ __forceinline__ void secam_demod_pair_body(const Args &args_in) {
                 }
             }
         };
-        if (CM_SECAM_PAIR_MID == 2 && b >= b_mid0 && b < b_mid1) {
-            // interior, step by step (fewer live registers than the batched form below)
-            const int m0 = m_start + 4 * b;
-            const __attribute__((address_space(4))) float *dcp = (const __attribute__((address_space(4))) float *)g.carrier2 + (m0 - lat + P);
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                const float d_e = phase_step_fast(st.iq_prev.x, st.iq_prev.y, i0[s], q0[s]);
-                const float d_o = phase_step_fast(i0[s], q0[s], i1[s], q1[s]);
-                st.iq_prev = pf2{i1[s], q1[s]};
-                const float own = st.chroma_back_mid(k, lk, d_e, d_o, dcp[s]);
-                const int n = m0 + s - 1 - lat;
-                const float luma = st.luma_step_mid(k, lw[s]);
-                const Rgb<float> o = st.finish(k, lk, luma, own_prev, nb_prev);
-                own_prev = own;
-                nb_prev = lane_from(idx1, own);
-                put_rgb<U8, kTile>(otile, wpos, n, o);
-                flush_after(s);
-            }
+        if (CM_SECAM_PAIR_MID && b >= b_mid0 && b < b_mid1) {
+            // interior, no guards: the eight phase steps of the body as four packed ones - step j into sample z[j] beside step j + 4
+            // into z[j + 4]: the earlier samples of step j > 0 are the pair (z[j - 1], z[j + 3]) as it came from the ring, those of
+            // step 0 (z[-1], z[3]) one v_pk_mov - behind ONE wave-uniform branch to the library atan2f, then the decimator two steps
+            // per packed update (cm_stages_pk.h: PhaseStepPk, HalfbandDn2Pk; bit-identical to the scalar steps)
+            const pf2 ci[4] = {pf2{ia.x, ia.y}, pf2{ia.z, ia.w}, pf2{ib.x, ib.y}, pf2{ib.z, ib.w}};
+            const pf2 cq[4] = {pf2{qa.x, qa.y}, pf2{qa.z, qa.w}, pf2{qb.x, qb.y}, pf2{qb.z, qb.w}};
+            const pf2 pi[4] = {__builtin_shufflevector(st.last_i, ci[3], 1, 2), ci[0], ci[1], ci[2]};
+            const pf2 pq[4] = {__builtin_shufflevector(st.last_q, cq[3], 1, 2), cq[0], cq[1], cq[2]};
+            PhaseStepPk ph[4];
+            PhaseStepPk::set4(ph, pi, pq, ci, cq);
+            st.last_i = ci[3];
+            st.last_q = cq[3];
             st.have_prev = 1;
-            continue;
-        }
-        if (CM_SECAM_PAIR_MID == 1 && b >= b_mid0 && b < b_mid1) {
-            // interior: the eight phase steps of the body together (one branch to the library atan2f), no guards
-            PhaseStep pe[4], po[4];
-            bool all_small = true;
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                const pf2 prev = s == 0 ? st.iq_prev : pf2{i1[s - 1], q1[s - 1]};
-                pe[s].set(prev.x, prev.y, i0[s], q0[s]);
-                po[s].set(i0[s], q0[s], i1[s], q1[s]);
-                all_small = all_small && pe[s].small() && po[s].small();
-            }
-            st.iq_prev = pf2{i1[3], q1[3]};
-            st.have_prev = 1;
-            float d_e[4], d_o[4];
-            if (__builtin_expect(__builtin_amdgcn_ballot_w64(!all_small) == 0ull, 1)) {
-#pragma unroll
-                for (int s = 0; s < 4; ++s) { d_e[s] = pe[s].series(); d_o[s] = po[s].series(); }
+            const float margin = __builtin_fminf(__builtin_fminf(ph[0].margin(), ph[1].margin()), __builtin_fminf(ph[2].margin(), ph[3].margin()));
+            pf2 f[4];       // (2 / pi) (d[j], d[j + 4]): frequencies_up - fc (secam.py:148)
+            if (__builtin_expect(__builtin_amdgcn_ballot_w64(!(margin > 0.f)) == 0ull, 1)) {
+                PhaseStepPk::series4(ph, kph, f);
             } else {
 #pragma unroll
-                for (int s = 0; s < 4; ++s) { d_e[s] = pe[s].full(); d_o[s] = po[s].full(); }
+                for (int j = 0; j < 4; ++j) f[j] = ph[j].full(kph);
             }
+            // steps s = 0, 1 decimate (d0, d1), (d2, d3) = the low halves, steps 2, 3 the high ones
+            const pf2 g01 = st.dn.template push2<0>(kp, ko, f[0], f[1], f[2], f[3]);
+            const pf2 g23 = st.dn.template push2<1>(kp, ko, f[0], f[1], f[2], f[3]);
+            const float g2[4] = {g01.x, g01.y, g23.x, g23.y};
             const int m0 = m_start + 4 * b;
             const __attribute__((address_space(4))) float *dcp = (const __attribute__((address_space(4))) float *)g.carrier2 + (m0 - lat + P);
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
-                const float own = st.chroma_back_mid(k, lk, d_e[s], d_o[s], dcp[s]);
+                const float own = st.chroma_back_mid(k, lk, g2[s], dcp[s]);
                 const int n = m0 + s - 1 - lat;
                 const float luma = st.luma_step_mid(k, lw[s]);
-                const Rgb<float> o = st.finish(k, lk, luma, own_prev, nb_prev);
+                const Rgb<float> o = st.finish(fk, luma, own_prev, nb_prev);
                 own_prev = own;
                 nb_prev = lane_from(idx1, own);
                 put_rgb<U8, kTile>(otile, wpos, n, o);
@@ -640,16 +640,19 @@ __device__ __forceinline__ void secam_demod_pair_body(const Args &args_in) {
             }
             continue;
         }
+        // guarded bodies: step s takes (z[2 s], z[2 s + 1])
+        const f4 i0 = {ia.x, ib.x, ia.y, ib.y}, i1 = {ia.z, ib.z, ia.w, ib.w};
+        const f4 q0 = {qa.x, qb.x, qa.y, qb.y}, q1 = {qa.z, qb.z, qa.w, qb.w};
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             const int m = m_start + 4 * b + s;
             int m4 = m - lat + P;                               // row-stream sample the decimator completes in this step
             m4 = m4 < 0 ? 0 : (m4 > Lc - 1 ? Lc - 1 : m4);
             const float dc = ((const __attribute__((address_space(4))) float *)g.carrier2)[m4];
-            const float own = st.chroma_step(k, lk, m, pf2{i0[s], q0[s]}, pf2{i1[s], q1[s]}, dc);
+            const float own = st.chroma_step(k, kp, lk, m, pf2{i0[s], q0[s]}, pf2{i1[s], q1[s]}, dc);
             const int n = m - 1 - lat;                          // the back end runs one sample behind the exchange
             const float luma = st.luma_step(k, n, lw[s]);
-            Rgb<float> o = st.finish(k, lk, luma, own_prev, nb_prev);
+            Rgb<float> o = st.finish(fk, luma, own_prev, nb_prev);
             own_prev = own;
             nb_prev = lane_from(idx1, own);
             if (n >= 0 && n < W) put_rgb<U8, kTile>(otile, wpos, n, o);

@@ -129,6 +129,46 @@ __device__ __forceinline__ pf2 pk_mul_xk(pf2 x, pf2 k) {   // d = k * x[XH]
 #endif
     return d;
 }
+// (v, -): a pair whose LOW half is v for the broadcasting forms above (their op_sel never reads the other half, which stays
+// undefined: no move is spent on a duplicate)
+__device__ __forceinline__ pf2 pk_lo(float v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    pf2 p = __builtin_nondeterministic_value(p);
+    p.x = v;
+    return p;
+#else
+    return pf2{v, v};
+#endif
+}
+// d = (x[0] * k.x, -(x[0] * k.y)): the product of a real sample with the conjugate of a carrier pair in SGPRs (exact negation)
+__device__ __forceinline__ pf2 pk_mul_bs_conj(pf2 x, pf2 k) {
+    pf2 d;
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(x), "s"(k));
+#else
+    d = pf2{x[0] * k.x, -(x[0] * k.y)};
+#endif
+    return d;
+}
+// (a.x, b.x) / (a.y, b.y): one v_pk_mov_b32 each (two complex samples -> their real parts / their imaginary parts)
+__device__ __forceinline__ pf2 pk_lolo(pf2 a, pf2 b) {
+    pf2 d;
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm("v_pk_mov_b32 %0, %1, %2 op_sel:[0,0]" : "=v"(d) : "v"(a), "v"(b));
+#else
+    d = pf2{a.x, b.x};
+#endif
+    return d;
+}
+__device__ __forceinline__ pf2 pk_hihi(pf2 a, pf2 b) {
+    pf2 d;
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm("v_pk_mov_b32 %0, %1, %2 op_sel:[1,1]" : "=v"(d) : "v"(a), "v"(b));
+#else
+    d = pf2{a.y, b.y};
+#endif
+    return d;
+}
 __device__ __forceinline__ pf2 pk_add(pf2 a, pf2 b) {
     pf2 d;
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -721,6 +761,199 @@ struct PhaseStep {
     __device__ __forceinline__ float full() const { return small() ? series() : atan2f(cross, dot); }
 };
 
+// ---- the phase steps two at a time (round 5; stage B of the wave pair, interior bodies) ----------------------------------------
+// A pair holds the same quantity of two phase steps; every v_pk_* below performs exactly the two scalar operations of
+// PhaseStep::set / series, in their order: bit-identical results, half the instructions.
+__device__ __forceinline__ pf2 pk_fma(pf2 a, pf2 b, pf2 c) {           // a * b + c
+    pf2 d;
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+#else
+    d = a * b + c;
+#endif
+    return d;
+}
+__device__ __forceinline__ pf2 pk_fma_nab(pf2 a, pf2 b, pf2 c) {       // -(a * b) + c, one rounding
+    pf2 d;
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm("v_pk_fma_f32 %0, %1, %2, %3 neg_lo:[1,0,0] neg_hi:[1,0,0]" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+#else
+    d = pf2{__builtin_fmaf(-a.x, b.x, c.x), __builtin_fmaf(-a.y, b.y, c.y)};
+#endif
+    return d;
+}
+__device__ __forceinline__ pf2 pk_fma_nc(pf2 a, pf2 b, pf2 c) {        // a * b - c, one rounding
+    pf2 d;
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm("v_pk_fma_f32 %0, %1, %2, %3 neg_lo:[0,0,1] neg_hi:[0,0,1]" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+#else
+    d = pf2{__builtin_fmaf(a.x, b.x, -c.x), __builtin_fmaf(a.y, b.y, -c.y)};
+#endif
+    return d;
+}
+// d = x * k[A] + k[B]: both constants broadcast from the halves of ONE VGPR pair
+template <int A, int B>
+__device__ __forceinline__ pf2 pk_fma_kk(pf2 x, pf2 k) {
+    pf2 d;
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (A == 0 && B == 1) asm("v_pk_fma_f32 %0, %1, %2, %2 op_sel:[0,0,1] op_sel_hi:[1,0,1]" : "=v"(d) : "v"(x), "v"(k));
+    else asm("v_pk_fma_f32 %0, %1, %2, %2 op_sel:[0,1,0] op_sel_hi:[1,1,0]" : "=v"(d) : "v"(x), "v"(k));
+#else
+    d = x * k[A] + k[B];
+#endif
+    return d;
+}
+// d = x * y + k[H]
+template <int H>
+__device__ __forceinline__ pf2 pk_fma_addk(pf2 x, pf2 y, pf2 k) {
+    pf2 d;
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (H == 0) asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,1,0]" : "=v"(d) : "v"(x), "v"(y), "v"(k));
+    else asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,1] op_sel_hi:[1,1,1]" : "=v"(d) : "v"(x), "v"(y), "v"(k));
+#else
+    d = x * y + k[H];
+#endif
+    return d;
+}
+
+struct PhaseKPk {          // constants of the packed phase steps, pinned in three VGPR pairs
+    pf2 a, b, c;           // (1/9, -1/7), (1/5, -1/3), (2 / pi, 2 / pi)
+    __device__ __forceinline__ void load(float two_over_pi) {
+        a = pf2{1.0f / 9.0f, -1.0f / 7.0f};
+        b = pf2{1.0f / 5.0f, -1.0f / 3.0f};
+        c = pf2{two_over_pi, two_over_pi};
+        pin_pair(a); pin_pair(b); pin_pair(c);
+    }
+};
+
+struct PhaseStepPk {
+    pf2 cross, dot;
+    // (pi, pq) = I / Q of the two earlier samples, (ci, cq) = of the two later ones
+    __device__ __forceinline__ void set(pf2 pi, pf2 pq, pf2 ci, pf2 cq) {
+        const pf2 t = pk_mul(pq, ci);
+        const pf2 e = pk_fma_nab(pq, ci, t);
+        cross = pk_add(pk_fma_nc(pi, cq, t), e);
+        dot = pk_fma(pi, ci, pk_mul(pq, cq));
+    }
+    // > 0 in both halves <=> both steps qualify for the series (dot > 0 and |cross| < dot / 4; PhaseStep::small has <=: a tie
+    // takes the library function here, whose result agrees to the last bit or two)
+    __device__ __forceinline__ float margin() const {
+        return __builtin_fminf(__builtin_fmaf(-4.0f, __builtin_fabsf(cross.x), dot.x), __builtin_fmaf(-4.0f, __builtin_fabsf(cross.y), dot.y));
+    }
+    // the two phase steps times 2 / pi
+    __device__ __forceinline__ pf2 series(const PhaseKPk &k) const {
+        pf2 rc;
+        rc.x = __builtin_amdgcn_rcpf(dot.x);
+        rc.y = __builtin_amdgcn_rcpf(dot.y);
+        const pf2 r = pk_mul(cross, rc);
+        const pf2 z = pk_mul(r, r);
+        pf2 p = pk_fma_kk<0, 1>(z, k.a);
+        p = pk_fma_addk<0>(z, p, k.b);
+        p = pk_fma_addk<1>(z, p, k.b);
+        return pk_mul(pk_fma(pk_mul(r, z), p, r), k.c);
+    }
+    // four packed steps stage by stage: a v_pk_* result feeding the next instruction costs a wait state (s_nop), four
+    // independent chains side by side have none
+    static __device__ __forceinline__ void set4(PhaseStepPk ph[4], const pf2 pi[4], const pf2 pq[4], const pf2 ci[4], const pf2 cq[4]) {
+        pf2 t[4], e[4], x[4], dd[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) t[j] = pk_mul(pq[j], ci[j]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) dd[j] = pk_mul(pq[j], cq[j]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) e[j] = pk_fma_nab(pq[j], ci[j], t[j]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) x[j] = pk_fma_nc(pi[j], cq[j], t[j]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) ph[j].dot = pk_fma(pi[j], ci[j], dd[j]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) ph[j].cross = pk_add(x[j], e[j]);
+    }
+    static __device__ __forceinline__ void series4(const PhaseStepPk ph[4], const PhaseKPk &k, pf2 f[4]) {
+        pf2 rc[4], r[4], z[4], p[4], rz[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            rc[j].x = __builtin_amdgcn_rcpf(ph[j].dot.x);
+            rc[j].y = __builtin_amdgcn_rcpf(ph[j].dot.y);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) r[j] = pk_mul(ph[j].cross, rc[j]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) z[j] = pk_mul(r[j], r[j]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) p[j] = pk_fma_kk<0, 1>(z[j], k.a);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) rz[j] = pk_mul(r[j], z[j]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) p[j] = pk_fma_addk<0>(z[j], p[j], k.b);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) p[j] = pk_fma_addk<1>(z[j], p[j], k.b);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) r[j] = pk_fma(rz[j], p[j], r[j]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) f[j] = pk_mul(r[j], k.c);
+    }
+    __device__ __forceinline__ pf2 full(const PhaseKPk &k) const {
+        PhaseStep a, b;
+        a.cross = cross.x; a.dot = dot.x;
+        b.cross = cross.y; b.dot = dot.y;
+        return pf2{a.full() * k.c.x, b.full() * k.c.x};
+    }
+};
+
+// ---- transposed-form half-band decimator with its accumulators in pairs: TWO push_pair steps per packed update ------------------
+// HalfbandChain::push_pair (cm_stages.h) pushes the odd sample through the chain and adds the centre tap's product of the even
+// sample to s[8].  Two consecutive steps (e0, o0), (e1, o1) are HalfbandUp2Pk::push2's update with o0 / o1 for x0 / x1 - here
+// taken from halves of DIFFERENT register pairs, the packed phase steps deliver them that way - plus the two centre-tap
+// products where the scalar chain adds them: on s'[8] between the pushes (the low half of the temporary of pair 4) and on
+// s''[8] after the second.  Bit-identical to two scalar steps; 20 packed + 3 scalar FMAs instead of 42.
+// The guarded row ends push one step at a time on the same registers (push_pair: the scalar chain on the halves).
+struct HalfbandDn2Pk {
+    pf2 q[10];          // q[i] = (s[2i - 1], s[2i]) of HalfbandChain; q[0].x is not state
+    __device__ __forceinline__ void reset() {
+#pragma unroll
+        for (int j = 0; j < 10; ++j) q[j] = pf2{0.f, 0.f};
+    }
+    template <int J> __device__ __forceinline__ float get() const {
+        if constexpr ((J & 1) != 0) return q[(J + 1) >> 1].x; else return q[J >> 1].y;
+    }
+    template <int J> __device__ __forceinline__ void put(float v) {
+        if constexpr ((J & 1) != 0) q[(J + 1) >> 1].x = v; else q[J >> 1].y = v;
+    }
+    template <int J> __device__ __forceinline__ void update(const TapsPk &k, float x) {
+        constexpr int t = (J + 1) < 10 ? (J + 1) : 18 - J;
+        put<J>(__builtin_fmaf(k.c2[t >> 1][t & 1], x, get<J + 1>()));
+        if constexpr (J < 17) update<J + 1>(k, x);
+    }
+    __device__ __forceinline__ float push_pair(const TapsPk &k, float even, float odd) {
+        const float out = __builtin_fmaf(k.c2[0].x, odd, get<0>());
+        update<0>(k, odd);
+        put<18>(k.c2[0].x * odd);
+        put<8>(__builtin_fmaf(k.c0.x, even, get<8>()));
+        return out;
+    }
+    // steps s, s + 1 with (even, odd) = (f0[H], f1[H]) and (f2[H], f3[H]); returns their two outputs
+    template <int H>
+    __device__ __forceinline__ pf2 push2(const TapsPk &ke, const TapsPkOdd &ko, pf2 f0, pf2 f1, pf2 f2, pf2 f3) {
+        const float out0 = __builtin_fmaf(ke.c2[0].x, f1[H], q[0].y);
+        pf2 t;
+        t = pk_fma_xk<H, 0, true>(f1, ko.a[0], q[1]);  q[0] = pk_fma_xk<H, 0, false>(f3, ke.c2[0], t);
+        t = pk_fma_xk<H, 0, true>(f1, ko.a[1], q[2]);  q[1] = pk_fma_xk<H, 0, false>(f3, ke.c2[1], t);
+        t = pk_fma_xk<H, 0, true>(f1, ko.a[2], q[3]);  q[2] = pk_fma_xk<H, 0, false>(f3, ke.c2[2], t);
+        t = pk_fma_xk<H, 0, true>(f1, ko.a[3], q[4]);  q[3] = pk_fma_xk<H, 0, false>(f3, ke.c2[3], t);
+        t = pk_fma_xk<H, 2, false>(f1, ke.c2[4], q[5]);
+        t.x = __builtin_fmaf(ke.c0.x, f0[H], t.x);                                                      // centre tap of the first step on s'[8]
+        q[4] = pk_fma_xk<H, 0, false>(f3, ke.c2[4], t);
+        t = pk_fma_xk<H, 1, true>(f1, ko.a[3], q[6]);  q[5] = pk_fma_xk<H, 1, false>(f3, ke.c2[4], t);
+        t = pk_fma_xk<H, 1, true>(f1, ko.a[2], q[7]);  q[6] = pk_fma_xk<H, 1, false>(f3, ke.c2[3], t);
+        t = pk_fma_xk<H, 1, true>(f1, ko.a[1], q[8]);  q[7] = pk_fma_xk<H, 1, false>(f3, ke.c2[2], t);
+        t = pk_fma_xk<H, 1, true>(f1, ko.a[0], q[9]);  q[8] = pk_fma_xk<H, 1, false>(f3, ke.c2[1], t);
+        t = pk_mul_xk<H, true>(f1, ko.a[4]);           q[9] = pk_fma_xk<H, 1, false>(f3, ke.c2[0], t);
+        q[4].y = __builtin_fmaf(ke.c0.x, f2[H], q[4].y);                                                // ... of the second on s''[8]
+        return pf2{out0, q[0].x};
+    }
+};
+
 struct SecamDemodKPk {   // uniform blocks of the chroma path in VGPR pairs
     TapsPk taps;
     SosPk<3> lpf;
@@ -932,22 +1165,21 @@ struct SecamDemodPkA {
     __device__ __forceinline__ void step_mid(const SecamDemodK<float> &k, const SecamDemodKPk &kp, float cc_now, float ch_d10, pf2 car_e, pf2 car_o,
                                              float &ch_out, pf2 &y0, pf2 &y1) {
         const float b = iir_bp<VP::VB>(bpf, k.bpf, cc_now);
-        const float ch = k.has_bell ? iir_bp<false>(bell, k.bell, b) : b;
+        // the bell section always runs and a variant without one (secam.py:167-170) takes its input instead: a select on a wave-uniform
+        // flag (a branch per step cost more, two copies of the body cost stage A its registers)
+        const float bl = iir_bp<false>(bell, k.bell, b);
+        const float ch = k.has_bell ? bl : b;
         ch_out = ch;
         const float a_odd = up.template push<VP::VT>(k.taps, ch);
         const float a_even = k.taps.c0 * ch_d10;
-        const pf2 sgn = {1.f, -1.f};
-        const pf2 p_e = pk_mul(pk_mul_bs<0>(pf2{a_even, a_even}, car_e), sgn);
-        const pf2 p_o = pk_mul(pk_mul_bs<0>(pf2{a_odd, a_odd}, car_o), sgn);
-        y0 = iir_sym_pk<0, 3>(lp, kp.lpf, p_e);
-        y1 = iir_sym_pk<0, 3>(lp, kp.lpf, p_o);
-        if (k.odd_l) {
-            const pf2 h = iq_hold;
-            iq_hold = y1;
-            y1 = y0;
-            y0 = h;
-        }
+        // data_up = cos part - j sin part (secam.py:143): the sign of Q as the instruction's neg_hi
+        const pf2 p_e = pk_mul_bs_conj(pk_lo(a_even), car_e);
+        const pf2 p_o = pk_mul_bs_conj(pk_lo(a_odd), car_o);
+        y0 = iir_sym_pk<0, 3>(lp, kp.lpf, p_e);       // the filter's own pair: an odd shift (k.odd_l) is the caller's, once per body of
+        y1 = iir_sym_pk<0, 3>(lp, kp.lpf, p_o);       // four steps, through hold() / set_hold()
     }
+    __device__ __forceinline__ pf2 hold() const { return iq_hold; }
+    __device__ __forceinline__ void set_hold(pf2 h) { iq_hold = h; }
 };
 
 // Stage A with the whole chroma front end in float64 (scalar): for the SECAM shapes whose float32 margin is thin - the
@@ -1014,33 +1246,61 @@ struct SecamDemodA64 {
         const double pi_o = a_odd * car[2], pq_o = -(a_odd * car[3]);
         double i0 = iir_sym<false>(lp_i, k.lpf, pi_e), q0 = iir_sym<false>(lp_q, k.lpf, pq_e);
         double i1 = iir_sym<false>(lp_i, k.lpf, pi_o), q1 = iir_sym<false>(lp_q, k.lpf, pq_o);
-        if (k.odd_l) {
-            const double ih = i_hold, qh = q_hold;
-            i_hold = i1; q_hold = q1;
-            i1 = i0; q1 = q0;
-            i0 = ih; q0 = qh;
-        }
-        y0 = pf2{(float)i0, (float)q0};
+        y0 = pf2{(float)i0, (float)q0};               // the filter's own pair (an odd shift is the caller's: hold() / set_hold())
         y1 = pf2{(float)i1, (float)q1};
+    }
+    // the held sample crosses to stage B as float32 either way, so the float value is all the interior bodies keep of it
+    __device__ __forceinline__ pf2 hold() const { return pf2{(float)i_hold, (float)q_hold}; }
+    __device__ __forceinline__ void set_hold(pf2 h) { i_hold = h.x; q_hold = h.y; }
+};
+
+struct SecamFinishK {
+    pf2 mo_rg, mp_rg;       // per lane: (m[0][c], m[1][c]) of this call's colour-difference signal and of the previous call's (times w_prev)
+    float mo_b, mp_b;
+    pf2 my_rg;              // (m[0][0], m[1][0]), wave-uniform (an SGPR pair)
+    float my_b;
+    __device__ __forceinline__ void load(const SecamDemodK<float> &k, const SecamDemodLaneK<float> &lk) {
+        const bool db = lk.own_is_db != 0.f;
+        mo_rg = pf2{db ? k.m[0][2] : k.m[0][1], db ? k.m[1][2] : k.m[1][1]};
+        mp_rg = pf2{(db ? k.m[0][1] : k.m[0][2]) * lk.w_prev, (db ? k.m[1][1] : k.m[1][2]) * lk.w_prev};
+        mo_b = db ? k.m[2][2] : k.m[2][1];
+        mp_b = (db ? k.m[2][1] : k.m[2][2]) * lk.w_prev;
+        my_rg = pf2{take_s(k.m[0][0]), take_s(k.m[1][0])};
+        my_b = k.m[2][0];
+        pin_pair(mo_rg); pin_pair(mp_rg);
     }
 };
 
+// Stage B.  Round 5: the decimator's accumulators live in register pairs (HalfbandDn2Pk) and the last (I, Q) sample in the high
+// halves of two pairs, so that the interior bodies of the row can take their eight phase steps as four packed ones and two
+// decimator steps per packed update (cm_secam_kernels.h); the guarded bodies at the row ends step through the same registers
+// one sample at a time (chroma_step: the operations of SecamDemodPk::chroma_step, in its order).
 struct SecamDemodPkB {
-    typedef VPolicy<CM_V_SECAM_B> VP;
     IirState<float, 3> ybs;
     IirState<float, 1> deemph;
-    HalfbandChain<float> dn;
+    HalfbandDn2Pk dn;
     float x_last;
-    pf2 iq_prev;
+    pf2 last_i, last_q;     // .y: I / Q of the newest 2x-rate sample (the packed bodies keep their last pair here)
     int have_prev;
 
     __device__ __forceinline__ void reset() {
         ybs.reset(); deemph.reset(); dn.reset();
         x_last = 0.f;
-        iq_prev = pf2{0.f, 0.f};
+        last_i = last_q = pf2{0.f, 0.f};
         have_prev = 0;
     }
-    __device__ __forceinline__ float chroma_step(const SecamDemodK<float> &k, const SecamDemodLaneK<float> &lk, int m, pf2 y0, pf2 y1, float dc) {
+    // de-emphasis: a first-order section (secam.py:175-177; SosK's b2 = a2 = 0, so iir_gen's second state stays 0)
+    __device__ __forceinline__ float deemph_step(const SecamDemodK<float> &k, float x) {
+        const float y = x + deemph.s1[0];
+        deemph.s1[0] = __builtin_fmaf(k.deemph.na1[0], y, k.deemph.b1[0] * x);
+        return y;
+    }
+    __device__ __forceinline__ float clip_scale(const SecamDemodLaneK<float> &lk, float g2, float dc) {
+        const float f2 = (g2 + dc) + lk.off2;                                    // 2 (f - fsc)
+        return __builtin_amdgcn_fmed3f(f2, lk.lo, lk.hi) * lk.scale;              // secam.py:290 (lo < hi)
+    }
+    __device__ __forceinline__ float chroma_step(const SecamDemodK<float> &k, const TapsPk &kp, const SecamDemodLaneK<float> &lk, int m, pf2 y0, pf2 y1,
+                                                 float dc) {
         const int W = k.width, Lc = k.width + k.preroll;
         const int m2 = m - k.s_b - 10, m3 = m2 - k.q_l, m4 = m3 - 9, n = m4 - k.preroll;
         float f_e = 0.f, f_o = 0.f;
@@ -1048,29 +1308,23 @@ struct SecamDemodPkB {
 #ifdef CM_EXP_SECAM_NO_PHASE   /* timing experiment (results wrong) */
             const float d_e = y0.x, d_o = y1.y;
 #else
-            const float d_e = have_prev ? phase_step_fast(iq_prev.x, iq_prev.y, y0.x, y0.y) : 0.f;  // secam.py:147: first step is 0
+            const float d_e = have_prev ? phase_step_fast(last_i.y, last_q.y, y0.x, y0.y) : 0.f;  // secam.py:147: first step is 0
             const float d_o = phase_step_fast(y0.x, y0.y, y1.x, y1.y);
 #endif
             have_prev = 1;
-            iq_prev = y1;
+            last_i.y = y1.x;
+            last_q.y = y1.y;
             f_e = d_e * k.two_over_pi;
             f_o = d_o * k.two_over_pi;
         }
-        const float g2 = dn.template push_pair<VP::VT>(k.taps, f_e, f_o);
+        const float g2 = dn.push_pair(kp, f_e, f_o);
         float c = 0.f;
-        if (n >= 0 && n < W) {
-            float f2 = (g2 + dc) + lk.off2;
-            f2 = f2 < lk.lo ? lk.lo : (f2 > lk.hi ? lk.hi : f2);
-            c = iir_gen<false>(deemph, k.deemph, f2 * lk.scale);
-        }
+        if (n >= 0 && n < W) c = deemph_step(k, clip_scale(lk, g2, dc));         // secam.py:290-296
         return c;
     }
-    // interior bodies: from the phase steps d_e, d_o (taken by the caller, several steps at a time) on
-    __device__ __forceinline__ float chroma_back_mid(const SecamDemodK<float> &k, const SecamDemodLaneK<float> &lk, float d_e, float d_o, float dc) {
-        const float g2 = dn.template push_pair<VP::VT>(k.taps, d_e * k.two_over_pi, d_o * k.two_over_pi);
-        float f2 = (g2 + dc) + lk.off2;
-        f2 = f2 < lk.lo ? lk.lo : (f2 > lk.hi ? lk.hi : f2);
-        return iir_gen<false>(deemph, k.deemph, f2 * lk.scale);
+    // interior bodies: from the decimated deviation g2 (the caller takes phase steps and decimator several steps at a time) on
+    __device__ __forceinline__ float chroma_back_mid(const SecamDemodK<float> &k, const SecamDemodLaneK<float> &lk, float g2, float dc) {
+        return deemph_step(k, clip_scale(lk, g2, dc));
     }
     __device__ __forceinline__ float luma_step_mid(const SecamDemodK<float> &k, float x_in) { return iir_sym<false>(ybs, k.ybs, x_in) * k.luma_gain; }
     __device__ __forceinline__ float luma_step(const SecamDemodK<float> &k, int n, float x_in) {
@@ -1083,14 +1337,16 @@ struct SecamDemodPkB {
         }
         return y * k.luma_gain;
     }
-    __device__ __forceinline__ Rgb<float> finish(const SecamDemodK<float> &k, const SecamDemodLaneK<float> &lk, float luma, float own, float prev) const {
-        prev = prev * lk.w_prev;
-        const float dr = lk.own_is_db != 0.f ? prev : own;   // secam.py:297-300
-        const float db = lk.own_is_db != 0.f ? own : prev;
+    // (r, g, b) = m . (luma, dr, db) with (dr, db) = (own, previous call's) or the other way round (secam.py:297-300): the matrix
+    // columns of "own" and "previous" are picked per lane once (SecamFinishK; w_prev folded into the latter), (r, g) run as a pair
+    __device__ __forceinline__ Rgb<float> finish(const SecamFinishK &fk, float luma, float own, float prev) const {
+        pf2 rg = pk_mul_xk<0, false>(pk_lo(prev), fk.mp_rg);
+        rg = pk_fma_xk<0, 0, false>(pk_lo(own), fk.mo_rg, rg);
+        rg = pk_fma_xk<0, 0, true>(pk_lo(luma), fk.my_rg, rg);
         Rgb<float> o;
-        o.r = fmaf_(k.m[0][0], luma, fmaf_(k.m[0][1], dr, k.m[0][2] * db));
-        o.g = fmaf_(k.m[1][0], luma, fmaf_(k.m[1][1], dr, k.m[1][2] * db));
-        o.b = fmaf_(k.m[2][0], luma, fmaf_(k.m[2][1], dr, k.m[2][2] * db));
+        o.r = rg.x;
+        o.g = rg.y;
+        o.b = fmaf_(fk.my_b, luma, fmaf_(fk.mo_b, own, fk.mp_b * prev));
         return o;
     }
 };

@@ -224,6 +224,12 @@ class _EngineBase(object):
         if plans is not None:
             plans.close()
 
+    def set_small_batch(self, mode):
+        """An engine with one kernel family (MacEngine: its kernels spread a row over the lanes whatever the batch) takes the pins that
+        leave it as it is; Engine / AmEngine override this with their plans' setters."""
+        if mode not in ('auto', 'rows'):
+            raise NotImplementedError('%s has no %r small-batch kernels' % (type(self).__name__, mode))
+
     @property
     def _plan(self):
         """the plan of the current device (created on first use)"""

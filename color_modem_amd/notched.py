@@ -50,7 +50,12 @@ class ShiftedNotchEngine(object):
         assert self.notch is not None
         bare = _BareStack(stack)
         self.base = engine.make_engine(bare, components=True, strip_chroma=strip_chroma, min_lines=min_lines)
-        self.encoder = engine.make_engine(bare, components=components, strip_chroma=strip_chroma, min_lines=min_lines)
+        # the wrapper's modulate IS its backend's (comb.py:90-94), and a notch takes no part in it: encode through the leaf engine - a comb
+        # wrapper's own `.encoder` - so that the per-row protocol (rowapi._step unwraps one level) opens its session on a plain encoder
+        enc = engine.make_engine(bare, components=components, strip_chroma=strip_chroma, min_lines=min_lines)
+        while getattr(enc, 'encoder', None) is not None:
+            enc = enc.encoder
+        self.encoder = enc
         backend = stack['backend']
         m = numpy.eye(3) if components else numpy.asarray(backend.decode_matrix, dtype=numpy.float64)
         self._matrix = numpy.ascontiguousarray(m, dtype=numpy.float64).reshape(-1)

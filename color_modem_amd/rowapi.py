@@ -77,7 +77,7 @@ class RowApi(object):
     @staticmethod
     def _step(run, eng, direction, frame, line):
         from color_modem_amd import engine
-        if direction == 'mod' and getattr(eng, 'encoder', None) is not None:
+        while direction == 'mod' and getattr(eng, 'encoder', None) is not None:
             eng = eng.encoder          # a comb wrapper encodes through its backend (comb.py:90-94): that engine's own session
         if getattr(eng, 'composite', False) or (direction == 'mod' and getattr(eng, 'composite_mod', False)):
             # a composition of kernels (wrapped.py) / an encoder with per-call host input (NIIR noise): the run's last rows go up as they are
@@ -123,12 +123,16 @@ class RowApi(object):
         rows of a field in exactly this order), as one float64 array [n, 3, W], from ONE launch."""
         rows = numpy.ascontiguousarray(composite_rows, dtype=numpy.float32)
         eng = self._engine(line=line + 2 * (max(len(rows), 1) - 1))
+        if len(rows) == 0:
+            return numpy.zeros((0, 3, eng.width))
         if rows.ndim != 2 or rows.shape[1] != eng.comp_width:
             raise ValueError('composite_rows must be [n, %d]' % eng.comp_width)
         return self._rows(self._demod_run, eng, 'demod', eng.demod_depth, frame, line, rows)
 
     def modulate_rows(self, frame, line, r, g, b):
         """What ``[modulate(frame, line + 2 * i, r[i], g[i], b[i]) for i in range(n)]`` returns, as one float64 array [n, W]."""
+        if len(r) == 0 and len(g) == 0 and len(b) == 0:
+            return numpy.zeros((0, self._engine(line=line).comp_width))
         rows = numpy.ascontiguousarray(numpy.stack([r, g, b], axis=1), dtype=numpy.float32)       # [n, 3, W]
         eng = self._engine(line=line + 2 * (max(len(rows), 1) - 1))
         if rows.ndim != 3 or rows.shape[2] != eng.in_width:
@@ -139,7 +143,7 @@ class RowApi(object):
         n = len(rows)
         if n == 0:
             return numpy.zeros((0,) + ((3, eng.width) if direction == 'demod' else (eng.comp_width,)))
-        if direction == 'mod' and getattr(eng, 'encoder', None) is not None:
+        while direction == 'mod' and getattr(eng, 'encoder', None) is not None:
             eng = eng.encoder
         if direction == 'mod' and getattr(eng, 'noise_level', 0.0):
             # niir.py:45-46: every modulate() call draws its own numpy.random samples, in call order; the run entry point draws for its newest row only
