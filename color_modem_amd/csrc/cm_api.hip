@@ -222,6 +222,7 @@ struct Pass {
     std::vector<unsigned char> k;  // DemodK<float, S> blob
     LaneK<float> *lanes = nullptr; // device
     int cycle = 0, n_lines = 0, luma_prev_bits = 0;
+    int wrap_mode = 0;             // cm_lane_table::wrap_mode (two-level comb: PassCfg::WRAP instances)
     int depth = 0;                 // halo lanes of the kernel instance
     std::string name;
 };
@@ -294,12 +295,15 @@ bool make_pass(const cm_plan_desc &d, bool pald, bool bsf, const cm_lane_table &
     if (!build_demod_k<float, S>(d, pald, bsf, k, sc, err)) return false;
     {   // capacities the kernels assume (cm_kernels.h): carrier padding, band-stop luma ring of the wave pair
         const int lat_front = pald ? 10 + k.q_e + 9 + 10 + k.q_l + 9 : 10 + k.q_e + k.q_l + 9;
-        const int lat_out = lat_front + 1 + k.s_p;
+        const bool wrap = tb.wrap_mode != 0;      // PassCfg::WRAP: one more step of output latency
+        const int lat_out = lat_front + 1 + k.s_p + (wrap ? 1 : 0);
         if (lat_out + 8 > kCarrierPad) { err = "pipeline latency beyond the carrier table padding"; return false; }
         const int luma_lag = lat_out - (10 + k.q_r + 9);   // steps between the band-stop luma sample and its use
         if (bsf && (pair ? luma_lag + 12 > luma_ring_slots<S>() : luma_lag > 15)) { err = "band-stop luma delay beyond its LDS ring"; return false; }
         const bool lcut = CM_QAM_LPF_IN_A != 0 && !pald && !bsf && depth >= 2 && !S::RT;     // PassCfg::kLcutCfg
-        const int ring_max = pald ? luma_delay_max_latency<S, 1>() : (lcut ? luma_delay_max_latency<S, 0, true>() : luma_delay_max_latency<S, 0>());
+        const int ring_max = pald ? luma_delay_max_latency<S, 1>()
+                           : (lcut ? (wrap ? luma_delay_max_latency<S, 0, true, 1>() : luma_delay_max_latency<S, 0, true>()) : luma_delay_max_latency<S, 0>());
+        if (wrap && !lcut) { err = "the two-level comb is built on the depth-2 QAM instances of the tuned shapes"; return false; }
         const int ring_win = pald ? ring_window<S, 1>() : (lcut ? ring_window<S, 0, true>() : ring_window<S, 0>());
         if (CM_LUMA_RING && !bsf && pair && lat_out > ring_max) { err = "pipeline latency beyond the luma delay ring"; return false; }
         if (CM_LUMA_RING && !bsf && pair && lat_out < 10 + ring_win) { err = "pipeline latency below the luma window"; return false; }
@@ -317,6 +321,7 @@ bool make_pass(const cm_plan_desc &d, bool pald, bool bsf, const cm_lane_table &
     pass.cycle = tb.frame_cycle;
     pass.n_lines = tb.n_lines;
     pass.luma_prev_bits = tb.luma_from_prev;
+    pass.wrap_mode = tb.wrap_mode;
     return true;
 }
 
@@ -383,7 +388,32 @@ bool select_for_shape(cm_plan *p, const cm_plan_desc &d, const char *sys, std::s
     err = "development build: PAL-D only";
     return false;
 #else
-    if (pald && depth == 2 && !first) {
+    const int wrap = d.demod_main.wrap_mode;
+    if (wrap) {
+        // SimpleCombModem / Simple3DCombModem around Pal3DModem as a two-level comb (cm_lane_table::wrap_mode): Pal3DModem's tables, the
+        // wrapper's average of consecutive calls in stage B, three halo lanes
+        if constexpr (HAS_PALD) {
+            if (pald || bsf || first || depth != 3 || d.skip_calls || (wrap != 1 && wrap != 2)) {
+                err = "a two-level comb (wrap_mode) takes the QAM pipeline, depth 3 (two table lines + the wrapper's), no plain first line";
+                return false;
+            }
+            if (minavg) {
+                p->fn = launch_demod<PassCfg<S, FRONT_QAM, false, 2, 16, false, true, true, true>, NoPass>;
+                p->fn_u8 = launch_demod<PassCfg<S, FRONT_QAM, false, 2, 16, true, true, true, true>, NoPass>;
+            } else if (notch) {
+                p->fn = launch_demod<PassCfg<S, FRONT_QAM, false, 2, 16, false, true, false, true>, NoPass>;
+                p->fn_u8 = launch_demod<PassCfg<S, FRONT_QAM, false, 2, 16, true, true, false, true>, NoPass>;
+            } else {
+                p->fn = launch_demod<PassCfg<S, FRONT_QAM, false, 2, 16, false, false, false, true>, NoPass>;
+                p->fn_u8 = launch_demod<PassCfg<S, FRONT_QAM, false, 2, 16, true, false, false, true>, NoPass>;
+            }
+            p->main.depth = 3;
+            what = std::string("qam front, depth 2") + (minavg ? ", minavg" : "") + (wrap == 2 ? " | minavg" : " | avg") + " of consecutive calls (two-level comb)";
+        } else {
+            err = std::string("no two-level comb instance for the ") + sys + " filter shapes";
+            return false;
+        }
+    } else if (pald && depth == 2 && !first) {
         // SimpleCombModem / Simple3DCombModem around PalDModem, the calls k >= 2 of every run (comb.py:96-113 over pal.py:79-127: both
         // chroma estimates come from the PAL-D front end there, two lines of history; cm_comb_wrap_demodulate_frames_fused supplies
         // the calls k < 2, which mix in the plain first-line decode)
@@ -484,6 +514,7 @@ bool select_any(cm_plan *p, const cm_plan_desc &d, std::string &err) {
     p->fn = nullptr;
     p->fn_u8 = nullptr;
     std::string what;
+    if (d.demod_main.wrap_mode) { err = "the two-level comb (wrap_mode) is built for the tuned shapes (the run-time shape: the composition)"; return false; }
     if (pald && depth == 2 && !first) {
         // the fused wrapped combs (select_for_shape) at the other sampling rates: the comb.avg form only - minavg / notch stay on the composition
         if (d.skip_calls != 2) { err = "the PAL-D front end with two lines of history serves the fused wrapped combs (skip_calls = 2)"; return false; }
@@ -865,6 +896,7 @@ void finish_geom(const cm_plan *p, const Pass &pass, Geom &g) {
     g.cycle = pass.cycle;
     g.n_lines = pass.n_lines;
     g.luma_prev_bits = pass.luma_prev_bits;
+    g.wrap_mode = pass.wrap_mode;
 }
 
 // ---- small batches: rows cut into segments (cm_kernels.h: Geom::seg_len) ---------------------------------------------------
@@ -1341,7 +1373,8 @@ int cm_plan_create(const cm_plan_desc *desc, cm_plan **out) {
     if (desc->height < 1) return fail(CM_ERR_INVALID, "height must be positive");
     if (desc->pipeline != CM_PIPE_QAM && desc->pipeline != CM_PIPE_PAL_D && desc->pipeline != CM_PIPE_SECAM)
         return fail(CM_ERR_INVALID, "unknown pipeline");
-    if (desc->depth < 0 || desc->depth > 2) return fail(CM_ERR_INVALID, "depth must be 0..2");
+    if (desc->demod_main.wrap_mode < 0 || desc->demod_main.wrap_mode > 2) return fail(CM_ERR_INVALID, "demod_main.wrap_mode must be 0, 1 or 2");
+    if (desc->depth < 0 || desc->depth > (desc->demod_main.wrap_mode ? 3 : 2)) return fail(CM_ERR_INVALID, "depth must be 0..2 (3 with demod_main.wrap_mode)");
     if (desc->skip_calls != 0 && desc->skip_calls != 2) return fail(CM_ERR_INVALID, "skip_calls must be 0 or 2");
     if (!desc->demod_main.table || desc->demod_main.frame_cycle < 1 || desc->demod_main.n_lines < 1)
         return fail(CM_ERR_INVALID, "demod_main table missing");
@@ -2788,7 +2821,7 @@ int wrap_frames(const cm_plan *inner, const cm_plan *first, const cm_plan *backe
 // the lane tables of plan.py (QamTables: fused_main) - which stores every call with k >= 2.  The calls k < 2 of every run mix in the
 // plain first-line decode (the QAM front end): they are the top four rows of every frame, and go through the composition above.
 bool wrap_fused_applies(const cm_plan *fused, const cm_plan *inner, int64_t n_frames) {
-    if (!fused || !fused->fn || fused->desc.skip_calls != 2) return false;
+    if (!fused || !fused->fn || (fused->desc.skip_calls != 2 && !fused->main.wrap_mode)) return false;
     const cm_plan_desc &d = inner->desc;
     if (d.height < 8 || d.width % 4 != 0) return false;
     if (inner->small_batch != CM_SMALL_BATCH_AUTO) return false;          // a pinned kernel family: the composition honours it
@@ -2840,6 +2873,10 @@ int wrap_frames_fused(const cm_plan *fused, const cm_plan *inner, const cm_plan 
     g.first_line[1] = 1;
     g.delay = D;
     g.total_calls = n_frames * g.calls_per_frame;
+    if (fused->main.wrap_mode) {      // a two-level comb (around Pal3DModem: one front end, so every call of every run): the whole decode
+        Geom none = g;
+        return run_plan(fused, g, none, false, stream, in8 != nullptr);
+    }
     g.skip_first = 2;
     Geom none = g;
     if ((rc = run_plan(fused, g, none, false, stream, in8 != nullptr))) return rc;

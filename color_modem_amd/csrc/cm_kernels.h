@@ -54,7 +54,9 @@ struct Geom {
     int k0;              // rows mode: index of the first submitted call within its run
     int delay;           // demodulation_delay (frames mode: output row = line - 2 * delay)
     int rows_mode;       // 1: input row i / output row i are the i-th submitted rows of one run
-    int luma_prev_bits;  // bit r: regime r takes its luma from the previous call's input row
+    int luma_prev_bits;  // bit r: regime r takes its luma from the previous call's input row; bit 8 + r: from the call before that one
+                         // (two-level combs)
+    int wrap_mode;       // PassCfg::WRAP instances: 1 = comb.avg, 2 = comb.minavg of consecutive calls' (u, v)
     int sparse;          // 1: one lane per run, call 0 of each run only (plain first-line pass)
     int seg_len;         // > 0: small batches - the row is cut into segments of seg_len samples (a multiple of 16) and every
     int seg_blocks;      // workgroup walks ONE segment of its 64 calls, starting seg_warm samples early from a zero state (the
@@ -197,11 +199,15 @@ __device__ __forceinline__ const float *ptr_from(int byte_index, const float *p)
 #ifndef CM_LCUT_DEPTH2_WAVES
 #define CM_LCUT_DEPTH2_WAVES 3
 #endif
-template <class S_, int FRONT_, bool BSF_, int DEPTH_, int TILE_, bool U8_ = false, bool NOTCH_ = false, bool MINAVG_ = false>
+// WRAP_: two-level comb (round 5; SimpleCombModem / Simple3DCombModem around Pal3DModem, comb.py:96-113 over pal.py:180-234): the lane
+// tables are the inner decoder's, and stage B averages (Geom::wrap_mode 1) or min-averages (2) the (u, v) they give with the (u, v) the
+// neighbouring lane - the previous call of the run - formed the same way, one step later in the stream; DEPTH_ + 1 halo lanes.
+template <class S_, int FRONT_, bool BSF_, int DEPTH_, int TILE_, bool U8_ = false, bool NOTCH_ = false, bool MINAVG_ = false, bool WRAP_ = false>
 struct PassCfg {
     typedef S_ S;
     static constexpr int FRONT = FRONT_, DEPTH = DEPTH_, TILE = TILE_;
-    static constexpr bool BSF = BSF_, U8 = U8_, NOTCH = NOTCH_, MINAVG = MINAVG_;
+    static constexpr bool BSF = BSF_, U8 = U8_, NOTCH = NOTCH_, MINAVG = MINAVG_, WRAP = WRAP_;
+    static constexpr int HALO = DEPTH_ + (WRAP_ ? 1 : 0);      // lanes of a workgroup that only recompute earlier calls
     static constexpr int kLdsInF = U8_ ? 64 * kInTile / 4 : kLdsIn;            // floats: byte tiles are a quarter
     static constexpr int kLdsOut = U8_ ? 64 * 3 * TILE_ / 4 : 3 * 64 * TILE_;  // floats
     static constexpr int kLdsFloats = kLdsInF + kLdsOut + (BSF_ ? kLdsRing : 0);
@@ -813,20 +819,21 @@ constexpr int kLumaSlots = 2 * 64 * 4;      // floats: [buffer][lane][4 steps] l
 // (the host checks lat_out against this: cm_api.hip).  11 KiB for PAL-BG (lat_out 46 = the limit), 12 KiB for the order-6 band-pass shapes, 20 KiB for the run-time shape.
 // The QAM front end is shorter (lat_out 26 / 28 / 32 for the PAL-BG / NTSC / NTSC-A shapes against 46 / 47 behind the PAL-D
 // front end): its ring is sized for that, so that those instances fit six workgroups per CU as well (25 instead of 30 KiB).
-template <class S, int FRONT = 0, bool LC = false> constexpr int luma_delay_blocks() {
+// X: extra steps of output latency (PassCfg::WRAP: the second exchange of the two-level combs)
+template <class S, int FRONT = 0, bool LC = false, int X = 0> constexpr int luma_delay_blocks() {
     if (S::RT) return 20;
-    if (FRONT == FRONT_QAM && CM_QAM_SHORT_RING) return ((S::NE >= 4 ? 32 : (S::NE == 3 ? 28 : 26)) - 10 - ring_window<S, FRONT, LC>() + 3) / 4 + 2;
-    return S::NE >= 3 ? 12 : 11 - ring_window<S, FRONT, LC>() / 4;
+    if (FRONT == FRONT_QAM && CM_QAM_SHORT_RING) return ((S::NE >= 4 ? 32 : (S::NE == 3 ? 28 : 26)) + X - 10 - ring_window<S, FRONT, LC>() + 3) / 4 + 2;
+    return (S::NE >= 3 ? 12 : 11 - ring_window<S, FRONT, LC>() / 4) + (X + 3) / 4;
 }
-template <class S, int FRONT = 0, bool LC = false> constexpr int luma_delay_max_latency() {
-    return 4 * (luma_delay_blocks<S, FRONT, LC>() - 2) + 10 + ring_window<S, FRONT, LC>();
+template <class S, int FRONT = 0, bool LC = false, int X = 0> constexpr int luma_delay_max_latency() {
+    return 4 * (luma_delay_blocks<S, FRONT, LC, X>() - 2) + 10 + ring_window<S, FRONT, LC>();
 }
 
 template <class Cfg>
 struct PairLds {
     static constexpr int kIn = Cfg::kPairLdsIn, kOut = Cfg::kLdsOut;
     static constexpr int kY = Cfg::BSF ? luma_ring_slots<typename Cfg::S>() * 64
-                                       : (CM_LUMA_RING ? luma_delay_blocks<typename Cfg::S, Cfg::FRONT, Cfg::kLcutCfg>() * 256 : kLumaSlots);
+                                       : (CM_LUMA_RING ? luma_delay_blocks<typename Cfg::S, Cfg::FRONT, Cfg::kLcutCfg, Cfg::WRAP ? 1 : 0>() * 256 : kLumaSlots);
     // hand-over ring: the 2x-rate pair (even, odd) per step, or - where stage A also takes the detector products and the
     // low-pass (LCUT: the QAM front end without the band-stop luma) - the two low-passed pairs (q_e, q_o)
     static constexpr bool kLcut = Cfg::kLcutCfg;
@@ -847,7 +854,7 @@ inline int pair_lds_floats(const DemodK<float, typename Cfg::S> &k) {
     typedef typename Cfg::S S;
     if (!S::RT || Cfg::BSF || !CM_LUMA_RING) return PairLds<Cfg>::kFloats;
     const int lat_front = Cfg::FRONT == FRONT_PALD ? 10 + k.q_e + 9 + 10 + k.q_l + 9 : 10 + k.q_e + k.q_l + 9;
-    const int lat_out = lat_front + 1 + k.s_p;
+    const int lat_out = lat_front + 1 + k.s_p + (Cfg::WRAP ? 1 : 0);
     constexpr int kWinX = ring_window<S, Cfg::FRONT, Cfg::kLcutCfg>();
     const int lr_o = (10 + kWinX - lat_out) & 3, lr_m = (lat_out - 10 - kWinX + lr_o) >> 2;
     return PairLds<Cfg>::kIn + PairLds<Cfg>::kMid + PairLds<Cfg>::kOut + PairLds<Cfg>::kUv + (lr_m + 2) * 256;
@@ -887,7 +894,7 @@ __device__ __forceinline__ void run_pair(const Geom &g, const DemodK<float, type
     constexpr int kYSlots = luma_ring_slots<S>();
     constexpr bool LRING = CM_LUMA_RING && !BSF;         // luma source samples through the LDS delay ring
     constexpr int kIT = Cfg::kPairInTile;                // samples per input tile row
-    constexpr int kLBmax = luma_delay_blocks<S, FRONT, Cfg::kLcutCfg>();   // tuned shapes: the ring's size; run-time shape: its limit
+    constexpr int kLBmax = luma_delay_blocks<S, FRONT, Cfg::kLcutCfg, Cfg::WRAP ? 1 : 0>();   // tuned shapes: the ring's size; run-time shape: its limit
     constexpr int kWinX = ring_window<S, FRONT, Cfg::kLcutCfg>();        // extra x samples stage A keeps behind its window
     typedef typename std::conditional<PALD, PalDFront<float, S>, QamFront<float, S, BSF>>::type Front;
     typedef typename Front::StageA StageA;
@@ -910,7 +917,7 @@ __device__ __forceinline__ void run_pair(const Geom &g, const DemodK<float, type
         seg = block / g.seg_blocks;
         block -= seg * g.seg_blocks;
     }
-    const LaneCall lc = locate_call(g, block, DEPTH, lane);
+    const LaneCall lc = locate_call(g, block, Cfg::HALO, lane);
     const long long frame = lc.frame;
     const int regime = lc.regime;
 
@@ -921,7 +928,7 @@ __device__ __forceinline__ void run_pair(const Geom &g, const DemodK<float, type
     int lat_luma = 0;
     if constexpr (!PALD) lat_luma = Front::luma_latency(k);
     const int sp = S::RT ? k.s_p : SP;          // run-time shapes: SP is the window size, k.s_p the delay
-    const int lat_out = lat_front + 1 + sp;     // n7 = t - lat_out
+    const int lat_out = lat_front + 1 + sp + (Cfg::WRAP ? 1 : 0);     // n7 = t - lat_out (WRAP: one more step for the second exchange)
     const int Wp = g.Wp;                          // the output row ends with the quad that holds sample W - 1
     const int T = (Wp + lat_out + 3) & ~3;
     const int front_off = StageA::pair_offset(k);   // detector pair index nd = t - front_off
@@ -1213,6 +1220,9 @@ __device__ __forceinline__ void run_pair(const Geom &g, const DemodK<float, type
     det.reset();
     back.reset();
     pf2 base_prev = {0.f, 0.f}, b1_prev = {0.f, 0.f}, b2_prev = {0.f, 0.f};
+    pf2 uv_own = {0.f, 0.f}, uv_nb = {0.f, 0.f};     // WRAP: the inner decoder's (u, v) of the step before - this lane's, the previous call's
+    const bool wrap_first = regime == 0;            // comb.py:97-99: the first call of a run returns the inner result as it is
+    const bool wrap_min = g.wrap_mode == 2;
     constexpr bool UVR = PairLds<Cfg>::kUv != 0;
     constexpr int kUvd = UVR ? 1 : (SP > 0 ? SP : 1);
     pf2 uvd[kUvd];   // (u, v) of the last SP steps (newest first); UVR: in LDS instead
@@ -1248,8 +1258,11 @@ __device__ __forceinline__ void run_pair(const Geom &g, const DemodK<float, type
     // delay ring: the block of body tb is lr_m blocks behind A's; a luma source row other than the own one (decoders with a
     // line of delay) is the row of the previous call, i.e. of the neighbouring lane
     int lr_r = lr_m == 0 ? 0 : kLB - lr_m;
-    const bool luma_prev = DEPTH >= 1 && ((g.luma_prev_bits >> regime) & 1) && lc.prev_row != lc.src_row;
-    const lds_float *lr_lane = lring + (luma_prev ? ((lane + 63) & 63) : lane) * 4;
+    // (calls back, never beyond the run's first call; at the bottom edge consecutive calls re-feed one row - image.py:79-81 - which makes
+    // no difference one call back and all the difference two calls back)
+    int luma_back = DEPTH >= 1 ? ((g.luma_prev_bits >> regime) & 1) + ((g.luma_prev_bits >> (8 + regime)) & 1) : 0;
+    if (luma_back > lc.kk) luma_back = lc.kk;
+    const lds_float *lr_lane = lring + ((lane + 64 - luma_back) & 63) * 4;
     // p_e, p_o: detector products of this step's pair; sc: (sn, cs) of the back-end sample
     auto sub_b = [&](auto sub_tag, auto edge_tag, pf2 &p_last, pf2 &uv_last, int tau, pf2 p_e, pf2 p_o, pf2 sc) {
         constexpr int SUB = decltype(sub_tag)::value;
@@ -1258,8 +1271,18 @@ __device__ __forceinline__ void run_pair(const Geom &g, const DemodK<float, type
         if constexpr (LCUT) base = det.dn.push_pair(kb.taps, p_e, p_o);      // (p_e, p_o) = stage A's low-passed pairs
         else base = det.template step<EDGE>(k, kb, p_last, tau - front_off, p_e, p_o);
         // the back end handles the PREVIOUS step's base pair: its neighbours were requested then
-        const int n6 = tau - lat_front - 1, n7 = n6 - sp;
+        const int n6 = tau - lat_front - 1 - (Cfg::WRAP ? 1 : 0), n7 = n6 - sp;
         pf2 uv = back.combine(lk, base_prev, b1_prev, b2_prev);
+        if constexpr (Cfg::WRAP) {
+            // second level, one step behind the first: avg / minavg of the previous call's result (asked of the neighbouring lane a step
+            // ago) and this call's, comb.py:103-104; a run's first call passes its own through (avg(x, x) = minavg(x, x) = x exactly)
+            const pf2 inner = uv;
+            const pf2 last = wrap_first ? uv_own : uv_nb;
+            if (wrap_min) uv = pf2{minavg_(last.x, uv_own.x), minavg_(last.y, uv_own.y)};
+            else uv = pf2{0.5f * (last.x + uv_own.x), 0.5f * (last.y + uv_own.y)};
+            uv_own = inner;
+            uv_nb = pf2{lane_from(idx1, inner.x), lane_from(idx1, inner.y)};
+        }
         base_prev = base;
         if (DEPTH >= 1) b1_prev = pf2{lane_from(idx1, base.x), lane_from(idx1, base.y)};
         if (DEPTH >= 2) b2_prev = pf2{lane_from(idx2, base.x), lane_from(idx2, base.y)};

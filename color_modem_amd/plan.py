@@ -22,7 +22,7 @@ import ctypes
 import numpy
 from color_modem_amd import design
 
-CM_ABI_VERSION = 7
+CM_ABI_VERSION = 8
 CM_SECAM_PRESENT, CM_SECAM_FLOAT64 = 1, 2      # cm_secam_desc.present (include/color_modem_hip.h)
 CM_PIPE_QAM, CM_PIPE_PAL_D, CM_PIPE_SECAM = 1, 2, 3
 CM_MAX_SECTIONS = 4
@@ -40,7 +40,7 @@ class IirDesc(ctypes.Structure):
 class LaneTable(ctypes.Structure):
     _fields_ = [('frame_cycle', ctypes.c_int32), ('n_lines', ctypes.c_int32),
                 ('table', ctypes.POINTER(ctypes.c_double)),
-                ('luma_from_prev', ctypes.c_int32), ('reserved', ctypes.c_int32)]
+                ('luma_from_prev', ctypes.c_int32), ('wrap_mode', ctypes.c_int32)]
 
 
 class SecamDesc(ctypes.Structure):
@@ -190,6 +190,12 @@ class QamTables(object):
         # chroma estimates of comb.py:103-104 are PAL-D decodes, i.e. combinations of this front end's base pairs over three lines;
         # the calls k < 2 mix in the plain decode of the first line and are left to the composition (skip_calls = 2)
         self.fused_main = bool(stack.get('fused_main'))
+        # SimpleCombModem / Simple3DCombModem around Pal3DModem as a TWO-LEVEL comb (round 5): the lane tables are Pal3DModem's own
+        # (components, strip_chroma=False - what the wrapper asks its backend for), and the kernel averages that result with the one the
+        # neighbouring lane (the previous call) formed the same way - comb.py:103-104 as written - before it strips and notches at the
+        # wrapper's line.  One more lane of halo, no fourth line in the tables.  (cm_lane_table::reserved = wrap_mode)
+        self.two_level = bool(stack.get('two_level'))
+        self.wrap_mode = 0
         b = self.backend
         self.lc = b.line_config
         self.LS = b.line_shift
@@ -215,7 +221,19 @@ class QamTables(object):
         # comb.py:9-15: which averaging function combines the two chroma estimates (wrapper, or Pal3DModem's two paths)
         from color_modem_amd import comb as comb_module
         fn = None
-        if self.demod_wrapper:
+        if self.two_level:
+            if self.kind != 'pal_3d' or not self.demod_wrapper:
+                raise NotImplementedError('the two-level comb serves SimpleCombModem / Simple3DCombModem around Pal3DModem')
+            wfn = stack.get('wrapper_avg')
+            if wfn is None or wfn is comb_module.avg:
+                self.wrap_mode = 1
+            elif wfn is comb_module.minavg:
+                self.wrap_mode = 2
+            else:
+                raise NotImplementedError('avg=%r around Pal3DModem: callables go through the composition (wrapped.py)' % (wfn,))
+            if self.comb._use_sin and self.comb._use_cos:
+                fn = self.comb._avg           # the tables' second estimate is Pal3DModem's own (pal.py:209-211)
+        elif self.demod_wrapper:
             fn = stack.get('wrapper_avg')
         elif self.kind == 'pal_3d' and self.comb._use_sin and self.comb._use_cos:
             fn = self.comb._avg
@@ -316,7 +334,7 @@ class QamTables(object):
 
     # -- full decoder at call k ---------------------------------------------------------------
     def decode(self, frame, line, k):
-        """Returns u, v, remod_line (None: luma unstripped or band-stop), luma_prev (bool), u2, v2.
+        """Returns u, v, remod_line (None: luma unstripped or band-stop), luma_prev (calls back: bool or 0 / 1 / 2), u2, v2.
         u2, v2 are None unless the decoder combines two estimates with comb.minavg: then the output is
         minavg(u, u2), minavg(v, v2)."""
         u, v, remod_line, luma_prev, u2, v2 = self._decode(frame, line, k)
@@ -346,7 +364,22 @@ class QamTables(object):
         else:
             own_delay = 1 if w == 'simple_3d' else 0
             if self.kind == 'pal_3d':
-                raise NotImplementedError('SimpleCombModem around Pal3DModem reaches back 3 lines; not built')
+                if not self.two_level:
+                    raise NotImplementedError('SimpleCombModem around Pal3DModem reaches back 3 lines: wrapped.py composes it (and runs long '
+                                              'batches as a two-level comb)')
+                # the inner decoder's own combination at this call (pal.py:180-234, strip_chroma=False); the wrapper level is the kernel's
+                r = self.uv_pal_3d(frame, line, k)
+                u2 = v2 = None
+                if self.minavg and k >= 2:
+                    (u, v), (u2, v2) = r
+                else:
+                    u, v = r
+                if k == 0:                                # comb.py:97-99: the inner result as it is, luma unstripped
+                    return u, v, None, 0, u2, v2
+                # comb.py:102: y = the previous call's inner luma (own_delay) or this call's; Pal3DModem's luma at its call j is the row
+                # of call 0 for j <= 1 (pal.py:191-201) and of call j - 1 after that (pal.py:223)
+                back = (1 if k == 1 else 2) if own_delay else 1
+                return u, v, line - 2 * own_delay, back, u2, v2      # comb.py:105-106 (modulation_delay = 0)
             if self.kind == 'pal_d':
                 if not self.fused_main:
                     raise NotImplementedError('SimpleCombModem around PalDModem mixes two front ends on the first two calls of a run; '
@@ -442,8 +475,10 @@ class QamTables(object):
                     if self.minavg:   # no second estimate at this call: minavg(a, a) = a
                         e[20:26] = self.phase_free(u2 if u2 is not None else u, f, line).reshape(-1)
                         e[26:32] = self.phase_free(v2 if v2 is not None else v, f, line).reshape(-1)
-                    if luma_prev:
+                    if int(luma_prev) >= 1:     # bit k: the luma source lies one call back, bit 8 + k: one more (two-level combs)
                         luma_prev_bits |= 1 << k
+                    if int(luma_prev) >= 2:
+                        luma_prev_bits |= 1 << (8 + k)
         return tab, luma_prev_bits
 
     def demod_first_table(self):
@@ -534,6 +569,7 @@ def build_qam_plan(stack, components=False, strip_chroma=True, min_lines=0):
     main = numpy.ascontiguousarray(main)
     mod = numpy.ascontiguousarray(mod)
     d.demod_main = _lane_table(main, bits)
+    d.demod_main.wrap_mode = tb.wrap_mode          # 0 / 1: avg / 2: minavg of consecutive calls' results in the kernel (two-level comb)
     d.demod_first = _lane_table(first)
     d.mod_main = _lane_table(mod)
     rot = None

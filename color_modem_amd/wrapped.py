@@ -24,6 +24,10 @@ hands it one float64 numpy row per call; elementwise functions of two arrays (th
 That also serves the wrappers around the plain decoders (NtscModem, PalSModem, NtscCombModem), whose comb.avg / comb.minavg forms are
 fused into lane tables instead.
 
+Round 5: around Pal3DModem every chroma estimate comes from ONE front end, so long batches run as a two-level comb in a single launch
+(`_TwoLevelStack`: Pal3DModem's lane tables + the average of consecutive calls inside the kernel, three halo lanes) - no scratch, no
+composition; short batches, avg= callables and the per-row protocol stay on the composition.
+
 Round 4: around PalDModem a fourth plan removes the component scratch from long batches.  From the third call of a run on, both
 chroma estimates the wrapper averages are PAL-D decodes - combinations of the PAL-D front end's base pairs of three consecutive
 lines - so the whole wrapper is one more line of history in the fused decoder's lane tables (plan.QamTables: fused_main; kernel
@@ -49,6 +53,16 @@ class _FusedStack(object):
 
     def __init__(self, stack):
         self._marked = dict(stack, fused_main=True)
+
+    def _stack(self):
+        return self._marked
+
+
+class _TwoLevelStack(object):
+    """The wrapper's stack around Pal3DModem marked for the two-level comb (plan.QamTables: two_level)."""
+
+    def __init__(self, stack):
+        self._marked = dict(stack, two_level=True)
 
     def _stack(self):
         return self._marked
@@ -92,6 +106,13 @@ class WrappedCombEngine(object):
                 self.fused = engine.Engine(_FusedStack(stack), components=components, strip_chroma=strip_chroma, min_lines=need)
             except NotImplementedError:      # no PAL-D depth-2 instance for this filter-set shape: the composition serves every batch
                 self.fused = None
+        elif stack['kind'] == 'pal_3d' and self.custom_avg is None and getattr(self.inner_modem, 'demodulation_delay', 0) == 1:
+            # round 5: around Pal3DModem every estimate comes from the QAM front end, so ONE plan decodes every call of every run - Pal3DModem's
+            # lane tables, the wrapper's average of consecutive calls inside the kernel (cm_lane_table::wrap_mode, PassCfg::WRAP)
+            try:
+                self.fused = engine.Engine(_TwoLevelStack(stack), components=components, strip_chroma=strip_chroma, min_lines=need)
+            except NotImplementedError:      # the run-time filter shape (other sampling rates): the composition
+                self.fused = None
         self.demod_depth = self.inner.demod_depth + 1
         self.mod_depth = 0
         self.n_lines = min(e.n_lines for e in (self.inner, self.first, self.mod, self.encoder) if e is not None)
@@ -106,7 +127,9 @@ class WrappedCombEngine(object):
 
     def describe(self):
         text = 'composition: %s (components, every call of the batch) | comb_wrap_back_kernel (small batches: wrap_back_scan_kernel)' % self.inner.describe()
-        if self.fused is not None:
+        if self.fused is not None and self.fused.built.tables.two_level:
+            text = 'long batches: %s; otherwise %s' % (self.fused.describe(), text)
+        elif self.fused is not None:
             text = 'long batches: %s + the composition on the top four rows; otherwise %s' % (self.fused.describe(), text)
         return text
 

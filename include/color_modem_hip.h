@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define CM_ABI_VERSION 7
+#define CM_ABI_VERSION 8
 
 enum cm_status {
     CM_OK = 0,
@@ -93,8 +93,14 @@ typedef struct {
     int32_t frame_cycle;  /* table rows per regime: frames repeat with this period */
     int32_t n_lines;      /* line numbers 0 .. n_lines-1 are tabulated */
     const double *table;  /* [frame_cycle][3][n_lines][CM_LANE_DOUBLES]; NULL = pass absent */
-    int32_t luma_from_prev; /* per regime (bit r): luma source is the previous call's input line */
-    int32_t reserved;
+    int32_t luma_from_prev; /* per regime (bit r): luma source is the previous call's input line; bit 8 + r (wrap_mode != 0): of the
+                             * call before that one */
+    int32_t wrap_mode;      /* demod_main only, ABI 8.  0: the tables are the whole decoder.  1 / 2: a TWO-LEVEL comb - SimpleCombModem /
+                             * Simple3DCombModem around Pal3DModem (comb.py:96-113 over pal.py:180-234): the tables are the inner decoder's
+                             * (components, strip_chroma = False) except [2], [3], [16] and luma_from_prev, which describe the wrapper's
+                             * strip (comb.py:105-106); the kernel combines every call's (u, v) with the previous call's by comb.avg (1) or
+                             * comb.minavg (2) - a run's first call passes through (comb.py:97-99) - before it strips, notches and
+                             * applies the matrix.  cm_plan_desc.depth counts the wrapper's line (3), frames entry points only. */
 } cm_lane_table;
 
 /* SECAM constants (secam.py:153-190), frequencies normalised to the Nyquist rate like the reference.

@@ -68,6 +68,9 @@ STACKS.update({
     'simple3d_pald_minavg': lambda lc: comb.Simple3DCombModem(pal.PalDModem(lc), avg=comb.minavg),
     'simple3d_pald_notch': lambda lc: comb.Simple3DCombModem(pal.PalDModem(lc), notch=6.0),
     'simple_pal3d_notch': lambda lc: comb.SimpleCombModem(pal.Pal3DModem(lc), notch=3.0, avg=comb.minavg),
+    # (no reference vectors of their own: the oracle, pinned on the stacks above, is the check)
+    'simple3d_pal3d_minavg2': lambda lc: comb.Simple3DCombModem(pal.Pal3DModem(lc, avg=comb.minavg), avg=comb.minavg, notch=5.0),
+    'simple_pal3d_sin': lambda lc: comb.SimpleCombModem(pal.Pal3DModem(lc, use_cos=False)),
 })
 
 

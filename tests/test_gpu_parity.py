@@ -987,7 +987,11 @@ def test_wrapped_pal_comb_vs_oracle(stack, size, first):
 @pytest.mark.parametrize('stack,size,frames', [('simple3d_pald', (720, 16), 1700), ('simple_pald', (720, 21), 1300),
                                                ('simple3d_pald_minavg', (720, 12), 2100), ('simple3d_pald_notch', (720, 576), 48),
                                                ('simple_pald', (720, 576), 45), ('simple3d_pald', (768, 16), 1700), ('simple_pald', (1280, 10), 2500),
-                                               ('simple3d_pald', (960, 12), 2100)])
+                                               ('simple3d_pald', (960, 12), 2100),
+                                               # round 5: around Pal3DModem long batches run as a two-level comb in one launch (cm_lane_table::wrap_mode)
+                                               ('simple3d_pal3d', (720, 16), 1700), ('simple_pal3d_notch', (720, 21), 1300),
+                                               ('simple3d_pal3d', (720, 576), 45), ('simple3d_pal3d_minavg2', (720, 12), 2100),
+                                               ('simple_pal3d_sin', (720, 10), 2500)])
 def test_wrapped_pal_comb_fused_long_batches(stack, size, frames):
     """Long batches around PalDModem run the fused plan (PAL-D front end, two lines of history: every call k >= 2 of a run in one
     pass over the frames) plus the composition on the top four rows (cm_comb_wrap_demodulate_frames_fused).  Against the float64
@@ -1036,7 +1040,8 @@ def test_wrapped_pal_comb_fused_variants(variant, std, size, frames):
     from color_modem_amd.color import pal
     lc = line.LineConfig(size, getattr(line.LineStandard, std))
     v = getattr(pal.PalVariant, variant)
-    for make in (lambda: comb.Simple3DCombModem(pal.PalDModem(lc, v)), lambda: comb.SimpleCombModem(pal.PalDModem(lc, v), avg=comb.minavg)):
+    for make in (lambda: comb.Simple3DCombModem(pal.PalDModem(lc, v)), lambda: comb.SimpleCombModem(pal.PalDModem(lc, v), avg=comb.minavg),
+                 lambda: comb.Simple3DCombModem(pal.Pal3DModem(lc, v)), lambda: comb.SimpleCombModem(pal.Pal3DModem(lc, v, avg=comb.minavg), avg=comb.minavg)):
         modem = make()
         eng = image.ImageModem(modem)._engine()
         assert eng.fused is not None, variant
