@@ -1112,6 +1112,11 @@ __device__ __forceinline__ void run_pair(const Geom &g, const DemodK<float, type
             sub_a(std::integral_constant<int, 2>(), edge_tag, fla, tb + 2, me[2], mo[2]);
             sub_a(std::integral_constant<int, 3>(), edge_tag, fla, tb + 3, me[3], mo[3]);
             }
+#if defined(CM_EXPERIMENTS) && defined(CM_EXP_NO_WINDOW_MOVES)   /* timing experiment (results wrong): the register windows never move - the
+            ceiling of what a rotating-index unroll of stage A could save (profiles/r05_headline_residue.txt) */
+#pragma unroll
+            for (int j = 0; j < 10; ++j) asm volatile("" : "+v"(xw[j]));
+#else
             if (kWinX >= 8) {
 #pragma unroll
                 for (int j = 0; j + 4 < kWinX; ++j) xo[kWinX >= 8 ? j : 0] = xo[kWinX >= 8 ? j + 4 : 0];
@@ -1120,6 +1125,7 @@ __device__ __forceinline__ void run_pair(const Geom &g, const DemodK<float, type
             }
 #pragma unroll
             for (int j = 0; j < 10; ++j) xw[j] = xw[j + 4];
+#endif
             if constexpr (PKF) {
                 xw[10] = xq.x; xw[11] = xq.y; xw[12] = xq.z; xw[13] = xq.w;
             } else {
@@ -1139,10 +1145,17 @@ __device__ __forceinline__ void run_pair(const Geom &g, const DemodK<float, type
                     if (U8) fill_tile_u8(g, itile, xp, nxt / kIT + 1, lane); else fill_tile<kIT>(g, itile, xp, nxt / kIT + 1, lane);
                 }
             }
+#if defined(CM_EXPERIMENTS) && defined(CM_EXP_NO_WINDOW_MOVES)
+            if (PALD) {
+#pragma unroll
+                for (int j = 0; j < 10; ++j) asm volatile("" : "+v"(ew[PALD ? j : 0]));
+            }
+#else
             if (PALD) {
 #pragma unroll
                 for (int j = 0; j < 10; ++j) ew[PALD ? j : 0] = ew[PALD ? j + 4 : 0];
             }
+#endif
             lds_float *slot = ring + ((tb >> 2) & 1) * (kMid / 2) + lane * 4;
             if constexpr (LCUT) {
                 // products with the phase-free carriers of the four pairs nd = tb - front_off + s, low-pass on (cos, sin)
