@@ -2704,25 +2704,31 @@ int run_wrap_inner(const cm_plan *inner, const cm_plan *first, Geom g, float *sc
     // samples).  Behind the main pass on one stream that latency is paid per chunk; on a side stream of the device it runs beside the main
     // pass (forked after everything queued on `stream` - the previous chunk's back end still reads this scratch - and joined before the back end).
     hipStream_t side = wrap_side_stream(inner->device);
-    hipEvent_t forked = nullptr, joined = nullptr;
-    if (side && (hipEventCreateWithFlags(&forked, hipEventDisableTiming) != hipSuccess ||
-                 hipEventCreateWithFlags(&joined, hipEventDisableTiming) != hipSuccess)) side = nullptr;
-    int rc = CM_OK;
-    if (side) {
-        HIP_TRY(hipEventRecord(forked, stream), CM_ERR_LAUNCH);
-        HIP_TRY(hipStreamWaitEvent(side, forked, 0), CM_ERR_LAUNCH);
-        rc = run_plan(first, s, none, false, side);
-        if (!rc) HIP_TRY(hipEventRecord(joined, side), CM_ERR_LAUNCH);
-        const int rc_main = run_plan(inner, g, none, false, stream);
-        if (!rc) HIP_TRY(hipStreamWaitEvent(stream, joined, 0), CM_ERR_LAUNCH);
-        if (!rc) rc = rc_main;
-    } else {
-        rc = run_plan(inner, g, none, false, stream);
+    struct EventPair {      // destroyed on every path out (the runtime releases them once the queued record / wait have completed)
+        hipEvent_t forked = nullptr, joined = nullptr;
+        ~EventPair() {
+            if (forked) (void)hipEventDestroy(forked);
+            if (joined) (void)hipEventDestroy(joined);
+        }
+    } ev;
+    if (side && (hipEventCreateWithFlags(&ev.forked, hipEventDisableTiming) != hipSuccess ||
+                 hipEventCreateWithFlags(&ev.joined, hipEventDisableTiming) != hipSuccess)) side = nullptr;
+    if (side && (hipEventRecord(ev.forked, stream) != hipSuccess || hipStreamWaitEvent(side, ev.forked, 0) != hipSuccess)) side = nullptr;   // nothing queued on the side yet
+    if (!side) {
+        int rc = run_plan(inner, g, none, false, stream);
         if (!rc) rc = run_plan(first, s, none, false, stream);
+        return rc;
     }
-    if (forked) (void)hipEventDestroy(forked);      // released by the runtime once the queued record / wait have completed
-    if (joined) (void)hipEventDestroy(joined);
-    return rc;
+    // forked: from here on the main stream must join the side stream on EVERY path, or a later hipFreeAsync of the scratch on `stream`
+    // could overtake the first-line kernel still running beside it
+    const int rc_first = run_plan(first, s, none, false, side);
+    const int rc_main = run_plan(inner, g, none, false, stream);
+    const bool joined = hipEventRecord(ev.joined, side) == hipSuccess && hipStreamWaitEvent(stream, ev.joined, 0) == hipSuccess;
+    if (!joined) {
+        (void)hipStreamSynchronize(side);
+        if (!rc_first && !rc_main) return fail(CM_ERR_LAUNCH, "joining the first-line pass of a wrapped comb failed");
+    }
+    return rc_first ? rc_first : rc_main;
 }
 struct AsyncBuf {
     hipStream_t stream = nullptr;

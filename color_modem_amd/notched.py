@@ -72,10 +72,12 @@ class ShiftedNotchEngine(object):
         self.base.set_small_batch(mode)
         self.encoder.set_small_batch(mode)
 
-    def _finish(self, yuv, groups, rows, skip):
-        """yuv [groups, 3, rows, W] (a torch tensor on the device) -> decode_components(notch(y), u, v) in a new tensor"""
+    def _finish(self, yuv, groups, rows, skip, out=None):
+        """yuv [groups, 3, rows, W] (a torch tensor on the device) -> decode_components(notch(y), u, v) in `out` (a contiguous tensor of the
+        same shape; default: a new one)"""
         import torch
-        out = torch.empty_like(yuv)
+        if out is None:
+            out = torch.empty_like(yuv)
         dp = ctypes.POINTER(ctypes.c_double)
         with torch.cuda.device(yuv.device):
             stream = torch.cuda.current_stream(yuv.device).cuda_stream
@@ -85,19 +87,30 @@ class ShiftedNotchEngine(object):
         return out
 
     # ---- frames --------------------------------------------------------------------------------
+    CHUNK_BYTES = 1 << 30      # component planes held at a time (the notch and matrix pass is per frame: chunks write straight into the result)
+
     def demodulate_frames(self, composite, first_frame=0, out=None):
         import torch
         was_numpy = isinstance(composite, numpy.ndarray)
-        yuv = self.base.demodulate_frames(torch.from_numpy(numpy.ascontiguousarray(composite, dtype=numpy.float32)).cuda() if was_numpy else composite,
-                                          first_frame)
+        comp = torch.from_numpy(numpy.ascontiguousarray(composite, dtype=numpy.float32)) if was_numpy else composite
+        if not torch.is_tensor(comp) or comp.dtype != torch.float32 or comp.dim() != 3 or tuple(comp.shape[1:]) != (self.height, self.comp_width):
+            raise ValueError('composite: expected float32 [n, %d, %d]' % (self.height, self.comp_width))
+        if not comp.is_cuda:
+            comp = comp.cuda()
+        comp = comp.contiguous()
+        n = int(comp.shape[0])
+        shape = (n, 3, self.height, self.width)
+        if out is None:
+            out = torch.empty(shape, dtype=torch.float32, device=comp.device)
+        else:
+            engine._check_out(out, shape, torch.float32, comp.device)
         # image.py:75-83: row r of a field is the result of call r + delay of its run; call 0 is never notched (comb.py:48-49, 97-99)
         skip = 0 if self.demodulation_delay > 0 else min(2, self.height)      # delay 0: rows 0 and 1 of a frame are the two fields' first calls
-        res = self._finish(yuv.contiguous(), yuv.shape[0], self.height, skip)
-        if out is not None:
-            engine._check_out(out, tuple(res.shape), res.dtype, res.device)
-            out.copy_(res)
-            res = out
-        return res.cpu().numpy() if was_numpy else res
+        step = max(1, self.CHUNK_BYTES // (3 * self.height * self.width * 4))
+        for f0 in range(0, n, step):
+            yuv = self.base.demodulate_frames(comp[f0:f0 + step], first_frame + f0)
+            self._finish(yuv.contiguous(), yuv.shape[0], self.height, skip, out=out[f0:f0 + step])
+        return out.cpu().numpy() if was_numpy else out
 
     def demodulate_frames_u8(self, composite8, first_frame=0, out=None):
         raise NotImplementedError('a notch with a non-zero FilterFunction shift runs on float rows (the PIL entry points convert on the host)')

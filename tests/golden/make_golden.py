@@ -536,7 +536,43 @@ def image_cases():
              back8=numpy.frombuffer(back.tobytes(), dtype=numpy.uint8).reshape(H, W, 3), frame=numpy.array(1))
 
 
+def test_picture(width, height):
+    """A deterministic picture with the structure of real ones (and one that compresses): colour bars over a vertical luminance ramp,
+    a zone plate (fine detail at every orientation), a saturated-transition checker, 0.5 % of hash noise; uint8 [H, W, 3]."""
+    x = numpy.arange(width)[None, :] / float(width)
+    y = numpy.arange(height)[:, None] / float(height)
+    bars = numpy.array([[1, 1, 1], [1, 1, 0], [0, 1, 1], [0, 1, 0], [1, 0, 1], [1, 0, 0], [0, 0, 1], [0, 0, 0]], dtype=numpy.float64)
+    rgb = bars[numpy.minimum((x * 8).astype(int), 7)[0]][None, :, :] * (0.25 + 0.75 * (1.0 - y))[:, :, None]
+    cx, cy = x - 0.5, (y - 0.6) * height / float(width)
+    zone = 0.5 + 0.5 * numpy.cos(900.0 * (cx * cx + cy * cy))
+    inside = ((cx * cx + cy * cy) < 0.03)
+    rgb = numpy.where(inside[:, :, None], zone[:, :, None] * numpy.array([1.0, 0.8, 0.6])[None, None, :], rgb * numpy.ones((height, 1, 1)))
+    check = ((numpy.arange(width)[None, :] // 12 + numpy.arange(height)[:, None] // 9) % 2).astype(numpy.float64)
+    band = (y > 0.88) * numpy.ones((1, width))
+    rgb = numpy.where(band[:, :, None] > 0, numpy.stack([check, 1.0 - check, 0.5 * check], axis=2), rgb)
+    rgb = 0.995 * rgb + 0.005 * testing.hash_uniform((height, width, 3), 977)
+    return numpy.uint8(numpy.rint(255.0 * numpy.clip(rgb, 0.0, 1.0)))
+
+
+def full_image_cases():
+    """uint8 through the reference's own ImageModem at FULL height (720x576: PAL-D and SECAM): the byte
+    boundary pinned at a realistic size, both directions."""
+    from PIL import Image
+    for stack, (W, H) in (('pal_d', (720, 576)), ('secam', (720, 576))):
+        rgb8 = test_picture(W, H)
+        img = Image.frombytes('RGB', (W, H), rgb8.tobytes())
+        lc = line_config(stack, (W, H))
+        im = image.ImageModem(STACKS[stack](lc))
+        comp_img = im.modulate(img, 2)
+        back = im.demodulate(comp_img, 2)
+        save('imagefull_' + stack, rgb8=rgb8, comp8=numpy.frombuffer(comp_img.tobytes(), dtype=numpy.uint8).reshape(H, W),
+             back8=numpy.frombuffer(back.tobytes(), dtype=numpy.uint8).reshape(H, W, 3), frame=numpy.array(2))
+
+
 if __name__ == '__main__':
+    if sys.argv[1:2] == ['full_images']:
+        full_image_cases()
+        sys.exit(0)
     if sys.argv[1:2] == ['options']:     # only the option / variant cases (the rest is unchanged), optionally some
         option_cases(sys.argv[2:])
         sys.exit(0)
@@ -569,3 +605,4 @@ if __name__ == '__main__':
     degenerate_cases()
     row_cases()
     image_cases()
+    full_image_cases()

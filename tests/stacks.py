@@ -83,6 +83,10 @@ def damped_avg(last, curr):      # non-linear and continuous (a discontinuous pi
     return 0.5 * (last + curr) / (1.0 + 4.0 * abs(last - curr))
 
 
+def numpy_damped_avg(last, curr):     # written against numpy ufuncs, like the reference's own minavg (comb.py:13-15): cannot take device tensors
+    return 0.5 * (last + curr) * numpy.exp(-2.0 * numpy.abs(last - curr))
+
+
 # notch= values whose FilterFunction shift is not 0 (comb.py:18-20 over utils.py:9-26): +1 at q = 1.0, +7 at q = 0.7 (PAL at 13.5 MHz; the values with a negative shift are unstable filters: the reference's own output overflows)
 STACKS.update({
     'pal_d_notchq1': lambda lc: pal.PalDModem(lc, notch=1.0),

@@ -16,6 +16,7 @@ FRAME_DEMOD = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(st
 FRAME_MOD = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(stacks.GOLDEN, 'frames_mod_*.npz')))
 ROWS = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(stacks.GOLDEN, 'rows_demod_*.npz')))
 IMAGES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(stacks.GOLDEN, 'image_*.npz')))
+IMAGES += sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(stacks.GOLDEN, 'imagefull_*.npz')))    # full-height pictures (round 5)
 
 
 def stack_of(name, prefix):
@@ -57,7 +58,7 @@ def test_rows_demod(name):
 def test_image_uint8(name):
     g = stacks.load(name)
     h, w = g['comp8'].shape
-    modem = stacks.make(name[len('image_'):], (w, h))
+    modem = stacks.make(name.split('_', 1)[1], (w, h))
     orc = cm_oracle.OracleModem(modem)
     comp8 = orc.image_modulate(int(g['frame']), g['rgb8'])
     # the byte rounding sits on a knife edge for a handful of samples; allow no more than 1 LSB
