@@ -205,6 +205,9 @@ def make_engine(modem, components=False, strip_chroma=True, min_lines=0):
     from color_modem_amd import notched
     if notched.shifted_notch(stack, strip_chroma) is not None:      # notch= values whose FilterFunction shift is not 0: the notch as a pass of its own
         return notched.ShiftedNotchEngine(modem, components, strip_chroma, min_lines)
+    from color_modem_amd import pal3d_callable
+    if pal3d_callable.custom_avg(stack) is not None:      # Pal3DModem(avg=f): its two estimates from two plans, f applied in between
+        return pal3d_callable.Pal3DCallableEngine(modem, components, strip_chroma, min_lines)
     if stack.get('demod_wrapper') and (kind in ('pal_d', 'pal_3d') or (kind in ('pal_s', 'ntsc', 'ntsc_comb') and _custom_avg(stack) and not stack.get('mod_wrapper'))):
         from color_modem_amd import wrapped
         return wrapped.WrappedCombEngine(modem, components, strip_chroma, min_lines)

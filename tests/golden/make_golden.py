@@ -275,6 +275,9 @@ STACKS.update({
     'simple_pal3d_favg': lambda lc: comb.SimpleCombModem(pal.Pal3DModem(lc), avg=damped_avg, notch=4.0),
     'simple_ntsc_favg': lambda lc: comb.SimpleCombModem(ntsc.NtscModem(lc), avg=damped_avg),
     'simple3d_ntsccomb_favg': lambda lc: comb.Simple3DCombModem(ntsc.NtscCombModem(lc), avg=weighted_avg),
+    # Pal3DModem's OWN average of its two estimates (pal.py:144-148, 176-179, 209-211) as a callable
+    'pal_3d_favg': lambda lc: pal.Pal3DModem(lc, avg=damped_avg, notch=4.0),
+    'pal_3d_wavg': lambda lc: pal.Pal3DModem(lc, avg=weighted_avg),
 })
 STANDARD = {'pal': 'GERBER_625', 'ntsc': 'NTSC_525', 'secam': 'GERBER_625', 'simple3d': 'GERBER_625', 'simple': 'GERBER_625'}
 STANDARD_OF = {'pal_d_palm': 'NTSC_525', 'pal_s_palm': 'NTSC_525', 'pal_d_60': 'NTSC_525', 'pal_s_60': 'NTSC_525',
@@ -445,10 +448,13 @@ def wrapper_cases(only=()):
         save('frames_demod_' + stack, inp=comp, out=out, frames=numpy.array(frames), size=numpy.array([W, H]))
 
 
-def callable_cases():
+def callable_cases(only=()):
     """SimpleCombModem / Simple3DCombModem with an avg= callable of the caller's own (comb.py:72, 81-84, 103-104)."""
     W, H = 720, 10
-    for stack, frames in (('simple3d_pald_favg', [1, 2]), ('simple_pal3d_favg', [0, 3]), ('simple_ntsc_favg', [1, 2]), ('simple3d_ntsccomb_favg', [0, 1])):
+    for stack, frames in (('simple3d_pald_favg', [1, 2]), ('simple_pal3d_favg', [0, 3]), ('simple_ntsc_favg', [1, 2]), ('simple3d_ntsccomb_favg', [0, 1]),
+                          ('pal_3d_favg', [0, 3]), ('pal_3d_wavg', [1, 2])):
+        if only and stack not in only:
+            continue
         lc = line_config(stack, (W, H))
         enc = STACKS['ntsc' if 'ntsc' in stack else 'pal_s'](lc)
         rgb = testing.synthetic_rgb(len(frames), H, W, seed=654)
@@ -592,7 +598,7 @@ if __name__ == '__main__':
         notch_shift_cases()
         sys.exit(0)
     if sys.argv[1:2] == ['callables']:
-        callable_cases()
+        callable_cases(sys.argv[2:])
         sys.exit(0)
     make_plans()
     frame_cases()

@@ -99,6 +99,9 @@ STACKS.update({
     'simple_pal3d_favg': lambda lc: comb.SimpleCombModem(pal.Pal3DModem(lc), avg=damped_avg, notch=4.0),
     'simple_ntsc_favg': lambda lc: comb.SimpleCombModem(ntsc.NtscModem(lc), avg=damped_avg),
     'simple3d_ntsccomb_favg': lambda lc: comb.Simple3DCombModem(ntsc.NtscCombModem(lc), avg=weighted_avg),
+    # Pal3DModem's own average of its two estimates as a callable (pal.py:144-148, 209-211)
+    'pal_3d_favg': lambda lc: pal.Pal3DModem(lc, avg=damped_avg, notch=4.0),
+    'pal_3d_wavg': lambda lc: pal.Pal3DModem(lc, avg=weighted_avg),
 })
 STANDARD = {'pal': 'GERBER_625', 'ntsc': 'NTSC_525', 'secam': 'GERBER_625', 'simple3d': 'GERBER_625', 'simple': 'GERBER_625'}
 STANDARD_OF = {'pal_d_palm': 'NTSC_525', 'pal_s_palm': 'NTSC_525', 'pal_d_60': 'NTSC_525', 'pal_s_60': 'NTSC_525',

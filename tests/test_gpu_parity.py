@@ -201,6 +201,26 @@ def test_image_uint8_golden(name):
     _flip_report(name, 'demodulate, oracle vs reference', numpy.abs(o_back.astype(int) - g['back8'].astype(int)))
 
 
+@pytest.mark.parametrize('stack,size', [('pal_d', (720, 32)), ('ntsc_comb_3d', (720, 24)), ('secam', (720, 32)), ('simple3d_pal3d', (720, 16)),
+                                        ('pal_3d_notchq07', (720, 16))])
+def test_batch_invariant_option(stack, size):
+    """ImageModem(modem, batch_invariant=True): a frame's result does not depend on the batch it arrives in, bit for bit:
+    one batch of 40 frames against the same frames one by one and in uneven groups."""
+    import torch
+    from oracle import cm_oracle
+    w, h = size
+    enc = 'ntsc' if 'ntsc' in stack else ('secam' if 'secam' in stack else 'pal_s')
+    rgb = testing.synthetic_rgb(4, h, w, seed=90 + h)
+    comp4 = cm_oracle.modulate_frames_f32(stacks.make(enc, size), rgb, first_frame=0, n_threads=4)
+    comp = torch.from_numpy(comp4).cuda().repeat(10, 1, 1).contiguous()
+    im = image.ImageModem(stacks.make(stack, size), batch_invariant=True)
+    whole = im.demodulate_frames(comp, first_frame=3)
+    for lo, hi in ((0, 1), (1, 2), (2, 9), (9, 40), (17, 18)):
+        part = im.demodulate_frames(comp[lo:hi].contiguous(), first_frame=3 + lo)
+        assert torch.equal(part, whole[lo:hi]), (stack, lo, hi)
+    assert stacks.rel_err(whole[0].cpu().numpy(), cm_oracle.demodulate_frames_f32(stacks.make(stack, size), comp4[:1], first_frame=3, n_threads=4)[0]) < TOL
+
+
 # ---- size-independent properties at the benchmark's frame size ------------------------------------------
 def test_full_size_properties_pal_d():
     import torch
@@ -1092,7 +1112,9 @@ def test_wrapped_pal_comb_fused_variants(variant, std, size, frames):
 
 
 @pytest.mark.parametrize('stack,size', [('simple3d_pald_favg', (720, 24)), ('simple_pal3d_favg', (720, 13)), ('simple_ntsc_favg', (720, 20)),
-                                        ('simple3d_ntsccomb_favg', (720, 480))])
+                                        ('simple3d_ntsccomb_favg', (720, 480)),
+                                        # round 5: Pal3DModem's OWN average as a callable (pal.py:144-148, 209-211; color_modem_amd/pal3d_callable.py)
+                                        ('pal_3d_favg', (720, 24)), ('pal_3d_wavg', (720, 576))])
 def test_comb_wrappers_with_avg_callables(stack, size):
     """SimpleCombModem(avg=f) with a function of the caller's own (ref comb.py:72, 81-84, 103-104): the composition cut in two, f applied
     to the component planes on the device in between (wrapped.py).  Frames in a batch, the per-row protocol with a break in the run, rows in
