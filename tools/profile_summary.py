@@ -36,6 +36,12 @@ if timed:
 for r in rows('kt', '*kernel_stats.csv'):
     print('  stats: %-90s calls %s avg %.4f ms  %s %%' % (r['Name'][:90], r['Calls'], float(r['AverageNs']) / 1e6, r['Percentage']))
 
+if os.path.isdir(os.path.join(out, 'kt_all')):      # the driver's default command: headline + other_configs (BASELINE configs 3 / 4)
+    print('kernel stats of the default run (python3 bench.py --gpus 1 --steps 20 --warmup 5: the headline and other_configs):')
+    for r in rows('kt_all', '*kernel_stats.csv'):
+        if float(r['Percentage']) >= 0.5:
+            print('  stats: %-90s calls %s avg %.4f ms  %s %%' % (r['Name'][:90], r['Calls'], float(r['AverageNs']) / 1e6, r['Percentage']))
+
 # ---- counters: mean over the last STEPS dispatches of the demodulator in each pass
 m = {}
 for sub in ('m1', 'm2', 's1', 's2'):
