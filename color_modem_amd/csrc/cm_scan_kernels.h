@@ -1149,11 +1149,7 @@ __global__ __launch_bounds__(64 * NW) void secam_mod_scan_kernel(const Geom g, c
     for (int i = 0; i < C1; ++i) {
         double f = fmaf_(fg, x[i], lk.fsc);                                   // secam.py:266 / 271
         f = f < k.f_min ? k.f_min : (f > k.f_max ? k.f_max : f);               // secam.py:272
-        const float ff = (float)f;
-        const float F = (float)(f - k.f0) * (ff + f0) / (ff * f0);
-        const float den = 1.f + k.kd * k.kd * F * F;
-        re[i] = k.m0 * (1.f + k.kn * k.kd * F * F) / den;
-        im[i] = k.m0 * F * (k.kn - k.kd) / den;
+        secam_bell_gain<float>((float)(f - k.f0), (float)f, f0, k.m0, k.kn, k.kd, re[i], im[i]);      // (cm_stages.h: the streaming encoder's)
         ph[i] = k.pi * f;
         if (n0 + i == 0) ph[i] = (double)lk.start_phase - (double)atan2f(im[i], re[i]);   // secam.py:244
     }
@@ -1182,7 +1178,7 @@ __global__ __launch_bounds__(64 * NW) void secam_mod_scan_kernel(const Geom g, c
             const int i = 4 * q + e;
             const double acc = ph[i] - k.two_pi * __builtin_floor(ph[i] * inv_two_pi);   // the running sum wrapped to [0, 2 pi)
             float sn, cs;
-            sincosf((float)acc, &sn, &cs);
+            sincos_((float)acc, sn, cs);                                                  // (cm_stages.h: the streaming encoder's)
             o[e] = y[i] + (re[i] * cs - im[i] * sn);                                      // secam.py:246, 276
         }
         if (n0 + 4 * q < g.Wp) scan_store4<U8>(op, n0 + 4 * q, o);

@@ -907,11 +907,55 @@ struct SecamModLaneK {
 };
 
 #if defined(__HIP_DEVICE_COMPILE__)
-__device__ __forceinline__ void sincos_(float x, float &s, float &c) { sincosf(x, &s, &c); }
+// sin / cos of the SECAM encoder's running phase (round 5).  The phase is kept wrapped to [0, 2 pi) in float64, so the library sincosf's
+// argument reduction for arbitrary floats - ~120 integer instructions per pixel, more than half of the encoder's instruction stream - is dead
+// weight: one rounding to the nearest quarter turn, a two-term Cody-Waite subtraction, the two cephes minimax polynomials of |y| <= pi / 4
+// (1 ulp each) and the quadrant's swap / signs.  Valid for |x| <= 8; within 1 - 2 ulp of sincosf there.
+__device__ __forceinline__ void sincos_(float x, float &s, float &c) {
+    const float k = __builtin_rintf(x * 0.636619772367581343f);               // quarter turns
+    float y = __builtin_fmaf(-k, 1.5707963705062866f, x);                     // pi / 2 = hi + lo
+    y = __builtin_fmaf(-k, -4.371139000186243e-8f, y);
+    const float z = y * y;
+    float ps = __builtin_fmaf(z, -1.9515295891e-4f, 8.3321608736e-3f);
+    ps = __builtin_fmaf(z, ps, -1.6666654611e-1f);
+    const float sy = __builtin_fmaf(y * z, ps, y);
+    float pc = __builtin_fmaf(z, 2.443315711809948e-5f, -1.388731625493765e-3f);
+    pc = __builtin_fmaf(z, pc, 4.166664568298827e-2f);
+    const float cy = __builtin_fmaf(z * z, pc, __builtin_fmaf(-0.5f, z, 1.0f));
+    const unsigned q = (unsigned)(int)k;
+    const bool swap = (q & 1u) != 0u;
+    const float s0 = swap ? cy : sy, c0 = swap ? sy : cy;
+    s = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, s0) ^ ((q & 2u) << 30));           // quadrants 2, 3: sin < 0
+    c = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, c0) ^ (((q + 1u) & 2u) << 30));     // quadrants 1, 2: cos < 0
+}
 #else
-inline void sincos_(float x, float &s, float &c) { s = std::sin(x); c = std::cos(x); }
+CM_HD void sincos_(float x, float &s, float &c) { s = std::sin(x); c = std::cos(x); }      // (host pass / the stage simulator)
 #endif
 CM_HD void sincos_(double x, double &s, double &c) { s = std::sin(x); c = std::cos(x); }
+
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ double clamp_(double x, double lo, double hi) { return __builtin_fmin(__builtin_fmax(x, lo), hi); }
+__device__ __forceinline__ float clamp_(float x, float lo, float hi) { return __builtin_fminf(__builtin_fmaxf(x, lo), hi); }
+#else
+template <typename T> CM_HD T clamp_(T x, T lo, T hi) { return x < lo ? lo : (x > hi ? hi : x); }
+#endif
+// bell pre-emphasis G = m0 (1 + j kn F) / (1 + j kd F), F = f / f0 - f0 / f (secam.py:241-243) as (re, im); df = f - f0 (formed in the
+// wide type by the caller), ff = f.  Round 5: the two quotients through reciprocals - on the device v_rcp_f32 (1 ulp) instead of three
+// IEEE divisions (~10 instructions each); one definition for the streaming and the scan encoder, so that they stay bit-identical.
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ float recip_(float x) { return __builtin_amdgcn_rcpf(x); }
+#else
+CM_HD float recip_(float x) { return 1.0f / x; }
+#endif
+CM_HD double recip_(double x) { return 1.0 / x; }
+template <typename T>
+CM_HD void secam_bell_gain(T df, T ff, T f0, T m0, T kn, T kd, T &re, T &im) {
+    const T F = df * (ff + f0) * recip_(ff * f0);
+    const T F2 = F * F;
+    const T rden = recip_(T(1) + kd * kd * F2);
+    re = m0 * (T(1) + kn * kd * F2) * rden;
+    im = m0 * F * (kn - kd) * rden;
+}
 
 template <typename T, typename TD>
 struct SecamMod {
@@ -939,20 +983,17 @@ struct SecamMod {
         if (EDGE && (n7 < 0 || n7 >= W)) return T(0);
         TD x = iir_gen<false>(lf_pre, k.lf_pre, w);
         TD f = fmaf_(lk.fdev * k.gain, x, lk.fsc);                    // secam.py:266 / 271
-        f = f < k.f_min ? k.f_min : (f > k.f_max ? k.f_max : f);      // secam.py:272
+        f = clamp_(f, k.f_min, k.f_max);                              // secam.py:272 (v_max_f64 + v_min_f64: two instructions, not six)
         // bell pre-emphasis G = m0 (1 + j kn F) / (1 + j kd F), F = f / f0 - f0 / f (secam.py:241-243)
-        T ff = T(f), f0 = T(k.f0);
-        T F = T(f - k.f0) * (ff + f0) / (ff * f0);
-        T den = T(1) + k.kd * k.kd * F * F;
-        T re = k.m0 * (T(1) + k.kn * k.kd * F * F) / den;
-        T im = k.m0 * F * (k.kn - k.kd) / den;
+        T re, im;
+        secam_bell_gain<T>(T(f - k.f0), T(f), T(k.f0), k.m0, k.kn, k.kd, re, im);
         if (EDGE && n7 == 0) {
             acc = TD(lk.start_phase) - TD(atan2_(im, re));             // secam.py:244: start - pi f[0] - arg G[0] + pi f[0]
         } else {
             acc += k.pi * f;                                          // cumsum(pi f)
         }
         if (acc >= k.two_pi) acc -= k.two_pi;
-        if (acc < TD(0)) acc += k.two_pi;
+        if (EDGE && acc < TD(0)) acc += k.two_pi;                      // (only the start phase of secam.py:244 can be negative: pi f > 0 afterwards)
         T sn, cs;
         sincos_(T(acc), sn, cs);
         return luma_d + (re * cs - im * sn);                           // secam.py:246, 276
