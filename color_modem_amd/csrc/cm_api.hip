@@ -303,7 +303,7 @@ bool make_pass(const cm_plan_desc &d, bool pald, bool bsf, const cm_lane_table &
         const bool lcut = CM_QAM_LPF_IN_A != 0 && !pald && !bsf && depth >= 2 && !S::RT;     // PassCfg::kLcutCfg
         const int ring_max = pald ? luma_delay_max_latency<S, 1>()
                            : (lcut ? (wrap ? luma_delay_max_latency<S, 0, true, 1>() : luma_delay_max_latency<S, 0, true>()) : luma_delay_max_latency<S, 0>());
-        if (wrap && !lcut) { err = "the two-level comb is built on the depth-2 QAM instances of the tuned shapes"; return false; }
+        if (wrap && !lcut && !S::RT) { err = "the two-level comb is built on the depth-2 QAM instances"; return false; }
         const int ring_win = pald ? ring_window<S, 1>() : (lcut ? ring_window<S, 0, true>() : ring_window<S, 0>());
         if (CM_LUMA_RING && !bsf && pair && lat_out > ring_max) { err = "pipeline latency beyond the luma delay ring"; return false; }
         if (CM_LUMA_RING && !bsf && pair && lat_out < 10 + ring_win) { err = "pipeline latency below the luma window"; return false; }
@@ -514,8 +514,15 @@ bool select_any(cm_plan *p, const cm_plan_desc &d, std::string &err) {
     p->fn = nullptr;
     p->fn_u8 = nullptr;
     std::string what;
-    if (d.demod_main.wrap_mode) { err = "the two-level comb (wrap_mode) is built for the tuned shapes (the run-time shape: the composition)"; return false; }
-    if (pald && depth == 2 && !first) {
+    if (d.demod_main.wrap_mode) {
+        // the two-level comb around Pal3DModem (select_for_shape) at the other sampling rates: comb.avg / comb.minavg of the wrapper over Pal3DModem's
+        // plain average - its own minavg and the notch stay on the composition there, like the fused plans around PalDModem
+        if (pald || bsf || first || depth != 3 || d.skip_calls) { err = "a two-level comb (wrap_mode) takes the QAM pipeline, depth 3, no plain first line"; return false; }
+        if (minavg || notch) { err = "the run-time shape runs the two-level comb without the inner minavg / the notch (those: the composition)"; return false; }
+        p->fn = launch_demod<PassCfg<S, FRONT_QAM, false, 2, 16, false, false, false, true>, NoPass>;
+        p->fn_u8 = launch_demod<PassCfg<S, FRONT_QAM, false, 2, 16, true, false, false, true>, NoPass>;
+        p->main.depth = 3; what = std::string("qam front, depth 2 | ") + (d.demod_main.wrap_mode == 2 ? "minavg" : "avg") + " of consecutive calls (two-level comb)";
+    } else if (pald && depth == 2 && !first) {
         // the fused wrapped combs (select_for_shape) at the other sampling rates: the comb.avg form only - minavg / notch stay on the composition
         if (d.skip_calls != 2) { err = "the PAL-D front end with two lines of history serves the fused wrapped combs (skip_calls = 2)"; return false; }
         if (minavg || notch) { err = "the run-time shape fuses the plain average only (minavg / notch: the composition)"; return false; }

@@ -1042,7 +1042,8 @@ def test_wrapped_pal_comb_vs_oracle(stack, size, first):
                                                # round 5: around Pal3DModem long batches run as a two-level comb in one launch (cm_lane_table::wrap_mode)
                                                ('simple3d_pal3d', (720, 16), 1700), ('simple_pal3d_notch', (720, 21), 1300),
                                                ('simple3d_pal3d', (720, 576), 45), ('simple3d_pal3d_minavg2', (720, 12), 2100),
-                                               ('simple_pal3d_sin', (720, 10), 2500)])
+                                               ('simple_pal3d_sin', (720, 10), 2500),
+                                               ('simple3d_pal3d', (768, 16), 1700), ('simple3d_pal3d', (1280, 10), 2500)])      # ... on the run-time filter shape
 def test_wrapped_pal_comb_fused_long_batches(stack, size, frames):
     """Long batches around PalDModem run the fused plan (PAL-D front end, two lines of history: every call k >= 2 of a run in one
     pass over the frames) plus the composition on the top four rows (cm_comb_wrap_demodulate_frames_fused).  Against the float64
