@@ -2,7 +2,8 @@ import sys, time, torch, numpy
 sys.path.insert(0,'.'); sys.path.insert(0,'tests')
 import stacks
 from color_modem_amd import image, testing
-for name, size in (('simple3d_pald',(768,576)), ('simple3d_pald',(1280,576)), ('simple3d_pald',(1920,576))):
+NAMES = sys.argv[1:] or ['simple3d_pald']
+for name, size in [(n, sz) for n in NAMES for sz in ((768,576), (1280,576), (1920,576))]:
     F = 1000 if size[0] < 1000 else 400
     m = stacks.make(name, size)
     eng = image.ImageModem(m)._engine()
