@@ -1271,7 +1271,10 @@ def test_hip_graph_capture():
             with pytest.raises(NotImplementedError):
                 weng.demodulate_frames(comp, 1, out=out)
         finally:
-            g2.capture_end()
+            import warnings
+            with warnings.catch_warnings():      # the refused call queued nothing: torch says so ("The CUDA Graph is empty") - expected here
+                warnings.simplefilter('ignore', UserWarning)
+                g2.capture_end()
     torch.cuda.synchronize()
     assert torch.equal(weng.demodulate_frames(comp, 1), wwant)
 
