@@ -438,8 +438,12 @@ def main():
         if world == 1 and args.other_configs:
             del comp, out
             torch.cuda.empty_cache()
-            res['other_configs'] = other_configs(torch, device, frames)
-            worst = max([worst] + [c['check']['max_rel_err'] for c in res['other_configs']])
+            try:
+                res['other_configs'] = other_configs(torch, device, frames)
+                worst = max([worst] + [c['check']['max_rel_err'] for c in res['other_configs']])
+            except Exception as e:      # the headline line must not be lost to a failure in the additional configurations: say so instead
+                res['other_configs'] = []
+                res['other_configs_error'] = '%s: %s' % (type(e).__name__, e)
         print(json.dumps(res))
         if worst > 1e-5:
             sys.stdout.flush()
