@@ -568,7 +568,7 @@ class AmEngine(_EngineBase):
         if self.width % 16:
             raise NotImplementedError('the fused uint8 boundary of the encoders needs a width that is a multiple of 16')
         if self.noise_level != 0.0:
-            raise NotImplementedError('the noisy NIIR encoder has no byte form: the PIL entry points convert on the host')
+            raise NotImplementedError('the noisy NIIR encoder has no byte form: ImageModem converts on the device around the float path')
         t, was_numpy = self._stage(rgb8, torch.uint8, (self.height, self.width, 3), 'rgb8')
         n = t.shape[0]
         if self.height < 2 * self.modulation_delay and n:

@@ -50,16 +50,51 @@ class ImageModem(object):
         return self._engine().demodulate_frames(composite, first_frame)
 
     def demodulate_frames_u8(self, composite8, first_frame=0):
-        """composite uint8 [F, H, W] -> rgb uint8 [F, H, W, 3], the byte conversions of ImageModem fused into the kernel."""
-        return self._engine().demodulate_frames_u8(composite8, first_frame)
+        """composite uint8 [F, H, W] -> rgb uint8 [F, H, W, 3], the byte conversions of ImageModem fused into the kernel; for the stacks
+        without a fused byte boundary (notches with a FilterFunction shift, avg= callables, widths that are not a multiple of 4) the same
+        conversions run on the device around the float path (round 5: no host detour, identical bytes to the host-side formulas)."""
+        try:
+            return self._engine().demodulate_frames_u8(composite8, first_frame)
+        except NotImplementedError:
+            return self._bytes_around_float(composite8, first_frame, demod=True)
 
     def modulate_frames(self, rgb, first_frame=0):
         """rgb [F, 3, H, W] float32 -> composite [F, H, W] float32."""
         return self._engine().modulate_frames(rgb, first_frame)
 
     def modulate_frames_u8(self, rgb8, first_frame=0):
-        """rgb uint8 [F, H, W, 3] -> composite uint8 [F, H, W], the byte conversions of ImageModem fused into the kernel."""
-        return self._engine().modulate_frames_u8(rgb8, first_frame)
+        """rgb uint8 [F, H, W, 3] -> composite uint8 [F, H, W], the byte conversions of ImageModem fused into the kernel (widths that are not
+        a multiple of 16, the noisy NIIR encoder: the same conversions on the device around the float path)."""
+        try:
+            return self._engine().modulate_frames_u8(rgb8, first_frame)
+        except NotImplementedError:
+            return self._bytes_around_float(rgb8, first_frame, demod=False)
+
+    def _bytes_around_float(self, x8, first_frame, demod):
+        """image.py:24-25, 47-55, 62, 75-83 as torch operations on the device, in float64 like the reference's numpy (so that every byte
+        equals what the host-side formulas give), around the float entry points; frames in chunks."""
+        import torch
+        was_numpy = isinstance(x8, numpy.ndarray)
+        t = torch.from_numpy(numpy.ascontiguousarray(x8, dtype=numpy.uint8)) if was_numpy else x8
+        if not torch.is_tensor(t) or t.dtype != torch.uint8 or t.dim() != (3 if demod else 4):
+            raise ValueError('expected uint8 %s' % ('[n, H, W]' if demod else '[n, H, W, 3]'))
+        if not t.is_cuda:
+            t = t.cuda()
+        n, h, w = int(t.shape[0]), int(t.shape[1]), int(t.shape[2])
+        out = torch.empty((n, h, w, 3) if demod else (n, h, w), dtype=torch.uint8, device=t.device)
+        step = max(1, (1 << 28) // max(1, h * w * 3 * 8))
+        eng = self._engine()
+        for f0 in range(0, n, step):
+            part = t[f0:f0 + step]
+            if demod:
+                comp = self.decode_composite_level(part.double() / 255.0).float().contiguous()
+                rgb = eng.demodulate_frames(comp, first_frame + f0)
+                out[f0:f0 + step] = torch.round(255.0 * rgb.double().clamp(0.0, 1.0)).to(torch.uint8).permute(0, 2, 3, 1)
+            else:
+                rgb = (part.double() / 255.0).float().permute(0, 3, 1, 2).contiguous()
+                comp = eng.modulate_frames(rgb, first_frame + f0)
+                out[f0:f0 + step] = torch.round(255.0 * self.encode_composite_level(comp.double()).clamp(0.0, 1.0)).to(torch.uint8)
+        return out.cpu().numpy() if was_numpy else out
 
     # ---- PIL API (one image = one frame) ---------------------------------------------------------
     def modulate(self, img, frame=0):
@@ -67,27 +102,15 @@ class ImageModem(object):
         if img.mode != 'RGB':
             img = img.convert('RGB')
         rgb8 = numpy.frombuffer(img.tobytes(), dtype=numpy.uint8).reshape(img.height, img.width, 3)
-        try:  # byte boundary fused into the kernel (widths that are multiples of 16)
-            comp8 = self._engine().modulate_frames_u8(rgb8[None].copy(), frame)[0]
-            return Image.frombytes('L', (comp8.shape[1], comp8.shape[0]), numpy.ascontiguousarray(comp8).tobytes())
-        except NotImplementedError:
-            pass
-        rgb = (rgb8.astype(numpy.float64) / 255.0).astype(numpy.float32).transpose(2, 0, 1)[None]
-        comp = self.modulate_frames(numpy.ascontiguousarray(rgb), frame)[0]
-        data = _as_bytes(self.encode_composite_level(comp.astype(numpy.float64)))
-        return Image.frombytes('L', (comp.shape[1], comp.shape[0]), data.tobytes())
+        # the byte boundary fused into the kernel (widths that are multiples of 16), else the same conversions on the device around the float path
+        comp8 = self.modulate_frames_u8(rgb8[None].copy(), frame)[0]
+        return Image.frombytes('L', (comp8.shape[1], comp8.shape[0]), numpy.ascontiguousarray(comp8).tobytes())
 
     def demodulate(self, img, frame=0):
         from PIL import Image
         if img.mode != 'L':
             img = img.convert('L')
         comp8 = numpy.frombuffer(img.tobytes(), dtype=numpy.uint8).reshape(img.height, img.width).copy()
-        try:  # byte boundary fused into the kernel (widths that are multiples of 4; every stack has an instance since round 3)
-            rgb8 = self._engine().demodulate_frames_u8(comp8[None], frame)[0]
-            return Image.frombytes('RGB', (rgb8.shape[1], rgb8.shape[0]), numpy.ascontiguousarray(rgb8).tobytes())
-        except NotImplementedError:
-            pass
-        comp = self.decode_composite_level(comp8.astype(numpy.float64) / 255.0).astype(numpy.float32)[None]
-        rgb = self.demodulate_frames(numpy.ascontiguousarray(comp), frame)[0]
-        data = _as_bytes(rgb.astype(numpy.float64)).transpose(1, 2, 0)
-        return Image.frombytes('RGB', (rgb.shape[2], rgb.shape[1]), numpy.ascontiguousarray(data).tobytes())
+        # the byte boundary fused into the kernel (widths that are multiples of 4), else the same conversions on the device around the float path
+        rgb8 = self.demodulate_frames_u8(comp8[None], frame)[0]
+        return Image.frombytes('RGB', (rgb8.shape[1], rgb8.shape[0]), numpy.ascontiguousarray(rgb8).tobytes())

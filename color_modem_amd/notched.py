@@ -113,7 +113,7 @@ class ShiftedNotchEngine(object):
         return out.cpu().numpy() if was_numpy else out
 
     def demodulate_frames_u8(self, composite8, first_frame=0, out=None):
-        raise NotImplementedError('a notch with a non-zero FilterFunction shift runs on float rows (the PIL entry points convert on the host)')
+        raise NotImplementedError('a notch with a non-zero FilterFunction shift runs on float rows (ImageModem converts on the device around them)')
 
     def modulate_frames(self, rgb, first_frame=0, out=None):
         return self.encoder.modulate_frames(rgb, first_frame, out=out)

@@ -163,7 +163,7 @@ class Pal3DCallableEngine(object):
         return out.cpu().numpy() if was_numpy else out
 
     def demodulate_frames_u8(self, composite8, first_frame=0, out=None):
-        raise NotImplementedError('Pal3DModem(avg=f) runs on float rows (the PIL entry points convert on the host)')
+        raise NotImplementedError('Pal3DModem(avg=f) runs on float rows (ImageModem converts on the device around them)')
 
     def modulate_frames(self, rgb, first_frame=0, out=None):
         return self.encoder.modulate_frames(rgb, first_frame, out=out)

@@ -193,7 +193,7 @@ class QamTables(object):
         # SimpleCombModem / Simple3DCombModem around Pal3DModem as a TWO-LEVEL comb (round 5): the lane tables are Pal3DModem's own
         # (components, strip_chroma=False - what the wrapper asks its backend for), and the kernel averages that result with the one the
         # neighbouring lane (the previous call) formed the same way - comb.py:103-104 as written - before it strips and notches at the
-        # wrapper's line.  One more lane of halo, no fourth line in the tables.  (cm_lane_table::reserved = wrap_mode)
+        # wrapper's line.  One more lane of halo, no fourth line in the tables.  (cm_lane_table::wrap_mode)
         self.two_level = bool(stack.get('two_level'))
         self.wrap_mode = 0
         b = self.backend

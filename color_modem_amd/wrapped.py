@@ -250,7 +250,7 @@ class WrappedCombEngine(object):
             engine._check_out(out, shape, dtype, comp.device)
         if self.custom_avg is not None:
             if dtype != torch.float32:
-                raise NotImplementedError('avg= callables run on float rows (the PIL entry points convert on the host)')
+                raise NotImplementedError('avg= callables run on float rows (ImageModem converts on the device around them)')
             self._frames_custom(comp, out, first_frame)
         else:
             self._call(fn, comp, out, int(comp.shape[0]), int(first_frame), fused=True)

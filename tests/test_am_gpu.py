@@ -439,17 +439,27 @@ def test_niir_bytes_on_grey_pictures(stack):
 
 
 def test_fused_uint8_am_limits():
-    """widths the byte tiles do not cover and the noisy encoder raise; the PIL entry points then convert on the host."""
+    """widths the byte tiles do not cover and the noisy encoder: the engines raise, ImageModem runs the conversions on the device around the float path."""
     from PIL import Image
+    from color_modem_amd.image import _as_bytes
     im = image.ImageModem(_am_modem('proto', (712, 8), 'FRENCH_819'))
     with pytest.raises(NotImplementedError):
-        im.modulate_frames_u8(numpy.zeros((1, 8, 712, 3), numpy.uint8))
+        im._engine().modulate_frames_u8(numpy.zeros((1, 8, 712, 3), numpy.uint8))
+    rgb8 = numpy.random.default_rng(5).integers(0, 256, (1, 8, 712, 3), dtype=numpy.uint8)
+    rgb = numpy.ascontiguousarray((rgb8.astype(numpy.float64) / 255.0).astype(numpy.float32).transpose(0, 3, 1, 2))
+    want = _as_bytes(image.ImageModem.encode_composite_level(im.modulate_frames(rgb, 0).astype(numpy.float64)))
+    assert numpy.array_equal(im.modulate_frames_u8(rgb8), want)
     assert im.demodulate_frames_u8(numpy.zeros((1, 8, 712), numpy.uint8)).shape == (1, 8, 712, 3)
-    assert im.modulate(Image.frombytes('RGB', (712, 8), bytes(712 * 8 * 3)), 0).size == (712, 8)
+    assert im.modulate(Image.frombytes('RGB', (712, 8), rgb8[0].tobytes()), 0).tobytes() == want[0].tobytes()
     noisy = image.ImageModem(_am_modem('niir_noise', (720, 8), 'GERBER_625'))
     with pytest.raises(NotImplementedError):
-        noisy.modulate_frames_u8(numpy.zeros((1, 8, 720, 3), numpy.uint8))
+        noisy._engine().modulate_frames_u8(numpy.zeros((1, 8, 720, 3), numpy.uint8))
+    assert noisy.modulate_frames_u8(numpy.zeros((1, 8, 720, 3), numpy.uint8)).shape == (1, 8, 720)
     assert noisy.modulate(Image.frombytes('RGB', (720, 8), bytes(720 * 8 * 3)), 0).size == (720, 8)
     im2 = image.ImageModem(_am_modem('niir', (722, 8), 'GERBER_625'))
     with pytest.raises(NotImplementedError):
-        im2.demodulate_frames_u8(numpy.zeros((1, 8, 722), numpy.uint8))
+        im2._engine().demodulate_frames_u8(numpy.zeros((1, 8, 722), numpy.uint8))
+    comp8 = numpy.random.default_rng(6).integers(0, 256, (2, 8, 722), dtype=numpy.uint8)
+    comp = image.ImageModem.decode_composite_level(comp8.astype(numpy.float64) / 255.0).astype(numpy.float32)
+    want = _as_bytes(im2.demodulate_frames(numpy.ascontiguousarray(comp), 1).astype(numpy.float64)).transpose(0, 2, 3, 1)
+    assert numpy.array_equal(im2.demodulate_frames_u8(comp8, 1), want)

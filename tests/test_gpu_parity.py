@@ -526,11 +526,20 @@ def test_fused_uint8_modulate_matches_float_path(stack, size, n_frames, first):
 
 def test_fused_uint8_modulate_needs_width_multiple_of_16():
     im = image.ImageModem(stacks.make('pal_s', (712, 8)))
-    with pytest.raises(NotImplementedError):
-        im.modulate_frames_u8(numpy.zeros((1, 8, 712, 3), numpy.uint8))
-    from PIL import Image      # the PIL entry point falls back to the float kernel
-    out = im.modulate(Image.frombytes('RGB', (712, 8), bytes(712 * 8 * 3)), 0)
-    assert out.size == (712, 8)
+    with pytest.raises(NotImplementedError):      # the engine's fused byte tiles
+        im._engine().modulate_frames_u8(numpy.zeros((1, 8, 712, 3), numpy.uint8))
+    # ImageModem then runs the same conversions on the device around the float kernel: the bytes of the host-side formulas (image.py:24, 47-62)
+    from color_modem_amd.image import _as_bytes
+    rgb8 = numpy.random.default_rng(3).integers(0, 256, (2, 8, 712, 3), dtype=numpy.uint8)
+    got = im.modulate_frames_u8(rgb8, 1)
+    rgb = (rgb8.astype(numpy.float64) / 255.0).astype(numpy.float32).transpose(0, 3, 1, 2)
+    want = _as_bytes(image.ImageModem.encode_composite_level(im.modulate_frames(numpy.ascontiguousarray(rgb), 1).astype(numpy.float64)))
+    assert got.dtype == numpy.uint8 and numpy.array_equal(got, want)
+    back = im.demodulate_frames_u8(got, 1)        # 712 is a multiple of 4: the fused decoder boundary
+    assert back.shape == (2, 8, 712, 3)
+    from PIL import Image
+    out = im.modulate(Image.frombytes('RGB', (712, 8), rgb8[0].tobytes()), 1)
+    assert out.size == (712, 8) and out.tobytes() == want[0].tobytes()
 
 
 @pytest.mark.parametrize('size,n_frames,first', [((720, 576), 2, 1), ((720, 21), 3, 4)])
@@ -839,6 +848,16 @@ def test_pil_images_through_the_composed_engines(stack):
     got = numpy.frombuffer(back.tobytes(), dtype=numpy.uint8).reshape(size[1], size[0], 3)
     d = numpy.abs(got.astype(int) - want.astype(int))
     assert d.max() <= 1 and (d > 0).mean() < 2e-3, (stack, d.max(), (d > 0).mean())
+    # the batch byte entry points of the same stacks (round 5): the conversions on the device around the float path, a cuda tensor in and
+    # out, byte for byte what the host-side formulas give
+    import torch
+    comp3 = numpy.stack([comp8, comp8[::-1], comp8])
+    got3 = im.demodulate_frames_u8(torch.from_numpy(comp3.copy()).cuda(), 1)
+    assert got3.is_cuda and got3.dtype == torch.uint8 and tuple(got3.shape) == (3, size[1], size[0], 3)
+    compf = image.ImageModem.decode_composite_level(comp3.astype(numpy.float64) / 255.0).astype(numpy.float32)
+    want3 = _as_bytes(im.demodulate_frames(numpy.ascontiguousarray(compf), 1).astype(numpy.float64)).transpose(0, 2, 3, 1)
+    assert numpy.array_equal(got3.cpu().numpy(), want3)
+    assert numpy.array_equal(got3[2].cpu().numpy(), numpy.frombuffer(im.demodulate(comp_img, 3).tobytes(), numpy.uint8).reshape(size[1], size[0], 3))
 
 
 def test_out_argument_is_validated():
