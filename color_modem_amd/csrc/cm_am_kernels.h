@@ -92,6 +92,18 @@ template <bool U8> inline int proto_pair_lds_floats(int dly) {
     return 2 * AmInTile<U8>::kBufFloats + 2 * 6 * 128 + proto_ring_slots(dly) * 64 + 8 * 128 + (U8 ? 64 * 3 * 16 / 4 : 3 * 64 * 16);
 }
 
+// Stage A's interior bodies: the six aligned samples of one filter (H 0: |band-pass|, 1: band-stop) of a body into their hand-over rows,
+// R of them the tail of the previous group.  asm statements: written as plain stores, the three branches around them are merged into
+// selects (36 moves per body).  The s_waitcnt lgkmcnt(0) in front of the body's barrier covers them.
+template <int R, int H>
+__device__ __forceinline__ void proto_put_rows(unsigned slot_addr, const pf2 (&raw)[8], const float (&ae)[8]) {
+#pragma unroll
+    for (int a = 0; a < 6; ++a) {          // aligned sample a = 3 s + j: row 2 (3 H + j) + s
+        const float v = H ? raw[2 + a - R].y : ae[2 + a - R];
+        asm volatile("ds_write_b32 %0, %1 offset:%2" :: "v"(slot_addr), "v"(v), "n"((2 * (3 * H + a % 3) + a / 3) * 256) : "memory");
+    }
+}
+
 template <bool U8>
 __global__ __launch_bounds__(128, 2) void proto_demod_pair_kernel(const ProtoDemodArgs args) {
     constexpr int kTile = 16, DEPTH = 1, Q = 6;
@@ -120,8 +132,9 @@ __global__ __launch_bounds__(128, 2) void proto_demod_pair_kernel(const ProtoDem
 
     if (role == 0) {
         // =================================== stage A ===========================================
-        ProtoDemodK<float> ka = k;
-        pin_taps3(ka.taps);
+        // Edge bodies: the scalar stages of cm_am_stages.h (taps and sections out of scalar registers).  Interior bodies (round 5): the
+        // interpolator's partial sums and (band-pass | band-stop) in packed float32 - Up3Pk, BpSymPk3 - instantiated per (ge.r, gr.r) so
+        // that aligning the raw outputs with the filters' groups is a choice of registers, not of instructions.
         const float *xp = am_in_row<U8>(g, lc);
         Up3<float> up;
         FF3<float, 3> ext, rem;
@@ -133,27 +146,7 @@ __global__ __launch_bounds__(128, 2) void proto_demod_pair_kernel(const ProtoDem
         if (kIT < W) am_fill<U8>(g, itile, xp, 1, lane);      // tile c + 1 is asked for when tile c is first read
         auto read_x = [&](int first) -> f2 { return am_read2<U8>(itile, lane, first, W); };
         f2 xv = read_x(0);
-        auto body = [&](auto edge_tag, int tb) __attribute__((always_inline)) {
-            constexpr bool EDGE = decltype(edge_tag)::value;
-            float hq[Q][2];
-            const f2 xd = *(const lds_f2 *)(xdel + (((tb >> 1) + 3) & 7) * 128 + lane * 2);       // x[tb - 10], x[tb - 9]: written five bodies ago
-            *(lds_f2 *)(xdel + ((tb >> 1) & 7) * 128 + lane * 2) = xv;
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                const int n1 = tb + s - kAmHalf;
-                float u[3], c1[3], y1[3];
-                up.push(ka.taps, xv[s], xd[s], u);
-                ext.template step<AM_FORM_BP, EDGE>(ka.ext, ka.ge, L, n1, u, c1);
-                rem.template step<AM_FORM_SYM, EDGE>(ka.rem, ka.gr, L, n1, u, y1);
-#pragma unroll
-                for (int j = 0; j < 3; ++j) {
-                    hq[j][s] = c1[j] < 0.f ? -c1[j] : c1[j];     // protosecam.py:98 (the factor pi / 2 is in chroma_gain)
-                    hq[3 + j][s] = y1[j];
-                }
-            }
-            lds_float *slot = hand + ((tb >> 1) & 1) * (Q * 128) + lane * 2;
-#pragma unroll
-            for (int q = 0; q < Q; ++q) *(lds_f2 *)(slot + q * 128) = f2{hq[q][0], hq[q][1]};
+        auto next_x = [&](int tb) __attribute__((always_inline)) {
             const int nxt = tb + 2;
             if ((nxt & (kIT - 1)) == 0 && nxt < W) {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -164,10 +157,72 @@ __global__ __launch_bounds__(128, 2) void proto_demod_pair_kernel(const ProtoDem
             xv = read_x(nxt);
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         };
+        // hand-over rows: quantity q (|band-pass| 0..2, band-stop 3..5) of step s in row 2 q + s of the body's buffer
+        auto edge_body = [&](int tb) __attribute__((always_inline)) {
+            const f2 xd = *(const lds_f2 *)(xdel + (((tb >> 1) + 3) & 7) * 128 + lane * 2);       // x[tb - 10], x[tb - 9]: written five bodies ago
+            *(lds_f2 *)(xdel + ((tb >> 1) & 7) * 128 + lane * 2) = xv;
+            lds_float *slot = hand + ((tb >> 1) & 1) * (Q * 128) + lane;
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const int n1 = tb + s - kAmHalf;
+                float u[3], c1[3], y1[3];
+                up.template push<false>(k.taps, xv[s], xd[s], u);
+                ext.template step<AM_FORM_BP, true>(k.ext, k.ge, L, n1, u, c1);
+                rem.template step<AM_FORM_SYM, true>(k.rem, k.gr, L, n1, u, y1);
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    slot[(2 * j + s) * 64] = __builtin_fabsf(c1[j]);     // protosecam.py:98 (the factor pi / 2 is in chroma_gain)
+                    slot[(2 * (3 + j) + s) * 64] = y1[j];
+                }
+            }
+            next_x(tb);
+        };
         int tb = 0;
-        for (; tb < t_mid0; tb += 2) body(std::true_type(), tb);
-        for (; tb < t_mid1; tb += 2) body(std::false_type(), tb);
-        for (; tb < T; tb += 2) body(std::true_type(), tb);
+        for (; tb < t_mid0; tb += 2) edge_body(tb);
+        if (tb < t_mid1) {
+            TapsPk3 kp;
+            BpSymK3 ks;
+            kp.load(k.taps);
+            ks.load(k.ext, k.rem);
+            Up3Pk upk;
+            BpSymPk3 er;
+            upk.from(up);
+            er.from(ext, rem);
+            // aligning the raw outputs with the filters' groups (FF3::step: g.r of them belong to the previous group) is a choice of
+            // registers per value of r: one uniform three-way branch per filter and body around the six stores, no instruction else
+            const int re = k.ge.r, rr = k.gr.r;
+            for (; tb < t_mid1; tb += 2) {
+                const f2 xd_ = *(const lds_f2 *)(xdel + (((tb >> 1) + 3) & 7) * 128 + lane * 2);
+                *(lds_f2 *)(xdel + ((tb >> 1) & 7) * 128 + lane * 2) = xv;
+                const pf2 xd = pf2{xd_.x, xd_.y}, xs = pf2{xv.x, xv.y};
+                lds_float *slot = hand + ((tb >> 1) & 1) * (Q * 128) + lane;
+                pf2 raw[8];                                // raw outputs -2 .. 5 of this body's two groups (.x: |band-pass|, .y: band-stop)
+                raw[0] = er.h2;
+                raw[1] = er.h1;
+                auto step = [&](auto s_tag) __attribute__((always_inline)) {
+                    constexpr int s = decltype(s_tag)::value;
+                    const pf2 u12 = upk.template push<s>(kp, xs);
+                    const pf2 u0 = pk_mul_xk<s, false>(xd, kp.c[10]);
+                    raw[2 + 3 * s] = er.template step<0>(ks, u0);
+                    raw[3 + 3 * s] = er.template step<0>(ks, u12);
+                    raw[4 + 3 * s] = er.template step<1>(ks, u12);
+                };
+                step(std::integral_constant<int, 0>());
+                step(std::integral_constant<int, 1>());
+                er.h2 = raw[6];
+                er.h1 = raw[7];
+                float ae[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) ae[i] = __builtin_fabsf(raw[i].x);     // protosecam.py:98 (the factor pi / 2 is in chroma_gain)
+                const unsigned slot_addr = (unsigned)(size_t)slot;
+                if (re == 0) proto_put_rows<0, 0>(slot_addr, raw, ae); else if (re == 1) proto_put_rows<1, 0>(slot_addr, raw, ae); else proto_put_rows<2, 0>(slot_addr, raw, ae);
+                if (rr == 0) proto_put_rows<0, 1>(slot_addr, raw, ae); else if (rr == 1) proto_put_rows<1, 1>(slot_addr, raw, ae); else proto_put_rows<2, 1>(slot_addr, raw, ae);
+                next_x(tb);
+            }
+            upk.to(up);
+            er.to(ext, rem);
+        }
+        for (; tb < T; tb += 2) edge_body(tb);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         return;
     }
@@ -187,19 +242,23 @@ __global__ __launch_bounds__(128, 2) void proto_demod_pair_kernel(const ProtoDem
     for (int j = 0; j < nring; ++j) ring[j * 64 + lane] = 0.f;
     lds_float *otile = U8 ? (lds_float *)((__attribute__((address_space(3))) unsigned char *)otile_base + lane * 3 * kTile) : otile_base + lane * kTile;
     const int wpos = ((lane >> CM_TILE_SWZ) & (kTile / 4 - 1)) << 2;
-    auto body = [&](auto edge_tag, int tb) __attribute__((always_inline)) {
+    auto body = [&](auto edge_tag, auto r_tag, int tb) __attribute__((always_inline)) {
         constexpr bool EDGE = decltype(edge_tag)::value;
+        constexpr int RP = decltype(r_tag)::value;
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // the hand-over of this body is complete
-        const lds_float *slot = hand + ((tb >> 1) & 1) * (Q * 128) + lane * 2;
-        f2 hq[Q];
+        const lds_float *slot = hand + ((tb >> 1) & 1) * (Q * 128) + lane;
+        float hq[Q][2];
 #pragma unroll
-        for (int q = 0; q < Q; ++q) hq[q] = *(const lds_f2 *)(slot + q * 128);
+        for (int q = 0; q < Q; ++q) {
+            hq[q][0] = slot[(2 * q) * 64];
+            hq[q][1] = slot[(2 * q + 1) * 64];
+        }
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             const int t = tb + s, n1 = t - kAmHalf;
             const float c1[3] = {hq[0][s], hq[1][s], hq[2][s]};
             float c2[3];
-            post.template step<AM_FORM_GEN, EDGE>(k.post, k.gp, L, n1 - k.ge.q, c1, c2);
+            post.template step<AM_FORM_GEN, EDGE, false, RP>(k.post, k.gp, L, n1 - k.ge.q, c1, c2);
             const pf2 d = dn.push(kp, pf2{c2[0], hq[3][s]}, pf2{c2[1], hq[4][s]}, pf2{c2[2], hq[5][s]});
             const float chroma = fmaf_(k.chroma_gain, d.x, -1.f), luma = k.luma_gain * d.y;
             ring[(t & (nring - 1)) * 64 + lane] = luma;
@@ -217,10 +276,13 @@ __global__ __launch_bounds__(128, 2) void proto_demod_pair_kernel(const ProtoDem
             }
         }
     };
+    typedef std::integral_constant<int, -1> RX;
     int tb = 0;
-    for (; tb < t_mid0; tb += 2) body(std::true_type(), tb);
-    for (; tb < t_mid1; tb += 2) body(std::false_type(), tb);
-    for (; tb < T; tb += 2) body(std::true_type(), tb);
+    for (; tb < t_mid0; tb += 2) body(std::true_type(), RX(), tb);
+    if (k.gp.r == 0) for (; tb < t_mid1; tb += 2) body(std::false_type(), std::integral_constant<int, 0>(), tb);
+    else if (k.gp.r == 1) for (; tb < t_mid1; tb += 2) body(std::false_type(), std::integral_constant<int, 1>(), tb);
+    else for (; tb < t_mid1; tb += 2) body(std::false_type(), std::integral_constant<int, 2>(), tb);
+    for (; tb < T; tb += 2) body(std::true_type(), RX(), tb);
 }
 
 struct ProtoModArgs {

@@ -113,7 +113,9 @@ struct FF3 {
     }
     // EDGE = false: the caller guarantees 0 <= 3 (n1 - q) and 3 n1 + 2 < L - 1 (the interior of a row: no latch, no clamp,
     // every output inside the sequence)
-    template <int FORM, bool EDGE = true, bool V = false>
+    // R: g.r known at compile time (0..2; the interior loops of the wave pairs are instantiated per value, so that the choice of
+    // registers below costs no instruction), -1: read from g
+    template <int FORM, bool EDGE = true, bool V = false, int R = -1>
     CM_HD void step(const SosK<T, NSEC> &k, const FFGeom &g, int L, int n1, const T in[3], T out[3]) {
         T y[3];
 #pragma unroll
@@ -130,8 +132,9 @@ struct FF3 {
             }
         }
         T o0, o1, o2;
-        if (g.r == 0) { o0 = y[0]; o1 = y[1]; o2 = y[2]; }
-        else if (g.r == 1) { o0 = h1; o1 = y[0]; o2 = y[1]; }
+        const int r = R >= 0 ? R : g.r;
+        if (r == 0) { o0 = y[0]; o1 = y[1]; o2 = y[2]; }
+        else if (r == 1) { o0 = h1; o1 = y[0]; o2 = y[1]; }
         else { o0 = h2; o1 = h1; o2 = y[0]; }
         h2 = y[1];
         h1 = y[2];
@@ -763,6 +766,120 @@ struct Dn3S {
         upd<1>(k, z[0], z[1], z[2]);
         s[19] = fma3<true>(tap3<59>(k), z[1], tap3<58>(k) * z[2]);
         return out;
+    }
+};
+// ---- stage A of proto_demod_pair_kernel in packed float32 (round 5; the interior bodies) ---------------------------------------------
+// d = x[XH] + s
+template <int XH>
+__device__ __forceinline__ pf2 pk_add_bx(pf2 x, pf2 s) {
+    pf2 d;
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (XH == 0) asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1]" : "=v"(d) : "v"(x), "v"(s));
+    else asm("v_pk_add_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,1]" : "=v"(d) : "v"(x), "v"(s));
+#else
+    d = x[XH] + s;
+#endif
+    return d;
+}
+// d = (k.y, k.x) * x[XH]
+template <int XH>
+__device__ __forceinline__ pf2 pk_mul_xk_swap(pf2 x, pf2 k) {
+    pf2 d;
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (XH == 0) asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[0,0]" : "=v"(d) : "v"(x), "v"(k));
+    else asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,0]" : "=v"(d) : "v"(x), "v"(k));
+#else
+    d = pf2{k.y * x[XH], k.x * x[XH]};
+#endif
+    return d;
+}
+// d = (k.x * y.x - x, k.y * y.y + x), x = xs[XH] (XH = -1: the pair xs itself): the second state of a (band-pass | band-stop) section pair
+template <int XH>
+__device__ __forceinline__ pf2 pk_fma_pm(pf2 k, pf2 y, pf2 xs) {
+    pf2 d;
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (XH < 0) asm("v_pk_fma_f32 %0, %1, %2, %3 neg_lo:[0,0,1]" : "=v"(d) : "v"(k), "v"(y), "v"(xs));
+    else if (XH == 0) asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,1,0] neg_lo:[0,0,1]" : "=v"(d) : "v"(k), "v"(y), "v"(xs));
+    else asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,1] op_sel_hi:[1,1,1] neg_lo:[0,0,1]" : "=v"(d) : "v"(k), "v"(y), "v"(xs));
+#else
+    const float xl = XH < 0 ? xs.x : xs[XH < 0 ? 0 : XH], xh = XH < 0 ? xs.y : xs[XH < 0 ? 0 : XH];
+    d = pf2{__builtin_fmaf(k.x, y.x, -xl), __builtin_fmaf(k.y, y.y, xh)};
+#endif
+    return d;
+}
+// Up3 with the partial sums in pairs: pair i = (s(3 i + 1), s(3 i + 2)) = slots (2 i, 2 i + 1) of Up3::s, so one step moves every pair
+// down by one and the two taps of a pair sit in one pair of TapsPk3 (the upper half of the symmetric filter: the same pairs, halves
+// swapped by op_sel).  The same 40 products and sums as Up3::push, in its order per output, two per instruction.
+struct Up3Pk {
+    pf2 s[19];
+    __device__ __forceinline__ void from(const Up3<float> &u) {
+#pragma unroll
+        for (int i = 0; i < 19; ++i) s[i] = pf2{take(u.s[2 * i]), take(u.s[2 * i + 1])};
+    }
+    __device__ __forceinline__ void to(Up3<float> &u) const {
+#pragma unroll
+        for (int i = 0; i < 19; ++i) { u.s[2 * i] = s[i].x; u.s[2 * i + 1] = s[i].y; }
+    }
+    template <int XH, int I> __device__ __forceinline__ void chain(const TapsPk3 &k, pf2 xv) {
+        if constexpr (I <= 9) s[I - 1] = pk_fma_xk<XH, 0, false>(xv, k.c[I], s[I]);
+        else s[I - 1] = pk_fma_xk<XH, 1, false>(xv, k.c[19 - I], s[I]);
+        if constexpr (I < 18) chain<XH, I + 1>(k, xv);
+    }
+    // x = xv[XH]; returns (out[1], out[2]) of Up3::push - out[0] = 3 h[30] x[t - 10] is the caller's
+    template <int XH> __device__ __forceinline__ pf2 push(const TapsPk3 &k, pf2 xv) {
+        const pf2 out = pk_fma_xk<XH, 0, false>(xv, k.c[0], s[0]);
+        chain<XH, 1>(k, xv);
+        s[18] = pk_mul_xk_swap<XH>(xv, k.c[0]);
+        return out;
+    }
+};
+// The band-pass (numerators 1 - z^-2) and the band-stop (1 + b1 z^-1 + z^-2) of the Proto-SECAM decoder run over the same samples:
+// section j of both as one pair (.x band-pass, .y band-stop) in the band-stop's four-operation form - iir_sym - with b1 = 0 and the
+// sign of x in the second state flipped for the band-pass half, which is iir_bp's arithmetic (t = 0 * x + s2 = s2).
+struct BpSymK3 {
+    pf2 na1[3], na2[3], b1[3];
+    __device__ __forceinline__ void load(const SosK<float, 3> &bp, const SosK<float, 3> &sym) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            na1[j] = pf2{take(bp.na1[j]), take(sym.na1[j])};
+            na2[j] = pf2{take(bp.na2[j]), take(sym.na2[j])};
+            b1[j] = pf2{0.f, take(sym.b1[j])};
+            pin_pair(na1[j]); pin_pair(na2[j]); pin_pair(b1[j]);
+        }
+    }
+};
+struct BpSymPk3 {
+    pf2 s1[3], s2[3], h1, h2;      // h1, h2: the raw outputs of the previous step (FF3::h1, h2)
+    __device__ __forceinline__ void from(const FF3<float, 3> &bp, const FF3<float, 3> &sym) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {      // (take: element by element - merged into vector loads the states would sit in scratch memory)
+            s1[j] = pf2{take(bp.st.s1[j]), take(sym.st.s1[j])};
+            s2[j] = pf2{take(bp.st.s2[j]), take(sym.st.s2[j])};
+        }
+        h1 = pf2{take(bp.h1), take(sym.h1)};
+        h2 = pf2{take(bp.h2), take(sym.h2)};
+    }
+    __device__ __forceinline__ void to(FF3<float, 3> &bp, FF3<float, 3> &sym) const {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) { bp.st.s1[j] = s1[j].x; sym.st.s1[j] = s1[j].y; bp.st.s2[j] = s2[j].x; sym.st.s2[j] = s2[j].y; }
+        bp.h1 = h1.x; sym.h1 = h1.y;
+        bp.h2 = h2.x; sym.h2 = h2.y;
+    }
+    // one sample x = xs[XH] through both cascades: (band-pass output, band-stop output)
+    template <int XH> __device__ __forceinline__ pf2 step(const BpSymK3 &k, pf2 xs) {
+        pf2 y = pk_add_bx<XH>(xs, s1[0]);
+        pf2 t = pk_fma_xk<XH, 0, false>(xs, k.b1[0], s2[0]);
+        s1[0] = pk_fma(k.na1[0], y, t);
+        s2[0] = pk_fma_pm<XH>(k.na2[0], y, xs);
+#pragma unroll
+        for (int j = 1; j < 3; ++j) {
+            const pf2 x = y;
+            y = pk_add(x, s1[j]);
+            t = pk_fma(k.b1[j], x, s2[j]);
+            s1[j] = pk_fma(k.na1[j], y, t);
+            s2[j] = pk_fma_pm<-1>(k.na2[j], y, x);
+        }
+        return y;
     }
 };
 // NiirBack for stage B of the wave pair: the four phase decimators as two packed pairs - (sin, cos) products | (carrier, its
