@@ -156,9 +156,10 @@ def other_configs(torch, device, frames):
     err_rt = max(_rel_err(numpy, got[i], want_rt[i]) for i in range(got.shape[0]))
     kern = eng.describe()
     name = 'SECAM IIIb (SecamModem) %s, 720x576, %d frames of smoothed random RGB'
-    res.append(entry(name % ('encode', frames), ms_enc, px, 16, err_enc, kern))
+    kern_enc = 'secam_mod_kernel; calls per workgroup 64 (one wavefront, three-plane input tiles), halo 0'      # cm_plan_describe names the decoder
+    res.append(entry(name % ('encode', frames), ms_enc, px, 16, err_enc, kern_enc))
     res.append(entry(name % ('decode', frames), ms_dec, px, 16, err_dec, kern))
-    res.append(entry(name % ('encode + decode round trip through HBM', frames), ms_rt, px, 32, max(err_enc, err_dec), kern))
+    res.append(entry(name % ('encode + decode round trip through HBM', frames), ms_rt, px, 32, max(err_enc, err_dec), 'secam_mod_kernel, then ' + kern))
     # each leg against the oracle on the same input is the parity statement; the device's round trip against the oracle's own
     # round trip is reported beside it (the discriminator amplifies the encoder's float32 rounding by ~ 1 / fdev: not gated)
     res[-1]['check']['end_to_end_vs_oracle_round_trip'] = float('%.3g' % err_rt)

@@ -3064,7 +3064,8 @@ int cm_plan_describe(const cm_plan *p, char *buf, int32_t buf_len) {
     const char *exp = "";
 #endif
     int n = snprintf(buf, buf_len, "%s; calls per workgroup 64 (%s), halo %d%s", p->main.name.c_str(),
-                     p->pair ? "two wavefronts: front end | detectors + back end" : "one wavefront", p->main.depth, exp);
+                     (p->pair || p->main.name.find("_pair") != std::string::npos) ? "two wavefronts: front end | detectors + back end" : "one wavefront",
+                     p->main.depth, exp);
     return n < buf_len ? n : buf_len - 1;
 }
 
