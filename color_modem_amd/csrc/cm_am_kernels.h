@@ -336,8 +336,12 @@ __global__ __launch_bounds__(128, 2) void proto_mod_pair_kernel(const ProtoModAr
 
     if (role == 0) {
         // =================================== stage A ===========================================
-        ProtoModK<float> ka = k;
-        pin_taps3(ka.taps);
+        // (round 5: the interior bodies run the interpolator on pairs of partial sums - Up3Pk, as stage A of the decoder; the edge bodies
+        // keep the scalar one with its taps out of scalar registers)
+        const ProtoModK<float> &ka = k;
+        TapsPk3 kp;
+        kp.load(k.taps);
+        Up3Pk upk;
         const long long frame = (long long)args.a.frame_base + lc.frame;
         const int line = DEPTH ? lc.line - 2 : lc.line;       // the line that is modulated
         const bool alt = args.a.line.alternate(frame, line);
@@ -379,15 +383,27 @@ __global__ __launch_bounds__(128, 2) void proto_mod_pair_kernel(const ProtoModAr
                 const float c = pre.template step<AM_FORM_GEN, EDGE>(ka.pre, ka.s_c, ka.width, t - d_c, d_in);
                 hq[3][s] = fmaf_(0.125f * ka.pre_gain, c, 0.125f);
                 hq[4][s] = y_in;
-                float u[3] = {0.f, 0.f, 0.f};
+                // hand-over rows: 0 the interpolator's phase 0 of the four steps, 1 / 2 its phases (1, 2) of steps 0, 1 / 2, 3
+                float u0 = 0.f;
+                pf2 u12 = pf2{0.f, 0.f};
                 const int i_y = t - d_y;
                 if (ka.luma_filter) {
                     const float y_fed = (!EDGE || (i_y >= 0 && i_y < ka.width)) ? y_in : 0.f;
                     const float y_del = ydel[((t - kAmHalf) & 15) * 64 + lane];
                     ydel[(t & 15) * 64 + lane] = y_fed;
-                    up.push(ka.taps, y_fed, y_del, u);
+                    if (EDGE) {
+                        float u[3];
+                        up.template push<false>(ka.taps, y_fed, y_del, u);
+                        u0 = u[0];
+                        u12 = pf2{u[1], u[2]};
+                    } else {
+                        u12 = upk.template push<0>(kp, pk_lo(y_fed));
+                        u0 = kp.c[10].x * y_del;
+                    }
                 }
-                hq[0][s] = u[0]; hq[1][s] = u[1]; hq[2][s] = u[2];
+                hq[0][s] = u0;
+                hq[1 + (s >> 1)][2 * (s & 1)] = u12.x;
+                hq[1 + (s >> 1)][2 * (s & 1) + 1] = u12.y;
             }
             lds_float *slot = hand + ((tb >> 2) & 1) * (Q * 256) + lane * 4;
 #pragma unroll
@@ -396,15 +412,23 @@ __global__ __launch_bounds__(128, 2) void proto_mod_pair_kernel(const ProtoModAr
         };
         int tb = 0;
         for (; tb < t_mid0; tb += 4) body(std::true_type(), tb);
-        for (; tb < t_mid1; tb += 4) body(std::false_type(), tb);
+        if (tb < t_mid1) {
+            upk.from(up);
+            for (; tb < t_mid1; tb += 4) body(std::false_type(), tb);
+            upk.to(up);
+        }
         for (; tb < T; tb += 4) body(std::true_type(), tb);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         return;
     }
 
     // ======================================= stage B ===========================================
-    ProtoModK<float> kb = k;
-    pin_taps3(kb.taps);
+    // (round 5: the interior bodies run the decimator two steps at a time on pairs of accumulators - Dn3Two - and are instantiated per
+    // gr.r, so that aligning the band-stop's raw outputs with its groups is a choice of registers; the edge bodies keep the scalar stages)
+    const ProtoModK<float> &kb = k;
+    Dn3TwoK dk;
+    dk.load(k.taps);
+    Dn3Two dn2;
     const long long frame = (long long)args.a.frame_base + lc.frame;
     const int line = DEPTH ? lc.line - 2 : lc.line;
     float cph, sph;
@@ -418,23 +442,36 @@ __global__ __launch_bounds__(128, 2) void proto_mod_pair_kernel(const ProtoModAr
     rem.reset();
     dn.reset();
     const int wpos = ((lane >> CM_TILE_SWZ) & (kTile / 4 - 1)) << 2;
-    auto body = [&](auto edge_tag, int tb) __attribute__((always_inline)) {
+    auto body = [&](auto edge_tag, auto r_tag, int tb) __attribute__((always_inline)) {
         constexpr bool EDGE = decltype(edge_tag)::value;
+        constexpr int RR = decltype(r_tag)::value;
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // the hand-over of this body is complete
         const lds_float *slot = hand + ((tb >> 2) & 1) * (Q * 256) + lane * 4;
         f4 hq[Q];
 #pragma unroll
         for (int q = 0; q < Q; ++q) hq[q] = *(const lds_f4 *)(slot + q * 256);
+        float lumas[4] = {hq[4][0], hq[4][1], hq[4][2], hq[4][3]};
+        if (kb.luma_filter) {
+            float y1[4][3];
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const float u[3] = {hq[0][s], hq[1 + (s >> 1)][2 * (s & 1)], hq[1 + (s >> 1)][2 * (s & 1) + 1]};
+                rem.template step<AM_FORM_SYM, EDGE, false, RR>(kb.rem, kb.gr, 3 * kb.width, tb + s - d_y - kAmHalf, u, y1[s]);
+                if (EDGE) lumas[s] = kb.luma_gain * dn.template push<false>(kb.taps, y1[s]);
+            }
+            if (!EDGE) {
+                const pf2 l01 = dn2.push2(dk, y1[0][0], pf2{y1[0][1], y1[0][2]}, y1[1][0], pf2{y1[1][1], y1[1][2]});
+                const pf2 l23 = dn2.push2(dk, y1[2][0], pf2{y1[2][1], y1[2][2]}, y1[3][0], pf2{y1[3][1], y1[3][2]});
+                lumas[0] = kb.luma_gain * l01.x;
+                lumas[1] = kb.luma_gain * l01.y;
+                lumas[2] = kb.luma_gain * l23.x;
+                lumas[3] = kb.luma_gain * l23.y;
+            }
+        }
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             const int t = tb + s;
-            float luma = hq[4][s];
-            if (kb.luma_filter) {
-                const float u[3] = {hq[0][s], hq[1][s], hq[2][s]};
-                float y1[3];
-                rem.template step<AM_FORM_SYM, EDGE>(kb.rem, kb.gr, 3 * kb.width, t - d_y - kAmHalf, u, y1);
-                luma = kb.luma_gain * dn.push(kb.taps, y1);
-            }
+            const float luma = lumas[s];
             const int n = t - lat;
             int nc = n;
             if (EDGE) nc = n < 0 ? 0 : (n > W - 1 ? W - 1 : n);
@@ -443,10 +480,17 @@ __global__ __launch_bounds__(128, 2) void proto_mod_pair_kernel(const ProtoModAr
             put_composite<U8, kTile>(g, otile_base, op, lane, wpos, n, fmaf_(cosp, hq[3][s], luma));
         }
     };
+    typedef std::integral_constant<int, -1> RX;
     int tb = 0;
-    for (; tb < t_mid0; tb += 4) body(std::true_type(), tb);
-    for (; tb < t_mid1; tb += 4) body(std::false_type(), tb);
-    for (; tb < T; tb += 4) body(std::true_type(), tb);
+    for (; tb < t_mid0; tb += 4) body(std::true_type(), RX(), tb);
+    if (tb < t_mid1) {
+        dn2.from(dn);
+        if (kb.gr.r == 0) for (; tb < t_mid1; tb += 4) body(std::false_type(), std::integral_constant<int, 0>(), tb);
+        else if (kb.gr.r == 1) for (; tb < t_mid1; tb += 4) body(std::false_type(), std::integral_constant<int, 1>(), tb);
+        else for (; tb < t_mid1; tb += 4) body(std::false_type(), std::integral_constant<int, 2>(), tb);
+        dn2.to(dn);
+    }
+    for (; tb < T; tb += 4) body(std::true_type(), RX(), tb);
 }
 
 // ---- NIIR / SECAM-IV ------------------------------------------------------------------------------------------------------

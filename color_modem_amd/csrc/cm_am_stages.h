@@ -882,6 +882,79 @@ struct BpSymPk3 {
         return y;
     }
 };
+// ---- Dn3 on ONE signal, two steps per call, packed along the accumulator index (round 5) ----------------------------------------------
+// One step of Dn3 is s'[d - 1] = b_d z1 + (a_d z2 + s[d]) for d = 1 .. 20 (a_d = h[3 d - 2], b_d = h[3 d - 1], s[20] = 0; d = 10 takes the
+// centre tap on z0 in between), so the accumulators move down by one per step and a pair (s[d], s[d + 1]) is no pair of the next step's
+// registers - but after TWO steps everything has moved by two: pair P[j] = (s[2 j], s[2 j + 1]) becomes the new P[j - 1] through four
+// v_pk_fma (a, b of step 1 with the tap pairs (2 j + 2, 2 j + 3), then a, b of step 2 with (2 j + 1, 2 j + 2)): per output the products
+// and sums of Dn3::push in its order, 40 packed for 80 scalar instructions.  The symmetric filter (a_d = b_(21 - d)) halves the tap pairs
+// again: the upper ones are the lower ones of the other kind with their halves swapped (op_sel).
+struct Dn3TwoK {
+    pf2 a1[5], b1[5], a2[5], b2[5], za, zb;      // a1[j] = (a(2 j + 2), a(2 j + 3)), a2[j] = (a(2 j + 1), a(2 j + 2)); za = (0, a(1)), zb = (0, b(1))
+    float h30;
+    static constexpr int ia(int d) { return tap3i(3 * d - 2); }
+    static constexpr int ib(int d) { return tap3i(3 * d - 1); }
+    template <int J> __device__ __forceinline__ void load_j(const Taps3<float> &t) {
+        a1[J] = pf2{take(t.h[ia(2 * J + 2)]), take(t.h[ia(2 * J + 3)])};
+        b1[J] = pf2{take(t.h[ib(2 * J + 2)]), take(t.h[ib(2 * J + 3)])};
+        a2[J] = pf2{take(t.h[ia(2 * J + 1)]), take(t.h[ia(2 * J + 2)])};
+        b2[J] = pf2{take(t.h[ib(2 * J + 1)]), take(t.h[ib(2 * J + 2)])};
+        pin_pair(a1[J]); pin_pair(b1[J]); pin_pair(a2[J]); pin_pair(b2[J]);
+        if constexpr (J + 1 < 5) load_j<J + 1>(t);
+    }
+    __device__ __forceinline__ void load(const Taps3<float> &t) {
+        load_j<0>(t);
+        za = pf2{0.f, take(t.h[ia(1)])};
+        zb = pf2{0.f, take(t.h[ib(1)])};
+        pin_pair(za); pin_pair(zb);
+        h30 = take(t.h[30]);
+    }
+};
+struct Dn3Two {
+    pf2 p[10];
+    __device__ __forceinline__ void from(const Dn3<float> &d) {
+#pragma unroll
+        for (int i = 0; i < 10; ++i) p[i] = pf2{take(d.s[2 * i]), take(d.s[2 * i + 1])};
+    }
+    __device__ __forceinline__ void to(Dn3<float> &d) const {
+#pragma unroll
+        for (int i = 0; i < 10; ++i) { d.s[2 * i] = p[i].x; d.s[2 * i + 1] = p[i].y; }
+    }
+    // T = kpair * z[XH] + T with the tap pair of (step, kind, j): the stored pair, or for j >= 5 the other kind's mirror pair swapped
+    template <int STEP, bool B, int J, int XH>
+    __device__ __forceinline__ pf2 tap(const Dn3TwoK &k, pf2 z, pf2 t) const {
+        if constexpr (J < 5) {
+            const pf2 &c = STEP == 1 ? (B ? k.b1[J] : k.a1[J]) : (B ? k.b2[J] : k.a2[J]);
+            return pk_fma_xk<XH, 0, false>(z, c, t);
+        } else if constexpr (STEP == 1) {
+            if constexpr (J == 9) return pk_fma_xk<XH, 1, false>(z, B ? k.za : k.zb, t);       // (a20, a21 = 0) = swapped (0, b1)
+            else return pk_fma_xk<XH, 1, false>(z, B ? k.a1[8 - J] : k.b1[8 - J], t);           // a(d) = b(21 - d)
+        } else {
+            return pk_fma_xk<XH, 1, false>(z, B ? k.a2[9 - J] : k.b2[9 - J], t);
+        }
+    }
+    template <int J>
+    __device__ __forceinline__ void pair(const Dn3TwoK &k, pf2 z12, pf2 w12, float z0, float w0) {
+        pf2 t;
+        if constexpr (J < 9) t = p[J + 1]; else t = pf2{0.f, 0.f};
+        t = tap<1, false, J, 1>(k, z12, t);
+        if constexpr (J == 4) t.x = fma3<true>(k.h30, z0, t.x);      // the centre tap: d = 10 of step 1 is this pair's low half ...
+        t = tap<1, true, J, 0>(k, z12, t);
+        t = tap<2, false, J, 1>(k, w12, t);
+        if constexpr (J == 4) t.y = fma3<true>(k.h30, w0, t.y);      // ... and of step 2 its high half
+        t = tap<2, true, J, 0>(k, w12, t);
+        p[J] = t;
+        if constexpr (J < 9) pair<J + 1>(k, z12, w12, z0, w0);
+    }
+    // z: the triple of the first step as z0 and (z1, z2), w: of the second; returns (Dn3::push(z), Dn3::push(w))
+    __device__ __forceinline__ pf2 push2(const Dn3TwoK &k, float z0, pf2 z12, float w0, pf2 w12) {
+        pf2 out;
+        out.x = p[0].x;
+        out.y = fma3<true>(k.zb.y, z12.x, fma3<true>(k.za.y, z12.y, p[0].y));      // s'[0] = b1 z1 + (a1 z2 + s[1])
+        pair<0>(k, z12, w12, z0, w0);
+        return out;
+    }
+};
 // NiirBack for stage B of the wave pair: the four phase decimators as two packed pairs - (sin, cos) products | (carrier, its
 // derivative); the fifth (saturation) runs in stage A, which has the low-passed envelope at hand
 struct NiirBackPk {
