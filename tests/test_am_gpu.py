@@ -112,6 +112,34 @@ def test_proto_round_trip_vs_oracle(stack, size, std, first):
         assert stacks.rel_err(back[i], back_ref[i]) < TOL, (stack, i)
 
 
+@pytest.mark.parametrize('std,width,r', [('FRENCH_819', 320, (0, 0, 0)), ('BELGIAN_819', 1504, (1, 1, 0)), ('FRENCH_819', 456, (2, 0, 2)),
+                                         ('FRENCH_819', 608, (0, 2, 1)), ('FRENCH_819', 472, (1, 2, 2)), ('FRENCH_819', 336, (2, 2, 0)),
+                                         ('BELGIAN_819', 1600, (1, 1, 2)), ('FRENCH_819', 504, (0, 2, 2)), ('FRENCH_819', 568, (1, 2, 1)),
+                                         ('FRENCH_819', 552, (2, 2, 1))])
+def test_proto_streaming_kernels_every_alignment(std, width, r):
+    """The wave-pair kernels pinned ('rows') on widths whose three FilterFunction shifts leave every remainder r = 3 q - shift the interior
+    bodies are instantiated / branch for (round 5: band-pass and band-stop in stage A of the decoder, the low-pass in its stage B, the
+    band-stop in stage B of the encoder) - the parameters carry the (band-pass, band-stop, low-pass) remainders and are checked first."""
+    from oracle import cm_oracle_am as oa
+    size = (width, 7)
+    lc = line.LineConfig(size, getattr(line.LineStandard, std))
+    modem = am_stacks.STACKS['proto'](lc)
+    got_r = []
+    for f in (modem._extract_chroma_up, modem._remove_chroma_up, modem._chroma_up_post_demod_filter):
+        got_r.append(3 * (-(-int(f.shift) // 3)) - int(f.shift))
+    assert tuple(got_r) == r
+    rgb = testing.synthetic_rgb(2, size[1], size[0], seed=width)
+    im = image.ImageModem(modem, batch_invariant=True)          # = set_small_batch('rows') on the engine
+    comp = im.modulate_frames(rgb, first_frame=3)
+    comp_ref = oa.modulate_frames(modem, rgb.astype(numpy.float64), 3)
+    assert stacks.rel_err(comp, comp_ref) < TOL
+    comp32 = comp_ref.astype(numpy.float32)
+    back = im.demodulate_frames(comp32, first_frame=3)
+    back_ref = oa.demodulate_frames(modem, comp32.astype(numpy.float64), 3)
+    for i in range(2):
+        assert stacks.rel_err(back[i], back_ref[i]) < TOL, (std, width, i)
+
+
 def test_niir_components_unstripped_noise():
     """NiirModem.demodulate_components(..., strip_chroma=False) row by row on noise (a reference-generated vector)."""
     z = am_stacks.load('am_niir_components_noise')
