@@ -585,12 +585,14 @@ __global__ __launch_bounds__(64 * NW) void niir_demod_scan_kernel(const Geom g, 
     // sample m of the previous call's phasor / of this call's
     auto prev_at = [&](int m) __attribute__((always_inline)) -> double {
         if (first) return (m >= 0 && m < L) ? fmaf_(syn_s, syn[m], syn_c * syn[L + m]) : 0.0;
+        // (the three rows of a signal lie kRow apart: an address, not a choice among three pointers - with a run-time m that choice
+        // went through a pointer array in scratch memory and a flat load per sample)
         const int i = m >= 0 ? m / 3 : -1, j = m - 3 * i;
-        return (j == 0 ? VD0 : (j == 1 ? VD1 : VD2))[i];
+        return VD0[j * kRow + i];
     };
     auto own_at = [&](int m) __attribute__((always_inline)) -> double {
         const int i = m >= 0 ? m / 3 : -1, j = m - 3 * i;
-        return (j == 0 ? PD0 : (j == 1 ? PD1 : PD2))[i];
+        return PD0[j * kRow + i];
     };
     auto car_at = [&](int m) __attribute__((always_inline)) -> double { return alt ? own_at(m) : prev_at(m); };      // carrier_up (niir.py:117-124)
     auto hue_at = [&](int m) __attribute__((always_inline)) -> double { return alt ? prev_at(m) : own_at(m); };      // the hue-modulated signal
