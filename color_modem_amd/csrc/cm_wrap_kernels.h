@@ -84,6 +84,14 @@ __global__ __launch_bounds__(64, 2) void comb_wrap_back_kernel(const WrapBackArg
     const int wpos = ((lane >> CM_TILE_SWZ) & (kTile / 4 - 1)) << 2;
     const int W = g.W;
     const int sp = RT ? k.s_p : SP;
+    // RT: which of the SP window positions is the delay - as opaque scalars: compared against the literals 0 .. SP - 1, hipcc turns the
+    // select chain below back into a dynamic index and the three windows into 144 bytes of scratch memory per lane
+    int sel[SP];
+#pragma unroll
+    for (int j = 0; j < SP; ++j) {
+        sel[j] = j;
+        if (RT) asm volatile("" : "+s"(sel[j]));
+    }
     const int T = (g.Wp + sp + 3) & ~3;
     const int s_flush = (sp + 3) & 3;                    // the step of a body whose output sample n7 = t - sp ends a quad
     // interior bodies: 0 <= n7 and t < W - 1 for the four steps - no zero-extension, no latch, every output inside the row
@@ -114,7 +122,7 @@ __global__ __launch_bounds__(64, 2) void comb_wrap_back_kernel(const WrapBackArg
             if (RT) {                                              // ... = t - s_p: uniform selects instead of a dynamic index
 #pragma unroll
                 for (int j = 0; j < SP; ++j)
-                    if (sp == j) { y_d = yw[SP - j + s]; u_d = uw[SP - j + s]; v_d = vw[SP - j + s]; }
+                    if (sp == sel[j]) { y_d = yw[SP - j + s]; u_d = uw[SP - j + s]; v_d = vw[SP - j + s]; }
             }
             // backend.modulate_components(frame, line - 2 own_delay, 0, u, v) (QamModCore::step, cm_stages.h)
             float wu = 0.f, wv = 0.f;
