@@ -220,7 +220,12 @@ struct PassCfg {
     // (with the cut behind the detector low-pass, CM_QAM_LPF_IN_A, stage B of the two-line combs sheds the low-pass state and
     // its coefficients: CM_LCUT_DEPTH2_WAVES = 3 asks for 168 VGPRs there too)
     static constexpr bool kLcutCfg = CM_QAM_LPF_IN_A != 0 && FRONT_ == 0 && !BSF_ && DEPTH_ >= 2 && !S_::RT;
-    static constexpr int kPairWaves = (NOTCH_ || MINAVG_ || S_::NE >= 4 || S_::NP >= 2 || S_::RT) ? 2
+    // Round 5 measured the instances that sit just above 168 again (same-box A/Bs, profiles/r05_wrapped_fused.txt): capped at 168 the fused
+    // comb wrappers - PAL-D front end with two lines of history, Pal3DModem's two-level comb - spill 2 - 16 registers outside their interior
+    // bodies and run 9 - 11 % faster at 3 waves per SIMD; the run-time filter shape loses 4 - 6 % there and stays at 2.
+    static constexpr bool kWrapperCfg = !S_::RT && S_::NE < 4 && S_::NP < 2 && ((FRONT_ == 1 && DEPTH_ >= 2) || WRAP_);
+    static constexpr int kPairWaves = kWrapperCfg ? 3
+                                    : (NOTCH_ || MINAVG_ || S_::NE >= 4 || S_::NP >= 2 || S_::RT) ? 2
                                     : (DEPTH_ >= 2 ? (kLcutCfg ? CM_LCUT_DEPTH2_WAVES : 2) : 3);
     // which kernel structure runs this instance.  Since the luma delay ring (CM_LUMA_RING) every instance runs on the wave
     // pair - those with more per-lane state in stage B at 2 waves per SIMD (measured: Pal3D 2.92 -> 2.72 ms, Simple3DComb(
