@@ -222,8 +222,9 @@ struct PassCfg {
     static constexpr bool kLcutCfg = CM_QAM_LPF_IN_A != 0 && FRONT_ == 0 && !BSF_ && DEPTH_ >= 2 && !S_::RT;
     // Round 5 measured the instances that sit just above 168 again (same-box A/Bs, profiles/r05_wrapped_fused.txt): capped at 168 the fused
     // comb wrappers - PAL-D front end with two lines of history, Pal3DModem's two-level comb - spill 2 - 16 registers outside their interior
-    // bodies and run 9 - 11 % faster at 3 waves per SIMD; the run-time filter shape loses 4 - 6 % there and stays at 2.
-    static constexpr bool kWrapperCfg = !S_::RT && S_::NE < 4 && S_::NP < 2 && ((FRONT_ == 1 && DEPTH_ >= 2) || WRAP_);
+    // bodies and run 9 - 11 % faster at 3 waves per SIMD, the one-line decoders with a notch on the NTSC shape (169 - 171 VGPRs, one spill) 7 %;
+    // the run-time filter shape loses 4 - 6 % there and stays at 2, the other instances are indifferent.
+    static constexpr bool kWrapperCfg = !S_::RT && S_::NE < 4 && S_::NP < 2 && ((FRONT_ == 1 && DEPTH_ >= 2) || WRAP_ || (DEPTH_ == 1 && NOTCH_ && !MINAVG_));
     static constexpr int kPairWaves = kWrapperCfg ? 3
                                     : (NOTCH_ || MINAVG_ || S_::NE >= 4 || S_::NP >= 2 || S_::RT) ? 2
                                     : (DEPTH_ >= 2 ? (kLcutCfg ? CM_LCUT_DEPTH2_WAVES : 2) : 3);
