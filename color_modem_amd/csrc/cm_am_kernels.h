@@ -748,11 +748,13 @@ struct NiirModArgs {
 // saturation-weighted mean hue of both calls and the previous call's saturation (previous call = neighbouring lane).
 // The three input planes arrive through 16-sample LDS tiles (global_load_lds, as the QAM encoders; round 2 read them with one
 // 16-byte load per lane and plane).  U8: the ImageModem byte boundary fused in (interleaved RGB bytes in, composite bytes out).
-template <int DEPTH, bool U8 = false>
+// RING: slots of the luma delay ring (8 / 16 / 32, the launch picks the smallest above the pre-correction shift: round 5 - with the fixed
+// 32 slots = 8 KiB a workgroup of this one-wave kernel took 24.5 KiB of LDS, six waves per CU)
+template <int DEPTH, bool U8 = false, int RING = kAmRing>
 __global__ __launch_bounds__(64, 2) void niir_mod_kernel(const NiirModArgs args) {
     constexpr int kTile = 16;
     constexpr int kIn = U8 ? kInTile3Bytes / 4 : kLdsIn3, kOut = U8 ? 64 * kOutTileU8 / 4 : 64 * kTile;
-    __shared__ __attribute__((aligned(16))) float lds_store[kIn + kOut + kAmRingFloats];
+    __shared__ __attribute__((aligned(16))) float lds_store[kIn + kOut + RING * 64];
     lds_float *itile = (lds_float *)lds_store;
     lds_float *otile_base = itile + kIn;
     lds_float *ring = otile_base + kOut;
@@ -778,7 +780,7 @@ __global__ __launch_bounds__(64, 2) void niir_mod_kernel(const NiirModArgs args)
     const int wpos = ((lane >> CM_TILE_SWZ) & (kTile / 4 - 1)) << 2;
     const int W = g.W, s_c = k.s_c;
     const int T = (g.Wp + s_c + 3) & ~3;
-    for (int j = 0; j < kAmRing; ++j) ring[j * 64 + lane] = 0.f;
+    for (int j = 0; j < RING; ++j) ring[j * 64 + lane] = 0.f;
     const float *np = args.noise ? args.noise + 2LL * lc.call * W : nullptr;
     f4 cur[3], nxt[3], nz[2] = {f4{0.f, 0.f, 0.f, 0.f}, f4{0.f, 0.f, 0.f, 0.f}};
     first_tile3<U8>(g, itile, rp, lane, nxt);
@@ -809,8 +811,8 @@ __global__ __launch_bounds__(64, 2) void niir_mod_kernel(const NiirModArgs args)
                 niir_offset_pixel<U8>(k.ed, r, gg, b, db, dr, nz[0][s], nz[1][s], np != nullptr);
             }
             if (t >= W) db = dr = 0.f;                                    // beyond the row the filter is fed its last sample anyway
-            ring[(t & (kAmRing - 1)) * 64 + lane] = y;
-            const float y_d = ring[((t - s_c) & (kAmRing - 1)) * 64 + lane];
+            ring[(t & (RING - 1)) * 64 + lane] = y;
+            const float y_d = ring[((t - s_c) & (RING - 1)) * 64 + lane];
             const int n = t - s_c;
             int nc = n < 0 ? 0 : (n > W - 1 ? W - 1 : n);
             const f2 cs = ((const_f2 *)args.a.carrier)[nc];

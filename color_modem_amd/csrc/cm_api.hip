@@ -2291,11 +2291,18 @@ int am_launch_mod(const cm_am_plan *p, Geom g, int64_t first_frame, hipStream_t 
         am_geom(p, first_frame, a.a);
         a.k = p->nm;
         a.noise = noise;
-        if (u8) {
-            if (depth) hipLaunchKernelGGL((niir_mod_kernel<1, true>), dim3((int)blocks), dim3(64), 0, stream, a);
-            else hipLaunchKernelGGL((niir_mod_kernel<0, true>), dim3((int)blocks), dim3(64), 0, stream, a);
-        } else if (depth) hipLaunchKernelGGL((niir_mod_kernel<1, false>), dim3((int)blocks), dim3(64), 0, stream, a);
-        else hipLaunchKernelGGL((niir_mod_kernel<0, false>), dim3((int)blocks), dim3(64), 0, stream, a);
+        // the luma delay ring in the smallest power of two above the pre-correction shift (plan creation checked s_c < kAmRing)
+        auto launch = [&](auto ring_tag) {
+            constexpr int RING = decltype(ring_tag)::value;
+            if (u8) {
+                if (depth) hipLaunchKernelGGL((niir_mod_kernel<1, true, RING>), dim3((int)blocks), dim3(64), 0, stream, a);
+                else hipLaunchKernelGGL((niir_mod_kernel<0, true, RING>), dim3((int)blocks), dim3(64), 0, stream, a);
+            } else if (depth) hipLaunchKernelGGL((niir_mod_kernel<1, false, RING>), dim3((int)blocks), dim3(64), 0, stream, a);
+            else hipLaunchKernelGGL((niir_mod_kernel<0, false, RING>), dim3((int)blocks), dim3(64), 0, stream, a);
+        };
+        if (p->nm.s_c < 8) launch(std::integral_constant<int, 8>());
+        else if (p->nm.s_c < 16) launch(std::integral_constant<int, 16>());
+        else launch(std::integral_constant<int, 32>());
     } else {
         if (noise) return fail(CM_ERR_INVALID, "noise planes are a NIIR encoder input (niir.py:45-46)");
         {
