@@ -86,10 +86,13 @@ __device__ __forceinline__ const float *am_out_row(const Geom &g, const LaneCall
 }
 constexpr int kProtoIT = 8;
 inline __host__ __device__ int proto_ring_slots(int dly) { return dly < 8 ? 8 : (dly < 16 ? 16 : 32); }
+// the decoder's luma ring is read BEFORE it is written in a step, so a delay of dly samples needs dly slots, not dly + 1 (dly = 8 at the
+// standard rates: 8 slots instead of 16 - with the shorter row delay below 26 KiB of LDS: six workgroups per CU, round 5)
+inline __host__ __device__ int proto_demod_ring_slots(int dly) { return dly <= 8 ? 8 : (dly <= 16 ? 16 : 32); }
 // floats of dynamic LDS: input tile (two buffers) | hand-over (2 buffers x 6 quantities) | luma delay ring | the row's last 16 samples (the
 // interpolator's phase 0 is x[t - 10]) | output tile
 template <bool U8> inline int proto_pair_lds_floats(int dly) {
-    return 2 * AmInTile<U8>::kBufFloats + 2 * 6 * 128 + proto_ring_slots(dly) * 64 + 8 * 128 + (U8 ? 64 * 3 * 16 / 4 : 3 * 64 * 16);
+    return 2 * AmInTile<U8>::kBufFloats + 2 * 6 * 128 + proto_demod_ring_slots(dly) * 64 + 4 * 128 + (U8 ? 64 * 3 * 16 / 4 : 3 * 64 * 16);
 }
 
 // Stage A's interior bodies: the six aligned samples of one filter (H 0: |band-pass|, 1: band-stop) of a body into their hand-over rows,
@@ -119,13 +122,13 @@ __global__ __launch_bounds__(128, 2) void proto_demod_pair_kernel(const ProtoDem
     const int W = g.W, L = 3 * W;
     const int lat_c = ProtoDemod<float>::lat_chroma(k), lat_y = ProtoDemod<float>::lat_luma(k);
     const int dly = lat_c - lat_y;                       // luma waits for the chroma path
-    const int nring = proto_ring_slots(dly);
+    const int nring = proto_demod_ring_slots(dly);
     const int T = (g.Wp + lat_c + 1) & ~1;
     lds_float *itile = lds;                              // two buffers: tile c lives in buffer c & 1
     lds_float *hand = itile + 2 * AmInTile<U8>::kBufFloats;
     lds_float *ring = hand + 2 * Q * 128;
-    lds_float *xdel = ring + nring * 64;                 // 8 blocks of 2 samples per lane: stage A's own delay of the row
-    lds_float *otile_base = xdel + 8 * 128;
+    lds_float *xdel = ring + nring * 64;                 // 4 blocks of 2 samples per lane: stage A's own delay of the row (+ one block in registers)
+    lds_float *otile_base = xdel + 4 * 128;
     // interior bodies: t >= lat_c (every filter behind its delay), t + 1 < W - 6 (the end-of-row latches stay away)
     int t_mid0 = (lat_c + 1) & ~1, t_mid1 = (W - 8) & ~1;
     if (t_mid1 <= t_mid0) t_mid0 = t_mid1 = 0;
@@ -139,7 +142,8 @@ __global__ __launch_bounds__(128, 2) void proto_demod_pair_kernel(const ProtoDem
         Up3<float> up;
         FF3<float, 3> ext, rem;
         up.reset(); ext.reset(); rem.reset();
-        for (int j = 0; j < 8; ++j) *(lds_f2 *)(xdel + j * 128 + lane * 2) = f2{0.f, 0.f};
+        for (int j = 0; j < 4; ++j) *(lds_f2 *)(xdel + j * 128 + lane * 2) = f2{0.f, 0.f};
+        f2 xlast = {0.f, 0.f};       // the previous body's samples: they go to the ring a body late, the slot read just before holds the block of five bodies ago
         am_fill<U8>(g, itile, xp, 0, lane);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_wave_barrier();
@@ -159,8 +163,9 @@ __global__ __launch_bounds__(128, 2) void proto_demod_pair_kernel(const ProtoDem
         };
         // hand-over rows: quantity q (|band-pass| 0..2, band-stop 3..5) of step s in row 2 q + s of the body's buffer
         auto edge_body = [&](int tb) __attribute__((always_inline)) {
-            const f2 xd = *(const lds_f2 *)(xdel + (((tb >> 1) + 3) & 7) * 128 + lane * 2);       // x[tb - 10], x[tb - 9]: written five bodies ago
-            *(lds_f2 *)(xdel + ((tb >> 1) & 7) * 128 + lane * 2) = xv;
+            const f2 xd = *(const lds_f2 *)(xdel + ((tb >> 1) & 3) * 128 + lane * 2);             // x[tb - 10], x[tb - 9]: written four bodies ago, a body old then
+            *(lds_f2 *)(xdel + ((tb >> 1) & 3) * 128 + lane * 2) = xlast;
+            xlast = xv;
             lds_float *slot = hand + ((tb >> 1) & 1) * (Q * 128) + lane;
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
@@ -192,8 +197,9 @@ __global__ __launch_bounds__(128, 2) void proto_demod_pair_kernel(const ProtoDem
             // registers per value of r: one uniform three-way branch per filter and body around the six stores, no instruction else
             const int re = k.ge.r, rr = k.gr.r;
             for (; tb < t_mid1; tb += 2) {
-                const f2 xd_ = *(const lds_f2 *)(xdel + (((tb >> 1) + 3) & 7) * 128 + lane * 2);
-                *(lds_f2 *)(xdel + ((tb >> 1) & 7) * 128 + lane * 2) = xv;
+                const f2 xd_ = *(const lds_f2 *)(xdel + ((tb >> 1) & 3) * 128 + lane * 2);
+                *(lds_f2 *)(xdel + ((tb >> 1) & 3) * 128 + lane * 2) = xlast;
+                xlast = xv;
                 const pf2 xd = pf2{xd_.x, xd_.y}, xs = pf2{xv.x, xv.y};
                 lds_float *slot = hand + ((tb >> 1) & 1) * (Q * 128) + lane;
                 pf2 raw[8];                                // raw outputs -2 .. 5 of this body's two groups (.x: |band-pass|, .y: band-stop)
@@ -261,8 +267,9 @@ __global__ __launch_bounds__(128, 2) void proto_demod_pair_kernel(const ProtoDem
             post.template step<AM_FORM_GEN, EDGE, false, RP>(k.post, k.gp, L, n1 - k.ge.q, c1, c2);
             const pf2 d = dn.push(kp, pf2{c2[0], hq[3][s]}, pf2{c2[1], hq[4][s]}, pf2{c2[2], hq[5][s]});
             const float chroma = fmaf_(k.chroma_gain, d.x, -1.f), luma = k.luma_gain * d.y;
+            const float luma_w = ring[((t - dly) & (nring - 1)) * 64 + lane];      // read first: with dly = nring this is the slot written next
             ring[(t & (nring - 1)) * 64 + lane] = luma;
-            const float luma_d = ring[((t - dly) & (nring - 1)) * 64 + lane];
+            const float luma_d = dly ? luma_w : luma;
             const float prev = lane_from(idx1, chroma) * w_prev;
             const float dr = alt ? prev : chroma, db = alt ? chroma : prev;             // protosecam.py:105-108
             Rgb<float> o;
@@ -302,7 +309,7 @@ struct ProtoModArgs {
 //                     global store
 // ---------------------------------------------------------------------------------------------------------------------
 template <bool U8> inline int proto_mod_pair_lds_floats(int dly) {
-    return (U8 ? kInTile3Bytes / 4 : kLdsIn3) + proto_ring_slots(dly) * 64 + 16 * 64 + 2 * 5 * 256 + (U8 ? 64 * kOutTileU8 / 4 : 64 * 16);
+    return (U8 ? kInTile3Bytes / 4 : kLdsIn3) + proto_ring_slots(dly) * 64 + 8 * 64 + 2 * 5 * 256 + (U8 ? 64 * kOutTileU8 / 4 : 64 * 16);
 }
 
 // U8: the ImageModem byte boundary fused in (image.py:27-56): interleaved RGB bytes in, composite bytes out (as the QAM encoders)
@@ -325,8 +332,8 @@ __global__ __launch_bounds__(128, 2) void proto_mod_pair_kernel(const ProtoModAr
     const int T = (g.Wp + lat + 3) & ~3;
     lds_float *itile = lds;
     lds_float *ring = itile + (U8 ? kInTile3Bytes / 4 : kLdsIn3);
-    lds_float *ydel = ring + nring * 64;                 // the luma fed to the interpolator, 16 steps back (its phase 0 is the sample of ten steps ago)
-    lds_float *hand = ydel + 16 * 64;
+    lds_float *ydel = ring + nring * 64;                 // the luma fed to the interpolator, 8 steps back (its phase 0 is the sample of ten steps ago:
+    lds_float *hand = ydel + 8 * 64;                     // two more in registers - 2 KiB of LDS less: five instead of four workgroups per CU, round 5)
     lds_float *otile_base = hand + 2 * Q * 256;
     // interior bodies: t >= lat + 4 (both paths behind their delays), t + 3 < W - 4
     int t_mid0 = (lat + 4 + 3) & ~3, t_mid1 = (W - 8) & ~3;
@@ -352,7 +359,8 @@ __global__ __launch_bounds__(128, 2) void proto_mod_pair_kernel(const ProtoModAr
         pre.reset();
         up.reset();
         for (int j = 0; j < nring; ++j) ring[j * 64 + lane] = 0.f;
-        for (int j = 0; j < 16; ++j) ydel[j * 64 + lane] = 0.f;
+        for (int j = 0; j < 8; ++j) ydel[j * 64 + lane] = 0.f;
+        float yd1 = 0.f, yd2 = 0.f;
         f4 cur[3], nxt[3];
         first_tile3<U8>(g, itile, rp, lane, nxt);
         auto body = [&](auto edge_tag, int tb) __attribute__((always_inline)) {
@@ -389,8 +397,11 @@ __global__ __launch_bounds__(128, 2) void proto_mod_pair_kernel(const ProtoModAr
                 const int i_y = t - d_y;
                 if (ka.luma_filter) {
                     const float y_fed = (!EDGE || (i_y >= 0 && i_y < ka.width)) ? y_in : 0.f;
-                    const float y_del = ydel[((t - kAmHalf) & 15) * 64 + lane];
-                    ydel[(t & 15) * 64 + lane] = y_fed;
+                    const float y8 = ydel[(t & 7) * 64 + lane];       // read before written: the sample of eight steps ago
+                    ydel[(t & 7) * 64 + lane] = y_fed;
+                    const float y_del = yd2;
+                    yd2 = yd1;
+                    yd1 = y8;
                     if (EDGE) {
                         float u[3];
                         up.template push<false>(ka.taps, y_fed, y_del, u);

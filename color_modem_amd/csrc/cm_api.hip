@@ -2365,7 +2365,7 @@ int cm_am_plan_create(const cm_am_desc *desc, cm_am_plan **out) {
     } else if (!build_proto_demod_k<float>(*desc, p->pd, err)) p->demod_error = err;
     else {
         const int dly = ProtoDemod<float>::lat_chroma(p->pd) - ProtoDemod<float>::lat_luma(p->pd);
-        if (dly < 0 || dly >= kAmRing) p->demod_error = "decoder: the luma delay does not fit the delay ring";
+        if (dly < 0 || dly > kAmRing) p->demod_error = "decoder: the luma delay does not fit the delay ring";
     }
     if (desc->kind == CM_AM_NIIR) {
     } else if (!build_proto_mod_k<float>(*desc, p->pm, err)) p->mod_error = err;
