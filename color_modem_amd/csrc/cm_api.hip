@@ -23,6 +23,13 @@
 #define CM_AM_PART (CM_PART == 0 || CM_PART == 2)
 #define CM_SCAN_PART (CM_PART == 0 || CM_PART == 3)
 #define CM_SHAPES_PART (CM_PART == 0 || CM_PART == 4)
+// 5 .. 7 (round 6): the tuned decoder instances of the wide rasters (cm_shapes_wide.h, generated) behind cm_host::select_wide_* - 5: the PAL-D front end,
+// 6: the QAM front end on the PAL shapes, 7: the NTSC shapes
+#define CM_WIDE_PALD_PART (CM_PART == 0 || CM_PART == 5)
+#define CM_WIDE_PAL_QAM_PART (CM_PART == 0 || CM_PART == 6)
+#define CM_WIDE_NTSC_PART (CM_PART == 0 || CM_PART == 7)
+#define CM_WIDE_PART (CM_WIDE_PALD_PART || CM_WIDE_PAL_QAM_PART || CM_WIDE_NTSC_PART)
+#define CM_DEMOD_PART (CM_MAIN_PART || CM_SHAPES_PART || CM_WIDE_PART)      /* parts that launch demod_pair_kernel instances */
 
 #include "../../include/color_modem_hip.h"
 #include "cm_kernels.h"
@@ -32,6 +39,7 @@
 #include "cm_mac_kernels.h"
 #endif
 #include "cm_plan.h"
+#include "cm_shapes_wide.h"
 #if CM_AM_PART
 #include "cm_am_kernels.h"
 #endif
@@ -74,6 +82,10 @@ int scan_launch_secam_demod(int c1, bool u8, int device, const ScanSecamK *k, co
 int scan_launch_wrap_back(int c1, bool u8, int device, const ScanModK *k, const ScanWrapArgs &a, const Geom &g, hipStream_t stream);
 // the decoder instances of every filter-set shape but PAL-BG's (CM_PART 4)
 bool select_other_shapes(cm_plan *p, const cm_plan_desc &d, std::string &err);
+// the tuned instances of the wide rasters (CM_PART 5 .. 7): 1 = selected, 0 = failed (err), -1 = no tuned instance for this plan (the run-time shape takes it)
+int select_wide_pald(cm_plan *p, const cm_plan_desc &d, std::string &err);
+int select_wide_pal_qam(cm_plan *p, const cm_plan_desc &d, std::string &err);
+int select_wide_ntsc(cm_plan *p, const cm_plan_desc &d, std::string &err);
 }  // namespace cm_host
 using cm_host::g_error;
 using cm_host::g_pointer_check;
@@ -133,7 +145,7 @@ int check_device(int plan_device, const void *a, const void *b) {
         if (e_ != hipSuccess) return fail(code, std::string(#expr) + ": " + hipGetErrorString(e_)); \
     } while (0)
 
-#if CM_MAIN_PART || CM_SHAPES_PART
+#if CM_DEMOD_PART
 // One launch = first-line workgroups [0, n_first) followed by the main pass's workgroups.
 typedef int (*LaunchFn)(const Geom &gm, const void *km, const Geom &gf, const void *kf, int n_first, int n_main,
                         hipStream_t);
@@ -226,11 +238,11 @@ struct Pass {
     int depth = 0;                 // halo lanes of the kernel instance
     std::string name;
 };
-#endif  // CM_MAIN_PART || CM_SHAPES_PART
+#endif  // CM_DEMOD_PART
 
 }  // namespace
 
-#if CM_MAIN_PART || CM_SHAPES_PART
+#if CM_DEMOD_PART
 typedef int (*ModLaunchFn)(const Geom &g, const void *k, int blocks, hipStream_t);
 
 // calls up to which the decoders' scan kernels beat the streaming kernels (profiles/r03_batch_curve.txt)
@@ -284,9 +296,9 @@ struct cm_plan {
     SecamModLaneK<float, double> *sm_lanes = nullptr;
 };
 
-#endif  // CM_MAIN_PART || CM_SHAPES_PART
+#endif  // CM_DEMOD_PART
 namespace {
-#if CM_MAIN_PART || CM_SHAPES_PART
+#if CM_DEMOD_PART
 
 template <class S>
 bool make_pass(const cm_plan_desc &d, bool pald, bool bsf, const cm_lane_table &tb, Pass &pass, std::string &err, bool pair, int depth = 0) {
@@ -305,8 +317,8 @@ bool make_pass(const cm_plan_desc &d, bool pald, bool bsf, const cm_lane_table &
                            : (lcut ? (wrap ? luma_delay_max_latency<S, 0, true, 1>() : luma_delay_max_latency<S, 0, true>()) : luma_delay_max_latency<S, 0>());
         if (wrap && !lcut && !S::RT) { err = "the two-level comb is built on the depth-2 QAM instances"; return false; }
         const int ring_win = pald ? ring_window<S, 1>() : (lcut ? ring_window<S, 0, true>() : ring_window<S, 0>());
-        if (CM_LUMA_RING && !bsf && pair && lat_out > ring_max) { err = "pipeline latency beyond the luma delay ring"; return false; }
-        if (CM_LUMA_RING && !bsf && pair && lat_out < 10 + ring_win) { err = "pipeline latency below the luma window"; return false; }
+        if (CM_LUMA_RING && !S::NORING && !bsf && pair && lat_out > ring_max) { err = "pipeline latency beyond the luma delay ring"; return false; }
+        if (CM_LUMA_RING && !S::NORING && !bsf && pair && lat_out < 10 + ring_win) { err = "pipeline latency below the luma window"; return false; }
     }
     pass.k.resize(sizeof(k));
     std::memcpy(pass.k.data(), &k, sizeof(k));
@@ -497,7 +509,7 @@ bool select_for_shape(cm_plan *p, const cm_plan_desc &d, const char *sys, std::s
 #endif
 }
 
-#endif  // CM_MAIN_PART || CM_SHAPES_PART
+#endif  // CM_DEMOD_PART
 #if CM_SHAPES_PART
 // Run-time shape (SysAny): any sampling rate whose filters fit 4 / 3 / 3 / 2 sections and a pre-correction shift <= 12.
 // The fused byte boundary exists where the tuned shapes have it (not with notch / minavg).
@@ -617,6 +629,12 @@ bool select_other_shapes(cm_plan *p, const cm_plan_desc &d, std::string &err) {
     if (!pald && match(signature_of<SysNtscI>())) return select_for_shape<SysNtscI, false, true>(p, d, "ntsc-i", err);
     if (!pald && match(signature_of<SysNtscSq>())) return select_for_shape<SysNtscSq, false, true>(p, d, "ntsc at 640 / 704 samples per line", err);
     if (!pald && match(signature_of<SysNtscA>())) return select_for_shape<SysNtscA, false, true>(p, d, "ntsc-a", err);
+    {   // the tuned shapes of the wide rasters (CM_PART 5 .. 7); -1: none of them serves this plan
+        int r = select_wide_pald(p, d, err);
+        if (r < 0) r = select_wide_pal_qam(p, d, err);
+        if (r < 0) r = select_wide_ntsc(p, d, err);
+        if (r >= 0) return r == 1;
+    }
 #endif
     if (fits_any(want) && (!first || fits_any(want_first))) return select_any(p, d, err);
     char buf[256];
@@ -630,6 +648,113 @@ bool select_other_shapes(cm_plan *p, const cm_plan_desc &d, std::string &err) {
 }  // namespace cm_host
 namespace {
 #endif  // CM_SHAPES_PART
+#if CM_WIDE_PART
+// ---- the tuned shapes of the wide rasters (round 6; cm_shapes_wide.h, written by tools/gen_wide_shapes.py) -----------------------
+// Every image width has its own sampling rate and with it its own filter orders and FilterFunction shift parities (ref line.py:49-55,
+// utils.py:44-64).  Until round 6 only 640 / 704 / 720 / 768 samples per line had kernel instances with these as compile-time constants and
+// every other width ran on the run-time shape (SysAny: padded sections, run-time parities, 41 KiB of LDS, 2 waves per SIMD: 65 - 80 % of
+// the tuned speed).  The instances here cover the plain stacks of the common wide rasters - PalDModem, Pal3DModem / the two-line combs,
+// PalSModem, NtscModem, NtscCombModem, Simple3DCombModem(NtscCombModem) and the fused comb wrappers around PalDModem / Pal3DModem - floats
+// and bytes; notch / minavg stay on the run-time shape there.
+enum WideKind { WIDE_PALD, WIDE_PAL_QAM, WIDE_NTSC };
+template <class S, class SF, WideKind KIND>
+int select_wide(cm_plan *p, const cm_plan_desc &d, const char *sys, std::string &err) {
+    const bool pald = d.pipeline == CM_PIPE_PAL_D;
+    const bool bsf = d.main_luma_bandstop != 0;
+    const bool first = d.first_is_plain != 0;
+    const int depth = d.depth, wrap = d.demod_main.wrap_mode;
+    if (d.notch.n_sections != 0 || d.chroma_average == CM_AVG_MIN) return -1;
+    typedef PassCfg<SF, FRONT_QAM, true, 0, 8> First;
+    typedef PassCfg<SF, FRONT_QAM, true, 0, 16, true> FirstU8;
+    std::string what;
+    p->fn = nullptr;
+    p->fn_u8 = nullptr;
+    if constexpr (KIND == WIDE_PALD) {
+        if (!pald || wrap) return -1;
+        if (depth == 1 && first && !d.skip_calls) {
+            p->fn = launch_demod<PassCfg<S, FRONT_PALD, false, 1, 16>, First>;
+            p->fn_u8 = launch_demod<PassCfg<S, FRONT_PALD, false, 1, 16, true>, FirstU8>;
+            p->main.depth = 1; what = "pal-d front, depth 1 | plain first line";
+        } else if (depth == 2 && !first && d.skip_calls == 2) {
+            p->fn = launch_demod<PassCfg<S, FRONT_PALD, false, 2, 16>, NoPass>;
+            p->fn_u8 = launch_demod<PassCfg<S, FRONT_PALD, false, 2, 16, true>, NoPass>;
+            p->main.depth = 2; what = "pal-d front, depth 2 (wrapped comb, calls k >= 2)";
+        } else return -1;
+    } else {
+        if (pald || d.skip_calls) return -1;
+        if (wrap) {
+            if constexpr (KIND == WIDE_PAL_QAM) {
+                if (bsf || first || depth != 3 || (wrap != 1 && wrap != 2)) return -1;
+                p->fn = launch_demod<PassCfg<S, FRONT_QAM, false, 2, 16, false, false, false, true>, NoPass>;
+                p->fn_u8 = launch_demod<PassCfg<S, FRONT_QAM, false, 2, 16, true, false, false, true>, NoPass>;
+                p->main.depth = 3; what = std::string("qam front, depth 2 | ") + (wrap == 2 ? "minavg" : "avg") + " of consecutive calls (two-level comb)";
+            } else return -1;
+        } else if (bsf) {
+            if (depth != 0 || first) return -1;
+            p->fn = launch_demod<PassCfg<S, FRONT_QAM, true, 0, 16>, NoPass>;
+            p->fn_u8 = launch_demod<PassCfg<S, FRONT_QAM, true, 0, 16, true>, NoPass>;
+            p->main.depth = 0; what = "qam front + band-stop, depth 0";
+        } else if (first) {
+            if constexpr (KIND == WIDE_NTSC) {
+                if (depth != 1) return -1;
+                p->fn = launch_demod<PassCfg<S, FRONT_QAM, false, 1, 16>, First>;
+                p->fn_u8 = launch_demod<PassCfg<S, FRONT_QAM, false, 1, 16, true>, FirstU8>;
+                p->main.depth = 1; what = "qam front, depth 1 | plain first line";
+            } else return -1;
+        } else {
+            if (depth > 2) return -1;
+            p->fn = launch_demod<PassCfg<S, FRONT_QAM, false, 2, 16>, NoPass>;
+            p->fn_u8 = launch_demod<PassCfg<S, FRONT_QAM, false, 2, 16, true>, NoPass>;
+            p->main.depth = 2; what = "qam front, depth 2";
+        }
+    }
+    p->pair = true;
+    p->main.name = std::string("demod_pair_kernel<") + sys + ": " + what + ">";
+    return make_passes<S, SF>(p, d, pald, bsf, first, err) ? 1 : 0;
+}
+// does the plan ask for exactly this shape?  (the passes that ignore the band-stop - no band-stop luma, no plain first line - match any)
+inline bool wide_match(const cm_plan_desc &d, bool pald, SysSignature have) {
+    const SysSignature want = signature_wanted(d, pald);
+    if (!d.main_luma_bandstop && !d.first_is_plain) { have.nr = want.nr; have.odd_r = want.odd_r; }
+    return same_signature(want, have);
+}
+}  // namespace
+namespace cm_host {
+#if CM_WIDE_PALD_PART
+int select_wide_pald(cm_plan *p, const cm_plan_desc &d, std::string &err) {
+    if (d.pipeline != CM_PIPE_PAL_D) return -1;
+    const SysSignature want_first = signature_wanted(d, false);
+#define CM_X(S, SF, LABEL) \
+    if (wide_match(d, true, signature_of<S>()) && (!d.first_is_plain || same_signature(want_first, signature_of<SF>()))) \
+        return select_wide<S, SF, WIDE_PALD>(p, d, LABEL, err);
+    CM_WIDE_PALD_SHAPES(CM_X)
+#undef CM_X
+    return -1;
+}
+#endif
+#if CM_WIDE_PAL_QAM_PART
+int select_wide_pal_qam(cm_plan *p, const cm_plan_desc &d, std::string &err) {
+    if (d.pipeline == CM_PIPE_PAL_D) return -1;
+#define CM_X(S, LABEL) \
+    if (wide_match(d, false, signature_of<S>())) return select_wide<S, S, WIDE_PAL_QAM>(p, d, LABEL, err);
+    CM_WIDE_PAL_QAM_SHAPES(CM_X)
+#undef CM_X
+    return -1;
+}
+#endif
+#if CM_WIDE_NTSC_PART
+int select_wide_ntsc(cm_plan *p, const cm_plan_desc &d, std::string &err) {
+    if (d.pipeline == CM_PIPE_PAL_D) return -1;
+#define CM_X(S, LABEL) \
+    if (wide_match(d, false, signature_of<S>())) return select_wide<S, S, WIDE_NTSC>(p, d, LABEL, err);
+    CM_WIDE_NTSC_SHAPES(CM_X)
+#undef CM_X
+    return -1;
+}
+#endif
+}  // namespace cm_host
+namespace {
+#endif  // CM_WIDE_PART
 #if CM_MAIN_PART
 // Pick the kernel instance (main pass + optional plain first-line pass in one launch): the PAL-BG shapes here, every other shape in CM_PART 4.
 bool select_kernels(cm_plan *p, const cm_plan_desc &d, std::string &err) {

@@ -199,6 +199,16 @@ __device__ __forceinline__ const float *ptr_from(int byte_index, const float *p)
 #ifndef CM_LCUT_DEPTH2_WAVES
 #define CM_LCUT_DEPTH2_WAVES 3
 #endif
+// the PAL-D front end on the shapes of the wide rasters (cm_shapes_wide.h): waves per SIMD the instances are compiled for.  Their luma delay
+// ring (30 - 34 KiB of LDS with it) leaves room for five or four workgroups per CU, and measured (profiles/r06_wide_shapes.txt) the 168-register
+// cap of 3 waves per SIMD - 8 to 72 bytes of scratch - loses to 2 waves per SIMD without spills from 1024 samples per line on (1280: 124 -> 130
+// Gpixel/s, 1920: 116 -> 120); the fused wrapper instances (two lines of history) of the 800 - 1024 rasters are the exception (118 -> 120 / 108 -> 111)
+#ifndef CM_WIDE_PALD_WAVES
+#define CM_WIDE_PALD_WAVES 2
+#endif
+#ifndef CM_WIDE_PALD_UP2     /* ... and whether their stage A runs the third half-band chain two steps at a time (HalfbandUp2Pk), which needs the registers of 2 waves per SIMD */
+#define CM_WIDE_PALD_UP2 0
+#endif
 // WRAP_: two-level comb (round 5; SimpleCombModem / Simple3DCombModem around Pal3DModem, comb.py:96-113 over pal.py:180-234): the lane
 // tables are the inner decoder's, and stage B averages (Geom::wrap_mode 1) or min-averages (2) the (u, v) they give with the (u, v) the
 // neighbouring lane - the previous call of the run - formed the same way, one step later in the stream; DEPTH_ + 1 halo lanes.
@@ -225,7 +235,8 @@ struct PassCfg {
     // bodies and run 9 - 11 % faster at 3 waves per SIMD, the one-line decoders with a notch on the NTSC shape (169 - 171 VGPRs, one spill) 7 %;
     // the run-time filter shape loses 4 - 6 % there and stays at 2, the other instances are indifferent.
     static constexpr bool kWrapperCfg = !S_::RT && S_::NE < 4 && S_::NP < 2 && ((FRONT_ == 1 && DEPTH_ >= 2) || WRAP_ || (DEPTH_ == 1 && NOTCH_ && !MINAVG_));
-    static constexpr int kPairWaves = kWrapperCfg ? 3
+    static constexpr int kPairWaves = (S_::WIDE && FRONT_ == 1) ? ((DEPTH_ >= 2 && S_::SP <= 3) ? 3 : CM_WIDE_PALD_WAVES)
+                                    : kWrapperCfg ? 3
                                     : (NOTCH_ || MINAVG_ || S_::NE >= 4 || S_::NP >= 2 || S_::RT) ? 2
                                     : (DEPTH_ >= 2 ? (kLcutCfg ? CM_LCUT_DEPTH2_WAVES : 2) : 3);
     // which kernel structure runs this instance.  Since the luma delay ring (CM_LUMA_RING) every instance runs on the wave
@@ -811,7 +822,7 @@ constexpr int kMidRing = 2 * 2 * 64 * 4;    // floats: [buffer][even | odd][lane
 #endif
 // band-stop luma ring of the pair kernels, written by A and read by B (lat_out - lat_luma + up to 12) steps later: 32 slots
 // for the tuned shapes, 64 for the run-time shape (high sampling rates; it runs 4 workgroups per CU, so the LDS is there)
-template <class S> constexpr int luma_ring_slots() { return S::RT ? 64 : 32; }
+template <class S> constexpr int luma_ring_slots() { return S::YS; }
 
 #ifndef CM_QAM_SHORT_RING
 #define CM_QAM_SHORT_RING 1
@@ -827,7 +838,7 @@ constexpr int kLumaSlots = 2 * 64 * 4;      // floats: [buffer][lane][4 steps] l
 // front end): its ring is sized for that, so that those instances fit six workgroups per CU as well (25 instead of 30 KiB).
 // X: extra steps of output latency (PassCfg::WRAP: the second exchange of the two-level combs)
 template <class S, int FRONT = 0, bool LC = false, int X = 0> constexpr int luma_delay_blocks() {
-    if (S::RT) return 20;
+    if (S::DYN) return 20;     // sized at launch (pair_lds_floats): this is the limit
     if (FRONT == FRONT_QAM && CM_QAM_SHORT_RING) return ((S::NE >= 4 ? 32 : (S::NE == 3 ? 28 : 26)) + X - 10 - ring_window<S, FRONT, LC>() + 3) / 4 + 2;
     return (S::NE >= 3 ? 12 : 11 - ring_window<S, FRONT, LC>() / 4) + (X + 3) / 4;
 }
@@ -839,7 +850,7 @@ template <class Cfg>
 struct PairLds {
     static constexpr int kIn = Cfg::kPairLdsIn, kOut = Cfg::kLdsOut;
     static constexpr int kY = Cfg::BSF ? luma_ring_slots<typename Cfg::S>() * 64
-                                       : (CM_LUMA_RING ? luma_delay_blocks<typename Cfg::S, Cfg::FRONT, Cfg::kLcutCfg, Cfg::WRAP ? 1 : 0>() * 256 : kLumaSlots);
+                                       : (CM_LUMA_RING && !Cfg::S::NORING ? luma_delay_blocks<typename Cfg::S, Cfg::FRONT, Cfg::kLcutCfg, Cfg::WRAP ? 1 : 0>() * 256 : kLumaSlots);
     // hand-over ring: the 2x-rate pair (even, odd) per step, or - where stage A also takes the detector products and the
     // low-pass (LCUT: the QAM front end without the band-stop luma) - the two low-passed pairs (q_e, q_o)
     static constexpr bool kLcut = Cfg::kLcutCfg;
@@ -858,7 +869,7 @@ struct PairLds<NoPass> {
 template <class Cfg>
 inline int pair_lds_floats(const DemodK<float, typename Cfg::S> &k) {
     typedef typename Cfg::S S;
-    if (!S::RT || Cfg::BSF || !CM_LUMA_RING) return PairLds<Cfg>::kFloats;
+    if (!S::DYN || Cfg::BSF || !CM_LUMA_RING) return PairLds<Cfg>::kFloats;
     const int lat_front = Cfg::FRONT == FRONT_PALD ? 10 + k.q_e + 9 + 10 + k.q_l + 9 : 10 + k.q_e + k.q_l + 9;
     const int lat_out = lat_front + 1 + k.s_p + (Cfg::WRAP ? 1 : 0);
     constexpr int kWinX = ring_window<S, Cfg::FRONT, Cfg::kLcutCfg>();
@@ -898,7 +909,7 @@ __device__ __forceinline__ void run_pair(const Geom &g, const DemodK<float, type
     constexpr int FRONT = Cfg::FRONT, DEPTH = Cfg::DEPTH, kTile = Cfg::TILE, SP = S::SP;
     constexpr bool BSF = Cfg::BSF, U8 = Cfg::U8, PALD = FRONT == FRONT_PALD;
     constexpr int kYSlots = luma_ring_slots<S>();
-    constexpr bool LRING = CM_LUMA_RING && !BSF;         // luma source samples through the LDS delay ring
+    constexpr bool LRING = CM_LUMA_RING && !BSF && !S::NORING;         // luma source samples through the LDS delay ring
     constexpr int kIT = Cfg::kPairInTile;                // samples per input tile row
     constexpr int kLBmax = luma_delay_blocks<S, FRONT, Cfg::kLcutCfg, Cfg::WRAP ? 1 : 0>();   // tuned shapes: the ring's size; run-time shape: its limit
     constexpr int kWinX = ring_window<S, FRONT, Cfg::kLcutCfg>();        // extra x samples stage A keeps behind its window
@@ -970,7 +981,7 @@ __device__ __forceinline__ void run_pair(const Geom &g, const DemodK<float, type
     // body tb, i.e. the block A wrote lr_m bodies before: lat_out = 4 lr_m + 10 - lr_o
     const int lr_o = (10 + kWinX - lat_out) & 3, lr_m = (lat_out - 10 - kWinX + lr_o) >> 2;
     // the run-time shape sizes its ring (the last region of the dynamic LDS) by the plan's latency: pair_lds_floats()
-    const int kLB = S::RT ? lr_m + 2 : kLBmax;
+    const int kLB = S::DYN ? lr_m + 2 : kLBmax;
 
     if (role == 0) {
         // =================================== stage A ===========================================
@@ -983,7 +994,7 @@ __device__ __forceinline__ void run_pair(const Geom &g, const DemodK<float, type
         TapsPk tkp;
         TapsPkOdd tko;
         Taps<float> tks;
-        constexpr bool UP2 = PKF && PALD && CM_PALD_UP2 != 0 && S::NE < 3;   // (the three-section band-pass has no registers for it: it would spill)
+        constexpr bool UP2 = PKF && PALD && CM_PALD_UP2 != 0 && (S::NE < 3 || (S::WIDE && CM_WIDE_PALD_UP2 != 0));   // (the three-section band-pass has no registers for it at 3 waves per SIMD: it would spill)
         if constexpr (UP2) tko.load(k.taps);
         if constexpr (PKF) {
             tkp.load(k.taps);
@@ -1243,8 +1254,14 @@ __device__ __forceinline__ void run_pair(const Geom &g, const DemodK<float, type
     const bool wrap_first = regime == 0;            // comb.py:97-99: the first call of a run returns the inner result as it is
     const bool wrap_min = g.wrap_mode == 2;
     constexpr bool UVR = PairLds<Cfg>::kUv != 0;
-    constexpr int kUvd = UVR ? 1 : (SP > 0 ? SP : 1);
-    pf2 uvd[kUvd];   // (u, v) of the last SP steps (newest first); UVR: in LDS instead
+    // (u, v) of the last SP steps.  SP <= 2 (the 13.5 MHz shapes): a window shifted by one every step (newest first).  Longer delays (the wide
+    // rasters: 3 .. 9 steps) would pay SP packed moves per step for that; there the window is kUvBanks banks of four slots indexed by the
+    // sub-step, a value moves one bank down when its slot is written again, and the tap SP steps back is a compile-time (bank, slot) of the
+    // sub-step: (SP - 1) / 4 moves per step - none up to SP = 4.  The same values either way.
+    constexpr bool UVB = !UVR && !S::RT && SP >= 3;
+    constexpr int kUvBanks = UVB ? (SP - 1) / 4 + 1 : 1;
+    constexpr int kUvd = UVR ? 1 : (UVB ? 4 * kUvBanks : (SP > 0 ? SP : 1));
+    pf2 uvd[kUvd];   // UVR: in LDS instead
 #pragma unroll
     for (int j = 0; j < kUvd; ++j) uvd[j] = pf2{0.f, 0.f};
     typedef __attribute__((address_space(3))) pf2 lds_pf2;
@@ -1312,6 +1329,10 @@ __device__ __forceinline__ void run_pair(const Geom &g, const DemodK<float, type
         if constexpr (UVR) {   // (u, v)[n6 - s_p] out of the LDS ring (this lane's own slots: in order within the wave)
             uvr[(n6 & 15) * 64] = uv;
             uv_d = uvr[((n6 - sp) & 15) * 64];
+        } else if constexpr (UVB) {
+            // before this step's write, bank m slot j holds the value of 4 m + e steps ago, e = (SUB - j) mod 4 taken from 1 .. 4
+            constexpr int e = (SP - 1) % 4 + 1;
+            uv_d = uvd[4 * ((SP - 1) / 4) + ((SUB - e) & 3)];
         } else {
             uv_d = SP > 0 ? uvd[SP > 0 ? SP - 1 : 0] : uv;
             if (S::RT) {   // (u, v)[n6 - s_p] out of the window: a chain of uniform selects instead of a dynamic register index
@@ -1322,7 +1343,11 @@ __device__ __forceinline__ void run_pair(const Geom &g, const DemodK<float, type
             }
         }
         Rgb<float> o = back.template step<EDGE>(k, kb, lk, uv_last, n6, uv, uv_d, y_src, sc);
-        if constexpr (!UVR) {
+        if constexpr (UVB) {
+#pragma unroll
+            for (int m = kUvBanks - 1; m > 0; --m) uvd[4 * m + SUB] = uvd[4 * (m - 1) + SUB];
+            uvd[SUB] = uv;
+        } else if constexpr (!UVR) {
 #pragma unroll
             for (int j = SP - 1; j > 0; --j) uvd[j] = uvd[j - 1];
             if (SP > 0) uvd[0] = uv;

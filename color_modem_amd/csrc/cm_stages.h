@@ -54,10 +54,20 @@ namespace cm {
 // RT_ = true: a run-time shape.  The section counts and SP_ are then MAXIMA (the host pads a shorter cascade with
 // identity sections, which cost arithmetic but no branch), the shift parities and the pre-correction shift are read from
 // DemodK at run time.  One such instance serves every sampling rate (= image width) without a tuned instance.
-template <int NE_, int NR_, int NL_, int NP_, bool ODD_E_, bool ODD_L_, bool ODD_R_, int SP_, bool RT_ = false>
+// LUMA_ (round 6, the tuned shapes of the wide rasters, cm_shapes_wide.h): everything above is a compile-time constant as in the
+// tuned shapes, but the pipeline latency grows with the sampling rate (46 steps at 720 samples per line, 63 at 1920) and with it
+// the luma delay ring of the wave pair.  0: the tuned shapes' ring of a fixed size; 1: sized at launch by the plan's latency
+// (dynamic LDS), like the run-time shape's; 2: no ring - stage A fetches the luma source samples a second time (one 16-byte
+// load per lane and body, L2 hits) and the LDS that frees buys a workgroup per CU.
+// YS_: slots of the band-stop luma ring of the wave pair (0: 32, the run-time shape 64).
+template <int NE_, int NR_, int NL_, int NP_, bool ODD_E_, bool ODD_L_, bool ODD_R_, int SP_, bool RT_ = false, int LUMA_ = 0, int YS_ = 0>
 struct Sys {
     static constexpr int NE = NE_, NR = NR_, NL = NL_, NP = NP_, SP = SP_;
     static constexpr bool ODD_E = ODD_E_, ODD_L = ODD_L_, ODD_R = ODD_R_, RT = RT_;
+    static constexpr bool WIDE = LUMA_ != 0;             // a shape of cm_shapes_wide.h
+    static constexpr bool DYN = RT_ || LUMA_ == 1;       // luma delay ring sized at launch
+    static constexpr bool NORING = LUMA_ == 2;           // no luma delay ring: a second visit of the row
+    static constexpr int YS = YS_ ? YS_ : (RT_ ? 64 : 32);
 };
 
 // ---- arithmetic helpers -------------------------------------------------------------------

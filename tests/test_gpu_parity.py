@@ -332,6 +332,38 @@ def test_other_widths_vs_oracle(stack, size):
         assert stacks.rel_err(got[i], want[i]) < TOL, (stack, size, i)
 
 
+# ---- round 6: the tuned kernel instances of the wide rasters (csrc/cm_shapes_wide.h, CM_PART 5 .. 7) ------------------------------
+WIDE_WIDTHS = (768, 800, 960, 1024, 1280, 1440, 1600, 1920)
+
+
+@pytest.mark.parametrize('width', WIDE_WIDTHS)
+@pytest.mark.parametrize('stack', ['pal_d', 'pal_3d', 'pal_s', 'ntsc', 'ntsc_comb', 'ntsc_comb_3d', 'ntsc_comb_simple'])
+def test_wide_tuned_instances_vs_oracle(stack, width):
+    """Every width of tools/gen_wide_shapes.py runs the plain stacks on a kernel instance compiled for its own filter-set shape (named in
+    describe()), on the STREAMING kernels (small batches pinned to whole rows - by default they take the scan kernel): floats against the
+    oracle at 1e-5, bytes against the float path (<= 1 LSB)."""
+    import torch
+    from oracle import cm_oracle
+    from color_modem_amd.image import _as_bytes
+    h = 22 if stack.startswith('pal') else 18
+    size = (width, h)
+    modem = stacks.make(stack, size)             # a few rows of the full-height standard: the sampling rate follows from the width
+    eng = image.ImageModem(modem)._engine()
+    eng.set_small_batch('rows')
+    assert '%d' % width in eng.describe() and 'samples per line' in eng.describe(), eng.describe()
+    comp = testing.synthetic_composite(3, h, width, seed=300 + width)
+    got = eng.demodulate_frames(comp, first_frame=2)
+    want = cm_oracle.demodulate_frames_f32(modem, comp, first_frame=2, n_threads=8)
+    for i in range(3):
+        assert stacks.rel_err(got[i], want[i]) < TOL, (stack, width, i)
+    comp8 = _as_bytes(image.ImageModem.encode_composite_level(comp.astype(numpy.float64)))
+    got8 = eng.demodulate_frames_u8(comp8, 2)
+    lvl = image.ImageModem.decode_composite_level(comp8.astype(numpy.float64) / 255.0).astype(numpy.float32)
+    ref8 = _as_bytes(numpy.moveaxis(eng.demodulate_frames(lvl, first_frame=2).astype(numpy.float64), 1, -1))
+    d8 = numpy.abs(numpy.asarray(got8).astype(numpy.int16) - ref8.astype(numpy.int16))
+    assert int(d8.max()) <= 1 and float((d8 > 0).mean()) < 2e-3, (stack, width, int(d8.max()))
+
+
 @pytest.mark.parametrize('stack,size', [('pal_d_notch', (768, 576)), ('pal_3d_notch', (1024, 576)), ('ntsc_comb_3d_notch', (640, 480)),
                                         ('pal_3d_minavg', (960, 576)), ('ntsc_simple_minavg', (768, 480)), ('ntsc_comb_3d_minavg', (1280, 480))])
 def test_options_at_other_widths_vs_oracle(stack, size):
