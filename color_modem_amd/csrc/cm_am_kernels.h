@@ -807,8 +807,8 @@ __global__ __launch_bounds__(64, 2) void niir_mod_kernel(const NiirModArgs args)
             const int t = tb + s;
             const float r = cur[0][s], gg = cur[1][s], b = cur[2][s];
             float y = fmaf_(k.e[0][0], r, fmaf_(k.e[0][1], gg, k.e[0][2] * b));
-            float db = fmaf_(k.e[1][0], r, fmaf_(k.e[1][1], gg, k.e[1][2] * b));
-            float dr = fmaf_(k.e[2][0], r, fmaf_(k.e[2][1], gg, k.e[2][2] * b));
+            float db = row3(k.e[1][0], k.e[1][1], k.e[1][2], r, gg, b);      // (unit rows - modulate_components - keep the sign of a zero: cm_am_stages.h)
+            float dr = row3(k.e[2][0], k.e[2][1], k.e[2][2], r, gg, b);
             if (DEPTH) {
                 float py = lane_from(idx1, y), pdb = lane_from(idx1, db), pdr = lane_from(idx1, dr);
                 float pr = lane_from(idx1, r), pg = lane_from(idx1, gg), pb = lane_from(idx1, b);

@@ -678,7 +678,7 @@ __global__ __launch_bounds__(64 * NW) void niir_demod_scan_kernel(const Geom g, 
             db *= keep;
             dr *= keep;
 #pragma unroll
-            for (int p = 0; p < 3; ++p) o[p][e] = fmaf_(k.m[3 * p], luma, fmaf_(k.m[3 * p + 1], db, k.m[3 * p + 2] * dr));
+            for (int p = 0; p < 3; ++p) o[p][e] = row3(k.m[3 * p], k.m[3 * p + 1], k.m[3 * p + 2], luma, db, dr);
         }
         if (n0 + 4 * q < g.Wp) {
             if (U8) scan_store_rgb4_u8(op, n0 + 4 * q, o[0], o[1], o[2]);
@@ -734,12 +734,12 @@ __global__ __launch_bounds__(64 * NW) void niir_mod_scan_kernel(const Geom g, co
     // (luma, db, dr) with the pedestal of one sample: niir_mod_kernel's body, the same operation order
     auto ybr_of = [&](float r, float gg, float b, float rr, float gr, float br, float nb, float nr, float &y, float &db, float &dr) {
         y = fmaf_(k.e[0], r, fmaf_(k.e[1], gg, k.e[2] * b));
-        db = fmaf_(k.e[3], r, fmaf_(k.e[4], gg, k.e[5] * b));
-        dr = fmaf_(k.e[6], r, fmaf_(k.e[7], gg, k.e[8] * b));
+        db = row3(k.e[3], k.e[4], k.e[5], r, gg, b);       // (unit rows keep the sign of a zero: cm_am_stages.h)
+        dr = row3(k.e[6], k.e[7], k.e[8], r, gg, b);
         if (depth) {
             const float py = fmaf_(k.e[0], rr, fmaf_(k.e[1], gr, k.e[2] * br));
-            const float pdb = fmaf_(k.e[3], rr, fmaf_(k.e[4], gr, k.e[5] * br));
-            const float pdr = fmaf_(k.e[6], rr, fmaf_(k.e[7], gr, k.e[8] * br));
+            const float pdb = row3(k.e[3], k.e[4], k.e[5], rr, gr, br);
+            const float pdr = row3(k.e[6], k.e[7], k.e[8], rr, gr, br);
             float odb, odr;
             double ed[6];
 #pragma unroll

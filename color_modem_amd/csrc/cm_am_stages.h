@@ -491,6 +491,34 @@ CM_HD float am_sqrt(float x) {
 }
 CM_HD double am_sqrt(double x) { return std::sqrt(x); }
 
+// One row of a colour matrix: a x + b y + c z - except that a UNIT row (the component protocol: modulate_components /
+// demodulate_components hand (luma, db, dr) over as they are) returns its component untouched, the sign of a zero included.  That sign
+// is data here: the NIIR encoder gives a pair its 0.1 pedestal at the hue arctan2(db, dr) (niir.py:42-49, 195), the decoder returns
+// saturation * sin / cos(hue) with saturation = max(r - 0.1, 0) (niir.py:63-67) - on grey pixels a pair of ZEROS whose signs are those
+// of sin / cos(hue) - and arctan2(0, -0) is pi: a comb wrapper that re-modulates the decoder's pair through the encoder
+// (comb.py:105-106 around niir.py:82-83) gets its pedestal at +0.1 or -0.1 by that sign.  (-0) + (+0) = +0: a multiply-add chain loses it.
+template <typename T>
+CM_HD T row3(T a, T b, T c, T x, T y, T z) {
+    if (a == T(1) && b == T(0) && c == T(0)) return x;
+    if (a == T(0) && b == T(1) && c == T(0)) return y;
+    if (a == T(0) && b == T(0) && c == T(1)) return z;
+    return fmaf_(a, x, fmaf_(b, y, c * z));
+}
+CM_HD float copysign_(float m, float s) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_copysignf(m, s);
+#else
+    return std::copysign(m, s);
+#endif
+}
+CM_HD double copysign_(double m, double s) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_copysign(m, s);
+#else
+    return std::copysign(m, s);
+#endif
+}
+
 // niir.py:134-163, 63-67, 52-61 on the decimated streams of one sample: comp = composite[n5]
 template <typename T>
 CM_HD Rgb<T> niir_finish(const NiirDemodK<T> &k, const NiirLineK<T> &lk, const NiirOut<T> &o, T comp, bool strip) {
@@ -512,9 +540,9 @@ CM_HD Rgb<T> niir_finish(const NiirDemodK<T> &k, const NiirLineK<T> &lk, const N
     db *= keep;
     dr *= keep;
     Rgb<T> out;
-    out.r = fmaf_(k.m[0][0], luma, fmaf_(k.m[0][1], db, k.m[0][2] * dr));
-    out.g = fmaf_(k.m[1][0], luma, fmaf_(k.m[1][1], db, k.m[1][2] * dr));
-    out.b = fmaf_(k.m[2][0], luma, fmaf_(k.m[2][1], db, k.m[2][2] * dr));
+    out.r = row3(k.m[0][0], k.m[0][1], k.m[0][2], luma, db, dr);       // (a unit row - demodulate_components - keeps the sign of a zero)
+    out.g = row3(k.m[1][0], k.m[1][1], k.m[1][2], luma, db, dr);
+    out.b = row3(k.m[2][0], k.m[2][1], k.m[2][2], luma, db, dr);
     return out;
 }
 
@@ -542,9 +570,9 @@ CM_HD void niir_add_offset(T &db, T &dr) {
         const T f = (r + T(0.1)) / r;
         db *= f;
         dr *= f;
-    } else {            // arctan2(0, 0) = 0: sin 0, cos 1
+    } else {            // arctan2(+-0, +0) = +-0: sin 0, cos 1; arctan2(+-0, -0) = +-pi: cos -1 (row3 above: the sign of a zero is data)
         db = T(0);
-        dr = T(0.1);
+        dr = copysign_(T(0.1), dr);
     }
 }
 // niir.py:42-49 with noise_level != 0: the pedestal comes from the clean saturation, the hue from the noisy pair
@@ -560,7 +588,7 @@ CM_HD void niir_add_offset_noise(T &db, T &dr, T n_b, T n_r) {
         dr = sat * dr / r;
     } else {
         db = T(0);
-        dr = sat;
+        dr = copysign_(sat, dr);
     }
 }
 // niir.py:187-198: saturation-weighted mean hue of this call (db, dr) and the previous one (pdb, pdr), the previous call's
@@ -570,14 +598,16 @@ CM_HD void niir_hue_correct(T db, T dr, T pdb, T pdr, T &odb, T &odr, T n_b = T(
     const T ls = am_sqrt(pdb * pdb + pdr * pdr), s = am_sqrt(db * db + dr * dr);
     T div = ls + s;
     if (div == T(0)) div = T(1);
-    const T adb = (pdb * ls + db * s) / div + n_b, adr = (pdr * ls + dr * s) / div + n_r;   // niir.py:192-194: noise on the mean
+    T adb = (pdb * ls + db * s) / div, adr = (pdr * ls + dr * s) / div;
+    if (n_b != T(0)) adb += n_b;      // niir.py:192-194: noise on the mean (no noise: nothing is added - (-0) + 0 would lose the sign the hue of a zero pair hangs on)
+    if (n_r != T(0)) adr += n_r;
     const T ra = am_sqrt(adb * adb + adr * adr), ep = ls + T(0.1);
     if (ra > T(0)) {
         odb = ep * adb / ra;
         odr = ep * adr / ra;
     } else {
         odb = T(0);
-        odr = ep;
+        odr = copysign_(ep, adr);
     }
 }
 
@@ -605,6 +635,9 @@ CM_HD void niir_chroma_f64(const double *ed, float rf, float gf, float bf, doubl
     const double q0 = ed[3] * r, q1 = ed[4] * g, q2 = ed[5] * b;
     db = (p0 + p1) + p2;
     dr = (q0 + q1) + q2;
+    // the component protocol (unit rows): the pair as it came in, the sign of a zero included (row3 above)
+    if (ed[0] == 0.0 && ed[1] == 1.0 && ed[2] == 0.0) db = g;
+    if (ed[3] == 0.0 && ed[4] == 0.0 && ed[5] == 1.0) dr = b;
 }
 // niir.py:42-49 in float64 (sin / cos of arctan2(db, dr) = db / r, dr / r; arctan2(0, 0) = 0)
 // (no contraction in these two either: where two nearly grey pixels of opposite hue meet, the mean of niir.py:190-191 cancels down to the
@@ -617,7 +650,7 @@ CM_HD void niir_add_offset_f64(double db, double dr, double nb, double nr, bool 
     if (noisy) { db += nb; dr += nr; }
     const double r = sqrt(db * db + dr * dr);
     if (r > 0.0) { odb = sat * db / r; odr = sat * dr / r; }
-    else { odb = 0.0; odr = sat; }
+    else { odb = 0.0; odr = copysign_(sat, dr); }
 }
 // niir.py:187-198 in float64
 CM_HD void niir_hue_correct_f64(double db, double dr, double pdb, double pdr, double nb, double nr, double &odb, double &odr) {
@@ -627,10 +660,12 @@ CM_HD void niir_hue_correct_f64(double db, double dr, double pdb, double pdr, do
     const double ls = sqrt(pdb * pdb + pdr * pdr), s = sqrt(db * db + dr * dr);
     double div = ls + s;
     if (div == 0.0) div = 1.0;
-    const double adb = (pdb * ls + db * s) / div + nb, adr = (pdr * ls + dr * s) / div + nr;
+    double adb = (pdb * ls + db * s) / div, adr = (pdr * ls + dr * s) / div;
+    if (nb != 0.0) adb += nb;
+    if (nr != 0.0) adr += nr;
     const double ra = sqrt(adb * adb + adr * adr), ep = ls + 0.1;
     if (ra > 0.0) { odb = ep * adb / ra; odr = ep * adr / ra; }
-    else { odb = 0.0; odr = ep; }
+    else { odb = 0.0; odr = copysign_(ep, adr); }
 }
 #ifndef CM_NIIR_SMALL_SAT2
 #define CM_NIIR_SMALL_SAT2 1e-4f

@@ -112,6 +112,8 @@ class RowSession(object):
             self.in_shape, self.out_shape, self.depth = (3, eng.in_width), (eng.comp_width,), eng.mod_depth
             self.fn = hook(direction) if hook else getattr(L, prefix + 'modulate_run')
         self.plans_of = eng._plans.get if hasattr(eng._plans, 'get') else eng._plans
+        # an encoder whose tables start above the picture (make_engine: line_offset): the line numbers it is passed move with them
+        self.line_offset = int(getattr(eng, 'line_offset', 0)) if direction == 'mod' else 0
         # ZERO_COPY: history and result rows live in pinned host memory, which the device reads and writes over the bus -
         # a call is one kernel launch and one synchronisation, no copy is enqueued (a row is 3 - 9 KB: latency, not
         # bandwidth).  Otherwise: device-resident history, one small upload and one download per call.
@@ -157,7 +159,7 @@ class RowSession(object):
                 stream = torch.cuda.current_stream(self.device)
                 try:
                     _native.check(self.fn(self.plans_of(self.device), self.hist_ptr + first * self.row_bytes, self.out_ptr, n,
-                                          int(frame), int(line) - 2 * (n - 1), int(k) - (n - 1), stream.cuda_stream))
+                                          int(frame), int(line) - 2 * (n - 1) + self.line_offset, int(k) - (n - 1), stream.cuda_stream))
                 finally:
                     stream.synchronize()
             self.held = (token, k)
@@ -178,7 +180,7 @@ class RowSession(object):
             first = self.pos - (n - 1)
             try:
                 _native.check(self.fn(self.plans_of(self.device), self.hist[first].data_ptr(), self.out.data_ptr(), n, int(frame),
-                                      int(line) - 2 * (n - 1), int(k) - (n - 1), stream.cuda_stream))
+                                      int(line) - 2 * (n - 1) + self.line_offset, int(k) - (n - 1), stream.cuda_stream))
                 self.pin_out.copy_(self.out[n - 1], non_blocking=True)
             finally:
                 stream.synchronize()                   # also when the call is refused: the upload from pin_in must have landed
@@ -198,10 +200,39 @@ def _custom_avg(stack):
     return fn is not None and fn is not comb.avg and fn is not comb.minavg
 
 
-def make_engine(modem, components=False, strip_chroma=True, min_lines=0):
-    """The engine of a modem stack: a cm_plan for the QAM / SECAM families, the plan-less MAC entry points for MacModem."""
+class _OffsetStack(object):
+    """A stack whose modulator tables start `line_offset` lines above the picture (plan.QamTables: line_offset)."""
+
+    def __init__(self, stack, line_offset):
+        self._shifted = dict(stack, line_offset=int(line_offset))
+
+    def _stack(self):
+        return self._shifted
+
+
+def make_engine(modem, components=False, strip_chroma=True, min_lines=0, line_offset=0):
+    """The engine of a modem stack: a cm_plan for the QAM / SECAM families, the plan-less MAC entry points for MacModem.
+    line_offset (generic.py's encoders only): modulate_run accepts line numbers down to -line_offset."""
+    from color_modem_amd import generic
+    if generic.needs_generic(modem):       # a wrapper inside a wrapper, wrappers around Pal3DModem(avg=f) / the NIIR modems: level by level (round 6)
+        return generic.make(modem, components, strip_chroma, min_lines, line_offset)
+    if line_offset:
+        eng = make_engine(modem, components, strip_chroma, min_lines)
+        if isinstance(eng, Engine):
+            return Engine(_OffsetStack(modem._stack(), line_offset), components, strip_chroma, min_lines)
+        if isinstance(eng, AmEngine):       # line geometry per lane on the device, any line number (cm_am_stages.h: AmLine)
+            return eng
+        if getattr(eng, 'encoder', None) is not None and isinstance(eng.encoder, Engine):
+            # a composition whose encoder is its leaf's engine (comb.py:90-94): that one gets the offset tables
+            eng.encoder = Engine(_OffsetStack(eng.encoder._modem_stack, line_offset), eng.encoder._components, True, min_lines)
+            return eng
+        raise NotImplementedError('%s has no encoder run above the picture' % type(eng).__name__)
     stack = modem._stack()
     kind = stack['kind']
+    if stack.get('demod_wrapper') and _custom_avg(stack) and not stack.get('mod_wrapper') and int(stack['backend'].line_config.size[0]) % 4:
+        # avg= callables at widths that are not a multiple of 4: the component buffer of wrapped.py's composition moves 16-byte vectors; the
+        # level-by-level engine runs the same statements through the engines' run entry points, which stage such rows by themselves
+        return generic.GenericCombEngine(modem, components, strip_chroma, min_lines)
     from color_modem_amd import notched
     if notched.shifted_notch(stack, strip_chroma) is not None:      # notch= values whose FilterFunction shift is not 0: the notch as a pass of its own
         return notched.ShiftedNotchEngine(modem, components, strip_chroma, min_lines)
@@ -277,7 +308,9 @@ class _EngineBase(object):
 class Engine(_EngineBase):
     def __init__(self, modem, components=False, strip_chroma=True, min_lines=0):
         self.built = plan.build_plan(modem, components, strip_chroma, min_lines)
-        self.n_lines = int(self.built.desc.demod_main.n_lines or self.built.desc.mod_main.n_lines)
+        self._modem_stack, self._components = modem._stack(), bool(components)
+        self.line_offset = int(self._modem_stack.get('line_offset', 0))      # modulator tables start this many lines above the picture (make_engine)
+        self.n_lines = int(self.built.desc.demod_main.n_lines or self.built.desc.mod_main.n_lines) - self.line_offset
         d = self.built.desc
         self.width, self.height = d.width, d.height
         self.comp_width = d.width
@@ -344,6 +377,8 @@ class Engine(_EngineBase):
     def demodulate_run(self, rows, frame, first_line, k0):
         """rows [n, W] float32 (numpy or cuda tensor) -> [n, 3, W] of the same kind: what calls k0 .. k0+n-1 of a run return."""
         torch = _torch()
+        if self.line_offset:
+            raise NotImplementedError('an engine with shifted modulator tables (line_offset) encodes only')
         x, was_numpy = self._stage(rows, torch.float32, (self.width,), 'rows')
         n = x.shape[0]
         return self._launch(_native.lib().cm_demodulate_run, x, None, (n, 3, self.width), torch.float32, was_numpy,
@@ -354,7 +389,7 @@ class Engine(_EngineBase):
         x, was_numpy = self._stage(rows, torch.float32, (3, self.width), 'rows')
         n = x.shape[0]
         return self._launch(_native.lib().cm_modulate_run, x, None, (n, self.width), torch.float32, was_numpy,
-                            n, int(frame), int(first_line), int(k0))
+                            n, int(frame), int(first_line) + self.line_offset, int(k0))
 
 
 class MacEngine(_EngineBase):

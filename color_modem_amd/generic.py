@@ -1,0 +1,381 @@
+# -*- coding: utf-8 -*-
+"""Stacks the fused plans do not express, evaluated level by level the way the reference evaluates them (round 6).
+
+The reference's wrappers work around ANY backend that has ``demodulate_components`` / ``modulate_components`` (ref comb.py:90-113,
+131-155): ``SimpleCombModem(ColorAveragingModem(x))`` (comb.py:105 folds the backend's ``modulation_delay`` into the strip line for exactly
+that), a comb wrapper inside a comb wrapper, ``ColorAveragingModem`` inside ``ColorAveragingModem``, wrappers around ``Pal3DModem(avg=f)``,
+around ``NiirModem`` / ``HueCorrectingNiirModem`` (the reference's cli.py:52-53 lists the latter).  The per-line coefficient tables of
+plan.py and the compositions of wrapped.py / pal3d_callable.py cover one wrapper around one decoder; everything else comes here:
+
+* the per-row protocol (``modem.demodulate(frame, line, row)`` ...) runs comb.py's own statements on float64 numpy rows around the
+  backend OBJECT's per-row protocol (color_modem_amd/comb.py: the ``_generic`` branches) - any call sequence, state for state;
+* the frame entry points run one LEVEL at a time over whole runs (a field of a frame = one run, image.py:47-55, 75-83): the backend's
+  engine in component form on every call of the run (``demodulate_run`` - its own kernels, whatever they are), the wrapper's average of
+  consecutive calls, its luma source and its strip through the backend's modulator engine (``modulate_run``) as float32 torch operations
+  on the device, the notch and the colour matrix through ``cm_notch_luma_f32``.
+
+A fallback, not a throughput path: two runs per frame and level, a few launches each (0.2 - 0.5 Gpixel/s at 720x576) - where rounds 1 - 5
+raised NotImplementedError.  No host arithmetic on the frame path.
+"""
+
+import ctypes
+
+import numpy
+
+from color_modem_amd import _native, avgfn
+
+
+def _leaf_kind(modem):
+    try:
+        return modem._stack()
+    except NotImplementedError:
+        return None
+
+
+def needs_generic(modem):
+    """True for the stacks the flattened plans / compositions refuse (what rounds 1 - 5 answered with NotImplementedError)."""
+    from color_modem_amd import comb, pal3d_callable
+    if isinstance(modem, comb.SimpleCombModem):
+        b = modem.backend
+        if isinstance(b, (comb.SimpleCombModem, comb.ColorAveragingModem)):
+            return True
+        st = _leaf_kind(b)
+        if st is None:
+            return True
+        return st['kind'] == 'niir' or pal3d_callable.custom_avg(st) is not None
+    if isinstance(modem, comb.ColorAveragingModem):
+        b = modem.backend
+        if isinstance(b, comb.ColorAveragingModem):
+            return True
+        if isinstance(b, comb.SimpleCombModem):
+            return needs_generic(b)
+        st = _leaf_kind(b)
+        if st is None:
+            return True
+        return st['kind'] == 'niir' or pal3d_callable.custom_avg(st) is not None
+    return False
+
+
+def _leaf(modem):
+    """the innermost modem of a stack: the one with the colour matrices"""
+    while hasattr(modem, 'backend') and not hasattr(modem, 'encode_matrix') and not hasattr(modem, 'qam'):
+        modem = modem.backend
+    return modem
+
+
+def _matrices(modem):
+    """(encode, decode) 3 x 3 of the stack's leaf (ref pal.py:35-46, ntsc.py:30-41, secam.py:193-208, niir.py:31-61 ...)"""
+    import importlib
+    m = _leaf(modem)
+    if hasattr(m, 'encode_matrix'):
+        return numpy.asarray(m.encode_matrix, dtype=numpy.float64), numpy.asarray(m.decode_matrix, dtype=numpy.float64)
+    mod = importlib.import_module(type(m).__module__)       # niir / protosecam / mac keep them as module constants
+    return numpy.asarray(mod.ENCODE, dtype=numpy.float64), numpy.asarray(mod.DECODE, dtype=numpy.float64)
+
+
+def field_schedule(height, delay):
+    """image.py:47-55 / 75-83 for one field: yields (field, input row of every call of its run, [(call, output row)]); call k is made at
+    line field + 2 k."""
+    for field in range(2):
+        rows_in, outs = [], []
+        for y in range(field, 2 * delay, 2):
+            if y >= height:
+                raise IndexError('image.py:49-50 / 77-78 feed row %d ahead of a field: the image has %d row(s)' % (y, height))
+            rows_in.append(y)
+        for y in range(field, height, 2):
+            iy = y + 2 * delay
+            while iy >= height:
+                iy -= 2
+            rows_in.append(iy)
+            outs.append((len(rows_in) - 1, y))
+        yield field, rows_in, outs
+
+
+class _GenericBase(object):
+    composite = True           # rowapi: runs come as their rows (the literal per-row branches of comb.py do not come here at all)
+    composite_mod = True
+
+    def _tensor(self, x, tail):
+        import torch
+        was_numpy = isinstance(x, numpy.ndarray)
+        t = torch.from_numpy(numpy.ascontiguousarray(x, dtype=numpy.float32)) if was_numpy else x
+        if not torch.is_tensor(t) or t.dtype != torch.float32 or tuple(t.shape[1:]) != tuple(tail):
+            raise ValueError('expected float32 [n, %s]' % ', '.join(map(str, tail)))
+        return (t if t.is_cuda else t.cuda()).contiguous(), was_numpy
+
+    def set_small_batch(self, mode):
+        for e in self._engines():
+            e.set_small_batch(mode)
+
+    def demodulate_frames_u8(self, composite8, first_frame=0, out=None):
+        raise NotImplementedError('a level-by-level stack runs on float rows (ImageModem converts on the device around them)')
+
+    def modulate_frames_u8(self, rgb8, first_frame=0, out=None):
+        raise NotImplementedError('a level-by-level stack runs on float rows (ImageModem converts on the device around them)')
+
+    # ---- frames = two runs per frame (image.py:47-55, 75-83) ------------------------------------------------------------
+    def _frames(self, x, first_frame, out, demod):
+        import torch
+        from color_modem_amd import engine
+        tail = (self.height, self.comp_width) if demod else (3, self.height, self.in_width)
+        t, was_numpy = self._tensor(x, tail)
+        n = int(t.shape[0])
+        shape = (n, 3, self.height, self.width) if demod else (n, self.height, self.comp_width)
+        if out is None:
+            out = torch.empty(shape, dtype=torch.float32, device=t.device)
+        else:
+            engine._check_out(out, shape, torch.float32, t.device)
+        delay = self.demodulation_delay if demod else self.modulation_delay
+        sched = [(field, torch.tensor(rows_in, device=t.device), torch.tensor([k for k, _ in outs], device=t.device),
+                  torch.tensor([y for _, y in outs], device=t.device)) for field, rows_in, outs in field_schedule(self.height, delay)]
+        for f in range(n):
+            for field, rows_in, ks, ys in sched:
+                if len(ys) == 0:
+                    continue
+                if demod:
+                    res = self.demodulate_run(t[f].index_select(0, rows_in), first_frame + f, field, 0)      # [calls, 3, W]
+                    out[f][:, ys] = res.index_select(0, ks).permute(1, 0, 2)
+                else:
+                    res = self.modulate_run(t[f].index_select(1, rows_in).permute(1, 0, 2).contiguous(), first_frame + f, field, 0)
+                    out[f][ys] = res.index_select(0, ks)
+        return out.cpu().numpy() if was_numpy else out
+
+    def demodulate_frames(self, composite, first_frame=0, out=None):
+        """composite [F, H, W] float32 (numpy or cuda tensor) -> rgb [F, 3, H, W] of the same kind."""
+        return self._frames(composite, int(first_frame), out, True)
+
+    def modulate_frames(self, rgb, first_frame=0, out=None):
+        """rgb [F, 3, H, W] float32 -> composite [F, H, W]."""
+        return self._frames(rgb, int(first_frame), out, False)
+
+
+class GenericCombEngine(_GenericBase):
+    """SimpleCombModem / Simple3DCombModem around any backend with the component protocol: comb.py:96-113 over whole runs."""
+
+    def __init__(self, modem, components=False, strip_chroma=True, min_lines=0, line_offset=0):
+        from color_modem_amd import comb, engine
+        assert isinstance(modem, comb.SimpleCombModem)
+        b = modem.backend
+        self.modem = modem
+        self.components, self.strip = bool(components), bool(strip_chroma)
+        self.own_delay = int(modem._own_delay)
+        self.avg = modem._avg
+        if not callable(self.avg):
+            raise TypeError('avg=%r is not callable' % (self.avg,))
+        self.notch = modem._notch if self.strip else None
+        lc = _leaf(b).line_config
+        # per-line tables of the engines below: the calls of a field run to line height + 2 (delays), the strip lines a few further
+        min_lines = max(int(min_lines), int(lc.size[1]) + 2 * (int(getattr(b, 'demodulation_delay', 0)) + int(getattr(b, 'modulation_delay', 0)) + 1) + 8)
+        self.inner = engine.make_engine(b, components=True, strip_chroma=False, min_lines=min_lines)     # comb.py:98 / 101
+        # a delay-line decoder's plan (PalDModem, NtscCombModem) leaves the first call of a run - the backend's own plain decode, comb.py:48-49 -
+        # to a pass that exists with band-stop luma only: unstripped, that one call comes from the leaf's plan (as in wrapped.py / rowapi.py)
+        self.first = None
+        desc = getattr(getattr(self.inner, 'built', None), 'desc', None)
+        if isinstance(self.inner, engine.Engine) and desc is not None and desc.first_is_plain:
+            self.first = engine.Engine(self.inner._modem_stack['backend'], components=True, strip_chroma=False, min_lines=min_lines)
+        self.mod = engine.make_engine(b, components=True, min_lines=min_lines)                           # comb.py:105-106
+        self.encoder = engine.make_engine(b, components=components, min_lines=min_lines, line_offset=line_offset)     # comb.py:90-94
+        for name in ('width', 'height', 'comp_width', 'in_width'):
+            setattr(self, name, getattr(self.inner, name))
+        self.modulation_delay = int(getattr(b, 'modulation_delay', 0))                                   # comb.py:75
+        self.demodulation_delay = int(getattr(b, 'demodulation_delay', 0)) + self.own_delay              # comb.py:76
+        # history a call needs: the previous call's backend result (one more line than the backend's own) and - behind a stateful backend
+        # modulator (ColorAveragingModem, HueCorrectingNiirModem) - the previous strip call's (u, v)
+        self.demod_depth = int(self.inner.demod_depth) + 1 + int(self.mod.mod_depth)
+        self.mod_depth = int(self.encoder.mod_depth)
+        self.n_lines = min(int(getattr(e, 'n_lines', 1 << 30)) for e in self._engines())
+        m = numpy.eye(3) if components else _matrices(b)[1]
+        self._matrix = numpy.ascontiguousarray(m, dtype=numpy.float64).reshape(-1)
+        f = self.notch
+        self._nb = numpy.ascontiguousarray(f.b if f is not None else [1.0], dtype=numpy.float64)
+        self._na = numpy.ascontiguousarray(f.a if f is not None else [1.0], dtype=numpy.float64)
+        self._nshift = int(f.shift) if f is not None else 0
+
+    def _engines(self):
+        return tuple(e for e in (self.inner, self.first, self.mod, self.encoder) if e is not None)
+
+    def describe(self):
+        return ('level by level (comb.py:96-113 over whole runs): [%s] (components, every call) | avg of consecutive calls on the device | '
+                'strip through [%s] | filter_rows_kernel + matrix' % (self.inner.describe().split(';')[0], self.mod.describe().split(';')[0]))
+
+    def demodulate_run(self, rows, frame, first_line, k0):
+        """rows [n, W]: calls k0 .. k0 + n - 1 of one run at lines first_line, first_line + 2, ... -> what each call returns [n, 3, W]
+        (with k0 > 0 the first demod_depth rows are history: their results are unspecified)."""
+        import torch
+        t, was_numpy = self._tensor(rows, (self.comp_width,))
+        n = int(t.shape[0])
+        if n == 0:
+            res = torch.empty((0, 3, self.width), dtype=torch.float32, device=t.device)
+            return res.cpu().numpy() if was_numpy else res
+        curr = self.inner.demodulate_run(t, frame, first_line, k0)               # comb.py:98 / 101: (y, u, v) of every call, unstripped
+        if self.first is not None and k0 == 0:
+            curr[0] = self.first.demodulate_run(t[:1], frame, first_line, 0)[0]
+        y, u, v = curr[:, 0].clone(), curr[:, 1].clone(), curr[:, 2].clone()     # a run's first call returns them as they are (comb.py:97-99)
+        if n > 1:
+            if self.own_delay:
+                y[1:] = curr[:-1, 0]                                             # comb.py:102
+            u[1:] = avgfn.apply(self.avg, curr[:-1, 1], curr[1:, 1])             # comb.py:103
+            v[1:] = avgfn.apply(self.avg, curr[:-1, 2], curr[1:, 2])             # comb.py:104
+            if self.strip:                                                       # comb.py:105-106: calls k >= 1 are a run of the backend's modulator
+                zuv = torch.stack([torch.zeros_like(u[1:]), u[1:], v[1:]], dim=1).contiguous()
+                line = first_line + 2 - 2 * (self.own_delay - self.modulation_delay)
+                y[1:] = y[1:] - self.mod.modulate_run(zuv, frame, line, k0)
+        out = torch.empty((1, 3, n, self.width), dtype=torch.float32, device=t.device)
+        yuv = torch.stack([y, u, v], dim=0)[None].contiguous()                   # [1, 3, n, W]: one group of n rows
+        dp = ctypes.POINTER(ctypes.c_double)
+        with torch.cuda.device(t.device):
+            stream = torch.cuda.current_stream(t.device).cuda_stream
+            # comb.py:107-110 (the notch on every stripped call: not on the first row of the buffer) and decode_components
+            _native.check(_native.lib().cm_notch_luma_f32(self._nb.ctypes.data_as(dp), len(self._nb), self._na.ctypes.data_as(dp), len(self._na),
+                                                          self._nshift, yuv.data_ptr(), out.data_ptr(), 1, n, int(self.width), 1,
+                                                          self._matrix.ctypes.data_as(dp), stream))
+        res = out[0].permute(1, 0, 2).contiguous()
+        return res.cpu().numpy() if was_numpy else res
+
+    def modulate_run(self, rows, frame, first_line, k0):
+        return self.encoder.modulate_run(rows, frame, first_line, k0)
+
+    def modulate_frames(self, rgb, first_frame=0, out=None):
+        return self.encoder.modulate_frames(rgb, first_frame, out=out)
+
+    def modulate_frames_u8(self, rgb8, first_frame=0, out=None):
+        return self.encoder.modulate_frames_u8(rgb8, first_frame, out=out)
+
+
+class GenericAveragingEngine(_GenericBase):
+    """ColorAveragingModem around any backend with modulate_components: comb.py:141-155 over whole runs; decoding is the backend's."""
+
+    def __init__(self, modem, components=False, strip_chroma=True, min_lines=0, line_offset=0):
+        from color_modem_amd import comb, engine
+        assert isinstance(modem, comb.ColorAveragingModem)
+        b = modem.backend
+        self.modem = modem
+        self.components = bool(components)
+        lc = _leaf(b).line_config
+        min_lines = max(int(min_lines), int(lc.size[1]) + 2 * (int(getattr(b, 'demodulation_delay', 0)) + int(getattr(b, 'modulation_delay', 0)) + 1) + 8)
+        # comb.py:152: the backend is called at line - 2 - its encoder must take runs that start two lines further up than this one's
+        self.mod = engine.make_engine(b, components=True, min_lines=min_lines, line_offset=int(line_offset) + 2)
+        self.decoder = engine.make_engine(b, components=components, strip_chroma=strip_chroma, min_lines=min_lines)   # comb.py:157-161
+        for name in ('width', 'height', 'comp_width', 'in_width', 'demod_depth', 'demodulation_delay'):
+            setattr(self, name, getattr(self.decoder, name))
+        self.modulation_delay = int(getattr(b, 'modulation_delay', 0)) + 1                                         # comb.py:133
+        self.mod_depth = int(self.mod.mod_depth) + 1
+        self.n_lines = min(int(getattr(e, 'n_lines', 1 << 30)) for e in self._engines())
+        self._encode = None if components else _matrices(b)[0]
+
+    def _engines(self):
+        return (self.mod, self.decoder)
+
+    def describe(self):
+        return ('level by level (comb.py:141-155 over whole runs): average of consecutive calls on the device | [%s] (components); decoding: %s'
+                % (self.mod.describe().split(';')[0], self.decoder.describe().split(';')[0]))
+
+    def modulate_run(self, rows, frame, first_line, k0):
+        """rows [n, 3, W]: (r, g, b) - or (y, u, v) of modulate_components - of calls k0 .. k0 + n - 1 of one run -> [n, W]"""
+        import torch
+        t, was_numpy = self._tensor(rows, (3, self.in_width))
+        n = int(t.shape[0])
+        if n == 0:
+            res = torch.empty((0, self.comp_width), dtype=torch.float32, device=t.device)
+            return res.cpu().numpy() if was_numpy else res
+        if self._encode is not None:                                             # comb.py:154-155: backend.encode_components
+            m = torch.as_tensor(self._encode, dtype=torch.float32, device=t.device)
+            t = torch.einsum('ij,njw->niw', m, t)
+        sent = t.clone()                                                         # a run's first call sends its own components (comb.py:142-146)
+        if n > 1:
+            sent[1:, 0] = t[:-1, 0]                                              # comb.py:147: the previous call's luma
+            sent[1:, 1:] = 0.5 * (t[1:, 1:] + t[:-1, 1:])                        # comb.py:148-149
+        res = self.mod.modulate_run(sent.contiguous(), frame, first_line - 2, k0)    # comb.py:152
+        return res.cpu().numpy() if was_numpy else res
+
+    def demodulate_run(self, rows, frame, first_line, k0):
+        return self.decoder.demodulate_run(rows, frame, first_line, k0)
+
+    def demodulate_frames(self, composite, first_frame=0, out=None):
+        return self.decoder.demodulate_frames(composite, first_frame, out=out)
+
+    def demodulate_frames_u8(self, composite8, first_frame=0, out=None):
+        return self.decoder.demodulate_frames_u8(composite8, first_frame, out=out)
+
+
+def make(modem, components=False, strip_chroma=True, min_lines=0, line_offset=0):
+    from color_modem_amd import comb
+    if isinstance(modem, comb.SimpleCombModem):
+        return GenericCombEngine(modem, components, strip_chroma, min_lines, line_offset)
+    return GenericAveragingEngine(modem, components, strip_chroma, min_lines, line_offset)
+
+
+class RowLoopEngine(object):
+    """ImageModem over a modem object that is not one of this package's (ref image.py:30, 49, 54-55, 63, 77, 82-83 drive ANY duck-typed
+    object with modulate / demodulate and an optional modulation_delay / demodulation_delay): the reference's row schedule, one call per
+    row, float64 numpy rows, on the host - what the reference itself would do with that object, nothing more."""
+
+    def __init__(self, modem):
+        self.modem = modem
+        self.modulation_delay = int(getattr(modem, 'modulation_delay', 0))        # image.py:30
+        self.demodulation_delay = int(getattr(modem, 'demodulation_delay', 0))    # image.py:63
+
+    def describe(self):
+        return 'row loop over a foreign modem object (%s): image.py:47-55, 75-83 call for call on the host' % type(self.modem).__name__
+
+    def set_small_batch(self, mode):
+        pass
+
+    @staticmethod
+    def _host(x):
+        if isinstance(x, numpy.ndarray):
+            return x, None
+        return x.detach().cpu().numpy(), x.device         # a torch tensor: back to where it came from
+
+    def demodulate_frames(self, composite, first_frame=0, out=None):
+        comp, device = self._host(composite)
+        comp = numpy.asarray(comp, dtype=numpy.float64)
+        n, height = comp.shape[0], comp.shape[1]
+        res = None
+        for i in range(n):
+            for field, rows_in, outs in field_schedule(height, self.demodulation_delay):
+                back = dict(outs)
+                for k, iy in enumerate(rows_in):
+                    rgb = self.modem.demodulate(first_frame + i, field + 2 * k, comp[i, iy])     # image.py:77, 82-83
+                    if k in back:
+                        if res is None:
+                            res = numpy.zeros((n, 3, height, len(rgb[0])), dtype=numpy.float32)
+                        res[i, :, back[k]] = numpy.stack(rgb)
+        if res is None:
+            res = numpy.zeros((n, 3, height, comp.shape[2]), dtype=numpy.float32)
+        return self._back(res, device, out)
+
+    def modulate_frames(self, rgb, first_frame=0, out=None):
+        x, device = self._host(rgb)
+        x = numpy.asarray(x, dtype=numpy.float64)
+        n, height = x.shape[0], x.shape[2]
+        res = None
+        for i in range(n):
+            for field, rows_in, outs in field_schedule(height, self.modulation_delay):
+                back = dict(outs)
+                for k, iy in enumerate(rows_in):
+                    row = self.modem.modulate(first_frame + i, field + 2 * k, x[i, 0, iy], x[i, 1, iy], x[i, 2, iy])   # image.py:49, 54-55
+                    if k in back:
+                        if res is None:
+                            res = numpy.zeros((n, height, len(row)), dtype=numpy.float32)
+                        res[i, back[k]] = row
+        if res is None:
+            res = numpy.zeros((n, height, x.shape[3]), dtype=numpy.float32)
+        return self._back(res, device, out)
+
+    @staticmethod
+    def _back(res, device, out):
+        if device is None and out is None:
+            return res
+        import torch
+        t = torch.from_numpy(res).to(device) if device is not None else torch.from_numpy(res)
+        if out is not None:
+            out.copy_(t)
+            return out
+        return t
+
+    def demodulate_frames_u8(self, composite8, first_frame=0, out=None):
+        raise NotImplementedError('a foreign modem object runs on float rows')
+
+    def modulate_frames_u8(self, rgb8, first_frame=0, out=None):
+        raise NotImplementedError('a foreign modem object runs on float rows')

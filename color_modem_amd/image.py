@@ -31,6 +31,12 @@ class ImageModem(object):
 
     def _engine(self):
         if self._engine_obj is None:
+            if not hasattr(self._modem, '_stack'):
+                # not one of this package's modems: the reference drives any duck-typed object with modulate / demodulate (image.py:30, 49,
+                # 54-55, 63, 77, 82-83) - so does this, row by row on the host (generic.RowLoopEngine), instead of an AttributeError
+                from color_modem_amd import generic
+                self._engine_obj = generic.RowLoopEngine(self._modem)
+                return self._engine_obj
             self._engine_obj = _engine.make_engine(self._modem)
             if self._batch_invariant:
                 self._engine_obj.set_small_batch('rows')

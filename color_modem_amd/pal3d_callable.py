@@ -92,21 +92,8 @@ class Pal3DCallableEngine(object):
 
     # ---- the function between the kernels -------------------------------------------------------------------------------------
     def _apply(self, x, y):
-        import torch
-        fn = self.fn
-        try:
-            res = fn(x, y)
-        except (TypeError, RuntimeError):
-            try:      # written against numpy: float64 arrays on the host, as the reference would hand it (pal.py:210-211)
-                res = fn(x.detach().cpu().double().numpy(), y.detach().cpu().double().numpy())
-            except TypeError as e:
-                raise TypeError('avg=%r must be an elementwise function of two arrays (it is tried on float32 torch tensors on the device, '
-                                'then on float64 numpy arrays): %s' % (fn, e))
-        if not torch.is_tensor(res):
-            res = torch.as_tensor(numpy.asarray(res), dtype=torch.float32, device=x.device)
-        if tuple(res.shape) != tuple(x.shape):
-            raise ValueError('avg=%r returned shape %s for inputs of shape %s' % (fn, tuple(res.shape), tuple(x.shape)))
-        return res.to(device=x.device, dtype=torch.float32)
+        from color_modem_amd import avgfn
+        return avgfn.apply(self.fn, x, y)
 
     def _combine(self, ya, yb, sign, plain):
         """ya, yb [..., 3, rows, W] from the two engines; sign [..., rows, 1] = the V-switch sign of the stripped line; plain [..., rows, 1]

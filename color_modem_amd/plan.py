@@ -218,6 +218,10 @@ class QamTables(object):
             self.table_frames = 2
         self.width, self.height = self.lc.size
         self.min_lines = int(min_lines)
+        # line_offset o (round 6, the level-by-level engines of generic.py): the MODULATOR table's row i describes line i - o, so that an
+        # encoder run can start above the picture - ColorAveragingModem sends its first call of a field to the backend at line - 2
+        # (comb.py:152), two of them nested at line - 4.  The engine adds o to the line numbers it passes (Engine.modulate_run).
+        self.line_offset = int(stack.get('line_offset', 0))
         # comb.py:9-15: which averaging function combines the two chroma estimates (wrapper, or Pal3DModem's two paths)
         from color_modem_amd import comb as comb_module
         fn = None
@@ -435,7 +439,7 @@ class QamTables(object):
     def n_lines(self):
         # the frame entry points need height + 2 delay lines; the per-row protocol takes any line number the caller
         # passes (the reference's size only sets fs and the line shift): min_lines grows the tables for it
-        return max(self.height + 2 * max(self.demodulation_delay, self.modulation_delay) + 4, self.min_lines)
+        return max(self.height + 2 * max(self.demodulation_delay, self.modulation_delay) + 4, self.min_lines) + self.line_offset
 
     def phase_free(self, lin, frame, line):
         """Re-express a combination over the base pairs B_{k-j} (detected at each line's own phase theta_j)
@@ -506,7 +510,7 @@ class QamTables(object):
         for f in range(self.table_frames):
             for k in range(3):
                 for line in range(n_lines):
-                    target = line - 2 if avg else line
+                    target = (line - self.line_offset) - 2 if avg else line - self.line_offset
                     p = self.phi(f, target)
                     e = tab[f, k, line]
                     e[0] = numpy.sin(p)

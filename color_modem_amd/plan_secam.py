@@ -43,7 +43,8 @@ def build_secam_plan(stack, components=False, min_lines=0):
     s.luma_bs = plan.iir_desc(m._chroma_demod_luma_filter)
     s.fm_lp = plan.iir_desc(m._chroma_demod._lowpass)
 
-    n_lines = max(height + 2 * d.modulation_delay + 4, int(min_lines))
+    offset = int(stack.get('line_offset', 0))     # the modulator table's row i describes line i - offset (plan.QamTables: line_offset)
+    n_lines = max(height + 2 * d.modulation_delay + 4, int(min_lines)) + offset
     demod = numpy.zeros((2, 3, n_lines, plan.CM_LANE_DOUBLES))
     for f in range(2):
         for k in range(3):
@@ -58,7 +59,7 @@ def build_secam_plan(stack, components=False, min_lines=0):
     for f in range(6):
         for k in range(3):
             for line in range(n_lines):
-                target = line - 2 if avg else line      # comb.py:152
+                target = (line - offset) - 2 if avg else line - offset      # comb.py:152
                 alt = lc.is_alternate_line(f, target)
                 e = mod[f, k, line]
                 e[0] = m._fsc_db if alt else m._fsc_dr

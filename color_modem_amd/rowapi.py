@@ -44,10 +44,13 @@ class RowApi(object):
         for eng in self._engines.values():
             eng.set_small_batch(mode)
 
-    def _engine(self, components=False, strip_chroma=True, line=0):
+    ABOVE = 8      # lines above the picture an encoder run may start at (a ColorAveragingModem calls its backend at line - 2, comb.py:152)
+
+    def _engine(self, components=False, strip_chroma=True, line=0, above=False):
         """The engine of this stack for the given protocol flavour; its per-line tables are grown (the plan is rebuilt)
-        when a call names a line beyond them - the reference takes any line number (line.py:57-65)."""
-        key = (bool(components), bool(strip_chroma))
+        when a call names a line beyond them - the reference takes any line number (line.py:57-65).  above: an encoder whose run starts
+        above the picture (a negative line number: this modem sits inside a ColorAveragingModem that runs level by level, generic.py)."""
+        key = (bool(components), bool(strip_chroma)) + (('above',) if above else ())
         eng = self._engines.get(key)
         if eng is None or line >= getattr(eng, 'n_lines', 1 << 30):
             from color_modem_amd import engine
@@ -57,7 +60,8 @@ class RowApi(object):
                 for run in (self._demod_run, self._mod_run):
                     for skey in [k for k in run.sessions if k[0] in gone]:
                         del run.sessions[skey]
-            eng = self._engines[key] = engine.make_engine(self, components=key[0], strip_chroma=key[1], min_lines=max(need, line + 1))
+            eng = self._engines[key] = engine.make_engine(self, components=key[0], strip_chroma=key[1], min_lines=max(need, line + 1),
+                                                          line_offset=self.ABOVE if above else 0)
             if self._small_batch is not None:
                 eng.set_small_batch(self._small_batch)
         return eng
@@ -162,13 +166,19 @@ class RowApi(object):
         run.rows = (hist + [rows[i] for i in range(max(0, n - depth - 1), n)])[-(depth + 1):]
         return out
 
+    def _starts_above(self, frame, line):
+        """does the encoder run this call belongs to start above the picture (at a negative line number)?"""
+        run = self._mod_run
+        continuing = frame == run.frame and line == run.line + 2 and run.k >= 0
+        return (line - 2 * (run.k + 1) if continuing else line) < 0
+
     def modulate(self, frame, line, r, g, b):
-        return self._modulate(self._engine(line=line), frame, line, r, g, b)
+        return self._modulate(self._engine(line=max(line, 0), above=self._starts_above(frame, line)), frame, line, r, g, b)
 
     def modulate_components(self, frame, line, y, u, v):
         """Composite row from (y, u, v) / (luma, dr, db) (ref qam.py:28-32 behind pal.py:48-52 / ntsc.py:43-45,
         comb.py:141-152, secam.py:258-276); shares the run state with modulate()."""
-        return self._modulate(self._engine(True, True, line), frame, line, y, u, v)
+        return self._modulate(self._engine(True, True, max(line, 0), above=self._starts_above(frame, line)), frame, line, y, u, v)
 
     def _modulate(self, eng, frame, line, r, g, b):
         assert len(r) == len(g) == len(b)

@@ -21,7 +21,8 @@ avg= callables other than comb.avg / comb.minavg (comb.py:72, 81-84) run through
 (`cm_comb_wrap_components_*` / `cm_comb_wrap_finish_*`): the caller's function is applied between the kernels to the (u, v) planes of
 consecutive calls - as float32 torch tensors ON THE DEVICE, a whole batch at a time ([frames, calls - 1, W] per run), where the reference
 hands it one float64 numpy row per call; elementwise functions of two arrays (the only kind that makes sense there) behave the same.
-A function that cannot take device tensors (numpy ufuncs: TypeError / RuntimeError) is called again with float64 numpy arrays on the host.
+A function that cannot take device tensors (numpy ufuncs raise TypeError on them) is called again with float64 numpy arrays on the host
+(color_modem_amd/avgfn.py; any other exception propagates).
 That also serves the wrappers around the plain decoders (NtscModem, PalSModem, NtscCombModem), whose comb.avg / comb.minavg forms are
 fused into lane tables instead.
 
@@ -40,7 +41,7 @@ import ctypes
 
 import numpy
 
-from color_modem_amd import _native, engine, plan
+from color_modem_amd import _native, avgfn, engine, plan
 
 
 class CombWrapDesc(ctypes.Structure):
@@ -189,29 +190,14 @@ class WrappedCombEngine(object):
     def _average(self, buf, runs):
         """buf [frames, calls, 3, W] as the inner decoder left it; runs: [lo, hi) call ranges of one frame.  (u, v) of every call but a
         run's first become avg(previous call's, this call's) - comb.py:103-104 - both taken from the buffer as it was."""
-        import torch
         fn = self.custom_avg
         for lo, hi in runs:
             if hi - lo < 2:
                 continue
             done = []
             for plane in (1, 2):
-                last, curr = buf[:, lo:hi - 1, plane], buf[:, lo + 1:hi, plane]
-                try:
-                    res = fn(last, curr)
-                except (TypeError, RuntimeError):
-                    # a function written against numpy (numpy.where, numpy.signbit ... - what the reference's own avg / minavg use) cannot
-                    # take device tensors: it gets float64 numpy arrays, as in the reference (comb.py:103-104), through host memory
-                    try:
-                        res = fn(last.detach().cpu().double().numpy(), curr.detach().cpu().double().numpy())
-                    except TypeError as e:
-                        raise TypeError('avg=%r must be an elementwise function of two arrays (it is tried on float32 torch tensors on the '
-                                        'device, a whole batch at a time, then on float64 numpy arrays): %s' % (fn, e))
-                if not torch.is_tensor(res):
-                    res = torch.as_tensor(numpy.asarray(res), dtype=torch.float32, device=buf.device)
-                if tuple(res.shape) != tuple(curr.shape):
-                    raise ValueError('avg=%r returned shape %s for inputs of shape %s' % (fn, tuple(res.shape), tuple(curr.shape)))
-                done.append(res.to(device=buf.device, dtype=torch.float32).clone())
+                # (avgfn: device tensors first; a function written against numpy - TypeError on them - gets float64 numpy arrays, as in the reference)
+                done.append(avgfn.apply(fn, buf[:, lo:hi - 1, plane], buf[:, lo + 1:hi, plane]).clone())
             buf[:, lo + 1:hi, 1] = done[0]
             buf[:, lo + 1:hi, 2] = done[1]
 

@@ -178,3 +178,29 @@ def skip_unserved(mode, fn):
         if mode == 'scan' and 'scan' in str(e):
             pytest.skip('scan: %s' % str(e)[:80])
         raise
+
+
+# ---- nested stacks (round 6; tests/golden/make_golden_nested.py names): they run level by level (color_modem_amd/generic.py) ------
+def _nested():
+    from color_modem_amd.color import niir
+    return {
+        'simple_avg_pals': ('GERBER_625', lambda lc: comb.SimpleCombModem(comb.ColorAveragingModem(pal.PalSModem(lc)))),
+        'simple3d_avg_pald_minavg': ('GERBER_625', lambda lc: comb.Simple3DCombModem(comb.ColorAveragingModem(pal.PalDModem(lc)), avg=comb.minavg)),
+        'simple_simple_ntsc': ('NTSC_525', lambda lc: comb.SimpleCombModem(comb.SimpleCombModem(ntsc.NtscModem(lc)))),
+        'simple3d_simple_ntsccomb': ('NTSC_525', lambda lc: comb.Simple3DCombModem(comb.SimpleCombModem(ntsc.NtscCombModem(lc)), avg=comb.minavg)),
+        'simple3d_pal3d_favg': ('GERBER_625', lambda lc: comb.Simple3DCombModem(pal.Pal3DModem(lc, avg=damped_avg), notch=4.0)),
+        'avg_pal3d_favg': ('GERBER_625', lambda lc: comb.ColorAveragingModem(pal.Pal3DModem(lc, avg=weighted_avg))),
+        'simple_niir_hue': ('GERBER_625', lambda lc: comb.SimpleCombModem(niir.HueCorrectingNiirModem(lc))),
+        'simple3d_niir': ('GERBER_625', lambda lc: comb.Simple3DCombModem(niir.NiirModem(lc), avg=weighted_avg)),
+        'avg_avg_secam': ('GERBER_625', lambda lc: comb.ColorAveragingModem(comb.ColorAveragingModem(secam.SecamModem(lc)))),
+        'avg_niir': ('GERBER_625', lambda lc: comb.ColorAveragingModem(niir.NiirModem(lc))),
+        'avg_avg_pals': ('GERBER_625', lambda lc: comb.ColorAveragingModem(comb.ColorAveragingModem(pal.PalSModem(lc)))),
+    }
+
+
+NESTED = _nested()
+
+
+def make_nested(name, size):
+    std, factory = NESTED[name]
+    return factory(line.LineConfig(tuple(int(v) for v in size), getattr(line.LineStandard, std)))

@@ -203,3 +203,17 @@ def test_long_cycle_plans_build():
         bp = plan.build_plan(modem)
         assert bp.desc.frame_rotation_cycle == cyc
         assert bp.desc.demod_main.frame_cycle == 2 and bp.desc.mod_main.frame_cycle == 2
+
+
+def test_generated_wide_shapes_header_is_current():
+    """csrc/cm_shapes_wide.h is what tools/gen_wide_shapes.py writes from the package's own filter designs (round 6): a design change
+    that moves a section count or a shift parity at one of its widths must regenerate the header, or those widths fall back to the
+    run-time shape silently."""
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location('gen_wide_shapes', os.path.join(root, 'tools', 'gen_wide_shapes.py'))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    with open(gen.HEADER) as fh:
+        assert fh.read() == gen.render(), 'run python tools/gen_wide_shapes.py'
