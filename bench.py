@@ -166,6 +166,61 @@ def other_configs(torch, device, frames):
     return res
 
 
+def library_sha16():
+    """first 16 hex digits of the SHA-256 of the shared object this process runs (profiles/traffic.json is tied to it)"""
+    import hashlib
+    from color_modem_amd import _native
+    h = hashlib.sha256()
+    with open(_native.LIB_PATH, 'rb') as fh:
+        for block in iter(lambda: fh.read(1 << 20), b''):
+            h.update(block)
+    return h.hexdigest()[:16]
+
+
+class ClockSampler(object):
+    """The shader clock the board holds while the timed steps run, read from sysfs (pp_dpm_sclk: the level marked '*') by a host thread
+    every few milliseconds - the kernel is power-bound, and what it gives back shows here.  None when the file is
+    not readable (another driver layout, a restricted container)."""
+
+    def __init__(self, dev_index):
+        import glob
+        import threading
+        self.paths = sorted(glob.glob('/sys/class/drm/card*/device/pp_dpm_sclk'))
+        self.path = self.paths[dev_index] if dev_index < len(self.paths) else None
+        self.samples, self._stop = [], threading.Event()
+        self._thread = threading.Thread(target=self._run, daemon=True)
+
+    def _read(self):
+        try:
+            with open(self.path) as fh:
+                for ln in fh:
+                    if ln.rstrip().endswith('*'):
+                        return float(ln.split(':')[1].split('M')[0])
+        except (OSError, ValueError, IndexError, TypeError):
+            return None
+        return None
+
+    def _run(self):
+        while not self._stop.is_set():
+            v = self._read()
+            if v is not None:
+                self.samples.append(v)
+            self._stop.wait(0.003)
+
+    def start(self):
+        if self.path:
+            self._thread.start()
+
+    def stop(self):
+        self._stop.set()
+        if self._thread.is_alive():
+            self._thread.join(1.0)
+        if not self.samples:
+            return None
+        s = sorted(self.samples)
+        return {'samples': len(s), 'min': s[0], 'median': s[len(s) // 2], 'max': s[-1], 'source': self.path}
+
+
 def host_threads():
     try:
         return max(1, len(os.sched_getaffinity(0)))
@@ -299,14 +354,16 @@ def main():
         raise SystemExit('--gpus %d but WORLD_SIZE=%d' % (args.gpus, world))
 
     import torch
+    backend = os.environ.get('CM_BENCH_BACKEND', 'nccl')     # 'gloo': rehearsal of the N > 1 path on a box with fewer GPUs than ranks
+    n_dev = torch.cuda.device_count()                        # (counting does not initialise the runtime on this image)
+    if n_dev < 1:
+        raise SystemExit('bench.py needs a GPU: the product path has no CPU implementation')
+    if backend == 'nccl' and world > n_dev:
+        backend = 'gloo'      # more ranks than GPUs on this box (every rank sees the same count): the launch-path rehearsal, reported as such
+    dev_index = local_rank if backend == 'nccl' else local_rank % n_dev
+    torch.cuda.set_device(dev_index)                         # the rank binds ITS device before the first HIP call of the process
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a GPU: the product path has no CPU implementation')
-    backend = os.environ.get('CM_BENCH_BACKEND', 'nccl')     # 'gloo': rehearsal of the N > 1 path on a box with fewer GPUs than ranks
-    n_dev = torch.cuda.device_count()
-    if backend == 'nccl' and world > max(n_dev, 1):
-        backend = 'gloo'      # more ranks than GPUs on this box (every rank sees the same count): the launch-path rehearsal, reported as such
-    dev_index = local_rank if backend == 'nccl' else local_rank % max(n_dev, 1)
-    torch.cuda.set_device(dev_index)
     device = torch.device('cuda', dev_index)
     dist = None
     if world > 1:
@@ -335,6 +392,9 @@ def main():
         eng.demodulate_frames(comp, first_frame, out=out)
     barrier()
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    sampler = ClockSampler(dev_index) if rank == 0 else None      # reads sysfs from a host thread: nothing is added to the stream
+    if sampler:
+        sampler.start()
     t0 = time.perf_counter()
     for a, b in ev:
         a.record()                      # same stream the library launches on (torch's current stream)
@@ -342,13 +402,20 @@ def main():
         b.record()
     barrier()
     elapsed = time.perf_counter() - t0
+    clock_stats = sampler.stop() if sampler else None
     kernel_ms = [a.elapsed_time(b) for a, b in ev]
 
     # ---- after the timed region -------------------------------------------------------------------------------------
     picks = sorted(set([0, frames // 2 - 1 if frames > 1 else 0, frames - 1])) if rank == 0 else [frames - 1]
     worst, bad = check_frames(torch, modem, comp, out, first_frame, picks)
-    rccl_ranks, gather = None, None
+    rccl_ranks, gather, rank_devices = None, None, None
     if dist is not None:
+        props = torch.cuda.get_device_properties(device)
+        me = {'rank': rank, 'local_rank': local_rank, 'device_index': dev_index, 'name': props.name,
+              'uuid': str(getattr(props, 'uuid', '')), 'pci_bus_id': '%04x:%02x:%02x' % (getattr(props, 'pci_domain_id', 0), getattr(props, 'pci_bus_id', 0), getattr(props, 'pci_device_id', 0)),
+              'pid': os.getpid()}
+        rank_devices = [None] * world
+        dist.all_gather_object(rank_devices, me)      # which GPU every rank really ran on: a mis-bound rank shows as a repeated uuid
         t = torch.tensor([elapsed, worst, float(bad)], dtype=torch.float64, device=device if backend == 'nccl' else 'cpu')
         tmin = t[0:1].clone()
         dist.all_reduce(tmin, op=dist.ReduceOp.MIN)       # the fastest rank's wall time beside the slowest (the reported one)
@@ -390,14 +457,20 @@ def main():
         mean_kernel_ms = sum(kernel_ms) / len(kernel_ms)
         achieved = BYTES_PER_PIXEL * px_step / (mean_kernel_ms * 1e-3) / 1e9
         valu_tflops = 2.0 * FMA_EQ_PER_PIXEL * px_step / (mean_kernel_ms * 1e-3) / 1e12
-        traffic = None
+        traffic, traffic_source = None, None
         tpath = os.path.join(ROOT, 'profiles', 'traffic.json')
+        lib_sha = library_sha16()
         if os.path.exists(tpath):
             with open(tpath) as fh:
                 tj = json.load(fh)
-            # a PMC measurement of THIS kernel on THIS workload only: same frame count, same kernel description
-            if tj.get('frames') == frames and tj.get('kernel') == eng.describe():
+            # a PMC measurement of THIS kernel on THIS workload by THIS library build only: same frame count, same kernel description,
+            # same hash of the shared object (tools/profile_bench.sh records it) - anything else would be a stale figure
+            if tj.get('frames') == frames and tj.get('kernel') == eng.describe() and tj.get('lib_sha16') == lib_sha:
                 traffic = tj.get('hbm_bytes_per_launch')
+                traffic_source = 'profiles/traffic.json: builder PMC run %s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, tools/profile_bench.sh), head %s, library %s' \
+                                 % (tj.get('date', '?'), tj.get('head', '?'), lib_sha)
+            else:
+                traffic_source = 'none: profiles/traffic.json was measured on another build / workload (library %s there, %s here)' % (tj.get('lib_sha16'), lib_sha)
         res = {
             'metric': 'Mpixels/s demodulated (720x576 PAL, 2D comb)',
             'value': round(value, 1), 'unit': 'Mpixels/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
@@ -409,7 +482,7 @@ def main():
                        'frames_per_gpu': frames, 'parallelism': 'frames sharded, one stream per GPU, no data-path collective',
                        'kernel': eng.describe()},
             'roofline': {'bound': 'hbm', 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
-                         'frac': round(achieved / HBM_PEAK_GBPS, 4), 'traffic': traffic,
+                         'frac': round(achieved / HBM_PEAK_GBPS, 4), 'traffic': traffic, 'traffic_source': traffic_source,
                          'kernel_ms': round(mean_kernel_ms, 4), 'algorithmic_bytes_per_launch': BYTES_PER_PIXEL * px_step,
                          'note': 'the HBM roofline is the one the metric names; the kernel is limited by the vector pipe and the '
                                  'power cap, see roofline_valu (DESIGN.md section 5)'},
@@ -417,6 +490,12 @@ def main():
                               'frac': round(valu_tflops / VALU_PEAK_TFLOPS, 4),
                               'sustained_peak': VALU_SUSTAINED_TFLOPS, 'frac_of_sustained': round(valu_tflops / VALU_SUSTAINED_TFLOPS, 4),
                               'fma_equivalents_per_pixel': FMA_EQ_PER_PIXEL,
+                              # the power give-back: at the 2.4 GHz the peak is quoted at, this arithmetic alone would take valu_limited_ms;
+                              # the clock the board held while the timed steps ran (sysfs, sampled from a thread) is beside it
+                              'valu_limited_ms_at_2400MHz': round(2.0 * FMA_EQ_PER_PIXEL * px_step / (VALU_PEAK_TFLOPS * 1e12) * 1e3, 4),
+                              'measured_kernel_ms': round(mean_kernel_ms, 4),
+                              'clock_MHz_if_valu_bound': round(2400.0 * valu_tflops / VALU_PEAK_TFLOPS, 1),
+                              'sclk_MHz_during_timed_steps': clock_stats,
                               'note': 'float32 FMA-equivalents of the PAL-D interior bodies per pixel '
                                       '(counted from the ISA of the interior bodies, tools/isa_fma_census.py, profiles/r04_headline_bound.txt) x 2 '
                                       'flop; sustained_peak = a bare v_fma_f32 loop under the 1400 W cap (profiles/r01_ubench_valu.txt)'},
@@ -428,6 +507,8 @@ def main():
         if world > 1:
             res['rccl_ranks'] = rccl_ranks
             res['ms_per_step_ranks'] = rank_ms
+            res['rank_devices'] = rank_devices
+            res['distinct_devices'] = len(set((d['uuid'] or d['pci_bus_id']) for d in rank_devices))
             res['gather'] = gather
             if backend != 'nccl':
                 res['rehearsal'] = 'backend %s, %d ranks on %d GPU(s): launch-path rehearsal, not a scaling measurement' \
@@ -449,6 +530,9 @@ def main():
         if worst > 1e-5:
             sys.stdout.flush()
             raise SystemExit('bench.py: a timed output misses the oracle by %.3g (> 1e-5)' % worst)
+        if res.get('other_configs_error'):       # the headline line is out; a broken additional configuration still fails the run
+            sys.stdout.flush()
+            raise SystemExit('bench.py: other_configs failed: %s' % res['other_configs_error'])
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

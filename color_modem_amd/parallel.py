@@ -69,3 +69,27 @@ def demodulate_frames_sharded(demodulate, composite, first_frame=0, group=None, 
     if not torch.is_tensor(local):
         local = torch.as_tensor(local)
     return gather_frames(local, n, group)
+
+
+def demodulate_streams(engine, streams, devices, first_frames=None):
+    """ONE process, several devices ("one process per GPU or one process with 8 streams"): stream i - composite
+    [F_i, H, W] float32, a numpy array or a tensor anywhere - is demodulated on devices[i] under the frame numbers first_frames[i] ..
+    The launches of all streams are enqueued before any result is waited for (each on its device's current stream), so the GPUs run
+    side by side; the engine keeps one plan per device (engine._DevicePlans).  Returns the rgb [F_i, 3, H, W] tensors, each left on
+    its device.  A fallback for nodes where torch.distributed.run cannot be used - bench.py's ranks are the measured path."""
+    import torch
+    if len(streams) != len(devices):
+        raise ValueError('%d streams for %d devices' % (len(streams), len(devices)))
+    first_frames = [0] * len(streams) if first_frames is None else list(first_frames)
+    outs = []
+    for comp, dev, first in zip(streams, devices, first_frames):
+        device = torch.device('cuda', int(dev)) if not isinstance(dev, torch.device) else dev
+        t = torch.as_tensor(comp)
+        if t.dtype != torch.float32:
+            raise ValueError('streams are float32 [F, H, W]')
+        t = t.to(device, non_blocking=True).contiguous()
+        with torch.cuda.device(device):
+            outs.append(engine.demodulate_frames(t, int(first)))      # asynchronous: the launch returns as soon as it is enqueued
+    for dev in set(int(getattr(d, 'index', d)) for d in devices):
+        torch.cuda.synchronize(dev)
+    return outs

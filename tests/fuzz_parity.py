@@ -1,5 +1,6 @@
 """Randomised parity sweep: random (stack, variant, image size, frame count, first frame) against the float64 oracle,
-both directions.  TEST TOOL (uses oracle/): python tests/fuzz_parity.py [cases] [seed] [pal|ntsc|secam|am]"""
+both directions.  TEST TOOL (uses oracle/): python tests/fuzz_parity.py [cases] [seed] [pal|ntsc|secam|am|nested]
+tests/test_gpu_fuzz.py runs a bounded fixed-seed slice of it (run() below) in the driver's GPU suite."""
 import sys, time, warnings
 import numpy
 sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
@@ -9,9 +10,6 @@ from color_modem_amd.color import ntsc, pal, secam
 from oracle import cm_oracle
 import stacks
 
-N = int(sys.argv[1]) if len(sys.argv) > 1 else 60
-rng = numpy.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
-ONLY = sys.argv[3] if len(sys.argv) > 3 else None       # 'pal' / 'ntsc' / 'secam': only that system's stacks (and no MAC cases)
 PAL_V = ['PAL', 'PAL_M', 'PAL_N']
 NTSC_V = ['NTSC', 'NTSC_I', 'NTSC_N', 'NTSC361', 'NTSC443', 'NTSC_A']
 SECAM_V = ['SECAM', 'SECAM_I', 'SECAM_II', 'SECAM_III', 'SECAM_A', 'SECAM_M', 'SECAM_N']
@@ -32,7 +30,7 @@ MAKERS = [
     ('Simple(Pal3D) f', 'pal', lambda lc, v: comb.SimpleCombModem(pal.Pal3DModem(lc, v), avg=stacks.damped_avg, notch=5.0)),
     ('Secam', 'secam', lambda lc, v: secam.SecamModem(lc, v)), ('Avg(Secam)', 'secam', lambda lc, v: comb.ColorAveragingModem(secam.SecamModem(lc, v))),
 ]
-WIDTHS = [480, 544, 640, 704, 720, 720, 720, 768, 960, 1024, 1280, 1440, 1920]
+WIDTHS = [480, 544, 640, 704, 720, 720, 720, 768, 800, 960, 1024, 1280, 1440, 1600, 1920]      # (768 .. 1920: the tuned shapes of csrc/cm_shapes_wide.h)
 
 
 def mac_case(rng):
@@ -93,77 +91,112 @@ def am_case(rng):
     else:
         e_dem = max(stacks.rel_err(a, b) for a, b in zip(back, want))
     return tag, e_mod, e_dem
-worst = 0.0
-bad = []
-t0 = time.time()
-done = 0
-while done < N:
-    if (ONLY is None and rng.random() < 0.16) or ONLY == 'am':
-        tag, e_mod, e_dem = mac_case(rng) if ONLY is None and rng.random() < 0.5 else am_case(rng)
+def nested_case(rng):
+    """stacks that run level by level (color_modem_amd/generic.py) at random sizes against oracle/cm_oracle_generic.py"""
+    from oracle import cm_oracle_generic as og
+    name = str(rng.choice(['simple_avg_pals', 'simple3d_avg_pald_minavg', 'simple_simple_ntsc', 'simple3d_simple_ntsccomb', 'simple3d_pal3d_favg',
+                           'simple_niir_hue', 'simple3d_niir', 'avg_avg_secam', 'avg_niir', 'avg_avg_pals']))
+    w = int(rng.choice([640, 702, 720, 720, 768, 960, 1024]))
+    h = int(rng.integers(6, 40))      # (two nested delays feed rows 0 .. 3 ahead of a field: image.py:49-50, 77-78)
+    nfr, first = int(rng.integers(1, 3)), int(rng.integers(0, 5000))
+    tag = '%-22s %-9s %4dx%-3d frames %d first %d' % (name[:22], 'nested', w, h, nfr, first)
+    modem = stacks.make_nested(name, (w, h))
+    im = image.ImageModem(modem)
+    rgb = testing.synthetic_rgb(nfr, h, w, seed=int(rng.integers(1 << 30)))
+    comp_ref = og.modulate_frames(modem, rgb.astype(numpy.float64), first)
+    e_mod = stacks.rel_err(im.modulate_frames(rgb, first_frame=first), comp_ref)
+    if name.startswith('avg_avg_secam'):      # SecamModem has no demodulate_components: the decoder is the backend's own
+        return tag, e_mod, 0.0
+    comp = comp_ref.astype(numpy.float32)
+    got, want = im.demodulate_frames(comp, first_frame=first), og.demodulate_frames(modem, comp, first)
+    return tag, e_mod, max(stacks.rel_err(a, b) for a, b in zip(got, want))
+
+
+def run(N, seed=1, ONLY=None, out=print, max_h=140, full_share=0.2):
+    """N cases from numpy.random.default_rng(seed); ONLY: 'pal' / 'ntsc' / 'secam' (that system's stacks), 'am' (Proto-SECAM / NIIR),
+    'nested' (generic.py), None (everything, MAC included).  -> (cases, worst error, tags of the failures)"""
+    print = out       # noqa: A001  (the sweep's lines go where the caller wants them)
+    rng = numpy.random.default_rng(seed)
+    worst = 0.0
+    bad = []
+    t0 = time.time()
+    done = 0
+    while done < N:
+        if (ONLY is None and rng.random() < 0.22) or ONLY in ('am', 'nested'):
+            pick = rng.random()
+            tag, e_mod, e_dem = nested_case(rng) if (ONLY == 'nested' or (ONLY is None and pick < 0.3)) else (mac_case(rng) if ONLY is None and pick < 0.65 else am_case(rng))
+            done += 1
+            worst = max(worst, e_mod, e_dem)
+            flag = '' if max(e_mod, e_dem) < 1e-5 else '   <-- FAIL'
+            if flag:
+                bad.append(tag)
+            print('%s  mod %.1e demod %.1e%s' % (tag, e_mod, e_dem, flag))
+            continue
+        name, system, make = MAKERS[rng.integers(len(MAKERS))]
+        if ONLY is not None and system != ONLY:
+            continue
+        vname = {'pal': PAL_V, 'ntsc': NTSC_V, 'secam': SECAM_V}[system][rng.integers({'pal': 3, 'ntsc': 6, 'secam': 7}[system])]
+        v = getattr({'pal': pal.PalVariant, 'ntsc': ntsc.NtscVariant, 'secam': secam.SecamVariant}[system], vname)
+        w = int(WIDTHS[rng.integers(len(WIDTHS))])
+        full = int(rng.choice([480, 576]))
+        h = int(rng.integers(1, max_h)) if rng.random() < 1.0 - full_share else full
+        nfr = int(rng.integers(1, 4))
+        first = int(rng.integers(0, 5000))
+        tag = '%-22s %-9s %4dx%-3d frames %d first %d' % (name, vname, w, h, nfr, first)
+        try:
+            lc = line.LineConfig((w, h), line.LineStandard.detect(full))
+            modem = make(lc, v)
+            im = image.ImageModem(modem)
+            rgb = testing.synthetic_rgb(nfr, h, w, seed=int(rng.integers(1 << 30)))
+            comp_ref = cm_oracle.modulate_frames_f32(modem, rgb, first_frame=first, n_threads=8)
+            e_mod = stacks.rel_err(im.modulate_frames(rgb, first_frame=first), comp_ref)
+            got = im.demodulate_frames(comp_ref, first_frame=first)
+            want = cm_oracle.demodulate_frames_f32(modem, comp_ref, first_frame=first, n_threads=8)
+            e_dem = max(stacks.rel_err(got[i], want[i]) for i in range(nfr))
+            e_u8 = 0.0
+            if rng.random() < 0.4:   # the fused byte boundaries against the host-side conversions around the float kernels
+                from color_modem_amd.image import _as_bytes
+                try:
+                    comp8 = _as_bytes(image.ImageModem.encode_composite_level(comp_ref.astype(numpy.float64)))
+                    got8 = im.demodulate_frames_u8(comp8, first_frame=first)
+                    ref_in = image.ImageModem.decode_composite_level(comp8.astype(numpy.float64) / 255.0).astype(numpy.float32)
+                    want8 = _as_bytes(im.demodulate_frames(ref_in, first_frame=first).astype(numpy.float64)).transpose(0, 2, 3, 1)
+                    d8 = numpy.abs(got8.astype(int) - want8.astype(int))
+                    rgb8 = _as_bytes(rgb.astype(numpy.float64)).transpose(0, 2, 3, 1)
+                    m8 = im.modulate_frames_u8(numpy.ascontiguousarray(rgb8), first_frame=first)
+                    rgbf = (rgb8.astype(numpy.float64) / 255.0).astype(numpy.float32).transpose(0, 3, 1, 2)
+                    w8 = _as_bytes(image.ImageModem.encode_composite_level(im.modulate_frames(numpy.ascontiguousarray(rgbf), first_frame=first).astype(numpy.float64)))
+                    dm = numpy.abs(m8.astype(int) - w8.astype(int))
+                    e_u8 = max(d8.max(), dm.max()) + max((d8 > 0).mean(), (dm > 0).mean())   # LSBs + share of differing bytes
+                    tag += '  u8 %d LSB %.1e' % (max(d8.max(), dm.max()), max((d8 > 0).mean(), (dm > 0).mean()))
+                    if d8.max() > 1 or dm.max() > 1 or max((d8 > 0).mean(), (dm > 0).mean()) > 5e-3:
+                        e_dem = 1.0
+                except NotImplementedError as e:
+                    tag += '  u8 n/a'
+        except (NotImplementedError, ValueError, IndexError) as e:
+            print('skip  %s: %s' % (tag, str(e)[:70]))
+            continue
         done += 1
         worst = max(worst, e_mod, e_dem)
         flag = '' if max(e_mod, e_dem) < 1e-5 else '   <-- FAIL'
         if flag:
             bad.append(tag)
+            import os
+            if os.path.isdir('gpurun_out'):     # keep the case for a look on the host (tests/secam_sim_probe.py and friends)
+                err = numpy.abs(got.astype(numpy.float64) - want) / numpy.abs(want).max(axis=(1, 2, 3), keepdims=True)
+                ix = numpy.unravel_index(err.argmax(), err.shape)
+                print('      worst demod sample at (frame, plane, row, col) = %s: got %.9g want %.9g' % (ix, got[ix], want[ix]))
+                numpy.savez_compressed('gpurun_out/fuzz_fail_%d.npz' % len(bad), tag=tag, comp=comp_ref[ix[0]:ix[0] + 1], got=got[ix[0]:ix[0] + 1],
+                                       first=first + ix[0], name=name, vname=vname, size=numpy.array([w, h, full]))
         print('%s  mod %.1e demod %.1e%s' % (tag, e_mod, e_dem, flag))
-        continue
-    name, system, make = MAKERS[rng.integers(len(MAKERS))]
-    if ONLY is not None and system != ONLY:
-        continue
-    vname = {'pal': PAL_V, 'ntsc': NTSC_V, 'secam': SECAM_V}[system][rng.integers({'pal': 3, 'ntsc': 6, 'secam': 7}[system])]
-    v = getattr({'pal': pal.PalVariant, 'ntsc': ntsc.NtscVariant, 'secam': secam.SecamVariant}[system], vname)
-    w = int(WIDTHS[rng.integers(len(WIDTHS))])
-    full = int(rng.choice([480, 576]))
-    h = int(rng.integers(1, 140)) if rng.random() < 0.8 else full
-    nfr = int(rng.integers(1, 4))
-    first = int(rng.integers(0, 5000))
-    tag = '%-22s %-9s %4dx%-3d frames %d first %d' % (name, vname, w, h, nfr, first)
-    try:
-        lc = line.LineConfig((w, h), line.LineStandard.detect(full))
-        modem = make(lc, v)
-        im = image.ImageModem(modem)
-        rgb = testing.synthetic_rgb(nfr, h, w, seed=int(rng.integers(1 << 30)))
-        comp_ref = cm_oracle.modulate_frames_f32(modem, rgb, first_frame=first, n_threads=8)
-        e_mod = stacks.rel_err(im.modulate_frames(rgb, first_frame=first), comp_ref)
-        got = im.demodulate_frames(comp_ref, first_frame=first)
-        want = cm_oracle.demodulate_frames_f32(modem, comp_ref, first_frame=first, n_threads=8)
-        e_dem = max(stacks.rel_err(got[i], want[i]) for i in range(nfr))
-        e_u8 = 0.0
-        if rng.random() < 0.4:   # the fused byte boundaries against the host-side conversions around the float kernels
-            from color_modem_amd.image import _as_bytes
-            try:
-                comp8 = _as_bytes(image.ImageModem.encode_composite_level(comp_ref.astype(numpy.float64)))
-                got8 = im.demodulate_frames_u8(comp8, first_frame=first)
-                ref_in = image.ImageModem.decode_composite_level(comp8.astype(numpy.float64) / 255.0).astype(numpy.float32)
-                want8 = _as_bytes(im.demodulate_frames(ref_in, first_frame=first).astype(numpy.float64)).transpose(0, 2, 3, 1)
-                d8 = numpy.abs(got8.astype(int) - want8.astype(int))
-                rgb8 = _as_bytes(rgb.astype(numpy.float64)).transpose(0, 2, 3, 1)
-                m8 = im.modulate_frames_u8(numpy.ascontiguousarray(rgb8), first_frame=first)
-                rgbf = (rgb8.astype(numpy.float64) / 255.0).astype(numpy.float32).transpose(0, 3, 1, 2)
-                w8 = _as_bytes(image.ImageModem.encode_composite_level(im.modulate_frames(numpy.ascontiguousarray(rgbf), first_frame=first).astype(numpy.float64)))
-                dm = numpy.abs(m8.astype(int) - w8.astype(int))
-                e_u8 = max(d8.max(), dm.max()) + max((d8 > 0).mean(), (dm > 0).mean())   # LSBs + share of differing bytes
-                tag += '  u8 %d LSB %.1e' % (max(d8.max(), dm.max()), max((d8 > 0).mean(), (dm > 0).mean()))
-                if d8.max() > 1 or dm.max() > 1 or max((d8 > 0).mean(), (dm > 0).mean()) > 5e-3:
-                    e_dem = 1.0
-            except NotImplementedError as e:
-                tag += '  u8 n/a'
-    except (NotImplementedError, ValueError, IndexError) as e:
-        print('skip  %s: %s' % (tag, str(e)[:70]))
-        continue
-    done += 1
-    worst = max(worst, e_mod, e_dem)
-    flag = '' if max(e_mod, e_dem) < 1e-5 else '   <-- FAIL'
-    if flag:
-        bad.append(tag)
-        import os
-        if os.path.isdir('gpurun_out'):     # keep the case for a look on the host (tests/secam_sim_probe.py and friends)
-            err = numpy.abs(got.astype(numpy.float64) - want) / numpy.abs(want).max(axis=(1, 2, 3), keepdims=True)
-            ix = numpy.unravel_index(err.argmax(), err.shape)
-            print('      worst demod sample at (frame, plane, row, col) = %s: got %.9g want %.9g' % (ix, got[ix], want[ix]))
-            numpy.savez_compressed('gpurun_out/fuzz_fail_%d.npz' % len(bad), tag=tag, comp=comp_ref[ix[0]:ix[0] + 1], got=got[ix[0]:ix[0] + 1],
-                                   first=first + ix[0], name=name, vname=vname, size=numpy.array([w, h, full]))
-    print('%s  mod %.1e demod %.1e%s' % (tag, e_mod, e_dem, flag))
-    sys.stdout.flush()
-print('cases %d, worst error %.2e, failures %d, %.0f s' % (done, worst, len(bad), time.time() - t0))
-sys.exit(1 if bad else 0)
+        sys.stdout.flush()
+    print('cases %d, worst error %.2e, failures %d, %.0f s' % (done, worst, len(bad), time.time() - t0))
+    return done, worst, bad
+
+
+if __name__ == '__main__':
+    _n = int(sys.argv[1]) if len(sys.argv) > 1 else 60
+    _seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    _only = sys.argv[3] if len(sys.argv) > 3 else None
+    sys.exit(1 if run(_n, _seed, _only)[2] else 0)
+

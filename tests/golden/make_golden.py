@@ -564,7 +564,7 @@ def full_image_cases():
     """uint8 through the reference's own ImageModem at FULL height (720x576: PAL-D and SECAM): the byte
     boundary pinned at a realistic size, both directions."""
     from PIL import Image
-    for stack, (W, H) in (('pal_d', (720, 576)), ('secam', (720, 576))):
+    for stack, (W, H) in (('pal_d', (720, 576)), ('secam', (720, 576)), ('ntsc_comb_3d', (720, 480))):      # (round 6: BASELINE configs[2] at its full size)
         rgb8 = test_picture(W, H)
         img = Image.frombytes('RGB', (W, H), rgb8.tobytes())
         lc = line_config(stack, (W, H))
@@ -575,9 +575,24 @@ def full_image_cases():
              back8=numpy.frombuffer(back.tobytes(), dtype=numpy.uint8).reshape(H, W, 3), frame=numpy.array(2))
 
 
+def full_frame_case():
+    """BASELINE configs[2] at its FULL size as floats: one 720x480 frame of a valid NTSC signal through
+    Simple3DCombModem(NtscCombModem) on the image.py row schedule.  The whole input is kept; of the reference's output the rows `rows`
+    (the top and bottom eight and every 16th: the line geometry of the full height at a tenth of the bytes)."""
+    W, H, frame = 720, 480, 3
+    stack = 'ntsc_comb_3d'
+    lc = line_config(stack, (W, H))
+    rgb = test_picture(W, H).astype(numpy.float64).transpose(2, 0, 1) / 255.0
+    comp = run_mod_frame(STACKS['ntsc'](lc), rgb, frame).astype(numpy.float32)
+    out = run_demod_frame(STACKS[stack](lc), comp.astype(numpy.float64), frame)
+    rows = numpy.array(sorted(set(list(range(8)) + list(range(0, H, 16)) + list(range(H - 8, H)))))
+    save('framefull_demod_' + stack, inp=comp[None], out_rows=out[:, rows][None], rows=rows, frames=numpy.array([frame]), size=numpy.array([W, H]))
+
+
 if __name__ == '__main__':
     if sys.argv[1:2] == ['full_images']:
         full_image_cases()
+        full_frame_case()
         sys.exit(0)
     if sys.argv[1:2] == ['options']:     # only the option / variant cases (the rest is unchanged), optionally some
         option_cases(sys.argv[2:])
@@ -612,3 +627,4 @@ if __name__ == '__main__':
     row_cases()
     image_cases()
     full_image_cases()
+    full_frame_case()

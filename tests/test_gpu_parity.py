@@ -167,6 +167,17 @@ def _flip_report(name, what, diff):
     return flips
 
 
+@pytest.mark.parametrize('mode', MODES)
+def test_full_size_frame_ntsc_3d_comb_golden(mode):
+    """BASELINE configs[2] - Simple3DCombModem(NtscCombModem), 720x480 - at its FULL size against the reference's own floats
+    (tests/golden/framefull_demod_ntsc_comb_3d.npz: the top and bottom eight rows and every 16th), on both kernel families."""
+    g = stacks.load('framefull_demod_ntsc_comb_3d')
+    modem = stacks.make('ntsc_comb_3d', g['size'])
+    eng = pinned(image.ImageModem(modem)._engine(), mode)
+    got = eng.demodulate_frames(g['inp'], first_frame=int(g['frames'][0]))
+    assert stacks.rel_err(got[0][:, g['rows']], g['out_rows'][0]) < TOL
+
+
 @pytest.mark.parametrize('name', sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(stacks.GOLDEN, 'image_*.npz')) +
                                         glob.glob(os.path.join(stacks.GOLDEN, 'imagefull_*.npz'))))
 def test_image_uint8_golden(name):

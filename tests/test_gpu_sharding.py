@@ -87,8 +87,28 @@ def test_bench_plain_invocations():
     two = _bench('--gpus', '2', '--frames', '24', '--steps', '2', '--warmup', '1', '--gather-frames', '3')
     assert two['n_gpus'] == 2 and two['check']['max_rel_err'] < 1e-5
     assert two['gather']['frames'] == 6 and two['gather']['own_share_intact'] and two['gather']['gather_ms'] > 0
+    # the CPU baseline and the additional configurations belong to the one-GPU line: rank 0 of an N > 1 run does not spend its time there
+    assert 'cpu_baseline' not in two and 'other_configs' not in two
+    # which device every rank ran on, as the ranks themselves report it
+    assert [d['rank'] for d in two['rank_devices']] == [0, 1] and all(d['name'] for d in two['rank_devices'])
+    assert one['roofline']['traffic_source'] and 'sclk_MHz_during_timed_steps' in one['roofline_valu']
     import torch
     if torch.cuda.device_count() >= 2:
         assert two['rccl_ranks'] == 2 and 'rehearsal' not in two
     else:
         assert two['rccl_ranks'] is None and 'rehearsal' in two
+
+
+def test_streams_on_several_devices_from_one_process():
+    """parallel.demodulate_streams ("or one process with 8 streams"): the fallback for a node where torch.distributed.run is
+    not usable.  Two streams on devices [0, 0] (the box has one GPU) equal two single calls bit for bit, frame numbers carried."""
+    import torch
+    from color_modem_amd import parallel
+    eng = image.ImageModem(stacks.make('pal_d', (720, 48)), batch_invariant=True)._engine()
+    a = testing.synthetic_composite(12, 48, 720, seed=5)
+    b = testing.synthetic_composite(9, 48, 720, seed=6)
+    devs = [0, min(1, torch.cuda.device_count() - 1)]
+    outs = parallel.demodulate_streams(eng, [a, b], devs, first_frames=[3, 15])
+    assert [o.device.index for o in outs] == devs and outs[0].shape == (12, 3, 48, 720) and outs[1].shape == (9, 3, 48, 720)
+    assert numpy.array_equal(outs[0].cpu().numpy(), eng.demodulate_frames(a, 3))
+    assert numpy.array_equal(outs[1].cpu().numpy(), eng.demodulate_frames(b, 15))

@@ -70,6 +70,14 @@ def test_image_uint8(name):
     assert diff.max() <= 1 and (diff > 0).mean() < 1e-3
 
 
+def test_full_size_frame_ntsc_3d_comb():
+    """BASELINE configs[2] at its full 720x480 size as floats: the rows the reference-generated set keeps (round 6)"""
+    g = stacks.load('framefull_demod_ntsc_comb_3d')
+    modem = stacks.make('ntsc_comb_3d', g['size'])
+    out = cm_oracle.OracleModem(modem).demodulate_frame(int(g['frames'][0]), g['inp'][0].astype(numpy.float64))
+    assert stacks.rel_err(out[:, g['rows']], g['out_rows'][0]) < TOL
+
+
 def test_degenerate_inputs():
     """Black / white / grey / saturated pictures and all-zero / constant composites through every family of the ORACLE (the C++ one and the numpy
     ones of MAC / Proto-SECAM / NIIR) against vectors the reference produced on exactly these inputs (tests/golden/degenerate_*.npz): until round

@@ -22,7 +22,7 @@ def test_frame_range_partitions():
         parallel.frame_range(4, 2, 2)
 
 
-def _worker(rank, world, port, result_path):
+def _worker(rank, world, port, result_path, n_frames=5):
     import sys
     here = os.path.dirname(os.path.abspath(__file__))
     sys.path.insert(0, os.path.dirname(here))
@@ -36,13 +36,13 @@ def _worker(rank, world, port, result_path):
     os.environ['MASTER_PORT'] = str(port)
     dist.init_process_group('gloo', rank=rank, world_size=world)
     modem = stacks.make('pal_d', (720, 8))
-    comp = testing.synthetic_composite(5, 8, 720, seed=77)
+    comp = testing.synthetic_composite(n_frames, 8, 720, seed=77)
 
     def demod(x, first):
         return torch.from_numpy(cm_oracle.demodulate_frames_f32(modem, numpy.asarray(x), first_frame=first))
 
     local = parallel.demodulate_frames_sharded(demod, torch.from_numpy(comp), first_frame=2, gather=False)
-    lo, hi = parallel.frame_range(5, world, rank)
+    lo, hi = parallel.frame_range(n_frames, world, rank)
     assert local.shape[0] == hi - lo
     full = parallel.demodulate_frames_sharded(demod, torch.from_numpy(comp), first_frame=2, gather=True)
     if rank == 0:
@@ -73,3 +73,22 @@ def test_two_rank_gloo_sharding(tmp_path):
     comp = testing.synthetic_composite(5, 8, 720, seed=77)
     want = cm_oracle.demodulate_frames_f32(modem, comp, first_frame=2)
     assert numpy.array_equal(got, want)
+
+
+def test_eight_rank_gloo_sharding(tmp_path):
+    """BASELINE configs[4] is eight ranks: the same path at world size 8 (uneven shares: 19 frames), CPU, the oracle as the compute
+    function - frame ranges, first_frame offsets and the padded all_gather of parallel.gather_frames at the driver's rank count."""
+    import torch.multiprocessing as mp
+    import stacks
+    from color_modem_amd import testing
+    from oracle import cm_oracle
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    result = str(tmp_path / 'full8.npy')
+    mp.spawn(_worker, args=(8, port, result, 19), nprocs=8, join=True)
+    got = numpy.load(result)
+    modem = stacks.make('pal_d', (720, 8))
+    comp = testing.synthetic_composite(19, 8, 720, seed=77)
+    want = cm_oracle.demodulate_frames_f32(modem, comp, first_frame=2)
+    assert got.shape == want.shape and numpy.array_equal(got, want)

@@ -30,6 +30,10 @@ for name in ('bench_line.json', 'bench_line_sustained.json', 'bench_line_default
         print('%-28s steps %5d  ms_per_step %.4f  kernel_ms %.4f  %.0f Mpixels/s  frac %.4f' % (name, d['steps'], d['ms_per_step'], d['roofline']['kernel_ms'], d['value'], d['roofline']['frac']))
         for c in d.get('other_configs', []):
             print('   other_configs: %-96s %.4f ms  %.0f Mpixels/s  frac %.4f  check %.2g' % (c['workload'][:96], c['ms'], c['mpixels_s'], c['roofline']['frac'], c['check']['max_rel_err']))
+        if d.get('other_configs_error'):
+            print('   other_configs FAILED: %s' % d['other_configs_error'])
+        print('   traffic_source: %s' % d['roofline'].get('traffic_source'))
+        print('   sclk during the timed steps: %s; VALU-limited %.4f ms at 2.4 GHz against %.4f measured' % (d['roofline_valu'].get('sclk_MHz_during_timed_steps'), d['roofline_valu'].get('valu_limited_ms_at_2400MHz', float('nan')), d['roofline']['kernel_ms']))
     except Exception as e:
         print(name, 'missing', e)
 PY

@@ -73,6 +73,22 @@ if 'FETCH_SIZE' in m and 'WRITE_SIZE' in m:
         pass
     if 'TCC_HIT_sum' in m:
         tj['l2_hit_rate'] = round(m['TCC_HIT_sum'] / (m['TCC_HIT_sum'] + m['TCC_MISS_sum']), 3)
+    # what the figure belongs to: bench.py refuses it for another build of the library (roofline.traffic_source)
+    import datetime
+    import hashlib
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib = os.environ.get('CM_LIB') or os.path.join(root, 'color_modem_amd', 'libcolor_modem_hip.so')
+    h = hashlib.sha256()
+    with open(lib, 'rb') as fh:
+        for block in iter(lambda: fh.read(1 << 20), b''):
+            h.update(block)
+    tj['lib_sha16'] = h.hexdigest()[:16]
+    tj['date'] = datetime.date.today().isoformat()
+    try:
+        tj['head'] = subprocess.check_output(['git', '-C', root, 'rev-parse', '--short', 'HEAD'], stderr=subprocess.DEVNULL).decode().strip()
+    except (OSError, subprocess.CalledProcessError):
+        tj['head'] = os.environ.get('CM_HEAD', 'unknown (no .git on the GPU box)')
     with open(os.path.join(out, 'traffic.json'), 'w') as fh:
         json.dump(tj, fh, indent=1)
 if 'SQ_WAVE_CYCLES' in m:
