@@ -32,6 +32,27 @@
 #define CM_DEMOD_PART (CM_MAIN_PART || CM_SHAPES_PART || CM_WIDE_PART)      /* parts that launch demod_pair_kernel instances */
 
 #include "../../include/color_modem_hip.h"
+
+#ifdef CM_HOST_DRY_RUN
+// Sanitizer build of the HOST code (tests/test_host_sanitize.py; round 6): `hipcc -fsanitize=address,undefined -DCM_HOST_DRY_RUN` makes a library whose plan constructors - descriptor validation, instance selection, every table builder and
+// coefficient conversion of cm_plan.h / cm_am_plan.h - run on a box WITHOUT a GPU: "device" tables are host allocations (so that ASan
+// watches every byte the constructors write), a device count of one is reported, and the compute entry points are never reached by that
+// test.  Nothing of this is compiled into the product library: without the macro a plan constructor answers CM_ERR_NO_DEVICE there.
+#include <cstdlib>
+namespace cm_dry {
+inline hipError_t malloc_(void **p, size_t n) { *p = std::malloc(n ? n : 1); return *p ? hipSuccess : hipErrorOutOfMemory; }
+inline hipError_t free_(void *p) { std::free(p); return hipSuccess; }
+inline hipError_t memcpy_(void *d, const void *s, size_t n, hipMemcpyKind) { std::memcpy(d, s, n); return hipSuccess; }
+inline hipError_t memset_(void *d, int v, size_t n) { std::memset(d, v, n); return hipSuccess; }
+inline hipError_t get_device_(int *d) { *d = 0; return hipSuccess; }
+}  // namespace cm_dry
+#define hipMalloc(p, n) cm_dry::malloc_((void **)(p), (n))
+#define hipFree(p) cm_dry::free_((void *)(p))
+#define hipMemcpy(d, s, n, k) cm_dry::memcpy_((void *)(d), (const void *)(s), (n), (k))
+#define hipMemset(d, v, n) cm_dry::memset_((void *)(d), (v), (n))
+#define hipGetDevice(d) cm_dry::get_device_(d)
+#endif
+
 #include "cm_kernels.h"
 #include "cm_mod_kernels.h"
 #include "cm_secam_kernels.h"
@@ -107,6 +128,11 @@ int allow_dynamic_lds(const void *kernel, int device, size_t bytes, const char *
     done.insert({kernel, device});
     return CM_OK;
 }
+#ifdef CM_HOST_DRY_RUN   /* the host sanitizer build never launches: no kernel instance is referenced, so none is compiled (a build of seconds) */
+#undef hipLaunchKernelGGL
+#define hipLaunchKernelGGL(...) ((void)0)
+#define allow_dynamic_lds(...) CM_OK
+#endif
 // A plan's tables live on the device that was current in cm_*_plan_create.  Every compute entry point checks that this
 // device is still the current one and that both image buffers are device memory of it: a plan used under another current
 // device, or fed another GPU's pointers, would otherwise fault inside the kernel (or run over peer access) instead of
@@ -1360,9 +1386,13 @@ const char *cm_last_error(void) { return g_error.c_str(); }
 int cm_abi_version(void) { return CM_ABI_VERSION; }
 
 int cm_device_count(void) {
+#ifdef CM_HOST_DRY_RUN
+    return 1;      // the host sanitizer build: plans are built against host memory (top of this file)
+#else
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;
     return n;
+#endif
 }
 
 // ---- FilterFunction.__call__ (utils.py:28-36) as a callable of its own: float64, one lane per row -------------------------------
@@ -1512,6 +1542,19 @@ int cm_plan_create(const cm_plan_desc *desc, cm_plan **out) {
         return fail(CM_ERR_INVALID, "demod_main table missing");
     if (desc->first_is_plain && (!desc->demod_first.table || desc->demod_first.n_lines != desc->demod_main.n_lines))
         return fail(CM_ERR_INVALID, "demod_first table missing or of different size");
+    {   // every filter record: a section count the descriptor can hold, a FilterFunction shift of sane size (found by the host sanitizer sweep of
+        // round 6: a negative count slipped through the run-time shape's padding as "no sections")
+        const struct { const cm_iir_desc *f; const char *name; } filters[] = {
+            {&desc->extract2x, "extract2x"}, {&desc->remove2x, "remove2x"}, {&desc->demod_lp, "demod_lp"}, {&desc->pald_lp, "pald_lp"},
+            {&desc->precorrect, "precorrect"}, {&desc->notch, "notch"}, {&desc->secam.pre_lp, "secam.pre_lp"}, {&desc->secam.lf_pre, "secam.lf_pre"},
+            {&desc->secam.lf_rev, "secam.lf_rev"}, {&desc->secam.bell, "secam.bell"}, {&desc->secam.chroma_bp, "secam.chroma_bp"},
+            {&desc->secam.luma_bs, "secam.luma_bs"}, {&desc->secam.fm_lp, "secam.fm_lp"}};
+        for (const auto &e : filters) {
+            if (e.f->n_sections < 0 || e.f->n_sections > CM_MAX_SECTIONS)
+                return fail(CM_ERR_INVALID, std::string(e.name) + ": n_sections must be 0 .. " + std::to_string(CM_MAX_SECTIONS));
+            if (e.f->shift < -4096 || e.f->shift > 4096) return fail(CM_ERR_INVALID, std::string(e.name) + ": FilterFunction shift out of range");
+        }
+    }
     if (cm_device_count() < 1) return fail(CM_ERR_NO_DEVICE, "no HIP device available (this library has no CPU path)");
     cm_plan *p = new cm_plan;
     p->desc = *desc;
