@@ -7,10 +7,15 @@
 
 #include <cmath>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../../include/color_modem_hip.h"
 #include "cm_stages.h"
+
+#ifndef CM_SECAM_FIRST_ORDER      /* 0: the SECAM encoder's first-order sections in the general five-operation form (A/B: profiles/r06_secam_mod_bound.txt) */
+#define CM_SECAM_FIRST_ORDER 1
+#endif
 
 namespace cm {
 
@@ -246,6 +251,16 @@ bool build_secam_mod_k(const cm_plan_desc &d, SecamModK<T, TD> &k, std::string &
     if (!convert_sos<TD, 2>(s.pre_lp, FORM_GEN, k.pre_lp, g1, err, "pre_lp", true)) return false;   // order 2 at low sampling rates (SECAM-A on 405 lines)
     if (!convert_sos_optional<TD, 1>(s.lf_pre, FORM_GEN, k.lf_pre, g2, err, "lf_pre")) return false;
     if (s.lf_pre.shift != 0 || s.pre_lp.shift < 0) { err = "SECAM encoder filter shifts outside what the kernel is built for"; return false; }
+    {   // first-order sections (b2 = a2 = 0) run in their own three-operation form (cm_stages.h: SecamMod::step); pre_lp's second-order
+        // section goes in front of its first-order one (the cascade's order changes its rounding at the float64 level only)
+        auto first_order = [](const SosK<TD, 2> &f, int j) { return f.na2[j] == TD(0) && f.b2[j] == TD(0); };
+        if (first_order(k.pre_lp, 0) && !first_order(k.pre_lp, 1)) {
+            std::swap(k.pre_lp.na1[0], k.pre_lp.na1[1]); std::swap(k.pre_lp.na2[0], k.pre_lp.na2[1]);
+            std::swap(k.pre_lp.b1[0], k.pre_lp.b1[1]); std::swap(k.pre_lp.b2[0], k.pre_lp.b2[1]);
+        }
+        k.pre_tail_first = (CM_SECAM_FIRST_ORDER && first_order(k.pre_lp, 1)) ? 1 : 0;
+        k.lf_first = (CM_SECAM_FIRST_ORDER && k.lf_pre.na2[0] == TD(0) && k.lf_pre.b2[0] == TD(0)) ? 1 : 0;
+    }
     k.width = d.width;
     k.s_p = s.pre_lp.shift;
     k.gain = TD(g1 * g2);

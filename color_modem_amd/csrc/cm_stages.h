@@ -41,7 +41,7 @@
     (defined(CM_EXP_NO_LUMA) || defined(CM_EXP_NO_STORE) || defined(CM_EXP_PLAIN_STORE) || defined(CM_EXP_NO_FILL_WAIT) ||   \
      defined(CM_EXP_NO_BSKIP) || defined(CM_EXP_ROLE_SWAP) || defined(CM_EXP_NO_FIR) || defined(CM_EXP_NO_PKFIR) ||          \
      defined(CM_EXP_NO_LPF) || defined(CM_EXP_SECAM_ALWAYS_FAST) || defined(CM_EXP_SECAM_NO_LPF) ||                          \
-     defined(CM_EXP_SECAM_NO_PHASE) || defined(CM_DEV_ROLE))
+     defined(CM_EXP_SECAM_NO_PHASE) || defined(CM_EXP_SECAM_MOD_F32) || defined(CM_DEV_ROLE))
 #error "CM_EXP_* / CM_DEV_ROLE switches produce wrong results by design: build them with -DCM_EXPERIMENTS (tools/dev_build.sh)"
 #endif
 
@@ -903,6 +903,8 @@ struct SecamModK {
     SosK<TD, 2> pre_lp;     // secam.py:171-172 (order 3: a first- and a second-order section)
     SosK<TD, 1> lf_pre;     // secam.py:175-177 forward
     TD gain;                // product of the section gains of both filters
+    int32_t pre_tail_first, lf_first;   // 1: pre_lp's second section / lf_pre is a FIRST-order section (b2 = a2 = 0; the host puts pre_lp's
+                                        // second-order section in front): three float64 operations instead of five, the same results bit for bit
     TD f_min, f_max, f0, pi, two_pi;
     T m0, kn, kd;
     T e[3][3];              // (luma, dr, db) = e . (r, g, b)
@@ -988,10 +990,48 @@ struct SecamMod {
                 if (n == W - 1) d_last = dd;
                 if (n >= W) dd = d_last;
             }
-            w = iir_gen<false>(pre_lp, k.pre_lp, dd);
+            // round 6: the order-3 pre-correction low-pass is a second-order and a FIRST-order section, the LF pre-emphasis a first-order
+            // one (secam.py:171-177, 211-221); the general section form spent two of its five float64 operations per sample on their
+            // b2 = a2 = 0 (12 of the encoder's ~20 float64 operations per pixel are these three sections' - profiles/r06_secam_mod_bound.txt)
+#if defined(CM_EXPERIMENTS) && defined(CM_EXP_SECAM_MOD_F32)   /* VERDICT r05 item 6's float32 sections: every operation of the two filters rounded to float32
+            (states kept in float64 variables, so this measures the ERROR of that arithmetic, not its speed) - profiles/r06_secam_mod_bound.txt */
+            if (k.pre_tail_first) {
+                const float xd = (float)dd, b10 = (float)k.pre_lp.b1[0], b20 = (float)k.pre_lp.b2[0], a10 = (float)k.pre_lp.na1[0], a20 = (float)k.pre_lp.na2[0];
+                const float y0 = xd + (float)pre_lp.s1[0];
+                const float t0 = __builtin_fmaf(b10, xd, (float)pre_lp.s2[0]);
+                pre_lp.s1[0] = (TD)__builtin_fmaf(a10, y0, t0);
+                pre_lp.s2[0] = (TD)__builtin_fmaf(a20, y0, b20 * xd);
+                const float w1 = y0 + (float)pre_lp.s1[1];
+                pre_lp.s1[1] = (TD)__builtin_fmaf((float)k.pre_lp.na1[1], w1, (float)k.pre_lp.b1[1] * y0);
+                w = (TD)w1;
+            } else
+#endif
+            if (k.pre_tail_first) {
+                TD y0 = dd + pre_lp.s1[0];
+                const TD t0 = fma3<false>(k.pre_lp.b1[0], dd, pre_lp.s2[0]);
+                pre_lp.s1[0] = fmaf_(k.pre_lp.na1[0], y0, t0);
+                pre_lp.s2[0] = fmaf_(k.pre_lp.na2[0], y0, k.pre_lp.b2[0] * dd);
+                w = y0 + pre_lp.s1[1];
+                pre_lp.s1[1] = fmaf_(k.pre_lp.na1[1], w, k.pre_lp.b1[1] * y0);      // (= the general form with s2 = 0: b1 y0 + 0)
+            } else {
+                w = iir_gen<false>(pre_lp, k.pre_lp, dd);
+            }
         }
         if (EDGE && (n7 < 0 || n7 >= W)) return T(0);
-        TD x = iir_gen<false>(lf_pre, k.lf_pre, w);
+        TD x;
+#if defined(CM_EXPERIMENTS) && defined(CM_EXP_SECAM_MOD_F32)
+        if (k.lf_first) {
+            const float xf = (float)w + (float)lf_pre.s1[0];
+            lf_pre.s1[0] = (TD)__builtin_fmaf((float)k.lf_pre.na1[0], xf, (float)k.lf_pre.b1[0] * (float)w);
+            x = (TD)xf;
+        } else
+#endif
+        if (k.lf_first) {
+            x = w + lf_pre.s1[0];
+            lf_pre.s1[0] = fmaf_(k.lf_pre.na1[0], x, k.lf_pre.b1[0] * w);
+        } else {
+            x = iir_gen<false>(lf_pre, k.lf_pre, w);
+        }
         TD f = fmaf_(lk.fdev * k.gain, x, lk.fsc);                    // secam.py:266 / 271
         f = clamp_(f, k.f_min, k.f_max);                              // secam.py:272 (v_max_f64 + v_min_f64: two instructions, not six)
         // bell pre-emphasis G = m0 (1 + j kn F) / (1 + j kd F), F = f / f0 - f0 / f (secam.py:241-243)
