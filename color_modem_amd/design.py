@@ -1,11 +1,35 @@
 # -*- coding: utf-8 -*-
-"""Filter design without scipy (host side, numpy only).
+# Ported from scipy.signal (scipy 1.15: _filter_design.py - buttap, cheb1ap, cheb2ap, besselap, lp2lp_zpk / lp2hp_zpk / lp2bp_zpk /
+# lp2bs_zpk, bilinear_zpk, zpk2tf, zpk2sos with _cplxreal / _nearest_real_complex_idx, iirfilter, buttord, iirnotch, group_delay, freqz;
+# _fir_filter_design.py - firwin with the Kaiser window; scipy.optimize's bounded scalar minimiser _minimize_scalar_bounded, as buttord
+# uses it).  Helper names, variable names and control flow follow scipy's; what this package adds is the numpy-only packaging of the
+# subset the modems request.  scipy is distributed under the BSD 3-clause licence, reproduced here as it requires:
+#
+#   Copyright (c) 2001-2002 Enthought, Inc. 2003-2024, SciPy Developers.
+#   All rights reserved.
+#
+#   Redistribution and use in source and binary forms, with or without modification, are permitted provided that the following
+#   conditions are met:
+#   1. Redistributions of source code must retain the above copyright notice, this list of conditions and the following disclaimer.
+#   2. Redistributions in binary form must reproduce the above copyright notice, this list of conditions and the following disclaimer
+#      in the documentation and/or other materials provided with the distribution.
+#   3. Neither the name of the copyright holder nor the names of its contributors may be used to endorse or promote products derived
+#      from this software without specific prior written permission.
+#
+#   THIS SOFTWARE IS PROVIDED BY THE COPYRIGHT HOLDERS AND CONTRIBUTORS "AS IS" AND ANY EXPRESS OR IMPLIED WARRANTIES, INCLUDING, BUT
+#   NOT LIMITED TO, THE IMPLIED WARRANTIES OF MERCHANTABILITY AND FITNESS FOR A PARTICULAR PURPOSE ARE DISCLAIMED. IN NO EVENT SHALL
+#   THE COPYRIGHT OWNER OR CONTRIBUTORS BE LIABLE FOR ANY DIRECT, INDIRECT, INCIDENTAL, SPECIAL, EXEMPLARY, OR CONSEQUENTIAL DAMAGES
+#   (INCLUDING, BUT NOT LIMITED TO, PROCUREMENT OF SUBSTITUTE GOODS OR SERVICES; LOSS OF USE, DATA, OR PROFITS; OR BUSINESS
+#   INTERRUPTION) HOWEVER CAUSED AND ON ANY THEORY OF LIABILITY, WHETHER IN CONTRACT, STRICT LIABILITY, OR TORT (INCLUDING NEGLIGENCE
+#   OR OTHERWISE) ARISING IN ANY WAY OUT OF THE USE OF THIS SOFTWARE, EVEN IF ADVISED OF THE POSSIBILITY OF SUCH DAMAGE.
+"""Filter design without scipy at run time (host side, numpy only) - a port of the scipy.signal routines the path requests (see the
+licence notice above).
 
 The reference designs every filter of the path with ``scipy.signal`` at construction time (/root/reference/color_modem/
 utils.py:9-64 ``FilterFunction`` + ``iirfilter`` / ``iirdesign``; ``comb.py:18-20`` ``iirnotch``; the FIR that
 ``resample_poly`` builds behind ``qam.py:35-57``, ``secam.py:136-149``, ``niir.py:109-145``, ``protosecam.py:83-102``,
-``mac.py:49-91``).  scipy is a third-party dependency with no pinned version there; this module restates
-the published algorithms those calls run - analog prototypes, frequency transformations, the bilinear transform,
+``mac.py:49-91``).  scipy is a third-party dependency with no pinned version there; this module carries
+scipy's own implementations of what those calls run - analog prototypes, frequency transformations, the bilinear transform,
 Butterworth order selection (with the bounded scalar minimiser its band-stop case uses), zero / pole pairing into
 second-order sections, the Kaiser-windowed low-pass - so that the product's plan constants do not move with the installed
 scipy.  ``tests/test_design.py`` holds every function to scipy's result (<= 1e-13) over every design the modems request,

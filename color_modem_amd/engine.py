@@ -220,7 +220,7 @@ def make_engine(modem, components=False, strip_chroma=True, min_lines=0, line_of
         eng = make_engine(modem, components, strip_chroma, min_lines)
         if isinstance(eng, Engine):
             return Engine(_OffsetStack(modem._stack(), line_offset), components, strip_chroma, min_lines)
-        if isinstance(eng, AmEngine):       # line geometry per lane on the device, any line number (cm_am_stages.h: AmLine)
+        if isinstance(eng, (AmEngine, MacEngine)):       # line geometry per lane on the device, any line number (cm_am_stages.h: AmLine; cm_mac_kernels.h)
             return eng
         if getattr(eng, 'encoder', None) is not None and isinstance(eng.encoder, Engine):
             # a composition whose encoder is its leaf's engine (comb.py:90-94): that one gets the offset tables
@@ -327,6 +327,11 @@ class Engine(_EngineBase):
         buf = ctypes.create_string_buffer(512)
         _native.lib().cm_plan_describe(self._plan, buf, 512)
         return buf.value.decode()
+
+    def has_fused_u8(self, direction):
+        """ImageModem's byte boundary inside the kernels (cm_*_frames_u8): every decoder instance at widths that are multiples of 4, every
+        encoder at multiples of 16 (the byte tiles)"""
+        return self.width % (4 if direction == 'demod' else 16) == 0
 
     SMALL_BATCH = {'auto': 0, 'rows': 1, 'segments': 2, 'scan': 3}
 
@@ -453,6 +458,9 @@ class MacEngine(_EngineBase):
             return 'mac_demod_kernel / mac_mod_kernel: one workgroup of 256 threads per 8 rows of a field, threads along the row'
         return 'mac_demod_generic_kernel / mac_mod_generic_kernel (resampling rows / lines): one workgroup per call'
 
+    def has_fused_u8(self, direction):
+        return True        # the resampling kernels carry the byte boundary for every shape
+
     def _needs_rows(self, n):
         if self.height < 2 * self.modulation_delay and n:
             raise IndexError('image.py:49-50 feeds row 1 ahead of a field under modulation_delay 1: the image has %d row(s)' % self.height)
@@ -532,6 +540,11 @@ class AmEngine(_EngineBase):
         L = _native.lib()
         self._plans = _DevicePlans(lambda out: L.cm_am_plan_create(ctypes.byref(d), out), L.cm_am_plan_destroy)
         self._plan
+
+    def has_fused_u8(self, direction):
+        if direction == 'demod':
+            return self.width % 4 == 0
+        return self.width % 16 == 0 and self.noise_level == 0.0      # (the noisy NIIR encoder has no byte form)
 
     def _noise(self, calls, newest_only=False):
         """(numpy.random.random_sample(W) - 0.5) * noise_level for db, then dr, per call in call order - exactly the

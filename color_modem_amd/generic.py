@@ -107,6 +107,9 @@ class _GenericBase(object):
         for e in self._engines():
             e.set_small_batch(mode)
 
+    def has_fused_u8(self, direction):
+        return False       # float rows; ImageModem converts on the device around them (the subclasses pass through what is their backend's)
+
     def demodulate_frames_u8(self, composite8, first_frame=0, out=None):
         raise NotImplementedError('a level-by-level stack runs on float rows (ImageModem converts on the device around them)')
 
@@ -163,7 +166,11 @@ class GenericCombEngine(_GenericBase):
         if not callable(self.avg):
             raise TypeError('avg=%r is not callable' % (self.avg,))
         self.notch = modem._notch if self.strip else None
-        lc = _leaf(b).line_config
+        leaf = _leaf(b)
+        if not callable(getattr(type(leaf), 'demodulate_components', None)) or _leaf_kind(leaf)['kind'] in ('mac', 'secam', 'protosecam'):
+            # the reference fails the same way at the first row: these modems have no demodulate_components for a comb wrapper to call (comb.py:98)
+            raise AttributeError("'%s' object has no attribute 'demodulate_components'" % type(leaf).__name__)
+        lc = leaf.line_config
         # per-line tables of the engines below: the calls of a field run to line height + 2 (delays), the strip lines a few further
         min_lines = max(int(min_lines), int(lc.size[1]) + 2 * (int(getattr(b, 'demodulation_delay', 0)) + int(getattr(b, 'modulation_delay', 0)) + 1) + 8)
         self.inner = engine.make_engine(b, components=True, strip_chroma=False, min_lines=min_lines)     # comb.py:98 / 101
@@ -241,6 +248,9 @@ class GenericCombEngine(_GenericBase):
     def modulate_frames_u8(self, rgb8, first_frame=0, out=None):
         return self.encoder.modulate_frames_u8(rgb8, first_frame, out=out)
 
+    def has_fused_u8(self, direction):
+        return direction == 'mod' and self.encoder.has_fused_u8('mod')       # comb.py:90-94: encoding is the backend's
+
 
 class GenericAveragingEngine(_GenericBase):
     """ColorAveragingModem around any backend with modulate_components: comb.py:141-155 over whole runs; decoding is the backend's."""
@@ -296,6 +306,9 @@ class GenericAveragingEngine(_GenericBase):
 
     def demodulate_frames_u8(self, composite8, first_frame=0, out=None):
         return self.decoder.demodulate_frames_u8(composite8, first_frame, out=out)
+
+    def has_fused_u8(self, direction):
+        return direction == 'demod' and self.decoder.has_fused_u8('demod')   # comb.py:157-161: decoding is the backend's
 
 
 def make(modem, components=False, strip_chroma=True, min_lines=0, line_offset=0):
@@ -373,6 +386,9 @@ class RowLoopEngine(object):
             out.copy_(t)
             return out
         return t
+
+    def has_fused_u8(self, direction):
+        return False
 
     def demodulate_frames_u8(self, composite8, first_frame=0, out=None):
         raise NotImplementedError('a foreign modem object runs on float rows')

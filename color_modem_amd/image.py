@@ -13,6 +13,16 @@ import numpy
 from color_modem_amd import engine as _engine
 
 
+def _fused_u8(eng, direction):
+    """Does this engine carry ImageModem's byte boundary inside its kernels for this direction?  An explicit answer (round 6; before, every
+    NotImplementedError of the byte entry point - a pinned small-batch family, a capturing stream - silently switched to the float path with
+    its own LSB rounding): engines say so through has_fused_u8(direction); the plan-based engines by their shape."""
+    probe = getattr(eng, 'has_fused_u8', None)
+    if probe is not None:
+        return bool(probe(direction))
+    return False
+
+
 def _as_bytes(array):
     # same clamp + round-half-even as ref image.py:7-8
     return numpy.uint8(numpy.rint(255.0 * numpy.clip(array, 0.0, 1.0)))
@@ -59,10 +69,10 @@ class ImageModem(object):
         """composite uint8 [F, H, W] -> rgb uint8 [F, H, W, 3], the byte conversions of ImageModem fused into the kernel; for the stacks
         without a fused byte boundary (notches with a FilterFunction shift, avg= callables, widths that are not a multiple of 4) the same
         conversions run on the device around the float path (round 5: no host detour, identical bytes to the host-side formulas)."""
-        try:
-            return self._engine().demodulate_frames_u8(composite8, first_frame)
-        except NotImplementedError:
-            return self._bytes_around_float(composite8, first_frame, demod=True)
+        eng = self._engine()
+        if _fused_u8(eng, 'demod'):
+            return eng.demodulate_frames_u8(composite8, first_frame)       # (a refusal of the native layer now surfaces instead of changing the path)
+        return self._bytes_around_float(composite8, first_frame, demod=True)
 
     def modulate_frames(self, rgb, first_frame=0):
         """rgb [F, 3, H, W] float32 -> composite [F, H, W] float32."""
@@ -71,10 +81,10 @@ class ImageModem(object):
     def modulate_frames_u8(self, rgb8, first_frame=0):
         """rgb uint8 [F, H, W, 3] -> composite uint8 [F, H, W], the byte conversions of ImageModem fused into the kernel (widths that are not
         a multiple of 16, the noisy NIIR encoder: the same conversions on the device around the float path)."""
-        try:
-            return self._engine().modulate_frames_u8(rgb8, first_frame)
-        except NotImplementedError:
-            return self._bytes_around_float(rgb8, first_frame, demod=False)
+        eng = self._engine()
+        if _fused_u8(eng, 'mod'):
+            return eng.modulate_frames_u8(rgb8, first_frame)
+        return self._bytes_around_float(rgb8, first_frame, demod=False)
 
     def _bytes_around_float(self, x8, first_frame, demod):
         """image.py:24-25, 47-55, 62, 75-83 as torch operations on the device, in float64 like the reference's numpy (so that every byte
@@ -87,9 +97,11 @@ class ImageModem(object):
         if not t.is_cuda:
             t = t.cuda()
         n, h, w = int(t.shape[0]), int(t.shape[1]), int(t.shape[2])
-        out = torch.empty((n, h, w, 3) if demod else (n, h, w), dtype=torch.uint8, device=t.device)
-        step = max(1, (1 << 28) // max(1, h * w * 3 * 8))
         eng = self._engine()
+        # picture and composite widths differ for some engines (MacEngine: 720 <-> 1080): the result is sized by the engine, not by the input
+        w_out = int(getattr(eng, 'width', w)) if demod else int(getattr(eng, 'comp_width', w))
+        out = torch.empty((n, h, w_out, 3) if demod else (n, h, w_out), dtype=torch.uint8, device=t.device)
+        step = max(1, (1 << 28) // max(1, h * max(w, w_out) * 3 * 8))
         for f0 in range(0, n, step):
             part = t[f0:f0 + step]
             if demod:

@@ -68,6 +68,9 @@ class ShiftedNotchEngine(object):
     def describe(self):
         return '%s (components, no notch) | filter_rows_kernel<float> (notch, shift %d) + matrix_planes_kernel' % (self.base.describe(), self.notch.shift)
 
+    def has_fused_u8(self, direction):
+        return direction == 'mod' and self.encoder.has_fused_u8('mod')      # the decoder is a composition of float kernels
+
     def set_small_batch(self, mode):
         self.base.set_small_batch(mode)
         self.encoder.set_small_batch(mode)

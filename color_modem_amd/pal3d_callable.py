@@ -82,9 +82,19 @@ class Pal3DCallableEngine(object):
         self._a = numpy.ascontiguousarray(f.a if f is not None else [1.0], dtype=numpy.float64)
         self._shift = int(f.shift) if f is not None else 0
 
+    def _row_parity(self, h):
+        """analog_line(row) % 2 for the rows of a picture (line.py:57-62), cached"""
+        cached = getattr(self, '_parity', None)
+        if cached is None or len(cached) != h:
+            cached = self._parity = numpy.array([self.lc.analog_line(int(r)) % 2 for r in range(h)], dtype=numpy.int64)
+        return cached
+
     def describe(self):
         return ('Pal3DModem(avg=f): 2 x %s (one estimate each, components) | f on the device | qam_mod_kernel (strip) | filter_rows_kernel + matrix'
                 % self.a.describe().split(';')[0])
+
+    def has_fused_u8(self, direction):
+        return direction == 'mod' and self.encoder.has_fused_u8('mod')      # the decoder is a composition of float kernels
 
     def set_small_batch(self, mode):
         for e in (self.a, self.b, self.mod, self.encoder):
@@ -96,7 +106,9 @@ class Pal3DCallableEngine(object):
         return avgfn.apply(self.fn, x, y)
 
     def _combine(self, ya, yb, sign, plain):
-        """ya, yb [..., 3, rows, W] from the two engines; sign [..., rows, 1] = the V-switch sign of the stripped line; plain [..., rows, 1]
+        """(f sees whole batches - the rows of the calls k < 2 of a run included, whose results are discarded below; the reference never calls
+        it there, pal.py:191-201: an f that is not defined on every finite pair of arrays should mask by itself.)
+        ya, yb [..., 3, rows, W] from the two engines; sign [..., rows, 1] = the V-switch sign of the stripped line; plain [..., rows, 1]
         (bool): rows that never reach f (calls k < 2) -> (y, u, v) with u, v combined"""
         import torch
         u = self._apply(ya[..., 1, :, :], yb[..., 1, :, :])
@@ -138,7 +150,9 @@ class Pal3DCallableEngine(object):
             part = comp[f0:f0 + step]
             m = int(part.shape[0])
             frames = numpy.arange(first_frame + f0, first_frame + f0 + m)
-            sgn = numpy.array([[-1.0 if self.lc.is_alternate_line(int(f), int(r)) else 1.0 for r in rows] for f in frames], dtype=numpy.float32)
+            # line.py:64-65: a line is an alternate one when its analog line number has the frame's parity - the rows' parities once per
+            # engine, the frames' per chunk (round 6: this was a Python loop over every (frame, row) of the chunk)
+            sgn = numpy.where(self._row_parity(h)[None, :] == (frames % 2)[:, None], -1.0, 1.0).astype(numpy.float32)
             sign = torch.from_numpy(sgn).to(comp.device).reshape(m, h, 1)
             ya = self.a.demodulate_frames(part, first_frame + f0)
             yb = self.b.demodulate_frames(part, first_frame + f0)

@@ -135,6 +135,11 @@ class WrappedCombEngine(object):
             text = 'long batches: %s + the composition on the top four rows; otherwise %s' % (self.fused.describe(), text)
         return text
 
+    def has_fused_u8(self, direction):
+        if direction == 'mod':
+            return self.encoder.has_fused_u8('mod')
+        return self.width % 4 == 0 and self.custom_avg is None       # (avg= callables sit between two float kernels)
+
     def set_small_batch(self, mode):
         """Engine.set_small_batch for the plans a wrapped decode runs through (inner decoder, plain first line, back end) and the encoder's."""
         for e in (self.inner, self.first, self.mod, self.encoder):

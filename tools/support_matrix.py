@@ -74,9 +74,46 @@ def widths():
                 sys.stdout.flush()
 
 
+def nested():
+    """Round 6: every wrapper around every backend kind, two levels deep - what the reference's classes accept (comb.py:71-167 sit on any
+    backend with demodulate_components / modulate_components) must run here; where the REFERENCE itself raises (a comb wrapper needs
+    demodulate_components: SecamModem, ProtoSecamModem and MacModem have none - AttributeError at the first row) the same refusal is
+    expected.  One line per stack: ok / the error."""
+    from color_modem_amd.color import mac, niir, protosecam
+    lc, ln = line.LineConfig((720, 20), line.LineStandard.GERBER_625), line.LineConfig((720, 20), line.LineStandard.NTSC_525)
+    leaves = [('PalS', lc, lambda c: pal.PalSModem(c), True), ('PalD', lc, lambda c: pal.PalDModem(c), True), ('Pal3D', lc, lambda c: pal.Pal3DModem(c), True),
+              ('Pal3D(avg=f)', lc, lambda c: pal.Pal3DModem(c, avg=lambda a, b: 0.25 * a + 0.75 * b), True),
+              ('Ntsc', ln, lambda c: ntsc.NtscModem(c), True), ('NtscComb', ln, lambda c: ntsc.NtscCombModem(c), True),
+              ('Niir', lc, lambda c: niir.NiirModem(c), True), ('HueCorrectingNiir', lc, lambda c: niir.HueCorrectingNiirModem(c), True),
+              ('Secam', lc, lambda c: secam.SecamModem(c), False), ('ProtoSecam', lc, lambda c: protosecam.ProtoSecamModem(c), False),
+              ('Mac', lc, lambda c: mac.MacModem(c), False)]
+    wrappers = [('Simple', lambda m: comb.SimpleCombModem(m)), ('Simple3D', lambda m: comb.Simple3DCombModem(m)),
+                ('Simple(minavg)', lambda m: comb.SimpleCombModem(m, avg=comb.minavg)), ('Avg', lambda m: comb.ColorAveragingModem(m))]
+    rows = bad = 0
+    for lname, cfg, leaf, has_components in leaves:
+        for n1, w1 in wrappers:
+            for n2, w2 in [('', None)] + wrappers:
+                name = ('%s(%s(%s))' % (n2, n1, lname)) if w2 else '%s(%s)' % (n1, lname)
+                modem = w1(leaf(cfg))
+                if w2:
+                    modem = w2(modem)
+                # the reference raises AttributeError where a comb wrapper meets a backend without demodulate_components
+                comb_on_top = ('Simple' in n1) or ('Simple' in n2)
+                expect_refusal = comb_on_top and not has_components
+                res = try_pair(lambda c, v: modem, None, cfg.size if hasattr(cfg, 'size') else (720, 20))
+                ok = ('ERROR' not in res and 'construct' not in res and 'demod:' not in res) if not expect_refusal else ('AttributeError' in res or 'demod' in res or 'construct' in res)
+                rows += 1
+                bad += 0 if ok else 1
+                print('%-44s %s%s' % (name, res[:110], '' if ok else '    <-- UNEXPECTED'))
+                sys.stdout.flush()
+    print('%d nested stacks, %d unexpected results' % (rows, bad))
+
+
 def main():
     if sys.argv[1:2] == ['widths']:
         return widths()
+    if sys.argv[1:2] == ['nested']:
+        return nested()
     for system, cls in (('pal', pal.PalVariant), ('ntsc', ntsc.NtscVariant), ('secam', secam.SecamVariant)):
         for vname in variants(cls):
             v = getattr(cls, vname)
