@@ -41,8 +41,8 @@ class MacModem(RowApi):
             self._width = int(variant_or_width.width)
         except AttributeError:
             self._width = int(variant_or_width)
-        if self._width < 1 or self._width > 4096 or line_config.size[0] > 1920:
-            raise NotImplementedError('MacModem: lines of 1 .. 4096 samples and rows of up to 1920 samples are built')
+        if self._width < 1 or self._width > 16384 or line_config.size[0] > 4096:
+            raise NotImplementedError('MacModem: lines of 1 .. 16384 samples and rows of up to 4096 samples are built (a call\'s rows live in one CU\'s LDS)')
 
     @staticmethod
     def encode_components(r, g, b):

@@ -80,6 +80,15 @@ int mac_launch(const cm_mac_plan *p, bool demod, const float *in, float *out, in
         g.luma_in.stage = g.chroma_in.stage = g.line_out.stage = g.line_in.stage = 0;
         if (demod) stage(g.line_in, lds_demod);
         else { stage(g.luma_in, lds_mod); stage(g.chroma_in, lds_mod); stage(g.line_out, lds_mod); }
+        // rows beyond 1920 samples / lines beyond ~13000 take more than the 64 KiB a kernel gets by default (round 6: up to the CU's 160 KiB)
+        if (demod && lds_demod > 64 * 1024) {
+            if (int rc = u8 ? allow_dynamic_lds((const void *)cm::mac_demod_generic_kernel<true>, p->device, lds_demod, "the MAC decoder")
+                            : allow_dynamic_lds((const void *)cm::mac_demod_generic_kernel<false>, p->device, lds_demod, "the MAC decoder")) return rc;
+        }
+        if (!demod && lds_mod > 64 * 1024) {
+            if (int rc = u8 ? allow_dynamic_lds((const void *)cm::mac_mod_generic_kernel<true>, p->device, lds_mod, "the MAC encoder")
+                            : allow_dynamic_lds((const void *)cm::mac_mod_generic_kernel<false>, p->device, lds_mod, "the MAC encoder")) return rc;
+        }
         if (demod && u8) hipLaunchKernelGGL(cm::mac_demod_generic_kernel<true>, dim3((unsigned)blocks), dim3(cm::kMacThreads), lds_demod, stream, g);
         else if (demod) hipLaunchKernelGGL(cm::mac_demod_generic_kernel<false>, dim3((unsigned)blocks), dim3(cm::kMacThreads), lds_demod, stream, g);
         else if (u8) hipLaunchKernelGGL(cm::mac_mod_generic_kernel<true>, dim3((unsigned)blocks), dim3(cm::kMacThreads), lds_mod, stream, g);
@@ -102,8 +111,10 @@ int cm_mac_plan_create(const cm_mac_desc *desc, cm_mac_plan **out) {
     if (!desc || !out) return fail(CM_ERR_INVALID, "null argument");
     *out = nullptr;
     if (desc->height <= 0 || desc->width <= 0 || desc->line_width <= 0) return fail(CM_ERR_INVALID, "width, height and line width must be positive");
-    if (desc->width > 1920) return fail(CM_ERR_UNSUPPORTED, "MAC: rows of more than 1920 samples do not fit the encoder's LDS layout");
-    if (desc->line_width > 4096) return fail(CM_ERR_UNSUPPORTED, "MAC: lines of more than 4096 samples are not supported");
+    // one workgroup holds a call's rows in LDS: (7 with line averaging, else 4) rows of `width` floats + 2160 in the encoder, the line + 2904
+    // in the decoder, of the CU's 160 KiB (ref mac.py:49-55, 71-74, 88-91 take any rational ratio; rounds 1 - 5 stopped at 1920 / 4096)
+    if (desc->width > 4096) return fail(CM_ERR_UNSUPPORTED, "MAC: rows of more than 4096 samples do not fit the encoder's LDS layout");
+    if (desc->line_width > 16384) return fail(CM_ERR_UNSUPPORTED, "MAC: lines of more than 16384 samples do not fit the decoder's LDS layout");
     if (cm_device_count() <= 0) return fail(CM_ERR_NO_DEVICE, "no HIP device: the MAC path runs on the GPU only");
     cm_mac_plan *p = new cm_mac_plan();
     p->desc = *desc;

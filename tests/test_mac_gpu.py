@@ -152,7 +152,8 @@ def test_resampled_golden(name):
         assert back.shape == (3, H, 720) and stacks.rel_err(back, g['back'][i]) < TOL, (name, int(f))
 
 
-@pytest.mark.parametrize('width,line_width', [(720, 720), (1920, 1080), (479, 1081), (704, 720)])
+@pytest.mark.parametrize('width,line_width', [(720, 720), (1920, 1080), (479, 1081), (704, 720),
+                                              (2560, 1080), (3840, 5000), (720, 14000)])      # round 6: beyond 64 KiB of LDS per workgroup
 def test_resampled_against_oracle(width, line_width):
     H = 21
     lc = line.LineConfig((width, H), STD)
@@ -199,10 +200,10 @@ def test_fused_byte_boundary(width, line_width, averaging):
 
 
 def test_limits_fail_loudly():
+    with pytest.raises(NotImplementedError):       # a call's rows live in one CU's LDS: 4096 samples per row, 16384 per line
+        mac.MacModem(line.LineConfig((4100, 8), STD))
     with pytest.raises(NotImplementedError):
-        mac.MacModem(line.LineConfig((2048, 8), STD))
-    with pytest.raises(NotImplementedError):
-        mac.MacModem(line.LineConfig((720, 8), STD), 5000)
+        mac.MacModem(line.LineConfig((720, 8), STD), 20000)
     im = image.ImageModem(make(8))
     with pytest.raises(ValueError):
         im.demodulate_frames(numpy.zeros((1, 8, 720), dtype=numpy.float32))
