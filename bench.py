@@ -39,7 +39,7 @@ if ROOT not in sys.path:
 WIDTH, HEIGHT = 720, 576
 HBM_PEAK_GBPS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 BYTES_PER_PIXEL = 16        # float32: one composite sample read, R, G, B written
-# vector-pipe side of the same kernel (DESIGN.md section 5): float32 FMA-equivalents the kernel executes per pixel, counted
+# vector-pipe side of the same kernel (DESIGN.md section 4): float32 FMA-equivalents the kernel executes per pixel, counted
 # from the ISA of the interior bodies of this tree (tools/isa_fma_census.py: 1 per scalar float instruction, 2 per v_pk_*_f32;
 # stage A 76.5 + stage B 129.0, the per-stage table in profiles/r04_headline_bound.txt), against the chip's vector float32
 # peak and against what a bare v_fma_f32 loop sustains under the board's power cap (profiles/r01_ubench_valu.txt)
@@ -179,7 +179,7 @@ def library_sha16():
 
 class ClockSampler(object):
     """The shader clock the board holds while the timed steps run, read from sysfs (pp_dpm_sclk: the level marked '*') by a host thread
-    every few milliseconds - the kernel is power-bound (DESIGN.md section 5), and what it gives back shows here.  None when the file is
+    every few milliseconds - the kernel is power-bound (DESIGN.md section 4), and what it gives back shows here.  None when the file is
     not readable (another driver layout, a restricted container)."""
 
     def __init__(self, dev_index):
@@ -485,7 +485,7 @@ def main():
                          'frac': round(achieved / HBM_PEAK_GBPS, 4), 'traffic': traffic, 'traffic_source': traffic_source,
                          'kernel_ms': round(mean_kernel_ms, 4), 'algorithmic_bytes_per_launch': BYTES_PER_PIXEL * px_step,
                          'note': 'the HBM roofline is the one the metric names; the kernel is limited by the vector pipe and the '
-                                 'power cap, see roofline_valu (DESIGN.md section 5)'},
+                                 'power cap, see roofline_valu (DESIGN.md section 4)'},
             'roofline_valu': {'bound': 'valu', 'achieved': round(valu_tflops, 1), 'peak': VALU_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                               'frac': round(valu_tflops / VALU_PEAK_TFLOPS, 4),
                               'sustained_peak': VALU_SUSTAINED_TFLOPS, 'frac_of_sustained': round(valu_tflops / VALU_SUSTAINED_TFLOPS, 4),

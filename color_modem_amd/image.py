@@ -32,7 +32,7 @@ class ImageModem(object):
     """batch_invariant (an addition to the reference's constructor): True pins the streaming kernels on whole rows for every batch size, so
     that a frame's result does not depend on the batch it arrives in - bit for bit, e.g. sharded against unsharded runs.  By default small
     batches take the row-parallel scan kernels or row segments (a picture in 18 instead of 200 microseconds), whose other operation
-    order shows at float32 resolution (<= 2e-6 of full scale, SECAM <= 6e-6: DESIGN.md section 3.7)."""
+    order shows at float32 resolution (<= 2e-6 of full scale, SECAM <= 6e-6: DESIGN.md section 3.5)."""
 
     def __init__(self, modem, batch_invariant=False):
         self._modem = modem

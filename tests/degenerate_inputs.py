@@ -75,7 +75,7 @@ def run(what='device'):
 
 
 # no sub-carrier: behind its band-pass the SECAM discriminator takes the angle of the filters' decaying rounding residues - the reference's float64
-# ones, another restatement's other ones (DESIGN.md section 8): neither is a signal, no implementation but the reference's own reproduces them
+# ones, another restatement's other ones (DESIGN.md section 5): neither is a signal, no implementation but the reference's own reproduces them
 KNOWN = {('secam', 'decode', 'constant 0.3'), ('secam_avg', 'decode', 'constant 0.3')}
 
 if __name__ == '__main__':

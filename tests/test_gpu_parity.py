@@ -1381,7 +1381,7 @@ def test_degenerate_inputs():
     against vectors THE REFERENCE produced on these inputs (tests/degenerate_inputs.py, tests/golden/degenerate_*.npz; round 3 compared with the
     oracle): float32 resolution - NIIR returns NaN exactly where the reference divides 0 / 0, its encoders hold the grey pictures through their
     float64 small-saturation path - except the one case that is the angle of rounding residues in the reference itself: SECAM decoding a
-    constant, carrier-free row (DESIGN.md section 8)."""
+    constant, carrier-free row (DESIGN.md section 5)."""
     import degenerate_inputs
     rows = degenerate_inputs.run('device')
     assert len(rows) >= 70
@@ -1424,7 +1424,7 @@ def test_secam_float32_margin_case_and_the_float64_switch():
 
 def test_blocked_mfma_decoder_parity(monkeypatch):
     """demod_blk_kernel: split-float16 Toeplitz MFMAs for the five FIR chains, luma source added at the flush.  Same
-    goldens, same tolerance as the streaming kernel it is an alternative to.  Round 2's experiment: compiled only into
+    goldens, same tolerance as the streaming kernel it is an alternative to.  Round 2's experiment (CHANGELOG.md: round-5 DESIGN section 3.6): compiled only into
     -DCM_EXPERIMENTS builds of the library since round 4 (the default build has no environment switch) - skipped elsewhere."""
     from oracle import cm_oracle
     monkeypatch.setenv('CM_BLK', '1')
