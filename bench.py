@@ -177,22 +177,41 @@ def library_sha16():
     return h.hexdigest()[:16]
 
 
+def sources_sha16():
+    """first 16 hex digits of the SHA-256 over the library's sources (csrc/*, include/color_modem_hip.h, names and contents) and the compile
+    flags of __graft_entry__.build(): the same kernels whatever directory they were compiled in (hipcc derives the compilation-unit id it
+    embeds in an object from the output path, so the shared object's own hash differs between checkouts of one tree)"""
+    import hashlib
+    import __graft_entry__ as entry
+    csrc = os.path.join(ROOT, 'color_modem_amd', 'csrc')
+    files = sorted(os.path.join(csrc, f) for f in os.listdir(csrc)) + [os.path.join(ROOT, 'include', 'color_modem_hip.h')]
+    h = hashlib.sha256(' '.join(entry.HIPCC_FLAGS).encode())
+    for path in files:
+        h.update(os.path.basename(path).encode())
+        with open(path, 'rb') as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 class ClockSampler(object):
     """The shader clock the board holds while the timed steps run, read from sysfs (pp_dpm_sclk: the level marked '*') by a host thread
-    every few milliseconds - the kernel is power-bound, and what it gives back shows here.  None when the file is
-    not readable (another driver layout, a restricted container)."""
+    every few milliseconds - the kernel is power-bound, and what it gives back shows here.  The card is the one whose
+    PCI address is the HIP device's (a box shows every GPU of its host in sysfs, only one of them to HIP); without a match, the busiest
+    card, said so in 'source'.  None when no file is readable (another driver layout, a restricted container)."""
 
-    def __init__(self, dev_index):
+    def __init__(self, pci_bus_id):
         import glob
         import threading
         self.paths = sorted(glob.glob('/sys/class/drm/card*/device/pp_dpm_sclk'))
-        self.path = self.paths[dev_index] if dev_index < len(self.paths) else None
-        self.samples, self._stop = [], threading.Event()
+        self.mine = [p for p in self.paths if pci_bus_id and os.path.basename(os.path.realpath(os.path.dirname(p))).lower().startswith(pci_bus_id.lower())]
+        self.watch = self.mine[:1] or self.paths
+        self.samples, self._stop = dict((p, []) for p in self.watch), threading.Event()
         self._thread = threading.Thread(target=self._run, daemon=True)
 
-    def _read(self):
+    @staticmethod
+    def _read(path):
         try:
-            with open(self.path) as fh:
+            with open(path) as fh:
                 for ln in fh:
                     if ln.rstrip().endswith('*'):
                         return float(ln.split(':')[1].split('M')[0])
@@ -202,23 +221,26 @@ class ClockSampler(object):
 
     def _run(self):
         while not self._stop.is_set():
-            v = self._read()
-            if v is not None:
-                self.samples.append(v)
+            for p in self.watch:
+                v = self._read(p)
+                if v is not None:
+                    self.samples[p].append(v)
             self._stop.wait(0.003)
 
     def start(self):
-        if self.path:
+        if self.watch:
             self._thread.start()
 
     def stop(self):
         self._stop.set()
         if self._thread.is_alive():
             self._thread.join(1.0)
-        if not self.samples:
+        series = [(sorted(v), p) for p, v in self.samples.items() if v]
+        if not series:
             return None
-        s = sorted(self.samples)
-        return {'samples': len(s), 'min': s[0], 'median': s[len(s) // 2], 'max': s[-1], 'source': self.path}
+        s, path = max(series, key=lambda e: e[0][len(e[0]) // 2])
+        how = 'the card at the HIP device\'s PCI address' if self.mine else 'the busiest of %d cards (no card matched the HIP device\'s PCI address)' % len(series)
+        return {'samples': len(s), 'min': s[0], 'median': s[len(s) // 2], 'max': s[-1], 'source': path + ': ' + how}
 
 
 def host_threads():
@@ -392,7 +414,9 @@ def main():
         eng.demodulate_frames(comp, first_frame, out=out)
     barrier()
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    sampler = ClockSampler(dev_index) if rank == 0 else None      # reads sysfs from a host thread: nothing is added to the stream
+    props0 = torch.cuda.get_device_properties(device) if device.type == 'cuda' else None
+    pci0 = '%04x:%02x:%02x' % (getattr(props0, 'pci_domain_id', 0), getattr(props0, 'pci_bus_id', 0), getattr(props0, 'pci_device_id', 0)) if props0 is not None else ''
+    sampler = ClockSampler(pci0) if rank == 0 else None      # reads sysfs from a host thread: nothing is added to the stream
     if sampler:
         sampler.start()
     t0 = time.perf_counter()
@@ -465,12 +489,18 @@ def main():
                 tj = json.load(fh)
             # a PMC measurement of THIS kernel on THIS workload by THIS library build only: same frame count, same kernel description,
             # same hash of the shared object (tools/profile_bench.sh records it) - anything else would be a stale figure
-            if tj.get('frames') == frames and tj.get('kernel') == eng.describe() and tj.get('lib_sha16') == lib_sha:
+            # same hash of the shared object (tools/profile_bench.sh records it) or, for a rebuild of the same tree in another directory, the
+            # same hash of the sources + compile flags - anything else would be a stale figure
+            src_sha = sources_sha16()
+            same_build = tj.get('lib_sha16') == lib_sha or (tj.get('src_sha16') is not None and tj.get('src_sha16') == src_sha)
+            if tj.get('frames') == frames and tj.get('kernel') == eng.describe() and same_build:
                 traffic = tj.get('hbm_bytes_per_launch')
-                traffic_source = 'profiles/traffic.json: builder PMC run %s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, tools/profile_bench.sh), head %s, library %s' \
-                                 % (tj.get('date', '?'), tj.get('head', '?'), lib_sha)
+                traffic_source = 'profiles/traffic.json: builder PMC run %s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, tools/profile_bench.sh), head %s, library %s (%s), sources %s' \
+                                 % (tj.get('date', '?'), tj.get('head', '?'), lib_sha, 'the measured binary' if tj.get('lib_sha16') == lib_sha
+                                    else 'a rebuild of the measured sources; measured: %s' % tj.get('lib_sha16'), src_sha)
             else:
-                traffic_source = 'none: profiles/traffic.json was measured on another build / workload (library %s there, %s here)' % (tj.get('lib_sha16'), lib_sha)
+                traffic_source = 'none: profiles/traffic.json was measured on another build / workload (library %s, sources %s there; %s, %s here)' \
+                                 % (tj.get('lib_sha16'), tj.get('src_sha16'), lib_sha, src_sha)
         res = {
             'metric': 'Mpixels/s demodulated (720x576 PAL, 2D comb)',
             'value': round(value, 1), 'unit': 'Mpixels/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,

@@ -416,6 +416,19 @@ def variant_cases(only=()):
         ('pal_3d', 'pal_s', 1920, [2]),
         ('secam', 'secam', 960, [0, 1]),
         ('secam', 'secam', 1280, [3]),
+        # round 6: the tuned instances of the wide rasters (csrc/cm_shapes_wide.h) against the reference itself, one width per stack
+        ('pal_d', 'pal_s', 1024, [0]),
+        ('pal_d', 'pal_s', 1280, [1, 2]),
+        ('pal_d', 'pal_s', 1920, [3]),
+        ('pal_3d', 'pal_s', 1440, [0]),
+        ('pal_s', 'pal_s', 1600, [1]),
+        ('pal_d', 'pal_s', 800, [2]),
+        ('ntsc_comb', 'ntsc', 960, [0, 1]),
+        ('ntsc_comb', 'ntsc', 1920, [1]),
+        ('ntsc_comb_3d', 'ntsc', 1440, [0]),
+        ('ntsc', 'ntsc', 1600, [1]),
+        ('ntsc', 'ntsc', 1024, [0]),
+        ('secam', 'secam', 1920, [0]),
     ]
     for stack, mod_stack, W, frames in cases:
         tag = stack if W == 720 else '%s_w%d' % (stack, W)

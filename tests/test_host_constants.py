@@ -217,3 +217,19 @@ def test_generated_wide_shapes_header_is_current():
     spec.loader.exec_module(gen)
     with open(gen.HEADER) as fh:
         assert fh.read() == gen.render(), 'run python tools/gen_wide_shapes.py'
+
+
+def test_recorded_hbm_traffic_belongs_to_these_sources():
+    """profiles/traffic.json (the PMC traffic bench.py reports as roofline.traffic) names the sources it was measured on; bench.py drops the
+    figure for any other tree.  A source change without a new tools/profile_bench.sh run would therefore ship a bench line without traffic:
+    this test says so here, before the GPU box does."""
+    import json
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    with open(os.path.join(root, 'profiles', 'traffic.json')) as fh:
+        tj = json.load(fh)
+    assert tj['src_sha16'] == bench.sources_sha16(), 'csrc/ or include/ changed since the traffic was measured: run tools/profile_bench.sh and copy traffic.json'
+    assert tj['frames'] == 1000 and tj['hbm_bytes_per_launch'] >= tj['algorithmic_bytes_per_launch']

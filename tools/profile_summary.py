@@ -84,6 +84,9 @@ if 'FETCH_SIZE' in m and 'WRITE_SIZE' in m:
         for block in iter(lambda: fh.read(1 << 20), b''):
             h.update(block)
     tj['lib_sha16'] = h.hexdigest()[:16]
+    sys.path.insert(0, root)
+    import bench
+    tj['src_sha16'] = bench.sources_sha16()
     tj['date'] = datetime.date.today().isoformat()
     try:
         tj['head'] = subprocess.check_output(['git', '-C', root, 'rev-parse', '--short', 'HEAD'], stderr=subprocess.DEVNULL).decode().strip()
