@@ -98,17 +98,19 @@ int check_wrap(const cm_plan *inner, const cm_plan *first, const cm_plan *backen
     if (w->minavg < 0 || w->minavg > 2) return fail(CM_ERR_INVALID, "minavg must be 0 (comb.avg), 1 (comb.minavg) or 2 (averaged by the caller)");
     return CM_OK;
 }
-// one non-blocking side stream per device, created on first use (the wrapped combs' first-line pass runs on it)
-hipStream_t wrap_side_stream(int device) {
+// two non-blocking side streams per device, created on first use: 0 - the wrapped combs' first-line pass; 1 - the composition on the top
+// rows of a fused wrapped comb (wrap_frames_fused), which forks to 0 itself
+hipStream_t wrap_side_stream(int device, int which = 0) {
     static std::mutex mu;
-    static hipStream_t streams[64] = {};
+    static hipStream_t streams[2][64] = {};
     if (device < 0 || device >= 64) return nullptr;
     std::lock_guard<std::mutex> lock(mu);
-    if (!streams[device] && hipStreamCreateWithFlags(&streams[device], hipStreamNonBlocking) != hipSuccess) {
-        (void)hipGetLastError();
-        streams[device] = nullptr;
+    hipStream_t &s = streams[which ? 1 : 0][device];
+    if (!s && hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) {       // (created with the device's highest priority: no
+        (void)hipGetLastError();                                                          //  difference measured, profiles/r06_wrapped_top_rows.txt)
+        s = nullptr;
     }
-    return streams[device];
+    return s;
 }
 // inner decoder over the calls of `g` into `scratch` ([frame][call][3][wp], or [call][3][wp] in rows mode), + the plain call 0s
 int run_wrap_inner(const cm_plan *inner, const cm_plan *first, Geom g, float *scratch, int64_t first_frame, bool with_first,
@@ -322,8 +324,40 @@ int wrap_frames_fused(const cm_plan *fused, const cm_plan *inner, const cm_plan 
     }
     g.skip_first = 2;
     Geom none = g;
-    if ((rc = run_plan(fused, g, none, false, stream, in8 != nullptr))) return rc;
-    return wrap_frames(inner, first, backend, w, in, in8, out, wp, n_frames, first_frame, stream, 4, 2);
+#ifndef CM_WRAP_TOP_BESIDE
+#define CM_WRAP_TOP_BESIDE 1
+#endif
+    // The composition on the top four rows is a few thousand calls on the scan kernels (0.1 ms at 720 samples per line, 0.27 ms at 1280: 5 - 10 %
+    // of the batch behind the fused pass on one stream); it stores the calls k < 2, the fused pass the others, so on a side stream of the
+    // device it runs BESIDE the fused pass: forked behind everything queued on `stream`, joined before anything queued after this call.
+    hipStream_t side = CM_WRAP_TOP_BESIDE ? wrap_side_stream(fused->device, 1) : nullptr;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (side && hipStreamIsCapturing(stream, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) side = nullptr;   // wrap_frames below refuses it
+    struct EventPair {
+        hipEvent_t forked = nullptr, joined = nullptr;
+        ~EventPair() {
+            if (forked) (void)hipEventDestroy(forked);
+            if (joined) (void)hipEventDestroy(joined);
+        }
+    } ev;
+    if (side && (hipEventCreateWithFlags(&ev.forked, hipEventDisableTiming) != hipSuccess ||
+                 hipEventCreateWithFlags(&ev.joined, hipEventDisableTiming) != hipSuccess)) side = nullptr;
+    if (side && (hipEventRecord(ev.forked, stream) != hipSuccess || hipStreamWaitEvent(side, ev.forked, 0) != hipSuccess)) side = nullptr;
+    if (!side) {
+        if ((rc = run_plan(fused, g, none, false, stream, in8 != nullptr))) return rc;
+        return wrap_frames(inner, first, backend, w, in, in8, out, wp, n_frames, first_frame, stream, 4, 2);
+    }
+    // forked: the caller's stream joins the side stream on every path out.  (The top rows on the STREAMING kernels instead - least work per
+    // call, three row walks of latency hidden behind a long fused pass - measured no better than the scan kernels beside it: 114 / 118 / 105
+    // against 119 / 117 / 110 Gpixel/s at 1024 / 1280 / 1920 samples per line, profiles/r06_wrapped_top_rows.txt.)
+    const int rc_top = wrap_frames(inner, first, backend, w, in, in8, out, wp, n_frames, first_frame, side, 4, 2);
+    const int rc_main = run_plan(fused, g, none, false, stream, in8 != nullptr);
+    const bool joined = hipEventRecord(ev.joined, side) == hipSuccess && hipStreamWaitEvent(stream, ev.joined, 0) == hipSuccess;
+    if (!joined) {
+        (void)hipStreamSynchronize(side);
+        if (!rc_top && !rc_main) return fail(CM_ERR_LAUNCH, "joining the top rows of a fused wrapped comb failed");
+    }
+    return rc_top ? rc_top : rc_main;
 }
 }  // namespace
 }  // extern "C++"

@@ -37,4 +37,7 @@ for name in ('bench_line.json', 'bench_line_sustained.json', 'bench_line_default
     except Exception as e:
         print(name, 'missing', e)
 PY
+# the line as the driver will print it once this run's traffic.json is committed: same command, traffic from the passes above
+cp "$OUT/traffic.json" "$ROOT/profiles/traffic.json"
+python3 bench.py --gpus 1 --steps 20 --warmup 5 --cpu-sample 0 --other-configs 0 > "$OUT/bench_line_with_traffic.json" 2>> "$OUT/bench.err"
 cat "$OUT/summary.txt"
