@@ -118,7 +118,7 @@ __global__ __launch_bounds__(128, 2) void proto_demod_pair_kernel(const ProtoDem
     const Geom &g = args.g;
     const ProtoDemodK<float> &k = args.k;
     const int lane = threadIdx.x & 63;
-    const LaneCall lc = locate_call(g, blockIdx.x, DEPTH, lane);
+    const LaneCall lc = locate_call(g, xcd_block((int)blockIdx.x, (int)gridDim.x), DEPTH, lane);
     const int W = g.W, L = 3 * W;
     const int lat_c = ProtoDemod<float>::lat_chroma(k), lat_y = ProtoDemod<float>::lat_luma(k);
     const int dly = lat_c - lat_y;                       // luma waits for the chroma path
@@ -322,7 +322,7 @@ __global__ __launch_bounds__(128, 2) void proto_mod_pair_kernel(const ProtoModAr
     const Geom &g = args.g;
     const ProtoModK<float> &k = args.k;
     const int lane = threadIdx.x & 63;
-    const LaneCall lc = locate_call(g, blockIdx.x, DEPTH, lane);
+    const LaneCall lc = locate_call(g, xcd_block((int)blockIdx.x, (int)gridDim.x), DEPTH, lane);
     const int W = g.W;
     const int lat_y = ProtoMod<float>::lat_luma(k), lat_c = ProtoMod<float>::lat_chroma(k);
     const int lat = lat_y > lat_c ? lat_y : lat_c;
@@ -744,8 +744,9 @@ __global__ __launch_bounds__(128, 2) void niir_demod_pair_kernel(const NiirPairA
     extern __shared__ __attribute__((aligned(16))) float niir_pair_lds[];
     lds_float *lds = (lds_float *)niir_pair_lds;
     const int role = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
-    if ((int)blockIdx.x < args.n_first) niir_pair_body<true, U8>(args.m, args.gf, blockIdx.x, lds, role);
-    else niir_pair_body<false, U8>(args.m, args.m.g, (int)blockIdx.x - args.n_first, lds, role);
+    const int bid = xcd_block((int)blockIdx.x, (int)gridDim.x);
+    if (bid < args.n_first) niir_pair_body<true, U8>(args.m, args.gf, bid, lds, role);
+    else niir_pair_body<false, U8>(args.m, args.m.g, bid - args.n_first, lds, role);
 }
 
 struct NiirModArgs {
@@ -772,7 +773,7 @@ __global__ __launch_bounds__(64, 2) void niir_mod_kernel(const NiirModArgs args)
     const Geom &g = args.g;
     const NiirModK<float> &k = args.k;
     const int lane = threadIdx.x;
-    const LaneCall lc = locate_call(g, blockIdx.x, DEPTH, lane);
+    const LaneCall lc = locate_call(g, xcd_block((int)blockIdx.x, (int)gridDim.x), DEPTH, lane);
     const float *rp, *op;
     mod_rows<U8>(g, lc, rp, op);
     const long long frame = (long long)args.a.frame_base + lc.frame;

@@ -103,7 +103,7 @@ __global__ __launch_bounds__(64, 1) void demod_blk_kernel(const PassArgs<S> args
     const Geom &g = args.g;
     const K &k = args.k;
     const int lane = threadIdx.x;
-    const LaneCall lc = locate_call(g, blockIdx.x, DEPTH, lane);
+    const LaneCall lc = locate_call(g, xcd_block((int)blockIdx.x, (int)gridDim.x), DEPTH, lane);
     const float *xp = g.in + lc.frame * g.in_frame_stride + (long long)lc.src_row * g.Wp;
     // luma source row: the own row, or the previous call's where the plan says so (cm_kernels.h: run_pair)
     const float *lp = g.in + lc.frame * g.in_frame_stride +

@@ -493,6 +493,24 @@ __device__ __forceinline__ void fill_tile(const Geom &g, lds_float *itile, const
     }
 }
 
+// Workgroups are dealt round-robin over the 8 XCDs (observed, MI355X_MICROARCH.md: blocks b and b + 8 share one).  With the linear block
+// id as the position in the batch, every XCD walks the whole batch at once: each of its translation caches and its L2 see the pages and
+// the halo rows of all ~1000 resident workgroups.  1: the blocks of one XCD take a contiguous eighth of the batch instead (bijective for
+// any grid size) - a choice of speed only, the result does not depend on it.  Measured (profiles/r06_xcd_remap.txt): rows whose pitch
+// is a multiple of 4 KiB + 6 - 7 %, and the slow mode some widths fell into on some runs (PAL-D at 1600 / 1920 samples per line, the NTSC
+// combs at 1920: 125 - 135 instead of 150 - 165 Gpixel/s, by process) is gone; the other shapes +- 1 %.
+#ifndef CM_XCD_REMAP
+#define CM_XCD_REMAP 1
+#endif
+__device__ __forceinline__ int xcd_block(int b, int n) {
+#if CM_XCD_REMAP
+    const int q = n >> 3, r = n & 7, x = b & 7, i = b >> 3;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
+#else
+    (void)n;
+    return b;
+#endif
+}
 // Which call of the flattened [frame][run][call] list a lane owns, and where its rows live.
 struct LaneCall {
     long long frame;
@@ -1476,13 +1494,14 @@ __global__ __launch_bounds__(64, 2) void demod_kernel(const PassArgs<typename Ma
     constexpr int kFloats = Main::kLdsFloats > First::kLdsFloats ? Main::kLdsFloats : First::kLdsFloats;
     __shared__ __attribute__((aligned(16))) float lds_store[kFloats];
     lds_float *lds = (lds_float *)lds_store;
+    const int bid = xcd_block((int)blockIdx.x, (int)gridDim.x);
     if constexpr (!std::is_same<First, NoPass>::value) {
-        if ((int)blockIdx.x < n_first) {
-            run_lane<First>(first_args.g, first_args.k, blockIdx.x, lds);
+        if (bid < n_first) {
+            run_lane<First>(first_args.g, first_args.k, bid, lds);
             return;
         }
     }
-    run_lane<Main>(main_args.g, main_args.k, (int)blockIdx.x - n_first, lds);
+    run_lane<Main>(main_args.g, main_args.k, bid - n_first, lds);
 }
 
 // Which wave of a pair plays which stage (experiment, off by default).  Stage B is the heavier one (about 290 against 168
@@ -1520,9 +1539,10 @@ __global__ __launch_bounds__(128, CM_PAIR_WAVES_PER_SIMD) void demod_pair_kernel
     role ^= 1;
 #endif
 #endif
+    const int bid = xcd_block((int)blockIdx.x, (int)gridDim.x);
     if constexpr (!std::is_same<First, NoPass>::value) {
-        if ((int)blockIdx.x < n_first) {
-            run_pair<First>(first_args.g, first_args.k, blockIdx.x, lds, role);
+        if (bid < n_first) {
+            run_pair<First>(first_args.g, first_args.k, bid, lds, role);
             return;
         }
     }
@@ -1555,7 +1575,7 @@ __global__ __launch_bounds__(128, CM_PAIR_WAVES_PER_SIMD) void demod_pair_kernel
         my_load = role ? kLoadB : kLoadA;
     }
 #endif
-    run_pair<Main>(main_args.g, main_args.k, (int)blockIdx.x - n_first, lds, role);
+    run_pair<Main>(main_args.g, main_args.k, bid - n_first, lds, role);
 #if CM_SIMD_BALANCE
     if (cnt && (threadIdx.x & 63) == 0) atomicSub(cnt + simd, my_load);
 #endif

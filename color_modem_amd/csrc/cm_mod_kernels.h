@@ -247,7 +247,7 @@ __global__ __launch_bounds__(64, CM_QAM_MOD_WAVES) void qam_mod_kernel(const Mod
     const Geom &g = args.g;
     const ModK<float, NP> &k = args.k;
     const int lane = threadIdx.x;
-    const LaneCall lc = locate_call(g, blockIdx.x, DEPTH, lane);
+    const LaneCall lc = locate_call(g, xcd_block((int)blockIdx.x, (int)gridDim.x), DEPTH, lane);
     const float *rp, *op;
     mod_rows<U8>(g, lc, rp, op);
     ModLaneK<float> lk;

@@ -70,7 +70,7 @@ __global__ __launch_bounds__(64, CM_SECAM_WAVES) void secam_demod_kernel(const S
     SecamDemodKPk kp;      // the quadrature low-pass runs on the pair (I, Q) (cm_stages_pk.h)
     kp.load(k);
     const int lane = threadIdx.x;
-    const LaneCall lc = locate_call(g, blockIdx.x, DEPTH, lane);
+    const LaneCall lc = locate_call(g, xcd_block((int)blockIdx.x, (int)gridDim.x), DEPTH, lane);
     const float *xp, *op;
     if (U8) {
         xp = (const float *)((const unsigned char *)g.in + lc.frame * g.in_frame_stride + (long long)lc.src_row * g.W);
@@ -358,7 +358,7 @@ __device__ __forceinline__ void secam_demod_pair_body(const Args &args_in) {
     SecamDemodK<float> k = args.k;
     const int role = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
-    const LaneCall lc = locate_call(g, blockIdx.x, DEPTH, lane);
+    const LaneCall lc = locate_call(g, xcd_block((int)blockIdx.x, (int)gridDim.x), DEPTH, lane);
 
     // ---- stream geometry (identical in both waves) ------------------------------------------------
     const int W = g.W, P = k.preroll, Lc = W + P;
@@ -680,7 +680,7 @@ __global__ __launch_bounds__(64, CM_SECAM_MOD_WAVES) void secam_mod_kernel(const
     const Geom &g = args.g;
     const SecamModK<float, double> &k = args.k;
     const int lane = threadIdx.x;
-    const LaneCall lc = locate_call(g, blockIdx.x, DEPTH, lane);
+    const LaneCall lc = locate_call(g, xcd_block((int)blockIdx.x, (int)gridDim.x), DEPTH, lane);
     const float *rp, *op;
     mod_rows<U8>(g, lc, rp, op);
     SecamModLaneK<float, double> lk;

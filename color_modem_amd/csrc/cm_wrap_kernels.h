@@ -48,7 +48,7 @@ __global__ __launch_bounds__(64, 2) void comb_wrap_back_kernel(const WrapBackArg
     const Geom &g = args.g;
     const ModK<float, NP> &k = args.k;
     const int lane = threadIdx.x;
-    const LaneCall lc = locate_call(g, blockIdx.x, DEPTH, lane);
+    const LaneCall lc = locate_call(g, xcd_block((int)blockIdx.x, (int)gridDim.x), DEPTH, lane);
     const long long row_stride = g.in_row_stride ? g.in_row_stride : g.W;
     const float *rp = g.in + lc.frame * g.in_frame_stride + (long long)lc.src_row * row_stride;
     const float *op;

@@ -1,8 +1,10 @@
-"""Decoder throughput across image widths, one table per stack: python tools/quick_bench_widths.py [STACK ...] [--widths 720,1024,...] [--u8]
+"""Decoder throughput across image widths, one table per stack: python tools/quick_bench_widths.py [STACK ...] [--widths=720,1024,...] [--u8] [--mpix=295]
 
 Every row is the same stack at another image width (= sampling rate = filter-set shape); the 720-wide row is the tuned instance of
 rounds 1 - 5, the others name the instance that served them (`describe()`): a tuned shape of cm_shapes_wide.h or the run-time shape.
-Frames are scaled so that every row moves about the same number of pixels (~295 M)."""
+Frames are scaled so that every row moves about the same number of pixels (--mpix, default 295 M).  A launch of 295 Mpixel is only 2 - 4
+fills of the device with workgroups (64 scan lines each, 4 - 6 workgroups per CU), so the last, partly empty fill weighs differently at every
+width (2376 workgroups on 1024 slots at 1920 samples per line: 2.3 fills take the time of 3); --mpix=1200 makes that a few per cent."""
 import sys
 import torch
 sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
@@ -15,12 +17,16 @@ for a in sys.argv[1:]:
     if a.startswith('--widths'):
         widths = tuple(int(v) for v in a.split('=')[1].split(','))
 u8 = '--u8' in sys.argv
+mpix = 295.0
+for a in sys.argv[1:]:
+    if a.startswith('--mpix'):
+        mpix = float(a.split('=')[1])
 names = args or ['pal_d', 'pal_3d', 'pal_s', 'simple3d_pald', 'simple3d_pal3d', 'ntsc_comb', 'ntsc_comb_3d', 'ntsc', 'secam']
 for name in names:
     h = 480 if name.startswith('ntsc') else 576
     base = None
     for w in widths:
-        F = max(8, int(295e6 / (w * h)) // 4 * 4)
+        F = max(8, int(mpix * 1e6 / (w * h)) // 4 * 4)
         try:
             eng = image.ImageModem(stacks.make(name, (w, h)))._engine()
             if u8:
