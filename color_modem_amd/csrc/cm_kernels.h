@@ -224,7 +224,6 @@ struct PassCfg {
     // wave-pair kernels: float rows enter through 16-sample tiles (64-byte row segments) when the luma delay ring takes the
     // LDS (CM_LUMA_RING); byte tiles stay 32 samples wide
     static constexpr int kPairInTile = (U8_ || !CM_LUMA_RING) ? kInTile : CM_PAIR_TILE;
-    static constexpr int kPairLdsIn = U8_ ? 64 * kInTile / 4 : 64 * kPairInTile;   // floats
     // wave-pair kernels: 3 waves per SIMD need <= 168 VGPRs; the instances with more per-lane state in stage B (a second
     // line of history, the notch, the second combination of minavg) would spill there and get 2 waves per SIMD instead
     // (with the cut behind the detector low-pass, CM_QAM_LPF_IN_A, stage B of the two-line combs sheds the low-pass state and
@@ -239,6 +238,16 @@ struct PassCfg {
                                     : kWrapperCfg ? 3
                                     : (NOTCH_ || MINAVG_ || S_::NE >= 4 || S_::NP >= 2 || S_::RT) ? 2
                                     : (DEPTH_ >= 2 ? (kLcutCfg ? CM_LCUT_DEPTH2_WAVES : 2) : 3);
+    // The widest shapes (pre-correction shift >= 6: 1920 samples per line) at 2 waves per SIMD keep TWO input tiles per row, tile t + 1 asked
+    // for at the first read of tile t: the fill has two bodies (8 steps) to arrive instead of one.  With one tile a fill that takes longer
+    // than a body stalls stage A and, through the barrier, the pair - the slow mode PAL-D and the NTSC combs fell into at that width
+    // (137 -> 152 Gpixel/s on a box that showed it; profiles/r06_xcd_remap.txt).  Not elsewhere: the instances whose registers allow
+    // 3 waves per SIMD lose a workgroup per CU to the 2 KiB (5 - 7 %), the other 2-wave instances measured 0 +- 2 %.
+#ifndef CM_WIDE_TWO_TILES
+#define CM_WIDE_TWO_TILES 1
+#endif
+    static constexpr bool kPairTwoTiles = CM_WIDE_TWO_TILES != 0 && S_::WIDE && S_::SP >= 6 && !BSF_ && !U8_ && CM_LUMA_RING != 0 && kPairWaves == 2;
+    static constexpr int kPairLdsIn = U8_ ? 64 * kInTile / 4 : 64 * kPairInTile * (kPairTwoTiles ? 2 : 1);   // floats
     // which kernel structure runs this instance.  Since the luma delay ring (CM_LUMA_RING) every instance runs on the wave
     // pair - those with more per-lane state in stage B at 2 waves per SIMD (measured: Pal3D 2.92 -> 2.72 ms, Simple3DComb(
     // NtscComb) 2.43 -> 2.34 ms per 1000 frames against the one-wave kernel, profiles/r01_pair_notes.md section 9).
@@ -1049,10 +1058,13 @@ __device__ __forceinline__ void run_pair(const Geom &g, const DemodK<float, type
             for (int j = 0; j < kYSlots; ++j) yring[j * 64 + lane] = 0.f;
         }
         const lds_float *xrow = itile + lane * kIT;
+        constexpr bool TT = Cfg::kPairTwoTiles;     // two tiles [64][kIT] side by side: tile t lives in half t & 1
         auto read_x = [&](int first) -> f4 {  // x[first .. first + 3] from the input tile, zero outside the row
             f4 v;
             if (U8)
                 v = decode_bytes(*(const lds_u32 *)((const lds_u8 *)itile + lane * kIT + (first & (kIT - 1))));
+            else if (TT)
+                v = *(const lds_f4 *)(xrow + ((first / kIT) & 1) * (64 * kIT) + (first & (kIT - 1)));
             else
                 v = *(const lds_f4 *)(xrow + (first & (kIT - 1)));
             if (first + 3 >= W) {
@@ -1067,7 +1079,8 @@ __device__ __forceinline__ void run_pair(const Geom &g, const DemodK<float, type
             if (BSF || LRING) return f4{0.f, 0.f, 0.f, 0.f};
             return load_luma<U8>(lp, first, check, W);
         };
-        if (U8) fill_tile_u8(g, itile, xp, tb0 / kInTile, lane); else fill_tile<kIT>(g, itile, xp, tb0 / kIT, lane);
+        if (U8) fill_tile_u8(g, itile, xp, tb0 / kInTile, lane);
+        else fill_tile<kIT>(g, itile + (TT ? ((tb0 / kIT) & 1) * (64 * kIT) : 0), xp, tb0 / kIT, lane);
         f4 lum_cur = read_luma(tb0 - lat_out, true);   // luma source of B's first block
         if (LRING) {   // blocks B reads before A has written them lie before the row: zeros
             for (int j = 0; j < kLB; ++j) *(lds_f4 *)(lring + j * 256 + lane * 4) = f4{0.f, 0.f, 0.f, 0.f};
@@ -1080,6 +1093,15 @@ __device__ __forceinline__ void run_pair(const Geom &g, const DemodK<float, type
             xw[10] = x0.x; xw[11] = x0.y; xw[12] = x0.z; xw[13] = x0.w;
             if constexpr (PKF) fa.prime(tkp, x0.x);
         }
+        // two tiles: the first read of tile t asks for tile t + 1 (the other half: its last read was a body ago)
+        auto next_tile = [&](int first) {
+            if (first + kIT < W && first + kIT < T_end) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_wave_barrier();
+                fill_tile<kIT>(g, itile + ((first / kIT + 1) & 1) * (64 * kIT), xp, first / kIT + 1, lane);
+            }
+        };
+        if constexpr (TT) next_tile(tb0);
         auto sub_a = [&](auto sub_tag, auto edge_tag, FrontLatch<float> &fla, int tau, float &m_even, float &m_odd) {
             constexpr int SUB = decltype(sub_tag)::value;
             constexpr bool EDGE = decltype(edge_tag)::value;
@@ -1126,6 +1148,9 @@ __device__ __forceinline__ void run_pair(const Geom &g, const DemodK<float, type
                     CM_ACC(d_other, t0);
                 }
                 xq = read_x(nxt);
+                if constexpr (TT) {
+                    if ((nxt & (kIT - 1)) == 0 && nxt < W) next_tile(nxt);
+                } else
                 if ((nxt & (kIT - 1)) == kIT - 4 && nxt + 4 < W && nxt + 4 < T_end) {
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                     __builtin_amdgcn_wave_barrier();
@@ -1174,6 +1199,9 @@ __device__ __forceinline__ void run_pair(const Geom &g, const DemodK<float, type
                     f4 xn = read_x(nxt);
                     xw[10] = xn.x; xw[11] = xn.y; xw[12] = xn.z; xw[13] = xn.w;
                 }
+                if constexpr (TT) {
+                    if ((nxt & (kIT - 1)) == 0 && nxt < W) next_tile(nxt);
+                } else
                 if ((nxt & (kIT - 1)) == kIT - 4 && nxt + 4 < W && nxt + 4 < T_end) {  // that was the last read of this tile: refill it
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                     __builtin_amdgcn_wave_barrier();

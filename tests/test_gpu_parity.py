@@ -947,7 +947,7 @@ def test_plan_refuses_host_pointers():
                                             ('pal_d', 'pal_s', (722, 40)), ('ntsc', 'ntsc', (720, 30)), ('pal_d_notch', 'pal_s', (720, 576)),
                                             ('ntsc_simple_minavg', 'ntsc', (704, 24)), ('pal_3d_minavg', 'pal_s', (720, 21)),
                                             ('ntsc_a', 'ntsc_a', (720, 20)), ('pal_s', 'pal_s', (960, 18)), ('pal_d', 'pal_s', (1280, 576)),
-                                            ('ntsc_comb_3d', 'ntsc', (1920, 480)), ('pal_3d', 'pal_s', (1440, 576)),
+                                            ('ntsc_comb_3d', 'ntsc', (1920, 480)), ('pal_3d', 'pal_s', (1440, 576)), ('pal_d', 'pal_s', (1920, 576)),
                                             ('secam', 'secam', (720, 576)), ('secam', 'secam', (768, 576)), ('secam_a', 'secam_a', (720, 405)),
                                             ('secam', 'secam', (640, 480)), ('secam_avg', 'secam_avg', (720, 576))])
 def test_small_batch_modes(stack, enc, size):
