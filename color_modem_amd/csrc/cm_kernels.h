@@ -246,7 +246,10 @@ struct PassCfg {
 #ifndef CM_WIDE_TWO_TILES
 #define CM_WIDE_TWO_TILES 1
 #endif
-    static constexpr bool kPairTwoTiles = CM_WIDE_TWO_TILES != 0 && S_::WIDE && S_::SP >= 6 && !BSF_ && !U8_ && CM_LUMA_RING != 0 && kPairWaves == 2;
+#ifndef CM_WIDE_TWO_TILES_SP
+#define CM_WIDE_TWO_TILES_SP 6
+#endif
+    static constexpr bool kPairTwoTiles = CM_WIDE_TWO_TILES != 0 && S_::WIDE && S_::SP >= CM_WIDE_TWO_TILES_SP && !BSF_ && !U8_ && CM_LUMA_RING != 0 && kPairWaves == 2;
     static constexpr int kPairLdsIn = U8_ ? 64 * kInTile / 4 : 64 * kPairInTile * (kPairTwoTiles ? 2 : 1);   // floats
     // which kernel structure runs this instance.  Since the luma delay ring (CM_LUMA_RING) every instance runs on the wave
     // pair - those with more per-lane state in stage B at 2 waves per SIMD (measured: Pal3D 2.92 -> 2.72 ms, Simple3DComb(
