@@ -223,7 +223,6 @@ struct PassCfg {
     static constexpr int kLdsFloats = kLdsInF + kLdsOut + (BSF_ ? kLdsRing : 0);
     // wave-pair kernels: float rows enter through 16-sample tiles (64-byte row segments) when the luma delay ring takes the
     // LDS (CM_LUMA_RING); byte tiles stay 32 samples wide
-    static constexpr int kPairInTile = (U8_ || !CM_LUMA_RING) ? kInTile : CM_PAIR_TILE;
     // wave-pair kernels: 3 waves per SIMD need <= 168 VGPRs; the instances with more per-lane state in stage B (a second
     // line of history, the notch, the second combination of minavg) would spill there and get 2 waves per SIMD instead
     // (with the cut behind the detector low-pass, CM_QAM_LPF_IN_A, stage B of the two-line combs sheds the low-pass state and
@@ -249,7 +248,12 @@ struct PassCfg {
 #ifndef CM_WIDE_TWO_TILES_SP
 #define CM_WIDE_TWO_TILES_SP 6
 #endif
-    static constexpr bool kPairTwoTiles = CM_WIDE_TWO_TILES != 0 && S_::WIDE && S_::SP >= CM_WIDE_TWO_TILES_SP && !BSF_ && !U8_ && CM_LUMA_RING != 0 && kPairWaves == 2;
+#ifndef CM_WIDE_TILE          /* samples per input tile row of that class; 16 (64-byte row segments), one or two tiles: mean of 30 placements 139 - 140 against 144 Gpixel/s with two tiles of 8 (one of 8: 136), profiles/r06_xcd_remap.txt */
+#define CM_WIDE_TILE 8
+#endif
+    static constexpr bool kWideLatClass = S_::WIDE && S_::SP >= CM_WIDE_TWO_TILES_SP && !BSF_ && !U8_ && CM_LUMA_RING != 0 && kPairWaves == 2;
+    static constexpr int kPairInTile = (U8_ || !CM_LUMA_RING) ? kInTile : (kWideLatClass ? CM_WIDE_TILE : CM_PAIR_TILE);
+    static constexpr bool kPairTwoTiles = CM_WIDE_TWO_TILES != 0 && kWideLatClass;
     static constexpr int kPairLdsIn = U8_ ? 64 * kInTile / 4 : 64 * kPairInTile * (kPairTwoTiles ? 2 : 1);   // floats
     // which kernel structure runs this instance.  Since the luma delay ring (CM_LUMA_RING) every instance runs on the wave
     // pair - those with more per-lane state in stage B at 2 waves per SIMD (measured: Pal3D 2.92 -> 2.72 ms, Simple3DComb(
