@@ -233,7 +233,19 @@ struct PassCfg {
     // bodies and run 9 - 11 % faster at 3 waves per SIMD, the one-line decoders with a notch on the NTSC shape (169 - 171 VGPRs, one spill) 7 %;
     // the run-time filter shape loses 4 - 6 % there and stays at 2, the other instances are indifferent.
     static constexpr bool kWrapperCfg = !S_::RT && S_::NE < 4 && S_::NP < 2 && ((FRONT_ == 1 && DEPTH_ >= 2) || WRAP_ || (DEPTH_ == 1 && NOTCH_ && !MINAVG_));
-    static constexpr int kPairWaves = (S_::WIDE && FRONT_ == 1) ? ((DEPTH_ >= 2 && S_::SP <= 3) ? 3 : CM_WIDE_PALD_WAVES)
+    // Which wide PAL-D-front instances run WITHOUT the luma delay ring (stage A fetches the luma source a second time: one load per lane and
+    // body, L2 hits) at 3 waves per SIMD - 20 KiB of LDS, six workgroups per CU.  Bit 0: the byte instances - the decoder (+3 ... +5 % at
+    // 800 - 1920 samples per line) and, from a pre-correction shift of 4 on (1280 ...), the fused wrapper (+2.5 ... +5.5 %; at 800 / 1024 it
+    // already runs 3 waves with its ring and loses 23 % without).  Bit 1: the float one-line decoder of the 1920 class (+2 %, and 142 ... 151
+    // instead of 136 ... 151 Gpixel/s over 30 buffer placements: more resident waves hide the slow placements).  The float wrappers (two
+    // lines of history) do not fit 168 registers: -7 ... -9 %.  profiles/r06_xcd_remap.txt, follow-up 4.
+#ifndef CM_WIDE_PALD_NORING
+#define CM_WIDE_PALD_NORING 3
+#endif
+    static constexpr bool kNoRing = S_::NORING || (S_::WIDE && FRONT_ == 1 && CM_LUMA_RING != 0 &&
+                                                   ((((CM_WIDE_PALD_NORING) & 1) != 0 && U8_ && (DEPTH_ == 1 || S_::SP >= 4)) ||
+                                                    (((CM_WIDE_PALD_NORING) & 2) != 0 && !U8_ && DEPTH_ == 1 && S_::SP >= 6)));
+    static constexpr int kPairWaves = (S_::WIDE && FRONT_ == 1) ? ((kNoRing || (DEPTH_ >= 2 && S_::SP <= 3)) ? 3 : CM_WIDE_PALD_WAVES)
                                     : kWrapperCfg ? 3
                                     : (NOTCH_ || MINAVG_ || S_::NE >= 4 || S_::NP >= 2 || S_::RT) ? 2
                                     : (DEPTH_ >= 2 ? (kLcutCfg ? CM_LCUT_DEPTH2_WAVES : 2) : 3);
@@ -884,7 +896,7 @@ template <class Cfg>
 struct PairLds {
     static constexpr int kIn = Cfg::kPairLdsIn, kOut = Cfg::kLdsOut;
     static constexpr int kY = Cfg::BSF ? luma_ring_slots<typename Cfg::S>() * 64
-                                       : (CM_LUMA_RING && !Cfg::S::NORING ? luma_delay_blocks<typename Cfg::S, Cfg::FRONT, Cfg::kLcutCfg, Cfg::WRAP ? 1 : 0>() * 256 : kLumaSlots);
+                                       : (CM_LUMA_RING && !Cfg::kNoRing ? luma_delay_blocks<typename Cfg::S, Cfg::FRONT, Cfg::kLcutCfg, Cfg::WRAP ? 1 : 0>() * 256 : kLumaSlots);
     // hand-over ring: the 2x-rate pair (even, odd) per step, or - where stage A also takes the detector products and the
     // low-pass (LCUT: the QAM front end without the band-stop luma) - the two low-passed pairs (q_e, q_o)
     static constexpr bool kLcut = Cfg::kLcutCfg;
@@ -903,7 +915,7 @@ struct PairLds<NoPass> {
 template <class Cfg>
 inline int pair_lds_floats(const DemodK<float, typename Cfg::S> &k) {
     typedef typename Cfg::S S;
-    if (!S::DYN || Cfg::BSF || !CM_LUMA_RING) return PairLds<Cfg>::kFloats;
+    if (!S::DYN || Cfg::BSF || !CM_LUMA_RING || Cfg::kNoRing) return PairLds<Cfg>::kFloats;
     const int lat_front = Cfg::FRONT == FRONT_PALD ? 10 + k.q_e + 9 + 10 + k.q_l + 9 : 10 + k.q_e + k.q_l + 9;
     const int lat_out = lat_front + 1 + k.s_p + (Cfg::WRAP ? 1 : 0);
     constexpr int kWinX = ring_window<S, Cfg::FRONT, Cfg::kLcutCfg>();
@@ -943,7 +955,7 @@ __device__ __forceinline__ void run_pair(const Geom &g, const DemodK<float, type
     constexpr int FRONT = Cfg::FRONT, DEPTH = Cfg::DEPTH, kTile = Cfg::TILE, SP = S::SP;
     constexpr bool BSF = Cfg::BSF, U8 = Cfg::U8, PALD = FRONT == FRONT_PALD;
     constexpr int kYSlots = luma_ring_slots<S>();
-    constexpr bool LRING = CM_LUMA_RING && !BSF && !S::NORING;         // luma source samples through the LDS delay ring
+    constexpr bool LRING = CM_LUMA_RING && !BSF && !Cfg::kNoRing;      // luma source samples through the LDS delay ring
     constexpr int kIT = Cfg::kPairInTile;                // samples per input tile row
     constexpr int kLBmax = luma_delay_blocks<S, FRONT, Cfg::kLcutCfg, Cfg::WRAP ? 1 : 0>();   // tuned shapes: the ring's size; run-time shape: its limit
     constexpr int kWinX = ring_window<S, FRONT, Cfg::kLcutCfg>();        // extra x samples stage A keeps behind its window
