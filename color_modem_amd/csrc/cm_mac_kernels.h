@@ -57,11 +57,11 @@ __device__ __forceinline__ MacSegment mac_segment(const MacArgs &a) {
         s.f = 0;
         s.fld = 0;
         s.n_field = a.H;
-        s.k_begin = (int)blockIdx.x * kMacSegment;
+        s.k_begin = xcd_block((int)blockIdx.x, (int)gridDim.x) * kMacSegment;
     } else {
         const int half = (a.H + 1) >> 1;
         const int segs = (half + kMacSegment - 1) / kMacSegment;
-        const int b = (int)blockIdx.x;
+        const int b = xcd_block((int)blockIdx.x, (int)gridDim.x);
         const int seg = b % segs, ff = b / segs;
         s.f = ff >> 1;
         s.fld = ff & 1;
@@ -442,10 +442,11 @@ __global__ __launch_bounds__(kMacThreads) void mac_mod_generic_kernel(const MacG
     mac_stage_taps(line_out, mac_stage_taps(chroma_in, mac_stage_taps(luma_in, comp + (a.averaging ? 6 : 3) * W, t), t), t);   // the second row slot exists with averaging only
     int f, out_row, row_a, row_b, line;
     if (a.rows_mode) {
-        f = 0; out_row = (int)blockIdx.x; row_b = out_row; row_a = a.averaging && out_row > 0 ? out_row - 1 : out_row;
+        f = 0; out_row = xcd_block((int)blockIdx.x, (int)gridDim.x); row_b = out_row; row_a = a.averaging && out_row > 0 ? out_row - 1 : out_row;
         line = a.first_line + 2 * out_row - (a.averaging ? 2 : 0);
     } else {
-        f = (int)(blockIdx.x / a.H); out_row = (int)(blockIdx.x % a.H); row_a = row_b = out_row; line = out_row;
+        const int bid = xcd_block((int)blockIdx.x, (int)gridDim.x);
+        f = bid / a.H; out_row = bid % a.H; row_a = row_b = out_row; line = out_row;
         if (a.averaging) {
             row_b += 2;
             while (row_b >= a.H) row_b -= 2;
